@@ -1,0 +1,15 @@
+"""fastpm_amd -- MI355X-native particle-mesh force step for FastPM.
+
+A drop-in for the path behind ``fastpm_solver_compute_force`` (reference
+libfastpm/gravity.c:458-529).  The product is the C-ABI HIP library
+``libfastpm_hip.so`` (include/fastpm_hip.h, sources in fastpm_amd/csrc/); this
+package is the thin host-side mirror of the reference's PM interface used by the
+tests, the benchmark and the multi-GPU driver.  There is no CPU fallback: every
+entry point raises if the HIP library or a GPU is missing.
+"""
+from .lib import FastPMHipError, library_path, load_library  # noqa: F401
+from .pm import (KERNEL_TYPES, SOFTENING_TYPES, PM, Store, fastpm_kernel_type_get_orders,  # noqa: F401
+                 fastpm_solver_compute_force)
+
+__all__ = ["PM", "Store", "fastpm_solver_compute_force", "fastpm_kernel_type_get_orders",
+           "KERNEL_TYPES", "SOFTENING_TYPES", "FastPMHipError", "load_library", "library_path"]

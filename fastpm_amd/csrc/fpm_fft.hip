@@ -1,0 +1,203 @@
+// fpm_fft.hip -- the DFTs of the PM force step on rocFFT (replaces PFFT/FFTW, reference
+// libfastpm/pmpfft.c:265-303 plans, :370-399 pm_r2c / pm_c2r).
+//
+// Conventions kept from the reference: forward e^{-ikx}; r2c result x 1/Norm (pmpfft.c:381-385,
+// folded into the last forward pass as rocFFT's scale factor); c2r unnormalised and in place;
+// real meshes padded to N+2 in z.  k-space layout is [x][y_loc][kz] (kz fastest).
+//
+//   nranks == 1 : one 3-D rocFFT plan each way.
+//   nranks  > 1 : slabs along x.  forward = batched 2-D (y,z) r2c in place on the slab, pack into
+//                 per-destination chunks, [all-to-all by the caller], strided 1-D c2c along x in
+//                 place on the received [x][y_loc][kz] block.  backward is the mirror image.
+#include "fpm_internal.h"
+
+namespace fpm {
+
+template <typename F> struct Cplx2 { F re, im; };
+
+// [xl][N][nzc] (2-D FFT output, in place in the canvas) -> send[r][xl][yl][nzc]
+// PACK = false is the inverse (recv[s][xl][yl][nzc] -> [xl][N][nzc]).
+template <typename F, bool PACK>
+__global__ __launch_bounds__(256) void slab_pack_kernel(int xl, int N, int yl, int nzc,
+                                                        Cplx2<F> *__restrict__ slab,
+                                                        Cplx2<F> *__restrict__ chunks)
+{
+    const int ixl = blockIdx.y;
+    const int rem = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rem >= N * nzc) return;
+    const int iy = rem / nzc, iz = rem - iy * nzc;
+    const int r = iy / yl, iyl = iy - r * yl;
+    const long long a = ((long long) ixl * N + iy) * nzc + iz;
+    const long long b = (((long long) r * xl + ixl) * yl + iyl) * nzc + iz;
+    if (PACK) chunks[b] = slab[a];
+    else slab[a] = chunks[b];
+}
+
+static int make_plan(rocfft_plan *plan, rocfft_result_placement placement, rocfft_transform_type type,
+                     bool f64, size_t dim, const size_t *lengths, size_t batch, rocfft_array_type in_type,
+                     rocfft_array_type out_type, const size_t *in_strides, size_t in_dist,
+                     const size_t *out_strides, size_t out_dist, double scale)
+{
+    rocfft_plan_description desc = nullptr;
+    FPM_CHECK_FFT(rocfft_plan_description_create(&desc));
+    rocfft_status s = rocfft_plan_description_set_data_layout(desc, in_type, out_type, nullptr, nullptr, dim,
+                                                              in_strides, in_dist, dim, out_strides, out_dist);
+    if (s == rocfft_status_success && scale != 1.0) s = rocfft_plan_description_set_scale_factor(desc, scale);
+    if (s == rocfft_status_success)
+        s = rocfft_plan_create(plan, placement, type, f64 ? rocfft_precision_double : rocfft_precision_single,
+                               dim, lengths, batch, desc);
+    rocfft_plan_description_destroy(desc);
+    FPM_CHECK_FFT(s);
+    return 0;
+}
+
+static int fft_exec(fpmhip_plan *p, rocfft_plan plan, void *in, void *out)
+{
+    void *ib[1] = {in}, *ob[1] = {out};
+    FPM_CHECK_FFT(rocfft_execute(plan, ib, ob, p->fft_info));
+    return 0;
+}
+
+static bool g_rocfft_ready = false;
+
+int fft_setup(fpmhip_plan *p)
+{
+    if (!g_rocfft_ready) {
+        FPM_CHECK_FFT(rocfft_setup());
+        g_rocfft_ready = true;
+    }
+    const MeshGeo &g = p->mg;
+    const size_t N = g.N, nzc = g.nzc, xl = g.xl, yl = g.yl;
+    const double inv_norm = 1.0 / p->lay.Norm;
+    if (p->lay.nranks == 1) {
+        // rocFFT lengths / strides are fastest-dimension first: (z, y, x)
+        const size_t len[3] = {N, N, N};
+        const size_t rs[3] = {1, N + 2, N * (N + 2)};
+        const size_t cs[3] = {1, nzc, N * nzc};
+        FPM_TRY(make_plan(&p->p_r2c3d, rocfft_placement_notinplace, rocfft_transform_type_real_forward, p->f64, 3,
+                          len, 1, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, rs,
+                          N * N * (N + 2), cs, N * N * nzc, inv_norm));
+        FPM_TRY(make_plan(&p->p_c2r3d, rocfft_placement_inplace, rocfft_transform_type_real_inverse, p->f64, 3,
+                          len, 1, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, cs,
+                          N * N * nzc, rs, N * N * (N + 2), 1.0));
+    } else {
+        const size_t len2[2] = {N, N};
+        const size_t rs2[2] = {1, N + 2};
+        const size_t cs2[2] = {1, nzc};
+        FPM_TRY(make_plan(&p->p_r2c2d, rocfft_placement_inplace, rocfft_transform_type_real_forward, p->f64, 2,
+                          len2, xl, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, rs2,
+                          N * (N + 2), cs2, N * nzc, 1.0));
+        FPM_TRY(make_plan(&p->p_c2r2d, rocfft_placement_inplace, rocfft_transform_type_real_inverse, p->f64, 2,
+                          len2, xl, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, cs2,
+                          N * nzc, rs2, N * (N + 2), 1.0));
+        // 1-D along x on [x][yl][nzc]: stride yl*nzc, batch yl*nzc at distance 1
+        const size_t len1[1] = {N};
+        const size_t st1[1] = {yl * nzc};
+        FPM_TRY(make_plan(&p->p_xfwd, rocfft_placement_inplace, rocfft_transform_type_complex_forward, p->f64, 1,
+                          len1, yl * nzc, rocfft_array_type_complex_interleaved,
+                          rocfft_array_type_complex_interleaved, st1, 1, st1, 1, inv_norm));
+        FPM_TRY(make_plan(&p->p_xbwd, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, p->f64, 1,
+                          len1, yl * nzc, rocfft_array_type_complex_interleaved,
+                          rocfft_array_type_complex_interleaved, st1, 1, st1, 1, 1.0));
+    }
+    size_t work = 0;
+    rocfft_plan all[] = {p->p_r2c3d, p->p_c2r3d, p->p_r2c2d, p->p_c2r2d, p->p_xfwd, p->p_xbwd};
+    for (rocfft_plan q : all) {
+        if (!q) continue;
+        size_t w = 0;
+        FPM_CHECK_FFT(rocfft_plan_get_work_buffer_size(q, &w));
+        work = std::max(work, w);
+    }
+    FPM_CHECK_FFT(rocfft_execution_info_create(&p->fft_info));
+    if (work > 0) {
+        FPM_CHECK_HIP(hipMalloc(&p->fft_work, work));
+        p->fft_work_bytes = work;
+        FPM_CHECK_FFT(rocfft_execution_info_set_work_buffer(p->fft_info, p->fft_work, work));
+    }
+    FPM_CHECK_FFT(rocfft_execution_info_set_stream(p->fft_info, p->stream));
+    return 0;
+}
+
+void fft_teardown(fpmhip_plan *p)
+{
+    rocfft_plan all[] = {p->p_r2c3d, p->p_c2r3d, p->p_r2c2d, p->p_c2r2d, p->p_xfwd, p->p_xbwd};
+    for (rocfft_plan q : all) if (q) rocfft_plan_destroy(q);
+    if (p->fft_info) rocfft_execution_info_destroy(p->fft_info);
+    if (p->fft_work) (void) hipFree(p->fft_work);
+}
+
+template <typename F, bool PACK>
+static int launch_pack(fpmhip_plan *p, void *slab, void *chunks)
+{
+    const MeshGeo &g = p->mg;
+    dim3 grid((unsigned) (((long long) g.N * g.nzc + 255) / 256), g.xl);
+    slab_pack_kernel<F, PACK><<<grid, 256, 0, p->stream>>>(g.xl, g.N, g.yl, g.nzc, (Cplx2<F> *) slab,
+                                                            (Cplx2<F> *) chunks);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace fpm
+
+using namespace fpm;
+
+extern "C" {
+
+int fpmhip_r2c(fpmhip_plan *p, void *canvas, void *delta_k)
+{
+    if (!p || !canvas || !delta_k) FPM_FAIL(-1, "null argument");
+    if (p->lay.nranks != 1) FPM_FAIL(-1, "fpmhip_r2c is the one-rank transform; use the fft_yz/fft_x stages");
+    if (canvas == delta_k) FPM_FAIL(-1, "pm_r2c is out of place (pmapi.h:97-100)");
+    StageTimer tm(p, FPMHIP_T_R2C);
+    return fft_exec(p, p->p_r2c3d, canvas, delta_k);
+}
+
+int fpmhip_c2r(fpmhip_plan *p, void *inplace)
+{
+    if (!p || !inplace) FPM_FAIL(-1, "null argument");
+    if (p->lay.nranks != 1) FPM_FAIL(-1, "fpmhip_c2r is the one-rank transform; use the fft_yz/fft_x stages");
+    StageTimer tm(p, FPMHIP_T_C2R);
+    return fft_exec(p, p->p_c2r3d, inplace, nullptr);
+}
+
+int fpmhip_fft_yz_forward(fpmhip_plan *p, void *canvas, void *send)
+{
+    if (!p || !canvas || !send) FPM_FAIL(-1, "null argument");
+    if (p->lay.nranks == 1) FPM_FAIL(-1, "staged FFT needs nranks > 1");
+    {
+        StageTimer tm(p, FPMHIP_T_R2C);
+        FPM_TRY(fft_exec(p, p->p_r2c2d, canvas, nullptr));
+    }
+    StageTimer tm(p, FPMHIP_T_PACK);
+    return p->f64 ? launch_pack<double, true>(p, canvas, send) : launch_pack<float, true>(p, canvas, send);
+}
+
+int fpmhip_fft_x_forward(fpmhip_plan *p, void *recv)
+{
+    if (!p || !recv) FPM_FAIL(-1, "null argument");
+    if (p->lay.nranks == 1) FPM_FAIL(-1, "staged FFT needs nranks > 1");
+    StageTimer tm(p, FPMHIP_T_R2C);
+    return fft_exec(p, p->p_xfwd, recv, nullptr);
+}
+
+int fpmhip_fft_x_backward(fpmhip_plan *p, void *buf)
+{
+    if (!p || !buf) FPM_FAIL(-1, "null argument");
+    if (p->lay.nranks == 1) FPM_FAIL(-1, "staged FFT needs nranks > 1");
+    StageTimer tm(p, FPMHIP_T_C2R);
+    return fft_exec(p, p->p_xbwd, buf, nullptr);
+}
+
+int fpmhip_fft_yz_backward(fpmhip_plan *p, void *recv, void *canvas)
+{
+    if (!p || !recv || !canvas) FPM_FAIL(-1, "null argument");
+    if (p->lay.nranks == 1) FPM_FAIL(-1, "staged FFT needs nranks > 1");
+    {
+        StageTimer tm(p, FPMHIP_T_PACK);
+        FPM_TRY((p->f64 ? launch_pack<double, false>(p, canvas, recv) : launch_pack<float, false>(p, canvas, recv)));
+    }
+    StageTimer tm(p, FPMHIP_T_C2R);
+    return fft_exec(p, p->p_c2r2d, canvas, nullptr);
+}
+
+}  // extern "C"

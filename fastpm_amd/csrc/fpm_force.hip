@@ -1,0 +1,107 @@
+// fpm_force.hip -- fastpm_solver_compute_force on one MI355X (reference libfastpm/gravity.c:458-529):
+// paint -> normalise -> r2c -> softening -> 3 x (transfer -> c2r) -> readout [-> potential].
+// With one rank there are no ghosts (pmghosts.c:67: rank == ThisTask always) and no collectives.
+#include "fpm_internal.h"
+
+using namespace fpm;
+
+namespace {
+
+struct HostStage {
+    double *x = nullptr;
+    float *mass = nullptr, *acc = nullptr, *pot = nullptr;
+    int64_t cap = 0;
+};
+
+// device staging for fpmhip_force_host, one per plan (kept in a side table to keep the plan POD-ish)
+static std::vector<std::pair<fpmhip_plan *, HostStage>> g_stage;
+
+HostStage *stage_for(fpmhip_plan *p)
+{
+    for (auto &e : g_stage) if (e.first == p) return &e.second;
+    g_stage.push_back({p, HostStage()});
+    return &g_stage.back().second;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fpmhip_force(fpmhip_plan *p, const fpmhip_particles *pt, int kernel, int softening, double total_mass,
+                 void *delta_k_out)
+{
+    if (!p || !pt) FPM_FAIL(-1, "null argument");
+    if (p->lay.nranks != 1)
+        FPM_FAIL(-1, "fpmhip_force is the one-rank path; with nranks > 1 drive the stages around the two exchanges");
+    int po, go, dfo, dc;
+    FPM_TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));                  // gravity.c:169
+    if (softening < 0 || softening > FPMHIP_SOFTENING_GAUSSIAN36) FPM_FAIL(-1, "wrong softening kernel type");
+    if (pt->np > 0 && !pt->acc) FPM_FAIL(-1, "particles without an acc column");
+
+    FPM_TRY(ensure_buffer(p, BUF_CANVAS));
+    FPM_TRY(ensure_buffer(p, BUF_F1));
+    FPM_TRY(ensure_buffer(p, BUF_F2));
+    void *canvas = p->buf[BUF_CANVAS];
+    void *delta_k = delta_k_out;
+    if (!delta_k) {
+        FPM_TRY(ensure_buffer(p, BUF_DELTA_K));
+        delta_k = p->buf[BUF_DELTA_K];
+    }
+
+    if (total_mass < 0) FPM_TRY(fpmhip_total_mass(p, pt, &total_mass));                   // gravity.c:330-341
+    const double mean_mass_per_cell = total_mass / p->lay.Norm;                           // gravity.c:342
+    FPM_TRY(fpmhip_paint(p, pt, 1.0 / mean_mass_per_cell, canvas));                       // gravity.c:336-345
+    FPM_TRY(fpmhip_r2c(p, canvas, delta_k));                                              // gravity.c:351
+    FPM_TRY(fpmhip_softening(p, delta_k, softening));                                     // gravity.c:476
+
+    // the canvas is free again after the out-of-place r2c: it carries the x component
+    void *f[3] = {canvas, p->buf[BUF_F1], p->buf[BUF_F2]};
+    for (int d = 0; d < 3; d++) {                                                         // gravity.c:373-397
+        FPM_TRY(fpmhip_transfer(p, delta_k, f[d], kernel, d));
+        FPM_TRY(fpmhip_c2r(p, f[d]));
+    }
+    FPM_TRY(fpmhip_readout3(p, pt, f[0], f[1], f[2]));
+    if (pt->potential) {                                                                  // gravity.c:487-492
+        FPM_TRY(fpmhip_transfer(p, delta_k, canvas, kernel, FPMHIP_FIELD_POTENTIAL));
+        FPM_TRY(fpmhip_c2r(p, canvas));
+        FPM_TRY(fpmhip_readout1(p, pt, canvas, pt->potential, 1, 0));
+    }
+    return 0;
+}
+
+int fpmhip_force_host(fpmhip_plan *p, const fpmhip_particles *ph, int kernel, int softening, void *delta_k_host)
+{
+    if (!p || !ph) FPM_FAIL(-1, "null argument");
+    if (ph->np > 0 && (!ph->x || !ph->acc)) FPM_FAIL(-1, "store without x or acc columns");
+    HostStage *st = stage_for(p);
+    const int64_t np = ph->np;
+    if (np > st->cap || (ph->mass && !st->mass) || (ph->potential && !st->pot)) {
+        if (st->x) { (void) hipFree(st->x); (void) hipFree(st->acc); }
+        if (st->mass) (void) hipFree(st->mass);
+        if (st->pot) (void) hipFree(st->pot);
+        *st = HostStage();
+        int64_t cap = std::max<int64_t>(np + np / 16, 1024);
+        FPM_CHECK_HIP(hipMalloc(&st->x, cap * 3 * sizeof(double)));
+        FPM_CHECK_HIP(hipMalloc(&st->acc, cap * 3 * sizeof(float)));
+        if (ph->mass) FPM_CHECK_HIP(hipMalloc(&st->mass, cap * sizeof(float)));
+        if (ph->potential) FPM_CHECK_HIP(hipMalloc(&st->pot, cap * sizeof(float)));
+        st->cap = cap;
+    }
+    FPM_CHECK_HIP(hipMemcpyAsync(st->x, ph->x, np * 3 * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    if (ph->mass) FPM_CHECK_HIP(hipMemcpyAsync(st->mass, ph->mass, np * sizeof(float), hipMemcpyHostToDevice, p->stream));
+    fpmhip_particles pd = *ph;
+    pd.x = st->x;
+    pd.mass = ph->mass ? st->mass : nullptr;
+    pd.acc = st->acc;
+    pd.potential = ph->potential ? st->pot : nullptr;
+    FPM_TRY(ensure_buffer(p, BUF_DELTA_K));
+    FPM_TRY(fpmhip_force(p, &pd, kernel, softening, -1.0, p->buf[BUF_DELTA_K]));
+    FPM_CHECK_HIP(hipMemcpyAsync(ph->acc, st->acc, np * 3 * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+    if (ph->potential)
+        FPM_CHECK_HIP(hipMemcpyAsync(ph->potential, st->pot, np * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+    FPM_CHECK_HIP(hipStreamSynchronize(p->stream));   // the caller reads acc on the host right away
+    if (delta_k_host) FPM_TRY(fpmhip_export_delta_k(p, p->buf[BUF_DELTA_K], delta_k_host));
+    return 0;
+}
+
+}  // extern "C"

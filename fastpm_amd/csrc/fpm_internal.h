@@ -1,0 +1,157 @@
+// fpm_internal.h -- private state of libfastpm_hip (gfx950 only).
+// The public boundary is include/fastpm_hip.h; nothing here is exported.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "fastpm_hip.h"
+
+namespace fpm {
+
+void set_error(const char *fmt, ...);
+
+#define FPM_CHECK_HIP(expr)                                                              \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            fpm::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+            return -2;                                                                   \
+        }                                                                                \
+    } while (0)
+
+#define FPM_CHECK_FFT(expr)                                                              \
+    do {                                                                                 \
+        rocfft_status s_ = (expr);                                                       \
+        if (s_ != rocfft_status_success) {                                               \
+            fpm::set_error("%s:%d: %s -> rocfft_status %d", __FILE__, __LINE__, #expr, (int) s_); \
+            return -3;                                                                   \
+        }                                                                                \
+    } while (0)
+
+#define FPM_FAIL(code, ...)                    \
+    do {                                       \
+        fpm::set_error(__VA_ARGS__);           \
+        return (code);                         \
+    } while (0)
+
+#define FPM_TRY(expr)                          \
+    do {                                       \
+        int rc_ = (expr);                      \
+        if (rc_ != 0) return rc_;              \
+    } while (0)
+
+// Particle tiles: TX x TY x TZ cells, z fastest (a tile row is TZ contiguous cells).
+constexpr int TILE_X = 8;
+constexpr int TILE_Y = 8;
+constexpr int TILE_Z = 32;
+constexpr int TILE_CELLS = TILE_X * TILE_Y * TILE_Z;
+
+enum { BUF_CANVAS = 0, BUF_DELTA_K, BUF_F0, BUF_F1, BUF_F2, BUF_XCHG, BUF_COUNT };
+
+// Geometry handed to kernels by value.
+struct MeshGeo {
+    int N;             // mesh cells per side
+    int xl;            // local x planes (N / nranks)
+    int xstart;        // first global x plane of this rank
+    int xplanes;       // planes present in a real buffer: xl + halo
+    int periodic_x;    // 1 if nranks == 1 (wrap in x inside the kernel)
+    int yl;            // local ky rows in k space
+    int ystart;
+    int nzc;           // N/2 + 1
+    long long str0;    // real strides: N*(N+2)
+    long long str1;    // N+2
+    double inv_cell;   // 1.0 / (BoxSize / N), pmpfft.c:150-151
+    int ntx, nty, ntz; // tile grid over [xplanes][N][N]
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+    int stage;
+};
+
+}  // namespace fpm
+
+struct fpmhip_plan {
+    fpmhip_geom geom;
+    fpmhip_layout lay;
+    fpm::MeshGeo mg;
+    int device;
+    hipStream_t stream;
+    bool f64;
+    size_t esize;  // sizeof(FastPMFloat)
+
+    // float32 per-axis tables, pmapi.c:234-275: [k | k_finite | kk | kk_finite | kk_finite2] x N
+    std::vector<float> h_tab;
+    float *d_tab = nullptr;
+    // double separable factor tables (decic / gaussian), 3 x N
+    double *d_fac = nullptr;
+
+    // rocFFT
+    rocfft_plan p_r2c3d = nullptr, p_c2r3d = nullptr;
+    rocfft_plan p_r2c2d = nullptr, p_c2r2d = nullptr;
+    rocfft_plan p_xfwd = nullptr, p_xbwd = nullptr;
+    rocfft_execution_info fft_info = nullptr;
+    void *fft_work = nullptr;
+    size_t fft_work_bytes = 0;
+
+    // mesh buffers (lazily allocated)
+    void *buf[fpm::BUF_COUNT] = {nullptr};
+
+    // tile binning of the particles
+    int64_t bin_cap_own = 0, bin_cap_dup = 0;
+    double *sx = nullptr, *sy = nullptr, *sz = nullptr;  // own entries [0, np), dup entries after
+    float *smass = nullptr;
+    int *sidx = nullptr;
+    int ntiles = 0;
+    int *tile_cnt = nullptr;   // [2 * ntiles + 1] counts: own tiles then dup tiles
+    int *tile_off = nullptr;   // exclusive scan of tile_cnt (+ total at the end)
+    int *tile_cur = nullptr;   // scatter cursors
+    void *scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
+    int *h_pinned = nullptr;   // pinned scratch for small read-backs
+    double *d_scalar = nullptr;
+    const double *binned_x = nullptr;
+    const float *binned_mass = nullptr;
+    int64_t binned_np = -1;
+    int64_t binned_ndup = 0;
+
+    // timing
+    bool timing = false;
+    std::vector<fpm::EventPair> ev_used;
+    std::vector<fpm::EventPair> ev_free;
+    double t_ms[FPMHIP_T_COUNT] = {0};
+    int64_t t_n[FPMHIP_T_COUNT] = {0};
+};
+
+namespace fpm {
+
+// RAII stage timer: records a HIP event pair on the plan's stream when timing is on.
+struct StageTimer {
+    fpmhip_plan *p;
+    EventPair ev;
+    bool on;
+    StageTimer(fpmhip_plan *plan, int stage);
+    ~StageTimer();
+};
+
+int ensure_buffer(fpmhip_plan *p, int which);
+int ensure_bins(fpmhip_plan *p, int64_t np, int64_t ndup, bool has_mass);
+
+// fpm_particles.hip
+int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt);
+
+// fpm_fft.hip
+int fft_setup(fpmhip_plan *p);
+void fft_teardown(fpmhip_plan *p);
+
+// fpm_kspace.hip
+int upload_factor_tables(fpmhip_plan *p, const std::vector<double> &fx);
+
+}  // namespace fpm

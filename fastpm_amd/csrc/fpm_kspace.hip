@@ -1,0 +1,390 @@
+// fpm_kspace.hip -- pointwise k-space work of the PM force step for gfx950 (HBM-bound streams):
+//   fused gravity transfer  (reference libfastpm/gravity.c:14-64, 174-242; transfer.c:153-186, 212-220)
+//   softening kernels       (reference gravity.c:66-108, 244-270; transfer.c:42-65, 188-210)
+//   de-CIC                  (reference transfer.c:77-113)
+//   P(k) binning            (reference powerspectrum.c:35-111)
+//   NaN / range scan        (reference pmapi.c:335-356)
+//   halo-plane add, reference-layout export.
+// k-space layout: [x][y_loc][kz], kz fastest (fpmhip_layout.ostrides); one thread per complex
+// number, 2 * sizeof(F) contiguous bytes per lane.
+#include <cmath>
+
+#include "fpm_internal.h"
+
+namespace fpm {
+
+template <typename F> struct Cplx { F re, im; };
+
+static inline unsigned blocks_for(long long n, int bs) { return (unsigned) ((n + bs - 1) / bs); }
+
+// grid: x = blocks over the (y_loc, kz) plane, y = ix.  Decodes the plane index.
+#define KSPACE_INDEX(g)                                                         \
+    const int ix = blockIdx.y;                                                  \
+    const int rem = blockIdx.x * blockDim.x + threadIdx.x;                      \
+    if (rem >= (g).yl * (g).nzc) return;                                        \
+    const int iyl = rem / (g).nzc, iz = rem - iyl * (g).nzc;                    \
+    const int iy = iyl + (g).ystart;                                            \
+    const long long ind = ((long long) ix * (g).yl + iyl) * (g).nzc + iz;       \
+    (void) iy; (void) iz;
+
+// gravity_apply_kernel_transfer for COLUMN_ACC / COLUMN_POTENTIAL in one pass, keeping the
+// reference's rounding points (each of its three passes stores FastPMFloat):
+//   a = (F)(delta * (1 / kk_sum))          transfer.c:171-183   (0 where kk_sum == 0)
+//   b = (F)(a * -1)                        gravity.c:17         (exact)
+//   c = ((F)(-b.im * kf), (F)(b.re * kf))  gravity.c:58-60      (0 on self-conjugate modes, :44-56)
+// kk: the potorder table, kt: the gradorder table (both float32, pmapi.c:234-275).
+template <typename F>
+__global__ __launch_bounds__(256) void transfer_kernel(MeshGeo g, const float *__restrict__ kk,
+                                                       const float *__restrict__ kt, int dir,
+                                                       const Cplx<F> *__restrict__ from,
+                                                       Cplx<F> *__restrict__ to)
+{
+    KSPACE_INDEX(g)
+    const int N = g.N;
+    double kk_finite = 0;
+    kk_finite += kk[ix];
+    kk_finite += kk[iy];
+    kk_finite += kk[iz];
+    Cplx<F> v = from[ind];
+    F are, aim;
+    if (kk_finite != 0) {
+        const double r = 1 / kk_finite;
+        are = (F) (v.re * r);
+        aim = (F) (v.im * r);
+    } else {
+        are = 0;
+        aim = 0;
+    }
+    const F bre = (F) (are * -1.0), bim = (F) (aim * -1.0);
+    Cplx<F> out;
+    if (dir < 0) {   // potential: stops after the sign flip (gravity.c:205-207)
+        out.re = bre;
+        out.im = bim;
+    } else {
+        const int id = dir == 0 ? ix : (dir == 1 ? iy : iz);
+        const double k_finite = kt[id];
+        const bool selfconj = ix == (N - ix) % N && iy == (N - iy) % N && iz == (N - iz) % N;
+        if (selfconj) {
+            out.re = 0;
+            out.im = 0;
+        } else {
+            out.re = (F) (-bim * k_finite);
+            out.im = (F) (bre * k_finite);
+        }
+    }
+    to[ind] = out;
+}
+
+// to = from * (fx[ix] * fy[iy] * fz[iz]) with double factor tables: de-CIC (transfer.c:77-113)
+// and Gaussian softening (gravity.c:66-102).
+template <typename F>
+__global__ __launch_bounds__(256) void separable_kernel(MeshGeo g, const double *__restrict__ fac,
+                                                        const Cplx<F> *__restrict__ from,
+                                                        Cplx<F> *__restrict__ to)
+{
+    KSPACE_INDEX(g)
+    double smth = 1.0;
+    smth *= fac[ix];
+    smth *= fac[iy];
+    smth *= fac[iz];
+    Cplx<F> v = from[ind];
+    v.re = (F) (v.re * smth);
+    v.im = (F) (v.im * smth);
+    to[ind] = v;
+}
+
+// mode 0: low pass kk < kth2 (transfer.c:42-65); mode 1: exp(-36 (k/knq)^36) (gravity.c:103-108
+// through transfer.c:188-210).  kk = float32 k^2 table.
+template <typename F>
+__global__ __launch_bounds__(256) void radial_kernel(MeshGeo g, const float *__restrict__ kk, int mode,
+                                                     double param, Cplx<F> *__restrict__ data)
+{
+    KSPACE_INDEX(g)
+    double k2 = 0;
+    k2 += kk[ix];
+    k2 += kk[iy];
+    k2 += kk[iz];
+    double smth;
+    if (mode == 0) {
+        smth = k2 < param ? 1 : 0;
+    } else {
+        const double k = sqrt(k2);
+        const double xx = k / param;
+        smth = exp(-36 * pow(xx, 36.0));
+    }
+    Cplx<F> v = data[ind];
+    v.re = (F) (v.re * smth);
+    v.im = (F) (v.im * smth);
+    data[ind] = v;
+}
+
+// powerspectrum.c:62-110: integer-wavenumber bins, weight 2 except on the kz = 0 and N/2 planes,
+// DC skipped.  (The reference tests the rank-local kz index, :94; with the slab layout kz is
+// never split so local == absolute.)  Per-block LDS bins, then one global atomic per bin.
+template <typename F>
+__global__ __launch_bounds__(256) void power_kernel(MeshGeo g, double k0, const Cplx<F> *__restrict__ d1,
+                                                    const Cplx<F> *__restrict__ d2, int nbins,
+                                                    double *__restrict__ gk, double *__restrict__ gp,
+                                                    double *__restrict__ gn)
+{
+    extern __shared__ double lds[];
+    double *lk = lds, *lp = lds + nbins, *ln = lds + 2 * nbins;
+    for (int i = threadIdx.x; i < 3 * nbins; i += blockDim.x) lds[i] = 0;
+    __syncthreads();
+    const int N = g.N;
+    const int ix = blockIdx.y;
+    const int plane = g.yl * g.nzc;
+    for (int rem = blockIdx.x * blockDim.x + threadIdx.x; rem < plane; rem += gridDim.x * blockDim.x) {
+        const int iyl = rem / g.nzc, iz = rem - iyl * g.nzc;
+        const int iy = iyl + g.ystart;
+        const long long ind = ((long long) ix * g.yl + iyl) * g.nzc + iz;
+        long long kk = 0;
+        int ik = ix; if (ik > N / 2) ik -= N; kk += (long long) ik * ik;
+        ik = iy; if (ik > N / 2) ik -= N; kk += (long long) ik * ik;
+        ik = iz; if (ik > N / 2) ik -= N; kk += (long long) ik * ik;
+        long long bin = ((long long) floor(sqrt((double) kk))) - 2;
+        if (bin < 0) bin = 0;
+        while ((bin + 1) * (bin + 1) <= kk) bin++;
+        if (bin >= nbins) continue;
+        if (ix == 0 && iy == 0 && iz == 0) continue;
+        const double k = sqrt((double) kk) * k0;
+        const Cplx<F> a = d1[ind], b = d2[ind];
+        const double value = (double) a.re * (double) b.re + (double) a.im * (double) b.im;
+        const int w = (iz == 0 || iz == N / 2) ? 1 : 2;
+        atomicAdd(&ln[bin], (double) w);
+        atomicAdd(&lp[bin], w * value);
+        atomicAdd(&lk[bin], w * k);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) {
+        if (ln[i] != 0) {
+            unsafeAtomicAdd(&gk[i], lk[i]);
+            unsafeAtomicAdd(&gp[i], lp[i]);
+            unsafeAtomicAdd(&gn[i], ln[i]);
+        }
+    }
+}
+
+template <typename F>
+__global__ __launch_bounds__(256) void check_values_kernel(const F *__restrict__ f, long long n,
+                                                           unsigned long long *__restrict__ count)
+{
+    unsigned long long oo = 0;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long) gridDim.x * blockDim.x) {
+        const F v = f[i];
+        if (v > (F) 1e15 || v < (F) -1e15 || v != v) oo++;
+    }
+    for (int off = 32; off > 0; off >>= 1) oo += __shfl_down(oo, off);
+    if ((threadIdx.x & 63) == 0 && oo) atomicAdd(count, oo);
+}
+
+template <typename F>
+__global__ __launch_bounds__(256) void plane_add_kernel(F *__restrict__ dst, const F *__restrict__ src, long long n)
+{
+    long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = dst[i] + src[i];
+}
+
+// [x][y_loc][kz] -> [y_loc][kz][x]  (the reference's PFFT-transposed ORegion, pmpfft.c:198-202).
+// 32 x 32 LDS tile transpose over (x, plane index).
+template <typename F>
+__global__ __launch_bounds__(256) void to_reference_layout_kernel(int N, long long plane,
+                                                                  const Cplx<F> *__restrict__ in,
+                                                                  Cplx<F> *__restrict__ out)
+{
+    __shared__ Cplx<F> tile[32][33];
+    const long long p0 = (long long) blockIdx.x * 32;
+    const int x0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int x = x0 + r;
+        const long long q = p0 + tx;
+        if (x < N && q < plane) tile[r][tx] = in[(long long) x * plane + q];
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const long long q = p0 + r;
+        const int x = x0 + tx;
+        if (x < N && q < plane) out[q * N + x] = tile[tx][r];
+    }
+}
+
+}  // namespace fpm
+
+using namespace fpm;
+
+template <typename F>
+static int transfer_impl(fpmhip_plan *p, const void *from, void *to, int potorder, int gradorder, int dir)
+{
+    const MeshGeo &g = p->mg;
+    const int64_t N = g.N;
+    const float *kk = p->d_tab + (2 + potorder) * N;    // kk, kk_finite, kk_finite2 (transfer.c:166)
+    const float *kt = p->d_tab + gradorder * N;          // k, k_finite             (gravity.c:38)
+    dim3 grid(blocks_for((long long) g.yl * g.nzc, 256), g.N);
+    transfer_kernel<F><<<grid, 256, 0, p->stream>>>(g, kk, kt, dir, (const Cplx<F> *) from, (Cplx<F> *) to);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <typename F>
+static int separable_impl(fpmhip_plan *p, const std::vector<double> &fac, const void *from, void *to)
+{
+    const MeshGeo &g = p->mg;
+    // one table serves the three axes (cubic mesh, pmpfft.c:146-157)
+    FPM_CHECK_HIP(hipMemcpyAsync(p->d_fac, fac.data(), g.N * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    FPM_CHECK_HIP(hipStreamSynchronize(p->stream));   // fac is a host temporary
+    dim3 grid(blocks_for((long long) g.yl * g.nzc, 256), g.N);
+    separable_kernel<F><<<grid, 256, 0, p->stream>>>(g, p->d_fac, (const Cplx<F> *) from, (Cplx<F> *) to);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+static double sinc_unnormed(double x)   // transfer.c:67-74
+{
+    if (x < 1e-5 && x > -1e-5) {
+        double x2 = x * x;
+        return 1.0 - x2 / 6. + x2 * x2 / 120.;
+    }
+    return sin(x) / x;
+}
+
+extern "C" {
+
+int fpmhip_transfer(fpmhip_plan *p, const void *delta_k, void *out, int kernel, int field)
+{
+    if (!p || !delta_k || !out) FPM_FAIL(-1, "null argument");
+    int po, go, dfo, dc;
+    FPM_TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));
+    if (field < 0 || field > FPMHIP_FIELD_POTENTIAL) FPM_FAIL(-1, "Unknown type for gravity attribute");
+    // deconvolveorder (GADGET / EASTWOOD) de-CICs the stale canvas and is then overwritten
+    // (gravity.c:182-190): no effect on the result, not executed here.
+    StageTimer tm(p, FPMHIP_T_TRANSFER);
+    const int dir = field == FPMHIP_FIELD_POTENTIAL ? -1 : field;
+    return p->f64 ? transfer_impl<double>(p, delta_k, out, po, go, dir)
+                  : transfer_impl<float>(p, delta_k, out, po, go, dir);
+}
+
+int fpmhip_decic(fpmhip_plan *p, const void *from, void *to)
+{
+    if (!p || !from || !to) FPM_FAIL(-1, "null argument");
+    const int64_t N = p->mg.N;
+    std::vector<double> fac(N);
+    for (int64_t i = 0; i < N; i++) {
+        double w = p->h_tab[i] * p->geom.BoxSize / N;         // transfer.c:90
+        double cic = sinc_unnormed(0.5 * w);
+        fac[i] = 1.0 / pow(cic, 2);                            // transfer.c:93
+    }
+    StageTimer tm(p, FPMHIP_T_TRANSFER);
+    return p->f64 ? separable_impl<double>(p, fac, from, to) : separable_impl<float>(p, fac, from, to);
+}
+
+int fpmhip_softening(fpmhip_plan *p, void *delta_k, int type)
+{
+    if (!p || !delta_k) FPM_FAIL(-1, "null argument");
+    const MeshGeo &g = p->mg;
+    const int64_t N = g.N;
+    const double BoxSize = p->geom.BoxSize;
+    if (type == FPMHIP_SOFTENING_NONE) return 0;
+    StageTimer tm(p, FPMHIP_T_DEALIAS);
+    dim3 grid(blocks_for((long long) g.yl * g.nzc, 256), g.N);
+    const float *kk = p->d_tab + 2 * N;
+    switch (type) {
+    case FPMHIP_SOFTENING_GAUSSIAN:
+    case FPMHIP_SOFTENING_GADGET_LONG_RANGE: {
+        const double nrms = type == FPMHIP_SOFTENING_GAUSSIAN ? 1.0 : pow(2, 0.5) * 1.25;   // gravity.c:255-259
+        const double r0 = nrms * BoxSize / N;                                                // gravity.c:70
+        std::vector<double> fac(N);
+        for (int64_t i = 0; i < N; i++) fac[i] = exp(-0.5 * pow(p->h_tab[i] * r0, 2));       // gravity.c:82
+        return p->f64 ? separable_impl<double>(p, fac, delta_k, delta_k)
+                      : separable_impl<float>(p, fac, delta_k, delta_k);
+    }
+    case FPMHIP_SOFTENING_TWO_THIRD: {
+        const double k_nq = M_PI / BoxSize * N;               // gravity.c:249
+        const double kth = 2.0 / 3 * k_nq;
+        if (p->f64) radial_kernel<double><<<grid, 256, 0, p->stream>>>(g, kk, 0, kth * kth, (Cplx<double> *) delta_k);
+        else radial_kernel<float><<<grid, 256, 0, p->stream>>>(g, kk, 0, kth * kth, (Cplx<float> *) delta_k);
+        break;
+    }
+    case FPMHIP_SOFTENING_GAUSSIAN36: {
+        const double k_nq = M_PI / BoxSize * N;               // gravity.c:262
+        if (p->f64) radial_kernel<double><<<grid, 256, 0, p->stream>>>(g, kk, 1, k_nq, (Cplx<double> *) delta_k);
+        else radial_kernel<float><<<grid, 256, 0, p->stream>>>(g, kk, 1, k_nq, (Cplx<float> *) delta_k);
+        break;
+    }
+    default:
+        FPM_FAIL(-1, "wrong softening kernel type");          // gravity.c:268
+    }
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int fpmhip_powerspectrum(fpmhip_plan *p, const void *d1, const void *d2, double *ksum, double *psum, double *nmodes)
+{
+    if (!p || !d1 || !ksum || !psum || !nmodes) FPM_FAIL(-1, "null argument");
+    if (!d2) d2 = d1;
+    const MeshGeo &g = p->mg;
+    const int nbins = g.N / 2;
+    double *dbins = nullptr;
+    FPM_CHECK_HIP(hipMalloc(&dbins, 3 * nbins * sizeof(double)));
+    FPM_CHECK_HIP(hipMemsetAsync(dbins, 0, 3 * nbins * sizeof(double), p->stream));
+    const double k0 = 2 * M_PI / p->geom.BoxSize;
+    const int plane = g.yl * g.nzc;
+    dim3 grid(std::max(1u, std::min(blocks_for(plane, 256 * 8), 64u)), g.N);
+    const size_t lds = 3 * nbins * sizeof(double);
+    if (p->f64)
+        power_kernel<double><<<grid, 256, lds, p->stream>>>(g, k0, (const Cplx<double> *) d1, (const Cplx<double> *) d2,
+                                                             nbins, dbins, dbins + nbins, dbins + 2 * nbins);
+    else
+        power_kernel<float><<<grid, 256, lds, p->stream>>>(g, k0, (const Cplx<float> *) d1, (const Cplx<float> *) d2,
+                                                            nbins, dbins, dbins + nbins, dbins + 2 * nbins);
+    std::vector<double> h(3 * nbins);
+    hipError_t e = hipMemcpyAsync(h.data(), dbins, 3 * nbins * sizeof(double), hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    (void) hipFree(dbins);
+    FPM_CHECK_HIP(e);
+    for (int i = 0; i < nbins; i++) { ksum[i] = h[i]; psum[i] = h[nbins + i]; nmodes[i] = h[2 * nbins + i]; }
+    return 0;
+}
+
+int fpmhip_check_values(fpmhip_plan *p, const void *mesh, int64_t *count)
+{
+    if (!p || !mesh || !count) FPM_FAIL(-1, "null argument");
+    unsigned long long *d = (unsigned long long *) p->d_scalar;
+    FPM_CHECK_HIP(hipMemsetAsync(d, 0, sizeof(*d), p->stream));
+    if (p->f64) check_values_kernel<double><<<2048, 256, 0, p->stream>>>((const double *) mesh, p->lay.allocsize, d);
+    else check_values_kernel<float><<<2048, 256, 0, p->stream>>>((const float *) mesh, p->lay.allocsize, d);
+    FPM_CHECK_HIP(hipMemcpyAsync(p->h_pinned, d, sizeof(*d), hipMemcpyDeviceToHost, p->stream));
+    FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
+    *count = (int64_t) * (unsigned long long *) p->h_pinned;
+    return 0;
+}
+
+int fpmhip_plane_add(fpmhip_plan *p, void *dst, const void *src)
+{
+    if (!p || !dst || !src) FPM_FAIL(-1, "null argument");
+    StageTimer tm(p, FPMHIP_T_HALO);
+    const long long n = p->lay.plane_elems;
+    if (p->f64) plane_add_kernel<double><<<blocks_for(n, 256), 256, 0, p->stream>>>((double *) dst, (const double *) src, n);
+    else plane_add_kernel<float><<<blocks_for(n, 256), 256, 0, p->stream>>>((float *) dst, (const float *) src, n);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int fpmhip_export_delta_k(fpmhip_plan *p, const void *delta_k, void *host)
+{
+    if (!p || !delta_k || !host) FPM_FAIL(-1, "null argument");
+    FPM_TRY(ensure_buffer(p, BUF_XCHG));
+    const MeshGeo &g = p->mg;
+    const long long plane = (long long) g.yl * g.nzc;
+    dim3 grid(blocks_for(plane, 32), blocks_for(g.N, 32));
+    if (p->f64) to_reference_layout_kernel<double><<<grid, 256, 0, p->stream>>>(g.N, plane, (const Cplx<double> *) delta_k, (Cplx<double> *) p->buf[BUF_XCHG]);
+    else to_reference_layout_kernel<float><<<grid, 256, 0, p->stream>>>(g.N, plane, (const Cplx<float> *) delta_k, (Cplx<float> *) p->buf[BUF_XCHG]);
+    FPM_CHECK_HIP(hipGetLastError());
+    FPM_CHECK_HIP(hipMemcpyAsync(host, p->buf[BUF_XCHG], (size_t) 2 * p->lay.complex_elems * p->esize,
+                                 hipMemcpyDeviceToHost, p->stream));
+    FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
+    return 0;
+}
+
+}  // extern "C"

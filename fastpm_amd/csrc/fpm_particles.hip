@@ -1,0 +1,474 @@
+// fpm_particles.hip -- particle side of the PM force step for gfx950:
+//   tile binning (counting sort with wavefront-aggregated atomics),
+//   CIC paint  (reference libfastpm/painter.c:320-339 + painter-cic.c:34-110),
+//   CIC readout(reference libfastpm/painter.c:358-374 + painter-cic.c:113-190),
+//   mass sum   (reference libfastpm/gravity.c:330-335).
+//
+// Design (bandwidth-bound, no MFMA): particles are binned into TILE_X x TILE_Y x TILE_Z cell
+// tiles; a particle whose CIC cloud crosses a tile face is listed again ("dup") in every other
+// tile it touches.  One workgroup owns one tile: it accumulates its entries into an LDS copy of
+// the tile (LDS atomics only) and then writes the tile to HBM once, with plain coalesced
+// stores, already multiplied by the density normalisation.  No global atomics, no memset, the
+// mesh is written exactly once.  The binned copy of the positions (SoA, tile order) is reused by
+// the readout, whose 8-corner gathers then hit L1/L2 because a wave's particles share a tile.
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
+
+#include "fpm_internal.h"
+
+namespace fpm {
+
+// ------------------------------------------------------------------------------------------
+// CIC index / weight arithmetic, shared by paint and readout.  Follows painter-cic.c:45-76:
+// X = pos * InvCellSize; I = (int) floor(X); D = X - I (before the wrap); T = 1 - D; then the
+// periodic wrap of I and I+1, then the shift to rank-local x.  All in double, no contraction.
+// ------------------------------------------------------------------------------------------
+struct Cic {
+    int i0[3];   // base cell, local in x
+    int i1[3];   // base + 1 (wrapped / halo plane)
+    double d[3], t[3];
+};
+
+__device__ __forceinline__ int wrap_cell(int i, int n)
+{
+    while (i < 0) i += n;
+    while (i >= n) i -= n;
+    return i;
+}
+
+// Returns false if the particle's base x plane is not owned by this rank.
+__device__ __forceinline__ bool cic_setup(const MeshGeo &g, double px, double py, double pz, Cic &c)
+{
+    const double pos[3] = {px, py, pz};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        double X = pos[a] * g.inv_cell;
+        int I = (int) floor(X);
+        c.d[a] = X - I;
+        c.t[a] = 1. - c.d[a];
+        c.i0[a] = wrap_cell(I, g.N);
+        c.i1[a] = wrap_cell(I + 1, g.N);
+    }
+    if (!g.periodic_x) {
+        // slab: the particle's base plane is owned by this rank (the caller's decomposition
+        // guarantees it, solver.c:449); plane xl is the halo plane owned by rank + 1.
+        c.i0[0] -= g.xstart;
+        c.i1[0] = c.i0[0] + 1;
+        return c.i0[0] >= 0 && c.i0[0] < g.xl;
+    }
+    return true;
+}
+
+__device__ __forceinline__ int tile_id(const MeshGeo &g, int tx, int ty, int tz)
+{
+    return (tx * g.nty + ty) * g.ntz + tz;
+}
+
+// Wavefront-aggregated atomic increment: lanes of the wave that target the same counter are
+// merged into one atomicAdd by the first of them.  Returns each lane's slot when RET.
+template <bool RET>
+__device__ __forceinline__ int wave_agg_inc(int *counters, int key, bool active)
+{
+    int slot = -1;
+    unsigned long long remaining = __ballot(active);
+    const int lane = __lane_id();
+    while (remaining) {
+        int leader = __ffsll((long long) remaining) - 1;
+        int k = __shfl(key, leader);
+        bool mine = active && key == k;
+        unsigned long long same = __ballot(mine);
+        int cnt = __popcll(same);
+        int base = 0;
+        if (lane == leader) {
+            if (RET) base = atomicAdd(&counters[k], cnt);
+            else (void) atomicAdd(&counters[k], cnt);
+        }
+        if (RET) {
+            base = __shfl(base, leader);
+            if (mine) slot = base + __popcll(same & ((1ull << lane) - 1ull));
+        }
+        remaining &= ~same;
+    }
+    return slot;
+}
+
+// Pass A / C of the counting sort.  SCATTER = false: count entries per tile (own tiles in
+// cnt[0, ntiles), dup tiles in cnt[ntiles, 2 ntiles)).  SCATTER = true: place the entries.
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void bin_kernel(MeshGeo g, int ntiles, const double *__restrict__ x,
+                                                  const float *__restrict__ mass, long long np,
+                                                  int *__restrict__ cnt_or_cur,
+                                                  double *__restrict__ sx, double *__restrict__ sy,
+                                                  double *__restrict__ sz, float *__restrict__ smass,
+                                                  int *__restrict__ sidx)
+{
+    long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = i < np;
+    double px = 0, py = 0, pz = 0;
+    float pm = 0;
+    int t0[3] = {0, 0, 0}, t1[3] = {0, 0, 0};
+    if (active) {
+        px = x[3 * i + 0];
+        py = x[3 * i + 1];
+        pz = x[3 * i + 2];
+        if (SCATTER && mass) pm = mass[i];
+        Cic c;
+        if (!cic_setup(g, px, py, pz, c)) {
+            // not this rank's particle: flagged in the last counter slot, reported by the host
+            if (!SCATTER) atomicAdd(&cnt_or_cur[2 * ntiles + 1], 1);
+            active = false;
+        }
+        t0[0] = c.i0[0] / TILE_X; t0[1] = c.i0[1] / TILE_Y; t0[2] = c.i0[2] / TILE_Z;
+        t1[0] = c.i1[0] / TILE_X; t1[1] = c.i1[1] / TILE_Y; t1[2] = c.i1[2] / TILE_Z;
+    }
+    // own tile
+    {
+        int key = tile_id(g, t0[0], t0[1], t0[2]);
+        int slot = wave_agg_inc<SCATTER>(cnt_or_cur, key, active);
+        if (SCATTER && active) {
+            sx[slot] = px; sy[slot] = py; sz[slot] = pz;
+            if (smass) smass[slot] = pm;
+            sidx[slot] = (int) i;
+        }
+    }
+    // the up to 7 other tiles the cloud touches
+#pragma unroll
+    for (int c = 1; c < 8; c++) {
+        const int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
+        bool need = active && (!bx || t1[0] != t0[0]) && (!by || t1[1] != t0[1]) && (!bz || t1[2] != t0[2]);
+        if (__ballot(need) == 0) continue;
+        int key = ntiles + tile_id(g, bx ? t1[0] : t0[0], by ? t1[1] : t0[1], bz ? t1[2] : t0[2]);
+        int slot = wave_agg_inc<SCATTER>(cnt_or_cur, key, need);
+        if (SCATTER && need) {
+            sx[slot] = px; sy[slot] = py; sz[slot] = pz;
+            if (smass) smass[slot] = pm;
+            sidx[slot] = (int) i;
+        }
+    }
+}
+
+// XCD-aware block -> tile map: consecutive tiles (which share mesh rows in the readout) go to
+// the same XCD / L2.  Workgroup b is dispatched to XCD b % 8 (MI355X_MICROARCH.md); bijective
+// for any ntiles.
+__device__ __forceinline__ int xcd_remap(int b, int n)
+{
+    const int q = n / 8, r = n % 8;
+    const int xcd = b % 8, j = b / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
+// One workgroup = one tile.  LDS tile of F accumulators; entries of the tile (own, then dup)
+// add the corners that fall inside the tile with LDS atomics; then the tile goes to HBM with
+// plain stores: canvas = (F) (sum * scale), i.e. painter-cic.c:21-27 followed by
+// transfer.c:212-220 with the same rounding points.
+template <typename F>
+__global__ __launch_bounds__(256) void paint_tiles_kernel(MeshGeo g, int ntiles,
+                                                          const int *__restrict__ off,
+                                                          const double *__restrict__ sx,
+                                                          const double *__restrict__ sy,
+                                                          const double *__restrict__ sz,
+                                                          const float *__restrict__ smass, double M0,
+                                                          double scale, F *__restrict__ canvas)
+{
+    __shared__ F tile[TILE_CELLS];
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int tz = t % g.ntz, ty = (t / g.ntz) % g.nty, tx = t / (g.ntz * g.nty);
+    const int x0 = tx * TILE_X, y0 = ty * TILE_Y, z0 = tz * TILE_Z;
+
+    for (int i = threadIdx.x; i < TILE_CELLS; i += 256) tile[i] = 0;
+    __syncthreads();
+
+#pragma unroll
+    for (int part = 0; part < 2; part++) {
+        const int key = part * ntiles + t;
+        const int beg = off[key], end = off[key + 1];
+        for (int e = beg + threadIdx.x; e < end; e += 256) {
+            Cic c;
+            (void) cic_setup(g, sx[e], sy[e], sz[e], c);
+            double w = smass ? (M0 + smass[e]) : M0;      // store.c:119-128
+            c.d[1] *= w;                                    // painter-cic.c:78-79
+            c.t[1] *= w;
+            const int lx[2] = {c.i0[0] - x0, c.i1[0] - x0};
+            const int ly[2] = {c.i0[1] - y0, c.i1[1] - y0};
+            const int lz[2] = {c.i0[2] - z0, c.i1[2] - z0};
+            const double wx[2] = {c.t[0], c.d[0]}, wy[2] = {c.t[1], c.d[1]}, wz[2] = {c.t[2], c.d[2]};
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int bx = (k >> 2) & 1, by = (k >> 1) & 1, bz = k & 1;
+                if ((unsigned) lx[bx] < (unsigned) TILE_X && (unsigned) ly[by] < (unsigned) TILE_Y &&
+                    (unsigned) lz[bz] < (unsigned) TILE_Z) {
+                    double f = wz[bz] * wx[bx] * wy[by];    // painter-cic.c:84-107: Wz*Wx*Wy
+                    atomicAdd(&tile[(lx[bx] * TILE_Y + ly[by]) * TILE_Z + lz[bz]], (F) f);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    for (int i = threadIdx.x; i < TILE_CELLS; i += 256) {
+        const int lz = i % TILE_Z, ly = (i / TILE_Z) % TILE_Y, lx = i / (TILE_Z * TILE_Y);
+        const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
+        if (gx < g.xplanes && gy < g.N && gz < g.N) {
+            F *row = canvas + (long long) gx * g.str0 + (long long) gy * g.str1;
+            row[gz] = (F) (tile[i] * scale);
+            if (gz == g.N - 1) { row[g.N] = 0; row[g.N + 1] = 0; }   // pm_clear'ed padding
+        }
+    }
+}
+
+// Baseline for A/B evidence: one thread per particle, one global atomicAdd per corner
+// (what a direct transcription of the OpenMP loop would be).
+template <typename F>
+__global__ __launch_bounds__(256) void paint_atomic_kernel(MeshGeo g, const double *__restrict__ x,
+                                                           const float *__restrict__ mass, double M0,
+                                                           long long np, F *__restrict__ canvas)
+{
+    long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= np) return;
+    Cic c;
+    if (!cic_setup(g, x[3 * i], x[3 * i + 1], x[3 * i + 2], c)) return;
+    double w = mass ? (M0 + mass[i]) : M0;
+    c.d[1] *= w;
+    c.t[1] *= w;
+    const int ix[2] = {c.i0[0], c.i1[0]}, iy[2] = {c.i0[1], c.i1[1]}, iz[2] = {c.i0[2], c.i1[2]};
+    const double wx[2] = {c.t[0], c.d[0]}, wy[2] = {c.t[1], c.d[1]}, wz[2] = {c.t[2], c.d[2]};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int bx = (k >> 2) & 1, by = (k >> 1) & 1, bz = k & 1;
+        double f = wz[bz] * wx[bx] * wy[by];
+        unsafeAtomicAdd(&canvas[(long long) ix[bx] * g.str0 + (long long) iy[by] * g.str1 + iz[bz]], (F) f);
+    }
+}
+
+template <typename F>
+__global__ __launch_bounds__(256) void scale_kernel(F *__restrict__ buf, long long n, double value)
+{
+    long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) buf[i] = (F) (buf[i] * value);
+}
+
+// CIC readout of NC meshes at once.  value = sum over corners in the order 000,001,...,111
+// (x,y,z bits) of mesh * (Wz*Wx*Wy), accumulated in double (painter-cic.c:161-189), then
+// out = (float) value (store.c:79-91).  BINNED: thread j handles binned entry j (tile order,
+// coherent gathers) and scatters the result to the particle's original row.
+template <typename F, int NC, bool BINNED>
+__global__ __launch_bounds__(256) void readout_kernel(MeshGeo g, long long np,
+                                                      const double *__restrict__ sx,
+                                                      const double *__restrict__ sy,
+                                                      const double *__restrict__ sz,
+                                                      const int *__restrict__ sidx,
+                                                      const double *__restrict__ x,
+                                                      const F *__restrict__ m0, const F *__restrict__ m1,
+                                                      const F *__restrict__ m2, float *__restrict__ out,
+                                                      int nmemb, int memb0)
+{
+    long long j = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= np) return;
+    double px, py, pz;
+    long long row;
+    if (BINNED) {
+        px = sx[j]; py = sy[j]; pz = sz[j];
+        row = sidx[j];
+    } else {
+        px = x[3 * j]; py = x[3 * j + 1]; pz = x[3 * j + 2];
+        row = j;
+    }
+    Cic c;
+    if (!cic_setup(g, px, py, pz, c)) return;
+    const int ix[2] = {c.i0[0], c.i1[0]}, iy[2] = {c.i0[1], c.i1[1]}, iz[2] = {c.i0[2], c.i1[2]};
+    const double wx[2] = {c.t[0], c.d[0]}, wy[2] = {c.t[1], c.d[1]}, wz[2] = {c.t[2], c.d[2]};
+    const F *mesh[3] = {m0, m1, m2};
+    double value[NC];
+#pragma unroll
+    for (int q = 0; q < NC; q++) value[q] = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int bx = (k >> 2) & 1, by = (k >> 1) & 1, bz = k & 1;
+        const long long ind = (long long) ix[bx] * g.str0 + (long long) iy[by] * g.str1 + iz[bz];
+        const double wgt = wz[bz] * wx[bx] * wy[by];
+#pragma unroll
+        for (int q = 0; q < NC; q++) value[q] += (double) mesh[q][ind] * wgt;
+    }
+#pragma unroll
+    for (int q = 0; q < NC; q++) out[row * nmemb + memb0 + q] = (float) value[q];
+}
+
+// gravity.c:330-335: sum of M0 + mass[i].  (Per-block double partial sums, then one atomic
+// per block; the reference sums serially, so only the rounding order differs.)
+__global__ __launch_bounds__(256) void mass_sum_kernel(const float *__restrict__ mass, double M0,
+                                                       long long np, double *__restrict__ out)
+{
+    __shared__ double part[256];
+    double s = 0;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < np;
+         i += (long long) gridDim.x * blockDim.x)
+        s += M0 + (double) mass[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) part[threadIdx.x] += part[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, part[0]);
+}
+
+static inline unsigned blocks_for(long long n, int bs) { return (unsigned) ((n + bs - 1) / bs); }
+
+int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt)
+{
+    StageTimer tm(p, FPMHIP_T_SORT);
+    const long long np = pt->np;
+    const int nt = p->ntiles;
+    const int ncnt = 2 * nt + 1;
+    if (np >= (1ll << 31) - 1) FPM_FAIL(-1, "np %lld exceeds the int32 index range of one rank", np);
+    FPM_TRY(ensure_bins(p, np, np / 2 + 1024, pt->mass != nullptr));
+
+    // slot 2 * nt stays 0 (scan total lands there); slot 2 * nt + 1 counts unowned particles
+    FPM_CHECK_HIP(hipMemsetAsync(p->tile_cnt, 0, (ncnt + 1) * sizeof(int), p->stream));
+    if (np > 0)
+        bin_kernel<false><<<blocks_for(np, 256), 256, 0, p->stream>>>(p->mg, nt, pt->x, pt->mass, np, p->tile_cnt,
+                                                                       nullptr, nullptr, nullptr, nullptr, nullptr);
+    // exclusive scan of the 2 * ntiles counts (+1 slot -> grand total at off[2 * ntiles])
+    size_t tmp_bytes = 0;
+    FPM_CHECK_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, p->tile_cnt, p->tile_off, 0, (size_t) ncnt,
+                                          rocprim::plus<int>(), p->stream));
+    if (tmp_bytes > p->scan_tmp_bytes) {
+        if (p->scan_tmp) FPM_CHECK_HIP(hipFree(p->scan_tmp));
+        FPM_CHECK_HIP(hipMalloc(&p->scan_tmp, tmp_bytes));
+        p->scan_tmp_bytes = tmp_bytes;
+    }
+    FPM_CHECK_HIP(rocprim::exclusive_scan(p->scan_tmp, tmp_bytes, p->tile_cnt, p->tile_off, 0, (size_t) ncnt,
+                                          rocprim::plus<int>(), p->stream));
+    // capacity check for the dup entries: one small read-back
+    FPM_CHECK_HIP(hipMemcpyAsync(p->h_pinned, p->tile_off + 2 * nt, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    FPM_CHECK_HIP(hipMemcpyAsync(p->h_pinned + 1, p->tile_cnt + 2 * nt + 1, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
+    const long long total = p->h_pinned[0];
+    if (p->h_pinned[1] != 0)
+        FPM_FAIL(-6, "%d particles are outside this rank's slab [%d, %d) in x: decompose before the force "
+                     "(reference solver.c:449)", p->h_pinned[1], p->mg.xstart, p->mg.xstart + p->mg.xl);
+    if (total < np) FPM_FAIL(-5, "internal: binned %lld entries for %lld particles", total, np);
+    const long long ndup = total - np;
+    if (total > p->bin_cap_own) FPM_TRY(ensure_bins(p, np, ndup, pt->mass != nullptr));
+
+    FPM_CHECK_HIP(hipMemcpyAsync(p->tile_cur, p->tile_off, ncnt * sizeof(int), hipMemcpyDeviceToDevice, p->stream));
+    if (np > 0)
+        bin_kernel<true><<<blocks_for(np, 256), 256, 0, p->stream>>>(p->mg, nt, pt->x, pt->mass, np, p->tile_cur,
+                                                                      p->sx, p->sy, p->sz,
+                                                                      pt->mass ? p->smass : nullptr, p->sidx);
+    FPM_CHECK_HIP(hipGetLastError());
+    p->binned_x = pt->x;
+    p->binned_mass = pt->mass;
+    p->binned_np = np;
+    p->binned_ndup = ndup;
+    return 0;
+}
+
+template <typename F>
+static int paint_impl(fpmhip_plan *p, const fpmhip_particles *pt, double scale, F *canvas)
+{
+    if (p->geom.paint_mode == FPMHIP_PAINT_ATOMIC) {
+        StageTimer tm(p, FPMHIP_T_PAINT);
+        FPM_CHECK_HIP(hipMemsetAsync(canvas, 0, (size_t) p->lay.allocsize * sizeof(F), p->stream));
+        if (pt->np > 0)
+            paint_atomic_kernel<F><<<blocks_for(pt->np, 256), 256, 0, p->stream>>>(p->mg, pt->x, pt->mass, pt->M0,
+                                                                                    pt->np, canvas);
+        scale_kernel<F><<<2048, 256, 0, p->stream>>>(canvas, p->lay.real_elems, scale);
+        FPM_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
+    FPM_TRY(bin_particles(p, pt));
+    StageTimer tm(p, FPMHIP_T_PAINT);
+    paint_tiles_kernel<F><<<p->ntiles, 256, 0, p->stream>>>(p->mg, p->ntiles, p->tile_off, p->sx, p->sy, p->sz,
+                                                             pt->mass ? p->smass : nullptr, pt->M0, scale, canvas);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <typename F, int NC>
+static int readout_impl(fpmhip_plan *p, const fpmhip_particles *pt, const F *m0, const F *m1, const F *m2,
+                        float *out, int nmemb, int memb0)
+{
+    const long long np = pt->np;
+    if (np == 0) return 0;
+    if (p->geom.paint_mode == FPMHIP_PAINT_ATOMIC) {
+        StageTimer tm(p, FPMHIP_T_READOUT);
+        readout_kernel<F, NC, false><<<blocks_for(np, 256), 256, 0, p->stream>>>(
+            p->mg, np, nullptr, nullptr, nullptr, nullptr, pt->x, m0, m1, m2, out, nmemb, memb0);
+        FPM_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
+    if (p->binned_x != pt->x || p->binned_np != np) FPM_TRY(bin_particles(p, pt));
+    StageTimer tm(p, FPMHIP_T_READOUT);
+    readout_kernel<F, NC, true><<<blocks_for(np, 256), 256, 0, p->stream>>>(
+        p->mg, np, p->sx, p->sy, p->sz, p->sidx, nullptr, m0, m1, m2, out, nmemb, memb0);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace fpm
+
+using namespace fpm;
+
+static int check_particles(const fpmhip_plan *p, const fpmhip_particles *pt)
+{
+    if (!p || !pt) FPM_FAIL(-1, "null argument");
+    if (pt->np < 0) FPM_FAIL(-1, "negative particle count");
+    if (pt->np > 0 && !pt->x) FPM_FAIL(-1, "particles without positions");
+    return 0;
+}
+
+extern "C" {
+
+int fpmhip_paint(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void *canvas)
+{
+    FPM_TRY(check_particles(p, pt));
+    if (!canvas) FPM_FAIL(-1, "null canvas");
+    return p->f64 ? paint_impl<double>(p, pt, scale, (double *) canvas)
+                  : paint_impl<float>(p, pt, scale, (float *) canvas);
+}
+
+int fpmhip_invalidate_binning(fpmhip_plan *p)
+{
+    if (!p) FPM_FAIL(-1, "null plan");
+    p->binned_np = -1;
+    p->binned_x = nullptr;
+    return 0;
+}
+
+int fpmhip_readout3(fpmhip_plan *p, const fpmhip_particles *pt, const void *m0, const void *m1, const void *m2)
+{
+    FPM_TRY(check_particles(p, pt));
+    if (!pt->acc && pt->np > 0) FPM_FAIL(-1, "particles without an acc column");
+    if (!m0 || !m1 || !m2) FPM_FAIL(-1, "null mesh");
+    return p->f64 ? readout_impl<double, 3>(p, pt, (const double *) m0, (const double *) m1, (const double *) m2, pt->acc, 3, 0)
+                  : readout_impl<float, 3>(p, pt, (const float *) m0, (const float *) m1, (const float *) m2, pt->acc, 3, 0);
+}
+
+int fpmhip_readout1(fpmhip_plan *p, const fpmhip_particles *pt, const void *m, float *out, int nmemb, int memb)
+{
+    FPM_TRY(check_particles(p, pt));
+    if (!m || (!out && pt->np > 0)) FPM_FAIL(-1, "null mesh or output");
+    if (memb < 0 || memb >= nmemb) FPM_FAIL(-1, "memb %d greater than nmemb %d", memb, nmemb);   // store.c:83-85
+    return p->f64 ? readout_impl<double, 1>(p, pt, (const double *) m, nullptr, nullptr, out, nmemb, memb)
+                  : readout_impl<float, 1>(p, pt, (const float *) m, nullptr, nullptr, out, nmemb, memb);
+}
+
+int fpmhip_total_mass(fpmhip_plan *p, const fpmhip_particles *pt, double *total)
+{
+    FPM_TRY(check_particles(p, pt));
+    if (!total) FPM_FAIL(-1, "null output");
+    if (!pt->mass) {
+        *total = (double) pt->np * pt->M0;
+        return 0;
+    }
+    FPM_CHECK_HIP(hipMemsetAsync(p->d_scalar, 0, sizeof(double), p->stream));
+    if (pt->np > 0) mass_sum_kernel<<<1024, 256, 0, p->stream>>>(pt->mass, pt->M0, pt->np, p->d_scalar);
+    FPM_CHECK_HIP(hipMemcpyAsync(p->h_pinned, p->d_scalar, sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
+    *total = *(double *) p->h_pinned;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,369 @@
+// fpm_plan.hip -- plan = GPU twin of pm_init (reference libfastpm/pmpfft.c:108-319):
+// geometry, float32 k tables (pmapi.c:234-275), buffers, stage timers, small helpers.
+#include <cmath>
+#include <cstring>
+
+#include "fpm_internal.h"
+
+namespace fpm {
+
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+StageTimer::StageTimer(fpmhip_plan *plan, int stage) : p(plan), on(plan->timing)
+{
+    if (!on) return;
+    if (!p->ev_free.empty()) {
+        ev = p->ev_free.back();
+        p->ev_free.pop_back();
+    } else {
+        if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) {
+            on = false;
+            return;
+        }
+    }
+    ev.stage = stage;
+    (void) hipEventRecord(ev.a, p->stream);
+}
+
+StageTimer::~StageTimer()
+{
+    if (!on) return;
+    (void) hipEventRecord(ev.b, p->stream);
+    p->ev_used.push_back(ev);
+}
+
+int ensure_buffer(fpmhip_plan *p, int which)
+{
+    if (which < 0 || which >= BUF_COUNT) FPM_FAIL(-1, "bad buffer index %d", which);
+    if (p->buf[which]) return 0;
+    FPM_CHECK_HIP(hipMalloc(&p->buf[which], (size_t) p->lay.allocsize * p->esize));
+    return 0;
+}
+
+int ensure_bins(fpmhip_plan *p, int64_t np, int64_t ndup, bool has_mass)
+{
+    // own entries and dup entries share the arrays: [0, np) own, [np, np + ndup) dups
+    int64_t need = np + ndup;
+    int64_t have = p->bin_cap_own;
+    if (need > have || (has_mass && !p->smass)) {
+        int64_t cap = need > have ? need + need / 8 + 1024 : have;
+        if (p->sx) { (void) hipFree(p->sx); (void) hipFree(p->sy); (void) hipFree(p->sz); (void) hipFree(p->sidx); }
+        if (p->smass) { (void) hipFree(p->smass); p->smass = nullptr; }
+        p->sx = p->sy = p->sz = nullptr;
+        p->sidx = nullptr;
+        FPM_CHECK_HIP(hipMalloc(&p->sx, cap * sizeof(double)));
+        FPM_CHECK_HIP(hipMalloc(&p->sy, cap * sizeof(double)));
+        FPM_CHECK_HIP(hipMalloc(&p->sz, cap * sizeof(double)));
+        FPM_CHECK_HIP(hipMalloc(&p->sidx, cap * sizeof(int)));
+        if (has_mass) FPM_CHECK_HIP(hipMalloc(&p->smass, cap * sizeof(float)));
+        p->bin_cap_own = cap;
+        p->binned_np = -1;
+    }
+    return 0;
+}
+
+// The five float32 per-axis tables of pmapi.c:234-275 (pm_create_k_factors) from MeshtoK
+// (pmpfft.c:308-318).  Host arithmetic, written out so that float and double sub-expressions
+// round exactly where the reference's do.
+static double sinc_unnormed(double x)   // pmapi.c:213-220
+{
+    if (x < 1e-5 && x > -1e-5) {
+        double x2 = x * x;
+        return 1.0 - x2 / 6. + x2 * x2 / 120.;
+    }
+    return sin(x) / x;
+}
+
+static void build_k_tables(int64_t N, double BoxSize, std::vector<float> &tab)
+{
+    tab.resize(5 * N);
+    float *k_ = &tab[0], *k_finite = &tab[N], *kk = &tab[2 * N], *kk_finite = &tab[3 * N],
+          *kk_finite2 = &tab[4 * N];
+    const double cell = BoxSize / N;
+    for (int64_t i = 0; i < N; i++) {
+        int64_t ii = (i >= N / 2) ? i - N : i;
+        double mesh_to_k = ii * 2 * M_PI / BoxSize;
+        float k = (float) mesh_to_k;
+        float w = (float) (k * cell);
+        float ff1 = (float) sinc_unnormed(0.5 * w);
+        float ff2 = (float) sinc_unnormed(w);
+        k_[i] = k;
+        kk[i] = k * k;
+        // 4-point central difference, pmapi.c:223-232, :263
+        k_finite[i] = (float) (1 / cell * (1 / 6.0 * (8 * sin((double) w) - sin(2 * (double) w))));
+        float k2 = k * k;
+        kk_finite2[i] = (float) (k2 * (4 / 3.0 * ff1 * ff1 - 1 / 3.0 * ff2 * ff2));
+        kk_finite[i] = k2 * (ff1 * ff1);
+    }
+}
+
+}  // namespace fpm
+
+using namespace fpm;
+
+extern "C" {
+
+const char *fpmhip_version(void) { return "fastpm_hip 0.1 (gfx950)"; }
+
+const char *fpmhip_last_error(void) { return g_err.c_str(); }
+
+int fpmhip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// reference libfastpm/gravity.c:111-171
+int fpmhip_kernel_type_get_orders(int type, int *potorder, int *gradorder, int *difforder,
+                                  int *deconvolveorder)
+{
+    int po, go, dfo = 1, dc = 0;
+    switch (type) {
+    case FPMHIP_KERNEL_EASTWOOD: po = 0; go = 0; dc = 2; break;
+    case FPMHIP_KERNEL_NAIVE: po = 0; go = 0; break;
+    case FPMHIP_KERNEL_GADGET: po = 0; go = 1; dc = 2; break;
+    case FPMHIP_KERNEL_1_4_DIFF0: po = 0; go = 1; dfo = 0; break;
+    case FPMHIP_KERNEL_1_4: po = 0; go = 1; break;
+    case FPMHIP_KERNEL_3_4: po = 1; go = 1; break;
+    case FPMHIP_KERNEL_5_4: po = 2; go = 1; break;
+    case FPMHIP_KERNEL_3_2: po = 1; go = 0; break;
+    default: FPM_FAIL(-1, "Wrong kernel type");
+    }
+    if (potorder) *potorder = po;
+    if (gradorder) *gradorder = go;
+    if (difforder) *difforder = dfo;
+    if (deconvolveorder) *deconvolveorder = dc;
+    return 0;
+}
+
+int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
+{
+    if (!geom || !out) FPM_FAIL(-1, "null argument");
+    const int64_t N = geom->Nmesh;
+    if (N < 2 || N % 2 != 0) FPM_FAIL(-1, "Nmesh must be even, but %lld is odd.", (long long) N);
+    if (N > 8192) FPM_FAIL(-1, "Nmesh %lld too large", (long long) N);
+    if (geom->precision != 32 && geom->precision != 64) FPM_FAIL(-1, "precision must be 32 or 64");
+    if (geom->nranks < 1 || geom->rank < 0 || geom->rank >= geom->nranks) FPM_FAIL(-1, "bad rank %d/%d", geom->rank, geom->nranks);
+    if (N % geom->nranks != 0) FPM_FAIL(-1, "Nmesh %lld not divisible by nranks %d", (long long) N, geom->nranks);
+    if (!(geom->BoxSize > 0)) FPM_FAIL(-1, "BoxSize must be positive");
+
+    int ndev = 0;
+    FPM_CHECK_HIP(hipGetDeviceCount(&ndev));
+    if (ndev < 1) FPM_FAIL(-4, "no HIP device: the MI355X path cannot run (there is no CPU fallback)");
+    int dev = geom->device;
+    if (dev < 0) FPM_CHECK_HIP(hipGetDevice(&dev));
+    FPM_CHECK_HIP(hipSetDevice(dev));
+
+    fpmhip_plan *p = new fpmhip_plan();
+    p->geom = *geom;
+    p->device = dev;
+    p->stream = (hipStream_t) stream;
+    p->f64 = geom->precision == 64;
+    p->esize = p->f64 ? 8 : 4;
+
+    const int P = geom->nranks;
+    const int xl = (int) (N / P), yl = (int) (N / P), nzc = (int) (N / 2 + 1);
+    fpmhip_layout &L = p->lay;
+    memset(&L, 0, sizeof(L));
+    L.Nmesh = N;
+    L.BoxSize = geom->BoxSize;
+    L.precision = geom->precision;
+    L.nranks = P;
+    L.rank = geom->rank;
+    L.ihalo = P > 1 ? 1 : 0;
+    L.plane_elems = N * (N + 2);
+    L.istart[0] = (int64_t) geom->rank * xl; L.istart[1] = 0; L.istart[2] = 0;
+    L.isize[0] = xl; L.isize[1] = N; L.isize[2] = N;
+    L.istrides[0] = L.plane_elems; L.istrides[1] = N + 2; L.istrides[2] = 1;
+    L.ostart[0] = 0; L.ostart[1] = (int64_t) geom->rank * yl; L.ostart[2] = 0;
+    L.osize[0] = N; L.osize[1] = yl; L.osize[2] = nzc;
+    L.ostrides[0] = (int64_t) yl * nzc; L.ostrides[1] = nzc; L.ostrides[2] = 1;
+    L.real_elems = (xl + L.ihalo) * L.plane_elems;
+    L.complex_elems = N * (int64_t) yl * nzc;
+    L.allocsize = std::max(L.real_elems, 2 * L.complex_elems);
+    L.Norm = (double) N * (double) N * (double) N;
+
+    MeshGeo &g = p->mg;
+    g.N = (int) N; g.xl = xl; g.xstart = geom->rank * xl; g.xplanes = xl + (int) L.ihalo;
+    g.periodic_x = P == 1; g.yl = yl; g.ystart = geom->rank * yl; g.nzc = nzc;
+    g.str0 = L.plane_elems; g.str1 = N + 2;
+    g.inv_cell = 1.0 / (geom->BoxSize / N);
+    g.ntx = (g.xplanes + TILE_X - 1) / TILE_X;
+    g.nty = ((int) N + TILE_Y - 1) / TILE_Y;
+    g.ntz = ((int) N + TILE_Z - 1) / TILE_Z;
+    p->ntiles = g.ntx * g.nty * g.ntz;
+
+    build_k_tables(N, geom->BoxSize, p->h_tab);
+    int rc = 0;
+    do {
+        if (hipMalloc(&p->d_tab, 5 * N * sizeof(float)) != hipSuccess) { rc = -2; break; }
+        if (hipMemcpy(p->d_tab, p->h_tab.data(), 5 * N * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { rc = -2; break; }
+        if (hipMalloc(&p->d_fac, 3 * N * sizeof(double)) != hipSuccess) { rc = -2; break; }
+        if (hipMalloc(&p->tile_cnt, (2 * (size_t) p->ntiles + 2) * sizeof(int)) != hipSuccess) { rc = -2; break; }
+        if (hipMalloc(&p->tile_off, (2 * (size_t) p->ntiles + 2) * sizeof(int)) != hipSuccess) { rc = -2; break; }
+        if (hipMalloc(&p->tile_cur, (2 * (size_t) p->ntiles + 2) * sizeof(int)) != hipSuccess) { rc = -2; break; }
+        if (hipHostMalloc((void **) &p->h_pinned, 4096) != hipSuccess) { rc = -2; break; }
+        if (hipMalloc(&p->d_scalar, 4096) != hipSuccess) { rc = -2; break; }
+    } while (0);
+    if (rc != 0) {
+        set_error("device allocation failed while creating the plan: %s", hipGetErrorString(hipGetLastError()));
+        fpmhip_plan_destroy(p);
+        return rc;
+    }
+    rc = fft_setup(p);
+    if (rc != 0) {
+        fpmhip_plan_destroy(p);
+        return rc;
+    }
+    if (geom->np_max > 0) {
+        rc = ensure_bins(p, geom->np_max, geom->np_max / 2, false);
+        if (rc != 0) { fpmhip_plan_destroy(p); return rc; }
+    }
+    *out = p;
+    return 0;
+}
+
+void fpmhip_plan_destroy(fpmhip_plan *p)
+{
+    if (!p) return;
+    (void) hipSetDevice(p->device);
+    (void) hipStreamSynchronize(p->stream);
+    fft_teardown(p);
+    for (int i = 0; i < BUF_COUNT; i++) if (p->buf[i]) (void) hipFree(p->buf[i]);
+    void *ptrs[] = {p->d_tab, p->d_fac, p->sx, p->sy, p->sz, p->smass, p->sidx, p->tile_cnt,
+                    p->tile_off, p->tile_cur, p->scan_tmp, p->d_scalar};
+    for (void *q : ptrs) if (q) (void) hipFree(q);
+    if (p->h_pinned) (void) hipHostFree(p->h_pinned);
+    for (auto &e : p->ev_used) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
+    for (auto &e : p->ev_free) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
+    delete p;
+}
+
+int fpmhip_plan_layout(const fpmhip_plan *p, fpmhip_layout *out)
+{
+    if (!p || !out) FPM_FAIL(-1, "null argument");
+    *out = p->lay;
+    return 0;
+}
+
+int fpmhip_plan_set_stream(fpmhip_plan *p, void *stream)
+{
+    if (!p) FPM_FAIL(-1, "null plan");
+    p->stream = (hipStream_t) stream;
+    FPM_CHECK_FFT(rocfft_execution_info_set_stream(p->fft_info, p->stream));
+    return 0;
+}
+
+void *fpmhip_plan_buffer(fpmhip_plan *p, int which)
+{
+    if (!p) return nullptr;
+    if (ensure_buffer(p, which) != 0) return nullptr;
+    return p->buf[which];
+}
+
+int fpmhip_sync(fpmhip_plan *p)
+{
+    if (!p) FPM_FAIL(-1, "null plan");
+    FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
+    return 0;
+}
+
+void *fpmhip_plane_ptr(fpmhip_plan *p, void *mesh, int64_t ix)
+{
+    if (!p || !mesh) return nullptr;
+    return (char *) mesh + (size_t) ix * p->lay.plane_elems * p->esize;
+}
+
+int64_t fpmhip_exchange_chunk_elems(const fpmhip_plan *p)
+{
+    if (!p) return -1;
+    return 2 * (int64_t) p->mg.xl * p->mg.yl * p->mg.nzc;
+}
+
+static const char *stage_names[FPMHIP_T_COUNT] = {"sort", "paint", "r2c", "dealias", "transfer",
+                                                  "c2r", "readout", "halo", "pack"};
+
+const char *fpmhip_timing_name(int stage)
+{
+    if (stage < 0 || stage >= FPMHIP_T_COUNT) return "?";
+    return stage_names[stage];
+}
+
+int fpmhip_timing_enable(fpmhip_plan *p, int on)
+{
+    if (!p) FPM_FAIL(-1, "null plan");
+    p->timing = on != 0;
+    return 0;
+}
+
+static int timing_collect(fpmhip_plan *p)
+{
+    if (p->ev_used.empty()) return 0;
+    FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
+    for (auto &e : p->ev_used) {
+        float ms = 0;
+        FPM_CHECK_HIP(hipEventElapsedTime(&ms, e.a, e.b));
+        p->t_ms[e.stage] += ms;
+        p->t_n[e.stage] += 1;
+        p->ev_free.push_back(e);
+    }
+    p->ev_used.clear();
+    return 0;
+}
+
+int fpmhip_timing_reset(fpmhip_plan *p)
+{
+    if (!p) FPM_FAIL(-1, "null plan");
+    FPM_TRY(timing_collect(p));
+    for (int i = 0; i < FPMHIP_T_COUNT; i++) { p->t_ms[i] = 0; p->t_n[i] = 0; }
+    return 0;
+}
+
+int fpmhip_timing_get(fpmhip_plan *p, int stage, double *total_ms, int64_t *count)
+{
+    if (!p || stage < 0 || stage >= FPMHIP_T_COUNT) FPM_FAIL(-1, "bad timing query");
+    FPM_TRY(timing_collect(p));
+    if (total_ms) *total_ms = p->t_ms[stage];
+    if (count) *count = p->t_n[stage];
+    return 0;
+}
+
+int fpmhip_malloc(void **ptr, size_t bytes)
+{
+    if (!ptr) FPM_FAIL(-1, "null argument");
+    FPM_CHECK_HIP(hipMalloc(ptr, bytes));
+    return 0;
+}
+
+int fpmhip_free(void *ptr)
+{
+    FPM_CHECK_HIP(hipFree(ptr));
+    return 0;
+}
+
+int fpmhip_memcpy_h2d(fpmhip_plan *p, void *dst, const void *src, size_t bytes)
+{
+    FPM_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, p ? p->stream : 0));
+    FPM_CHECK_HIP(hipStreamSynchronize(p ? p->stream : 0));
+    return 0;
+}
+
+int fpmhip_memcpy_d2h(fpmhip_plan *p, void *dst, const void *src, size_t bytes)
+{
+    FPM_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, p ? p->stream : 0));
+    FPM_CHECK_HIP(hipStreamSynchronize(p ? p->stream : 0));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,281 @@
+"""Host-side mirror of the reference's PM interface for the force path.
+
+Same names, argument meaning and error behaviour as the reference so that the
+parity tests read like the reference's own calls:
+
+    PM                             <- struct PM / pm_init          libfastpm/pmpfft.c:108-319
+    PM.alloc / pm_alloc            <- pm_alloc                      libfastpm/pmapi.c:11-16
+    PM.paint                       <- pm_clear + fastpm_paint_local libfastpm/painter.c:320-339
+    PM.r2c / PM.c2r                <- pm_r2c / pm_c2r               libfastpm/pmpfft.c:370-399
+    PM.apply_softening_transfer    <- apply_softening_transfer      libfastpm/gravity.c:244-270
+    PM.gravity_apply_kernel_transfer <- gravity_apply_kernel_transfer  gravity.c:174-242
+    PM.readout                     <- fastpm_readout_local          libfastpm/painter.c:358-374
+    PM.apply_decic_transfer        <- fastpm_apply_decic_transfer   libfastpm/transfer.c:77-113
+    PM.powerspectrum               <- fastpm_powerspectrum_init_from_delta  powerspectrum.c:35-124
+    Store                          <- the FastPMStore columns the path touches  api/fastpm/store.h:62-135
+    fastpm_solver_compute_force    <- gravity.c:458-529
+
+All compute happens in libfastpm_hip.so through the C ABI (include/fastpm_hip.h); torch only
+owns device memory and the stream.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from .lib import FastPMHipError, check
+
+# api/fastpm/libfastpm.h:39-54 (enum order is ABI)
+KERNEL_TYPES = {"3_4": 0, "3_2": 1, "5_4": 2, "1_4": 3, "1_4_diff0": 4, "gadget": 5, "eastwood": 6, "naive": 7}
+SOFTENING_TYPES = {"none": 0, "gaussian": 1, "gadget_long_range": 2, "two_third": 3, "gaussian36": 4}
+FIELD_ACC = (0, 1, 2)
+FIELD_POTENTIAL = 3
+PAINT_TILED, PAINT_ATOMIC = 0, 1
+
+
+def _enum(table, v):
+    if isinstance(v, str):
+        if v not in table:
+            raise FastPMHipError("unknown enum name %r" % v)
+        return table[v]
+    return int(v)
+
+
+def fastpm_kernel_type_get_orders(kernel):
+    """gravity.c:111-171 -> (potorder, gradorder, difforder, deconvolveorder); raises on a wrong type."""
+    L = _lib.load_library()
+    o = [ctypes.c_int() for _ in range(4)]
+    check(L.fpmhip_kernel_type_get_orders(_enum(KERNEL_TYPES, kernel), *[ctypes.byref(v) for v in o]))
+    return tuple(v.value for v in o)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class Store:
+    """The columns of FastPMStore the force step reads/writes, as device tensors:
+    x float64 [np][3], mass float32 [np] or None (+ meta.M0), acc float32 [np][3],
+    potential float32 [np] or None."""
+
+    def __init__(self, x, mass=None, M0=1.0, potential=False, device="cuda"):
+        self.x = torch.as_tensor(x, dtype=torch.float64, device=device).contiguous()
+        assert self.x.ndim == 2 and self.x.shape[1] == 3
+        self.np = int(self.x.shape[0])
+        self.mass = None if mass is None else torch.as_tensor(mass, dtype=torch.float32, device=device).contiguous()
+        self.M0 = float(M0)
+        self.acc = torch.zeros((self.np, 3), dtype=torch.float32, device=self.x.device)
+        self.potential = torch.zeros(self.np, dtype=torch.float32, device=self.x.device) if potential else None
+
+    def _c(self, np_=None):
+        c = _lib.Particles()
+        c.x = self.x.data_ptr()
+        c.mass = 0 if self.mass is None else self.mass.data_ptr()
+        c.M0 = self.M0
+        c.np = self.np if np_ is None else np_
+        c.acc = self.acc.data_ptr()
+        c.potential = 0 if self.potential is None else self.potential.data_ptr()
+        return c
+
+
+class PM:
+    """One rank's particle mesh on one MI355X (struct PM + its plans)."""
+
+    def __init__(self, Nmesh, BoxSize, precision=64, nranks=1, rank=0, device=None, np_max=0,
+                 paint_mode=PAINT_TILED):
+        self._L = _lib.load_library()
+        self._plan = ctypes.c_void_p()
+        if not torch.cuda.is_available():
+            raise FastPMHipError("no HIP device: the MI355X path cannot run (there is no CPU fallback)")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", int(device))
+        g = _lib.Geom(int(Nmesh), float(BoxSize), int(precision), int(nranks), int(rank), int(self.device.index),
+                      int(np_max), int(paint_mode), 0)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            check(self._L.fpmhip_plan_create(ctypes.byref(g), ctypes.c_void_p(stream), ctypes.byref(self._plan)))
+        self.layout = _lib.Layout()
+        check(self._L.fpmhip_plan_layout(self._plan, ctypes.byref(self.layout)))
+        self.Nmesh, self.BoxSize, self.precision = int(Nmesh), float(BoxSize), int(precision)
+        self.nranks, self.rank = int(nranks), int(rank)
+        self.dtype = torch.float64 if precision == 64 else torch.float32
+        self.allocsize = int(self.layout.allocsize)
+        self.Norm = float(self.layout.Norm)
+
+    # ---- lifetime
+    def destroy(self):
+        if self._plan:
+            self._L.fpmhip_plan_destroy(self._plan)
+            self._plan = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def use_current_stream(self):
+        with torch.cuda.device(self.device):
+            check(self._L.fpmhip_plan_set_stream(self._plan, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def sync(self):
+        check(self._L.fpmhip_sync(self._plan))
+
+    # ---- pmapi.c:11-34
+    def alloc(self):
+        return torch.zeros(self.allocsize, dtype=self.dtype, device=self.device)
+
+    # ---- views for tests / host handlers
+    def real_view(self, buf):
+        """[x_loc (+halo)][y][N+2] view of a real-space mesh."""
+        L = self.layout
+        nx = L.isize[0] + L.ihalo
+        return buf[: nx * L.plane_elems].view(nx, self.Nmesh, self.Nmesh + 2)
+
+    def complex_view(self, buf):
+        """[x][y_loc][kz] complex view of a k-space mesh (fpmhip_layout.ostrides)."""
+        L = self.layout
+        n = int(L.complex_elems)
+        return torch.view_as_complex(buf[: 2 * n].view(n, 2)).view(L.osize[0], L.osize[1], L.osize[2])
+
+    # ---- stages
+    def total_mass(self, store):
+        out = ctypes.c_double()
+        check(self._L.fpmhip_total_mass(self._plan, ctypes.byref(store._c()), ctypes.byref(out)))
+        return out.value
+
+    def paint(self, canvas, store, scale=1.0):
+        check(self._L.fpmhip_paint(self._plan, ctypes.byref(store._c()), float(scale), _ptr(canvas)))
+
+    def invalidate_binning(self):
+        check(self._L.fpmhip_invalidate_binning(self._plan))
+
+    def r2c(self, canvas, delta_k):
+        check(self._L.fpmhip_r2c(self._plan, _ptr(canvas), _ptr(delta_k)))
+
+    def c2r(self, inplace):
+        check(self._L.fpmhip_c2r(self._plan, _ptr(inplace)))
+
+    def apply_softening_transfer(self, softening, delta_k):
+        check(self._L.fpmhip_softening(self._plan, _ptr(delta_k), _enum(SOFTENING_TYPES, softening)))
+
+    def gravity_apply_kernel_transfer(self, kernel, delta_k, canvas, field):
+        check(self._L.fpmhip_transfer(self._plan, _ptr(delta_k), _ptr(canvas), _enum(KERNEL_TYPES, kernel), int(field)))
+
+    def readout3(self, meshes, store):
+        check(self._L.fpmhip_readout3(self._plan, ctypes.byref(store._c()), *[_ptr(m) for m in meshes]))
+
+    def readout(self, mesh, store, out, nmemb=1, memb=0):
+        check(self._L.fpmhip_readout1(self._plan, ctypes.byref(store._c()), _ptr(mesh), _ptr(out), int(nmemb), int(memb)))
+
+    def apply_decic_transfer(self, src, dst):
+        check(self._L.fpmhip_decic(self._plan, _ptr(src), _ptr(dst)))
+
+    def powerspectrum_sums(self, d1, d2=None):
+        nb = self.Nmesh // 2
+        k, p, n = (np.zeros(nb) for _ in range(3))
+        cp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        check(self._L.fpmhip_powerspectrum(self._plan, _ptr(d1), _ptr(d2) if d2 is not None else None, cp(k), cp(p), cp(n)))
+        return k, p, n
+
+    def powerspectrum(self, d1, d2=None):
+        """powerspectrum.c:35-124 on one rank: (k, P, Nmodes) per integer-wavenumber bin."""
+        k, p, n = self.powerspectrum_sums(d1, d2)
+        nz = n != 0
+        k[nz] /= n[nz]
+        p[nz] /= n[nz]
+        p[nz] *= self.BoxSize ** 3
+        return k, p, n
+
+    def check_values(self, mesh):
+        out = ctypes.c_int64()
+        check(self._L.fpmhip_check_values(self._plan, _ptr(mesh), ctypes.byref(out)))
+        return out.value
+
+    def export_delta_k(self, delta_k):
+        """Host copy of delta_k in the reference's PFFT-transposed layout [y_loc][kz][x]."""
+        L = self.layout
+        cdt = np.complex128 if self.precision == 64 else np.complex64
+        out = np.empty((L.osize[1], L.osize[2], L.osize[0]), dtype=cdt)
+        check(self._L.fpmhip_export_delta_k(self._plan, _ptr(delta_k), out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    # ---- slab stages (nranks > 1)
+    def plane(self, mesh, ix):
+        L = self.layout
+        return mesh[ix * L.plane_elems: (ix + 1) * L.plane_elems]
+
+    def plane_add(self, dst_plane, src_plane):
+        check(self._L.fpmhip_plane_add(self._plan, _ptr(dst_plane), _ptr(src_plane)))
+
+    def exchange_chunk_elems(self):
+        return int(self._L.fpmhip_exchange_chunk_elems(self._plan))
+
+    def fft_yz_forward(self, canvas, send):
+        check(self._L.fpmhip_fft_yz_forward(self._plan, _ptr(canvas), _ptr(send)))
+
+    def fft_x_forward(self, recv):
+        check(self._L.fpmhip_fft_x_forward(self._plan, _ptr(recv)))
+
+    def fft_x_backward(self, buf):
+        check(self._L.fpmhip_fft_x_backward(self._plan, _ptr(buf)))
+
+    def fft_yz_backward(self, recv, canvas):
+        check(self._L.fpmhip_fft_yz_backward(self._plan, _ptr(recv), _ptr(canvas)))
+
+    # ---- whole step, one rank
+    def compute_force(self, store, kernel="1_4", softening="none", delta_k=None, total_mass=-1.0):
+        check(self._L.fpmhip_force(self._plan, ctypes.byref(store._c()), _enum(KERNEL_TYPES, kernel),
+                                   _enum(SOFTENING_TYPES, softening), float(total_mass), _ptr(delta_k)))
+
+    def compute_force_host(self, x, mass=None, M0=1.0, kernel="1_4", softening="none", potential=False,
+                           want_delta_k=False):
+        """fpmhip_force_host: numpy in (as libfastpm holds its store), numpy out."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        n = len(x)
+        acc = np.zeros((n, 3), dtype=np.float32)
+        pot = np.zeros(n, dtype=np.float32) if potential else None
+        m = None if mass is None else np.ascontiguousarray(mass, dtype=np.float32)
+        c = _lib.Particles()
+        c.x = x.ctypes.data
+        c.mass = 0 if m is None else m.ctypes.data
+        c.M0, c.np = float(M0), n
+        c.acc = acc.ctypes.data
+        c.potential = 0 if pot is None else pot.ctypes.data
+        dk = None
+        if want_delta_k:
+            L = self.layout
+            cdt = np.complex128 if self.precision == 64 else np.complex64
+            dk = np.empty((L.osize[1], L.osize[2], L.osize[0]), dtype=cdt)
+        check(self._L.fpmhip_force_host(self._plan, ctypes.byref(c), _enum(KERNEL_TYPES, kernel),
+                                        _enum(SOFTENING_TYPES, softening),
+                                        None if dk is None else dk.ctypes.data_as(ctypes.c_void_p)))
+        return acc, pot, dk
+
+    # ---- timing (CLOCK names of gravity.c)
+    def timing_enable(self, on=True):
+        check(self._L.fpmhip_timing_enable(self._plan, int(on)))
+
+    def timing_reset(self):
+        check(self._L.fpmhip_timing_reset(self._plan))
+
+    def timings(self):
+        out = {}
+        for i, name in enumerate(_lib.TIMING_STAGES):
+            ms, n = ctypes.c_double(), ctypes.c_int64()
+            check(self._L.fpmhip_timing_get(self._plan, i, ctypes.byref(ms), ctypes.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+
+def fastpm_solver_compute_force(pm, store, dealias="none", kernel="1_4", delta_k=None, Time=1.0):
+    """Mirror of fastpm_solver_compute_force(fastpm, pm, painter, dealias, kernel, delta_k, Time)
+    (gravity.c:458-529) for one CDM species and the CIC painter: overwrites store.acc
+    (and store.potential if that column exists) and fills delta_k (post-softening, pre-deCIC)."""
+    if pm.nranks != 1:
+        from .distributed import slab_compute_force
+        return slab_compute_force(pm, store, dealias=dealias, kernel=kernel, delta_k=delta_k)
+    pm.compute_force(store, kernel=kernel, softening=dealias, delta_k=delta_k)
+    return delta_k

@@ -1,0 +1,197 @@
+/*
+ * fastpm_hip.h -- C ABI of the MI355X-native particle-mesh force step.
+ *
+ * This is the whole drop-in boundary: plain C, plain pointers and sizes, no C++/torch types.
+ * It replaces the body of
+ *
+ *     void fastpm_solver_compute_force(FastPMSolver *, PM *, FastPMPainter *,
+ *              FastPMSofteningType, FastPMKernelType, FastPMFloat * delta_k, double Time);
+ *                                    (reference api/fastpm/gravity.h:12-19,
+ *                                     defined libfastpm/gravity.c:457-529)
+ *
+ * and the L2 primitives it calls.  INTEGRATION.md shows the gravity_hip.c a libfastpm
+ * maintainer adds to bind it.  All entry points return 0 on success and a negative code on
+ * failure; fpmhip_last_error() then returns a message (the reference convention is
+ * fastpm_raise(-1, ...) -> abort, libfastpm/logging.c:242-251: the binding maps nonzero to that).
+ *
+ * Conventions
+ *   - "FastPMFloat" is float (precision 32) or double (64), api/fastpm/libfastpm.h:27-37.
+ *   - A "mesh buffer" is device memory holding fpmhip_layout.allocsize FastPMFloat values.
+ *   - Pointers named *_dev are device pointers on the plan's device; *_host are host pointers.
+ *   - Every call is asynchronous on the plan's stream unless it takes host output pointers.
+ *   - Ranks: slab decomposition of the mesh along x (Nproc = {nranks, 1}, which the reference
+ *     API allows: api/fastpm/solver.h:71 NprocY, libfastpm/pmpfft.c:117-136).  The library does
+ *     all rank-local work; the two exchange steps (mesh-halo plane and FFT transpose) are plain
+ *     contiguous buffers handed to the caller's collective (RCCL all-to-all / send-recv).
+ */
+#ifndef FASTPM_HIP_H
+#define FASTPM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fpmhip_plan fpmhip_plan;
+
+/* enum values are the reference's (api/fastpm/libfastpm.h:39-54) */
+enum { FPMHIP_KERNEL_3_4 = 0, FPMHIP_KERNEL_3_2, FPMHIP_KERNEL_5_4, FPMHIP_KERNEL_1_4,
+       FPMHIP_KERNEL_1_4_DIFF0, FPMHIP_KERNEL_GADGET, FPMHIP_KERNEL_EASTWOOD, FPMHIP_KERNEL_NAIVE };
+enum { FPMHIP_SOFTENING_NONE = 0, FPMHIP_SOFTENING_GAUSSIAN, FPMHIP_SOFTENING_GADGET_LONG_RANGE,
+       FPMHIP_SOFTENING_TWO_THIRD, FPMHIP_SOFTENING_GAUSSIAN36 };
+/* field selector of fpmhip_transfer: COLUMN_ACC memb 0..2, COLUMN_POTENTIAL (gravity.c:478-483) */
+enum { FPMHIP_FIELD_ACC_X = 0, FPMHIP_FIELD_ACC_Y = 1, FPMHIP_FIELD_ACC_Z = 2, FPMHIP_FIELD_POTENTIAL = 3 };
+/* paint algorithm */
+enum { FPMHIP_PAINT_TILED = 0,      /* tile-binned particles, LDS-staged tiles, no global atomics */
+       FPMHIP_PAINT_ATOMIC = 1 };   /* one global atomicAdd per corner (baseline for A/B evidence) */
+
+/* What pm_init takes (libfastpm/pmpfft.h:29-35 PMInit) + where this rank sits. */
+typedef struct {
+    int64_t Nmesh;        /* cubic mesh, must be even (pmpfft.c:143) and divisible by nranks */
+    double  BoxSize;
+    int32_t precision;    /* 32 or 64 = FASTPM_FFT_PRECISION */
+    int32_t nranks;       /* slabs along x */
+    int32_t rank;
+    int32_t device;       /* HIP device ordinal; -1 = the current device */
+    int64_t np_max;       /* capacity hint for particle work buffers (grown on demand) */
+    int32_t paint_mode;   /* FPMHIP_PAINT_* */
+    int32_t reserved;
+} fpmhip_geom;
+
+/* What struct PM exposes to the hot path (pmpfft.h:43-70, pmapi.h:3-9).  Real strides are in
+ * reals, complex strides in complex numbers, all indexed by physical axis x,y,z. */
+typedef struct {
+    int64_t Nmesh;
+    double  BoxSize;
+    int32_t precision, nranks, rank, reserved;
+    int64_t istart[3], isize[3], istrides[3];   /* IRegion; isize excludes z padding and halo */
+    int64_t ihalo;          /* extra x planes after the local slab (0 if nranks == 1, else 1) */
+    int64_t plane_elems;    /* reals in one x plane = Nmesh * (Nmesh + 2) */
+    int64_t ostart[3], osize[3], ostrides[3];   /* ORegion: [x][y_loc][kz], kz fastest */
+    int64_t real_elems;     /* reals used by a real-space mesh incl. halo plane */
+    int64_t complex_elems;  /* complex numbers in a k-space mesh */
+    int64_t allocsize;      /* FastPMFloat elements every mesh buffer must hold */
+    double  Norm;           /* Nmesh^3 (pmpfft.c:146-154) */
+} fpmhip_layout;
+
+/* The columns of FastPMStore the force step reads and writes (api/fastpm/store.h:62-135). */
+typedef struct {
+    const double *x;        /* [np][3], already wrapped to [0, BoxSize] (store.c:446-475) */
+    const float  *mass;     /* [np] or NULL -> every particle weighs M0 (store.c:119-128) */
+    double        M0;
+    int64_t       np;
+    float        *acc;      /* [np][3], overwritten (store.c:79-91) */
+    float        *potential;/* [np] or NULL (gravity.c:487-492) */
+} fpmhip_particles;
+
+/* ---- library ---- */
+const char *fpmhip_version(void);
+const char *fpmhip_last_error(void);
+int fpmhip_device_count(void);
+
+/* fastpm_kernel_type_get_orders, api/fastpm/gravity.h:5-10 / libfastpm/gravity.c:111-171 */
+int fpmhip_kernel_type_get_orders(int type, int *potorder, int *gradorder,
+                                  int *difforder, int *deconvolveorder);
+
+/* ---- plan: the GPU twin of pm_init (pmpfft.c:108-319): geometry, k tables, rocFFT plans,
+ *      work buffers.  stream = hipStream_t (NULL = the null stream). ---- */
+int  fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **plan);
+void fpmhip_plan_destroy(fpmhip_plan *plan);
+int  fpmhip_plan_layout(const fpmhip_plan *plan, fpmhip_layout *out);
+int  fpmhip_plan_set_stream(fpmhip_plan *plan, void *stream);
+/* plan-owned mesh buffers: 0 = canvas, 1 = delta_k, 2..4 = force components, 5 = exchange */
+void *fpmhip_plan_buffer(fpmhip_plan *plan, int which);
+int  fpmhip_sync(fpmhip_plan *plan);
+
+/* ---- the whole force step, one rank (nranks == 1): gravity.c:458-529 ----
+ * delta_k_dev (nullable) receives delta(k)/N^3 after softening, before de-CIC, in the plan's
+ * k layout (fpmhip_layout.ostrides).  total_mass < 0 -> computed here (gravity.c:330-341). */
+int fpmhip_force(fpmhip_plan *plan, const fpmhip_particles *p_dev, int kernel, int softening,
+                 double total_mass, void *delta_k_dev);
+/* Same with host-resident store columns, as libfastpm has them today: copies x (and mass) up,
+ * acc (and potential) down; delta_k_host (nullable) is written in the REFERENCE's layout
+ * (PFFT transposed [y][z][x], pmpfft.c:198-202) so host handlers iterate it with PMKIter. */
+int fpmhip_force_host(fpmhip_plan *plan, const fpmhip_particles *p_host, int kernel, int softening,
+                      void *delta_k_host);
+
+/* ---- stages (any nranks).  gravity.c:305-356 / :359-429 in pieces. ---- */
+
+/* pm_clear + fastpm_paint_local + multiply transfer (pmapi.c:30-34, painter.c:320-339,
+ * painter-cic.c:34-110, transfer.c:212-220): canvas = scale * sum of CIC weights.  Writes
+ * every cell of the local slab and of the halo plane. */
+int fpmhip_paint(fpmhip_plan *plan, const fpmhip_particles *p_dev, double scale, void *canvas_dev);
+/* sum of fastpm_store_get_mass over the local particles (gravity.c:330-335) -> host double */
+int fpmhip_total_mass(fpmhip_plan *plan, const fpmhip_particles *p_dev, double *total_host);
+/* The readout reuses the tile binning of the last paint when (x, np) are unchanged; call this
+ * if the positions behind the same pointer were modified in between. */
+int fpmhip_invalidate_binning(fpmhip_plan *plan);
+
+/* mesh halo (replaces the particle ghosts of pmghosts.c:112-307 for a slab decomposition):
+ * after paint, plane `isize[0]` (the halo) is sent to rank+1 and added to its plane 0;
+ * before readout, plane 0 of each force mesh is sent to rank-1 into its halo plane. */
+void *fpmhip_plane_ptr(fpmhip_plan *plan, void *mesh_dev, int64_t ix);
+int   fpmhip_plane_add(fpmhip_plan *plan, void *dst_plane_dev, const void *src_plane_dev);
+
+/* pm_r2c / pm_c2r (pmpfft.c:370-399) for nranks == 1: r2c out of place, x 1/Norm; c2r in
+ * place, unnormalised. */
+int fpmhip_r2c(fpmhip_plan *plan, void *canvas_dev, void *delta_k_dev);
+int fpmhip_c2r(fpmhip_plan *plan, void *inplace_dev);
+/* nranks > 1: the same transforms split around the one all-to-all each needs.
+ *   forward : yz_forward(canvas -> send) ; all-to-all(send -> recv) ; x_forward(recv) = delta_k
+ *   backward: x_backward(buf) ; all-to-all(buf -> recv) ; yz_backward(recv -> canvas)
+ * Exchange buffers are split in nranks equal contiguous chunks, chunk r goes to / comes from
+ * rank r; fpmhip_exchange_chunk_elems() gives the chunk length in FastPMFloat elements. */
+int64_t fpmhip_exchange_chunk_elems(const fpmhip_plan *plan);
+int fpmhip_fft_yz_forward(fpmhip_plan *plan, void *canvas_dev, void *send_dev);
+int fpmhip_fft_x_forward(fpmhip_plan *plan, void *recv_inplace_dev);
+int fpmhip_fft_x_backward(fpmhip_plan *plan, void *inplace_dev);
+int fpmhip_fft_yz_backward(fpmhip_plan *plan, void *recv_dev, void *canvas_dev);
+
+/* apply_softening_transfer (gravity.c:244-270), in place on delta_k */
+int fpmhip_softening(fpmhip_plan *plan, void *delta_k_dev, int softening);
+/* gravity_apply_kernel_transfer for ACC / POTENTIAL (gravity.c:174-242), fused into one
+ * pointwise pass: laplace (transfer.c:153-186), x -1 (gravity.c:17), gradient (gravity.c:21-64),
+ * with the reference's intermediate roundings. */
+int fpmhip_transfer(fpmhip_plan *plan, const void *delta_k_dev, void *out_dev, int kernel, int field);
+
+/* fastpm_readout_local (painter.c:358-374, painter-cic.c:113-190): one or three meshes.
+ * readout3 writes acc[i][0..2]; readout1 writes out[i * nmemb + memb]. */
+int fpmhip_readout3(fpmhip_plan *plan, const fpmhip_particles *p_dev,
+                    const void *mesh0_dev, const void *mesh1_dev, const void *mesh2_dev);
+int fpmhip_readout1(fpmhip_plan *plan, const fpmhip_particles *p_dev, const void *mesh_dev,
+                    float *out_dev, int nmemb, int memb);
+
+/* ---- what the caller does next with delta_k (solver.c:471-473) ---- */
+/* fastpm_apply_decic_transfer (transfer.c:77-113) */
+int fpmhip_decic(fpmhip_plan *plan, const void *from_dev, void *to_dev);
+/* fastpm_powerspectrum_init_from_delta before the Allreduce (powerspectrum.c:35-111): raw
+ * per-bin sums (Nmesh/2 bins) of w*k, w*Re(d1 conj d2), w on the host.  Synchronises. */
+int fpmhip_powerspectrum(fpmhip_plan *plan, const void *d1_dev, const void *d2_dev,
+                         double *ksum_host, double *psum_host, double *nmodes_host);
+/* pm_check_values (pmapi.c:335-356): count of NaN / |v| > 1e15 entries.  Synchronises. */
+int fpmhip_check_values(fpmhip_plan *plan, const void *mesh_dev, int64_t *count_host);
+/* copy a k-space mesh to the host in the reference's PFFT-transposed layout [y][z][x] */
+int fpmhip_export_delta_k(fpmhip_plan *plan, const void *delta_k_dev, void *delta_k_host);
+
+/* ---- per-stage timing with HIP events on the plan's stream (the reference's CLOCK names,
+ *      gravity.c:276,320,344,348,369-372,474) ---- */
+enum { FPMHIP_T_SORT = 0, FPMHIP_T_PAINT, FPMHIP_T_R2C, FPMHIP_T_DEALIAS, FPMHIP_T_TRANSFER,
+       FPMHIP_T_C2R, FPMHIP_T_READOUT, FPMHIP_T_HALO, FPMHIP_T_PACK, FPMHIP_T_COUNT };
+int fpmhip_timing_enable(fpmhip_plan *plan, int on);
+int fpmhip_timing_reset(fpmhip_plan *plan);
+/* Synchronises; total milliseconds and launch count of one stage since the last reset. */
+int fpmhip_timing_get(fpmhip_plan *plan, int stage, double *total_ms, int64_t *count);
+const char *fpmhip_timing_name(int stage);
+
+/* ---- plain device-memory helpers so a C host needs no HIP headers ---- */
+int fpmhip_malloc(void **ptr_dev, size_t bytes);
+int fpmhip_free(void *ptr_dev);
+int fpmhip_memcpy_h2d(fpmhip_plan *plan, void *dst_dev, const void *src_host, size_t bytes);
+int fpmhip_memcpy_d2h(fpmhip_plan *plan, void *dst_host, const void *src_dev, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,176 @@
+/*
+ * pm_oracle.c -- CPU restatement of FastPM's particle-mesh force step (see pm_oracle.h).
+ *
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see pm_oracle.h for why).
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off -fopenmp; no -ffast-math, so every
+ * double/float operation rounds exactly where the C source says it does).
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "pm_oracle.h"
+
+#ifndef M_PI
+#define M_PI (3.14159265358979323846264338327950288)
+#endif
+
+void orc_set_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void) n;
+#endif
+}
+
+int orc_get_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* gravity.c:111-171 */
+int orc_kernel_type_get_orders(int type, int *potorder, int *gradorder,
+                               int *difforder, int *deconvolveorder)
+{
+    static const int table[8][4] = {
+        /* pot grad diff deconv */
+        {1, 1, 1, 0},   /* 3_4        gravity.c:153-158 */
+        {1, 0, 1, 0},   /* 3_2        :165-170 */
+        {2, 1, 1, 0},   /* 5_4        :159-164 */
+        {0, 1, 1, 0},   /* 1_4        :147-152 */
+        {0, 1, 0, 0},   /* 1_4_DIFF0  :141-146 */
+        {0, 1, 1, 2},   /* GADGET     :135-140 */
+        {0, 0, 1, 2},   /* EASTWOOD   :118-126 */
+        {0, 0, 1, 0},   /* NAIVE      :127-132 */
+    };
+    if (type < 0 || type > 7) return -1;
+    *potorder = table[type][0];
+    *gradorder = table[type][1];
+    *difforder = table[type][2];
+    *deconvolveorder = table[type][3];
+    return 0;
+}
+
+static double sinc_unnormed(double x)     /* pmapi.c:213-220 */
+{
+    if (x < 1e-5 && x > -1e-5) {
+        double x2 = x * x;
+        return 1.0 - x2 / 6. + x2 * x2 / 120.;
+    }
+    return sin(x) / x;
+}
+
+static double diff_kernel(double w)       /* pmapi.c:223-232 */
+{
+    return 1 / 6.0 * (8 * sin(w) - sin(2 * w));
+}
+
+/* pmapi.c:234-275 pm_create_k_factors; MeshtoK from pmpfft.c:308-318.
+ * Every table entry is a float; note which sub-expressions are float and which double. */
+void orc_k_tables(int64_t N, double BoxSize, float *k_, float *k_finite,
+                  float *kk, float *kk_finite, float *kk_finite2)
+{
+    double CellSize = BoxSize / N;
+    for (int64_t ind = 0; ind < N; ind++) {
+        int64_t ii = ind;
+        if (ii >= N / 2) ii -= N;                         /* pmpfft.c:313-315: N/2 -> -N/2 */
+        double MeshtoK = ii * 2 * M_PI / BoxSize;         /* pmpfft.c:316 */
+        float k = MeshtoK;                                /* pmapi.c:255 */
+        float w = k * CellSize;                           /* :256 double product -> float */
+        float ff1 = sinc_unnormed(0.5 * w);               /* :257 */
+        float ff2 = sinc_unnormed(w);                     /* :258 */
+        k_[ind] = k;                                      /* :260 */
+        kk[ind] = k * k;                                  /* :261 float product */
+        k_finite[ind] = 1 / CellSize * diff_kernel(w);    /* :263 double -> float */
+        kk_finite2[ind] = k * k * (4 / 3.0 * ff1 * ff1 - 1 / 3.0 * ff2 * ff2);   /* :268 */
+        kk_finite[ind] = k * k * (ff1 * ff1);             /* :270 all-float */
+    }
+}
+
+/* store.c:36-49 */
+void orc_reduce_add_float(float *dest, const float *src, const int32_t *ighost_to_ipar,
+                          int64_t nghost, int nmemb)
+{
+    for (int64_t g = 0; g < nghost; g++)
+        for (int d = 0; d < nmemb; d++)
+            dest[(int64_t) ighost_to_ipar[g] * nmemb + d] += src[g * nmemb + d];
+}
+
+/* store.c:446-475 (the n > 10000 sanity raise is not restated) */
+void orc_store_wrap(double *x, int64_t np, double BoxSize)
+{
+    for (int64_t i = 0; i < np; i++)
+        for (int d = 0; d < 3; d++) {
+            double x1 = remainder(x[3 * i + d], BoxSize);
+            while (x1 < 0) x1 += BoxSize;
+            while (x1 > BoxSize) x1 -= BoxSize;
+            x[3 * i + d] = x1;
+        }
+}
+
+static int ipos_to_cart(int64_t N, int ipos, const int64_t *edges, int n)   /* pmpfft.c:353-366 */
+{
+    if (ipos < 0) {
+        ipos = ipos % (int) N;
+        if (ipos < 0) ipos += (int) N;
+    }
+    if (ipos >= N) ipos = ipos % (int) N;
+    for (int j = 0; j < n; j++)                      /* Grid.MeshtoCart, pmpfft.c:252-259 */
+        if (ipos >= edges[j] && ipos < edges[j + 1]) return j;
+    return -1;
+}
+
+/* pmghosts.c:31-80 pm_iter_ghosts with Below = 0, Above = 1 (CIC, support 2: :118-128) */
+int64_t orc_ghost_pairs(int64_t N, double BoxSize, const int64_t *edges_x, int nx,
+                        const int64_t *edges_y, int ny, int thisrank,
+                        const double *x, int64_t np, int32_t *pair_ipar, int32_t *pair_rank)
+{
+    const double inv = 1.0 / (BoxSize / N);
+    int64_t count = 0;
+    for (int64_t i = 0; i < np; i++) {
+        int left[3], right[3];
+        for (int d = 0; d < 3; d++) {
+            left[d] = floor(x[3 * i + d] * inv + 0.0);
+            right[d] = floor(x[3 * i + d] * inv + 1.0);
+        }
+        int ranks[8];
+        int used = 0;
+        int j[3];
+        for (j[2] = left[2]; j[2] <= right[2]; j[2]++)
+        for (j[0] = left[0]; j[0] <= right[0]; j[0]++)
+        for (j[1] = left[1]; j[1] <= right[1]; j[1]++) {
+            int rx = ipos_to_cart(N, j[0], edges_x, nx);
+            int ry = ipos_to_cart(N, j[1], edges_y, ny);
+            int rank = rx * ny + ry;                  /* pmpfft.c:367 */
+            if (rank == thisrank) continue;
+            int ptr;
+            for (ptr = 0; ptr < used; ptr++) if (rank == ranks[ptr]) break;
+            if (ptr == used) {
+                ranks[used++] = rank;
+                if (pair_ipar) { pair_ipar[count] = (int32_t) i; pair_rank[count] = rank; }
+                count++;
+            }
+        }
+    }
+    return count;
+}
+
+#define F float
+#define SUF f32
+#include "pm_oracle_impl.h"
+#undef F
+#undef SUF
+
+#define F double
+#define SUF f64
+#include "pm_oracle_impl.h"
+#undef F
+#undef SUF

@@ -1,0 +1,343 @@
+"""
+pm_oracle.py -- Python driver of the CPU oracle for FastPM's PM force step.
+
+TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module; nothing under fastpm_amd/ does.
+
+PARITY UNPINNED: the reference cannot be built in this image (GSL and PFFT are
+missing) and holds no golden vectors for this path in isolation; see
+oracle/pm_oracle.h.  The arithmetic lives in oracle/pm_oracle.c (each function
+cites the reference file:line); this file strings the stages together in the
+order of libfastpm/gravity.c:458-529 and supplies the DFT, which the reference
+delegates to PFFT/FFTW (libfastpm/pmpfft.c:370-399) and we delegate to
+scipy.fft (pocketfft) with the same conventions: forward e^{-ikx} unnormalised
+then x 1/N^3, backward unnormalised, padded real input, transposed [y][z][x]
+complex output.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import scipy.fft
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    """Compile oracle/libpm_oracle.so with gcc (Makefile next to this file)."""
+    so = os.path.join(_HERE, "libpm_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("pm_oracle.c", "pm_oracle_impl.h", "pm_oracle.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libpm_oracle.so"])
+    return so
+
+
+class Geom(ctypes.Structure):
+    _fields_ = [("Nmesh", ctypes.c_int64), ("BoxSize", ctypes.c_double),
+                ("istart", ctypes.c_int64 * 3), ("isize", ctypes.c_int64 * 3),
+                ("istrides", ctypes.c_int64 * 3),
+                ("ostart", ctypes.c_int64 * 3), ("osize", ctypes.c_int64 * 3),
+                ("ostrides", ctypes.c_int64 * 3), ("allocsize", ctypes.c_int64)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+        _LIB.orc_ghost_pairs.restype = ctypes.c_int64
+        _LIB.orc_check_values_f32.restype = ctypes.c_int64
+        _LIB.orc_check_values_f64.restype = ctypes.c_int64
+        _LIB.orc_get_max_threads.restype = ctypes.c_int
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+KERNELS = {"3_4": 0, "3_2": 1, "5_4": 2, "1_4": 3, "1_4_diff0": 4, "gadget": 5, "eastwood": 6, "naive": 7}
+SOFTENINGS = {"none": 0, "gaussian": 1, "gadget_long_range": 2, "two_third": 3, "gaussian36": 4}
+
+
+def block_edges(n, p):
+    """PFFT-style block distribution: blocks of ceil(n/p), trailing ranks may be empty."""
+    blk = -(-n // p)
+    return [min(r * blk, n) for r in range(p + 1)]
+
+
+def auto_nproc(ntask, nprocy=0):
+    """libfastpm/pmpfft.c:117-136: Ny = largest divisor of NTask not exceeding ceil(sqrt(NTask))."""
+    ny = nprocy
+    if ny <= 0:
+        ny = 1
+        while ny * ny < ntask:
+            ny += 1
+        while ny >= 1:
+            if ntask % ny == 0:
+                break
+            ny -= 1
+    assert ntask % ny == 0
+    return ntask // ny, ny
+
+
+def make_geom(N, BoxSize, nproc=(1, 1), rank=0):
+    """Geometry of rank `rank` on an Nx x Ny process mesh, transposed PFFT layout
+    (libfastpm/pmpfft.c:160-210): real [x_loc][y_loc][N+2]; complex [y_loc][z_loc][x]."""
+    nx, ny = nproc
+    assert N % 2 == 0, "Nmesh must be even (pmpfft.c:143)"
+    rx, ry = rank // ny, rank % ny                    # pmpfft.c:367 rank = rx * Ny + ry
+    ex, ey = block_edges(N, nx), block_edges(N, ny)
+    ez = block_edges(N // 2 + 1, ny)
+    g = Geom()
+    g.Nmesh, g.BoxSize = N, BoxSize
+    g.istart[:] = [ex[rx], ey[ry], 0]
+    g.isize[:] = [ex[rx + 1] - ex[rx], ey[ry + 1] - ey[ry], N]
+    g.istrides[:] = [g.isize[1] * (N + 2), N + 2, 1]
+    # complex: y split over Nproc[0], z over Nproc[1], x whole; x fastest
+    oy = block_edges(N, nx)
+    g.ostart[:] = [0, oy[rx], ez[ry]]
+    g.osize[:] = [N, oy[rx + 1] - oy[rx], ez[ry + 1] - ez[ry]]
+    g.ostrides[0] = 1
+    g.ostrides[2] = g.osize[0]
+    g.ostrides[1] = g.osize[2] * g.ostrides[2]
+    ireal = g.isize[0] * g.istrides[0]
+    oreal = 2 * g.osize[1] * g.ostrides[1]
+    g.allocsize = max(ireal, oreal)
+    return g
+
+
+def k_tables(N, BoxSize):
+    """The five float32 per-axis tables (pmapi.c:234-275): dict of arrays of length N."""
+    t = {n: np.empty(N, dtype=np.float32) for n in ("k", "k_finite", "kk", "kk_finite", "kk_finite2")}
+    lib().orc_k_tables(ctypes.c_int64(N), ctypes.c_double(BoxSize), _p(t["k"]), _p(t["k_finite"]),
+                       _p(t["kk"]), _p(t["kk_finite"]), _p(t["kk_finite2"]))
+    return t
+
+
+def kernel_orders(kernel):
+    o = [ctypes.c_int() for _ in range(4)]
+    rc = lib().orc_kernel_type_get_orders(int(kernel), *[ctypes.byref(v) for v in o])
+    if rc != 0:
+        raise ValueError("Wrong kernel type")       # gravity.c:169
+    return tuple(v.value for v in o)
+
+
+class PMOracle:
+    """One rank's view of the PM (struct PM, libfastpm/pmpfft.h:43-70) plus the stage functions."""
+
+    def __init__(self, N, BoxSize, precision=64, nproc=(1, 1), rank=0, threads=1):
+        assert precision in (32, 64)
+        self.N, self.BoxSize = int(N), float(BoxSize)
+        self.precision = precision
+        self.F = np.float64 if precision == 64 else np.float32
+        self.C = np.complex128 if precision == 64 else np.complex64
+        self.suf = "f64" if precision == 64 else "f32"
+        self.nproc, self.rank = tuple(nproc), rank
+        self.g = make_geom(N, BoxSize, nproc, rank)
+        self.allocsize = int(self.g.allocsize)
+        self.Norm = float(N) ** 3
+        self.threads = threads
+        lib().orc_set_threads(int(threads))
+
+    def _fn(self, name):
+        lib().orc_set_threads(int(self.threads))
+        return getattr(lib(), "orc_%s_%s" % (name, self.suf))
+
+    # --- pmapi.c:11-34
+    def alloc(self):
+        return np.zeros(self.allocsize, dtype=self.F)
+
+    # --- painter.c:320-339
+    def paint(self, canvas, x, mass=None, M0=1.0):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if mass is not None:
+            mass = np.ascontiguousarray(mass, dtype=np.float32)
+        self._fn("paint")(ctypes.byref(self.g), _p(canvas), _p(x), _p(mass),
+                          ctypes.c_double(M0), ctypes.c_int64(len(x)))
+
+    # --- painter.c:358-374
+    def readout(self, canvas, x, out=None, nmemb=1, memb=0, accumulate=False, out_f64=None):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if out is None and out_f64 is None:
+            out = np.zeros((len(x), nmemb), dtype=np.float32)
+        self._fn("readout")(ctypes.byref(self.g), _p(canvas), _p(x), ctypes.c_int64(len(x)),
+                            _p(out), ctypes.c_int(nmemb), ctypes.c_int(memb),
+                            ctypes.c_int(int(accumulate)), _p(out_f64))
+        return out
+
+    def scale(self, buf, value):
+        self._fn("scale")(_p(buf), ctypes.c_int64(buf.size), ctypes.c_double(value))
+
+    # --- views of the flat buffers
+    def real_view(self, buf):
+        g = self.g
+        n0, n1 = g.isize[0], g.isize[1]
+        return buf[: n0 * g.istrides[0]].reshape(n0, n1, self.N + 2)
+
+    def complex_view(self, buf):
+        """[y_loc][z_loc][x] complex view of the local ORegion."""
+        g = self.g
+        n = g.osize[1] * g.osize[2] * g.osize[0]
+        return buf[: 2 * n].view(self.C).reshape(g.osize[1], g.osize[2], g.osize[0])
+
+    # --- pmpfft.c:370-388 (single rank); multi-rank: global_r2c below
+    def r2c(self, canvas):
+        assert self.nproc == (1, 1)
+        return global_r2c([self], [canvas])[0]
+
+    # --- pmpfft.c:390-399
+    def c2r(self, buf):
+        assert self.nproc == (1, 1)
+        global_c2r([self], [buf])
+        return buf
+
+    def softening(self, delta_k, softening):
+        rc = self._fn("softening")(ctypes.byref(self.g), int(softening), _p(delta_k))
+        if rc != 0:
+            raise ValueError("wrong softening kernel type")     # gravity.c:268
+
+    def kernel_transfer(self, kernel, delta_k, canvas, memb=0, potential=False):
+        rc = self._fn("kernel_transfer")(ctypes.byref(self.g), int(kernel), _p(delta_k), _p(canvas),
+                                         int(potential), int(memb))
+        if rc != 0:
+            raise ValueError("Wrong kernel type")                # gravity.c:169
+
+    def laplace(self, src, dst, order):
+        self._fn("laplace")(ctypes.byref(self.g), _p(src), _p(dst), int(order))
+
+    def grad(self, src, dst, dir, order):
+        self._fn("grad")(ctypes.byref(self.g), _p(src), _p(dst), int(dir), int(order))
+
+    def decic(self, src, dst):
+        self._fn("decic")(ctypes.byref(self.g), _p(src), _p(dst))
+
+    def powerspectrum_sums(self, d1, d2=None, local_z_rule=False):
+        d2 = d1 if d2 is None else d2
+        nb = self.N // 2
+        k, p, n = (np.zeros(nb) for _ in range(3))
+        self._fn("powerspectrum")(ctypes.byref(self.g), _p(d1), _p(d2), _p(k), _p(p), _p(n),
+                                  int(local_z_rule))
+        return k, p, n
+
+    def check_values(self, buf):
+        return int(self._fn("check_values")(_p(buf), ctypes.c_int64(buf.size)))
+
+
+def powerspectrum_finalize(ksum, psum, nmodes, BoxSize):
+    """powerspectrum.c:117-123 after the three Allreduces (:113-115)."""
+    k, p = ksum.copy(), psum.copy()
+    nz = nmodes != 0
+    k[nz] /= nmodes[nz]
+    p[nz] /= nmodes[nz]
+    p[nz] *= BoxSize ** 3
+    return k, p, nmodes
+
+
+def global_r2c(pms, canvases, workers=-1):
+    """pm_r2c (pmpfft.c:370-388) over all ranks of one process mesh at once: assemble the
+    global real mesh, DFT it, hand each rank its transposed ORegion block, then x 1/Norm over
+    each rank's whole buffer (:381-385)."""
+    pm0 = pms[0]
+    N = pm0.N
+    full = np.empty((N, N, N), dtype=pm0.F)
+    for pm, cv in zip(pms, canvases):
+        g = pm.g
+        full[g.istart[0]:g.istart[0] + g.isize[0], g.istart[1]:g.istart[1] + g.isize[1], :] = \
+            pm.real_view(cv)[:, :, :N]
+    ck = scipy.fft.rfftn(full, workers=workers)             # [x][y][kz], forward e^{-ikx}
+    assert ck.dtype == pm0.C
+    outs = []
+    for pm in pms:
+        g = pm.g
+        out = pm.alloc()
+        blk = ck[:, g.ostart[1]:g.ostart[1] + g.osize[1], g.ostart[2]:g.ostart[2] + g.osize[2]]
+        pm.complex_view(out)[...] = np.transpose(blk, (1, 2, 0))
+        pm.scale(out, 1 / pm.Norm)
+        outs.append(out)
+    return outs
+
+
+def global_c2r(pms, bufs, workers=-1):
+    """pm_c2r (pmpfft.c:390-399), in place, unnormalised, over all ranks at once."""
+    pm0 = pms[0]
+    N = pm0.N
+    ck = np.empty((N, N, N // 2 + 1), dtype=pm0.C)
+    for pm, b in zip(pms, bufs):
+        g = pm.g
+        ck[:, g.ostart[1]:g.ostart[1] + g.osize[1], g.ostart[2]:g.ostart[2] + g.osize[2]] = \
+            np.transpose(pm.complex_view(b), (2, 0, 1))
+    full = scipy.fft.irfftn(ck, s=(N, N, N), norm="forward", workers=workers)
+    assert full.dtype == pm0.F
+    for pm, b in zip(pms, bufs):
+        g = pm.g
+        b[:] = 0
+        pm.real_view(b)[:, :, :N] = \
+            full[g.istart[0]:g.istart[0] + g.isize[0], g.istart[1]:g.istart[1] + g.isize[1], :]
+
+
+def total_mass(x, mass, M0):
+    """gravity.c:330-335: serial double running sum of fastpm_store_get_mass (np.cumsum is a
+    sequential running sum, so this rounds like the reference's loop)."""
+    if len(x) == 0:
+        return 0.0
+    if mass is None:
+        return float(np.cumsum(np.full(len(x), M0, dtype=np.float64))[-1])
+    return float(np.cumsum(M0 + np.asarray(mass, dtype=np.float32).astype(np.float64))[-1])
+
+
+def compute_force(pm, x, mass=None, M0=1.0, kernel=KERNELS["1_4"], softening=0, potential=False,
+                  keep=False):
+    """fastpm_solver_compute_force (gravity.c:458-529) on ONE rank (no ghosts: pmghosts.c:67
+    `rank == ThisTask` always).  Returns dict(acc float32 [np][3], delta_k, ...)."""
+    assert pm.nproc == (1, 1)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    res = {}
+    canvas = pm.alloc()                                     # gravity.c:468 (pm_alloc zeroes)
+    pm.paint(canvas, x, mass, M0)                           # gravity.c:336
+    mean_mass_per_cell = total_mass(x, mass, M0) / pm.Norm  # gravity.c:342
+    pm.scale(canvas, 1.0 / mean_mass_per_cell)              # gravity.c:345
+    if keep:
+        res["canvas_painted"] = canvas.copy()
+    delta_k = pm.r2c(canvas)                                # gravity.c:351
+    pm.softening(delta_k, softening)                        # gravity.c:476
+    res["delta_k"] = delta_k
+    acc = np.zeros((len(x), 3), dtype=np.float32)
+    acc64 = np.zeros((len(x), 3), dtype=np.float64)
+    for d in range(3):                                      # gravity.c:373-397
+        pm.kernel_transfer(kernel, delta_k, canvas, memb=d)
+        if keep:
+            res["transfer_%d" % d] = canvas.copy()
+        pm.c2r(canvas)
+        if keep:
+            res["force_mesh_%d" % d] = canvas.copy()
+        pm.readout(canvas, x, out=acc, nmemb=3, memb=d, out_f64=acc64)
+    res["acc"], res["acc_f64"] = acc, acc64
+    if potential:
+        pot = np.zeros((len(x), 1), dtype=np.float32)
+        pm.kernel_transfer(kernel, delta_k, canvas, potential=True)
+        pm.c2r(canvas)
+        pm.readout(canvas, x, out=pot, nmemb=1, memb=0)
+        res["potential"] = pot[:, 0]
+    return res
+
+
+def ghost_pairs(N, BoxSize, nproc, rank, x):
+    """pmghosts.c:31-80: (ipar, target rank) pairs in the reference's probe order."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    ex = np.array(block_edges(N, nproc[0]), dtype=np.int64)
+    ey = np.array(block_edges(N, nproc[1]), dtype=np.int64)
+    args = (ctypes.c_int64(N), ctypes.c_double(BoxSize), _p(ex), int(nproc[0]), _p(ey), int(nproc[1]),
+            int(rank), _p(x), ctypes.c_int64(len(x)))
+    n = lib().orc_ghost_pairs(*args, None, None)
+    ipar = np.empty(n, dtype=np.int32)
+    tgt = np.empty(n, dtype=np.int32)
+    lib().orc_ghost_pairs(*args, _p(ipar), _p(tgt))
+    return ipar, tgt
+
+
+def store_wrap(x, BoxSize):
+    x = np.ascontiguousarray(x, dtype=np.float64).copy()
+    lib().orc_store_wrap(_p(x), ctypes.c_int64(len(x)), ctypes.c_double(BoxSize))
+    return x

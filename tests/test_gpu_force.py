@@ -1,0 +1,147 @@
+"""Parity of the whole force step (fastpm_solver_compute_force, gravity.c:458-529) on the GPU
+against the CPU oracle, through the C ABI.
+
+Tolerances (stated, per BASELINE.json north_star "a stated fp64 tolerance"):
+  fp64 mesh: max |acc_gpu - acc_oracle| / rms(acc_oracle) <= 1e-6   (acc is a float column:
+             one float ulp is 6e-8 relative; FFT round-off and paint add order are ~1e-15)
+  fp32 mesh: <= 2e-5 (mesh values carry float round-off, reordered atomic adds)
+  delta_k  : <= 1e-12 (fp64) / 1e-5 (fp32) relative to rms
+"""
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+TOL_ACC = {64: 1e-6, 32: 2e-5}
+TOL_DK = {64: 1e-12, 32: 1e-5}
+
+
+def _run(oracle, N, nc, L, precision, x, mass=None, M0=1.0, kernel="1_4", softening="none", potential=False):
+    import torch
+    from fastpm_amd import PM, Store, fastpm_solver_compute_force
+    pmo = oracle.PMOracle(N, L, precision)
+    ref = oracle.compute_force(pmo, x, mass=mass, M0=M0, kernel=oracle.KERNELS[kernel],
+                               softening=oracle.SOFTENINGS[softening], potential=potential)
+    pm = PM(N, L, precision)
+    st = Store(x, mass=mass, M0=M0, potential=potential)
+    dk = pm.alloc()
+    fastpm_solver_compute_force(pm, st, dealias=softening, kernel=kernel, delta_k=dk)
+    torch.cuda.synchronize()
+    acc = st.acc.cpu().numpy()
+    dkg = pm.complex_view(dk).cpu().numpy()
+    dko = util.oracle_k_to_xyk(pmo, ref["delta_k"])
+    out = {"acc": acc, "ref": ref, "dk_err": util.rel_err(dkg.view(pmo.F), np.ascontiguousarray(dko).view(pmo.F)),
+           "acc_err": util.rel_err(acc, ref["acc"])}
+    if potential:
+        out["pot_err"] = util.rel_err(st.potential.cpu().numpy(), ref["potential"])
+    pm.destroy()
+    return out
+
+
+@pytest.mark.parametrize("precision", [64, 32])
+@pytest.mark.parametrize("load", ["a", "b", "c"])
+def test_force_parity(oracle, precision, load):
+    N, nc, L = 64, 32, 96.0
+    x = {"a": lambda: util.load_a(nc, L, N), "b": lambda: util.load_b(nc, L, N), "c": lambda: util.load_c(nc, L)}[load]()
+    r = _run(oracle, N, nc, L, precision, x)
+    assert r["dk_err"] <= TOL_DK[precision], r["dk_err"]
+    assert r["acc_err"] <= TOL_ACC[precision], r["acc_err"]
+
+
+@pytest.mark.parametrize("kernel", ["3_4", "3_2", "5_4", "1_4", "1_4_diff0", "gadget", "eastwood", "naive"])
+def test_every_kernel_type(oracle, kernel):
+    N, nc, L = 32, 16, 48.0
+    r = _run(oracle, N, nc, L, 64, util.load_a(nc, L, N), kernel=kernel)
+    assert r["acc_err"] <= TOL_ACC[64], (kernel, r["acc_err"])
+
+
+@pytest.mark.parametrize("softening", ["none", "gaussian", "gadget_long_range", "two_third", "gaussian36"])
+def test_every_softening_type(oracle, softening):
+    N, nc, L = 32, 16, 48.0
+    r = _run(oracle, N, nc, L, 64, util.load_a(nc, L, N), softening=softening)
+    assert r["dk_err"] <= 1e-11, (softening, r["dk_err"])
+    assert r["acc_err"] <= TOL_ACC[64], (softening, r["acc_err"])
+
+
+def test_mass_column_and_potential(oracle):
+    N, nc, L = 32, 16, 48.0
+    x = util.load_b(nc, L, N)
+    rng = np.random.default_rng(3)
+    mass = rng.uniform(0.0, 2.0, len(x)).astype(np.float32)
+    r = _run(oracle, N, nc, L, 64, x, mass=mass, M0=0.75, potential=True)
+    assert r["acc_err"] <= TOL_ACC[64]
+    assert r["pot_err"] <= TOL_ACC[64]
+
+
+def test_edge_positions(oracle):
+    """x == 0, x == BoxSize exactly (store.c:446-475 allows it), cell faces, one particle per tile face."""
+    N, L = 32, 48.0
+    h = L / N
+    x = np.array([[0.0, 0.0, 0.0], [L, L, L], [L, 0.0, h * 7], [h * 8, h * 8, h * 32 - 1e-9],
+                  [h * 7.999999, h * 15.5, h * 31.999999], [L - 1e-12, L / 2, L / 3],
+                  [h * 31.5, h * 31.5, h * 31.5], [0.5 * h, 0.5 * h, 0.5 * h]])
+    r = _run(oracle, N, 2, L, 64, x)
+    assert r["acc_err"] <= TOL_ACC[64], r["acc_err"]
+
+
+def test_single_particle_and_empty(oracle):
+    import torch
+    from fastpm_amd import PM, Store
+    N, L = 16, 48.0
+    r = _run(oracle, N, 1, L, 64, np.array([[10.3, 20.1, 47.9]]))
+    # one particle: the force on itself must vanish to round-off in both implementations
+    assert np.abs(r["acc"]).max() <= 1e-5 and np.abs(r["ref"]["acc"]).max() <= 1e-5
+    # empty store: nothing to do, nothing crashes (total mass 0 -> inf scale, mesh stays finite zeros * inf = nan
+    # in the reference too; only check that the call with np == 0 and explicit mass returns)
+    pm = PM(N, L, 64)
+    st = Store(np.zeros((0, 3)))
+    pm.compute_force(st, total_mass=1.0)
+    torch.cuda.synchronize()
+    pm.destroy()
+
+
+def test_atomic_paint_mode_agrees(oracle):
+    """The naive global-atomics painter (kept for A/B evidence) gives the same answer."""
+    import torch
+    from fastpm_amd import PM, Store
+    from fastpm_amd.pm import PAINT_ATOMIC
+    N, nc, L = 64, 32, 96.0
+    x = util.load_b(nc, L, N)
+    accs = []
+    for mode in (0, PAINT_ATOMIC):
+        pm = PM(N, L, 64, paint_mode=mode)
+        st = Store(x)
+        pm.compute_force(st)
+        torch.cuda.synchronize()
+        accs.append(st.acc.cpu().numpy())
+        pm.destroy()
+    assert util.rel_err(accs[0], accs[1]) <= 1e-6
+
+
+def test_force_host_entry_and_reference_layout(oracle):
+    """fpmhip_force_host: host columns in/out and delta_k in the reference's [y][kz][x] layout."""
+    from fastpm_amd import PM
+    N, nc, L = 32, 16, 48.0
+    x = util.load_a(nc, L, N)
+    pmo = oracle.PMOracle(N, L, 64)
+    ref = oracle.compute_force(pmo, x)
+    pm = PM(N, L, 64)
+    acc, pot, dk = pm.compute_force_host(x, want_delta_k=True)
+    assert util.rel_err(acc, ref["acc"]) <= TOL_ACC[64]
+    dko = pmo.complex_view(ref["delta_k"])
+    assert dk.shape == dko.shape
+    assert util.rel_err(dk.view(np.float64), np.ascontiguousarray(dko).view(np.float64)) <= TOL_DK[64]
+    pm.destroy()
+
+
+def test_wrong_enums_raise():
+    from fastpm_amd import PM, Store, FastPMHipError
+    pm = PM(16, 48.0, 64)
+    st = Store(np.array([[1.0, 2.0, 3.0]]))
+    with pytest.raises(FastPMHipError, match="Wrong kernel type"):
+        pm.compute_force(st, kernel=17)
+    with pytest.raises(FastPMHipError, match="wrong softening"):
+        pm.compute_force(st, softening=9)
+    pm.destroy()
