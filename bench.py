@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-updates/sec of the PM force step (fastpm_solver_compute_force) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1: this process)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+A "step" is one force call (reference libfastpm/gravity.c:458-529: paint -> r2c -> transfer ->
+3 x (c2r -> readout)) over one synthetic particle load already resident in HBM.
+  N = 1 : BASELINE.json configs[1]: 256^3 particles, B = 2 (512^3 mesh), fp64, one MI355X.
+  N > 1 : weak scaling, ~256^3 particles per GPU, B = 2, slab-decomposed mesh, RCCL all-to-all:
+          N = 2 -> 320^3 / 640^3, N = 4 -> 400^3 / 800^3, N = 8 -> 512^3 / 1024^3 (configs[2]).
+Prints ONE JSON line (rank 0).  value = particles of all ranks / max-over-ranks step time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+WORKLOADS = {1: (256, 512), 2: (320, 640), 4: (400, 800), 8: (512, 1024)}
+
+
+def make_particles(nc, Nmesh, BoxSize, nranks, rank, device, seed=1234, sigma_cells=0.3):
+    """Load A: lattice q = (i + 0.5) L / nc plus Gaussian displacement sigma = 0.3 cell,
+    generated on the device, only the lattice planes of this rank's x slab.  The displacement is
+    clamped to +-0.95 cell so that every particle stays in its slab (no decomposition needed:
+    lattice points sit mid-way in 2-cell blocks and slab edges are at even cells)."""
+    assert nc % nranks == 0 and (Nmesh // nranks) % 2 == 0
+    h = BoxSize / Nmesh
+    npl = nc // nranks
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed + rank)
+    ix = torch.arange(rank * npl, (rank + 1) * npl, device=device, dtype=torch.float64)
+    g = torch.arange(nc, device=device, dtype=torch.float64)
+    q = torch.stack(torch.meshgrid((ix + 0.5) * (BoxSize / nc), (g + 0.5) * (BoxSize / nc),
+                                   (g + 0.5) * (BoxSize / nc), indexing="ij"), dim=-1).reshape(-1, 3)
+    d = torch.randn(q.shape, generator=gen, device=device, dtype=torch.float64) * (sigma_cells * h)
+    d.clamp_(-0.95 * h, 0.95 * h)
+    x = torch.remainder(q + d, BoxSize)
+    return x.contiguous()
+
+
+def algorithmic_bytes(np_local, Nmesh, nranks, esize):
+    """SURVEY 8(d) per-kernel algorithmic bytes for ONE launch of each stage on one rank."""
+    nr = Nmesh * Nmesh * (Nmesh + 2) // nranks          # padded reals of the local mesh
+    s = esize
+    return {
+        "sort": 24 * np_local + 28 * np_local,           # read x, write binned x + index (our addition)
+        "paint": 24 * np_local + s * nr,                 # K2
+        "r2c": 2 * s * nr,                               # K5 (FFT at its floor: read once, write once)
+        "transfer": 2 * s * nr,                          # K7
+        "c2r": 2 * s * nr,                               # K8
+        "readout": 3 * s * nr + 36 * np_local,           # K9 fused over the 3 components
+    }
+
+
+def cpu_baseline(nthreads):
+    """The CPU oracle (kind "port": our C/OpenMP restatement of the reference's algorithm +
+    scipy pocketfft) timed on a bounded sample of the N = 1 workload: the same load at 1/8 scale
+    (128^3 particles on a 256^3 fp64 mesh, B = 2 as in configs[1]), one force call."""
+    from oracle import pm_oracle
+    nc, N = 128, 256
+    L = 3.0 * nc
+    rng = np.random.Generator(np.random.PCG64(1234))
+    g = (np.arange(nc) + 0.5) * L / nc
+    q = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
+    x = np.remainder(q + rng.normal(0.0, 0.3 * L / N, q.shape), L)
+    pmo = pm_oracle.PMOracle(N, L, 64, threads=nthreads)
+    t0 = time.perf_counter()
+    pm_oracle.compute_force(pmo, x)
+    dt = time.perf_counter() - t0
+    return {"value": len(x) / dt, "unit": "particle-updates/s", "cores": nthreads, "kind": "port",
+            "sample": "1 force call, 128^3 particles on 256^3 fp64 mesh (configs[1] at 1/8 scale), "
+                      "oracle/pm_oracle.c OpenMP + scipy.fft, %.2f s" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--precision", type=int, default=64)
+    ap.add_argument("--nc", type=int, default=0, help="override particles per side")
+    ap.add_argument("--nmesh", type=int, default=0, help="override mesh per side")
+    ap.add_argument("--paint-mode", type=int, default=0, help="0 tiled (default), 1 global atomics")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from fastpm_amd import PM, Store
+
+    nc, Nmesh = WORKLOADS.get(world, (None, None))
+    if args.nc:
+        nc = args.nc
+    if args.nmesh:
+        Nmesh = args.nmesh
+    if nc is None:
+        raise SystemExit("no default workload for %d GPUs; pass --nc/--nmesh" % world)
+    BoxSize = 3.0 * nc                                  # tests/standard.lua:5-6: 384 / 128
+    esize = args.precision // 8
+
+    x = make_particles(nc, Nmesh, BoxSize, world, rank, device)
+    np_local = x.shape[0]
+    np_total = nc ** 3
+    pm = PM(Nmesh, BoxSize, precision=args.precision, nranks=world, rank=rank, np_max=np_local,
+            paint_mode=args.paint_mode)
+    store = Store(x, device=device)
+    delta_k = pm.alloc()
+    if world > 1:
+        from fastpm_amd.distributed import SlabForce
+        force = SlabForce(pm, dist.group.WORLD)
+        step = lambda: force.compute_force(store, kernel="1_4", dealias="none", delta_k=delta_k)
+    else:
+        step = lambda: pm.compute_force(store, kernel="1_4", softening="none", delta_k=delta_k,
+                                        total_mass=float(np_total))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    pm.timing_enable(True)
+    pm.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tm = pm.timings()
+    pm.timing_enable(False)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    acc_ok = bool(torch.isfinite(store.acc).all().item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = np_total * args.steps / dt
+        ab = algorithmic_bytes(np_local, Nmesh, world, esize)
+        stages = {}
+        for name, (ms, n) in tm.items():
+            if n == 0:
+                continue
+            avg_ms = ms / n
+            e = {"launches_per_step": n / args.steps, "avg_ms": round(avg_ms, 4)}
+            if name in ab:
+                e["alg_GBs"] = round(ab[name] / (avg_ms * 1e-3) / 1e9, 1)
+            stages[name] = e
+        # the dominant kernel = the stage with the largest total time among those with a roofline
+        dom = max((n for n in stages if n in ab), key=lambda n: tm[n][0])
+        avg_s = tm[dom][0] / tm[dom][1] * 1e-3
+        achieved = ab[dom] / avg_s / 1e9
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "alg_bytes_per_launch": ab[dom], "avg_launch_ms": round(avg_s * 1e3, 4)}
+        b_alg = 60 * np_local + 12 * esize * (Nmesh * Nmesh * (Nmesh + 2) // world)
+        out = {
+            "metric": "particle-updates/sec (PM force step)", "value": value, "unit": "particle-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
+            "config": {"workload": "%d^3 particles, B=2 (%d^3 mesh), fp%d, %dxMI355X%s" % (
+                nc, Nmesh, args.precision, world, "" if world > 1 else " single-GPU rocFFT path (configs[1])"),
+                "particles": np_total, "nmesh": Nmesh, "load": "A: lattice + 0.3-cell Gaussian jitter",
+                "kernel": "1_4", "softening": "none", "decomposition": "slab %dx1" % world,
+                "paint_mode": "tiled" if args.paint_mode == 0 else "atomic"},
+            "per_gpu": value / world, "finite": acc_ok,
+            "step_alg_GBs": round(b_alg / (ms_per_step * 1e-3) / 1e9, 1),
+            "roofline": roofline, "stages": stages,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            except Exception as e:      # the baseline is a report, never the product
+                out["cpu_baseline"] = {"value": None, "unit": "particle-updates/s", "cores": 0,
+                                       "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,7 +5,9 @@ Tolerances (stated, per BASELINE.json north_star "a stated fp64 tolerance"):
   fp64 mesh: max |acc_gpu - acc_oracle| / rms(acc_oracle) <= 1e-6   (acc is a float column:
              one float ulp is 6e-8 relative; FFT round-off and paint add order are ~1e-15)
   fp32 mesh: <= 2e-5 (mesh values carry float round-off, reordered atomic adds)
-  delta_k  : <= 1e-12 (fp64) / 1e-5 (fp32) relative to rms
+  delta_k  : max |dk_gpu - dk_oracle| / max |dk_oracle| <= 1e-14 (fp64) / 5e-7 (fp32): the DC mode
+             is 1.0, so this is an absolute bound of a few mesh-dtype ulps on every mode (measured:
+             1e-16 and 6e-8; the fp32 oracle itself is 6e-8 away from the fp64 one)
 """
 import numpy as np
 import pytest
@@ -15,7 +17,7 @@ import util
 pytestmark = pytest.mark.gpu
 
 TOL_ACC = {64: 1e-6, 32: 2e-5}
-TOL_DK = {64: 1e-12, 32: 1e-5}
+TOL_DK = {64: 1e-14, 32: 5e-7}
 
 
 def _run(oracle, N, nc, L, precision, x, mass=None, M0=1.0, kernel="1_4", softening="none", potential=False):
@@ -32,7 +34,7 @@ def _run(oracle, N, nc, L, precision, x, mass=None, M0=1.0, kernel="1_4", soften
     acc = st.acc.cpu().numpy()
     dkg = pm.complex_view(dk).cpu().numpy()
     dko = util.oracle_k_to_xyk(pmo, ref["delta_k"])
-    out = {"acc": acc, "ref": ref, "dk_err": util.rel_err(dkg.view(pmo.F), np.ascontiguousarray(dko).view(pmo.F)),
+    out = {"acc": acc, "ref": ref, "dk_err": util.max_err(dkg, dko),
            "acc_err": util.rel_err(acc, ref["acc"])}
     if potential:
         out["pot_err"] = util.rel_err(st.potential.cpu().numpy(), ref["potential"])
@@ -61,7 +63,7 @@ def test_every_kernel_type(oracle, kernel):
 def test_every_softening_type(oracle, softening):
     N, nc, L = 32, 16, 48.0
     r = _run(oracle, N, nc, L, 64, util.load_a(nc, L, N), softening=softening)
-    assert r["dk_err"] <= 1e-11, (softening, r["dk_err"])
+    assert r["dk_err"] <= TOL_DK[64], (softening, r["dk_err"])
     assert r["acc_err"] <= TOL_ACC[64], (softening, r["acc_err"])
 
 
@@ -132,7 +134,7 @@ def test_force_host_entry_and_reference_layout(oracle):
     assert util.rel_err(acc, ref["acc"]) <= TOL_ACC[64]
     dko = pmo.complex_view(ref["delta_k"])
     assert dk.shape == dko.shape
-    assert util.rel_err(dk.view(np.float64), np.ascontiguousarray(dko).view(np.float64)) <= TOL_DK[64]
+    assert util.max_err(dk, dko) <= TOL_DK[64]
     pm.destroy()
 
 

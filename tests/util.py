@@ -62,3 +62,11 @@ def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     s = np.sqrt((b ** 2).mean())
     return np.abs(a - b).max() / (s if s > 0 else 1.0)
+
+
+def max_err(a, b):
+    """max |a-b| / max |b|"""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    s = np.abs(b).max()
+    return np.abs(a - b).max() / (s if s > 0 else 1.0)
