@@ -1,0 +1,167 @@
+"""Slab-decomposed force step across the GPUs of one node: one process per GPU, RCCL over xGMI.
+
+What the reference does with MPI and what replaces it here:
+
+  reference (libfastpm)                                   here
+  ------------------------------------------------------  -----------------------------------------
+  MPI_Allreduce(total_mass)          gravity.c:341        all_reduce of one double
+  particle ghosts out / forces back  pmghosts.c:112-307   mesh halo: one x plane to rank+1 after the
+    (Alltoallv_sparse x4)            gravity.c:283-286,     paint (added), one plane of each force
+                                     :420                   mesh from rank+1 before the readout
+  PFFT global transposes inside      pmpfft.c:377-396     one all_to_all_single per 3-D transform
+    pfft_execute_dft_r2c / c2r                              (slabs: Nproc = {P, 1})
+
+The mesh halo gives the same sums as particle ghosts in a different order: every
+(particle, corner) pair is added exactly once, on the rank that owns the particle, and the one
+foreign plane it can touch travels as N*(N+2) mesh values instead of per-particle records.
+
+The per-rank work is the C-ABI stage calls of fastpm_amd.pm.PM; this module only sequences them
+around the exchanges.  `SlabForce.steps` is a generator that yields each communication request, so
+the same code runs (a) over torch.distributed (backend nccl = RCCL on the GPUs, gloo in the CPU
+tests) and (b) over `run_virtual`, which plays all ranks of a decomposition on ONE GPU.
+"""
+import torch
+import torch.distributed as dist
+
+from .pm import FIELD_POTENTIAL, KERNEL_TYPES, SOFTENING_TYPES, _enum
+
+
+class SlabForce:
+    """fastpm_solver_compute_force for rank `pm.rank` of `pm.nranks` x-slabs (gravity.c:458-529)."""
+
+    def __init__(self, pm, group=None):
+        self.pm = pm
+        self.group = group
+        self.P, self.rank = pm.nranks, pm.rank
+        self.canvas = pm.alloc()
+        self.work = pm.alloc()
+        self.force = [self.canvas, pm.alloc(), pm.alloc()]    # canvas is free after the forward FFT
+        self.delta_k = None
+        self.tmp_plane = torch.zeros(int(pm.layout.plane_elems), dtype=self.canvas.dtype, device=self.canvas.device)
+        self.scalar = torch.zeros(1, dtype=torch.float64, device=self.canvas.device)
+
+    # -- the step, as a generator of communication requests ------------------------------------
+    def steps(self, store, kernel="1_4", dealias="none", delta_k=None):
+        pm = self.pm
+        kernel = _enum(KERNEL_TYPES, kernel)
+        dealias = _enum(SOFTENING_TYPES, dealias)
+        xl = pm.layout.isize[0]
+        if delta_k is None:
+            if self.delta_k is None:
+                self.delta_k = pm.alloc()
+            delta_k = self.delta_k
+
+        # gravity.c:330-342: total mass over all ranks -> mean mass per cell
+        self.scalar[0] = pm.total_mass(store)
+        yield ("allreduce", self.scalar)
+        total_mass = float(self.scalar.item())
+        mean_mass_per_cell = total_mass / pm.Norm
+
+        # gravity.c:336-345: paint + normalise; the halo plane goes to the next slab
+        pm.paint(self.canvas, store, 1.0 / mean_mass_per_cell)
+        yield ("shift", [(pm.plane(self.canvas, xl), self.tmp_plane, +1)])
+        pm.plane_add(pm.plane(self.canvas, 0), self.tmp_plane)
+
+        # gravity.c:351 pm_r2c: 2-D (y,z) transforms, transpose, 1-D x transform (x 1/Norm)
+        pm.fft_yz_forward(self.canvas, self.work)
+        yield ("alltoall", delta_k, self.work)
+        pm.fft_x_forward(delta_k)
+        pm.apply_softening_transfer(dealias, delta_k)                     # gravity.c:476
+
+        # gravity.c:373-397: per component transfer -> c2r
+        for d in range(3):
+            yield from self._backward(delta_k, kernel, d, self.force[d])
+        # the plane each boundary particle's cloud reaches into comes from the next slab
+        yield ("shift", [(pm.plane(f, 0), pm.plane(f, xl), -1) for f in self.force])
+        pm.readout3(self.force, store)
+
+        if store.potential is not None:                                   # gravity.c:487-492
+            f = self.force[0]
+            yield from self._backward(delta_k, kernel, FIELD_POTENTIAL, f)
+            yield ("shift", [(pm.plane(f, 0), pm.plane(f, xl), -1)])
+            pm.readout(f, store, store.potential, 1, 0)
+
+    def _backward(self, delta_k, kernel, field, out):
+        pm = self.pm
+        # `out` doubles as the k-space scratch: transfer -> x transform in place -> transpose
+        pm.gravity_apply_kernel_transfer(kernel, delta_k, out, field)
+        pm.fft_x_backward(out)
+        yield ("alltoall", self.work, out)
+        pm.fft_yz_backward(self.work, out)
+
+    # -- execution over torch.distributed -------------------------------------------------------
+    def compute_force(self, store, kernel="1_4", dealias="none", delta_k=None):
+        for req in self.steps(store, kernel, dealias, delta_k):
+            self._communicate(req)
+        return delta_k if delta_k is not None else self.delta_k
+
+    def _communicate(self, req):
+        kind = req[0]
+        g = self.group
+        if kind == "allreduce":
+            dist.all_reduce(req[1], op=dist.ReduceOp.SUM, group=g)
+        elif kind == "alltoall":
+            n = self.pm.exchange_chunk_elems() * self.P
+            dist.all_to_all_single(req[1][:n], req[2][:n], group=g)
+        elif kind == "shift":
+            ops = []
+            for send, recv, direction in req[1]:
+                dst = (self.rank + direction) % self.P
+                src = (self.rank - direction) % self.P
+                ops.append(dist.P2POp(dist.isend, send, _global_rank(g, dst), group=g))
+                ops.append(dist.P2POp(dist.irecv, recv, _global_rank(g, src), group=g))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        else:
+            raise ValueError(kind)
+
+
+def _global_rank(group, r):
+    return r if group is None or group is dist.group.WORLD else dist.get_global_rank(group, r)
+
+
+def slab_compute_force(pm, store, dealias="none", kernel="1_4", delta_k=None, group=None):
+    """One-shot convenience used by fastpm_solver_compute_force when pm.nranks > 1."""
+    cache = getattr(pm, "_slab_force", None)
+    if cache is None:
+        cache = pm._slab_force = SlabForce(pm, group)
+    return cache.compute_force(store, kernel=kernel, dealias=dealias, delta_k=delta_k)
+
+
+def run_virtual(forces, stores, kernel="1_4", dealias="none", delta_ks=None):
+    """Play every rank of a slab decomposition in ONE process (all plans on one GPU): advance each
+    rank's step generator to its next communication request, then perform that request locally.
+    Same stage code, same buffers, same chunking as the distributed run; only the transport differs."""
+    P = len(forces)
+    assert all(f.P == P for f in forces)
+    delta_ks = delta_ks or [None] * P
+    gens = [f.steps(s, kernel, dealias, dk) for f, s, dk in zip(forces, stores, delta_ks)]
+    while True:
+        reqs = []
+        for g in gens:
+            try:
+                reqs.append(next(g))
+            except StopIteration:
+                reqs.append(None)
+        if all(r is None for r in reqs):
+            return
+        assert all(r is not None and r[0] == reqs[0][0] for r in reqs), "ranks out of step"
+        kind = reqs[0][0]
+        if kind == "allreduce":
+            total = sum(r[1].clone() for r in reqs)
+            for r in reqs:
+                r[1].copy_(total)
+        elif kind == "alltoall":
+            chunk = forces[0].pm.exchange_chunk_elems()
+            for dst in range(P):
+                for src in range(P):
+                    reqs[dst][1][src * chunk:(src + 1) * chunk].copy_(reqs[src][2][dst * chunk:(dst + 1) * chunk])
+        elif kind == "shift":
+            nmsg = len(reqs[0][1])
+            for m in range(nmsg):
+                sends = [reqs[r][1][m][0].clone() for r in range(P)]
+                for r in range(P):
+                    direction = reqs[r][1][m][2]
+                    reqs[(r + direction) % P][1][m][1].copy_(sends[r])
+        else:
+            raise ValueError(kind)

@@ -1,0 +1,151 @@
+"""CPU stand-in for the rank-local stage calls of fastpm_amd.pm.PM, for the gloo tests ONLY.
+
+It lets tests/test_dist_gloo.py run fastpm_amd.distributed.SlabForce (the N > 1 orchestration:
+halo shifts, all-to-all transposes, all-reduce) with world_size 2 on CPU and compare against the
+single-rank oracle.  Built from numpy/scipy and the oracle's k-space functions; never imported by
+the product."""
+import ctypes
+
+import numpy as np
+import scipy.fft
+import torch
+
+from oracle import pm_oracle as O
+
+
+class _Layout:
+    pass
+
+
+class CpuSlabOps:
+    def __init__(self, Nmesh, BoxSize, nranks, rank, precision=64):
+        N, P = int(Nmesh), int(nranks)
+        assert N % P == 0
+        self.Nmesh, self.BoxSize, self.nranks, self.rank, self.precision = N, float(BoxSize), P, rank, precision
+        self.xl = self.yl = N // P
+        self.nzc = N // 2 + 1
+        self.F = np.float64 if precision == 64 else np.float32
+        self.C = np.complex128 if precision == 64 else np.complex64
+        self.dtype = torch.float64 if precision == 64 else torch.float32
+        L = self.layout = _Layout()
+        L.isize = [self.xl, N, N]
+        L.ihalo = 1 if P > 1 else 0
+        L.plane_elems = N * (N + 2)
+        L.real_elems = (self.xl + L.ihalo) * L.plane_elems
+        L.complex_elems = N * self.yl * self.nzc
+        self.allocsize = max(L.real_elems, 2 * L.complex_elems)
+        self.Norm = float(N) ** 3
+        # oracle geometry of the [x][y_loc][kz] k-space block
+        g = self.g = O.Geom()
+        g.Nmesh, g.BoxSize = N, BoxSize
+        g.ostart[:] = [0, rank * self.yl, 0]
+        g.osize[:] = [N, self.yl, self.nzc]
+        g.ostrides[:] = [self.yl * self.nzc, self.nzc, 1]
+        g.allocsize = self.allocsize
+        self.suf = "f64" if precision == 64 else "f32"
+
+    # ---- memory
+    def alloc(self):
+        return torch.zeros(self.allocsize, dtype=self.dtype)
+
+    def plane(self, mesh, ix):
+        pe = self.layout.plane_elems
+        return mesh[ix * pe:(ix + 1) * pe]
+
+    def exchange_chunk_elems(self):
+        return 2 * self.xl * self.yl * self.nzc
+
+    def _real(self, buf):
+        nx = self.xl + self.layout.ihalo
+        return buf.numpy()[: nx * self.layout.plane_elems].reshape(nx, self.Nmesh, self.Nmesh + 2)
+
+    def _cplx(self, buf, shape):
+        n = int(np.prod(shape))
+        return buf.numpy()[: 2 * n].view(self.C).reshape(shape)
+
+    # ---- particles (CIC with a halo plane; painter-cic.c arithmetic, vectorised)
+    def _cic(self, store):
+        N = self.Nmesh
+        inv = 1.0 / (self.BoxSize / N)
+        X = store.x.numpy() * inv
+        I = np.floor(X).astype(np.int64)
+        D = X - I
+        T = 1.0 - D
+        I0 = np.mod(I, N)
+        ix0 = I0[:, 0] - self.rank * self.xl
+        assert ((ix0 >= 0) & (ix0 < self.xl)).all(), "particle outside its slab"
+        if self.nranks == 1:
+            ix = [ix0, np.mod(ix0 + 1, N)]
+        else:
+            ix = [ix0, ix0 + 1]
+        iy = [I0[:, 1], np.mod(I0[:, 1] + 1, N)]
+        iz = [I0[:, 2], np.mod(I0[:, 2] + 1, N)]
+        return ix, iy, iz, [T, D]
+
+    def total_mass(self, store):
+        if store.mass is None:
+            return store.np * store.M0
+        return float((store.M0 + store.mass.numpy().astype(np.float64)).sum())
+
+    def paint(self, canvas, store, scale):
+        ix, iy, iz, W = self._cic(store)
+        w = store.M0 if store.mass is None else store.M0 + store.mass.numpy().astype(np.float64)
+        mesh = np.zeros(self._real(canvas).shape, dtype=np.float64)
+        for bx in (0, 1):
+            for by in (0, 1):
+                for bz in (0, 1):
+                    np.add.at(mesh, (ix[bx], iy[by], iz[bz]), W[bz][:, 2] * W[bx][:, 0] * (W[by][:, 1] * w))
+        canvas.zero_()
+        self._real(canvas)[...] = (mesh * scale).astype(self.F)
+
+    def plane_add(self, dst, src):
+        dst += src
+
+    def readout3(self, meshes, store):
+        for d, m in enumerate(meshes):
+            self.readout(m, store, store.acc, 3, d)
+
+    def readout(self, mesh, store, out, nmemb, memb):
+        ix, iy, iz, W = self._cic(store)
+        m = self._real(mesh)
+        value = np.zeros(store.np)
+        for bx in (0, 1):
+            for by in (0, 1):
+                for bz in (0, 1):
+                    value += m[ix[bx], iy[by], iz[bz]] * (W[bz][:, 2] * W[bx][:, 0] * W[by][:, 1])
+        out.numpy().reshape(store.np, nmemb)[:, memb] = value.astype(np.float32)
+
+    # ---- FFT stages
+    def fft_yz_forward(self, canvas, send):
+        N, xl, yl, nzc, P = self.Nmesh, self.xl, self.yl, self.nzc, self.nranks
+        a = scipy.fft.rfft2(self._real(canvas)[:xl, :, :N], axes=(1, 2))
+        s = self._cplx(send, (P, xl, yl, nzc))
+        for r in range(P):
+            s[r] = a[:, r * yl:(r + 1) * yl, :]
+
+    def fft_x_forward(self, recv):
+        v = self._cplx(recv, (self.Nmesh, self.yl, self.nzc))
+        v[...] = scipy.fft.fft(v, axis=0) * (1.0 / self.Norm)
+
+    def fft_x_backward(self, buf):
+        v = self._cplx(buf, (self.Nmesh, self.yl, self.nzc))
+        v[...] = scipy.fft.ifft(v, axis=0, norm="forward")
+
+    def fft_yz_backward(self, recv, canvas):
+        N, xl, yl, nzc, P = self.Nmesh, self.xl, self.yl, self.nzc, self.nranks
+        r_ = self._cplx(recv, (P, xl, yl, nzc)).copy()
+        a = np.concatenate([r_[s] for s in range(P)], axis=1)
+        canvas.zero_()
+        self._real(canvas)[:xl, :, :N] = scipy.fft.irfft2(a, s=(N, N), axes=(1, 2), norm="forward")
+
+    # ---- k space: the oracle's C functions on this rank's [x][y_loc][kz] block
+    def apply_softening_transfer(self, softening, delta_k):
+        a = delta_k.numpy()
+        rc = getattr(O.lib(), "orc_softening_" + self.suf)(ctypes.byref(self.g), int(softening), O._p(a))
+        assert rc == 0
+
+    def gravity_apply_kernel_transfer(self, kernel, delta_k, out, field):
+        rc = getattr(O.lib(), "orc_kernel_transfer_" + self.suf)(
+            ctypes.byref(self.g), int(kernel), O._p(delta_k.numpy()), O._p(out.numpy()),
+            int(field == 3), int(field if field < 3 else 0))
+        assert rc == 0

@@ -1,0 +1,65 @@
+"""The N > 1 orchestration (fastpm_amd.distributed.SlabForce: all-reduce of the mass, halo-plane
+shifts, all-to-all transposes) over torch.distributed with the gloo backend, world_size 2 and 4,
+on CPU.  The rank-local stage calls are served by tests/cpu_slab_ops.py (numpy/scipy + the
+oracle's k-space functions); the result must equal the one-rank oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import util  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, N, L, x, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from cpu_slab_ops import CpuSlabOps
+    from fastpm_amd.distributed import SlabForce
+    from fastpm_amd.pm import Store
+    owner = (np.floor(x[:, 0] * (1.0 / (L / N))).astype(np.int64) % N) // (N // world)
+    idx = np.nonzero(owner == rank)[0]
+    ops = CpuSlabOps(N, L, world, rank)
+    store = Store(x[idx], potential=True, device="cpu")
+    force = SlabForce(ops, dist.group.WORLD)
+    dk = force.compute_force(store, kernel="1_4", dealias="gaussian")
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), idx=idx, acc=store.acc.numpy(),
+             pot=store.potential.numpy(), dk=ops._cplx(dk, (N, ops.yl, ops.nzc)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_slab_force_over_gloo_matches_one_rank_oracle(oracle, tmp_path, world):
+    N, nc, L = 16, 8, 24.0
+    x = util.load_b(nc, L, N, rms_cells=2.0)
+    ref = oracle.compute_force(oracle.PMOracle(N, L, 64), x, softening=oracle.SOFTENINGS["gaussian"], potential=True)
+    mp.spawn(_worker, args=(world, _free_port(), N, L, x, str(tmp_path)), nprocs=world, join=True)
+    acc = np.zeros_like(ref["acc"])
+    pot = np.zeros_like(ref["potential"])
+    dks = []
+    for r in range(world):
+        d = np.load(tmp_path / ("rank%d.npz" % r))
+        acc[d["idx"]] = d["acc"]
+        pot[d["idx"]] = d["pot"]
+        dks.append(d["dk"])
+    dk = np.concatenate(dks, axis=1)
+    dko = util.oracle_k_to_xyk(oracle.PMOracle(N, L, 64), ref["delta_k"])
+    assert util.max_err(dk, dko) <= 1e-13
+    assert util.rel_err(acc, ref["acc"]) <= 1e-6
+    assert util.rel_err(pot, ref["potential"]) <= 1e-6

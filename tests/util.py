@@ -35,7 +35,7 @@ def load_b(nc, BoxSize, Nmesh, seed=5678, rms_cells=4.0):
     dk = (rng.normal(size=k2.shape) + 1j * rng.normal(size=k2.shape)) * amp
     disp = []
     for kk in (kx, ky, kz):
-        disp.append(np.fft.irfftn(1j * kk / k2 * dk, s=(nc, nc, nc)))
+        disp.append(np.fft.irfftn(1j * kk / k2 * dk, s=(nc, nc, nc), axes=(0, 1, 2)))
     d = np.stack(disp, axis=-1).reshape(-1, 3)
     d *= rms_cells * (BoxSize / Nmesh) / np.sqrt((d ** 2).mean())
     return wrap(lattice(nc, BoxSize) + d, BoxSize)
