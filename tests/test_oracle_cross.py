@@ -1,0 +1,113 @@
+"""The C oracle (oracle/pm_oracle.c) against the independent numpy statement
+(oracle/pm_oracle_np.py): bit-exact where the operation order is fixed, a few ulp where only the
+summation order differs."""
+import numpy as np
+import pytest
+
+import util
+
+
+@pytest.fixture(scope="module")
+def onp():
+    from oracle import pm_oracle_np
+    return pm_oracle_np
+
+
+@pytest.mark.parametrize("N,L", [(8, 8.0), (16, 50.0), (24, 71.3), (64, 192.0)])
+def test_k_tables_bit_exact(oracle, onp, N, L):
+    a, b = oracle.k_tables(N, L), onp.k_tables(N, L)
+    for name in a:
+        assert np.array_equal(a[name], b[name]), name
+
+
+@pytest.mark.parametrize("precision", [64, 32])
+def test_paint_and_readout(oracle, onp, precision):
+    N, nc, L = 16, 8, 48.0
+    x = util.load_b(nc, L, N, rms_cells=2.0)
+    rng = np.random.default_rng(2)
+    mass = rng.uniform(0, 1, len(x)).astype(np.float32)
+    pm = oracle.PMOracle(N, L, precision)
+    cv = pm.alloc()
+    pm.paint(cv, x, mass=mass, M0=0.5)
+    m_c = pm.real_view(cv)[:, :, :N]
+    m_np = onp.paint(x, N, L, mass=mass, M0=0.5, dtype=pm.F)
+    assert util.max_err(m_c, m_np) <= (1e-14 if precision == 64 else 1e-6)     # add order differs
+    out = np.zeros((len(x), 1))
+    pm.readout(cv, x, out_f64=out)
+    assert np.array_equal(out[:, 0], onp.readout(m_c, x, L))                    # same order: bit exact
+
+
+@pytest.mark.parametrize("precision", [64, 32])
+@pytest.mark.parametrize("kernel", ["3_4", "3_2", "5_4", "1_4", "naive"])
+def test_kernel_transfer_bit_exact(oracle, onp, precision, kernel):
+    N, L = 16, 37.0
+    pm = oracle.PMOracle(N, L, precision)
+    rng = np.random.default_rng(11)
+    dk = pm.alloc()
+    dk[:] = rng.normal(size=dk.shape).astype(pm.F)
+    c = util.oracle_k_to_xyk(pm, dk).copy()
+    po, go, _, _ = oracle.kernel_orders(oracle.KERNELS[kernel])
+    out = pm.alloc()
+    for d in (0, 1, 2, None):
+        pm.kernel_transfer(oracle.KERNELS[kernel], dk, out, memb=d or 0, potential=d is None)
+        got = util.oracle_k_to_xyk(pm, out)
+        exp = onp.kernel_transfer(c, L, po, go, d, F=pm.F)
+        assert np.array_equal(got, exp), (kernel, d)
+
+
+def test_decic_and_powerspectrum(oracle, onp):
+    N, L = 16, 37.0
+    pm = oracle.PMOracle(N, L, 64)
+    rng = np.random.default_rng(12)
+    dk = pm.alloc()
+    dk[:] = rng.normal(size=dk.shape)
+    c = util.oracle_k_to_xyk(pm, dk).copy()
+    out = pm.alloc()
+    pm.decic(dk, out)
+    assert np.array_equal(util.oracle_k_to_xyk(pm, out), onp.decic(c, L))
+    k1, p1, n1 = oracle.powerspectrum_finalize(*pm.powerspectrum_sums(dk), L)
+    k2, p2, n2 = onp.powerspectrum(c, L)
+    assert np.array_equal(n1, n2)
+    assert np.allclose(p1, p2, rtol=1e-13) and np.allclose(k1, k2, rtol=1e-13)
+
+
+def test_multirank_geometry_consistency(oracle):
+    """make_geom (pmpfft.c:117-210): the local boxes of an Nx x Ny process mesh tile the global boxes."""
+    N, L = 16, 16.0
+    for ntask in (1, 2, 4, 8):
+        nproc = oracle.auto_nproc(ntask)
+        assert nproc == {1: (1, 1), 2: (1, 2), 4: (2, 2), 8: (4, 2)}[ntask]
+        real = np.zeros((N, N), dtype=int)
+        cplx = np.zeros((N, N // 2 + 1), dtype=int)
+        for r in range(ntask):
+            g = oracle.make_geom(N, L, nproc, r)
+            real[g.istart[0]:g.istart[0] + g.isize[0], g.istart[1]:g.istart[1] + g.isize[1]] += 1
+            cplx[g.ostart[1]:g.ostart[1] + g.osize[1], g.ostart[2]:g.ostart[2] + g.osize[2]] += 1
+            assert g.ostrides[0] == 1 and g.ostrides[2] == N                       # [y][z][x]
+        assert np.all(real == 1) and np.all(cplx == 1)
+
+
+def test_multirank_paint_with_ghosts_equals_one_rank(oracle):
+    """The reference's own decomposition logic restated: region-clipped paint of local + ghost
+    particles on a 2 x 2 process mesh sums to the one-rank mesh (painter-cic.c:83-108 clipping +
+    pmghosts.c ghosts)."""
+    N, nc, L, nproc = 16, 8, 48.0, (2, 2)
+    x = util.load_b(nc, L, N, rms_cells=2.0)
+    one = oracle.PMOracle(N, L, 64)
+    cv1 = one.alloc()
+    one.paint(cv1, x)
+    full = np.zeros((N, N, N))
+    h = L / N
+    cx, cy = np.floor(x[:, 0] / h).astype(int) % N, np.floor(x[:, 1] / h).astype(int) % N
+    owner = (cx // (N // 2)) * 2 + cy // (N // 2)
+    pms = [oracle.PMOracle(N, L, 64, nproc, r) for r in range(4)]
+    sends = [oracle.ghost_pairs(N, L, nproc, r, x[owner == r]) for r in range(4)]
+    for r, pm in enumerate(pms):
+        cv = pm.alloc()
+        pm.paint(cv, x[owner == r])
+        for s in range(4):
+            ipar, tgt = sends[s]
+            pm.paint(cv, x[owner == s][ipar[tgt == r]])
+        g = pm.g
+        full[g.istart[0]:g.istart[0] + g.isize[0], g.istart[1]:g.istart[1] + g.isize[1], :] = pm.real_view(cv)[:, :, :N]
+    assert util.max_err(full, one.real_view(cv1)[:, :, :N]) <= 1e-14
