@@ -1,0 +1,113 @@
+/*
+ * fastpm_gravity_hip.c -- C99 host side of the MI355X force step: the file that takes the place of
+ * libfastpm/gravity.c.  No arithmetic happens here: it checks what the reference checks, marshals
+ * the store columns into the C-ABI call and maps errors to the reference's raise-and-abort.
+ */
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "fastpm_gravity_hip.h"
+
+static void default_handler(int code, const char *message, void *userdata)
+{
+    (void) userdata;
+    fprintf(stderr, "fastpm_hip raise(%d): %s\n", code, message);
+    if (code != 0) abort();                                   /* logging.c:100-103 */
+}
+
+static fpm_msg_handler g_handler = default_handler;
+static void *g_userdata = NULL;
+
+void fpm_set_msg_handler(fpm_msg_handler handler, void *userdata)
+{
+    g_handler = handler ? handler : default_handler;
+    g_userdata = userdata;
+}
+
+static void fpm_raise(int code, const char *fmt, ...)        /* logging.c:242-251 */
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_handler(code, buf, g_userdata);
+}
+
+#define HIP_OR_RAISE(expr) do { if ((expr) != 0) fpm_raise(-1, "%s\n", fpmhip_last_error()); } while (0)
+
+PMView *fastpm_create_pm_hip(int Ngrid, double BoxSize, int precision)
+{
+    PMView *pm = calloc(1, sizeof(*pm));
+    fpmhip_geom g;
+    memset(&g, 0, sizeof(g));
+    g.Nmesh = Ngrid;
+    g.BoxSize = BoxSize;
+    g.precision = precision;
+    g.nranks = 1;
+    g.rank = 0;
+    g.device = -1;
+    if (fpmhip_plan_create(&g, NULL, &pm->plan) != 0) {
+        fpm_raise(-1, "%s\n", fpmhip_last_error());            /* e.g. pmpfft.c:143-145 odd Nmesh */
+        free(pm);
+        return NULL;
+    }
+    fpmhip_layout lay;
+    fpmhip_plan_layout(pm->plan, &lay);
+    for (int d = 0; d < 3; d++) {
+        pm->Nmesh[d] = Ngrid;
+        pm->BoxSize[d] = BoxSize;
+    }
+    pm->NTask = 1;
+    pm->ThisTask = 0;
+    pm->Nproc[0] = pm->Nproc[1] = 1;
+    pm->allocsize = lay.allocsize;
+    pm->Norm = lay.Norm;
+    return pm;
+}
+
+void fastpm_free_pm_hip(PMView *pm)
+{
+    if (!pm) return;
+    fpmhip_plan_destroy(pm->plan);
+    free(pm);
+}
+
+void fastpm_kernel_type_get_orders_hip(FastPMKernelType type, int *potorder, int *gradorder,
+                                       int *difforder, int *deconvolveorder)
+{
+    if (fpmhip_kernel_type_get_orders((int) type, potorder, gradorder, difforder, deconvolveorder) != 0)
+        fpm_raise(-1, "Wrong kernel type\n");                  /* gravity.c:169 */
+}
+
+void fastpm_solver_compute_force_hip(FastPMSolverView *fastpm, PMView *pm, FastPMPainterView *painter,
+                                     FastPMSofteningType dealias, FastPMKernelType kernel,
+                                     void *delta_k, double Time)
+{
+    (void) Time;                                               /* only the LRA-neutrino branch reads it */
+    if (painter && painter->type != FASTPM_PAINTER_CIC) {
+        fpm_raise(-1, "the MI355X force step implements the CIC painter (the default, painter.c:137-142)\n");
+        return;
+    }
+    int nspecies = 0;
+    FastPMStoreView *p = NULL;
+    for (int si = 0; si < FASTPM_SOLVER_NSPECIES; si++) {      /* gravity.c:279-287 species loop */
+        if (!fastpm->has_species[si] || !fastpm->species[si]) continue;
+        p = fastpm->species[si];
+        nspecies++;
+    }
+    if (nspecies != 1) {
+        fpm_raise(-1, "the MI355X force step handles one particle species per call (got %d)\n", nspecies);
+        return;
+    }
+    fpmhip_particles part;
+    part.x = &p->x[0][0];
+    part.mass = p->mass;
+    part.M0 = p->meta.M0;
+    part.np = (int64_t) p->np;
+    part.acc = &p->acc[0][0];
+    part.potential = p->potential;                             /* gravity.c:487-492: nacc = 3 or 4 */
+    HIP_OR_RAISE(fpmhip_force_host(pm->plan, &part, (int) kernel, (int) dealias, delta_k));
+}
