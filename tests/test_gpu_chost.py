@@ -18,7 +18,7 @@ class StoreView(ctypes.Structure):
 
 
 class SolverView(ctypes.Structure):
-    _fields_ = [("species", ctypes.POINTER(StoreView) * 6), ("has_species", ctypes.c_char * 6)]
+    _fields_ = [("species", ctypes.POINTER(StoreView) * 6), ("has_species", ctypes.c_ubyte * 6)]
 
 
 class PainterView(ctypes.Structure):
@@ -57,7 +57,7 @@ def test_c_host_force_matches_oracle(oracle):
     st = StoreView(len(x), x.ctypes.data, acc.ctypes.data, pot.ctypes.data, None, 1.0)
     sv = SolverView()
     sv.species[1] = ctypes.pointer(st)                   # FASTPM_SPECIES_CDM
-    sv.has_species = b"\x00\x01\x00\x00\x00\x00"
+    sv.has_species[1] = 1
     pm = H.fastpm_create_pm_hip(N, L, 64)
     assert pm
     dk = np.zeros(pmo.allocsize, dtype=np.float64)
