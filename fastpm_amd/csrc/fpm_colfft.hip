@@ -1,0 +1,403 @@
+// fpm_colfft.hip -- hand-written strided ("column") FFT passes for gfx950.
+//
+// Why: the 3-D transforms are 69 % of the force step and rocFFT's strided passes (`sbcc`) move
+// 2.75x the algorithmic read traffic on the [..][N/2+1] k-space layout (profiles/r01): every
+// (N/2+1)-long row is misaligned to the 128-B line.  These kernels do the x and y passes of the
+// 3-D transform with exactly-once, whole-line HBM traffic, and they let the pointwise work ride
+// along for free:
+//   * backward x pass: the gravity transfer (reference gravity.c:174-242, fused as in
+//     fpm_kspace.hip) for ALL THREE components from one read of delta(k)  -> removes 3 transfer
+//     sweeps and 2 of 3 reads,
+//   * forward x pass: the 1/N^3 of pm_r2c (reference pmpfft.c:381-385),
+//   * y passes of the slab decomposition: the pack / unpack around the all-to-all.
+// The contiguous z pass (r2c / c2r, unit stride) stays on rocFFT, which runs it at ~5 TB/s.
+//
+// Kernel shape: one workgroup transforms COLS = 8 adjacent columns (8 x 16 B = one 128-B line per
+// row) of length N.  Thread (tau, c): column c, T = N/8 threads per column, 8 elements per
+// thread in registers (rows tau + T*j) -> every global access of a wave is 8 full lines.  Mixed
+// radix Cooley-Tukey, first radix 8, stages exchange through LDS laid out [index][column] (column
+// fastest: a wave's 64 lanes touch 1 KiB contiguous, <= 2-way bank conflicts for every stage
+// pattern).  Twiddles W_N^j come from a host-built double table staged in LDS.
+#include "fpm_internal.h"
+
+namespace fpm {
+
+template <typename F> struct C2 { F x, y; };
+
+template <typename F> __device__ __forceinline__ C2<F> cadd(C2<F> a, C2<F> b) { return {a.x + b.x, a.y + b.y}; }
+template <typename F> __device__ __forceinline__ C2<F> csub(C2<F> a, C2<F> b) { return {a.x - b.x, a.y - b.y}; }
+template <typename F> __device__ __forceinline__ C2<F> cmul(C2<F> a, C2<F> b)
+{
+    return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+// multiply by S*i (S = -1: forward, e^{-i..}; S = +1: backward)
+template <int S, typename F> __device__ __forceinline__ C2<F> muli(C2<F> a)
+{
+    return S < 0 ? C2<F>{a.y, -a.x} : C2<F>{-a.y, a.x};
+}
+
+template <int S, typename F> __device__ __forceinline__ void dft2(C2<F> *v)
+{
+    C2<F> t = v[0];
+    v[0] = cadd(t, v[1]);
+    v[1] = csub(t, v[1]);
+}
+
+template <int S, typename F> __device__ __forceinline__ void dft4(C2<F> *v)
+{
+    C2<F> a0 = cadd(v[0], v[2]), a1 = csub(v[0], v[2]);
+    C2<F> a2 = cadd(v[1], v[3]), a3 = muli<S>(csub(v[1], v[3]));
+    v[0] = cadd(a0, a2);
+    v[2] = csub(a0, a2);
+    v[1] = cadd(a1, a3);
+    v[3] = csub(a1, a3);
+}
+
+template <int S, typename F> __device__ __forceinline__ void dft8(C2<F> *v)
+{
+    C2<F> e[4] = {v[0], v[2], v[4], v[6]};
+    C2<F> o[4] = {v[1], v[3], v[5], v[7]};
+    dft4<S>(e);
+    dft4<S>(o);
+    const F h = (F) 0.70710678118654752440;
+    // w8^1 = (1 + S i)/sqrt2, w8^2 = S i, w8^3 = (-1 + S i)/sqrt2
+    C2<F> t1 = cadd(o[1], muli<S>(o[1]));
+    t1.x *= h; t1.y *= h;
+    C2<F> t2 = muli<S>(o[2]);
+    C2<F> t3 = csub(muli<S>(o[3]), o[3]);
+    t3.x *= h; t3.y *= h;
+    v[0] = cadd(e[0], o[0]); v[4] = csub(e[0], o[0]);
+    v[1] = cadd(e[1], t1);   v[5] = csub(e[1], t1);
+    v[2] = cadd(e[2], t2);   v[6] = csub(e[2], t2);
+    v[3] = cadd(e[3], t3);   v[7] = csub(e[3], t3);
+}
+
+template <int R, int S, typename F> __device__ __forceinline__ void dftR(C2<F> *v)
+{
+    if (R == 8) dft8<S>(v);
+    else if (R == 4) dft4<S>(v);
+    else dft2<S>(v);
+}
+
+constexpr int COLS = 8;   // columns per workgroup: 8 x complex<double> = one 128-B line per row
+constexpr int EPT = 8;    // elements per thread
+
+// One Cooley-Tukey stage of radix R on the 8 values of this thread.
+//   PP = product of the radices before this stage, MP = N / PP (remaining length before it).
+//   Butterfly b = tau + T*q (q < 8/R): (kprev, t) = (b / M, b % M) with M = MP / R.
+//   in : values (kprev, ts*M + t), ts < R  [registers v[q*R + ts]]
+//   out: values (kprev + PP*k, t) * W_MP^{t k} -> LDS index (kprev + PP*k)*M + t, or, for the
+//        last stage (M == 1), register slot q + (8/R)*k which is row tau + T*slot.
+template <int R, int PP, int N, int S, bool LAST, typename F>
+__device__ __forceinline__ void stage(C2<F> *v, C2<F> *lds, const C2<F> *tw, int tau, int c)
+{
+    constexpr int T = N / EPT, MP = N / PP, M = MP / R, NB = EPT / R;
+    C2<F> out[EPT];
+#pragma unroll
+    for (int q = 0; q < NB; q++) {
+        const int b = tau + T * q;
+        const int kprev = b / M, t = b % M;
+        C2<F> w[R];
+#pragma unroll
+        for (int ts = 0; ts < R; ts++) w[ts] = v[q * R + ts];
+        dftR<R, S>(w);
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            C2<F> val = w[k];
+            if (!LAST && k > 0) {
+                C2<F> ww = tw[(t * k * PP) & (N - 1)];
+                if (S > 0) ww.y = -ww.y;          // table holds e^{-2 pi i j / N}
+                val = cmul(val, ww);
+            }
+            if (LAST) out[q + NB * k] = val;
+            else lds[((kprev + PP * k) * M + t) * COLS + c] = val;
+        }
+    }
+    if (LAST) {
+#pragma unroll
+        for (int j = 0; j < EPT; j++) v[j] = out[j];
+    }
+}
+
+// Gather this thread's inputs of the NEXT stage (radix R, PP = radices before it) from LDS.
+template <int R, int PP, int N, typename F>
+__device__ __forceinline__ void gather(C2<F> *v, const C2<F> *lds, int tau, int c)
+{
+    constexpr int T = N / EPT, MP = N / PP, M = MP / R, NB = EPT / R;
+#pragma unroll
+    for (int q = 0; q < NB; q++) {
+        const int b = tau + T * q;
+        const int kprev = b / M, t = b % M;
+#pragma unroll
+        for (int ts = 0; ts < R; ts++) v[q * R + ts] = lds[(kprev * MP + ts * M + t) * COLS + c];
+    }
+}
+
+// Full length-N transform of the 8 register values of each thread (rows tau + T*j in, rows
+// tau + T*j out, natural order).  N = 8 * R2 * R3 * R4 (trailing radices may be 1).
+template <int N, int R2, int R3, int R4, int S, typename F>
+__device__ __forceinline__ void fft_core(C2<F> *v, C2<F> *lds, const C2<F> *tw, int tau, int c)
+{
+    static_assert(8 * R2 * R3 * R4 == N, "radices must multiply to N");
+    constexpr bool L1 = R2 == 1;
+    stage<8, 1, N, S, L1>(v, lds, tw, tau, c);
+    if (!L1) {
+        __syncthreads();
+        gather<R2, 8, N>(v, lds, tau, c);
+        constexpr bool L2 = R3 == 1;
+        __syncthreads();
+        stage<R2, 8, N, S, L2>(v, lds, tw, tau, c);
+        if (!L2) {
+            __syncthreads();
+            gather<R3, 8 * R2, N>(v, lds, tau, c);
+            constexpr bool L3 = R4 == 1;
+            __syncthreads();
+            stage<R3, 8 * R2, N, S, L3>(v, lds, tw, tau, c);
+            if (!L3) {
+                __syncthreads();
+                gather<R4, 8 * R2 * R3, N>(v, lds, tau, c);
+                __syncthreads();
+                stage<R4, 8 * R2 * R3, N, S, true>(v, lds, tw, tau, c);
+            }
+        }
+    }
+}
+
+// Address map of one pass: element (batch, row i, column col) lives at
+//   batch * bstride + (i / rsplit) * rhi + (i % rsplit) * rlo + col        (complex units)
+// rsplit = N, rhi = 0 gives a plain row stride rlo; the split form addresses the slab exchange
+// chunks [rank][x_loc][y_loc][kz] directly (pack / unpack fused into the y pass).
+struct ColMap {
+    long long bstride, rhi, rlo;
+    int rsplit;
+};
+
+__device__ __forceinline__ long long col_addr(const ColMap &m, int batch, int i, int col)
+{
+    return (long long) batch * m.bstride + (long long) (i / m.rsplit) * m.rhi + (long long) (i % m.rsplit) * m.rlo + col;
+}
+
+__device__ __forceinline__ int xcd_tile(int b, int n)
+{
+    const int q = n / 8, r = n % 8;
+    const int xcd = b % 8, j = b / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
+template <typename F>
+__device__ __forceinline__ void stage_twiddles(C2<F> *tw, const double *tw_global, int n)
+{
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        tw[i].x = (F) tw_global[2 * i];
+        tw[i].y = (F) tw_global[2 * i + 1];
+    }
+}
+
+// Plain pass: out = scale * FFT_S(in) along the row axis, for `nbatch` planes of `ncols` columns.
+template <int N, int R2, int R3, int R4, int S, typename F>
+__global__ __launch_bounds__(N) void colfft_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ out,
+                                                   ColMap im, ColMap om, int ncols, int ntiles_per_batch,
+                                                   int ntiles, const double *__restrict__ tw_global, F scale)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    C2<F> *lds = (C2<F> *) smem;
+    C2<F> *tw = lds + N * COLS;
+    constexpr int T = N / EPT;
+    const int c = threadIdx.x % COLS, tau = threadIdx.x / COLS;
+    stage_twiddles(tw, tw_global, N);
+    const int tile = xcd_tile(blockIdx.x, ntiles);
+    const int batch = tile / ntiles_per_batch;
+    const int col = (tile % ntiles_per_batch) * COLS + c;
+    const bool live = col < ncols;
+    C2<F> v[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; j++) v[j] = live ? in[col_addr(im, batch, tau + T * j, col)] : C2<F>{0, 0};
+    __syncthreads();
+    fft_core<N, R2, R3, R4, S>(v, lds, tw, tau, c);
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+            C2<F> r = v[j];
+            if (scale != (F) 1) { r.x *= scale; r.y *= scale; }
+            out[col_addr(om, batch, tau + T * j, col)] = r;
+        }
+    }
+}
+
+// Backward x pass fused with the gravity transfer for the three ACC components (and nothing else
+// is read): delta_k [x][y_loc][kz] -> out_d = IFFT_x( transfer_d(delta_k) ), d = 0, 1, 2.
+// The transfer keeps the reference's rounding points (see fpm_kspace.hip transfer_kernel):
+//   b = -(F)(delta * (1 / (kk[x] + kk[y] + kk[z])))   ;   c_d = ((F)(-b.im * kf_d), (F)(b.re * kf_d)).
+template <int N, int R2, int R3, int R4, typename F>
+__global__ __launch_bounds__(N) void colfft_xback3_kernel(const C2<F> *__restrict__ dk, C2<F> *__restrict__ o0,
+                                                          C2<F> *__restrict__ o1, C2<F> *__restrict__ o2,
+                                                          long long rstride, int ncols, int nzc, int ystart,
+                                                          int ntiles, const float *__restrict__ kk,
+                                                          const float *__restrict__ kt,
+                                                          const double *__restrict__ tw_global)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    C2<F> *lds = (C2<F> *) smem;
+    C2<F> *tw = lds + N * COLS;
+    constexpr int T = N / EPT;
+    const int c = threadIdx.x % COLS, tau = threadIdx.x / COLS;
+    stage_twiddles(tw, tw_global, N);
+    const int tile = xcd_tile(blockIdx.x, ntiles);
+    const int col = tile * COLS + c;
+    const bool live = col < ncols;
+    const int iyl = live ? col / nzc : 0, iz = live ? col - iyl * nzc : 0;
+    const int iy = iyl + ystart;
+    const double kky = kk[iy], kkz = kk[iz];
+    const bool yz_self = iy == (N - iy) % N && iz == (N - iz) % N;
+    C2<F> b[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+        const int ix = tau + T * j;
+        C2<F> d = live ? dk[(long long) ix * rstride + col] : C2<F>{0, 0};
+        double kk_finite = 0;
+        kk_finite += kk[ix];
+        kk_finite += kky;
+        kk_finite += kkz;
+        F are, aim;
+        if (kk_finite != 0) {
+            const double r = 1 / kk_finite;
+            are = (F) (d.x * r);
+            aim = (F) (d.y * r);
+        } else {
+            are = 0;
+            aim = 0;
+        }
+        b[j].x = (F) (are * -1.0);
+        b[j].y = (F) (aim * -1.0);
+    }
+    C2<F> *outs[3] = {o0, o1, o2};
+#pragma unroll
+    for (int dir = 0; dir < 3; dir++) {
+        C2<F> v[EPT];
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+            const int ix = tau + T * j;
+            const double k_finite = dir == 0 ? kt[ix] : (dir == 1 ? kt[iy] : kt[iz]);
+            const bool selfconj = yz_self && ix == (N - ix) % N;
+            if (selfconj) {
+                v[j].x = 0;
+                v[j].y = 0;
+            } else {
+                v[j].x = (F) (-b[j].y * k_finite);
+                v[j].y = (F) (b[j].x * k_finite);
+            }
+        }
+        __syncthreads();
+        fft_core<N, R2, R3, R4, +1>(v, lds, tw, tau, c);
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < EPT; j++) outs[dir][(long long) (tau + T * j) * rstride + col] = v[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+template <typename K> static int set_lds(K kernel, size_t bytes)
+{
+    static size_t granted = 64 * 1024;   // one per kernel instantiation
+    if (bytes > granted) {
+        FPM_CHECK_HIP(hipFuncSetAttribute((const void *) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+        granted = bytes;
+    }
+    return 0;
+}
+
+#define COLFFT_DISPATCH(N_, CALL)                                            \
+    switch (N_) {                                                            \
+    case 16: { CALL(16, 2, 1, 1); } break;                                   \
+    case 32: { CALL(32, 4, 1, 1); } break;                                   \
+    case 64: { CALL(64, 8, 1, 1); } break;                                   \
+    case 128: { CALL(128, 8, 2, 1); } break;                                 \
+    case 256: { CALL(256, 8, 4, 1); } break;                                 \
+    case 512: { CALL(512, 8, 8, 1); } break;                                 \
+    case 1024: { CALL(1024, 8, 8, 2); } break;                               \
+    default: FPM_FAIL(-1, "column FFT: unsupported length %d", (int) (N_)); \
+    }
+
+bool colfft_supported(int N) { return N >= 16 && N <= 1024 && (N & (N - 1)) == 0; }
+
+template <typename F>
+static int colfft_launch(fpmhip_plan *p, int dir, const void *in, void *out, const ColMap &im, const ColMap &om,
+                         int nbatch, int ncols, double scale)
+{
+    const int N = p->mg.N;
+    const int tpb = (ncols + COLS - 1) / COLS;
+    const int ntiles = tpb * nbatch;
+    const size_t lds = (size_t) N * COLS * sizeof(C2<F>) + (size_t) N * sizeof(C2<F>);
+#define CALL_PLAIN(n, r2, r3, r4)                                                                              \
+    if (dir < 0) {                                                                                             \
+        FPM_TRY(set_lds(colfft_kernel<n, r2, r3, r4, -1, F>, lds));                                            \
+        colfft_kernel<n, r2, r3, r4, -1, F><<<ntiles, n, lds, p->stream>>>((const C2<F> *) in, (C2<F> *) out,  \
+                                                                          im, om, ncols, tpb, ntiles,         \
+                                                                          p->d_twiddle, (F) scale);           \
+    } else {                                                                                                   \
+        FPM_TRY(set_lds(colfft_kernel<n, r2, r3, r4, +1, F>, lds));                                            \
+        colfft_kernel<n, r2, r3, r4, +1, F><<<ntiles, n, lds, p->stream>>>((const C2<F> *) in, (C2<F> *) out,  \
+                                                                          im, om, ncols, tpb, ntiles,         \
+                                                                          p->d_twiddle, (F) scale);           \
+    }
+    COLFFT_DISPATCH(N, CALL_PLAIN)
+#undef CALL_PLAIN
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// x pass on [x][y_loc][kz]: columns are the whole (y_loc, kz) plane, contiguous.
+int colfft_x(fpmhip_plan *p, int dir, const void *in, void *out, double scale)
+{
+    const MeshGeo &g = p->mg;
+    const long long plane = (long long) g.yl * g.nzc;
+    ColMap m{0, 0, plane, g.N};
+    return p->f64 ? colfft_launch<double>(p, dir, in, out, m, m, 1, (int) plane, scale)
+                  : colfft_launch<float>(p, dir, in, out, m, m, 1, (int) plane, scale);
+}
+
+// y pass on [x_loc][y][kz] planes.  chunked != 0: the OTHER side of the pass is the slab exchange
+// layout [rank][x_loc][y_loc][kz] (output when dir < 0 = pack, input when dir > 0 = unpack).
+int colfft_y(fpmhip_plan *p, int dir, const void *in, void *out, int chunked)
+{
+    const MeshGeo &g = p->mg;
+    const long long plane = (long long) g.N * g.nzc;
+    ColMap natural{plane, 0, g.nzc, g.N};
+    ColMap chunks{(long long) g.yl * g.nzc, (long long) g.xl * g.yl * g.nzc, g.nzc, g.yl};
+    const ColMap &im = (chunked && dir > 0) ? chunks : natural;
+    const ColMap &om = (chunked && dir < 0) ? chunks : natural;
+    return p->f64 ? colfft_launch<double>(p, dir, in, out, im, om, g.xl, g.nzc, 1.0)
+                  : colfft_launch<float>(p, dir, in, out, im, om, g.xl, g.nzc, 1.0);
+}
+
+template <typename F>
+static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, void *o2, int potorder, int gradorder)
+{
+    const MeshGeo &g = p->mg;
+    const int N = g.N;
+    const long long plane = (long long) g.yl * g.nzc;
+    const int ntiles = (int) ((plane + COLS - 1) / COLS);
+    const size_t lds = (size_t) N * COLS * sizeof(C2<F>) + (size_t) N * sizeof(C2<F>);
+    const float *kk = p->d_tab + (2 + potorder) * (size_t) N;
+    const float *kt = p->d_tab + gradorder * (size_t) N;
+#define CALL_X3(n, r2, r3, r4)                                                                               \
+    FPM_TRY(set_lds(colfft_xback3_kernel<n, r2, r3, r4, F>, lds));                                           \
+    colfft_xback3_kernel<n, r2, r3, r4, F><<<ntiles, n, lds, p->stream>>>(                                   \
+        (const C2<F> *) dk, (C2<F> *) o0, (C2<F> *) o1, (C2<F> *) o2, plane, (int) plane, g.nzc, g.ystart,  \
+        ntiles, kk, kt, p->d_twiddle);
+    COLFFT_DISPATCH(N, CALL_X3)
+#undef CALL_X3
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int colfft_xback3(fpmhip_plan *p, const void *dk, void *o0, void *o1, void *o2, int potorder, int gradorder)
+{
+    return p->f64 ? xback3_launch<double>(p, dk, o0, o1, o2, potorder, gradorder)
+                  : xback3_launch<float>(p, dk, o0, o1, o2, potorder, gradorder);
+}
+
+}  // namespace fpm

@@ -69,7 +69,34 @@ int fft_setup(fpmhip_plan *p)
     const MeshGeo &g = p->mg;
     const size_t N = g.N, nzc = g.nzc, xl = g.xl, yl = g.yl;
     const double inv_norm = 1.0 / p->lay.Norm;
-    if (p->lay.nranks == 1) {
+    p->own_fft = p->geom.fft_mode == FPMHIP_FFT_AUTO && colfft_supported(g.N);
+    if (p->own_fft) {
+        // rocFFT only transforms the contiguous z rows: N real <-> N/2+1 complex, batch xl * N
+        const size_t len1[1] = {N};
+        const size_t one[1] = {1};
+        FPM_TRY(make_plan(&p->p_zr2c_op, rocfft_placement_notinplace, rocfft_transform_type_real_forward, p->f64, 1,
+                          len1, xl * N, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, one,
+                          N + 2, one, nzc, 1.0));
+        FPM_TRY(make_plan(&p->p_zr2c_ip, rocfft_placement_inplace, rocfft_transform_type_real_forward, p->f64, 1,
+                          len1, xl * N, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, one,
+                          N + 2, one, nzc, 1.0));
+        FPM_TRY(make_plan(&p->p_zc2r_ip, rocfft_placement_inplace, rocfft_transform_type_real_inverse, p->f64, 1,
+                          len1, xl * N, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, one,
+                          nzc, one, N + 2, 1.0));
+        // twiddles e^{-2 pi i j / N} in double, octant-exact where it matters (j = 0, N/4, N/2, ...)
+        std::vector<double> tw(2 * N);
+        for (size_t j = 0; j < N; j++) {
+            const double a = -2.0 * M_PI * (double) j / (double) N;
+            tw[2 * j] = cos(a);
+            tw[2 * j + 1] = sin(a);
+        }
+        tw[0] = 1; tw[1] = 0;
+        tw[2 * (N / 2)] = -1; tw[2 * (N / 2) + 1] = 0;
+        tw[2 * (N / 4)] = 0; tw[2 * (N / 4) + 1] = -1;
+        tw[2 * (3 * N / 4)] = 0; tw[2 * (3 * N / 4) + 1] = 1;
+        FPM_CHECK_HIP(hipMalloc(&p->d_twiddle, 2 * N * sizeof(double)));
+        FPM_CHECK_HIP(hipMemcpy(p->d_twiddle, tw.data(), 2 * N * sizeof(double), hipMemcpyHostToDevice));
+    } else if (p->lay.nranks == 1) {
         // rocFFT lengths / strides are fastest-dimension first: (z, y, x)
         const size_t len[3] = {N, N, N};
         const size_t rs[3] = {1, N + 2, N * (N + 2)};
@@ -101,7 +128,8 @@ int fft_setup(fpmhip_plan *p)
                           rocfft_array_type_complex_interleaved, st1, 1, st1, 1, 1.0));
     }
     size_t work = 0;
-    rocfft_plan all[] = {p->p_r2c3d, p->p_c2r3d, p->p_r2c2d, p->p_c2r2d, p->p_xfwd, p->p_xbwd};
+    rocfft_plan all[] = {p->p_r2c3d, p->p_c2r3d, p->p_r2c2d, p->p_c2r2d, p->p_xfwd, p->p_xbwd,
+                         p->p_zr2c_op, p->p_zr2c_ip, p->p_zc2r_ip};
     for (rocfft_plan q : all) {
         if (!q) continue;
         size_t w = 0;
@@ -120,7 +148,8 @@ int fft_setup(fpmhip_plan *p)
 
 void fft_teardown(fpmhip_plan *p)
 {
-    rocfft_plan all[] = {p->p_r2c3d, p->p_c2r3d, p->p_r2c2d, p->p_c2r2d, p->p_xfwd, p->p_xbwd};
+    rocfft_plan all[] = {p->p_r2c3d, p->p_c2r3d, p->p_r2c2d, p->p_c2r2d, p->p_xfwd, p->p_xbwd,
+                         p->p_zr2c_op, p->p_zr2c_ip, p->p_zc2r_ip};
     for (rocfft_plan q : all) if (q) rocfft_plan_destroy(q);
     if (p->fft_info) rocfft_execution_info_destroy(p->fft_info);
     if (p->fft_work) (void) hipFree(p->fft_work);
@@ -143,12 +172,23 @@ using namespace fpm;
 
 extern "C" {
 
+int fpmhip_plan_staged_fft(const fpmhip_plan *p)
+{
+    if (!p) return 0;
+    return p->lay.nranks > 1 || p->own_fft;
+}
+
 int fpmhip_r2c(fpmhip_plan *p, void *canvas, void *delta_k)
 {
     if (!p || !canvas || !delta_k) FPM_FAIL(-1, "null argument");
     if (p->lay.nranks != 1) FPM_FAIL(-1, "fpmhip_r2c is the one-rank transform; use the fft_yz/fft_x stages");
     if (canvas == delta_k) FPM_FAIL(-1, "pm_r2c is out of place (pmapi.h:97-100)");
     StageTimer tm(p, FPMHIP_T_R2C);
+    if (p->own_fft) {
+        FPM_TRY(fft_exec(p, p->p_zr2c_op, canvas, delta_k));
+        FPM_TRY(colfft_y(p, -1, delta_k, delta_k, 0));
+        return colfft_x(p, -1, delta_k, delta_k, 1.0 / p->lay.Norm);
+    }
     return fft_exec(p, p->p_r2c3d, canvas, delta_k);
 }
 
@@ -157,13 +197,32 @@ int fpmhip_c2r(fpmhip_plan *p, void *inplace)
     if (!p || !inplace) FPM_FAIL(-1, "null argument");
     if (p->lay.nranks != 1) FPM_FAIL(-1, "fpmhip_c2r is the one-rank transform; use the fft_yz/fft_x stages");
     StageTimer tm(p, FPMHIP_T_C2R);
+    if (p->own_fft) {
+        FPM_TRY(colfft_x(p, +1, inplace, inplace, 1.0));
+        FPM_TRY(colfft_y(p, +1, inplace, inplace, 0));
+        return fft_exec(p, p->p_zc2r_ip, inplace, nullptr);
+    }
     return fft_exec(p, p->p_c2r3d, inplace, nullptr);
 }
 
 int fpmhip_fft_yz_forward(fpmhip_plan *p, void *canvas, void *send)
 {
     if (!p || !canvas || !send) FPM_FAIL(-1, "null argument");
-    if (p->lay.nranks == 1) FPM_FAIL(-1, "staged FFT needs nranks > 1");
+    if (!fpmhip_plan_staged_fft(p)) FPM_FAIL(-1, "staged FFT needs nranks > 1 or the column-FFT back end");
+    if (p->own_fft) {
+        StageTimer tm(p, FPMHIP_T_R2C);
+        if (p->lay.nranks == 1) {
+            // one rank: the chunk layout is the natural one; z pass (out of place unless aliased), y in place
+            if (canvas == send) FPM_TRY(fft_exec(p, p->p_zr2c_ip, canvas, nullptr));
+            else FPM_TRY(fft_exec(p, p->p_zr2c_op, canvas, send));
+            return colfft_y(p, -1, send, send, 0);
+        }
+        if (canvas == send) FPM_FAIL(-1, "fft_yz_forward: canvas and send must differ when nranks > 1");
+        // z pass in place on the slab, then the y pass writes straight into the exchange chunks
+        // [rank][x_loc][y_loc][kz] (pack fused into the pass)
+        FPM_TRY(fft_exec(p, p->p_zr2c_ip, canvas, nullptr));
+        return colfft_y(p, -1, canvas, send, 1);
+    }
     {
         StageTimer tm(p, FPMHIP_T_R2C);
         FPM_TRY(fft_exec(p, p->p_r2c2d, canvas, nullptr));
@@ -175,29 +234,56 @@ int fpmhip_fft_yz_forward(fpmhip_plan *p, void *canvas, void *send)
 int fpmhip_fft_x_forward(fpmhip_plan *p, void *recv)
 {
     if (!p || !recv) FPM_FAIL(-1, "null argument");
-    if (p->lay.nranks == 1) FPM_FAIL(-1, "staged FFT needs nranks > 1");
+    if (!fpmhip_plan_staged_fft(p)) FPM_FAIL(-1, "staged FFT needs nranks > 1 or the column-FFT back end");
     StageTimer tm(p, FPMHIP_T_R2C);
+    if (p->own_fft) return colfft_x(p, -1, recv, recv, 1.0 / p->lay.Norm);
     return fft_exec(p, p->p_xfwd, recv, nullptr);
 }
 
 int fpmhip_fft_x_backward(fpmhip_plan *p, void *buf)
 {
     if (!p || !buf) FPM_FAIL(-1, "null argument");
-    if (p->lay.nranks == 1) FPM_FAIL(-1, "staged FFT needs nranks > 1");
+    if (!fpmhip_plan_staged_fft(p)) FPM_FAIL(-1, "staged FFT needs nranks > 1 or the column-FFT back end");
     StageTimer tm(p, FPMHIP_T_C2R);
+    if (p->own_fft) return colfft_x(p, +1, buf, buf, 1.0);
     return fft_exec(p, p->p_xbwd, buf, nullptr);
 }
 
 int fpmhip_fft_yz_backward(fpmhip_plan *p, void *recv, void *canvas)
 {
     if (!p || !recv || !canvas) FPM_FAIL(-1, "null argument");
-    if (p->lay.nranks == 1) FPM_FAIL(-1, "staged FFT needs nranks > 1");
+    if (!fpmhip_plan_staged_fft(p)) FPM_FAIL(-1, "staged FFT needs nranks > 1 or the column-FFT back end");
+    if (p->own_fft) {
+        StageTimer tm(p, FPMHIP_T_C2R);
+        // y pass reads the exchange chunks directly (unpack fused) and writes the natural slab
+        if (p->lay.nranks > 1 && recv == canvas) FPM_FAIL(-1, "fft_yz_backward: recv and canvas must differ when nranks > 1");
+        FPM_TRY(colfft_y(p, +1, recv, canvas, p->lay.nranks > 1 ? 1 : 0));
+        return fft_exec(p, p->p_zc2r_ip, canvas, nullptr);
+    }
     {
         StageTimer tm(p, FPMHIP_T_PACK);
         FPM_TRY((p->f64 ? launch_pack<double, false>(p, canvas, recv) : launch_pack<float, false>(p, canvas, recv)));
     }
     StageTimer tm(p, FPMHIP_T_C2R);
     return fft_exec(p, p->p_c2r2d, canvas, nullptr);
+}
+
+int fpmhip_transfer_fft_x_backward3(fpmhip_plan *p, const void *delta_k, void *o0, void *o1, void *o2, int kernel)
+{
+    if (!p || !delta_k || !o0 || !o1 || !o2) FPM_FAIL(-1, "null argument");
+    if (!fpmhip_plan_staged_fft(p)) FPM_FAIL(-1, "staged FFT needs nranks > 1 or the column-FFT back end");
+    int po, go, dfo, dc;
+    FPM_TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));
+    if (p->own_fft) {
+        StageTimer tm(p, FPMHIP_T_XBACK3);
+        return colfft_xback3(p, delta_k, o0, o1, o2, po, go);
+    }
+    void *o[3] = {o0, o1, o2};
+    for (int d = 0; d < 3; d++) {
+        FPM_TRY(fpmhip_transfer(p, delta_k, o[d], kernel, d));
+        FPM_TRY(fpmhip_fft_x_backward(p, o[d]));
+    }
+    return 0;
 }
 
 }  // extern "C"

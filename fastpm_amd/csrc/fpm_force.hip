@@ -25,6 +25,21 @@ HostStage *stage_for(fpmhip_plan *p)
 
 }  // namespace
 
+namespace fpm {
+void release_host_stage(fpmhip_plan *p)
+{
+    for (size_t i = 0; i < g_stage.size(); i++) {
+        if (g_stage[i].first != p) continue;
+        HostStage &st = g_stage[i].second;
+        if (st.x) { (void) hipFree(st.x); (void) hipFree(st.acc); }
+        if (st.mass) (void) hipFree(st.mass);
+        if (st.pot) (void) hipFree(st.pot);
+        g_stage.erase(g_stage.begin() + i);
+        return;
+    }
+}
+}  // namespace fpm
+
 extern "C" {
 
 int fpmhip_force(fpmhip_plan *p, const fpmhip_particles *pt, int kernel, int softening, double total_mass,
@@ -56,9 +71,15 @@ int fpmhip_force(fpmhip_plan *p, const fpmhip_particles *pt, int kernel, int sof
 
     // the canvas is free again after the out-of-place r2c: it carries the x component
     void *f[3] = {canvas, p->buf[BUF_F1], p->buf[BUF_F2]};
-    for (int d = 0; d < 3; d++) {                                                         // gravity.c:373-397
-        FPM_TRY(fpmhip_transfer(p, delta_k, f[d], kernel, d));
-        FPM_TRY(fpmhip_c2r(p, f[d]));
+    if (p->own_fft) {
+        // one sweep over delta_k: the three transfers + the x pass of their inverse transforms
+        FPM_TRY(fpmhip_transfer_fft_x_backward3(p, delta_k, f[0], f[1], f[2], kernel));
+        for (int d = 0; d < 3; d++) FPM_TRY(fpmhip_fft_yz_backward(p, f[d], f[d]));
+    } else {
+        for (int d = 0; d < 3; d++) {                                                     // gravity.c:373-397
+            FPM_TRY(fpmhip_transfer(p, delta_k, f[d], kernel, d));
+            FPM_TRY(fpmhip_c2r(p, f[d]));
+        }
     }
     FPM_TRY(fpmhip_readout3(p, pt, f[0], f[1], f[2]));
     if (pt->potential) {                                                                  // gravity.c:487-492

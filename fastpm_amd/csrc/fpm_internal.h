@@ -97,6 +97,10 @@ struct fpmhip_plan {
     rocfft_plan p_r2c3d = nullptr, p_c2r3d = nullptr;
     rocfft_plan p_r2c2d = nullptr, p_c2r2d = nullptr;
     rocfft_plan p_xfwd = nullptr, p_xbwd = nullptr;
+    // own column-FFT mode: rocFFT only does the contiguous z pass (1-D r2c / c2r, batch xl*N)
+    bool own_fft = false;
+    rocfft_plan p_zr2c_op = nullptr, p_zr2c_ip = nullptr, p_zc2r_ip = nullptr;
+    double *d_twiddle = nullptr;   // e^{-2 pi i j / N}, j < N (re, im)
     rocfft_execution_info fft_info = nullptr;
     void *fft_work = nullptr;
     size_t fft_work_bytes = 0;
@@ -150,6 +154,15 @@ int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt);
 // fpm_fft.hip
 int fft_setup(fpmhip_plan *p);
 void fft_teardown(fpmhip_plan *p);
+
+// fpm_colfft.hip
+bool colfft_supported(int N);
+int colfft_x(fpmhip_plan *p, int dir, const void *in, void *out, double scale);
+int colfft_y(fpmhip_plan *p, int dir, const void *in, void *out, int chunked);
+int colfft_xback3(fpmhip_plan *p, const void *dk, void *o0, void *o1, void *o2, int potorder, int gradorder);
+
+// fpm_force.hip
+void release_host_stage(fpmhip_plan *p);
 
 // fpm_kspace.hip
 int upload_factor_tables(fpmhip_plan *p, const std::vector<double> &fx);

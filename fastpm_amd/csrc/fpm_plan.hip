@@ -241,7 +241,8 @@ void fpmhip_plan_destroy(fpmhip_plan *p)
     (void) hipStreamSynchronize(p->stream);
     fft_teardown(p);
     for (int i = 0; i < BUF_COUNT; i++) if (p->buf[i]) (void) hipFree(p->buf[i]);
-    void *ptrs[] = {p->d_tab, p->d_fac, p->sx, p->sy, p->sz, p->smass, p->sidx, p->tile_cnt,
+    release_host_stage(p);
+    void *ptrs[] = {p->d_twiddle, p->d_tab, p->d_fac, p->sx, p->sy, p->sz, p->smass, p->sidx, p->tile_cnt,
                     p->tile_off, p->tile_cur, p->scan_tmp, p->d_scalar};
     for (void *q : ptrs) if (q) (void) hipFree(q);
     if (p->h_pinned) (void) hipHostFree(p->h_pinned);
@@ -292,7 +293,7 @@ int64_t fpmhip_exchange_chunk_elems(const fpmhip_plan *p)
 }
 
 static const char *stage_names[FPMHIP_T_COUNT] = {"sort", "paint", "r2c", "dealias", "transfer",
-                                                  "c2r", "readout", "halo", "pack"};
+                                                  "c2r", "readout", "halo", "pack", "xback3"};
 
 const char *fpmhip_timing_name(int stage)
 {

@@ -68,9 +68,12 @@ class SlabForce:
         pm.fft_x_forward(delta_k)
         pm.apply_softening_transfer(dealias, delta_k)                     # gravity.c:476
 
-        # gravity.c:373-397: per component transfer -> c2r
+        # gravity.c:373-397: per component transfer -> c2r.  The three transfers and the x passes
+        # come from ONE sweep over delta_k; then one transpose + (y,z) passes per component.
+        pm.transfer_fft_x_backward3(kernel, delta_k, self.force)
         for d in range(3):
-            yield from self._backward(delta_k, kernel, d, self.force[d])
+            yield ("alltoall", self.work, self.force[d])
+            pm.fft_yz_backward(self.work, self.force[d])
         # the plane each boundary particle's cloud reaches into comes from the next slab
         yield ("shift", [(pm.plane(f, 0), pm.plane(f, xl), -1) for f in self.force])
         pm.readout3(self.force, store)

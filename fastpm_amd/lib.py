@@ -13,7 +13,7 @@ class FastPMHipError(RuntimeError):
 class Geom(ctypes.Structure):
     _fields_ = [("Nmesh", ctypes.c_int64), ("BoxSize", ctypes.c_double), ("precision", ctypes.c_int32),
                 ("nranks", ctypes.c_int32), ("rank", ctypes.c_int32), ("device", ctypes.c_int32),
-                ("np_max", ctypes.c_int64), ("paint_mode", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("np_max", ctypes.c_int64), ("paint_mode", ctypes.c_int32), ("fft_mode", ctypes.c_int32)]
 
 
 class Layout(ctypes.Structure):
@@ -61,6 +61,8 @@ SYMBOLS = {
     "fpmhip_fft_yz_backward": (_I, [_P, _P, _P]),
     "fpmhip_softening": (_I, [_P, _P, _I]),
     "fpmhip_transfer": (_I, [_P, _P, _P, _I, _I]),
+    "fpmhip_transfer_fft_x_backward3": (_I, [_P, _P, _P, _P, _P, _I]),
+    "fpmhip_plan_staged_fft": (_I, [_P]),
     "fpmhip_readout3": (_I, [_P, ctypes.POINTER(Particles), _P, _P, _P]),
     "fpmhip_readout1": (_I, [_P, ctypes.POINTER(Particles), _P, _P, _I, _I]),
     "fpmhip_decic": (_I, [_P, _P, _P]),
@@ -77,7 +79,7 @@ SYMBOLS = {
     "fpmhip_memcpy_d2h": (_I, [_P, _P, _P, ctypes.c_size_t]),
 }
 
-TIMING_STAGES = ["sort", "paint", "r2c", "dealias", "transfer", "c2r", "readout", "halo", "pack"]
+TIMING_STAGES = ["sort", "paint", "r2c", "dealias", "transfer", "c2r", "readout", "halo", "pack", "xback3"]
 
 
 def library_path():

@@ -32,6 +32,7 @@ SOFTENING_TYPES = {"none": 0, "gaussian": 1, "gadget_long_range": 2, "two_third"
 FIELD_ACC = (0, 1, 2)
 FIELD_POTENTIAL = 3
 PAINT_TILED, PAINT_ATOMIC = 0, 1
+FFT_AUTO, FFT_ROCFFT = 0, 1
 
 
 def _enum(table, v):
@@ -83,7 +84,7 @@ class PM:
     """One rank's particle mesh on one MI355X (struct PM + its plans)."""
 
     def __init__(self, Nmesh, BoxSize, precision=64, nranks=1, rank=0, device=None, np_max=0,
-                 paint_mode=PAINT_TILED):
+                 paint_mode=PAINT_TILED, fft_mode=FFT_AUTO):
         self._L = _lib.load_library()
         self._plan = ctypes.c_void_p()
         if not torch.cuda.is_available():
@@ -92,7 +93,7 @@ class PM:
             device = torch.cuda.current_device()
         self.device = torch.device("cuda", int(device))
         g = _lib.Geom(int(Nmesh), float(BoxSize), int(precision), int(nranks), int(rank), int(self.device.index),
-                      int(np_max), int(paint_mode), 0)
+                      int(np_max), int(paint_mode), int(fft_mode))
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream().cuda_stream
             check(self._L.fpmhip_plan_create(ctypes.byref(g), ctypes.c_void_p(stream), ctypes.byref(self._plan)))
@@ -224,6 +225,14 @@ class PM:
 
     def fft_yz_backward(self, recv, canvas):
         check(self._L.fpmhip_fft_yz_backward(self._plan, _ptr(recv), _ptr(canvas)))
+
+    def staged_fft(self):
+        return bool(self._L.fpmhip_plan_staged_fft(self._plan))
+
+    def transfer_fft_x_backward3(self, kernel, delta_k, outs):
+        """The three ACC transfers + the x pass of their inverse FFTs from one read of delta_k."""
+        check(self._L.fpmhip_transfer_fft_x_backward3(self._plan, _ptr(delta_k), _ptr(outs[0]), _ptr(outs[1]),
+                                                      _ptr(outs[2]), _enum(KERNEL_TYPES, kernel)))
 
     # ---- whole step, one rank
     def compute_force(self, store, kernel="1_4", softening="none", delta_k=None, total_mass=-1.0):

@@ -47,6 +47,11 @@ enum { FPMHIP_FIELD_ACC_X = 0, FPMHIP_FIELD_ACC_Y = 1, FPMHIP_FIELD_ACC_Z = 2, F
 enum { FPMHIP_PAINT_TILED = 0,      /* tile-binned particles, LDS-staged tiles, no global atomics */
        FPMHIP_PAINT_ATOMIC = 1 };   /* one global atomicAdd per corner (baseline for A/B evidence) */
 
+/* FFT back end.  AUTO: hand-written column passes for x and y (fused with the transfer, the
+ * 1/N^3 and the slab pack/unpack) + rocFFT for the contiguous z pass when Nmesh is a power of two
+ * in [16, 1024]; rocFFT 3-D (or 2-D + 1-D) plans otherwise.  ROCFFT forces the latter. */
+enum { FPMHIP_FFT_AUTO = 0, FPMHIP_FFT_ROCFFT = 1 };
+
 /* What pm_init takes (libfastpm/pmpfft.h:29-35 PMInit) + where this rank sits. */
 typedef struct {
     int64_t Nmesh;        /* cubic mesh, must be even (pmpfft.c:143) and divisible by nranks */
@@ -57,7 +62,7 @@ typedef struct {
     int32_t device;       /* HIP device ordinal; -1 = the current device */
     int64_t np_max;       /* capacity hint for particle work buffers (grown on demand) */
     int32_t paint_mode;   /* FPMHIP_PAINT_* */
-    int32_t reserved;
+    int32_t fft_mode;     /* FPMHIP_FFT_* */
 } fpmhip_geom;
 
 /* What struct PM exposes to the hot path (pmpfft.h:43-70, pmapi.h:3-9).  Real strides are in
@@ -155,6 +160,15 @@ int fpmhip_softening(fpmhip_plan *plan, void *delta_k_dev, int softening);
  * pointwise pass: laplace (transfer.c:153-186), x -1 (gravity.c:17), gradient (gravity.c:21-64),
  * with the reference's intermediate roundings. */
 int fpmhip_transfer(fpmhip_plan *plan, const void *delta_k_dev, void *out_dev, int kernel, int field);
+/* The three COLUMN_ACC transfers AND the x pass of their inverse transforms in one sweep:
+ * out_d = IFFT_x(transfer_d(delta_k)), d = 0,1,2, from a single read of delta_k (same roundings as
+ * fpmhip_transfer).  Follow with fpmhip_fft_yz_backward per component (after the all-to-all when
+ * nranks > 1).  Falls back to 3 x (fpmhip_transfer + x pass) when the column FFT is not in use. */
+int fpmhip_transfer_fft_x_backward3(fpmhip_plan *plan, const void *delta_k_dev, void *out0_dev,
+                                    void *out1_dev, void *out2_dev, int kernel);
+/* 1 if the staged FFT entry points (fft_yz_*, fft_x_*) work for this plan (always for nranks > 1;
+ * for nranks == 1 only with the column-FFT back end) */
+int fpmhip_plan_staged_fft(const fpmhip_plan *plan);
 
 /* fastpm_readout_local (painter.c:358-374, painter-cic.c:113-190): one or three meshes.
  * readout3 writes acc[i][0..2]; readout1 writes out[i * nmemb + memb]. */
@@ -178,7 +192,9 @@ int fpmhip_export_delta_k(fpmhip_plan *plan, const void *delta_k_dev, void *delt
 /* ---- per-stage timing with HIP events on the plan's stream (the reference's CLOCK names,
  *      gravity.c:276,320,344,348,369-372,474) ---- */
 enum { FPMHIP_T_SORT = 0, FPMHIP_T_PAINT, FPMHIP_T_R2C, FPMHIP_T_DEALIAS, FPMHIP_T_TRANSFER,
-       FPMHIP_T_C2R, FPMHIP_T_READOUT, FPMHIP_T_HALO, FPMHIP_T_PACK, FPMHIP_T_COUNT };
+       FPMHIP_T_C2R, FPMHIP_T_READOUT, FPMHIP_T_HALO, FPMHIP_T_PACK,
+       FPMHIP_T_XBACK3,      /* fused 3-component transfer + backward x pass */
+       FPMHIP_T_COUNT };
 int fpmhip_timing_enable(fpmhip_plan *plan, int on);
 int fpmhip_timing_reset(fpmhip_plan *plan);
 /* Synchronises; total milliseconds and launch count of one stage since the last reset. */

@@ -138,6 +138,11 @@ class CpuSlabOps:
         canvas.zero_()
         self._real(canvas)[:xl, :, :N] = scipy.fft.irfft2(a, s=(N, N), axes=(1, 2), norm="forward")
 
+    def transfer_fft_x_backward3(self, kernel, delta_k, outs):
+        for d in range(3):
+            self.gravity_apply_kernel_transfer(kernel, delta_k, outs[d], d)
+            self.fft_x_backward(outs[d])
+
     # ---- k space: the oracle's C functions on this rank's [x][y_loc][kz] block
     def apply_softening_transfer(self, softening, delta_k):
         a = delta_k.numpy()
