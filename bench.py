@@ -59,6 +59,7 @@ def algorithmic_bytes(np_local, Nmesh, nranks, esize):
         "transfer": 2 * s * nr,                          # K7
         "c2r": 2 * s * nr,                               # K8
         "readout": 3 * s * nr + 36 * np_local,           # K9 fused over the 3 components
+        "xback3": 4 * s * nr,                            # fused K7 x3 + x pass of K8 x3: 1 read, 3 writes
     }
 
 
@@ -91,6 +92,7 @@ def main():
     ap.add_argument("--nc", type=int, default=0, help="override particles per side")
     ap.add_argument("--nmesh", type=int, default=0, help="override mesh per side")
     ap.add_argument("--paint-mode", type=int, default=0, help="0 tiled (default), 1 global atomics")
+    ap.add_argument("--fft-mode", type=int, default=0, help="0 auto (column FFT + rocFFT z pass), 1 rocFFT only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -123,7 +125,7 @@ def main():
     np_local = x.shape[0]
     np_total = nc ** 3
     pm = PM(Nmesh, BoxSize, precision=args.precision, nranks=world, rank=rank, np_max=np_local,
-            paint_mode=args.paint_mode)
+            paint_mode=args.paint_mode, fft_mode=args.fft_mode)
     store = Store(x, device=device)
     delta_k = pm.alloc()
     if world > 1:
@@ -189,7 +191,8 @@ def main():
                 nc, Nmesh, args.precision, world, "" if world > 1 else " single-GPU rocFFT path (configs[1])"),
                 "particles": np_total, "nmesh": Nmesh, "load": "A: lattice + 0.3-cell Gaussian jitter",
                 "kernel": "1_4", "softening": "none", "decomposition": "slab %dx1" % world,
-                "paint_mode": "tiled" if args.paint_mode == 0 else "atomic"},
+                "paint_mode": "tiled" if args.paint_mode == 0 else "atomic",
+                "fft": "column passes + rocFFT z" if pm.staged_fft() and args.fft_mode == 0 else "rocFFT"},
             "per_gpu": value / world, "finite": acc_ok,
             "step_alg_GBs": round(b_alg / (ms_per_step * 1e-3) / 1e9, 1),
             "roofline": roofline, "stages": stages,

@@ -18,6 +18,8 @@
 // radix Cooley-Tukey, first radix 8, stages exchange through LDS laid out [index][column] (column
 // fastest: a wave's 64 lanes touch 1 KiB contiguous, <= 2-way bank conflicts for every stage
 // pattern).  Twiddles W_N^j come from a host-built double table staged in LDS.
+#include <cstdlib>
+
 #include "fpm_internal.h"
 
 namespace fpm {
@@ -26,9 +28,13 @@ template <typename F> struct C2 { F x, y; };
 
 template <typename F> __device__ __forceinline__ C2<F> cadd(C2<F> a, C2<F> b) { return {a.x + b.x, a.y + b.y}; }
 template <typename F> __device__ __forceinline__ C2<F> csub(C2<F> a, C2<F> b) { return {a.x - b.x, a.y - b.y}; }
+// fused multiply-adds here: the DFT is compared to other FFT libraries within round-off, not bit for
+// bit, so the butterflies may contract (the CIC and transfer arithmetic elsewhere may not)
+__device__ __forceinline__ double ffma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float ffma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 template <typename F> __device__ __forceinline__ C2<F> cmul(C2<F> a, C2<F> b)
 {
-    return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+    return {ffma(a.x, b.x, -(a.y * b.y)), ffma(a.x, b.y, a.y * b.x)};
 }
 // multiply by S*i (S = -1: forward, e^{-i..}; S = +1: backward)
 template <int S, typename F> __device__ __forceinline__ C2<F> muli(C2<F> a)
@@ -194,6 +200,9 @@ __device__ __forceinline__ void stage_twiddles(C2<F> *tw, const double *tw_globa
 }
 
 // Plain pass: out = scale * FFT_S(in) along the row axis, for `nbatch` planes of `ncols` columns.
+// One tile per workgroup (61 VGPRs, 2 workgroups/CU at N = 512): measured 0.47 ms per 2.16 GB
+// pass = the speed of a contiguous device copy of the same bytes (tools/ubench/wr_pattern.hip).
+// A persistent variant with register prefetch of the next tile needed 178 VGPRs and ran slower.
 template <int N, int R2, int R3, int R4, int S, typename F>
 __global__ __launch_bounds__(N) void colfft_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ out,
                                                    ColMap im, ColMap om, int ncols, int ntiles_per_batch,
@@ -204,7 +213,6 @@ __global__ __launch_bounds__(N) void colfft_kernel(const C2<F> *__restrict__ in,
     C2<F> *tw = lds + N * COLS;
     constexpr int T = N / EPT;
     const int c = threadIdx.x % COLS, tau = threadIdx.x / COLS;
-    stage_twiddles(tw, tw_global, N);
     const int tile = xcd_tile(blockIdx.x, ntiles);
     const int batch = tile / ntiles_per_batch;
     const int col = (tile % ntiles_per_batch) * COLS + c;
@@ -212,6 +220,7 @@ __global__ __launch_bounds__(N) void colfft_kernel(const C2<F> *__restrict__ in,
     C2<F> v[EPT];
 #pragma unroll
     for (int j = 0; j < EPT; j++) v[j] = live ? in[col_addr(im, batch, tau + T * j, col)] : C2<F>{0, 0};
+    stage_twiddles(tw, tw_global, N);       // after the data loads are in flight
     __syncthreads();
     fft_core<N, R2, R3, R4, S>(v, lds, tw, tau, c);
     if (live) {
@@ -228,32 +237,42 @@ __global__ __launch_bounds__(N) void colfft_kernel(const C2<F> *__restrict__ in,
 // is read): delta_k [x][y_loc][kz] -> out_d = IFFT_x( transfer_d(delta_k) ), d = 0, 1, 2.
 // The transfer keeps the reference's rounding points (see fpm_kspace.hip transfer_kernel):
 //   b = -(F)(delta * (1 / (kk[x] + kk[y] + kk[z])))   ;   c_d = ((F)(-b.im * kf_d), (F)(b.re * kf_d)).
+// b stays in registers across the three transforms; __launch_bounds__(N, 4) keeps the kernel at
+// 128 VGPRs so that two workgroups share a CU (measured 1.32 ms vs 1.46 ms at one per CU;
+// re-reading delta_k per component instead: 1.63 ms; HBM floor for 1 read + 3 writes in this
+// access pattern: 1.02 ms, tools/ubench/wr_pattern.hip).
 template <int N, int R2, int R3, int R4, typename F>
-__global__ __launch_bounds__(N) void colfft_xback3_kernel(const C2<F> *__restrict__ dk, C2<F> *__restrict__ o0,
-                                                          C2<F> *__restrict__ o1, C2<F> *__restrict__ o2,
-                                                          long long rstride, int ncols, int nzc, int ystart,
-                                                          int ntiles, const float *__restrict__ kk,
-                                                          const float *__restrict__ kt,
-                                                          const double *__restrict__ tw_global)
+__global__ __launch_bounds__(N, 4) void colfft_xback3_kernel(const C2<F> *__restrict__ dk, C2<F> *__restrict__ o0,
+                                                             C2<F> *__restrict__ o1, C2<F> *__restrict__ o2,
+                                                             long long rstride, int ncols, int nzc, int ystart,
+                                                             int ntiles, const float *__restrict__ kk,
+                                                             const float *__restrict__ kt,
+                                                             const double *__restrict__ tw_global)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     C2<F> *lds = (C2<F> *) smem;
     C2<F> *tw = lds + N * COLS;
     constexpr int T = N / EPT;
     const int c = threadIdx.x % COLS, tau = threadIdx.x / COLS;
-    stage_twiddles(tw, tw_global, N);
     const int tile = xcd_tile(blockIdx.x, ntiles);
     const int col = tile * COLS + c;
     const bool live = col < ncols;
+    // uniform 64-bit row base (SGPRs) + one 32-bit per-thread element offset: keeps the eight load
+    // and eight store addresses out of the VGPR budget (tau * rstride + col < 2^28 for N <= 1024)
+    const unsigned toff = (unsigned) tau * (unsigned) rstride + (unsigned) col;
+    const long long jstride = (long long) T * rstride;
+    C2<F> b[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; j++) b[j] = live ? (dk + j * jstride)[toff] : C2<F>{0, 0};
+    stage_twiddles(tw, tw_global, N);
     const int iyl = live ? col / nzc : 0, iz = live ? col - iyl * nzc : 0;
     const int iy = iyl + ystart;
     const double kky = kk[iy], kkz = kk[iz];
     const bool yz_self = iy == (N - iy) % N && iz == (N - iz) % N;
-    C2<F> b[EPT];
+    // raw delta_k -> b (laplace and sign, transfer.c:171-183, gravity.c:17)
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
         const int ix = tau + T * j;
-        C2<F> d = live ? dk[(long long) ix * rstride + col] : C2<F>{0, 0};
         double kk_finite = 0;
         kk_finite += kk[ix];
         kk_finite += kky;
@@ -261,8 +280,8 @@ __global__ __launch_bounds__(N) void colfft_xback3_kernel(const C2<F> *__restric
         F are, aim;
         if (kk_finite != 0) {
             const double r = 1 / kk_finite;
-            are = (F) (d.x * r);
-            aim = (F) (d.y * r);
+            are = (F) (b[j].x * r);
+            aim = (F) (b[j].y * r);
         } else {
             are = 0;
             aim = 0;
@@ -271,27 +290,28 @@ __global__ __launch_bounds__(N) void colfft_xback3_kernel(const C2<F> *__restric
         b[j].y = (F) (aim * -1.0);
     }
     C2<F> *outs[3] = {o0, o1, o2};
-#pragma unroll
+#pragma unroll 1
     for (int dir = 0; dir < 3; dir++) {
         C2<F> v[EPT];
 #pragma unroll
         for (int j = 0; j < EPT; j++) {
             const int ix = tau + T * j;
             const double k_finite = dir == 0 ? kt[ix] : (dir == 1 ? kt[iy] : kt[iz]);
-            const bool selfconj = yz_self && ix == (N - ix) % N;
+            const bool selfconj = yz_self && ix == (N - ix) % N;       // gravity.c:44-56
             if (selfconj) {
                 v[j].x = 0;
                 v[j].y = 0;
             } else {
-                v[j].x = (F) (-b[j].y * k_finite);
+                v[j].x = (F) (-b[j].y * k_finite);                     // gravity.c:58-60
                 v[j].y = (F) (b[j].x * k_finite);
             }
         }
         __syncthreads();
         fft_core<N, R2, R3, R4, +1>(v, lds, tw, tau, c);
         if (live) {
+            C2<F> *dst = outs[dir];
 #pragma unroll
-            for (int j = 0; j < EPT; j++) outs[dir][(long long) (tau + T * j) * rstride + col] = v[j];
+            for (int j = 0; j < EPT; j++) (dst + j * jstride)[toff] = v[j];
         }
     }
 }
@@ -331,15 +351,16 @@ static int colfft_launch(fpmhip_plan *p, int dir, const void *in, void *out, con
     const int tpb = (ncols + COLS - 1) / COLS;
     const int ntiles = tpb * nbatch;
     const size_t lds = (size_t) N * COLS * sizeof(C2<F>) + (size_t) N * sizeof(C2<F>);
+    const int grid = ntiles;
 #define CALL_PLAIN(n, r2, r3, r4)                                                                              \
     if (dir < 0) {                                                                                             \
         FPM_TRY(set_lds(colfft_kernel<n, r2, r3, r4, -1, F>, lds));                                            \
-        colfft_kernel<n, r2, r3, r4, -1, F><<<ntiles, n, lds, p->stream>>>((const C2<F> *) in, (C2<F> *) out,  \
+        colfft_kernel<n, r2, r3, r4, -1, F><<<grid, n, lds, p->stream>>>((const C2<F> *) in, (C2<F> *) out,  \
                                                                           im, om, ncols, tpb, ntiles,         \
                                                                           p->d_twiddle, (F) scale);           \
     } else {                                                                                                   \
         FPM_TRY(set_lds(colfft_kernel<n, r2, r3, r4, +1, F>, lds));                                            \
-        colfft_kernel<n, r2, r3, r4, +1, F><<<ntiles, n, lds, p->stream>>>((const C2<F> *) in, (C2<F> *) out,  \
+        colfft_kernel<n, r2, r3, r4, +1, F><<<grid, n, lds, p->stream>>>((const C2<F> *) in, (C2<F> *) out,  \
                                                                           im, om, ncols, tpb, ntiles,         \
                                                                           p->d_twiddle, (F) scale);           \
     }
@@ -383,9 +404,10 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
     const size_t lds = (size_t) N * COLS * sizeof(C2<F>) + (size_t) N * sizeof(C2<F>);
     const float *kk = p->d_tab + (2 + potorder) * (size_t) N;
     const float *kt = p->d_tab + gradorder * (size_t) N;
+    const int grid = ntiles;
 #define CALL_X3(n, r2, r3, r4)                                                                               \
     FPM_TRY(set_lds(colfft_xback3_kernel<n, r2, r3, r4, F>, lds));                                           \
-    colfft_xback3_kernel<n, r2, r3, r4, F><<<ntiles, n, lds, p->stream>>>(                                   \
+    colfft_xback3_kernel<n, r2, r3, r4, F><<<grid, n, lds, p->stream>>>(                                     \
         (const C2<F> *) dk, (C2<F> *) o0, (C2<F> *) o1, (C2<F> *) o2, plane, (int) plane, g.nzc, g.ystart,  \
         ntiles, kk, kt, p->d_twiddle);
     COLFFT_DISPATCH(N, CALL_X3)

@@ -9,6 +9,8 @@
 //   nranks  > 1 : slabs along x.  forward = batched 2-D (y,z) r2c in place on the slab, pack into
 //                 per-destination chunks, [all-to-all by the caller], strided 1-D c2c along x in
 //                 place on the received [x][y_loc][kz] block.  backward is the mirror image.
+#include <cstdlib>
+
 #include "fpm_internal.h"
 
 namespace fpm {
@@ -185,8 +187,14 @@ int fpmhip_r2c(fpmhip_plan *p, void *canvas, void *delta_k)
     if (canvas == delta_k) FPM_FAIL(-1, "pm_r2c is out of place (pmapi.h:97-100)");
     StageTimer tm(p, FPMHIP_T_R2C);
     if (p->own_fft) {
-        FPM_TRY(fft_exec(p, p->p_zr2c_op, canvas, delta_k));
-        FPM_TRY(colfft_y(p, -1, delta_k, delta_k, 0));
+        static int zip = getenv("FPMHIP_ZIP") ? atoi(getenv("FPMHIP_ZIP")) : 0;
+        if (zip) {   // z pass in place on the canvas, y pass moves the data to delta_k
+            FPM_TRY(fft_exec(p, p->p_zr2c_ip, canvas, nullptr));
+            FPM_TRY(colfft_y(p, -1, canvas, delta_k, 0));
+        } else {
+            FPM_TRY(fft_exec(p, p->p_zr2c_op, canvas, delta_k));
+            FPM_TRY(colfft_y(p, -1, delta_k, delta_k, 0));
+        }
         return colfft_x(p, -1, delta_k, delta_k, 1.0 / p->lay.Norm);
     }
     return fft_exec(p, p->p_r2c3d, canvas, delta_k);
@@ -213,8 +221,12 @@ int fpmhip_fft_yz_forward(fpmhip_plan *p, void *canvas, void *send)
         StageTimer tm(p, FPMHIP_T_R2C);
         if (p->lay.nranks == 1) {
             // one rank: the chunk layout is the natural one; z pass (out of place unless aliased), y in place
-            if (canvas == send) FPM_TRY(fft_exec(p, p->p_zr2c_ip, canvas, nullptr));
-            else FPM_TRY(fft_exec(p, p->p_zr2c_op, canvas, send));
+            static int zip = getenv("FPMHIP_ZIP") ? atoi(getenv("FPMHIP_ZIP")) : 0;
+            if (canvas == send || zip) {
+                FPM_TRY(fft_exec(p, p->p_zr2c_ip, canvas, nullptr));
+                return colfft_y(p, -1, canvas, send, 0);
+            }
+            FPM_TRY(fft_exec(p, p->p_zr2c_op, canvas, send));
             return colfft_y(p, -1, send, send, 0);
         }
         if (canvas == send) FPM_FAIL(-1, "fft_yz_forward: canvas and send must differ when nranks > 1");
