@@ -316,6 +316,59 @@ __global__ __launch_bounds__(N, 4) void colfft_xback3_kernel(const C2<F> *__rest
     }
 }
 
+// Forward z pass: real rows of N = 2M values -> N/2+1 complex values (the contiguous axis), one
+// read and one write of the mesh in ONE kernel (rocFFT's batched 1-D r2c takes two: an M-point
+// complex FFT and a separate `r2c_even_post`, 0.92 ms instead of 0.45 ms at 512^3 fp64).
+// A workgroup takes 8 adjacent rows; the row is read as M complex numbers z[n] = x[2n] + i x[2n+1],
+// transformed with the same register/LDS FFT core (thread (tau, c): row c, elements tau + T*j),
+// and untangled:  X[k] = E[k] + W_N^k O[k],  E = (Z[k] + conj Z[M-k]) / 2,  O = (Z[k] - conj Z[M-k]) / 2i.
+template <int M, int R2, int R3, int R4, typename F>
+__global__ __launch_bounds__(M) void rowfft_r2c_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ out,
+                                                       long long pitch, int nrows,
+                                                       const double *__restrict__ tw_global)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    C2<F> *lds = (C2<F> *) smem;
+    C2<F> *tw = lds + M * COLS;        // W_M^j, j < M
+    C2<F> *twn = tw + M;               // W_N^k, k < M  (N = 2M)
+    constexpr int T = M / EPT;
+    const int c = threadIdx.x % COLS, tau = threadIdx.x / COLS;
+    const long long row = (long long) blockIdx.x * COLS + c;
+    const bool live = row < nrows;
+    const C2<F> *src = in + row * pitch;
+    C2<F> v[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; j++) v[j] = live ? src[tau + T * j] : C2<F>{0, 0};
+    for (int i = threadIdx.x; i < M; i += blockDim.x) {
+        tw[i].x = (F) tw_global[4 * i];          // W_M^i = W_N^{2i}
+        tw[i].y = (F) tw_global[4 * i + 1];
+        twn[i].x = (F) tw_global[2 * i];
+        twn[i].y = (F) tw_global[2 * i + 1];
+    }
+    __syncthreads();
+    fft_core<M, R2, R3, R4, -1>(v, lds, tw, tau, c);
+    // exchange so that every thread can pair Z[k] with Z[M - k]
+#pragma unroll
+    for (int j = 0; j < EPT; j++) lds[(tau + T * j) * COLS + c] = v[j];
+    __syncthreads();
+    C2<F> *dst = out + row * pitch;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+        const int k = tau + T * j;
+        const C2<F> a = v[j];
+        C2<F> bq = lds[((M - k) & (M - 1)) * COLS + c];
+        bq.y = -bq.y;                                          // conj Z[M-k]
+        const C2<F> e = {(a.x + bq.x) * (F) 0.5, (a.y + bq.y) * (F) 0.5};
+        const C2<F> d = {(a.x - bq.x) * (F) 0.5, (a.y - bq.y) * (F) 0.5};
+        const C2<F> o = {d.y, -d.x};                           // d / i
+        const C2<F> x = cadd(e, cmul(twn[k], o));
+        if (live) {
+            dst[k] = x;
+            if (k == 0) dst[M] = C2<F>{a.x - a.y, 0};          // X[N/2] = Re Z0 - Im Z0
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -392,6 +445,32 @@ int colfft_y(fpmhip_plan *p, int dir, const void *in, void *out, int chunked)
     const ColMap &om = (chunked && dir < 0) ? chunks : natural;
     return p->f64 ? colfft_launch<double>(p, dir, in, out, im, om, g.xl, g.nzc, 1.0)
                   : colfft_launch<float>(p, dir, in, out, im, om, g.xl, g.nzc, 1.0);
+}
+
+template <typename F>
+static int rowfft_launch(fpmhip_plan *p, const void *in, void *out)
+{
+    const MeshGeo &g = p->mg;
+    const int M = g.N / 2;
+    const int nrows = g.xl * g.N;
+    const int nblocks = (nrows + COLS - 1) / COLS;
+    const size_t lds = (size_t) M * COLS * sizeof(C2<F>) + 2 * (size_t) M * sizeof(C2<F>);
+#define CALL_ROW(n, r2, r3, r4)                                                                         \
+    FPM_TRY(set_lds(rowfft_r2c_kernel<n, r2, r3, r4, F>, lds));                                         \
+    rowfft_r2c_kernel<n, r2, r3, r4, F><<<nblocks, n, lds, p->stream>>>((const C2<F> *) in, (C2<F> *) out, \
+                                                                        (long long) g.nzc, nrows, p->d_twiddle);
+    COLFFT_DISPATCH(M, CALL_ROW)
+#undef CALL_ROW
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// z pass forward (r2c) on [x_loc][y][N+2] real rows -> [x_loc][y][N/2+1]; in place or out of place
+bool rowfft_supported(int N) { return N >= 32 && colfft_supported(N / 2); }
+
+int rowfft_r2c(fpmhip_plan *p, const void *in, void *out)
+{
+    return p->f64 ? rowfft_launch<double>(p, in, out) : rowfft_launch<float>(p, in, out);
 }
 
 template <typename F>

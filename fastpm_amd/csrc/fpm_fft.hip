@@ -62,6 +62,15 @@ static int fft_exec(fpmhip_plan *p, rocfft_plan plan, void *in, void *out)
 
 static bool g_rocfft_ready = false;
 
+// forward z pass of the column-FFT back end: own fused r2c row kernel when N/2 is supported,
+// rocFFT's batched 1-D r2c (two kernels) otherwise
+static int z_forward(fpmhip_plan *p, void *in, void *out)
+{
+    if (rowfft_supported(p->mg.N)) return rowfft_r2c(p, in, out);
+    if (in == out) return fft_exec(p, p->p_zr2c_ip, in, nullptr);
+    return fft_exec(p, p->p_zr2c_op, in, out);
+}
+
 int fft_setup(fpmhip_plan *p)
 {
     if (!g_rocfft_ready) {
@@ -187,14 +196,8 @@ int fpmhip_r2c(fpmhip_plan *p, void *canvas, void *delta_k)
     if (canvas == delta_k) FPM_FAIL(-1, "pm_r2c is out of place (pmapi.h:97-100)");
     StageTimer tm(p, FPMHIP_T_R2C);
     if (p->own_fft) {
-        static int zip = getenv("FPMHIP_ZIP") ? atoi(getenv("FPMHIP_ZIP")) : 0;
-        if (zip) {   // z pass in place on the canvas, y pass moves the data to delta_k
-            FPM_TRY(fft_exec(p, p->p_zr2c_ip, canvas, nullptr));
-            FPM_TRY(colfft_y(p, -1, canvas, delta_k, 0));
-        } else {
-            FPM_TRY(fft_exec(p, p->p_zr2c_op, canvas, delta_k));
-            FPM_TRY(colfft_y(p, -1, delta_k, delta_k, 0));
-        }
+        FPM_TRY(z_forward(p, canvas, delta_k));
+        FPM_TRY(colfft_y(p, -1, delta_k, delta_k, 0));
         return colfft_x(p, -1, delta_k, delta_k, 1.0 / p->lay.Norm);
     }
     return fft_exec(p, p->p_r2c3d, canvas, delta_k);
@@ -221,18 +224,13 @@ int fpmhip_fft_yz_forward(fpmhip_plan *p, void *canvas, void *send)
         StageTimer tm(p, FPMHIP_T_R2C);
         if (p->lay.nranks == 1) {
             // one rank: the chunk layout is the natural one; z pass (out of place unless aliased), y in place
-            static int zip = getenv("FPMHIP_ZIP") ? atoi(getenv("FPMHIP_ZIP")) : 0;
-            if (canvas == send || zip) {
-                FPM_TRY(fft_exec(p, p->p_zr2c_ip, canvas, nullptr));
-                return colfft_y(p, -1, canvas, send, 0);
-            }
-            FPM_TRY(fft_exec(p, p->p_zr2c_op, canvas, send));
+            FPM_TRY(z_forward(p, canvas, send));
             return colfft_y(p, -1, send, send, 0);
         }
         if (canvas == send) FPM_FAIL(-1, "fft_yz_forward: canvas and send must differ when nranks > 1");
         // z pass in place on the slab, then the y pass writes straight into the exchange chunks
         // [rank][x_loc][y_loc][kz] (pack fused into the pass)
-        FPM_TRY(fft_exec(p, p->p_zr2c_ip, canvas, nullptr));
+        FPM_TRY(z_forward(p, canvas, canvas));
         return colfft_y(p, -1, canvas, send, 1);
     }
     {

@@ -159,6 +159,8 @@ void fft_teardown(fpmhip_plan *p);
 bool colfft_supported(int N);
 int colfft_x(fpmhip_plan *p, int dir, const void *in, void *out, double scale);
 int colfft_y(fpmhip_plan *p, int dir, const void *in, void *out, int chunked);
+bool rowfft_supported(int N);
+int rowfft_r2c(fpmhip_plan *p, const void *in, void *out);
 int colfft_xback3(fpmhip_plan *p, const void *dk, void *o0, void *o1, void *o2, int potorder, int gradorder);
 
 // fpm_force.hip

@@ -1,0 +1,111 @@
+"""Parity at the BASELINE.json configuration sizes.
+
+configs[0] (tests/standard.lua: 128^3 particles, 256^3 mesh; the file itself says pm_nc_factor = 3,
+i.e. 384^3 -- both are run) against the oracle directly (the oracle needs a few seconds there);
+configs[1] (256^3 particles, 512^3 mesh, fp64) through size-independent properties, since the CPU
+oracle is too slow to be a unit test at that size:
+  * momentum conservation: sum_i acc_i = 0 for equal masses (the PM force is antisymmetric),
+  * the DC mode of delta_k is exactly the mean density 1 and P(k) is finite and positive,
+  * decomposition invariance: 2 virtual slab ranks reproduce the one-rank accelerations,
+  * the fp32-mesh build agrees with the fp64-mesh build: acc to 1e-4 of rms, P(k) to < 1 % up to
+    k_Nyquist / 2 (the metric's accuracy half, BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("Nmesh,precision", [(256, 32), (256, 64), (384, 32)])
+def test_config0_standard_lua_sizes(oracle, Nmesh, precision):
+    import torch
+    from fastpm_amd import PM, Store
+    nc, L = 128, 384.0                                    # tests/standard.lua:5-6
+    x = util.load_b(nc, L, Nmesh, rms_cells=3.0)
+    pmo = oracle.PMOracle(Nmesh, L, precision, threads=8)
+    ref = oracle.compute_force(pmo, x)
+    pm = PM(Nmesh, L, precision)
+    st = Store(x)
+    dk = pm.alloc()
+    pm.compute_force(st, kernel="1_4", softening="none", delta_k=dk)
+    torch.cuda.synchronize()
+    tol_acc, tol_dk = (1e-6, 1e-14) if precision == 64 else (3e-5, 5e-7)
+    assert util.rel_err(st.acc.cpu().numpy(), ref["acc"]) <= tol_acc
+    assert util.max_err(pm.complex_view(dk).cpu().numpy(), util.oracle_k_to_xyk(pmo, ref["delta_k"])) <= tol_dk
+    # P(k) of the de-CIC'ed field, reference estimator on both sides: < 1e-6 (bins are double sums)
+    dko = pmo.alloc()
+    pmo.decic(ref["delta_k"], dko)
+    k1, p1, n1 = oracle.powerspectrum_finalize(*pmo.powerspectrum_sums(dko), L)
+    pm.apply_decic_transfer(dk, dk)
+    k2, p2, n2 = pm.powerspectrum(dk)
+    sel = np.arange(len(p1)) <= Nmesh // 4
+    assert np.array_equal(n1, n2)
+    assert np.abs(p2[sel][1:] / p1[sel][1:] - 1).max() <= (1e-9 if precision == 64 else 1e-4)
+    pm.destroy()
+
+
+def _config1_particles():
+    import torch
+    nc, N = 256, 512
+    L = 3.0 * nc
+    h = L / N
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(99)
+    g = (torch.arange(nc, device="cuda", dtype=torch.float64) + 0.5) * (L / nc)
+    q = torch.stack(torch.meshgrid(g, g, g, indexing="ij"), dim=-1).reshape(-1, 3)
+    d = torch.randn(q.shape, generator=gen, device="cuda", dtype=torch.float64) * (0.3 * h)
+    d.clamp_(-0.95 * h, 0.95 * h)
+    return torch.remainder(q + d, L).contiguous(), nc, N, L
+
+
+def test_config1_properties():
+    import torch
+    from fastpm_amd import PM, Store
+    from fastpm_amd.distributed import SlabForce, run_virtual
+    x, nc, N, L = _config1_particles()
+    pm = PM(N, L, 64)
+    st = Store(x)
+    dk = pm.alloc()
+    pm.compute_force(st, delta_k=dk)
+    torch.cuda.synchronize()
+    acc = st.acc.double()
+    rms = float(acc.pow(2).mean().sqrt())
+    assert torch.isfinite(acc).all() and rms > 0
+    assert float(acc.sum(0).abs().max()) / (rms * len(acc) ** 0.5) < 1e-3          # momentum conservation
+    c = pm.complex_view(dk)
+    assert abs(complex(c[0, 0, 0].item()) - 1.0) < 1e-12                              # mean of 1 + delta
+    pm.apply_decic_transfer(dk, dk)
+    k64, p64, n64 = pm.powerspectrum(dk)
+    assert np.all(np.isfinite(p64)) and np.all(p64[1:] > 0) and n64[1] == 18
+    acc64 = st.acc.clone()
+    del c, dk
+    pm.destroy()
+
+    # fp32 mesh vs fp64 mesh
+    pm32 = PM(N, L, 32)
+    st32 = Store(x)
+    dk32 = pm32.alloc()
+    pm32.compute_force(st32, delta_k=dk32)
+    pm32.apply_decic_transfer(dk32, dk32)
+    k32, p32, n32 = pm32.powerspectrum(dk32)
+    torch.cuda.synchronize()
+    assert float((st32.acc - acc64).abs().max()) / rms < 1e-4
+    sel = slice(1, N // 4 + 1)
+    assert np.abs(p32[sel] / p64[sel] - 1).max() < 1e-2
+    del dk32
+    pm32.destroy()
+
+    # decomposition invariance: two virtual slab ranks on this GPU
+    P = 2
+    owner = (torch.floor(x[:, 0] * (1.0 / (L / N))).long() % N) // (N // P)
+    idx = [torch.nonzero(owner == r)[:, 0] for r in range(P)]
+    pms = [PM(N, L, 64, nranks=P, rank=r) for r in range(P)]
+    stores = [Store(x[idx[r]].contiguous()) for r in range(P)]
+    forces = [SlabForce(p) for p in pms]
+    run_virtual(forces, stores)
+    torch.cuda.synchronize()
+    for r in range(P):
+        assert float((stores[r].acc - acc64[idx[r]]).abs().max()) / rms < 1e-6
+    for p in pms:
+        p.destroy()
