@@ -63,24 +63,74 @@ def algorithmic_bytes(np_local, Nmesh, nranks, esize):
     }
 
 
-def cpu_baseline(nthreads):
+def pmc_traffic(stage, Nmesh, np_total, args, world):
+    """HBM bytes per launch of `stage` from the committed PMC profile (rocprofv3 cannot run inside
+    the bench): profiles/r01_c_traffic.json, only when the configuration matches the profiled one."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_c_traffic.json")))
+        c = t["config"]
+        if (c["nmesh"], c["particles"], c["precision"], c["n_gpus"]) != (Nmesh, np_total, args.precision, world):
+            return None
+        if args.fft_mode != 0 or args.paint_mode != 0:
+            return None
+        return t["hbm_bytes_per_launch_by_stage"].get(stage)
+    except Exception:
+        return None
+
+
+def cpu_baseline(ncores, x_dev, Nmesh, BoxSize, acc_dev, pm):
     """The CPU oracle (kind "port": our C/OpenMP restatement of the reference's algorithm +
-    scipy pocketfft) timed on a bounded sample of the N = 1 workload: the same load at 1/8 scale
-    (128^3 particles on a 256^3 fp64 mesh, B = 2 as in configs[1]), one force call."""
+    scipy pocketfft) timed on the box's host cores: a quick thread-count sweep at 1/8 scale picks
+    the best OpenMP width, then ONE force call of the full N = 1 workload (the very particles the
+    GPU just ran) is timed.  Its result doubles as the parity check of the metric's accuracy half:
+    acceleration parity and P(k) relative error up to k_Nyquist / 2 (reference estimator
+    powerspectrum.c:35-124 on the de-CIC'ed delta_k, transfer.c:77-113)."""
     from oracle import pm_oracle
     nc, N = 128, 256
     L = 3.0 * nc
     rng = np.random.Generator(np.random.PCG64(1234))
     g = (np.arange(nc) + 0.5) * L / nc
     q = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
-    x = np.remainder(q + rng.normal(0.0, 0.3 * L / N, q.shape), L)
-    pmo = pm_oracle.PMOracle(N, L, 64, threads=nthreads)
+    xs = np.remainder(q + rng.normal(0.0, 0.3 * L / N, q.shape), L)
+    best = None
+    tried = []
+    for nth in sorted({min(ncores, t) for t in (16, 32, 64, ncores)}):
+        pmo = pm_oracle.PMOracle(N, L, 64, threads=nth)
+        t0 = time.perf_counter()
+        pm_oracle.compute_force(pmo, xs)
+        dt = time.perf_counter() - t0
+        tried.append("%d thr %.2f s" % (nth, dt))
+        if best is None or dt < best[0]:
+            best = (dt, nth)
+    nth = best[1]
+    # the full workload, once
+    x = x_dev.cpu().numpy()
+    pmo = pm_oracle.PMOracle(Nmesh, BoxSize, 64, threads=nth)
     t0 = time.perf_counter()
-    pm_oracle.compute_force(pmo, x)
+    ref = pm_oracle.compute_force(pmo, x)
     dt = time.perf_counter() - t0
-    return {"value": len(x) / dt, "unit": "particle-updates/s", "cores": nthreads, "kind": "port",
-            "sample": "1 force call, 128^3 particles on 256^3 fp64 mesh (configs[1] at 1/8 scale), "
-                      "oracle/pm_oracle.c OpenMP + scipy.fft, %.2f s" % dt}
+    # parity of the GPU run on the same particles
+    dk = pm.alloc()
+    from fastpm_amd import Store
+    st = Store(x_dev)
+    pm.compute_force(st, kernel="1_4", softening="none", delta_k=dk)
+    pm.apply_decic_transfer(dk, dk)
+    kg, pg, ng = pm.powerspectrum(dk)
+    acc = st.acc.cpu().numpy()
+    dko = pmo.alloc()
+    pmo.decic(ref["delta_k"], dko)
+    ko, po, no = pm_oracle.powerspectrum_finalize(*pmo.powerspectrum_sums(dko), BoxSize)
+    sel = slice(1, Nmesh // 4 + 1)                                  # up to k_Nyquist / 2
+    pk_err = float(np.abs(pg[sel] / po[sel] - 1).max())
+    rms = float(np.sqrt((ref["acc"].astype(np.float64) ** 2).mean()))
+    acc_err = float(np.abs(acc - ref["acc"]).max() / rms)
+    base = {"value": len(x) / dt, "unit": "particle-updates/s", "cores": nth, "kind": "port",
+            "sample": "1 force call of the full workload (%d particles, %d^3 fp64 mesh) in %.2f s with %d OpenMP "
+                      "threads + scipy.fft workers on %d host cores (oracle/pm_oracle.c); width chosen by a "
+                      "1/8-scale sweep: %s" % (len(x), Nmesh, dt, nth, ncores, ", ".join(tried))}
+    parity = {"sample": "GPU vs CPU oracle on the full workload's particles",
+              "pk_rel_err_max_to_half_nyquist": pk_err, "acc_max_err_over_rms": acc_err}
+    return base, parity
 
 
 def main():
@@ -179,7 +229,7 @@ def main():
         avg_s = tm[dom][0] / tm[dom][1] * 1e-3
         achieved = ab[dom] / avg_s / 1e9
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, Nmesh, np_total, args, world),
                     "alg_bytes_per_launch": ab[dom], "avg_launch_ms": round(avg_s * 1e3, 4)}
         b_alg = 60 * np_local + 12 * esize * (Nmesh * Nmesh * (Nmesh + 2) // world)
         out = {
@@ -199,7 +249,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+                out["cpu_baseline"], out["parity"] = cpu_baseline(os.cpu_count() or 1, x, Nmesh, BoxSize,
+                                                                  store.acc, pm)
             except Exception as e:      # the baseline is a report, never the product
                 out["cpu_baseline"] = {"value": None, "unit": "particle-updates/s", "cores": 0,
                                        "kind": "port", "sample": "failed: %r" % (e,)}

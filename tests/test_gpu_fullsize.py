@@ -77,7 +77,7 @@ def test_config1_properties():
     assert abs(complex(c[0, 0, 0].item()) - 1.0) < 1e-12                              # mean of 1 + delta
     pm.apply_decic_transfer(dk, dk)
     k64, p64, n64 = pm.powerspectrum(dk)
-    assert np.all(np.isfinite(p64)) and np.all(p64[1:] > 0) and n64[1] == 18
+    assert np.all(np.isfinite(p64)) and np.all(p64[1:] > 0) and n64[1] == 26
     acc64 = st.acc.clone()
     del c, dk
     pm.destroy()
