@@ -1,0 +1,113 @@
+// fpm_step.hip -- the particle updates either side of the force step ("next" row 1 of the scope):
+//   kick   (reference libfastpm/factors.c:136-171 fastpm_kick_one, :175-197 fastpm_kick_store)
+//   drift  (reference libfastpm/factors.c:72-110 fastpm_drift_one, :373-392 fastpm_drift_store)
+//   wrap   (reference libfastpm/store.c:446-475 fastpm_store_wrap)
+// Pure streaming kernels (kick: read acc 12 + v 12 [+ dx1, dx2 24], write v 12 B per particle;
+// drift: read x 24 + v 12 [+24], write x 24).  The factor tables (32 samples from GSL growth
+// integrals, factors.c:233-371) stay on the host; the kernels get the looked-up scalars.
+// Arithmetic follows the reference's float/double promotion line by line; no FMA contraction.
+#include "fpm_internal.h"
+
+namespace fpm {
+
+static inline unsigned blocks_for(long long n, int bs) { return (unsigned) ((n + bs - 1) / bs); }
+
+// one thread per (particle, component): the three components are independent
+__global__ __launch_bounds__(256) void kick_kernel(const float *__restrict__ acc, const float *__restrict__ v,
+                                                   const float *__restrict__ dx1, const float *__restrict__ dx2,
+                                                   float *__restrict__ vo, long long n3, fpmhip_kick_factor k)
+{
+    long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n3) return;
+    float ax = acc[i];                                                  // factors.c:153
+    if (k.forcemode == FPMHIP_FORCE_COLA) ax += (dx1[i] * k.q1 + dx2[i] * k.q2);   // :154-156 (double sum -> float)
+    float out = v[i] + ax * k.dda;                                      // :157 float + float*double -> float
+    if (k.forcemode == FPMHIP_FORCE_COLA) out += (dx1[i] * k.Dv1 + dx2[i] * k.Dv2);   // :158-160
+    vo[i] = out;
+}
+
+__global__ __launch_bounds__(256) void drift_kernel(const double *__restrict__ x, const float *__restrict__ v,
+                                                    const float *__restrict__ dx1, const float *__restrict__ dx2,
+                                                    double *__restrict__ xo, long long n3, fpmhip_drift_factor f)
+{
+    long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n3) return;
+    double out;
+    switch (f.forcemode) {                                              // factors.c:90-108
+    case FPMHIP_FORCE_2LPT:
+        out = x[i] + dx1[i] * f.da1 + dx2[i] * f.da2;
+        break;
+    case FPMHIP_FORCE_ZA:
+        out = x[i] + dx1[i] * f.da1;
+        break;
+    case FPMHIP_FORCE_COLA: {
+        double vv = v[i] - (dx1[i] * f.Dv1 + dx2[i] * f.Dv2);
+        out = x[i] + vv * f.dyyy;
+        out += dx1[i] * f.da1 + dx2[i] * f.da2;
+        break;
+    }
+    default:   // FASTPM, PM
+        out = x[i] + v[i] * f.dyyy;
+        break;
+    }
+    xo[i] = out;
+}
+
+__global__ __launch_bounds__(256) void wrap_kernel(double *__restrict__ x, long long n3, double BoxSize)
+{
+    long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n3) return;
+    double x1 = remainder(x[i], BoxSize);                               // store.c:454
+    while (x1 < 0) x1 += BoxSize;
+    while (x1 > BoxSize) x1 -= BoxSize;
+    x[i] = x1;
+}
+
+}  // namespace fpm
+
+using namespace fpm;
+
+extern "C" {
+
+int fpmhip_kick(fpmhip_plan *p, const float *acc, const float *v_in, const float *dx1, const float *dx2,
+                float *v_out, int64_t np, const fpmhip_kick_factor *kick)
+{
+    if (!p || !kick || (np > 0 && (!acc || !v_in || !v_out))) FPM_FAIL(-1, "null argument");
+    if (kick->forcemode < FPMHIP_FORCE_FASTPM || kick->forcemode > FPMHIP_FORCE_ZA) FPM_FAIL(-1, "bad force mode %d", kick->forcemode);
+    if (kick->forcemode == FPMHIP_FORCE_COLA && (!dx1 || !dx2)) FPM_FAIL(-1, "COLA kick needs dx1 and dx2 (solver.c:83-87)");
+    if (np == 0) return 0;
+    kick_kernel<<<blocks_for(3 * np, 256), 256, 0, p->stream>>>(acc, v_in, dx1, dx2, v_out, 3 * np, *kick);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int fpmhip_drift(fpmhip_plan *p, const double *x_in, const float *v, const float *dx1, const float *dx2,
+                 double *x_out, int64_t np, const fpmhip_drift_factor *drift)
+{
+    if (!p || !drift || (np > 0 && (!x_in || !x_out))) FPM_FAIL(-1, "null argument");
+    const int m = drift->forcemode;
+    if (m < FPMHIP_FORCE_FASTPM || m > FPMHIP_FORCE_ZA) FPM_FAIL(-1, "bad force mode %d", m);
+    if ((m == FPMHIP_FORCE_FASTPM || m == FPMHIP_FORCE_PM || m == FPMHIP_FORCE_COLA) && np > 0 && !v) FPM_FAIL(-1, "drift needs the v column");
+    if ((m == FPMHIP_FORCE_COLA || m == FPMHIP_FORCE_2LPT) && np > 0 && (!dx1 || !dx2)) FPM_FAIL(-1, "this drift needs dx1 and dx2");
+    if (m == FPMHIP_FORCE_ZA && np > 0 && !dx1) FPM_FAIL(-1, "ZA drift needs dx1");
+    if (np == 0) return 0;
+    drift_kernel<<<blocks_for(3 * np, 256), 256, 0, p->stream>>>(x_in, v, dx1, dx2, x_out, 3 * np, *drift);
+    FPM_CHECK_HIP(hipGetLastError());
+    // positions moved: the tile binning of the last paint no longer describes them
+    p->binned_np = -1;
+    p->binned_x = nullptr;
+    return 0;
+}
+
+int fpmhip_wrap(fpmhip_plan *p, double *x, int64_t np)
+{
+    if (!p || (np > 0 && !x)) FPM_FAIL(-1, "null argument");
+    if (np == 0) return 0;
+    wrap_kernel<<<blocks_for(3 * np, 256), 256, 0, p->stream>>>(x, 3 * np, p->geom.BoxSize);
+    FPM_CHECK_HIP(hipGetLastError());
+    p->binned_np = -1;
+    p->binned_x = nullptr;
+    return 0;
+}
+
+}  // extern "C"

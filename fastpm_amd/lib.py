@@ -31,6 +31,16 @@ class Particles(ctypes.Structure):
                 ("np", ctypes.c_int64), ("acc", ctypes.c_void_p), ("potential", ctypes.c_void_p)]
 
 
+class KickFactor(ctypes.Structure):
+    _fields_ = [("forcemode", ctypes.c_int32), ("pad", ctypes.c_int32), ("dda", ctypes.c_double),
+                ("Dv1", ctypes.c_double), ("Dv2", ctypes.c_double), ("q1", ctypes.c_double), ("q2", ctypes.c_double)]
+
+
+class DriftFactor(ctypes.Structure):
+    _fields_ = [("forcemode", ctypes.c_int32), ("pad", ctypes.c_int32), ("dyyy", ctypes.c_double),
+                ("da1", ctypes.c_double), ("da2", ctypes.c_double), ("Dv1", ctypes.c_double), ("Dv2", ctypes.c_double)]
+
+
 # every symbol include/fastpm_hip.h declares: name -> (restype, argtypes)
 _P, _I, _D, _I64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_int64
 _PI = ctypes.POINTER(ctypes.c_int)
@@ -69,6 +79,9 @@ SYMBOLS = {
     "fpmhip_powerspectrum": (_I, [_P, _P, _P, _P, _P, _P]),
     "fpmhip_check_values": (_I, [_P, _P, ctypes.POINTER(_I64)]),
     "fpmhip_export_delta_k": (_I, [_P, _P, _P]),
+    "fpmhip_kick": (_I, [_P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(KickFactor)]),
+    "fpmhip_drift": (_I, [_P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(DriftFactor)]),
+    "fpmhip_wrap": (_I, [_P, _P, _I64]),
     "fpmhip_timing_enable": (_I, [_P, _I]),
     "fpmhip_timing_reset": (_I, [_P]),
     "fpmhip_timing_get": (_I, [_P, _I, ctypes.POINTER(_D), ctypes.POINTER(_I64)]),

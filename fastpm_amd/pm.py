@@ -60,10 +60,14 @@ class Store:
     x float64 [np][3], mass float32 [np] or None (+ meta.M0), acc float32 [np][3],
     potential float32 [np] or None."""
 
-    def __init__(self, x, mass=None, M0=1.0, potential=False, device="cuda"):
+    def __init__(self, x, mass=None, M0=1.0, potential=False, device="cuda", v=None, dx1=None, dx2=None,
+                 a_x=1.0, a_v=1.0):
         self.x = torch.as_tensor(x, dtype=torch.float64, device=device).contiguous()
         assert self.x.ndim == 2 and self.x.shape[1] == 3
         self.np = int(self.x.shape[0])
+        col = lambda c: None if c is None else torch.as_tensor(c, dtype=torch.float32, device=device).contiguous()
+        self.v, self.dx1, self.dx2 = col(v), col(dx1), col(dx2)       # store.h:108-112
+        self.a_x, self.a_v = float(a_x), float(a_v)                   # meta.a_x / meta.a_v, store.h:91-93
         self.mass = None if mass is None else torch.as_tensor(mass, dtype=torch.float32, device=device).contiguous()
         self.M0 = float(M0)
         self.acc = torch.zeros((self.np, 3), dtype=torch.float32, device=self.x.device)
@@ -78,6 +82,72 @@ class Store:
         c.acc = self.acc.data_ptr()
         c.potential = 0 if self.potential is None else self.potential.data_ptr()
         return c
+
+
+FORCE_TYPES = {"fastpm": 0, "pm": 1, "cola": 2, "2lpt": 3, "za": 4}      # libfastpm.h:39-44
+
+
+class _Factor:
+    """The 32-sample tables FastPMKickFactor / FastPMDriftFactor carry (api/fastpm/solver.h:20-58),
+    filled by the caller (fastpm_kick_init / fastpm_drift_init need the GSL growth integrals and
+    stay on the host), and the lookup of factors.c:38-69 / :112-134."""
+
+    def __init__(self, forcemode, ai, ac, af, t0, t1, t2):
+        self.forcemode = _enum(FORCE_TYPES, forcemode)
+        self.ai, self.ac, self.af = float(ai), float(ac), float(af)
+        self.t = [np.asarray(t, dtype=np.float64) for t in (t0, t1, t2)]
+        self.nsamples = len(self.t[0])
+
+    def lookup(self, a):
+        if a == self.af:
+            return tuple(t[-1] for t in self.t)
+        if a == self.ai:
+            return tuple(t[0] for t in self.t)
+        ind = (a - self.ai) / (self.af - self.ai) * (self.nsamples - 1)
+        l = int(np.floor(ind))
+        u, v = l + 1 - ind, ind - l
+        if l + 1 >= self.nsamples or l < 0:
+            raise FastPMHipError("kick/drift beyond factor's available range. ")
+        return tuple(t[l] * u + t[l + 1] * v for t in self.t)
+
+
+class KickFactor(_Factor):
+    """tables dda, Dv1, Dv2; q1, q2 for the COLA force (factors.c:233-311)."""
+
+    def __init__(self, forcemode, ai, ac, af, dda, Dv1, Dv2, q1=0.0, q2=0.0):
+        super().__init__(forcemode, ai, ac, af, dda, Dv1, Dv2)
+        self.q1, self.q2 = float(q1), float(q2)
+
+
+class DriftFactor(_Factor):
+    """tables dyyy, da1, da2; Dv1, Dv2 at ac for COLA (factors.c:313-371)."""
+
+    def __init__(self, forcemode, ai, ac, af, dyyy, da1, da2, Dv1=0.0, Dv2=0.0):
+        super().__init__(forcemode, ai, ac, af, dyyy, da1, da2)
+        self.Dv1, self.Dv2 = float(Dv1), float(Dv2)
+
+
+def fastpm_kick_store(pm, kick, pi, po, af):
+    """fastpm_kick_store(kick, pi, po, af), factors.c:175-197, on the device columns."""
+    f, i = kick.lookup(af), kick.lookup(pi.a_v)
+    k = _lib.KickFactor(kick.forcemode, 0, f[0] - i[0], f[1] - i[1], f[2] - i[2], kick.q1, kick.q2)
+    check(pm._L.fpmhip_kick(pm._plan, _ptr(pi.acc), _ptr(pi.v), _ptr(pi.dx1), _ptr(pi.dx2), _ptr(po.v), pi.np,
+                            ctypes.byref(k)))
+    po.a_v = af
+
+
+def fastpm_drift_store(pm, drift, pi, po, af):
+    """fastpm_drift_store(drift, pi, po, af), factors.c:373-392, on the device columns."""
+    f, i = drift.lookup(af), drift.lookup(pi.a_x)
+    d = _lib.DriftFactor(drift.forcemode, 0, f[0] - i[0], f[1] - i[1], f[2] - i[2], drift.Dv1, drift.Dv2)
+    check(pm._L.fpmhip_drift(pm._plan, _ptr(pi.x), _ptr(pi.v), _ptr(pi.dx1), _ptr(pi.dx2), _ptr(po.x), pi.np,
+                             ctypes.byref(d)))
+    po.a_x = af
+
+
+def fastpm_store_wrap(pm, p):
+    """fastpm_store_wrap(p, BoxSize), store.c:446-475, in place on the device column."""
+    check(pm._L.fpmhip_wrap(pm._plan, _ptr(p.x), p.np))
 
 
 class PM:

@@ -189,6 +189,24 @@ int fpmhip_check_values(fpmhip_plan *plan, const void *mesh_dev, int64_t *count_
 /* copy a k-space mesh to the host in the reference's PFFT-transposed layout [y][z][x] */
 int fpmhip_export_delta_k(fpmhip_plan *plan, const void *delta_k_dev, void *delta_k_host);
 
+/* ---- "next" row 1: the particle updates either side of the force step, device-resident ----
+ * FastPMForceType, api/fastpm/libfastpm.h:39-44 */
+enum { FPMHIP_FORCE_FASTPM = 0, FPMHIP_FORCE_PM, FPMHIP_FORCE_COLA, FPMHIP_FORCE_2LPT, FPMHIP_FORCE_ZA };
+/* The scalars fastpm_kick_one derives from FastPMKickFactor by two table lookups
+ * (libfastpm/factors.c:136-148): dda = dda(af) - dda(a_v), likewise Dv1, Dv2; q1, q2 as stored. */
+typedef struct { int32_t forcemode, pad; double dda, Dv1, Dv2, q1, q2; } fpmhip_kick_factor;
+/* Same for FastPMDriftFactor (factors.c:72-86): dyyy, da1, da2 differences; Dv1, Dv2 as stored. */
+typedef struct { int32_t forcemode, pad; double dyyy, da1, da2, Dv1, Dv2; } fpmhip_drift_factor;
+/* fastpm_kick_store (factors.c:175-197): v_out = v_in + acc * dda (+ COLA terms); columns float[np][3] */
+int fpmhip_kick(fpmhip_plan *plan, const float *acc_dev, const float *v_in_dev, const float *dx1_dev,
+                const float *dx2_dev, float *v_out_dev, int64_t np, const fpmhip_kick_factor *kick);
+/* fastpm_drift_store (factors.c:373-392): x_out = x_in + v * dyyy (PM / FASTPM), or the 2LPT / ZA /
+ * COLA forms of fastpm_drift_one; x double[np][3] */
+int fpmhip_drift(fpmhip_plan *plan, const double *x_in_dev, const float *v_dev, const float *dx1_dev,
+                 const float *dx2_dev, double *x_out_dev, int64_t np, const fpmhip_drift_factor *drift);
+/* fastpm_store_wrap (store.c:446-475): x = remainder(x, BoxSize) shifted into [0, BoxSize], in place */
+int fpmhip_wrap(fpmhip_plan *plan, double *x_dev, int64_t np);
+
 /* ---- per-stage timing with HIP events on the plan's stream (the reference's CLOCK names,
  *      gravity.c:276,320,344,348,369-372,474) ---- */
 enum { FPMHIP_T_SORT = 0, FPMHIP_T_PAINT, FPMHIP_T_R2C, FPMHIP_T_DEALIAS, FPMHIP_T_TRANSFER,

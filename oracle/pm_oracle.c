@@ -163,6 +163,69 @@ int64_t orc_ghost_pairs(int64_t N, double BoxSize, const int64_t *edges_x, int n
     return count;
 }
 
+/* factors.c:38-69 fastpm_drift_lookup == :112-134 fastpm_kick_lookup: linear interpolation in a
+ * table of nsamples values spanning [ai, af]; exact end points.  Returns -1 beyond the range
+ * (the reference raises). */
+int orc_factor_lookup(double ai, double af_table, int nsamples, const double *t0, const double *t1,
+                      const double *t2, double a, double *o0, double *o1, double *o2)
+{
+    if (a == af_table) {
+        *o0 = t0[nsamples - 1]; *o1 = t1[nsamples - 1]; *o2 = t2[nsamples - 1];
+        return 0;
+    }
+    if (a == ai) {
+        *o0 = t0[0]; *o1 = t1[0]; *o2 = t2[0];
+        return 0;
+    }
+    double ind = (a - ai) / (af_table - ai) * (nsamples - 1);
+    int l = floor(ind);
+    double u = l + 1 - ind;
+    double v = ind - l;
+    if (l + 1 >= nsamples) return -1;
+    *o0 = t0[l] * u + t0[l + 1] * v;
+    *o1 = t1[l] * u + t1[l + 1] * v;
+    *o2 = t2[l] * u + t2[l + 1] * v;
+    return 0;
+}
+
+/* factors.c:136-171 fastpm_kick_one over a store (:175-197); dda, Dv1, Dv2 are the f - i differences */
+void orc_kick(int forcemode, double dda, double Dv1, double Dv2, double q1, double q2, const float *acc,
+              const float *v, const float *dx1, const float *dx2, float *vo_, int64_t np)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < np; i++)
+        for (int d = 0; d < 3; d++) {
+            float ax = acc[3 * i + d];
+            if (forcemode == 2) ax += (dx1[3 * i + d] * q1 + dx2[3 * i + d] * q2);
+            float vo = v[3 * i + d] + ax * dda;
+            if (forcemode == 2) vo += (dx1[3 * i + d] * Dv1 + dx2[3 * i + d] * Dv2);
+            vo_[3 * i + d] = vo;
+        }
+}
+
+/* factors.c:72-110 fastpm_drift_one over a store (:373-392), without the PGD term (:103-108) */
+void orc_drift(int forcemode, double dyyy, double da1, double da2, double Dv1, double Dv2, const double *x,
+               const float *v, const float *dx1, const float *dx2, double *xo_, int64_t np)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < np; i++)
+        for (int d = 0; d < 3; d++) {
+            const int64_t j = 3 * i + d;
+            double xo = 0, vv;
+            switch (forcemode) {
+            case 3: xo = x[j] + dx1[j] * da1 + dx2[j] * da2; break;             /* 2LPT */
+            case 4: xo = x[j] + dx1[j] * da1; break;                            /* ZA */
+            case 0: case 1: xo = x[j] + v[j] * dyyy; break;                     /* FASTPM, PM */
+            case 2:                                                             /* COLA */
+                vv = v[j] - (dx1[j] * Dv1 + dx2[j] * Dv2);
+                xo = x[j] + vv * dyyy;
+                xo += dx1[j] * da1 + dx2[j] * da2;
+                break;
+            }
+            xo_[j] = xo;
+        }
+}
+
 #define F float
 #define SUF f32
 #include "pm_oracle_impl.h"

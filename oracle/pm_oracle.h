@@ -87,6 +87,15 @@ ORC_DECL(f64, double)
 void orc_reduce_add_float(float *dest, const float *src, const int32_t *ighost_to_ipar,
                           int64_t nghost, int nmemb);
 
+/* factors.c:38-69 / :112-134 table lookup; :136-197 kick; :72-110, :373-392 drift.
+ * forcemode values = FastPMForceType (libfastpm.h:39-44): FASTPM 0, PM 1, COLA 2, 2LPT 3, ZA 4 */
+int orc_factor_lookup(double ai, double af_table, int nsamples, const double *t0, const double *t1,
+                      const double *t2, double a, double *o0, double *o1, double *o2);
+void orc_kick(int forcemode, double dda, double Dv1, double Dv2, double q1, double q2, const float *acc,
+              const float *v, const float *dx1, const float *dx2, float *vo, int64_t np);
+void orc_drift(int forcemode, double dyyy, double da1, double da2, double Dv1, double Dv2, const double *x,
+               const float *v, const float *dx1, const float *dx2, double *xo, int64_t np);
+
 /* store.c:446-475: wrap positions into [0, BoxSize] with remainder(). */
 void orc_store_wrap(double *x, int64_t np, double BoxSize);
 

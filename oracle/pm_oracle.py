@@ -341,3 +341,38 @@ def store_wrap(x, BoxSize):
     x = np.ascontiguousarray(x, dtype=np.float64).copy()
     lib().orc_store_wrap(_p(x), ctypes.c_int64(len(x)), ctypes.c_double(BoxSize))
     return x
+
+
+FORCE_MODES = {"fastpm": 0, "pm": 1, "cola": 2, "2lpt": 3, "za": 4}
+
+
+def factor_lookup(ai, af_table, tables, a):
+    """factors.c:38-69 / :112-134: (t0, t1, t2) interpolated at scale factor a."""
+    t = [np.ascontiguousarray(x, dtype=np.float64) for x in tables]
+    o = [ctypes.c_double() for _ in range(3)]
+    rc = lib().orc_factor_lookup(ctypes.c_double(ai), ctypes.c_double(af_table), len(t[0]), _p(t[0]), _p(t[1]),
+                                 _p(t[2]), ctypes.c_double(a), *[ctypes.byref(v) for v in o])
+    if rc != 0:
+        raise ValueError("kick/drift beyond factor's available range.")      # factors.c:61, :127
+    return tuple(v.value for v in o)
+
+
+def kick(forcemode, dda, Dv1, Dv2, q1, q2, acc, v, dx1=None, dx2=None):
+    """fastpm_kick_store (factors.c:175-197) with the looked-up differences; returns v_out."""
+    acc = np.ascontiguousarray(acc, dtype=np.float32)
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    vo = np.empty_like(v)
+    cd = ctypes.c_double
+    lib().orc_kick(int(forcemode), cd(dda), cd(Dv1), cd(Dv2), cd(q1), cd(q2), _p(acc), _p(v), _p(dx1), _p(dx2),
+                   _p(vo), ctypes.c_int64(len(v)))
+    return vo
+
+
+def drift(forcemode, dyyy, da1, da2, Dv1, Dv2, x, v=None, dx1=None, dx2=None):
+    """fastpm_drift_store (factors.c:373-392) with the looked-up differences; returns x_out."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    xo = np.empty_like(x)
+    cd = ctypes.c_double
+    lib().orc_drift(int(forcemode), cd(dyyy), cd(da1), cd(da2), cd(Dv1), cd(Dv2), _p(x), _p(v), _p(dx1), _p(dx2),
+                    _p(xo), ctypes.c_int64(len(x)))
+    return xo

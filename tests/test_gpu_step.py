@@ -1,0 +1,112 @@
+"""Kick / drift / wrap on the device ("next" row 1, reference factors.c:72-197, 373-392;
+store.c:446-475) against the oracle: bit-exact (pure element-wise arithmetic, same promotions),
+and a 5-step plain-PM leapfrog evolution (the shape of BASELINE configs[0]) kept entirely on the
+GPU against the same evolution on the CPU oracle."""
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _eds_tables(forcemode, ai, ac, af, n=32):
+    """Smooth stand-ins for the 32-sample factor tables (the real ones need the GSL growth
+    integrals, factors.c:233-371): Einstein-de Sitter plain-PM integrals, E = a^-1.5."""
+    a = ai * (1.0 * (n - 1 - np.arange(n)) / (n - 1)) + af * (1.0 * np.arange(n) / (n - 1))   # factors.c:276-277
+    dyyy = -2.0 * (a ** -0.5 - ai ** -0.5)
+    dda = -1.5 * 2.0 * (a ** 0.5 - ai ** 0.5)
+    D = a
+    return a, dyyy, dda, D - ai, (D ** 2 - ai ** 2) * (-3.0 / 7)
+
+
+@pytest.mark.parametrize("mode", ["fastpm", "pm", "cola", "2lpt", "za"])
+def test_kick_drift_bit_exact(oracle, mode):
+    import torch
+    from fastpm_amd import PM, Store, KickFactor, DriftFactor, fastpm_kick_store, fastpm_drift_store, fastpm_store_wrap
+    N, L, n = 16, 48.0, 5000
+    rng = np.random.default_rng(7)
+    x = rng.uniform(0, L, (n, 3))
+    v, dx1, dx2, acc = (rng.normal(size=(n, 3)).astype(np.float32) for _ in range(4))
+    ai, ac, af = 0.2, 0.25, 0.3
+    _, dyyy, dda, da1, da2 = _eds_tables(mode, ai, ac, af)
+    kick = KickFactor(mode, ai, ac, af, dda, da1 * 0.7, da2 * 0.3, q1=0.37, q2=-0.11)
+    drift = DriftFactor(mode, ai, ac, af, dyyy, da1, da2, Dv1=0.21, Dv2=-0.05)
+    pm = PM(N, L, 64)
+    st = Store(x, v=v, dx1=dx1, dx2=dx2, a_x=ai, a_v=ai)
+    st.acc.copy_(torch.from_numpy(acc))
+    a_to = 0.2731                                    # inside the table: exercises the interpolation
+    fastpm_kick_store(pm, kick, st, st, a_to)
+    kf, ki = oracle.factor_lookup(ai, af, kick.t, a_to), oracle.factor_lookup(ai, af, kick.t, ai)
+    ref_v = oracle.kick(oracle.FORCE_MODES[mode], kf[0] - ki[0], kf[1] - ki[1], kf[2] - ki[2], 0.37, -0.11, acc, v, dx1, dx2)
+    torch.cuda.synchronize()
+    assert np.array_equal(st.v.cpu().numpy(), ref_v) and st.a_v == a_to
+    fastpm_drift_store(pm, drift, st, st, af)
+    df, di = oracle.factor_lookup(ai, af, drift.t, af), oracle.factor_lookup(ai, af, drift.t, ai)
+    ref_x = oracle.drift(oracle.FORCE_MODES[mode], df[0] - di[0], df[1] - di[1], df[2] - di[2], 0.21, -0.05, x, ref_v, dx1, dx2)
+    torch.cuda.synchronize()
+    assert np.array_equal(st.x.cpu().numpy(), ref_x) and st.a_x == af
+    fastpm_store_wrap(pm, st)
+    torch.cuda.synchronize()
+    w = st.x.cpu().numpy()
+    assert np.array_equal(w, oracle.store_wrap(ref_x, L)) and w.min() >= 0 and w.max() <= L
+    pm.destroy()
+
+
+def test_lookup_out_of_range_raises():
+    from fastpm_amd import KickFactor, FastPMHipError
+    _, dyyy, dda, da1, da2 = _eds_tables("pm", 0.2, 0.25, 0.3)
+    k = KickFactor("pm", 0.2, 0.25, 0.3, dda, da1, da2)
+    with pytest.raises(FastPMHipError, match="beyond factor"):
+        k.lookup(0.31)
+
+
+@pytest.mark.parametrize("nc,N,precision", [(32, 64, 64), (128, 256, 32)])
+def test_five_step_pm_evolution(oracle, nc, N, precision):
+    """tests/standard.lua shape (force_mode = "pm", 5 force evaluations, time_step linspace(0.1, 1, 5)):
+    K-D-F-K leapfrog with every column resident on the device, vs the oracle on the CPU."""
+    import torch
+    from fastpm_amd import (PM, Store, KickFactor, DriftFactor, fastpm_kick_store, fastpm_drift_store,
+                            fastpm_store_wrap, fastpm_solver_compute_force)
+    L = 3.0 * nc
+    x0 = util.load_a(nc, L, N, sigma_cells=0.5)
+    steps = np.linspace(0.1, 1.0, 5)
+    pm = PM(N, L, precision)
+    pmo = oracle.PMOracle(N, L, precision, threads=8)
+    st = Store(x0, v=np.zeros_like(x0, dtype=np.float32), a_x=steps[0], a_v=steps[0])
+    xo, vo = x0.copy(), np.zeros_like(x0, dtype=np.float32)
+    dk = pm.alloc()
+    fastpm_solver_compute_force(pm, st, dealias="none", kernel="1_4", delta_k=dk)
+    acc_o = oracle.compute_force(pmo, xo)["acc"]
+    for s in range(len(steps) - 1):
+        ai, af = steps[s], steps[s + 1]
+        ac = 0.5 * (ai + af)
+        _, dyyy, dda, da1, da2 = _eds_tables("pm", ai, ac, af)
+        kick = KickFactor("pm", ai, ac, af, dda * 1e-2, da1, da2)       # scaled: keep the run in the linear regime
+        drift = DriftFactor("pm", ai, ac, af, dyyy * 1e-1, da1, da2)
+        # device
+        fastpm_kick_store(pm, kick, st, st, ac)
+        fastpm_drift_store(pm, drift, st, st, af)
+        fastpm_store_wrap(pm, st)
+        fastpm_solver_compute_force(pm, st, dealias="none", kernel="1_4", delta_k=dk)
+        fastpm_kick_store(pm, kick, st, st, af)
+        # oracle
+        k1 = oracle.factor_lookup(ai, af, kick.t, ac)
+        k0 = oracle.factor_lookup(ai, af, kick.t, ai)
+        vo = oracle.kick(1, k1[0] - k0[0], 0, 0, 0, 0, acc_o, vo)
+        d1 = oracle.factor_lookup(ai, af, drift.t, af)
+        d0 = oracle.factor_lookup(ai, af, drift.t, ai)
+        xo = oracle.store_wrap(oracle.drift(1, d1[0] - d0[0], 0, 0, 0, 0, xo, vo), L)
+        acc_o = oracle.compute_force(pmo, xo)["acc"]
+        k2 = oracle.factor_lookup(ai, af, kick.t, af)
+        vo = oracle.kick(1, k2[0] - k1[0], 0, 0, 0, 0, acc_o, vo)
+    torch.cuda.synchronize()
+    h = L / N
+    dx = np.abs(st.x.cpu().numpy() - xo)
+    dx = np.minimum(dx, L - dx)                        # a particle may sit on either side of the wrap
+    moved = np.abs(xo - x0)
+    assert np.minimum(moved, L - moved).max() > 0.05 * h          # the run did move particles
+    tol = 1e-6 if precision == 64 else 2e-4
+    assert dx.max() <= tol * h, dx.max() / h
+    assert util.rel_err(st.v.cpu().numpy(), vo) <= (1e-6 if precision == 64 else 5e-4)
+    pm.destroy()
