@@ -82,8 +82,8 @@ def test_five_step_pm_evolution(oracle, nc, N, precision):
         ai, af = steps[s], steps[s + 1]
         ac = 0.5 * (ai + af)
         _, dyyy, dda, da1, da2 = _eds_tables("pm", ai, ac, af)
-        kick = KickFactor("pm", ai, ac, af, dda * 1e-2, da1, da2)       # scaled: keep the run in the linear regime
-        drift = DriftFactor("pm", ai, ac, af, dyyy * 1e-1, da1, da2)
+        kick = KickFactor("pm", ai, ac, af, dda * 0.3, da1, da2)
+        drift = DriftFactor("pm", ai, ac, af, dyyy * 0.3, da1, da2)
         # device
         fastpm_kick_store(pm, kick, st, st, ac)
         fastpm_drift_store(pm, drift, st, st, af)
