@@ -78,30 +78,67 @@ template <int S, typename F> __device__ __forceinline__ void dft8(C2<F> *v)
     v[3] = cadd(e[3], t3);   v[7] = csub(e[3], t3);
 }
 
+template <int S, typename F> __device__ __forceinline__ void dft3(C2<F> *v)
+{
+    const F s3 = (F) 0.86602540378443864676;           // sin(2 pi / 3)
+    C2<F> t1 = cadd(v[1], v[2]);
+    C2<F> t2 = {v[0].x - (F) 0.5 * t1.x, v[0].y - (F) 0.5 * t1.y};
+    C2<F> d = csub(v[1], v[2]);
+    C2<F> t3 = muli<S>(C2<F>{s3 * d.x, s3 * d.y});
+    v[0] = cadd(v[0], t1);
+    v[1] = cadd(t2, t3);
+    v[2] = csub(t2, t3);
+}
+
+template <int S, typename F> __device__ __forceinline__ void dft5(C2<F> *v)
+{
+    const F c1 = (F) 0.30901699437494742410, c2 = (F) -0.80901699437494742410;   // cos(2pi/5), cos(4pi/5)
+    const F s1 = (F) 0.95105651629515357212, s2 = (F) 0.58778525229247312917;    // sin(2pi/5), sin(4pi/5)
+    C2<F> a1 = cadd(v[1], v[4]), a2 = cadd(v[2], v[3]);
+    C2<F> b1 = csub(v[1], v[4]), b2 = csub(v[2], v[3]);
+    C2<F> e1 = {v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y};
+    C2<F> e2 = {v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y};
+    C2<F> d1 = muli<S>(C2<F>{s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y});
+    C2<F> d2 = muli<S>(C2<F>{s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y});
+    v[0] = cadd(v[0], cadd(a1, a2));
+    v[1] = cadd(e1, d1);
+    v[4] = csub(e1, d1);
+    v[2] = cadd(e2, d2);
+    v[3] = csub(e2, d2);
+}
+
 template <int R, int S, typename F> __device__ __forceinline__ void dftR(C2<F> *v)
 {
     if (R == 8) dft8<S>(v);
+    else if (R == 5) dft5<S>(v);
     else if (R == 4) dft4<S>(v);
+    else if (R == 3) dft3<S>(v);
     else dft2<S>(v);
 }
 
 constexpr int COLS = 8;   // columns per workgroup: 8 x complex<double> = one 128-B line per row
-constexpr int EPT = 8;    // elements per thread
+constexpr int EPT = 8;    // elements per thread at load / store time
+constexpr int VMAX = 10;  // register slots: a radix-3 / radix-5 stage touches up to 2*5 (or 3*3) values
 
-// One Cooley-Tukey stage of radix R on the 8 values of this thread.
+// One Cooley-Tukey stage of radix R on this thread's values.
 //   PP = product of the radices before this stage, MP = N / PP (remaining length before it).
-//   Butterfly b = tau + T*q (q < 8/R): (kprev, t) = (b / M, b % M) with M = MP / R.
+//   N/R butterflies per column, NB = ceil((N/R) / T) per thread: b = tau + T*q (guarded when N/R is
+//   not a multiple of T, which only happens for the radix-3 / radix-5 stages).
+//   (kprev, t) = (b / M, b % M) with M = MP / R.
 //   in : values (kprev, ts*M + t), ts < R  [registers v[q*R + ts]]
 //   out: values (kprev + PP*k, t) * W_MP^{t k} -> LDS index (kprev + PP*k)*M + t, or, for the
-//        last stage (M == 1), register slot q + (8/R)*k which is row tau + T*slot.
+//        last stage (M == 1, R in {2,4,8}), register slot q + (8/R)*k which is row tau + T*slot.
 template <int R, int PP, int N, int S, bool LAST, typename F>
 __device__ __forceinline__ void stage(C2<F> *v, C2<F> *lds, const C2<F> *tw, int tau, int c)
 {
-    constexpr int T = N / EPT, MP = N / PP, M = MP / R, NB = EPT / R;
+    constexpr int T = N / EPT, MP = N / PP, M = MP / R, NBF = N / R, NB = (NBF + T - 1) / T;
+    static_assert(!LAST || (NB * R == EPT && NBF % T == 0), "the last radix must be 2, 4 or 8");
+    static_assert(NB * R <= VMAX, "too many values per thread");
     C2<F> out[EPT];
 #pragma unroll
     for (int q = 0; q < NB; q++) {
         const int b = tau + T * q;
+        if (NBF % T != 0 && b >= NBF) continue;
         const int kprev = b / M, t = b % M;
         C2<F> w[R];
 #pragma unroll
@@ -111,11 +148,11 @@ __device__ __forceinline__ void stage(C2<F> *v, C2<F> *lds, const C2<F> *tw, int
         for (int k = 0; k < R; k++) {
             C2<F> val = w[k];
             if (!LAST && k > 0) {
-                C2<F> ww = tw[(t * k * PP) & (N - 1)];
+                C2<F> ww = tw[(t * k * PP) % N];
                 if (S > 0) ww.y = -ww.y;          // table holds e^{-2 pi i j / N}
                 val = cmul(val, ww);
             }
-            if (LAST) out[q + NB * k] = val;
+            if (LAST) out[(q + NB * k) % EPT] = val;
             else lds[((kprev + PP * k) * M + t) * COLS + c] = val;
         }
     }
@@ -129,10 +166,11 @@ __device__ __forceinline__ void stage(C2<F> *v, C2<F> *lds, const C2<F> *tw, int
 template <int R, int PP, int N, typename F>
 __device__ __forceinline__ void gather(C2<F> *v, const C2<F> *lds, int tau, int c)
 {
-    constexpr int T = N / EPT, MP = N / PP, M = MP / R, NB = EPT / R;
+    constexpr int T = N / EPT, MP = N / PP, M = MP / R, NBF = N / R, NB = (NBF + T - 1) / T;
 #pragma unroll
     for (int q = 0; q < NB; q++) {
         const int b = tau + T * q;
+        if (NBF % T != 0 && b >= NBF) continue;
         const int kprev = b / M, t = b % M;
 #pragma unroll
         for (int ts = 0; ts < R; ts++) v[q * R + ts] = lds[(kprev * MP + ts * M + t) * COLS + c];
@@ -217,7 +255,7 @@ __global__ __launch_bounds__(N) void colfft_kernel(const C2<F> *__restrict__ in,
     const int batch = tile / ntiles_per_batch;
     const int col = (tile % ntiles_per_batch) * COLS + c;
     const bool live = col < ncols;
-    C2<F> v[EPT];
+    C2<F> v[VMAX];
 #pragma unroll
     for (int j = 0; j < EPT; j++) v[j] = live ? in[col_addr(im, batch, tau + T * j, col)] : C2<F>{0, 0};
     stage_twiddles(tw, tw_global, N);       // after the data loads are in flight
@@ -292,7 +330,7 @@ __global__ __launch_bounds__(N, 4) void colfft_xback3_kernel(const C2<F> *__rest
     C2<F> *outs[3] = {o0, o1, o2};
 #pragma unroll 1
     for (int dir = 0; dir < 3; dir++) {
-        C2<F> v[EPT];
+        C2<F> v[VMAX];
 #pragma unroll
         for (int j = 0; j < EPT; j++) {
             const int ix = tau + T * j;
@@ -336,7 +374,7 @@ __global__ __launch_bounds__(M) void rowfft_r2c_kernel(const C2<F> *__restrict__
     const long long row = (long long) blockIdx.x * COLS + c;
     const bool live = row < nrows;
     const C2<F> *src = in + row * pitch;
-    C2<F> v[EPT];
+    C2<F> v[VMAX];
 #pragma unroll
     for (int j = 0; j < EPT; j++) v[j] = live ? src[tau + T * j] : C2<F>{0, 0};
     for (int i = threadIdx.x; i < M; i += blockDim.x) {
@@ -356,7 +394,7 @@ __global__ __launch_bounds__(M) void rowfft_r2c_kernel(const C2<F> *__restrict__
     for (int j = 0; j < EPT; j++) {
         const int k = tau + T * j;
         const C2<F> a = v[j];
-        C2<F> bq = lds[((M - k) & (M - 1)) * COLS + c];
+        C2<F> bq = lds[((M - k) % M) * COLS + c];
         bq.y = -bq.y;                                          // conj Z[M-k]
         const C2<F> e = {(a.x + bq.x) * (F) 0.5, (a.y + bq.y) * (F) 0.5};
         const C2<F> d = {(a.x - bq.x) * (F) 0.5, (a.y - bq.y) * (F) 0.5};
@@ -382,19 +420,38 @@ template <typename K> static int set_lds(K kernel, size_t bytes)
     return 0;
 }
 
+// lengths the column kernels are instantiated for: first radix 8, last radix 2 / 4 / 8, at most one
+// or two radix-3 / radix-5 stages in between (640 = 8*5*8*2 and 800 = 8*5*5*4 are the 2- and 4-GPU
+// weak-scaling meshes, 384 = 8*3*8*2 is tests/standard.lua's literal mesh).
 #define COLFFT_DISPATCH(N_, CALL)                                            \
     switch (N_) {                                                            \
     case 16: { CALL(16, 2, 1, 1); } break;                                   \
     case 32: { CALL(32, 4, 1, 1); } break;                                   \
+    case 48: { CALL(48, 3, 2, 1); } break;                                   \
     case 64: { CALL(64, 8, 1, 1); } break;                                   \
+    case 80: { CALL(80, 5, 2, 1); } break;                                   \
+    case 96: { CALL(96, 3, 4, 1); } break;                                   \
     case 128: { CALL(128, 8, 2, 1); } break;                                 \
+    case 160: { CALL(160, 5, 4, 1); } break;                                 \
+    case 192: { CALL(192, 3, 8, 1); } break;                                 \
     case 256: { CALL(256, 8, 4, 1); } break;                                 \
+    case 320: { CALL(320, 5, 8, 1); } break;                                 \
+    case 384: { CALL(384, 3, 8, 2); } break;                                 \
+    case 400: { CALL(400, 5, 5, 2); } break;                                 \
     case 512: { CALL(512, 8, 8, 1); } break;                                 \
+    case 640: { CALL(640, 5, 8, 2); } break;                                 \
+    case 768: { CALL(768, 3, 8, 4); } break;                                 \
+    case 800: { CALL(800, 5, 5, 4); } break;                                 \
     case 1024: { CALL(1024, 8, 8, 2); } break;                               \
     default: FPM_FAIL(-1, "column FFT: unsupported length %d", (int) (N_)); \
     }
 
-bool colfft_supported(int N) { return N >= 16 && N <= 1024 && (N & (N - 1)) == 0; }
+bool colfft_supported(int N)
+{
+    static const int ok[] = {16, 32, 48, 64, 80, 96, 128, 160, 192, 256, 320, 384, 400, 512, 640, 768, 800, 1024};
+    for (int n : ok) if (n == N) return true;
+    return false;
+}
 
 template <typename F>
 static int colfft_launch(fpmhip_plan *p, int dir, const void *in, void *out, const ColMap &im, const ColMap &om,
@@ -466,7 +523,7 @@ static int rowfft_launch(fpmhip_plan *p, const void *in, void *out)
 }
 
 // z pass forward (r2c) on [x_loc][y][N+2] real rows -> [x_loc][y][N/2+1]; in place or out of place
-bool rowfft_supported(int N) { return N >= 32 && colfft_supported(N / 2); }
+bool rowfft_supported(int N) { return N >= 32 && N % 2 == 0 && colfft_supported(N / 2); }
 
 int rowfft_r2c(fpmhip_plan *p, const void *in, void *out)
 {

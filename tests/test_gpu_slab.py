@@ -49,6 +49,59 @@ def test_virtual_ranks_match_one_rank_oracle(oracle, P, load, precision):
         pm.destroy()
 
 
+@pytest.mark.parametrize("N,P", [(24, 2), (48, 4), (40, 2), (32, 2)])
+def test_virtual_ranks_rocfft_backend(oracle, N, P):
+    """The rocFFT slab path (2-D batched plans + pack/unpack kernels + strided 1-D x plans): what
+    bench.py runs for mesh sizes that are not a power of two (640^3 on 2 GPUs, 800^3 on 4)."""
+    import torch
+    from fastpm_amd import PM, Store
+    from fastpm_amd.pm import FFT_ROCFFT
+    from fastpm_amd.distributed import SlabForce, run_virtual
+    nc, L = N // 2, 3.0 * (N // 2)
+    x = util.load_b(nc, L, N, rms_cells=2.0)
+    pmo = oracle.PMOracle(N, L, 64)
+    ref = oracle.compute_force(pmo, x)
+    idx = _split(x, N, L, P)
+    pms = [PM(N, L, 64, nranks=P, rank=r, fft_mode=FFT_ROCFFT) for r in range(P)]
+    stores = [Store(x[idx[r]]) for r in range(P)]
+    dks = [pm.alloc() for pm in pms]
+    run_virtual([SlabForce(pm) for pm in pms], stores, delta_ks=dks)
+    torch.cuda.synchronize()
+    acc = np.zeros_like(ref["acc"])
+    for r in range(P):
+        acc[idx[r]] = stores[r].acc.cpu().numpy()
+    dk = np.concatenate([pm.complex_view(d).cpu().numpy() for pm, d in zip(pms, dks)], axis=1)
+    assert util.max_err(dk, util.oracle_k_to_xyk(pmo, ref["delta_k"])) <= 1e-14
+    assert util.rel_err(acc, ref["acc"]) <= 1e-6
+    for pm in pms:
+        pm.destroy()
+
+
+@pytest.mark.parametrize("N,P", [(48, 2), (80, 4), (96, 3)])
+def test_virtual_ranks_mixed_radix_column_fft(oracle, N, P):
+    """Slab path with the hand-written column FFT at lengths with radix-3 / radix-5 stages
+    (the 640^3 and 800^3 weak-scaling meshes are 8*5*8*2 and 8*5*5*4)."""
+    import torch
+    from fastpm_amd import PM, Store
+    from fastpm_amd.distributed import SlabForce, run_virtual
+    nc, L = N // 2, 3.0 * (N // 2)
+    x = util.load_b(nc, L, N, rms_cells=2.0)
+    pmo = oracle.PMOracle(N, L, 64)
+    ref = oracle.compute_force(pmo, x)
+    idx = _split(x, N, L, P)
+    pms = [PM(N, L, 64, nranks=P, rank=r) for r in range(P)]
+    assert all(pm.staged_fft() for pm in pms)
+    stores = [Store(x[idx[r]]) for r in range(P)]
+    run_virtual([SlabForce(pm) for pm in pms], stores)
+    torch.cuda.synchronize()
+    acc = np.zeros_like(ref["acc"])
+    for r in range(P):
+        acc[idx[r]] = stores[r].acc.cpu().numpy()
+    assert util.rel_err(acc, ref["acc"]) <= 1e-6
+    for pm in pms:
+        pm.destroy()
+
+
 def test_unowned_particle_is_an_error():
     from fastpm_amd import PM, Store, FastPMHipError
     N, L, P = 32, 48.0, 2

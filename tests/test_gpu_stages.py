@@ -238,7 +238,7 @@ def test_binning_reuse_and_invalidate(oracle):
 
 
 @pytest.mark.parametrize("precision", [64, 32])
-@pytest.mark.parametrize("N", [16, 32, 64, 128, 256])
+@pytest.mark.parametrize("N", [16, 32, 48, 64, 80, 96, 128, 160, 192, 256])
 def test_column_fft_backend_matches_rocfft_and_oracle(oracle, precision, N):
     """The hand-written x / y column passes (+ rocFFT z pass) against pocketfft and against the
     pure-rocFFT back end, forward and backward, plus the fused 3-component transfer + x pass."""
