@@ -35,6 +35,8 @@ class SlabForce:
         self.P, self.rank = pm.nranks, pm.rank
         self.canvas = pm.alloc()
         self.work = pm.alloc()
+        self.work2 = pm.alloc()                                # second transpose landing zone (overlap)
+        self._pending = {}
         self.force = [self.canvas, pm.alloc(), pm.alloc()]    # canvas is free after the forward FFT
         self.delta_k = None
         self.tmp_plane = torch.zeros(int(pm.layout.plane_elems), dtype=self.canvas.dtype, device=self.canvas.device)
@@ -71,9 +73,17 @@ class SlabForce:
         # gravity.c:373-397: per component transfer -> c2r.  The three transfers and the x passes
         # come from ONE sweep over delta_k; then one transpose + (y,z) passes per component.
         pm.transfer_fft_x_backward3(kernel, delta_k, self.force)
-        for d in range(3):
-            yield ("alltoall", self.work, self.force[d])
-            pm.fft_yz_backward(self.work, self.force[d])
+        # the transposes run on the collective's own stream: component d+1 is in flight over xGMI
+        # while the (y,z) passes of component d run on the compute stream
+        yield ("alltoall_start", self.work, self.force[0], 0)
+        yield ("alltoall_start", self.work2, self.force[1], 1)
+        yield ("wait", 0)
+        pm.fft_yz_backward(self.work, self.force[0])
+        yield ("alltoall_start", self.work, self.force[2], 2)      # ordered after the pass above
+        yield ("wait", 1)
+        pm.fft_yz_backward(self.work2, self.force[1])
+        yield ("wait", 2)
+        pm.fft_yz_backward(self.work, self.force[2])
         # the plane each boundary particle's cloud reaches into comes from the next slab
         yield ("shift", [(pm.plane(f, 0), pm.plane(f, xl), -1) for f in self.force])
         pm.readout3(self.force, store)
@@ -106,6 +116,11 @@ class SlabForce:
         elif kind == "alltoall":
             n = self.pm.exchange_chunk_elems() * self.P
             dist.all_to_all_single(req[1][:n], req[2][:n], group=g)
+        elif kind == "alltoall_start":
+            n = self.pm.exchange_chunk_elems() * self.P
+            self._pending[req[3]] = dist.all_to_all_single(req[1][:n], req[2][:n], group=g, async_op=True)
+        elif kind == "wait":
+            self._pending.pop(req[1]).wait()
         elif kind == "shift":
             ops = []
             for send, recv, direction in req[1]:
@@ -154,11 +169,13 @@ def run_virtual(forces, stores, kernel="1_4", dealias="none", delta_ks=None):
             total = sum(r[1].clone() for r in reqs)
             for r in reqs:
                 r[1].copy_(total)
-        elif kind == "alltoall":
+        elif kind in ("alltoall", "alltoall_start"):
             chunk = forces[0].pm.exchange_chunk_elems()
             for dst in range(P):
                 for src in range(P):
                     reqs[dst][1][src * chunk:(src + 1) * chunk].copy_(reqs[src][2][dst * chunk:(dst + 1) * chunk])
+        elif kind == "wait":
+            pass
         elif kind == "shift":
             nmsg = len(reqs[0][1])
             for m in range(nmsg):
