@@ -6,6 +6,9 @@
 // drift: read x 24 + v 12 [+24], write x 24).  The factor tables (32 samples from GSL growth
 // integrals, factors.c:233-371) stay on the host; the kernels get the looked-up scalars.
 // Arithmetic follows the reference's float/double promotion line by line; no FMA contraction.
+#include <algorithm>
+#include <cmath>
+
 #include "fpm_internal.h"
 
 namespace fpm {
@@ -63,6 +66,39 @@ __global__ __launch_bounds__(256) void wrap_kernel(double *__restrict__ x, long 
     x[i] = x1;
 }
 
+// fastpm_store_summary (store.c:807-908) before its Allreduces: per-member min, max, sum, sum of
+// squares of a float column, accumulated in double.  Per-block partials, final reduce on the host.
+__global__ __launch_bounds__(256) void summary_kernel(const float *__restrict__ col, long long np, int nmemb,
+                                                      double *__restrict__ partial)
+{
+    __shared__ double sh[256];
+    for (int d = 0; d < nmemb; d++) {
+        double tmin = 1e20, tmax = -1e20, s1 = 0, s2 = 0;                 // store.c:829-833
+        for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < np;
+             i += (long long) gridDim.x * blockDim.x) {
+            const double value = col[i * nmemb + d];
+            s1 += value;
+            s2 += value * value;
+            tmin = fmin(tmin, value);
+            tmax = fmax(tmax, value);
+        }
+        double vals[4] = {tmin, tmax, s1, s2};
+        for (int q = 0; q < 4; q++) {
+            sh[threadIdx.x] = vals[q];
+            __syncthreads();
+            for (int k = 128; k > 0; k >>= 1) {
+                if (threadIdx.x < k) {
+                    const double a = sh[threadIdx.x], b = sh[threadIdx.x + k];
+                    sh[threadIdx.x] = q == 0 ? fmin(a, b) : (q == 1 ? fmax(a, b) : a + b);
+                }
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) partial[((long long) blockIdx.x * nmemb + d) * 4 + q] = sh[0];
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace fpm
 
 using namespace fpm;
@@ -107,6 +143,33 @@ int fpmhip_wrap(fpmhip_plan *p, double *x, int64_t np)
     FPM_CHECK_HIP(hipGetLastError());
     p->binned_np = -1;
     p->binned_x = nullptr;
+    return 0;
+}
+
+int fpmhip_store_summary(fpmhip_plan *p, const float *column, int nmemb, int64_t np, double *rmin, double *rmax,
+                         double *rsum1, double *rsum2)
+{
+    if (!p || !rmin || !rmax || !rsum1 || !rsum2 || (np > 0 && !column)) FPM_FAIL(-1, "null argument");
+    if (nmemb < 1 || nmemb > 9) FPM_FAIL(-1, "memb %d out of range", nmemb);
+    for (int d = 0; d < nmemb; d++) { rmin[d] = 1e20; rmax[d] = -1e20; rsum1[d] = 0; rsum2[d] = 0; }
+    if (np == 0) return 0;
+    const int nblocks = (int) std::min<long long>(1024, (np + 255) / 256);
+    double *partial = nullptr;
+    FPM_CHECK_HIP(hipMalloc(&partial, (size_t) nblocks * nmemb * 4 * sizeof(double)));
+    summary_kernel<<<nblocks, 256, 0, p->stream>>>(column, np, nmemb, partial);
+    std::vector<double> h((size_t) nblocks * nmemb * 4);
+    hipError_t e = hipMemcpyAsync(h.data(), partial, h.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    (void) hipFree(partial);
+    FPM_CHECK_HIP(e);
+    for (int b = 0; b < nblocks; b++)
+        for (int d = 0; d < nmemb; d++) {
+            const double *q = &h[((size_t) b * nmemb + d) * 4];
+            rmin[d] = fmin(rmin[d], q[0]);
+            rmax[d] = fmax(rmax[d], q[1]);
+            rsum1[d] += q[2];
+            rsum2[d] += q[3];
+        }
     return 0;
 }
 

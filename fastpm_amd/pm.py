@@ -150,6 +150,76 @@ def fastpm_store_wrap(pm, p):
     check(pm._L.fpmhip_wrap(pm._plan, _ptr(p.x), p.np))
 
 
+def fastpm_store_summary(pm, column, fmt, group=None):
+    """fastpm_store_summary(p, attribute, comm, fmt, ...) (store.c:807-908) for a float column tensor
+    [np][nmemb]: one array per character of fmt ('<' min, '>' max, '-' mean, 's' std, 'S', 'v', 'V')."""
+    nmemb = 1 if column.ndim == 1 else int(column.shape[1])
+    n = int(column.shape[0])
+    arrs = [np.zeros(nmemb) for _ in range(4)]
+    cp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    check(pm._L.fpmhip_store_summary(pm._plan, _ptr(column), nmemb, n, *[cp(a) for a in arrs]))
+    rmin, rmax, rsum1, rsum2 = arrs
+    ntot = float(n)
+    if pm.nranks > 1:                                   # store.c:869-873: the five Allreduces
+        import torch.distributed as dist
+        t = torch.tensor(np.concatenate([rsum1, rsum2, [ntot]]), dtype=torch.float64, device=column.device)
+        dist.all_reduce(t, group=group)
+        rsum1, rsum2, ntot = t[:nmemb].cpu().numpy(), t[nmemb:2 * nmemb].cpu().numpy(), float(t[-1])
+        lo = torch.tensor(rmin, dtype=torch.float64, device=column.device)
+        hi = torch.tensor(rmax, dtype=torch.float64, device=column.device)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        rmin, rmax = lo.cpu().numpy(), hi.cpu().numpy()
+    out = []
+    var = rsum2 / ntot - (rsum1 / ntot) ** 2
+    for ch in fmt:                                      # store.c:879-904
+        if ch == "-":
+            out.append(rsum1 / ntot)
+        elif ch == "<":
+            out.append(rmin.copy())
+        elif ch == ">":
+            out.append(rmax.copy())
+        elif ch == "s":
+            out.append(np.sqrt(var))
+        elif ch == "S":
+            out.append(np.sqrt(ntot / (ntot - 1.0)) * np.sqrt(var))
+        elif ch == "v":
+            out.append(var)
+        elif ch == "V":
+            out.append(ntot / (ntot - 1.0) * var)
+        else:
+            raise FastPMHipError("Unknown format str. Use '<->sSvV'")
+    return out
+
+
+class VPM:
+    """vpm_create / vpm_find (libfastpm/vpm.c:9-58): one PM (one GPU plan) per {a_start, pm_nc_factor}
+    entry, picked by scale factor."""
+
+    def __init__(self, nc, BoxSize, vpminit, precision=64, nranks=1, rank=0, make_pm=None):
+        self.entries = []
+        make_pm = make_pm or (lambda nmesh: PM(nmesh, BoxSize, precision, nranks=nranks, rank=rank))
+        for a_start, factor in vpminit:                 # vpm.c:34-43
+            nmesh = int(nc * factor)
+            if nmesh % nranks != 0:
+                raise FastPMHipError("PM mesh is not divided by the process mesh.")       # vpm.c:45-53
+            self.entries.append((float(a_start), factor, make_pm(nmesh)))
+
+    def find(self, a):
+        """vpm.c:9-20: the last entry whose a_start <= a (the first entry if none)."""
+        i = 0
+        while i < len(self.entries) and not self.entries[i][0] > a:
+            i += 1
+        if i == 0:
+            i = 1
+        return self.entries[i - 1][2]
+
+    def destroy(self):
+        for _, _, pm in self.entries:
+            if hasattr(pm, "destroy"):
+                pm.destroy()
+
+
 class PM:
     """One rank's particle mesh on one MI355X (struct PM + its plans)."""
 

@@ -207,6 +207,11 @@ int fpmhip_drift(fpmhip_plan *plan, const double *x_in_dev, const float *v_dev, 
 /* fastpm_store_wrap (store.c:446-475): x = remainder(x, BoxSize) shifted into [0, BoxSize], in place */
 int fpmhip_wrap(fpmhip_plan *plan, double *x_dev, int64_t np);
 
+/* fastpm_store_summary (store.c:807-908) before its Allreduces: per member of a float column
+ * (nmemb values per particle) the min, max, sum and sum of squares in double.  Synchronises. */
+int fpmhip_store_summary(fpmhip_plan *plan, const float *column_dev, int nmemb, int64_t np,
+                         double *rmin_host, double *rmax_host, double *rsum1_host, double *rsum2_host);
+
 /* ---- per-stage timing with HIP events on the plan's stream (the reference's CLOCK names,
  *      gravity.c:276,320,344,348,369-372,474) ---- */
 enum { FPMHIP_T_SORT = 0, FPMHIP_T_PAINT, FPMHIP_T_R2C, FPMHIP_T_DEALIAS, FPMHIP_T_TRANSFER,

@@ -62,3 +62,13 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".c", ".h")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "pm_oracle" not in text and "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_vpm_find_logic():
+    """vpm_find (libfastpm/vpm.c:9-20) without a GPU: stand-in PM objects."""
+    from fastpm_amd import VPM
+    v = VPM(128, 384.0, [(0.0, 1), (0.25, 2), (0.5, 3)], make_pm=lambda nmesh: nmesh)
+    assert [e[2] for e in v.entries] == [128, 256, 384]
+    assert v.find(0.1) == 128 and v.find(0.25) == 256 and v.find(0.49) == 256 and v.find(0.5) == 384 and v.find(1.0) == 384
+    w = VPM(128, 384.0, [(0.3, 2), (0.6, 3)], make_pm=lambda nmesh: nmesh)
+    assert w.find(0.1) == 256                      # "Start with the first pm", vpm.c:17-18

@@ -110,3 +110,37 @@ def test_five_step_pm_evolution(oracle, nc, N, precision):
     assert dx.max() <= tol * h, dx.max() / h
     assert util.rel_err(st.v.cpu().numpy(), vo) <= (1e-6 if precision == 64 else 5e-4)
     pm.destroy()
+
+
+def test_store_summary_matches_reference_formulas():
+    """fastpm_store_summary (store.c:807-908): min / std / mean / max of acc, as gravity.c:403-417 logs."""
+    import torch
+    from fastpm_amd import PM, fastpm_store_summary
+    rng = np.random.default_rng(13)
+    a = rng.normal(0.3, 2.0, (100003, 3)).astype(np.float32)
+    pm = PM(16, 48.0, 64)
+    lo, sd, mean, hi = fastpm_store_summary(pm, torch.from_numpy(a).cuda(), "<s->")
+    a64 = a.astype(np.float64)
+    assert np.array_equal(lo, a64.min(0)) and np.array_equal(hi, a64.max(0))
+    assert np.allclose(mean, a64.mean(0), rtol=1e-12)
+    assert np.allclose(sd, np.sqrt((a64 ** 2).mean(0) - a64.mean(0) ** 2), rtol=1e-10)
+    pm.destroy()
+
+
+def test_variable_mesh_plans():
+    """vpm.c: one plan per pm_nc_factor (configs[4]: B = 1 -> 3); forces from each mesh vs the oracle."""
+    import torch
+    from fastpm_amd import VPM, Store
+    from oracle import pm_oracle as O
+    nc, L = 32, 96.0
+    vpm = VPM(nc, L, [(0.0, 1), (0.3, 2), (0.6, 3)])
+    x = util.load_b(nc, L, 2 * nc, rms_cells=1.5)
+    for a, B in ((0.1, 1), (0.4, 2), (0.9, 3)):
+        pm = vpm.find(a)
+        assert pm.Nmesh == nc * B
+        st = Store(x)
+        pm.compute_force(st)
+        torch.cuda.synchronize()
+        ref = O.compute_force(O.PMOracle(nc * B, L, 64), x)["acc"]
+        assert util.rel_err(st.acc.cpu().numpy(), ref) <= 1e-6
+    vpm.destroy()
