@@ -134,6 +134,78 @@ class SlabForce:
             raise ValueError(kind)
 
 
+class SlabDecompose:
+    """fastpm_decompose (solver.c:571-592): fastpm_store_wrap + fastpm_store_decompose
+    (store.c:485-657) for x slabs, every column resident on the device.  The result has the
+    reference's particle order: the ones that stay (original order), then what arrived from rank 0,
+    1, ... each in its sender's order."""
+
+    def __init__(self, pm, group=None):
+        self.pm, self.group = pm, group
+        self.P, self.rank = pm.nranks, pm.rank
+
+    def steps(self, store):
+        pm = self.pm
+        pm.wrap(store)                                           # solver.c:583
+        order, counts = pm.decompose_order(store)                # store.c:519-546
+        nstay, send_counts = counts[0], counts[1:]
+        dev = store.x.device
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+        rc = torch.empty_like(sc)
+        yield ("alltoall_counts", rc, sc)                        # store.c:570-572
+        recv_counts = [int(v) for v in rc.tolist()]
+        nrecv = sum(recv_counts)
+        for name, col in store.columns():                        # one exchange per column
+            perm = pm.gather_rows(col, order)                    # store.c:548 fastpm_store_permute
+            recv = torch.empty((nrecv,) + tuple(col.shape[1:]), dtype=col.dtype, device=dev)
+            yield ("alltoallv", recv, perm[nstay:], recv_counts, send_counts)     # store.c:611-621
+            setattr(store, name, torch.cat([perm[:nstay], recv]).contiguous())
+        store.np = nstay + nrecv                                 # store.c:589, 635
+        if hasattr(pm, "invalidate_binning"):
+            pm.invalidate_binning()
+
+    def decompose(self, store):
+        for req in self.steps(store):
+            kind = req[0]
+            if kind == "alltoall_counts":
+                dist.all_to_all_single(req[1], req[2], group=self.group)
+            elif kind == "alltoallv":
+                dist.all_to_all_single(req[1], req[2], output_split_sizes=req[3], input_split_sizes=req[4],
+                                       group=self.group)
+            else:
+                raise ValueError(kind)
+
+
+def run_virtual_decompose(decomposers, stores):
+    """All ranks of a decomposition in one process (see run_virtual)."""
+    P = len(decomposers)
+    gens = [d.steps(s) for d, s in zip(decomposers, stores)]
+    while True:
+        reqs = []
+        for g in gens:
+            try:
+                reqs.append(next(g))
+            except StopIteration:
+                reqs.append(None)
+        if all(r is None for r in reqs):
+            return
+        kind = reqs[0][0]
+        if kind == "alltoall_counts":
+            for dst in range(P):
+                for src in range(P):
+                    reqs[dst][1][src] = reqs[src][2][dst]
+        elif kind == "alltoallv":
+            for dst in range(P):
+                off = 0
+                for src in range(P):
+                    n = reqs[dst][3][src]
+                    so = sum(reqs[src][4][:dst])
+                    reqs[dst][1][off:off + n].copy_(reqs[src][2][so:so + n])
+                    off += n
+        else:
+            raise ValueError(kind)
+
+
 def _global_rank(group, r):
     return r if group is None or group is dist.group.WORLD else dist.get_global_rank(group, r)
 

@@ -82,6 +82,8 @@ SYMBOLS = {
     "fpmhip_kick": (_I, [_P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(KickFactor)]),
     "fpmhip_drift": (_I, [_P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(DriftFactor)]),
     "fpmhip_wrap": (_I, [_P, _P, _I64]),
+    "fpmhip_decompose_order": (_I, [_P, _P, _I64, _P, ctypes.POINTER(_I64)]),
+    "fpmhip_gather_rows": (_I, [_P, _P, _P, _P, _I64, _I]),
     "fpmhip_store_summary": (_I, [_P, _P, _I, _I64, _P, _P, _P, _P]),
     "fpmhip_timing_enable": (_I, [_P, _I]),
     "fpmhip_timing_reset": (_I, [_P]),

@@ -68,10 +68,17 @@ class Store:
         col = lambda c: None if c is None else torch.as_tensor(c, dtype=torch.float32, device=device).contiguous()
         self.v, self.dx1, self.dx2 = col(v), col(dx1), col(dx2)       # store.h:108-112
         self.a_x, self.a_v = float(a_x), float(a_v)                   # meta.a_x / meta.a_v, store.h:91-93
+        self.id = None                                                # uint64 ids as int64, store.h:113
         self.mass = None if mass is None else torch.as_tensor(mass, dtype=torch.float32, device=device).contiguous()
         self.M0 = float(M0)
         self.acc = torch.zeros((self.np, 3), dtype=torch.float32, device=self.x.device)
         self.potential = torch.zeros(self.np, dtype=torch.float32, device=self.x.device) if potential else None
+
+    COLUMNS = ("x", "v", "acc", "dx1", "dx2", "mass", "potential", "id")
+
+    def columns(self):
+        """(name, tensor) of every allocated column, in the order of the struct (store.h:104-131)."""
+        return [(n, getattr(self, n)) for n in self.COLUMNS if getattr(self, n, None) is not None]
 
     def _c(self, np_=None):
         c = _lib.Particles()
@@ -402,6 +409,23 @@ class PM:
                                         _enum(SOFTENING_TYPES, softening),
                                         None if dk is None else dk.ctypes.data_as(ctypes.c_void_p)))
         return acc, pot, dk
+
+    # ---- decompose pieces (store.c:485-657)
+    def wrap(self, store):
+        check(self._L.fpmhip_wrap(self._plan, _ptr(store.x), store.np))
+
+    def decompose_order(self, store):
+        """-> (order int32 tensor, counts [stay, to rank 0, ..., to rank P-1])"""
+        order = torch.empty(store.np, dtype=torch.int32, device=self.device)
+        counts = (ctypes.c_int64 * (self.nranks + 1))()
+        check(self._L.fpmhip_decompose_order(self._plan, _ptr(store.x), store.np, _ptr(order), counts))
+        return order, [int(c) for c in counts]
+
+    def gather_rows(self, col, order):
+        out = torch.empty_like(col)
+        rowbytes = col.element_size() * (1 if col.ndim == 1 else int(col.shape[1]))
+        check(self._L.fpmhip_gather_rows(self._plan, _ptr(col), _ptr(out), _ptr(order), int(col.shape[0]), rowbytes))
+        return out
 
     # ---- timing (CLOCK names of gravity.c)
     def timing_enable(self, on=True):

@@ -207,6 +207,18 @@ int fpmhip_drift(fpmhip_plan *plan, const double *x_in_dev, const float *v_dev, 
 /* fastpm_store_wrap (store.c:446-475): x = remainder(x, BoxSize) shifted into [0, BoxSize], in place */
 int fpmhip_wrap(fpmhip_plan *plan, double *x_dev, int64_t np);
 
+/* ---- "next" row 3: the device half of fastpm_store_decompose (store.c:485-657), slabs ----
+ * Owner rank of every particle (FastPMTargetPM, store.c:476-483) and the reference's stable order:
+ * order_dev[0 .. counts[0]) = particles that stay, then the leavers grouped by target rank 0..P-1,
+ * original order inside each group (store.c:527-553).  counts_host has nranks + 1 entries:
+ * [stay, to rank 0, ..., to rank P-1].  Synchronises. */
+int fpmhip_decompose_order(fpmhip_plan *plan, const double *x_dev, int64_t np, int *order_dev,
+                           int64_t *counts_host);
+/* dst[i] = src[order[i]] for rows of rowbytes (4, 8, 12, 16, 24, 36) bytes: fastpm_store_permute
+ * (store.c:377-444) applied to one column, out of place */
+int fpmhip_gather_rows(fpmhip_plan *plan, const void *src_dev, void *dst_dev, const int *order_dev,
+                       int64_t n, int rowbytes);
+
 /* fastpm_store_summary (store.c:807-908) before its Allreduces: per member of a float column
  * (nmemb values per particle) the min, max, sum and sum of squares in double.  Synchronises. */
 int fpmhip_store_summary(fpmhip_plan *plan, const float *column_dev, int nmemb, int64_t np,

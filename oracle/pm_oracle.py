@@ -376,3 +376,41 @@ def drift(forcemode, dyyy, da1, da2, Dv1, Dv2, x, v=None, dx1=None, dx2=None):
     lib().orc_drift(int(forcemode), cd(dyyy), cd(da1), cd(da2), cd(Dv1), cd(Dv2), _p(x), _p(v), _p(dx1), _p(dx2),
                     _p(xo), ctypes.c_int64(len(x)))
     return xo
+
+
+def pos_to_rank(N, BoxSize, nproc, x):
+    """pm_pos_to_rank (pmpfft.c:344-368): rank = rx * Ny + ry from the x, y cell of each position."""
+    x = np.asarray(x, dtype=np.float64)
+    inv = 1.0 / (BoxSize / N)
+    ex = np.array(block_edges(N, nproc[0]))
+    ey = np.array(block_edges(N, nproc[1]))
+    ix = np.mod(np.floor(x[:, 0] * inv).astype(np.int64), N)
+    iy = np.mod(np.floor(x[:, 1] * inv).astype(np.int64), N)
+    rx = np.searchsorted(ex, ix, side="right") - 1
+    ry = np.searchsorted(ey, iy, side="right") - 1
+    return rx * nproc[1] + ry
+
+
+def store_decompose(N, BoxSize, nproc, stores):
+    """fastpm_decompose (solver.c:571-592) over all ranks at once: wrap (store.c:446-475), then
+    fastpm_store_decompose (store.c:485-657).  `stores` = one dict of column arrays per rank (must
+    contain "x").  Returns the new per-rank dicts in the reference's order: particles that stay
+    (original order), then arrivals from rank 0, 1, ... in each sender's order."""
+    P = nproc[0] * nproc[1]
+    wrapped, targets = [], []
+    for r, st in enumerate(stores):
+        st = dict(st)
+        st["x"] = store_wrap(st["x"], BoxSize)
+        wrapped.append(st)
+        targets.append(pos_to_rank(N, BoxSize, nproc, st["x"]))
+    out = []
+    for r in range(P):
+        new = {}
+        for name in wrapped[r]:
+            parts = [wrapped[r][name][targets[r] == r]]
+            for s in range(P):
+                if s != r:
+                    parts.append(wrapped[s][name][targets[s] == r])
+            new[name] = np.concatenate(parts)
+        out.append(new)
+    return out

@@ -115,6 +115,20 @@ class CpuSlabOps:
                     value += m[ix[bx], iy[by], iz[bz]] * (W[bz][:, 2] * W[bx][:, 0] * W[by][:, 1])
         out.numpy().reshape(store.np, nmemb)[:, memb] = value.astype(np.float32)
 
+    # ---- decompose pieces
+    def wrap(self, store):
+        store.x.copy_(torch.from_numpy(O.store_wrap(store.x.numpy(), self.BoxSize)))
+
+    def decompose_order(self, store):
+        tgt = O.pos_to_rank(self.Nmesh, self.BoxSize, (self.nranks, 1), store.x.numpy())
+        key = np.where(tgt == self.rank, 0, tgt + 1)
+        order = np.argsort(key, kind="stable").astype(np.int32)
+        counts = np.bincount(key, minlength=self.nranks + 1)
+        return torch.from_numpy(order), [int(c) for c in counts]
+
+    def gather_rows(self, col, order):
+        return col[order.long()].contiguous()
+
     # ---- FFT stages
     def fft_yz_forward(self, canvas, send):
         N, xl, yl, nzc, P = self.Nmesh, self.xl, self.yl, self.nzc, self.nranks

@@ -63,3 +63,40 @@ def test_slab_force_over_gloo_matches_one_rank_oracle(oracle, tmp_path, world):
     assert util.max_err(dk, dko) <= 1e-13
     assert util.rel_err(acc, ref["acc"]) <= 1e-6
     assert util.rel_err(pot, ref["potential"]) <= 1e-6
+
+
+def _decompose_worker(rank, world, port, N, L, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cpu_slab_ops import CpuSlabOps
+    from fastpm_amd.distributed import SlabDecompose
+    from fastpm_amd.pm import Store
+    d = np.load(os.path.join(out_dir, "in%d.npz" % rank))
+    st = Store(d["x"], v=d["v"], device="cpu")
+    st.id = torch.from_numpy(d["id"])
+    SlabDecompose(CpuSlabOps(N, L, world, rank), dist.group.WORLD).decompose(st)
+    np.savez(os.path.join(out_dir, "out%d.npz" % rank), x=st.x.numpy(), v=st.v.numpy(), id=st.id.numpy(), np=st.np)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_decompose_over_gloo_matches_reference_order(oracle, tmp_path, world):
+    """fastpm_store_decompose's exchange (Alltoall of counts + Alltoallv of rows) over torch.distributed."""
+    N, L = 24, 36.0
+    rng = np.random.default_rng(23)
+    ostores = []
+    for r in range(world):
+        n = 400 + 100 * r
+        st = {"x": rng.uniform(-0.2 * L, 1.2 * L, (n, 3)), "v": rng.normal(size=(n, 3)).astype(np.float32),
+              "id": rng.integers(0, 2 ** 62, n, dtype=np.int64)}
+        np.savez(tmp_path / ("in%d.npz" % r), **st)
+        ostores.append(st)
+    mp.spawn(_decompose_worker, args=(world, _free_port(), N, L, str(tmp_path)), nprocs=world, join=True)
+    ref = oracle.store_decompose(N, L, (world, 1), ostores)
+    for r in range(world):
+        d = np.load(tmp_path / ("out%d.npz" % r))
+        assert int(d["np"]) == len(ref[r]["x"])
+        for name in ("x", "v", "id"):
+            assert np.array_equal(d[name], ref[r][name]), (r, name)
