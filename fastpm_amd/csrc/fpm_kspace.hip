@@ -75,6 +75,71 @@ __global__ __launch_bounds__(256) void transfer_kernel(MeshGeo g, const float *_
     to[ind] = out;
 }
 
+// fastpm_apply_laplace_transfer alone (transfer.c:153-186), for the 2LPT solver
+template <typename F>
+__global__ __launch_bounds__(256) void laplace_kernel(MeshGeo g, const float *__restrict__ kk,
+                                                      const Cplx<F> *__restrict__ from, Cplx<F> *__restrict__ to)
+{
+    KSPACE_INDEX(g)
+    double kk_finite = 0;
+    kk_finite += kk[ix];
+    kk_finite += kk[iy];
+    kk_finite += kk[iz];
+    Cplx<F> v = from[ind];
+    if (kk_finite != 0) {
+        const double r = 1 / kk_finite;
+        v.re = (F) (v.re * r);
+        v.im = (F) (v.im * r);
+    } else {
+        v.re = 0;
+        v.im = 0;
+    }
+    to[ind] = v;
+}
+
+// fastpm_apply_diff_transfer (transfer.c:115-151) as pm2lpt.c uses it, i.e. IN PLACE: the zeroing
+// of the self-conjugate modes (:133-136) is followed by an unconditional block (:137-143) that, in
+// place, recomputes (-0 * kf, 0 * kf) there -- zero either way.  Elsewhere (re, im) -> (-im kf, re kf).
+template <typename F>
+__global__ __launch_bounds__(256) void diff_kernel(MeshGeo g, const float *__restrict__ kt, int dir,
+                                                   Cplx<F> *__restrict__ data)
+{
+    KSPACE_INDEX(g)
+    const int N = g.N;
+    const int id = dir == 0 ? ix : (dir == 1 ? iy : iz);
+    const double k_finite = kt[id];
+    Cplx<F> v = data[ind];
+    if (ix == (N - ix) % N && iy == (N - iy) % N && iz == (N - iz) % N) {
+        v.re = 0;
+        v.im = 0;
+    }
+    Cplx<F> o;
+    o.re = (F) (-v.im * k_finite);
+    o.im = (F) (v.re * k_finite);
+    data[ind] = o;
+}
+
+// acc[i] = acc[i] + sign * a[i] * b[i] in FastPMFloat arithmetic (pm2lpt.c:112-130)
+template <typename F>
+__global__ __launch_bounds__(256) void mesh_fma_kernel(F *__restrict__ acc, const F *__restrict__ a,
+                                                       const F *__restrict__ b, long long n, int negative)
+{
+    long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const F prod = a[i] * b[i];
+        acc[i] = negative ? acc[i] - prod : acc[i] + prod;
+    }
+}
+
+template <typename F>
+__global__ __launch_bounds__(256) void mesh_scale_kernel(F *__restrict__ buf, long long n, double value)
+{
+    long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) buf[i] = (F) (buf[i] * value);
+}
+
 // to = from * (fx[ix] * fy[iy] * fz[iz]) with double factor tables: de-CIC (transfer.c:77-113)
 // and Gaussian softening (gravity.c:66-102).
 template <typename F>
@@ -263,6 +328,54 @@ int fpmhip_transfer(fpmhip_plan *p, const void *delta_k, void *out, int kernel, 
     const int dir = field == FPMHIP_FIELD_POTENTIAL ? -1 : field;
     return p->f64 ? transfer_impl<double>(p, delta_k, out, po, go, dir)
                   : transfer_impl<float>(p, delta_k, out, po, go, dir);
+}
+
+int fpmhip_laplace(fpmhip_plan *p, const void *from, void *to, int order)
+{
+    if (!p || !from || !to) FPM_FAIL(-1, "null argument");
+    if (order < 0 || order > 2) FPM_FAIL(-1, "laplace order %d", order);
+    const MeshGeo &g = p->mg;
+    const float *kk = p->d_tab + (2 + order) * (size_t) g.N;
+    dim3 grid(blocks_for((long long) g.yl * g.nzc, 256), g.N);
+    StageTimer tm(p, FPMHIP_T_TRANSFER);
+    if (p->f64) laplace_kernel<double><<<grid, 256, 0, p->stream>>>(g, kk, (const Cplx<double> *) from, (Cplx<double> *) to);
+    else laplace_kernel<float><<<grid, 256, 0, p->stream>>>(g, kk, (const Cplx<float> *) from, (Cplx<float> *) to);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int fpmhip_diff(fpmhip_plan *p, void *inplace, int dir, int order)
+{
+    if (!p || !inplace) FPM_FAIL(-1, "null argument");
+    if (order < 0 || order > 1 || dir < 0 || dir > 2) FPM_FAIL(-1, "diff dir %d order %d", dir, order);
+    const MeshGeo &g = p->mg;
+    const float *kt = p->d_tab + order * (size_t) g.N;
+    dim3 grid(blocks_for((long long) g.yl * g.nzc, 256), g.N);
+    StageTimer tm(p, FPMHIP_T_TRANSFER);
+    if (p->f64) diff_kernel<double><<<grid, 256, 0, p->stream>>>(g, kt, dir, (Cplx<double> *) inplace);
+    else diff_kernel<float><<<grid, 256, 0, p->stream>>>(g, kt, dir, (Cplx<float> *) inplace);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int fpmhip_mesh_fma(fpmhip_plan *p, void *acc, const void *a, const void *b, int negative)
+{
+    if (!p || !acc || !a || !b) FPM_FAIL(-1, "null argument");
+    const long long n = p->lay.real_elems;               // IRegion.total incl. padding (+ halo)
+    if (p->f64) mesh_fma_kernel<double><<<2048, 256, 0, p->stream>>>((double *) acc, (const double *) a, (const double *) b, n, negative);
+    else mesh_fma_kernel<float><<<2048, 256, 0, p->stream>>>((float *) acc, (const float *) a, (const float *) b, n, negative);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int fpmhip_mesh_scale(fpmhip_plan *p, void *buf, double value)
+{
+    if (!p || !buf) FPM_FAIL(-1, "null argument");
+    const long long n = p->lay.allocsize;                // transfer.c:212-220: the whole allocsize
+    if (p->f64) mesh_scale_kernel<double><<<2048, 256, 0, p->stream>>>((double *) buf, n, value);
+    else mesh_scale_kernel<float><<<2048, 256, 0, p->stream>>>((float *) buf, n, value);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 int fpmhip_decic(fpmhip_plan *p, const void *from, void *to)

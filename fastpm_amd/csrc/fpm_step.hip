@@ -56,6 +56,32 @@ __global__ __launch_bounds__(256) void drift_kernel(const double *__restrict__ x
     xo[i] = out;
 }
 
+// pm_2lpt_evolve (pm2lpt.c:168-210) without the dv1 branch: x += D1 dx1 + D2 dx2;
+// v += dx2 Dv2; v += Dv1 dx1 (two separate float += double steps, as in the reference)
+__global__ __launch_bounds__(256) void lpt_evolve_kernel(double *__restrict__ x, float *__restrict__ v,
+                                                         const float *__restrict__ dx1, const float *__restrict__ dx2,
+                                                         long long n3, double D1, double D2, double Dv1, double Dv2)
+{
+    long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n3) return;
+    x[i] += D1 * dx1[i] + D2 * dx2[i];
+    if (v) {
+        float vv = v[i];
+        vv += dx2[i] * Dv2;
+        vv += Dv1 * dx1[i];
+        v[i] = vv;
+    }
+}
+
+// x[i][d] += shift[d] (pm2lpt.c:29-33, 150-154)
+__global__ __launch_bounds__(256) void shift_kernel(double *__restrict__ x, long long n3, double s0, double s1, double s2)
+{
+    long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n3) return;
+    const int d = (int) (i % 3);
+    x[i] += d == 0 ? s0 : (d == 1 ? s1 : s2);
+}
+
 __global__ __launch_bounds__(256) void wrap_kernel(double *__restrict__ x, long long n3, double BoxSize)
 {
     long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
@@ -140,6 +166,29 @@ int fpmhip_wrap(fpmhip_plan *p, double *x, int64_t np)
     if (!p || (np > 0 && !x)) FPM_FAIL(-1, "null argument");
     if (np == 0) return 0;
     wrap_kernel<<<blocks_for(3 * np, 256), 256, 0, p->stream>>>(x, 3 * np, p->geom.BoxSize);
+    FPM_CHECK_HIP(hipGetLastError());
+    p->binned_np = -1;
+    p->binned_x = nullptr;
+    return 0;
+}
+
+int fpmhip_lpt_evolve(fpmhip_plan *p, double *x, float *v, const float *dx1, const float *dx2, int64_t np,
+                      double D1, double D2, double Dv1, double Dv2)
+{
+    if (!p || (np > 0 && (!x || !dx1 || !dx2))) FPM_FAIL(-1, "null argument");
+    if (np == 0) return 0;
+    lpt_evolve_kernel<<<blocks_for(3 * np, 256), 256, 0, p->stream>>>(x, v, dx1, dx2, 3 * np, D1, D2, Dv1, Dv2);
+    FPM_CHECK_HIP(hipGetLastError());
+    p->binned_np = -1;
+    p->binned_x = nullptr;
+    return 0;
+}
+
+int fpmhip_shift(fpmhip_plan *p, double *x, int64_t np, const double shift[3])
+{
+    if (!p || !shift || (np > 0 && !x)) FPM_FAIL(-1, "null argument");
+    if (np == 0) return 0;
+    shift_kernel<<<blocks_for(3 * np, 256), 256, 0, p->stream>>>(x, 3 * np, shift[0], shift[1], shift[2]);
     FPM_CHECK_HIP(hipGetLastError());
     p->binned_np = -1;
     p->binned_x = nullptr;

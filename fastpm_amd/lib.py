@@ -84,6 +84,12 @@ SYMBOLS = {
     "fpmhip_wrap": (_I, [_P, _P, _I64]),
     "fpmhip_decompose_order": (_I, [_P, _P, _I64, _P, ctypes.POINTER(_I64)]),
     "fpmhip_gather_rows": (_I, [_P, _P, _P, _P, _I64, _I]),
+    "fpmhip_laplace": (_I, [_P, _P, _P, _I]),
+    "fpmhip_diff": (_I, [_P, _P, _I, _I]),
+    "fpmhip_mesh_fma": (_I, [_P, _P, _P, _P, _I]),
+    "fpmhip_mesh_scale": (_I, [_P, _P, _D]),
+    "fpmhip_shift": (_I, [_P, _P, _I64, ctypes.POINTER(_D)]),
+    "fpmhip_lpt_evolve": (_I, [_P, _P, _P, _P, _P, _I64, _D, _D, _D, _D]),
     "fpmhip_store_summary": (_I, [_P, _P, _I, _I64, _P, _P, _P, _P]),
     "fpmhip_timing_enable": (_I, [_P, _I]),
     "fpmhip_timing_reset": (_I, [_P]),

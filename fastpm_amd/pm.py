@@ -157,6 +157,64 @@ def fastpm_store_wrap(pm, p):
     check(pm._L.fpmhip_wrap(pm._plan, _ptr(p.x), p.np))
 
 
+def pm_2lpt_solve(pm, delta_k, p, shift=(0.0, 0.0, 0.0), kernel="1_4"):
+    """pm_2lpt_solve(pm, delta_k, NULL, p, shift, type) (pm2lpt.c:14-164) on one rank, everything on
+    the device: fills p.dx1 and p.dx2 (float [np][3]) from the linear density delta_k (k-space mesh in
+    the plan's layout).  12 c2r + 1 r2c on the same operators as the force step."""
+    if pm.nranks != 1:
+        raise FastPMHipError("pm_2lpt_solve: one rank only in this round")
+    potorder, gradorder, difforder, _ = fastpm_kernel_type_get_orders(kernel)          # pm2lpt.c:17-18
+    L = pm._L
+    shift = (ctypes.c_double * 3)(*[float(v) for v in shift])
+    neg = (ctypes.c_double * 3)(*[-float(v) for v in shift])
+    check(L.fpmhip_shift(pm._plan, _ptr(p.x), p.np, neg))                             # pm2lpt.c:29-33
+    if p.dx1 is None:
+        p.dx1 = torch.zeros((p.np, 3), dtype=torch.float32, device=p.x.device)
+    if p.dx2 is None:
+        p.dx2 = torch.zeros((p.np, 3), dtype=torch.float32, device=p.x.device)
+    source, workspace = pm.alloc(), pm.alloc()
+    field = [pm.alloc() for _ in range(3)]
+    D1, D2 = (1, 2, 0), (2, 0, 1)
+    for d in range(3):                                                                # 1LPT, pm2lpt.c:62-87
+        check(L.fpmhip_laplace(pm._plan, _ptr(delta_k), _ptr(workspace), potorder))
+        check(L.fpmhip_diff(pm._plan, _ptr(workspace), d, difforder))
+        pm.c2r(workspace)
+        pm.readout(workspace, p, p.dx1, nmemb=3, memb=d)
+    for d in range(3):                                                                # 2LPT, :90-96
+        check(L.fpmhip_laplace(pm._plan, _ptr(delta_k), _ptr(field[d]), potorder))
+        check(L.fpmhip_diff(pm._plan, _ptr(field[d]), d, difforder))
+        check(L.fpmhip_diff(pm._plan, _ptr(field[d]), d, difforder))
+        pm.c2r(field[d])
+    for d in range(3):                                                                # :98-106
+        check(L.fpmhip_mesh_fma(pm._plan, _ptr(source), _ptr(field[D1[d]]), _ptr(field[D2[d]]), 0))
+    for d in range(3):                                                                # :108-121
+        check(L.fpmhip_laplace(pm._plan, _ptr(delta_k), _ptr(workspace), potorder))
+        check(L.fpmhip_diff(pm._plan, _ptr(workspace), D1[d], difforder))
+        check(L.fpmhip_diff(pm._plan, _ptr(workspace), D2[d], difforder))
+        pm.c2r(workspace)
+        check(L.fpmhip_mesh_fma(pm._plan, _ptr(source), _ptr(workspace), _ptr(workspace), 1))
+    pm.r2c(source, workspace)                                                         # :122-123
+    source.copy_(workspace)
+    for d in range(3):                                                                # :125-141
+        check(L.fpmhip_laplace(pm._plan, _ptr(source), _ptr(workspace), potorder))
+        check(L.fpmhip_diff(pm._plan, _ptr(workspace), d, difforder))
+        pm.c2r(workspace)
+        check(L.fpmhip_mesh_scale(pm._plan, _ptr(workspace), 3.0 / 7))
+        pm.readout(workspace, p, p.dx2, nmemb=3, memb=d)
+    check(L.fpmhip_shift(pm._plan, _ptr(p.x), p.np, shift))                           # :150-154
+    pm.invalidate_binning()
+
+
+def pm_2lpt_evolve(pm, p, D1, D2, Dv1, Dv2, aout, zaonly=False):
+    """pm_2lpt_evolve (pm2lpt.c:168-210) with the growth numbers supplied by the host (they come from
+    the GSL growth ODE, cosmology.c): x += D1 dx1 + D2 dx2, v += Dv2 dx2 + Dv1 dx1."""
+    if zaonly:
+        D2, Dv2 = 0.0, 0.0
+    check(pm._L.fpmhip_lpt_evolve(pm._plan, _ptr(p.x), _ptr(p.v), _ptr(p.dx1), _ptr(p.dx2), p.np,
+                                  float(D1), float(D2), float(Dv1), float(Dv2)))
+    p.a_x = p.a_v = float(aout)
+
+
 def fastpm_store_summary(pm, column, fmt, group=None):
     """fastpm_store_summary(p, attribute, comm, fmt, ...) (store.c:807-908) for a float column tensor
     [np][nmemb]: one array per character of fmt ('<' min, '>' max, '-' mean, 's' std, 'S', 'v', 'V')."""

@@ -219,6 +219,22 @@ int fpmhip_decompose_order(fpmhip_plan *plan, const double *x_dev, int64_t np, i
 int fpmhip_gather_rows(fpmhip_plan *plan, const void *src_dev, void *dst_dev, const int *order_dev,
                        int64_t n, int rowbytes);
 
+/* ---- "next" row 4: the extra operators pm_2lpt_solve (pm2lpt.c:14-164) needs beside r2c / c2r /
+ *      readout: laplace alone, the in-place diff transfer, mesh products, scaling, shift, evolve ---- */
+/* fastpm_apply_laplace_transfer (transfer.c:153-186) */
+int fpmhip_laplace(fpmhip_plan *plan, const void *from_dev, void *to_dev, int order);
+/* fastpm_apply_diff_transfer (transfer.c:115-151) in place, as pm2lpt.c calls it */
+int fpmhip_diff(fpmhip_plan *plan, void *inplace_dev, int dir, int order);
+/* acc += a * b (negative = 0) or acc -= a * b (negative != 0) over the real mesh (pm2lpt.c:112-130) */
+int fpmhip_mesh_fma(fpmhip_plan *plan, void *acc_dev, const void *a_dev, const void *b_dev, int negative);
+/* fastpm_apply_multiply_transfer (transfer.c:212-220) in place */
+int fpmhip_mesh_scale(fpmhip_plan *plan, void *buf_dev, double value);
+/* x[i][d] += shift[d] (pm2lpt.c:29-33, 150-154) */
+int fpmhip_shift(fpmhip_plan *plan, double *x_dev, int64_t np, const double shift[3]);
+/* pm_2lpt_evolve (pm2lpt.c:168-210), dv1-less: x += D1 dx1 + D2 dx2; v += Dv2 dx2 + Dv1 dx1 (v may be NULL) */
+int fpmhip_lpt_evolve(fpmhip_plan *plan, double *x_dev, float *v_dev, const float *dx1_dev, const float *dx2_dev,
+                      int64_t np, double D1, double D2, double Dv1, double Dv2);
+
 /* fastpm_store_summary (store.c:807-908) before its Allreduces: per member of a float column
  * (nmemb values per particle) the min, max, sum and sum of squares in double.  Synchronises. */
 int fpmhip_store_summary(fpmhip_plan *plan, const float *column_dev, int nmemb, int64_t np,

@@ -414,3 +414,54 @@ def store_decompose(N, BoxSize, nproc, stores):
             new[name] = np.concatenate(parts)
         out.append(new)
     return out
+
+
+def pm_2lpt_solve(pm, delta_k, x, shift=(0.0, 0.0, 0.0), kernel=KERNELS["1_4"]):
+    """pm_2lpt_solve (pm2lpt.c:14-164) on one rank, no dv1: returns (dx1, dx2) float32 [np][3].
+    The diff transfer is the reference's in-place form, whose self-conjugate modes end up zero
+    (transfer.c:133-143), i.e. the same arithmetic as orc_grad."""
+    assert pm.nproc == (1, 1)
+    potorder, gradorder, difforder, _ = kernel_orders(kernel)
+    xs = np.ascontiguousarray(x, dtype=np.float64) - np.asarray(shift, dtype=np.float64)     # pm2lpt.c:29-33
+    n = len(xs)
+    dx1 = np.zeros((n, 3), dtype=np.float32)
+    dx2 = np.zeros((n, 3), dtype=np.float32)
+    source, workspace = pm.alloc(), pm.alloc()
+    field = [pm.alloc() for _ in range(3)]
+    D1, D2 = (1, 2, 0), (2, 0, 1)
+    for d in range(3):
+        pm.laplace(delta_k, workspace, potorder)
+        pm.grad(workspace, workspace, d, difforder)
+        pm.c2r(workspace)
+        pm.readout(workspace, xs, out=dx1, nmemb=3, memb=d)
+    for d in range(3):
+        pm.laplace(delta_k, field[d], potorder)
+        pm.grad(field[d], field[d], d, difforder)
+        pm.grad(field[d], field[d], d, difforder)
+        pm.c2r(field[d])
+    nreal = pm.g.isize[0] * pm.g.istrides[0]                    # IRegion.total
+    for d in range(3):
+        source[:nreal] += field[D1[d]][:nreal] * field[D2[d]][:nreal]
+    for d in range(3):
+        pm.laplace(delta_k, workspace, potorder)
+        pm.grad(workspace, workspace, D1[d], difforder)
+        pm.grad(workspace, workspace, D2[d], difforder)
+        pm.c2r(workspace)
+        source[:nreal] -= workspace[:nreal] * workspace[:nreal]
+    source = pm.r2c(source)
+    for d in range(3):
+        pm.laplace(source, workspace, potorder)
+        pm.grad(workspace, workspace, d, difforder)
+        pm.c2r(workspace)
+        pm.scale(workspace, 3.0 / 7)
+        pm.readout(workspace, xs, out=dx2, nmemb=3, memb=d)
+    return dx1, dx2
+
+
+def pm_2lpt_evolve(x, v, dx1, dx2, D1, D2, Dv1, Dv2):
+    """pm_2lpt_evolve (pm2lpt.c:168-210), dv1-less."""
+    xo = np.asarray(x, dtype=np.float64) + (D1 * dx1.astype(np.float64) + D2 * dx2.astype(np.float64))
+    vo = np.asarray(v, dtype=np.float32).copy()
+    vo = (vo.astype(np.float64) + dx2.astype(np.float64) * Dv2).astype(np.float32)
+    vo = (vo.astype(np.float64) + Dv1 * dx1.astype(np.float64)).astype(np.float32)
+    return xo, vo

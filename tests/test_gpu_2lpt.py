@@ -1,0 +1,56 @@
+"""2LPT initial conditions on the device ("next" row 4): pm_2lpt_solve / pm_2lpt_evolve
+(reference libfastpm/pm2lpt.c:14-210) on the same operators as the force step, against the oracle's
+restatement.  Tolerance: dx1, dx2 are float columns read out of fp64 meshes that went through 12 c2r
+and 1 r2c (rocFFT/column FFT vs pocketfft): 1e-6 of rms."""
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _linear_delta_k(pmo, seed, amp=0.02):
+    """A Hermitian-consistent delta(k): FFT of a smooth real Gaussian field."""
+    rng = np.random.default_rng(seed)
+    N = pmo.N
+    cv = pmo.alloc()
+    f = rng.normal(size=(N, N, N))
+    k1 = np.fft.fftfreq(N) * N
+    kx, ky, kz = np.meshgrid(k1, k1, k1[: N // 2 + 1], indexing="ij")
+    k2 = kx ** 2 + ky ** 2 + kz ** 2
+    fk = np.fft.rfftn(f) * np.exp(-k2 / (2 * (N / 8.0) ** 2))
+    fk[0, 0, 0] = 0
+    f = np.fft.irfftn(fk, s=(N, N, N), axes=(0, 1, 2))
+    pmo.real_view(cv)[:, :, :N] = amp * f / f.std()
+    return pmo.r2c(cv)
+
+
+@pytest.mark.parametrize("kernel,shift", [("1_4", (0.0, 0.0, 0.0)), ("3_4", (0.75, 0.75, 0.75)), ("1_4_diff0", (0.0, 0.0, 0.0))])
+def test_2lpt_solve_and_evolve(oracle, kernel, shift):
+    import torch
+    from fastpm_amd import PM, Store, pm_2lpt_solve, pm_2lpt_evolve
+    N, nc, L = 32, 16, 48.0
+    pmo = oracle.PMOracle(N, L, 64)
+    dk = _linear_delta_k(pmo, 5)
+    q = util.lattice(nc, L) + np.asarray(shift)
+    ref1, ref2 = oracle.pm_2lpt_solve(pmo, dk, q, shift=shift, kernel=oracle.KERNELS[kernel])
+    pm = PM(N, L, 64)
+    d_dk = pm.alloc()
+    pm.complex_view(d_dk).copy_(torch.from_numpy(np.ascontiguousarray(util.oracle_k_to_xyk(pmo, dk))).cuda())
+    st = Store(q, v=np.zeros_like(q, dtype=np.float32))
+    pm_2lpt_solve(pm, d_dk, st, shift=shift, kernel=kernel)
+    torch.cuda.synchronize()
+    assert np.array_equal(st.x.cpu().numpy(), (q - np.asarray(shift)) + np.asarray(shift))   # shifted back (pm2lpt.c:150-154)
+    assert util.rel_err(st.dx1.cpu().numpy(), ref1) <= 1e-6
+    assert util.rel_err(st.dx2.cpu().numpy(), ref2) <= 1e-6
+    assert np.abs(ref2).max() > 0 and np.abs(ref1).max() > 10 * np.abs(ref2).max()            # 2nd order is 2nd order
+    # evolve to a = 0.1 with made-up growth numbers (the real ones come from the GSL growth ODE)
+    D1, D2, Dv1, Dv2 = 0.1, -3.0 / 7 * 0.01, 0.03, -0.002
+    xo, vo = oracle.pm_2lpt_evolve((q - np.asarray(shift)) + np.asarray(shift), np.zeros_like(ref1),
+                                   st.dx1.cpu().numpy(), st.dx2.cpu().numpy(), D1, D2, Dv1, Dv2)
+    pm_2lpt_evolve(pm, st, D1, D2, Dv1, Dv2, aout=0.1)
+    torch.cuda.synchronize()
+    assert np.array_equal(st.x.cpu().numpy(), xo) and np.array_equal(st.v.cpu().numpy(), vo)
+    assert st.a_x == 0.1 and st.a_v == 0.1
+    pm.destroy()
