@@ -321,9 +321,21 @@ int fpmhip_transfer(fpmhip_plan *p, const void *delta_k, void *out, int kernel, 
     if (!p || !delta_k || !out) FPM_FAIL(-1, "null argument");
     int po, go, dfo, dc;
     FPM_TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));
-    if (field < 0 || field > FPMHIP_FIELD_POTENTIAL) FPM_FAIL(-1, "Unknown type for gravity attribute");
+    if (field < 0 || field > FPMHIP_FIELD_TIDAL_ZX) FPM_FAIL(-1, "Unknown type for gravity attribute");   // gravity.c:240
     // deconvolveorder (GADGET / EASTWOOD) de-CICs the stale canvas and is then overwritten
     // (gravity.c:182-190): no effect on the result, not executed here.
+    if (field == FPMHIP_FIELD_DENSITY) {                     // gravity.c:208-210: multiply by 1.0
+        if (out != delta_k)
+            FPM_CHECK_HIP(hipMemcpyAsync(out, delta_k, (size_t) p->lay.allocsize * p->esize, hipMemcpyDeviceToDevice, p->stream));
+        return 0;
+    }
+    if (field >= FPMHIP_FIELD_TIDAL_XX) {                    // gravity.c:211-233: pot, then two gradients
+        static const int d1[6] = {0, 1, 2, 0, 1, 2}, d2[6] = {0, 1, 2, 1, 2, 0};
+        const int m = field - FPMHIP_FIELD_TIDAL_XX;
+        FPM_TRY(fpmhip_transfer(p, delta_k, out, kernel, FPMHIP_FIELD_POTENTIAL));
+        FPM_TRY(fpmhip_diff(p, out, d1[m], go));             // apply_grad_transfer in place == diff in place
+        return fpmhip_diff(p, out, d2[m], go);
+    }
     StageTimer tm(p, FPMHIP_T_TRANSFER);
     const int dir = field == FPMHIP_FIELD_POTENTIAL ? -1 : field;
     return p->f64 ? transfer_impl<double>(p, delta_k, out, po, go, dir)
@@ -482,6 +494,34 @@ int fpmhip_plane_add(fpmhip_plan *p, void *dst, const void *src)
     else plane_add_kernel<float><<<blocks_for(n, 256), 256, 0, p->stream>>>((float *) dst, (const float *) src, n);
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+int fpmhip_import_delta_k(fpmhip_plan *p, const void *host, void *delta_k)
+{
+    if (!p || !delta_k || !host) FPM_FAIL(-1, "null argument");
+    FPM_TRY(ensure_buffer(p, BUF_XCHG));
+    if (delta_k == p->buf[BUF_XCHG]) FPM_FAIL(-1, "import target must not be the exchange buffer");
+    const MeshGeo &g = p->mg;
+    const long long plane = (long long) g.yl * g.nzc;
+    FPM_CHECK_HIP(hipMemcpyAsync(p->buf[BUF_XCHG], host, (size_t) 2 * p->lay.complex_elems * p->esize,
+                                 hipMemcpyHostToDevice, p->stream));
+    // [y_loc][kz][x] -> [x][y_loc][kz]: the same tile transpose with the roles of the axes swapped
+    dim3 grid(blocks_for(g.N, 32), blocks_for(plane, 32));
+    if (p->f64) to_reference_layout_kernel<double><<<grid, 256, 0, p->stream>>>((int) plane, g.N, (const Cplx<double> *) p->buf[BUF_XCHG], (Cplx<double> *) delta_k);
+    else to_reference_layout_kernel<float><<<grid, 256, 0, p->stream>>>((int) plane, g.N, (const Cplx<float> *) p->buf[BUF_XCHG], (Cplx<float> *) delta_k);
+    FPM_CHECK_HIP(hipGetLastError());
+    FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
+    return 0;
+}
+
+int fpmhip_transfer_host(fpmhip_plan *p, int kernel, const void *delta_k_host, void *canvas_host, int field)
+{
+    if (!p || !delta_k_host || !canvas_host) FPM_FAIL(-1, "null argument");
+    FPM_TRY(ensure_buffer(p, BUF_DELTA_K));
+    FPM_TRY(ensure_buffer(p, BUF_CANVAS));
+    FPM_TRY(fpmhip_import_delta_k(p, delta_k_host, p->buf[BUF_DELTA_K]));
+    FPM_TRY(fpmhip_transfer(p, p->buf[BUF_DELTA_K], p->buf[BUF_CANVAS], kernel, field));
+    return fpmhip_export_delta_k(p, p->buf[BUF_CANVAS], canvas_host);
 }
 
 int fpmhip_export_delta_k(fpmhip_plan *p, const void *delta_k, void *host)

@@ -79,6 +79,8 @@ SYMBOLS = {
     "fpmhip_powerspectrum": (_I, [_P, _P, _P, _P, _P, _P]),
     "fpmhip_check_values": (_I, [_P, _P, ctypes.POINTER(_I64)]),
     "fpmhip_export_delta_k": (_I, [_P, _P, _P]),
+    "fpmhip_import_delta_k": (_I, [_P, _P, _P]),
+    "fpmhip_transfer_host": (_I, [_P, _I, _P, _P, _I]),
     "fpmhip_kick": (_I, [_P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(KickFactor)]),
     "fpmhip_drift": (_I, [_P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(DriftFactor)]),
     "fpmhip_wrap": (_I, [_P, _P, _I64]),

@@ -408,6 +408,14 @@ class PM:
         check(self._L.fpmhip_export_delta_k(self._plan, _ptr(delta_k), out.ctypes.data_as(ctypes.c_void_p)))
         return out
 
+    def gravity_apply_kernel_transfer_host(self, kernel, delta_k_host, field):
+        """gravity_apply_kernel_transfer on host meshes in the reference layout [y_loc][kz][x]."""
+        src = np.ascontiguousarray(delta_k_host)
+        out = np.empty_like(src)
+        check(self._L.fpmhip_transfer_host(self._plan, _enum(KERNEL_TYPES, kernel), src.ctypes.data_as(ctypes.c_void_p),
+                                           out.ctypes.data_as(ctypes.c_void_p), int(field)))
+        return out
+
     # ---- slab stages (nranks > 1)
     def plane(self, mesh, ix):
         L = self.layout

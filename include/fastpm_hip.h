@@ -42,7 +42,10 @@ enum { FPMHIP_KERNEL_3_4 = 0, FPMHIP_KERNEL_3_2, FPMHIP_KERNEL_5_4, FPMHIP_KERNE
 enum { FPMHIP_SOFTENING_NONE = 0, FPMHIP_SOFTENING_GAUSSIAN, FPMHIP_SOFTENING_GADGET_LONG_RANGE,
        FPMHIP_SOFTENING_TWO_THIRD, FPMHIP_SOFTENING_GAUSSIAN36 };
 /* field selector of fpmhip_transfer: COLUMN_ACC memb 0..2, COLUMN_POTENTIAL (gravity.c:478-483) */
-enum { FPMHIP_FIELD_ACC_X = 0, FPMHIP_FIELD_ACC_Y = 1, FPMHIP_FIELD_ACC_Z = 2, FPMHIP_FIELD_POTENTIAL = 3 };
+enum { FPMHIP_FIELD_ACC_X = 0, FPMHIP_FIELD_ACC_Y = 1, FPMHIP_FIELD_ACC_Z = 2, FPMHIP_FIELD_POTENTIAL = 3,
+       FPMHIP_FIELD_DENSITY = 4,                 /* COLUMN_DENSITY (gravity.c:208-210) */
+       FPMHIP_FIELD_TIDAL_XX = 5, FPMHIP_FIELD_TIDAL_YY, FPMHIP_FIELD_TIDAL_ZZ,   /* COLUMN_TIDAL memb 0..5 */
+       FPMHIP_FIELD_TIDAL_XY, FPMHIP_FIELD_TIDAL_YZ, FPMHIP_FIELD_TIDAL_ZX };     /* (gravity.c:211-233) */
 /* paint algorithm */
 enum { FPMHIP_PAINT_TILED = 0,      /* tile-binned particles, LDS-staged tiles, no global atomics */
        FPMHIP_PAINT_ATOMIC = 1 };   /* one global atomicAdd per corner (baseline for A/B evidence) */
@@ -186,8 +189,12 @@ int fpmhip_powerspectrum(fpmhip_plan *plan, const void *d1_dev, const void *d2_d
                          double *ksum_host, double *psum_host, double *nmodes_host);
 /* pm_check_values (pmapi.c:335-356): count of NaN / |v| > 1e15 entries.  Synchronises. */
 int fpmhip_check_values(fpmhip_plan *plan, const void *mesh_dev, int64_t *count_host);
-/* copy a k-space mesh to the host in the reference's PFFT-transposed layout [y][z][x] */
+/* copy a k-space mesh to the host in the reference's PFFT-transposed layout [y][z][x], and back */
 int fpmhip_export_delta_k(fpmhip_plan *plan, const void *delta_k_dev, void *delta_k_host);
+int fpmhip_import_delta_k(fpmhip_plan *plan, const void *delta_k_host, void *delta_k_dev);
+/* gravity_apply_kernel_transfer (api/fastpm/gravity.h:21-22, gravity.c:174-242) for callers whose
+ * meshes live on the host in the reference layout: upload, transfer (any field), download */
+int fpmhip_transfer_host(fpmhip_plan *plan, int kernel, const void *delta_k_host, void *canvas_host, int field);
 
 /* ---- "next" row 1: the particle updates either side of the force step, device-resident ----
  * FastPMForceType, api/fastpm/libfastpm.h:39-44 */

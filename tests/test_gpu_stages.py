@@ -281,3 +281,29 @@ def test_column_fft_backend_matches_rocfft_and_oracle(oracle, precision, N):
     assert util.max_err(pm.real_view(k_own).cpu().numpy()[:, :, :N], pmo.real_view(cv)[:, :, :N]) <= 10 * tol
     pm.destroy()
     pr.destroy()
+
+
+def test_host_mesh_transfer_all_fields(oracle):
+    """gravity_apply_kernel_transfer for host meshes in the reference layout (the companion public
+    symbol of api/fastpm/gravity.h:21-22): ACC, POTENTIAL, DENSITY and the six TIDAL members."""
+    N, L = 16, 37.0
+    pmo = oracle.PMOracle(N, L, 64)
+    dk = _rand_k(pmo, 61)
+    pm = _pm(N, L, 64)
+    host = np.ascontiguousarray(pmo.complex_view(dk))        # [y][kz][x]
+    po, go, _, _ = oracle.kernel_orders(oracle.KERNELS["3_4"])
+    tid = [(0, 0), (1, 1), (2, 2), (0, 1), (1, 2), (2, 0)]
+    for field in range(11):
+        got = pm.gravity_apply_kernel_transfer_host("3_4", host, field)
+        ref = pmo.alloc()
+        if field <= 3:
+            pmo.kernel_transfer(oracle.KERNELS["3_4"], dk, ref, memb=field % 3, potential=field == 3)
+        elif field == 4:
+            ref[:] = dk
+        else:
+            d1, d2 = tid[field - 5]
+            pmo.kernel_transfer(oracle.KERNELS["3_4"], dk, ref, potential=True)       # gravity.c:213-216
+            pmo.grad(ref, ref, d1, go)
+            pmo.grad(ref, ref, d2, go)
+        assert np.array_equal(got, pmo.complex_view(ref)), field
+    pm.destroy()
