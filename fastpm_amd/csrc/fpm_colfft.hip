@@ -331,9 +331,14 @@ __global__ __launch_bounds__(N, 4) void colfft_xback3_kernel(const C2<F> *__rest
 #pragma unroll 1
     for (int dir = 0; dir < 3; dir++) {
         C2<F> v[VMAX];
+        // an opaque copy of tau per iteration: keeps the compiler from hoisting the table values,
+        // flags and store addresses of all three iterations above the loop, where they would have
+        // to live in (spilled) registers across the transforms (12 spilled VGPRs = +14 % HBM traffic)
+        int tau_o = tau;
+        asm volatile("" : "+v"(tau_o));
 #pragma unroll
         for (int j = 0; j < EPT; j++) {
-            const int ix = tau + T * j;
+            const int ix = tau_o + T * j;
             const double k_finite = dir == 0 ? kt[ix] : (dir == 1 ? kt[iy] : kt[iz]);
             const bool selfconj = yz_self && ix == (N - ix) % N;       // gravity.c:44-56
             if (selfconj) {
@@ -348,8 +353,9 @@ __global__ __launch_bounds__(N, 4) void colfft_xback3_kernel(const C2<F> *__rest
         fft_core<N, R2, R3, R4, +1>(v, lds, tw, tau, c);
         if (live) {
             C2<F> *dst = outs[dir];
+            const unsigned toff_o = (unsigned) tau_o * (unsigned) rstride + (unsigned) col;
 #pragma unroll
-            for (int j = 0; j < EPT; j++) (dst + j * jstride)[toff] = v[j];
+            for (int j = 0; j < EPT; j++) (dst + j * jstride)[toff_o] = v[j];
         }
     }
 }
@@ -494,22 +500,34 @@ int colfft_x(fpmhip_plan *p, int dir, const void *in, void *out, double scale)
 // layout [rank][x_loc][y_loc][kz] (output when dir < 0 = pack, input when dir > 0 = unpack).
 int colfft_y(fpmhip_plan *p, int dir, const void *in, void *out, int chunked)
 {
+    return colfft_y_range(p, dir, in, out, chunked, 0, p->mg.xl);
+}
+
+// the same for the x planes [x0, x0 + nx) only
+int colfft_y_range(fpmhip_plan *p, int dir, const void *in, void *out, int chunked, int x0, int nx)
+{
     const MeshGeo &g = p->mg;
     const long long plane = (long long) g.N * g.nzc;
     ColMap natural{plane, 0, g.nzc, g.N};
     ColMap chunks{(long long) g.yl * g.nzc, (long long) g.xl * g.yl * g.nzc, g.nzc, g.yl};
     const ColMap &im = (chunked && dir > 0) ? chunks : natural;
     const ColMap &om = (chunked && dir < 0) ? chunks : natural;
-    return p->f64 ? colfft_launch<double>(p, dir, in, out, im, om, g.xl, g.nzc, 1.0)
-                  : colfft_launch<float>(p, dir, in, out, im, om, g.xl, g.nzc, 1.0);
+    const size_t cb = 2 * p->esize;
+    const char *inp = (const char *) in + (size_t) x0 * im.bstride * cb;
+    char *outp = (char *) out + (size_t) x0 * om.bstride * cb;
+    return p->f64 ? colfft_launch<double>(p, dir, inp, outp, im, om, nx, g.nzc, 1.0)
+                  : colfft_launch<float>(p, dir, inp, outp, im, om, nx, g.nzc, 1.0);
 }
 
 template <typename F>
-static int rowfft_launch(fpmhip_plan *p, const void *in, void *out)
+static int rowfft_launch(fpmhip_plan *p, const void *in_, void *out_, int x0, int nx)
 {
     const MeshGeo &g = p->mg;
     const int M = g.N / 2;
-    const int nrows = g.xl * g.N;
+    const int nrows = nx * g.N;
+    const size_t off = (size_t) x0 * g.N * g.nzc * sizeof(C2<F>);
+    const void *in = (const char *) in_ + off;
+    void *out = (char *) out_ + off;
     const int nblocks = (nrows + COLS - 1) / COLS;
     const size_t lds = (size_t) M * COLS * sizeof(C2<F>) + 2 * (size_t) M * sizeof(C2<F>);
 #define CALL_ROW(n, r2, r3, r4)                                                                         \
@@ -525,9 +543,11 @@ static int rowfft_launch(fpmhip_plan *p, const void *in, void *out)
 // z pass forward (r2c) on [x_loc][y][N+2] real rows -> [x_loc][y][N/2+1]; in place or out of place
 bool rowfft_supported(int N) { return N >= 32 && N % 2 == 0 && colfft_supported(N / 2); }
 
-int rowfft_r2c(fpmhip_plan *p, const void *in, void *out)
+int rowfft_r2c(fpmhip_plan *p, const void *in, void *out) { return rowfft_r2c_range(p, in, out, 0, p->mg.xl); }
+
+int rowfft_r2c_range(fpmhip_plan *p, const void *in, void *out, int x0, int nx)
 {
-    return p->f64 ? rowfft_launch<double>(p, in, out) : rowfft_launch<float>(p, in, out);
+    return p->f64 ? rowfft_launch<double>(p, in, out, x0, nx) : rowfft_launch<float>(p, in, out, x0, nx);
 }
 
 template <typename F>

@@ -94,6 +94,19 @@ int fft_setup(fpmhip_plan *p)
         FPM_TRY(make_plan(&p->p_zc2r_ip, rocfft_placement_inplace, rocfft_transform_type_real_inverse, p->f64, 1,
                           len1, xl * N, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, one,
                           nzc, one, N + 2, 1.0));
+        {   // plane chunking through the Infinity Cache (FPMHIP_CHUNK_MB = 0 disables)
+            const char *e = getenv("FPMHIP_CHUNK_MB");
+            const double mb = e ? atof(e) : 0.0;
+            const double plane_bytes = (double) N * nzc * 2 * p->esize;
+            int cp = mb > 0 ? (int) (mb * 1048576.0 / plane_bytes) : 0;
+            if (cp >= 1 && cp < (int) xl) {
+                while (xl % cp != 0) cp--;
+                p->chunk_planes = cp;
+                FPM_TRY(make_plan(&p->p_zc2r_chunk, rocfft_placement_inplace, rocfft_transform_type_real_inverse,
+                                  p->f64, 1, len1, (size_t) cp * N, rocfft_array_type_hermitian_interleaved,
+                                  rocfft_array_type_real, one, nzc, one, N + 2, 1.0));
+            }
+        }
         // twiddles e^{-2 pi i j / N} in double, octant-exact where it matters (j = 0, N/4, N/2, ...)
         std::vector<double> tw(2 * N);
         for (size_t j = 0; j < N; j++) {
@@ -140,7 +153,7 @@ int fft_setup(fpmhip_plan *p)
     }
     size_t work = 0;
     rocfft_plan all[] = {p->p_r2c3d, p->p_c2r3d, p->p_r2c2d, p->p_c2r2d, p->p_xfwd, p->p_xbwd,
-                         p->p_zr2c_op, p->p_zr2c_ip, p->p_zc2r_ip};
+                         p->p_zr2c_op, p->p_zr2c_ip, p->p_zc2r_ip, p->p_zc2r_chunk};
     for (rocfft_plan q : all) {
         if (!q) continue;
         size_t w = 0;
@@ -160,7 +173,7 @@ int fft_setup(fpmhip_plan *p)
 void fft_teardown(fpmhip_plan *p)
 {
     rocfft_plan all[] = {p->p_r2c3d, p->p_c2r3d, p->p_r2c2d, p->p_c2r2d, p->p_xfwd, p->p_xbwd,
-                         p->p_zr2c_op, p->p_zr2c_ip, p->p_zc2r_ip};
+                         p->p_zr2c_op, p->p_zr2c_ip, p->p_zc2r_ip, p->p_zc2r_chunk};
     for (rocfft_plan q : all) if (q) rocfft_plan_destroy(q);
     if (p->fft_info) rocfft_execution_info_destroy(p->fft_info);
     if (p->fft_work) (void) hipFree(p->fft_work);
@@ -174,6 +187,31 @@ static int launch_pack(fpmhip_plan *p, void *slab, void *chunks)
     slab_pack_kernel<F, PACK><<<grid, 256, 0, p->stream>>>(g.xl, g.N, g.yl, g.nzc, (Cplx2<F> *) slab,
                                                             (Cplx2<F> *) chunks);
     FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// forward (z then y) and backward (y then z) pass pairs of the column-FFT back end, chunk by chunk
+static int zy_forward(fpmhip_plan *p, void *in, void *mid, void *out, int chunked)
+{
+    // in --z--> mid --y--> out   (mid == in for an in-place z pass; out may alias mid when !chunked)
+    const int xl = p->mg.xl, cp = p->chunk_planes && rowfft_supported(p->mg.N) ? p->chunk_planes : xl;
+    for (int x0 = 0; x0 < xl; x0 += cp) {
+        if (cp == xl) FPM_TRY(z_forward(p, in, mid));
+        else FPM_TRY(rowfft_r2c_range(p, in, mid, x0, cp));
+        FPM_TRY(colfft_y_range(p, -1, mid, out, chunked, x0, cp));
+    }
+    return 0;
+}
+
+static int yz_backward(fpmhip_plan *p, void *in, void *out, int chunked)
+{
+    const int xl = p->mg.xl, cp = p->chunk_planes ? p->chunk_planes : xl;
+    const size_t plane_bytes = (size_t) p->mg.N * p->mg.nzc * 2 * p->esize;
+    for (int x0 = 0; x0 < xl; x0 += cp) {
+        FPM_TRY(colfft_y_range(p, +1, in, out, chunked, x0, cp));
+        if (cp == xl) FPM_TRY(fft_exec(p, p->p_zc2r_ip, out, nullptr));
+        else FPM_TRY(fft_exec(p, p->p_zc2r_chunk, (char *) out + (size_t) x0 * plane_bytes, nullptr));
+    }
     return 0;
 }
 
@@ -196,8 +234,7 @@ int fpmhip_r2c(fpmhip_plan *p, void *canvas, void *delta_k)
     if (canvas == delta_k) FPM_FAIL(-1, "pm_r2c is out of place (pmapi.h:97-100)");
     StageTimer tm(p, FPMHIP_T_R2C);
     if (p->own_fft) {
-        FPM_TRY(z_forward(p, canvas, delta_k));
-        FPM_TRY(colfft_y(p, -1, delta_k, delta_k, 0));
+        FPM_TRY(zy_forward(p, canvas, delta_k, delta_k, 0));
         return colfft_x(p, -1, delta_k, delta_k, 1.0 / p->lay.Norm);
     }
     return fft_exec(p, p->p_r2c3d, canvas, delta_k);
@@ -210,8 +247,7 @@ int fpmhip_c2r(fpmhip_plan *p, void *inplace)
     StageTimer tm(p, FPMHIP_T_C2R);
     if (p->own_fft) {
         FPM_TRY(colfft_x(p, +1, inplace, inplace, 1.0));
-        FPM_TRY(colfft_y(p, +1, inplace, inplace, 0));
-        return fft_exec(p, p->p_zc2r_ip, inplace, nullptr);
+        return yz_backward(p, inplace, inplace, 0);
     }
     return fft_exec(p, p->p_c2r3d, inplace, nullptr);
 }
@@ -224,14 +260,12 @@ int fpmhip_fft_yz_forward(fpmhip_plan *p, void *canvas, void *send)
         StageTimer tm(p, FPMHIP_T_R2C);
         if (p->lay.nranks == 1) {
             // one rank: the chunk layout is the natural one; z pass (out of place unless aliased), y in place
-            FPM_TRY(z_forward(p, canvas, send));
-            return colfft_y(p, -1, send, send, 0);
+            return zy_forward(p, canvas, send, send, 0);
         }
         if (canvas == send) FPM_FAIL(-1, "fft_yz_forward: canvas and send must differ when nranks > 1");
         // z pass in place on the slab, then the y pass writes straight into the exchange chunks
         // [rank][x_loc][y_loc][kz] (pack fused into the pass)
-        FPM_TRY(z_forward(p, canvas, canvas));
-        return colfft_y(p, -1, canvas, send, 1);
+        return zy_forward(p, canvas, canvas, send, 1);
     }
     {
         StageTimer tm(p, FPMHIP_T_R2C);
@@ -267,8 +301,7 @@ int fpmhip_fft_yz_backward(fpmhip_plan *p, void *recv, void *canvas)
         StageTimer tm(p, FPMHIP_T_C2R);
         // y pass reads the exchange chunks directly (unpack fused) and writes the natural slab
         if (p->lay.nranks > 1 && recv == canvas) FPM_FAIL(-1, "fft_yz_backward: recv and canvas must differ when nranks > 1");
-        FPM_TRY(colfft_y(p, +1, recv, canvas, p->lay.nranks > 1 ? 1 : 0));
-        return fft_exec(p, p->p_zc2r_ip, canvas, nullptr);
+        return yz_backward(p, recv, canvas, p->lay.nranks > 1 ? 1 : 0);
     }
     {
         StageTimer tm(p, FPMHIP_T_PACK);

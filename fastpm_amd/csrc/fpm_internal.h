@@ -100,6 +100,10 @@ struct fpmhip_plan {
     // own column-FFT mode: rocFFT only does the contiguous z pass (1-D r2c / c2r, batch xl*N)
     bool own_fft = false;
     rocfft_plan p_zr2c_op = nullptr, p_zr2c_ip = nullptr, p_zc2r_ip = nullptr;
+    // (z, y) passes run plane-chunk by plane-chunk so that the intermediate of a dependent pair of
+    // sweeps is still in the 256 MiB Infinity Cache when the second sweep reads it
+    int chunk_planes = 0;                  // 0 = whole slab in one go
+    rocfft_plan p_zc2r_chunk = nullptr;    // z c2r for chunk_planes * N rows
     double *d_twiddle = nullptr;   // e^{-2 pi i j / N}, j < N (re, im)
     rocfft_execution_info fft_info = nullptr;
     void *fft_work = nullptr;
@@ -159,6 +163,8 @@ void fft_teardown(fpmhip_plan *p);
 bool colfft_supported(int N);
 int colfft_x(fpmhip_plan *p, int dir, const void *in, void *out, double scale);
 int colfft_y(fpmhip_plan *p, int dir, const void *in, void *out, int chunked);
+int colfft_y_range(fpmhip_plan *p, int dir, const void *in, void *out, int chunked, int x0, int nx);
+int rowfft_r2c_range(fpmhip_plan *p, const void *in, void *out, int x0, int nx);
 bool rowfft_supported(int N);
 int rowfft_r2c(fpmhip_plan *p, const void *in, void *out);
 int colfft_xback3(fpmhip_plan *p, const void *dk, void *o0, void *o1, void *o2, int potorder, int gradorder);
