@@ -171,7 +171,11 @@ __global__ __launch_bounds__(256) void paint_tiles_kernel(MeshGeo g, int ntiles,
                                                           const float *__restrict__ smass, double M0,
                                                           double scale, F *__restrict__ canvas)
 {
-    __shared__ F tile[TILE_CELLS];
+    // accumulators are double for both mesh precisions: the reference adds the double weight to the
+    // cell in double and rounds to FastPMFloat per add (painter-cic.c:24); one rounding at the end is
+    // the same tolerance class, and ds_add_f64 runs 7x faster than ds_add_f32 here (measured
+    // SQ_LDS_IDX_ACTIVE 5.6e7 vs 4.1e8 for the same adds; fp32 paint 0.77 -> ms below)
+    __shared__ double tile[TILE_CELLS];
     const int t = xcd_remap(blockIdx.x, ntiles);
     const int tz = t % g.ntz, ty = (t / g.ntz) % g.nty, tx = t / (g.ntz * g.nty);
     const int x0 = tx * TILE_X, y0 = ty * TILE_Y, z0 = tz * TILE_Z;
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(256) void paint_tiles_kernel(MeshGeo g, int ntiles,
                 if ((unsigned) lx[bx] < (unsigned) TILE_X && (unsigned) ly[by] < (unsigned) TILE_Y &&
                     (unsigned) lz[bz] < (unsigned) TILE_Z) {
                     double f = wz[bz] * wx[bx] * wy[by];    // painter-cic.c:84-107: Wz*Wx*Wy
-                    atomicAdd(&tile[(lx[bx] * TILE_Y + ly[by]) * TILE_Z + lz[bz]], (F) f);
+                    atomicAdd(&tile[(lx[bx] * TILE_Y + ly[by]) * TILE_Z + lz[bz]], f);
                 }
             }
         }
