@@ -128,7 +128,7 @@ constexpr int VMAX = 10;  // register slots: a radix-3 / radix-5 stage touches u
 //   in : values (kprev, ts*M + t), ts < R  [registers v[q*R + ts]]
 //   out: values (kprev + PP*k, t) * W_MP^{t k} -> LDS index (kprev + PP*k)*M + t, or, for the
 //        last stage (M == 1, R in {2,4,8}), register slot q + (8/R)*k which is row tau + T*slot.
-template <int R, int PP, int N, int S, bool LAST, typename F>
+template <int R, int PP, int N, int S, bool LAST, int CW, typename F>
 __device__ __forceinline__ void stage(C2<F> *v, C2<F> *lds, const C2<F> *tw, int tau, int c)
 {
     constexpr int T = N / EPT, MP = N / PP, M = MP / R, NBF = N / R, NB = (NBF + T - 1) / T;
@@ -153,7 +153,7 @@ __device__ __forceinline__ void stage(C2<F> *v, C2<F> *lds, const C2<F> *tw, int
                 val = cmul(val, ww);
             }
             if (LAST) out[(q + NB * k) % EPT] = val;
-            else lds[((kprev + PP * k) * M + t) * COLS + c] = val;
+            else lds[((kprev + PP * k) * M + t) * CW + c] = val;
         }
     }
     if (LAST) {
@@ -163,7 +163,7 @@ __device__ __forceinline__ void stage(C2<F> *v, C2<F> *lds, const C2<F> *tw, int
 }
 
 // Gather this thread's inputs of the NEXT stage (radix R, PP = radices before it) from LDS.
-template <int R, int PP, int N, typename F>
+template <int R, int PP, int N, int CW, typename F>
 __device__ __forceinline__ void gather(C2<F> *v, const C2<F> *lds, int tau, int c)
 {
     constexpr int T = N / EPT, MP = N / PP, M = MP / R, NBF = N / R, NB = (NBF + T - 1) / T;
@@ -173,35 +173,35 @@ __device__ __forceinline__ void gather(C2<F> *v, const C2<F> *lds, int tau, int 
         if (NBF % T != 0 && b >= NBF) continue;
         const int kprev = b / M, t = b % M;
 #pragma unroll
-        for (int ts = 0; ts < R; ts++) v[q * R + ts] = lds[(kprev * MP + ts * M + t) * COLS + c];
+        for (int ts = 0; ts < R; ts++) v[q * R + ts] = lds[(kprev * MP + ts * M + t) * CW + c];
     }
 }
 
 // Full length-N transform of the 8 register values of each thread (rows tau + T*j in, rows
 // tau + T*j out, natural order).  N = 8 * R2 * R3 * R4 (trailing radices may be 1).
-template <int N, int R2, int R3, int R4, int S, typename F>
+template <int N, int R2, int R3, int R4, int S, int CW, typename F>
 __device__ __forceinline__ void fft_core(C2<F> *v, C2<F> *lds, const C2<F> *tw, int tau, int c)
 {
     static_assert(8 * R2 * R3 * R4 == N, "radices must multiply to N");
     constexpr bool L1 = R2 == 1;
-    stage<8, 1, N, S, L1>(v, lds, tw, tau, c);
+    stage<8, 1, N, S, L1, CW>(v, lds, tw, tau, c);
     if (!L1) {
         __syncthreads();
-        gather<R2, 8, N>(v, lds, tau, c);
+        gather<R2, 8, N, CW>(v, lds, tau, c);
         constexpr bool L2 = R3 == 1;
         __syncthreads();
-        stage<R2, 8, N, S, L2>(v, lds, tw, tau, c);
+        stage<R2, 8, N, S, L2, CW>(v, lds, tw, tau, c);
         if (!L2) {
             __syncthreads();
-            gather<R3, 8 * R2, N>(v, lds, tau, c);
+            gather<R3, 8 * R2, N, CW>(v, lds, tau, c);
             constexpr bool L3 = R4 == 1;
             __syncthreads();
-            stage<R3, 8 * R2, N, S, L3>(v, lds, tw, tau, c);
+            stage<R3, 8 * R2, N, S, L3, CW>(v, lds, tw, tau, c);
             if (!L3) {
                 __syncthreads();
-                gather<R4, 8 * R2 * R3, N>(v, lds, tau, c);
+                gather<R4, 8 * R2 * R3, N, CW>(v, lds, tau, c);
                 __syncthreads();
-                stage<R4, 8 * R2 * R3, N, S, true>(v, lds, tw, tau, c);
+                stage<R4, 8 * R2 * R3, N, S, true, CW>(v, lds, tw, tau, c);
             }
         }
     }
@@ -241,26 +241,26 @@ __device__ __forceinline__ void stage_twiddles(C2<F> *tw, const double *tw_globa
 // One tile per workgroup (61 VGPRs, 2 workgroups/CU at N = 512): measured 0.47 ms per 2.16 GB
 // pass = the speed of a contiguous device copy of the same bytes (tools/ubench/wr_pattern.hip).
 // A persistent variant with register prefetch of the next tile needed 178 VGPRs and ran slower.
-template <int N, int R2, int R3, int R4, int S, typename F>
-__global__ __launch_bounds__(N) void colfft_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ out,
+template <int N, int R2, int R3, int R4, int S, int CW, typename F>
+__global__ __launch_bounds__(N / 8 * CW) void colfft_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ out,
                                                    ColMap im, ColMap om, int ncols, int ntiles_per_batch,
                                                    int ntiles, const double *__restrict__ tw_global, F scale)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     C2<F> *lds = (C2<F> *) smem;
-    C2<F> *tw = lds + N * COLS;
+    C2<F> *tw = lds + N * CW;
     constexpr int T = N / EPT;
-    const int c = threadIdx.x % COLS, tau = threadIdx.x / COLS;
+    const int c = threadIdx.x % CW, tau = threadIdx.x / CW;
     const int tile = xcd_tile(blockIdx.x, ntiles);
     const int batch = tile / ntiles_per_batch;
-    const int col = (tile % ntiles_per_batch) * COLS + c;
+    const int col = (tile % ntiles_per_batch) * CW + c;
     const bool live = col < ncols;
     C2<F> v[VMAX];
 #pragma unroll
     for (int j = 0; j < EPT; j++) v[j] = live ? in[col_addr(im, batch, tau + T * j, col)] : C2<F>{0, 0};
     stage_twiddles(tw, tw_global, N);       // after the data loads are in flight
     __syncthreads();
-    fft_core<N, R2, R3, R4, S>(v, lds, tw, tau, c);
+    fft_core<N, R2, R3, R4, S, CW>(v, lds, tw, tau, c);
     if (live) {
 #pragma unroll
         for (int j = 0; j < EPT; j++) {
@@ -279,8 +279,8 @@ __global__ __launch_bounds__(N) void colfft_kernel(const C2<F> *__restrict__ in,
 // 128 VGPRs so that two workgroups share a CU (measured 1.32 ms vs 1.46 ms at one per CU;
 // re-reading delta_k per component instead: 1.63 ms; HBM floor for 1 read + 3 writes in this
 // access pattern: 1.02 ms, tools/ubench/wr_pattern.hip).
-template <int N, int R2, int R3, int R4, typename F>
-__global__ __launch_bounds__(N, 4) void colfft_xback3_kernel(const C2<F> *__restrict__ dk, C2<F> *__restrict__ o0,
+template <int N, int R2, int R3, int R4, int CW, typename F>
+__global__ __launch_bounds__(N / 8 * CW, 4) void colfft_xback3_kernel(const C2<F> *__restrict__ dk, C2<F> *__restrict__ o0,
                                                              C2<F> *__restrict__ o1, C2<F> *__restrict__ o2,
                                                              long long rstride, int ncols, int nzc, int ystart,
                                                              int ntiles, const float *__restrict__ kk,
@@ -289,11 +289,11 @@ __global__ __launch_bounds__(N, 4) void colfft_xback3_kernel(const C2<F> *__rest
 {
     extern __shared__ __align__(16) unsigned char smem[];
     C2<F> *lds = (C2<F> *) smem;
-    C2<F> *tw = lds + N * COLS;
+    C2<F> *tw = lds + N * CW;
     constexpr int T = N / EPT;
-    const int c = threadIdx.x % COLS, tau = threadIdx.x / COLS;
+    const int c = threadIdx.x % CW, tau = threadIdx.x / CW;
     const int tile = xcd_tile(blockIdx.x, ntiles);
-    const int col = tile * COLS + c;
+    const int col = tile * CW + c;
     const bool live = col < ncols;
     // uniform 64-bit row base (SGPRs) + one 32-bit per-thread element offset: keeps the eight load
     // and eight store addresses out of the VGPR budget (tau * rstride + col < 2^28 for N <= 1024)
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(N, 4) void colfft_xback3_kernel(const C2<F> *__rest
             }
         }
         __syncthreads();
-        fft_core<N, R2, R3, R4, +1>(v, lds, tw, tau, c);
+        fft_core<N, R2, R3, R4, +1, CW>(v, lds, tw, tau, c);
         if (live) {
             C2<F> *dst = outs[dir];
             const unsigned toff_o = (unsigned) tau_o * (unsigned) rstride + (unsigned) col;
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(M) void rowfft_r2c_kernel(const C2<F> *__restrict__
         twn[i].y = (F) tw_global[2 * i + 1];
     }
     __syncthreads();
-    fft_core<M, R2, R3, R4, -1>(v, lds, tw, tau, c);
+    fft_core<M, R2, R3, R4, -1, COLS>(v, lds, tw, tau, c);
     // exchange so that every thread can pair Z[k] with Z[M - k]
 #pragma unroll
     for (int j = 0; j < EPT; j++) lds[(tau + T * j) * COLS + c] = v[j];
@@ -464,24 +464,30 @@ static int colfft_launch(fpmhip_plan *p, int dir, const void *in, void *out, con
                          int nbatch, int ncols, double scale)
 {
     const int N = p->mg.N;
-    const int tpb = (ncols + COLS - 1) / COLS;
+    // one 128-B line per row: 8 columns of complex<double>, 16 of complex<float> (while the
+    // workgroup still fits 1024 threads)
+    constexpr int CW = (sizeof(F) == 4) ? 16 : 8;
+    const bool wide = sizeof(F) == 4 && N <= 512;
+    const int cw = wide ? CW : 8;
+    const int tpb = (ncols + cw - 1) / cw;
     const int ntiles = tpb * nbatch;
-    const size_t lds = (size_t) N * COLS * sizeof(C2<F>) + (size_t) N * sizeof(C2<F>);
+    const size_t lds = (size_t) N * cw * sizeof(C2<F>) + (size_t) N * sizeof(C2<F>);
     const int grid = ntiles;
-#define CALL_PLAIN(n, r2, r3, r4)                                                                              \
+#define CALL_PLAIN_W(n, r2, r3, r4, W)                                                                         \
     if (dir < 0) {                                                                                             \
-        FPM_TRY(set_lds(colfft_kernel<n, r2, r3, r4, -1, F>, lds));                                            \
-        colfft_kernel<n, r2, r3, r4, -1, F><<<grid, n, lds, p->stream>>>((const C2<F> *) in, (C2<F> *) out,  \
-                                                                          im, om, ncols, tpb, ntiles,         \
-                                                                          p->d_twiddle, (F) scale);           \
+        FPM_TRY(set_lds(colfft_kernel<n, r2, r3, r4, -1, W, F>, lds));                                         \
+        colfft_kernel<n, r2, r3, r4, -1, W, F><<<grid, n / 8 * W, lds, p->stream>>>(                           \
+            (const C2<F> *) in, (C2<F> *) out, im, om, ncols, tpb, ntiles, p->d_twiddle, (F) scale);           \
     } else {                                                                                                   \
-        FPM_TRY(set_lds(colfft_kernel<n, r2, r3, r4, +1, F>, lds));                                            \
-        colfft_kernel<n, r2, r3, r4, +1, F><<<grid, n, lds, p->stream>>>((const C2<F> *) in, (C2<F> *) out,  \
-                                                                          im, om, ncols, tpb, ntiles,         \
-                                                                          p->d_twiddle, (F) scale);           \
+        FPM_TRY(set_lds(colfft_kernel<n, r2, r3, r4, +1, W, F>, lds));                                         \
+        colfft_kernel<n, r2, r3, r4, +1, W, F><<<grid, n / 8 * W, lds, p->stream>>>(                           \
+            (const C2<F> *) in, (C2<F> *) out, im, om, ncols, tpb, ntiles, p->d_twiddle, (F) scale);           \
     }
+#define CALL_PLAIN(n, r2, r3, r4)                                                                              \
+    if (wide) { CALL_PLAIN_W(n, r2, r3, r4, (n <= 512 ? CW : 8)) } else { CALL_PLAIN_W(n, r2, r3, r4, 8) }
     COLFFT_DISPATCH(N, CALL_PLAIN)
 #undef CALL_PLAIN
+#undef CALL_PLAIN_W
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -556,18 +562,24 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
     const MeshGeo &g = p->mg;
     const int N = g.N;
     const long long plane = (long long) g.yl * g.nzc;
-    const int ntiles = (int) ((plane + COLS - 1) / COLS);
-    const size_t lds = (size_t) N * COLS * sizeof(C2<F>) + (size_t) N * sizeof(C2<F>);
+    constexpr int CW = (sizeof(F) == 4) ? 16 : 8;
+    const bool wide = sizeof(F) == 4 && N <= 512;
+    const int cw = wide ? CW : 8;
+    const int ntiles = (int) ((plane + cw - 1) / cw);
+    const size_t lds = (size_t) N * cw * sizeof(C2<F>) + (size_t) N * sizeof(C2<F>);
     const float *kk = p->d_tab + (2 + potorder) * (size_t) N;
     const float *kt = p->d_tab + gradorder * (size_t) N;
     const int grid = ntiles;
-#define CALL_X3(n, r2, r3, r4)                                                                               \
-    FPM_TRY(set_lds(colfft_xback3_kernel<n, r2, r3, r4, F>, lds));                                           \
-    colfft_xback3_kernel<n, r2, r3, r4, F><<<grid, n, lds, p->stream>>>(                                     \
+#define CALL_X3_W(n, r2, r3, r4, W)                                                                          \
+    FPM_TRY(set_lds(colfft_xback3_kernel<n, r2, r3, r4, W, F>, lds));                                        \
+    colfft_xback3_kernel<n, r2, r3, r4, W, F><<<grid, n / 8 * W, lds, p->stream>>>(                          \
         (const C2<F> *) dk, (C2<F> *) o0, (C2<F> *) o1, (C2<F> *) o2, plane, (int) plane, g.nzc, g.ystart,  \
         ntiles, kk, kt, p->d_twiddle);
+#define CALL_X3(n, r2, r3, r4)                                                                               \
+    if (wide) { CALL_X3_W(n, r2, r3, r4, (n <= 512 ? CW : 8)) } else { CALL_X3_W(n, r2, r3, r4, 8) }
     COLFFT_DISPATCH(N, CALL_X3)
 #undef CALL_X3
+#undef CALL_X3_W
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }
