@@ -48,6 +48,34 @@ def make_particles(nc, Nmesh, BoxSize, nranks, rank, device, seed=1234, sigma_ce
     return x.contiguous()
 
 
+def make_particles_clustered(nc, Nmesh, BoxSize, device, load, seed=5678):
+    """Single-GPU stress loads.  "b": lattice + Zel'dovich-like displacement from a
+    P(k) ~ k^-2 field scaled to rms 4 cells (z=0-like cell-occupancy variance); "c": uniform random
+    with 10 % of the particles inside 0.1 % of the volume (adversarial for atomics / tile balance)."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    h = BoxSize / Nmesh
+    if load == "c":
+        n = nc ** 3
+        x = torch.rand((n, 3), generator=gen, device=device, dtype=torch.float64) * BoxSize
+        m = n // 10
+        x[:m] = BoxSize * 0.37 + torch.rand((m, 3), generator=gen, device=device, dtype=torch.float64) * (BoxSize * 0.1)
+        return torch.remainder(x, BoxSize).contiguous()
+    k1 = torch.fft.fftfreq(nc, device=device, dtype=torch.float64) * nc
+    kx, ky, kz = torch.meshgrid(k1, k1, k1[: nc // 2 + 1].abs(), indexing="ij")
+    k2 = kx ** 2 + ky ** 2 + kz ** 2
+    k2[0, 0, 0] = 1.0
+    amp = k2 ** -0.5
+    amp[0, 0, 0] = 0.0
+    dk = torch.complex(torch.randn(k2.shape, generator=gen, device=device, dtype=torch.float64),
+                       torch.randn(k2.shape, generator=gen, device=device, dtype=torch.float64)) * amp
+    d = torch.stack([torch.fft.irfftn(1j * kk / k2 * dk, s=(nc, nc, nc)) for kk in (kx, ky, kz)], dim=-1).reshape(-1, 3)
+    d = d * (4.0 * h / d.pow(2).mean().sqrt())
+    g = (torch.arange(nc, device=device, dtype=torch.float64) + 0.5) * (BoxSize / nc)
+    q = torch.stack(torch.meshgrid(g, g, g, indexing="ij"), dim=-1).reshape(-1, 3)
+    return torch.remainder(q + d, BoxSize).contiguous()
+
+
 def algorithmic_bytes(np_local, Nmesh, nranks, esize):
     """SURVEY 8(d) per-kernel algorithmic bytes for ONE launch of each stage on one rank."""
     nr = Nmesh * Nmesh * (Nmesh + 2) // nranks          # padded reals of the local mesh
@@ -143,6 +171,8 @@ def main():
     ap.add_argument("--nmesh", type=int, default=0, help="override mesh per side")
     ap.add_argument("--paint-mode", type=int, default=0, help="0 tiled (default), 1 global atomics")
     ap.add_argument("--fft-mode", type=int, default=0, help="0 auto (column FFT + rocFFT z pass), 1 rocFFT only")
+    ap.add_argument("--load", default="a", choices=["a", "b", "c"],
+                    help="a: lattice + 0.3-cell jitter (default); b: clustered (rms 4 cells); c: adversarial (1 GPU only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -171,7 +201,12 @@ def main():
     BoxSize = 3.0 * nc                                  # tests/standard.lua:5-6: 384 / 128
     esize = args.precision // 8
 
-    x = make_particles(nc, Nmesh, BoxSize, world, rank, device)
+    if args.load != "a":
+        if world != 1:
+            raise SystemExit("--load b/c are single-GPU stress loads")
+        x = make_particles_clustered(nc, Nmesh, BoxSize, device, args.load)
+    else:
+        x = make_particles(nc, Nmesh, BoxSize, world, rank, device)
     np_local = x.shape[0]
     np_total = nc ** 3
     pm = PM(Nmesh, BoxSize, precision=args.precision, nranks=world, rank=rank, np_max=np_local,
@@ -239,7 +274,9 @@ def main():
             "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
             "config": {"workload": "%d^3 particles, B=2 (%d^3 mesh), fp%d, %dxMI355X%s" % (
                 nc, Nmesh, args.precision, world, "" if world > 1 else " single-GPU rocFFT path (configs[1])"),
-                "particles": np_total, "nmesh": Nmesh, "load": "A: lattice + 0.3-cell Gaussian jitter",
+                "particles": np_total, "nmesh": Nmesh,
+                "load": {"a": "A: lattice + 0.3-cell Gaussian jitter", "b": "B: clustered, Zel'dovich-like rms 4 cells",
+                         "c": "C: adversarial, 10 % of particles in 0.1 % of the volume"}[args.load],
                 "kernel": "1_4", "softening": "none", "decomposition": "slab %dx1" % world,
                 "paint_mode": "tiled" if args.paint_mode == 0 else "atomic",
                 "fft": "column passes + rocFFT z" if pm.staged_fft() and args.fft_mode == 0 else "rocFFT"},

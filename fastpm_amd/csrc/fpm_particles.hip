@@ -73,7 +73,11 @@ __device__ __forceinline__ int wave_agg_inc(int *counters, int key, bool active)
     int slot = -1;
     unsigned long long remaining = __ballot(active);
     const int lane = __lane_id();
-    while (remaining) {
+    // Spatially coherent input (the normal case: lattice order, or the order a previous decompose
+    // left) has a handful of distinct tiles per wave.  After 6 merged groups the wave is treated as
+    // incoherent and every lane still waiting issues its own atomic (random order would otherwise
+    // loop up to 64 times: 3.9 ms instead of 0.6 ms of binning on a shuffled 16.8 M-particle load).
+    for (int round = 0; remaining && round < 6; round++) {
         int leader = __ffsll((long long) remaining) - 1;
         int k = __shfl(key, leader);
         bool mine = active && key == k;
@@ -89,6 +93,10 @@ __device__ __forceinline__ int wave_agg_inc(int *counters, int key, bool active)
             if (mine) slot = base + __popcll(same & ((1ull << lane) - 1ull));
         }
         remaining &= ~same;
+    }
+    if (remaining & (1ull << lane)) {
+        if (RET) slot = atomicAdd(&counters[key], 1);
+        else (void) atomicAdd(&counters[key], 1);
     }
     return slot;
 }
