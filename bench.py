@@ -88,14 +88,26 @@ def algorithmic_bytes(np_local, Nmesh, nranks, esize):
         "c2r": 2 * s * nr,                               # K8
         "readout": 3 * s * nr + 36 * np_local,           # K9 fused over the 3 components
         "xback3": 4 * s * nr,                            # fused K7 x3 + x pass of K8 x3: 1 read, 3 writes
+        # single kernels (nested timers): one pass of the 3-pass FFT reads and writes the mesh once
+        "k_colfft": 2 * s * nr, "k_rowfft": 2 * s * nr, "k_zc2r": 2 * s * nr,
     }
+
+
+# which entries of the timing table are single GPU kernels (a roofline is quoted per kernel), and
+# the kernel each one is in the rocprofv3 trace
+KERNELS = {"paint": "fpm::paint_tiles_kernel", "readout": "fpm::readout_kernel", "xback3": "fpm::colfft_xback3_kernel",
+           "k_colfft": "fpm::colfft_kernel", "k_rowfft": "fpm::rowfft_r2c_kernel",
+           "k_zc2r": "rocFFT fft_rtc_back_len*_C2R (1-D c2r, z pass)", "transfer": "fpm::transfer_kernel"}
+STAGES_OF_KERNELS = {"k_colfft": "r2c/c2r", "k_rowfft": "r2c", "k_zc2r": "c2r"}
+
 
 
 def pmc_traffic(stage, Nmesh, np_total, args, world):
     """HBM bytes per launch of `stage` from the committed PMC profile (rocprofv3 cannot run inside
-    the bench): profiles/r01_c_traffic.json, only when the configuration matches the profiled one."""
+    the bench): profiles/r01_d_traffic.json (tools/pmc_traffic.py), only when the configuration matches
+    the profiled one."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_c_traffic.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_d_traffic.json")))
         c = t["config"]
         if (c["nmesh"], c["particles"], c["precision"], c["n_gpus"]) != (Nmesh, np_total, args.precision, world):
             return None
@@ -259,11 +271,12 @@ def main():
             if name in ab:
                 e["alg_GBs"] = round(ab[name] / (avg_ms * 1e-3) / 1e9, 1)
             stages[name] = e
-        # the dominant kernel = the stage with the largest total time among those with a roofline
-        dom = max((n for n in stages if n in ab), key=lambda n: tm[n][0])
+        # the dominant kernel = the single kernel with the largest total time in the timed region
+        dom = max((n for n in stages if n in ab and n in KERNELS), key=lambda n: tm[n][0])
         avg_s = tm[dom][0] / tm[dom][1] * 1e-3
         achieved = ab[dom] / avg_s / 1e9
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        roofline = {"kernel": KERNELS[dom], "timer": dom, "launches_per_step": tm[dom][1] / args.steps,
+                    "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, Nmesh, np_total, args, world),
                     "alg_bytes_per_launch": ab[dom], "avg_launch_ms": round(avg_s * 1e3, 4)}
         b_alg = 60 * np_local + 12 * esize * (Nmesh * Nmesh * (Nmesh + 2) // world)

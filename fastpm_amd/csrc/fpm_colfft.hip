@@ -463,6 +463,7 @@ template <typename F>
 static int colfft_launch(fpmhip_plan *p, int dir, const void *in, void *out, const ColMap &im, const ColMap &om,
                          int nbatch, int ncols, double scale)
 {
+    StageTimer ktm(p, FPMHIP_T_K_COLFFT);
     const int N = p->mg.N;
     // one 128-B line per row: 8 columns of complex<double>, 16 of complex<float> (while the
     // workgroup still fits 1024 threads)
@@ -528,6 +529,7 @@ int colfft_y_range(fpmhip_plan *p, int dir, const void *in, void *out, int chunk
 template <typename F>
 static int rowfft_launch(fpmhip_plan *p, const void *in_, void *out_, int x0, int nx)
 {
+    StageTimer ktm(p, FPMHIP_T_K_ROWFFT);
     const MeshGeo &g = p->mg;
     const int M = g.N / 2;
     const int nrows = nx * g.N;

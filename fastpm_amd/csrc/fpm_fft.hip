@@ -209,6 +209,7 @@ static int yz_backward(fpmhip_plan *p, void *in, void *out, int chunked)
     const size_t plane_bytes = (size_t) p->mg.N * p->mg.nzc * 2 * p->esize;
     for (int x0 = 0; x0 < xl; x0 += cp) {
         FPM_TRY(colfft_y_range(p, +1, in, out, chunked, x0, cp));
+        StageTimer ktm(p, FPMHIP_T_K_ZC2R);
         if (cp == xl) FPM_TRY(fft_exec(p, p->p_zc2r_ip, out, nullptr));
         else FPM_TRY(fft_exec(p, p->p_zc2r_chunk, (char *) out + (size_t) x0 * plane_bytes, nullptr));
     }

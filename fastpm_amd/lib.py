@@ -103,7 +103,8 @@ SYMBOLS = {
     "fpmhip_memcpy_d2h": (_I, [_P, _P, _P, ctypes.c_size_t]),
 }
 
-TIMING_STAGES = ["sort", "paint", "r2c", "dealias", "transfer", "c2r", "readout", "halo", "pack", "xback3"]
+TIMING_STAGES = ["sort", "paint", "r2c", "dealias", "transfer", "c2r", "readout", "halo", "pack", "xback3",
+                 "k_colfft", "k_rowfft", "k_zc2r"]
 
 
 def library_path():

@@ -252,6 +252,10 @@ int fpmhip_store_summary(fpmhip_plan *plan, const float *column_dev, int nmemb, 
 enum { FPMHIP_T_SORT = 0, FPMHIP_T_PAINT, FPMHIP_T_R2C, FPMHIP_T_DEALIAS, FPMHIP_T_TRANSFER,
        FPMHIP_T_C2R, FPMHIP_T_READOUT, FPMHIP_T_HALO, FPMHIP_T_PACK,
        FPMHIP_T_XBACK3,      /* fused 3-component transfer + backward x pass */
+       /* single kernels inside the r2c / c2r stages (nested inside the stage timers) */
+       FPMHIP_T_K_COLFFT,    /* one column pass (x or y, either direction): colfft_kernel */
+       FPMHIP_T_K_ROWFFT,    /* forward z pass: rowfft_r2c_kernel */
+       FPMHIP_T_K_ZC2R,      /* backward z pass: rocFFT 1-D c2r */
        FPMHIP_T_COUNT };
 int fpmhip_timing_enable(fpmhip_plan *plan, int on);
 int fpmhip_timing_reset(fpmhip_plan *plan);
