@@ -45,13 +45,24 @@ extern "C" {
 int fpmhip_force(fpmhip_plan *p, const fpmhip_particles *pt, int kernel, int softening, double total_mass,
                  void *delta_k_out)
 {
-    if (!p || !pt) FPM_FAIL(-1, "null argument");
+    return fpmhip_force_species(p, pt, 1, kernel, softening, total_mass, delta_k_out);
+}
+
+// The species loop of gravity.c:279-287 (ghosts), :323-338 (paint every species into one canvas,
+// total mass over all of them) and :387-395 (read every species out of each force mesh).
+int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets, int kernel, int softening,
+                         double total_mass, void *delta_k_out)
+{
+    if (!p || !sets || nsets < 1) FPM_FAIL(-1, "null argument");
+    if (nsets > 6) FPM_FAIL(-1, "at most FASTPM_SOLVER_NSPECIES = 6 species");
+    const fpmhip_particles *pt = &sets[0];
     if (p->lay.nranks != 1)
         FPM_FAIL(-1, "fpmhip_force is the one-rank path; with nranks > 1 drive the stages around the two exchanges");
     int po, go, dfo, dc;
     FPM_TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));                  // gravity.c:169
     if (softening < 0 || softening > FPMHIP_SOFTENING_GAUSSIAN36) FPM_FAIL(-1, "wrong softening kernel type");
-    if (pt->np > 0 && !pt->acc) FPM_FAIL(-1, "particles without an acc column");
+    for (int si = 0; si < nsets; si++)
+        if (sets[si].np > 0 && !sets[si].acc) FPM_FAIL(-1, "particles without an acc column");
 
     FPM_TRY(ensure_buffer(p, BUF_CANVAS));
     FPM_TRY(ensure_buffer(p, BUF_F1));
@@ -63,9 +74,17 @@ int fpmhip_force(fpmhip_plan *p, const fpmhip_particles *pt, int kernel, int sof
         delta_k = p->buf[BUF_DELTA_K];
     }
 
-    if (total_mass < 0) FPM_TRY(fpmhip_total_mass(p, pt, &total_mass));                   // gravity.c:330-341
+    if (total_mass < 0) {                                                                 // gravity.c:330-341
+        total_mass = 0;
+        for (int si = 0; si < nsets; si++) {
+            double m = 0;
+            FPM_TRY(fpmhip_total_mass(p, &sets[si], &m));
+            total_mass += m;
+        }
+    }
     const double mean_mass_per_cell = total_mass / p->lay.Norm;                           // gravity.c:342
     FPM_TRY(fpmhip_paint(p, pt, 1.0 / mean_mass_per_cell, canvas));                       // gravity.c:336-345
+    for (int si = 1; si < nsets; si++) FPM_TRY(fpmhip_paint_add(p, &sets[si], 1.0 / mean_mass_per_cell, canvas));
     FPM_TRY(fpmhip_r2c(p, canvas, delta_k));                                              // gravity.c:351
     FPM_TRY(fpmhip_softening(p, delta_k, softening));                                     // gravity.c:476
 
@@ -81,11 +100,15 @@ int fpmhip_force(fpmhip_plan *p, const fpmhip_particles *pt, int kernel, int sof
             FPM_TRY(fpmhip_c2r(p, f[d]));
         }
     }
-    FPM_TRY(fpmhip_readout3(p, pt, f[0], f[1], f[2]));
-    if (pt->potential) {                                                                  // gravity.c:487-492
+    // with several species the last paint's binning belongs to the last one: read that one first
+    for (int si = nsets - 1; si >= 0; si--) FPM_TRY(fpmhip_readout3(p, &sets[si], f[0], f[1], f[2]));
+    bool any_pot = false;
+    for (int si = 0; si < nsets; si++) any_pot = any_pot || sets[si].potential != nullptr;
+    if (any_pot) {                                                                        // gravity.c:487-492
         FPM_TRY(fpmhip_transfer(p, delta_k, canvas, kernel, FPMHIP_FIELD_POTENTIAL));
         FPM_TRY(fpmhip_c2r(p, canvas));
-        FPM_TRY(fpmhip_readout1(p, pt, canvas, pt->potential, 1, 0));
+        for (int si = 0; si < nsets; si++)
+            if (sets[si].potential) FPM_TRY(fpmhip_readout1(p, &sets[si], canvas, sets[si].potential, 1, 0));
     }
     return 0;
 }

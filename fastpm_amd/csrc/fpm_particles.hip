@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void paint_tiles_kernel(MeshGeo g, int ntiles,
                                                           const double *__restrict__ sy,
                                                           const double *__restrict__ sz,
                                                           const float *__restrict__ smass, double M0,
-                                                          double scale, F *__restrict__ canvas)
+                                                          double scale, F *__restrict__ canvas, int accumulate)
 {
     // accumulators are double for both mesh precisions: the reference adds the double weight to the
     // cell in double and rounds to FastPMFloat per add (painter-cic.c:24); one rounding at the end is
@@ -223,8 +223,9 @@ __global__ __launch_bounds__(256) void paint_tiles_kernel(MeshGeo g, int ntiles,
         const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
         if (gx < g.xplanes && gy < g.N && gz < g.N) {
             F *row = canvas + (long long) gx * g.str0 + (long long) gy * g.str1;
-            row[gz] = (F) (tile[i] * scale);
-            if (gz == g.N - 1) { row[g.N] = 0; row[g.N + 1] = 0; }   // pm_clear'ed padding
+            const F mine = (F) (tile[i] * scale);
+            row[gz] = accumulate ? (F) (row[gz] + mine) : mine;      // further species add (gravity.c:326-338)
+            if (gz == g.N - 1 && !accumulate) { row[g.N] = 0; row[g.N + 1] = 0; }   // pm_clear'ed padding
         }
     }
 }
@@ -438,9 +439,10 @@ int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt)
 }
 
 template <typename F>
-static int paint_impl(fpmhip_plan *p, const fpmhip_particles *pt, double scale, F *canvas)
+static int paint_impl(fpmhip_plan *p, const fpmhip_particles *pt, double scale, F *canvas, int accumulate)
 {
     if (p->geom.paint_mode == FPMHIP_PAINT_ATOMIC) {
+        if (accumulate) FPM_FAIL(-1, "paint_add needs the tiled painter");
         StageTimer tm(p, FPMHIP_T_PAINT);
         FPM_CHECK_HIP(hipMemsetAsync(canvas, 0, (size_t) p->lay.allocsize * sizeof(F), p->stream));
         if (pt->np > 0)
@@ -453,7 +455,8 @@ static int paint_impl(fpmhip_plan *p, const fpmhip_particles *pt, double scale, 
     FPM_TRY(bin_particles(p, pt));
     StageTimer tm(p, FPMHIP_T_PAINT);
     paint_tiles_kernel<F><<<p->ntiles, 256, 0, p->stream>>>(p->mg, p->ntiles, p->tile_off, p->sx, p->sy, p->sz,
-                                                             pt->mass ? p->smass : nullptr, pt->M0, scale, canvas);
+                                                             pt->mass ? p->smass : nullptr, pt->M0, scale, canvas,
+                                                             accumulate);
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -513,8 +516,16 @@ int fpmhip_paint(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void 
 {
     FPM_TRY(check_particles(p, pt));
     if (!canvas) FPM_FAIL(-1, "null canvas");
-    return p->f64 ? paint_impl<double>(p, pt, scale, (double *) canvas)
-                  : paint_impl<float>(p, pt, scale, (float *) canvas);
+    return p->f64 ? paint_impl<double>(p, pt, scale, (double *) canvas, 0)
+                  : paint_impl<float>(p, pt, scale, (float *) canvas, 0);
+}
+
+int fpmhip_paint_add(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void *canvas)
+{
+    FPM_TRY(check_particles(p, pt));
+    if (!canvas) FPM_FAIL(-1, "null canvas");
+    return p->f64 ? paint_impl<double>(p, pt, scale, (double *) canvas, 1)
+                  : paint_impl<float>(p, pt, scale, (float *) canvas, 1);
 }
 
 int fpmhip_invalidate_binning(fpmhip_plan *p)

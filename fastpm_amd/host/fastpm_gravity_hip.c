@@ -91,23 +91,27 @@ void fastpm_solver_compute_force_hip(FastPMSolverView *fastpm, PMView *pm, FastP
         fpm_raise(-1, "the MI355X force step implements the CIC painter (the default, painter.c:137-142)\n");
         return;
     }
+    fpmhip_particles parts[FASTPM_SOLVER_NSPECIES];
     int nspecies = 0;
-    FastPMStoreView *p = NULL;
     for (int si = 0; si < FASTPM_SOLVER_NSPECIES; si++) {      /* gravity.c:279-287 species loop */
         if (!fastpm->has_species[si] || !fastpm->species[si]) continue;
-        p = fastpm->species[si];
-        nspecies++;
+        FastPMStoreView *p = fastpm->species[si];
+        fpmhip_particles *part = &parts[nspecies++];
+        part->x = &p->x[0][0];
+        part->mass = p->mass;
+        part->M0 = p->meta.M0;
+        part->np = (int64_t) p->np;
+        part->acc = &p->acc[0][0];
+        part->potential = p->potential;                        /* gravity.c:487-492: nacc = 3 or 4 */
     }
-    if (nspecies != 1) {
-        fpm_raise(-1, "the MI355X force step handles one particle species per call (got %d)\n", nspecies);
+    if (nspecies == 0) {
+        fpm_raise(-1, "no particle species in the solver\n");
         return;
     }
-    fpmhip_particles part;
-    part.x = &p->x[0][0];
-    part.mass = p->mass;
-    part.M0 = p->meta.M0;
-    part.np = (int64_t) p->np;
-    part.acc = &p->acc[0][0];
-    part.potential = p->potential;                             /* gravity.c:487-492: nacc = 3 or 4 */
+    if (nspecies > 1) {
+        fpm_raise(-1, "host-column path: one species per call (device columns: fpmhip_force_species)\n");
+        return;
+    }
+    const fpmhip_particles part = parts[0];
     HIP_OR_RAISE(fpmhip_force_host(pm->plan, &part, (int) kernel, (int) dealias, delta_k));
 }

@@ -452,6 +452,15 @@ class PM:
         check(self._L.fpmhip_force(self._plan, ctypes.byref(store._c()), _enum(KERNEL_TYPES, kernel),
                                    _enum(SOFTENING_TYPES, softening), float(total_mass), _ptr(delta_k)))
 
+    def compute_force_species(self, stores, kernel="1_4", softening="none", delta_k=None, total_mass=-1.0):
+        """Several species (fastpm->species[], solver.h:83-88) through one mesh."""
+        arr = (_lib.Particles * len(stores))(*[s._c() for s in stores])
+        check(self._L.fpmhip_force_species(self._plan, arr, len(stores), _enum(KERNEL_TYPES, kernel),
+                                           _enum(SOFTENING_TYPES, softening), float(total_mass), _ptr(delta_k)))
+
+    def paint_add(self, canvas, store, scale=1.0):
+        check(self._L.fpmhip_paint_add(self._plan, ctypes.byref(store._c()), float(scale), _ptr(canvas)))
+
     def compute_force_host(self, x, mass=None, M0=1.0, kernel="1_4", softening="none", potential=False,
                            want_delta_k=False):
         """fpmhip_force_host: numpy in (as libfastpm holds its store), numpy out."""

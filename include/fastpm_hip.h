@@ -118,6 +118,10 @@ int  fpmhip_sync(fpmhip_plan *plan);
  * k layout (fpmhip_layout.ostrides).  total_mass < 0 -> computed here (gravity.c:330-341). */
 int fpmhip_force(fpmhip_plan *plan, const fpmhip_particles *p_dev, int kernel, int softening,
                  double total_mass, void *delta_k_dev);
+/* The same for several particle species painted into one mesh (the species loops of
+ * gravity.c:279-287, 323-338, 387-395): sets[0..nsets), every set gets its own acc. */
+int fpmhip_force_species(fpmhip_plan *plan, const fpmhip_particles *sets_dev, int nsets, int kernel,
+                         int softening, double total_mass, void *delta_k_dev);
 /* Same with host-resident store columns, as libfastpm has them today: copies x (and mass) up,
  * acc (and potential) down; delta_k_host (nullable) is written in the REFERENCE's layout
  * (PFFT transposed [y][z][x], pmpfft.c:198-202) so host handlers iterate it with PMKIter. */
@@ -130,6 +134,8 @@ int fpmhip_force_host(fpmhip_plan *plan, const fpmhip_particles *p_host, int ker
  * painter-cic.c:34-110, transfer.c:212-220): canvas = scale * sum of CIC weights.  Writes
  * every cell of the local slab and of the halo plane. */
 int fpmhip_paint(fpmhip_plan *plan, const fpmhip_particles *p_dev, double scale, void *canvas_dev);
+/* a further species into the same canvas: canvas += scale * sum of CIC weights (gravity.c:326-338) */
+int fpmhip_paint_add(fpmhip_plan *plan, const fpmhip_particles *p_dev, double scale, void *canvas_dev);
 /* sum of fastpm_store_get_mass over the local particles (gravity.c:330-335) -> host double */
 int fpmhip_total_mass(fpmhip_plan *plan, const fpmhip_particles *p_dev, double *total_host);
 /* The readout reuses the tile binning of the last paint when (x, np) are unchanged; call this

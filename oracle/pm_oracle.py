@@ -465,3 +465,24 @@ def pm_2lpt_evolve(x, v, dx1, dx2, D1, D2, Dv1, Dv2):
     vo = (vo.astype(np.float64) + dx2.astype(np.float64) * Dv2).astype(np.float32)
     vo = (vo.astype(np.float64) + Dv1 * dx1.astype(np.float64)).astype(np.float32)
     return xo, vo
+
+
+def compute_force_species(pm, species, kernel=KERNELS["1_4"], softening=0):
+    """fastpm_solver_compute_force with several species (gravity.c:323-338, 387-395): `species` is a
+    list of dicts {x, mass (or None), M0}.  Returns (list of acc arrays, delta_k)."""
+    assert pm.nproc == (1, 1)
+    canvas = pm.alloc()
+    tm = 0.0
+    for sp in species:
+        tm += total_mass(sp["x"], sp.get("mass"), sp.get("M0", 1.0))
+        pm.paint(canvas, sp["x"], sp.get("mass"), sp.get("M0", 1.0))
+    pm.scale(canvas, 1.0 / (tm / pm.Norm))
+    delta_k = pm.r2c(canvas)
+    pm.softening(delta_k, softening)
+    accs = [np.zeros((len(sp["x"]), 3), dtype=np.float32) for sp in species]
+    for d in range(3):
+        pm.kernel_transfer(kernel, delta_k, canvas, memb=d)
+        pm.c2r(canvas)
+        for sp, acc in zip(species, accs):
+            pm.readout(canvas, sp["x"], out=acc, nmemb=3, memb=d)
+    return accs, delta_k

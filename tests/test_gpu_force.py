@@ -147,3 +147,26 @@ def test_wrong_enums_raise():
     with pytest.raises(FastPMHipError, match="wrong softening"):
         pm.compute_force(st, softening=9)
     pm.destroy()
+
+
+def test_two_species_share_one_mesh(oracle):
+    """CDM + a second, lighter species with a mass column (the species loops of gravity.c:323-338,
+    387-395): both are painted into one density mesh, each gets its own acc."""
+    import torch
+    from fastpm_amd import PM, Store
+    N, nc, L = 32, 16, 48.0
+    x1 = util.load_a(nc, L, N)
+    x2 = util.load_b(nc, L, N, seed=77)[::3]
+    rng = np.random.default_rng(8)
+    m2 = rng.uniform(0, 0.05, len(x2)).astype(np.float32)
+    pmo = oracle.PMOracle(N, L, 64)
+    accs, dko = oracle.compute_force_species(pmo, [{"x": x1, "M0": 1.0}, {"x": x2, "mass": m2, "M0": 0.1}])
+    pm = PM(N, L, 64)
+    s1, s2 = Store(x1, M0=1.0), Store(x2, mass=m2, M0=0.1)
+    dk = pm.alloc()
+    pm.compute_force_species([s1, s2], delta_k=dk)
+    torch.cuda.synchronize()
+    assert util.max_err(pm.complex_view(dk).cpu().numpy(), util.oracle_k_to_xyk(pmo, dko)) <= TOL_DK[64]
+    assert util.rel_err(s1.acc.cpu().numpy(), accs[0]) <= TOL_ACC[64]
+    assert util.rel_err(s2.acc.cpu().numpy(), accs[1]) <= TOL_ACC[64]
+    pm.destroy()
