@@ -486,3 +486,63 @@ def compute_force_species(pm, species, kernel=KERNELS["1_4"], softening=0):
         for sp, acc in zip(species, accs):
             pm.readout(canvas, sp["x"], out=acc, nmemb=3, memb=d)
     return accs, delta_k
+
+
+def compute_force_multirank(N, BoxSize, nproc, x, precision=64, kernel=KERNELS["1_4"], softening=0):
+    """fastpm_solver_compute_force as the REFERENCE runs it on an Nx x Ny process mesh, every rank in
+    this process: particle ghosts out (pmghosts.c:112-245), region-clipped paint of local + ghost
+    particles (painter-cic.c:83-108), r2c, per component transfer -> c2r -> readout of local AND ghost
+    particles (gravity.c:387-395), then the ghost values travel back and are ADDED in float, serially
+    (pmghosts.c:247-307, store.c:36-49).  Returns acc in the order of x."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    P = nproc[0] * nproc[1]
+    owner = pos_to_rank(N, BoxSize, nproc, x)
+    idx = [np.nonzero(owner == r)[0] for r in range(P)]
+    pms = [PMOracle(N, BoxSize, precision, nproc, r) for r in range(P)]
+    local = [x[idx[r]] for r in range(P)]
+    sends = [ghost_pairs(N, BoxSize, nproc, r, local[r]) for r in range(P)]        # (ipar, target) per sender
+    # ghosts received by rank r, in sender-rank order (Alltoallv layout), with where they came from
+    ghosts, origin = [], []
+    for r in range(P):
+        gx, go = [], []
+        for s in range(P):
+            ipar, tgt = sends[s]
+            sel = ipar[tgt == r]
+            gx.append(local[s][sel])
+            go += [(s, int(i)) for i in sel]
+        ghosts.append(np.concatenate(gx) if gx else np.zeros((0, 3)))
+        origin.append(go)
+    canvases = []
+    for r, pm in enumerate(pms):
+        cv = pm.alloc()
+        pm.paint(cv, local[r])
+        if len(ghosts[r]):
+            pm.paint(cv, ghosts[r])
+        canvases.append(cv)
+    mean = total_mass(x, None, 1.0) / pms[0].Norm
+    for pm, cv in zip(pms, canvases):
+        pm.scale(cv, 1.0 / mean)
+    dks = global_r2c(pms, canvases)
+    for pm, dk in zip(pms, dks):
+        pm.softening(dk, softening)
+    acc_l = [np.zeros((len(local[r]), 3), dtype=np.float32) for r in range(P)]
+    acc_g = [np.zeros((len(ghosts[r]), 3), dtype=np.float32) for r in range(P)]
+    for d in range(3):
+        for pm, dk, cv in zip(pms, dks, canvases):
+            pm.kernel_transfer(kernel, dk, cv, memb=d)
+        global_c2r(pms, canvases)
+        for r, pm in enumerate(pms):
+            pm.readout(canvases[r], local[r], out=acc_l[r], nmemb=3, memb=d)
+            if len(ghosts[r]):
+                pm.readout(canvases[r], ghosts[r], out=acc_g[r], nmemb=3, memb=d)
+    # pm_ghosts_reduce: each owner adds what its ghosts collected elsewhere, in ighost order
+    for s in range(P):
+        ipar, tgt = sends[s]
+        for gi in range(len(ipar)):
+            r = int(tgt[gi])
+            j = origin[r].index((s, int(ipar[gi])))
+            acc_l[s][ipar[gi]] += acc_g[r][j]
+    acc = np.zeros((len(x), 3), dtype=np.float32)
+    for r in range(P):
+        acc[idx[r]] = acc_l[r]
+    return acc
