@@ -110,8 +110,8 @@ int fpmhip_decompose_order(fpmhip_plan *p, const double *x, int64_t np, int *ord
 int fpmhip_gather_rows(fpmhip_plan *p, const void *src, void *dst, const int *order, int64_t n, int rowbytes)
 {
     if (!p || (n > 0 && (!src || !dst || !order))) FPM_FAIL(-1, "null argument");
-    if (src == dst) FPM_FAIL(-1, "gather_rows is out of place");
     if (n == 0) return 0;
+    if (src == dst) FPM_FAIL(-1, "gather_rows is out of place");
     const unsigned nb = blocks_for(n, 256);
 #define GO(B) gather_rows_kernel<B><<<nb, 256, 0, p->stream>>>((const char *) src, (char *) dst, order, n)
     switch (rowbytes) {

@@ -147,3 +147,28 @@ def test_decompose_virtual_ranks_match_reference_order(oracle, P):
     assert total == sum(len(o["x"]) for o in ostores)
     for pm in pms:
         pm.destroy()
+
+
+def test_virtual_ranks_with_an_empty_rank(oracle):
+    """All particles in the first half of the box: rank 1 of 2 owns nothing (np == 0) but still takes
+    part in every exchange; then decompose a store that has to send everything away."""
+    import torch
+    from fastpm_amd import PM, Store
+    from fastpm_amd.distributed import SlabDecompose, SlabForce, run_virtual, run_virtual_decompose
+    N, L, P = 32, 48.0, 2
+    rng = np.random.default_rng(31)
+    x = rng.uniform(0, L, (4000, 3))
+    x[:, 0] *= 0.49                                       # x < L/2: all on rank 0
+    ref = oracle.compute_force(oracle.PMOracle(N, L, 64), x)["acc"]
+    pms = [PM(N, L, 64, nranks=P, rank=r) for r in range(P)]
+    stores = [Store(x), Store(np.zeros((0, 3)))]
+    run_virtual([SlabForce(pm) for pm in pms], stores)
+    torch.cuda.synchronize()
+    assert util.rel_err(stores[0].acc.cpu().numpy(), ref) <= 1e-6
+    # now hand every particle to the WRONG rank and let decompose sort it out
+    stores = [Store(np.zeros((0, 3))), Store(x)]
+    run_virtual_decompose([SlabDecompose(pm) for pm in pms], stores)
+    assert stores[0].np == len(x) and stores[1].np == 0
+    assert np.array_equal(stores[0].x.cpu().numpy(), oracle.store_wrap(x, L))
+    for pm in pms:
+        pm.destroy()
