@@ -76,10 +76,14 @@ def make_particles_clustered(nc, Nmesh, BoxSize, device, load, seed=5678):
     return torch.remainder(q + d, BoxSize).contiguous()
 
 
-def algorithmic_bytes(np_local, Nmesh, nranks, esize):
+def algorithmic_bytes(np_local, Nmesh, nranks, esize, gradient="kspace"):
     """SURVEY 8(d) per-kernel algorithmic bytes for ONE launch of each stage on one rank."""
     nr = Nmesh * Nmesh * (Nmesh + 2) // nranks          # padded reals of the local mesh
     s = esize
+    if gradient == "real":                               # one potential mesh instead of three force meshes
+        return {"sort": 52 * np_local, "paint": 24 * np_local + s * nr, "r2c": 2 * s * nr, "c2r": 2 * s * nr,
+                "readout": s * nr + 36 * np_local, "xback3": 2 * s * nr,
+                "k_colfft": 2 * s * nr, "k_rowfft": 2 * s * nr, "k_zc2r": 2 * s * nr}
     return {
         "sort": 24 * np_local + 28 * np_local,           # read x, write binned x + index (our addition)
         "paint": 24 * np_local + s * nr,                 # K2
@@ -111,7 +115,7 @@ def pmc_traffic(stage, Nmesh, np_total, args, world):
         c = t["config"]
         if (c["nmesh"], c["particles"], c["precision"], c["n_gpus"]) != (Nmesh, np_total, args.precision, world):
             return None
-        if args.fft_mode != 0 or args.paint_mode != 0:
+        if args.fft_mode != 0 or args.paint_mode != 0 or args.gradient != "kspace":
             return None
         return t["hbm_bytes_per_launch_by_stage"].get(stage)
     except Exception:
@@ -185,6 +189,10 @@ def main():
     ap.add_argument("--fft-mode", type=int, default=0, help="0 auto (column FFT + rocFFT z pass), 1 rocFFT only")
     ap.add_argument("--load", default="a", choices=["a", "b", "c"],
                     help="a: lattice + 0.3-cell jitter (default); b: clustered (rms 4 cells); c: adversarial (1 GPU only)")
+    ap.add_argument("--gradient", default="kspace", choices=["kspace", "real"],
+                    help="kspace (default): the reference's arithmetic, 3 inverse FFTs; real: FPMHIP_GRADIENT_REAL, "
+                         "1 inverse FFT of the potential + stencil readout (acc within 2e-7 max|acc| of kspace)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra leg that times the other gradient mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -221,47 +229,69 @@ def main():
         x = make_particles(nc, Nmesh, BoxSize, world, rank, device)
     np_local = x.shape[0]
     np_total = nc ** 3
-    pm = PM(Nmesh, BoxSize, precision=args.precision, nranks=world, rank=rank, np_max=np_local,
-            paint_mode=args.paint_mode, fft_mode=args.fft_mode)
-    store = Store(x, device=device)
-    delta_k = pm.alloc()
-    if world > 1:
-        from fastpm_amd.distributed import SlabForce
-        force = SlabForce(pm, dist.group.WORLD)
-        step = lambda: force.compute_force(store, kernel="1_4", dealias="none", delta_k=delta_k)
-    else:
-        step = lambda: pm.compute_force(store, kernel="1_4", softening="none", delta_k=delta_k,
-                                        total_mass=float(np_total))
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    pm.timing_enable(True)
-    pm.timing_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    tm = pm.timings()
-    pm.timing_enable(False)
+    def timed_run(gradient):
+        """W untimed + K timed force calls in one gradient mode; max over ranks of the wall time."""
+        pm = PM(Nmesh, BoxSize, precision=args.precision, nranks=world, rank=rank, np_max=np_local,
+                paint_mode=args.paint_mode, fft_mode=args.fft_mode, gradient_mode=1 if gradient == "real" else 0)
+        store = Store(x, device=device)
+        delta_k = pm.alloc()
+        if world > 1:
+            from fastpm_amd.distributed import SlabForce
+            force = SlabForce(pm, dist.group.WORLD)
+            step = lambda: force.compute_force(store, kernel="1_4", dealias="none", delta_k=delta_k)
+        else:
+            step = lambda: pm.compute_force(store, kernel="1_4", softening="none", delta_k=delta_k,
+                                            total_mass=float(np_total))
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        pm.timing_enable(True)
+        pm.timing_reset()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        tm = pm.timings()
+        pm.timing_enable(False)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return pm, store, dt, tm
 
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    pm, store, dt, tm = timed_run(args.gradient)
+
+    # extra leg, outside the timed region above and reported beside it: the same workload in the OTHER
+    # gradient mode (same W and K, same bracket), and how far its accelerations are from the main run's
+    alt = None
+    if not args.no_alt:
+        other = "real" if args.gradient == "kspace" else "kspace"
+        pm2, store2, dt2, tm2 = timed_run(other)
+        dev = torch.stack([(store2.acc - store.acc).abs().max(), store.acc.abs().max()]).to(torch.float64)
+        if world > 1:
+            dist.all_reduce(dev, op=dist.ReduceOp.MAX)
+        alt = {"gradient": other, "ms_per_step": dt2 / args.steps * 1e3, "value": np_total * args.steps / dt2,
+               "kernel_ms_per_step": round(sum(tm2[n][0] for n in ("sort", "paint", "r2c", "dealias", "transfer", "c2r",
+                                                                   "readout", "halo", "pack", "xback3")) / args.steps, 3),
+               "acc_max_abs_dev_over_max_abs_acc": float(dev[0] / dev[1]),
+               "note": "same W/K and timing bracket as the headline run; not part of `value`"}
+        del store2
+        pm2.destroy()
 
     acc_ok = bool(torch.isfinite(store.acc).all().item())
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = np_total * args.steps / dt
-        ab = algorithmic_bytes(np_local, Nmesh, world, esize)
+        ab = algorithmic_bytes(np_local, Nmesh, world, esize, args.gradient)
+        if args.gradient == "real":
+            KERNELS["readout"] = "fpm::readout_grad_kernel"
         stages = {}
         for name, (ms, n) in tm.items():
             if n == 0:
@@ -279,7 +309,9 @@ def main():
                     "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, Nmesh, np_total, args, world),
                     "alg_bytes_per_launch": ab[dom], "avg_launch_ms": round(avg_s * 1e3, 4)}
-        b_alg = 60 * np_local + 12 * esize * (Nmesh * Nmesh * (Nmesh + 2) // world)
+        # 60 B per particle + 12 mesh sweeps (paint 1, r2c 2, 3 x (transfer 2 + readout 1)); the
+        # real-space gradient needs 6 (paint 1, r2c 2, potential transfer + c2r 2, readout 1)
+        b_alg = 60 * np_local + (12 if args.gradient == "kspace" else 6) * esize * (Nmesh * Nmesh * (Nmesh + 2) // world)
         out = {
             "metric": "particle-updates/sec (PM force step)", "value": value, "unit": "particle-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -291,6 +323,8 @@ def main():
                 "load": {"a": "A: lattice + 0.3-cell Gaussian jitter", "b": "B: clustered, Zel'dovich-like rms 4 cells",
                          "c": "C: adversarial, 10 % of particles in 0.1 % of the volume"}[args.load],
                 "kernel": "1_4", "softening": "none", "decomposition": "slab %dx1" % world,
+                "gradient": {"kspace": "k space, 3 inverse FFTs (the reference's arithmetic)",
+                             "real": "real space, 1 inverse FFT + stencil readout (FPMHIP_GRADIENT_REAL)"}[args.gradient],
                 "paint_mode": "tiled" if args.paint_mode == 0 else "atomic",
                 "fft": "column passes + rocFFT z" if pm.staged_fft() and args.fft_mode == 0 else "rocFFT"},
             "per_gpu": value / world, "finite": acc_ok,
@@ -302,6 +336,8 @@ def main():
             "roofline": roofline, "stages": stages,
         }
         out["exposed_comm_ms_per_step"] = round(ms_per_step - out["kernel_ms_per_step"], 3) if world > 1 else 0.0
+        if alt is not None:
+            out["other_gradient_mode"] = alt
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"], out["parity"] = cpu_baseline(os.cpu_count() or 1, x, Nmesh, BoxSize,

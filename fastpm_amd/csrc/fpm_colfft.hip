@@ -279,7 +279,8 @@ __global__ __launch_bounds__(N / 8 * CW) void colfft_kernel(const C2<F> *__restr
 // 128 VGPRs so that two workgroups share a CU (measured 1.32 ms vs 1.46 ms at one per CU;
 // re-reading delta_k per component instead: 1.63 ms; HBM floor for 1 read + 3 writes in this
 // access pattern: 1.02 ms, tools/ubench/wr_pattern.hip).
-template <int N, int R2, int R3, int R4, int CW, typename F>
+// POT: one output, the potential b itself (gravity.c:188-190) -- the real-space-gradient mode's x pass.
+template <int N, int R2, int R3, int R4, int CW, bool POT, typename F>
 __global__ __launch_bounds__(N / 8 * CW, 4) void colfft_xback3_kernel(const C2<F> *__restrict__ dk, C2<F> *__restrict__ o0,
                                                              C2<F> *__restrict__ o1, C2<F> *__restrict__ o2,
                                                              long long rstride, int ncols, int nzc, int ystart,
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(N / 8 * CW, 4) void colfft_xback3_kernel(const C2<F
     }
     C2<F> *outs[3] = {o0, o1, o2};
 #pragma unroll 1
-    for (int dir = 0; dir < 3; dir++) {
+    for (int dir = 0; dir < (POT ? 1 : 3); dir++) {
         C2<F> v[VMAX];
         // an opaque copy of tau per iteration: keeps the compiler from hoisting the table values,
         // flags and store addresses of all three iterations above the loop, where they would have
@@ -341,7 +342,9 @@ __global__ __launch_bounds__(N / 8 * CW, 4) void colfft_xback3_kernel(const C2<F
             const int ix = tau_o + T * j;
             const double k_finite = dir == 0 ? kt[ix] : (dir == 1 ? kt[iy] : kt[iz]);
             const bool selfconj = yz_self && ix == (N - ix) % N;       // gravity.c:44-56
-            if (selfconj) {
+            if (POT) {
+                v[j] = b[j];
+            } else if (selfconj) {
                 v[j].x = 0;
                 v[j].y = 0;
             } else {
@@ -559,7 +562,8 @@ int rowfft_r2c_range(fpmhip_plan *p, const void *in, void *out, int x0, int nx)
 }
 
 template <typename F>
-static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, void *o2, int potorder, int gradorder)
+static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, void *o2, int potorder, int gradorder,
+                         bool pot)
 {
     const MeshGeo &g = p->mg;
     const int N = g.N;
@@ -572,24 +576,33 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
     const float *kk = p->d_tab + (2 + potorder) * (size_t) N;
     const float *kt = p->d_tab + gradorder * (size_t) N;
     const int grid = ntiles;
-#define CALL_X3_W(n, r2, r3, r4, W)                                                                          \
-    FPM_TRY(set_lds(colfft_xback3_kernel<n, r2, r3, r4, W, F>, lds));                                        \
-    colfft_xback3_kernel<n, r2, r3, r4, W, F><<<grid, n / 8 * W, lds, p->stream>>>(                          \
+#define CALL_X3_P(n, r2, r3, r4, W, P)                                                                       \
+    FPM_TRY(set_lds(colfft_xback3_kernel<n, r2, r3, r4, W, P, F>, lds));                                     \
+    colfft_xback3_kernel<n, r2, r3, r4, W, P, F><<<grid, n / 8 * W, lds, p->stream>>>(                       \
         (const C2<F> *) dk, (C2<F> *) o0, (C2<F> *) o1, (C2<F> *) o2, plane, (int) plane, g.nzc, g.ystart,  \
         ntiles, kk, kt, p->d_twiddle);
+#define CALL_X3_W(n, r2, r3, r4, W)                                                                          \
+    if (pot) { CALL_X3_P(n, r2, r3, r4, W, true) } else { CALL_X3_P(n, r2, r3, r4, W, false) }
 #define CALL_X3(n, r2, r3, r4)                                                                               \
     if (wide) { CALL_X3_W(n, r2, r3, r4, (n <= 512 ? CW : 8)) } else { CALL_X3_W(n, r2, r3, r4, 8) }
     COLFFT_DISPATCH(N, CALL_X3)
 #undef CALL_X3
 #undef CALL_X3_W
+#undef CALL_X3_P
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 int colfft_xback3(fpmhip_plan *p, const void *dk, void *o0, void *o1, void *o2, int potorder, int gradorder)
 {
-    return p->f64 ? xback3_launch<double>(p, dk, o0, o1, o2, potorder, gradorder)
-                  : xback3_launch<float>(p, dk, o0, o1, o2, potorder, gradorder);
+    return p->f64 ? xback3_launch<double>(p, dk, o0, o1, o2, potorder, gradorder, false)
+                  : xback3_launch<float>(p, dk, o0, o1, o2, potorder, gradorder, false);
+}
+
+int colfft_xback_pot(fpmhip_plan *p, const void *dk, void *out, int potorder)
+{
+    return p->f64 ? xback3_launch<double>(p, dk, out, out, out, potorder, 0, true)
+                  : xback3_launch<float>(p, dk, out, out, out, potorder, 0, true);
 }
 
 }  // namespace fpm

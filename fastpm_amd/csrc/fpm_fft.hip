@@ -330,4 +330,19 @@ int fpmhip_transfer_fft_x_backward3(fpmhip_plan *p, const void *delta_k, void *o
     return 0;
 }
 
+// The POTENTIAL transfer and the x pass of its inverse transform in one sweep (real-space-gradient mode).
+int fpmhip_transfer_fft_x_backward_pot(fpmhip_plan *p, const void *delta_k, void *out, int kernel)
+{
+    if (!p || !delta_k || !out) FPM_FAIL(-1, "null argument");
+    if (!fpmhip_plan_staged_fft(p)) FPM_FAIL(-1, "staged FFT needs nranks > 1 or the column-FFT back end");
+    int po, go, dfo, dc;
+    FPM_TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));
+    if (p->own_fft) {
+        StageTimer tm(p, FPMHIP_T_XBACK3);
+        return colfft_xback_pot(p, delta_k, out, po);
+    }
+    FPM_TRY(fpmhip_transfer(p, delta_k, out, kernel, FPMHIP_FIELD_POTENTIAL));
+    return fpmhip_fft_x_backward(p, out);
+}
+
 }  // extern "C"

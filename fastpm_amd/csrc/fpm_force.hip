@@ -64,9 +64,13 @@ int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets
     for (int si = 0; si < nsets; si++)
         if (sets[si].np > 0 && !sets[si].acc) FPM_FAIL(-1, "particles without an acc column");
 
+    // FPMHIP_GRADIENT_REAL: one inverse FFT (the potential) + stencil readout, for gradorder = 1
+    const bool real_grad = p->geom.gradient_mode == FPMHIP_GRADIENT_REAL && go == 1;
     FPM_TRY(ensure_buffer(p, BUF_CANVAS));
-    FPM_TRY(ensure_buffer(p, BUF_F1));
-    FPM_TRY(ensure_buffer(p, BUF_F2));
+    if (!real_grad) {
+        FPM_TRY(ensure_buffer(p, BUF_F1));
+        FPM_TRY(ensure_buffer(p, BUF_F2));
+    }
     void *canvas = p->buf[BUF_CANVAS];
     void *delta_k = delta_k_out;
     if (!delta_k) {
@@ -88,6 +92,23 @@ int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets
     FPM_TRY(fpmhip_r2c(p, canvas, delta_k));                                              // gravity.c:351
     FPM_TRY(fpmhip_softening(p, delta_k, softening));                                     // gravity.c:476
 
+    bool any_pot = false;
+    for (int si = 0; si < nsets; si++) any_pot = any_pot || sets[si].potential != nullptr;
+    if (real_grad) {
+        // the canvas is free again after the out-of-place r2c: it carries the potential
+        if (p->own_fft) {
+            FPM_TRY(fpmhip_transfer_fft_x_backward_pot(p, delta_k, canvas, kernel));
+            FPM_TRY(fpmhip_fft_yz_backward(p, canvas, canvas));
+        } else {
+            FPM_TRY(fpmhip_transfer(p, delta_k, canvas, kernel, FPMHIP_FIELD_POTENTIAL));
+            FPM_TRY(fpmhip_c2r(p, canvas));
+        }
+        for (int si = nsets - 1; si >= 0; si--) FPM_TRY(fpmhip_readout_grad(p, &sets[si], canvas, nullptr));
+        for (int si = 0; si < nsets; si++)                                                // gravity.c:487-492
+            if (sets[si].potential) FPM_TRY(fpmhip_readout1(p, &sets[si], canvas, sets[si].potential, 1, 0));
+        return 0;
+    }
+
     // the canvas is free again after the out-of-place r2c: it carries the x component
     void *f[3] = {canvas, p->buf[BUF_F1], p->buf[BUF_F2]};
     if (p->own_fft) {
@@ -102,8 +123,6 @@ int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets
     }
     // with several species the last paint's binning belongs to the last one: read that one first
     for (int si = nsets - 1; si >= 0; si--) FPM_TRY(fpmhip_readout3(p, &sets[si], f[0], f[1], f[2]));
-    bool any_pot = false;
-    for (int si = 0; si < nsets; si++) any_pot = any_pot || sets[si].potential != nullptr;
     if (any_pot) {                                                                        // gravity.c:487-492
         FPM_TRY(fpmhip_transfer(p, delta_k, canvas, kernel, FPMHIP_FIELD_POTENTIAL));
         FPM_TRY(fpmhip_c2r(p, canvas));

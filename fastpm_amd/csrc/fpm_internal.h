@@ -168,6 +168,7 @@ int rowfft_r2c_range(fpmhip_plan *p, const void *in, void *out, int x0, int nx);
 bool rowfft_supported(int N);
 int rowfft_r2c(fpmhip_plan *p, const void *in, void *out);
 int colfft_xback3(fpmhip_plan *p, const void *dk, void *o0, void *o1, void *o2, int potorder, int gradorder);
+int colfft_xback_pot(fpmhip_plan *p, const void *dk, void *out, int potorder);
 
 // fpm_force.hip
 void release_host_stage(fpmhip_plan *p);

@@ -262,6 +262,68 @@ __global__ __launch_bounds__(256) void scale_kernel(F *__restrict__ buf, long lo
     for (; i < n; i += stride) buf[i] = (F) (buf[i] * value);
 }
 
+// Copy the RX x RY x RZ region of a mesh that starts at local cell (x0, y0, z0), z0 EVEN, into LDS
+// (periodic wrap in y, z and -- one rank -- in x; on a slab, local planes 0 .. xl come from `mesh`
+// (xl = its halo plane) and, when `halo` is given, planes -2, -1, xl+1, xl+2 from there; anything
+// else reads as 0 and is never used).
+// Straight-line: U independent loads in flight per thread, then the LDS stores.  Measured on the
+// 13 x 13 x 37 fp64 region of readout_grad_tiles_kernel (32768 tiles): a plain loop serialises the
+// load latencies, 1.99 ms for the whole kernel; `while` wraps and pointer branches inside an unrolled
+// body compile to divergent control flow with a wait per element, 1.61 ms; branch-free scalar loads
+// 1.06 ms; pairs 0.89 ms.  A row starts at an even z, so it is RZ / 2 aligned pairs (one 2 x F load
+// each; a pair never straddles the periodic wrap because N is even) + 1 single when RZ is odd.
+template <typename F, int RX, int RY, int RZ>
+__device__ __forceinline__ void stage_region(F *__restrict__ reg, const F *__restrict__ mesh,
+                                             const F *__restrict__ halo, const MeshGeo &g, int x0, int y0, int z0)
+{
+    constexpr int U = 7, PR = (RZ + 1) / 2, NQ = RX * RY * PR;
+    struct __align__(2 * sizeof(F)) F2 { F a, b; };
+    const bool small = g.N < 64;       // uniform: offsets up to TILE + 5 need a true modulo on tiny meshes
+    for (int q0 = threadIdx.x; q0 < NQ; q0 += 256 * U) {
+        F2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int q = min(q0 + u * 256, NQ - 1);
+            const int pz = q % PR, row = q / PR, ry = row % RY, rx = row / RY;
+            int lx = x0 + rx, gy = y0 + ry, gz = z0 + 2 * pz;
+            if (small) {
+                gy = ((gy % g.N) + g.N) % g.N;
+                gz = ((gz % g.N) + g.N) % g.N;
+            } else {
+                gy += gy < 0 ? g.N : 0; gy -= gy >= g.N ? g.N : 0;
+                gz += gz < 0 ? g.N : 0; gz -= gz >= g.N ? g.N : 0;
+            }
+            bool ok = true;
+            const F *pl;
+            if (g.periodic_x) {                   // uniform
+                if (small) lx = ((lx % g.N) + g.N) % g.N;
+                else { lx += lx < 0 ? g.N : 0; lx -= lx >= g.N ? g.N : 0; }
+                pl = mesh + (long long) lx * g.str0;
+            } else if (halo) {                    // uniform
+                ok = lx >= -2 && lx <= g.xl + 2;
+                const bool lo = lx < 0, hi = lx > g.xl;
+                const int hp = !ok ? 0 : (lo ? lx + 2 : (hi ? lx - g.xl + 1 : lx));
+                pl = ((lo || hi) && ok ? halo : mesh) + (long long) hp * g.str0;
+            } else {
+                ok = lx >= 0 && lx < g.xplanes;
+                pl = mesh + (long long) (ok ? lx : 0) * g.str0;
+            }
+            // gz is even and <= N - 2: the second value of a pair is still inside the row
+            const F2 val = *(const F2 *) (pl + (long long) gy * g.str1 + gz);
+            v[u] = ok ? val : F2{0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int q = q0 + u * 256;
+            if (q < NQ) {
+                const int pz = q % PR, row = q / PR;
+                reg[row * RZ + 2 * pz] = v[u].a;
+                if (2 * pz + 1 < RZ) reg[row * RZ + 2 * pz + 1] = v[u].b;
+            }
+        }
+    }
+}
+
 // CIC readout of NC meshes at once.  value = sum over corners in the order 000,001,...,111
 // (x,y,z bits) of mesh * (Wz*Wx*Wy), accumulated in double (painter-cic.c:161-189), then
 // out = (float) value (store.c:79-91).  BINNED: thread j handles binned entry j (tile order,
@@ -308,12 +370,153 @@ __global__ __launch_bounds__(256) void readout_kernel(MeshGeo g, long long np,
     for (int q = 0; q < NC; q++) out[row * nmemb + memb0 + q] = (float) value[q];
 }
 
-// CIC readout of the three force meshes with the mesh staged through LDS: one workgroup per tile
-// copies the (TILE+1)^3-shaped region of each mesh it can touch (periodic wrap / halo plane
-// resolved at copy time, rows of TILE_Z+1 contiguous values -> coalesced) into LDS, then its own
-// binned particles gather their 8 corners from LDS.  Same arithmetic and corner order as
-// readout_kernel (bit-identical results); HBM sees each mesh row once per tile instead of once per
-// particle wave (measured traffic of the direct-gather kernel: 1.6x the algorithmic bytes).
+// acc_d = sum over corners (order 000..111, weights as readout_kernel) of W * G_d(corner), where
+// at(ox, oy, oz) is phi at offsets (ox-2, oy-2, oz-2) from the particle's base cell.
+template <typename At>
+__device__ __forceinline__ void grad_cic(At at, const Cic &c, double inv12h, double *value)
+{
+    double core[2][2][2];
+#pragma unroll
+    for (int bx = 0; bx < 2; bx++)
+#pragma unroll
+        for (int by = 0; by < 2; by++)
+#pragma unroll
+            for (int bz = 0; bz < 2; bz++) core[bx][by][bz] = at(2 + bx, 2 + by, 2 + bz);
+    const double wx[2] = {c.t[0], c.d[0]}, wy[2] = {c.t[1], c.d[1]}, wz[2] = {c.t[2], c.d[2]};
+    double G[3][2][2][2];      // [dir][bx][by][bz]
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            {   // x line at (by, bz) = (a, b)
+                const double f0 = at(0, 2 + a, 2 + b), f1 = at(1, 2 + a, 2 + b), f4 = at(4, 2 + a, 2 + b), f5 = at(5, 2 + a, 2 + b);
+                const double f2 = core[0][a][b], f3 = core[1][a][b];
+                G[0][0][a][b] = (8 * (f3 - f1) - (f4 - f0)) * inv12h;
+                G[0][1][a][b] = (8 * (f4 - f2) - (f5 - f1)) * inv12h;
+            }
+            {   // y line at (bx, bz) = (a, b)
+                const double f0 = at(2 + a, 0, 2 + b), f1 = at(2 + a, 1, 2 + b), f4 = at(2 + a, 4, 2 + b), f5 = at(2 + a, 5, 2 + b);
+                const double f2 = core[a][0][b], f3 = core[a][1][b];
+                G[1][a][0][b] = (8 * (f3 - f1) - (f4 - f0)) * inv12h;
+                G[1][a][1][b] = (8 * (f4 - f2) - (f5 - f1)) * inv12h;
+            }
+            {   // z line at (bx, by) = (a, b)
+                const double f0 = at(2 + a, 2 + b, 0), f1 = at(2 + a, 2 + b, 1), f4 = at(2 + a, 2 + b, 4), f5 = at(2 + a, 2 + b, 5);
+                const double f2 = core[a][b][0], f3 = core[a][b][1];
+                G[2][a][b][0] = (8 * (f3 - f1) - (f4 - f0)) * inv12h;
+                G[2][a][b][1] = (8 * (f4 - f2) - (f5 - f1)) * inv12h;
+            }
+        }
+    value[0] = value[1] = value[2] = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int bx = (k >> 2) & 1, by = (k >> 1) & 1, bz = k & 1;
+        const double wgt = wz[bz] * wx[bx] * wy[by];
+#pragma unroll
+        for (int q = 0; q < 3; q++) value[q] += G[q][bx][by][bz] * wgt;
+    }
+}
+
+// Readout of the ACC components straight from the POTENTIAL mesh ("real-space gradient" mode).
+// For the finite-difference kernels (gradorder = 1) the k-space gradient i k_finite(w),
+// k_finite = (8 sin w - sin 2w) / (6 h)  (pmapi.c:252-262), is the transform of the 4-point
+// stencil  G_d(c) = (8 (phi(c + e_d) - phi(c - e_d)) - (phi(c + 2 e_d) - phi(c - 2 e_d))) / (12 h),
+// so  acc_d(p) = sum_corners W(corner) G_d(corner)  equals the reference's transfer -> c2r ->
+// readout per component up to rounding (the reference rounds k_finite to float32: measured
+// max |difference| = 5.7e-8 max|acc|, i.e. below one float32 ulp of the largest value).  One inverse
+// FFT instead of three.  Corner order and weights as readout_kernel; G in double.
+// The 2 x 2 x 2 core of phi is shared by the three directions: 8 + 3 * 16 = 56 gathers.
+// x planes: periodic wrap (one rank), or planes -2, -1, xl+1, xl+2 from `halo` (slab; plane xl is the
+// canvas' own halo plane).
+template <typename F, bool BINNED>
+__global__ __launch_bounds__(256) void readout_grad_kernel(MeshGeo g, long long np,
+                                                           const double *__restrict__ sx,
+                                                           const double *__restrict__ sy,
+                                                           const double *__restrict__ sz,
+                                                           const int *__restrict__ sidx,
+                                                           const double *__restrict__ x,
+                                                           const F *__restrict__ phi, const F *__restrict__ halo,
+                                                           float *__restrict__ out, double inv12h)
+{
+    const long long j = (long long) xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    if (j >= np) return;
+    double px, py, pz;
+    long long row;
+    if (BINNED) {
+        px = sx[j]; py = sy[j]; pz = sz[j];
+        row = sidx[j];
+    } else {
+        px = x[3 * j]; py = x[3 * j + 1]; pz = x[3 * j + 2];
+        row = j;
+    }
+    Cic c;
+    if (!cic_setup(g, px, py, pz, c)) return;
+    // plane bases and row / column offsets for the offsets -2 .. +3 around the base cell
+    const F *xp[6];
+    long long yo[6];
+    int zo[6];
+#pragma unroll
+    for (int o = 0; o < 6; o++) {
+        int lx = c.i0[0] + o - 2;
+        if (g.periodic_x) {
+            lx = wrap_cell(lx, g.N);
+            xp[o] = phi + (long long) lx * g.str0;
+        } else {
+            xp[o] = lx < 0 ? halo + (long long) (lx + 2) * g.str0
+                           : (lx > g.xl ? halo + (long long) (lx - g.xl + 1) * g.str0 : phi + (long long) lx * g.str0);
+        }
+        yo[o] = (long long) wrap_cell(c.i0[1] + o - 2, g.N) * g.str1;
+        zo[o] = wrap_cell(c.i0[2] + o - 2, g.N);
+    }
+    double value[3];
+    grad_cic([&](int ox, int oy, int oz) { return (double) xp[ox][yo[oy] + zo[oz]]; }, c, inv12h, value);
+#pragma unroll
+    for (int q = 0; q < 3; q++) out[row * 3 + q] = (float) value[q];
+}
+
+// The same with the potential staged through LDS: one workgroup per tile copies the
+// (TILE + 5)^3-shaped region its particles' stencils can touch (13 x 13 x 37 values, 49 KB in fp64:
+// three workgroups per CU), then every particle takes its 56 values from LDS.  Same arithmetic as
+// readout_grad_kernel (grad_cic), bit-identical results.  The default.
+template <typename F>
+__global__ __launch_bounds__(256) void readout_grad_tiles_kernel(MeshGeo g, int ntiles, const int *__restrict__ off,
+                                                                 const double *__restrict__ sx,
+                                                                 const double *__restrict__ sy,
+                                                                 const double *__restrict__ sz,
+                                                                 const int *__restrict__ sidx,
+                                                                 const F *__restrict__ phi, const F *__restrict__ halo,
+                                                                 float *__restrict__ out, double inv12h)
+{
+    constexpr int RX = TILE_X + 5, RY = TILE_Y + 5, RZ = TILE_Z + 5, RN = RX * RY * RZ;
+    extern __shared__ __align__(16) unsigned char smem_rg[];
+    F *reg = (F *) smem_rg;                       // [RX][RY][RZ]
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int beg = off[t], end = off[t + 1];
+    if (beg == end) return;
+    const int tz = t % g.ntz, ty = (t / g.ntz) % g.nty, tx = t / (g.ntz * g.nty);
+    const int x0 = tx * TILE_X - 2, y0 = ty * TILE_Y - 2, z0 = tz * TILE_Z - 2;
+    stage_region<F, RX, RY, RZ>(reg, phi, halo, g, x0, y0, z0);
+    __syncthreads();
+    for (int j = beg + threadIdx.x; j < end; j += 256) {
+        Cic c;
+        (void) cic_setup(g, sx[j], sy[j], sz[j], c);
+        // the region starts 2 cells below the tile; the un-wrapped base cell is inside the tile
+        const int lx = c.i0[0] - x0 - 2, ly = c.i0[1] - y0 - 2, lz = c.i0[2] - z0 - 2;
+        const F *base = reg + (lx * RY + ly) * RZ + lz;
+        double value[3];
+        grad_cic([&](int ox, int oy, int oz) { return (double) base[(ox * RY + oy) * RZ + oz]; }, c, inv12h, value);
+        const long long row = sidx[j];
+#pragma unroll
+        for (int q = 0; q < 3; q++) out[row * 3 + q] = (float) value[q];
+    }
+}
+
+// CIC readout of the three force meshes with the mesh staged through LDS (the default): one workgroup
+// per tile copies the (TILE+1)^3-shaped region of each mesh it can touch (periodic wrap / halo plane
+// resolved at copy time, stage_region) into LDS, then its own binned particles gather their 8 corners
+// from LDS.  Same arithmetic and corner order as readout_kernel (bit-identical results); HBM sees each
+// mesh row once per tile instead of once per particle wave (measured traffic of the direct-gather
+// kernel: 1.6x the algorithmic bytes).
 template <typename F>
 __global__ __launch_bounds__(256) void readout3_tiles_kernel(MeshGeo g, int ntiles, const int *__restrict__ off,
                                                              const double *__restrict__ sx,
@@ -332,18 +535,8 @@ __global__ __launch_bounds__(256) void readout3_tiles_kernel(MeshGeo g, int ntil
     const int tz = t % g.ntz, ty = (t / g.ntz) % g.nty, tx = t / (g.ntz * g.nty);
     const int x0 = tx * TILE_X, y0 = ty * TILE_Y, z0 = tz * TILE_Z;
     const F *mesh[3] = {m0, m1, m2};
-    for (int e = threadIdx.x; e < RN; e += 256) {
-        const int rz = e % RZ, ry = (e / RZ) % RY, rx = e / (RZ * RY);
-        int gx = x0 + rx, gy = y0 + ry, gz = z0 + rz;
-        if (g.periodic_x) { if (gx >= g.N) gx -= g.N; }
-        else if (gx >= g.xplanes) gx = g.xplanes - 1;         // beyond the halo plane: never addressed
-        if (gy >= g.N) gy -= g.N;
-        if (gz >= g.N) gz -= g.N;
-        const bool ok = gx < g.xplanes && gy < g.N && gz < g.N;   // partial tiles at the mesh edge
-        const long long ind = (long long) gx * g.str0 + (long long) gy * g.str1 + gz;
 #pragma unroll
-        for (int q = 0; q < 3; q++) reg[q * RN + e] = ok ? mesh[q][ind] : (F) 0;
-    }
+    for (int q = 0; q < 3; q++) stage_region<F, RX, RY, RZ>(reg + q * RN, mesh[q], (const F *) nullptr, g, x0, y0, z0);
     __syncthreads();
     for (int j = beg + threadIdx.x; j < end; j += 256) {
         Cic c;
@@ -476,9 +669,10 @@ static int readout_impl(fpmhip_plan *p, const fpmhip_particles *pt, const F *m0,
     }
     if (p->binned_x != pt->x || p->binned_np != np) FPM_TRY(bin_particles(p, pt));
     StageTimer tm(p, FPMHIP_T_READOUT);
-    // measured on configs[1]: LDS-staged 2.46 ms vs direct gather of the binned entries 1.07 ms (64 KB of
-    // LDS per workgroup leaves 2 workgroups per CU and serialises copy and gather); kept for A/B only
-    static int lds_mode = getenv("FPMHIP_READOUT") ? atoi(getenv("FPMHIP_READOUT")) : 0;
+    // measured on configs[1] (loads A / B / C): LDS-staged 1.05 / 1.14 / 1.79 ms, direct gather of the
+    // binned entries 1.10 / 1.23 / 2.03 ms (the LDS kernel took 2.46 ms before stage_region() kept its
+    // loads in flight, see there).  FPMHIP_READOUT=0 selects the direct kernel (A/B).
+    static int lds_mode = getenv("FPMHIP_READOUT") ? atoi(getenv("FPMHIP_READOUT")) : 1;
     if (NC == 3 && nmemb == 3 && memb0 == 0 && lds_mode) {
         const size_t lds = (size_t) 3 * (TILE_X + 1) * (TILE_Y + 1) * (TILE_Z + 1) * sizeof(F);
         static bool granted = false;
@@ -494,6 +688,43 @@ static int readout_impl(fpmhip_plan *p, const fpmhip_particles *pt, const F *m0,
     }
     readout_kernel<F, NC, true><<<blocks_for(np, 256), 256, 0, p->stream>>>(
         p->mg, np, p->sx, p->sy, p->sz, p->sidx, nullptr, m0, m1, m2, out, nmemb, memb0);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <typename F>
+static int readout_grad_impl(fpmhip_plan *p, const fpmhip_particles *pt, const F *phi, const F *halo)
+{
+    const long long np = pt->np;
+    if (np == 0) return 0;
+    const double inv12h = p->mg.inv_cell / 12.0;
+    if (p->geom.paint_mode == FPMHIP_PAINT_ATOMIC) {
+        StageTimer tm(p, FPMHIP_T_READOUT);
+        readout_grad_kernel<F, false><<<blocks_for(np, 256), 256, 0, p->stream>>>(
+            p->mg, np, nullptr, nullptr, nullptr, nullptr, pt->x, phi, halo, pt->acc, inv12h);
+        FPM_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
+    if (p->binned_x != pt->x || p->binned_np != np) FPM_TRY(bin_particles(p, pt));
+    StageTimer tm(p, FPMHIP_T_READOUT);
+    // measured on configs[1] (loads A / B / C): LDS-staged 0.83 / 0.93 / 1.53 ms, direct gather of the
+    // binned entries 1.58 / 1.85 / 2.91 ms.  FPMHIP_READOUT_GRAD=1 selects the direct kernel (A/B).
+    static int lds_mode = getenv("FPMHIP_READOUT_GRAD") ? atoi(getenv("FPMHIP_READOUT_GRAD")) != 1 : 1;
+    if (lds_mode) {
+        const size_t lds = (size_t) (TILE_X + 5) * (TILE_Y + 5) * (TILE_Z + 5) * sizeof(F);
+        static bool granted = false;
+        if (!granted) {
+            FPM_CHECK_HIP(hipFuncSetAttribute((const void *) readout_grad_tiles_kernel<F>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            granted = true;
+        }
+        readout_grad_tiles_kernel<F><<<p->ntiles, 256, lds, p->stream>>>(p->mg, p->ntiles, p->tile_off, p->sx, p->sy,
+                                                                          p->sz, p->sidx, phi, halo, pt->acc, inv12h);
+        FPM_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
+    readout_grad_kernel<F, true><<<blocks_for(np, 256), 256, 0, p->stream>>>(
+        p->mg, np, p->sx, p->sy, p->sz, p->sidx, nullptr, phi, halo, pt->acc, inv12h);
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -543,6 +774,16 @@ int fpmhip_readout3(fpmhip_plan *p, const fpmhip_particles *pt, const void *m0, 
     if (!m0 || !m1 || !m2) FPM_FAIL(-1, "null mesh");
     return p->f64 ? readout_impl<double, 3>(p, pt, (const double *) m0, (const double *) m1, (const double *) m2, pt->acc, 3, 0)
                   : readout_impl<float, 3>(p, pt, (const float *) m0, (const float *) m1, (const float *) m2, pt->acc, 3, 0);
+}
+
+int fpmhip_readout_grad(fpmhip_plan *p, const fpmhip_particles *pt, const void *phi, const void *halo)
+{
+    FPM_TRY(check_particles(p, pt));
+    if (!pt->acc && pt->np > 0) FPM_FAIL(-1, "particles without an acc column");
+    if (!phi) FPM_FAIL(-1, "null mesh");
+    if (p->lay.nranks > 1 && !halo) FPM_FAIL(-1, "readout_grad on a slab needs the four halo planes -2, -1, xl+1, xl+2");
+    return p->f64 ? readout_grad_impl<double>(p, pt, (const double *) phi, (const double *) halo)
+                  : readout_grad_impl<float>(p, pt, (const float *) phi, (const float *) halo);
 }
 
 int fpmhip_readout1(fpmhip_plan *p, const fpmhip_particles *pt, const void *m, float *out, int nmemb, int memb)

@@ -23,7 +23,7 @@ tests) and (b) over `run_virtual`, which plays all ranks of a decomposition on O
 import torch
 import torch.distributed as dist
 
-from .pm import FIELD_POTENTIAL, KERNEL_TYPES, SOFTENING_TYPES, _enum
+from .pm import FIELD_POTENTIAL, GRADIENT_REAL, KERNEL_TYPES, SOFTENING_TYPES, _enum
 
 
 class SlabForce:
@@ -35,9 +35,11 @@ class SlabForce:
         self.P, self.rank = pm.nranks, pm.rank
         self.canvas = pm.alloc()
         self.work = pm.alloc()
-        self.work2 = pm.alloc()                                # second transpose landing zone (overlap)
         self._pending = {}
-        self.force = [self.canvas, pm.alloc(), pm.alloc()]    # canvas is free after the forward FFT
+        self.real_gradient = getattr(pm, "gradient_mode", 0) == GRADIENT_REAL
+        self.work2 = None                                      # second transpose landing zone (overlap)
+        self.force = [self.canvas, None, None]                 # canvas is free after the forward FFT
+        self.halo = None                                       # potential planes -2, -1, xl+1, xl+2
         self.delta_k = None
         self.tmp_plane = torch.zeros(int(pm.layout.plane_elems), dtype=self.canvas.dtype, device=self.canvas.device)
         self.scalar = torch.zeros(1, dtype=torch.float64, device=self.canvas.device)
@@ -70,8 +72,14 @@ class SlabForce:
         pm.fft_x_forward(delta_k)
         pm.apply_softening_transfer(dealias, delta_k)                     # gravity.c:476
 
+        if self.real_gradient and _gradorder(kernel) == 1:
+            yield from self._real_gradient_force(store, kernel, delta_k)
+            return
+
         # gravity.c:373-397: per component transfer -> c2r.  The three transfers and the x passes
         # come from ONE sweep over delta_k; then one transpose + (y,z) passes per component.
+        if self.work2 is None:
+            self.work2, self.force[1], self.force[2] = pm.alloc(), pm.alloc(), pm.alloc()
         pm.transfer_fft_x_backward3(kernel, delta_k, self.force)
         # the transposes run on the collective's own stream: component d+1 is in flight over xGMI
         # while the (y,z) passes of component d run on the compute stream
@@ -93,6 +101,28 @@ class SlabForce:
             yield from self._backward(delta_k, kernel, FIELD_POTENTIAL, f)
             yield ("shift", [(pm.plane(f, 0), pm.plane(f, xl), -1)])
             pm.readout(f, store, store.potential, 1, 0)
+
+    def _real_gradient_force(self, store, kernel, delta_k):
+        """FPMHIP_GRADIENT_REAL: ONE inverse transform (the potential), then the stencil readout.  Two
+        all-to-alls per force instead of four; the stencil reaches 2 planes below and 3 above the slab's
+        base planes: plane xl goes to the canvas' halo plane, the other four to a side buffer."""
+        pm = self.pm
+        xl = pm.layout.isize[0]
+        pe = int(pm.layout.plane_elems)
+        if xl < 3:
+            raise ValueError("the real-space gradient needs at least 3 x planes per slab")
+        if self.halo is None:
+            self.halo = torch.zeros(4 * pe, dtype=self.canvas.dtype, device=self.canvas.device)
+        phi = self.canvas
+        pm.transfer_fft_x_backward_pot(kernel, delta_k, phi)
+        yield ("alltoall", self.work, phi)
+        pm.fft_yz_backward(self.work, phi)
+        yield ("shift", [(pm.plane(phi, 0), pm.plane(phi, xl), -1),              # -> rank-1: its plane xl
+                         (pm.plane(phi, 1, 2), self.halo[2 * pe:], -1),          #            its planes xl+1, xl+2
+                         (pm.plane(phi, xl - 2, 2), self.halo[:2 * pe], +1)])    # -> rank+1: its planes -2, -1
+        pm.readout_grad(phi, store, self.halo)
+        if store.potential is not None:                                   # gravity.c:487-492, no extra FFT
+            pm.readout(phi, store, store.potential, 1, 0)
 
     def _backward(self, delta_k, kernel, field, out):
         pm = self.pm
@@ -204,6 +234,12 @@ def run_virtual_decompose(decomposers, stores):
                     off += n
         else:
             raise ValueError(kind)
+
+
+def _gradorder(kernel):
+    # gravity.c:111-171: gradorder = 1 (4-point k_finite) for every kernel but EASTWOOD, NAIVE and 3_2
+    return 0 if _enum(KERNEL_TYPES, kernel) in (_enum(KERNEL_TYPES, "eastwood"), _enum(KERNEL_TYPES, "naive"),
+                                                 _enum(KERNEL_TYPES, "3_2")) else 1
 
 
 def _global_rank(group, r):

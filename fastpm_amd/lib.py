@@ -13,7 +13,8 @@ class FastPMHipError(RuntimeError):
 class Geom(ctypes.Structure):
     _fields_ = [("Nmesh", ctypes.c_int64), ("BoxSize", ctypes.c_double), ("precision", ctypes.c_int32),
                 ("nranks", ctypes.c_int32), ("rank", ctypes.c_int32), ("device", ctypes.c_int32),
-                ("np_max", ctypes.c_int64), ("paint_mode", ctypes.c_int32), ("fft_mode", ctypes.c_int32)]
+                ("np_max", ctypes.c_int64), ("paint_mode", ctypes.c_int32), ("fft_mode", ctypes.c_int32),
+                ("gradient_mode", ctypes.c_int32)]
 
 
 class Layout(ctypes.Structure):
@@ -75,8 +76,10 @@ SYMBOLS = {
     "fpmhip_transfer": (_I, [_P, _P, _P, _I, _I]),
     "fpmhip_transfer_fft_x_backward3": (_I, [_P, _P, _P, _P, _P, _I]),
     "fpmhip_plan_staged_fft": (_I, [_P]),
+    "fpmhip_transfer_fft_x_backward_pot": (_I, [_P, _P, _P, _I]),
     "fpmhip_readout3": (_I, [_P, ctypes.POINTER(Particles), _P, _P, _P]),
     "fpmhip_readout1": (_I, [_P, ctypes.POINTER(Particles), _P, _P, _I, _I]),
+    "fpmhip_readout_grad": (_I, [_P, ctypes.POINTER(Particles), _P, _P]),
     "fpmhip_decic": (_I, [_P, _P, _P]),
     "fpmhip_powerspectrum": (_I, [_P, _P, _P, _P, _P, _P]),
     "fpmhip_check_values": (_I, [_P, _P, ctypes.POINTER(_I64)]),

@@ -33,6 +33,7 @@ FIELD_ACC = (0, 1, 2)
 FIELD_POTENTIAL = 3
 PAINT_TILED, PAINT_ATOMIC = 0, 1
 FFT_AUTO, FFT_ROCFFT = 0, 1
+GRADIENT_KSPACE, GRADIENT_REAL = 0, 1
 
 
 def _enum(table, v):
@@ -289,7 +290,7 @@ class PM:
     """One rank's particle mesh on one MI355X (struct PM + its plans)."""
 
     def __init__(self, Nmesh, BoxSize, precision=64, nranks=1, rank=0, device=None, np_max=0,
-                 paint_mode=PAINT_TILED, fft_mode=FFT_AUTO):
+                 paint_mode=PAINT_TILED, fft_mode=FFT_AUTO, gradient_mode=GRADIENT_KSPACE):
         self._L = _lib.load_library()
         self._plan = ctypes.c_void_p()
         if not torch.cuda.is_available():
@@ -298,7 +299,8 @@ class PM:
             device = torch.cuda.current_device()
         self.device = torch.device("cuda", int(device))
         g = _lib.Geom(int(Nmesh), float(BoxSize), int(precision), int(nranks), int(rank), int(self.device.index),
-                      int(np_max), int(paint_mode), int(fft_mode))
+                      int(np_max), int(paint_mode), int(fft_mode), int(gradient_mode))
+        self.gradient_mode = int(gradient_mode)
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream().cuda_stream
             check(self._L.fpmhip_plan_create(ctypes.byref(g), ctypes.c_void_p(stream), ctypes.byref(self._plan)))
@@ -370,6 +372,10 @@ class PM:
     def gravity_apply_kernel_transfer(self, kernel, delta_k, canvas, field):
         check(self._L.fpmhip_transfer(self._plan, _ptr(delta_k), _ptr(canvas), _enum(KERNEL_TYPES, kernel), int(field)))
 
+    def readout_grad(self, phi, store, halo=None):
+        check(self._L.fpmhip_readout_grad(self._plan, ctypes.byref(store._c()), _ptr(phi),
+                                          _ptr(halo) if halo is not None else None))
+
     def readout3(self, meshes, store):
         check(self._L.fpmhip_readout3(self._plan, ctypes.byref(store._c()), *[_ptr(m) for m in meshes]))
 
@@ -417,9 +423,9 @@ class PM:
         return out
 
     # ---- slab stages (nranks > 1)
-    def plane(self, mesh, ix):
+    def plane(self, mesh, ix, n=1):
         L = self.layout
-        return mesh[ix * L.plane_elems: (ix + 1) * L.plane_elems]
+        return mesh[ix * L.plane_elems: (ix + n) * L.plane_elems]
 
     def plane_add(self, dst_plane, src_plane):
         check(self._L.fpmhip_plane_add(self._plan, _ptr(dst_plane), _ptr(src_plane)))
@@ -446,6 +452,11 @@ class PM:
         """The three ACC transfers + the x pass of their inverse FFTs from one read of delta_k."""
         check(self._L.fpmhip_transfer_fft_x_backward3(self._plan, _ptr(delta_k), _ptr(outs[0]), _ptr(outs[1]),
                                                       _ptr(outs[2]), _enum(KERNEL_TYPES, kernel)))
+
+    def transfer_fft_x_backward_pot(self, kernel, delta_k, out):
+        """The POTENTIAL transfer + the x pass of its inverse FFT (real-space-gradient mode)."""
+        check(self._L.fpmhip_transfer_fft_x_backward_pot(self._plan, _ptr(delta_k), _ptr(out),
+                                                         _enum(KERNEL_TYPES, kernel)))
 
     # ---- whole step, one rank
     def compute_force(self, store, kernel="1_4", softening="none", delta_k=None, total_mass=-1.0):

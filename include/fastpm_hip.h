@@ -55,6 +55,19 @@ enum { FPMHIP_PAINT_TILED = 0,      /* tile-binned particles, LDS-staged tiles, 
  * in [16, 1024]; rocFFT 3-D (or 2-D + 1-D) plans otherwise.  ROCFFT forces the latter. */
 enum { FPMHIP_FFT_AUTO = 0, FPMHIP_FFT_ROCFFT = 1 };
 
+/* Where the gradient of the force is taken.
+ * KSPACE (default, 0): the reference's arithmetic -- per component, transfer (laplace, i k_finite
+ *   rounded to float32 as pmapi.c:234-275 stores it) -> c2r -> readout: three inverse FFTs
+ *   (gravity.c:373-397).
+ * REAL: one inverse FFT of the potential; the CIC readout applies the 4-point central difference
+ *   whose transform i k_finite is (fpmhip_readout_grad).  The same operator in the other domain:
+ *   accelerations differ from KSPACE only by rounding -- the float32 rounding of the k_finite table is
+ *   not reproduced -- measured max |diff| <= 1e-7 max|acc| (fp64 mesh; tests state 2e-7).  delta_k is
+ *   identical.  Used only for kernels with gradorder = 1 (1_4, 3_4, 5_4, GADGET, 1_4_DIFF0); the
+ *   others (exact i k gradient) always take the KSPACE route.  With nranks > 1 it needs 2 all-to-alls
+ *   per force instead of 4, plus four extra halo planes of the potential. */
+enum { FPMHIP_GRADIENT_KSPACE = 0, FPMHIP_GRADIENT_REAL = 1 };
+
 /* What pm_init takes (libfastpm/pmpfft.h:29-35 PMInit) + where this rank sits. */
 typedef struct {
     int64_t Nmesh;        /* cubic mesh, must be even (pmpfft.c:143) and divisible by nranks */
@@ -66,6 +79,7 @@ typedef struct {
     int64_t np_max;       /* capacity hint for particle work buffers (grown on demand) */
     int32_t paint_mode;   /* FPMHIP_PAINT_* */
     int32_t fft_mode;     /* FPMHIP_FFT_* */
+    int32_t gradient_mode; /* FPMHIP_GRADIENT_* */
 } fpmhip_geom;
 
 /* What struct PM exposes to the hot path (pmpfft.h:43-70, pmapi.h:3-9).  Real strides are in
@@ -175,6 +189,9 @@ int fpmhip_transfer(fpmhip_plan *plan, const void *delta_k_dev, void *out_dev, i
  * nranks > 1).  Falls back to 3 x (fpmhip_transfer + x pass) when the column FFT is not in use. */
 int fpmhip_transfer_fft_x_backward3(fpmhip_plan *plan, const void *delta_k_dev, void *out0_dev,
                                     void *out1_dev, void *out2_dev, int kernel);
+/* The COLUMN_POTENTIAL transfer (gravity.c:188-190) and the x pass of its inverse transform in one
+ * sweep; follow with fpmhip_fft_yz_backward and fpmhip_readout_grad (FPMHIP_GRADIENT_REAL). */
+int fpmhip_transfer_fft_x_backward_pot(fpmhip_plan *plan, const void *delta_k_dev, void *out_dev, int kernel);
 /* 1 if the staged FFT entry points (fft_yz_*, fft_x_*) work for this plan (always for nranks > 1;
  * for nranks == 1 only with the column-FFT back end) */
 int fpmhip_plan_staged_fft(const fpmhip_plan *plan);
@@ -185,6 +202,13 @@ int fpmhip_readout3(fpmhip_plan *plan, const fpmhip_particles *p_dev,
                     const void *mesh0_dev, const void *mesh1_dev, const void *mesh2_dev);
 int fpmhip_readout1(fpmhip_plan *plan, const fpmhip_particles *p_dev, const void *mesh_dev,
                     float *out_dev, int nmemb, int memb);
+/* The three COLUMN_ACC readouts from ONE mesh, the potential (FPMHIP_FIELD_POTENTIAL transfer ->
+ * c2r): acc[i][d] = sum over CIC corners of W * G_d(corner), G_d the 4-point central difference
+ * whose transform is i k_finite (pmapi.c:252-262), i.e. the gradient of gravity.c:21-64 for
+ * gradorder = 1 applied in real space (see FPMHIP_GRADIENT_REAL).  halo_dev: nranks > 1 only,
+ * four planes [-2, -1, xl+1, xl+2] of the potential from the neighbour slabs. */
+int fpmhip_readout_grad(fpmhip_plan *plan, const fpmhip_particles *p_dev, const void *phi_dev,
+                        const void *halo_dev);
 
 /* ---- what the caller does next with delta_k (solver.c:471-473) ---- */
 /* fastpm_apply_decic_transfer (transfer.c:77-113) */

@@ -66,6 +66,7 @@ void orc_paint_##SUF(const orc_geom *g, F *canvas, const double *x, const float 
                      double M0, int64_t np); \
 void orc_readout_##SUF(const orc_geom *g, const F *canvas, const double *x, int64_t np, \
                        float *out, int nmemb, int memb, int accumulate, double *out_f64); \
+void orc_readout_grad_##SUF(const orc_geom *g, const F *phi, const double *x, int64_t np, float *out); \
 void orc_scale_##SUF(F *buf, int64_t n, double value); \
 void orc_laplace_##SUF(const orc_geom *g, const F *from, F *to, int order); \
 void orc_grad_##SUF(const orc_geom *g, const F *from, F *to, int dir, int order); \

@@ -167,6 +167,15 @@ class PMOracle:
                             ctypes.c_int(int(accumulate)), _p(out_f64))
         return out
 
+    def readout_grad(self, phi, x):
+        """Checker for the GPU library's FPMHIP_GRADIENT_REAL mode (not reference code): acc from the
+        potential mesh through the 4-point stencil; one rank only."""
+        assert self.nproc == (1, 1)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.zeros((len(x), 3), dtype=np.float32)
+        self._fn("readout_grad")(ctypes.byref(self.g), _p(phi), _p(x), ctypes.c_int64(len(x)), _p(out))
+        return out
+
     def scale(self, buf, value):
         self._fn("scale")(_p(buf), ctypes.c_int64(buf.size), ctypes.c_double(value))
 
@@ -288,7 +297,7 @@ def total_mass(x, mass, M0):
 
 
 def compute_force(pm, x, mass=None, M0=1.0, kernel=KERNELS["1_4"], softening=0, potential=False,
-                  keep=False):
+                  keep=False, gradient="kspace"):
     """fastpm_solver_compute_force (gravity.c:458-529) on ONE rank (no ghosts: pmghosts.c:67
     `rank == ThisTask` always).  Returns dict(acc float32 [np][3], delta_k, ...)."""
     assert pm.nproc == (1, 1)
@@ -303,6 +312,17 @@ def compute_force(pm, x, mass=None, M0=1.0, kernel=KERNELS["1_4"], softening=0, 
     delta_k = pm.r2c(canvas)                                # gravity.c:351
     pm.softening(delta_k, softening)                        # gravity.c:476
     res["delta_k"] = delta_k
+    if gradient == "real" and kernel_orders(kernel)[1] == 1:
+        # the library's FPMHIP_GRADIENT_REAL mode (NOT the reference's arithmetic): potential -> c2r ->
+        # stencil readout.  The default gradient="kspace" below is the reference's.
+        pm.kernel_transfer(kernel, delta_k, canvas, potential=True)
+        pm.c2r(canvas)
+        res["acc"] = pm.readout_grad(canvas, x)
+        if potential:
+            pot = np.zeros((len(x), 1), dtype=np.float32)
+            pm.readout(canvas, x, out=pot, nmemb=1, memb=0)
+            res["potential"] = pot[:, 0]
+        return res
     acc = np.zeros((len(x), 3), dtype=np.float32)
     acc64 = np.zeros((len(x), 3), dtype=np.float64)
     for d in range(3):                                      # gravity.c:373-397

@@ -99,6 +99,44 @@ void FN(orc_readout)(const orc_geom *g, const F *canvas, const double *x, int64_
     }
 }
 
+/* NOT a restatement of reference code: the checker for this repository's FPMHIP_GRADIENT_REAL mode
+ * (include/fastpm_hip.h).  The reference takes the gradient in k space, i k_finite(w) with
+ * k_finite = (8 sin w - sin 2w) / (6 h) (pmapi.c:252-262, gravity.c:21-64); its real-space form is the
+ * 4-point central difference G_d(c) = (8 (phi(c+e_d) - phi(c-e_d)) - (phi(c+2e_d) - phi(c-2e_d))) / (12 h).
+ * acc[i][d] = (float) sum over CIC corners (order and weights as orc_readout) of W * G_d(corner), G in
+ * double.  One rank, periodic in all three axes.  tests/ compare it BOTH with the GPU's real mode
+ * (tight) and with the k-space oracle orc_kernel_transfer -> c2r -> orc_readout (<= 2e-7 max|acc|). */
+void FN(orc_readout_grad)(const orc_geom *g, const F *phi, const double *x, int64_t np, float *out)
+{
+    const int N = (int) g->Nmesh;
+    const double inv12h = (1.0 / (g->BoxSize / g->Nmesh)) / 12.0;
+#define PHI(ix, iy, iz) ((double) phi[(int64_t) (((ix) % N + N) % N) * g->istrides[0] + \
+                                      (int64_t) (((iy) % N + N) % N) * g->istrides[1] + (((iz) % N + N) % N)])
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < np; i++) {
+        int I[3], I1[3];
+        double D[3], T[3];
+        FN(cic_setup)(g, &x[3 * i], I, I1, D, T);
+        double value[3] = {0, 0, 0};
+        for (int c = 0; c < 8; c++) {
+            int b[3] = {(c >> 2) & 1, (c >> 1) & 1, c & 1};
+            int ci[3] = {I[0] + b[0], I[1] + b[1], I[2] + b[2]};
+            double wgt = (b[2] ? D[2] : T[2]) * (b[0] ? D[0] : T[0]) * (b[1] ? D[1] : T[1]);
+            for (int d = 0; d < 3; d++) {
+                int e[3] = {d == 0, d == 1, d == 2};
+                double p1 = PHI(ci[0] + e[0], ci[1] + e[1], ci[2] + e[2]);
+                double m1 = PHI(ci[0] - e[0], ci[1] - e[1], ci[2] - e[2]);
+                double p2 = PHI(ci[0] + 2 * e[0], ci[1] + 2 * e[1], ci[2] + 2 * e[2]);
+                double m2 = PHI(ci[0] - 2 * e[0], ci[1] - 2 * e[1], ci[2] - 2 * e[2]);
+                double G = (8 * (p1 - m1) - (p2 - m2)) * inv12h;
+                value[d] += G * wgt;
+            }
+        }
+        for (int d = 0; d < 3; d++) out[3 * i + d] = (float) value[d];
+    }
+#undef PHI
+}
+
 /* transfer.c:212-220 fastpm_apply_multiply_transfer over the whole allocsize (padding too);
  * also pmpfft.c:381-385 (to[i] *= 1 / Norm). */
 void FN(orc_scale)(F *buf, int64_t n, double value)

@@ -18,7 +18,8 @@ class _Layout:
 
 
 class CpuSlabOps:
-    def __init__(self, Nmesh, BoxSize, nranks, rank, precision=64):
+    def __init__(self, Nmesh, BoxSize, nranks, rank, precision=64, gradient_mode=0):
+        self.gradient_mode = gradient_mode
         N, P = int(Nmesh), int(nranks)
         assert N % P == 0
         self.Nmesh, self.BoxSize, self.nranks, self.rank, self.precision = N, float(BoxSize), P, rank, precision
@@ -48,9 +49,9 @@ class CpuSlabOps:
     def alloc(self):
         return torch.zeros(self.allocsize, dtype=self.dtype)
 
-    def plane(self, mesh, ix):
+    def plane(self, mesh, ix, n=1):
         pe = self.layout.plane_elems
-        return mesh[ix * pe:(ix + 1) * pe]
+        return mesh[ix * pe:(ix + n) * pe]
 
     def exchange_chunk_elems(self):
         return 2 * self.xl * self.yl * self.nzc
@@ -115,6 +116,33 @@ class CpuSlabOps:
                     value += m[ix[bx], iy[by], iz[bz]] * (W[bz][:, 2] * W[bx][:, 0] * W[by][:, 1])
         out.numpy().reshape(store.np, nmemb)[:, memb] = value.astype(np.float32)
 
+    def readout_grad(self, phi, store, halo=None):
+        """fpmhip_readout_grad: planes -2 .. xl+2 of the potential = [halo 0,1 | slab + its halo plane |
+        halo 2,3] (one rank: periodic wrap), 4-point stencil, CIC weights."""
+        N, xl = self.Nmesh, self.xl
+        m = self._real(phi)
+        if self.nranks == 1:
+            ext = np.concatenate([m[-2:], m, m[:3]], axis=0)
+        else:
+            h = halo.numpy().reshape(4, N, N + 2)
+            ext = np.concatenate([h[:2], m[:xl + 1], h[2:]], axis=0)     # index = local plane + 2
+        ext = ext[:, :, :N].astype(np.float64)
+        inv12h = (1.0 / (self.BoxSize / N)) / 12.0
+        ix, iy, iz, W = self._cic(store)
+        acc = np.zeros((store.np, 3))
+        yy = lambda a, o: np.mod(a + o, N)
+        for bx in (0, 1):
+            for by in (0, 1):
+                for bz in (0, 1):
+                    cx, cy, cz = ix[0] + bx + 2, iy[by], iz[bz]
+                    wgt = W[bz][:, 2] * W[bx][:, 0] * W[by][:, 1]
+                    gx = 8 * (ext[cx + 1, cy, cz] - ext[cx - 1, cy, cz]) - (ext[cx + 2, cy, cz] - ext[cx - 2, cy, cz])
+                    gy = 8 * (ext[cx, yy(cy, 1), cz] - ext[cx, yy(cy, -1), cz]) - (ext[cx, yy(cy, 2), cz] - ext[cx, yy(cy, -2), cz])
+                    gz = 8 * (ext[cx, cy, yy(cz, 1)] - ext[cx, cy, yy(cz, -1)]) - (ext[cx, cy, yy(cz, 2)] - ext[cx, cy, yy(cz, -2)])
+                    for d, gd in enumerate((gx, gy, gz)):
+                        acc[:, d] += gd * inv12h * wgt
+        store.acc.numpy()[...] = acc.astype(np.float32)
+
     # ---- decompose pieces
     def wrap(self, store):
         store.x.copy_(torch.from_numpy(O.store_wrap(store.x.numpy(), self.BoxSize)))
@@ -156,6 +184,10 @@ class CpuSlabOps:
         for d in range(3):
             self.gravity_apply_kernel_transfer(kernel, delta_k, outs[d], d)
             self.fft_x_backward(outs[d])
+
+    def transfer_fft_x_backward_pot(self, kernel, delta_k, out):
+        self.gravity_apply_kernel_transfer(kernel, delta_k, out, 3)
+        self.fft_x_backward(out)
 
     # ---- k space: the oracle's C functions on this rank's [x][y_loc][kz] block
     def apply_softening_transfer(self, softening, delta_k):

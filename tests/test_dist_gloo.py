@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, N, L, x, out_dir):
+def _worker(rank, world, port, N, L, x, out_dir, gradient_mode=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -34,7 +34,7 @@ def _worker(rank, world, port, N, L, x, out_dir):
     from fastpm_amd.pm import Store
     owner = (np.floor(x[:, 0] * (1.0 / (L / N))).astype(np.int64) % N) // (N // world)
     idx = np.nonzero(owner == rank)[0]
-    ops = CpuSlabOps(N, L, world, rank)
+    ops = CpuSlabOps(N, L, world, rank, gradient_mode=gradient_mode)
     store = Store(x[idx], potential=True, device="cpu")
     force = SlabForce(ops, dist.group.WORLD)
     dk = force.compute_force(store, kernel="1_4", dealias="gaussian")
@@ -62,6 +62,29 @@ def test_slab_force_over_gloo_matches_one_rank_oracle(oracle, tmp_path, world):
     dko = util.oracle_k_to_xyk(oracle.PMOracle(N, L, 64), ref["delta_k"])
     assert util.max_err(dk, dko) <= 1e-13
     assert util.rel_err(acc, ref["acc"]) <= 1e-6
+    assert util.rel_err(pot, ref["potential"]) <= 1e-6
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_slab_force_real_gradient_over_gloo(oracle, tmp_path, world):
+    """FPMHIP_GRADIENT_REAL on slabs: one transposed inverse FFT of the potential, the five halo planes
+    (xl into the canvas, -2, -1, xl+1, xl+2 into the side buffer), stencil readout.  Equal to the
+    one-rank real-gradient checker, and within 2e-7 max|acc| of the reference's k-space arithmetic."""
+    N, nc, L = 16, 8, 24.0
+    x = util.load_b(nc, L, N, rms_cells=2.0)
+    pm = oracle.PMOracle(N, L, 64)
+    ref = oracle.compute_force(pm, x, softening=oracle.SOFTENINGS["gaussian"], potential=True, gradient="real")
+    refk = oracle.compute_force(pm, x, softening=oracle.SOFTENINGS["gaussian"], potential=True)
+    mp.spawn(_worker, args=(world, _free_port(), N, L, x, str(tmp_path), 1), nprocs=world, join=True)
+    acc = np.zeros_like(ref["acc"])
+    pot = np.zeros_like(ref["potential"])
+    for r in range(world):
+        d = np.load(tmp_path / ("rank%d.npz" % r))
+        acc[d["idx"]] = d["acc"]
+        pot[d["idx"]] = d["pot"]
+    scale = np.abs(refk["acc"]).max()
+    assert np.abs(acc - ref["acc"]).max() <= 1.5e-7 * scale          # float32 last-bit flips only
+    assert np.abs(acc - refk["acc"]).max() <= 2e-7 * scale
     assert util.rel_err(pot, ref["potential"]) <= 1e-6
 
 

@@ -1,0 +1,126 @@
+"""FPMHIP_GRADIENT_REAL (include/fastpm_hip.h): ONE inverse FFT of the potential + a CIC readout that
+applies the 4-point central difference whose transform is the reference's i k_finite(w).  Checked
+(a) tightly against the CPU checker of the same arithmetic (oracle orc_readout_grad; float32 last-bit
+    flips from FFT round-off only: <= 1.5e-7 max|acc| on an fp64 mesh),
+(b) against the restated REFERENCE arithmetic (k-space gradient, three inverse FFTs): stated tolerance
+    2e-7 max|acc| on an fp64 mesh, 1e-5 on an fp32 mesh (differencing float32 potentials),
+(c) decomposition invariance: P virtual slabs on one GPU == one rank, to the same bound as (a),
+(d) delta_k equal to the k-space mode's (the forward half is shared; the LDS atomic adds of the paint
+    are unordered, so two runs agree to an ulp of the mesh dtype, not bit for bit)."""
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+# of max|acc|.  fp32 meshes: differencing float32 potentials costs precision that grows with the
+# potential's dynamic range (measured 6e-7 at 32^3, 2.5e-6 at 96^3): the mode is meant for fp64 meshes
+TOL_SAME = {64: 1.5e-7, 32: 1e-5}     # vs the checker of the same arithmetic
+TOL_REF = {64: 2e-7, 32: 1e-5}        # vs the reference's k-space arithmetic
+
+
+def _gpu_force(N, L, precision, x, kernel, gradient_mode, potential=False, mass=None, fft_mode=0, paint_mode=0):
+    import torch
+    from fastpm_amd import PM, Store
+    pm = PM(N, L, precision, gradient_mode=gradient_mode, fft_mode=fft_mode, paint_mode=paint_mode)
+    st = Store(x, mass=mass, potential=potential)
+    dk = pm.alloc()
+    pm.compute_force(st, kernel=kernel, softening="none", delta_k=dk)
+    torch.cuda.synchronize()
+    out = {"acc": st.acc.cpu().numpy(), "dk": dk.cpu().numpy()}
+    if potential:
+        out["pot"] = st.potential.cpu().numpy()
+    pm.destroy()
+    return out
+
+
+@pytest.mark.parametrize("precision", [64, 32])
+@pytest.mark.parametrize("load", ["a", "b", "c"])
+def test_real_gradient_force(oracle, precision, load):
+    N, nc, L = 64, 32, 96.0
+    x = {"a": lambda: util.load_a(nc, L, N), "b": lambda: util.load_b(nc, L, N), "c": lambda: util.load_c(nc, L)}[load]()
+    pmo = oracle.PMOracle(N, L, precision)
+    same = oracle.compute_force(pmo, x, gradient="real", potential=True)
+    ref = oracle.compute_force(pmo, x, potential=True)
+    g = _gpu_force(N, L, precision, x, "1_4", 1, potential=True)
+    gk = _gpu_force(N, L, precision, x, "1_4", 0)
+    scale = np.abs(ref["acc"]).max()
+    assert np.abs(g["acc"] - same["acc"]).max() <= TOL_SAME[precision] * scale
+    assert np.abs(g["acc"] - ref["acc"]).max() <= TOL_REF[precision] * scale
+    assert util.rel_err(g["pot"], ref["potential"]) <= (1e-6 if precision == 64 else 2e-5)
+    assert util.max_err(g["dk"], gk["dk"]) <= (1e-15 if precision == 64 else 5e-7)
+
+
+@pytest.mark.parametrize("kernel", ["3_4", "3_2", "5_4", "1_4", "1_4_diff0", "gadget", "eastwood", "naive"])
+def test_real_gradient_every_kernel_type(oracle, kernel):
+    """gradorder = 1 kernels take the stencil route; 3_2 / EASTWOOD / NAIVE (exact i k) silently keep the
+    reference's k-space route and stay bit-equal to the k-space mode."""
+    N, nc, L = 32, 16, 48.0
+    x = util.load_a(nc, L, N)
+    ref = oracle.compute_force(oracle.PMOracle(N, L, 64), x, kernel=oracle.KERNELS[kernel])
+    g = _gpu_force(N, L, 64, x, kernel, 1)
+    assert np.abs(g["acc"] - ref["acc"]).max() <= TOL_REF[64] * np.abs(ref["acc"]).max()
+    if kernel in ("3_2", "eastwood", "naive"):
+        assert np.array_equal(g["acc"], _gpu_force(N, L, 64, x, kernel, 0)["acc"])
+
+
+@pytest.mark.parametrize("fft_mode,paint_mode", [(1, 0), (0, 1), (1, 1)])
+def test_real_gradient_other_back_ends(oracle, fft_mode, paint_mode):
+    """rocFFT-only plans and the unbinned (global-atomics) particle path give the same accelerations."""
+    N, nc, L = 48, 24, 72.0
+    x = util.load_b(nc, L, N)
+    mass = np.random.default_rng(3).uniform(0, 1, len(x)).astype(np.float32)
+    same = oracle.compute_force(oracle.PMOracle(N, L, 64), x, mass=mass, gradient="real")
+    g = _gpu_force(N, L, 64, x, "1_4", 1, mass=mass, fft_mode=fft_mode, paint_mode=paint_mode)
+    assert np.abs(g["acc"] - same["acc"]).max() <= TOL_SAME[64] * np.abs(same["acc"]).max()
+
+
+@pytest.mark.parametrize("N,P", [(32, 2), (48, 4), (40, 2), (96, 3)])
+@pytest.mark.parametrize("precision", [64, 32])
+def test_real_gradient_virtual_slabs(oracle, N, P, precision):
+    import torch
+    from fastpm_amd import PM, Store
+    from fastpm_amd.distributed import SlabForce, run_virtual
+    nc, L = N // 2, 1.5 * N
+    x = util.load_b(nc, L, N)
+    same = oracle.compute_force(oracle.PMOracle(N, L, precision), x, gradient="real", potential=True)
+    owner = (np.floor(x[:, 0] * (1.0 / (L / N))).astype(np.int64) % N) // (N // P)
+    idx = [np.nonzero(owner == r)[0] for r in range(P)]
+    pms = [PM(N, L, precision, nranks=P, rank=r, gradient_mode=1) for r in range(P)]
+    stores = [Store(x[idx[r]], potential=True) for r in range(P)]
+    forces = [SlabForce(pm) for pm in pms]
+    run_virtual(forces, stores, kernel="1_4", dealias="none")
+    torch.cuda.synchronize()
+    assert all(f.real_gradient and f.work2 is None for f in forces)     # 2 mesh buffers fewer per rank
+    acc = np.zeros_like(same["acc"])
+    pot = np.zeros_like(same["potential"])
+    for r in range(P):
+        acc[idx[r]] = stores[r].acc.cpu().numpy()
+        pot[idx[r]] = stores[r].potential.cpu().numpy()
+    assert np.abs(acc - same["acc"]).max() <= TOL_SAME[precision] * np.abs(same["acc"]).max()
+    assert util.rel_err(pot, same["potential"]) <= (1e-6 if precision == 64 else 2e-5)
+    one = _gpu_force(N, L, precision, x, "1_4", 1)
+    assert np.abs(acc - one["acc"]).max() <= TOL_SAME[precision] * np.abs(same["acc"]).max()
+    for pm in pms:
+        pm.destroy()
+
+
+def test_lds_tiled_variant_is_bit_identical(oracle, monkeypatch):
+    """readout_grad_tiles_kernel (default) and the direct-gather readout_grad_kernel (FPMHIP_READOUT_GRAD=1)
+    share grad_cic: bit-identical accelerations."""
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path.insert(0, 'tests'); import util, torch;"
+            "from fastpm_amd import PM, Store;"
+            "x = util.load_b(24, 72.0, 48); pm = PM(48, 72.0, 64, gradient_mode=1); st = Store(x);"
+            "pm.compute_force(st, kernel='1_4'); torch.cuda.synchronize(); np.save(sys.argv[1], st.acc.cpu().numpy())")
+    import os
+    import tempfile
+    outs = []
+    for mode in ("1", "2"):
+        f = os.path.join(tempfile.mkdtemp(), "acc.npy")
+        env = dict(os.environ, FPMHIP_READOUT_GRAD=mode)
+        subprocess.run([sys.executable, "-c", code, f], check=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        outs.append(np.load(f))
+    assert np.array_equal(outs[0], outs[1])

@@ -232,3 +232,34 @@ def test_ghost_pairs_match_cic_window(oracle):
                     if r != rank:
                         exp.add((i, r))
         assert set(zip(ipar.tolist(), tgt.tolist())) == exp
+
+
+@pytest.mark.parametrize("kernel", ["1_4", "3_4", "5_4", "gadget"])
+def test_real_space_gradient_checker_equals_kspace_gradient(oracle, kernel):
+    """The 4-point central difference in real space IS the k-space gradient i k_finite(w),
+    k_finite = (8 sin w - sin 2w) / (6 h) (pmapi.c:252-262): the checker for the library's
+    FPMHIP_GRADIENT_REAL mode (oracle orc_readout_grad) against the restated reference arithmetic
+    (transfer -> c2r -> readout per component).  What is left is rounding: the reference rounds
+    k_finite to float32."""
+    N, nc, L = 32, 16, 48.0
+    x = util.load_b(nc, L, N, rms_cells=3.0)
+    pm = oracle.PMOracle(N, L, 64)
+    a = oracle.compute_force(pm, x, kernel=oracle.KERNELS[kernel])
+    b = oracle.compute_force(pm, x, kernel=oracle.KERNELS[kernel], gradient="real")
+    assert np.abs(a["acc"] - b["acc"]).max() <= 2e-7 * np.abs(a["acc"]).max()
+    assert np.array_equal(a["delta_k"], b["delta_k"])
+
+
+def test_real_space_gradient_of_a_plane_wave(oracle):
+    """KAT: phi = cos(k x) on the mesh -> acc_x at a mesh point = -sin(k x) k_finite-exactly, acc_y = acc_z = 0."""
+    N, L = 16, 16.0
+    pm = oracle.PMOracle(N, L, 64)
+    phi = pm.alloc()
+    ix = np.arange(N)
+    w = 2 * np.pi * 3 / N
+    pm.real_view(phi)[:, :, :N] = np.cos(w * ix)[:, None, None]
+    x = np.stack([ix.astype(np.float64), np.full(N, 5.0), np.full(N, 7.0)], axis=1)
+    acc = pm.readout_grad(phi, x)
+    kf = (8 * np.sin(w) - np.sin(2 * w)) / 6.0
+    assert np.allclose(acc[:, 0], -np.sin(w * ix) * kf, atol=1e-6)
+    assert np.abs(acc[:, 1:]).max() == 0
