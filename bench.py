@@ -91,18 +91,20 @@ def algorithmic_bytes(np_local, Nmesh, nranks, esize, gradient="kspace"):
         "transfer": 2 * s * nr,                          # K7
         "c2r": 2 * s * nr,                               # K8
         "readout": 3 * s * nr + 36 * np_local,           # K9 fused over the 3 components
-        "xback3": 4 * s * nr,                            # fused K7 x3 + x pass of K8 x3: 1 read, 3 writes
+        "xback3": 3 * s * nr,                            # fused K7 + x pass of K8 for the x component and the
+                                                         # potential: 1 read, 2 writes (4 s nr with FPMHIP_XBACK3=1)
         # single kernels (nested timers): one pass of the 3-pass FFT reads and writes the mesh once
         "k_colfft": 2 * s * nr, "k_rowfft": 2 * s * nr, "k_zc2r": 2 * s * nr,
+        "k_yback2": 3 * s * nr,                          # potential in, y and z components out
     }
 
 
 # which entries of the timing table are single GPU kernels (a roofline is quoted per kernel), and
 # the kernel each one is in the rocprofv3 trace
-KERNELS = {"paint": "fpm::paint_tiles_kernel", "readout": "fpm::readout_kernel", "xback3": "fpm::colfft_xback3_kernel",
-           "k_colfft": "fpm::colfft_kernel", "k_rowfft": "fpm::rowfft_r2c_kernel",
+KERNELS = {"paint": "fpm::paint_tiles_kernel", "readout": "fpm::readout3_tiles_kernel", "xback3": "fpm::colfft_xback3_kernel",
+           "k_colfft": "fpm::colfft_kernel", "k_rowfft": "fpm::rowfft_r2c_kernel", "k_yback2": "fpm::colfft_yback2_kernel",
            "k_zc2r": "rocFFT fft_rtc_back_len*_C2R (1-D c2r, z pass)", "transfer": "fpm::transfer_kernel"}
-STAGES_OF_KERNELS = {"k_colfft": "r2c/c2r", "k_rowfft": "r2c", "k_zc2r": "c2r"}
+STAGES_OF_KERNELS = {"k_colfft": "r2c/c2r", "k_rowfft": "r2c", "k_zc2r": "c2r", "k_yback2": "c2r"}
 
 
 
@@ -291,7 +293,7 @@ def main():
         value = np_total * args.steps / dt
         ab = algorithmic_bytes(np_local, Nmesh, world, esize, args.gradient)
         if args.gradient == "real":
-            KERNELS["readout"] = "fpm::readout_grad_kernel"
+            KERNELS["readout"] = "fpm::readout_grad_tiles_kernel"
         stages = {}
         for name, (ms, n) in tm.items():
             if n == 0:

@@ -279,8 +279,12 @@ __global__ __launch_bounds__(N / 8 * CW) void colfft_kernel(const C2<F> *__restr
 // 128 VGPRs so that two workgroups share a CU (measured 1.32 ms vs 1.46 ms at one per CU;
 // re-reading delta_k per component instead: 1.63 ms; HBM floor for 1 read + 3 writes in this
 // access pattern: 1.02 ms, tools/ubench/wr_pattern.hip).
-// POT: one output, the potential b itself (gravity.c:188-190) -- the real-space-gradient mode's x pass.
-template <int N, int R2, int R3, int R4, int CW, bool POT, typename F>
+// MODE 0: the three ACC components (o0, o1, o2).
+// MODE 1: one output, the potential b itself (gravity.c:188-190) -- the real-space-gradient mode's x pass.
+// MODE 2: two outputs, o0 = the x component and o1 = the potential: the y and z gradient factors depend
+//         on ky / kz only, commute with the x transform and are applied by colfft_yback2_kernel after the
+//         transpose -- one mesh less to write here and, on slabs, one all-to-all less.
+template <int N, int R2, int R3, int R4, int CW, int MODE, typename F>
 __global__ __launch_bounds__(N / 8 * CW, 4) void colfft_xback3_kernel(const C2<F> *__restrict__ dk, C2<F> *__restrict__ o0,
                                                              C2<F> *__restrict__ o1, C2<F> *__restrict__ o2,
                                                              long long rstride, int ncols, int nzc, int ystart,
@@ -328,9 +332,8 @@ __global__ __launch_bounds__(N / 8 * CW, 4) void colfft_xback3_kernel(const C2<F
         b[j].x = (F) (are * -1.0);
         b[j].y = (F) (aim * -1.0);
     }
-    C2<F> *outs[3] = {o0, o1, o2};
 #pragma unroll 1
-    for (int dir = 0; dir < (POT ? 1 : 3); dir++) {
+    for (int dir = 0; dir < (MODE == 0 ? 3 : MODE); dir++) {
         C2<F> v[VMAX];
         // an opaque copy of tau per iteration: keeps the compiler from hoisting the table values,
         // flags and store addresses of all three iterations above the loop, where they would have
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(N / 8 * CW, 4) void colfft_xback3_kernel(const C2<F
             const int ix = tau_o + T * j;
             const double k_finite = dir == 0 ? kt[ix] : (dir == 1 ? kt[iy] : kt[iz]);
             const bool selfconj = yz_self && ix == (N - ix) % N;       // gravity.c:44-56
-            if (POT) {
+            if (MODE == 1 || (MODE == 2 && dir == 1)) {
                 v[j] = b[j];
             } else if (selfconj) {
                 v[j].x = 0;
@@ -355,10 +358,56 @@ __global__ __launch_bounds__(N / 8 * CW, 4) void colfft_xback3_kernel(const C2<F
         __syncthreads();
         fft_core<N, R2, R3, R4, +1, CW>(v, lds, tw, tau, c);
         if (live) {
-            C2<F> *dst = outs[dir];
+            C2<F> *dst = dir == 0 ? o0 : (dir == 1 ? o1 : o2);
             const unsigned toff_o = (unsigned) tau_o * (unsigned) rstride + (unsigned) col;
 #pragma unroll
             for (int j = 0; j < EPT; j++) (dst + j * jstride)[toff_o] = v[j];
+        }
+    }
+}
+
+// Backward y pass of the potential with the y and z gradient factors applied on the way in:
+//   out_y = IFFT_y( i kt[ky] a ),  out_z = IFFT_y( i kt[kz] a ),   a = IFFT_x(b) after the transpose,
+// with the rounding of gravity.c:58-60 applied to a:  ((F) (-a.im * k), (F) (a.re * k)).  One read of
+// the potential, two writes; the same factors (the float32 k_finite table) as transfer_kernel, applied
+// after the x transform instead of before it -- they do not depend on kx.  Rows = ky, columns = kz.
+template <int N, int R2, int R3, int R4, int CW, typename F>
+__global__ __launch_bounds__(N / 8 * CW, 4) void colfft_yback2_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ oy,
+                                                             C2<F> *__restrict__ oz, ColMap im, ColMap om,
+                                                             int ncols, int ntiles_per_batch, int ntiles,
+                                                             const float *__restrict__ kt,
+                                                             const double *__restrict__ tw_global)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    C2<F> *lds = (C2<F> *) smem;
+    C2<F> *tw = lds + N * CW;
+    constexpr int T = N / EPT;
+    const int c = threadIdx.x % CW, tau = threadIdx.x / CW;
+    const int tile = xcd_tile(blockIdx.x, ntiles);
+    const int batch = tile / ntiles_per_batch;
+    const int col = (tile % ntiles_per_batch) * CW + c;
+    const bool live = col < ncols;
+    C2<F> a[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; j++) a[j] = live ? in[col_addr(im, batch, tau + T * j, col)] : C2<F>{0, 0};
+    stage_twiddles(tw, tw_global, N);
+#pragma unroll 1
+    for (int dir = 1; dir < 3; dir++) {
+        C2<F> v[VMAX];
+        int tau_o = tau;                     // see colfft_xback3_kernel
+        asm volatile("" : "+v"(tau_o));
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+            const double k_finite = dir == 1 ? kt[tau_o + T * j] : kt[live ? col : 0];
+            v[j].x = (F) (-a[j].y * k_finite);
+            v[j].y = (F) (a[j].x * k_finite);
+        }
+        __syncthreads();
+        fft_core<N, R2, R3, R4, +1, CW>(v, lds, tw, tau, c);
+        if (live) {
+            C2<F> *dst = dir == 1 ? oy : oz;
+#pragma unroll
+            for (int j = 0; j < EPT; j++) dst[col_addr(om, batch, tau_o + T * j, col)] = v[j];
         }
     }
 }
@@ -530,6 +579,44 @@ int colfft_y_range(fpmhip_plan *p, int dir, const void *in, void *out, int chunk
 }
 
 template <typename F>
+static int yback2_launch(fpmhip_plan *p, const void *in, void *oy, void *oz, const ColMap &im, const ColMap &om,
+                         int nbatch, int ncols, int gradorder)
+{
+    StageTimer ktm(p, FPMHIP_T_K_YBACK2);
+    const int N = p->mg.N;
+    constexpr int CW = (sizeof(F) == 4) ? 16 : 8;
+    const bool wide = sizeof(F) == 4 && N <= 512;
+    const int cw = wide ? CW : 8;
+    const int tpb = (ncols + cw - 1) / cw;
+    const int ntiles = tpb * nbatch;
+    const size_t lds = (size_t) N * cw * sizeof(C2<F>) + (size_t) N * sizeof(C2<F>);
+    const float *kt = p->d_tab + gradorder * (size_t) N;
+#define CALL_Y2_W(n, r2, r3, r4, W)                                                                          \
+    FPM_TRY(set_lds(colfft_yback2_kernel<n, r2, r3, r4, W, F>, lds));                                        \
+    colfft_yback2_kernel<n, r2, r3, r4, W, F><<<ntiles, n / 8 * W, lds, p->stream>>>(                        \
+        (const C2<F> *) in, (C2<F> *) oy, (C2<F> *) oz, im, om, ncols, tpb, ntiles, kt, p->d_twiddle);
+#define CALL_Y2(n, r2, r3, r4)                                                                               \
+    if (wide) { CALL_Y2_W(n, r2, r3, r4, (n <= 512 ? CW : 8)) } else { CALL_Y2_W(n, r2, r3, r4, 8) }
+    COLFFT_DISPATCH(N, CALL_Y2)
+#undef CALL_Y2
+#undef CALL_Y2_W
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// backward y pass of the transposed potential -> the y and z force components (both [x_loc][y][kz])
+int colfft_yback2(fpmhip_plan *p, const void *in, void *oy, void *oz, int chunked, int gradorder)
+{
+    const MeshGeo &g = p->mg;
+    const long long plane = (long long) g.N * g.nzc;
+    ColMap natural{plane, 0, g.nzc, g.N};
+    ColMap chunks{(long long) g.yl * g.nzc, (long long) g.xl * g.yl * g.nzc, g.nzc, g.yl};
+    const ColMap &im = chunked ? chunks : natural;
+    return p->f64 ? yback2_launch<double>(p, in, oy, oz, im, natural, g.xl, g.nzc, gradorder)
+                  : yback2_launch<float>(p, in, oy, oz, im, natural, g.xl, g.nzc, gradorder);
+}
+
+template <typename F>
 static int rowfft_launch(fpmhip_plan *p, const void *in_, void *out_, int x0, int nx)
 {
     StageTimer ktm(p, FPMHIP_T_K_ROWFFT);
@@ -563,7 +650,7 @@ int rowfft_r2c_range(fpmhip_plan *p, const void *in, void *out, int x0, int nx)
 
 template <typename F>
 static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, void *o2, int potorder, int gradorder,
-                         bool pot)
+                         int mode)
 {
     const MeshGeo &g = p->mg;
     const int N = g.N;
@@ -582,7 +669,8 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
         (const C2<F> *) dk, (C2<F> *) o0, (C2<F> *) o1, (C2<F> *) o2, plane, (int) plane, g.nzc, g.ystart,  \
         ntiles, kk, kt, p->d_twiddle);
 #define CALL_X3_W(n, r2, r3, r4, W)                                                                          \
-    if (pot) { CALL_X3_P(n, r2, r3, r4, W, true) } else { CALL_X3_P(n, r2, r3, r4, W, false) }
+    if (mode == 1) { CALL_X3_P(n, r2, r3, r4, W, 1) } else if (mode == 2) { CALL_X3_P(n, r2, r3, r4, W, 2) }   \
+    else { CALL_X3_P(n, r2, r3, r4, W, 0) }
 #define CALL_X3(n, r2, r3, r4)                                                                               \
     if (wide) { CALL_X3_W(n, r2, r3, r4, (n <= 512 ? CW : 8)) } else { CALL_X3_W(n, r2, r3, r4, 8) }
     COLFFT_DISPATCH(N, CALL_X3)
@@ -595,14 +683,20 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
 
 int colfft_xback3(fpmhip_plan *p, const void *dk, void *o0, void *o1, void *o2, int potorder, int gradorder)
 {
-    return p->f64 ? xback3_launch<double>(p, dk, o0, o1, o2, potorder, gradorder, false)
-                  : xback3_launch<float>(p, dk, o0, o1, o2, potorder, gradorder, false);
+    return p->f64 ? xback3_launch<double>(p, dk, o0, o1, o2, potorder, gradorder, 0)
+                  : xback3_launch<float>(p, dk, o0, o1, o2, potorder, gradorder, 0);
 }
 
 int colfft_xback_pot(fpmhip_plan *p, const void *dk, void *out, int potorder)
 {
-    return p->f64 ? xback3_launch<double>(p, dk, out, out, out, potorder, 0, true)
-                  : xback3_launch<float>(p, dk, out, out, out, potorder, 0, true);
+    return p->f64 ? xback3_launch<double>(p, dk, out, out, out, potorder, 0, 1)
+                  : xback3_launch<float>(p, dk, out, out, out, potorder, 0, 1);
+}
+
+int colfft_xback_potx(fpmhip_plan *p, const void *dk, void *out_x, void *out_pot, int potorder, int gradorder)
+{
+    return p->f64 ? xback3_launch<double>(p, dk, out_x, out_pot, out_pot, potorder, gradorder, 2)
+                  : xback3_launch<float>(p, dk, out_x, out_pot, out_pot, potorder, gradorder, 2);
 }
 
 }  // namespace fpm

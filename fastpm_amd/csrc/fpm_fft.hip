@@ -228,6 +228,11 @@ int fpmhip_plan_staged_fft(const fpmhip_plan *p)
     return p->lay.nranks > 1 || p->own_fft;
 }
 
+int fpmhip_plan_column_fft(const fpmhip_plan *p)
+{
+    return p && p->own_fft ? 1 : 0;
+}
+
 int fpmhip_r2c(fpmhip_plan *p, void *canvas, void *delta_k)
 {
     if (!p || !canvas || !delta_k) FPM_FAIL(-1, "null argument");
@@ -328,6 +333,50 @@ int fpmhip_transfer_fft_x_backward3(fpmhip_plan *p, const void *delta_k, void *o
         FPM_TRY(fpmhip_fft_x_backward(p, o[d]));
     }
     return 0;
+}
+
+// The x ACC component and the POTENTIAL, each with the x pass of its inverse transform, from one read
+// of delta_k; fpmhip_fft_yz_backward_grad2 turns the (transposed) potential into the y and z components.
+int fpmhip_transfer_fft_x_backward_potx(fpmhip_plan *p, const void *delta_k, void *out_x, void *out_pot, int kernel)
+{
+    if (!p || !delta_k || !out_x || !out_pot) FPM_FAIL(-1, "null argument");
+    if (!fpmhip_plan_staged_fft(p)) FPM_FAIL(-1, "staged FFT needs nranks > 1 or the column-FFT back end");
+    int po, go, dfo, dc;
+    FPM_TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));
+    if (p->own_fft) {
+        StageTimer tm(p, FPMHIP_T_XBACK3);
+        return colfft_xback_potx(p, delta_k, out_x, out_pot, po, go);
+    }
+    FPM_TRY(fpmhip_transfer(p, delta_k, out_x, kernel, FPMHIP_FIELD_ACC_X));
+    FPM_TRY(fpmhip_fft_x_backward(p, out_x));
+    FPM_TRY(fpmhip_transfer(p, delta_k, out_pot, kernel, FPMHIP_FIELD_POTENTIAL));
+    return fpmhip_fft_x_backward(p, out_pot);
+}
+
+// recv = the potential after fpmhip_transfer_fft_x_backward_potx (and the all-to-all when nranks > 1):
+// out_y / out_z = the y / z ACC components in real space.  The gradient factors i k_finite[ky],
+// i k_finite[kz] (the float32 table of pmapi.c:234-275, rounding of gravity.c:58-60) are applied to the
+// x-transformed potential: they do not depend on kx, so this equals transfer -> c2r per component up
+// to the rounding of the mesh dtype.  Only for kernels with gradorder = 1: with the exact i k gradient
+// the reference's zeroing of the self-conjugate modes (gravity.c:44-56) is not a rounding-level detail.
+// nranks == 1: recv may be out_y (in place).
+int fpmhip_fft_yz_backward_grad2(fpmhip_plan *p, void *recv, void *out_y, void *out_z, int kernel)
+{
+    if (!p || !recv || !out_y || !out_z) FPM_FAIL(-1, "null argument");
+    if (!p->own_fft) FPM_FAIL(-1, "fft_yz_backward_grad2 needs the column-FFT back end");
+    int po, go, dfo, dc;
+    FPM_TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));
+    if (go != 1) FPM_FAIL(-1, "fft_yz_backward_grad2 is for kernels with gradorder = 1");
+    if (out_y == out_z) FPM_FAIL(-1, "out_y and out_z must differ");
+    if (p->lay.nranks > 1 && (recv == out_y || recv == out_z)) FPM_FAIL(-1, "recv and the outputs must differ when nranks > 1");
+    StageTimer tm(p, FPMHIP_T_C2R);
+    FPM_TRY(colfft_yback2(p, recv, out_y, out_z, p->lay.nranks > 1 ? 1 : 0, go));
+    {
+        StageTimer ktm(p, FPMHIP_T_K_ZC2R);
+        FPM_TRY(fft_exec(p, p->p_zc2r_ip, out_y, nullptr));
+    }
+    StageTimer ktm(p, FPMHIP_T_K_ZC2R);
+    return fft_exec(p, p->p_zc2r_ip, out_z, nullptr);
 }
 
 // The POTENTIAL transfer and the x pass of its inverse transform in one sweep (real-space-gradient mode).

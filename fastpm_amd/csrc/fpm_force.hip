@@ -111,7 +111,14 @@ int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets
 
     // the canvas is free again after the out-of-place r2c: it carries the x component
     void *f[3] = {canvas, p->buf[BUF_F1], p->buf[BUF_F2]};
-    if (p->own_fft) {
+    static const int three = getenv("FPMHIP_XBACK3") ? atoi(getenv("FPMHIP_XBACK3")) : 0;   // A/B
+    if (p->own_fft && go == 1 && !three) {
+        // one sweep over delta_k: the x component and the potential through their x passes; the y and
+        // z gradient factors are applied to the potential in its y pass (they do not depend on kx)
+        FPM_TRY(fpmhip_transfer_fft_x_backward_potx(p, delta_k, f[0], f[1], kernel));
+        FPM_TRY(fpmhip_fft_yz_backward(p, f[0], f[0]));
+        FPM_TRY(fpmhip_fft_yz_backward_grad2(p, f[1], f[1], f[2], kernel));
+    } else if (p->own_fft) {
         // one sweep over delta_k: the three transfers + the x pass of their inverse transforms
         FPM_TRY(fpmhip_transfer_fft_x_backward3(p, delta_k, f[0], f[1], f[2], kernel));
         for (int d = 0; d < 3; d++) FPM_TRY(fpmhip_fft_yz_backward(p, f[d], f[d]));

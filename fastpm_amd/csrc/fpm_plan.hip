@@ -294,7 +294,7 @@ int64_t fpmhip_exchange_chunk_elems(const fpmhip_plan *p)
 
 static const char *stage_names[FPMHIP_T_COUNT] = {"sort", "paint", "r2c", "dealias", "transfer",
                                                   "c2r", "readout", "halo", "pack", "xback3",
-                                                  "k_colfft", "k_rowfft", "k_zc2r"};
+                                                  "k_colfft", "k_rowfft", "k_zc2r", "k_yback2"};
 
 const char *fpmhip_timing_name(int stage)
 {

@@ -29,9 +29,10 @@ from .pm import FIELD_POTENTIAL, GRADIENT_REAL, KERNEL_TYPES, SOFTENING_TYPES, _
 class SlabForce:
     """fastpm_solver_compute_force for rank `pm.rank` of `pm.nranks` x-slabs (gravity.c:458-529)."""
 
-    def __init__(self, pm, group=None):
+    def __init__(self, pm, group=None, three_transposes=False):
         self.pm = pm
         self.group = group
+        self.three_transposes = three_transposes               # A/B: one transpose per ACC component
         self.P, self.rank = pm.nranks, pm.rank
         self.canvas = pm.alloc()
         self.work = pm.alloc()
@@ -76,10 +77,30 @@ class SlabForce:
             yield from self._real_gradient_force(store, kernel, delta_k)
             return
 
-        # gravity.c:373-397: per component transfer -> c2r.  The three transfers and the x passes
-        # come from ONE sweep over delta_k; then one transpose + (y,z) passes per component.
         if self.work2 is None:
             self.work2, self.force[1], self.force[2] = pm.alloc(), pm.alloc(), pm.alloc()
+        if _gradorder(kernel) == 1 and pm.column_fft() and not self.three_transposes:
+            # gravity.c:373-397 with TWO meshes through the transpose instead of three: the x component
+            # and the potential; the y and z gradient factors depend on ky / kz only, so they are applied
+            # to the potential after its x transform and transpose, in its y pass (same float32 factors)
+            pm.transfer_fft_x_backward_potx(kernel, delta_k, self.force[0], self.force[1])
+            yield ("alltoall_start", self.work, self.force[0], 0)
+            yield ("alltoall_start", self.work2, self.force[1], 1)
+            yield ("wait", 0)
+            pm.fft_yz_backward(self.work, self.force[0])               # overlaps the second transpose
+            yield ("wait", 1)
+            pm.fft_yz_backward_grad2(kernel, self.work2, self.force[1], self.force[2])
+            yield ("shift", [(pm.plane(f, 0), pm.plane(f, xl), -1) for f in self.force])
+            pm.readout3(self.force, store)
+            if store.potential is not None:                                   # gravity.c:487-492
+                f = self.force[0]
+                yield from self._backward(delta_k, kernel, FIELD_POTENTIAL, f)
+                yield ("shift", [(pm.plane(f, 0), pm.plane(f, xl), -1)])
+                pm.readout(f, store, store.potential, 1, 0)
+            return
+
+        # gravity.c:373-397: per component transfer -> c2r.  The three transfers and the x passes
+        # come from ONE sweep over delta_k; then one transpose + (y,z) passes per component.
         pm.transfer_fft_x_backward3(kernel, delta_k, self.force)
         # the transposes run on the collective's own stream: component d+1 is in flight over xGMI
         # while the (y,z) passes of component d run on the compute stream

@@ -76,7 +76,10 @@ SYMBOLS = {
     "fpmhip_transfer": (_I, [_P, _P, _P, _I, _I]),
     "fpmhip_transfer_fft_x_backward3": (_I, [_P, _P, _P, _P, _P, _I]),
     "fpmhip_plan_staged_fft": (_I, [_P]),
+    "fpmhip_plan_column_fft": (_I, [_P]),
     "fpmhip_transfer_fft_x_backward_pot": (_I, [_P, _P, _P, _I]),
+    "fpmhip_transfer_fft_x_backward_potx": (_I, [_P, _P, _P, _P, _I]),
+    "fpmhip_fft_yz_backward_grad2": (_I, [_P, _P, _P, _P, _I]),
     "fpmhip_readout3": (_I, [_P, ctypes.POINTER(Particles), _P, _P, _P]),
     "fpmhip_readout1": (_I, [_P, ctypes.POINTER(Particles), _P, _P, _I, _I]),
     "fpmhip_readout_grad": (_I, [_P, ctypes.POINTER(Particles), _P, _P]),
@@ -109,7 +112,7 @@ SYMBOLS = {
 }
 
 TIMING_STAGES = ["sort", "paint", "r2c", "dealias", "transfer", "c2r", "readout", "halo", "pack", "xback3",
-                 "k_colfft", "k_rowfft", "k_zc2r"]
+                 "k_colfft", "k_rowfft", "k_zc2r", "k_yback2"]
 
 
 def library_path():

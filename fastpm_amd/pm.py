@@ -448,10 +448,23 @@ class PM:
     def staged_fft(self):
         return bool(self._L.fpmhip_plan_staged_fft(self._plan))
 
+    def column_fft(self):
+        return bool(self._L.fpmhip_plan_column_fft(self._plan))
+
     def transfer_fft_x_backward3(self, kernel, delta_k, outs):
         """The three ACC transfers + the x pass of their inverse FFTs from one read of delta_k."""
         check(self._L.fpmhip_transfer_fft_x_backward3(self._plan, _ptr(delta_k), _ptr(outs[0]), _ptr(outs[1]),
                                                       _ptr(outs[2]), _enum(KERNEL_TYPES, kernel)))
+
+    def transfer_fft_x_backward_potx(self, kernel, delta_k, out_x, out_pot):
+        """x ACC component + potential, each through the x pass of its inverse FFT (two-transpose form)."""
+        check(self._L.fpmhip_transfer_fft_x_backward_potx(self._plan, _ptr(delta_k), _ptr(out_x), _ptr(out_pot),
+                                                          _enum(KERNEL_TYPES, kernel)))
+
+    def fft_yz_backward_grad2(self, kernel, recv, out_y, out_z):
+        """(transposed) potential -> y and z ACC components in real space."""
+        check(self._L.fpmhip_fft_yz_backward_grad2(self._plan, _ptr(recv), _ptr(out_y), _ptr(out_z),
+                                                   _enum(KERNEL_TYPES, kernel)))
 
     def transfer_fft_x_backward_pot(self, kernel, delta_k, out):
         """The POTENTIAL transfer + the x pass of its inverse FFT (real-space-gradient mode)."""

@@ -189,12 +189,26 @@ int fpmhip_transfer(fpmhip_plan *plan, const void *delta_k_dev, void *out_dev, i
  * nranks > 1).  Falls back to 3 x (fpmhip_transfer + x pass) when the column FFT is not in use. */
 int fpmhip_transfer_fft_x_backward3(fpmhip_plan *plan, const void *delta_k_dev, void *out0_dev,
                                     void *out1_dev, void *out2_dev, int kernel);
+/* Two-transpose form of the three COLUMN_ACC inverse transforms, for kernels with gradorder = 1 and the
+ * column-FFT back end (fpmhip_plan_staged_fft): out_x = IFFT_x(transfer_x(delta_k)) and
+ * out_pot = IFFT_x(potential transfer) from one read of delta_k; then (after the all-to-all of EACH when
+ * nranks > 1) fpmhip_fft_yz_backward(out_x) and fpmhip_fft_yz_backward_grad2(out_pot -> y, z): the
+ * gradient factors i k_finite[ky], i k_finite[kz] (the same float32 table, the rounding of
+ * gravity.c:58-60) do not depend on kx and are applied after the x transform -- equal to
+ * transfer -> c2r per component up to the rounding of the mesh dtype; one mesh write less, and on slabs
+ * 3 all-to-alls per force instead of 4.  recv may be out_y when nranks == 1. */
+int fpmhip_transfer_fft_x_backward_potx(fpmhip_plan *plan, const void *delta_k_dev, void *out_x_dev,
+                                        void *out_pot_dev, int kernel);
+int fpmhip_fft_yz_backward_grad2(fpmhip_plan *plan, void *recv_dev, void *out_y_dev, void *out_z_dev, int kernel);
 /* The COLUMN_POTENTIAL transfer (gravity.c:188-190) and the x pass of its inverse transform in one
  * sweep; follow with fpmhip_fft_yz_backward and fpmhip_readout_grad (FPMHIP_GRADIENT_REAL). */
 int fpmhip_transfer_fft_x_backward_pot(fpmhip_plan *plan, const void *delta_k_dev, void *out_dev, int kernel);
 /* 1 if the staged FFT entry points (fft_yz_*, fft_x_*) work for this plan (always for nranks > 1;
  * for nranks == 1 only with the column-FFT back end) */
 int fpmhip_plan_staged_fft(const fpmhip_plan *plan);
+/* 1 if the hand-written column-FFT back end is in use (FPMHIP_FFT_AUTO and a supported Nmesh): the
+ * fused entry points fpmhip_transfer_fft_x_backward_potx / fpmhip_fft_yz_backward_grad2 need it */
+int fpmhip_plan_column_fft(const fpmhip_plan *plan);
 
 /* fastpm_readout_local (painter.c:358-374, painter-cic.c:113-190): one or three meshes.
  * readout3 writes acc[i][0..2]; readout1 writes out[i * nmemb + memb]. */
@@ -286,6 +300,7 @@ enum { FPMHIP_T_SORT = 0, FPMHIP_T_PAINT, FPMHIP_T_R2C, FPMHIP_T_DEALIAS, FPMHIP
        FPMHIP_T_K_COLFFT,    /* one column pass (x or y, either direction): colfft_kernel */
        FPMHIP_T_K_ROWFFT,    /* forward z pass: rowfft_r2c_kernel */
        FPMHIP_T_K_ZC2R,      /* backward z pass: rocFFT 1-D c2r */
+       FPMHIP_T_K_YBACK2,    /* colfft_yback2_kernel: potential -> y and z components, y pass (1 read, 2 writes) */
        FPMHIP_T_COUNT };
 int fpmhip_timing_enable(fpmhip_plan *plan, int on);
 int fpmhip_timing_reset(fpmhip_plan *plan);

@@ -185,6 +185,27 @@ class CpuSlabOps:
             self.gravity_apply_kernel_transfer(kernel, delta_k, outs[d], d)
             self.fft_x_backward(outs[d])
 
+    def column_fft(self):
+        return True
+
+    def transfer_fft_x_backward_potx(self, kernel, delta_k, out_x, out_pot):
+        self.gravity_apply_kernel_transfer(kernel, delta_k, out_x, 0)
+        self.fft_x_backward(out_x)
+        self.transfer_fft_x_backward_pot(kernel, delta_k, out_pot)
+
+    def fft_yz_backward_grad2(self, kernel, recv, out_y, out_z):
+        """fpmhip_fft_yz_backward_grad2: i k_finite[ky], i k_finite[kz] (float32 table) on the transposed,
+        x-transformed potential, then the (y, z) inverse transforms."""
+        N, xl, yl, nzc, P = self.Nmesh, self.xl, self.yl, self.nzc, self.nranks
+        assert O.kernel_orders(int(kernel))[1] == 1
+        kf = O.k_tables(N, self.BoxSize)["k_finite"].astype(np.float64)
+        r_ = self._cplx(recv, (P, xl, yl, nzc)).copy()
+        a = np.concatenate([r_[s] for s in range(P)], axis=1)            # [x_loc][y][kz]
+        for out, fac in ((out_y, kf[None, :, None]), (out_z, kf[None, None, :nzc])):
+            v = (1j * a * fac).astype(self.C)
+            out.zero_()
+            self._real(out)[:xl, :, :N] = scipy.fft.irfft2(v, s=(N, N), axes=(1, 2), norm="forward")
+
     def transfer_fft_x_backward_pot(self, kernel, delta_k, out):
         self.gravity_apply_kernel_transfer(kernel, delta_k, out, 3)
         self.fft_x_backward(out)

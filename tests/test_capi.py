@@ -28,7 +28,7 @@ def test_header_symbols_are_exported_and_bound():
 
 def test_struct_layouts_match_header_sizes():
     from fastpm_amd import lib
-    assert ctypes.sizeof(lib.Geom) == 48
+    assert ctypes.sizeof(lib.Geom) == 56      # + gradient_mode, padded to 8
     assert ctypes.sizeof(lib.Particles) == 48
     assert ctypes.sizeof(lib.Layout) == 8 + 8 + 16 + 9 * 8 + 16 + 9 * 8 + 24 + 8
 
