@@ -110,15 +110,17 @@ STAGES_OF_KERNELS = {"k_colfft": "r2c/c2r", "k_rowfft": "r2c", "k_zc2r": "c2r", 
 
 def pmc_traffic(stage, Nmesh, np_total, args, world):
     """HBM bytes per launch of `stage` from the committed PMC profile (rocprofv3 cannot run inside
-    the bench): profiles/r01_d_traffic.json (tools/pmc_traffic.py), only when the configuration matches
+    the bench): profiles/r01_e_<gradient>_traffic.json (tools/pmc_traffic.py, tools/profile_round.sh), only when the configuration matches
     the profiled one."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_d_traffic.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_e_%s_traffic.json" % args.gradient)))
         c = t["config"]
         if (c["nmesh"], c["particles"], c["precision"], c["n_gpus"]) != (Nmesh, np_total, args.precision, world):
             return None
-        if args.fft_mode != 0 or args.paint_mode != 0 or args.gradient != "kspace":
+        if args.fft_mode != 0 or args.paint_mode != 0 or c.get("gradient", "kspace") != args.gradient:
             return None
+        if any(os.environ.get(v) for v in ("FPMHIP_XBACK3", "FPMHIP_READOUT", "FPMHIP_READOUT_GRAD")):
+            return None                                   # A/B variants were not the profiled kernels
         return t["hbm_bytes_per_launch_by_stage"].get(stage)
     except Exception:
         return None

@@ -4,7 +4,7 @@ bench.py (one --kernel-trace --stats, one --pmc FETCH_SIZE, one --pmc WRITE_SIZE
 MI355X_MICROARCH.md prescribes).  HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: the
 x2 is the gfx950 FETCH_SIZE correction (128-B requests tallied at 64 B), confirmed on kernels whose
 reads are exactly one mesh.
-usage: pmc_traffic.py <trace.db> <fetch.db> <write.db> <tag> <nmesh> <particles> <precision> [outdir]"""
+usage: pmc_traffic.py <trace.db> <fetch.db> <write.db> <tag> <nmesh> <particles> <precision> [outdir [gradient]]"""
 import json
 import os
 import sqlite3
@@ -46,15 +46,17 @@ def main():
     stage = {
         "sort": add(hbm("bin_kernel<false>"), hbm("bin_kernel<true>")),
         "paint": hbm("paint_tiles"),
-        "readout": hbm("readout_kernel"),
+        "readout": hbm("readout3_tiles") or hbm("readout_grad_tiles") or hbm("readout_kernel") or hbm("readout_grad_kernel"),
         "xback3": hbm("xback3"),
+        "k_yback2": hbm("yback2"),
         "k_colfft": hbm("colfft_kernel<%s" % N),
         "k_rowfft": hbm("rowfft_r2c"),
         "k_zc2r": hbm("C2R"),
         "transfer": hbm("transfer_kernel"),
     }
+    gradient = sys.argv[9] if len(sys.argv) > 9 else "kspace"
     out = {"config": {"nmesh": int(nmesh), "particles": int(npart), "precision": int(prec), "n_gpus": 1,
-                      "fft": "column passes + rocFFT z"},
+                      "fft": "column passes + rocFFT z", "gradient": gradient},
            "method": __doc__.split("usage")[0].strip(),
            "hbm_bytes_per_launch_by_stage": {k: v for k, v in stage.items() if v is not None},
            "kernels": kern}
