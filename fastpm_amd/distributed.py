@@ -26,17 +26,54 @@ import torch.distributed as dist
 from .pm import FIELD_POTENTIAL, GRADIENT_REAL, KERNEL_TYPES, SOFTENING_TYPES, _enum
 
 
-class SlabForce:
+class _SlabRank:
+    """One rank of a slab decomposition: executes the communication requests a `steps` generator yields
+    over torch.distributed (nccl = RCCL on the GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, pm, group=None):
+        self.pm = pm
+        self.group = group
+        self.P, self.rank = pm.nranks, pm.rank
+        self._pending = {}
+
+    def run(self, gen):
+        for req in gen:
+            self._communicate(req)
+
+    def _communicate(self, req):
+        kind = req[0]
+        g = self.group
+        if kind == "allreduce":
+            dist.all_reduce(req[1], op=dist.ReduceOp.SUM, group=g)
+        elif kind == "alltoall":
+            n = self.pm.exchange_chunk_elems() * self.P
+            dist.all_to_all_single(req[1][:n], req[2][:n], group=g)
+        elif kind == "alltoall_start":
+            n = self.pm.exchange_chunk_elems() * self.P
+            self._pending[req[3]] = dist.all_to_all_single(req[1][:n], req[2][:n], group=g, async_op=True)
+        elif kind == "wait":
+            self._pending.pop(req[1]).wait()
+        elif kind == "shift":
+            ops = []
+            for send, recv, direction in req[1]:
+                dst = (self.rank + direction) % self.P
+                src = (self.rank - direction) % self.P
+                ops.append(dist.P2POp(dist.isend, send, _global_rank(g, dst), group=g))
+                ops.append(dist.P2POp(dist.irecv, recv, _global_rank(g, src), group=g))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        else:
+            raise ValueError(kind)
+
+
+class SlabForce(_SlabRank):
     """fastpm_solver_compute_force for rank `pm.rank` of `pm.nranks` x-slabs (gravity.c:458-529)."""
 
     def __init__(self, pm, group=None, three_transposes=False):
-        self.pm = pm
-        self.group = group
+        super().__init__(pm, group)
         self.three_transposes = three_transposes               # A/B: one transpose per ACC component
-        self.P, self.rank = pm.nranks, pm.rank
         self.canvas = pm.alloc()
         self.work = pm.alloc()
-        self._pending = {}
         self.real_gradient = getattr(pm, "gradient_mode", 0) == GRADIENT_REAL
         self.work2 = None                                      # second transpose landing zone (overlap)
         self.force = [self.canvas, None, None]                 # canvas is free after the forward FFT
@@ -155,34 +192,81 @@ class SlabForce:
 
     # -- execution over torch.distributed -------------------------------------------------------
     def compute_force(self, store, kernel="1_4", dealias="none", delta_k=None):
-        for req in self.steps(store, kernel, dealias, delta_k):
-            self._communicate(req)
+        self.run(self.steps(store, kernel, dealias, delta_k))
         return delta_k if delta_k is not None else self.delta_k
 
-    def _communicate(self, req):
-        kind = req[0]
-        g = self.group
-        if kind == "allreduce":
-            dist.all_reduce(req[1], op=dist.ReduceOp.SUM, group=g)
-        elif kind == "alltoall":
-            n = self.pm.exchange_chunk_elems() * self.P
-            dist.all_to_all_single(req[1][:n], req[2][:n], group=g)
-        elif kind == "alltoall_start":
-            n = self.pm.exchange_chunk_elems() * self.P
-            self._pending[req[3]] = dist.all_to_all_single(req[1][:n], req[2][:n], group=g, async_op=True)
-        elif kind == "wait":
-            self._pending.pop(req[1]).wait()
-        elif kind == "shift":
-            ops = []
-            for send, recv, direction in req[1]:
-                dst = (self.rank + direction) % self.P
-                src = (self.rank - direction) % self.P
-                ops.append(dist.P2POp(dist.isend, send, _global_rank(g, dst), group=g))
-                ops.append(dist.P2POp(dist.irecv, recv, _global_rank(g, src), group=g))
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        else:
-            raise ValueError(kind)
+
+class Slab2LPT(_SlabRank):
+    """pm_2lpt_solve (pm2lpt.c:14-164) for rank `pm.rank` of `pm.nranks` x-slabs: the sequence of
+    pm.pm_2lpt_solve with every c2r / r2c split around its all-to-all and a halo-plane shift before each
+    readout (the reference creates ghosts instead, pm2lpt.c:35-36).  Particles must sit on the slab that
+    owns floor(x / h) (the lattice the caller fills, store.c:659-712, decomposed by x); a non-zero `shift`
+    would move them across slab edges and is not supported on slabs (decompose the shifted positions and
+    call with shift 0 instead)."""
+
+    def __init__(self, pm, group=None):
+        super().__init__(pm, group)
+        self.work = pm.alloc()
+        self.source, self.workspace = pm.alloc(), pm.alloc()
+        self.field = [pm.alloc() for _ in range(3)]
+
+    def _c2r(self, buf):
+        pm = self.pm
+        pm.fft_x_backward(buf)
+        yield ("alltoall", self.work, buf)
+        pm.fft_yz_backward(self.work, buf)
+
+    def _readout(self, mesh, store, column, memb):
+        pm = self.pm
+        xl = pm.layout.isize[0]
+        yield ("shift", [(pm.plane(mesh, 0), pm.plane(mesh, xl), -1)])
+        pm.readout(mesh, store, column, 3, memb)
+
+    def steps(self, store, delta_k, kernel="1_4"):
+        from .pm import fastpm_kernel_type_get_orders
+        pm = self.pm
+        potorder, gradorder, difforder, _ = fastpm_kernel_type_get_orders(kernel)      # pm2lpt.c:17-18
+        p = store
+        if p.dx1 is None:
+            p.dx1 = torch.zeros((p.np, 3), dtype=torch.float32, device=p.x.device)
+        if p.dx2 is None:
+            p.dx2 = torch.zeros((p.np, 3), dtype=torch.float32, device=p.x.device)
+        source, workspace, field = self.source, self.workspace, self.field
+        source.zero_()                                                                 # pm_alloc'ed fresh, :40-48
+        D1, D2 = (1, 2, 0), (2, 0, 1)
+        for d in range(3):                                                             # 1LPT, pm2lpt.c:62-87
+            pm.laplace(delta_k, workspace, potorder)
+            pm.diff(workspace, d, difforder)
+            yield from self._c2r(workspace)
+            yield from self._readout(workspace, p, p.dx1, d)
+        for d in range(3):                                                             # 2LPT, :90-96
+            pm.laplace(delta_k, field[d], potorder)
+            pm.diff(field[d], d, difforder)
+            pm.diff(field[d], d, difforder)
+            yield from self._c2r(field[d])
+        for d in range(3):                                                             # :98-106
+            pm.mesh_fma(source, field[D1[d]], field[D2[d]], 0)
+        for d in range(3):                                                             # :108-121
+            pm.laplace(delta_k, workspace, potorder)
+            pm.diff(workspace, D1[d], difforder)
+            pm.diff(workspace, D2[d], difforder)
+            yield from self._c2r(workspace)
+            pm.mesh_fma(source, workspace, workspace, 1)
+        pm.fft_yz_forward(source, self.work)                                           # :122-123 pm_r2c
+        yield ("alltoall", workspace, self.work)
+        pm.fft_x_forward(workspace)
+        source.copy_(workspace)
+        for d in range(3):                                                             # :125-141
+            pm.laplace(source, workspace, potorder)
+            pm.diff(workspace, d, difforder)
+            yield from self._c2r(workspace)
+            pm.mesh_scale(workspace, 3.0 / 7)
+            yield from self._readout(workspace, p, p.dx2, d)
+        if hasattr(pm, "invalidate_binning"):
+            pm.invalidate_binning()
+
+    def solve(self, store, delta_k, kernel="1_4"):
+        self.run(self.steps(store, delta_k, kernel))
 
 
 class SlabDecompose:
@@ -282,7 +366,12 @@ def run_virtual(forces, stores, kernel="1_4", dealias="none", delta_ks=None):
     P = len(forces)
     assert all(f.P == P for f in forces)
     delta_ks = delta_ks or [None] * P
-    gens = [f.steps(s, kernel, dealias, dk) for f, s, dk in zip(forces, stores, delta_ks)]
+    run_virtual_steps(forces, [f.steps(s, kernel, dealias, dk) for f, s, dk in zip(forces, stores, delta_ks)])
+
+
+def run_virtual_steps(forces, gens):
+    """The executor behind run_virtual, for any per-rank `steps` generators (SlabForce, Slab2LPT)."""
+    P = len(forces)
     while True:
         reqs = []
         for g in gens:

@@ -163,7 +163,7 @@ def pm_2lpt_solve(pm, delta_k, p, shift=(0.0, 0.0, 0.0), kernel="1_4"):
     the device: fills p.dx1 and p.dx2 (float [np][3]) from the linear density delta_k (k-space mesh in
     the plan's layout).  12 c2r + 1 r2c on the same operators as the force step."""
     if pm.nranks != 1:
-        raise FastPMHipError("pm_2lpt_solve: one rank only in this round")
+        raise FastPMHipError("pm_2lpt_solve is the one-rank form; use fastpm_amd.distributed.Slab2LPT on slabs")
     potorder, gradorder, difforder, _ = fastpm_kernel_type_get_orders(kernel)          # pm2lpt.c:17-18
     L = pm._L
     shift = (ctypes.c_double * 3)(*[float(v) for v in shift])
@@ -381,6 +381,19 @@ class PM:
 
     def readout(self, mesh, store, out, nmemb=1, memb=0):
         check(self._L.fpmhip_readout1(self._plan, ctypes.byref(store._c()), _ptr(mesh), _ptr(out), int(nmemb), int(memb)))
+
+    # ---- mesh operators of pm2lpt.c (transfer.c:115-186, pm2lpt.c:98-121)
+    def laplace(self, src, dst, order):
+        check(self._L.fpmhip_laplace(self._plan, _ptr(src), _ptr(dst), int(order)))
+
+    def diff(self, inplace, direction, order):
+        check(self._L.fpmhip_diff(self._plan, _ptr(inplace), int(direction), int(order)))
+
+    def mesh_fma(self, dst, a, b, mode):
+        check(self._L.fpmhip_mesh_fma(self._plan, _ptr(dst), _ptr(a), _ptr(b), int(mode)))
+
+    def mesh_scale(self, inplace, value):
+        check(self._L.fpmhip_mesh_scale(self._plan, _ptr(inplace), float(value)))
 
     def apply_decic_transfer(self, src, dst):
         check(self._L.fpmhip_decic(self._plan, _ptr(src), _ptr(dst)))

@@ -188,6 +188,25 @@ class CpuSlabOps:
     def column_fft(self):
         return True
 
+    # ---- pm2lpt.c's mesh operators
+    def laplace(self, src, dst, order):
+        getattr(O.lib(), "orc_laplace_" + self.suf)(ctypes.byref(self.g), O._p(src.numpy()), O._p(dst.numpy()), int(order))
+
+    def diff(self, inplace, direction, order):
+        a = inplace.numpy()
+        getattr(O.lib(), "orc_grad_" + self.suf)(ctypes.byref(self.g), O._p(a), O._p(a), int(direction), int(order))
+
+    def mesh_fma(self, dst, a, b, negative):
+        n = self.layout.real_elems
+        prod = a.numpy()[:n] * b.numpy()[:n]
+        if negative:
+            dst.numpy()[:n] -= prod
+        else:
+            dst.numpy()[:n] += prod
+
+    def mesh_scale(self, inplace, value):
+        inplace.numpy()[...] *= value
+
     def transfer_fft_x_backward_potx(self, kernel, delta_k, out_x, out_pot):
         self.gravity_apply_kernel_transfer(kernel, delta_k, out_x, 0)
         self.fft_x_backward(out_x)

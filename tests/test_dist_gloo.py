@@ -88,6 +88,56 @@ def test_slab_force_real_gradient_over_gloo(oracle, tmp_path, world):
     assert util.rel_err(pot, ref["potential"]) <= 1e-6
 
 
+def _lpt_worker(rank, world, port, N, L, q, dkx, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from cpu_slab_ops import CpuSlabOps
+    from fastpm_amd.distributed import Slab2LPT
+    from fastpm_amd.pm import Store
+    owner = (np.floor(q[:, 0] * (1.0 / (L / N))).astype(np.int64) % N) // (N // world)
+    idx = np.nonzero(owner == rank)[0]
+    ops = CpuSlabOps(N, L, world, rank)
+    dk = ops.alloc()
+    ops._cplx(dk, (N, ops.yl, ops.nzc))[...] = dkx[:, rank * ops.yl:(rank + 1) * ops.yl, :]
+    store = Store(q[idx], device="cpu")
+    Slab2LPT(ops, dist.group.WORLD).solve(store, dk, kernel="1_4")
+    np.savez(os.path.join(out_dir, "lpt%d.npz" % rank), idx=idx, dx1=store.dx1.numpy(), dx2=store.dx2.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_slab_2lpt_over_gloo_matches_one_rank_oracle(oracle, tmp_path):
+    """distributed.Slab2LPT (pm2lpt.c:14-164 on slabs: 12 transposed c2r, 1 r2c, 6 halo shifts) over gloo,
+    world_size 2, against the one-rank oracle."""
+    world, N, nc, L = 2, 16, 8, 24.0
+    pm = oracle.PMOracle(N, L, 64)
+    rng = np.random.default_rng(11)
+    cv = pm.alloc()
+    f = rng.normal(size=(N, N, N))
+    fk = np.fft.rfftn(f)
+    k1 = np.fft.fftfreq(N) * N
+    kx, ky, kz = np.meshgrid(k1, k1, k1[: N // 2 + 1], indexing="ij")
+    fk *= np.exp(-(kx ** 2 + ky ** 2 + kz ** 2) / (2 * 2.0 ** 2))
+    fk[0, 0, 0] = 0
+    f = np.fft.irfftn(fk, s=(N, N, N), axes=(0, 1, 2))
+    pm.real_view(cv)[:, :, :N] = 0.02 * f / f.std()
+    dk = pm.r2c(cv)
+    q = util.lattice(nc, L)
+    ref1, ref2 = oracle.pm_2lpt_solve(pm, dk, q, shift=(0.0, 0.0, 0.0), kernel=oracle.KERNELS["1_4"])
+    dkx = np.ascontiguousarray(util.oracle_k_to_xyk(pm, dk))
+    mp.spawn(_lpt_worker, args=(world, _free_port(), N, L, q, dkx, str(tmp_path)), nprocs=world, join=True)
+    dx1, dx2 = np.zeros_like(ref1), np.zeros_like(ref2)
+    for r in range(world):
+        d = np.load(tmp_path / ("lpt%d.npz" % r))
+        dx1[d["idx"]] = d["dx1"]
+        dx2[d["idx"]] = d["dx2"]
+    assert util.rel_err(dx1, ref1) <= 1e-6
+    assert util.rel_err(dx2, ref2) <= 1e-6
+    assert np.abs(ref2).max() > 0
+
+
 def _decompose_worker(rank, world, port, N, L, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
