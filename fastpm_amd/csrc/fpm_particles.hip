@@ -101,9 +101,56 @@ __device__ __forceinline__ int wave_agg_inc(int *counters, int key, bool active)
     return slot;
 }
 
+// The same for the scatter pass, split in two so that no atomic's return value is waited for before
+// the next atomic is issued: issue() merges the lanes of a class that target the same cursor, the
+// group's first lane issues ONE returning atomicAdd and keeps the (pending) result in its own register;
+// every lane remembers its group's leader and its rank inside the group.  resolve() then fetches the
+// base from the leader's register.  A wave issues the atomics of all 8 corner classes back to back
+// (up to ~20 dependent round trips of ~1-2 us each before: 0.46 ms -> see DESIGN.md for the scatter pass).
+struct AggSlot {
+    int pend;     // leader lanes: the returned base (in flight until first use)
+    int leader;   // lane that holds my group's base
+    int rank;     // my position inside the group
+};
+
+__device__ __forceinline__ AggSlot wave_agg_issue(int *counters, int key, bool active)
+{
+    AggSlot a{0, 0, 0};
+    unsigned long long remaining = __ballot(active);
+    const int lane = __lane_id();
+    for (int round = 0; remaining && round < 6; round++) {
+        const int leader = __ffsll((long long) remaining) - 1;
+        const int k = __shfl(key, leader);
+        const bool mine = active && key == k;
+        const unsigned long long same = __ballot(mine);
+        if (lane == leader) a.pend = atomicAdd(&counters[k], __popcll(same));
+        if (mine) {
+            a.leader = leader;
+            a.rank = __popcll(same & ((1ull << lane) - 1ull));
+        }
+        remaining &= ~same;
+    }
+    if (remaining & (1ull << lane)) {
+        a.pend = atomicAdd(&counters[key], 1);
+        a.leader = lane;
+        a.rank = 0;
+    }
+    return a;
+}
+
+__device__ __forceinline__ int wave_agg_resolve(const AggSlot &a)
+{
+    return __shfl(a.pend, a.leader) + a.rank;
+}
+
 // Pass A / C of the counting sort.  SCATTER = false: count entries per tile (own tiles in
 // cnt[0, ntiles), dup tiles in cnt[ntiles, 2 ntiles)).  SCATTER = true: place the entries.
-template <bool SCATTER>
+// A thread takes PPT particles (block-strided, so a wave still reads 64 consecutive rows): all
+// position loads first, then all atomics, then all stores -- the kernel is a chain of dependent
+// memory round trips per wave, and PPT independent chains overlap them.
+constexpr int BIN_PPT = 2;
+
+template <bool SCATTER, int PPT>
 __global__ __launch_bounds__(256) void bin_kernel(MeshGeo g, int ntiles, const double *__restrict__ x,
                                                   const float *__restrict__ mass, long long np,
                                                   int *__restrict__ cnt_or_cur,
@@ -111,49 +158,77 @@ __global__ __launch_bounds__(256) void bin_kernel(MeshGeo g, int ntiles, const d
                                                   double *__restrict__ sz, float *__restrict__ smass,
                                                   int *__restrict__ sidx)
 {
-    long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    bool active = i < np;
-    double px = 0, py = 0, pz = 0;
-    float pm = 0;
-    int t0[3] = {0, 0, 0}, t1[3] = {0, 0, 0};
-    if (active) {
-        px = x[3 * i + 0];
-        py = x[3 * i + 1];
-        pz = x[3 * i + 2];
-        if (SCATTER && mass) pm = mass[i];
-        Cic c;
-        if (!cic_setup(g, px, py, pz, c)) {
-            // not this rank's particle: flagged in the last counter slot, reported by the host
-            if (!SCATTER) atomicAdd(&cnt_or_cur[2 * ntiles + 1], 1);
-            active = false;
-        }
-        t0[0] = c.i0[0] / TILE_X; t0[1] = c.i0[1] / TILE_Y; t0[2] = c.i0[2] / TILE_Z;
-        t1[0] = c.i1[0] / TILE_X; t1[1] = c.i1[1] / TILE_Y; t1[2] = c.i1[2] / TILE_Z;
-    }
-    // own tile
-    {
-        int key = tile_id(g, t0[0], t0[1], t0[2]);
-        int slot = wave_agg_inc<SCATTER>(cnt_or_cur, key, active);
-        if (SCATTER && active) {
-            sx[slot] = px; sy[slot] = py; sz[slot] = pz;
-            if (smass) smass[slot] = pm;
-            sidx[slot] = (int) i;
-        }
-    }
-    // the up to 7 other tiles the cloud touches
+    const long long i0 = (long long) blockIdx.x * (256 * PPT) + threadIdx.x;
+    double px[PPT], py[PPT], pz[PPT];
+    float pm[PPT];
+    bool active[PPT];
 #pragma unroll
-    for (int c = 1; c < 8; c++) {
-        const int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
-        bool need = active && (!bx || t1[0] != t0[0]) && (!by || t1[1] != t0[1]) && (!bz || t1[2] != t0[2]);
-        if (__ballot(need) == 0) continue;
-        int key = ntiles + tile_id(g, bx ? t1[0] : t0[0], by ? t1[1] : t0[1], bz ? t1[2] : t0[2]);
-        int slot = wave_agg_inc<SCATTER>(cnt_or_cur, key, need);
-        if (SCATTER && need) {
-            sx[slot] = px; sy[slot] = py; sz[slot] = pz;
-            if (smass) smass[slot] = pm;
-            sidx[slot] = (int) i;
+    for (int u = 0; u < PPT; u++) {
+        const long long i = i0 + u * 256;
+        active[u] = i < np;
+        px[u] = py[u] = pz[u] = 0;
+        pm[u] = 0;
+        if (active[u]) {
+            px[u] = x[3 * i + 0];
+            py[u] = x[3 * i + 1];
+            pz[u] = x[3 * i + 2];
+            if (SCATTER && mass) pm[u] = mass[i];
         }
     }
+    bool need[PPT][8];
+    int key[PPT][8];
+#pragma unroll
+    for (int u = 0; u < PPT; u++) {
+        int t0[3] = {0, 0, 0}, t1[3] = {0, 0, 0};
+        if (active[u]) {
+            Cic c;
+            if (!cic_setup(g, px[u], py[u], pz[u], c)) {
+                // not this rank's particle: flagged in the last counter slot, reported by the host
+                if (!SCATTER) atomicAdd(&cnt_or_cur[2 * ntiles + 1], 1);
+                active[u] = false;
+            }
+            t0[0] = c.i0[0] / TILE_X; t0[1] = c.i0[1] / TILE_Y; t0[2] = c.i0[2] / TILE_Z;
+            t1[0] = c.i1[0] / TILE_X; t1[1] = c.i1[1] / TILE_Y; t1[2] = c.i1[2] / TILE_Z;
+        }
+        // class 0: the own tile; classes 1..7: the up to 7 other tiles the cloud touches
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
+            need[u][c] = active[u] && (!bx || t1[0] != t0[0]) && (!by || t1[1] != t0[1]) && (!bz || t1[2] != t0[2]);
+            key[u][c] = (c ? ntiles : 0) + tile_id(g, bx ? t1[0] : t0[0], by ? t1[1] : t0[1], bz ? t1[2] : t0[2]);
+        }
+    }
+    if (!SCATTER) {
+#pragma unroll
+        for (int u = 0; u < PPT; u++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                if (__ballot(need[u][c]) == 0) continue;
+                (void) wave_agg_inc<false>(cnt_or_cur, key[u][c], need[u][c]);
+            }
+        return;
+    }
+    AggSlot a[PPT][8];
+#pragma unroll
+    for (int u = 0; u < PPT; u++)
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            a[u][c] = AggSlot{0, 0, 0};
+            if (__ballot(need[u][c]) == 0) continue;
+            a[u][c] = wave_agg_issue(cnt_or_cur, key[u][c], need[u][c]);
+        }
+#pragma unroll
+    for (int u = 0; u < PPT; u++)
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            if (__ballot(need[u][c]) == 0) continue;
+            const int slot = wave_agg_resolve(a[u][c]);
+            if (need[u][c]) {
+                sx[slot] = px[u]; sy[slot] = py[u]; sz[slot] = pz[u];
+                if (smass) smass[slot] = pm[u];
+                sidx[slot] = (int) (i0 + u * 256);
+            }
+        }
 }
 
 // XCD-aware block -> tile map: consecutive tiles (which share mesh rows in the readout) go to
@@ -593,7 +668,7 @@ int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt)
     // slot 2 * nt stays 0 (scan total lands there); slot 2 * nt + 1 counts unowned particles
     FPM_CHECK_HIP(hipMemsetAsync(p->tile_cnt, 0, (ncnt + 1) * sizeof(int), p->stream));
     if (np > 0)
-        bin_kernel<false><<<blocks_for(np, 256), 256, 0, p->stream>>>(p->mg, nt, pt->x, pt->mass, np, p->tile_cnt,
+        bin_kernel<false, BIN_PPT><<<blocks_for(np, 256 * BIN_PPT), 256, 0, p->stream>>>(p->mg, nt, pt->x, pt->mass, np, p->tile_cnt,
                                                                        nullptr, nullptr, nullptr, nullptr, nullptr);
     // exclusive scan of the 2 * ntiles counts (+1 slot -> grand total at off[2 * ntiles])
     size_t tmp_bytes = 0;
@@ -620,7 +695,7 @@ int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt)
 
     FPM_CHECK_HIP(hipMemcpyAsync(p->tile_cur, p->tile_off, ncnt * sizeof(int), hipMemcpyDeviceToDevice, p->stream));
     if (np > 0)
-        bin_kernel<true><<<blocks_for(np, 256), 256, 0, p->stream>>>(p->mg, nt, pt->x, pt->mass, np, p->tile_cur,
+        bin_kernel<true, BIN_PPT><<<blocks_for(np, 256 * BIN_PPT), 256, 0, p->stream>>>(p->mg, nt, pt->x, pt->mass, np, p->tile_cur,
                                                                       p->sx, p->sy, p->sz,
                                                                       pt->mass ? p->smass : nullptr, p->sidx);
     FPM_CHECK_HIP(hipGetLastError());
