@@ -1,0 +1,276 @@
+"""reference_run -- CPU restatement of what the reference's driver does AROUND the force path in its own
+regression test tests/lightcone.lua (run by tests/run-test-lightcone.sh, pinned by
+tests/run-test-lightcone.check): Gaussian IC with the reference's seeded generator -> remove cosmic variance
+-> induce correlation from tests/powerspec.txt -> 2LPT -> K D D F K steps with FASTPM kick/drift factors ->
+per-step "D^2(a, 1.0) P(k<...)" log line.
+
+TEST INFRASTRUCTURE ONLY.  Its purpose is to PIN the oracle (and, through tests/test_gpu_reference_log.py,
+the GPU library) against the golden numbers the reference's test suite holds: every operator on the force
+path (paint, r2c, transfer, c2r, readout) and the "next" rows (kick, drift, 2LPT, de-CIC, P(k)) sits between
+the seed and those log lines.  Everything here cites the reference file:line it restates; the RANLXD1
+generator (a GSL dependency absent from this image) is restated in ic_oracle.c.
+
+`ops` abstracts who executes the mesh / particle operators: OracleOps (this file, the CPU oracle) or the GPU
+adapter in tests/test_gpu_reference_log.py.
+"""
+import ctypes
+import os
+
+import numpy as np
+from scipy.integrate import quad
+
+from . import pm_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+# tests/run-test-lightcone.check, verbatim numbers (nc = 64, boxsize = 512, seed 100, Omega_m = 0.307494,
+# time_step = linspace(0.1, 1, 8), force_mode "fastpm", growth_mode "LCDM", pm_nc_factor 1, kernel 1_4)
+CHECK = {
+    "sigma8_input": "0.815897",
+    "dx1": ("5.36177", "5.36177", "5.36177", "5.36177"),
+    "dx2": ("0.455678", "0.44748", "0.453293", "0.45215"),
+    "plin": [("0.1", "17305.5"), ("0.228571", "17200.9"), ("0.357143", "17110"), ("0.485714", "17064.7"),
+             ("0.614286", "17043.4"), ("0.742857", "17028.1"), ("0.871429", "17014.2"), ("1", "17002.2")],
+}
+
+
+class Cosmology:
+    """libfastpm/cosmology.c for T_cmb = 0, no ncdm, w = -1, flat: HubbleEa :185-201, DHubbleEaDa :226-244,
+    D2HubbleEaDa2 :246-265, Omega_m :211-215, growth_mode LCDM :374-388, DGrowthFactorDa :403-427,
+    D2GrowthFactorDa2 :429-462."""
+
+    def __init__(self, Omega_m):
+        self.Om = Omega_m
+        self.OL = 1 - Omega_m                          # :48 with Omega_r = Omega_k = 0
+        self._g1 = self._growth_int(1.0)
+
+    def E(self, a):
+        return np.sqrt(self.Om / a ** 3 + self.OL)
+
+    def dEda(self, a):
+        return 0.5 / self.E(a) * (-3 * self.Om / a ** 4)
+
+    def d2Eda2(self, a):
+        E, dE = self.E(a), self.dEda(a)
+        return 0.5 / E * (12 * self.Om / a ** 5 - 2 * dE ** 2)
+
+    def Omega_m(self, a):
+        return self.Om / a ** 3 / self.E(a) ** 2
+
+    def _growth_int(self, a):                          # :267-299, qag epsrel 1e-9
+        f = lambda x: (x / (self.Om + (1 - self.Om - self.OL) * x + self.OL * x ** 3)) ** 1.5
+        return self.E(a) * quad(f, 0, a, epsrel=1e-11, epsabs=0)[0]
+
+    def growth(self, a):
+        """FastPMGrowthInfo in LCDM mode: D1, f1, D2, f2 (:379-387; note D2 > 0, the 3/7 sits in dx2)."""
+        Om = self.Omega_m(a)
+        D1 = self._growth_int(a) / self._g1
+        return {"a": a, "D1": D1, "f1": Om ** (5. / 9), "D2": D1 * D1 * (Om / self.Omega_m(1.0)) ** (-1. / 143),
+                "f2": 2 * Om ** (6. / 11)}
+
+    def dDda(self, a):                                 # :412-418
+        E = self.E(a)
+        return self.dEda(a) * self.growth(a)["D1"] / E + E * (a * E) ** -3 / self._g1
+
+    def d2Dda2(self, a):                               # :441-449
+        E, dE = self.E(a), self.dEda(a)
+        return self.d2Eda2(a) * self.growth(a)["D1"] / E - (dE + 3 / a * E) * (a * E) ** -3 / self._g1
+
+    # libfastpm/factors.c:198-231
+    def G_p(self, a):
+        return self.growth(a)["D1"]
+
+    def g_p(self, a):
+        return self.dDda(a)
+
+    def G_f(self, a):
+        return a ** 3 * self.E(a) * self.g_p(a)
+
+    def g_f(self, a):
+        E, dD = self.E(a), self.dDda(a)
+        return 3 * a * a * E * dD + a ** 3 * self.dEda(a) * dD + a ** 3 * E * self.d2Dda2(a)
+
+
+def _samples(ai, af, n=32):
+    i = np.arange(n)
+    return ai * (1.0 * (n - 1 - i) / (n - 1)) + af * (1.0 * i / (n - 1))
+
+
+def kick_tables(c, ai, ac, af):
+    """fastpm_kick_init, FASTPM force mode (factors.c:233-311): (dda, Dv1, Dv2) tables of 32 samples."""
+    gi = c.growth(ai)
+    Dv1i = gi["D1"] * ai * ai * c.E(ai) * gi["f1"]
+    Dv2i = gi["D2"] * ai * ai * c.E(ai) * gi["f2"]
+    dda, Dv1, Dv2 = [], [], []
+    for ae in _samples(ai, af):
+        ge = c.growth(ae)
+        dda.append(-1.5 * c.Omega_m(ac) * ac * c.E(ac) * (c.G_f(ae) - c.G_f(ai)) / c.g_f(ac))       # :295-298
+        Dv1.append(ge["D1"] * ae * ae * c.E(ae) * ge["f1"] - Dv1i)
+        Dv2.append(ge["D2"] * ae * ae * c.E(ae) * ge["f2"] - Dv2i)
+    return np.array(dda), np.array(Dv1), np.array(Dv2)
+
+
+def drift_tables(c, ai, ac, af):
+    """fastpm_drift_init, FASTPM force mode (factors.c:324-371): (dyyy, da1, da2)."""
+    gi = c.growth(ai)
+    dyyy, da1, da2 = [], [], []
+    for ae in _samples(ai, af):
+        ge = c.growth(ae)
+        dyyy.append(1 / (ac ** 3 * c.E(ac)) * (c.G_p(ae) - c.G_p(ai)) / c.g_p(ac))                   # :354-356
+        da1.append(ge["D1"] - gi["D1"])
+        da2.append(ge["D2"] - gi["D2"])
+    return np.array(dyyy), np.array(da1), np.array(da2)
+
+
+class PowerTable:
+    """fastpm_funck_init_from_string + fastpm_funck_eval (powerspectrum.c:347-425): bisection, log-log."""
+
+    def __init__(self, path=os.path.join(GOLDEN, "reference_tests_powerspec.txt")):
+        t = np.loadtxt(path)
+        self.k, self.f = t[:, 0].copy(), t[:, 1].copy()
+
+    def __call__(self, k):
+        k = np.asarray(k, dtype=np.float64)
+        out = np.ones_like(k)                                            # :396 k == 0 -> 1
+        nz = k != 0
+        kk = k[nz]
+        r = np.clip(np.searchsorted(self.k, kk, side="right"), 1, len(self.k) - 1)    # while (k < fk->k[m]) r = m
+        l = r - 1
+        lk = np.log(kk)
+        f = ((lk - np.log(self.k[l])) * np.log(self.f[r]) + (np.log(self.k[r]) - lk) * np.log(self.f[l])) \
+            / (np.log(self.k[r]) - np.log(self.k[l]))
+        out[nz] = np.exp(f)
+        return out
+
+    def sigma(self, R):
+        """fastpm_powerspectrum_sigma (powerspectrum.c:231-279)."""
+        def integrand(k):
+            kr = R * k
+            if kr < 1e-8:
+                return 0.0
+            w = 3 * (np.sin(kr) / kr ** 3 - np.cos(kr) / kr ** 2)
+            return 4 * np.pi * k * k * w * w * float(self(np.array([k]))[0]) / (2 * np.pi) ** 3
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return np.sqrt(quad(integrand, 0, 500.0 / R, limit=20000, epsrel=1e-8)[0])
+
+
+def initial_delta_k_xyk(N, BoxSize, seed, power, F=np.float64):
+    """src/fastpm.c:476-523 for lightcone.lua: fastpm_ic_fill_gaussiank (gadget scheme) ->
+    fastpm_ic_remove_variance (initialcondition.c:66-98) -> fastpm_ic_induce_correlation (:55-64, transfer.c:
+    188-210).  Returns complex [x][y][kz] in the mesh dtype's complex type, and the white-noise variance
+    (pm_compute_variance, the 'Variance of input white noise' log line)."""
+    C = np.complex128 if F == np.float64 else np.complex64
+    g = np.zeros((N, N, N // 2 + 1, 2))
+    O.lib().orc_fill_gaussian_gadget(int(N), int(seed), O._p(g))
+    wk = (g[..., 0].astype(F) + 1j * g[..., 1].astype(F)).astype(C)     # stored as FastPMFloat
+    a, b = wk.real.astype(np.float64), wk.imag.astype(np.float64)
+    phase = np.arctan2(b, a)
+    un = np.cos(phase) + 1j * np.sin(phase)
+    un[(a == 0) & (b == 0)] = 0
+    un = (un.real.astype(F) + 1j * un.imag.astype(F)).astype(C)
+    kk1 = O.k_tables(N, BoxSize)["kk"].astype(np.float64)
+    kk = kk1[:, None, None] + kk1[None, :, None] + kk1[None, None, : N // 2 + 1]
+    tr = np.sqrt(power(np.sqrt(kk))) * np.sqrt(1.0 / BoxSize ** 3)
+    out = ((un.real.astype(np.float64) * tr).astype(F) + 1j * (un.imag.astype(np.float64) * tr).astype(F)).astype(C)
+    return out
+
+
+def column_std(col):
+    """fastpm_store_summary(..., "s") (store.c:807-908): sqrt(<x^2> - <x>^2) per member, sums in double."""
+    a = np.asarray(col, dtype=np.float64)
+    return np.sqrt((a * a).mean(0) - a.mean(0) ** 2)
+
+
+def large_scale_power(k, p, nmodes, Nmax, k0):
+    """fastpm_powerspectrum_large_scale (powerspectrum.c:170-184)."""
+    kmax = Nmax * k0
+    num = den = 0.0
+    i = 0
+    while i == 0 or (i < len(k) and k[i] <= kmax):
+        num += p[i] * nmodes[i]
+        den += nmodes[i]
+        i += 1
+    return num / den
+
+
+class OracleOps:
+    """The operators of the run, executed by the CPU oracle."""
+
+    def __init__(self, N, BoxSize, precision=64, threads=8):
+        self.pm = O.PMOracle(N, BoxSize, precision, threads=threads)
+        self.N, self.L = N, BoxSize
+
+    def lpt(self, dk_xyk, q):
+        dk = self.pm.alloc()
+        self.pm.complex_view(dk)[...] = np.transpose(dk_xyk.astype(self.pm.C), (1, 2, 0))
+        return O.pm_2lpt_solve(self.pm, dk, q, shift=(0.0, 0.0, 0.0), kernel=O.KERNELS["1_4"])
+
+    def force(self, x):
+        """fastpm_do_force (solver.c:404-478): acc, then P(k) sums of the de-CIC'ed delta_k."""
+        r = O.compute_force(self.pm, x)
+        d = self.pm.alloc()
+        self.pm.decic(r["delta_k"], d)
+        return r["acc"], O.powerspectrum_finalize(*self.pm.powerspectrum_sums(d), self.L)
+
+    def kick(self, dda, acc, v):
+        return O.kick(O.FORCE_MODES["fastpm"], dda, 0.0, 0.0, 0.0, 0.0, acc, v)
+
+    def drift(self, dyyy, x, v):
+        return O.drift(O.FORCE_MODES["fastpm"], dyyy, 0.0, 0.0, 0.0, 0.0, x, v)
+
+    def wrap(self, x):
+        return O.store_wrap(x, self.L)
+
+
+def run_lightcone_test(ops, N=64, BoxSize=512.0, seed=100, Omega_m=0.307494, time_step=None, F=np.float64,
+                       nsteps=None):
+    """tests/lightcone.lua up to the quantities the .check file pins.  Returns a dict of log values."""
+    time_step = np.linspace(0.1, 1.0, 8) if time_step is None else np.asarray(time_step)
+    if nsteps is not None:
+        time_step = time_step[: nsteps + 1]
+    c = Cosmology(Omega_m)
+    power = PowerTable()
+    log = {"sigma8_input": power.sigma(8.0)}
+    dk = initial_delta_k_xyk(N, BoxSize, seed, power, F)
+    g = np.arange(N) * (BoxSize / N)                                     # store.c:659-712, shift = 0
+    q = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
+    dx1, dx2 = ops.lpt(dk, q)
+    log["dx1"], log["dx2"] = column_std(dx1), column_std(dx2)
+    a0 = float(time_step[0])
+    gi = c.growth(a0)                                                    # pm2lpt.c:168-210
+    Dv1 = gi["D1"] * a0 * a0 * c.E(a0) * gi["f1"]
+    Dv2 = gi["D2"] * a0 * a0 * c.E(a0) * gi["f2"]
+    x, v = O.pm_2lpt_evolve(q, np.zeros((len(q), 3), dtype=np.float32), dx1, dx2, gi["D1"], gi["D2"], Dv1, Dv2)
+    k0 = 2 * np.pi / BoxSize
+    log["plin"] = []
+
+    def force(a):
+        nonlocal x
+        x = ops.wrap(x)                                                  # fastpm_decompose: store_wrap, solver.c:577
+        acc, (k, p, nm) = ops.force(x)
+        D1 = c.growth(a)["D1"]
+        log["plin"].append((a, large_scale_power(k, p, nm, 4, k0) / D1 ** 2))     # src/fastpm.c:1736-1746
+        return acc
+
+    lookup = lambda tabs, ai, af, a: O.factor_lookup(ai, af, tabs, a)[0]
+    acc = force(a0)
+    for i in range(len(time_step) - 1):                                  # solver.c:289-296 K D D F K, timemachine.c:68-88
+        ai, af = float(time_step[i]), float(time_step[i + 1])
+        ac = float(np.exp(0.5 * np.log(ai) + 0.5 * np.log(af)))
+        t = kick_tables(c, ai, ai, ac)                                   # kick: a.i = a_v, a.r = force time, a.f
+        v = ops.kick(lookup(t, ai, ac, ac) - lookup(t, ai, ac, ai), acc, v)
+        t = drift_tables(c, ai, ac, ac)                                  # drift: a.r = a_v
+        x = ops.drift(lookup(t, ai, ac, ac) - lookup(t, ai, ac, ai), x, v)
+        t = drift_tables(c, ac, ac, af)
+        x = ops.drift(lookup(t, ac, af, af) - lookup(t, ac, af, ac), x, v)
+        acc = force(af)
+        t = kick_tables(c, ac, af, af)
+        v = ops.kick(lookup(t, ac, af, af) - lookup(t, ac, af, ac), acc, v)
+    return log
+
+
+def matches(value, text):
+    """Does `value` print as `text` under the reference's "%g" (6 significant digits)?"""
+    return ("%g" % value) == text

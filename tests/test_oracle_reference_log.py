@@ -1,0 +1,57 @@
+"""PIN: the CPU oracle against the golden numbers the reference's own regression test holds.
+
+tests/run-test-lightcone.check (reference) lists log lines that tests/lightcone.lua must print; the numbers
+below are copied from it (oracle/reference_run.py CHECK).  Between the random seed and those lines sits every
+operator of the force path -- CIC paint, normalisation, r2c, the k-space transfer, three c2r, CIC readout --
+and every "next" row -- 2LPT, kick, drift, wrap, de-CIC, the P(k) estimator -- over SEVEN full time steps
+to a = 1.  oracle/reference_run.py restates what the reference's driver does around them (GSL's RANLXD1
+generator and the gadget-scheme Gaussian field: oracle/ic_oracle.c; LCDM-mode growth; FASTPM kick/drift
+factor tables); the mesh and particle arithmetic is the oracle's (oracle/pm_oracle.c).  The input power
+spectrum table is the reference's data file tests/powerspec.txt, kept as a fixture.
+
+Every number must print, under the reference's "%g", exactly as the reference printed it."""
+import numpy as np
+import pytest
+
+from oracle import reference_run as R
+
+
+@pytest.fixture(scope="module")
+def log():
+    return R.run_lightcone_test(R.OracleOps(64, 512.0, 64))
+
+
+def test_input_table_sigma8(log):
+    assert len(R.PowerTable().k) == 1769                     # "Found 1769 pairs of values in input spectrum table"
+    assert R.matches(log["sigma8_input"], R.CHECK["sigma8_input"])
+
+
+def test_2lpt_displacement_dispersions(log):
+    """"dx1  : 5.36177 5.36177 5.36177 5.36177" and "dx2  : 0.455678 0.44748 0.453293 0.45215" (src/fastpm.c:
+    1650-1668): k tables, laplace and diff transfers, 12 c2r + 1 r2c, readout, store summary.  dx2 depends on
+    the phases of every mode, i.e. on the restated RANLXD1 stream and the gadget seed-table walk."""
+    for d in range(3):
+        assert R.matches(log["dx1"][d], R.CHECK["dx1"][d])
+        assert R.matches(log["dx2"][d], R.CHECK["dx2"][d])
+    assert R.matches(log["dx1"].mean(), R.CHECK["dx1"][3])
+    assert R.matches(log["dx2"].mean(), R.CHECK["dx2"][3])
+
+
+def test_large_scale_power_after_every_force_of_the_run(log):
+    """"D^2(a, 1.0) P(k<0.0490625) = ..." at a = 0.1 ... 1 (src/fastpm.c:1736-1746): the force step's delta_k
+    (paint, normalise, r2c), de-CIC, the P(k) estimator -- and, from the second line on, the accelerations of
+    all previous force calls through the FASTPM kick and drift factors."""
+    assert len(log["plin"]) == len(R.CHECK["plin"]) == 8
+    for (a, p), (atext, ptext) in zip(log["plin"], R.CHECK["plin"]):
+        assert R.matches(a, atext)
+        assert R.matches(p, ptext), (a, p, ptext)
+
+
+def test_ranlxd1_stream_is_a_uniform_48_bit_stream():
+    import ctypes
+    from oracle import pm_oracle as O
+    s = np.zeros(4096)
+    O.lib().orc_ranlxd1_stream(ctypes.c_ulong(100), len(s), O._p(s))
+    assert (s >= 0).all() and (s < 1).all()
+    assert np.all(s * 2.0 ** 48 == np.floor(s * 2.0 ** 48))          # 48-bit mantissas
+    assert abs(s.mean() - 0.5) < 0.02
