@@ -25,7 +25,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 class FlatLCDM:
     """E(a), growth D1 (normalised to 1 at a = 1) and the LCDM-mode second order growth
-    D2 = -3/7 D1^2 Omega_m(a)^(-1/143) (cf. factors.c:262-264), with logarithmic rates f1, f2."""
+    D2 = D1^2 (Omega_m(a) / Omega_m)^(-1/143) (cosmology.c:385), with logarithmic rates f1, f2."""
 
     def __init__(self, omega_m=0.3):
         self.om = omega_m
@@ -64,7 +64,8 @@ class FlatLCDM:
         return 3 * a * a * self.E(a) * self.g_p(a) + a ** 3 * self.dEda(a) * self.g_p(a) + a ** 3 * self.E(a) * d2
 
     def D2(self, a):
-        return -3.0 / 7 * self.D1(a) ** 2 * self.omega_a(a) ** (-1.0 / 143)
+        # cosmology.c:385 (LCDM mode): positive, without the 3/7 -- pm_2lpt_solve's dx2 carries it (pm2lpt.c:139)
+        return self.D1(a) ** 2 * (self.omega_a(a) / self.om) ** (-1.0 / 143)
 
     def f2(self, a):
         h = 1e-4 * a

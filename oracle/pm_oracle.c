@@ -1,7 +1,7 @@
 /*
  * pm_oracle.c -- CPU restatement of FastPM's particle-mesh force step (see pm_oracle.h).
  *
- * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see pm_oracle.h for why).
+ * TEST INFRASTRUCTURE ONLY; parity PINNED against the reference's check file (see pm_oracle.h).
  * Build: make -C oracle   (gcc -O2 -ffp-contract=off -fopenmp; no -ffast-math, so every
  * double/float operation rounds exactly where the C source says it does).
  */

@@ -5,11 +5,18 @@
  * call this.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
  * leg use it, and only as the checker / the timed CPU baseline.
  *
- * PARITY UNPINNED: the reference (fastpm/fastpm @ 2025-03-10) cannot be built
- * in this image (it needs GSL headers and PFFT 1.0.8-alpha3-fftw3, neither
- * vendored nor installed) and its tests hold no golden vectors for this path
- * in isolation (only end-to-end log greps that need the full binary).  This
- * restatement is therefore pinned only against analytic known-answer tests
+ * PARITY PINNED against the golden numbers of the reference's own regression
+ * test.  The reference (fastpm/fastpm @ 2025-03-10) cannot be built in this
+ * image (it needs GSL headers and PFFT 1.0.8-alpha3-fftw3, neither vendored
+ * nor installed), so there is no oracle/_ref; but its test suite pins the log
+ * lines of tests/lightcone.lua in tests/run-test-lightcone.check, and this
+ * oracle -- driven by oracle/reference_run.py, which restates the driver around
+ * the path, with GSL's RANLXD1 generator restated in oracle/ic_oracle.c --
+ * reproduces every one of them to the printed digit: the input sigma8, the
+ * 2LPT dispersions "dx1 : ..." and "dx2 : ...", and all eight
+ * "D^2(a, 1.0) P(k<...)" lines of the seven-step run to a = 1
+ * (tests/test_oracle_reference_log.py).  Every function below sits between
+ * the seed and those numbers.  Also checked: analytic known-answer tests
  * (tests/test_oracle_kat.py) and a second, independent numpy statement of the
  * same arithmetic (oracle/pm_oracle_np.py).
  *

@@ -4,9 +4,12 @@ pm_oracle.py -- Python driver of the CPU oracle for FastPM's PM force step.
 TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg may import this module; nothing under fastpm_amd/ does.
 
-PARITY UNPINNED: the reference cannot be built in this image (GSL and PFFT are
-missing) and holds no golden vectors for this path in isolation; see
-oracle/pm_oracle.h.  The arithmetic lives in oracle/pm_oracle.c (each function
+PARITY PINNED: the reference cannot be built in this image (GSL and PFFT are
+missing), but this oracle reproduces, to the printed digit, every golden log
+line the reference's own regression test pins (tests/run-test-lightcone.check:
+sigma8, dx1, dx2 and eight "D^2 P(k<)" lines over seven time steps) when driven
+by oracle/reference_run.py; see oracle/pm_oracle.h and
+tests/test_oracle_reference_log.py.  The arithmetic lives in oracle/pm_oracle.c (each function
 cites the reference file:line); this file strings the stages together in the
 order of libfastpm/gravity.c:458-529 and supplies the DFT, which the reference
 delegates to PFFT/FFTW (libfastpm/pmpfft.c:370-399) and we delegate to

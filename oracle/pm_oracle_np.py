@@ -1,8 +1,8 @@
 """
 pm_oracle_np.py -- a SECOND, independent statement of the force-step arithmetic in pure numpy.
 
-TEST INFRASTRUCTURE ONLY (see oracle/pm_oracle.h).  PARITY UNPINNED against the real reference
-(unbuildable here); this file exists so that the C oracle (oracle/pm_oracle.c) is checked by
+TEST INFRASTRUCTURE ONLY (see oracle/pm_oracle.h).  The C oracle is pinned against the reference's check file
+(tests/test_oracle_reference_log.py); this file exists so that the C oracle (oracle/pm_oracle.c) is checked by
 something other than itself: both were written separately from the reference text
 (file:line cited per function) and tests/test_oracle_cross.py requires them to agree --
 bit for bit where the operation order is fixed, to a few ulp where only the summation order differs.

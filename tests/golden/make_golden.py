@@ -3,8 +3,8 @@
 
 These are OUTPUTS OF THIS REPOSITORY'S CPU ORACLE (oracle/pm_oracle.c + scipy pocketfft), not of the
 reference: the reference cannot be built in this image (GSL / PFFT missing) and has no Python
-implementation to import, so there is nothing of the reference itself to record (parity unpinned,
-DESIGN.md section 5).  They serve two purposes: (1) freeze the oracle -- tests/test_golden.py requires
+implementation to import, so these vectors are not reference output (the oracle itself is pinned against the reference's
+check file by tests/test_oracle_reference_log.py).  They serve two purposes: (1) freeze the oracle -- tests/test_golden.py requires
 the oracle to reproduce them, so an accidental change of its arithmetic shows up; (2) let the GPU
 tests compare against committed data and not only against a live oracle build.
 
