@@ -178,6 +178,22 @@ def cpu_baseline(ncores, x_dev, Nmesh, BoxSize, acc_dev, pm):
                       "1/8-scale sweep: %s" % (len(x), Nmesh, dt, nth, ncores, ", ".join(tried))}
     parity = {"sample": "GPU vs CPU oracle on the full workload's particles",
               "pk_rel_err_max_to_half_nyquist": pk_err, "acc_max_err_over_rms": acc_err}
+    # the reference's own golden numbers (tests/run-test-lightcone.check): its 64^3 regression run with every
+    # mesh / particle operator executed by the GPU library, compared digit for digit
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from gpu_reference_ops import GpuOps
+        from oracle import reference_run as R
+        log = R.run_lightcone_test(GpuOps(64, 512.0, 64, pm.gradient_mode))
+        got = [R.matches(log["dx1"][d], R.CHECK["dx1"][d]) for d in range(3)]
+        got += [R.matches(log["dx2"][d], R.CHECK["dx2"][d]) for d in range(3)]
+        got += [R.matches(p, t[1]) for (a, p), t in zip(log["plin"], R.CHECK["plin"])]
+        parity["reference_check_file"] = {"lines_matched": "%d/%d" % (sum(got), len(got)),
+                                          "what": "dx1, dx2 dispersions and the 8 'D^2(a,1.0) P(k<0.0490625)' lines of the "
+                                                  "reference's tests/run-test-lightcone.check, printed with %g",
+                                          "P_large_scale": ["%g" % p for a, p in log["plin"]]}
+    except Exception as e:
+        parity["reference_check_file"] = {"lines_matched": None, "error": repr(e)}
     return base, parity
 
 
