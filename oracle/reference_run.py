@@ -29,6 +29,9 @@ CHECK = {
     "sigma8_input": "0.815897",
     "dx1": ("5.36177", "5.36177", "5.36177", "5.36177"),
     "dx2": ("0.455678", "0.44748", "0.453293", "0.45215"),
+    # second number of the same lines: sigma(8) of the MEASURED spectrum / D1^2; the reference integrates with
+    # GSL QAG at epsrel 1e-4 (powerspectrum.c:268), so only ~4 digits are integrator-independent
+    "sigma8_measured": [6.20821, 2.54189, 1.55758, 1.14191, 0.928101, 0.805797, 0.731205, 0.682708],
     "plin": [("0.1", "17305.5"), ("0.228571", "17200.9"), ("0.357143", "17110"), ("0.485714", "17064.7"),
              ("0.614286", "17043.4"), ("0.742857", "17028.1"), ("0.871429", "17014.2"), ("1", "17002.2")],
 }
@@ -177,6 +180,38 @@ def initial_delta_k_xyk(N, BoxSize, seed, power, F=np.float64):
     return out
 
 
+def measured_sigma(k, p, R=8.0):
+    """fastpm_powerspectrum_sigma (powerspectrum.c:231-279) of a MEASURED spectrum: fastpm_funck_eval on the bin
+    table (linear interpolation next to the empty k = 0 bin, log-log elsewhere and beyond the last bin)."""
+    k, p = np.asarray(k, dtype=np.float64), np.asarray(p, dtype=np.float64)
+
+    def ev(x):
+        if x == 0:
+            return 1.0
+        l, r = 0, len(k) - 1
+        while r - l > 1:
+            m = (r + l) // 2
+            if x < k[m]:
+                r = m
+            else:
+                l = m
+        k1, k2, f1, f2 = k[l], k[r], p[l], p[r]
+        if f1 <= 0 or f2 <= 0 or k1 == 0 or k2 == 0:
+            return ((x - k1) * f2 + (k2 - x) * f1) / (k2 - k1)
+        return np.exp(((np.log(x) - np.log(k1)) * np.log(f2) + (np.log(k2) - np.log(x)) * np.log(f1)) / (np.log(k2) - np.log(k1)))
+
+    def integrand(x):
+        kr = R * x
+        if kr < 1e-8:
+            return 0.0
+        w = 3 * (np.sin(kr) / kr ** 3 - np.cos(kr) / kr ** 2)
+        return 4 * np.pi * x * x * w * w * ev(x) / (2 * np.pi) ** 3
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return np.sqrt(quad(integrand, 0, 500.0 / R, limit=5000, epsrel=1e-7, points=list(k[1:]))[0])
+
+
 def column_std(col):
     """fastpm_store_summary(..., "s") (store.c:807-908): sqrt(<x^2> - <x>^2) per member, sums in double."""
     a = np.asarray(col, dtype=np.float64)
@@ -244,7 +279,7 @@ def run_lightcone_test(ops, N=64, BoxSize=512.0, seed=100, Omega_m=0.307494, tim
     Dv2 = gi["D2"] * a0 * a0 * c.E(a0) * gi["f2"]
     x, v = O.pm_2lpt_evolve(q, np.zeros((len(q), 3), dtype=np.float32), dx1, dx2, gi["D1"], gi["D2"], Dv1, Dv2)
     k0 = 2 * np.pi / BoxSize
-    log["plin"] = []
+    log["plin"], log["sigma8_measured"] = [], []
 
     def force(a):
         nonlocal x
@@ -252,6 +287,7 @@ def run_lightcone_test(ops, N=64, BoxSize=512.0, seed=100, Omega_m=0.307494, tim
         acc, (k, p, nm) = ops.force(x)
         D1 = c.growth(a)["D1"]
         log["plin"].append((a, large_scale_power(k, p, nm, 4, k0) / D1 ** 2))     # src/fastpm.c:1736-1746
+        log["sigma8_measured"].append(measured_sigma(k, p) / D1 ** 2)
         return acc
 
     lookup = lambda tabs, ai, af, a: O.factor_lookup(ai, af, tabs, a)[0]

@@ -27,6 +27,8 @@ def _check(log):
     assert len(log["plin"]) == 8
     for (a, p), (atext, ptext) in zip(log["plin"], R.CHECK["plin"]):
         assert R.matches(p, ptext), (a, p, ptext)
+    for got, ref in zip(log["sigma8_measured"], R.CHECK["sigma8_measured"]):      # all P(k) bins; QAG epsrel 1e-4
+        assert abs(got / ref - 1) < 3e-4, (got, ref)
 
 
 @pytest.mark.parametrize("precision,gradient_mode", [(64, 0), (64, 1), (32, 0)])

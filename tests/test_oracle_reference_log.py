@@ -47,6 +47,14 @@ def test_large_scale_power_after_every_force_of_the_run(log):
         assert R.matches(p, ptext), (a, p, ptext)
 
 
+def test_sigma8_of_the_measured_spectra(log):
+    """The second number of the same lines, "Sigma8 = ...": sigma(8 Mpc/h) of the MEASURED spectrum over D1^2 --
+    every P(k) bin up to the Nyquist frequency enters.  The reference integrates with GSL QAG at epsrel = 1e-4
+    (powerspectrum.c:268), so the comparison is to 3e-4, not to the printed digit."""
+    for got, ref in zip(log["sigma8_measured"], R.CHECK["sigma8_measured"]):
+        assert abs(got / ref - 1) < 3e-4, (got, ref)
+
+
 def test_ranlxd1_stream_is_a_uniform_48_bit_stream():
     import ctypes
     from oracle import pm_oracle as O
