@@ -181,6 +181,7 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
     L.precision = geom->precision;
     L.nranks = P;
     L.rank = geom->rank;
+    L.gradient_mode = geom->gradient_mode;
     L.ihalo = P > 1 ? 1 : 0;
     L.plane_elems = N * (N + 2);
     L.istart[0] = (int64_t) geom->rank * xl; L.istart[1] = 0; L.istart[2] = 0;
@@ -365,6 +366,13 @@ int fpmhip_memcpy_d2h(fpmhip_plan *p, void *dst, const void *src, size_t bytes)
 {
     FPM_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, p ? p->stream : 0));
     FPM_CHECK_HIP(hipStreamSynchronize(p ? p->stream : 0));
+    return 0;
+}
+
+int fpmhip_memcpy_d2d(fpmhip_plan *p, void *dst, const void *src, size_t bytes)
+{
+    if (!dst || !src) FPM_FAIL(-1, "null argument");
+    FPM_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, p ? p->stream : 0));
     return 0;
 }
 

@@ -1,0 +1,207 @@
+/*
+ * fastpm_slab_hip.c -- see fastpm_slab_hip.h.  The sequence is fastpm_amd/distributed.py::SlabForce.steps in
+ * C99, with blocking exchanges.
+ */
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "fastpm_slab_hip.h"
+
+#define TRY(expr) do { int rc_ = (expr); if (rc_ != 0) return rc_; } while (0)
+
+enum { B_CANVAS = 0, B_DELTA_K = 1, B_F0 = 2, B_F1 = 3, B_F2 = 4, B_XCHG = 5 };   /* fpmhip_plan_buffer ids */
+
+static int exchange(fpmhip_plan *plan, const fastpm_hip_transport *t, const void *send, void *recv, size_t chunk_bytes)
+{
+    TRY(fpmhip_sync(plan));
+    return t->alltoall(t->ctx, send, recv, chunk_bytes);
+}
+
+/* planes [ix, ix + n) of `mesh` to rank + dir, received from rank - dir into planes starting at recv */
+static int shift(fpmhip_plan *plan, const fastpm_hip_transport *t, void *mesh, int64_t ix, int n, void *recv, int dir,
+                 size_t plane_bytes)
+{
+    const int P = t->nranks;
+    TRY(fpmhip_sync(plan));
+    return t->sendrecv(t->ctx, fpmhip_plane_ptr(plan, mesh, ix), (t->rank + dir + P) % P, recv,
+                       (t->rank - dir + P) % P, (size_t) n * plane_bytes);
+}
+
+int fastpm_hip_slab_force(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *p,
+                          int kernel, int softening, void *delta_k)
+{
+    fpmhip_layout lay;
+    TRY(fpmhip_plan_layout(plan, &lay));
+    if (lay.nranks != t->nranks || lay.rank != t->rank) return -1;
+    int po, go, dfo, dc;
+    TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));
+    const int64_t xl = lay.isize[0];
+    const size_t esize = (size_t) lay.precision / 8;
+    const size_t plane_bytes = (size_t) lay.plane_elems * esize;
+    const size_t chunk_bytes = (size_t) fpmhip_exchange_chunk_elems(plan) * esize;
+    void *canvas = fpmhip_plan_buffer(plan, B_CANVAS), *work = fpmhip_plan_buffer(plan, B_XCHG);
+    if (!delta_k) delta_k = fpmhip_plan_buffer(plan, B_DELTA_K);
+    if (!canvas || !work || !delta_k) return -2;
+
+    /* gravity.c:330-345: total mass over all ranks, paint, normalise; the halo plane goes to rank + 1 */
+    double total = 0;
+    TRY(fpmhip_total_mass(plan, p, &total));
+    TRY(t->allreduce_sum(t->ctx, &total));
+    TRY(fpmhip_paint(plan, p, 1.0 / (total / lay.Norm), canvas));
+    void *tmp = work;                                           /* free until the forward transform */
+    TRY(shift(plan, t, canvas, xl, 1, tmp, +1, plane_bytes));
+    TRY(fpmhip_plane_add(plan, fpmhip_plane_ptr(plan, canvas, 0), tmp));
+
+    /* gravity.c:351 pm_r2c, gravity.c:476 softening */
+    TRY(fpmhip_fft_yz_forward(plan, canvas, work));
+    TRY(exchange(plan, t, work, delta_k, chunk_bytes));
+    TRY(fpmhip_fft_x_forward(plan, delta_k));
+    TRY(fpmhip_softening(plan, delta_k, softening));
+
+    if (lay.gradient_mode == FPMHIP_GRADIENT_REAL && go == 1) {
+        /* one transposed mesh, the potential; planes xl | xl+1, xl+2 from rank + 1, planes -2, -1 from rank - 1 */
+        if (xl < 3) return -3;
+        void *halo = fpmhip_plan_buffer(plan, B_F1);            /* 4 planes of side buffer */
+        void *phi = canvas;
+        TRY(fpmhip_transfer_fft_x_backward_pot(plan, delta_k, phi, kernel));
+        TRY(exchange(plan, t, phi, work, chunk_bytes));
+        TRY(fpmhip_fft_yz_backward(plan, work, phi));
+        TRY(shift(plan, t, phi, 0, 1, fpmhip_plane_ptr(plan, phi, xl), -1, plane_bytes));
+        TRY(shift(plan, t, phi, 1, 2, fpmhip_plane_ptr(plan, halo, 2), -1, plane_bytes));
+        TRY(shift(plan, t, phi, xl - 2, 2, halo, +1, plane_bytes));
+        TRY(fpmhip_readout_grad(plan, p, phi, halo));
+        if (p->potential) TRY(fpmhip_readout1(plan, p, phi, p->potential, 1, 0));   /* gravity.c:487-492 */
+        return 0;
+    }
+
+    void *f[3] = {canvas, fpmhip_plan_buffer(plan, B_F1), fpmhip_plan_buffer(plan, B_F2)};
+    void *work2 = fpmhip_plan_buffer(plan, B_F0);
+    if (!f[1] || !f[2] || !work2) return -2;
+    if (go == 1 && fpmhip_plan_column_fft(plan)) {
+        /* two meshes through the transpose: the x component and the potential (see fastpm_hip.h) */
+        TRY(fpmhip_transfer_fft_x_backward_potx(plan, delta_k, f[0], f[1], kernel));
+        TRY(exchange(plan, t, f[0], work, chunk_bytes));
+        TRY(exchange(plan, t, f[1], work2, chunk_bytes));
+        TRY(fpmhip_fft_yz_backward(plan, work, f[0]));
+        TRY(fpmhip_fft_yz_backward_grad2(plan, work2, f[1], f[2], kernel));
+    } else {
+        for (int d = 0; d < 3; d++) {                           /* gravity.c:373-397 */
+            TRY(fpmhip_transfer(plan, delta_k, f[d], kernel, d));
+            TRY(fpmhip_fft_x_backward(plan, f[d]));
+            TRY(exchange(plan, t, f[d], work, chunk_bytes));
+            TRY(fpmhip_fft_yz_backward(plan, work, f[d]));
+        }
+    }
+    for (int d = 0; d < 3; d++)
+        TRY(shift(plan, t, f[d], 0, 1, fpmhip_plane_ptr(plan, f[d], xl), -1, plane_bytes));
+    TRY(fpmhip_readout3(plan, p, f[0], f[1], f[2]));
+    if (p->potential) {                                         /* gravity.c:487-492 */
+        TRY(fpmhip_transfer(plan, delta_k, f[0], kernel, FPMHIP_FIELD_POTENTIAL));
+        TRY(fpmhip_fft_x_backward(plan, f[0]));
+        TRY(exchange(plan, t, f[0], work, chunk_bytes));
+        TRY(fpmhip_fft_yz_backward(plan, work, f[0]));
+        TRY(shift(plan, t, f[0], 0, 1, fpmhip_plane_ptr(plan, f[0], xl), -1, plane_bytes));
+        TRY(fpmhip_readout1(plan, p, f[0], p->potential, 1, 0));
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Loopback transport: ranks = threads of one process.  Each collective: publish my pointers, barrier, copy what
+ * I receive from the others' published send buffers (device-to-device on my plan's stream, then synchronise),
+ * barrier (nobody reuses a send buffer before everyone has read it).
+ */
+typedef struct {
+    int nranks;
+    pthread_barrier_t barrier;
+    const void **send;      /* [nranks] published send pointers */
+    int *dest;              /* [nranks] sendrecv destinations */
+    double *value;          /* [nranks] */
+    fpmhip_plan **plan;     /* [nranks] */
+} loop_shared;
+
+typedef struct { loop_shared *sh; int rank; } loop_ctx;
+
+static int loop_allreduce(void *c_, double *v)
+{
+    loop_ctx *c = c_;
+    loop_shared *s = c->sh;
+    s->value[c->rank] = *v;
+    pthread_barrier_wait(&s->barrier);
+    double sum = 0;
+    for (int r = 0; r < s->nranks; r++) sum += s->value[r];
+    pthread_barrier_wait(&s->barrier);
+    *v = sum;
+    return 0;
+}
+
+static int loop_alltoall(void *c_, const void *send, void *recv, size_t chunk)
+{
+    loop_ctx *c = c_;
+    loop_shared *s = c->sh;
+    int rc = 0;
+    s->send[c->rank] = send;
+    pthread_barrier_wait(&s->barrier);
+    for (int src = 0; src < s->nranks && rc == 0; src++)
+        rc = fpmhip_memcpy_d2d(s->plan[c->rank], (char *) recv + (size_t) src * chunk,
+                               (const char *) s->send[src] + (size_t) c->rank * chunk, chunk);
+    if (rc == 0) rc = fpmhip_sync(s->plan[c->rank]);
+    pthread_barrier_wait(&s->barrier);
+    return rc;
+}
+
+static int loop_sendrecv(void *c_, const void *send, int dest, void *recv, int source, size_t bytes)
+{
+    loop_ctx *c = c_;
+    loop_shared *s = c->sh;
+    s->send[c->rank] = send;
+    s->dest[c->rank] = dest;
+    pthread_barrier_wait(&s->barrier);
+    int rc = s->dest[source] == c->rank ? 0 : -1;
+    if (rc == 0) rc = fpmhip_memcpy_d2d(s->plan[c->rank], recv, s->send[source], bytes);
+    if (rc == 0) rc = fpmhip_sync(s->plan[c->rank]);
+    pthread_barrier_wait(&s->barrier);
+    return rc;
+}
+
+fastpm_hip_transport *fastpm_hip_loopback_create(int nranks)
+{
+    loop_shared *s = calloc(1, sizeof(*s));
+    s->nranks = nranks;
+    pthread_barrier_init(&s->barrier, NULL, (unsigned) nranks);
+    s->send = calloc((size_t) nranks, sizeof(*s->send));
+    s->dest = calloc((size_t) nranks, sizeof(*s->dest));
+    s->value = calloc((size_t) nranks, sizeof(*s->value));
+    s->plan = calloc((size_t) nranks, sizeof(*s->plan));
+    fastpm_hip_transport *t = calloc((size_t) nranks, sizeof(*t));
+    for (int r = 0; r < nranks; r++) {
+        loop_ctx *c = calloc(1, sizeof(*c));
+        c->sh = s;
+        c->rank = r;
+        t[r].ctx = c;
+        t[r].rank = r;
+        t[r].nranks = nranks;
+        t[r].allreduce_sum = loop_allreduce;
+        t[r].alltoall = loop_alltoall;
+        t[r].sendrecv = loop_sendrecv;
+    }
+    return t;
+}
+
+void fastpm_hip_loopback_bind(fastpm_hip_transport *t, fpmhip_plan *plan)
+{
+    loop_ctx *c = t->ctx;
+    c->sh->plan[c->rank] = plan;
+}
+
+void fastpm_hip_loopback_destroy(fastpm_hip_transport *all)
+{
+    if (!all) return;
+    loop_shared *s = ((loop_ctx *) all[0].ctx)->sh;
+    const int n = s->nranks;
+    for (int r = 0; r < n; r++) free(all[r].ctx);
+    pthread_barrier_destroy(&s->barrier);
+    free(s->send); free(s->dest); free(s->value); free(s->plan); free(s);
+    free(all);
+}

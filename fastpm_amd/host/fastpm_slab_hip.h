@@ -1,0 +1,52 @@
+/*
+ * fastpm_slab_hip.h -- C host side of the MI355X force step for NTask > 1 (x slabs, NprocY = 1).
+ *
+ * fastpm_solver_compute_force (gravity.c:458-529) needs three kinds of exchange between ranks; the caller
+ * supplies them as three functions on DEVICE pointers.  Inside libfastpm they are GPU-aware MPI calls on
+ * pm->Comm2D (INTEGRATION.md section 3 shows them); tests/test_gpu_chost.py plugs the in-process loopback
+ * transport declared at the end of this file.  No arithmetic happens on the host.
+ */
+#ifndef FASTPM_SLAB_HIP_H
+#define FASTPM_SLAB_HIP_H
+
+#include <stddef.h>
+#include "fastpm_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Blocking, MPI-like semantics: fastpm_hip_slab_force synchronises the plan's stream before each call, and
+ * on return the receive buffer must be complete (or ordered before later work on the plan's stream).
+ * Every function returns 0 on success. */
+typedef struct {
+    void *ctx;
+    int rank, nranks;
+    /* MPI_Allreduce(MPI_IN_PLACE, value, 1, MPI_DOUBLE, MPI_SUM)                 gravity.c:341 */
+    int (*allreduce_sum)(void *ctx, double *value_host);
+    /* MPI_Alltoall of nranks equal chunks of chunk_bytes: chunk r of send goes to rank r and lands as
+     * chunk `my rank` of its recv                                                 pmpfft.c:377-396 */
+    int (*alltoall)(void *ctx, const void *send_dev, void *recv_dev, size_t chunk_bytes);
+    /* MPI_Sendrecv: send `bytes` to rank dest, receive `bytes` from rank source  (mesh halo planes) */
+    int (*sendrecv)(void *ctx, const void *send_dev, int dest, void *recv_dev, int source, size_t bytes);
+} fastpm_hip_transport;
+
+/* The force step on this rank's slab: total mass all-reduce, paint, halo plane to rank+1, forward transform
+ * around one all-to-all, softening, the backward half in the plan's gradient mode (two transposed meshes for
+ * the k-space gradient of gradorder-1 kernels, three otherwise, one for FPMHIP_GRADIENT_REAL), halo planes
+ * back, readout [, potential].  p_dev: device columns of the particles this rank owns (decomposed by x).
+ * delta_k_dev (nullable): receives delta(k)/N^3 after softening in the plan's [x][y_loc][kz] layout.
+ * Mesh buffers are the plan's own.  Returns 0, or the first nonzero code (fpmhip_last_error() has the text). */
+int fastpm_hip_slab_force(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *p_dev,
+                          int kernel, int softening, void *delta_k_dev);
+
+/* ---- in-process loopback transport: all ranks are threads of ONE process (tests; a single-GPU dry run of a
+ * multi-rank configuration).  create returns an array of nranks transports sharing one barrier. ---- */
+fastpm_hip_transport *fastpm_hip_loopback_create(int nranks);
+void fastpm_hip_loopback_bind(fastpm_hip_transport *t, fpmhip_plan *plan);   /* the plan whose stream copies use */
+void fastpm_hip_loopback_destroy(fastpm_hip_transport *all);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -19,7 +19,7 @@ class Geom(ctypes.Structure):
 
 class Layout(ctypes.Structure):
     _fields_ = [("Nmesh", ctypes.c_int64), ("BoxSize", ctypes.c_double), ("precision", ctypes.c_int32),
-                ("nranks", ctypes.c_int32), ("rank", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("nranks", ctypes.c_int32), ("rank", ctypes.c_int32), ("gradient_mode", ctypes.c_int32),
                 ("istart", ctypes.c_int64 * 3), ("isize", ctypes.c_int64 * 3), ("istrides", ctypes.c_int64 * 3),
                 ("ihalo", ctypes.c_int64), ("plane_elems", ctypes.c_int64),
                 ("ostart", ctypes.c_int64 * 3), ("osize", ctypes.c_int64 * 3), ("ostrides", ctypes.c_int64 * 3),
@@ -108,6 +108,7 @@ SYMBOLS = {
     "fpmhip_malloc": (_I, [ctypes.POINTER(_P), ctypes.c_size_t]),
     "fpmhip_free": (_I, [_P]),
     "fpmhip_memcpy_h2d": (_I, [_P, _P, _P, ctypes.c_size_t]),
+    "fpmhip_memcpy_d2d": (_I, [_P, _P, _P, ctypes.c_size_t]),
     "fpmhip_memcpy_d2h": (_I, [_P, _P, _P, ctypes.c_size_t]),
 }
 

@@ -87,7 +87,7 @@ typedef struct {
 typedef struct {
     int64_t Nmesh;
     double  BoxSize;
-    int32_t precision, nranks, rank, reserved;
+    int32_t precision, nranks, rank, gradient_mode;   /* as given in fpmhip_geom */
     int64_t istart[3], isize[3], istrides[3];   /* IRegion; isize excludes z padding and halo */
     int64_t ihalo;          /* extra x planes after the local slab (0 if nranks == 1, else 1) */
     int64_t plane_elems;    /* reals in one x plane = Nmesh * (Nmesh + 2) */
@@ -313,6 +313,8 @@ int fpmhip_malloc(void **ptr_dev, size_t bytes);
 int fpmhip_free(void *ptr_dev);
 int fpmhip_memcpy_h2d(fpmhip_plan *plan, void *dst_dev, const void *src_host, size_t bytes);
 int fpmhip_memcpy_d2h(fpmhip_plan *plan, void *dst_host, const void *src_dev, size_t bytes);
+/* device to device on the plan's stream, asynchronous (an in-process transport uses it) */
+int fpmhip_memcpy_d2d(fpmhip_plan *plan, void *dst_dev, const void *src_dev, size_t bytes);
 
 #ifdef __cplusplus
 }

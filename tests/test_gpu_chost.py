@@ -75,3 +75,79 @@ def test_c_host_force_matches_oracle(oracle):
     assert msgs and msgs[0][0] == -1 and "Wrong kernel type" in msgs[0][1]
     H.fpm_set_msg_handler(None, None)
     H.fastpm_free_pm_hip(pm)
+
+
+# ---- NTask > 1: fastpm_hip_slab_force (fastpm_amd/host/fastpm_slab_hip.c) ---------------------------------
+class Transport(ctypes.Structure):
+    _fields_ = [("ctx", ctypes.c_void_p), ("rank", ctypes.c_int), ("nranks", ctypes.c_int),
+                ("allreduce_sum", ctypes.c_void_p), ("alltoall", ctypes.c_void_p), ("sendrecv", ctypes.c_void_p)]
+
+
+def test_host_library_exports_the_slab_force():
+    H = _host()
+    for name in ("fastpm_hip_slab_force", "fastpm_hip_loopback_create", "fastpm_hip_loopback_bind",
+                 "fastpm_hip_loopback_destroy"):
+        assert hasattr(H, name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,P,kernel,gradient_mode", [(32, 2, "1_4", 0), (48, 4, "1_4", 0), (32, 2, "eastwood", 0),
+                                                      (48, 4, "1_4", 1), (40, 2, "3_4", 1)])
+def test_c_host_slab_force_matches_one_rank_oracle(oracle, N, P, kernel, gradient_mode):
+    """The C99 slab sequence with an in-process transport: P host threads, one plan each on the same GPU,
+    exchanging through fastpm_hip_loopback (pthread barrier + device-to-device copies) exactly where
+    libfastpm would call MPI.  Must equal the one-rank oracle (decomposition invariance)."""
+    import threading
+    import torch
+    from fastpm_amd import PM, Store
+    from fastpm_amd.pm import KERNEL_TYPES
+    H = _host()
+    H.fastpm_hip_loopback_create.restype = ctypes.POINTER(Transport)
+    H.fastpm_hip_loopback_create.argtypes = [ctypes.c_int]
+    H.fastpm_hip_loopback_bind.argtypes = [ctypes.POINTER(Transport), ctypes.c_void_p]
+    H.fastpm_hip_loopback_destroy.argtypes = [ctypes.POINTER(Transport)]
+    H.fastpm_hip_slab_force.argtypes = [ctypes.c_void_p, ctypes.POINTER(Transport), ctypes.c_void_p, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_void_p]
+    nc, L = N // 2, 1.5 * N
+    x = util.load_b(nc, L, N)
+    pmo = oracle.PMOracle(N, L, 64)
+    ref = oracle.compute_force(pmo, x, kernel=oracle.KERNELS[kernel], potential=True,
+                               gradient="real" if gradient_mode else "kspace")
+    owner = (np.floor(x[:, 0] * (1.0 / (L / N))).astype(np.int64) % N) // (N // P)
+    idx = [np.nonzero(owner == r)[0] for r in range(P)]
+    pms = [PM(N, L, 64, nranks=P, rank=r, gradient_mode=gradient_mode) for r in range(P)]
+    stores = [Store(x[idx[r]], potential=True) for r in range(P)]
+    dks = [pm.alloc() for pm in pms]
+    tr = H.fastpm_hip_loopback_create(P)
+    rcs = [None] * P
+
+    def rank_main(r):
+        torch.cuda.set_device(0)
+        H.fastpm_hip_loopback_bind(ctypes.byref(tr[r]), pms[r]._plan)
+        part = stores[r]._c()
+        rcs[r] = H.fastpm_hip_slab_force(pms[r]._plan, ctypes.byref(tr[r]), ctypes.byref(part),
+                                         KERNEL_TYPES[kernel], 0, ctypes.c_void_p(dks[r].data_ptr()))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert all(not t.is_alive() for t in threads), "a rank hung"
+    torch.cuda.synchronize()
+    assert rcs == [0] * P, rcs
+    H.fastpm_hip_loopback_destroy(tr)
+    acc = np.zeros_like(ref["acc"])
+    pot = np.zeros_like(ref["potential"])
+    for r in range(P):
+        acc[idx[r]] = stores[r].acc.cpu().numpy()
+        pot[idx[r]] = stores[r].potential.cpu().numpy()
+    dk = np.concatenate([pm.complex_view(d).cpu().numpy() for pm, d in zip(pms, dks)], axis=1)
+    assert util.max_err(dk, util.oracle_k_to_xyk(pmo, ref["delta_k"])) <= 1e-14
+    if gradient_mode:
+        assert np.abs(acc - ref["acc"]).max() <= 1.5e-7 * np.abs(ref["acc"]).max()
+    else:
+        assert util.rel_err(acc, ref["acc"]) <= 1e-6
+    assert util.rel_err(pot, ref["potential"]) <= 1e-6
+    for pm in pms:
+        pm.destroy()
