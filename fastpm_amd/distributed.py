@@ -121,12 +121,14 @@ class SlabForce(_SlabRank):
             # and the potential; the y and z gradient factors depend on ky / kz only, so they are applied
             # to the potential after its x transform and transpose, in its y pass (same float32 factors)
             pm.transfer_fft_x_backward_potx(kernel, delta_k, self.force[0], self.force[1])
-            yield ("alltoall_start", self.work, self.force[0], 0)
+            # the potential goes first: its y pass + two z passes (the larger share of the compute) then run
+            # while the x component is still on xGMI
             yield ("alltoall_start", self.work2, self.force[1], 1)
-            yield ("wait", 0)
-            pm.fft_yz_backward(self.work, self.force[0])               # overlaps the second transpose
+            yield ("alltoall_start", self.work, self.force[0], 0)
             yield ("wait", 1)
             pm.fft_yz_backward_grad2(kernel, self.work2, self.force[1], self.force[2])
+            yield ("wait", 0)
+            pm.fft_yz_backward(self.work, self.force[0])
             yield ("shift", [(pm.plane(f, 0), pm.plane(f, xl), -1) for f in self.force])
             pm.readout3(self.force, store)
             if store.potential is not None:                                   # gravity.c:487-492
