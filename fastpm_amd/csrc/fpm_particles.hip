@@ -347,15 +347,17 @@ __global__ __launch_bounds__(256) void scale_kernel(F *__restrict__ buf, long lo
 // body compile to divergent control flow with a wait per element, 1.61 ms; branch-free scalar loads
 // 1.06 ms; pairs 0.89 ms.  A row starts at an even z, so it is RZ / 2 aligned pairs (one 2 x F load
 // each; a pair never straddles the periodic wrap because N is even) + 1 single when RZ is odd.
-template <typename F, int RX, int RY, int RZ>
-__device__ __forceinline__ void stage_region(F *__restrict__ reg, const F *__restrict__ mesh,
-                                             const F *__restrict__ halo, const MeshGeo &g, int x0, int y0, int z0)
+template <typename F, int RX, int RY, int RZ, int NC>
+__device__ __forceinline__ void stage_regions(F *__restrict__ reg, const F *const *mesh,
+                                              const F *__restrict__ halo, const MeshGeo &g, int x0, int y0, int z0)
 {
-    constexpr int U = 7, PR = (RZ + 1) / 2, NQ = RX * RY * PR;
+    // NC meshes with the same geometry share the address arithmetic; their loads are issued together
+    // (U * NC in flight per thread).  reg holds NC consecutive regions of RX * RY * RZ values.
+    constexpr int U = NC == 1 ? 7 : 4, PR = (RZ + 1) / 2, NQ = RX * RY * PR, RN = RX * RY * RZ;
     struct __align__(2 * sizeof(F)) F2 { F a, b; };
     const bool small = g.N < 64;       // uniform: offsets up to TILE + 5 need a true modulo on tiny meshes
     for (int q0 = threadIdx.x; q0 < NQ; q0 += 256 * U) {
-        F2 v[U];
+        F2 v[U][NC];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int q = min(q0 + u * 256, NQ - 1);
@@ -368,35 +370,51 @@ __device__ __forceinline__ void stage_region(F *__restrict__ reg, const F *__res
                 gy += gy < 0 ? g.N : 0; gy -= gy >= g.N ? g.N : 0;
                 gz += gz < 0 ? g.N : 0; gz -= gz >= g.N ? g.N : 0;
             }
-            bool ok = true;
-            const F *pl;
+            bool ok = true, from_halo = false;
+            long long off;
             if (g.periodic_x) {                   // uniform
                 if (small) lx = ((lx % g.N) + g.N) % g.N;
                 else { lx += lx < 0 ? g.N : 0; lx -= lx >= g.N ? g.N : 0; }
-                pl = mesh + (long long) lx * g.str0;
-            } else if (halo) {                    // uniform
+                off = (long long) lx * g.str0;
+            } else if (halo) {                    // uniform (NC == 1 only)
                 ok = lx >= -2 && lx <= g.xl + 2;
                 const bool lo = lx < 0, hi = lx > g.xl;
                 const int hp = !ok ? 0 : (lo ? lx + 2 : (hi ? lx - g.xl + 1 : lx));
-                pl = ((lo || hi) && ok ? halo : mesh) + (long long) hp * g.str0;
+                from_halo = (lo || hi) && ok;
+                off = (long long) hp * g.str0;
             } else {
                 ok = lx >= 0 && lx < g.xplanes;
-                pl = mesh + (long long) (ok ? lx : 0) * g.str0;
+                off = (long long) (ok ? lx : 0) * g.str0;
             }
+            off += (long long) gy * g.str1 + gz;
             // gz is even and <= N - 2: the second value of a pair is still inside the row
-            const F2 val = *(const F2 *) (pl + (long long) gy * g.str1 + gz);
-            v[u] = ok ? val : F2{0, 0};
+#pragma unroll
+            for (int m = 0; m < NC; m++) {
+                const F2 val = *(const F2 *) ((from_halo ? halo : mesh[m]) + off);
+                v[u][m] = ok ? val : F2{0, 0};
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int q = q0 + u * 256;
             if (q < NQ) {
                 const int pz = q % PR, row = q / PR;
-                reg[row * RZ + 2 * pz] = v[u].a;
-                if (2 * pz + 1 < RZ) reg[row * RZ + 2 * pz + 1] = v[u].b;
+#pragma unroll
+                for (int m = 0; m < NC; m++) {
+                    reg[m * RN + row * RZ + 2 * pz] = v[u][m].a;
+                    if (2 * pz + 1 < RZ) reg[m * RN + row * RZ + 2 * pz + 1] = v[u][m].b;
+                }
             }
         }
     }
+}
+
+template <typename F, int RX, int RY, int RZ>
+__device__ __forceinline__ void stage_region(F *__restrict__ reg, const F *__restrict__ mesh,
+                                             const F *__restrict__ halo, const MeshGeo &g, int x0, int y0, int z0)
+{
+    const F *m[1] = {mesh};
+    stage_regions<F, RX, RY, RZ, 1>(reg, m, halo, g, x0, y0, z0);
 }
 
 // CIC readout of NC meshes at once.  value = sum over corners in the order 000,001,...,111
@@ -610,8 +628,7 @@ __global__ __launch_bounds__(256) void readout3_tiles_kernel(MeshGeo g, int ntil
     const int tz = t % g.ntz, ty = (t / g.ntz) % g.nty, tx = t / (g.ntz * g.nty);
     const int x0 = tx * TILE_X, y0 = ty * TILE_Y, z0 = tz * TILE_Z;
     const F *mesh[3] = {m0, m1, m2};
-#pragma unroll
-    for (int q = 0; q < 3; q++) stage_region<F, RX, RY, RZ>(reg + q * RN, mesh[q], (const F *) nullptr, g, x0, y0, z0);
+    stage_regions<F, RX, RY, RZ, 3>(reg, mesh, (const F *) nullptr, g, x0, y0, z0);
     __syncthreads();
     for (int j = beg + threadIdx.x; j < end; j += 256) {
         Cic c;
