@@ -37,15 +37,46 @@ CHECK = {
 }
 
 
+# tests/run-test-lightcone-ODE.check: the same run with growth_mode = "ODE" (tests/lightcone-ODE.lua); dx1, dx2 and
+# the first line are the same, the later lines differ from the LCDM ones in the 5th-6th digit -- through nothing but
+# f1, f2, D2 in the velocity of the initial condition and in the kick / drift factors.
+CHECK_ODE = {
+    "plin": [("0.1", "17305.5"), ("0.228571", "17201.1"), ("0.357143", "17110.2"), ("0.485714", "17064.9"),
+             ("0.614286", "17043.7"), ("0.742857", "17028.4"), ("0.871429", "17014.5"), ("1", "17002.5")],
+}
+
+
 class Cosmology:
     """libfastpm/cosmology.c for T_cmb = 0, no ncdm, w = -1, flat: HubbleEa :185-201, DHubbleEaDa :226-244,
     D2HubbleEaDa2 :246-265, Omega_m :211-215, growth_mode LCDM :374-388, DGrowthFactorDa :403-427,
     D2GrowthFactorDa2 :429-462."""
 
-    def __init__(self, Omega_m):
+    def __init__(self, Omega_m, growth_mode="LCDM"):
         self.Om = Omega_m
         self.OL = 1 - Omega_m                          # :48 with Omega_r = Omega_k = 0
         self._g1 = self._growth_int(1.0)
+        self.growth_mode = growth_mode
+        self._ode = {}
+        if growth_mode == "ODE":
+            self._ode1 = self._ode_solve(1.0)
+
+    def _ode_solve(self, a):
+        """growth_ode_solve (:300-372): {d1, F1, d2, F2} from a = 0.00625 in matter domination; the reference
+        integrates with GSL rkf45 at 1e-8, here scipy at 1e-11."""
+        from scipy.integrate import solve_ivp
+        if a in self._ode:
+            return self._ode[a]
+        aini = 0.00625
+
+        def rhs(x, y):
+            E, dE = self.E(x), self.dEda(x)
+            d = [y[1], -(2. + x / E * dE) * y[1] + 1.5 * self.Omega_m(x) * y[0],
+                 y[3], -(2. + x / E * dE) * y[3] + 1.5 * self.Omega_m(x) * (y[2] - y[0] * y[0])]
+            return [v / x for v in d]
+        y0 = [aini, aini, -3. / 7 * aini * aini, 2 * (-3. / 7 * aini * aini)]
+        sol = solve_ivp(rhs, (aini, a), y0, rtol=1e-11, atol=1e-13, method="DOP853")
+        self._ode[a] = sol.y[:, -1]
+        return self._ode[a]
 
     def E(self, a):
         return np.sqrt(self.Om / a ** 3 + self.OL)
@@ -66,16 +97,26 @@ class Cosmology:
 
     def growth(self, a):
         """FastPMGrowthInfo in LCDM mode: D1, f1, D2, f2 (:379-387; note D2 > 0, the 3/7 sits in dx2)."""
+        if self.growth_mode == "ODE":                  # :389-397
+            y, y1 = self._ode_solve(a), self._ode1
+            return {"a": a, "D1": y[0] / y1[0], "f1": y[1] / y[0], "D2": y[2] / y1[2], "f2": y[3] / y[2]}
         Om = self.Omega_m(a)
         D1 = self._growth_int(a) / self._g1
         return {"a": a, "D1": D1, "f1": Om ** (5. / 9), "D2": D1 * D1 * (Om / self.Omega_m(1.0)) ** (-1. / 143),
                 "f2": 2 * Om ** (6. / 11)}
 
-    def dDda(self, a):                                 # :412-418
+    def dDda(self, a):                                 # :412-418 (LCDM), :420-421 (ODE)
+        if self.growth_mode == "ODE":
+            g = self.growth(a)
+            return g["f1"] * g["D1"] / a
         E = self.E(a)
         return self.dEda(a) * self.growth(a)["D1"] / E + E * (a * E) ** -3 / self._g1
 
-    def d2Dda2(self, a):                               # :441-449
+    def d2Dda2(self, a):                               # :441-449 (LCDM), :450-458 (ODE)
+        if self.growth_mode == "ODE":
+            g = self.growth(a)
+            ans = -(3. + a / self.E(a) * self.dEda(a)) * g["f1"] + 1.5 * self.Omega_m(a)
+            return ans * g["D1"] / (a * a)
         E, dE = self.E(a), self.dEda(a)
         return self.d2Eda2(a) * self.growth(a)["D1"] / E - (dE + 3 / a * E) * (a * E) ** -3 / self._g1
 
@@ -260,12 +301,12 @@ class OracleOps:
 
 
 def run_lightcone_test(ops, N=64, BoxSize=512.0, seed=100, Omega_m=0.307494, time_step=None, F=np.float64,
-                       nsteps=None):
+                       nsteps=None, growth_mode="LCDM"):
     """tests/lightcone.lua up to the quantities the .check file pins.  Returns a dict of log values."""
     time_step = np.linspace(0.1, 1.0, 8) if time_step is None else np.asarray(time_step)
     if nsteps is not None:
         time_step = time_step[: nsteps + 1]
-    c = Cosmology(Omega_m)
+    c = Cosmology(Omega_m, growth_mode)
     power = PowerTable()
     log = {"sigma8_input": power.sigma(8.0)}
     dk = initial_delta_k_xyk(N, BoxSize, seed, power, F)

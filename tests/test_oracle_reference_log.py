@@ -47,6 +47,17 @@ def test_large_scale_power_after_every_force_of_the_run(log):
         assert R.matches(p, ptext), (a, p, ptext)
 
 
+def test_growth_mode_ode_variant_of_the_run():
+    """tests/run-test-lightcone-ODE.check: the same run with growth_mode = "ODE".  Its eight lines differ from the
+    LCDM ones in the 5th-6th digit (17200.9 -> 17201.1, ...) through nothing but f1, f2 and D2 in the initial
+    velocities and in the kick / drift factors -- and are reproduced to the printed digit as well: the comparison
+    resolves changes of 1e-5 in what the particles were given between two force calls."""
+    log = R.run_lightcone_test(R.OracleOps(64, 512.0, 64), growth_mode="ODE")
+    assert [t for _, t in R.CHECK_ODE["plin"]] != [t for _, t in R.CHECK["plin"]]
+    for (a, p), (atext, ptext) in zip(log["plin"], R.CHECK_ODE["plin"]):
+        assert R.matches(p, ptext), (a, p, ptext)
+
+
 def test_sigma8_of_the_measured_spectra(log):
     """The second number of the same lines, "Sigma8 = ...": sigma(8 Mpc/h) of the MEASURED spectrum over D1^2 --
     every P(k) bin up to the Nyquist frequency enters.  The reference integrates with GSL QAG at epsrel = 1e-4
