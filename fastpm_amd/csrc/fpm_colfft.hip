@@ -520,7 +520,7 @@ static int colfft_launch(fpmhip_plan *p, int dir, const void *in, void *out, con
     // one 128-B line per row: 8 columns of complex<double>, 16 of complex<float> (while the
     // workgroup still fits 1024 threads)
     constexpr int CW = (sizeof(F) == 4) ? 16 : 8;
-    const bool wide = sizeof(F) == 4 && N <= 512;
+    const bool wide = sizeof(F) == 4 && N <= 512 && !getenv("FPMHIP_NARROW");
     const int cw = wide ? CW : 8;
     const int tpb = (ncols + cw - 1) / cw;
     const int ntiles = tpb * nbatch;
@@ -585,7 +585,7 @@ static int yback2_launch(fpmhip_plan *p, const void *in, void *oy, void *oz, con
     StageTimer ktm(p, FPMHIP_T_K_YBACK2);
     const int N = p->mg.N;
     constexpr int CW = (sizeof(F) == 4) ? 16 : 8;
-    const bool wide = sizeof(F) == 4 && N <= 512;
+    const bool wide = sizeof(F) == 4 && N <= 512 && !getenv("FPMHIP_NARROW");
     const int cw = wide ? CW : 8;
     const int tpb = (ncols + cw - 1) / cw;
     const int ntiles = tpb * nbatch;
@@ -656,7 +656,7 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
     const int N = g.N;
     const long long plane = (long long) g.yl * g.nzc;
     constexpr int CW = (sizeof(F) == 4) ? 16 : 8;
-    const bool wide = sizeof(F) == 4 && N <= 512;
+    const bool wide = sizeof(F) == 4 && N <= 512 && !getenv("FPMHIP_NARROW");
     const int cw = wide ? CW : 8;
     const int ntiles = (int) ((plane + cw - 1) / cw);
     const size_t lds = (size_t) N * cw * sizeof(C2<F>) + (size_t) N * sizeof(C2<F>);
