@@ -175,6 +175,8 @@ void fft_teardown(fpmhip_plan *p)
     rocfft_plan all[] = {p->p_r2c3d, p->p_c2r3d, p->p_r2c2d, p->p_c2r2d, p->p_xfwd, p->p_xbwd,
                          p->p_zr2c_op, p->p_zr2c_ip, p->p_zc2r_ip, p->p_zc2r_chunk};
     for (rocfft_plan q : all) if (q) rocfft_plan_destroy(q);
+    for (auto &e : p->zc2r_by_nx) if (e.second) rocfft_plan_destroy(e.second);
+    p->zc2r_by_nx.clear();
     if (p->fft_info) rocfft_execution_info_destroy(p->fft_info);
     if (p->fft_work) (void) hipFree(p->fft_work);
 }
@@ -203,16 +205,61 @@ static int zy_forward(fpmhip_plan *p, void *in, void *mid, void *out, int chunke
     return 0;
 }
 
+// own fused c2r row kernel when N/2 is supported (FPMHIP_ZC2R=rocfft forces rocFFT's batched 1-D c2r, A/B)
+static bool own_zc2r(const fpmhip_plan *p)
+{
+    static const bool force_rocfft = getenv("FPMHIP_ZC2R") && std::string(getenv("FPMHIP_ZC2R")) == "rocfft";
+    return !force_rocfft && rowfft_supported(p->mg.N);
+}
+
 static int yz_backward(fpmhip_plan *p, void *in, void *out, int chunked)
 {
     const int xl = p->mg.xl, cp = p->chunk_planes ? p->chunk_planes : xl;
     const size_t plane_bytes = (size_t) p->mg.N * p->mg.nzc * 2 * p->esize;
     for (int x0 = 0; x0 < xl; x0 += cp) {
         FPM_TRY(colfft_y_range(p, +1, in, out, chunked, x0, cp));
+        if (own_zc2r(p)) { FPM_TRY(rowfft_c2r_range(p, out, x0, cp)); continue; }
         StageTimer ktm(p, FPMHIP_T_K_ZC2R);
         if (cp == xl) FPM_TRY(fft_exec(p, p->p_zc2r_ip, out, nullptr));
         else FPM_TRY(fft_exec(p, p->p_zc2r_chunk, (char *) out + (size_t) x0 * plane_bytes, nullptr));
     }
+    return 0;
+}
+
+// in-place z c2r of the planes [x0, x0 + nx): the full-slab plan, or a batch-(nx * N) plan made on first use
+static int zc2r_range(fpmhip_plan *p, void *buf, int x0, int nx)
+{
+    if (own_zc2r(p)) return rowfft_c2r_range(p, buf, x0, nx);
+    StageTimer ktm(p, FPMHIP_T_K_ZC2R);
+    if (x0 == 0 && nx == p->mg.xl) return fft_exec(p, p->p_zc2r_ip, buf, nullptr);
+    rocfft_plan plan = nullptr;
+    for (auto &e : p->zc2r_by_nx) if (e.first == nx) plan = e.second;
+    if (!plan) {
+        const size_t N = p->mg.N, nzc = p->mg.nzc;
+        const size_t len1[1] = {N};
+        const size_t one[1] = {1};
+        FPM_TRY(make_plan(&plan, rocfft_placement_inplace, rocfft_transform_type_real_inverse, p->f64, 1, len1,
+                          (size_t) nx * N, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, one, nzc,
+                          one, N + 2, 1.0));
+        size_t w = 0;
+        FPM_CHECK_FFT(rocfft_plan_get_work_buffer_size(plan, &w));
+        if (w > p->fft_work_bytes) {
+            FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
+            if (p->fft_work) (void) hipFree(p->fft_work);
+            FPM_CHECK_HIP(hipMalloc(&p->fft_work, w));
+            p->fft_work_bytes = w;
+            FPM_CHECK_FFT(rocfft_execution_info_set_work_buffer(p->fft_info, p->fft_work, w));
+        }
+        p->zc2r_by_nx.push_back({nx, plan});
+    }
+    const size_t plane_bytes = (size_t) p->mg.N * p->mg.nzc * 2 * p->esize;
+    return fft_exec(p, plan, (char *) buf + (size_t) x0 * plane_bytes, nullptr);
+}
+
+static int check_range(const fpmhip_plan *p, int x0, int nx)
+{
+    if (!p->own_fft || !rowfft_supported(p->mg.N)) FPM_FAIL(-1, "ranged stage calls need the column-FFT back end (see fpmhip_plan_ranged_fft)");
+    if (x0 < 0 || nx < 1 || x0 + nx > p->mg.xl) FPM_FAIL(-1, "plane range [%d, %d) outside the slab of %d planes", x0, x0 + nx, p->mg.xl);
     return 0;
 }
 
@@ -221,6 +268,48 @@ static int yz_backward(fpmhip_plan *p, void *in, void *out, int chunked)
 using namespace fpm;
 
 extern "C" {
+
+int fpmhip_plan_ranged_fft(const fpmhip_plan *p)
+{
+    return p && p->own_fft && rowfft_supported(p->mg.N) ? 1 : 0;
+}
+
+// The (y, z) halves of the slab transforms for the x planes [x0, x0 + nx) only, so that the all-to-all of one
+// plane range can be in flight while the next range is being transformed (fastpm_amd/distributed.py).
+int fpmhip_fft_yz_forward_range(fpmhip_plan *p, void *canvas, void *send, int x0, int nx)
+{
+    if (!p || !canvas || !send) FPM_FAIL(-1, "null argument");
+    FPM_TRY(check_range(p, x0, nx));
+    if (p->lay.nranks > 1 && canvas == send) FPM_FAIL(-1, "fft_yz_forward: canvas and send must differ when nranks > 1");
+    StageTimer tm(p, FPMHIP_T_R2C);
+    FPM_TRY(rowfft_r2c_range(p, canvas, canvas, x0, nx));
+    return colfft_y_range(p, -1, canvas, send, p->lay.nranks > 1 ? 1 : 0, x0, nx);
+}
+
+int fpmhip_fft_yz_backward_range(fpmhip_plan *p, void *recv, void *canvas, int x0, int nx)
+{
+    if (!p || !recv || !canvas) FPM_FAIL(-1, "null argument");
+    FPM_TRY(check_range(p, x0, nx));
+    if (p->lay.nranks > 1 && recv == canvas) FPM_FAIL(-1, "fft_yz_backward: recv and canvas must differ when nranks > 1");
+    StageTimer tm(p, FPMHIP_T_C2R);
+    FPM_TRY(colfft_y_range(p, +1, recv, canvas, p->lay.nranks > 1 ? 1 : 0, x0, nx));
+    return zc2r_range(p, canvas, x0, nx);
+}
+
+int fpmhip_fft_yz_backward_grad2_range(fpmhip_plan *p, void *recv, void *out_y, void *out_z, int kernel, int x0, int nx)
+{
+    if (!p || !recv || !out_y || !out_z) FPM_FAIL(-1, "null argument");
+    FPM_TRY(check_range(p, x0, nx));
+    int po, go, dfo, dc;
+    FPM_TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));
+    if (go != 1) FPM_FAIL(-1, "fft_yz_backward_grad2 is for kernels with gradorder = 1");
+    if (out_y == out_z) FPM_FAIL(-1, "out_y and out_z must differ");
+    if (p->lay.nranks > 1 && (recv == out_y || recv == out_z)) FPM_FAIL(-1, "recv and the outputs must differ when nranks > 1");
+    StageTimer tm(p, FPMHIP_T_C2R);
+    FPM_TRY(colfft_yback2_range(p, recv, out_y, out_z, p->lay.nranks > 1 ? 1 : 0, go, x0, nx));
+    FPM_TRY(zc2r_range(p, out_y, x0, nx));
+    return zc2r_range(p, out_z, x0, nx);
+}
 
 int fpmhip_plan_staged_fft(const fpmhip_plan *p)
 {
@@ -371,12 +460,8 @@ int fpmhip_fft_yz_backward_grad2(fpmhip_plan *p, void *recv, void *out_y, void *
     if (p->lay.nranks > 1 && (recv == out_y || recv == out_z)) FPM_FAIL(-1, "recv and the outputs must differ when nranks > 1");
     StageTimer tm(p, FPMHIP_T_C2R);
     FPM_TRY(colfft_yback2(p, recv, out_y, out_z, p->lay.nranks > 1 ? 1 : 0, go));
-    {
-        StageTimer ktm(p, FPMHIP_T_K_ZC2R);
-        FPM_TRY(fft_exec(p, p->p_zc2r_ip, out_y, nullptr));
-    }
-    StageTimer ktm(p, FPMHIP_T_K_ZC2R);
-    return fft_exec(p, p->p_zc2r_ip, out_z, nullptr);
+    FPM_TRY(zc2r_range(p, out_y, 0, p->mg.xl));
+    return zc2r_range(p, out_z, 0, p->mg.xl);
 }
 
 // The POTENTIAL transfer and the x pass of its inverse transform in one sweep (real-space-gradient mode).

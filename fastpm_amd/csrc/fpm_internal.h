@@ -104,6 +104,7 @@ struct fpmhip_plan {
     // sweeps is still in the 256 MiB Infinity Cache when the second sweep reads it
     int chunk_planes = 0;                  // 0 = whole slab in one go
     rocfft_plan p_zc2r_chunk = nullptr;    // z c2r for chunk_planes * N rows
+    std::vector<std::pair<int, rocfft_plan>> zc2r_by_nx;   // z c2r for nx * N rows (ranged stage calls)
     double *d_twiddle = nullptr;   // e^{-2 pi i j / N}, j < N (re, im)
     rocfft_execution_info fft_info = nullptr;
     void *fft_work = nullptr;
@@ -170,7 +171,9 @@ int rowfft_r2c(fpmhip_plan *p, const void *in, void *out);
 int colfft_xback3(fpmhip_plan *p, const void *dk, void *o0, void *o1, void *o2, int potorder, int gradorder);
 int colfft_xback_pot(fpmhip_plan *p, const void *dk, void *out, int potorder);
 int colfft_xback_potx(fpmhip_plan *p, const void *dk, void *out_x, void *out_pot, int potorder, int gradorder);
+int rowfft_c2r_range(fpmhip_plan *p, void *buf, int x0, int nx);
 int colfft_yback2(fpmhip_plan *p, const void *in, void *oy, void *oz, int chunked, int gradorder);
+int colfft_yback2_range(fpmhip_plan *p, const void *in, void *oy, void *oz, int chunked, int gradorder, int x0, int nx);
 
 // fpm_force.hip
 void release_host_stage(fpmhip_plan *p);

@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256) void readout_grad_tiles_kernel(MeshGeo g, int 
                                                                  const F *__restrict__ phi, const F *__restrict__ halo,
                                                                  float *__restrict__ out, double inv12h)
 {
-    constexpr int RX = TILE_X + 5, RY = TILE_Y + 5, RZ = TILE_Z + 5, RN = RX * RY * RZ;
+    constexpr int RX = TILE_X + 5, RY = TILE_Y + 5, RZ = TILE_Z + 5;
     extern __shared__ __align__(16) unsigned char smem_rg[];
     F *reg = (F *) smem_rg;                       // [RX][RY][RZ]
     const int t = xcd_remap(blockIdx.x, ntiles);

@@ -50,9 +50,22 @@ class _SlabRank:
             dist.all_to_all_single(req[1][:n], req[2][:n], group=g)
         elif kind == "alltoall_start":
             n = self.pm.exchange_chunk_elems() * self.P
-            self._pending[req[3]] = dist.all_to_all_single(req[1][:n], req[2][:n], group=g, async_op=True)
+            self._pending[req[3]] = [dist.all_to_all_single(req[1][:n], req[2][:n], group=g, async_op=True)]
+        elif kind == "alltoall_range_start":
+            # the planes [x0, x0 + nx) of every per-rank chunk: P - 1 send / receive pairs in one batch (the
+            # shape all_to_all takes on RCCL anyway) + a local copy for this rank's own piece
+            _, recv, send, x0, nx, tag = req
+            ops = []
+            for r, (s, d) in enumerate(zip(_range_views(self.pm, send, x0, nx), _range_views(self.pm, recv, x0, nx))):
+                if r == self.rank:
+                    d.copy_(s)
+                else:
+                    ops.append(dist.P2POp(dist.isend, s, _global_rank(g, r), group=g))
+                    ops.append(dist.P2POp(dist.irecv, d, _global_rank(g, r), group=g))
+            self._pending[tag] = dist.batch_isend_irecv(ops) if ops else []
         elif kind == "wait":
-            self._pending.pop(req[1]).wait()
+            for w in self._pending.pop(req[1]):
+                w.wait()
         elif kind == "shift":
             ops = []
             for send, recv, direction in req[1]:
@@ -69,9 +82,13 @@ class _SlabRank:
 class SlabForce(_SlabRank):
     """fastpm_solver_compute_force for rank `pm.rank` of `pm.nranks` x-slabs (gravity.c:458-529)."""
 
-    def __init__(self, pm, group=None, three_transposes=False):
+    def __init__(self, pm, group=None, three_transposes=False, chunks=4):
         super().__init__(pm, group)
         self.three_transposes = three_transposes               # A/B: one transpose per ACC component
+        # plane ranges the transposes are cut into so that a range's all-to-all overlaps the (y, z) passes of
+        # the next (forward) / previous (backward) range; 1 = whole-slab exchanges
+        self.chunks = chunks
+        self.extra = None                                      # third output mesh of the pipelined backward half
         self.canvas = pm.alloc()
         self.work = pm.alloc()
         self.real_gradient = getattr(pm, "gradient_mode", 0) == GRADIENT_REAL
@@ -105,8 +122,16 @@ class SlabForce(_SlabRank):
         pm.plane_add(pm.plane(self.canvas, 0), self.tmp_plane)
 
         # gravity.c:351 pm_r2c: 2-D (y,z) transforms, transpose, 1-D x transform (x 1/Norm)
-        pm.fft_yz_forward(self.canvas, self.work)
-        yield ("alltoall", delta_k, self.work)
+        ranges = self._ranges()
+        if len(ranges) == 1:
+            pm.fft_yz_forward(self.canvas, self.work)
+            yield ("alltoall", delta_k, self.work)
+        else:
+            for i, (x0, nx) in enumerate(ranges):           # range i is on xGMI while range i + 1 is transformed
+                pm.fft_yz_forward_range(self.canvas, self.work, x0, nx)
+                yield ("alltoall_range_start", delta_k, self.work, x0, nx, ("fwd", i))
+            for i in range(len(ranges)):
+                yield ("wait", ("fwd", i))
         pm.fft_x_forward(delta_k)
         pm.apply_softening_transfer(dealias, delta_k)                     # gravity.c:476
 
@@ -116,6 +141,32 @@ class SlabForce(_SlabRank):
 
         if self.work2 is None:
             self.work2, self.force[1], self.force[2] = pm.alloc(), pm.alloc(), pm.alloc()
+        if _gradorder(kernel) == 1 and pm.column_fft() and not self.three_transposes and len(ranges) > 1:
+            # the two-transpose form below, pipelined over plane ranges.  A range's outputs must not land in a
+            # buffer that later ranges are still being sent from: y -> force[2], z -> a third mesh, and x ->
+            # force[1], which is free once every range of the potential has arrived.
+            if self.extra is None:
+                self.extra = pm.alloc()
+            pm.transfer_fft_x_backward_potx(kernel, delta_k, self.force[0], self.force[1])
+            for i, (x0, nx) in enumerate(ranges):
+                yield ("alltoall_range_start", self.work2, self.force[1], x0, nx, ("pot", i))
+            for i, (x0, nx) in enumerate(ranges):
+                yield ("alltoall_range_start", self.work, self.force[0], x0, nx, ("x", i))
+            for i, (x0, nx) in enumerate(ranges):
+                yield ("wait", ("pot", i))
+                pm.fft_yz_backward_grad2_range(kernel, self.work2, self.force[2], self.extra, x0, nx)
+            for i, (x0, nx) in enumerate(ranges):
+                yield ("wait", ("x", i))
+                pm.fft_yz_backward_range(self.work, self.force[1], x0, nx)
+            meshes = [self.force[1], self.force[2], self.extra]
+            yield ("shift", [(pm.plane(f, 0), pm.plane(f, xl), -1) for f in meshes])
+            pm.readout3(meshes, store)
+            if store.potential is not None:                                   # gravity.c:487-492
+                f = self.force[0]
+                yield from self._backward(delta_k, kernel, FIELD_POTENTIAL, f)
+                yield ("shift", [(pm.plane(f, 0), pm.plane(f, xl), -1)])
+                pm.readout(f, store, store.potential, 1, 0)
+            return
         if _gradorder(kernel) == 1 and pm.column_fft() and not self.three_transposes:
             # gravity.c:373-397 with TWO meshes through the transpose instead of three: the x component
             # and the potential; the y and z gradient factors depend on ky / kz only, so they are applied
@@ -175,14 +226,33 @@ class SlabForce(_SlabRank):
             self.halo = torch.zeros(4 * pe, dtype=self.canvas.dtype, device=self.canvas.device)
         phi = self.canvas
         pm.transfer_fft_x_backward_pot(kernel, delta_k, phi)
-        yield ("alltoall", self.work, phi)
-        pm.fft_yz_backward(self.work, phi)
+        ranges = self._ranges()
+        if len(ranges) == 1:
+            yield ("alltoall", self.work, phi)
+            pm.fft_yz_backward(self.work, phi)
+        else:
+            if self.force[1] is None:
+                self.force[1] = pm.alloc()                  # the real-space potential must not land in the send buffer
+            for i, (x0, nx) in enumerate(ranges):
+                yield ("alltoall_range_start", self.work, phi, x0, nx, ("pot", i))
+            phi = self.force[1]
+            for i, (x0, nx) in enumerate(ranges):
+                yield ("wait", ("pot", i))
+                pm.fft_yz_backward_range(self.work, phi, x0, nx)
         yield ("shift", [(pm.plane(phi, 0), pm.plane(phi, xl), -1),              # -> rank-1: its plane xl
                          (pm.plane(phi, 1, 2), self.halo[2 * pe:], -1),          #            its planes xl+1, xl+2
                          (pm.plane(phi, xl - 2, 2), self.halo[:2 * pe], +1)])    # -> rank+1: its planes -2, -1
         pm.readout_grad(phi, store, self.halo)
         if store.potential is not None:                                   # gravity.c:487-492, no extra FFT
             pm.readout(phi, store, store.potential, 1, 0)
+
+    def _ranges(self):
+        pm = self.pm
+        xl = int(pm.layout.isize[0])
+        c = int(self.chunks)
+        if c <= 1 or self.P == 1 or not getattr(pm, "ranged_fft", lambda: False)() or xl % c != 0:
+            return [(0, xl)]
+        return [(i * (xl // c), xl // c) for i in range(c)]
 
     def _backward(self, delta_k, kernel, field, out):
         pm = self.pm
@@ -343,6 +413,13 @@ def run_virtual_decompose(decomposers, stores):
             raise ValueError(kind)
 
 
+def _range_views(pm, buf, x0, nx):
+    """The planes [x0, x0 + nx) of each of the P per-rank chunks of an exchange buffer."""
+    chunk = pm.exchange_chunk_elems()
+    row = chunk // int(pm.layout.isize[0])
+    return [buf[r * chunk + x0 * row: r * chunk + (x0 + nx) * row] for r in range(pm.nranks)]
+
+
 def _gradorder(kernel):
     # gravity.c:111-171: gradorder = 1 (4-point k_finite) for every kernel but EASTWOOD, NAIVE and 3_2
     return 0 if _enum(KERNEL_TYPES, kernel) in (_enum(KERNEL_TYPES, "eastwood"), _enum(KERNEL_TYPES, "naive"),
@@ -394,6 +471,14 @@ def run_virtual_steps(forces, gens):
             for dst in range(P):
                 for src in range(P):
                     reqs[dst][1][src * chunk:(src + 1) * chunk].copy_(reqs[src][2][dst * chunk:(dst + 1) * chunk])
+        elif kind == "alltoall_range_start":
+            pm = forces[0].pm
+            x0, nx = reqs[0][3], reqs[0][4]
+            sends = [_range_views(pm, r[2], x0, nx) for r in reqs]
+            recvs = [_range_views(pm, r[1], x0, nx) for r in reqs]
+            for dst in range(P):
+                for src in range(P):
+                    recvs[dst][src].copy_(sends[src][dst])
         elif kind == "wait":
             pass
         elif kind == "shift":

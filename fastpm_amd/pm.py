@@ -458,6 +458,19 @@ class PM:
     def fft_yz_backward(self, recv, canvas):
         check(self._L.fpmhip_fft_yz_backward(self._plan, _ptr(recv), _ptr(canvas)))
 
+    def ranged_fft(self):
+        return bool(self._L.fpmhip_plan_ranged_fft(self._plan))
+
+    def fft_yz_forward_range(self, canvas, send, x0, nx):
+        check(self._L.fpmhip_fft_yz_forward_range(self._plan, _ptr(canvas), _ptr(send), int(x0), int(nx)))
+
+    def fft_yz_backward_range(self, recv, canvas, x0, nx):
+        check(self._L.fpmhip_fft_yz_backward_range(self._plan, _ptr(recv), _ptr(canvas), int(x0), int(nx)))
+
+    def fft_yz_backward_grad2_range(self, kernel, recv, out_y, out_z, x0, nx):
+        check(self._L.fpmhip_fft_yz_backward_grad2_range(self._plan, _ptr(recv), _ptr(out_y), _ptr(out_z),
+                                                         _enum(KERNEL_TYPES, kernel), int(x0), int(nx)))
+
     def staged_fft(self):
         return bool(self._L.fpmhip_plan_staged_fft(self._plan))
 

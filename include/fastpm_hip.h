@@ -206,6 +206,15 @@ int fpmhip_transfer_fft_x_backward_pot(fpmhip_plan *plan, const void *delta_k_de
 /* 1 if the staged FFT entry points (fft_yz_*, fft_x_*) work for this plan (always for nranks > 1;
  * for nranks == 1 only with the column-FFT back end) */
 int fpmhip_plan_staged_fft(const fpmhip_plan *plan);
+/* The (y, z) halves for the x planes [x0, x0 + nx) of the slab only: the exchange of one plane range can be in
+ * flight while the next range is transformed.  Within an exchange chunk the planes of one range are contiguous:
+ * range (x0, nx) of the chunk for rank r starts r * fpmhip_exchange_chunk_elems() + x0 * (chunk / xl) elements
+ * into the buffer.  Available when fpmhip_plan_ranged_fft() is 1 (column-FFT back end, Nmesh / 2 supported). */
+int fpmhip_plan_ranged_fft(const fpmhip_plan *plan);
+int fpmhip_fft_yz_forward_range(fpmhip_plan *plan, void *canvas_dev, void *send_dev, int x0, int nx);
+int fpmhip_fft_yz_backward_range(fpmhip_plan *plan, void *recv_dev, void *canvas_dev, int x0, int nx);
+int fpmhip_fft_yz_backward_grad2_range(fpmhip_plan *plan, void *recv_dev, void *out_y_dev, void *out_z_dev,
+                                       int kernel, int x0, int nx);
 /* 1 if the hand-written column-FFT back end is in use (FPMHIP_FFT_AUTO and a supported Nmesh): the
  * fused entry points fpmhip_transfer_fft_x_backward_potx / fpmhip_fft_yz_backward_grad2 need it */
 int fpmhip_plan_column_fft(const fpmhip_plan *plan);

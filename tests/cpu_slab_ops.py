@@ -165,6 +165,33 @@ class CpuSlabOps:
         for r in range(P):
             s[r] = a[:, r * yl:(r + 1) * yl, :]
 
+    # ---- the same for the planes [x0, x0 + nx) only (pipelined exchanges)
+    def ranged_fft(self):
+        return True
+
+    def fft_yz_forward_range(self, canvas, send, x0, nx):
+        N, xl, yl, nzc, P = self.Nmesh, self.xl, self.yl, self.nzc, self.nranks
+        a = scipy.fft.rfft2(self._real(canvas)[x0:x0 + nx, :, :N], axes=(1, 2))
+        s = self._cplx(send, (P, xl, yl, nzc))
+        for r in range(P):
+            s[r, x0:x0 + nx] = a[:, r * yl:(r + 1) * yl, :]
+
+    def fft_yz_backward_range(self, recv, canvas, x0, nx):
+        N, xl, yl, nzc, P = self.Nmesh, self.xl, self.yl, self.nzc, self.nranks
+        r_ = self._cplx(recv, (P, xl, yl, nzc))[:, x0:x0 + nx].copy()
+        a = np.concatenate([r_[s] for s in range(P)], axis=1)
+        self._real(canvas)[x0:x0 + nx, :, :N] = scipy.fft.irfft2(a, s=(N, N), axes=(1, 2), norm="forward")
+
+    def fft_yz_backward_grad2_range(self, kernel, recv, out_y, out_z, x0, nx):
+        N, xl, yl, nzc, P = self.Nmesh, self.xl, self.yl, self.nzc, self.nranks
+        assert O.kernel_orders(int(kernel))[1] == 1
+        kf = O.k_tables(N, self.BoxSize)["k_finite"].astype(np.float64)
+        r_ = self._cplx(recv, (P, xl, yl, nzc))[:, x0:x0 + nx].copy()
+        a = np.concatenate([r_[s] for s in range(P)], axis=1)
+        for out, fac in ((out_y, kf[None, :, None]), (out_z, kf[None, None, :nzc])):
+            v = (1j * a * fac).astype(self.C)
+            self._real(out)[x0:x0 + nx, :, :N] = scipy.fft.irfft2(v, s=(N, N), axes=(1, 2), norm="forward")
+
     def fft_x_forward(self, recv):
         v = self._cplx(recv, (self.Nmesh, self.yl, self.nzc))
         v[...] = scipy.fft.fft(v, axis=0) * (1.0 / self.Norm)

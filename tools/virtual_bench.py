@@ -2,7 +2,7 @@
 """Play bench.py's multi-GPU workloads on ONE GPU with virtual ranks (fastpm_amd.distributed.run_virtual):
 every rank's stage kernels run at their real sizes (so size-dependent failures and per-rank compute
 times show up on the 1-GPU box); only the transport (device copies instead of RCCL) differs.
-usage: virtual_bench.py [P ...]"""
+usage: virtual_bench.py [P ...]      (FPM_VB_CHUNKS=c sets SlabForce(chunks=c), FPM_VB_GRADIENT=1 the real-space gradient)"""
 import os
 import sys
 import time
@@ -24,10 +24,10 @@ def main():
         pms, stores, forces = [], [], []
         for r in range(P):
             x = bench.make_particles(nc, N, L, P, r, device)
-            pm = PM(N, L, 64, nranks=P, rank=r, np_max=x.shape[0])
+            pm = PM(N, L, 64, nranks=P, rank=r, np_max=x.shape[0], gradient_mode=int(os.environ.get("FPM_VB_GRADIENT", "0")))
             pms.append(pm)
             stores.append(Store(x))
-            forces.append(SlabForce(pm))
+            forces.append(SlabForce(pm, chunks=int(os.environ.get("FPM_VB_CHUNKS", "4"))))
         run_virtual(forces, stores)                    # warm-up (rocFFT kernels are compiled here)
         torch.cuda.synchronize()
         for pm in pms:
@@ -41,7 +41,7 @@ def main():
         acc = torch.cat([s.acc for s in stores]).double()
         rms = float(acc.pow(2).mean().sqrt())
         mom = float(acc.sum(0).abs().max()) / (rms * len(acc) ** 0.5)
-        per_rank = sum(ms for ms, n in tm.values())
+        per_rank = sum(ms for name, (ms, n) in tm.items() if not name.startswith("k_"))     # k_* are nested timers
         print("P=%d nc=%d N=%d: staged_fft(own)=%s finite=%s momentum=%.2e | rank-0 compute %.2f ms/step "
               "(all %d ranks serialised incl. copies: %.1f ms) | %s" % (
                   P, nc, N, pms[0].staged_fft() and (N & (N - 1)) == 0, bool(torch.isfinite(acc).all()), mom, per_rank, P,
