@@ -103,7 +103,7 @@ def algorithmic_bytes(np_local, Nmesh, nranks, esize, gradient="kspace"):
 # the kernel each one is in the rocprofv3 trace
 KERNELS = {"paint": "fpm::paint_tiles_kernel", "readout": "fpm::readout3_tiles_kernel", "xback3": "fpm::colfft_xback3_kernel",
            "k_colfft": "fpm::colfft_kernel", "k_rowfft": "fpm::rowfft_r2c_kernel", "k_yback2": "fpm::colfft_yback2_kernel",
-           "k_zc2r": "rocFFT fft_rtc_back_len*_C2R (1-D c2r, z pass)", "transfer": "fpm::transfer_kernel"}
+           "k_zc2r": "fpm::rowfft_c2r_kernel", "transfer": "fpm::transfer_kernel"}
 STAGES_OF_KERNELS = {"k_colfft": "r2c/c2r", "k_rowfft": "r2c", "k_zc2r": "c2r", "k_yback2": "c2r"}
 
 
@@ -206,7 +206,7 @@ def main():
     ap.add_argument("--nc", type=int, default=0, help="override particles per side")
     ap.add_argument("--nmesh", type=int, default=0, help="override mesh per side")
     ap.add_argument("--paint-mode", type=int, default=0, help="0 tiled (default), 1 global atomics")
-    ap.add_argument("--fft-mode", type=int, default=0, help="0 auto (column FFT + rocFFT z pass), 1 rocFFT only")
+    ap.add_argument("--fft-mode", type=int, default=0, help="0 auto (hand-written row and column passes), 1 rocFFT only")
     ap.add_argument("--load", default="a", choices=["a", "b", "c"],
                     help="a: lattice + 0.3-cell jitter (default); b: clustered (rms 4 cells); c: adversarial (1 GPU only)")
     ap.add_argument("--gradient", default="kspace", choices=["kspace", "real"],
@@ -346,7 +346,7 @@ def main():
                 "gradient": {"kspace": "k space, 3 inverse FFTs (the reference's arithmetic)",
                              "real": "real space, 1 inverse FFT + stencil readout (FPMHIP_GRADIENT_REAL)"}[args.gradient],
                 "paint_mode": "tiled" if args.paint_mode == 0 else "atomic",
-                "fft": "column passes + rocFFT z" if pm.staged_fft() and args.fft_mode == 0 else "rocFFT"},
+                "fft": "hand-written row + column passes" if pm.column_fft() else "rocFFT"},
             "per_gpu": value / world, "finite": acc_ok,
             # rank 0: time inside this library's kernels vs the rest of the step (for N > 1 the rest is
             # the RCCL all-to-alls / halo shifts that are not hidden behind compute)

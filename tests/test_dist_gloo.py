@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, N, L, x, out_dir, gradient_mode=0):
+def _worker(rank, world, port, N, L, x, out_dir, gradient_mode=0, chunks=4):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -36,7 +36,8 @@ def _worker(rank, world, port, N, L, x, out_dir, gradient_mode=0):
     idx = np.nonzero(owner == rank)[0]
     ops = CpuSlabOps(N, L, world, rank, gradient_mode=gradient_mode)
     store = Store(x[idx], potential=True, device="cpu")
-    force = SlabForce(ops, dist.group.WORLD)
+    force = SlabForce(ops, dist.group.WORLD, chunks=chunks)
+    assert len(force._ranges()) == (chunks if chunks > 1 else 1)
     dk = force.compute_force(store, kernel="1_4", dealias="gaussian")
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), idx=idx, acc=store.acc.numpy(),
              pot=store.potential.numpy(), dk=ops._cplx(dk, (N, ops.yl, ops.nzc)))
@@ -44,12 +45,14 @@ def _worker(rank, world, port, N, L, x, out_dir, gradient_mode=0):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_slab_force_over_gloo_matches_one_rank_oracle(oracle, tmp_path, world):
+@pytest.mark.parametrize("world,chunks", [(2, 4), (4, 4), (2, 1), (4, 2)])
+def test_slab_force_over_gloo_matches_one_rank_oracle(oracle, tmp_path, world, chunks):
+    """chunks > 1: the transposes are cut into plane ranges (batched isend / irecv per range, asynchronous);
+    chunks = 1: one all_to_all_single per transform."""
     N, nc, L = 16, 8, 24.0
     x = util.load_b(nc, L, N, rms_cells=2.0)
     ref = oracle.compute_force(oracle.PMOracle(N, L, 64), x, softening=oracle.SOFTENINGS["gaussian"], potential=True)
-    mp.spawn(_worker, args=(world, _free_port(), N, L, x, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), N, L, x, str(tmp_path), 0, chunks), nprocs=world, join=True)
     acc = np.zeros_like(ref["acc"])
     pot = np.zeros_like(ref["potential"])
     dks = []

@@ -40,6 +40,24 @@ for w in dist.batch_isend_irecv(ops):
     w.wait()
 assert all(torch.equal(x, y) for x, y in zip(send, recv))
 
+# the per-range exchange of the pipelined transposes: slices of big buffers, asynchronous, several batches queued
+big_s = torch.arange(1 << 20, dtype=torch.float64, device=dev)
+big_r = torch.zeros(1 << 20, dtype=torch.float64, device=dev)
+pending = []
+for c in range(4):
+    ops = []
+    for peer in range(P):
+        s_, r_ = big_s[c * 1000 + peer * 5000: c * 1000 + peer * 5000 + 1000], big_r[c * 1000 + peer * 5000: c * 1000 + peer * 5000 + 1000]
+        if peer == r:
+            r_.copy_(s_)
+        else:
+            ops += [dist.P2POp(dist.isend, s_, peer, group=g), dist.P2POp(dist.irecv, r_, peer, group=g)]
+    pending.append(dist.batch_isend_irecv(ops) if ops else [])
+for ws in pending:
+    for w in ws:
+        w.wait()
+assert torch.equal(big_r[:4000], big_s[:4000])
+
 cnt = torch.tensor([7], dtype=torch.int64, device=dev)
 got = torch.zeros_like(cnt)
 dist.all_to_all_single(got, cnt, group=g)

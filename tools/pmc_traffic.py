@@ -51,12 +51,12 @@ def main():
         "k_yback2": hbm("yback2"),
         "k_colfft": hbm("colfft_kernel<%s" % N),
         "k_rowfft": hbm("rowfft_r2c"),
-        "k_zc2r": hbm("C2R"),
+        "k_zc2r": hbm("rowfft_c2r") or hbm("C2R"),
         "transfer": hbm("transfer_kernel"),
     }
     gradient = sys.argv[9] if len(sys.argv) > 9 else "kspace"
     out = {"config": {"nmesh": int(nmesh), "particles": int(npart), "precision": int(prec), "n_gpus": 1,
-                      "fft": "column passes + rocFFT z", "gradient": gradient},
+                      "fft": "hand-written row + column passes", "gradient": gradient},
            "method": __doc__.split("usage")[0].strip(),
            "hbm_bytes_per_launch_by_stage": {k: v for k, v in stage.items() if v is not None},
            "kernels": kern}
