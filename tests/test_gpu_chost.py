@@ -151,3 +151,34 @@ def test_c_host_slab_force_matches_one_rank_oracle(oracle, N, P, kernel, gradien
     assert util.rel_err(pot, ref["potential"]) <= 1e-6
     for pm in pms:
         pm.destroy()
+
+
+@pytest.mark.gpu
+def test_plain_c_program_runs_the_force(oracle, tmp_path):
+    """fastpm_amd/host/example_force.c: gcc, no Python in the process -- the C host library and the HIP library
+    only.  Its printed accelerations must be the oracle's for the same (closed-form) particle positions."""
+    import subprocess
+    host = os.path.join(ROOT, "fastpm_amd", "host")
+    exe = str(tmp_path / "example_force")
+    subprocess.run(["gcc", "-std=gnu99", "-O2", "-I" + os.path.join(ROOT, "include"), "-I" + host,
+                    os.path.join(host, "example_force.c"), "-L" + os.path.join(ROOT, "fastpm_amd"),
+                    "-lfastpm_hip_host", "-lfastpm_hip", "-lm", "-Wl,-rpath," + os.path.join(ROOT, "fastpm_amd"),
+                    "-o", exe], check=True)
+    nc, B = 24, 2
+    r = subprocess.run([exe, str(nc), str(B), "64"], capture_output=True, text=True, check=True)
+    lines = {l.split()[0] + (l.split()[1] if l.startswith("acc std") else ""): l.split() for l in r.stdout.splitlines()}
+    L, h = 3.0 * nc, 3.0
+    A, k = 0.35 * h, 2 * np.pi / L
+    g = (np.arange(nc) + 0.5) * h
+    q = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
+    x = np.empty_like(q)
+    x[:, 0] = np.fmod(q[:, 0] + A * np.sin(2 * k * q[:, 0]) * np.cos(k * q[:, 1]) + L, L)
+    x[:, 1] = np.fmod(q[:, 1] + A * np.sin(3 * k * q[:, 1]) * np.cos(k * q[:, 2]) + L, L)
+    x[:, 2] = np.fmod(q[:, 2] + A * np.sin(k * q[:, 2]) * np.cos(2 * k * q[:, 0]) + L, L)
+    ref = oracle.compute_force(oracle.PMOracle(nc * B, L, 64), x)["acc"].astype(np.float64)
+    std = np.sqrt((ref ** 2).mean(0) - ref.mean(0) ** 2)
+    got = np.array([float(v) for v in lines["accstd"][2:5]])
+    assert np.allclose(got, std, rtol=1e-6), (got, std)
+    for i in range(4):
+        row = np.array([float(v) for v in lines["acc[%d]" % i][1:4]])
+        assert np.abs(row - ref[i]).max() <= 1e-6 * np.abs(ref).max()
