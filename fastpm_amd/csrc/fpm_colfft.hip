@@ -558,6 +558,13 @@ template <typename K> static int set_lds(K kernel, size_t bytes)
     default: FPM_FAIL(-1, "column FFT: unsupported length %d", (int) (N_)); \
     }
 
+// fp32 meshes: 16 columns per workgroup (one 128-B line per row) unless FPMHIP_NARROW is set (A/B: 8 columns)
+static bool narrow_tiles()
+{
+    static const bool narrow = getenv("FPMHIP_NARROW") != nullptr;
+    return narrow;
+}
+
 bool colfft_supported(int N)
 {
     static const int ok[] = {16, 32, 48, 64, 80, 96, 128, 160, 192, 256, 320, 384, 400, 512, 640, 768, 800, 1024};
@@ -574,7 +581,7 @@ static int colfft_launch(fpmhip_plan *p, int dir, const void *in, void *out, con
     // one 128-B line per row: 8 columns of complex<double>, 16 of complex<float> (while the
     // workgroup still fits 1024 threads)
     constexpr int CW = (sizeof(F) == 4) ? 16 : 8;
-    const bool wide = sizeof(F) == 4 && N <= 512 && !getenv("FPMHIP_NARROW");
+    const bool wide = sizeof(F) == 4 && N <= 512 && !narrow_tiles();
     const int cw = wide ? CW : 8;
     const int tpb = (ncols + cw - 1) / cw;
     const int ntiles = tpb * nbatch;
@@ -639,7 +646,7 @@ static int yback2_launch(fpmhip_plan *p, const void *in, void *oy, void *oz, con
     StageTimer ktm(p, FPMHIP_T_K_YBACK2);
     const int N = p->mg.N;
     constexpr int CW = (sizeof(F) == 4) ? 16 : 8;
-    const bool wide = sizeof(F) == 4 && N <= 512 && !getenv("FPMHIP_NARROW");
+    const bool wide = sizeof(F) == 4 && N <= 512 && !narrow_tiles();
     const int cw = wide ? CW : 8;
     const int tpb = (ncols + cw - 1) / cw;
     const int ntiles = tpb * nbatch;
@@ -746,7 +753,7 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
     const int N = g.N;
     const long long plane = (long long) g.yl * g.nzc;
     constexpr int CW = (sizeof(F) == 4) ? 16 : 8;
-    const bool wide = sizeof(F) == 4 && N <= 512 && !getenv("FPMHIP_NARROW");
+    const bool wide = sizeof(F) == 4 && N <= 512 && !narrow_tiles();
     const int cw = wide ? CW : 8;
     const int ntiles = (int) ((plane + cw - 1) / cw);
     const size_t lds = (size_t) N * cw * sizeof(C2<F>) + (size_t) N * sizeof(C2<F>);
