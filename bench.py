@@ -223,11 +223,18 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # dry run of the N > 1 code path where RCCL cannot run (all ranks on ONE GPU, exchanges staged through the host
+    # over gloo): FPM_BENCH_BACKEND=gloo FPM_BENCH_SHARE_GPU=1.  Never the measured configuration.
+    backend = os.environ.get("FPM_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("FPM_BENCH_SHARE_GPU") else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from fastpm_amd import PM, Store
 
@@ -280,7 +287,7 @@ def main():
         tm = pm.timings()
         pm.timing_enable(False)
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return pm, store, dt, tm
@@ -295,6 +302,7 @@ def main():
         pm2, store2, dt2, tm2 = timed_run(other)
         dev = torch.stack([(store2.acc - store.acc).abs().max(), store.acc.abs().max()]).to(torch.float64)
         if world > 1:
+            dev = dev if backend == "nccl" else dev.cpu()
             dist.all_reduce(dev, op=dist.ReduceOp.MAX)
         alt = {"gradient": other, "ms_per_step": dt2 / args.steps * 1e3, "value": np_total * args.steps / dt2,
                "kernel_ms_per_step": round(sum(tm2[n][0] for n in ("sort", "paint", "r2c", "dealias", "transfer", "c2r",

@@ -43,6 +43,11 @@ class _SlabRank:
     def _communicate(self, req):
         kind = req[0]
         g = self.group
+        if kind == "wait" and not self._pending.get(req[1]):
+            self._pending.pop(req[1], None)
+            return
+        if self._host_staged(req):
+            return self._communicate_staged(req)
         if kind == "allreduce":
             dist.all_reduce(req[1], op=dist.ReduceOp.SUM, group=g)
         elif kind == "alltoall":
@@ -75,6 +80,55 @@ class _SlabRank:
                 ops.append(dist.P2POp(dist.irecv, recv, _global_rank(g, src), group=g))
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+        else:
+            raise ValueError(kind)
+
+
+    # -- device tensors over a backend that only moves host memory (gloo): staged through the host, blocking.
+    #    Lets the multi-rank code path run where RCCL cannot (e.g. every rank on one GPU); never used with nccl.
+    def _host_staged(self, req):
+        t = req[1] if torch.is_tensor(req[1]) else (req[1][0][0] if req[0] == "shift" else None)
+        return t is not None and t.is_cuda and dist.get_backend(self.group) == "gloo"
+
+    def _communicate_staged(self, req):
+        kind = req[0]
+        g = self.group
+        if kind == "allreduce":
+            h = req[1].cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=g)
+            req[1].copy_(h)
+        elif kind in ("alltoall", "alltoall_start"):
+            n = self.pm.exchange_chunk_elems() * self.P
+            s = req[2][:n].cpu()
+            r = torch.empty_like(s)
+            dist.all_to_all_single(r, s, group=g)
+            req[1][:n].copy_(r)
+            if kind == "alltoall_start":
+                self._pending[req[3]] = []
+        elif kind == "alltoall_range_start":
+            _, recv, send, x0, nx, tag = req
+            sv, rv = _range_views(self.pm, send, x0, nx), _range_views(self.pm, recv, x0, nx)
+            s = torch.cat([v.cpu() for v in sv])
+            r = torch.empty_like(s)
+            dist.all_to_all_single(r, s, group=g)
+            for v, piece in zip(rv, r.chunk(self.P)):
+                v.copy_(piece)
+            self._pending[tag] = []
+        elif kind == "shift":
+            ops, back = [], []
+            for send, recv, direction in req[1]:
+                dst = (self.rank + direction) % self.P
+                src = (self.rank - direction) % self.P
+                hr = torch.empty(recv.shape, dtype=recv.dtype)
+                ops.append(dist.P2POp(dist.isend, send.cpu(), _global_rank(g, dst), group=g))
+                ops.append(dist.P2POp(dist.irecv, hr, _global_rank(g, src), group=g))
+                back.append((recv, hr))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            for recv, hr in back:
+                recv.copy_(hr)
+        elif kind == "wait":
+            self._pending.pop(req[1], None)
         else:
             raise ValueError(kind)
 

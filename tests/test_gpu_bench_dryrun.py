@@ -1,0 +1,28 @@
+"""bench.py's N > 1 code path (one process per rank, SlabForce over torch.distributed, the alt leg, the JSON line)
+run end to end on the 1-GPU box: two and four ranks share the GPU and the exchanges are staged through the host
+over gloo (FPM_BENCH_BACKEND=gloo FPM_BENCH_SHARE_GPU=1) -- RCCL refuses two ranks on one device.  The numbers it
+prints are not measurements; the accelerations of the two gradient modes must agree and everything must be
+finite."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("nranks,port", [(2, 29611), (4, 29612)])
+def test_multi_rank_bench_path(nranks, port):
+    env = dict(os.environ, FPM_BENCH_BACKEND="gloo", FPM_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", str(nranks), "--steps", "2", "--warmup", "1", "--nc", "64", "--nmesh", "128"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == nranks and d["finite"] and d["scaling"] == "weak" and d["config"]["particles"] == 64 ** 3
+    assert d["value"] > 0 and d["roofline"]["bound"] == "hbm"
+    assert d["other_gradient_mode"]["acc_max_abs_dev_over_max_abs_acc"] < 2e-7
