@@ -82,7 +82,8 @@ def algorithmic_bytes(np_local, Nmesh, nranks, esize, gradient="kspace"):
     s = esize
     if gradient == "real":                               # one potential mesh instead of three force meshes
         return {"sort": 52 * np_local, "paint": 24 * np_local + s * nr, "r2c": 2 * s * nr, "c2r": 2 * s * nr,
-                "readout": s * nr + 36 * np_local, "xback3": 2 * s * nr,
+                # one rank: the forward x pass is fused in (reads the y pass' output, writes delta_k + potential)
+                "readout": s * nr + 36 * np_local, "xback3": (3 if nranks == 1 else 2) * s * nr,
                 "k_colfft": 2 * s * nr, "k_rowfft": 2 * s * nr, "k_zc2r": 2 * s * nr}
     return {
         "sort": 24 * np_local + 28 * np_local,           # read x, write binned x + index (our addition)
@@ -91,8 +92,9 @@ def algorithmic_bytes(np_local, Nmesh, nranks, esize, gradient="kspace"):
         "transfer": 2 * s * nr,                          # K7
         "c2r": 2 * s * nr,                               # K8
         "readout": 3 * s * nr + 36 * np_local,           # K9 fused over the 3 components
-        "xback3": 3 * s * nr,                            # fused K7 + x pass of K8 for the x component and the
-                                                         # potential: 1 read, 2 writes (4 s nr with FPMHIP_XBACK3=1)
+        # fused K7 + x pass of K8 for the x component and the potential: 1 read, 2 writes; on one rank the forward
+        # x pass of K5 is fused in as well (1 read, delta_k + 2 writes)
+        "xback3": (4 if nranks == 1 else 3) * s * nr,
         # single kernels (nested timers): one pass of the 3-pass FFT reads and writes the mesh once
         "k_colfft": 2 * s * nr, "k_rowfft": 2 * s * nr, "k_zc2r": 2 * s * nr,
         "k_yback2": 3 * s * nr,                          # potential in, y and z components out

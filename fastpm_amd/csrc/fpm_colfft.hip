@@ -284,13 +284,17 @@ __global__ __launch_bounds__(N / 8 * CW) void colfft_kernel(const C2<F> *__restr
 // MODE 2: two outputs, o0 = the x component and o1 = the potential: the y and z gradient factors depend
 //         on ky / kz only, commute with the x transform and are applied by colfft_yback2_kernel after the
 //         transpose -- one mesh less to write here and, on slabs, one all-to-all less.
-template <int N, int R2, int R3, int R4, int CW, int MODE, typename F>
-__global__ __launch_bounds__(N / 8 * CW, 4) void colfft_xback3_kernel(const C2<F> *__restrict__ dk, C2<F> *__restrict__ o0,
+// FWD (one rank, no softening between r2c and transfer): `dk` holds the output of the forward y pass; the
+//   kernel first runs the forward x pass (x fwd_scale, as colfft_kernel would), stores delta_k over its input
+//   and carries on from registers -- delta_k is written once and never re-read (one mesh sweep less).
+template <int N, int R2, int R3, int R4, int CW, int MODE, bool FWD, typename F>
+__global__ __launch_bounds__(N / 8 * CW, 4) void colfft_xback3_kernel(const C2<F> *dk, C2<F> *__restrict__ o0,
                                                              C2<F> *__restrict__ o1, C2<F> *__restrict__ o2,
                                                              long long rstride, int ncols, int nzc, int ystart,
                                                              int ntiles, const float *__restrict__ kk,
                                                              const float *__restrict__ kt,
-                                                             const double *__restrict__ tw_global)
+                                                             const double *__restrict__ tw_global,
+                                                             C2<F> *dk_store, F fwd_scale)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     C2<F> *lds = (C2<F> *) smem;
@@ -308,6 +312,19 @@ __global__ __launch_bounds__(N / 8 * CW, 4) void colfft_xback3_kernel(const C2<F
 #pragma unroll
     for (int j = 0; j < EPT; j++) b[j] = live ? (dk + j * jstride)[toff] : C2<F>{0, 0};
     stage_twiddles(tw, tw_global, N);
+    if (FWD) {
+        C2<F> v[VMAX];
+#pragma unroll
+        for (int j = 0; j < EPT; j++) v[j] = b[j];
+        __syncthreads();
+        fft_core<N, R2, R3, R4, -1, CW>(v, lds, tw, tau, c);
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+            b[j] = v[j];
+            if (fwd_scale != (F) 1) { b[j].x *= fwd_scale; b[j].y *= fwd_scale; }       // as colfft_kernel
+            if (live) (dk_store + j * jstride)[toff] = b[j];
+        }
+    }
     const int iyl = live ? col / nzc : 0, iz = live ? col - iyl * nzc : 0;
     const int iy = iyl + ystart;
     const double kky = kk[iy], kkz = kk[iz];
@@ -747,7 +764,7 @@ int rowfft_c2r_range(fpmhip_plan *p, void *buf, int x0, int nx)
 
 template <typename F>
 static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, void *o2, int potorder, int gradorder,
-                         int mode)
+                         int mode, bool fwd = false, double fwd_scale = 1.0)
 {
     const MeshGeo &g = p->mg;
     const int N = g.N;
@@ -760,11 +777,13 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
     const float *kk = p->d_tab + (2 + potorder) * (size_t) N;
     const float *kt = p->d_tab + gradorder * (size_t) N;
     const int grid = ntiles;
-#define CALL_X3_P(n, r2, r3, r4, W, P)                                                                       \
-    FPM_TRY(set_lds(colfft_xback3_kernel<n, r2, r3, r4, W, P, F>, lds));                                     \
-    colfft_xback3_kernel<n, r2, r3, r4, W, P, F><<<grid, n / 8 * W, lds, p->stream>>>(                       \
+#define CALL_X3_Q(n, r2, r3, r4, W, P, Q)                                                                    \
+    FPM_TRY(set_lds(colfft_xback3_kernel<n, r2, r3, r4, W, P, Q, F>, lds));                                  \
+    colfft_xback3_kernel<n, r2, r3, r4, W, P, Q, F><<<grid, n / 8 * W, lds, p->stream>>>(                    \
         (const C2<F> *) dk, (C2<F> *) o0, (C2<F> *) o1, (C2<F> *) o2, plane, (int) plane, g.nzc, g.ystart,  \
-        ntiles, kk, kt, p->d_twiddle);
+        ntiles, kk, kt, p->d_twiddle, (C2<F> *) dk, (F) fwd_scale);
+#define CALL_X3_P(n, r2, r3, r4, W, P)                                                                       \
+    if (fwd) { CALL_X3_Q(n, r2, r3, r4, W, P, true) } else { CALL_X3_Q(n, r2, r3, r4, W, P, false) }
 #define CALL_X3_W(n, r2, r3, r4, W)                                                                          \
     if (mode == 1) { CALL_X3_P(n, r2, r3, r4, W, 1) } else if (mode == 2) { CALL_X3_P(n, r2, r3, r4, W, 2) }   \
     else { CALL_X3_P(n, r2, r3, r4, W, 0) }
@@ -774,6 +793,7 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
 #undef CALL_X3
 #undef CALL_X3_W
 #undef CALL_X3_P
+#undef CALL_X3_Q
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -788,6 +808,15 @@ int colfft_xback_pot(fpmhip_plan *p, const void *dk, void *out, int potorder)
 {
     return p->f64 ? xback3_launch<double>(p, dk, out, out, out, potorder, 0, 1)
                   : xback3_launch<float>(p, dk, out, out, out, potorder, 0, 1);
+}
+
+// forward x pass (x scale) + transfer + backward x pass(es) from ONE read of the forward y pass' output, which
+// delta_k overwrites in place.  mode as colfft_xback3_kernel's MODE.
+int colfft_xfwd_xback(fpmhip_plan *p, void *dk_inout, void *o0, void *o1, void *o2, int potorder, int gradorder,
+                      int mode, double scale)
+{
+    return p->f64 ? xback3_launch<double>(p, dk_inout, o0, o1, o2, potorder, gradorder, mode, true, scale)
+                  : xback3_launch<float>(p, dk_inout, o0, o1, o2, potorder, gradorder, mode, true, scale);
 }
 
 int colfft_xback_potx(fpmhip_plan *p, const void *dk, void *out_x, void *out_pot, int potorder, int gradorder)

@@ -335,6 +335,29 @@ int fpmhip_r2c(fpmhip_plan *p, void *canvas, void *delta_k)
     return fft_exec(p, p->p_r2c3d, canvas, delta_k);
 }
 
+// pm_r2c and the x pass of the inverse transforms of the force in one go (one rank, column-FFT back end, no
+// softening in between): delta_k = r2c(canvas) is written once and not read again.
+//   mode 0: out0..2 = the three ACC components      (then fpmhip_fft_yz_backward on each)
+//   mode 1: out0 = the potential                    (FPMHIP_GRADIENT_REAL: fft_yz_backward, readout_grad)
+//   mode 2: out0 = the x component, out1 = potential (fft_yz_backward(out0), fft_yz_backward_grad2(out1 -> y, z))
+int fpmhip_r2c_transfer_fft_x_backward(fpmhip_plan *p, void *canvas, void *delta_k, int kernel, int mode,
+                                       void *out0, void *out1, void *out2)
+{
+    if (!p || !canvas || !delta_k || !out0) FPM_FAIL(-1, "null argument");
+    if (p->lay.nranks != 1 || !p->own_fft) FPM_FAIL(-1, "r2c_transfer_fft_x_backward: one rank with the column-FFT back end");
+    if (canvas == delta_k) FPM_FAIL(-1, "pm_r2c is out of place (pmapi.h:97-100)");
+    if (mode < 0 || mode > 2 || (mode != 1 && !out1) || (mode == 0 && !out2)) FPM_FAIL(-1, "bad mode / outputs");
+    int po, go, dfo, dc;
+    FPM_TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));
+    {
+        StageTimer tm(p, FPMHIP_T_R2C);
+        FPM_TRY(zy_forward(p, canvas, delta_k, delta_k, 0));
+    }
+    StageTimer tm(p, FPMHIP_T_XBACK3);
+    return colfft_xfwd_xback(p, delta_k, out0, mode == 1 ? out0 : out1, mode == 0 ? out2 : (mode == 1 ? out0 : out1),
+                             po, go, mode, 1.0 / p->lay.Norm);
+}
+
 int fpmhip_c2r(fpmhip_plan *p, void *inplace)
 {
     if (!p || !inplace) FPM_FAIL(-1, "null argument");

@@ -89,15 +89,22 @@ int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets
     const double mean_mass_per_cell = total_mass / p->lay.Norm;                           // gravity.c:342
     FPM_TRY(fpmhip_paint(p, pt, 1.0 / mean_mass_per_cell, canvas));                       // gravity.c:336-345
     for (int si = 1; si < nsets; si++) FPM_TRY(fpmhip_paint_add(p, &sets[si], 1.0 / mean_mass_per_cell, canvas));
-    FPM_TRY(fpmhip_r2c(p, canvas, delta_k));                                              // gravity.c:351
-    FPM_TRY(fpmhip_softening(p, delta_k, softening));                                     // gravity.c:476
+    // Without a softening kernel between them, the forward x pass runs straight on into the transfer and the
+    // backward x pass(es) (fpmhip_r2c_transfer_fft_x_backward): delta_k is stored once and not read again.
+    static const bool nofuse = getenv("FPMHIP_NOFUSE") != nullptr;                        // A/B
+    const bool fuse_x = p->own_fft && softening == FPMHIP_SOFTENING_NONE && !nofuse;
+    if (!fuse_x) {
+        FPM_TRY(fpmhip_r2c(p, canvas, delta_k));                                          // gravity.c:351
+        FPM_TRY(fpmhip_softening(p, delta_k, softening));                                 // gravity.c:476
+    }
 
     bool any_pot = false;
     for (int si = 0; si < nsets; si++) any_pot = any_pot || sets[si].potential != nullptr;
     if (real_grad) {
         // the canvas is free again after the out-of-place r2c: it carries the potential
         if (p->own_fft) {
-            FPM_TRY(fpmhip_transfer_fft_x_backward_pot(p, delta_k, canvas, kernel));
+            if (fuse_x) FPM_TRY(fpmhip_r2c_transfer_fft_x_backward(p, canvas, delta_k, kernel, 1, canvas, nullptr, nullptr));
+            else FPM_TRY(fpmhip_transfer_fft_x_backward_pot(p, delta_k, canvas, kernel));
             FPM_TRY(fpmhip_fft_yz_backward(p, canvas, canvas));
         } else {
             FPM_TRY(fpmhip_transfer(p, delta_k, canvas, kernel, FPMHIP_FIELD_POTENTIAL));
@@ -115,12 +122,14 @@ int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets
     if (p->own_fft && go == 1 && !three) {
         // one sweep over delta_k: the x component and the potential through their x passes; the y and
         // z gradient factors are applied to the potential in its y pass (they do not depend on kx)
-        FPM_TRY(fpmhip_transfer_fft_x_backward_potx(p, delta_k, f[0], f[1], kernel));
+        if (fuse_x) FPM_TRY(fpmhip_r2c_transfer_fft_x_backward(p, canvas, delta_k, kernel, 2, f[0], f[1], nullptr));
+        else FPM_TRY(fpmhip_transfer_fft_x_backward_potx(p, delta_k, f[0], f[1], kernel));
         FPM_TRY(fpmhip_fft_yz_backward(p, f[0], f[0]));
         FPM_TRY(fpmhip_fft_yz_backward_grad2(p, f[1], f[1], f[2], kernel));
     } else if (p->own_fft) {
         // one sweep over delta_k: the three transfers + the x pass of their inverse transforms
-        FPM_TRY(fpmhip_transfer_fft_x_backward3(p, delta_k, f[0], f[1], f[2], kernel));
+        if (fuse_x) FPM_TRY(fpmhip_r2c_transfer_fft_x_backward(p, canvas, delta_k, kernel, 0, f[0], f[1], f[2]));
+        else FPM_TRY(fpmhip_transfer_fft_x_backward3(p, delta_k, f[0], f[1], f[2], kernel));
         for (int d = 0; d < 3; d++) FPM_TRY(fpmhip_fft_yz_backward(p, f[d], f[d]));
     } else {
         for (int d = 0; d < 3; d++) {                                                     // gravity.c:373-397

@@ -170,6 +170,8 @@ bool rowfft_supported(int N);
 int rowfft_r2c(fpmhip_plan *p, const void *in, void *out);
 int colfft_xback3(fpmhip_plan *p, const void *dk, void *o0, void *o1, void *o2, int potorder, int gradorder);
 int colfft_xback_pot(fpmhip_plan *p, const void *dk, void *out, int potorder);
+int colfft_xfwd_xback(fpmhip_plan *p, void *dk_inout, void *o0, void *o1, void *o2, int potorder, int gradorder,
+                      int mode, double scale);
 int colfft_xback_potx(fpmhip_plan *p, const void *dk, void *out_x, void *out_pot, int potorder, int gradorder);
 int rowfft_c2r_range(fpmhip_plan *p, void *buf, int x0, int nx);
 int colfft_yback2(fpmhip_plan *p, const void *in, void *oy, void *oz, int chunked, int gradorder);

@@ -200,6 +200,13 @@ int fpmhip_transfer_fft_x_backward3(fpmhip_plan *plan, const void *delta_k_dev, 
 int fpmhip_transfer_fft_x_backward_potx(fpmhip_plan *plan, const void *delta_k_dev, void *out_x_dev,
                                         void *out_pot_dev, int kernel);
 int fpmhip_fft_yz_backward_grad2(fpmhip_plan *plan, void *recv_dev, void *out_y_dev, void *out_z_dev, int kernel);
+/* One rank, column-FFT back end, no softening: pm_r2c AND the transfer + x pass of the inverse transforms in one
+ * go -- the forward x pass keeps delta_k's columns in registers, stores delta_k once and continues into the
+ * transfer, so delta_k is never re-read.  mode 0: out0..2 = the three ACC components; mode 1: out0 = potential;
+ * mode 2: out0 = x component, out1 = potential.  Same arithmetic as fpmhip_r2c followed by the matching
+ * fpmhip_transfer_fft_x_backward*.  fpmhip_force uses it when softening == FPMHIP_SOFTENING_NONE. */
+int fpmhip_r2c_transfer_fft_x_backward(fpmhip_plan *plan, void *canvas_dev, void *delta_k_dev, int kernel, int mode,
+                                       void *out0_dev, void *out1_dev, void *out2_dev);
 /* The COLUMN_POTENTIAL transfer (gravity.c:188-190) and the x pass of its inverse transform in one
  * sweep; follow with fpmhip_fft_yz_backward and fpmhip_readout_grad (FPMHIP_GRADIENT_REAL). */
 int fpmhip_transfer_fft_x_backward_pot(fpmhip_plan *plan, const void *delta_k_dev, void *out_dev, int kernel);
