@@ -358,6 +358,22 @@ int fpmhip_r2c_transfer_fft_x_backward(fpmhip_plan *p, void *canvas, void *delta
                              po, go, mode, 1.0 / p->lay.Norm);
 }
 
+// The same fusion for the staged transforms (any nranks): recv = what the forward all-to-all delivered (or the
+// forward (y,z) passes' output on one rank); on return it holds delta_k, and out* the x passes of the inverse
+// transforms.  Equals fpmhip_fft_x_forward followed by the matching fpmhip_transfer_fft_x_backward*.
+int fpmhip_fft_x_forward_transfer_backward(fpmhip_plan *p, void *recv, int kernel, int mode, void *out0, void *out1,
+                                           void *out2)
+{
+    if (!p || !recv || !out0) FPM_FAIL(-1, "null argument");
+    if (!p->own_fft) FPM_FAIL(-1, "fft_x_forward_transfer_backward needs the column-FFT back end");
+    if (mode < 0 || mode > 2 || (mode != 1 && !out1) || (mode == 0 && !out2)) FPM_FAIL(-1, "bad mode / outputs");
+    int po, go, dfo, dc;
+    FPM_TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));
+    StageTimer tm(p, FPMHIP_T_XBACK3);
+    return colfft_xfwd_xback(p, recv, out0, mode == 1 ? out0 : out1, mode == 0 ? out2 : (mode == 1 ? out0 : out1),
+                             po, go, mode, 1.0 / p->lay.Norm);
+}
+
 int fpmhip_c2r(fpmhip_plan *p, void *inplace)
 {
     if (!p || !inplace) FPM_FAIL(-1, "null argument");

@@ -186,11 +186,14 @@ class SlabForce(_SlabRank):
                 yield ("alltoall_range_start", delta_k, self.work, x0, nx, ("fwd", i))
             for i in range(len(ranges)):
                 yield ("wait", ("fwd", i))
-        pm.fft_x_forward(delta_k)
-        pm.apply_softening_transfer(dealias, delta_k)                     # gravity.c:476
+        # without a softening kernel the forward x pass, the transfer and the backward x pass(es) are one kernel
+        fuse_x = dealias == 0 and pm.column_fft() and not self.three_transposes
+        if not fuse_x:
+            pm.fft_x_forward(delta_k)
+            pm.apply_softening_transfer(dealias, delta_k)                 # gravity.c:476
 
         if self.real_gradient and _gradorder(kernel) == 1:
-            yield from self._real_gradient_force(store, kernel, delta_k)
+            yield from self._real_gradient_force(store, kernel, delta_k, fuse_x)
             return
 
         if self.work2 is None:
@@ -201,7 +204,10 @@ class SlabForce(_SlabRank):
             # force[1], which is free once every range of the potential has arrived.
             if self.extra is None:
                 self.extra = pm.alloc()
-            pm.transfer_fft_x_backward_potx(kernel, delta_k, self.force[0], self.force[1])
+            if fuse_x:
+                pm.fft_x_forward_transfer_backward(kernel, delta_k, 2, [self.force[0], self.force[1]])
+            else:
+                pm.transfer_fft_x_backward_potx(kernel, delta_k, self.force[0], self.force[1])
             for i, (x0, nx) in enumerate(ranges):
                 yield ("alltoall_range_start", self.work2, self.force[1], x0, nx, ("pot", i))
             for i, (x0, nx) in enumerate(ranges):
@@ -225,7 +231,10 @@ class SlabForce(_SlabRank):
             # gravity.c:373-397 with TWO meshes through the transpose instead of three: the x component
             # and the potential; the y and z gradient factors depend on ky / kz only, so they are applied
             # to the potential after its x transform and transpose, in its y pass (same float32 factors)
-            pm.transfer_fft_x_backward_potx(kernel, delta_k, self.force[0], self.force[1])
+            if fuse_x:
+                pm.fft_x_forward_transfer_backward(kernel, delta_k, 2, [self.force[0], self.force[1]])
+            else:
+                pm.transfer_fft_x_backward_potx(kernel, delta_k, self.force[0], self.force[1])
             # the potential goes first: its y pass + two z passes (the larger share of the compute) then run
             # while the x component is still on xGMI
             yield ("alltoall_start", self.work2, self.force[1], 1)
@@ -245,7 +254,10 @@ class SlabForce(_SlabRank):
 
         # gravity.c:373-397: per component transfer -> c2r.  The three transfers and the x passes
         # come from ONE sweep over delta_k; then one transpose + (y,z) passes per component.
-        pm.transfer_fft_x_backward3(kernel, delta_k, self.force)
+        if fuse_x:
+            pm.fft_x_forward_transfer_backward(kernel, delta_k, 0, self.force)
+        else:
+            pm.transfer_fft_x_backward3(kernel, delta_k, self.force)
         # the transposes run on the collective's own stream: component d+1 is in flight over xGMI
         # while the (y,z) passes of component d run on the compute stream
         yield ("alltoall_start", self.work, self.force[0], 0)
@@ -267,7 +279,7 @@ class SlabForce(_SlabRank):
             yield ("shift", [(pm.plane(f, 0), pm.plane(f, xl), -1)])
             pm.readout(f, store, store.potential, 1, 0)
 
-    def _real_gradient_force(self, store, kernel, delta_k):
+    def _real_gradient_force(self, store, kernel, delta_k, fuse_x=False):
         """FPMHIP_GRADIENT_REAL: ONE inverse transform (the potential), then the stencil readout.  Two
         all-to-alls per force instead of four; the stencil reaches 2 planes below and 3 above the slab's
         base planes: plane xl goes to the canvas' halo plane, the other four to a side buffer."""
@@ -279,7 +291,10 @@ class SlabForce(_SlabRank):
         if self.halo is None:
             self.halo = torch.zeros(4 * pe, dtype=self.canvas.dtype, device=self.canvas.device)
         phi = self.canvas
-        pm.transfer_fft_x_backward_pot(kernel, delta_k, phi)
+        if fuse_x:
+            pm.fft_x_forward_transfer_backward(kernel, delta_k, 1, [phi])
+        else:
+            pm.transfer_fft_x_backward_pot(kernel, delta_k, phi)
         ranges = self._ranges()
         if len(ranges) == 1:
             yield ("alltoall", self.work, phi)

@@ -56,15 +56,20 @@ int fastpm_hip_slab_force(fpmhip_plan *plan, const fastpm_hip_transport *t, cons
     /* gravity.c:351 pm_r2c, gravity.c:476 softening */
     TRY(fpmhip_fft_yz_forward(plan, canvas, work));
     TRY(exchange(plan, t, work, delta_k, chunk_bytes));
-    TRY(fpmhip_fft_x_forward(plan, delta_k));
-    TRY(fpmhip_softening(plan, delta_k, softening));
+    /* without a softening kernel the forward x pass runs on into the transfer and the backward x pass(es) */
+    const int fuse_x = softening == FPMHIP_SOFTENING_NONE && fpmhip_plan_column_fft(plan);
+    if (!fuse_x) {
+        TRY(fpmhip_fft_x_forward(plan, delta_k));
+        TRY(fpmhip_softening(plan, delta_k, softening));
+    }
 
     if (lay.gradient_mode == FPMHIP_GRADIENT_REAL && go == 1) {
         /* one transposed mesh, the potential; planes xl | xl+1, xl+2 from rank + 1, planes -2, -1 from rank - 1 */
         if (xl < 3) return -3;
         void *halo = fpmhip_plan_buffer(plan, B_F1);            /* 4 planes of side buffer */
         void *phi = canvas;
-        TRY(fpmhip_transfer_fft_x_backward_pot(plan, delta_k, phi, kernel));
+        if (fuse_x) TRY(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 1, phi, NULL, NULL));
+        else TRY(fpmhip_transfer_fft_x_backward_pot(plan, delta_k, phi, kernel));
         TRY(exchange(plan, t, phi, work, chunk_bytes));
         TRY(fpmhip_fft_yz_backward(plan, work, phi));
         TRY(shift(plan, t, phi, 0, 1, fpmhip_plane_ptr(plan, phi, xl), -1, plane_bytes));
@@ -80,12 +85,17 @@ int fastpm_hip_slab_force(fpmhip_plan *plan, const fastpm_hip_transport *t, cons
     if (!f[1] || !f[2] || !work2) return -2;
     if (go == 1 && fpmhip_plan_column_fft(plan)) {
         /* two meshes through the transpose: the x component and the potential (see fastpm_hip.h) */
-        TRY(fpmhip_transfer_fft_x_backward_potx(plan, delta_k, f[0], f[1], kernel));
+        if (fuse_x) TRY(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 2, f[0], f[1], NULL));
+        else TRY(fpmhip_transfer_fft_x_backward_potx(plan, delta_k, f[0], f[1], kernel));
         TRY(exchange(plan, t, f[0], work, chunk_bytes));
         TRY(exchange(plan, t, f[1], work2, chunk_bytes));
         TRY(fpmhip_fft_yz_backward(plan, work, f[0]));
         TRY(fpmhip_fft_yz_backward_grad2(plan, work2, f[1], f[2], kernel));
     } else {
+        if (fuse_x) {
+            TRY(fpmhip_fft_x_forward(plan, delta_k));
+            TRY(fpmhip_softening(plan, delta_k, softening));
+        }
         for (int d = 0; d < 3; d++) {                           /* gravity.c:373-397 */
             TRY(fpmhip_transfer(plan, delta_k, f[d], kernel, d));
             TRY(fpmhip_fft_x_backward(plan, f[d]));

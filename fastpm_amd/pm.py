@@ -492,6 +492,13 @@ class PM:
         check(self._L.fpmhip_fft_yz_backward_grad2(self._plan, _ptr(recv), _ptr(out_y), _ptr(out_z),
                                                    _enum(KERNEL_TYPES, kernel)))
 
+    def fft_x_forward_transfer_backward(self, kernel, recv, mode, outs):
+        """fft_x_forward(recv) + transfer + the x pass(es) of the inverse transforms in one kernel (no softening in
+        between): mode 0 -> outs = 3 ACC components, 1 -> [potential], 2 -> [x component, potential]."""
+        o = [_ptr(t) for t in outs] + [None] * (3 - len(outs))
+        check(self._L.fpmhip_fft_x_forward_transfer_backward(self._plan, _ptr(recv), _enum(KERNEL_TYPES, kernel),
+                                                             int(mode), *o))
+
     def transfer_fft_x_backward_pot(self, kernel, delta_k, out):
         """The POTENTIAL transfer + the x pass of its inverse FFT (real-space-gradient mode)."""
         check(self._L.fpmhip_transfer_fft_x_backward_pot(self._plan, _ptr(delta_k), _ptr(out),

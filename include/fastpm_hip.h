@@ -207,6 +207,11 @@ int fpmhip_fft_yz_backward_grad2(fpmhip_plan *plan, void *recv_dev, void *out_y_
  * fpmhip_transfer_fft_x_backward*.  fpmhip_force uses it when softening == FPMHIP_SOFTENING_NONE. */
 int fpmhip_r2c_transfer_fft_x_backward(fpmhip_plan *plan, void *canvas_dev, void *delta_k_dev, int kernel, int mode,
                                        void *out0_dev, void *out1_dev, void *out2_dev);
+/* The same fusion for the staged transforms (any nranks, column-FFT back end): recv holds what the forward
+ * all-to-all delivered; on return it holds delta_k and out* the x passes of the inverse transforms (modes as above).
+ * Only valid when no softening kernel is to be applied to delta_k in between. */
+int fpmhip_fft_x_forward_transfer_backward(fpmhip_plan *plan, void *recv_inplace_dev, int kernel, int mode,
+                                           void *out0_dev, void *out1_dev, void *out2_dev);
 /* The COLUMN_POTENTIAL transfer (gravity.c:188-190) and the x pass of its inverse transform in one
  * sweep; follow with fpmhip_fft_yz_backward and fpmhip_readout_grad (FPMHIP_GRADIENT_REAL). */
 int fpmhip_transfer_fft_x_backward_pot(fpmhip_plan *plan, const void *delta_k_dev, void *out_dev, int kernel);

@@ -252,6 +252,15 @@ class CpuSlabOps:
             out.zero_()
             self._real(out)[:xl, :, :N] = scipy.fft.irfft2(v, s=(N, N), axes=(1, 2), norm="forward")
 
+    def fft_x_forward_transfer_backward(self, kernel, recv, mode, outs):
+        self.fft_x_forward(recv)
+        if mode == 0:
+            self.transfer_fft_x_backward3(kernel, recv, outs)
+        elif mode == 1:
+            self.transfer_fft_x_backward_pot(kernel, recv, outs[0])
+        else:
+            self.transfer_fft_x_backward_potx(kernel, recv, outs[0], outs[1])
+
     def transfer_fft_x_backward_pot(self, kernel, delta_k, out):
         self.gravity_apply_kernel_transfer(kernel, delta_k, out, 3)
         self.fft_x_backward(out)

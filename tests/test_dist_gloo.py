@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, N, L, x, out_dir, gradient_mode=0, chunks=4):
+def _worker(rank, world, port, N, L, x, out_dir, gradient_mode=0, chunks=4, dealias="gaussian"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -38,21 +38,22 @@ def _worker(rank, world, port, N, L, x, out_dir, gradient_mode=0, chunks=4):
     store = Store(x[idx], potential=True, device="cpu")
     force = SlabForce(ops, dist.group.WORLD, chunks=chunks)
     assert len(force._ranges()) == (chunks if chunks > 1 else 1)
-    dk = force.compute_force(store, kernel="1_4", dealias="gaussian")
+    dk = force.compute_force(store, kernel="1_4", dealias=dealias)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), idx=idx, acc=store.acc.numpy(),
              pot=store.potential.numpy(), dk=ops._cplx(dk, (N, ops.yl, ops.nzc)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,chunks", [(2, 4), (4, 4), (2, 1), (4, 2)])
-def test_slab_force_over_gloo_matches_one_rank_oracle(oracle, tmp_path, world, chunks):
+@pytest.mark.parametrize("world,chunks,dealias", [(2, 4, "gaussian"), (4, 4, "gaussian"), (2, 1, "gaussian"),
+                                                  (4, 2, "none"), (2, 4, "none")])
+def test_slab_force_over_gloo_matches_one_rank_oracle(oracle, tmp_path, world, chunks, dealias):
     """chunks > 1: the transposes are cut into plane ranges (batched isend / irecv per range, asynchronous);
     chunks = 1: one all_to_all_single per transform."""
     N, nc, L = 16, 8, 24.0
     x = util.load_b(nc, L, N, rms_cells=2.0)
-    ref = oracle.compute_force(oracle.PMOracle(N, L, 64), x, softening=oracle.SOFTENINGS["gaussian"], potential=True)
-    mp.spawn(_worker, args=(world, _free_port(), N, L, x, str(tmp_path), 0, chunks), nprocs=world, join=True)
+    ref = oracle.compute_force(oracle.PMOracle(N, L, 64), x, softening=oracle.SOFTENINGS[dealias], potential=True)
+    mp.spawn(_worker, args=(world, _free_port(), N, L, x, str(tmp_path), 0, chunks, dealias), nprocs=world, join=True)
     acc = np.zeros_like(ref["acc"])
     pot = np.zeros_like(ref["potential"])
     dks = []
