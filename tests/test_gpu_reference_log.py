@@ -39,7 +39,7 @@ def test_gpu_reproduces_the_reference_check_file(precision, gradient_mode):
     ops.pm.destroy()
 
 
-@pytest.mark.parametrize("P,gradient_mode", [(2, 0), (4, 1)])
+@pytest.mark.parametrize("P,gradient_mode", [(2, 0), (4, 1), (8, 0), (8, 1)])
 def test_gpu_slabs_reproduce_the_reference_check_file(P, gradient_mode):
     ops = SlabGpuOps(64, 512.0, P, gradient_mode)
     _check(R.run_lightcone_test(ops))
