@@ -679,7 +679,8 @@ int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt)
     const long long np = pt->np;
     const int nt = p->ntiles;
     const int ncnt = 2 * nt + 1;
-    if (np >= (1ll << 31) - 1) FPM_FAIL(-1, "np %lld exceeds the int32 index range of one rank", np);
+    // own + dup entries (up to 8 per particle, ~1.3 on average at B = 2) are indexed with int32
+    if (np >= 1500000000ll) FPM_FAIL(-1, "np %lld exceeds the int32 index range of one rank's binned entries", np);
     FPM_TRY(ensure_bins(p, np, np / 2 + 1024, pt->mass != nullptr));
 
     // slot 2 * nt stays 0 (scan total lands there); slot 2 * nt + 1 counts unowned particles
