@@ -74,10 +74,13 @@ __device__ __forceinline__ int wave_agg_inc(int *counters, int key, bool active)
     unsigned long long remaining = __ballot(active);
     const int lane = __lane_id();
     // Spatially coherent input (the normal case: lattice order, or the order a previous decompose
-    // left) has a handful of distinct tiles per wave.  After 6 merged groups the wave is treated as
-    // incoherent and every lane still waiting issues its own atomic (random order would otherwise
-    // loop up to 64 times: 3.9 ms instead of 0.6 ms of binning on a shuffled 16.8 M-particle load).
-    for (int round = 0; remaining && round < 6; round++) {
+    // left) has a handful of distinct tiles per wave.  After 6 merged groups the merging goes on only
+    // while groups still have 3 or more lanes (a clustered load spreads a wave over ~20 tiles: 1.36 ->
+    // 1.03 ms); then every lane still waiting issues its own atomic (random order would otherwise loop
+    // up to 64 times: 3.9 ms instead of 0.6 ms of binning on a shuffled 16.8 M-particle load).  Giving up
+    // as soon as ONE group is small is worse: lanes of the larger groups behind it then collide on the
+    // same counters one by one (clustered load 2.6 ms).
+    for (int round = 0; remaining && round < 24; round++) {
         int leader = __ffsll((long long) remaining) - 1;
         int k = __shfl(key, leader);
         bool mine = active && key == k;
@@ -93,6 +96,7 @@ __device__ __forceinline__ int wave_agg_inc(int *counters, int key, bool active)
             if (mine) slot = base + __popcll(same & ((1ull << lane) - 1ull));
         }
         remaining &= ~same;
+        if (round >= 5 && cnt < 3) break;      // uniform: after 6 groups keep merging only while it pays
     }
     if (remaining & (1ull << lane)) {
         if (RET) slot = atomicAdd(&counters[key], 1);
@@ -118,7 +122,7 @@ __device__ __forceinline__ AggSlot wave_agg_issue(int *counters, int key, bool a
     AggSlot a{0, 0, 0};
     unsigned long long remaining = __ballot(active);
     const int lane = __lane_id();
-    for (int round = 0; remaining && round < 6; round++) {
+    for (int round = 0; remaining && round < 24; round++) {
         const int leader = __ffsll((long long) remaining) - 1;
         const int k = __shfl(key, leader);
         const bool mine = active && key == k;
@@ -129,6 +133,7 @@ __device__ __forceinline__ AggSlot wave_agg_issue(int *counters, int key, bool a
             a.rank = __popcll(same & ((1ull << lane) - 1ull));
         }
         remaining &= ~same;
+        if (round >= 5 && __popcll(same) < 3) break;   // uniform: after 6 groups keep merging only while it pays
     }
     if (remaining & (1ull << lane)) {
         a.pend = atomicAdd(&counters[key], 1);
