@@ -52,6 +52,9 @@ constexpr int TILE_X = 8;
 constexpr int TILE_Y = 8;
 constexpr int TILE_Z = 32;
 constexpr int TILE_CELLS = TILE_X * TILE_Y * TILE_Z;
+// The counting sort keeps BIN_PRIV private copies of every tile counter / cursor, picked by workgroup id: a dense
+// clump puts thousands of particles into a few tiles and their atomics serialise per ADDRESS at the memory side.
+constexpr int BIN_PRIV = 8;
 
 enum { BUF_CANVAS = 0, BUF_DELTA_K, BUF_F0, BUF_F1, BUF_F2, BUF_XCHG, BUF_COUNT };
 

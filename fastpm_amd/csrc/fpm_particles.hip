@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void bin_kernel(MeshGeo g, int ntiles, const d
             Cic c;
             if (!cic_setup(g, px[u], py[u], pz[u], c)) {
                 // not this rank's particle: flagged in the last counter slot, reported by the host
-                if (!SCATTER) atomicAdd(&cnt_or_cur[2 * ntiles + 1], 1);
+                if (!SCATTER) atomicAdd(&cnt_or_cur[2 * ntiles * BIN_PRIV + 1], 1);
                 active[u] = false;
             }
             t0[0] = c.i0[0] / TILE_X; t0[1] = c.i0[1] / TILE_Y; t0[2] = c.i0[2] / TILE_Z;
@@ -200,7 +200,9 @@ __global__ __launch_bounds__(256) void bin_kernel(MeshGeo g, int ntiles, const d
         for (int c = 0; c < 8; c++) {
             const int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
             need[u][c] = active[u] && (!bx || t1[0] != t0[0]) && (!by || t1[1] != t0[1]) && (!bz || t1[2] != t0[2]);
-            key[u][c] = (c ? ntiles : 0) + tile_id(g, bx ? t1[0] : t0[0], by ? t1[1] : t0[1], bz ? t1[2] : t0[2]);
+            // counter / cursor copy (blockIdx.x % BIN_PRIV) of the tile: layout [own | dup][tile][copy]
+            key[u][c] = ((c ? ntiles : 0) + tile_id(g, bx ? t1[0] : t0[0], by ? t1[1] : t0[1], bz ? t1[2] : t0[2])) * BIN_PRIV
+                        + (int) (blockIdx.x % BIN_PRIV);
         }
     }
     if (!SCATTER) {
@@ -678,35 +680,44 @@ __global__ __launch_bounds__(256) void mass_sum_kernel(const float *__restrict__
 
 static inline unsigned blocks_for(long long n, int bs) { return (unsigned) ((n + bs - 1) / bs); }
 
+// tile offsets = the scanned counters at copy 0 of every tile (+ the grand total)
+__global__ __launch_bounds__(256) void tile_offsets_kernel(const int *__restrict__ scanned, int *__restrict__ off, int n)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j <= n) off[j] = scanned[(long long) j * BIN_PRIV];
+}
+
 int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt)
 {
     StageTimer tm(p, FPMHIP_T_SORT);
     const long long np = pt->np;
     const int nt = p->ntiles;
-    const int ncnt = 2 * nt + 1;
+    const int ncnt = 2 * nt * BIN_PRIV + 1;         // [own | dup][tile][copy] + the slot the scan total lands in
     // own + dup entries (up to 8 per particle, ~1.3 on average at B = 2) are indexed with int32
     if (np >= 1500000000ll) FPM_FAIL(-1, "np %lld exceeds the int32 index range of one rank's binned entries", np);
     FPM_TRY(ensure_bins(p, np, np / 2 + 1024, pt->mass != nullptr));
 
-    // slot 2 * nt stays 0 (scan total lands there); slot 2 * nt + 1 counts unowned particles
+    // slot ncnt - 1 stays 0 (scan total lands there); slot ncnt counts unowned particles
     FPM_CHECK_HIP(hipMemsetAsync(p->tile_cnt, 0, (ncnt + 1) * sizeof(int), p->stream));
     if (np > 0)
         bin_kernel<false, BIN_PPT><<<blocks_for(np, 256 * BIN_PPT), 256, 0, p->stream>>>(p->mg, nt, pt->x, pt->mass, np, p->tile_cnt,
                                                                        nullptr, nullptr, nullptr, nullptr, nullptr);
-    // exclusive scan of the 2 * ntiles counts (+1 slot -> grand total at off[2 * ntiles])
+    // exclusive scan of the counts (+1 slot -> grand total): the cursors of the scatter pass; the tile offsets the
+    // paint and readout kernels use are its entries at copy 0
     size_t tmp_bytes = 0;
-    FPM_CHECK_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, p->tile_cnt, p->tile_off, 0, (size_t) ncnt,
+    FPM_CHECK_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, p->tile_cnt, p->tile_cur, 0, (size_t) ncnt,
                                           rocprim::plus<int>(), p->stream));
     if (tmp_bytes > p->scan_tmp_bytes) {
         if (p->scan_tmp) FPM_CHECK_HIP(hipFree(p->scan_tmp));
         FPM_CHECK_HIP(hipMalloc(&p->scan_tmp, tmp_bytes));
         p->scan_tmp_bytes = tmp_bytes;
     }
-    FPM_CHECK_HIP(rocprim::exclusive_scan(p->scan_tmp, tmp_bytes, p->tile_cnt, p->tile_off, 0, (size_t) ncnt,
+    FPM_CHECK_HIP(rocprim::exclusive_scan(p->scan_tmp, tmp_bytes, p->tile_cnt, p->tile_cur, 0, (size_t) ncnt,
                                           rocprim::plus<int>(), p->stream));
+    tile_offsets_kernel<<<blocks_for(2 * nt + 1, 256), 256, 0, p->stream>>>(p->tile_cur, p->tile_off, 2 * nt);
     // capacity check for the dup entries: one small read-back
     FPM_CHECK_HIP(hipMemcpyAsync(p->h_pinned, p->tile_off + 2 * nt, sizeof(int), hipMemcpyDeviceToHost, p->stream));
-    FPM_CHECK_HIP(hipMemcpyAsync(p->h_pinned + 1, p->tile_cnt + 2 * nt + 1, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    FPM_CHECK_HIP(hipMemcpyAsync(p->h_pinned + 1, p->tile_cnt + ncnt, sizeof(int), hipMemcpyDeviceToHost, p->stream));
     FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
     const long long total = p->h_pinned[0];
     if (p->h_pinned[1] != 0)
@@ -716,7 +727,6 @@ int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt)
     const long long ndup = total - np;
     if (total > p->bin_cap_own) FPM_TRY(ensure_bins(p, np, ndup, pt->mass != nullptr));
 
-    FPM_CHECK_HIP(hipMemcpyAsync(p->tile_cur, p->tile_off, ncnt * sizeof(int), hipMemcpyDeviceToDevice, p->stream));
     if (np > 0)
         bin_kernel<true, BIN_PPT><<<blocks_for(np, 256 * BIN_PPT), 256, 0, p->stream>>>(p->mg, nt, pt->x, pt->mass, np, p->tile_cur,
                                                                       p->sx, p->sy, p->sz,

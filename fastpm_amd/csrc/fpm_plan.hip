@@ -211,9 +211,9 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
         if (hipMalloc(&p->d_tab, 5 * N * sizeof(float)) != hipSuccess) { rc = -2; break; }
         if (hipMemcpy(p->d_tab, p->h_tab.data(), 5 * N * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { rc = -2; break; }
         if (hipMalloc(&p->d_fac, 3 * N * sizeof(double)) != hipSuccess) { rc = -2; break; }
-        if (hipMalloc(&p->tile_cnt, (2 * (size_t) p->ntiles + 2) * sizeof(int)) != hipSuccess) { rc = -2; break; }
+        if (hipMalloc(&p->tile_cnt, (2 * (size_t) p->ntiles * fpm::BIN_PRIV + 2) * sizeof(int)) != hipSuccess) { rc = -2; break; }
         if (hipMalloc(&p->tile_off, (2 * (size_t) p->ntiles + 2) * sizeof(int)) != hipSuccess) { rc = -2; break; }
-        if (hipMalloc(&p->tile_cur, (2 * (size_t) p->ntiles + 2) * sizeof(int)) != hipSuccess) { rc = -2; break; }
+        if (hipMalloc(&p->tile_cur, (2 * (size_t) p->ntiles * fpm::BIN_PRIV + 2) * sizeof(int)) != hipSuccess) { rc = -2; break; }
         if (hipHostMalloc((void **) &p->h_pinned, 4096) != hipSuccess) { rc = -2; break; }
         if (hipMalloc(&p->d_scalar, 4096) != hipSuccess) { rc = -2; break; }
     } while (0);
