@@ -113,59 +113,102 @@ def linear_power(k, ns=0.96, k0=0.2):
     return k ** ns / (1 + (k / k0) ** 2) ** 2
 
 
-def gaussian_delta_k(pm, seed, amplitude):
-    """delta(k) on the plan's k-space layout from white noise in real space (Hermitian by construction:
-    it is the r2c of a real field), shaped by sqrt(P(k))."""
+def gaussian_delta_k(pm, seed, amplitude, transforms=None):
+    """delta(k) on the plan's k-space layout from white noise in real space (Hermitian by construction: it is the
+    r2c of a real field), shaped by sqrt(P(k)).  The noise of global x plane i comes from generator seed + i, so
+    the field is the same however many slabs the mesh is cut into."""
     import torch
-    gen = torch.Generator(device=pm.device)
-    gen.manual_seed(seed)
     N, L = pm.Nmesh, pm.BoxSize
+    xl, x0 = int(pm.layout.isize[0]), int(pm.layout.istart[0])
+    yl, y0 = int(pm.layout.osize[1]), int(pm.layout.ostart[1])
     white = pm.alloc()
-    pm.real_view(white)[:, :, :N] = torch.randn((N, N, N), generator=gen, device=pm.device, dtype=pm.dtype)
+    rv = pm.real_view(white)
+    gen = torch.Generator(device=pm.device)
+    for i in range(xl):
+        gen.manual_seed(seed * 100003 + x0 + i)
+        rv[i, :, :N] = torch.randn((N, N), generator=gen, device=pm.device, dtype=pm.dtype)
     dk = pm.alloc()
-    pm.r2c(white, dk)                                       # <|dk|^2> = 1 / N^3 per mode
+    if transforms is None:
+        pm.r2c(white, dk)                                   # <|dk|^2> = 1 / N^3 per mode
+    else:
+        transforms.r2c(white, dk)
     k1 = 2 * np.pi / L * torch.fft.fftfreq(N, d=1.0 / N, device=pm.device).to(pm.dtype)
-    kx, ky, kz = torch.meshgrid(k1, k1, k1[: N // 2 + 1].abs(), indexing="ij")
+    kx, ky, kz = torch.meshgrid(k1, k1[y0:y0 + yl], k1[: N // 2 + 1].abs(), indexing="ij")
     kk = (kx ** 2 + ky ** 2 + kz ** 2).sqrt()
-    kk[0, 0, 0] = 1.0
+    zero = kk == 0
+    kk[zero] = 1.0
     shape = torch.from_numpy(np.sqrt(linear_power(kk.cpu().numpy()))).to(pm.device).to(pm.dtype)
-    shape[0, 0, 0] = 0.0
+    shape[zero] = 0.0
     c = pm.complex_view(dk)
     c *= shape * (amplitude * (N ** 1.5) / L ** 1.5)        # P(k) = amplitude^2 * linear_power(k)
     return dk
 
 
 def run(nc=64, B=2, BoxSize=None, steps=5, a0=0.1, a1=1.0, mode="fastpm", seed=100, amplitude=1.0, precision=64,
-        vpm=None, verbose=True):
+        vpm=None, verbose=True, gradient_mode=0):
+    """One rank, or -- when torch.distributed is initialised -- one x slab per rank: Slab2LPT, SlabDecompose before
+    every force (fastpm_decompose, solver.c:449), SlabForce, all-reduced P(k) sums (powerspectrum.c:113-115)."""
     import torch
+    import torch.distributed as dist
     from fastpm_amd import (PM, VPM, Store, fastpm_drift_store, fastpm_kick_store, fastpm_store_wrap,
                             pm_2lpt_evolve, pm_2lpt_solve)
+    from fastpm_amd.distributed import Slab2LPT, SlabDecompose, SlabForce, SlabTransforms
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    group = dist.group.WORLD if world > 1 else None
     L = BoxSize or 4.0 * nc
     c = FlatLCDM()
     time_step = np.linspace(a0, a1, steps)                   # tests/standard.lua:21
-    lptpm = PM(nc, L, precision)                             # the IC mesh has the particle resolution (solver.c:112)
-    dk = gaussian_delta_k(lptpm, seed, amplitude)
-    g = np.arange(nc) * L / nc                               # shift = false: particles start on mesh points
-    q = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
+
+    def spectrum(pm, dk):
+        """powerspectrum.c:35-124 with the Allreduce of the three bin sums."""
+        sums = [torch.from_numpy(t) for t in pm.powerspectrum_sums(dk)]
+        if world > 1:
+            for t in sums:
+                dist.all_reduce(t, group=group)
+        k, pk, n = [t.numpy() for t in sums]
+        nz = n != 0
+        k[nz] /= n[nz]
+        pk[nz] *= L ** 3 / n[nz]
+        return k, pk, n
+
+    lptpm = PM(nc, L, precision, nranks=world, rank=rank)    # the IC mesh has the particle resolution (solver.c:112)
+    dk = gaussian_delta_k(lptpm, seed, amplitude, SlabTransforms(lptpm, group) if world > 1 else None)
+    # shift = false: particles start on mesh points; this rank's slab of the lattice (store.c:659-712)
+    g = np.arange(nc) * L / nc
+    gx = g[rank * (nc // world):(rank + 1) * (nc // world)]
+    q = np.stack(np.meshgrid(gx, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
     p = Store(q, v=np.zeros_like(q, dtype=np.float32), a_x=a0, a_v=a0)
-    pm_2lpt_solve(lptpm, dk, p, kernel="1_4")
+    if world > 1:
+        Slab2LPT(lptpm, group).solve(p, dk, kernel="1_4")
+    else:
+        pm_2lpt_solve(lptpm, dk, p, kernel="1_4")
     # linear P(k) of the IC field at a = 1 (D1 = 1), same estimator, for the growth check
-    k_lin, p_lin, _ = lptpm.powerspectrum(dk)
+    k_lin, p_lin, _ = spectrum(lptpm, dk)
     D1, D2 = c.D1(a0), c.D2(a0)
     pm_2lpt_evolve(lptpm, p, D1, D2, D1 * a0 * a0 * c.E(a0) * c.f1(a0), D2 * a0 * a0 * c.E(a0) * c.f2(a0), aout=a0)
     fastpm_store_wrap(lptpm, p)
     lptpm.destroy()
-    meshes = VPM(nc, L, vpm or [(0.0, B)], precision=precision)
+    meshes = VPM(nc, L, vpm or [(0.0, B)], precision=precision, nranks=world, rank=rank,
+                 make_pm=lambda nmesh: PM(nmesh, L, precision, nranks=world, rank=rank, gradient_mode=gradient_mode))
+    slab = {}
     spectra = []
 
     def force(a):
         pm = meshes.find(a)
         delta_k = pm.alloc()
-        pm.compute_force(p, kernel="1_4", softening="none", delta_k=delta_k)
+        if world > 1:
+            if id(pm) not in slab:
+                slab[id(pm)] = (SlabDecompose(pm, group), SlabForce(pm, group))
+            slab[id(pm)][0].decompose(p)                     # fastpm_decompose, solver.c:449
+            p.acc = torch.zeros((p.np, 3), dtype=torch.float32, device=p.x.device)
+            slab[id(pm)][1].compute_force(p, kernel="1_4", dealias="none", delta_k=delta_k)
+        else:
+            pm.compute_force(p, kernel="1_4", softening="none", delta_k=delta_k)
         pm.apply_decic_transfer(delta_k, delta_k)            # solver.c:471
-        k, pk, n = pm.powerspectrum(delta_k)                 # FORCE/AFTER handler
+        k, pk, n = spectrum(pm, delta_k)                     # FORCE/AFTER handler
         spectra.append((a, pm.Nmesh, k, pk, n))
-        if verbose:
+        if verbose and rank == 0:
             lo = slice(1, 4)
             print("a = %.4f  mesh %d^3  P(k<%.3g)/P_lin/D^2 = %s" % (
                 a, pm.Nmesh, k[3], np.round(pk[lo] / (p_lin[lo] * c.D1(a) ** 2), 4)), flush=True)
@@ -183,7 +226,7 @@ def run(nc=64, B=2, BoxSize=None, steps=5, a0=0.1, a1=1.0, mode="fastpm", seed=1
         fastpm_kick_store(pm, kick_factor(c, mode, ac, af, af), p, p, af)      # v: a_c -> a_f, force at a_f
     torch.cuda.synchronize()
     meshes.destroy()
-    return {"cosmology": c, "k_lin": k_lin, "p_lin": p_lin, "spectra": spectra, "store": p}
+    return {"cosmology": c, "k_lin": k_lin, "p_lin": p_lin, "spectra": spectra, "store": p, "rank": rank, "world": world}
 
 
 if __name__ == "__main__":
@@ -193,5 +236,27 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--mode", default="fastpm", choices=["fastpm", "pm", "cola"])
     ap.add_argument("--precision", type=int, default=64)
+    ap.add_argument("--gradient", type=int, default=0, help="1: FPMHIP_GRADIENT_REAL")
+    ap.add_argument("--json", default=None, help="rank 0 writes the spectra here")
     a = ap.parse_args()
-    run(nc=a.nc, B=a.B, steps=a.steps, mode=a.mode, precision=a.precision)
+    # under torch.distributed.run: one rank per GPU over RCCL (MINIPM_BACKEND=gloo MINIPM_SHARE_GPU=1: every rank
+    # on GPU 0 with host-staged exchanges -- a dry run for 1-GPU boxes)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch
+        import torch.distributed as dist
+        local = 0 if os.environ.get("MINIPM_SHARE_GPU") else int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        backend = os.environ.get("MINIPM_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    r = run(nc=a.nc, B=a.B, steps=a.steps, mode=a.mode, precision=a.precision, gradient_mode=a.gradient)
+    if a.json and r["rank"] == 0:
+        import json
+        json.dump({"p_lin": r["p_lin"].tolist(), "spectra": [[float(s[0]), int(s[1]), s[3].tolist()] for s in r["spectra"]]},
+                  open(a.json, "w"))
+    if r["world"] > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()

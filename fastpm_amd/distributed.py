@@ -337,6 +337,31 @@ class SlabForce(_SlabRank):
         return delta_k if delta_k is not None else self.delta_k
 
 
+class SlabTransforms(_SlabRank):
+    """pm_r2c / pm_c2r (pmpfft.c:370-399) on x slabs as stand-alone calls: the (y,z) passes, one all-to-all, the x
+    pass (and back).  r2c carries the 1 / Nmesh^3 like the reference's."""
+
+    def __init__(self, pm, group=None):
+        super().__init__(pm, group)
+        self.work = pm.alloc()
+
+    def r2c_steps(self, canvas, delta_k):
+        self.pm.fft_yz_forward(canvas, self.work)
+        yield ("alltoall", delta_k, self.work)
+        self.pm.fft_x_forward(delta_k)
+
+    def c2r_steps(self, buf):
+        self.pm.fft_x_backward(buf)
+        yield ("alltoall", self.work, buf)
+        self.pm.fft_yz_backward(self.work, buf)
+
+    def r2c(self, canvas, delta_k):
+        self.run(self.r2c_steps(canvas, delta_k))
+
+    def c2r(self, buf):
+        self.run(self.c2r_steps(buf))
+
+
 class Slab2LPT(_SlabRank):
     """pm_2lpt_solve (pm2lpt.c:14-164) for rank `pm.rank` of `pm.nranks` x-slabs: the sequence of
     pm.pm_2lpt_solve with every c2r / r2c split around its all-to-all and a halo-plane shift before each
@@ -441,15 +466,19 @@ class SlabDecompose:
             pm.invalidate_binning()
 
     def decompose(self, store):
+        staged = store.x.is_cuda and dist.get_backend(self.group) == "gloo"     # see _SlabRank._host_staged
         for req in self.steps(store):
             kind = req[0]
+            recv, send = (torch.empty(req[1].shape, dtype=req[1].dtype), req[2].cpu()) if staged else (req[1], req[2])
             if kind == "alltoall_counts":
-                dist.all_to_all_single(req[1], req[2], group=self.group)
+                dist.all_to_all_single(recv, send, group=self.group)
             elif kind == "alltoallv":
-                dist.all_to_all_single(req[1], req[2], output_split_sizes=req[3], input_split_sizes=req[4],
+                dist.all_to_all_single(recv, send, output_split_sizes=req[3], input_split_sizes=req[4],
                                        group=self.group)
             else:
                 raise ValueError(kind)
+            if staged:
+                req[1].copy_(recv)
 
 
 def run_virtual_decompose(decomposers, stores):

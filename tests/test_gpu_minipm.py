@@ -39,3 +39,31 @@ def test_large_scale_power_follows_linear_growth(mode, vpm, lo, hi):
         assert r["spectra"][-1][3][1] / (r["p_lin"][1] * c.D1(1.0) ** 2) < 0.97
     x = r["store"].x.cpu().numpy()
     assert np.isfinite(x).all() and x.min() >= 0 and x.max() <= 4.0 * 32
+
+
+@pytest.mark.parametrize("nranks,port,gradient", [(2, 29631, 0), (4, 29632, 1)])
+def test_multi_rank_run_gives_the_one_rank_spectra(tmp_path, nranks, port, gradient):
+    """examples/minipm.py under torch.distributed.run: Slab2LPT, SlabDecompose before every force, SlabForce,
+    all-reduced P(k) -- every rank a process of its own.  On the 1-GPU box the ranks share the GPU and exchange
+    through the host over gloo (MINIPM_BACKEND=gloo MINIPM_SHARE_GPU=1; with RCCL on a multi-GPU node it is one rank
+    per GPU).  The initial field does not depend on the number of slabs, so every P(k) bin of every step must equal
+    the one-rank run's (to round-off: the particle order and the summation order differ)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "examples", "minipm.py")
+    args = ["--nc", "32", "--B", "2", "--steps", "4", "--mode", "fastpm", "--gradient", str(gradient)]
+    one, many = str(tmp_path / "one.json"), str(tmp_path / "many.json")
+    subprocess.run([sys.executable, script] + args + ["--json", one], check=True, cwd=root, timeout=600,
+                   capture_output=True)
+    env = dict(os.environ, MINIPM_BACKEND="gloo", MINIPM_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), script] + args + ["--json", many],
+                       cwd=root, env=env, timeout=900, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = json.load(open(one)), json.load(open(many))
+    assert np.allclose(a["p_lin"][1:], b["p_lin"][1:], rtol=1e-10)
+    assert len(a["spectra"]) == len(b["spectra"]) == 4
+    for sa, sb in zip(a["spectra"], b["spectra"]):
+        assert sa[0] == sb[0] and sa[1] == sb[1]
+        assert np.allclose(sa[2][1:], sb[2][1:], rtol=1e-7), (sa[0], np.abs(np.array(sa[2][1:]) / np.array(sb[2][1:]) - 1).max())
