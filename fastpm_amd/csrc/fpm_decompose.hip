@@ -75,35 +75,41 @@ int fpmhip_decompose_order(fpmhip_plan *p, const double *x, int64_t np, int *ord
     if (np >= (1ll << 31) - 1) FPM_FAIL(-1, "np exceeds the int32 index range of one rank");
     for (int k = 0; k <= P; k++) counts_host[k] = 0;
     if (np == 0) return 0;
-    unsigned char *key_in = nullptr, *key_out = nullptr;
-    int *idx_in = nullptr;
-    unsigned long long *d_counts = nullptr;
-    void *tmp = nullptr;
-    int rc = 0;
-    do {
-        if (hipMalloc(&key_in, np) != hipSuccess || hipMalloc(&key_out, np) != hipSuccess ||
-            hipMalloc(&idx_in, np * sizeof(int)) != hipSuccess ||
-            hipMalloc(&d_counts, (P + 1) * sizeof(unsigned long long)) != hipSuccess) { rc = -2; break; }
-        if (hipMemsetAsync(d_counts, 0, (P + 1) * sizeof(unsigned long long), p->stream) != hipSuccess) { rc = -2; break; }
-        target_kernel<<<blocks_for(np, 256), 256, 0, p->stream>>>(p->mg, P, p->lay.rank, x, np, key_in, idx_in, d_counts);
-        // stable LSD radix sort on the rank key: leavers grouped by target, original order inside
-        // each group, exactly the order store.c:540-546 builds with its offsets[] pass
-        int bits = 1;
-        while ((1 << bits) < P + 1) bits++;
-        size_t tmp_bytes = 0;
-        if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_in, key_out, idx_in, order, (size_t) np, 0, bits,
-                                      p->stream) != hipSuccess) { rc = -2; break; }
-        if (hipMalloc(&tmp, tmp_bytes) != hipSuccess) { rc = -2; break; }
-        if (rocprim::radix_sort_pairs(tmp, tmp_bytes, key_in, key_out, idx_in, order, (size_t) np, 0, bits,
-                                      p->stream) != hipSuccess) { rc = -2; break; }
-        std::vector<unsigned long long> h(P + 1);
-        if (hipMemcpyAsync(h.data(), d_counts, (P + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                           p->stream) != hipSuccess || hipStreamSynchronize(p->stream) != hipSuccess) { rc = -2; break; }
-        for (int k = 0; k <= P; k++) counts_host[k] = (int64_t) h[k];
-    } while (0);
-    for (void *q : {(void *) key_in, (void *) key_out, (void *) idx_in, (void *) d_counts, tmp})
-        if (q) (void) hipFree(q);
-    if (rc != 0) FPM_FAIL(rc, "decompose: %s", hipGetErrorString(hipGetLastError()));
+    // scratch lives in the plan: four hipMalloc / hipFree pairs per call cost more than the sort itself
+    if (np > p->dec_cap || !p->dec_counts) {
+        for (void *q : {(void *) p->dec_key_in, (void *) p->dec_key_out, (void *) p->dec_idx}) if (q) (void) hipFree(q);
+        p->dec_key_in = p->dec_key_out = nullptr;
+        p->dec_idx = nullptr;
+        const int64_t cap = np + np / 8 + 1024;
+        if (hipMalloc(&p->dec_key_in, cap) != hipSuccess || hipMalloc(&p->dec_key_out, cap) != hipSuccess ||
+            hipMalloc(&p->dec_idx, cap * sizeof(int)) != hipSuccess)
+            FPM_FAIL(-2, "decompose: %s", hipGetErrorString(hipGetLastError()));
+        if (!p->dec_counts && hipMalloc(&p->dec_counts, 256 * sizeof(unsigned long long)) != hipSuccess)
+            FPM_FAIL(-2, "decompose: %s", hipGetErrorString(hipGetLastError()));
+        p->dec_cap = cap;
+    }
+    unsigned char *key_in = p->dec_key_in, *key_out = p->dec_key_out;
+    int *idx_in = p->dec_idx;
+    unsigned long long *d_counts = p->dec_counts;
+    FPM_CHECK_HIP(hipMemsetAsync(d_counts, 0, (P + 1) * sizeof(unsigned long long), p->stream));
+    target_kernel<<<blocks_for(np, 256), 256, 0, p->stream>>>(p->mg, P, p->lay.rank, x, np, key_in, idx_in, d_counts);
+    // stable LSD radix sort on the rank key: leavers grouped by target, original order inside
+    // each group, exactly the order store.c:540-546 builds with its offsets[] pass
+    int bits = 1;
+    while ((1 << bits) < P + 1) bits++;
+    size_t tmp_bytes = 0;
+    FPM_CHECK_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_in, key_out, idx_in, order, (size_t) np, 0, bits, p->stream));
+    if (tmp_bytes > p->dec_tmp_bytes) {
+        if (p->dec_tmp) (void) hipFree(p->dec_tmp);
+        p->dec_tmp = nullptr;
+        FPM_CHECK_HIP(hipMalloc(&p->dec_tmp, tmp_bytes));
+        p->dec_tmp_bytes = tmp_bytes;
+    }
+    FPM_CHECK_HIP(rocprim::radix_sort_pairs(p->dec_tmp, tmp_bytes, key_in, key_out, idx_in, order, (size_t) np, 0, bits, p->stream));
+    unsigned long long *h = (unsigned long long *) p->h_pinned;         // pinned scratch (>= 256 * 8 bytes)
+    FPM_CHECK_HIP(hipMemcpyAsync(h, d_counts, (P + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, p->stream));
+    FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
+    for (int k = 0; k <= P; k++) counts_host[k] = (int64_t) h[k];
     return 0;
 }
 

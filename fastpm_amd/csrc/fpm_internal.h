@@ -132,6 +132,13 @@ struct fpmhip_plan {
     const double *binned_x = nullptr;
     const float *binned_mass = nullptr;
     int64_t binned_np = -1;
+    // decompose scratch (keys, indices, radix-sort temporary), grown on demand
+    unsigned char *dec_key_in = nullptr, *dec_key_out = nullptr;
+    int *dec_idx = nullptr;
+    unsigned long long *dec_counts = nullptr;
+    void *dec_tmp = nullptr;
+    int64_t dec_cap = 0;
+    size_t dec_tmp_bytes = 0;
     int64_t binned_ndup = 0;
 
     // timing

@@ -197,8 +197,10 @@ __global__ __launch_bounds__(256) void power_kernel(MeshGeo g, double k0, const 
     for (int i = threadIdx.x; i < 3 * nbins; i += blockDim.x) lds[i] = 0;
     __syncthreads();
     const int N = g.N;
-    const int ix = blockIdx.y;
     const int plane = g.yl * g.nzc;
+    // a workgroup walks several x planes before it flushes its LDS bins: with one plane per workgroup the
+    // 32768 x 768 flushes serialised on 768 addresses (0.72 ms for a 0.25 ms read of the mesh)
+    for (int ix = blockIdx.y; ix < N; ix += gridDim.y)
     for (int rem = blockIdx.x * blockDim.x + threadIdx.x; rem < plane; rem += gridDim.x * blockDim.x) {
         const int iyl = rem / g.nzc, iz = rem - iyl * g.nzc;
         const int iy = iyl + g.ystart;
@@ -455,7 +457,7 @@ int fpmhip_powerspectrum(fpmhip_plan *p, const void *d1, const void *d2, double 
     FPM_CHECK_HIP(hipMemsetAsync(dbins, 0, 3 * nbins * sizeof(double), p->stream));
     const double k0 = 2 * M_PI / p->geom.BoxSize;
     const int plane = g.yl * g.nzc;
-    dim3 grid(std::max(1u, std::min(blocks_for(plane, 256 * 8), 64u)), g.N);
+    dim3 grid(std::max(1u, std::min(blocks_for(plane, 256 * 8), 64u)), (unsigned) std::min(g.N, 32));
     const size_t lds = 3 * nbins * sizeof(double);
     if (p->f64)
         power_kernel<double><<<grid, 256, lds, p->stream>>>(g, k0, (const Cplx<double> *) d1, (const Cplx<double> *) d2,
