@@ -867,6 +867,21 @@ int fpmhip_paint_add(fpmhip_plan *p, const fpmhip_particles *pt, double scale, v
                   : paint_impl<float>(p, pt, scale, (float *) canvas, 1);
 }
 
+// The permutation that puts the particles in tile order: order[j] = row of the j-th particle in tile order (the own
+// entries of a binning of `pt`).  A store whose rows are in arbitrary order (a snapshot read back, a random
+// shuffle) costs the counting sort 7x more than a coherent one; permuting every column once with
+// fpmhip_gather_rows(order) makes all later force calls coherent.
+int fpmhip_tile_order(fpmhip_plan *p, const fpmhip_particles *pt, int *order)
+{
+    FPM_TRY(check_particles(p, pt));
+    if (pt->np == 0) return 0;
+    if (!order) FPM_FAIL(-1, "null output");
+    if (p->geom.paint_mode == FPMHIP_PAINT_ATOMIC) FPM_FAIL(-1, "tile_order needs the tiled painter");
+    FPM_TRY(bin_particles(p, pt));
+    FPM_CHECK_HIP(hipMemcpyAsync(order, p->sidx, (size_t) pt->np * sizeof(int), hipMemcpyDeviceToDevice, p->stream));
+    return fpmhip_invalidate_binning(p);          // the caller is about to permute the rows behind pt->x
+}
+
 int fpmhip_invalidate_binning(fpmhip_plan *p)
 {
     if (!p) FPM_FAIL(-1, "null plan");

@@ -62,6 +62,7 @@ SYMBOLS = {
     "fpmhip_paint": (_I, [_P, ctypes.POINTER(Particles), _D, _P]),
     "fpmhip_paint_add": (_I, [_P, ctypes.POINTER(Particles), _D, _P]),
     "fpmhip_total_mass": (_I, [_P, ctypes.POINTER(Particles), ctypes.POINTER(_D)]),
+    "fpmhip_tile_order": (_I, [_P, ctypes.POINTER(Particles), _P]),
     "fpmhip_invalidate_binning": (_I, [_P]),
     "fpmhip_plane_ptr": (_P, [_P, _P, _I64]),
     "fpmhip_plane_add": (_I, [_P, _P, _P]),

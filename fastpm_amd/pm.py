@@ -357,6 +357,16 @@ class PM:
     def paint(self, canvas, store, scale=1.0):
         check(self._L.fpmhip_paint(self._plan, ctypes.byref(store._c()), float(scale), _ptr(canvas)))
 
+    def sort_store_by_tile(self, store):
+        """Permute every column of the store into tile order (fpmhip_tile_order + fpmhip_gather_rows): later force
+        calls then bin coherent rows.  Returns the permutation (new row j = old row order[j])."""
+        order = torch.empty(store.np, dtype=torch.int32, device=store.x.device)
+        check(self._L.fpmhip_tile_order(self._plan, ctypes.byref(store._c()), _ptr(order)))
+        for name, col in store.columns():
+            setattr(store, name, self.gather_rows(col, order))
+        self.invalidate_binning()
+        return order
+
     def invalidate_binning(self):
         check(self._L.fpmhip_invalidate_binning(self._plan))
 

@@ -307,3 +307,29 @@ def test_host_mesh_transfer_all_fields(oracle):
             pmo.grad(ref, ref, d2, go)
         assert np.array_equal(got, pmo.complex_view(ref)), field
     pm.destroy()
+
+
+def test_sort_store_by_tile_is_a_permutation_that_speeds_up_binning(oracle):
+    """fpmhip_tile_order: rows in random order -> tile order; the force of every particle is unchanged (it follows
+    its row) and the store is a permutation of the original."""
+    import torch
+    from fastpm_amd import PM, Store
+    N, nc, L = 64, 32, 96.0
+    x = util.load_c(nc, L)                                   # random order, one dense clump
+    v = np.arange(len(x) * 3, dtype=np.float32).reshape(-1, 3)
+    pm = PM(N, L, 64)
+    a = Store(x, v=v)
+    pm.compute_force(a, kernel="1_4")
+    acc0 = a.acc.cpu().numpy().copy()
+    b = Store(x, v=v)
+    order = pm.sort_store_by_tile(b).cpu().numpy()
+    assert np.array_equal(np.sort(order), np.arange(len(x)))
+    assert np.array_equal(b.x.cpu().numpy(), x[order]) and np.array_equal(b.v.cpu().numpy(), v[order])
+    pm.compute_force(b, kernel="1_4")
+    torch.cuda.synchronize()
+    assert np.abs(b.acc.cpu().numpy() - acc0[order]).max() <= 1.2e-7 * np.abs(acc0).max()
+    # tile order: consecutive rows share tiles
+    cell = np.floor(b.x.cpu().numpy() * (N / L)).astype(np.int64) % N
+    tile = (cell[:, 0] // 8 * (N // 8) + cell[:, 1] // 8) * (N // 32) + cell[:, 2] // 32
+    assert (np.diff(tile) >= 0).all()
+    pm.destroy()
