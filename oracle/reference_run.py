@@ -13,7 +13,6 @@ generator (a GSL dependency absent from this image) is restated in ic_oracle.c.
 `ops` abstracts who executes the mesh / particle operators: OracleOps (this file, the CPU oracle) or the GPU
 adapter in tests/test_gpu_reference_log.py.
 """
-import ctypes
 import os
 
 import numpy as np

@@ -3,7 +3,6 @@
 element-wise particle operators (kick, drift, wrap, summary), the caller-side k-space operators (de-CIC, P(k)), the
 slab decompose pieces, 2LPT, and one whole K D D F K step.  HIP-event timing around K repetitions; algorithmic bytes
 as the reference's loops touch them.  Prints one JSON object."""
-import ctypes
 import json
 import os
 import sys

@@ -1,5 +1,4 @@
 """Can two ranks share ONE GPU under RCCL (only to exercise the nccl code path on a 1-GPU box)?"""
-import os
 import torch
 import torch.distributed as dist
 torch.cuda.set_device(0)
