@@ -390,7 +390,8 @@ __global__ __launch_bounds__(N / 8 * CW, 4) void colfft_xback3_kernel(const C2<F
 // after the x transform instead of before it -- they do not depend on kx.  Rows = ky, columns = kz.
 template <int N, int R2, int R3, int R4, int CW, typename F>
 __global__ __launch_bounds__(N / 8 * CW, 4) void colfft_yback2_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ oy,
-                                                             C2<F> *__restrict__ oz, ColMap im, ColMap om,
+                                                             C2<F> *__restrict__ oz, C2<F> *__restrict__ op,
+                                                             ColMap im, ColMap om,
                                                              int ncols, int ntiles_per_batch, int ntiles,
                                                              const float *__restrict__ kt,
                                                              const double *__restrict__ tw_global)
@@ -408,21 +409,27 @@ __global__ __launch_bounds__(N / 8 * CW, 4) void colfft_yback2_kernel(const C2<F
 #pragma unroll
     for (int j = 0; j < EPT; j++) a[j] = live ? in[col_addr(im, batch, tau + T * j, col)] : C2<F>{0, 0};
     stage_twiddles(tw, tw_global, N);
+    // op != nullptr: a third output, the potential itself (gravity.c:487-492 wants it read out too): its y pass
+    // comes from the same read instead of a second transfer + x pass (+ all-to-all on slabs)
 #pragma unroll 1
-    for (int dir = 1; dir < 3; dir++) {
+    for (int dir = op ? 0 : 1; dir < 3; dir++) {
         C2<F> v[VMAX];
         int tau_o = tau;                     // see colfft_xback3_kernel
         asm volatile("" : "+v"(tau_o));
 #pragma unroll
         for (int j = 0; j < EPT; j++) {
-            const double k_finite = dir == 1 ? kt[tau_o + T * j] : kt[live ? col : 0];
-            v[j].x = (F) (-a[j].y * k_finite);
-            v[j].y = (F) (a[j].x * k_finite);
+            if (dir == 0) {
+                v[j] = a[j];
+            } else {
+                const double k_finite = dir == 1 ? kt[tau_o + T * j] : kt[live ? col : 0];
+                v[j].x = (F) (-a[j].y * k_finite);
+                v[j].y = (F) (a[j].x * k_finite);
+            }
         }
         __syncthreads();
         fft_core<N, R2, R3, R4, +1, CW>(v, lds, tw, tau, c);
         if (live) {
-            C2<F> *dst = dir == 1 ? oy : oz;
+            C2<F> *dst = dir == 0 ? op : (dir == 1 ? oy : oz);
 #pragma unroll
             for (int j = 0; j < EPT; j++) dst[col_addr(om, batch, tau_o + T * j, col)] = v[j];
         }
@@ -657,7 +664,7 @@ int colfft_y_range(fpmhip_plan *p, int dir, const void *in, void *out, int chunk
 }
 
 template <typename F>
-static int yback2_launch(fpmhip_plan *p, const void *in, void *oy, void *oz, const ColMap &im, const ColMap &om,
+static int yback2_launch(fpmhip_plan *p, const void *in, void *oy, void *oz, void *op, const ColMap &im, const ColMap &om,
                          int nbatch, int ncols, int gradorder)
 {
     StageTimer ktm(p, FPMHIP_T_K_YBACK2);
@@ -672,7 +679,7 @@ static int yback2_launch(fpmhip_plan *p, const void *in, void *oy, void *oz, con
 #define CALL_Y2_W(n, r2, r3, r4, W)                                                                          \
     FPM_TRY(set_lds(colfft_yback2_kernel<n, r2, r3, r4, W, F>, lds));                                        \
     colfft_yback2_kernel<n, r2, r3, r4, W, F><<<ntiles, n / 8 * W, lds, p->stream>>>(                        \
-        (const C2<F> *) in, (C2<F> *) oy, (C2<F> *) oz, im, om, ncols, tpb, ntiles, kt, p->d_twiddle);
+        (const C2<F> *) in, (C2<F> *) oy, (C2<F> *) oz, (C2<F> *) op, im, om, ncols, tpb, ntiles, kt, p->d_twiddle);
 #define CALL_Y2(n, r2, r3, r4)                                                                               \
     if (wide) { CALL_Y2_W(n, r2, r3, r4, (n <= 512 ? CW : 8)) } else { CALL_Y2_W(n, r2, r3, r4, 8) }
     COLFFT_DISPATCH(N, CALL_Y2)
@@ -683,13 +690,14 @@ static int yback2_launch(fpmhip_plan *p, const void *in, void *oy, void *oz, con
 }
 
 // backward y pass of the transposed potential -> the y and z force components (both [x_loc][y][kz])
-int colfft_yback2(fpmhip_plan *p, const void *in, void *oy, void *oz, int chunked, int gradorder)
+int colfft_yback2(fpmhip_plan *p, const void *in, void *oy, void *oz, void *op, int chunked, int gradorder)
 {
-    return colfft_yback2_range(p, in, oy, oz, chunked, gradorder, 0, p->mg.xl);
+    return colfft_yback2_range(p, in, oy, oz, op, chunked, gradorder, 0, p->mg.xl);
 }
 
 // the same for the x planes [x0, x0 + nx) only
-int colfft_yback2_range(fpmhip_plan *p, const void *in, void *oy, void *oz, int chunked, int gradorder, int x0, int nx)
+int colfft_yback2_range(fpmhip_plan *p, const void *in, void *oy, void *oz, void *op, int chunked, int gradorder, int x0,
+                        int nx)
 {
     const MeshGeo &g = p->mg;
     const long long plane = (long long) g.N * g.nzc;
@@ -700,8 +708,9 @@ int colfft_yback2_range(fpmhip_plan *p, const void *in, void *oy, void *oz, int 
     const char *inp = (const char *) in + (size_t) x0 * im.bstride * cb;
     char *oyp = (char *) oy + (size_t) x0 * natural.bstride * cb;
     char *ozp = (char *) oz + (size_t) x0 * natural.bstride * cb;
-    return p->f64 ? yback2_launch<double>(p, inp, oyp, ozp, im, natural, nx, g.nzc, gradorder)
-                  : yback2_launch<float>(p, inp, oyp, ozp, im, natural, nx, g.nzc, gradorder);
+    char *opp = op ? (char *) op + (size_t) x0 * natural.bstride * cb : nullptr;
+    return p->f64 ? yback2_launch<double>(p, inp, oyp, ozp, opp, im, natural, nx, g.nzc, gradorder)
+                  : yback2_launch<float>(p, inp, oyp, ozp, opp, im, natural, nx, g.nzc, gradorder);
 }
 
 template <typename F>

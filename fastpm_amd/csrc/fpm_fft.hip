@@ -296,7 +296,8 @@ int fpmhip_fft_yz_backward_range(fpmhip_plan *p, void *recv, void *canvas, int x
     return zc2r_range(p, canvas, x0, nx);
 }
 
-int fpmhip_fft_yz_backward_grad2_range(fpmhip_plan *p, void *recv, void *out_y, void *out_z, int kernel, int x0, int nx)
+int fpmhip_fft_yz_backward_grad2_range(fpmhip_plan *p, void *recv, void *out_y, void *out_z, void *out_pot, int kernel,
+                                       int x0, int nx)
 {
     if (!p || !recv || !out_y || !out_z) FPM_FAIL(-1, "null argument");
     FPM_TRY(check_range(p, x0, nx));
@@ -304,10 +305,12 @@ int fpmhip_fft_yz_backward_grad2_range(fpmhip_plan *p, void *recv, void *out_y, 
     FPM_TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));
     if (go != 1) FPM_FAIL(-1, "fft_yz_backward_grad2 is for kernels with gradorder = 1");
     if (out_y == out_z) FPM_FAIL(-1, "out_y and out_z must differ");
+    if (out_pot && (out_pot == out_y || out_pot == out_z || out_pot == recv)) FPM_FAIL(-1, "out_pot must be a buffer of its own");
     if (p->lay.nranks > 1 && (recv == out_y || recv == out_z)) FPM_FAIL(-1, "recv and the outputs must differ when nranks > 1");
     StageTimer tm(p, FPMHIP_T_C2R);
-    FPM_TRY(colfft_yback2_range(p, recv, out_y, out_z, p->lay.nranks > 1 ? 1 : 0, go, x0, nx));
+    FPM_TRY(colfft_yback2_range(p, recv, out_y, out_z, out_pot, p->lay.nranks > 1 ? 1 : 0, go, x0, nx));
     FPM_TRY(zc2r_range(p, out_y, x0, nx));
+    if (out_pot) FPM_TRY(zc2r_range(p, out_pot, x0, nx));
     return zc2r_range(p, out_z, x0, nx);
 }
 
@@ -488,7 +491,7 @@ int fpmhip_transfer_fft_x_backward_potx(fpmhip_plan *p, const void *delta_k, voi
 // to the rounding of the mesh dtype.  Only for kernels with gradorder = 1: with the exact i k gradient
 // the reference's zeroing of the self-conjugate modes (gravity.c:44-56) is not a rounding-level detail.
 // nranks == 1: recv may be out_y (in place).
-int fpmhip_fft_yz_backward_grad2(fpmhip_plan *p, void *recv, void *out_y, void *out_z, int kernel)
+int fpmhip_fft_yz_backward_grad2(fpmhip_plan *p, void *recv, void *out_y, void *out_z, void *out_pot, int kernel)
 {
     if (!p || !recv || !out_y || !out_z) FPM_FAIL(-1, "null argument");
     if (!p->own_fft) FPM_FAIL(-1, "fft_yz_backward_grad2 needs the column-FFT back end");
@@ -498,8 +501,10 @@ int fpmhip_fft_yz_backward_grad2(fpmhip_plan *p, void *recv, void *out_y, void *
     if (out_y == out_z) FPM_FAIL(-1, "out_y and out_z must differ");
     if (p->lay.nranks > 1 && (recv == out_y || recv == out_z)) FPM_FAIL(-1, "recv and the outputs must differ when nranks > 1");
     StageTimer tm(p, FPMHIP_T_C2R);
-    FPM_TRY(colfft_yback2(p, recv, out_y, out_z, p->lay.nranks > 1 ? 1 : 0, go));
+    if (out_pot && (out_pot == out_y || out_pot == out_z || out_pot == recv)) FPM_FAIL(-1, "out_pot must be a buffer of its own");
+    FPM_TRY(colfft_yback2(p, recv, out_y, out_z, out_pot, p->lay.nranks > 1 ? 1 : 0, go));
     FPM_TRY(zc2r_range(p, out_y, 0, p->mg.xl));
+    if (out_pot) FPM_TRY(zc2r_range(p, out_pot, 0, p->mg.xl));
     return zc2r_range(p, out_z, 0, p->mg.xl);
 }
 

@@ -125,7 +125,19 @@ int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets
         if (fuse_x) FPM_TRY(fpmhip_r2c_transfer_fft_x_backward(p, canvas, delta_k, kernel, 2, f[0], f[1], nullptr));
         else FPM_TRY(fpmhip_transfer_fft_x_backward_potx(p, delta_k, f[0], f[1], kernel));
         FPM_TRY(fpmhip_fft_yz_backward(p, f[0], f[0]));
-        FPM_TRY(fpmhip_fft_yz_backward_grad2(p, f[1], f[1], f[2], kernel));
+        // the potential column (gravity.c:487-492) rides along: its (y, z) passes from the same read
+        void *potmesh = nullptr;
+        if (any_pot) {
+            FPM_TRY(ensure_buffer(p, BUF_F0));
+            potmesh = p->buf[BUF_F0];
+        }
+        FPM_TRY(fpmhip_fft_yz_backward_grad2(p, f[1], f[1], f[2], potmesh, kernel));
+        if (any_pot) {
+            for (int si = nsets - 1; si >= 0; si--) FPM_TRY(fpmhip_readout3(p, &sets[si], f[0], f[1], f[2]));
+            for (int si = 0; si < nsets; si++)
+                if (sets[si].potential) FPM_TRY(fpmhip_readout1(p, &sets[si], potmesh, sets[si].potential, 1, 0));
+            return 0;
+        }
     } else if (p->own_fft) {
         // one sweep over delta_k: the three transfers + the x pass of their inverse transforms
         if (fuse_x) FPM_TRY(fpmhip_r2c_transfer_fft_x_backward(p, canvas, delta_k, kernel, 0, f[0], f[1], f[2]));

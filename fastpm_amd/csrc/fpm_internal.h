@@ -184,8 +184,9 @@ int colfft_xfwd_xback(fpmhip_plan *p, void *dk_inout, void *o0, void *o1, void *
                       int mode, double scale);
 int colfft_xback_potx(fpmhip_plan *p, const void *dk, void *out_x, void *out_pot, int potorder, int gradorder);
 int rowfft_c2r_range(fpmhip_plan *p, void *buf, int x0, int nx);
-int colfft_yback2(fpmhip_plan *p, const void *in, void *oy, void *oz, int chunked, int gradorder);
-int colfft_yback2_range(fpmhip_plan *p, const void *in, void *oy, void *oz, int chunked, int gradorder, int x0, int nx);
+int colfft_yback2(fpmhip_plan *p, const void *in, void *oy, void *oz, void *op, int chunked, int gradorder);
+int colfft_yback2_range(fpmhip_plan *p, const void *in, void *oy, void *oz, void *op, int chunked, int gradorder, int x0,
+                        int nx);
 
 // fpm_force.hip
 void release_host_stage(fpmhip_plan *p);

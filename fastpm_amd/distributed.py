@@ -143,6 +143,7 @@ class SlabForce(_SlabRank):
         # the next (forward) / previous (backward) range; 1 = whole-slab exchanges
         self.chunks = chunks
         self.extra = None                                      # third output mesh of the pipelined backward half
+        self.potmesh = None                                    # real-space potential when the store has that column
         self.canvas = pm.alloc()
         self.work = pm.alloc()
         self.real_gradient = getattr(pm, "gradient_mode", 0) == GRADIENT_REAL
@@ -212,20 +213,24 @@ class SlabForce(_SlabRank):
                 yield ("alltoall_range_start", self.work2, self.force[1], x0, nx, ("pot", i))
             for i, (x0, nx) in enumerate(ranges):
                 yield ("alltoall_range_start", self.work, self.force[0], x0, nx, ("x", i))
+            # the potential column (gravity.c:487-492) rides along with the transposed potential: no second
+            # transfer, x pass and all-to-all for it
+            potmesh = None
+            if store.potential is not None:
+                if self.potmesh is None:
+                    self.potmesh = pm.alloc()
+                potmesh = self.potmesh
             for i, (x0, nx) in enumerate(ranges):
                 yield ("wait", ("pot", i))
-                pm.fft_yz_backward_grad2_range(kernel, self.work2, self.force[2], self.extra, x0, nx)
+                pm.fft_yz_backward_grad2_range(kernel, self.work2, self.force[2], self.extra, x0, nx, out_pot=potmesh)
             for i, (x0, nx) in enumerate(ranges):
                 yield ("wait", ("x", i))
                 pm.fft_yz_backward_range(self.work, self.force[1], x0, nx)
-            meshes = [self.force[1], self.force[2], self.extra]
+            meshes = [self.force[1], self.force[2], self.extra] + ([potmesh] if potmesh is not None else [])
             yield ("shift", [(pm.plane(f, 0), pm.plane(f, xl), -1) for f in meshes])
-            pm.readout3(meshes, store)
-            if store.potential is not None:                                   # gravity.c:487-492
-                f = self.force[0]
-                yield from self._backward(delta_k, kernel, FIELD_POTENTIAL, f)
-                yield ("shift", [(pm.plane(f, 0), pm.plane(f, xl), -1)])
-                pm.readout(f, store, store.potential, 1, 0)
+            pm.readout3(meshes[:3], store)
+            if potmesh is not None:
+                pm.readout(potmesh, store, store.potential, 1, 0)
             return
         if _gradorder(kernel) == 1 and pm.column_fft() and not self.three_transposes:
             # gravity.c:373-397 with TWO meshes through the transpose instead of three: the x component
@@ -239,17 +244,20 @@ class SlabForce(_SlabRank):
             # while the x component is still on xGMI
             yield ("alltoall_start", self.work2, self.force[1], 1)
             yield ("alltoall_start", self.work, self.force[0], 0)
+            potmesh = None
+            if store.potential is not None:                                   # gravity.c:487-492, see above
+                if self.potmesh is None:
+                    self.potmesh = pm.alloc()
+                potmesh = self.potmesh
             yield ("wait", 1)
-            pm.fft_yz_backward_grad2(kernel, self.work2, self.force[1], self.force[2])
+            pm.fft_yz_backward_grad2(kernel, self.work2, self.force[1], self.force[2], out_pot=potmesh)
             yield ("wait", 0)
             pm.fft_yz_backward(self.work, self.force[0])
-            yield ("shift", [(pm.plane(f, 0), pm.plane(f, xl), -1) for f in self.force])
+            meshes = list(self.force) + ([potmesh] if potmesh is not None else [])
+            yield ("shift", [(pm.plane(f, 0), pm.plane(f, xl), -1) for f in meshes])
             pm.readout3(self.force, store)
-            if store.potential is not None:                                   # gravity.c:487-492
-                f = self.force[0]
-                yield from self._backward(delta_k, kernel, FIELD_POTENTIAL, f)
-                yield ("shift", [(pm.plane(f, 0), pm.plane(f, xl), -1)])
-                pm.readout(f, store, store.potential, 1, 0)
+            if potmesh is not None:
+                pm.readout(potmesh, store, store.potential, 1, 0)
             return
 
         # gravity.c:373-397: per component transfer -> c2r.  The three transfers and the x passes

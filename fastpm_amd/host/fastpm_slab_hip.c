@@ -90,7 +90,17 @@ int fastpm_hip_slab_force(fpmhip_plan *plan, const fastpm_hip_transport *t, cons
         TRY(exchange(plan, t, f[0], work, chunk_bytes));
         TRY(exchange(plan, t, f[1], work2, chunk_bytes));
         TRY(fpmhip_fft_yz_backward(plan, work, f[0]));
-        TRY(fpmhip_fft_yz_backward_grad2(plan, work2, f[1], f[2], kernel));
+        /* the potential column rides along: no second transfer, x pass and all-to-all for it */
+        void *potmesh = p->potential ? fpmhip_plan_buffer(plan, B_DELTA_K) : NULL;
+        if (p->potential && (delta_k == potmesh || !potmesh)) potmesh = NULL;     /* the caller wants delta_k kept there */
+        TRY(fpmhip_fft_yz_backward_grad2(plan, work2, f[1], f[2], potmesh, kernel));
+        if (potmesh) {
+            for (int d = 0; d < 3; d++)
+                TRY(shift(plan, t, f[d], 0, 1, fpmhip_plane_ptr(plan, f[d], xl), -1, plane_bytes));
+            TRY(shift(plan, t, potmesh, 0, 1, fpmhip_plane_ptr(plan, potmesh, xl), -1, plane_bytes));
+            TRY(fpmhip_readout3(plan, p, f[0], f[1], f[2]));
+            return fpmhip_readout1(plan, p, potmesh, p->potential, 1, 0);
+        }
     } else {
         if (fuse_x) {
             TRY(fpmhip_fft_x_forward(plan, delta_k));

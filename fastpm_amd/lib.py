@@ -82,11 +82,11 @@ SYMBOLS = {
     "fpmhip_r2c_transfer_fft_x_backward": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "fpmhip_fft_x_forward_transfer_backward": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "fpmhip_transfer_fft_x_backward_potx": (_I, [_P, _P, _P, _P, _I]),
-    "fpmhip_fft_yz_backward_grad2": (_I, [_P, _P, _P, _P, _I]),
+    "fpmhip_fft_yz_backward_grad2": (_I, [_P, _P, _P, _P, _P, _I]),
     "fpmhip_plan_ranged_fft": (_I, [_P]),
     "fpmhip_fft_yz_forward_range": (_I, [_P, _P, _P, _I, _I]),
     "fpmhip_fft_yz_backward_range": (_I, [_P, _P, _P, _I, _I]),
-    "fpmhip_fft_yz_backward_grad2_range": (_I, [_P, _P, _P, _P, _I, _I, _I]),
+    "fpmhip_fft_yz_backward_grad2_range": (_I, [_P, _P, _P, _P, _P, _I, _I, _I]),
     "fpmhip_readout3": (_I, [_P, ctypes.POINTER(Particles), _P, _P, _P]),
     "fpmhip_readout1": (_I, [_P, ctypes.POINTER(Particles), _P, _P, _I, _I]),
     "fpmhip_readout_grad": (_I, [_P, ctypes.POINTER(Particles), _P, _P]),

@@ -477,8 +477,9 @@ class PM:
     def fft_yz_backward_range(self, recv, canvas, x0, nx):
         check(self._L.fpmhip_fft_yz_backward_range(self._plan, _ptr(recv), _ptr(canvas), int(x0), int(nx)))
 
-    def fft_yz_backward_grad2_range(self, kernel, recv, out_y, out_z, x0, nx):
+    def fft_yz_backward_grad2_range(self, kernel, recv, out_y, out_z, x0, nx, out_pot=None):
         check(self._L.fpmhip_fft_yz_backward_grad2_range(self._plan, _ptr(recv), _ptr(out_y), _ptr(out_z),
+                                                         _ptr(out_pot) if out_pot is not None else None,
                                                          _enum(KERNEL_TYPES, kernel), int(x0), int(nx)))
 
     def staged_fft(self):
@@ -497,9 +498,10 @@ class PM:
         check(self._L.fpmhip_transfer_fft_x_backward_potx(self._plan, _ptr(delta_k), _ptr(out_x), _ptr(out_pot),
                                                           _enum(KERNEL_TYPES, kernel)))
 
-    def fft_yz_backward_grad2(self, kernel, recv, out_y, out_z):
-        """(transposed) potential -> y and z ACC components in real space."""
+    def fft_yz_backward_grad2(self, kernel, recv, out_y, out_z, out_pot=None):
+        """(transposed) potential -> y and z ACC components in real space (and, with out_pot, the potential itself)."""
         check(self._L.fpmhip_fft_yz_backward_grad2(self._plan, _ptr(recv), _ptr(out_y), _ptr(out_z),
+                                                   _ptr(out_pot) if out_pot is not None else None,
                                                    _enum(KERNEL_TYPES, kernel)))
 
     def fft_x_forward_transfer_backward(self, kernel, recv, mode, outs):

@@ -205,7 +205,10 @@ int fpmhip_transfer_fft_x_backward3(fpmhip_plan *plan, const void *delta_k_dev, 
  * 3 all-to-alls per force instead of 4.  recv may be out_y when nranks == 1. */
 int fpmhip_transfer_fft_x_backward_potx(fpmhip_plan *plan, const void *delta_k_dev, void *out_x_dev,
                                         void *out_pot_dev, int kernel);
-int fpmhip_fft_yz_backward_grad2(fpmhip_plan *plan, void *recv_dev, void *out_y_dev, void *out_z_dev, int kernel);
+/* out_pot_dev (nullable, a buffer of its own): also the potential in real space -- its (y, z) passes come from the same
+ * read of recv, so the potential column (gravity.c:487-492) costs no second transfer, x pass or all-to-all. */
+int fpmhip_fft_yz_backward_grad2(fpmhip_plan *plan, void *recv_dev, void *out_y_dev, void *out_z_dev, void *out_pot_dev,
+                                 int kernel);
 /* One rank, column-FFT back end, no softening: pm_r2c AND the transfer + x pass of the inverse transforms in one
  * go -- the forward x pass keeps delta_k's columns in registers, stores delta_k once and continues into the
  * transfer, so delta_k is never re-read.  mode 0: out0..2 = the three ACC components; mode 1: out0 = potential;
@@ -232,7 +235,7 @@ int fpmhip_plan_ranged_fft(const fpmhip_plan *plan);
 int fpmhip_fft_yz_forward_range(fpmhip_plan *plan, void *canvas_dev, void *send_dev, int x0, int nx);
 int fpmhip_fft_yz_backward_range(fpmhip_plan *plan, void *recv_dev, void *canvas_dev, int x0, int nx);
 int fpmhip_fft_yz_backward_grad2_range(fpmhip_plan *plan, void *recv_dev, void *out_y_dev, void *out_z_dev,
-                                       int kernel, int x0, int nx);
+                                       void *out_pot_dev, int kernel, int x0, int nx);
 /* 1 if the hand-written column-FFT back end is in use (FPMHIP_FFT_AUTO and a supported Nmesh): the
  * fused entry points fpmhip_transfer_fft_x_backward_potx / fpmhip_fft_yz_backward_grad2 need it */
 int fpmhip_plan_column_fft(const fpmhip_plan *plan);

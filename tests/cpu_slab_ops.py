@@ -182,7 +182,7 @@ class CpuSlabOps:
         a = np.concatenate([r_[s] for s in range(P)], axis=1)
         self._real(canvas)[x0:x0 + nx, :, :N] = scipy.fft.irfft2(a, s=(N, N), axes=(1, 2), norm="forward")
 
-    def fft_yz_backward_grad2_range(self, kernel, recv, out_y, out_z, x0, nx):
+    def fft_yz_backward_grad2_range(self, kernel, recv, out_y, out_z, x0, nx, out_pot=None):
         N, xl, yl, nzc, P = self.Nmesh, self.xl, self.yl, self.nzc, self.nranks
         assert O.kernel_orders(int(kernel))[1] == 1
         kf = O.k_tables(N, self.BoxSize)["k_finite"].astype(np.float64)
@@ -191,6 +191,8 @@ class CpuSlabOps:
         for out, fac in ((out_y, kf[None, :, None]), (out_z, kf[None, None, :nzc])):
             v = (1j * a * fac).astype(self.C)
             self._real(out)[x0:x0 + nx, :, :N] = scipy.fft.irfft2(v, s=(N, N), axes=(1, 2), norm="forward")
+        if out_pot is not None:
+            self._real(out_pot)[x0:x0 + nx, :, :N] = scipy.fft.irfft2(a, s=(N, N), axes=(1, 2), norm="forward")
 
     def fft_x_forward(self, recv):
         v = self._cplx(recv, (self.Nmesh, self.yl, self.nzc))
@@ -239,7 +241,7 @@ class CpuSlabOps:
         self.fft_x_backward(out_x)
         self.transfer_fft_x_backward_pot(kernel, delta_k, out_pot)
 
-    def fft_yz_backward_grad2(self, kernel, recv, out_y, out_z):
+    def fft_yz_backward_grad2(self, kernel, recv, out_y, out_z, out_pot=None):
         """fpmhip_fft_yz_backward_grad2: i k_finite[ky], i k_finite[kz] (float32 table) on the transposed,
         x-transformed potential, then the (y, z) inverse transforms."""
         N, xl, yl, nzc, P = self.Nmesh, self.xl, self.yl, self.nzc, self.nranks
@@ -251,6 +253,9 @@ class CpuSlabOps:
             v = (1j * a * fac).astype(self.C)
             out.zero_()
             self._real(out)[:xl, :, :N] = scipy.fft.irfft2(v, s=(N, N), axes=(1, 2), norm="forward")
+        if out_pot is not None:
+            out_pot.zero_()
+            self._real(out_pot)[:xl, :, :N] = scipy.fft.irfft2(a, s=(N, N), axes=(1, 2), norm="forward")
 
     def fft_x_forward_transfer_backward(self, kernel, recv, mode, outs):
         self.fft_x_forward(recv)
