@@ -531,11 +531,13 @@ class PM:
         check(self._L.fpmhip_paint_add(self._plan, ctypes.byref(store._c()), float(scale), _ptr(canvas)))
 
     def compute_force_host(self, x, mass=None, M0=1.0, kernel="1_4", softening="none", potential=False,
-                           want_delta_k=False):
-        """fpmhip_force_host: numpy in (as libfastpm holds its store), numpy out."""
+                           want_delta_k=False, acc=None, delta_k=None):
+        """fpmhip_force_host: numpy in (as libfastpm holds its store), numpy out.  acc / delta_k: optional
+        preallocated outputs (a fresh 200 MB numpy array per call costs more than the copies)."""
         x = np.ascontiguousarray(x, dtype=np.float64)
         n = len(x)
-        acc = np.zeros((n, 3), dtype=np.float32)
+        if acc is None:
+            acc = np.zeros((n, 3), dtype=np.float32)
         pot = np.zeros(n, dtype=np.float32) if potential else None
         m = None if mass is None else np.ascontiguousarray(mass, dtype=np.float32)
         c = _lib.Particles()
@@ -544,8 +546,8 @@ class PM:
         c.M0, c.np = float(M0), n
         c.acc = acc.ctypes.data
         c.potential = 0 if pot is None else pot.ctypes.data
-        dk = None
-        if want_delta_k:
+        dk = delta_k
+        if want_delta_k and dk is None:
             L = self.layout
             cdt = np.complex128 if self.precision == 64 else np.complex64
             dk = np.empty((L.osize[1], L.osize[2], L.osize[0]), dtype=cdt)
