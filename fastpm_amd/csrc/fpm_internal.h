@@ -132,6 +132,8 @@ struct fpmhip_plan {
     const double *binned_x = nullptr;
     const float *binned_mass = nullptr;
     int64_t binned_np = -1;
+    double *d_decic = nullptr;   // de-CIC factors 1 / sinc^2(w / 2) per axis index (transfer.c:90-93), built on first use
+    double *d_bins = nullptr;    // 3 * Nmesh / 2 doubles: P(k) bin sums
     // decompose scratch (keys, indices, radix-sort temporary), grown on demand
     unsigned char *dec_key_in = nullptr, *dec_key_out = nullptr;
     int *dec_idx = nullptr;

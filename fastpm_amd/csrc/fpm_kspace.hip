@@ -186,11 +186,14 @@ __global__ __launch_bounds__(256) void radial_kernel(MeshGeo g, const float *__r
 // powerspectrum.c:62-110: integer-wavenumber bins, weight 2 except on the kz = 0 and N/2 planes,
 // DC skipped.  (The reference tests the rank-local kz index, :94; with the slab layout kz is
 // never split so local == absolute.)  Per-block LDS bins, then one global atomic per bin.
-template <typename F>
-__global__ __launch_bounds__(256) void power_kernel(MeshGeo g, double k0, const Cplx<F> *__restrict__ d1,
-                                                    const Cplx<F> *__restrict__ d2, int nbins,
+// DECIC: d1 (== d2) is first multiplied, in place, by the de-CIC factors (separable_kernel's arithmetic and rounding,
+// transfer.c:77-113) and the sums are taken of the compensated values: fastpm_apply_decic_transfer followed by
+// fastpm_powerspectrum_init_from_delta (solver.c:471 + the FORCE/AFTER handler) in one sweep.
+template <typename F, bool DECIC>
+__global__ __launch_bounds__(256) void power_kernel(MeshGeo g, double k0, Cplx<F> *d1,
+                                                    const Cplx<F> *d2, int nbins,
                                                     double *__restrict__ gk, double *__restrict__ gp,
-                                                    double *__restrict__ gn)
+                                                    double *__restrict__ gn, const double *__restrict__ fac)
 {
     extern __shared__ double lds[];
     double *lk = lds, *lp = lds + nbins, *ln = lds + 2 * nbins;
@@ -212,10 +215,20 @@ __global__ __launch_bounds__(256) void power_kernel(MeshGeo g, double k0, const 
         long long bin = ((long long) floor(sqrt((double) kk))) - 2;
         if (bin < 0) bin = 0;
         while ((bin + 1) * (bin + 1) <= kk) bin++;
+        Cplx<F> a = d1[ind];
+        if (DECIC) {
+            double smth = 1.0;
+            smth *= fac[ix];
+            smth *= fac[iy];
+            smth *= fac[iz];
+            a.re = (F) (a.re * smth);
+            a.im = (F) (a.im * smth);
+            d1[ind] = a;
+        }
         if (bin >= nbins) continue;
         if (ix == 0 && iy == 0 && iz == 0) continue;
         const double k = sqrt((double) kk) * k0;
-        const Cplx<F> a = d1[ind], b = d2[ind];
+        const Cplx<F> b = DECIC ? a : d2[ind];
         const double value = (double) a.re * (double) b.re + (double) a.im * (double) b.im;
         const int w = (iz == 0 || iz == N / 2) ? 1 : 2;
         atomicAdd(&ln[bin], (double) w);
@@ -392,9 +405,9 @@ int fpmhip_mesh_scale(fpmhip_plan *p, void *buf, double value)
     return 0;
 }
 
-int fpmhip_decic(fpmhip_plan *p, const void *from, void *to)
+static int ensure_decic_table(fpmhip_plan *p)
 {
-    if (!p || !from || !to) FPM_FAIL(-1, "null argument");
+    if (p->d_decic) return 0;
     const int64_t N = p->mg.N;
     std::vector<double> fac(N);
     for (int64_t i = 0; i < N; i++) {
@@ -402,8 +415,22 @@ int fpmhip_decic(fpmhip_plan *p, const void *from, void *to)
         double cic = sinc_unnormed(0.5 * w);
         fac[i] = 1.0 / pow(cic, 2);                            // transfer.c:93
     }
+    FPM_CHECK_HIP(hipMalloc(&p->d_decic, N * sizeof(double)));
+    FPM_CHECK_HIP(hipMemcpy(p->d_decic, fac.data(), N * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int fpmhip_decic(fpmhip_plan *p, const void *from, void *to)
+{
+    if (!p || !from || !to) FPM_FAIL(-1, "null argument");
+    FPM_TRY(ensure_decic_table(p));
+    const MeshGeo &g = p->mg;
     StageTimer tm(p, FPMHIP_T_TRANSFER);
-    return p->f64 ? separable_impl<double>(p, fac, from, to) : separable_impl<float>(p, fac, from, to);
+    dim3 grid(blocks_for((long long) g.yl * g.nzc, 256), g.N);
+    if (p->f64) separable_kernel<double><<<grid, 256, 0, p->stream>>>(g, p->d_decic, (const Cplx<double> *) from, (Cplx<double> *) to);
+    else separable_kernel<float><<<grid, 256, 0, p->stream>>>(g, p->d_decic, (const Cplx<float> *) from, (Cplx<float> *) to);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 int fpmhip_softening(fpmhip_plan *p, void *delta_k, int type)
@@ -446,32 +473,45 @@ int fpmhip_softening(fpmhip_plan *p, void *delta_k, int type)
     return 0;
 }
 
-int fpmhip_powerspectrum(fpmhip_plan *p, const void *d1, const void *d2, double *ksum, double *psum, double *nmodes)
+static int powerspectrum_impl(fpmhip_plan *p, void *d1, const void *d2, bool decic, double *ksum, double *psum,
+                              double *nmodes)
 {
-    if (!p || !d1 || !ksum || !psum || !nmodes) FPM_FAIL(-1, "null argument");
-    if (!d2) d2 = d1;
     const MeshGeo &g = p->mg;
     const int nbins = g.N / 2;
-    double *dbins = nullptr;
-    FPM_CHECK_HIP(hipMalloc(&dbins, 3 * nbins * sizeof(double)));
+    if (!p->d_bins) FPM_CHECK_HIP(hipMalloc(&p->d_bins, 3 * (size_t) nbins * sizeof(double)));
+    double *dbins = p->d_bins;
     FPM_CHECK_HIP(hipMemsetAsync(dbins, 0, 3 * nbins * sizeof(double), p->stream));
     const double k0 = 2 * M_PI / p->geom.BoxSize;
     const int plane = g.yl * g.nzc;
     dim3 grid(std::max(1u, std::min(blocks_for(plane, 256 * 8), 64u)), (unsigned) std::min(g.N, 32));
     const size_t lds = 3 * nbins * sizeof(double);
-    if (p->f64)
-        power_kernel<double><<<grid, 256, lds, p->stream>>>(g, k0, (const Cplx<double> *) d1, (const Cplx<double> *) d2,
-                                                             nbins, dbins, dbins + nbins, dbins + 2 * nbins);
-    else
-        power_kernel<float><<<grid, 256, lds, p->stream>>>(g, k0, (const Cplx<float> *) d1, (const Cplx<float> *) d2,
-                                                            nbins, dbins, dbins + nbins, dbins + 2 * nbins);
+#define POWER(F, D)                                                                                          \
+    power_kernel<F, D><<<grid, 256, lds, p->stream>>>(g, k0, (Cplx<F> *) d1, (const Cplx<F> *) d2, nbins, dbins, \
+                                                      dbins + nbins, dbins + 2 * nbins, p->d_decic)
+    if (p->f64) { if (decic) POWER(double, true); else POWER(double, false); }
+    else { if (decic) POWER(float, true); else POWER(float, false); }
+#undef POWER
     std::vector<double> h(3 * nbins);
-    hipError_t e = hipMemcpyAsync(h.data(), dbins, 3 * nbins * sizeof(double), hipMemcpyDeviceToHost, p->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
-    (void) hipFree(dbins);
-    FPM_CHECK_HIP(e);
+    FPM_CHECK_HIP(hipMemcpyAsync(h.data(), dbins, 3 * nbins * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
     for (int i = 0; i < nbins; i++) { ksum[i] = h[i]; psum[i] = h[nbins + i]; nmodes[i] = h[2 * nbins + i]; }
     return 0;
+}
+
+int fpmhip_powerspectrum(fpmhip_plan *p, const void *d1, const void *d2, double *ksum, double *psum, double *nmodes)
+{
+    if (!p || !d1 || !ksum || !psum || !nmodes) FPM_FAIL(-1, "null argument");
+    return powerspectrum_impl(p, const_cast<void *>(d1), d2 ? d2 : d1, false, ksum, psum, nmodes);
+}
+
+// fastpm_apply_decic_transfer(delta_k, delta_k) (solver.c:471) + fastpm_powerspectrum_init_from_delta(delta_k,
+// delta_k) (the FORCE/AFTER handler) in ONE sweep: delta_k is compensated in place and binned on the way.
+int fpmhip_decic_powerspectrum(fpmhip_plan *p, void *delta_k, double *ksum, double *psum, double *nmodes)
+{
+    if (!p || !delta_k || !ksum || !psum || !nmodes) FPM_FAIL(-1, "null argument");
+    FPM_TRY(ensure_decic_table(p));
+    StageTimer tm(p, FPMHIP_T_TRANSFER);
+    return powerspectrum_impl(p, delta_k, delta_k, true, ksum, psum, nmodes);
 }
 
 int fpmhip_check_values(fpmhip_plan *p, const void *mesh, int64_t *count)

@@ -244,7 +244,7 @@ void fpmhip_plan_destroy(fpmhip_plan *p)
     for (int i = 0; i < BUF_COUNT; i++) if (p->buf[i]) (void) hipFree(p->buf[i]);
     release_host_stage(p);
     void *ptrs[] = {p->d_twiddle, p->d_tab, p->d_fac, p->sx, p->sy, p->sz, p->smass, p->sidx, p->tile_cnt,
-                    p->tile_off, p->tile_cur, p->scan_tmp, p->d_scalar, p->dec_key_in, p->dec_key_out, p->dec_idx, p->dec_counts, p->dec_tmp};
+                    p->tile_off, p->tile_cur, p->scan_tmp, p->d_scalar, p->d_decic, p->d_bins, p->dec_key_in, p->dec_key_out, p->dec_idx, p->dec_counts, p->dec_tmp};
     for (void *q : ptrs) if (q) (void) hipFree(q);
     if (p->h_pinned) (void) hipHostFree(p->h_pinned);
     for (auto &e : p->ev_used) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }

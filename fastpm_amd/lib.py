@@ -91,6 +91,7 @@ SYMBOLS = {
     "fpmhip_readout1": (_I, [_P, ctypes.POINTER(Particles), _P, _P, _I, _I]),
     "fpmhip_readout_grad": (_I, [_P, ctypes.POINTER(Particles), _P, _P]),
     "fpmhip_decic": (_I, [_P, _P, _P]),
+    "fpmhip_decic_powerspectrum": (_I, [_P, _P, _P, _P, _P]),
     "fpmhip_powerspectrum": (_I, [_P, _P, _P, _P, _P, _P]),
     "fpmhip_check_values": (_I, [_P, _P, ctypes.POINTER(_I64)]),
     "fpmhip_export_delta_k": (_I, [_P, _P, _P]),

@@ -261,6 +261,10 @@ int fpmhip_decic(fpmhip_plan *plan, const void *from_dev, void *to_dev);
  * per-bin sums (Nmesh/2 bins) of w*k, w*Re(d1 conj d2), w on the host.  Synchronises. */
 int fpmhip_powerspectrum(fpmhip_plan *plan, const void *d1_dev, const void *d2_dev,
                          double *ksum_host, double *psum_host, double *nmodes_host);
+/* Both of the above on the same mesh in ONE sweep: delta_k is de-CIC'ed in place (solver.c:471) and the compensated
+ * values are binned on the way (the FORCE/AFTER handler's fastpm_powerspectrum_init_from_delta(delta_k, delta_k)). */
+int fpmhip_decic_powerspectrum(fpmhip_plan *plan, void *delta_k_inplace_dev,
+                               double *ksum_host, double *psum_host, double *nmodes_host);
 /* pm_check_values (pmapi.c:335-356): count of NaN / |v| > 1e15 entries.  Synchronises. */
 int fpmhip_check_values(fpmhip_plan *plan, const void *mesh_dev, int64_t *count_host);
 /* copy a k-space mesh to the host in the reference's PFFT-transposed layout [y][z][x], and back */

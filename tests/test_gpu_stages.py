@@ -333,3 +333,23 @@ def test_sort_store_by_tile_is_a_permutation_that_speeds_up_binning(oracle):
     tile = (cell[:, 0] // 8 * (N // 8) + cell[:, 1] // 8) * (N // 32) + cell[:, 2] // 32
     assert (np.diff(tile) >= 0).all()
     pm.destroy()
+
+
+@pytest.mark.parametrize("precision", [64, 32])
+def test_fused_decic_powerspectrum_equals_the_two_calls(precision):
+    """fpmhip_decic_powerspectrum = fastpm_apply_decic_transfer in place + fastpm_powerspectrum_init_from_delta, one sweep."""
+    import torch
+    from fastpm_amd import PM, Store
+    N, nc, L = 64, 32, 96.0
+    pm = PM(N, L, precision)
+    st = Store(util.load_b(nc, L, N))
+    dk = pm.alloc()
+    pm.compute_force(st, delta_k=dk)
+    a, b = dk.clone(), dk.clone()
+    pm.apply_decic_transfer(a, a)
+    k1, p1, n1 = pm.powerspectrum(a)
+    k2, p2, n2 = pm.decic_powerspectrum(b)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert np.array_equal(n1, n2) and np.allclose(k1, k2, rtol=1e-14) and np.allclose(p1, p2, rtol=1e-12)
+    pm.destroy()

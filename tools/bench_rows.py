@@ -66,6 +66,8 @@ def main():
     d2 = pm.alloc()
     row("decic", timed(lambda: pm.apply_decic_transfer(dk, d2)), 2 * pm.layout.complex_elems * 16, "one read, one write of delta_k")
     row("powerspectrum", timed(lambda: pm.powerspectrum_sums(dk)), pm.layout.complex_elems * 16, "one read (synchronises: bin sums to the host)")
+    row("decic + powerspectrum fused", timed(lambda: pm.decic_powerspectrum(dk)), 2 * pm.layout.complex_elems * 16,
+        "one read, one write (synchronises)")
     row("decompose_order", timed(lambda: pm.decompose_order(st)), n * 24 + n * 8, "x in, order out (radix sort of owner keys; 1 rank: all stay)")
     order, _ = pm.decompose_order(st)
     row("gather_rows(x)", timed(lambda: pm.gather_rows(st.x, order)), n * 48 + n * 4, "permute one double[3] column")
@@ -95,8 +97,7 @@ def main():
         fastpm_drift_store(pm, df, st, st, 0.2)
         fastpm_store_wrap(pm, st)
         pm.compute_force(st, delta_k=dk)
-        pm.apply_decic_transfer(dk, dk)
-        pm.powerspectrum_sums(dk)
+        pm.decic_powerspectrum(dk)                       # solver.c:471 + the FORCE/AFTER handler, one sweep
         fastpm_kick_store(pm, kf, st, st, 0.2)
     ms = timed(step, reps=5, warm=1)
     out["kddfk_step_ms"] = round(ms, 3)
