@@ -99,6 +99,8 @@ SYMBOLS = {
     "fpmhip_transfer_host": (_I, [_P, _I, _P, _P, _I]),
     "fpmhip_kick": (_I, [_P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(KickFactor)]),
     "fpmhip_drift": (_I, [_P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(DriftFactor)]),
+    "fpmhip_leapfrog": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I, ctypes.POINTER(KickFactor), ctypes.POINTER(KickFactor),
+                             ctypes.POINTER(DriftFactor), ctypes.POINTER(DriftFactor), _I]),
     "fpmhip_wrap": (_I, [_P, _P, _I64]),
     "fpmhip_decompose_order": (_I, [_P, _P, _I64, _P, ctypes.POINTER(_I64)]),
     "fpmhip_gather_rows": (_I, [_P, _P, _P, _P, _I64, _I]),

@@ -153,6 +153,28 @@ def fastpm_drift_store(pm, drift, pi, po, af):
     po.a_x = af
 
 
+def fastpm_leapfrog_store(pm, kicks, drifts, p, wrap=True):
+    """kick(s), two drifts and the wrap of one leapfrog step in one pass over the columns (fpmhip_leapfrog): `kicks`
+    = [(KickFactor, af)] or two of them, `drifts` = [(DriftFactor, af), (DriftFactor, af)]; the same looked-up factor
+    differences as fastpm_kick_store / fastpm_drift_store, bit-identical columns."""
+    ks = []
+    a_v = p.a_v
+    for kick, af in kicks:
+        f, i = kick.lookup(af), kick.lookup(a_v)
+        ks.append(_lib.KickFactor(kick.forcemode, 0, f[0] - i[0], f[1] - i[1], f[2] - i[2], kick.q1, kick.q2))
+        a_v = af
+    ds = []
+    a_x = p.a_x
+    for drift, af in drifts:
+        f, i = drift.lookup(af), drift.lookup(a_x)
+        ds.append(_lib.DriftFactor(drift.forcemode, 0, f[0] - i[0], f[1] - i[1], f[2] - i[2], drift.Dv1, drift.Dv2))
+        a_x = af
+    check(pm._L.fpmhip_leapfrog(pm._plan, _ptr(p.acc), _ptr(p.v), _ptr(p.x), _ptr(p.dx1), _ptr(p.dx2), p.np, len(ks),
+                                ctypes.byref(ks[0]), ctypes.byref(ks[-1]), ctypes.byref(ds[0]), ctypes.byref(ds[1]),
+                                int(bool(wrap))))
+    p.a_v, p.a_x = a_v, a_x
+
+
 def fastpm_store_wrap(pm, p):
     """fastpm_store_wrap(p, BoxSize), store.c:446-475, in place on the device column."""
     check(pm._L.fpmhip_wrap(pm._plan, _ptr(p.x), p.np))

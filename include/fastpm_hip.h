@@ -291,6 +291,15 @@ int fpmhip_drift(fpmhip_plan *plan, const double *x_in_dev, const float *v_dev, 
                  const float *dx2_dev, double *x_out_dev, int64_t np, const fpmhip_drift_factor *drift);
 /* fastpm_store_wrap (store.c:446-475): x = remainder(x, BoxSize) shifted into [0, BoxSize], in place */
 int fpmhip_wrap(fpmhip_plan *plan, double *x_dev, int64_t np);
+/* The K D D run of the leapfrog template (solver.c:289-296) + the wrap that fastpm_decompose applies before the next
+ * force (solver.c:583), in ONE pass: v = kick(v) [twice when nkick == 2: the kick that closes a step and the one that
+ * opens the next act on the same acc]; x = drift1(drift0(x, v), v); x = wrap(x) if wrap != 0.  Every update is the
+ * stand-alone call's arithmetic, so the result is bit-identical to fpmhip_kick, fpmhip_drift x 2, fpmhip_wrap; the
+ * columns are read and written once (84 B per particle instead of 204 B).  Force modes FASTPM, PM, COLA. */
+int fpmhip_leapfrog(fpmhip_plan *plan, const float *acc_dev, float *v_dev, double *x_dev, const float *dx1_dev,
+                    const float *dx2_dev, int64_t np, int nkick, const fpmhip_kick_factor *kick0,
+                    const fpmhip_kick_factor *kick1, const fpmhip_drift_factor *drift0,
+                    const fpmhip_drift_factor *drift1, int wrap);
 
 /* ---- "next" row 3: the device half of fastpm_store_decompose (store.c:485-657), slabs ----
  * Owner rank of every particle (FastPMTargetPM, store.c:476-483) and the reference's stable order:

@@ -144,3 +144,39 @@ def test_variable_mesh_plans():
         ref = O.compute_force(O.PMOracle(nc * B, L, 64), x)["acc"]
         assert util.rel_err(st.acc.cpu().numpy(), ref) <= 1e-6
     vpm.destroy()
+
+
+@pytest.mark.parametrize("mode,nkick", [("fastpm", 1), ("pm", 2), ("cola", 1), ("cola", 2)])
+def test_fused_leapfrog_is_bit_identical_to_the_separate_calls(mode, nkick):
+    """fpmhip_leapfrog = kick [x2] + drift + drift + wrap in one pass over the columns, every update the stand-alone
+    kernel's arithmetic: identical bits in v and x."""
+    import torch
+    from fastpm_amd import (PM, DriftFactor, KickFactor, Store, fastpm_drift_store, fastpm_kick_store,
+                            fastpm_leapfrog_store, fastpm_store_wrap)
+    rng = np.random.default_rng(5)
+    n, L = 20000, 100.0
+    x = rng.uniform(-5, L + 5, (n, 3))
+    cols = dict(v=rng.normal(size=(n, 3)).astype(np.float32), dx1=rng.normal(size=(n, 3)).astype(np.float32),
+                dx2=rng.normal(size=(n, 3)).astype(np.float32))
+    acc = rng.normal(size=(n, 3)).astype(np.float32)
+    t = lambda s: np.sort(rng.uniform(0, s, 32))
+    k0 = KickFactor(mode, 0.1, 0.1, 0.15, t(2.0), t(1.0), t(1.0), q1=0.3, q2=0.05)
+    k1 = KickFactor(mode, 0.15, 0.2, 0.2, t(2.0), t(1.0), t(1.0), q1=0.4, q2=0.07)
+    d0 = DriftFactor(mode, 0.1, 0.15, 0.15, t(3.0), t(1.0), t(1.0), Dv1=0.2, Dv2=0.03)
+    d1 = DriftFactor(mode, 0.15, 0.15, 0.2, t(3.0), t(1.0), t(1.0), Dv1=0.2, Dv2=0.03)
+    pm = PM(16, L, 64)
+    a = Store(x, a_x=0.1, a_v=0.1 if nkick == 1 else 0.1, **cols)
+    b = Store(x, a_x=0.1, a_v=0.1, **cols)
+    for s in (a, b):
+        s.acc.copy_(torch.from_numpy(acc).cuda())
+    kicks = [(k0, 0.15)] + ([(k1, 0.2)] if nkick == 2 else [])
+    for k, af in kicks:                                            # separate calls
+        fastpm_kick_store(pm, k, a, a, af)
+    fastpm_drift_store(pm, d0, a, a, 0.15)
+    fastpm_drift_store(pm, d1, a, a, 0.2)
+    fastpm_store_wrap(pm, a)
+    fastpm_leapfrog_store(pm, kicks, [(d0, 0.15), (d1, 0.2)], b)   # one pass
+    torch.cuda.synchronize()
+    assert torch.equal(a.v, b.v) and torch.equal(a.x, b.x)
+    assert a.a_v == b.a_v and a.a_x == b.a_x
+    pm.destroy()
