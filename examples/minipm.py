@@ -113,34 +113,15 @@ def linear_power(k, ns=0.96, k0=0.2):
     return k ** ns / (1 + (k / k0) ** 2) ** 2
 
 
-def gaussian_delta_k(pm, seed, amplitude, transforms=None):
-    """delta(k) on the plan's k-space layout from white noise in real space (Hermitian by construction: it is the
-    r2c of a real field), shaped by sqrt(P(k)).  The noise of global x plane i comes from generator seed + i, so
-    the field is the same however many slabs the mesh is cut into."""
-    import torch
-    N, L = pm.Nmesh, pm.BoxSize
-    xl, x0 = int(pm.layout.isize[0]), int(pm.layout.istart[0])
-    yl, y0 = int(pm.layout.osize[1]), int(pm.layout.ostart[1])
-    white = pm.alloc()
-    rv = pm.real_view(white)
-    gen = torch.Generator(device=pm.device)
-    for i in range(xl):
-        gen.manual_seed(seed * 100003 + x0 + i)
-        rv[i, :, :N] = torch.randn((N, N), generator=gen, device=pm.device, dtype=pm.dtype)
+def gaussian_delta_k(pm, seed, amplitude):
+    """delta(k) the way the reference makes it (src/fastpm.c:476-523): fastpm_ic_fill_gaussiank's gadget scheme from
+    the seed -- the same field however many slabs the mesh is cut into -- then fastpm_ic_induce_correlation with
+    P(k) = amplitude^2 * linear_power(k) handed over as a (k, P) table, all on the device."""
+    from fastpm_amd import fastpm_ic_fill_gaussiank, fastpm_ic_induce_correlation
     dk = pm.alloc()
-    if transforms is None:
-        pm.r2c(white, dk)                                   # <|dk|^2> = 1 / N^3 per mode
-    else:
-        transforms.r2c(white, dk)
-    k1 = 2 * np.pi / L * torch.fft.fftfreq(N, d=1.0 / N, device=pm.device).to(pm.dtype)
-    kx, ky, kz = torch.meshgrid(k1, k1[y0:y0 + yl], k1[: N // 2 + 1].abs(), indexing="ij")
-    kk = (kx ** 2 + ky ** 2 + kz ** 2).sqrt()
-    zero = kk == 0
-    kk[zero] = 1.0
-    shape = torch.from_numpy(np.sqrt(linear_power(kk.cpu().numpy()))).to(pm.device).to(pm.dtype)
-    shape[zero] = 0.0
-    c = pm.complex_view(dk)
-    c *= shape * (amplitude * (N ** 1.5) / L ** 1.5)        # P(k) = amplitude^2 * linear_power(k)
+    fastpm_ic_fill_gaussiank(pm, dk, seed)
+    k = np.logspace(-4, 2, 1024)
+    fastpm_ic_induce_correlation(pm, dk, k, amplitude ** 2 * linear_power(k))
     return dk
 
 
@@ -152,7 +133,7 @@ def run(nc=64, B=2, BoxSize=None, steps=5, a0=0.1, a1=1.0, mode="fastpm", seed=1
     import torch.distributed as dist
     from fastpm_amd import (PM, VPM, Store, fastpm_drift_store, fastpm_kick_store, fastpm_store_wrap,
                             pm_2lpt_evolve, pm_2lpt_solve)
-    from fastpm_amd.distributed import Slab2LPT, SlabDecompose, SlabForce, SlabTransforms
+    from fastpm_amd.distributed import Slab2LPT, SlabDecompose, SlabForce
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     group = dist.group.WORLD if world > 1 else None
@@ -173,7 +154,7 @@ def run(nc=64, B=2, BoxSize=None, steps=5, a0=0.1, a1=1.0, mode="fastpm", seed=1
         return k, pk, n
 
     lptpm = PM(nc, L, precision, nranks=world, rank=rank)    # the IC mesh has the particle resolution (solver.c:112)
-    dk = gaussian_delta_k(lptpm, seed, amplitude, SlabTransforms(lptpm, group) if world > 1 else None)
+    dk = gaussian_delta_k(lptpm, seed, amplitude)
     # shift = false: particles start on mesh points; this rank's slab of the lattice (store.c:659-712)
     g = np.arange(nc) * L / nc
     gx = g[rank * (nc // world):(rank + 1) * (nc // world)]

@@ -93,6 +93,11 @@ SYMBOLS = {
     "fpmhip_decic": (_I, [_P, _P, _P]),
     "fpmhip_decic_powerspectrum": (_I, [_P, _P, _P, _P, _P]),
     "fpmhip_powerspectrum": (_I, [_P, _P, _P, _P, _P, _P]),
+    "fpmhip_ic_fill_gaussian": (_I, [_P, _P, _I]),
+    "fpmhip_ic_remove_variance": (_I, [_P, _P]),
+    "fpmhip_ic_induce_correlation": (_I, [_P, _P, _P, _P, _I]),
+    "fpmhip_ic_uniform_stream": (_I, [ctypes.c_ulong, _I, _P]),
+    "fpmhip_ic_seed_table": (_I, [_I, _I, _P]),
     "fpmhip_check_values": (_I, [_P, _P, ctypes.POINTER(_I64)]),
     "fpmhip_export_delta_k": (_I, [_P, _P, _P]),
     "fpmhip_import_delta_k": (_I, [_P, _P, _P]),

@@ -238,6 +238,25 @@ def pm_2lpt_evolve(pm, p, D1, D2, Dv1, Dv2, aout, zaonly=False):
     p.a_x = p.a_v = float(aout)
 
 
+def fastpm_ic_fill_gaussiank(pm, delta_k, seed, scheme="gadget"):
+    """fastpm_ic_fill_gaussiank (initialcondition.c:18-40).  The gadget scheme -- the reference's default, the one that
+    gives the same field on any number of ranks -- is the one on the device; "fast" and "slow" fill a real-space
+    mesh rank by rank from one sequential stream and are not offered."""
+    if scheme != "gadget":
+        raise ValueError("only the gadget scheme is implemented, got %r" % (scheme,))
+    return pm.ic_fill_gaussian(delta_k, seed)
+
+
+def fastpm_ic_remove_variance(pm, delta_k):
+    """fastpm_ic_remove_variance (initialcondition.c:66-98)."""
+    return pm.ic_remove_variance(delta_k)
+
+
+def fastpm_ic_induce_correlation(pm, delta_k, k, p):
+    """fastpm_ic_induce_correlation (initialcondition.c:55-64); (k, p) is the table a FastPMPowerSpectrum holds."""
+    return pm.ic_induce_correlation(delta_k, k, p)
+
+
 def fastpm_store_summary(pm, column, fmt, group=None):
     """fastpm_store_summary(p, attribute, comm, fmt, ...) (store.c:807-908) for a float column tensor
     [np][nmemb]: one array per character of fmt ('<' min, '>' max, '-' mean, 's' std, 'S', 'v', 'V')."""
@@ -457,6 +476,27 @@ class PM:
         p[nz] /= n[nz]
         p[nz] *= self.BoxSize ** 3
         return k, p, n
+
+    def ic_fill_gaussian(self, delta_k, seed):
+        """fastpm_ic_fill_gaussiank, gadget scheme (initialcondition.c:18-40, 144-266): white noise of unit variance
+        per mode in this rank's k-space slab, the reference's field for the seed."""
+        check(self._L.fpmhip_ic_fill_gaussian(self._plan, _ptr(delta_k), int(seed)))
+        return delta_k
+
+    def ic_remove_variance(self, delta_k):
+        """fastpm_ic_remove_variance (initialcondition.c:66-98)."""
+        check(self._L.fpmhip_ic_remove_variance(self._plan, _ptr(delta_k)))
+        return delta_k
+
+    def ic_induce_correlation(self, delta_k, k, p):
+        """fastpm_ic_induce_correlation (initialcondition.c:42-64) with P(k) as the table fastpm_funck_eval reads."""
+        k = np.ascontiguousarray(k, dtype=np.float64)
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        if k.shape != p.shape or k.ndim != 1:
+            raise ValueError("k and p must be 1-d tables of one length")
+        cp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        check(self._L.fpmhip_ic_induce_correlation(self._plan, _ptr(delta_k), cp(k), cp(p), int(k.size)))
+        return delta_k
 
     def check_values(self, mesh):
         out = ctypes.c_int64()

@@ -265,6 +265,25 @@ int fpmhip_powerspectrum(fpmhip_plan *plan, const void *d1_dev, const void *d2_d
  * values are binned on the way (the FORCE/AFTER handler's fastpm_powerspectrum_init_from_delta(delta_k, delta_k)). */
 int fpmhip_decic_powerspectrum(fpmhip_plan *plan, void *delta_k_inplace_dev,
                                double *ksum_host, double *psum_host, double *nmodes_host);
+/* ---- what comes before the first force: the Gaussian initial field ---- */
+/* fastpm_ic_fill_gaussiank with FASTPM_DELTAK_GADGET (initialcondition.c:18-40, 144-266): unit-variance white noise in
+ * k space from per-(x, y)-column RANLXD1 streams (GSL's gsl_rng_ranlxd1, restated), seeded by one master stream's walk
+ * over the plane -- the same field for every decomposition.  Fills this rank's k-space slab [x][y_loc][kz].  The
+ * uniforms are GSL's bit for bit; log / sqrt / sin / cos are the device's, so the field agrees with the reference's
+ * to ~1e-15 of its rms.  Synchronises. */
+int fpmhip_ic_fill_gaussian(fpmhip_plan *plan, void *delta_k_dev, int seed);
+/* fastpm_ic_remove_variance (initialcondition.c:66-98): every mode to unit modulus, phase kept. */
+int fpmhip_ic_remove_variance(fpmhip_plan *plan, void *delta_k_inplace_dev);
+/* fastpm_ic_induce_correlation (initialcondition.c:42-64, transfer.c:188-210): delta_k *= sqrt(P(k) / V), P(k)
+ * evaluated from the host table (k[size], p[size]) exactly as fastpm_funck_eval does (powerspectrum.c:391-425:
+ * bisection, log-log interpolation, 1 at k = 0).  size <= 4096.  Synchronises. */
+int fpmhip_ic_induce_correlation(fpmhip_plan *plan, void *delta_k_inplace_dev, const double *k_host,
+                                 const double *p_host, int size);
+/* Host-only views of the generator (no device work): n numbers of gsl_rng_uniform after gsl_rng_set(ranlxd1, seed),
+ * and the N x N seed table of the gadget scheme (initialcondition.c:156-171; table[0][0] of the reference). */
+int fpmhip_ic_uniform_stream(unsigned long seed, int n, double *out_host);
+int fpmhip_ic_seed_table(int Nmesh, int seed, unsigned int *table_host);
+
 /* pm_check_values (pmapi.c:335-356): count of NaN / |v| > 1e15 entries.  Synchronises. */
 int fpmhip_check_values(fpmhip_plan *plan, const void *mesh_dev, int64_t *count_host);
 /* copy a k-space mesh to the host in the reference's PFFT-transposed layout [y][z][x], and back */

@@ -308,7 +308,10 @@ def run_lightcone_test(ops, N=64, BoxSize=512.0, seed=100, Omega_m=0.307494, tim
     c = Cosmology(Omega_m, growth_mode)
     power = PowerTable()
     log = {"sigma8_input": power.sigma(8.0)}
-    dk = initial_delta_k_xyk(N, BoxSize, seed, power, F)
+    if hasattr(ops, "initial_delta_k"):                                 # the operator under test makes the field
+        dk = ops.initial_delta_k(seed, power.k, power.f)                # itself (src/fastpm.c:476-523)
+    else:
+        dk = initial_delta_k_xyk(N, BoxSize, seed, power, F)
     g = np.arange(N) * (BoxSize / N)                                     # store.c:659-712, shift = 0
     q = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
     dx1, dx2 = ops.lpt(dk, q)

@@ -16,9 +16,12 @@ class GpuOps:
         import torch
         from fastpm_amd import Store, pm_2lpt_solve
         pm = self.pm
-        dk = pm.alloc()
-        ctype = np.complex128 if pm.precision == 64 else np.complex64
-        pm.complex_view(dk).copy_(torch.from_numpy(np.ascontiguousarray(dk_xyk.astype(ctype))).cuda())
+        if isinstance(dk_xyk, torch.Tensor):                  # made on the device by initial_delta_k
+            dk = dk_xyk
+        else:
+            dk = pm.alloc()
+            ctype = np.complex128 if pm.precision == 64 else np.complex64
+            pm.complex_view(dk).copy_(torch.from_numpy(np.ascontiguousarray(dk_xyk.astype(ctype))).cuda())
         st = Store(q, v=np.zeros((len(q), 3), dtype=np.float32))
         pm_2lpt_solve(pm, dk, st, kernel="1_4")
         torch.cuda.synchronize()
@@ -60,6 +63,20 @@ class GpuOps:
         st = Store(x)
         fastpm_store_wrap(self.pm, st)
         return st.x.cpu().numpy()
+
+
+class GpuIcOps(GpuOps):
+    """GpuOps whose initial field, too, is made by the library from the seed (src/fastpm.c:476-523:
+    fastpm_ic_fill_gaussiank -> fastpm_ic_remove_variance -> fastpm_ic_induce_correlation)."""
+
+    def initial_delta_k(self, seed, k, p):
+        from fastpm_amd import fastpm_ic_fill_gaussiank, fastpm_ic_induce_correlation, fastpm_ic_remove_variance
+        pm = self.pm
+        dk = pm.alloc()
+        fastpm_ic_fill_gaussiank(pm, dk, seed)
+        fastpm_ic_remove_variance(pm, dk)
+        fastpm_ic_induce_correlation(pm, dk, k, p)
+        return dk
 
 
 class SlabGpuOps(GpuOps):

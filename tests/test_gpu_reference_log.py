@@ -15,7 +15,7 @@ import pytest
 from oracle import reference_run as R
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from gpu_reference_ops import GpuOps, SlabGpuOps  # noqa: E402
+from gpu_reference_ops import GpuIcOps, GpuOps, SlabGpuOps  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -36,6 +36,16 @@ def test_gpu_reproduces_the_reference_check_file(precision, gradient_mode):
     ops = GpuOps(64, 512.0, precision, gradient_mode)
     log = R.run_lightcone_test(ops, F=np.float64 if precision == 64 else np.float32)
     _check(log)
+    ops.pm.destroy()
+
+
+@pytest.mark.parametrize("precision", [64, 32])
+def test_gpu_reproduces_the_reference_check_file_from_the_seed(precision):
+    """As above with the initial field made on the device as well (fpmhip_ic_fill_gaussian from seed = 100,
+    remove_variance, induce_correlation with the reference's tests/powerspec.txt): from the seed to the last P(k)
+    line nothing but factor tables comes from the host."""
+    ops = GpuIcOps(64, 512.0, precision)
+    _check(R.run_lightcone_test(ops, F=np.float64 if precision == 64 else np.float32))
     ops.pm.destroy()
 
 
