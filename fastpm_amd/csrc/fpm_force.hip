@@ -162,11 +162,28 @@ int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets
 
 int fpmhip_force_host(fpmhip_plan *p, const fpmhip_particles *ph, int kernel, int softening, void *delta_k_host)
 {
-    if (!p || !ph) FPM_FAIL(-1, "null argument");
-    if (ph->np > 0 && (!ph->x || !ph->acc)) FPM_FAIL(-1, "store without x or acc columns");
+    return fpmhip_force_species_host(p, ph, 1, kernel, softening, delta_k_host);
+}
+
+// All species of the solver with host-resident columns (gravity.c:279-287, 323-338, 387-395): the sets are staged
+// back to back in one device region, go through fpmhip_force_species, and every set's acc (and potential) comes back.
+int fpmhip_force_species_host(fpmhip_plan *p, const fpmhip_particles *sets, int nsets, int kernel, int softening,
+                              void *delta_k_host)
+{
+    if (!p || !sets || nsets < 1) FPM_FAIL(-1, "null argument");
+    if (nsets > 6) FPM_FAIL(-1, "at most FASTPM_SOLVER_NSPECIES = 6 species");
+    int64_t np = 0;
+    bool any_mass = false, any_pot = false;
+    for (int si = 0; si < nsets; si++) {
+        const fpmhip_particles &ph = sets[si];
+        if (ph.np < 0) FPM_FAIL(-1, "negative particle count");
+        if (ph.np > 0 && (!ph.x || !ph.acc)) FPM_FAIL(-1, "store without x or acc columns");
+        np += ph.np;
+        any_mass |= ph.mass != nullptr;
+        any_pot |= ph.potential != nullptr;
+    }
     HostStage *st = stage_for(p);
-    const int64_t np = ph->np;
-    if (np > st->cap || (ph->mass && !st->mass) || (ph->potential && !st->pot)) {
+    if (np > st->cap || (any_mass && !st->mass) || (any_pot && !st->pot)) {
         if (st->x) { (void) hipFree(st->x); (void) hipFree(st->acc); }
         if (st->mass) (void) hipFree(st->mass);
         if (st->pot) (void) hipFree(st->pot);
@@ -174,22 +191,38 @@ int fpmhip_force_host(fpmhip_plan *p, const fpmhip_particles *ph, int kernel, in
         int64_t cap = std::max<int64_t>(np + np / 16, 1024);
         FPM_CHECK_HIP(hipMalloc(&st->x, cap * 3 * sizeof(double)));
         FPM_CHECK_HIP(hipMalloc(&st->acc, cap * 3 * sizeof(float)));
-        if (ph->mass) FPM_CHECK_HIP(hipMalloc(&st->mass, cap * sizeof(float)));
-        if (ph->potential) FPM_CHECK_HIP(hipMalloc(&st->pot, cap * sizeof(float)));
+        if (any_mass) FPM_CHECK_HIP(hipMalloc(&st->mass, cap * sizeof(float)));
+        if (any_pot) FPM_CHECK_HIP(hipMalloc(&st->pot, cap * sizeof(float)));
         st->cap = cap;
     }
-    FPM_CHECK_HIP(hipMemcpyAsync(st->x, ph->x, np * 3 * sizeof(double), hipMemcpyHostToDevice, p->stream));
-    if (ph->mass) FPM_CHECK_HIP(hipMemcpyAsync(st->mass, ph->mass, np * sizeof(float), hipMemcpyHostToDevice, p->stream));
-    fpmhip_particles pd = *ph;
-    pd.x = st->x;
-    pd.mass = ph->mass ? st->mass : nullptr;
-    pd.acc = st->acc;
-    pd.potential = ph->potential ? st->pot : nullptr;
+    fpmhip_particles pd[6];
+    int64_t off = 0;
+    for (int si = 0; si < nsets; si++) {
+        const fpmhip_particles &ph = sets[si];
+        pd[si] = ph;
+        pd[si].x = st->x + 3 * off;
+        pd[si].mass = ph.mass ? st->mass + off : nullptr;
+        pd[si].acc = st->acc + 3 * off;
+        pd[si].potential = ph.potential ? st->pot + off : nullptr;
+        if (ph.np > 0) {
+            FPM_CHECK_HIP(hipMemcpyAsync(st->x + 3 * off, ph.x, ph.np * 3 * sizeof(double), hipMemcpyHostToDevice,
+                                         p->stream));
+            if (ph.mass)
+                FPM_CHECK_HIP(hipMemcpyAsync(st->mass + off, ph.mass, ph.np * sizeof(float), hipMemcpyHostToDevice,
+                                             p->stream));
+        }
+        off += ph.np;
+    }
     FPM_TRY(ensure_buffer(p, BUF_DELTA_K));
-    FPM_TRY(fpmhip_force(p, &pd, kernel, softening, -1.0, p->buf[BUF_DELTA_K]));
-    FPM_CHECK_HIP(hipMemcpyAsync(ph->acc, st->acc, np * 3 * sizeof(float), hipMemcpyDeviceToHost, p->stream));
-    if (ph->potential)
-        FPM_CHECK_HIP(hipMemcpyAsync(ph->potential, st->pot, np * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+    FPM_TRY(fpmhip_force_species(p, pd, nsets, kernel, softening, -1.0, p->buf[BUF_DELTA_K]));
+    for (int si = 0; si < nsets; si++) {
+        const fpmhip_particles &ph = sets[si];
+        if (ph.np == 0) continue;
+        FPM_CHECK_HIP(hipMemcpyAsync(ph.acc, pd[si].acc, ph.np * 3 * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+        if (ph.potential)
+            FPM_CHECK_HIP(hipMemcpyAsync(ph.potential, pd[si].potential, ph.np * sizeof(float), hipMemcpyDeviceToHost,
+                                         p->stream));
+    }
     FPM_CHECK_HIP(hipStreamSynchronize(p->stream));   // the caller reads acc on the host right away
     if (delta_k_host) FPM_TRY(fpmhip_export_delta_k(p, p->buf[BUF_DELTA_K], delta_k_host));
     return 0;

@@ -108,10 +108,5 @@ void fastpm_solver_compute_force_hip(FastPMSolverView *fastpm, PMView *pm, FastP
         fpm_raise(-1, "no particle species in the solver\n");
         return;
     }
-    if (nspecies > 1) {
-        fpm_raise(-1, "host-column path: one species per call (device columns: fpmhip_force_species)\n");
-        return;
-    }
-    const fpmhip_particles part = parts[0];
-    HIP_OR_RAISE(fpmhip_force_host(pm->plan, &part, (int) kernel, (int) dealias, delta_k));
+    HIP_OR_RAISE(fpmhip_force_species_host(pm->plan, parts, nspecies, (int) kernel, (int) dealias, delta_k));
 }

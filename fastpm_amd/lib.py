@@ -59,6 +59,7 @@ SYMBOLS = {
     "fpmhip_force": (_I, [_P, ctypes.POINTER(Particles), _I, _I, _D, _P]),
     "fpmhip_force_species": (_I, [_P, ctypes.POINTER(Particles), _I, _I, _I, _D, _P]),
     "fpmhip_force_host": (_I, [_P, ctypes.POINTER(Particles), _I, _I, _P]),
+    "fpmhip_force_species_host": (_I, [_P, ctypes.POINTER(Particles), _I, _I, _I, _P]),
     "fpmhip_paint": (_I, [_P, ctypes.POINTER(Particles), _D, _P]),
     "fpmhip_paint_add": (_I, [_P, ctypes.POINTER(Particles), _D, _P]),
     "fpmhip_total_mass": (_I, [_P, ctypes.POINTER(Particles), ctypes.POINTER(_D)]),

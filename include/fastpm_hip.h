@@ -141,6 +141,9 @@ int fpmhip_force_species(fpmhip_plan *plan, const fpmhip_particles *sets_dev, in
  * (PFFT transposed [y][z][x], pmpfft.c:198-202) so host handlers iterate it with PMKIter. */
 int fpmhip_force_host(fpmhip_plan *plan, const fpmhip_particles *p_host, int kernel, int softening,
                       void *delta_k_host);
+/* ... for every species the solver holds (gravity.c:279-287, 323-338, 387-395), all columns on the host. */
+int fpmhip_force_species_host(fpmhip_plan *plan, const fpmhip_particles *sets_host, int nsets, int kernel,
+                              int softening, void *delta_k_host);
 
 /* ---- stages (any nranks).  gravity.c:305-356 / :359-429 in pieces. ---- */
 

@@ -77,6 +77,36 @@ def test_c_host_force_matches_oracle(oracle):
     H.fastpm_free_pm_hip(pm)
 
 
+@pytest.mark.gpu
+def test_c_host_force_with_two_species(oracle):
+    """CDM + NCDM stores in the solver (solver.h:83-88), both host-resident: one mesh, each its own acc
+    (gravity.c:279-287, 323-338, 387-395) -- and an empty third species on the way."""
+    H = _host()
+    N, nc, L = 32, 16, 48.0
+    x1 = util.load_a(nc, L, N)
+    x2 = np.ascontiguousarray(util.load_b(nc, L, N, seed=77)[::3])
+    m2 = np.random.default_rng(8).uniform(0, 0.05, len(x2)).astype(np.float32)
+    pmo = oracle.PMOracle(N, L, 64)
+    accs, dko = oracle.compute_force_species(pmo, [{"x": x1, "M0": 1.0}, {"x": x2, "mass": m2, "M0": 0.1}])
+    a1 = np.zeros((len(x1), 3), dtype=np.float32)
+    a2 = np.zeros((len(x2), 3), dtype=np.float32)
+    s1 = StoreView(len(x1), x1.ctypes.data, a1.ctypes.data, None, None, 1.0)
+    s2 = StoreView(len(x2), x2.ctypes.data, a2.ctypes.data, None, m2.ctypes.data, 0.1)
+    s3 = StoreView(0, None, None, None, None, 1.0)
+    sv = SolverView()
+    for si, s in ((1, s1), (2, s2), (4, s3)):
+        sv.species[si] = ctypes.pointer(s)
+        sv.has_species[si] = 1
+    pm = H.fastpm_create_pm_hip(N, L, 64)
+    dk = np.zeros(pmo.allocsize, dtype=np.float64)
+    painter = PainterView(0, 2)
+    H.fastpm_solver_compute_force_hip(ctypes.byref(sv), pm, ctypes.byref(painter), 0, 3, dk.ctypes.data, 1.0)
+    assert util.rel_err(a1, accs[0]) <= 1e-6
+    assert util.rel_err(a2, accs[1]) <= 1e-6
+    assert util.max_err(pmo.complex_view(dk), pmo.complex_view(dko)) <= 1e-14
+    H.fastpm_free_pm_hip(pm)
+
+
 # ---- NTask > 1: fastpm_hip_slab_force (fastpm_amd/host/fastpm_slab_hip.c) ---------------------------------
 class Transport(ctypes.Structure):
     _fields_ = [("ctx", ctypes.c_void_p), ("rank", ctypes.c_int), ("nranks", ctypes.c_int),
