@@ -11,6 +11,8 @@
 //                 place on the received [x][y_loc][kz] block.  backward is the mirror image.
 #include <cstdlib>
 
+#include <mutex>
+
 #include "fpm_internal.h"
 
 namespace fpm {
@@ -60,7 +62,8 @@ static int fft_exec(fpmhip_plan *p, rocfft_plan plan, void *in, void *out)
     return 0;
 }
 
-static bool g_rocfft_ready = false;
+static std::once_flag g_rocfft_once;          // plans may be created from several host threads (one per GPU)
+static rocfft_status g_rocfft_status = rocfft_status_success;
 
 // forward z pass of the column-FFT back end: own fused r2c row kernel when N/2 is supported,
 // rocFFT's batched 1-D r2c (two kernels) otherwise
@@ -73,10 +76,8 @@ static int z_forward(fpmhip_plan *p, void *in, void *out)
 
 int fft_setup(fpmhip_plan *p)
 {
-    if (!g_rocfft_ready) {
-        FPM_CHECK_FFT(rocfft_setup());
-        g_rocfft_ready = true;
-    }
+    std::call_once(g_rocfft_once, [] { g_rocfft_status = rocfft_setup(); });
+    FPM_CHECK_FFT(g_rocfft_status);
     const MeshGeo &g = p->mg;
     const size_t N = g.N, nzc = g.nzc, xl = g.xl, yl = g.yl;
     const double inv_norm = 1.0 / p->lay.Norm;

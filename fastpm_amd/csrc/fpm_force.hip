@@ -5,41 +5,6 @@
 
 using namespace fpm;
 
-namespace {
-
-struct HostStage {
-    double *x = nullptr;
-    float *mass = nullptr, *acc = nullptr, *pot = nullptr;
-    int64_t cap = 0;
-};
-
-// device staging for fpmhip_force_host, one per plan (kept in a side table to keep the plan POD-ish)
-static std::vector<std::pair<fpmhip_plan *, HostStage>> g_stage;
-
-HostStage *stage_for(fpmhip_plan *p)
-{
-    for (auto &e : g_stage) if (e.first == p) return &e.second;
-    g_stage.push_back({p, HostStage()});
-    return &g_stage.back().second;
-}
-
-}  // namespace
-
-namespace fpm {
-void release_host_stage(fpmhip_plan *p)
-{
-    for (size_t i = 0; i < g_stage.size(); i++) {
-        if (g_stage[i].first != p) continue;
-        HostStage &st = g_stage[i].second;
-        if (st.x) { (void) hipFree(st.x); (void) hipFree(st.acc); }
-        if (st.mass) (void) hipFree(st.mass);
-        if (st.pot) (void) hipFree(st.pot);
-        g_stage.erase(g_stage.begin() + i);
-        return;
-    }
-}
-}  // namespace fpm
-
 extern "C" {
 
 int fpmhip_force(fpmhip_plan *p, const fpmhip_particles *pt, int kernel, int softening, double total_mass,
@@ -182,12 +147,12 @@ int fpmhip_force_species_host(fpmhip_plan *p, const fpmhip_particles *sets, int 
         any_mass |= ph.mass != nullptr;
         any_pot |= ph.potential != nullptr;
     }
-    HostStage *st = stage_for(p);
+    fpm::HostStage *st = &p->host_stage;      // device staging of the host columns, owned by the plan
     if (np > st->cap || (any_mass && !st->mass) || (any_pot && !st->pot)) {
         if (st->x) { (void) hipFree(st->x); (void) hipFree(st->acc); }
         if (st->mass) (void) hipFree(st->mass);
         if (st->pot) (void) hipFree(st->pot);
-        *st = HostStage();
+        *st = fpm::HostStage();
         int64_t cap = std::max<int64_t>(np + np / 16, 1024);
         FPM_CHECK_HIP(hipMalloc(&st->x, cap * 3 * sizeof(double)));
         FPM_CHECK_HIP(hipMalloc(&st->acc, cap * 3 * sizeof(float)));

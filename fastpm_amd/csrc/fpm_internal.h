@@ -74,6 +74,13 @@ struct MeshGeo {
     int ntx, nty, ntz; // tile grid over [xplanes][N][N]
 };
 
+// device staging of host-resident store columns (fpmhip_force_host / fpmhip_force_species_host)
+struct HostStage {
+    double *x = nullptr;
+    float *mass = nullptr, *acc = nullptr, *pot = nullptr;
+    int64_t cap = 0;
+};
+
 struct EventPair {
     hipEvent_t a, b;
     int stage;
@@ -132,6 +139,7 @@ struct fpmhip_plan {
     const double *binned_x = nullptr;
     const float *binned_mass = nullptr;
     int64_t binned_np = -1;
+    fpm::HostStage host_stage;
     double *d_decic = nullptr;   // de-CIC factors 1 / sinc^2(w / 2) per axis index (transfer.c:90-93), built on first use
     double *d_bins = nullptr;    // 3 * Nmesh / 2 doubles: P(k) bin sums
     // decompose scratch (keys, indices, radix-sort temporary), grown on demand
@@ -191,7 +199,6 @@ int colfft_yback2_range(fpmhip_plan *p, const void *in, void *oy, void *oz, void
                         int nx);
 
 // fpm_force.hip
-void release_host_stage(fpmhip_plan *p);
 
 // fpm_kspace.hip
 int upload_factor_tables(fpmhip_plan *p, const std::vector<double> &fx);

@@ -659,6 +659,46 @@ __global__ __launch_bounds__(256) void readout3_tiles_kernel(MeshGeo g, int ntil
     }
 }
 
+// A/B variant (FPMHIP_READOUT=2): one workgroup per (tile, component).  A third of the LDS per workgroup (21 KB
+// instead of 64 KB: 7 instead of 2 workgroups per CU to hide the staging loads behind), at the price of reading the
+// tile's positions three times (L2) and 4-byte result stores.
+template <typename F>
+__global__ __launch_bounds__(256) void readout1of3_tiles_kernel(MeshGeo g, int ntiles, const int *__restrict__ off,
+                                                                const double *__restrict__ sx,
+                                                                const double *__restrict__ sy,
+                                                                const double *__restrict__ sz,
+                                                                const int *__restrict__ sidx,
+                                                                const F *__restrict__ m0, const F *__restrict__ m1,
+                                                                const F *__restrict__ m2, float *__restrict__ out)
+{
+    constexpr int RX = TILE_X + 1, RY = TILE_Y + 1, RZ = TILE_Z + 1;
+    extern __shared__ __align__(16) unsigned char smem_ro[];
+    F *reg = (F *) smem_ro;                       // [RX][RY][RZ]
+    const int b = xcd_remap(blockIdx.x, 3 * ntiles);
+    const int t = b / 3, comp = b - 3 * t;
+    const int beg = off[t], end = off[t + 1];
+    if (beg == end) return;
+    const int tz = t % g.ntz, ty = (t / g.ntz) % g.nty, tx = t / (g.ntz * g.nty);
+    const int x0 = tx * TILE_X, y0 = ty * TILE_Y, z0 = tz * TILE_Z;
+    const F *mesh = comp == 0 ? m0 : (comp == 1 ? m1 : m2);
+    stage_region<F, RX, RY, RZ>(reg, mesh, (const F *) nullptr, g, x0, y0, z0);
+    __syncthreads();
+    for (int j = beg + threadIdx.x; j < end; j += 256) {
+        Cic c;
+        (void) cic_setup(g, sx[j], sy[j], sz[j], c);
+        const int lx = c.i0[0] - x0, ly = c.i0[1] - y0, lz = c.i0[2] - z0;
+        const double wx[2] = {c.t[0], c.d[0]}, wy[2] = {c.t[1], c.d[1]}, wz[2] = {c.t[2], c.d[2]};
+        double value = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int bx = (k >> 2) & 1, by = (k >> 1) & 1, bz = k & 1;
+            const int li = ((lx + bx) * RY + (ly + by)) * RZ + (lz + bz);
+            value += (double) reg[li] * (wz[bz] * wx[bx] * wy[by]);
+        }
+        out[(long long) sidx[j] * 3 + comp] = (float) value;
+    }
+}
+
 // gravity.c:330-335: sum of M0 + mass[i].  (Per-block double partial sums, then one atomic
 // per block; the reference sums serially, so only the rounding order differs.)
 __global__ __launch_bounds__(256) void mass_sum_kernel(const float *__restrict__ mass, double M0,
@@ -777,10 +817,25 @@ static int readout_impl(fpmhip_plan *p, const fpmhip_particles *pt, const F *m0,
     }
     if (p->binned_x != pt->x || p->binned_np != np) FPM_TRY(bin_particles(p, pt));
     StageTimer tm(p, FPMHIP_T_READOUT);
-    // measured on configs[1] (loads A / B / C): LDS-staged 1.05 / 1.14 / 1.79 ms, direct gather of the
-    // binned entries 1.10 / 1.23 / 2.03 ms (the LDS kernel took 2.46 ms before stage_region() kept its
-    // loads in flight, see there).  FPMHIP_READOUT=0 selects the direct kernel (A/B).
-    static int lds_mode = getenv("FPMHIP_READOUT") ? atoi(getenv("FPMHIP_READOUT")) : 1;
+    // measured on configs[1] (loads A / B / C; tools/ab_readout.sh):
+    //   2 (fp64 default) LDS-staged, one workgroup per (tile, component)   0.96 / 1.03 / 1.89 ms
+    //   1 (fp32 default) LDS-staged, three meshes per workgroup            1.06 / 1.14 / 1.80 ms
+    //   0           direct gather of the binned entries               1.10 / 1.23 / 2.03 ms
+    // (the LDS kernel took 2.46 ms before stage_region() kept its loads in flight, see there).  Load C is 16.8 M
+    // uniformly random rows, 10 % of them in 0.1 % of the volume: its result rows are scattered, and three 4-byte
+    // stores per row cost more than one 12-byte store; stores that keep the lattice's row order (A, B, any real run)
+    // gain 10 %.  Sending the dense tiles to kernel 1 and the rest to kernel 2 was tried: no better on C, and the
+    // second launch's idle workgroups cost A 0.06 ms.  On fp32 meshes three regions are 32 KB, five workgroups fit a
+    // CU as it is, and kernel 1 stays ahead (0.55 vs 0.63 ms).
+    static int lds_env = getenv("FPMHIP_READOUT") ? atoi(getenv("FPMHIP_READOUT")) : -1;
+    const int lds_mode = lds_env >= 0 ? lds_env : (sizeof(F) == 8 ? 2 : 1);
+    if (NC == 3 && nmemb == 3 && memb0 == 0 && lds_mode == 2) {
+        const size_t lds = (size_t) (TILE_X + 1) * (TILE_Y + 1) * (TILE_Z + 1) * sizeof(F);
+        readout1of3_tiles_kernel<F><<<3 * p->ntiles, 256, lds, p->stream>>>(p->mg, p->ntiles, p->tile_off, p->sx,
+                                                                             p->sy, p->sz, p->sidx, m0, m1, m2, out);
+        FPM_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     if (NC == 3 && nmemb == 3 && memb0 == 0 && lds_mode) {
         const size_t lds = (size_t) 3 * (TILE_X + 1) * (TILE_Y + 1) * (TILE_Z + 1) * sizeof(F);
         static bool granted = false;

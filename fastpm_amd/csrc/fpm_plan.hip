@@ -242,8 +242,8 @@ void fpmhip_plan_destroy(fpmhip_plan *p)
     (void) hipStreamSynchronize(p->stream);
     fft_teardown(p);
     for (int i = 0; i < BUF_COUNT; i++) if (p->buf[i]) (void) hipFree(p->buf[i]);
-    release_host_stage(p);
-    void *ptrs[] = {p->d_twiddle, p->d_tab, p->d_fac, p->sx, p->sy, p->sz, p->smass, p->sidx, p->tile_cnt,
+    void *ptrs[] = {p->host_stage.x, p->host_stage.acc, p->host_stage.mass, p->host_stage.pot,
+                    p->d_twiddle, p->d_tab, p->d_fac, p->sx, p->sy, p->sz, p->smass, p->sidx, p->tile_cnt,
                     p->tile_off, p->tile_cur, p->scan_tmp, p->d_scalar, p->d_decic, p->d_bins, p->dec_key_in, p->dec_key_out, p->dec_idx, p->dec_counts, p->dec_tmp};
     for (void *q : ptrs) if (q) (void) hipFree(q);
     if (p->h_pinned) (void) hipHostFree(p->h_pinned);

@@ -46,7 +46,7 @@ def main():
     stage = {
         "sort": add(hbm("bin_kernel<false>"), hbm("bin_kernel<true>")),
         "paint": hbm("paint_tiles"),
-        "readout": hbm("readout3_tiles") or hbm("readout_grad_tiles") or hbm("readout_kernel") or hbm("readout_grad_kernel"),
+        "readout": hbm("readout1of3_tiles") or hbm("readout3_tiles") or hbm("readout_grad_tiles") or hbm("readout_kernel") or hbm("readout_grad_kernel"),
         "xback3": hbm("xback3"),
         "k_yback2": hbm("yback2"),
         "k_colfft": hbm("colfft_kernel<%s" % N),
