@@ -26,7 +26,7 @@ void fpm_set_msg_handler(fpm_msg_handler handler, void *userdata)
     g_userdata = userdata;
 }
 
-static void fpm_raise(int code, const char *fmt, ...)        /* logging.c:242-251 */
+void fpm_raise_hip(int code, const char *fmt, ...)           /* logging.c:242-251; shared by the host files */
 {
     char buf[1024];
     va_list ap;
@@ -35,6 +35,7 @@ static void fpm_raise(int code, const char *fmt, ...)        /* logging.c:242-25
     va_end(ap);
     g_handler(code, buf, g_userdata);
 }
+#define fpm_raise fpm_raise_hip
 
 #define HIP_OR_RAISE(expr) do { if ((expr) != 0) fpm_raise(-1, "%s\n", fpmhip_last_error()); } while (0)
 

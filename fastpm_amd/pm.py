@@ -257,6 +257,30 @@ def fastpm_ic_induce_correlation(pm, delta_k, k, p):
     return pm.ic_induce_correlation(delta_k, k, p)
 
 
+def fastpm_powerspectrum_large_scale(pm, k, p, nmodes, Nmax):
+    """fastpm_powerspectrum_large_scale (powerspectrum.c:170-184) of a measured (k, P, Nmodes): the mode-weighted
+    mean power of the bins with k <= Nmax * k0 (the first bin always counts)."""
+    kmax = Nmax * 2 * np.pi / pm.BoxSize
+    num = den = 0.0
+    i = 0
+    while i == 0 or (i < len(k) and k[i] <= kmax):
+        num += p[i] * nmodes[i]
+        den += nmodes[i]
+        i += 1
+    return num / den
+
+
+def fastpm_powerspectrum_write(pm, k, p, nmodes, filename, N):
+    """fastpm_powerspectrum_write (powerspectrum.c:149-168): the "# k p N" rows and the seven metadata lines."""
+    V, L = pm.BoxSize ** 3, pm.BoxSize
+    with open(filename, "w") as fp:
+        fp.write("# k p N \n")
+        for row in zip(k, p, nmodes):
+            fp.write("%g %g %g\n" % row)
+        fp.write("# metadata 7\n# volume %g float64\n# shotnoise %g float64\n# N1 %g int\n# N2 %g int\n"
+                 "# Lz %g float64\n# Lx %g float64\n# Ly %g float64\n" % (V, V / N, N, N, L, L, L))
+
+
 def fastpm_store_summary(pm, column, fmt, group=None):
     """fastpm_store_summary(p, attribute, comm, fmt, ...) (store.c:807-908) for a float column tensor
     [np][nmemb]: one array per character of fmt ('<' min, '>' max, '-' mean, 's' std, 'S', 'v', 'V')."""

@@ -41,7 +41,11 @@ def _host():
 def test_host_library_exports():
     H = _host()
     for name in ("fastpm_solver_compute_force_hip", "fastpm_kernel_type_get_orders_hip",
-                 "fastpm_create_pm_hip", "fastpm_free_pm_hip", "fpm_set_msg_handler"):
+                 "fastpm_create_pm_hip", "fastpm_free_pm_hip", "fpm_set_msg_handler",
+                 "fastpm_powerspectrum_init_from_delta_hip", "fastpm_decic_powerspectrum_hip",
+                 "fastpm_apply_decic_transfer_hip", "fastpm_powerspectrum_write_hip",
+                 "fastpm_powerspectrum_large_scale_hip", "fastpm_powerspectrum_eval_hip",
+                 "fastpm_powerspectrum_init_from_string_hip", "fastpm_funck_eval_hip"):
         assert hasattr(H, name)
 
 
@@ -104,6 +108,122 @@ def test_c_host_force_with_two_species(oracle):
     assert util.rel_err(a1, accs[0]) <= 1e-6
     assert util.rel_err(a2, accs[1]) <= 1e-6
     assert util.max_err(pmo.complex_view(dk), pmo.complex_view(dko)) <= 1e-14
+    H.fastpm_free_pm_hip(pm)
+
+
+# ---- what the caller does next with delta_k: fastpm_powerspectrum_hip.c ---------------------------------------
+class FuncK(ctypes.Structure):
+    _fields_ = [("size", ctypes.c_size_t), ("k", ctypes.POINTER(ctypes.c_double)),
+                ("f", ctypes.POINTER(ctypes.c_double))]
+
+
+class PowerSpectrumView(ctypes.Structure):
+    _fields_ = [("base", FuncK), ("edges", ctypes.POINTER(ctypes.c_double)), ("pm", ctypes.c_void_p),
+                ("k0", ctypes.c_double), ("Volume", ctypes.c_double), ("Nmodes", ctypes.POINTER(ctypes.c_double))]
+
+    def arrays(self):
+        n = self.base.size
+        return (np.array(self.base.k[:n]), np.array(self.base.f[:n]), np.array(self.Nmodes[:n]),
+                np.array(self.edges[:n + 1]))
+
+
+def _ps_host():
+    H = _host()
+    H.fastpm_powerspectrum_large_scale_hip.restype = ctypes.c_double
+    H.fastpm_powerspectrum_large_scale_hip.argtypes = [ctypes.POINTER(PowerSpectrumView), ctypes.c_int]
+    H.fastpm_powerspectrum_eval_hip.restype = ctypes.c_double
+    H.fastpm_powerspectrum_eval_hip.argtypes = [ctypes.POINTER(PowerSpectrumView), ctypes.c_double]
+    H.fastpm_powerspectrum_write_hip.argtypes = [ctypes.POINTER(PowerSpectrumView), ctypes.c_char_p, ctypes.c_double]
+    H.fastpm_powerspectrum_init_from_delta_hip.argtypes = [ctypes.POINTER(PowerSpectrumView), ctypes.c_void_p,
+                                                           ctypes.c_void_p, ctypes.c_void_p]
+    H.fastpm_decic_powerspectrum_hip.argtypes = [ctypes.POINTER(PowerSpectrumView), ctypes.c_void_p, ctypes.c_void_p]
+    H.fastpm_apply_decic_transfer_hip.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    H.fastpm_powerspectrum_init_from_string_hip.argtypes = [ctypes.POINTER(PowerSpectrumView), ctypes.c_char_p]
+    H.fastpm_powerspectrum_scale_hip.argtypes = [ctypes.POINTER(PowerSpectrumView), ctypes.c_double]
+    H.fastpm_powerspectrum_destroy_hip.argtypes = [ctypes.POINTER(PowerSpectrumView)]
+    return H
+
+
+def test_c_host_power_table_functions():
+    """No GPU: fastpm_powerspectrum_init_from_string / eval / scale on the reference's tests/powerspec.txt
+    (tests/golden/reference_tests_powerspec.txt) against the oracle's PowerTable."""
+    from oracle import reference_run as R
+    H = _ps_host()
+    text = open(os.path.join(ROOT, "tests", "golden", "reference_tests_powerspec.txt")).read()
+    ps = PowerSpectrumView()
+    assert H.fastpm_powerspectrum_init_from_string_hip(ctypes.byref(ps), (text + "# a comment\nnot numbers\n").encode()) == 0
+    table = R.PowerTable()
+    k, f, _, _ = ps.arrays()
+    assert ps.base.size == len(table.k) and np.array_equal(k, table.k) and np.array_equal(f, table.f)
+    for x in (0.0, 1e-6, 1.0493e-05, 3.3e-3, 0.05, 0.7, 12.0, 1e4):
+        got = H.fastpm_powerspectrum_eval_hip(ctypes.byref(ps), x)
+        want = float(table(np.array([x]))[0])
+        assert got == pytest.approx(want, rel=1e-14), x
+    H.fastpm_powerspectrum_scale_hip(ctypes.byref(ps), 2.0)
+    k2, f2, _, _ = ps.arrays()
+    assert f2[0] == f[0] and np.array_equal(f2[1:], 2.0 * f[1:])          # powerspectrum.c:285: the first row stays
+    H.fastpm_powerspectrum_destroy_hip(ctypes.byref(ps))
+
+
+@pytest.mark.gpu
+def test_c_host_decic_powerspectrum_and_dump(oracle, tmp_path):
+    """force -> delta_k on the host -> de-CIC + P(k) through the C host (solver.c:471 + the FORCE/AFTER handler),
+    the large-scale power line of the log, and the "# k p N" file of fastpm_powerspectrum_write."""
+    from oracle import reference_run as R
+    H = _ps_host()
+    N, nc, L = 32, 16, 48.0
+    x = util.load_b(nc, L, N)
+    pmo = oracle.PMOracle(N, L, 64)
+    ref = oracle.compute_force(pmo, x)
+    dko = pmo.alloc()
+    pmo.decic(ref["delta_k"], dko)
+    kr, pr, nr = oracle.powerspectrum_finalize(*pmo.powerspectrum_sums(dko), L)
+    acc = np.zeros((len(x), 3), dtype=np.float32)
+    st = StoreView(len(x), x.ctypes.data, acc.ctypes.data, None, None, 1.0)
+    sv = SolverView()
+    sv.species[1] = ctypes.pointer(st)
+    sv.has_species[1] = 1
+    pm = H.fastpm_create_pm_hip(N, L, 64)
+    dk = np.zeros(pmo.allocsize, dtype=np.float64)
+    painter = PainterView(0, 2)
+    H.fastpm_solver_compute_force_hip(ctypes.byref(sv), pm, ctypes.byref(painter), 0, 3, dk.ctypes.data, 1.0)
+    # the two calls of the reference, one after the other
+    dk2 = np.zeros_like(dk)
+    H.fastpm_apply_decic_transfer_hip(pm, dk.ctypes.data, dk2.ctypes.data)
+    assert util.max_err(pmo.complex_view(dk2), pmo.complex_view(dko)) <= 1e-14
+    ps = PowerSpectrumView()
+    H.fastpm_powerspectrum_init_from_delta_hip(ctypes.byref(ps), pm, dk2.ctypes.data, dk2.ctypes.data)
+    k, p, n, edges = ps.arrays()
+    assert np.array_equal(n, nr) and np.allclose(k, kr, rtol=1e-13, atol=0) and np.allclose(p, pr, rtol=1e-12, atol=0)
+    assert np.allclose(edges, np.arange(N // 2 + 1) * 2 * np.pi / L, rtol=1e-15)
+    assert ps.Volume == L ** 3 and ps.k0 == 2 * np.pi / L
+    big = H.fastpm_powerspectrum_large_scale_hip(ctypes.byref(ps), 4)
+    assert big == pytest.approx(R.large_scale_power(kr, pr, nr, 4, 2 * np.pi / L), rel=1e-12)
+    # ... and both in one sweep, in place
+    ps1 = PowerSpectrumView()
+    H.fastpm_decic_powerspectrum_hip(ctypes.byref(ps1), pm, dk.ctypes.data)
+    assert np.array_equal(dk, dk2)
+    k1, p1, n1, _ = ps1.arrays()
+    assert np.array_equal(n1, n) and np.allclose(p1, p, rtol=1e-13, atol=0) and np.allclose(k1, k, rtol=1e-13, atol=0)
+    # the dump: powerspectrum.c:149-168, character for character
+    fn = tmp_path / "powerspec_1.0000.txt"
+    H.fastpm_powerspectrum_write_hip(ctypes.byref(ps), str(fn).encode(), float(len(x)))
+    want = ["# k p N "] + ["%g %g %g" % (a, b, c) for a, b, c in zip(k, p, n)]
+    want += ["# metadata 7", "# volume %g float64" % L ** 3, "# shotnoise %g float64" % (L ** 3 / len(x)),
+             "# N1 %g int" % len(x), "# N2 %g int" % len(x), "# Lz %g float64" % L, "# Lx %g float64" % L,
+             "# Ly %g float64" % L]
+    assert fn.read_text() == "\n".join(want) + "\n"
+    back = np.loadtxt(fn)                                        # the reference's own readers take it (python/, nbodykit)
+    assert back.shape == (N // 2, 3)
+    # the Python host mirror writes the same file and the same log number
+    from fastpm_amd import PM, fastpm_powerspectrum_large_scale, fastpm_powerspectrum_write
+    ppm = PM(N, L, 64)
+    fastpm_powerspectrum_write(ppm, k, p, n, tmp_path / "py.txt", float(len(x)))
+    assert (tmp_path / "py.txt").read_text() == fn.read_text()
+    assert fastpm_powerspectrum_large_scale(ppm, k, p, n, 4) == pytest.approx(big, rel=1e-14)
+    ppm.destroy()
+    for s in (ps, ps1):
+        H.fastpm_powerspectrum_destroy_hip(ctypes.byref(s))
     H.fastpm_free_pm_hip(pm)
 
 
