@@ -589,6 +589,12 @@ static bool narrow_tiles()
     return narrow;
 }
 
+// fp32, N = 512, the fused kernels (SQ counters, rocprofv3 --pmc): the 16-column workgroups are 1024 threads at
+// 82-104 VGPRs, i.e. ONE workgroup per CU, so a workgroup's load, transform and store phases run one after the other
+// (colfft_xback3: 0.73 ms = 0.43 ms of HBM time + 0.30 ms of VALU time; fp64 fits two 512-thread workgroups per CU
+// and overlaps them).  Tried, measured, not kept: 8-column workgroups fit twice but move 64-byte row segments
+// (0.81 ms); 16 elements per thread (512 threads x 16 columns) needs > 128 VGPRs and spills (xback3 0.80, yback2
+// 0.97 instead of 0.57 ms); fused multiply-adds in the butterflies (-ffp-contract=fast) change nothing measurable.
 bool colfft_supported(int N)
 {
     static const int ok[] = {16, 32, 48, 64, 80, 96, 128, 160, 192, 256, 320, 384, 400, 512, 640, 768, 800, 1024};
