@@ -215,6 +215,9 @@ def main():
                     help="kspace (default): the reference's arithmetic, 3 inverse FFTs; real: FPMHIP_GRADIENT_REAL, "
                          "1 inverse FFT of the potential + stencil readout (acc within 2e-7 max|acc| of kspace)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra leg that times the other gradient mode")
+    ap.add_argument("--alt", action="store_true",
+                    help="run that extra leg on N > 1 GPUs too (off by default there: a second collective phase after "
+                         "the measured one must never be what a scaling run hangs or times out in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -299,7 +302,7 @@ def main():
     # extra leg, outside the timed region above and reported beside it: the same workload in the OTHER
     # gradient mode (same W and K, same bracket), and how far its accelerations are from the main run's
     alt = None
-    if not args.no_alt:
+    if not args.no_alt and (world == 1 or args.alt):
         try:
             other = "real" if args.gradient == "kspace" else "kspace"
             pm2, store2, dt2, tm2 = timed_run(other)
