@@ -2,7 +2,7 @@
 """Randomised parity sweep of the force step against the CPU oracle: mesh size (column-FFT sizes and rocFFT-only
 sizes), particle load and count, kernel, softening, precision, gradient mode, paint / FFT back end, masses,
 potential column, and -- when P > 1 -- virtual slabs with a random number of exchange ranges.
-usage: fuzz_parity.py [ncases] [seed]      (prints one line per case; exits non-zero on the first failure)"""
+usage: tests/fuzz_parity.py [ncases] [seed]      (prints one line per case; exits non-zero on the first failure)"""
 import os
 import sys
 
