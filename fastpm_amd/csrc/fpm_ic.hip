@@ -160,17 +160,22 @@ __device__ static inline double funck_eval(const double *__restrict__ tk, const 
 }
 
 // delta_k *= sqrt(P(k)) * sqrt(1 / V) with k = sqrt(sum of the float32 kk tables) (transfer.c:198-207,
-// initialcondition.c:48-53).  The table sits in LDS.
-template <typename F>
+// initialcondition.c:48-53).  The table sits in LDS when it fits (IN_LDS; up to 4096 rows), else it is read where
+// it is.
+template <typename F, bool IN_LDS>
 __global__ __launch_bounds__(256) void induce_correlation_kernel(MeshGeo g, const float *__restrict__ kk,
                                                                  const double *__restrict__ tk,
                                                                  const double *__restrict__ tf, int size,
                                                                  double volume, F *__restrict__ d)
 {
     extern __shared__ double lds[];
-    double *lk = lds, *lf = lds + size;
-    for (int t = threadIdx.x; t < size; t += blockDim.x) { lk[t] = tk[t]; lf[t] = tf[t]; }
-    __syncthreads();
+    const double *lk = tk, *lf = tf;
+    if (IN_LDS) {
+        for (int t = threadIdx.x; t < size; t += blockDim.x) { lds[t] = tk[t]; lds[size + t] = tf[t]; }
+        __syncthreads();
+        lk = lds;
+        lf = lds + size;
+    }
     const int ix = blockIdx.y;
     const int rem = blockIdx.x * blockDim.x + threadIdx.x;
     if (rem >= g.yl * g.nzc) return;
@@ -257,7 +262,7 @@ int fpmhip_ic_remove_variance(fpmhip_plan *p, void *delta_k)
 int fpmhip_ic_induce_correlation(fpmhip_plan *p, void *delta_k, const double *k, const double *pk, int size)
 {
     if (!p || !delta_k || !k || !pk) FPM_FAIL(-1, "null argument");
-    if (size < 1 || size > 4096) FPM_FAIL(-1, "power spectrum table of %d rows (1 .. 4096 supported)", size);
+    if (size < 1) FPM_FAIL(-1, "empty power spectrum table");
     const MeshGeo &g = p->mg;
     double *d_t = nullptr;
     FPM_CHECK_HIP(hipMalloc(&d_t, 2 * (size_t) size * sizeof(double)));
@@ -267,13 +272,13 @@ int fpmhip_ic_induce_correlation(fpmhip_plan *p, void *delta_k, const double *k,
         const float *kk = p->d_tab + 2 * (size_t) g.N;             // the kk = k * k table, pmapi.c:262
         const double L = p->geom.BoxSize;
         dim3 grid((unsigned) (((long long) g.yl * g.nzc + 255) / 256), (unsigned) g.N);
-        const size_t lds = 2 * (size_t) size * sizeof(double);
-        if (p->f64)
-            induce_correlation_kernel<double><<<grid, 256, lds, p->stream>>>(g, kk, d_t, d_t + size, size, L * L * L,
-                                                                             (double *) delta_k);
-        else
-            induce_correlation_kernel<float><<<grid, 256, lds, p->stream>>>(g, kk, d_t, d_t + size, size, L * L * L,
-                                                                            (float *) delta_k);
+        const bool in_lds = size <= 4096;                          // 64 KB: the default dynamic LDS limit
+        const size_t lds = in_lds ? 2 * (size_t) size * sizeof(double) : 0;
+#define INDUCE(F, L_)                                                                                             \
+    induce_correlation_kernel<F, L_><<<grid, 256, lds, p->stream>>>(g, kk, d_t, d_t + size, size, L * L * L, (F *) delta_k)
+        if (p->f64) { if (in_lds) INDUCE(double, true); else INDUCE(double, false); }
+        else { if (in_lds) INDUCE(float, true); else INDUCE(float, false); }
+#undef INDUCE
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(p->stream);      // the caller's table may go away after the call

@@ -279,7 +279,7 @@ int fpmhip_ic_fill_gaussian(fpmhip_plan *plan, void *delta_k_dev, int seed);
 int fpmhip_ic_remove_variance(fpmhip_plan *plan, void *delta_k_inplace_dev);
 /* fastpm_ic_induce_correlation (initialcondition.c:42-64, transfer.c:188-210): delta_k *= sqrt(P(k) / V), P(k)
  * evaluated from the host table (k[size], p[size]) exactly as fastpm_funck_eval does (powerspectrum.c:391-425:
- * bisection, log-log interpolation, 1 at k = 0).  size <= 4096.  Synchronises. */
+ * bisection, log-log interpolation, 1 at k = 0).  Synchronises. */
 int fpmhip_ic_induce_correlation(fpmhip_plan *plan, void *delta_k_inplace_dev, const double *k_host,
                                  const double *p_host, int size);
 /* Host-only views of the generator (no device work): n numbers of gsl_rng_uniform after gsl_rng_set(ranlxd1, seed),

@@ -114,8 +114,18 @@ def test_remove_variance_and_induce_correlation(precision):
                       / (np.log(k[r]) - np.log(k[l])))
     want = white * np.sqrt(np.vectorize(ev)(kabs)) * np.sqrt(1.0 / L ** 3)
     assert np.abs(got - want).max() <= (1e-14 if precision == 64 else 4e-7) * np.abs(want).max()
+    # a table too long for LDS is read from global memory: same numbers
+    kl = np.logspace(-4, 2, 6000)
+    pl = 3.0 * kl ** -1.5
+    fastpm_ic_fill_gaussiank(pm, dk, seed)
+    fastpm_ic_induce_correlation(pm, dk, kl, pl)
+    long_table = pm.complex_view(dk).cpu().numpy()
+    fastpm_ic_fill_gaussiank(pm, dk, seed)
+    fastpm_ic_induce_correlation(pm, dk, kl[::2], pl[::2])          # a pure power law: any sampling interpolates it exactly
+    short_table = pm.complex_view(dk).cpu().numpy()
+    assert np.abs(long_table - short_table).max() <= (1e-12 if precision == 64 else 4e-7) * np.abs(short_table).max()
     with pytest.raises(Exception):
-        fastpm_ic_induce_correlation(pm, dk, np.arange(5000.0), np.ones(5000))
+        fastpm_ic_induce_correlation(pm, dk, np.zeros(0), np.zeros(0))
     pm.destroy()
 
 
