@@ -126,13 +126,13 @@ def gaussian_delta_k(pm, seed, amplitude):
 
 
 def run(nc=64, B=2, BoxSize=None, steps=5, a0=0.1, a1=1.0, mode="fastpm", seed=100, amplitude=1.0, precision=64,
-        vpm=None, verbose=True, gradient_mode=0):
+        vpm=None, verbose=True, gradient_mode=0, pk_prefix=None):
     """One rank, or -- when torch.distributed is initialised -- one x slab per rank: Slab2LPT, SlabDecompose before
     every force (fastpm_decompose, solver.c:449), SlabForce, all-reduced P(k) sums (powerspectrum.c:113-115)."""
     import torch
     import torch.distributed as dist
-    from fastpm_amd import (PM, VPM, Store, fastpm_drift_store, fastpm_kick_store, fastpm_store_wrap,
-                            pm_2lpt_evolve, pm_2lpt_solve)
+    from fastpm_amd import (PM, VPM, Store, fastpm_kick_store, fastpm_leapfrog_store, fastpm_powerspectrum_write,
+                            fastpm_store_wrap, pm_2lpt_evolve, pm_2lpt_solve)
     from fastpm_amd.distributed import Slab2LPT, SlabDecompose, SlabForce
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
@@ -189,6 +189,8 @@ def run(nc=64, B=2, BoxSize=None, steps=5, a0=0.1, a1=1.0, mode="fastpm", seed=1
         pm.apply_decic_transfer(delta_k, delta_k)            # solver.c:471
         k, pk, n = spectrum(pm, delta_k)                     # FORCE/AFTER handler
         spectra.append((a, pm.Nmesh, k, pk, n))
+        if pk_prefix and rank == 0:                          # write_powerspectrum, src/fastpm.c:1757-1776
+            fastpm_powerspectrum_write(pm, k, pk, n, "%s_%0.04f.txt" % (pk_prefix, a), float(nc) ** 3)
         if verbose and rank == 0:
             lo = slice(1, 4)
             print("a = %.4f  mesh %d^3  P(k<%.3g)/P_lin/D^2 = %s" % (
@@ -199,10 +201,10 @@ def run(nc=64, B=2, BoxSize=None, steps=5, a0=0.1, a1=1.0, mode="fastpm", seed=1
     for i in range(len(time_step) - 1):                       # K D D F K (solver.c:289-296)
         ai, af = time_step[i], time_step[i + 1]
         ac = np.sqrt(ai * af)
-        fastpm_kick_store(pm, kick_factor(c, mode, ai, ai, ac), p, p, ac)      # v: a_i -> a_c, force at a_i
-        fastpm_drift_store(pm, drift_factor(c, mode, ai, ac, ac), p, p, ac)    # x: a_i -> a_c, velocity at a_c
-        fastpm_drift_store(pm, drift_factor(c, mode, ac, ac, af), p, p, af)    # x: a_c -> a_f
-        fastpm_store_wrap(pm, p)
+        # v: a_i -> a_c with the force at a_i; x: a_i -> a_c -> a_f with the velocity at a_c; wrap -- one pass over
+        # the columns (fpmhip_leapfrog; the same bits as fastpm_kick_store + 2 x fastpm_drift_store + store_wrap)
+        fastpm_leapfrog_store(pm, [(kick_factor(c, mode, ai, ai, ac), ac)],
+                              [(drift_factor(c, mode, ai, ac, ac), ac), (drift_factor(c, mode, ac, ac, af), af)], p)
         pm = force(af)
         fastpm_kick_store(pm, kick_factor(c, mode, ac, af, af), p, p, af)      # v: a_c -> a_f, force at a_f
     torch.cuda.synchronize()
@@ -219,6 +221,8 @@ if __name__ == "__main__":
     ap.add_argument("--precision", type=int, default=64)
     ap.add_argument("--gradient", type=int, default=0, help="1: FPMHIP_GRADIENT_REAL")
     ap.add_argument("--json", default=None, help="rank 0 writes the spectra here")
+    ap.add_argument("--vpm", default=None, help="variable force mesh, 'a_start:factor,...' e.g. 0:1,0.3:2,0.6:3 (vpm.c)")
+    ap.add_argument("--pk-prefix", default=None, help="rank 0 dumps P(k) after every force to <prefix>_<a>.txt")
     a = ap.parse_args()
     # under torch.distributed.run: one rank per GPU over RCCL (MINIPM_BACKEND=gloo MINIPM_SHARE_GPU=1: every rank
     # on GPU 0 with host-staged exchanges -- a dry run for 1-GPU boxes)
@@ -232,7 +236,9 @@ if __name__ == "__main__":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    r = run(nc=a.nc, B=a.B, steps=a.steps, mode=a.mode, precision=a.precision, gradient_mode=a.gradient)
+    vpm = [(float(s.split(":")[0]), int(s.split(":")[1])) for s in a.vpm.split(",")] if a.vpm else None
+    r = run(nc=a.nc, B=a.B, steps=a.steps, mode=a.mode, precision=a.precision, gradient_mode=a.gradient, vpm=vpm,
+            pk_prefix=a.pk_prefix)
     if a.json and r["rank"] == 0:
         import json
         json.dump({"p_lin": r["p_lin"].tolist(), "spectra": [[float(s[0]), int(s[1]), s[3].tolist()] for s in r["spectra"]]},

@@ -67,3 +67,29 @@ def test_multi_rank_run_gives_the_one_rank_spectra(tmp_path, nranks, port, gradi
     for sa, sb in zip(a["spectra"], b["spectra"]):
         assert sa[0] == sb[0] and sa[1] == sb[1]
         assert np.allclose(sa[2][1:], sb[2][1:], rtol=1e-7), (sa[0], np.abs(np.array(sa[2][1:]) / np.array(sb[2][1:]) - 1).max())
+
+
+def test_variable_mesh_cola_run_with_power_spectrum_dumps(tmp_path):
+    """configs[3] / configs[4] in miniature on two ranks: COLA stepping on a variable force mesh B = 1 -> 3
+    (vpm.c) with the P(k) file of every step written in the reference's format (powerspectrum.c:149-168)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "examples", "minipm.py")
+    prefix = str(tmp_path / "powerspec")
+    env = dict(os.environ, MINIPM_BACKEND="gloo", MINIPM_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29633", script, "--nc", "32", "--steps", "5",
+                        "--mode", "cola", "--vpm", "0:1,0.3:2,0.6:3", "--pk-prefix", prefix],
+                       cwd=root, env=env, timeout=900, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    files = sorted(os.listdir(tmp_path))
+    assert files == ["powerspec_%0.04f.txt" % a for a in np.linspace(0.1, 1.0, 5)]
+    sizes = []
+    for f in files:
+        text = open(tmp_path / f).read().splitlines()
+        assert text[0] == "# k p N " and text[-8] == "# metadata 7" and text[-5] == "# N1 32768 int"
+        assert text[-7] == "# volume %g float64" % (128.0 ** 3) and text[-1] == "# Ly 128 float64"
+        t = np.loadtxt(tmp_path / f)
+        sizes.append(len(t))
+        assert np.isfinite(t).all() and (t[1:, 1] > 0).all() and t[1:, 2].sum() > 0
+    assert sizes == [16, 32, 32, 48, 48]                       # Nmesh / 2 bins: B = 1, 2, 2, 3, 3
