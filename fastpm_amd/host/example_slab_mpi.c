@@ -1,0 +1,112 @@
+/*
+ * example_slab_mpi.c -- the force step under the reference's own process model: one MPI rank per x slab
+ * (pmpfft.c:117-136 with Nproc = {NTask, 1}), plain C99, no Python.  Each rank owns the particles whose x cell lies in
+ * its slab (what fastpm_decompose guarantees at solver.c:449), keeps their columns on its GPU and calls
+ * fastpm_hip_slab_force with the MPI transport (fastpm_slab_mpi.c).
+ *
+ *   make mpi            (in this directory: needs mpi.h / libmpi, e.g. MPICH under /opt/conda)
+ *   mpiexec -n P ./example_slab_mpi [nc] [B] [precision] [gradient_mode] [gpu_aware]
+ *
+ * Ranks take device (rank mod device count): on a one-GPU box they share it.  Particles: the sine-displaced
+ * lattice of example_force.c, so tests/test_gpu_chost.py compares the printed numbers with the one-rank oracle.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "fastpm_gravity_hip.h"
+#include "fastpm_slab_mpi.h"
+
+#define CHECK(expr) do { if ((expr) != 0) { fprintf(stderr, "rank %d: %s failed: %s\n", rank, #expr, fpmhip_last_error()); \
+                                            MPI_Abort(MPI_COMM_WORLD, 1); } } while (0)
+
+int main(int argc, char **argv)
+{
+    MPI_Init(&argc, &argv);
+    int rank, P;
+    MPI_Comm_rank(MPI_COMM_WORLD, &rank);
+    MPI_Comm_size(MPI_COMM_WORLD, &P);
+    const int nc = argc > 1 ? atoi(argv[1]) : 32;
+    const int B = argc > 2 ? atoi(argv[2]) : 2;
+    const int precision = argc > 3 ? atoi(argv[3]) : 64;
+    const int gradient_mode = argc > 4 ? atoi(argv[4]) : 0;
+    const int gpu_aware = argc > 5 ? atoi(argv[5]) : 0;
+    const int Nmesh = nc * B;
+    const double BoxSize = 3.0 * nc;
+    if (Nmesh % P) {
+        if (rank == 0) fprintf(stderr, "PM mesh is not divided by the process mesh.\n");      /* vpm.c:45-53 */
+        MPI_Abort(MPI_COMM_WORLD, 1);
+    }
+
+    fpmhip_geom g = {0};
+    g.Nmesh = Nmesh;
+    g.BoxSize = BoxSize;
+    g.precision = precision;
+    g.nranks = P;
+    g.rank = rank;
+    g.device = rank % (fpmhip_device_count() > 0 ? fpmhip_device_count() : 1);
+    g.gradient_mode = gradient_mode;
+    fpmhip_plan *plan = NULL;
+    CHECK(fpmhip_plan_create(&g, NULL, &plan));
+    fastpm_hip_transport *t = fastpm_hip_mpi_transport_create(MPI_COMM_WORLD, plan, gpu_aware);
+
+    /* this rank's particles: x cell in [rank * N / P, (rank + 1) * N / P) */
+    const size_t ntot = (size_t) nc * nc * nc;
+    double (*x)[3] = malloc(ntot * sizeof(*x));
+    long long *id = malloc(ntot * sizeof(*id));
+    const double h = BoxSize / nc, A = 0.35 * h, k = 2 * M_PI / BoxSize, inv_cell = 1.0 / (BoxSize / Nmesh);
+    const int xl = Nmesh / P;
+    size_t np = 0, i = 0;
+    for (int ix = 0; ix < nc; ix++)
+        for (int iy = 0; iy < nc; iy++)
+            for (int iz = 0; iz < nc; iz++, i++) {
+                const double q[3] = {(ix + 0.5) * h, (iy + 0.5) * h, (iz + 0.5) * h};
+                const double px = fmod(q[0] + A * sin(2 * k * q[0]) * cos(k * q[1]) + BoxSize, BoxSize);
+                int cell = (int) floor(px * inv_cell);
+                if (cell >= Nmesh) cell -= Nmesh;
+                if (cell / xl != rank) continue;
+                x[np][0] = px;
+                x[np][1] = fmod(q[1] + A * sin(3 * k * q[1]) * cos(k * q[2]) + BoxSize, BoxSize);
+                x[np][2] = fmod(q[2] + A * sin(k * q[2]) * cos(2 * k * q[0]) + BoxSize, BoxSize);
+                id[np++] = (long long) i;
+            }
+
+    fpmhip_particles part = {0};
+    void *dx = NULL, *dacc = NULL;
+    CHECK(fpmhip_malloc(&dx, (np ? np : 1) * 3 * sizeof(double)));
+    CHECK(fpmhip_malloc(&dacc, (np ? np : 1) * 3 * sizeof(float)));
+    CHECK(fpmhip_memcpy_h2d(plan, dx, x, np * 3 * sizeof(double)));
+    part.x = dx;
+    part.M0 = 1.0;
+    part.np = (int64_t) np;
+    part.acc = dacc;
+
+    CHECK(fastpm_hip_slab_force(plan, t, &part, FASTPM_KERNEL_1_4, FASTPM_SOFTENING_NONE, NULL));
+
+    float (*acc)[3] = calloc(np ? np : 1, sizeof(*acc));
+    CHECK(fpmhip_memcpy_d2h(plan, acc, dacc, np * 3 * sizeof(float)));
+    double s[7] = {0, 0, 0, 0, 0, 0, (double) np};
+    for (i = 0; i < np; i++)
+        for (int d = 0; d < 3; d++) { s[d] += acc[i][d]; s[3 + d] += (double) acc[i][d] * acc[i][d]; }
+    MPI_Allreduce(MPI_IN_PLACE, s, 7, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD);
+    /* the first four particles of the lattice, from whichever rank owns them */
+    double first[4][3] = {{0}};
+    for (i = 0; i < np; i++)
+        if (id[i] < 4) for (int d = 0; d < 3; d++) first[id[i]][d] = acc[i][d];
+    MPI_Allreduce(MPI_IN_PLACE, first, 12, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD);
+    if (rank == 0) {
+        const double n = s[6];
+        printf("ranks %d np %.0f Nmesh %d precision %d gradient_mode %d\n", P, n, Nmesh, precision, gradient_mode);
+        printf("acc std %.9g %.9g %.9g\n", sqrt(s[3] / n - pow(s[0] / n, 2)), sqrt(s[4] / n - pow(s[1] / n, 2)),
+               sqrt(s[5] / n - pow(s[2] / n, 2)));
+        for (int j = 0; j < 4; j++) printf("acc[%d] %.9g %.9g %.9g\n", j, first[j][0], first[j][1], first[j][2]);
+    }
+    printf("rank %d owns %zu particles on device %d\n", rank, np, g.device);
+
+    free(acc); free(x); free(id);
+    fpmhip_free(dx); fpmhip_free(dacc);
+    fastpm_hip_mpi_transport_destroy(t);
+    fpmhip_plan_destroy(plan);
+    MPI_Finalize();
+    return 0;
+}

@@ -1,0 +1,113 @@
+/*
+ * fastpm_slab_mpi.c -- see fastpm_slab_mpi.h.  Replaces, for the force step, the collectives of the reference:
+ * MPI_Allreduce(total mass) gravity.c:341, the transposes inside pfft_execute pmpfft.c:377-396 (one MPI_Alltoall
+ * per transform on x slabs) and the ghost exchange pmghosts.c:203-307 (here: one mesh plane to each neighbour).
+ */
+#include <limits.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "fastpm_slab_mpi.h"
+
+typedef struct {
+    MPI_Comm comm;
+    fpmhip_plan *plan;
+    int gpu_aware;
+    int nranks;
+    void *hsend, *hrecv;          /* host staging (gpu_aware == 0), grown on demand */
+    size_t hbytes;
+} mpi_ctx;
+
+static int stage_reserve(mpi_ctx *c, size_t bytes)
+{
+    if (bytes <= c->hbytes) return 0;
+    free(c->hsend);
+    free(c->hrecv);
+    c->hsend = malloc(bytes);
+    c->hrecv = malloc(bytes);
+    c->hbytes = (c->hsend && c->hrecv) ? bytes : 0;
+    return c->hbytes ? 0 : -1;
+}
+
+/* counts are ints in MPI-3: move `bytes` as `count` elements of a contiguous type of `unit` bytes */
+static int split_count(size_t bytes, MPI_Datatype *type, int *count)
+{
+    size_t unit = 1;
+    while (unit < ((size_t) 1 << 20) && bytes % (unit * 2) == 0) unit *= 2;
+    if (bytes / unit > (size_t) INT_MAX) return -1;
+    *count = (int) (bytes / unit);
+    MPI_Type_contiguous((int) unit, MPI_BYTE, type);
+    MPI_Type_commit(type);
+    return 0;
+}
+
+static int mpi_allreduce(void *ctx, double *value)
+{
+    mpi_ctx *c = ctx;
+    return MPI_Allreduce(MPI_IN_PLACE, value, 1, MPI_DOUBLE, MPI_SUM, c->comm) == MPI_SUCCESS ? 0 : -1;
+}
+
+static int mpi_alltoall(void *ctx, const void *send_dev, void *recv_dev, size_t chunk_bytes)
+{
+    mpi_ctx *c = ctx;
+    MPI_Datatype type;
+    int count, rc;
+    if (split_count(chunk_bytes, &type, &count)) return -1;
+    if (c->gpu_aware) {
+        rc = MPI_Alltoall(send_dev, count, type, recv_dev, count, type, c->comm);
+    } else {
+        const size_t total = chunk_bytes * (size_t) c->nranks;
+        if (stage_reserve(c, total)) { MPI_Type_free(&type); return -1; }
+        if (fpmhip_memcpy_d2h(c->plan, c->hsend, send_dev, total)) { MPI_Type_free(&type); return -1; }
+        rc = MPI_Alltoall(c->hsend, count, type, c->hrecv, count, type, c->comm);
+        if (rc == MPI_SUCCESS && fpmhip_memcpy_h2d(c->plan, recv_dev, c->hrecv, total)) rc = MPI_ERR_OTHER;
+    }
+    MPI_Type_free(&type);
+    return rc == MPI_SUCCESS ? 0 : -1;
+}
+
+static int mpi_sendrecv(void *ctx, const void *send_dev, int dest, void *recv_dev, int source, size_t bytes)
+{
+    mpi_ctx *c = ctx;
+    MPI_Datatype type;
+    int count, rc;
+    if (split_count(bytes, &type, &count)) return -1;
+    if (c->gpu_aware) {
+        rc = MPI_Sendrecv(send_dev, count, type, dest, 0, recv_dev, count, type, source, 0, c->comm, MPI_STATUS_IGNORE);
+    } else {
+        if (stage_reserve(c, bytes)) { MPI_Type_free(&type); return -1; }
+        if (fpmhip_memcpy_d2h(c->plan, c->hsend, send_dev, bytes)) { MPI_Type_free(&type); return -1; }
+        rc = MPI_Sendrecv(c->hsend, count, type, dest, 0, c->hrecv, count, type, source, 0, c->comm, MPI_STATUS_IGNORE);
+        if (rc == MPI_SUCCESS && fpmhip_memcpy_h2d(c->plan, recv_dev, c->hrecv, bytes)) rc = MPI_ERR_OTHER;
+    }
+    MPI_Type_free(&type);
+    return rc == MPI_SUCCESS ? 0 : -1;
+}
+
+fastpm_hip_transport *fastpm_hip_mpi_transport_create(MPI_Comm comm, fpmhip_plan *plan, int gpu_aware)
+{
+    fastpm_hip_transport *t = calloc(1, sizeof(*t));
+    mpi_ctx *c = calloc(1, sizeof(*c));
+    if (!t || !c) { free(t); free(c); return NULL; }
+    c->comm = comm;
+    c->plan = plan;
+    c->gpu_aware = gpu_aware;
+    MPI_Comm_size(comm, &c->nranks);
+    t->ctx = c;
+    MPI_Comm_rank(comm, &t->rank);
+    t->nranks = c->nranks;
+    t->allreduce_sum = mpi_allreduce;
+    t->alltoall = mpi_alltoall;
+    t->sendrecv = mpi_sendrecv;
+    return t;
+}
+
+void fastpm_hip_mpi_transport_destroy(fastpm_hip_transport *t)
+{
+    if (!t) return;
+    mpi_ctx *c = t->ctx;
+    free(c->hsend);
+    free(c->hrecv);
+    free(c);
+    free(t);
+}

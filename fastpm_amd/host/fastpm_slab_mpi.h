@@ -1,0 +1,28 @@
+/*
+ * fastpm_slab_mpi.h -- the MPI transport of fastpm_hip_slab_force: the three exchanges of the force step as calls
+ * on an MPI communicator, i.e. what libfastpm plugs in with pm->Comm2D (pmpfft.c:117-136: Nproc = {NTask, 1}).
+ *
+ * Compiled only where an MPI is present (`make mpi` in this directory; the image has MPICH 3.3.2 under
+ * /opt/conda).  gpu_aware != 0: the device pointers go to MPI as they are (a GPU-aware MPI build over xGMI / RCCL
+ * does the copies).  gpu_aware == 0: every exchange is staged through host buffers the transport owns -- works with
+ * any MPI, and is what tests/test_gpu_chost.py runs under `mpiexec -n P` with all ranks sharing the one GPU.
+ */
+#ifndef FASTPM_SLAB_MPI_H
+#define FASTPM_SLAB_MPI_H
+
+#include <mpi.h>
+
+#include "fastpm_slab_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* rank / nranks are taken from comm.  plan: the plan whose stream the staging copies are ordered on. */
+fastpm_hip_transport *fastpm_hip_mpi_transport_create(MPI_Comm comm, fpmhip_plan *plan, int gpu_aware);
+void fastpm_hip_mpi_transport_destroy(fastpm_hip_transport *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -332,3 +332,46 @@ def test_plain_c_program_runs_the_force(oracle, tmp_path):
     for i in range(4):
         row = np.array([float(v) for v in lines["acc[%d]" % i][1:4]])
         assert np.abs(row - ref[i]).max() <= 1e-6 * np.abs(ref).max()
+
+
+# ---- the reference's own process model: MPI ranks (fastpm_slab_mpi.c + example_slab_mpi.c) -------------------------
+MPI_ROOT = os.environ.get("FPM_MPI_ROOT", "/opt/conda")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,nc,B,precision,gradient_mode", [(2, 24, 2, 64, 0), (4, 24, 2, 64, 1), (3, 24, 2, 32, 0)])
+def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode):
+    """`mpiexec -n P example_slab_mpi`: P separate processes, plain C99, exchanging through MPI_Alltoall /
+    MPI_Sendrecv / MPI_Allreduce on MPI_COMM_WORLD exactly where libfastpm's PFFT transposes, ghost exchange and
+    mass all-reduce sit (the image's MPICH is not GPU-aware, so the transport stages through the host; on the
+    one-GPU box the ranks share the device).  Printed accelerations = the one-rank oracle's."""
+    import subprocess
+    mpiexec = os.path.join(MPI_ROOT, "bin", "mpiexec")
+    if not (os.path.exists(mpiexec) and os.path.exists(os.path.join(MPI_ROOT, "include", "mpi.h"))):
+        pytest.skip("no MPI in this image")
+    host = os.path.join(ROOT, "fastpm_amd", "host")
+    subprocess.run(["make", "-C", host, "mpi", "MPI_INC=" + os.path.join(MPI_ROOT, "include"),
+                    "MPI_LIB=" + os.path.join(MPI_ROOT, "lib")], check=True, capture_output=True)
+    exe = os.path.join(ROOT, "fastpm_amd", "example_slab_mpi")
+    r = subprocess.run([mpiexec, "-n", str(P), exe, str(nc), str(B), str(precision), str(gradient_mode)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    lines = {l.split()[0] + (l.split()[1] if l.startswith("acc std") else ""): l.split() for l in r.stdout.splitlines()}
+    assert lines["ranks"][1] == str(P) and float(lines["ranks"][3]) == nc ** 3        # every particle has one owner
+    assert sum(1 for l in r.stdout.splitlines() if l.startswith("rank ")) == P
+    L, h = 3.0 * nc, 3.0
+    A, k = 0.35 * h, 2 * np.pi / L
+    g = (np.arange(nc) + 0.5) * h
+    q = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
+    x = np.empty_like(q)
+    x[:, 0] = np.fmod(q[:, 0] + A * np.sin(2 * k * q[:, 0]) * np.cos(k * q[:, 1]) + L, L)
+    x[:, 1] = np.fmod(q[:, 1] + A * np.sin(3 * k * q[:, 1]) * np.cos(k * q[:, 2]) + L, L)
+    x[:, 2] = np.fmod(q[:, 2] + A * np.sin(k * q[:, 2]) * np.cos(2 * k * q[:, 0]) + L, L)
+    ref = oracle.compute_force(oracle.PMOracle(nc * B, L, precision), x)["acc"].astype(np.float64)
+    std = np.sqrt((ref ** 2).mean(0) - ref.mean(0) ** 2)
+    got = np.array([float(v) for v in lines["accstd"][2:5]])
+    tol = 1e-6 if precision == 64 else 2e-5
+    assert np.allclose(got, std, rtol=tol), (got, std)
+    for i in range(4):
+        row = np.array([float(v) for v in lines["acc[%d]" % i][1:4]])
+        assert np.abs(row - ref[i]).max() <= tol * np.abs(ref).max()
