@@ -594,7 +594,9 @@ static bool narrow_tiles()
 // (colfft_xback3: 0.73 ms = 0.43 ms of HBM time + 0.30 ms of VALU time; fp64 fits two 512-thread workgroups per CU
 // and overlaps them).  Tried, measured, not kept: 8-column workgroups fit twice but move 64-byte row segments
 // (0.81 ms); 16 elements per thread (512 threads x 16 columns) needs > 128 VGPRs and spills (xback3 0.80, yback2
-// 0.97 instead of 0.57 ms); fused multiply-adds in the butterflies (-ffp-contract=fast) change nothing measurable.
+// 0.97 instead of 0.57 ms); capping the 1024-thread kernels at 64 VGPRs so that two fit a CU spills 19 / 36 dwords per
+// lane (force step 4.57 instead of 4.13 ms); fused multiply-adds in the butterflies (-ffp-contract=fast) change
+// nothing measurable.
 bool colfft_supported(int N)
 {
     static const int ok[] = {16, 32, 48, 64, 80, 96, 128, 160, 192, 256, 320, 384, 400, 512, 640, 768, 800, 1024};
