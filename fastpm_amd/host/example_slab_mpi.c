@@ -5,7 +5,11 @@
  * fastpm_hip_slab_force with the MPI transport (fastpm_slab_mpi.c).
  *
  *   make mpi            (in this directory: needs mpi.h / libmpi, e.g. MPICH under /opt/conda)
- *   mpiexec -n P ./example_slab_mpi [nc] [B] [precision] [gradient_mode] [gpu_aware]
+ *   mpiexec -n P ./example_slab_mpi [nc] [B] [precision] [gradient_mode] [gpu_aware] [host_columns]
+ *
+ * host_columns = 1: the store columns and delta_k stay on the host, as in today's libfastpm
+ * (fastpm_hip_slab_force_host); every rank then also prints one element and the square sum of its delta_k slab,
+ * which is in the reference's ORegion layout [y_loc][kz][x].
  *
  * Ranks take device (rank mod device count): on a one-GPU box they share it.  Particles: the sine-displaced
  * lattice of example_force.c, so tests/test_gpu_chost.py compares the printed numbers with the one-rank oracle.
@@ -31,6 +35,7 @@ int main(int argc, char **argv)
     const int precision = argc > 3 ? atoi(argv[3]) : 64;
     const int gradient_mode = argc > 4 ? atoi(argv[4]) : 0;
     const int gpu_aware = argc > 5 ? atoi(argv[5]) : 0;
+    const int host_columns = argc > 6 ? atoi(argv[6]) : 0;
     const int Nmesh = nc * B;
     const double BoxSize = 3.0 * nc;
     if (Nmesh % P) {
@@ -73,18 +78,40 @@ int main(int argc, char **argv)
 
     fpmhip_particles part = {0};
     void *dx = NULL, *dacc = NULL;
-    CHECK(fpmhip_malloc(&dx, (np ? np : 1) * 3 * sizeof(double)));
-    CHECK(fpmhip_malloc(&dacc, (np ? np : 1) * 3 * sizeof(float)));
-    CHECK(fpmhip_memcpy_h2d(plan, dx, x, np * 3 * sizeof(double)));
-    part.x = dx;
+    float (*acc)[3] = calloc(np ? np : 1, sizeof(*acc));
     part.M0 = 1.0;
     part.np = (int64_t) np;
-    part.acc = dacc;
-
-    CHECK(fastpm_hip_slab_force(plan, t, &part, FASTPM_KERNEL_1_4, FASTPM_SOFTENING_NONE, NULL));
-
-    float (*acc)[3] = calloc(np ? np : 1, sizeof(*acc));
-    CHECK(fpmhip_memcpy_d2h(plan, acc, dacc, np * 3 * sizeof(float)));
+    if (host_columns) {
+        fpmhip_layout lay;
+        CHECK(fpmhip_plan_layout(plan, &lay));
+        void *delta_k = malloc((size_t) lay.allocsize * (precision / 8));       /* pm_alloc */
+        part.x = &x[0][0];
+        part.acc = &acc[0][0];
+        CHECK(fastpm_hip_slab_force_host(plan, t, &part, FASTPM_KERNEL_1_4, FASTPM_SOFTENING_NONE, delta_k));
+        /* ORegion of this rank: y rows [rank * N / P, ...), strides [y_loc][kz][x] (pmpfft.c:198-202) */
+        const size_t nzc = Nmesh / 2 + 1, yl = Nmesh / P, n = yl * nzc * Nmesh;
+        const size_t at = ((size_t) 1 * nzc + 2) * Nmesh + 3;                   /* (y_loc, kz, x) = (1, 2, 3) */
+        double sum = 0, re, im;
+        if (precision == 64) {
+            const double *d = delta_k;
+            for (i = 0; i < 2 * n; i++) sum += d[i] * d[i];
+            re = d[2 * at]; im = d[2 * at + 1];
+        } else {
+            const float *d = delta_k;
+            for (i = 0; i < 2 * n; i++) sum += (double) d[i] * d[i];
+            re = d[2 * at]; im = d[2 * at + 1];
+        }
+        printf("dk %d %.12g %.12g %.12g\n", rank, re, im, sum);
+        free(delta_k);
+    } else {
+        CHECK(fpmhip_malloc(&dx, (np ? np : 1) * 3 * sizeof(double)));
+        CHECK(fpmhip_malloc(&dacc, (np ? np : 1) * 3 * sizeof(float)));
+        CHECK(fpmhip_memcpy_h2d(plan, dx, x, np * 3 * sizeof(double)));
+        part.x = dx;
+        part.acc = dacc;
+        CHECK(fastpm_hip_slab_force(plan, t, &part, FASTPM_KERNEL_1_4, FASTPM_SOFTENING_NONE, NULL));
+        CHECK(fpmhip_memcpy_d2h(plan, acc, dacc, np * 3 * sizeof(float)));
+    }
     double s[7] = {0, 0, 0, 0, 0, 0, (double) np};
     for (i = 0; i < np; i++)
         for (int d = 0; d < 3; d++) { s[d] += acc[i][d]; s[3 + d] += (double) acc[i][d] * acc[i][d]; }
@@ -104,7 +131,8 @@ int main(int argc, char **argv)
     printf("rank %d owns %zu particles on device %d\n", rank, np, g.device);
 
     free(acc); free(x); free(id);
-    fpmhip_free(dx); fpmhip_free(dacc);
+    if (dx) fpmhip_free(dx);
+    if (dacc) fpmhip_free(dacc);
     fastpm_hip_mpi_transport_destroy(t);
     fpmhip_plan_destroy(plan);
     MPI_Finalize();

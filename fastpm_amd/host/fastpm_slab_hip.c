@@ -127,6 +127,37 @@ int fastpm_hip_slab_force(fpmhip_plan *plan, const fastpm_hip_transport *t, cons
     return 0;
 }
 
+int fastpm_hip_slab_force_host(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *ph,
+                               int kernel, int softening, void *delta_k_host)
+{
+    const size_t np = (size_t) ph->np, n1 = np ? np : 1;
+    if (np && (!ph->x || !ph->acc)) return -1;
+    void *dx = NULL, *dm = NULL, *da = NULL, *dp = NULL;
+    int rc = fpmhip_malloc(&dx, n1 * 3 * sizeof(double));
+    if (!rc) rc = fpmhip_malloc(&da, n1 * 3 * sizeof(float));
+    if (!rc && ph->mass) rc = fpmhip_malloc(&dm, n1 * sizeof(float));
+    if (!rc && ph->potential) rc = fpmhip_malloc(&dp, n1 * sizeof(float));
+    if (!rc && np) rc = fpmhip_memcpy_h2d(plan, dx, ph->x, np * 3 * sizeof(double));
+    if (!rc && np && ph->mass) rc = fpmhip_memcpy_h2d(plan, dm, ph->mass, np * sizeof(float));
+    if (!rc) {
+        fpmhip_particles pd = *ph;
+        pd.x = dx;
+        pd.mass = ph->mass ? dm : NULL;
+        pd.acc = da;
+        pd.potential = ph->potential ? dp : NULL;
+        void *dk = fpmhip_plan_buffer(plan, B_DELTA_K);
+        rc = dk ? fastpm_hip_slab_force(plan, t, &pd, kernel, softening, dk) : -2;
+        if (!rc && np) rc = fpmhip_memcpy_d2h(plan, ph->acc, da, np * 3 * sizeof(float));
+        if (!rc && np && ph->potential) rc = fpmhip_memcpy_d2h(plan, ph->potential, dp, np * sizeof(float));
+        if (!rc && delta_k_host) rc = fpmhip_export_delta_k(plan, dk, delta_k_host);
+    }
+    if (dx) fpmhip_free(dx);
+    if (da) fpmhip_free(da);
+    if (dm) fpmhip_free(dm);
+    if (dp) fpmhip_free(dp);
+    return rc;
+}
+
 /* ------------------------------------------------------------------------------------------------------------
  * Loopback transport: ranks = threads of one process.  Each collective: publish my pointers, barrier, copy what
  * I receive from the others' published send buffers (device-to-device on my plan's stream, then synchronise),

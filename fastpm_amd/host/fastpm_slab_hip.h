@@ -40,6 +40,13 @@ typedef struct {
 int fastpm_hip_slab_force(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *p_dev,
                           int kernel, int softening, void *delta_k_dev);
 
+/* The same with HOST-resident store columns and a host delta_k, as libfastpm holds them (the NTask > 1 twin of
+ * fpmhip_force_host): x (and mass) go up, acc (and potential) come down, delta_k_host (nullable; allocsize
+ * FastPMFloat) is written in the reference's ORegion layout of this rank -- [y_loc][kz][x], pmpfft.c:198-202 with
+ * Nproc = {NTask, 1} -- so the FORCE/AFTER handlers iterate it with PMKIter as they do today. */
+int fastpm_hip_slab_force_host(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *p_host,
+                               int kernel, int softening, void *delta_k_host);
+
 /* ---- in-process loopback transport: all ranks are threads of ONE process (tests; a single-GPU dry run of a
  * multi-rank configuration).  create returns an array of nranks transports sharing one barrier. ---- */
 fastpm_hip_transport *fastpm_hip_loopback_create(int nranks);

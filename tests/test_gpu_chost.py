@@ -339,8 +339,9 @@ MPI_ROOT = os.environ.get("FPM_MPI_ROOT", "/opt/conda")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("P,nc,B,precision,gradient_mode", [(2, 24, 2, 64, 0), (4, 24, 2, 64, 1), (3, 24, 2, 32, 0)])
-def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode):
+@pytest.mark.parametrize("P,nc,B,precision,gradient_mode,host_columns", [
+    (2, 24, 2, 64, 0, 0), (4, 24, 2, 64, 1, 0), (3, 24, 2, 32, 0, 0), (2, 24, 2, 64, 0, 1), (4, 24, 2, 32, 1, 1)])
+def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode, host_columns):
     """`mpiexec -n P example_slab_mpi`: P separate processes, plain C99, exchanging through MPI_Alltoall /
     MPI_Sendrecv / MPI_Allreduce on MPI_COMM_WORLD exactly where libfastpm's PFFT transposes, ghost exchange and
     mass all-reduce sit (the image's MPICH is not GPU-aware, so the transport stages through the host; on the
@@ -353,7 +354,8 @@ def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode
     subprocess.run(["make", "-C", host, "mpi", "MPI_INC=" + os.path.join(MPI_ROOT, "include"),
                     "MPI_LIB=" + os.path.join(MPI_ROOT, "lib")], check=True, capture_output=True)
     exe = os.path.join(ROOT, "fastpm_amd", "example_slab_mpi")
-    r = subprocess.run([mpiexec, "-n", str(P), exe, str(nc), str(B), str(precision), str(gradient_mode)],
+    r = subprocess.run([mpiexec, "-n", str(P), exe, str(nc), str(B), str(precision), str(gradient_mode), "0",
+                        str(host_columns)],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     lines = {l.split()[0] + (l.split()[1] if l.startswith("acc std") else ""): l.split() for l in r.stdout.splitlines()}
@@ -367,10 +369,24 @@ def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode
     x[:, 0] = np.fmod(q[:, 0] + A * np.sin(2 * k * q[:, 0]) * np.cos(k * q[:, 1]) + L, L)
     x[:, 1] = np.fmod(q[:, 1] + A * np.sin(3 * k * q[:, 1]) * np.cos(k * q[:, 2]) + L, L)
     x[:, 2] = np.fmod(q[:, 2] + A * np.sin(k * q[:, 2]) * np.cos(2 * k * q[:, 0]) + L, L)
-    ref = oracle.compute_force(oracle.PMOracle(nc * B, L, precision), x)["acc"].astype(np.float64)
+    pmo = oracle.PMOracle(nc * B, L, precision)
+    full = oracle.compute_force(pmo, x)
+    ref = full["acc"].astype(np.float64)
     std = np.sqrt((ref ** 2).mean(0) - ref.mean(0) ** 2)
     got = np.array([float(v) for v in lines["accstd"][2:5]])
     tol = 1e-6 if precision == 64 else 2e-5
+    if host_columns:
+        # fastpm_hip_slab_force_host: every rank's delta_k slab is the reference's ORegion, [y_loc][kz][x]
+        dko = pmo.complex_view(full["delta_k"]).astype(np.complex128)              # [y][kz][x]
+        yl = nc * B // P
+        dks = [l.split() for l in r.stdout.splitlines() if l.startswith("dk ")]
+        assert sorted(int(d[1]) for d in dks) == list(range(P))
+        for d in dks:
+            rk = int(d[1])
+            want = dko[rk * yl + 1, 2, 3]
+            rel = 1e-11 if precision == 64 else 1e-4
+            assert abs(complex(float(d[2]), float(d[3])) - want) <= rel * np.abs(dko).max()
+            assert float(d[4]) == pytest.approx((np.abs(dko[rk * yl:(rk + 1) * yl]) ** 2).sum(), rel=1e-9 if precision == 64 else 1e-4)
     assert np.allclose(got, std, rtol=tol), (got, std)
     for i in range(4):
         row = np.array([float(v) for v in lines["acc[%d]" % i][1:4]])
