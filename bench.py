@@ -266,6 +266,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    notes = []
+
     def timed_run(gradient):
         """W untimed + K timed force calls in one gradient mode; max over ranks of the wall time."""
         pm = PM(Nmesh, BoxSize, precision=args.precision, nranks=world, rank=rank, np_max=np_local,
@@ -274,8 +276,14 @@ def main():
         delta_k = pm.alloc()
         if world > 1:
             from fastpm_amd.distributed import SlabForce
-            force = SlabForce(pm, dist.group.WORLD)
-            step = lambda: force.compute_force(store, kernel="1_4", dealias="none", delta_k=delta_k)
+            holder = {"force": SlabForce(pm, dist.group.WORLD)}
+            step = lambda: holder["force"].compute_force(store, kernel="1_4", dealias="none", delta_k=delta_k)
+            try:                                   # one untimed call first: if the pipelined exchange (plane ranges as
+                step()                             # coalesced isend / irecv batches) is refused by this RCCL build,
+                torch.cuda.synchronize()           # every rank sees the same error and takes the plain
+            except Exception as e:                 # one-all_to_all_single-per-transpose path instead
+                notes.append("pipelined exchange failed (%r); running with chunks=1" % (e,))
+                holder["force"] = SlabForce(pm, dist.group.WORLD, chunks=1)
         else:
             step = lambda: pm.compute_force(store, kernel="1_4", softening="none", delta_k=delta_k,
                                             total_mass=float(np_total))
@@ -374,6 +382,8 @@ def main():
         out["exposed_comm_ms_per_step"] = round(ms_per_step - out["kernel_ms_per_step"], 3) if world > 1 else 0.0
         if alt is not None:
             out["other_gradient_mode"] = alt
+        if notes:
+            out["notes"] = notes
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"], out["parity"] = cpu_baseline(os.cpu_count() or 1, x, Nmesh, BoxSize,
