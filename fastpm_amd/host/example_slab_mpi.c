@@ -5,7 +5,11 @@
  * fastpm_hip_slab_force with the MPI transport (fastpm_slab_mpi.c).
  *
  *   make mpi            (in this directory: needs mpi.h / libmpi, e.g. MPICH under /opt/conda)
- *   mpiexec -n P ./example_slab_mpi [nc] [B] [precision] [gradient_mode] [gpu_aware] [host_columns]
+ *   mpiexec -n P ./example_slab_mpi [nc] [B] [precision] [gradient_mode] [gpu_aware] [host_columns] [decompose]
+ *
+ * decompose = 1: the particles start on the WRONG ranks (particle i on rank i mod P) with an id and a velocity
+ * column beside x, and fastpm_hip_slab_decompose (fastpm_decompose, solver.c:571-592) brings every row to the rank
+ * that owns its x cell before the force.
  *
  * host_columns = 1: the store columns and delta_k stay on the host, as in today's libfastpm
  * (fastpm_hip_slab_force_host); every rank then also prints one element and the square sum of its delta_k slab,
@@ -36,6 +40,7 @@ int main(int argc, char **argv)
     const int gradient_mode = argc > 4 ? atoi(argv[4]) : 0;
     const int gpu_aware = argc > 5 ? atoi(argv[5]) : 0;
     const int host_columns = argc > 6 ? atoi(argv[6]) : 0;
+    const int decompose = argc > 7 ? atoi(argv[7]) : 0;
     const int Nmesh = nc * B;
     const double BoxSize = 3.0 * nc;
     if (Nmesh % P) {
@@ -69,12 +74,43 @@ int main(int argc, char **argv)
                 const double px = fmod(q[0] + A * sin(2 * k * q[0]) * cos(k * q[1]) + BoxSize, BoxSize);
                 int cell = (int) floor(px * inv_cell);
                 if (cell >= Nmesh) cell -= Nmesh;
-                if (cell / xl != rank) continue;
+                if (decompose ? (int) (i % (size_t) P) != rank : cell / xl != rank) continue;
                 x[np][0] = px;
                 x[np][1] = fmod(q[1] + A * sin(3 * k * q[1]) * cos(k * q[2]) + BoxSize, BoxSize);
                 x[np][2] = fmod(q[2] + A * sin(k * q[2]) * cos(2 * k * q[0]) + BoxSize, BoxSize);
                 id[np++] = (long long) i;
             }
+
+    if (decompose) {
+        /* columns x | id | v on the device with room for every particle; v is a function of id, so a row that
+         * lost its companions on the way would show */
+        void *cx = NULL, *cid = NULL, *cv = NULL;
+        float (*v)[3] = malloc((np ? np : 1) * sizeof(*v));
+        for (i = 0; i < np; i++) { v[i][0] = (float) id[i]; v[i][1] = (float) id[i] + 0.5f; v[i][2] = -(float) id[i]; }
+        CHECK(fpmhip_malloc(&cx, ntot * 3 * sizeof(double)));
+        CHECK(fpmhip_malloc(&cid, ntot * sizeof(long long)));
+        CHECK(fpmhip_malloc(&cv, ntot * 3 * sizeof(float)));
+        CHECK(fpmhip_memcpy_h2d(plan, cx, x, np * 3 * sizeof(double)));
+        CHECK(fpmhip_memcpy_h2d(plan, cid, id, np * sizeof(long long)));
+        CHECK(fpmhip_memcpy_h2d(plan, cv, v, np * 3 * sizeof(float)));
+        fastpm_hip_column cols[3] = {{cx, 24}, {cid, 8}, {cv, 12}};
+        int64_t n64 = (int64_t) np;
+        CHECK(fastpm_hip_slab_decompose(plan, t, cols, 3, &n64, (int64_t) ntot));
+        np = (size_t) n64;
+        v = realloc(v, (np ? np : 1) * sizeof(*v));
+        CHECK(fpmhip_memcpy_d2h(plan, x, cx, np * 3 * sizeof(double)));
+        CHECK(fpmhip_memcpy_d2h(plan, id, cid, np * sizeof(long long)));
+        CHECK(fpmhip_memcpy_d2h(plan, v, cv, np * 3 * sizeof(float)));
+        size_t bad = 0;
+        for (i = 0; i < np; i++) {
+            int cell = (int) floor(x[i][0] * inv_cell);
+            if (cell >= Nmesh) cell -= Nmesh;
+            if (cell / xl != rank || v[i][0] != (float) id[i] || v[i][1] != (float) id[i] + 0.5f || v[i][2] != -(float) id[i]) bad++;
+        }
+        printf("decomposed %d np %zu bad %zu\n", rank, np, bad);
+        free(v);
+        fpmhip_free(cx); fpmhip_free(cid); fpmhip_free(cv);
+    }
 
     fpmhip_particles part = {0};
     void *dx = NULL, *dacc = NULL;

@@ -127,6 +127,45 @@ int fastpm_hip_slab_force(fpmhip_plan *plan, const fastpm_hip_transport *t, cons
     return 0;
 }
 
+int fastpm_hip_slab_decompose(fpmhip_plan *plan, const fastpm_hip_transport *t, fastpm_hip_column *cols, int ncols,
+                              int64_t *np_io, int64_t np_upper)
+{
+    if (!t->alltoall_counts || !t->alltoallv) return -1;
+    if (ncols < 1 || cols[0].rowbytes != 24) return -1;
+    const int P = t->nranks;
+    const int64_t np = *np_io;
+    int64_t *counts = calloc((size_t) 4 * P + 1, sizeof(int64_t));     /* [stay, to 0 .. to P-1] | recv | rows */
+    if (!counts) return -2;
+    int64_t *recv_counts = counts + P + 1;
+    void *order = NULL, *tmp = NULL;
+    int rc = fpmhip_wrap(plan, cols[0].data_dev, np);                    /* solver.c:583 */
+    if (!rc) rc = fpmhip_malloc(&order, (size_t) (np ? np : 1) * sizeof(int));
+    if (!rc) rc = fpmhip_decompose_order(plan, cols[0].data_dev, np, order, counts);      /* store.c:519-553 */
+    if (!rc) rc = t->alltoall_counts(t->ctx, counts + 1, recv_counts);                   /* store.c:570-572 */
+    int64_t nstay = counts[0], nrecv = 0;
+    for (int r = 0; r < P && !rc; r++) nrecv += recv_counts[r];
+    if (!rc && nstay + nrecv > np_upper) rc = -4;                                           /* store.c:591-597 */
+    int maxrow = 0;
+    for (int c = 0; c < ncols; c++) if (cols[c].rowbytes > maxrow) maxrow = cols[c].rowbytes;
+    if (!rc) rc = fpmhip_malloc(&tmp, (size_t) (np ? np : 1) * maxrow);
+    for (int c = 0; c < ncols && !rc; c++) {
+        const size_t rb = (size_t) cols[c].rowbytes;
+        rc = fpmhip_gather_rows(plan, cols[c].data_dev, tmp, order, np, cols[c].rowbytes);   /* store.c:548 permute */
+        if (!rc) rc = fpmhip_memcpy_d2d(plan, cols[c].data_dev, tmp, (size_t) nstay * rb);
+        if (!rc) rc = fpmhip_sync(plan);
+        if (!rc) rc = t->alltoallv(t->ctx, (const char *) tmp + (size_t) nstay * rb, counts + 1,
+                                   (char *) cols[c].data_dev + (size_t) nstay * rb, recv_counts, cols[c].rowbytes);
+    }
+    if (!rc) {
+        *np_io = nstay + nrecv;                                          /* store.c:589, 635 */
+        rc = fpmhip_invalidate_binning(plan);
+    }
+    if (order) fpmhip_free(order);
+    if (tmp) fpmhip_free(tmp);
+    free(counts);
+    return rc;
+}
+
 int fastpm_hip_slab_force_host(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *ph,
                                int kernel, int softening, void *delta_k_host)
 {

@@ -29,7 +29,28 @@ typedef struct {
     int (*alltoall)(void *ctx, const void *send_dev, void *recv_dev, size_t chunk_bytes);
     /* MPI_Sendrecv: send `bytes` to rank dest, receive `bytes` from rank source  (mesh halo planes) */
     int (*sendrecv)(void *ctx, const void *send_dev, int dest, void *recv_dev, int source, size_t bytes);
+    /* -- only fastpm_hip_slab_decompose needs the two below; a transport without them leaves them NULL -- */
+    /* MPI_Alltoall of one count per rank (host arrays of nranks entries)          store.c:570-572 */
+    int (*alltoall_counts)(void *ctx, const int64_t *send_host, int64_t *recv_host);
+    /* MPI_Alltoallv of rows of `rowbytes` bytes: send_rows[r] rows, stored back to back in rank order, go to
+     * rank r; recv_rows[r] rows arrive from rank r, stored back to back in rank order   store.c:611-621 */
+    int (*alltoallv)(void *ctx, const void *send_dev, const int64_t *send_rows, void *recv_dev,
+                     const int64_t *recv_rows, int rowbytes);
 } fastpm_hip_transport;
+
+/* One column of the store on the device: rows of rowbytes (4, 8, 12, 16, 24 or 36) bytes. */
+typedef struct {
+    void *data_dev;
+    int rowbytes;
+} fastpm_hip_column;
+
+/* fastpm_decompose for x slabs (solver.c:571-592: fastpm_store_wrap, then fastpm_store_decompose, store.c:485-657)
+ * with every column on the device.  cols[0] is x (double[3]); all columns hold np_upper rows of capacity.  On
+ * return *np is the new count and every column holds, in the reference's order, the particles that stayed
+ * (original order) followed by what arrived from rank 0, 1, ... (each in its sender's order).  Returns -4 when
+ * the particles do not fit np_upper (the reference raises "need %td particles; %td allocated", store.c:591-597). */
+int fastpm_hip_slab_decompose(fpmhip_plan *plan, const fastpm_hip_transport *t, fastpm_hip_column *cols, int ncols,
+                              int64_t *np, int64_t np_upper);
 
 /* The force step on this rank's slab: total mass all-reduce, paint, halo plane to rank+1, forward transform
  * around one all-to-all, softening, the backward half in the plan's gradient mode (two transposed meshes for

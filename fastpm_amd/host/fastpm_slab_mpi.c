@@ -20,6 +20,7 @@ typedef struct {
 
 static int stage_reserve(mpi_ctx *c, size_t bytes)
 {
+    if (bytes == 0) bytes = 1;
     if (bytes <= c->hbytes) return 0;
     free(c->hsend);
     free(c->hrecv);
@@ -84,6 +85,44 @@ static int mpi_sendrecv(void *ctx, const void *send_dev, int dest, void *recv_de
     return rc == MPI_SUCCESS ? 0 : -1;
 }
 
+static int mpi_alltoall_counts(void *ctx, const int64_t *send, int64_t *recv)
+{
+    mpi_ctx *c = ctx;
+    return MPI_Alltoall((void *) send, 1, MPI_INT64_T, recv, 1, MPI_INT64_T, c->comm) == MPI_SUCCESS ? 0 : -1;
+}
+
+static int mpi_alltoallv(void *ctx, const void *send_dev, const int64_t *send_rows, void *recv_dev,
+                         const int64_t *recv_rows, int rowbytes)
+{
+    mpi_ctx *c = ctx;
+    const int P = c->nranks;
+    int *cnt = malloc((size_t) 4 * P * sizeof(int));
+    if (!cnt) return -1;
+    int *sc = cnt, *sd = cnt + P, *rcn = cnt + 2 * P, *rd = cnt + 3 * P;
+    int64_t ns = 0, nr = 0;
+    for (int r = 0; r < P; r++) {
+        if (send_rows[r] > INT_MAX || recv_rows[r] > INT_MAX || ns > INT_MAX || nr > INT_MAX) { free(cnt); return -1; }
+        sc[r] = (int) send_rows[r]; sd[r] = (int) ns; ns += send_rows[r];
+        rcn[r] = (int) recv_rows[r]; rd[r] = (int) nr; nr += recv_rows[r];
+    }
+    MPI_Datatype row;
+    MPI_Type_contiguous(rowbytes, MPI_BYTE, &row);
+    MPI_Type_commit(&row);
+    int rc;
+    if (c->gpu_aware) {
+        rc = MPI_Alltoallv((void *) send_dev, sc, sd, row, recv_dev, rcn, rd, row, c->comm);
+    } else {
+        const size_t sb = (size_t) ns * rowbytes, rbts = (size_t) nr * rowbytes;
+        rc = stage_reserve(c, sb > rbts ? sb : rbts) ? MPI_ERR_OTHER : MPI_SUCCESS;
+        if (rc == MPI_SUCCESS && sb && fpmhip_memcpy_d2h(c->plan, c->hsend, send_dev, sb)) rc = MPI_ERR_OTHER;
+        if (rc == MPI_SUCCESS) rc = MPI_Alltoallv(c->hsend, sc, sd, row, c->hrecv, rcn, rd, row, c->comm);
+        if (rc == MPI_SUCCESS && rbts && fpmhip_memcpy_h2d(c->plan, recv_dev, c->hrecv, rbts)) rc = MPI_ERR_OTHER;
+    }
+    MPI_Type_free(&row);
+    free(cnt);
+    return rc == MPI_SUCCESS ? 0 : -1;
+}
+
 fastpm_hip_transport *fastpm_hip_mpi_transport_create(MPI_Comm comm, fpmhip_plan *plan, int gpu_aware)
 {
     fastpm_hip_transport *t = calloc(1, sizeof(*t));
@@ -99,6 +138,8 @@ fastpm_hip_transport *fastpm_hip_mpi_transport_create(MPI_Comm comm, fpmhip_plan
     t->allreduce_sum = mpi_allreduce;
     t->alltoall = mpi_alltoall;
     t->sendrecv = mpi_sendrecv;
+    t->alltoall_counts = mpi_alltoall_counts;
+    t->alltoallv = mpi_alltoallv;
     return t;
 }
 

@@ -230,7 +230,8 @@ def test_c_host_decic_powerspectrum_and_dump(oracle, tmp_path):
 # ---- NTask > 1: fastpm_hip_slab_force (fastpm_amd/host/fastpm_slab_hip.c) ---------------------------------
 class Transport(ctypes.Structure):
     _fields_ = [("ctx", ctypes.c_void_p), ("rank", ctypes.c_int), ("nranks", ctypes.c_int),
-                ("allreduce_sum", ctypes.c_void_p), ("alltoall", ctypes.c_void_p), ("sendrecv", ctypes.c_void_p)]
+                ("allreduce_sum", ctypes.c_void_p), ("alltoall", ctypes.c_void_p), ("sendrecv", ctypes.c_void_p),
+                ("alltoall_counts", ctypes.c_void_p), ("alltoallv", ctypes.c_void_p)]
 
 
 def test_host_library_exports_the_slab_force():
@@ -339,9 +340,10 @@ MPI_ROOT = os.environ.get("FPM_MPI_ROOT", "/opt/conda")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("P,nc,B,precision,gradient_mode,host_columns", [
-    (2, 24, 2, 64, 0, 0), (4, 24, 2, 64, 1, 0), (3, 24, 2, 32, 0, 0), (2, 24, 2, 64, 0, 1), (4, 24, 2, 32, 1, 1)])
-def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode, host_columns):
+@pytest.mark.parametrize("P,nc,B,precision,gradient_mode,host_columns,decompose", [
+    (2, 24, 2, 64, 0, 0, 0), (4, 24, 2, 64, 1, 0, 0), (3, 24, 2, 32, 0, 0, 0), (2, 24, 2, 64, 0, 1, 0),
+    (4, 24, 2, 32, 1, 1, 0), (2, 24, 2, 64, 0, 0, 1), (4, 24, 2, 64, 0, 1, 1), (3, 24, 2, 64, 1, 0, 1)])
+def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode, host_columns, decompose):
     """`mpiexec -n P example_slab_mpi`: P separate processes, plain C99, exchanging through MPI_Alltoall /
     MPI_Sendrecv / MPI_Allreduce on MPI_COMM_WORLD exactly where libfastpm's PFFT transposes, ghost exchange and
     mass all-reduce sit (the image's MPICH is not GPU-aware, so the transport stages through the host; on the
@@ -355,12 +357,17 @@ def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode
                     "MPI_LIB=" + os.path.join(MPI_ROOT, "lib")], check=True, capture_output=True)
     exe = os.path.join(ROOT, "fastpm_amd", "example_slab_mpi")
     r = subprocess.run([mpiexec, "-n", str(P), exe, str(nc), str(B), str(precision), str(gradient_mode), "0",
-                        str(host_columns)],
+                        str(host_columns), str(decompose)],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     lines = {l.split()[0] + (l.split()[1] if l.startswith("acc std") else ""): l.split() for l in r.stdout.splitlines()}
     assert lines["ranks"][1] == str(P) and float(lines["ranks"][3]) == nc ** 3        # every particle has one owner
     assert sum(1 for l in r.stdout.splitlines() if l.startswith("rank ")) == P
+    if decompose:
+        # fastpm_hip_slab_decompose: every row (x, id, v together) reached the rank that owns its x cell
+        dec = [l.split() for l in r.stdout.splitlines() if l.startswith("decomposed ")]
+        assert sorted(int(d[1]) for d in dec) == list(range(P))
+        assert sum(int(d[3]) for d in dec) == nc ** 3 and all(int(d[5]) == 0 for d in dec)
     L, h = 3.0 * nc, 3.0
     A, k = 0.35 * h, 2 * np.pi / L
     g = (np.arange(nc) + 0.5) * h
