@@ -398,3 +398,90 @@ def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode
     for i in range(4):
         row = np.array([float(v) for v in lines["acc[%d]" % i][1:4]])
         assert np.abs(row - ref[i]).max() <= tol * np.abs(ref).max()
+
+
+# ---- kick / drift / wrap through the C host (fastpm_factors_hip.c) -----------------------------------------------
+class DriftFactorView(ctypes.Structure):
+    _fields_ = [("forcemode", ctypes.c_int), ("ai", ctypes.c_double), ("ac", ctypes.c_double), ("af", ctypes.c_double),
+                ("nsamples", ctypes.c_int), ("Dv1", ctypes.c_double), ("Dv2", ctypes.c_double),
+                ("dyyy", ctypes.c_double * 32), ("da1", ctypes.c_double * 32), ("da2", ctypes.c_double * 32)]
+
+
+class KickFactorView(ctypes.Structure):
+    _fields_ = [("forcemode", ctypes.c_int), ("ai", ctypes.c_double), ("ac", ctypes.c_double), ("af", ctypes.c_double),
+                ("nsamples", ctypes.c_int), ("q1", ctypes.c_double), ("q2", ctypes.c_double),
+                ("dda", ctypes.c_double * 32), ("Dv1", ctypes.c_double * 32), ("Dv2", ctypes.c_double * 32)]
+
+
+class DeviceStoreView(ctypes.Structure):
+    _fields_ = [("np", ctypes.c_size_t), ("x", ctypes.c_void_p), ("v", ctypes.c_void_p), ("acc", ctypes.c_void_p),
+                ("dx1", ctypes.c_void_p), ("dx2", ctypes.c_void_p), ("a_x", ctypes.c_double), ("a_v", ctypes.c_double)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fastpm", "cola"])
+def test_c_host_kick_drift_wrap_and_leapfrog(mode):
+    """fastpm_kick_store / fastpm_drift_store / fastpm_store_wrap through the C host's factor structs (the
+    reference's members, solver.h:117-146; two table lookups on the host, one launch) give the bits of the Python
+    mirror's calls; the fused leapfrog gives the bits of the three separate calls."""
+    import torch
+    from fastpm_amd import DriftFactor, KickFactor, Store, fastpm_drift_store, fastpm_kick_store, fastpm_store_wrap
+    from fastpm_amd.pm import FORCE_TYPES
+    H = _host()
+    for f in ("fastpm_kick_store_hip", "fastpm_drift_store_hip"):
+        getattr(H, f).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(DeviceStoreView),
+                                  ctypes.POINTER(DeviceStoreView), ctypes.c_double]
+    H.fastpm_store_wrap_hip.argtypes = [ctypes.c_void_p, ctypes.POINTER(DeviceStoreView)]
+    H.fastpm_leapfrog_store_hip.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p,
+                                            ctypes.c_double, ctypes.c_void_p, ctypes.c_double,
+                                            ctypes.POINTER(DeviceStoreView), ctypes.c_int]
+    rng = np.random.default_rng(11)
+    n, L = 5000, 64.0
+    x = rng.uniform(-3, L + 3, (n, 3))
+    cols = {k: rng.normal(size=(n, 3)).astype(np.float32) for k in ("v", "dx1", "dx2")}
+    acc = rng.normal(size=(n, 3)).astype(np.float32)
+    t = lambda s: np.sort(rng.uniform(0, s, 32))
+    kt, dt = [t(2.0), t(1.0), t(1.0)], [t(3.0), t(1.0), t(1.0)]
+    ai, ac, af = 0.1, 0.15, 0.2
+    kick = KickFactor(mode, ai, ac, af, *kt, q1=0.3, q2=0.05)
+    drift = DriftFactor(mode, ai, ac, af, *dt, Dv1=0.2, Dv2=0.03)
+    kv = KickFactorView(FORCE_TYPES[mode], ai, ac, af, 32, 0.3, 0.05, *[(ctypes.c_double * 32)(*a) for a in kt])
+    dv = DriftFactorView(FORCE_TYPES[mode], ai, ac, af, 32, 0.2, 0.03, *[(ctypes.c_double * 32)(*a) for a in dt])
+    pm = H.fastpm_create_pm_hip(16, L, 64)
+
+    def fresh():
+        s = Store(x, a_x=ai, a_v=ai, **cols)
+        s.acc.copy_(torch.from_numpy(acc).cuda())
+        return s
+
+    def view(s):
+        return DeviceStoreView(s.np, s.x.data_ptr(), s.v.data_ptr(), s.acc.data_ptr(), s.dx1.data_ptr(),
+                               s.dx2.data_ptr(), s.a_x, s.a_v)
+    from fastpm_amd import PM
+    ppm = PM(16, L, 64)
+    a, b, c = fresh(), fresh(), fresh()
+    fastpm_kick_store(ppm, kick, a, a, 0.13)                      # an interior point of the tables and an end point
+    fastpm_drift_store(ppm, drift, a, a, 0.17)
+    fastpm_drift_store(ppm, drift, a, a, af)
+    fastpm_store_wrap(ppm, a)
+    vb = view(b)
+    H.fastpm_kick_store_hip(pm, ctypes.byref(kv), ctypes.byref(vb), ctypes.byref(vb), 0.13)
+    H.fastpm_drift_store_hip(pm, ctypes.byref(dv), ctypes.byref(vb), ctypes.byref(vb), 0.17)
+    H.fastpm_drift_store_hip(pm, ctypes.byref(dv), ctypes.byref(vb), ctypes.byref(vb), af)
+    H.fastpm_store_wrap_hip(pm, ctypes.byref(vb))
+    vc = view(c)
+    H.fastpm_leapfrog_store_hip(pm, ctypes.byref(kv), 0.13, ctypes.byref(dv), 0.17, ctypes.byref(dv), af, ctypes.byref(vc), 1)
+    torch.cuda.synchronize()
+    for s, sv in ((b, vb), (c, vc)):
+        assert torch.equal(a.v, s.v) and torch.equal(a.x, s.x)
+        assert sv.a_v == 0.13 and sv.a_x == af
+    # beyond the table: the reference raises (factors.c:63, 128)
+    msgs = []
+    HANDLER = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p)
+    h = HANDLER(lambda code, msg, ud: msgs.append((code, msg.decode())))
+    H.fpm_set_msg_handler(h, None)
+    H.fastpm_kick_store_hip(pm, ctypes.byref(kv), ctypes.byref(vb), ctypes.byref(vb), 0.5)
+    assert msgs and "kick beyond factor's available range" in msgs[0][1]
+    H.fpm_set_msg_handler(None, None)
+    ppm.destroy()
+    H.fastpm_free_pm_hip(pm)
