@@ -11,6 +11,7 @@
  * column beside x, and fastpm_hip_slab_decompose (fastpm_decompose, solver.c:571-592) brings every row to the rank
  * that owns its x cell before the force.
  *
+ * gpu_aware: 0 = MPI with host staging, 1 = GPU-aware MPI (device pointers go to MPI), 2 = RCCL (one rank per GPU).
  * host_columns = 1: the store columns and delta_k stay on the host, as in today's libfastpm
  * (fastpm_hip_slab_force_host); every rank then also prints one element and the square sum of its delta_k slab,
  * which is in the reference's ORegion layout [y_loc][kz][x].
@@ -27,6 +28,46 @@
 
 #define CHECK(expr) do { if ((expr) != 0) { fprintf(stderr, "rank %d: %s failed: %s\n", rank, #expr, fpmhip_last_error()); \
                                             MPI_Abort(MPI_COMM_WORLD, 1); } } while (0)
+
+/* Every function of a transport on small device buffers with a known pattern: value (sender, receiver, row). */
+static int transport_selftest(const fastpm_hip_transport *t, fpmhip_plan *plan)
+{
+    const int P = t->nranks, r = t->rank, n = 1000;
+    int bad = 0;
+    double s = r + 1.0;
+    if (t->allreduce_sum(t->ctx, &s) || s != P * (P + 1) / 2.0) bad++;
+    double *h = malloc((size_t) 2 * P * n * sizeof(double)), *g = h + (size_t) P * n;
+    void *ds = NULL, *dr = NULL;
+    if (fpmhip_malloc(&ds, (size_t) P * n * sizeof(double)) || fpmhip_malloc(&dr, (size_t) P * n * sizeof(double))) return 100;
+    for (int q = 0; q < P; q++) for (int i = 0; i < n; i++) h[q * n + i] = 1e6 * r + 1e3 * q + i;
+    fpmhip_memcpy_h2d(plan, ds, h, (size_t) P * n * sizeof(double));
+    if (t->alltoall(t->ctx, ds, dr, n * sizeof(double))) bad++;
+    fpmhip_memcpy_d2h(plan, g, dr, (size_t) P * n * sizeof(double));
+    for (int q = 0; q < P; q++) for (int i = 0; i < n; i++) if (g[q * n + i] != 1e6 * q + 1e3 * r + i) { bad++; break; }
+    if (t->sendrecv(t->ctx, ds, (r + 1) % P, dr, (r + P - 1) % P, n * sizeof(double))) bad++;
+    fpmhip_memcpy_d2h(plan, g, dr, n * sizeof(double));
+    for (int i = 0; i < n; i++) if (g[i] != 1e6 * ((r + P - 1) % P) + i) { bad++; break; }
+    if (t->alltoall_counts && t->alltoallv) {
+        int64_t *sc = malloc((size_t) 2 * P * sizeof(int64_t)), *rc = sc + P;
+        for (int q = 0; q < P; q++) sc[q] = (r + 2 * q) % 5;             /* uneven, some zero */
+        if (t->alltoall_counts(t->ctx, sc, rc)) bad++;
+        for (int q = 0; q < P; q++) if (rc[q] != (q + 2 * r) % 5) bad++;
+        size_t o = 0;
+        for (int q = 0; q < P; q++) for (int64_t i = 0; i < sc[q]; i++, o++)
+            for (int d = 0; d < 3; d++) h[3 * o + d] = 1e6 * r + 1e3 * q + 10 * i + d;      /* rows of 24 bytes */
+        fpmhip_memcpy_h2d(plan, ds, h, (o ? o : 1) * 24);
+        if (t->alltoallv(t->ctx, ds, sc, dr, rc, 24)) bad++;
+        size_t nr = 0;
+        for (int q = 0; q < P; q++) nr += (size_t) rc[q];
+        fpmhip_memcpy_d2h(plan, g, dr, (nr ? nr : 1) * 24);
+        o = 0;
+        for (int q = 0; q < P; q++) for (int64_t i = 0; i < rc[q]; i++, o++)
+            for (int d = 0; d < 3; d++) if (g[3 * o + d] != 1e6 * q + 1e3 * r + 10 * i + d) bad++;
+        free(sc);
+    }
+    fpmhip_free(ds); fpmhip_free(dr); free(h);
+    return bad;
+}
 
 int main(int argc, char **argv)
 {
@@ -58,7 +99,10 @@ int main(int argc, char **argv)
     g.gradient_mode = gradient_mode;
     fpmhip_plan *plan = NULL;
     CHECK(fpmhip_plan_create(&g, NULL, &plan));
-    fastpm_hip_transport *t = fastpm_hip_mpi_transport_create(MPI_COMM_WORLD, plan, gpu_aware);
+    fastpm_hip_transport *t = gpu_aware == 2 ? fastpm_hip_rccl_transport_create(MPI_COMM_WORLD, g.device)
+                                             : fastpm_hip_mpi_transport_create(MPI_COMM_WORLD, plan, gpu_aware);
+    if (!t) { fprintf(stderr, "rank %d: no transport\n", rank); MPI_Abort(MPI_COMM_WORLD, 1); }
+    printf("transport %d selftest bad %d\n", rank, transport_selftest(t, plan));
 
     /* this rank's particles: x cell in [rank * N / P, (rank + 1) * N / P) */
     const size_t ntot = (size_t) nc * nc * nc;
@@ -169,7 +213,8 @@ int main(int argc, char **argv)
     free(acc); free(x); free(id);
     if (dx) fpmhip_free(dx);
     if (dacc) fpmhip_free(dacc);
-    fastpm_hip_mpi_transport_destroy(t);
+    if (gpu_aware == 2) fastpm_hip_rccl_transport_destroy(t);
+    else fastpm_hip_mpi_transport_destroy(t);
     fpmhip_plan_destroy(plan);
     MPI_Finalize();
     return 0;

@@ -34,6 +34,8 @@ int fastpm_hip_slab_force(fpmhip_plan *plan, const fastpm_hip_transport *t, cons
     fpmhip_layout lay;
     TRY(fpmhip_plan_layout(plan, &lay));
     if (lay.nranks != t->nranks || lay.rank != t->rank) return -1;
+    if (lay.nranks == 1)            /* no ghosts, no transposes (pmghosts.c:67: rank == ThisTask always) */
+        return fpmhip_force(plan, p, kernel, softening, -1.0, delta_k);
     int po, go, dfo, dc;
     TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));
     const int64_t xl = lay.isize[0];
@@ -130,8 +132,12 @@ int fastpm_hip_slab_force(fpmhip_plan *plan, const fastpm_hip_transport *t, cons
 int fastpm_hip_slab_decompose(fpmhip_plan *plan, const fastpm_hip_transport *t, fastpm_hip_column *cols, int ncols,
                               int64_t *np_io, int64_t np_upper)
 {
-    if (!t->alltoall_counts || !t->alltoallv) return -1;
     if (ncols < 1 || cols[0].rowbytes != 24) return -1;
+    if (t->nranks == 1) {           /* every particle stays: fastpm_store_wrap is all that is left */
+        int rc1 = fpmhip_wrap(plan, cols[0].data_dev, *np_io);
+        return rc1 ? rc1 : fpmhip_invalidate_binning(plan);
+    }
+    if (!t->alltoall_counts || !t->alltoallv) return -1;
     const int P = t->nranks;
     const int64_t np = *np_io;
     int64_t *counts = calloc((size_t) 4 * P + 1, sizeof(int64_t));     /* [stay, to 0 .. to P-1] | recv | rows */

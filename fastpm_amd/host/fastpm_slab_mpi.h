@@ -22,6 +22,12 @@ extern "C" {
 fastpm_hip_transport *fastpm_hip_mpi_transport_create(MPI_Comm comm, fpmhip_plan *plan, int gpu_aware);
 void fastpm_hip_mpi_transport_destroy(fastpm_hip_transport *t);
 
+/* The same transport on RCCL (fastpm_slab_rccl.c): grouped ncclSend / ncclRecv over xGMI for the transposes, halo
+ * planes and particle rows, ncclAllReduce for the total mass; comm is used for the bootstrap (ncclUniqueId
+ * broadcast, row counts).  One rank per GPU; `device` is this rank's GPU. */
+fastpm_hip_transport *fastpm_hip_rccl_transport_create(MPI_Comm comm, int device);
+void fastpm_hip_rccl_transport_destroy(fastpm_hip_transport *t);
+
 #ifdef __cplusplus
 }
 #endif

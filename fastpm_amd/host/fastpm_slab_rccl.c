@@ -1,0 +1,125 @@
+/*
+ * fastpm_slab_rccl.c -- the transport of fastpm_hip_slab_force / fastpm_hip_slab_decompose on RCCL: the transposes,
+ * the halo planes and the particle exchange go GPU to GPU over xGMI as grouped ncclSend / ncclRecv (what
+ * ncclAllToAll is made of; xGMI is point to point, one link per GPU pair), the total mass as an ncclAllReduce.
+ * MPI is used for the bootstrap only (broadcast of the ncclUniqueId, the per-rank row counts of the decompose):
+ * libfastpm is an MPI program and has the communicator.  One rank per GPU -- RCCL refuses two ranks on one device,
+ * so on a one-GPU box this transport runs with one rank (tests/test_gpu_chost.py), where every send is to self.
+ *
+ * Blocking semantics, as the transport contract asks: every call ends with a synchronisation of the transport's
+ * own stream.
+ */
+#define __HIP_PLATFORM_AMD__
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+#include <stdlib.h>
+
+#include "fastpm_slab_mpi.h"
+
+typedef struct {
+    MPI_Comm mpi;
+    ncclComm_t comm;
+    hipStream_t stream;
+    double *dscalar;
+    int nranks;
+} rccl_ctx;
+
+#define OK_HIP(e) ((e) == hipSuccess)
+#define OK_NCCL(e) ((e) == ncclSuccess)
+
+static int finish(rccl_ctx *c, int ok)
+{
+    return ok && OK_HIP(hipStreamSynchronize(c->stream)) ? 0 : -1;
+}
+
+static int rccl_allreduce(void *ctx, double *value)
+{
+    rccl_ctx *c = ctx;
+    int ok = OK_HIP(hipMemcpyAsync(c->dscalar, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    ok = ok && OK_NCCL(ncclAllReduce(c->dscalar, c->dscalar, 1, ncclDouble, ncclSum, c->comm, c->stream));
+    ok = ok && OK_HIP(hipMemcpyAsync(value, c->dscalar, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return finish(c, ok);
+}
+
+static int rccl_alltoall(void *ctx, const void *send, void *recv, size_t chunk_bytes)
+{
+    rccl_ctx *c = ctx;
+    int ok = OK_NCCL(ncclGroupStart());
+    for (int r = 0; r < c->nranks && ok; r++) {
+        ok = OK_NCCL(ncclSend((const char *) send + (size_t) r * chunk_bytes, chunk_bytes, ncclInt8, r, c->comm, c->stream))
+             && OK_NCCL(ncclRecv((char *) recv + (size_t) r * chunk_bytes, chunk_bytes, ncclInt8, r, c->comm, c->stream));
+    }
+    ok = OK_NCCL(ncclGroupEnd()) && ok;
+    return finish(c, ok);
+}
+
+static int rccl_sendrecv(void *ctx, const void *send, int dest, void *recv, int source, size_t bytes)
+{
+    rccl_ctx *c = ctx;
+    int ok = OK_NCCL(ncclGroupStart());
+    ok = ok && OK_NCCL(ncclSend(send, bytes, ncclInt8, dest, c->comm, c->stream));
+    ok = ok && OK_NCCL(ncclRecv(recv, bytes, ncclInt8, source, c->comm, c->stream));
+    ok = OK_NCCL(ncclGroupEnd()) && ok;
+    return finish(c, ok);
+}
+
+static int rccl_alltoall_counts(void *ctx, const int64_t *send, int64_t *recv)
+{
+    rccl_ctx *c = ctx;
+    return MPI_Alltoall((void *) send, 1, MPI_INT64_T, recv, 1, MPI_INT64_T, c->mpi) == MPI_SUCCESS ? 0 : -1;
+}
+
+static int rccl_alltoallv(void *ctx, const void *send, const int64_t *send_rows, void *recv, const int64_t *recv_rows,
+                          int rowbytes)
+{
+    rccl_ctx *c = ctx;
+    size_t so = 0, ro = 0;
+    int ok = OK_NCCL(ncclGroupStart());
+    for (int r = 0; r < c->nranks && ok; r++) {
+        const size_t sb = (size_t) send_rows[r] * rowbytes, rb = (size_t) recv_rows[r] * rowbytes;
+        if (sb) ok = ok && OK_NCCL(ncclSend((const char *) send + so, sb, ncclInt8, r, c->comm, c->stream));
+        if (rb) ok = ok && OK_NCCL(ncclRecv((char *) recv + ro, rb, ncclInt8, r, c->comm, c->stream));
+        so += sb;
+        ro += rb;
+    }
+    ok = OK_NCCL(ncclGroupEnd()) && ok;
+    return finish(c, ok);
+}
+
+fastpm_hip_transport *fastpm_hip_rccl_transport_create(MPI_Comm comm, int device)
+{
+    fastpm_hip_transport *t = calloc(1, sizeof(*t));
+    rccl_ctx *c = calloc(1, sizeof(*c));
+    if (!t || !c) { free(t); free(c); return NULL; }
+    c->mpi = comm;
+    MPI_Comm_size(comm, &c->nranks);
+    MPI_Comm_rank(comm, &t->rank);
+    t->nranks = c->nranks;
+    ncclUniqueId id;
+    int ok = OK_HIP(hipSetDevice(device));
+    if (t->rank == 0) ok = ok && OK_NCCL(ncclGetUniqueId(&id));
+    MPI_Bcast(&id, (int) sizeof(id), MPI_BYTE, 0, comm);
+    ok = ok && OK_NCCL(ncclCommInitRank(&c->comm, c->nranks, id, t->rank));
+    ok = ok && OK_HIP(hipStreamCreate(&c->stream));
+    ok = ok && OK_HIP(hipMalloc((void **) &c->dscalar, sizeof(double)));
+    if (!ok) { free(t); free(c); return NULL; }
+    t->ctx = c;
+    t->allreduce_sum = rccl_allreduce;
+    t->alltoall = rccl_alltoall;
+    t->sendrecv = rccl_sendrecv;
+    t->alltoall_counts = rccl_alltoall_counts;
+    t->alltoallv = rccl_alltoallv;
+    return t;
+}
+
+void fastpm_hip_rccl_transport_destroy(fastpm_hip_transport *t)
+{
+    if (!t) return;
+    rccl_ctx *c = t->ctx;
+    (void) hipStreamSynchronize(c->stream);
+    (void) hipFree(c->dscalar);
+    (void) ncclCommDestroy(c->comm);
+    (void) hipStreamDestroy(c->stream);
+    free(c);
+    free(t);
+}

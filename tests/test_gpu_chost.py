@@ -363,6 +363,8 @@ def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode
     lines = {l.split()[0] + (l.split()[1] if l.startswith("acc std") else ""): l.split() for l in r.stdout.splitlines()}
     assert lines["ranks"][1] == str(P) and float(lines["ranks"][3]) == nc ** 3        # every particle has one owner
     assert sum(1 for l in r.stdout.splitlines() if l.startswith("rank ")) == P
+    st = [l.split() for l in r.stdout.splitlines() if l.startswith("transport ")]      # every transport function, checked
+    assert len(st) == P and all(s[-1] == "0" for s in st), st
     if decompose:
         # fastpm_hip_slab_decompose: every row (x, id, v together) reached the rank that owns its x cell
         dec = [l.split() for l in r.stdout.splitlines() if l.startswith("decomposed ")]
@@ -485,3 +487,35 @@ def test_c_host_kick_drift_wrap_and_leapfrog(mode):
     H.fpm_set_msg_handler(None, None)
     ppm.destroy()
     H.fastpm_free_pm_hip(pm)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("decompose", [0, 1])
+def test_rccl_transport_one_rank(oracle, decompose):
+    """The RCCL transport of the C host (fastpm_slab_rccl.c: grouped ncclSend / ncclRecv, ncclAllReduce; bootstrap
+    over MPI).  RCCL refuses two ranks on one device, so on this box it runs with ONE rank: communicator creation, every
+    transport function with itself as the peer (the self test the example prints), and the force through the same
+    program.  The multi-GPU data path of the same calls is what the MPI-transport tests above pin."""
+    import subprocess
+    mpiexec = os.path.join(MPI_ROOT, "bin", "mpiexec")
+    if not (os.path.exists(mpiexec) and os.path.exists(os.path.join(MPI_ROOT, "include", "mpi.h"))):
+        pytest.skip("no MPI in this image")
+    host = os.path.join(ROOT, "fastpm_amd", "host")
+    subprocess.run(["make", "-C", host, "mpi"], check=True, capture_output=True)
+    nc, B = 24, 2
+    r = subprocess.run([mpiexec, "-n", "1", os.path.join(ROOT, "fastpm_amd", "example_slab_mpi"), str(nc), str(B), "64",
+                        "0", "2", "0", str(decompose)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "transport 0 selftest bad 0" in r.stdout
+    lines = {l.split()[0] + (l.split()[1] if l.startswith("acc std") else ""): l.split() for l in r.stdout.splitlines()}
+    L, h = 3.0 * nc, 3.0
+    A, k = 0.35 * h, 2 * np.pi / L
+    g = (np.arange(nc) + 0.5) * h
+    q = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
+    x = np.empty_like(q)
+    x[:, 0] = np.fmod(q[:, 0] + A * np.sin(2 * k * q[:, 0]) * np.cos(k * q[:, 1]) + L, L)
+    x[:, 1] = np.fmod(q[:, 1] + A * np.sin(3 * k * q[:, 1]) * np.cos(k * q[:, 2]) + L, L)
+    x[:, 2] = np.fmod(q[:, 2] + A * np.sin(k * q[:, 2]) * np.cos(2 * k * q[:, 0]) + L, L)
+    ref = oracle.compute_force(oracle.PMOracle(nc * B, L, 64), x)["acc"].astype(np.float64)
+    std = np.sqrt((ref ** 2).mean(0) - ref.mean(0) ** 2)
+    assert np.allclose([float(v) for v in lines["accstd"][2:5]], std, rtol=1e-6)
