@@ -355,6 +355,13 @@ int fpmhip_free(void *ptr)
     return 0;
 }
 
+int fpmhip_memset(fpmhip_plan *p, void *dst, int value, size_t bytes)
+{
+    if (!dst && bytes) FPM_FAIL(-1, "null argument");
+    FPM_CHECK_HIP(hipMemsetAsync(dst, value, bytes, p ? p->stream : 0));
+    return 0;
+}
+
 int fpmhip_memcpy_h2d(fpmhip_plan *p, void *dst, const void *src, size_t bytes)
 {
     FPM_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, p ? p->stream : 0));

@@ -123,6 +123,7 @@ SYMBOLS = {
     "fpmhip_timing_name": (ctypes.c_char_p, [_I]),
     "fpmhip_malloc": (_I, [ctypes.POINTER(_P), ctypes.c_size_t]),
     "fpmhip_free": (_I, [_P]),
+    "fpmhip_memset": (_I, [_P, _P, _I, ctypes.c_size_t]),
     "fpmhip_memcpy_h2d": (_I, [_P, _P, _P, ctypes.c_size_t]),
     "fpmhip_memcpy_d2d": (_I, [_P, _P, _P, ctypes.c_size_t]),
     "fpmhip_memcpy_d2h": (_I, [_P, _P, _P, ctypes.c_size_t]),

@@ -376,6 +376,7 @@ const char *fpmhip_timing_name(int stage);
 /* ---- plain device-memory helpers so a C host needs no HIP headers ---- */
 int fpmhip_malloc(void **ptr_dev, size_t bytes);
 int fpmhip_free(void *ptr_dev);
+int fpmhip_memset(fpmhip_plan *plan, void *dst_dev, int byte_value, size_t bytes);     /* on the plan's stream */
 int fpmhip_memcpy_h2d(fpmhip_plan *plan, void *dst_dev, const void *src_host, size_t bytes);
 int fpmhip_memcpy_d2h(fpmhip_plan *plan, void *dst_host, const void *src_dev, size_t bytes);
 /* device to device on the plan's stream, asynchronous (an in-process transport uses it) */

@@ -519,3 +519,22 @@ def test_rccl_transport_one_rank(oracle, decompose):
     ref = oracle.compute_force(oracle.PMOracle(nc * B, L, 64), x)["acc"].astype(np.float64)
     std = np.sqrt((ref ** 2).mean(0) - ref.mean(0) ** 2)
     assert np.allclose([float(v) for v in lines["accstd"][2:5]], std, rtol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [64, 32])
+def test_plain_c_program_prints_the_reference_lpt_lines(tmp_path, precision):
+    """fastpm_amd/host/example_lpt_check.c: seed 100 -> gadget-scheme field -> remove variance -> induce the
+    reference's tests/powerspec.txt -> pm_2lpt_solve, all in C99 over the C ABI; it prints the "dx1  :" and "dx2  :"
+    lines with the reference's format string, and they must BE the lines of tests/run-test-lightcone.check."""
+    import subprocess
+    from oracle import reference_run as R
+    host = os.path.join(ROOT, "fastpm_amd", "host")
+    exe = str(tmp_path / "example_lpt_check")
+    subprocess.run(["gcc", "-std=gnu99", "-O2", "-I" + os.path.join(ROOT, "include"), "-I" + host,
+                    os.path.join(host, "example_lpt_check.c"), "-L" + os.path.join(ROOT, "fastpm_amd"),
+                    "-lfastpm_hip_host", "-lfastpm_hip", "-lm", "-Wl,-rpath," + os.path.join(ROOT, "fastpm_amd"),
+                    "-o", exe], check=True)
+    table = os.path.join(ROOT, "tests", "golden", "reference_tests_powerspec.txt")
+    r = subprocess.run([exe, table, "64", "512", "100", str(precision)], capture_output=True, text=True, check=True)
+    assert r.stdout.splitlines() == ["dx1  : " + " ".join(R.CHECK["dx1"]), "dx2  : " + " ".join(R.CHECK["dx2"])]
