@@ -116,7 +116,6 @@ template <int R, int S, typename F> __device__ __forceinline__ void dftR(C2<F> *
     else dft2<S>(v);
 }
 
-constexpr int COLS = 8;   // columns per workgroup: 8 x complex<double> = one 128-B line per row
 constexpr int EPT = 8;    // elements per thread at load / store time
 constexpr int VMAX = 10;  // register slots: a radix-3 / radix-5 stage touches up to 2*5 (or 3*3) values
 
@@ -442,18 +441,18 @@ __global__ __launch_bounds__(N / 8 * CW, 4) void colfft_yback2_kernel(const C2<F
 // A workgroup takes 8 adjacent rows; the row is read as M complex numbers z[n] = x[2n] + i x[2n+1],
 // transformed with the same register/LDS FFT core (thread (tau, c): row c, elements tau + T*j),
 // and untangled:  X[k] = E[k] + W_N^k O[k],  E = (Z[k] + conj Z[M-k]) / 2,  O = (Z[k] - conj Z[M-k]) / 2i.
-template <int M, int R2, int R3, int R4, typename F>
-__global__ __launch_bounds__(M) void rowfft_r2c_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ out,
+template <int M, int R2, int R3, int R4, int RW, typename F>
+__global__ __launch_bounds__(M / 8 * RW) void rowfft_r2c_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ out,
                                                        long long pitch, int nrows,
                                                        const double *__restrict__ tw_global)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     C2<F> *lds = (C2<F> *) smem;
-    C2<F> *tw = lds + M * COLS;        // W_M^j, j < M
+    C2<F> *tw = lds + M * RW;        // W_M^j, j < M
     C2<F> *twn = tw + M;               // W_N^k, k < M  (N = 2M)
     constexpr int T = M / EPT;
-    const int c = threadIdx.x % COLS, tau = threadIdx.x / COLS;
-    const long long row = (long long) blockIdx.x * COLS + c;
+    const int c = threadIdx.x % RW, tau = threadIdx.x / RW;
+    const long long row = (long long) blockIdx.x * RW + c;
     const bool live = row < nrows;
     const C2<F> *src = in + row * pitch;
     C2<F> v[VMAX];
@@ -466,17 +465,17 @@ __global__ __launch_bounds__(M) void rowfft_r2c_kernel(const C2<F> *__restrict__
         twn[i].y = (F) tw_global[2 * i + 1];
     }
     __syncthreads();
-    fft_core<M, R2, R3, R4, -1, COLS>(v, lds, tw, tau, c);
+    fft_core<M, R2, R3, R4, -1, RW>(v, lds, tw, tau, c);
     // exchange so that every thread can pair Z[k] with Z[M - k]
 #pragma unroll
-    for (int j = 0; j < EPT; j++) lds[(tau + T * j) * COLS + c] = v[j];
+    for (int j = 0; j < EPT; j++) lds[(tau + T * j) * RW + c] = v[j];
     __syncthreads();
     C2<F> *dst = out + row * pitch;
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
         const int k = tau + T * j;
         const C2<F> a = v[j];
-        C2<F> bq = lds[((M - k) % M) * COLS + c];
+        C2<F> bq = lds[((M - k) % M) * RW + c];
         bq.y = -bq.y;                                          // conj Z[M-k]
         const C2<F> e = {(a.x + bq.x) * (F) 0.5, (a.y + bq.y) * (F) 0.5};
         const C2<F> d = {(a.x - bq.x) * (F) 0.5, (a.y - bq.y) * (F) 0.5};
@@ -494,17 +493,17 @@ __global__ __launch_bounds__(M) void rowfft_r2c_kernel(const C2<F> *__restrict__
 //   Z'[k] = (X[k] + conj X[M-k]) + i conj(W_N^k) (X[k] - conj X[M-k]),   z' = IFFT_M(Z') (unnormalised),
 // and the row is z'[n] = x[2n] + i x[2n+1].  One read and one write of the mesh in one kernel; rocFFT's batched
 // 1-D c2r is as fast at N = 512 (0.42 ms) but 2.5x slower per byte at N = 1024 (1.05 ms vs 0.43 ms here).
-template <int M, int R2, int R3, int R4, typename F>
-__global__ __launch_bounds__(M) void rowfft_c2r_kernel(C2<F> *__restrict__ buf, long long pitch, int nrows,
+template <int M, int R2, int R3, int R4, int RW, typename F>
+__global__ __launch_bounds__(M / 8 * RW) void rowfft_c2r_kernel(C2<F> *__restrict__ buf, long long pitch, int nrows,
                                                        const double *__restrict__ tw_global)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    C2<F> *lds = (C2<F> *) smem;               // (M + 1) * COLS: the half spectrum, then the FFT exchange area
-    C2<F> *tw = lds + (M + 1) * COLS;          // W_M^j, j < M
+    C2<F> *lds = (C2<F> *) smem;               // (M + 1) * RW: the half spectrum, then the FFT exchange area
+    C2<F> *tw = lds + (M + 1) * RW;          // W_M^j, j < M
     C2<F> *twn = tw + M;                       // W_N^k, k < M  (N = 2M)
     constexpr int T = M / EPT;
-    const int c = threadIdx.x % COLS, tau = threadIdx.x / COLS;
-    const long long row = (long long) blockIdx.x * COLS + c;
+    const int c = threadIdx.x % RW, tau = threadIdx.x / RW;
+    const long long row = (long long) blockIdx.x * RW + c;
     const bool live = row < nrows;
     C2<F> *src = buf + row * pitch;
     C2<F> v[VMAX];
@@ -521,14 +520,14 @@ __global__ __launch_bounds__(M) void rowfft_c2r_kernel(C2<F> *__restrict__ buf, 
         twn[i].y = (F) tw_global[2 * i + 1];
     }
 #pragma unroll
-    for (int j = 0; j < EPT; j++) lds[(tau + T * j) * COLS + c] = v[j];
-    if (tau == 0) lds[M * COLS + c] = xm;
+    for (int j = 0; j < EPT; j++) lds[(tau + T * j) * RW + c] = v[j];
+    if (tau == 0) lds[M * RW + c] = xm;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
         const int k = tau + T * j;
         const C2<F> a = v[j];
-        C2<F> bq = lds[(M - k) * COLS + c];                    // X[M-k]  (k = 0 pairs with X[M])
+        C2<F> bq = lds[(M - k) * RW + c];                    // X[M-k]  (k = 0 pairs with X[M])
         bq.y = -bq.y;
         const C2<F> s = cadd(a, bq), d = csub(a, bq);
         const C2<F> w = {twn[k].x, -twn[k].y};                 // conj W_N^k
@@ -536,7 +535,7 @@ __global__ __launch_bounds__(M) void rowfft_c2r_kernel(C2<F> *__restrict__ buf, 
         v[j] = C2<F>{s.x - o.y, s.y + o.x};                    // s + i o
     }
     __syncthreads();                                           // everyone has read its partner
-    fft_core<M, R2, R3, R4, +1, COLS>(v, lds, tw, tau, c);
+    fft_core<M, R2, R3, R4, +1, RW>(v, lds, tw, tau, c);
     if (live) {
 #pragma unroll
         for (int j = 0; j < EPT; j++) src[tau + T * j] = v[j];
@@ -597,6 +596,20 @@ static bool narrow_tiles()
 // 0.97 instead of 0.57 ms); capping the 1024-thread kernels at 64 VGPRs so that two fit a CU spills 19 / 36 dwords per
 // lane (force step 4.57 instead of 4.13 ms); fused multiply-adds in the butterflies (-ffp-contract=fast) change
 // nothing measurable.
+// Long columns (N >= 1024 in fp64): 8 columns of N complex doubles are 128 KB of LDS and N threads -- one workgroup per
+// CU, nothing to overlap its load / transform / store phases with.  Four columns (64-byte row segments) fit twice:
+// 1024^3 mesh on one GPU (tools/ab_half_tiles.py), plain pass 4.36 -> 3.94 ms, colfft_yback2 8.38 -> 7.77 ms.
+// FPMHIP_HALF_TILES=0/1 forces the choice for an A/B.
+// N = 640 and 800 (92 / 115 KB for 8 columns, also one workgroup per CU) were tried with 4 columns on the 2- and 4-GPU
+// workloads: plain pass 1.27 -> 1.22 ms, colfft_yback2 1.27 -> 1.46 and 1.45 -> 1.59 ms -- their radix-5 stages leave
+// threads idle in a 4-column workgroup; the threshold stays at 1024.
+constexpr int HALF_TILES_FROM = 1024;
+template <typename F> static bool half_tiles(int N)
+{
+    static const int v = getenv("FPMHIP_HALF_TILES") ? atoi(getenv("FPMHIP_HALF_TILES")) : -1;
+    return v < 0 ? (sizeof(F) == 8 && N >= HALF_TILES_FROM) : (v != 0 && N >= HALF_TILES_FROM);
+}
+
 bool colfft_supported(int N)
 {
     static const int ok[] = {16, 32, 48, 64, 80, 96, 128, 160, 192, 256, 320, 384, 400, 512, 640, 768, 800, 1024};
@@ -614,7 +627,8 @@ static int colfft_launch(fpmhip_plan *p, int dir, const void *in, void *out, con
     // workgroup still fits 1024 threads)
     constexpr int CW = (sizeof(F) == 4) ? 16 : 8;
     const bool wide = sizeof(F) == 4 && N <= 512 && !narrow_tiles();
-    const int cw = wide ? CW : 8;
+    const bool half = !wide && half_tiles<F>(N);
+    const int cw = wide ? CW : (half ? 4 : 8);
     const int tpb = (ncols + cw - 1) / cw;
     const int ntiles = tpb * nbatch;
     const size_t lds = (size_t) N * cw * sizeof(C2<F>) + (size_t) N * sizeof(C2<F>);
@@ -630,7 +644,8 @@ static int colfft_launch(fpmhip_plan *p, int dir, const void *in, void *out, con
             (const C2<F> *) in, (C2<F> *) out, im, om, ncols, tpb, ntiles, p->d_twiddle, (F) scale);           \
     }
 #define CALL_PLAIN(n, r2, r3, r4)                                                                              \
-    if (wide) { CALL_PLAIN_W(n, r2, r3, r4, (n <= 512 ? CW : 8)) } else { CALL_PLAIN_W(n, r2, r3, r4, 8) }
+    if (wide) { CALL_PLAIN_W(n, r2, r3, r4, (n <= 512 ? CW : 8)) }                                              \
+    else if (half) { CALL_PLAIN_W(n, r2, r3, r4, (n >= HALF_TILES_FROM ? 4 : 8)) } else { CALL_PLAIN_W(n, r2, r3, r4, 8) }
     COLFFT_DISPATCH(N, CALL_PLAIN)
 #undef CALL_PLAIN
 #undef CALL_PLAIN_W
@@ -679,7 +694,8 @@ static int yback2_launch(fpmhip_plan *p, const void *in, void *oy, void *oz, voi
     const int N = p->mg.N;
     constexpr int CW = (sizeof(F) == 4) ? 16 : 8;
     const bool wide = sizeof(F) == 4 && N <= 512 && !narrow_tiles();
-    const int cw = wide ? CW : 8;
+    const bool half = !wide && half_tiles<F>(N);
+    const int cw = wide ? CW : (half ? 4 : 8);
     const int tpb = (ncols + cw - 1) / cw;
     const int ntiles = tpb * nbatch;
     const size_t lds = (size_t) N * cw * sizeof(C2<F>) + (size_t) N * sizeof(C2<F>);
@@ -689,7 +705,8 @@ static int yback2_launch(fpmhip_plan *p, const void *in, void *oy, void *oz, voi
     colfft_yback2_kernel<n, r2, r3, r4, W, F><<<ntiles, n / 8 * W, lds, p->stream>>>(                        \
         (const C2<F> *) in, (C2<F> *) oy, (C2<F> *) oz, (C2<F> *) op, im, om, ncols, tpb, ntiles, kt, p->d_twiddle);
 #define CALL_Y2(n, r2, r3, r4)                                                                               \
-    if (wide) { CALL_Y2_W(n, r2, r3, r4, (n <= 512 ? CW : 8)) } else { CALL_Y2_W(n, r2, r3, r4, 8) }
+    if (wide) { CALL_Y2_W(n, r2, r3, r4, (n <= 512 ? CW : 8)) }                                              \
+    else if (half) { CALL_Y2_W(n, r2, r3, r4, (n >= HALF_TILES_FROM ? 4 : 8)) } else { CALL_Y2_W(n, r2, r3, r4, 8) }
     COLFFT_DISPATCH(N, CALL_Y2)
 #undef CALL_Y2
 #undef CALL_Y2_W
@@ -721,6 +738,10 @@ int colfft_yback2_range(fpmhip_plan *p, const void *in, void *oy, void *oz, void
                   : yback2_launch<float>(p, inp, oyp, ozp, opp, im, natural, nx, g.nzc, gradorder);
 }
 
+// Rows per workgroup of the z passes: 8, or 4 when 8 rows of M complex doubles (+ two twiddle tables) are more than
+// half of a CU's LDS (M >= 512, i.e. N >= 1024 in fp64: 82 KB -> one workgroup per CU; 4 rows are 49 KB -> three).
+template <typename F> constexpr int row_width(int M) { return sizeof(F) == 8 && M >= 512 ? 4 : 8; }
+
 template <typename F>
 static int rowfft_launch(fpmhip_plan *p, const void *in_, void *out_, int x0, int nx)
 {
@@ -731,12 +752,16 @@ static int rowfft_launch(fpmhip_plan *p, const void *in_, void *out_, int x0, in
     const size_t off = (size_t) x0 * g.N * g.nzc * sizeof(C2<F>);
     const void *in = (const char *) in_ + off;
     void *out = (char *) out_ + off;
-    const int nblocks = (nrows + COLS - 1) / COLS;
-    const size_t lds = (size_t) M * COLS * sizeof(C2<F>) + 2 * (size_t) M * sizeof(C2<F>);
+    const int rw = row_width<F>(M);
+    const int nblocks = (nrows + rw - 1) / rw;
+    const size_t lds = (size_t) M * rw * sizeof(C2<F>) + 2 * (size_t) M * sizeof(C2<F>);
 #define CALL_ROW(n, r2, r3, r4)                                                                         \
-    FPM_TRY(set_lds(rowfft_r2c_kernel<n, r2, r3, r4, F>, lds));                                         \
-    rowfft_r2c_kernel<n, r2, r3, r4, F><<<nblocks, n, lds, p->stream>>>((const C2<F> *) in, (C2<F> *) out, \
-                                                                        (long long) g.nzc, nrows, p->d_twiddle);
+    {                                                                                                   \
+        constexpr int RW_ = row_width<F>(n);                                                            \
+        FPM_TRY(set_lds(rowfft_r2c_kernel<n, r2, r3, r4, RW_, F>, lds));                                \
+        rowfft_r2c_kernel<n, r2, r3, r4, RW_, F><<<nblocks, n / 8 * RW_, lds, p->stream>>>(             \
+            (const C2<F> *) in, (C2<F> *) out, (long long) g.nzc, nrows, p->d_twiddle);                 \
+    }
     COLFFT_DISPATCH(M, CALL_ROW)
 #undef CALL_ROW
     FPM_CHECK_HIP(hipGetLastError());
@@ -761,12 +786,16 @@ static int rowfft_c2r_launch(fpmhip_plan *p, void *buf_, int x0, int nx)
     const int M = g.N / 2;
     const int nrows = nx * g.N;
     void *buf = (char *) buf_ + (size_t) x0 * g.N * g.nzc * sizeof(C2<F>);
-    const int nblocks = (nrows + COLS - 1) / COLS;
-    const size_t lds = (size_t) (M + 1) * COLS * sizeof(C2<F>) + 2 * (size_t) M * sizeof(C2<F>);
+    const int rw = row_width<F>(M);
+    const int nblocks = (nrows + rw - 1) / rw;
+    const size_t lds = (size_t) (M + 1) * rw * sizeof(C2<F>) + 2 * (size_t) M * sizeof(C2<F>);
 #define CALL_ROWB(n, r2, r3, r4)                                                                         \
-    FPM_TRY(set_lds(rowfft_c2r_kernel<n, r2, r3, r4, F>, lds));                                          \
-    rowfft_c2r_kernel<n, r2, r3, r4, F><<<nblocks, n, lds, p->stream>>>((C2<F> *) buf, (long long) g.nzc, nrows, \
-                                                                        p->d_twiddle);
+    {                                                                                                    \
+        constexpr int RW_ = row_width<F>(n);                                                             \
+        FPM_TRY(set_lds(rowfft_c2r_kernel<n, r2, r3, r4, RW_, F>, lds));                                 \
+        rowfft_c2r_kernel<n, r2, r3, r4, RW_, F><<<nblocks, n / 8 * RW_, lds, p->stream>>>(              \
+            (C2<F> *) buf, (long long) g.nzc, nrows, p->d_twiddle);                                      \
+    }
     COLFFT_DISPATCH(M, CALL_ROWB)
 #undef CALL_ROWB
     FPM_CHECK_HIP(hipGetLastError());
@@ -788,6 +817,9 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
     const long long plane = (long long) g.yl * g.nzc;
     constexpr int CW = (sizeof(F) == 4) ? 16 : 8;
     const bool wide = sizeof(F) == 4 && N <= 512 && !narrow_tiles();
+    // no 4-column form here: with three transforms per column load the kernel is not waiting on memory the way the
+    // plain and two-transform passes are (N = 1024: 10.05 ms with 4 columns against 9.85 ms with 8)
+    const bool half = false;
     const int cw = wide ? CW : 8;
     const int ntiles = (int) ((plane + cw - 1) / cw);
     const size_t lds = (size_t) N * cw * sizeof(C2<F>) + (size_t) N * sizeof(C2<F>);
@@ -805,7 +837,8 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
     if (mode == 1) { CALL_X3_P(n, r2, r3, r4, W, 1) } else if (mode == 2) { CALL_X3_P(n, r2, r3, r4, W, 2) }   \
     else { CALL_X3_P(n, r2, r3, r4, W, 0) }
 #define CALL_X3(n, r2, r3, r4)                                                                               \
-    if (wide) { CALL_X3_W(n, r2, r3, r4, (n <= 512 ? CW : 8)) } else { CALL_X3_W(n, r2, r3, r4, 8) }
+    if (wide) { CALL_X3_W(n, r2, r3, r4, (n <= 512 ? CW : 8)) }                                              \
+    else if (half) { CALL_X3_W(n, r2, r3, r4, (n >= HALF_TILES_FROM ? 4 : 8)) } else { CALL_X3_W(n, r2, r3, r4, 8) }
     COLFFT_DISPATCH(N, CALL_X3)
 #undef CALL_X3
 #undef CALL_X3_W
