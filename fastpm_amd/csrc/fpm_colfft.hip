@@ -117,6 +117,11 @@ template <int R, int S, typename F> __device__ __forceinline__ void dftR(C2<F> *
 }
 
 constexpr int EPT = 8;    // elements per thread at load / store time
+// Waves per SIMD the fused kernels are compiled for (the VGPR budget is 512 / that).  4 everywhere (two 512-thread
+// workgroups per CU at N = 512) except for workgroups of 9 .. 12 waves (N = 640 with 8 columns): their 92 KB of LDS
+// allow one workgroup per CU, i.e. at most 3 waves on a SIMD, and with 128 VGPRs the radix-5 stages spilled 44 - 52
+// bytes per lane.
+constexpr int fused_min_waves(int threads) { return threads > 512 && threads <= 768 ? 3 : 4; }
 constexpr int VMAX = 10;  // register slots: a radix-3 / radix-5 stage touches up to 2*5 (or 3*3) values
 
 // One Cooley-Tukey stage of radix R on this thread's values.
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(N / 8 * CW) void colfft_kernel(const C2<F> *__restr
 //   kernel first runs the forward x pass (x fwd_scale, as colfft_kernel would), stores delta_k over its input
 //   and carries on from registers -- delta_k is written once and never re-read (one mesh sweep less).
 template <int N, int R2, int R3, int R4, int CW, int MODE, bool FWD, typename F>
-__global__ __launch_bounds__(N / 8 * CW, 4) void colfft_xback3_kernel(const C2<F> *dk, C2<F> *__restrict__ o0,
+__global__ __launch_bounds__(N / 8 * CW, fused_min_waves(N / 8 * CW)) void colfft_xback3_kernel(const C2<F> *dk, C2<F> *__restrict__ o0,
                                                              C2<F> *__restrict__ o1, C2<F> *__restrict__ o2,
                                                              long long rstride, int ncols, int nzc, int ystart,
                                                              int ntiles, const float *__restrict__ kk,
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(N / 8 * CW, 4) void colfft_xback3_kernel(const C2<F
 // the potential, two writes; the same factors (the float32 k_finite table) as transfer_kernel, applied
 // after the x transform instead of before it -- they do not depend on kx.  Rows = ky, columns = kz.
 template <int N, int R2, int R3, int R4, int CW, typename F>
-__global__ __launch_bounds__(N / 8 * CW, 4) void colfft_yback2_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ oy,
+__global__ __launch_bounds__(N / 8 * CW, fused_min_waves(N / 8 * CW)) void colfft_yback2_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ oy,
                                                              C2<F> *__restrict__ oz, C2<F> *__restrict__ op,
                                                              ColMap im, ColMap om,
                                                              int ncols, int ntiles_per_batch, int ntiles,
