@@ -144,3 +144,21 @@ def test_config2_mesh_on_one_gpu_properties():
     assert torch.equal(sub, sub2) or float((sub - sub2).abs().max()) < 1e-9
     del c, dk
     pm.destroy()
+
+
+def test_hand_written_fft_passes_agree_with_rocfft_at_the_multi_gpu_mesh_sizes():
+    """tools/check_fft_backends.py: the force through the hand-written row / column passes against the rocFFT back
+    end (fft_mode = 1) on the meshes of the 2-, 4- and 8-GPU workloads -- sizes with their own launch shapes (4-row /
+    4-column workgroups at 1024, 168-VGPR budget at 640, radix-5 plans at 800).  fp64: float32 last-bit flips of acc."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_fft_backends.py"), "640", "800", "1024"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert lines[-1] == "ok", r.stdout
+    for l in lines[:-1]:
+        err = float(l.split("=")[-1])
+        assert err < (2e-7 if "fp64" in l else 1e-4), l
