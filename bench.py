@@ -329,6 +329,13 @@ def main():
             alt = {"gradient": "real" if args.gradient == "kspace" else "kspace", "error": repr(e)}
 
     acc_ok = bool(torch.isfinite(store.acc).all().item())
+    # a size-independent property of the force at full scale, any N: equal-mass particles on a periodic mesh exert no
+    # net force on themselves -- |sum acc| / sum |acc| is round-off (float32 acc: ~1e-7), whatever the decomposition
+    mom = torch.cat([store.acc.double().sum(0), store.acc.double().abs().sum().reshape(1)])     # sum_x, _y, _z, sum |.|
+    if world > 1:
+        mom = mom if backend == "nccl" else mom.cpu()
+        dist.all_reduce(mom, op=dist.ReduceOp.SUM)
+    momentum_residual = float(mom[:3].abs().max() / mom[3])
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -371,7 +378,7 @@ def main():
                              "real": "real space, 1 inverse FFT + stencil readout (FPMHIP_GRADIENT_REAL)"}[args.gradient],
                 "paint_mode": "tiled" if args.paint_mode == 0 else "atomic",
                 "fft": "hand-written row + column passes" if pm.column_fft() else "rocFFT"},
-            "per_gpu": value / world, "finite": acc_ok,
+            "per_gpu": value / world, "finite": acc_ok, "momentum_residual": momentum_residual,
             # rank 0: time inside this library's kernels vs the rest of the step (for N > 1 the rest is
             # the RCCL all-to-alls / halo shifts that are not hidden behind compute)
             "kernel_ms_per_step": round(sum(tm[n][0] for n in ("sort", "paint", "r2c", "dealias", "transfer", "c2r",

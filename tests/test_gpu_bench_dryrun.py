@@ -25,6 +25,7 @@ def test_multi_rank_bench_path(nranks, port, alt):
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == nranks and d["finite"] and d["scaling"] == "weak" and d["config"]["particles"] == 64 ** 3
+    assert d["momentum_residual"] < 1e-6
     assert d["value"] > 0 and d["roofline"]["bound"] == "hbm"
     if alt:
         assert d["other_gradient_mode"]["acc_max_abs_dev_over_max_abs_acc"] < 2e-7
