@@ -8,7 +8,7 @@ for i in $(seq $REP); do
     cp /tmp/ab_$v.so fastpm_amd/libfastpm_hip.so
     python bench.py $ARGS --no-cpu-baseline --no-alt --steps 20 2>/dev/null > /tmp/ab_o.json
     python -c "
-import json; d=json.loads(open('/tmp/ab_o.json').read()); print('$v', '$ARGS', round(d['ms_per_step'],3), 'readout', d['stages']['readout']['avg_ms'], 'paint', d['stages']['paint']['avg_ms'], 'sort', d['stages']['sort']['avg_ms'])"
+import json; d=json.loads(open('/tmp/ab_o.json').read()); print('$v', '$ARGS', round(d['ms_per_step'],3), {k: v['avg_ms'] for k, v in d['stages'].items()})"
   done
 done
 cp /tmp/ab_A.so fastpm_amd/libfastpm_hip.so
