@@ -599,8 +599,10 @@ static bool narrow_tiles()
 // and overlaps them).  Tried, measured, not kept: 8-column workgroups fit twice but move 64-byte row segments
 // (0.81 ms); 16 elements per thread (512 threads x 16 columns) needs > 128 VGPRs and spills (xback3 0.80, yback2
 // 0.97 instead of 0.57 ms); capping the 1024-thread kernels at 64 VGPRs so that two fit a CU spills 19 / 36 dwords per
-// lane (force step 4.57 instead of 4.13 ms); fused multiply-adds in the butterflies (-ffp-contract=fast) change
-// nothing measurable.
+// lane (force step 4.57 instead of 4.13 ms); 512-thread workgroups that take their 16 columns as two sets of 8 one
+// after the other (inputs re-read through L2, first set's results parked in LDS, joint 128-byte stores; 83 VGPRs,
+// two per CU) ran colfft_yback2 in 0.67 instead of 0.59 ms; fused multiply-adds in the butterflies
+// (-ffp-contract=fast) change nothing measurable.
 // Long columns (N >= 1024 in fp64): 8 columns of N complex doubles are 128 KB of LDS and N threads -- one workgroup per
 // CU, nothing to overlap its load / transform / store phases with.  Four columns (64-byte row segments) fit twice:
 // 1024^3 mesh on one GPU (tools/ab_half_tiles.py), plain pass 4.36 -> 3.94 ms, colfft_yback2 8.38 -> 7.77 ms.
