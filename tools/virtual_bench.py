@@ -42,9 +42,9 @@ def main():
         rms = float(acc.pow(2).mean().sqrt())
         mom = float(acc.sum(0).abs().max()) / (rms * len(acc) ** 0.5)
         per_rank = sum(ms for name, (ms, n) in tm.items() if not name.startswith("k_"))     # k_* are nested timers
-        print("P=%d nc=%d N=%d: staged_fft(own)=%s finite=%s momentum=%.2e | rank-0 compute %.2f ms/step "
+        print("P=%d nc=%d N=%d: column_fft=%s finite=%s momentum=%.2e | rank-0 compute %.2f ms/step "
               "(all %d ranks serialised incl. copies: %.1f ms) | %s" % (
-                  P, nc, N, pms[0].staged_fft() and (N & (N - 1)) == 0, bool(torch.isfinite(acc).all()), mom, per_rank, P,
+                  P, nc, N, pms[0].column_fft(), bool(torch.isfinite(acc).all()), mom, per_rank, P,
                   dt * 1e3, {k: round(v[0], 2) for k, v in tm.items() if v[1]}), flush=True)
         for pm in pms:
             pm.destroy()
