@@ -244,7 +244,10 @@ __device__ __forceinline__ void stage_twiddles(C2<F> *tw, const double *tw_globa
 // Plain pass: out = scale * FFT_S(in) along the row axis, for `nbatch` planes of `ncols` columns.
 // One tile per workgroup (61 VGPRs, 2 workgroups/CU at N = 512): measured 0.47 ms per 2.16 GB
 // pass = the speed of a contiguous device copy of the same bytes (tools/ubench/wr_pattern.hip).
-// A persistent variant with register prefetch of the next tile needed 178 VGPRs and ran slower.
+// A persistent variant with register prefetch of the next tile needed 178 VGPRs and ran slower.  Exchanging the real
+// and the imaginary parts one after the other (half the LDS: four workgroups per CU instead of two at N = 512, two
+// instead of one at N = 1024 with 8 columns) changed nothing either (0.459 vs 0.462 ms; 4.07 vs 3.95 ms at 1024):
+// what holds the strided passes at 4.7 TB/s is not occupancy.
 template <int N, int R2, int R3, int R4, int S, int CW, typename F>
 __global__ __launch_bounds__(N / 8 * CW) void colfft_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ out,
                                                    ColMap im, ColMap om, int ncols, int ntiles_per_batch,
