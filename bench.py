@@ -17,8 +17,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# the host driver of this image only supports dmabuf IPC: without this RCCL's buffer sharing between the ranks of a node
+# fails with "hipIpcGetMemHandle: invalid argument" (already exported on the GPU boxes; set before the HIP runtime starts)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -17,7 +17,9 @@ import argparse
 import os
 import sys
 
-import numpy as np
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL between the ranks of a node
+
+import numpy as np  # noqa: E402
 from scipy.integrate import quad, solve_ivp
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
