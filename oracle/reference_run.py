@@ -199,7 +199,7 @@ class PowerTable:
             return np.sqrt(quad(integrand, 0, 500.0 / R, limit=20000, epsrel=1e-8)[0])
 
 
-def initial_delta_k_xyk(N, BoxSize, seed, power, F=np.float64):
+def initial_delta_k_xyk(N, BoxSize, seed, power, F=np.float64, remove_variance=True):
     """src/fastpm.c:476-523 for lightcone.lua: fastpm_ic_fill_gaussiank (gadget scheme) ->
     fastpm_ic_remove_variance (initialcondition.c:66-98) -> fastpm_ic_induce_correlation (:55-64, transfer.c:
     188-210).  Returns complex [x][y][kz] in the mesh dtype's complex type, and the white-noise variance
@@ -208,11 +208,14 @@ def initial_delta_k_xyk(N, BoxSize, seed, power, F=np.float64):
     g = np.zeros((N, N, N // 2 + 1, 2))
     O.lib().orc_fill_gaussian_gadget(int(N), int(seed), O._p(g))
     wk = (g[..., 0].astype(F) + 1j * g[..., 1].astype(F)).astype(C)     # stored as FastPMFloat
-    a, b = wk.real.astype(np.float64), wk.imag.astype(np.float64)
-    phase = np.arctan2(b, a)
-    un = np.cos(phase) + 1j * np.sin(phase)
-    un[(a == 0) & (b == 0)] = 0
-    un = (un.real.astype(F) + 1j * un.imag.astype(F)).astype(C)
+    if remove_variance:                                                  # src/fastpm.c:479-482, lua default false
+        a, b = wk.real.astype(np.float64), wk.imag.astype(np.float64)
+        phase = np.arctan2(b, a)
+        un = np.cos(phase) + 1j * np.sin(phase)
+        un[(a == 0) & (b == 0)] = 0
+        un = (un.real.astype(F) + 1j * un.imag.astype(F)).astype(C)
+    else:
+        un = wk
     kk1 = O.k_tables(N, BoxSize)["kk"].astype(np.float64)
     kk = kk1[:, None, None] + kk1[None, :, None] + kk1[None, None, : N // 2 + 1]
     tr = np.sqrt(power(np.sqrt(kk))) * np.sqrt(1.0 / BoxSize ** 3)
@@ -300,21 +303,24 @@ class OracleOps:
 
 
 def run_lightcone_test(ops, N=64, BoxSize=512.0, seed=100, Omega_m=0.307494, time_step=None, F=np.float64,
-                       nsteps=None, growth_mode="LCDM"):
-    """tests/lightcone.lua up to the quantities the .check file pins.  Returns a dict of log values."""
+                       nsteps=None, growth_mode="LCDM", lpt_ops=None, remove_variance=True):
+    """tests/lightcone.lua up to the quantities the .check file pins.  Returns a dict of log values.
+    N = nc (particles per side = the 2LPT mesh, lpt_nc_factor = 1); `ops` executes the force-side operators on ITS
+    mesh (nc * pm_nc_factor), `lpt_ops` (default: ops) the initial field and 2LPT on the nc mesh."""
     time_step = np.linspace(0.1, 1.0, 8) if time_step is None else np.asarray(time_step)
+    lpt_ops = ops if lpt_ops is None else lpt_ops
     if nsteps is not None:
         time_step = time_step[: nsteps + 1]
     c = Cosmology(Omega_m, growth_mode)
     power = PowerTable()
     log = {"sigma8_input": power.sigma(8.0)}
-    if hasattr(ops, "initial_delta_k"):                                 # the operator under test makes the field
-        dk = ops.initial_delta_k(seed, power.k, power.f)                # itself (src/fastpm.c:476-523)
-    else:
-        dk = initial_delta_k_xyk(N, BoxSize, seed, power, F)
+    if hasattr(lpt_ops, "initial_delta_k"):                             # the operator under test makes the field
+        dk = lpt_ops.initial_delta_k(seed, power.k, power.f, **({} if remove_variance else {"remove_variance": False}))
+    else:                                                               # itself (src/fastpm.c:476-523)
+        dk = initial_delta_k_xyk(N, BoxSize, seed, power, F, remove_variance)
     g = np.arange(N) * (BoxSize / N)                                     # store.c:659-712, shift = 0
     q = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
-    dx1, dx2 = ops.lpt(dk, q)
+    dx1, dx2 = lpt_ops.lpt(dk, q)
     log["dx1"], log["dx2"] = column_std(dx1), column_std(dx2)
     a0 = float(time_step[0])
     gi = c.growth(a0)                                                    # pm2lpt.c:168-210
@@ -322,11 +328,13 @@ def run_lightcone_test(ops, N=64, BoxSize=512.0, seed=100, Omega_m=0.307494, tim
     Dv2 = gi["D2"] * a0 * a0 * c.E(a0) * gi["f2"]
     x, v = O.pm_2lpt_evolve(q, np.zeros((len(q), 3), dtype=np.float32), dx1, dx2, gi["D1"], gi["D2"], Dv1, Dv2)
     k0 = 2 * np.pi / BoxSize
-    log["plin"], log["sigma8_measured"] = [], []
+    log["plin"], log["sigma8_measured"], log["vstd"] = [], [], []
+    a_v = a0
 
     def force(a):
         nonlocal x
         x = ops.wrap(x)                                                  # fastpm_decompose: store_wrap, solver.c:577
+        log["vstd"].append((a_v, column_std(v)))                         # report_domain, src/fastpm.c:1696-1704
         acc, (k, p, nm) = ops.force(x)
         D1 = c.growth(a)["D1"]
         log["plin"].append((a, large_scale_power(k, p, nm, 4, k0) / D1 ** 2))     # src/fastpm.c:1736-1746
@@ -344,10 +352,27 @@ def run_lightcone_test(ops, N=64, BoxSize=512.0, seed=100, Omega_m=0.307494, tim
         x = ops.drift(lookup(t, ai, ac, ac) - lookup(t, ai, ac, ai), x, v)
         t = drift_tables(c, ac, ac, af)
         x = ops.drift(lookup(t, ac, af, af) - lookup(t, ac, af, ac), x, v)
+        a_v = ac
         acc = force(af)
         t = kick_tables(c, ac, af, af)
         v = ops.kick(lookup(t, ac, af, af) - lookup(t, ac, af, ac), acc, v)
     return log
+
+
+# tests/run-test-restart.sh:12-13: the two log lines tests/restart.lua must print (nc = 128, boxsize = 384,
+# pm_nc_factor = 2 -> 256^3 force mesh, lpt_nc_factor = 1, seed 100, time_step {0.1, 0.5, 0.75, 1}, force_mode
+# "fastpm", kernel 1_4, growth_mode left at the lua default "ODE", remove_cosmic_variance left at false)
+CHECK_RESTART = {
+    "vstd": [("0.6124", ("1.63807", "1.75754", "1.94999")), ("0.8660", ("2.44703", "2.62561", "2.90857"))],
+}
+
+
+def run_restart_test(force_ops, lpt_ops, F=np.float64, nsteps=None):
+    """tests/restart.lua up to the 'Velocity dispersion (a = ...)' lines report_domain prints before the forces at
+    a = 0.75 and a = 1 (src/fastpm.c:1696-1704): the std of the velocity column after the kicks that used the
+    accelerations from the 256^3 mesh at a = 0.1, 0.5 (first line) and 0.75 (second line)."""
+    return run_lightcone_test(force_ops, N=128, BoxSize=384.0, seed=100, time_step=[0.1, 0.5, 0.75, 1.0], F=F,
+                              nsteps=nsteps, growth_mode="ODE", lpt_ops=lpt_ops, remove_variance=False)
 
 
 def matches(value, text):

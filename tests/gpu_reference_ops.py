@@ -69,12 +69,13 @@ class GpuIcOps(GpuOps):
     """GpuOps whose initial field, too, is made by the library from the seed (src/fastpm.c:476-523:
     fastpm_ic_fill_gaussiank -> fastpm_ic_remove_variance -> fastpm_ic_induce_correlation)."""
 
-    def initial_delta_k(self, seed, k, p):
+    def initial_delta_k(self, seed, k, p, remove_variance=True):
         from fastpm_amd import fastpm_ic_fill_gaussiank, fastpm_ic_induce_correlation, fastpm_ic_remove_variance
         pm = self.pm
         dk = pm.alloc()
         fastpm_ic_fill_gaussiank(pm, dk, seed)
-        fastpm_ic_remove_variance(pm, dk)
+        if remove_variance:
+            fastpm_ic_remove_variance(pm, dk)
         fastpm_ic_induce_correlation(pm, dk, k, p)
         return dk
 

@@ -55,3 +55,31 @@ def test_gpu_slabs_reproduce_the_reference_check_file(P, gradient_mode):
     _check(R.run_lightcone_test(ops))
     for pm in ops.pms:
         pm.destroy()
+
+
+def _check_restart(log):
+    got = {("%06.4f" % a): s for a, s in log["vstd"]}
+    for atext, stext in R.CHECK_RESTART["vstd"]:
+        for d in range(3):
+            assert R.matches(got[atext][d], stext[d]), (atext, got[atext], stext)
+
+
+@pytest.mark.parametrize("precision,gradient_mode", [(64, 0), (32, 0), (64, 1)])
+def test_gpu_reproduces_the_restart_check_lines_at_b2(precision, gradient_mode):
+    """tests/run-test-restart.sh:12-13 (restart.lua: 128^3 particles, pm_nc_factor = 2 -> 256^3 force mesh, seed 100):
+    the velocity dispersions after the kicks that applied the B = 2 accelerations, from the seed, every operator on
+    the GPU -- fp64 and fp32 meshes, and the real-space gradient."""
+    force = GpuOps(256, 384.0, precision, gradient_mode)
+    lpt = GpuIcOps(128, 384.0, precision)
+    _check_restart(R.run_restart_test(force, lpt, F=np.float64 if precision == 64 else np.float32))
+    force.pm.destroy()
+    lpt.pm.destroy()
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_gpu_slabs_reproduce_the_restart_check_lines_at_b2(P):
+    force = SlabGpuOps(256, 384.0, P)
+    lpt = SlabGpuOps(128, 384.0, P)
+    _check_restart(R.run_restart_test(force, lpt))
+    for pm in force.pms + lpt.pms:
+        pm.destroy()

@@ -66,6 +66,21 @@ def test_sigma8_of_the_measured_spectra(log):
         assert abs(got / ref - 1) < 3e-4, (got, ref)
 
 
+def test_restart_lua_velocity_dispersions_pin_the_b2_force():
+    """tests/run-test-restart.sh:12-13 -- the reference's SECOND pinned run, at configs[0]'s geometry: restart.lua is
+    128^3 particles, `pm_nc_factor = 2` (256^3 force mesh; the 2LPT runs on the 128^3 mesh), seed 100 without
+    remove_cosmic_variance, kernel 1_4, fastpm factors with the lua default growth_mode "ODE", steps {0.1, 0.5, 0.75,
+    1}.  report_domain (src/fastpm.c:1696-1704) prints the std of the velocity column before every force; the two
+    lines the script greps are the velocities after the kicks that applied the B = 2 accelerations of the forces at
+    a = 0.1, 0.5 and 0.75 -- a direct pin of acc -> v on a mesh finer than the particle grid, which the lightcone
+    check (pm_nc_factor = 1) cannot give.  Must print exactly as the reference printed it."""
+    log = R.run_restart_test(R.OracleOps(256, 384.0, 64), R.OracleOps(128, 384.0, 64))
+    got = {("%06.4f" % a): s for a, s in log["vstd"]}
+    for atext, stext in R.CHECK_RESTART["vstd"]:
+        for d in range(3):
+            assert R.matches(got[atext][d], stext[d]), (atext, got[atext], stext)
+
+
 def test_ranlxd1_stream_is_a_uniform_48_bit_stream():
     import ctypes
     from oracle import pm_oracle as O
