@@ -74,6 +74,8 @@ static int z_forward(fpmhip_plan *p, void *in, void *out)
     return fft_exec(p, p->p_zr2c_op, in, out);
 }
 
+static bool own_zc2r(const fpmhip_plan *p);
+
 int fft_setup(fpmhip_plan *p)
 {
     std::call_once(g_rocfft_once, [] { g_rocfft_status = rocfft_setup(); });
@@ -83,18 +85,22 @@ int fft_setup(fpmhip_plan *p)
     const double inv_norm = 1.0 / p->lay.Norm;
     p->own_fft = p->geom.fft_mode == FPMHIP_FFT_AUTO && colfft_supported(g.N);
     if (p->own_fft) {
-        // rocFFT only transforms the contiguous z rows: N real <-> N/2+1 complex, batch xl * N
+        // the contiguous z rows N real <-> N/2+1 complex, batch xl * N: the own row kernels (fpm_rowfft.hip) when N/2
+        // is a supported length, else rocFFT's batched 1-D plans
         const size_t len1[1] = {N};
         const size_t one[1] = {1};
-        FPM_TRY(make_plan(&p->p_zr2c_op, rocfft_placement_notinplace, rocfft_transform_type_real_forward, p->f64, 1,
-                          len1, xl * N, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, one,
-                          N + 2, one, nzc, 1.0));
-        FPM_TRY(make_plan(&p->p_zr2c_ip, rocfft_placement_inplace, rocfft_transform_type_real_forward, p->f64, 1,
-                          len1, xl * N, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, one,
-                          N + 2, one, nzc, 1.0));
-        FPM_TRY(make_plan(&p->p_zc2r_ip, rocfft_placement_inplace, rocfft_transform_type_real_inverse, p->f64, 1,
-                          len1, xl * N, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, one,
-                          nzc, one, N + 2, 1.0));
+        if (!rowfft_supported(g.N)) {
+            FPM_TRY(make_plan(&p->p_zr2c_op, rocfft_placement_notinplace, rocfft_transform_type_real_forward, p->f64, 1,
+                              len1, xl * N, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, one,
+                              N + 2, one, nzc, 1.0));
+            FPM_TRY(make_plan(&p->p_zr2c_ip, rocfft_placement_inplace, rocfft_transform_type_real_forward, p->f64, 1,
+                              len1, xl * N, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, one,
+                              N + 2, one, nzc, 1.0));
+        }
+        if (!own_zc2r(p))
+            FPM_TRY(make_plan(&p->p_zc2r_ip, rocfft_placement_inplace, rocfft_transform_type_real_inverse, p->f64, 1,
+                              len1, xl * N, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, one,
+                              nzc, one, N + 2, 1.0));
         {   // plane chunking through the Infinity Cache (FPMHIP_CHUNK_MB = 0 disables)
             const char *e = getenv("FPMHIP_CHUNK_MB");
             const double mb = e ? atof(e) : 0.0;
@@ -103,9 +109,10 @@ int fft_setup(fpmhip_plan *p)
             if (cp >= 1 && cp < (int) xl) {
                 while (xl % cp != 0) cp--;
                 p->chunk_planes = cp;
-                FPM_TRY(make_plan(&p->p_zc2r_chunk, rocfft_placement_inplace, rocfft_transform_type_real_inverse,
-                                  p->f64, 1, len1, (size_t) cp * N, rocfft_array_type_hermitian_interleaved,
-                                  rocfft_array_type_real, one, nzc, one, N + 2, 1.0));
+                if (!own_zc2r(p))
+                    FPM_TRY(make_plan(&p->p_zc2r_chunk, rocfft_placement_inplace, rocfft_transform_type_real_inverse,
+                                      p->f64, 1, len1, (size_t) cp * N, rocfft_array_type_hermitian_interleaved,
+                                      rocfft_array_type_real, one, nzc, one, N + 2, 1.0));
             }
         }
         // twiddles e^{-2 pi i j / N} in double, octant-exact where it matters (j = 0, N/4, N/2, ...)

@@ -1,0 +1,209 @@
+// fpm_rowfft.hip -- the contiguous z passes of the 3-D transforms: real rows of N = 2M values <-> N/2+1 complex
+// values, each ONE kernel with one read and one write of the mesh (rocFFT's batched 1-D r2c takes two kernels,
+// 0.92 ms instead of 0.45 ms at 512^3 fp64; its c2r is 2.5x slower per byte at N = 1024).  Replaces the z leg of
+// PFFT's r2c / c2r (reference libfastpm/pmpfft.c:370-399).  The FFT core is fpm_fftcore.h, used with rows in
+// the role of columns: thread (tau, c) holds elements tau + T*j of row c.
+#include <cstdlib>
+
+#include "fpm_fftcore.h"
+
+namespace fpm {
+
+// Rows per workgroup: 8, or 4 when 8 rows of M complex values (+ two twiddle tables) are more than half of a CU's
+// LDS (fp64: M >= 512, i.e. N >= 1024: 82 KB -> one workgroup per CU; 4 rows are 49 KB -> three) or more than 1024
+// threads (fp32, M = 1536).
+template <typename F> constexpr int row_width(int M) { return sizeof(F) == 8 ? (M >= 512 ? 4 : 8) : (M > 1024 ? 4 : 8); }
+
+template <typename PL, typename F> struct RowCfg {
+    static constexpr int M = PL::N;
+    static constexpr int RW = row_width<F>(M);
+    static constexpr int threads = PL::T * RW;
+    static constexpr size_t twb = (size_t) (PL::TWN + M) * sizeof(C2<F>);         // W_M^j (maybe half), W_N^k (k < M)
+    static constexpr size_t lds = twb + (size_t) (M + 1) * RW * sizeof(C2<F>);
+    static_assert(threads <= 1024, "workgroup too large");
+    static_assert(lds <= 160 * 1024, "LDS budget");
+};
+
+// Forward z pass.  A workgroup takes RW adjacent rows; the row is read as M complex numbers z[n] = x[2n] + i x[2n+1],
+// transformed with the register / LDS FFT core and untangled:
+//   X[k] = E[k] + W_N^k O[k],  E = (Z[k] + conj Z[M-k]) / 2,  O = (Z[k] - conj Z[M-k]) / 2i.
+template <typename PL, typename F>
+__global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_r2c_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ out,
+                                                       long long pitch, int nrows,
+                                                       const double *__restrict__ tw_global)
+{
+    using CF = RowCfg<PL, F>;
+    constexpr int M = PL::N, RW = CF::RW, T = PL::T, E = PL::E;
+    extern __shared__ __align__(16) unsigned char smem[];
+    C2<F> *tw = (C2<F> *) smem;        // W_M^j, j < PL::TWN
+    C2<F> *twn = tw + PL::TWN;         // W_N^k, k < M  (N = 2M)
+    C2<F> *lds = twn + M;
+    const int c = threadIdx.x % RW, tau = threadIdx.x / RW;
+    const long long row = (long long) blockIdx.x * RW + c;
+    const bool live = row < nrows;
+    const C2<F> *src = in + row * pitch;
+    C2<F> v[vmax(E)];
+#pragma unroll
+    for (int j = 0; j < E; j++) v[in_slot<PL>(j)] = live ? src[tau + T * j] : C2<F>{0, 0};
+    stage_twiddles(tw, tw_global, PL::TWN, 2);       // W_M^i = W_N^{2i}
+    stage_twiddles(twn, tw_global, M, 1);
+    __syncthreads();
+    fft_core<PL, -1, RW, false>(v, lds, tw, tau, c);
+    // exchange so that every thread can pair Z[k] with Z[M - k]
+#pragma unroll
+    for (int j = 0; j < E; j++) lds[(tau + T * j) * RW + c] = v[j];
+    __syncthreads();
+    C2<F> *dst = out + row * pitch;
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        const int k = tau + T * j;
+        const C2<F> a = v[j];
+        C2<F> bq = lds[((M - k) % M) * RW + c];
+        bq.y = -bq.y;                                          // conj Z[M-k]
+        const C2<F> e = {(a.x + bq.x) * (F) 0.5, (a.y + bq.y) * (F) 0.5};
+        const C2<F> d = {(a.x - bq.x) * (F) 0.5, (a.y - bq.y) * (F) 0.5};
+        const C2<F> o = {d.y, -d.x};                           // d / i
+        const C2<F> x = cadd(e, cmul(twn[k], o));
+        if (live) {
+            dst[k] = x;
+            if (k == 0) dst[M] = C2<F>{a.x - a.y, 0};          // X[N/2] = Re Z0 - Im Z0
+        }
+    }
+}
+
+// Backward z pass: N/2+1 complex values -> N = 2M real values, unnormalised (the c2r convention of FFTW / rocFFT), in
+// place row by row.  The inverse of rowfft_r2c_kernel: with X the half spectrum of a real row,
+//   Z'[k] = (X[k] + conj X[M-k]) + i conj(W_N^k) (X[k] - conj X[M-k]),   z' = IFFT_M(Z') (unnormalised),
+// and the row is z'[n] = x[2n] + i x[2n+1].
+template <typename PL, typename F>
+__global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_c2r_kernel(C2<F> *__restrict__ buf, long long pitch, int nrows,
+                                                       const double *__restrict__ tw_global)
+{
+    using CF = RowCfg<PL, F>;
+    constexpr int M = PL::N, RW = CF::RW, T = PL::T, E = PL::E;
+    extern __shared__ __align__(16) unsigned char smem[];
+    C2<F> *tw = (C2<F> *) smem;
+    C2<F> *twn = tw + PL::TWN;
+    C2<F> *lds = twn + M;                      // (M + 1) * RW: the half spectrum, then the FFT exchange area
+    const int c = threadIdx.x % RW, tau = threadIdx.x / RW;
+    const long long row = (long long) blockIdx.x * RW + c;
+    const bool live = row < nrows;
+    C2<F> *src = buf + row * pitch;
+    C2<F> x[E];
+#pragma unroll
+    for (int j = 0; j < E; j++) x[j] = live ? src[tau + T * j] : C2<F>{0, 0};
+    C2<F> xm = (live && tau == 0) ? src[M] : C2<F>{0, 0};
+    // a c2r transform reads only the real parts of X[0] and X[N/2] (FFTW, pocketfft and rocFFT all do): with the
+    // exact i k gradient (3_2, EASTWOOD, NAIVE) the Nyquist entry of a row does carry an imaginary part
+    if (tau == 0) { x[0].y = 0; xm.y = 0; }
+    stage_twiddles(tw, tw_global, PL::TWN, 2);
+    stage_twiddles(twn, tw_global, M, 1);
+#pragma unroll
+    for (int j = 0; j < E; j++) lds[(tau + T * j) * RW + c] = x[j];
+    if (tau == 0) lds[M * RW + c] = xm;
+    __syncthreads();
+    C2<F> v[vmax(E)];
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        const int k = tau + T * j;
+        const C2<F> a = x[j];
+        C2<F> bq = lds[(M - k) * RW + c];                    // X[M-k]  (k = 0 pairs with X[M])
+        bq.y = -bq.y;
+        const C2<F> s = cadd(a, bq), d = csub(a, bq);
+        const C2<F> w = {twn[k].x, -twn[k].y};                 // conj W_N^k
+        const C2<F> o = cmul(w, d);
+        v[in_slot<PL>(j)] = C2<F>{s.x - o.y, s.y + o.x};       // s + i o
+    }
+    __syncthreads();                                           // everyone has read its partner
+    fft_core<PL, +1, RW, false>(v, lds, tw, tau, c);
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < E; j++) src[tau + T * j] = v[j];
+    }
+}
+
+template <typename K> static int set_lds(K kernel, size_t bytes)
+{
+    static size_t granted = 64 * 1024;   // one per kernel instantiation
+    if (bytes > granted) {
+        FPM_CHECK_HIP(hipFuncSetAttribute((const void *) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+        granted = bytes;
+    }
+    return 0;
+}
+
+#define FPM_CASE(n, BODY) case n: { using PL = typename Fac<n, 0>::type; BODY(PL) } break;
+#define ROWFFT_DISPATCH(M_, BODY)                                                                                   \
+    switch (M_) {                                                                                                   \
+        FPM_CASE(16, BODY) FPM_CASE(32, BODY) FPM_CASE(48, BODY) FPM_CASE(64, BODY) FPM_CASE(80, BODY)              \
+        FPM_CASE(96, BODY) FPM_CASE(128, BODY) FPM_CASE(160, BODY) FPM_CASE(192, BODY) FPM_CASE(256, BODY)          \
+        FPM_CASE(320, BODY) FPM_CASE(384, BODY) FPM_CASE(400, BODY) FPM_CASE(512, BODY) FPM_CASE(640, BODY)         \
+        FPM_CASE(768, BODY) FPM_CASE(800, BODY) FPM_CASE(1024, BODY) FPM_CASE(1536, BODY)                           \
+    default: FPM_FAIL(-1, "row FFT: unsupported length %d", 2 * (int) (M_));                                        \
+    }
+
+// z pass forward (r2c) on [x_loc][y][N+2] real rows -> [x_loc][y][N/2+1]; in place or out of place
+bool rowfft_supported(int N)
+{
+    static const int ok[] = {16, 32, 48, 64, 80, 96, 128, 160, 192, 256, 320, 384, 400, 512, 640, 768, 800, 1024, 1536};
+    if (N < 32 || N % 2 != 0) return false;
+    for (int m : ok) if (m == N / 2) return true;
+    return false;
+}
+
+template <typename F>
+static int rowfft_launch(fpmhip_plan *p, const void *in_, void *out_, int x0, int nx)
+{
+    StageTimer ktm(p, FPMHIP_T_K_ROWFFT);
+    const MeshGeo &g = p->mg;
+    const long long nrows = (long long) nx * g.N;
+    const size_t off = (size_t) x0 * g.N * g.nzc * sizeof(C2<F>);
+    const void *in = (const char *) in_ + off;
+    void *out = (char *) out_ + off;
+#define CALL_ROW(PL)                                                                                    \
+    {                                                                                                   \
+        using CF = RowCfg<PL, F>;                                                                       \
+        FPM_TRY(set_lds(rowfft_r2c_kernel<PL, F>, CF::lds));                                            \
+        rowfft_r2c_kernel<PL, F><<<(unsigned) ((nrows + CF::RW - 1) / CF::RW), CF::threads, CF::lds, p->stream>>>( \
+            (const C2<F> *) in, (C2<F> *) out, (long long) g.nzc, (int) nrows, p->d_twiddle);           \
+    }
+    ROWFFT_DISPATCH(g.N / 2, CALL_ROW)
+#undef CALL_ROW
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int rowfft_r2c(fpmhip_plan *p, const void *in, void *out) { return rowfft_r2c_range(p, in, out, 0, p->mg.xl); }
+
+int rowfft_r2c_range(fpmhip_plan *p, const void *in, void *out, int x0, int nx)
+{
+    return p->f64 ? rowfft_launch<double>(p, in, out, x0, nx) : rowfft_launch<float>(p, in, out, x0, nx);
+}
+
+template <typename F>
+static int rowfft_c2r_launch(fpmhip_plan *p, void *buf_, int x0, int nx)
+{
+    StageTimer ktm(p, FPMHIP_T_K_ZC2R);
+    const MeshGeo &g = p->mg;
+    const long long nrows = (long long) nx * g.N;
+    void *buf = (char *) buf_ + (size_t) x0 * g.N * g.nzc * sizeof(C2<F>);
+#define CALL_ROWB(PL)                                                                                    \
+    {                                                                                                    \
+        using CF = RowCfg<PL, F>;                                                                        \
+        FPM_TRY(set_lds(rowfft_c2r_kernel<PL, F>, CF::lds));                                             \
+        rowfft_c2r_kernel<PL, F><<<(unsigned) ((nrows + CF::RW - 1) / CF::RW), CF::threads, CF::lds, p->stream>>>( \
+            (C2<F> *) buf, (long long) g.nzc, (int) nrows, p->d_twiddle);                                \
+    }
+    ROWFFT_DISPATCH(g.N / 2, CALL_ROWB)
+#undef CALL_ROWB
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// z pass backward (c2r), in place, on the planes [x0, x0 + nx)
+int rowfft_c2r_range(fpmhip_plan *p, void *buf, int x0, int nx)
+{
+    return p->f64 ? rowfft_c2r_launch<double>(p, buf, x0, nx) : rowfft_c2r_launch<float>(p, buf, x0, nx);
+}
+
+}  // namespace fpm
