@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Per-rank compute of the 8-GPU configs at full per-rank size on ONE GPU (tests/rank_share.py: the replicated
+universe), with per-kernel HIP-event timings against the HBM roofline.  Run it under rocprofv3 for the profile
+summaries in profiles/.    usage: rank_share_bench.py N [precision] [ncube]"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import rank_share  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+precision = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+ncube = int(sys.argv[3]) if len(sys.argv) > 3 else None
+P = 8
+acc, ref, t = rank_share.run_rank_share(N, P, precision, ncube=ncube, timing=True)
+n = ref.shape[0]
+rms = float(ref.double().pow(2).mean().sqrt())
+err = float((acc.view(P * P, n, 3).double() - ref.double()[None]).abs().max()) / rms
+s = precision // 8
+nr = N * N * (N + 2) // P                         # padded reals of the slab
+np_local = acc.shape[0]
+alg = {"sort": 52 * np_local, "paint": 24 * np_local + s * nr, "readout": 3 * s * nr + 36 * np_local,
+       "xback3": 4 * s * nr,                       # fused forward x + transfer + 2 backward x passes: 1 read, 3 writes
+       "k_colfft": 2 * s * nr, "k_rowfft": 2 * s * nr, "k_zc2r": 2 * s * nr, "k_yback2": 3 * s * nr}
+out = {"workload": "one rank of %d: %d^3 mesh fp%d, slab of %d planes, %d particles" % (P, N, precision, N // P, np_local),
+       "parity_vs_small_cube": err, "kernels": {}}
+for name, (ms, cnt) in sorted(t.items()):
+    if cnt == 0:
+        continue
+    e = {"ms_per_launch": ms / cnt, "launches": cnt}
+    if name in alg:
+        e["alg_GB"] = alg[name] / 1e9
+        e["TBps"] = alg[name] / (ms / cnt) / 1e9
+        e["frac_of_8TBps"] = e["TBps"] / 8.0
+    out["kernels"][name] = e
+# per-rank compute of ONE real step: every stage once (the x-pass kernel runs P times in the replicated loop)
+once = sum(v["ms_per_launch"] * (1 if k == "xback3" else v["launches"]) for k, v in out["kernels"].items()
+           if k in ("sort", "paint", "readout", "xback3", "k_colfft", "k_rowfft", "k_zc2r", "k_yback2"))
+out["per_rank_compute_ms_per_step"] = once
+out["particle_updates_per_s_per_gpu_compute_only"] = np_local / (once * 1e-3)
+print(json.dumps(out))
