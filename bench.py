@@ -114,12 +114,26 @@ STAGES_OF_KERNELS = {"k_colfft": "r2c/c2r", "k_rowfft": "r2c", "k_zc2r": "c2r", 
 
 
 
+PMC_PROFILE_TAG = "r02"          # profiles/<tag>_<gradient>_traffic.json: the committed PMC passes of this round
+
+
+def workload_label(nc, Nmesh, precision, world, own_fft):
+    """What actually ran, and which BASELINE.json configuration (if any) that is."""
+    named = {(256, 512, 64, 1): "configs[1]", (512, 1024, 64, 8): "configs[2]", (1024, 2048, 64, 8): "configs[3]"}
+    tag = named.get((nc, Nmesh, precision, world))
+    b = Nmesh / nc
+    return "%d^3 particles, B=%s (%d^3 mesh), fp%d, %dxMI355X, %s FFT passes%s" % (
+        nc, ("%d" % b) if b == int(b) else ("%.3g" % b), Nmesh, precision, world,
+        "hand-written row + column" if own_fft else "rocFFT", (" = BASELINE " + tag) if tag else " (not a BASELINE configuration)")
+
+
 def pmc_traffic(stage, Nmesh, np_total, args, world):
     """HBM bytes per launch of `stage` from the committed PMC profile (rocprofv3 cannot run inside
-    the bench): profiles/r01_e_<gradient>_traffic.json (tools/pmc_traffic.py, tools/profile_round.sh), only when the configuration matches
+    the bench): profiles/r02_<gradient>_traffic.json (tools/pmc_traffic.py, tools/profile_round.sh), only when the configuration matches
     the profiled one."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_e_%s_traffic.json" % args.gradient)))
+        path = os.path.join(ROOT, "profiles", "%s_%s_traffic.json" % (PMC_PROFILE_TAG, args.gradient))
+        t = json.load(open(path))
         c = t["config"]
         if (c["nmesh"], c["particles"], c["precision"], c["n_gpus"]) != (Nmesh, np_total, args.precision, world):
             return None
@@ -223,6 +237,8 @@ def main():
                     help="run that extra leg on N > 1 GPUs too (off by default there: a second collective phase after "
                          "the measured one must never be what a scaling run hangs or times out in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary legs (host-resident store columns; the 1024^3 mesh the 2e8 target is quoted on)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -332,6 +348,61 @@ def main():
         except Exception as e:        # the extra leg never takes the headline number down with it
             alt = {"gradient": "real" if args.gradient == "kspace" else "kspace", "error": repr(e)}
 
+    # secondary legs, outside the timed region and never part of `value` (N = 1 only):
+    #   host_columns: fpmhip_force_host, the call an UNMODIFIED libfastpm makes (store columns in host memory: x goes up
+    #                 over PCIe, acc comes back) -- the PCIe-inclusive rate of the drop-in boundary;
+    #   mesh1024    : 512^3 particles on a 1024^3 mesh (B = 2) on this one GPU -- the mesh size north_star's
+    #                 ">= 2e8 particle-updates/s/GPU at >= 40 % of the HBM roofline" target is quoted on.
+    secondary = None
+    if world == 1 and not args.no_secondary:
+        secondary = {}
+        try:
+            xh = x.cpu().numpy()
+            acch = np.zeros((len(xh), 3), dtype=np.float32)
+            pm.compute_force_host(xh, acc=acch)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                pm.compute_force_host(xh, acc=acch)
+            th = (time.perf_counter() - t0) / 3
+            secondary["host_columns"] = {"entry": "fpmhip_force_host", "ms_per_call": round(th * 1e3, 3),
+                                         "value": np_total / th, "unit": "particle-updates/s",
+                                         "bytes_over_pcie_per_call": 36 * np_total,
+                                         "note": "x (24 B/particle) host->device, acc (12 B/particle) device->host inside the call"}
+            del xh, acch
+        except Exception as e:
+            secondary["host_columns"] = {"error": repr(e)}
+        try:
+            nc2, N2 = 512, 1024
+            if (nc, Nmesh) != (nc2, N2) and torch.cuda.mem_get_info()[0] > 60e9:
+                x2 = make_particles(nc2, N2, 3.0 * nc2, 1, 0, device)
+                pm2 = PM(N2, 3.0 * nc2, precision=args.precision, np_max=x2.shape[0],
+                         gradient_mode=1 if args.gradient == "real" else 0)
+                st2 = Store(x2, device=device)
+                dk2 = pm2.alloc()
+                f2 = lambda: pm2.compute_force(st2, kernel="1_4", softening="none", delta_k=dk2, total_mass=float(nc2 ** 3))
+                f2()
+                torch.cuda.synchronize()
+                pm2.timing_enable(True)
+                pm2.timing_reset()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    f2()
+                torch.cuda.synchronize()
+                t2 = (time.perf_counter() - t0) / 3
+                tm2b = pm2.timings()
+                ab2 = algorithmic_bytes(x2.shape[0], N2, 1, esize, args.gradient)
+                b2 = 60 * x2.shape[0] + (12 if args.gradient == "kspace" else 6) * esize * N2 * N2 * (N2 + 2)
+                secondary["mesh1024"] = {
+                    "workload": workload_label(nc2, N2, args.precision, 1, pm2.column_fft()), "ms_per_step": round(t2 * 1e3, 3),
+                    "value": nc2 ** 3 / t2, "unit": "particle-updates/s", "step_frac": round(b2 / t2 / 1e9 / HBM_PEAK_GBS, 4),
+                    "kernel_fracs": {n: round(ab2[n] / (tm2b[n][0] / tm2b[n][1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                     for n in ab2 if n in tm2b and tm2b[n][1] > 0 and (n in KERNELS or n == "sort")},
+                    "finite": bool(torch.isfinite(st2.acc).all().item())}
+                del st2, dk2, x2
+                pm2.destroy()
+        except Exception as e:
+            secondary["mesh1024"] = {"error": repr(e)}
+
     acc_ok = bool(torch.isfinite(store.acc).all().item())
     # a size-independent property of the force at full scale, any N: equal-mass particles on a periodic mesh exert no
     # net force on themselves -- |sum acc| / sum |acc| is round-off (float32 acc: ~1e-7), whatever the decomposition
@@ -347,6 +418,8 @@ def main():
         ab = algorithmic_bytes(np_local, Nmesh, world, esize, args.gradient)
         if args.gradient == "real":
             KERNELS["readout"] = "fpm::readout_grad_tiles_kernel"
+        elif args.precision == 64:
+            KERNELS["readout"] = "fpm::readout1of3_tiles_kernel"
         stages = {}
         for name, (ms, n) in tm.items():
             if n == 0:
@@ -364,6 +437,25 @@ def main():
                     "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, Nmesh, np_total, args, world),
                     "alg_bytes_per_launch": ab[dom], "avg_launch_ms": round(avg_s * 1e3, 4)}
+        # every kernel of the step against the roofline, per launch (the dominant one above is the best-placed of
+        # them: it sums three launches); min_kernel = the lowest fraction, with its PMC traffic ratio
+        per_kernel = {}
+        for n in stages:
+            if n in ab and n in KERNELS:
+                a = ab[n] / (tm[n][0] / tm[n][1] * 1e-3) / 1e9
+                tr = pmc_traffic(n, Nmesh, np_total, args, world)
+                per_kernel[n] = {"kernel": KERNELS[n], "frac": round(a / HBM_PEAK_GBS, 4), "avg_launch_ms": stages[n]["avg_ms"],
+                                 "launches_per_step": stages[n]["launches_per_step"],
+                                 "traffic_over_alg": round(tr / ab[n], 3) if tr else None}
+        if "sort" in stages:                      # two kernels + a scan behind one timer
+            a = ab["sort"] / (tm["sort"][0] / tm["sort"][1] * 1e-3) / 1e9
+            tr = pmc_traffic("sort", Nmesh, np_total, args, world)
+            per_kernel["sort"] = {"kernel": "fpm::bin_kernel x2 + scan", "frac": round(a / HBM_PEAK_GBS, 4),
+                                  "avg_launch_ms": stages["sort"]["avg_ms"], "launches_per_step": stages["sort"]["launches_per_step"],
+                                  "traffic_over_alg": round(tr / ab["sort"], 3) if tr else None}
+        worst = min(per_kernel, key=lambda n: per_kernel[n]["frac"])
+        roofline["min_kernel"] = dict(per_kernel[worst], timer=worst)
+        roofline["kernels"] = per_kernel
         # 60 B per particle + 12 mesh sweeps (paint 1, r2c 2, 3 x (transfer 2 + readout 1)); the
         # real-space gradient needs 6 (paint 1, r2c 2, potential transfer + c2r 2, readout 1)
         b_alg = 60 * np_local + (12 if args.gradient == "kspace" else 6) * esize * (Nmesh * Nmesh * (Nmesh + 2) // world)
@@ -372,8 +464,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
-            "config": {"workload": "%d^3 particles, B=2 (%d^3 mesh), fp%d, %dxMI355X%s" % (
-                nc, Nmesh, args.precision, world, "" if world > 1 else " single-GPU rocFFT path (configs[1])"),
+            "config": {"workload": workload_label(nc, Nmesh, args.precision, world, pm.column_fft()),
                 "particles": np_total, "nmesh": Nmesh,
                 "load": {"a": "A: lattice + 0.3-cell Gaussian jitter", "b": "B: clustered, Zel'dovich-like rms 4 cells",
                          "c": "C: adversarial, 10 % of particles in 0.1 % of the volume"}[args.load],
@@ -390,9 +481,14 @@ def main():
             "step_alg_GBs": round(b_alg / (ms_per_step * 1e-3) / 1e9, 1),
             "roofline": roofline, "stages": stages,
         }
+        # the whole step against the roofline, B_alg / t / 8 TB/s
+        roofline["step_frac"] = round(b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        roofline["step_alg_bytes"] = b_alg
         out["exposed_comm_ms_per_step"] = round(ms_per_step - out["kernel_ms_per_step"], 3) if world > 1 else 0.0
         if alt is not None:
             out["other_gradient_mode"] = alt
+        if secondary:
+            out["secondary"] = secondary
         if notes:
             out["notes"] = notes
         if world == 1 and not args.no_cpu_baseline:

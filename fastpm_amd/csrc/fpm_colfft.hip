@@ -127,7 +127,7 @@ __global__ __launch_bounds__((ColCfg<PL, F>::threads)) void colfft_kernel(const 
 template <typename PL, int MODE, bool FWD, typename F>
 __global__ __launch_bounds__((ColCfg<PL, F, true>::threads), (fused_min_waves(ColCfg<PL, F, true>::threads, PL::E)))
 void colfft_xback3_kernel(const C2<F> *dk, C2<F> *__restrict__ o0, C2<F> *__restrict__ o1, C2<F> *__restrict__ o2,
-                          long long rstride, int ncols, int nzc, int ystart, int ntiles, const float *__restrict__ kk,
+                          long long rstride, int ncols, int nzl, int ystart, int zstart, int ntiles, const float *__restrict__ kk,
                           const float *__restrict__ kt, const double *__restrict__ tw_global, C2<F> *dk_store,
                           double fwd_scale)
 {
@@ -161,7 +161,7 @@ void colfft_xback3_kernel(const C2<F> *dk, C2<F> *__restrict__ o0, C2<F> *__rest
             if (live) (dk_store + j * jstride)[toff] = b[j];
         }
     }
-    const int iyl = live ? col / nzc : 0, iz = live ? col - iyl * nzc : 0;
+    const int iyl = live ? col / nzl : 0, iz = (live ? col - iyl * nzl : 0) + zstart;     // kz block of a pencil
     const int iy = iyl + ystart;
     const double kky = kk[iy], kkz = kk[iz];
     const bool yz_self = iy == (N - iy) % N && iz == (N - iz) % N;
@@ -229,7 +229,7 @@ template <typename PL, typename F>
 __global__ __launch_bounds__((ColCfg<PL, F>::threads), (fused_min_waves(ColCfg<PL, F>::threads, PL::E)))
 void colfft_yback2_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ oy, C2<F> *__restrict__ oz,
                           C2<F> *__restrict__ op, ColMap im, ColMap om, int ncols, int ntiles_per_batch, int ntiles,
-                          const float *__restrict__ kt, const double *__restrict__ tw_global)
+                          const float *__restrict__ kt, const double *__restrict__ tw_global, int zstart)
 {
     using CF = ColCfg<PL, F>;
     constexpr int CW = CF::CW, T = PL::T, E = PL::E;
@@ -258,7 +258,7 @@ void colfft_yback2_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ oy, 
             if (dir == 0) {
                 d = a[j];
             } else {
-                const double k_finite = dir == 1 ? kt[tau_o + T * j] : kt[live ? col : 0];
+                const double k_finite = dir == 1 ? kt[tau_o + T * j] : kt[live ? col + zstart : 0];
                 d.x = (F) (-a[j].y * k_finite);
                 d.y = (F) (a[j].x * k_finite);
             }
@@ -331,7 +331,7 @@ static int colfft_launch(fpmhip_plan *p, int dir, const void *in, void *out, con
 int colfft_x(fpmhip_plan *p, int dir, const void *in, void *out, double scale)
 {
     const MeshGeo &g = p->mg;
-    const long long plane = (long long) g.yl * g.nzc;
+    const long long plane = (long long) g.yl * g.nzl;
     ColMap m{0, 0, plane, g.N};
     return p->f64 ? colfft_launch<double>(p, dir, in, out, m, m, 1, (int) plane, scale)
                   : colfft_launch<float>(p, dir, in, out, m, m, 1, (int) plane, scale);
@@ -344,20 +344,24 @@ int colfft_y(fpmhip_plan *p, int dir, const void *in, void *out, int chunked)
     return colfft_y_range(p, dir, in, out, chunked, 0, p->mg.xl);
 }
 
+// The two sides of a y pass.  Real side ("A"): [ry'][x_loc][y_loc][kz_loc] -- what the (y <-> kz) exchange of a pencil
+// row delivers / takes; with Nproc[1] = 1 (slabs, one rank) y_loc = N and this is the natural [x_loc][y][kz].
+// k side ("B"): [rx'][x_loc][ky_loc][kz_loc] -- the (x <-> ky) exchange chunks; natural when Nproc[0] = 1.
+static ColMap ymap_a(const MeshGeo &g) { return ColMap{(long long) g.ylr * g.nzl, (long long) g.xl * g.ylr * g.nzl, g.nzl, g.ylr}; }
+static ColMap ymap_b(const MeshGeo &g) { return ColMap{(long long) g.yl * g.nzl, (long long) g.xl * g.yl * g.nzl, g.nzl, g.yl}; }
+
 // the same for the x planes [x0, x0 + nx) only
 int colfft_y_range(fpmhip_plan *p, int dir, const void *in, void *out, int chunked, int x0, int nx)
 {
+    (void) chunked;                       // the maps above reduce to the natural layout wherever there is no exchange
     const MeshGeo &g = p->mg;
-    const long long plane = (long long) g.N * g.nzc;
-    ColMap natural{plane, 0, g.nzc, g.N};
-    ColMap chunks{(long long) g.yl * g.nzc, (long long) g.xl * g.yl * g.nzc, g.nzc, g.yl};
-    const ColMap &im = (chunked && dir > 0) ? chunks : natural;
-    const ColMap &om = (chunked && dir < 0) ? chunks : natural;
+    const ColMap im = dir < 0 ? ymap_a(g) : ymap_b(g);
+    const ColMap om = dir < 0 ? ymap_b(g) : ymap_a(g);
     const size_t cb = 2 * p->esize;
     const char *inp = (const char *) in + (size_t) x0 * im.bstride * cb;
     char *outp = (char *) out + (size_t) x0 * om.bstride * cb;
-    return p->f64 ? colfft_launch<double>(p, dir, inp, outp, im, om, nx, g.nzc, 1.0)
-                  : colfft_launch<float>(p, dir, inp, outp, im, om, nx, g.nzc, 1.0);
+    return p->f64 ? colfft_launch<double>(p, dir, inp, outp, im, om, nx, g.nzl, 1.0)
+                  : colfft_launch<float>(p, dir, inp, outp, im, om, nx, g.nzl, 1.0);
 }
 
 template <typename F>
@@ -373,7 +377,7 @@ static int yback2_launch(fpmhip_plan *p, const void *in, void *oy, void *oz, voi
         FPM_TRY(set_lds(colfft_yback2_kernel<PL, F>, CF::lds));                                              \
         colfft_yback2_kernel<PL, F><<<ntiles, CF::threads, CF::lds, p->stream>>>(                            \
             (const C2<F> *) in, (C2<F> *) oy, (C2<F> *) oz, (C2<F> *) op, im, om, ncols, tpb, ntiles, kt,    \
-            p->d_twiddle);                                                                                   \
+            p->d_twiddle, p->mg.zstart);                                                                     \
     }
     COLFFT_DISPATCH(p->mg.N, sizeof(F), CALL_Y2)
 #undef CALL_Y2
@@ -391,18 +395,16 @@ int colfft_yback2(fpmhip_plan *p, const void *in, void *oy, void *oz, void *op, 
 int colfft_yback2_range(fpmhip_plan *p, const void *in, void *oy, void *oz, void *op, int chunked, int gradorder, int x0,
                         int nx)
 {
+    (void) chunked;
     const MeshGeo &g = p->mg;
-    const long long plane = (long long) g.N * g.nzc;
-    ColMap natural{plane, 0, g.nzc, g.N};
-    ColMap chunks{(long long) g.yl * g.nzc, (long long) g.xl * g.yl * g.nzc, g.nzc, g.yl};
-    const ColMap &im = chunked ? chunks : natural;
+    const ColMap im = ymap_b(g), om = ymap_a(g);
     const size_t cb = 2 * p->esize;
     const char *inp = (const char *) in + (size_t) x0 * im.bstride * cb;
-    char *oyp = (char *) oy + (size_t) x0 * natural.bstride * cb;
-    char *ozp = (char *) oz + (size_t) x0 * natural.bstride * cb;
-    char *opp = op ? (char *) op + (size_t) x0 * natural.bstride * cb : nullptr;
-    return p->f64 ? yback2_launch<double>(p, inp, oyp, ozp, opp, im, natural, nx, g.nzc, gradorder)
-                  : yback2_launch<float>(p, inp, oyp, ozp, opp, im, natural, nx, g.nzc, gradorder);
+    char *oyp = (char *) oy + (size_t) x0 * om.bstride * cb;
+    char *ozp = (char *) oz + (size_t) x0 * om.bstride * cb;
+    char *opp = op ? (char *) op + (size_t) x0 * om.bstride * cb : nullptr;
+    return p->f64 ? yback2_launch<double>(p, inp, oyp, ozp, opp, im, om, nx, g.nzl, gradorder)
+                  : yback2_launch<float>(p, inp, oyp, ozp, opp, im, om, nx, g.nzl, gradorder);
 }
 
 template <typename F>
@@ -411,7 +413,7 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
 {
     const MeshGeo &g = p->mg;
     const int N = g.N;
-    const long long plane = (long long) g.yl * g.nzc;
+    const long long plane = (long long) g.yl * g.nzl;
     const float *kk = p->d_tab + (2 + potorder) * (size_t) N;
     const float *kt = p->d_tab + gradorder * (size_t) N;
 #define CALL_X3_Q(PL, P, Q)                                                                                  \
@@ -420,8 +422,8 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
         const int ntiles = (int) ((plane + CF::CW - 1) / CF::CW);                                            \
         FPM_TRY(set_lds(colfft_xback3_kernel<PL, P, Q, F>, CF::lds));                                        \
         colfft_xback3_kernel<PL, P, Q, F><<<ntiles, CF::threads, CF::lds, p->stream>>>(                      \
-            (const C2<F> *) dk, (C2<F> *) o0, (C2<F> *) o1, (C2<F> *) o2, plane, (int) plane, g.nzc,        \
-            g.ystart, ntiles, kk, kt, p->d_twiddle, (C2<F> *) dk, fwd_scale);                                \
+            (const C2<F> *) dk, (C2<F> *) o0, (C2<F> *) o1, (C2<F> *) o2, plane, (int) plane, g.nzl,        \
+            g.ystart, g.zstart, ntiles, kk, kt, p->d_twiddle, (C2<F> *) dk, fwd_scale);                      \
     }
 #define CALL_X3_P(PL, P) if (fwd) CALL_X3_Q(PL, P, true) else CALL_X3_Q(PL, P, false)
 #define CALL_X3(PL) if (mode == 1) { CALL_X3_P(PL, 1) } else if (mode == 2) { CALL_X3_P(PL, 2) } else { CALL_X3_P(PL, 0) }

@@ -5,7 +5,7 @@
 // and the row gather that applies it to a column.  The exchange itself (Alltoall of counts, Alltoallv
 // of rows, store.c:570-639) is the caller's collective.
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "fpm_internal.h"
 
@@ -13,32 +13,85 @@ namespace fpm {
 
 static inline unsigned blocks_for(long long n, int bs) { return (unsigned) ((n + bs - 1) / bs); }
 
-// key 0 = stays (the reference's target -1), key r + 1 = goes to rank r; per-rank counts by
-// per-block LDS histogram + one global atomic per rank per block
-__global__ __launch_bounds__(256) void target_kernel(MeshGeo g, int nranks, int rank, const double *__restrict__ x,
-                                                     long long np, unsigned char *__restrict__ key,
-                                                     int *__restrict__ index, unsigned long long *__restrict__ counts)
+// A stable partition into P + 1 buckets (key 0 = stays, the reference's target -1; key r + 1 = goes to rank r)
+// instead of a general sort: two streaming passes and a scan of (blocks x buckets) counters.
+//   pass 1  owner of every particle -> key byte; per-block histogram -> hist[key][block]
+//   scan    exclusive over hist in (key, block) order = where each block's share of each bucket starts
+//   pass 2  keys re-read (1 byte per particle); rank inside the block by wave ballots in original order
+constexpr int DEC_ITEMS = 8;                       // particles per thread: a block covers 2048 consecutive rows
+constexpr int DEC_BLOCK = 256 * DEC_ITEMS;
+
+__device__ __forceinline__ int mesh_index(double pos, double inv_cell, int N)
+{
+    int ipos = (int) floor(pos * inv_cell);                      // pmpfft.c:347-349
+    if (ipos < 0) {                                              // pmpfft.c:357-363
+        ipos = ipos % N;
+        if (ipos < 0) ipos += N;
+    }
+    if (ipos >= N) ipos = ipos % N;
+    return ipos;
+}
+
+__global__ __launch_bounds__(256) void target_kernel(MeshGeo g, int nranks, int nranks_y, int rank,
+                                                     const double *__restrict__ x, long long np,
+                                                     unsigned char *__restrict__ key, int nblocks,
+                                                     int *__restrict__ hist)
 {
     __shared__ unsigned int h[257];
     for (int i = threadIdx.x; i <= nranks; i += blockDim.x) h[i] = 0;
     __syncthreads();
-    long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < np) {
-        int ipos = (int) floor(x[3 * i] * g.inv_cell);          // pmpfft.c:347-349
-        if (ipos < 0) {                                          // pmpfft.c:357-363
-            ipos = ipos % g.N;
-            if (ipos < 0) ipos += g.N;
+    const long long base = (long long) blockIdx.x * DEC_BLOCK;
+#pragma unroll
+    for (int j = 0; j < DEC_ITEMS; j++) {
+        const long long i = base + j * 256 + threadIdx.x;
+        if (i < np) {
+            // Grid.MeshtoCart[0 / 1] on even splits: rank = rx * Nproc[1] + ry (pmpfft.c:344-368)
+            int owner = mesh_index(x[3 * i], g.inv_cell, g.N) / g.xl * nranks_y;
+            if (nranks_y > 1) owner += mesh_index(x[3 * i + 1], g.inv_cell, g.N) / g.ylr;
+            const int k = owner == rank ? 0 : owner + 1;
+            key[i] = (unsigned char) k;
+            atomicAdd(&h[k], 1u);
         }
-        if (ipos >= g.N) ipos = ipos % g.N;
-        const int owner = ipos / g.xl;                           // Grid.MeshtoCart[0], even slabs
-        const int k = owner == rank ? 0 : owner + 1;
-        key[i] = (unsigned char) k;
-        index[i] = (int) i;
-        atomicAdd(&h[k], 1u);
     }
     __syncthreads();
-    for (int k = threadIdx.x; k <= nranks; k += blockDim.x)
-        if (h[k]) atomicAdd(&counts[k], (unsigned long long) h[k]);
+    for (int k = threadIdx.x; k <= nranks; k += blockDim.x) hist[(long long) k * nblocks + blockIdx.x] = (int) h[k];
+}
+
+__global__ __launch_bounds__(256) void partition_kernel(int nkeys, const unsigned char *__restrict__ key, long long np,
+                                                        int nblocks, const int *__restrict__ start,
+                                                        int *__restrict__ order)
+{
+    __shared__ int run[257];              // where the next row of bucket k from this block goes
+    __shared__ int wcnt[4][257];          // rows of bucket k in each wave, this round
+    for (int k = threadIdx.x; k < nkeys; k += blockDim.x) run[k] = start[(long long) k * nblocks + blockIdx.x];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long base = (long long) blockIdx.x * DEC_BLOCK;
+    for (int j = 0; j < DEC_ITEMS; j++) {
+        for (int k = threadIdx.x; k < 4 * 257; k += blockDim.x) (&wcnt[0][0])[k] = 0;
+        __syncthreads();
+        const long long i = base + j * 256 + threadIdx.x;
+        const bool active = i < np;
+        const int k = active ? key[i] : 0;
+        int rank = 0;
+        unsigned long long remaining = __ballot(active);
+        while (remaining) {                                       // one pass per distinct key in the wave
+            const int leader = __ffsll((long long) remaining) - 1;
+            const int kl = __shfl(k, leader);
+            const unsigned long long same = __ballot(active && k == kl);
+            if (active && k == kl) rank = __popcll(same & ((1ull << lane) - 1ull));
+            if (lane == leader) wcnt[wave][kl] = __popcll(same);
+            remaining &= ~same;
+        }
+        __syncthreads();
+        if (active) {
+            int off = run[k] + rank;
+            for (int w = 0; w < wave; w++) off += wcnt[w][k];
+            order[off] = (int) i;
+        }
+        __syncthreads();
+        for (int q = threadIdx.x; q < nkeys; q += blockDim.x) run[q] += wcnt[0][q] + wcnt[1][q] + wcnt[2][q] + wcnt[3][q];
+        __syncthreads();
+    }
 }
 
 template <int ROWB>
@@ -71,45 +124,48 @@ int fpmhip_decompose_order(fpmhip_plan *p, const double *x, int64_t np, int *ord
 {
     if (!p || !counts_host || (np > 0 && (!x || !order))) FPM_FAIL(-1, "null argument");
     const int P = p->lay.nranks;
-    if (P > 255) FPM_FAIL(-1, "decompose supports up to 255 slabs");
+    if (P > 255) FPM_FAIL(-1, "decompose supports up to 255 ranks");
     if (np >= (1ll << 31) - 1) FPM_FAIL(-1, "np exceeds the int32 index range of one rank");
     for (int k = 0; k <= P; k++) counts_host[k] = 0;
     if (np == 0) return 0;
-    // scratch lives in the plan: four hipMalloc / hipFree pairs per call cost more than the sort itself
-    if (np > p->dec_cap || !p->dec_counts) {
-        for (void *q : {(void *) p->dec_key_in, (void *) p->dec_key_out, (void *) p->dec_idx}) if (q) (void) hipFree(q);
-        p->dec_key_in = p->dec_key_out = nullptr;
-        p->dec_idx = nullptr;
+    const int nkeys = P + 1;
+    const int nblocks = (int) ((np + DEC_BLOCK - 1) / DEC_BLOCK);
+    const size_t nhist = (size_t) nkeys * nblocks + 1;              // + the grand total
+    // scratch lives in the plan: key bytes, the (key, block) histogram and its scan
+    if (np > p->dec_cap) {
+        if (p->dec_key_in) (void) hipFree(p->dec_key_in);
+        p->dec_key_in = nullptr;
         const int64_t cap = np + np / 8 + 1024;
-        if (hipMalloc(&p->dec_key_in, cap) != hipSuccess || hipMalloc(&p->dec_key_out, cap) != hipSuccess ||
-            hipMalloc(&p->dec_idx, cap * sizeof(int)) != hipSuccess)
-            FPM_FAIL(-2, "decompose: %s", hipGetErrorString(hipGetLastError()));
-        if (!p->dec_counts && hipMalloc(&p->dec_counts, 256 * sizeof(unsigned long long)) != hipSuccess)
-            FPM_FAIL(-2, "decompose: %s", hipGetErrorString(hipGetLastError()));
+        FPM_CHECK_HIP(hipMalloc(&p->dec_key_in, cap));
         p->dec_cap = cap;
     }
-    unsigned char *key_in = p->dec_key_in, *key_out = p->dec_key_out;
-    int *idx_in = p->dec_idx;
-    unsigned long long *d_counts = p->dec_counts;
-    FPM_CHECK_HIP(hipMemsetAsync(d_counts, 0, (P + 1) * sizeof(unsigned long long), p->stream));
-    target_kernel<<<blocks_for(np, 256), 256, 0, p->stream>>>(p->mg, P, p->lay.rank, x, np, key_in, idx_in, d_counts);
-    // stable LSD radix sort on the rank key: leavers grouped by target, original order inside
-    // each group, exactly the order store.c:540-546 builds with its offsets[] pass
-    int bits = 1;
-    while ((1 << bits) < P + 1) bits++;
+    if (nhist * sizeof(int) * 2 > p->dec_hist_bytes) {
+        if (p->dec_idx) (void) hipFree(p->dec_idx);
+        p->dec_idx = nullptr;
+        p->dec_hist_bytes = (nhist + nhist / 4 + 1024) * sizeof(int) * 2;
+        FPM_CHECK_HIP(hipMalloc(&p->dec_idx, p->dec_hist_bytes));
+    }
+    int *hist = p->dec_idx, *start = hist + (p->dec_hist_bytes / sizeof(int) / 2);
+    FPM_CHECK_HIP(hipMemsetAsync(hist + nhist - 1, 0, sizeof(int), p->stream));
+    target_kernel<<<nblocks, 256, 0, p->stream>>>(p->mg, P, p->lay.nranks_y, p->lay.rank, x, np, p->dec_key_in, nblocks, hist);
     size_t tmp_bytes = 0;
-    FPM_CHECK_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_in, key_out, idx_in, order, (size_t) np, 0, bits, p->stream));
+    FPM_CHECK_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, hist, start, 0, nhist, rocprim::plus<int>(), p->stream));
     if (tmp_bytes > p->dec_tmp_bytes) {
         if (p->dec_tmp) (void) hipFree(p->dec_tmp);
         p->dec_tmp = nullptr;
         FPM_CHECK_HIP(hipMalloc(&p->dec_tmp, tmp_bytes));
         p->dec_tmp_bytes = tmp_bytes;
     }
-    FPM_CHECK_HIP(rocprim::radix_sort_pairs(p->dec_tmp, tmp_bytes, key_in, key_out, idx_in, order, (size_t) np, 0, bits, p->stream));
-    unsigned long long *h = (unsigned long long *) p->h_pinned;         // pinned scratch (>= 256 * 8 bytes)
-    FPM_CHECK_HIP(hipMemcpyAsync(h, d_counts, (P + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, p->stream));
+    FPM_CHECK_HIP(rocprim::exclusive_scan(p->dec_tmp, tmp_bytes, hist, start, 0, nhist, rocprim::plus<int>(), p->stream));
+    partition_kernel<<<nblocks, 256, 0, p->stream>>>(nkeys, p->dec_key_in, np, nblocks, start, order);
+    FPM_CHECK_HIP(hipGetLastError());
+    // bucket sizes = differences of the bucket starts (store.c:527-539's counts)
+    int *h = p->h_pinned;                                              // pinned scratch (>= 257 ints)
+    FPM_CHECK_HIP(hipMemcpy2DAsync(h, sizeof(int), start, (size_t) nblocks * sizeof(int), sizeof(int), nkeys,
+                                   hipMemcpyDeviceToHost, p->stream));
+    FPM_CHECK_HIP(hipMemcpyAsync(h + nkeys, start + nhist - 1, sizeof(int), hipMemcpyDeviceToHost, p->stream));
     FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
-    for (int k = 0; k <= P; k++) counts_host[k] = (int64_t) h[k];
+    for (int k = 0; k <= P; k++) counts_host[k] = (int64_t) h[k + 1] - (int64_t) h[k];
     return 0;
 }
 

@@ -84,6 +84,8 @@ int fft_setup(fpmhip_plan *p)
     const size_t N = g.N, nzc = g.nzc, xl = g.xl, yl = g.yl;
     const double inv_norm = 1.0 / p->lay.Norm;
     p->own_fft = p->geom.fft_mode == FPMHIP_FFT_AUTO && colfft_supported(g.N);
+    if (p->lay.nranks_y > 1 && !(p->own_fft && rowfft_supported(g.N)))
+        FPM_FAIL(-1, "pencils (nranks_y > 1) need the hand-written FFT passes: Nmesh %d is not a supported length", g.N);
     if (p->own_fft) {
         // the contiguous z rows N real <-> N/2+1 complex, batch xl * N: the own row kernels (fpm_rowfft.hip) when N/2
         // is a supported length, else rocFFT's batched 1-D plans
@@ -287,6 +289,7 @@ int fpmhip_plan_ranged_fft(const fpmhip_plan *p)
 int fpmhip_fft_yz_forward_range(fpmhip_plan *p, void *canvas, void *send, int x0, int nx)
 {
     if (!p || !canvas || !send) FPM_FAIL(-1, "null argument");
+    if (p->lay.nranks_y > 1) FPM_FAIL(-1, "pencils: the (y, z) passes are separate stage calls, fpmhip_fft_z_* / fpmhip_fft_y_*");
     FPM_TRY(check_range(p, x0, nx));
     if (p->lay.nranks > 1 && canvas == send) FPM_FAIL(-1, "fft_yz_forward: canvas and send must differ when nranks > 1");
     StageTimer tm(p, FPMHIP_T_R2C);
@@ -297,6 +300,7 @@ int fpmhip_fft_yz_forward_range(fpmhip_plan *p, void *canvas, void *send, int x0
 int fpmhip_fft_yz_backward_range(fpmhip_plan *p, void *recv, void *canvas, int x0, int nx)
 {
     if (!p || !recv || !canvas) FPM_FAIL(-1, "null argument");
+    if (p->lay.nranks_y > 1) FPM_FAIL(-1, "pencils: the (y, z) passes are separate stage calls, fpmhip_fft_z_* / fpmhip_fft_y_*");
     FPM_TRY(check_range(p, x0, nx));
     if (p->lay.nranks > 1 && recv == canvas) FPM_FAIL(-1, "fft_yz_backward: recv and canvas must differ when nranks > 1");
     StageTimer tm(p, FPMHIP_T_C2R);
@@ -309,6 +313,7 @@ int fpmhip_fft_yz_backward_grad2_range(fpmhip_plan *p, void *recv, void *out_y, 
 {
     if (!p || !recv || !out_y || !out_z) FPM_FAIL(-1, "null argument");
     FPM_TRY(check_range(p, x0, nx));
+    if (p->lay.nranks_y > 1) FPM_FAIL(-1, "pencils: the (y, z) passes are separate stage calls, fpmhip_fft_z_* / fpmhip_fft_y_*");
     int po, go, dfo, dc;
     FPM_TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));
     if (go != 1) FPM_FAIL(-1, "fft_yz_backward_grad2 is for kernels with gradorder = 1");
@@ -336,6 +341,7 @@ int fpmhip_plan_column_fft(const fpmhip_plan *p)
 int fpmhip_r2c(fpmhip_plan *p, void *canvas, void *delta_k)
 {
     if (!p || !canvas || !delta_k) FPM_FAIL(-1, "null argument");
+    if (p->lay.nranks_y > 1) FPM_FAIL(-1, "pencils: the (y, z) passes are separate stage calls, fpmhip_fft_z_* / fpmhip_fft_y_*");
     if (p->lay.nranks != 1) FPM_FAIL(-1, "fpmhip_r2c is the one-rank transform; use the fft_yz/fft_x stages");
     if (canvas == delta_k) FPM_FAIL(-1, "pm_r2c is out of place (pmapi.h:97-100)");
     StageTimer tm(p, FPMHIP_T_R2C);
@@ -400,6 +406,7 @@ int fpmhip_c2r(fpmhip_plan *p, void *inplace)
 int fpmhip_fft_yz_forward(fpmhip_plan *p, void *canvas, void *send)
 {
     if (!p || !canvas || !send) FPM_FAIL(-1, "null argument");
+    if (p->lay.nranks_y > 1) FPM_FAIL(-1, "pencils: the (y, z) passes are separate stage calls, fpmhip_fft_z_* / fpmhip_fft_y_*");
     if (!fpmhip_plan_staged_fft(p)) FPM_FAIL(-1, "staged FFT needs nranks > 1 or the column-FFT back end");
     if (p->own_fft) {
         StageTimer tm(p, FPMHIP_T_R2C);
@@ -441,6 +448,7 @@ int fpmhip_fft_x_backward(fpmhip_plan *p, void *buf)
 int fpmhip_fft_yz_backward(fpmhip_plan *p, void *recv, void *canvas)
 {
     if (!p || !recv || !canvas) FPM_FAIL(-1, "null argument");
+    if (p->lay.nranks_y > 1) FPM_FAIL(-1, "pencils: the (y, z) passes are separate stage calls, fpmhip_fft_z_* / fpmhip_fft_y_*");
     if (!fpmhip_plan_staged_fft(p)) FPM_FAIL(-1, "staged FFT needs nranks > 1 or the column-FFT back end");
     if (p->own_fft) {
         StageTimer tm(p, FPMHIP_T_C2R);
@@ -502,6 +510,7 @@ int fpmhip_transfer_fft_x_backward_potx(fpmhip_plan *p, const void *delta_k, voi
 int fpmhip_fft_yz_backward_grad2(fpmhip_plan *p, void *recv, void *out_y, void *out_z, void *out_pot, int kernel)
 {
     if (!p || !recv || !out_y || !out_z) FPM_FAIL(-1, "null argument");
+    if (p->lay.nranks_y > 1) FPM_FAIL(-1, "pencils: the (y, z) passes are separate stage calls, fpmhip_fft_z_* / fpmhip_fft_y_*");
     if (!p->own_fft) FPM_FAIL(-1, "fft_yz_backward_grad2 needs the column-FFT back end");
     int po, go, dfo, dc;
     FPM_TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));
@@ -529,6 +538,62 @@ int fpmhip_transfer_fft_x_backward_pot(fpmhip_plan *p, const void *delta_k, void
     }
     FPM_TRY(fpmhip_transfer(p, delta_k, out, kernel, FPMHIP_FIELD_POTENTIAL));
     return fpmhip_fft_x_backward(p, out);
+}
+
+// ---- pencils (Nproc = {Nx, Ny}): the (y, z) passes as separate stages around the (y <-> kz) exchange inside a row of
+//      Ny ranks.  All of them also work with Ny = 1, where the "A" layout is the natural slab. ----
+//   forward : z_forward(canvas -> A) ; exchange A ; y_forward(A' -> B) ; exchange B ; fft_x_forward (or the fused form)
+//   backward: x backward ... ; exchange B ; y_backward(B' -> A) ; exchange A ; z_backward(A' -> canvas)
+int fpmhip_fft_z_forward(fpmhip_plan *p, void *canvas, void *send_a)
+{
+    if (!p || !canvas || !send_a) FPM_FAIL(-1, "null argument");
+    if (!p->own_fft || !rowfft_supported(p->mg.N)) FPM_FAIL(-1, "fft_z_forward needs the hand-written FFT passes");
+    if (p->lay.nranks_y > 1 && canvas == send_a) FPM_FAIL(-1, "fft_z_forward: canvas and send must differ on pencils");
+    StageTimer tm(p, FPMHIP_T_R2C);
+    return rowfft_r2c(p, canvas, send_a);
+}
+
+int fpmhip_fft_y_forward(fpmhip_plan *p, void *recv_a, void *send_b)
+{
+    if (!p || !recv_a || !send_b) FPM_FAIL(-1, "null argument");
+    if (!p->own_fft) FPM_FAIL(-1, "fft_y_forward needs the hand-written FFT passes");
+    if (p->lay.nranks > 1 && recv_a == send_b) FPM_FAIL(-1, "fft_y_forward: input and output must differ when nranks > 1");
+    StageTimer tm(p, FPMHIP_T_R2C);
+    return colfft_y(p, -1, recv_a, send_b, 1);
+}
+
+int fpmhip_fft_y_backward(fpmhip_plan *p, void *recv_b, void *send_a)
+{
+    if (!p || !recv_b || !send_a) FPM_FAIL(-1, "null argument");
+    if (!p->own_fft) FPM_FAIL(-1, "fft_y_backward needs the hand-written FFT passes");
+    if (p->lay.nranks > 1 && recv_b == send_a) FPM_FAIL(-1, "fft_y_backward: input and output must differ when nranks > 1");
+    StageTimer tm(p, FPMHIP_T_C2R);
+    return colfft_y(p, +1, recv_b, send_a, 1);
+}
+
+// the potential after its x pass and the (x <-> ky) exchange -> the y passes of the y and z ACC components (and of
+// the potential itself when out_pot is given), gradient factors as fpmhip_fft_yz_backward_grad2; each output then
+// goes through exchange A and fpmhip_fft_z_backward
+int fpmhip_fft_y_backward_grad2(fpmhip_plan *p, void *recv_b, void *out_y_a, void *out_z_a, void *out_pot_a, int kernel)
+{
+    if (!p || !recv_b || !out_y_a || !out_z_a) FPM_FAIL(-1, "null argument");
+    if (!p->own_fft) FPM_FAIL(-1, "fft_y_backward_grad2 needs the hand-written FFT passes");
+    int po, go, dfo, dc;
+    FPM_TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));
+    if (go != 1) FPM_FAIL(-1, "fft_y_backward_grad2 is for kernels with gradorder = 1");
+    if (out_y_a == out_z_a || recv_b == out_y_a || recv_b == out_z_a) FPM_FAIL(-1, "input and outputs must be different buffers");
+    if (out_pot_a && (out_pot_a == out_y_a || out_pot_a == out_z_a || out_pot_a == recv_b)) FPM_FAIL(-1, "out_pot must be a buffer of its own");
+    StageTimer tm(p, FPMHIP_T_C2R);
+    return colfft_yback2(p, recv_b, out_y_a, out_z_a, out_pot_a, 1, go);
+}
+
+int fpmhip_fft_z_backward(fpmhip_plan *p, void *recv_a, void *canvas)
+{
+    if (!p || !recv_a || !canvas) FPM_FAIL(-1, "null argument");
+    if (!p->own_fft || !rowfft_supported(p->mg.N)) FPM_FAIL(-1, "fft_z_backward needs the hand-written FFT passes");
+    if (p->lay.nranks_y > 1 && recv_a == canvas) FPM_FAIL(-1, "fft_z_backward: input and canvas must differ on pencils");
+    StageTimer tm(p, FPMHIP_T_C2R);
+    return rowfft_c2r_oop(p, recv_a, canvas);
 }
 
 }  // extern "C"

@@ -224,6 +224,7 @@ extern "C" {
 
 int fpmhip_ic_fill_gaussian(fpmhip_plan *p, void *delta_k, int seed)
 {
+    if (p && p->lay.nranks_y > 1) FPM_FAIL(-1, "the initial-condition operators run on slabs (nranks_y = 1)");
     if (!p || !delta_k) FPM_FAIL(-1, "null argument");
     const MeshGeo &g = p->mg;
     if (g.N % 2) FPM_FAIL(-1, "the gadget scheme needs an even mesh");
@@ -249,6 +250,7 @@ int fpmhip_ic_fill_gaussian(fpmhip_plan *p, void *delta_k, int seed)
 
 int fpmhip_ic_remove_variance(fpmhip_plan *p, void *delta_k)
 {
+    if (p && p->lay.nranks_y > 1) FPM_FAIL(-1, "the initial-condition operators run on slabs (nranks_y = 1)");
     if (!p || !delta_k) FPM_FAIL(-1, "null argument");
     const MeshGeo &g = p->mg;
     const long long n = (long long) g.N * g.yl * g.nzc;
@@ -261,6 +263,7 @@ int fpmhip_ic_remove_variance(fpmhip_plan *p, void *delta_k)
 
 int fpmhip_ic_induce_correlation(fpmhip_plan *p, void *delta_k, const double *k, const double *pk, int size)
 {
+    if (p && p->lay.nranks_y > 1) FPM_FAIL(-1, "the initial-condition operators run on slabs (nranks_y = 1)");
     if (!p || !delta_k || !k || !pk) FPM_FAIL(-1, "null argument");
     if (size < 1) FPM_FAIL(-1, "empty power spectrum table");
     const MeshGeo &g = p->mg;

@@ -65,10 +65,16 @@ struct MeshGeo {
     int xstart;        // first global x plane of this rank
     int xplanes;       // planes present in a real buffer: xl + halo
     int periodic_x;    // 1 if nranks == 1 (wrap in x inside the kernel)
-    int yl;            // local ky rows in k space
+    int yl;            // local ky rows in k space (N / Nproc[0])
     int ystart;
     int nzc;           // N/2 + 1
-    long long str0;    // real strides: N*(N+2)
+    int nzl;           // local kz entries = the k-space row pitch: nzc on slabs, ceil(nzc / Nproc[1]) on pencils
+    int zstart;        // first global kz of this rank
+    int ylr;           // local y rows of the real mesh (N / Nproc[1])
+    int yrstart;       // first global y row
+    int yplanes;       // rows present in a real plane: ylr + y halo
+    int periodic_y;    // 1 if Nproc[1] == 1 (wrap in y inside the kernel)
+    long long str0;    // real strides: yplanes*(N+2)
     long long str1;    // N+2
     double inv_cell;   // 1.0 / (BoxSize / N), pmpfft.c:150-151
     int ntx, nty, ntz; // tile grid over [xplanes][N][N]
@@ -142,13 +148,12 @@ struct fpmhip_plan {
     fpm::HostStage host_stage;
     double *d_decic = nullptr;   // de-CIC factors 1 / sinc^2(w / 2) per axis index (transfer.c:90-93), built on first use
     double *d_bins = nullptr;    // 3 * Nmesh / 2 doubles: P(k) bin sums
-    // decompose scratch (keys, indices, radix-sort temporary), grown on demand
-    unsigned char *dec_key_in = nullptr, *dec_key_out = nullptr;
+    // decompose scratch (key bytes; block histograms + their scan; scan temporary), grown on demand
+    unsigned char *dec_key_in = nullptr;
     int *dec_idx = nullptr;
-    unsigned long long *dec_counts = nullptr;
     void *dec_tmp = nullptr;
     int64_t dec_cap = 0;
-    size_t dec_tmp_bytes = 0;
+    size_t dec_tmp_bytes = 0, dec_hist_bytes = 0;
     int64_t binned_ndup = 0;
 
     // timing
@@ -194,6 +199,7 @@ int colfft_xfwd_xback(fpmhip_plan *p, void *dk_inout, void *o0, void *o1, void *
                       int mode, double scale);
 int colfft_xback_potx(fpmhip_plan *p, const void *dk, void *out_x, void *out_pot, int potorder, int gradorder);
 int rowfft_c2r_range(fpmhip_plan *p, void *buf, int x0, int nx);
+int rowfft_c2r_oop(fpmhip_plan *p, const void *in, void *out);
 int colfft_yback2(fpmhip_plan *p, const void *in, void *oy, void *oz, void *op, int chunked, int gradorder);
 int colfft_yback2_range(fpmhip_plan *p, const void *in, void *oy, void *oz, void *op, int chunked, int gradorder, int x0,
                         int nx);

@@ -18,13 +18,15 @@ template <typename F> struct Cplx { F re, im; };
 static inline unsigned blocks_for(long long n, int bs) { return (unsigned) ((n + bs - 1) / bs); }
 
 // grid: x = blocks over the (y_loc, kz) plane, y = ix.  Decodes the plane index.
+// (row pitch nzl, global kz = local + zstart; the padding entries of a pencil's last kz block are left alone)
 #define KSPACE_INDEX(g)                                                         \
     const int ix = blockIdx.y;                                                  \
     const int rem = blockIdx.x * blockDim.x + threadIdx.x;                      \
-    if (rem >= (g).yl * (g).nzc) return;                                        \
-    const int iyl = rem / (g).nzc, iz = rem - iyl * (g).nzc;                    \
-    const int iy = iyl + (g).ystart;                                            \
-    const long long ind = ((long long) ix * (g).yl + iyl) * (g).nzc + iz;       \
+    if (rem >= (g).yl * (g).nzl) return;                                        \
+    const int iyl = rem / (g).nzl, izl = rem - iyl * (g).nzl;                   \
+    const int iy = iyl + (g).ystart, iz = izl + (g).zstart;                     \
+    if (iz >= (g).nzc) return;                                                  \
+    const long long ind = ((long long) ix * (g).yl + iyl) * (g).nzl + izl;      \
     (void) iy; (void) iz;
 
 // gravity_apply_kernel_transfer for COLUMN_ACC / COLUMN_POTENTIAL in one pass, keeping the
@@ -200,14 +202,15 @@ __global__ __launch_bounds__(256) void power_kernel(MeshGeo g, double k0, Cplx<F
     for (int i = threadIdx.x; i < 3 * nbins; i += blockDim.x) lds[i] = 0;
     __syncthreads();
     const int N = g.N;
-    const int plane = g.yl * g.nzc;
+    const int plane = g.yl * g.nzl;
     // a workgroup walks several x planes before it flushes its LDS bins: with one plane per workgroup the
     // 32768 x 768 flushes serialised on 768 addresses (0.72 ms for a 0.25 ms read of the mesh)
     for (int ix = blockIdx.y; ix < N; ix += gridDim.y)
     for (int rem = blockIdx.x * blockDim.x + threadIdx.x; rem < plane; rem += gridDim.x * blockDim.x) {
-        const int iyl = rem / g.nzc, iz = rem - iyl * g.nzc;
-        const int iy = iyl + g.ystart;
-        const long long ind = ((long long) ix * g.yl + iyl) * g.nzc + iz;
+        const int iyl = rem / g.nzl, izl = rem - iyl * g.nzl;
+        const int iy = iyl + g.ystart, iz = izl + g.zstart;
+        if (iz >= g.nzc) continue;
+        const long long ind = ((long long) ix * g.yl + iyl) * g.nzl + izl;
         long long kk = 0;
         int ik = ix; if (ik > N / 2) ik -= N; kk += (long long) ik * ik;
         ik = iy; if (ik > N / 2) ik -= N; kk += (long long) ik * ik;
@@ -266,6 +269,21 @@ __global__ __launch_bounds__(256) void plane_add_kernel(F *__restrict__ dst, con
     if (i < n) dst[i] = dst[i] + src[i];
 }
 
+// Pencil halo in y: row `iy` of the planes [0, nx) of a real mesh <-> a contiguous buffer [nx][N + 2].
+// MODE 0: buffer = row (pack), 1: row = buffer (unpack), 2: row += buffer.
+template <typename F, int MODE>
+__global__ __launch_bounds__(256) void yrow_kernel(F *__restrict__ mesh, F *__restrict__ buf, long long str0, int rowlen,
+                                                   long long rowoff, int nx)
+{
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long) nx * rowlen) return;
+    const int x = (int) (i / rowlen), z = (int) (i - (long long) x * rowlen);
+    F *cell = mesh + x * str0 + rowoff + z;
+    if (MODE == 0) buf[i] = *cell;
+    else if (MODE == 1) *cell = buf[i];
+    else *cell = *cell + buf[i];
+}
+
 // [x][y_loc][kz] -> [y_loc][kz][x]  (the reference's PFFT-transposed ORegion, pmpfft.c:198-202).
 // 32 x 32 LDS tile transpose over (x, plane index).
 template <typename F>
@@ -301,7 +319,7 @@ static int transfer_impl(fpmhip_plan *p, const void *from, void *to, int potorde
     const int64_t N = g.N;
     const float *kk = p->d_tab + (2 + potorder) * N;    // kk, kk_finite, kk_finite2 (transfer.c:166)
     const float *kt = p->d_tab + gradorder * N;          // k, k_finite             (gravity.c:38)
-    dim3 grid(blocks_for((long long) g.yl * g.nzc, 256), g.N);
+    dim3 grid(blocks_for((long long) g.yl * g.nzl, 256), g.N);
     transfer_kernel<F><<<grid, 256, 0, p->stream>>>(g, kk, kt, dir, (const Cplx<F> *) from, (Cplx<F> *) to);
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
@@ -314,7 +332,7 @@ static int separable_impl(fpmhip_plan *p, const std::vector<double> &fac, const 
     // one table serves the three axes (cubic mesh, pmpfft.c:146-157)
     FPM_CHECK_HIP(hipMemcpyAsync(p->d_fac, fac.data(), g.N * sizeof(double), hipMemcpyHostToDevice, p->stream));
     FPM_CHECK_HIP(hipStreamSynchronize(p->stream));   // fac is a host temporary
-    dim3 grid(blocks_for((long long) g.yl * g.nzc, 256), g.N);
+    dim3 grid(blocks_for((long long) g.yl * g.nzl, 256), g.N);
     separable_kernel<F><<<grid, 256, 0, p->stream>>>(g, p->d_fac, (const Cplx<F> *) from, (Cplx<F> *) to);
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
@@ -363,7 +381,7 @@ int fpmhip_laplace(fpmhip_plan *p, const void *from, void *to, int order)
     if (order < 0 || order > 2) FPM_FAIL(-1, "laplace order %d", order);
     const MeshGeo &g = p->mg;
     const float *kk = p->d_tab + (2 + order) * (size_t) g.N;
-    dim3 grid(blocks_for((long long) g.yl * g.nzc, 256), g.N);
+    dim3 grid(blocks_for((long long) g.yl * g.nzl, 256), g.N);
     StageTimer tm(p, FPMHIP_T_TRANSFER);
     if (p->f64) laplace_kernel<double><<<grid, 256, 0, p->stream>>>(g, kk, (const Cplx<double> *) from, (Cplx<double> *) to);
     else laplace_kernel<float><<<grid, 256, 0, p->stream>>>(g, kk, (const Cplx<float> *) from, (Cplx<float> *) to);
@@ -377,7 +395,7 @@ int fpmhip_diff(fpmhip_plan *p, void *inplace, int dir, int order)
     if (order < 0 || order > 1 || dir < 0 || dir > 2) FPM_FAIL(-1, "diff dir %d order %d", dir, order);
     const MeshGeo &g = p->mg;
     const float *kt = p->d_tab + order * (size_t) g.N;
-    dim3 grid(blocks_for((long long) g.yl * g.nzc, 256), g.N);
+    dim3 grid(blocks_for((long long) g.yl * g.nzl, 256), g.N);
     StageTimer tm(p, FPMHIP_T_TRANSFER);
     if (p->f64) diff_kernel<double><<<grid, 256, 0, p->stream>>>(g, kt, dir, (Cplx<double> *) inplace);
     else diff_kernel<float><<<grid, 256, 0, p->stream>>>(g, kt, dir, (Cplx<float> *) inplace);
@@ -426,7 +444,7 @@ int fpmhip_decic(fpmhip_plan *p, const void *from, void *to)
     FPM_TRY(ensure_decic_table(p));
     const MeshGeo &g = p->mg;
     StageTimer tm(p, FPMHIP_T_TRANSFER);
-    dim3 grid(blocks_for((long long) g.yl * g.nzc, 256), g.N);
+    dim3 grid(blocks_for((long long) g.yl * g.nzl, 256), g.N);
     if (p->f64) separable_kernel<double><<<grid, 256, 0, p->stream>>>(g, p->d_decic, (const Cplx<double> *) from, (Cplx<double> *) to);
     else separable_kernel<float><<<grid, 256, 0, p->stream>>>(g, p->d_decic, (const Cplx<float> *) from, (Cplx<float> *) to);
     FPM_CHECK_HIP(hipGetLastError());
@@ -441,7 +459,7 @@ int fpmhip_softening(fpmhip_plan *p, void *delta_k, int type)
     const double BoxSize = p->geom.BoxSize;
     if (type == FPMHIP_SOFTENING_NONE) return 0;
     StageTimer tm(p, FPMHIP_T_DEALIAS);
-    dim3 grid(blocks_for((long long) g.yl * g.nzc, 256), g.N);
+    dim3 grid(blocks_for((long long) g.yl * g.nzl, 256), g.N);
     const float *kk = p->d_tab + 2 * N;
     switch (type) {
     case FPMHIP_SOFTENING_GAUSSIAN:
@@ -482,7 +500,7 @@ static int powerspectrum_impl(fpmhip_plan *p, void *d1, const void *d2, bool dec
     double *dbins = p->d_bins;
     FPM_CHECK_HIP(hipMemsetAsync(dbins, 0, 3 * nbins * sizeof(double), p->stream));
     const double k0 = 2 * M_PI / p->geom.BoxSize;
-    const int plane = g.yl * g.nzc;
+    const int plane = g.yl * g.nzl;
     dim3 grid(std::max(1u, std::min(blocks_for(plane, 256 * 8), 64u)), (unsigned) std::min(g.N, 32));
     const size_t lds = 3 * nbins * sizeof(double);
 #define POWER(F, D)                                                                                          \
@@ -538,13 +556,31 @@ int fpmhip_plane_add(fpmhip_plan *p, void *dst, const void *src)
     return 0;
 }
 
+// mode 0 pack, 1 unpack, 2 add (see yrow_kernel): row iy of planes [0, isize[0]) of `mesh`, buffer of isize[0] * (Nmesh + 2)
+int fpmhip_yrow(fpmhip_plan *p, void *mesh, int64_t iy, void *buf, int mode)
+{
+    if (!p || !mesh || !buf) FPM_FAIL(-1, "null argument");
+    const MeshGeo &g = p->mg;
+    if (iy < 0 || iy >= g.yplanes || mode < 0 || mode > 2) FPM_FAIL(-1, "yrow: row %lld / mode %d out of range", (long long) iy, mode);
+    StageTimer tm(p, FPMHIP_T_HALO);
+    const int rowlen = g.N + 2;
+    const long long n = (long long) g.xl * rowlen;
+#define YROW(F, M) yrow_kernel<F, M><<<blocks_for(n, 256), 256, 0, p->stream>>>((F *) mesh, (F *) buf, g.str0, rowlen, iy * g.str1, g.xl)
+    if (p->f64) { if (mode == 0) YROW(double, 0); else if (mode == 1) YROW(double, 1); else YROW(double, 2); }
+    else { if (mode == 0) YROW(float, 0); else if (mode == 1) YROW(float, 1); else YROW(float, 2); }
+#undef YROW
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int fpmhip_import_delta_k(fpmhip_plan *p, const void *host, void *delta_k)
 {
     if (!p || !delta_k || !host) FPM_FAIL(-1, "null argument");
+    if (p->lay.nranks_y > 1) FPM_FAIL(-1, "import / export of the reference layout: slabs only (a pencil's kz block is padded)");
     FPM_TRY(ensure_buffer(p, BUF_XCHG));
     if (delta_k == p->buf[BUF_XCHG]) FPM_FAIL(-1, "import target must not be the exchange buffer");
     const MeshGeo &g = p->mg;
-    const long long plane = (long long) g.yl * g.nzc;
+    const long long plane = (long long) g.yl * g.nzl;
     FPM_CHECK_HIP(hipMemcpyAsync(p->buf[BUF_XCHG], host, (size_t) 2 * p->lay.complex_elems * p->esize,
                                  hipMemcpyHostToDevice, p->stream));
     // [y_loc][kz][x] -> [x][y_loc][kz]: the same tile transpose with the roles of the axes swapped
@@ -569,9 +605,10 @@ int fpmhip_transfer_host(fpmhip_plan *p, int kernel, const void *delta_k_host, v
 int fpmhip_export_delta_k(fpmhip_plan *p, const void *delta_k, void *host)
 {
     if (!p || !delta_k || !host) FPM_FAIL(-1, "null argument");
+    if (p->lay.nranks_y > 1) FPM_FAIL(-1, "import / export of the reference layout: slabs only (a pencil's kz block is padded)");
     FPM_TRY(ensure_buffer(p, BUF_XCHG));
     const MeshGeo &g = p->mg;
-    const long long plane = (long long) g.yl * g.nzc;
+    const long long plane = (long long) g.yl * g.nzl;
     dim3 grid(blocks_for(plane, 32), blocks_for(g.N, 32));
     if (p->f64) to_reference_layout_kernel<double><<<grid, 256, 0, p->stream>>>(g.N, plane, (const Cplx<double> *) delta_k, (Cplx<double> *) p->buf[BUF_XCHG]);
     else to_reference_layout_kernel<float><<<grid, 256, 0, p->stream>>>(g.N, plane, (const Cplx<float> *) delta_k, (Cplx<float> *) p->buf[BUF_XCHG]);

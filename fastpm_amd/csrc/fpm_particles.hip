@@ -50,14 +50,21 @@ __device__ __forceinline__ bool cic_setup(const MeshGeo &g, double px, double py
         c.i0[a] = wrap_cell(I, g.N);
         c.i1[a] = wrap_cell(I + 1, g.N);
     }
+    bool mine = true;
     if (!g.periodic_x) {
         // slab: the particle's base plane is owned by this rank (the caller's decomposition
-        // guarantees it, solver.c:449); plane xl is the halo plane owned by rank + 1.
+        // guarantees it, solver.c:449); plane xl is the halo plane owned by the next rank in x.
         c.i0[0] -= g.xstart;
         c.i1[0] = c.i0[0] + 1;
-        return c.i0[0] >= 0 && c.i0[0] < g.xl;
+        mine = c.i0[0] >= 0 && c.i0[0] < g.xl;
     }
-    return true;
+    if (!g.periodic_y) {
+        // pencil: the same in y (pm_pos_to_rank, pmpfft.c:344-368); row ylr is the halo row
+        c.i0[1] -= g.yrstart;
+        c.i1[1] = c.i0[1] + 1;
+        mine = mine && c.i0[1] >= 0 && c.i0[1] < g.ylr;
+    }
+    return mine;
 }
 
 __device__ __forceinline__ int tile_id(const MeshGeo &g, int tx, int ty, int tz)
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(256) void paint_tiles_kernel(MeshGeo g, int ntiles,
     for (int i = threadIdx.x; i < TILE_CELLS; i += 256) {
         const int lz = i % TILE_Z, ly = (i / TILE_Z) % TILE_Y, lx = i / (TILE_Z * TILE_Y);
         const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
-        if (gx < g.xplanes && gy < g.N && gz < g.N) {
+        if (gx < g.xplanes && gy < g.yplanes && gz < g.N) {
             F *row = canvas + (long long) gx * g.str0 + (long long) gy * g.str1;
             const F mine = (F) (tile[i] * scale);
             row[gz] = accumulate ? (F) (row[gz] + mine) : mine;      // further species add (gravity.c:326-338)
@@ -370,28 +377,33 @@ __device__ __forceinline__ void stage_regions(F *__restrict__ reg, const F *cons
             const int q = min(q0 + u * 256, NQ - 1);
             const int pz = q % PR, row = q / PR, ry = row % RY, rx = row / RY;
             int lx = x0 + rx, gy = y0 + ry, gz = z0 + 2 * pz;
+            bool ok = true, from_halo = false;
             if (small) {
-                gy = ((gy % g.N) + g.N) % g.N;
+                if (g.periodic_y) gy = ((gy % g.N) + g.N) % g.N;
                 gz = ((gz % g.N) + g.N) % g.N;
             } else {
-                gy += gy < 0 ? g.N : 0; gy -= gy >= g.N ? g.N : 0;
+                if (g.periodic_y) { gy += gy < 0 ? g.N : 0; gy -= gy >= g.N ? g.N : 0; }
                 gz += gz < 0 ? g.N : 0; gz -= gz >= g.N ? g.N : 0;
             }
-            bool ok = true, from_halo = false;
+            if (!g.periodic_y) {                  // uniform: pencil rows 0 .. ylr (its halo row); others read 0
+                ok = gy >= 0 && gy < g.yplanes;
+                gy = ok ? gy : 0;
+            }
             long long off;
             if (g.periodic_x) {                   // uniform
                 if (small) lx = ((lx % g.N) + g.N) % g.N;
                 else { lx += lx < 0 ? g.N : 0; lx -= lx >= g.N ? g.N : 0; }
                 off = (long long) lx * g.str0;
             } else if (halo) {                    // uniform (NC == 1 only)
-                ok = lx >= -2 && lx <= g.xl + 2;
+                ok = ok && lx >= -2 && lx <= g.xl + 2;
                 const bool lo = lx < 0, hi = lx > g.xl;
                 const int hp = !ok ? 0 : (lo ? lx + 2 : (hi ? lx - g.xl + 1 : lx));
                 from_halo = (lo || hi) && ok;
                 off = (long long) hp * g.str0;
             } else {
-                ok = lx >= 0 && lx < g.xplanes;
-                off = (long long) (ok ? lx : 0) * g.str0;
+                const bool okx = lx >= 0 && lx < g.xplanes;
+                ok = ok && okx;
+                off = (long long) (okx ? lx : 0) * g.str0;
             }
             off += (long long) gy * g.str1 + gz;
             // gz is even and <= N - 2: the second value of a pair is still inside the row
@@ -440,22 +452,24 @@ __device__ __forceinline__ void stage_regions_rows(F *__restrict__ reg, const F 
     if (threadIdx.x < NROW) {
         const int row = threadIdx.x, rx = row / RY, ry = row - rx * RY;
         int lx = x0 + rx, gy = y0 + ry;
-        if (small) gy = ((gy % g.N) + g.N) % g.N;
-        else { gy += gy < 0 ? g.N : 0; gy -= gy >= g.N ? g.N : 0; }
         bool ok = true, from_halo = false;
+        if (!g.periodic_y) { ok = gy >= 0 && gy < g.yplanes; gy = ok ? gy : 0; }
+        else if (small) gy = ((gy % g.N) + g.N) % g.N;
+        else { gy += gy < 0 ? g.N : 0; gy -= gy >= g.N ? g.N : 0; }
         int plane;
         if (g.periodic_x) {                   // uniform
             if (small) lx = ((lx % g.N) + g.N) % g.N;
             else { lx += lx < 0 ? g.N : 0; lx -= lx >= g.N ? g.N : 0; }
             plane = lx;
         } else if (halo) {                    // uniform (NC == 1 only)
-            ok = lx >= -2 && lx <= g.xl + 2;
+            ok = ok && lx >= -2 && lx <= g.xl + 2;
             const bool lo = lx < 0, hi = lx > g.xl;
             plane = !ok ? 0 : (lo ? lx + 2 : (hi ? lx - g.xl + 1 : lx));
             from_halo = (lo || hi) && ok;
         } else {
-            ok = lx >= 0 && lx < g.xplanes;
-            plane = ok ? lx : 0;
+            const bool okx = lx >= 0 && lx < g.xplanes;
+            ok = ok && okx;
+            plane = okx ? lx : 0;
         }
         const long long off = (long long) plane * g.str0 + (long long) gy * g.str1;
         rowbase[row] = ok ? (off * 2 + (from_halo ? 1 : 0)) : -1;
@@ -866,8 +880,9 @@ int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt)
     FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
     const long long total = p->h_pinned[0];
     if (p->h_pinned[1] != 0)
-        FPM_FAIL(-6, "%d particles are outside this rank's slab [%d, %d) in x: decompose before the force "
-                     "(reference solver.c:449)", p->h_pinned[1], p->mg.xstart, p->mg.xstart + p->mg.xl);
+        FPM_FAIL(-6, "%d particles are outside this rank's region x [%d, %d), y [%d, %d): decompose before the force "
+                     "(reference solver.c:449)", p->h_pinned[1], p->mg.xstart, p->mg.xstart + p->mg.xl, p->mg.yrstart,
+                 p->mg.yrstart + p->mg.ylr);
     if (total < np) FPM_FAIL(-5, "internal: binned %lld entries for %lld particles", total, np);
     const long long ndup = total - np;
     if (total > p->bin_cap_own) FPM_TRY(ensure_bins(p, np, ndup, pt->mass != nullptr));

@@ -155,7 +155,6 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
     if (N > 8192) FPM_FAIL(-1, "Nmesh %lld too large", (long long) N);
     if (geom->precision != 32 && geom->precision != 64) FPM_FAIL(-1, "precision must be 32 or 64");
     if (geom->nranks < 1 || geom->rank < 0 || geom->rank >= geom->nranks) FPM_FAIL(-1, "bad rank %d/%d", geom->rank, geom->nranks);
-    if (N % geom->nranks != 0) FPM_FAIL(-1, "Nmesh %lld not divisible by nranks %d", (long long) N, geom->nranks);
     if (!(geom->BoxSize > 0)) FPM_FAIL(-1, "BoxSize must be positive");
 
     int ndev = 0;
@@ -173,7 +172,17 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
     p->esize = p->f64 ? 8 : 4;
 
     const int P = geom->nranks;
-    const int xl = (int) (N / P), yl = (int) (N / P), nzc = (int) (N / 2 + 1);
+    const int Ny = geom->nranks_y > 1 ? geom->nranks_y : 1;          // Nproc[1]
+    if (P % Ny != 0) FPM_FAIL(-1, "nranks %d is not a multiple of nranks_y %d", P, Ny);
+    const int Nx = P / Ny;                                           // Nproc[0]
+    if (N % Nx != 0 || N % Ny != 0)
+        FPM_FAIL(-1, "Nmesh %lld not divisible by the process mesh %d x %d (pmapi.c:69-77)", (long long) N, Nx, Ny);
+    if (Ny > 1 && geom->gradient_mode == FPMHIP_GRADIENT_REAL)
+        FPM_FAIL(-1, "FPMHIP_GRADIENT_REAL is a slab-only mode (its stencil halo is two planes deep in x only)");
+    const int rx = geom->rank / Ny, ry = geom->rank % Ny;            // MPI_Cart_create order, pmpfft.c:127-136
+    const int xl = (int) (N / Nx), yl = (int) (N / Nx), ylr = (int) (N / Ny), nzc = (int) (N / 2 + 1);
+    const int nzl = (nzc + Ny - 1) / Ny;                             // kz block, the last one padded
+    const int hx = Nx > 1 ? 1 : 0, hy = Ny > 1 ? 1 : 0;
     fpmhip_layout &L = p->lay;
     memset(&L, 0, sizeof(L));
     L.Nmesh = N;
@@ -182,26 +191,34 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
     L.nranks = P;
     L.rank = geom->rank;
     L.gradient_mode = geom->gradient_mode;
-    L.ihalo = P > 1 ? 1 : 0;
-    L.plane_elems = N * (N + 2);
-    L.istart[0] = (int64_t) geom->rank * xl; L.istart[1] = 0; L.istart[2] = 0;
-    L.isize[0] = xl; L.isize[1] = N; L.isize[2] = N;
+    L.nranks_x = Nx; L.nranks_y = Ny; L.rank_x = rx; L.rank_y = ry;
+    L.ihalo = hx;
+    L.ihalo_y = hy;
+    L.plane_elems = (int64_t) (ylr + hy) * (N + 2);
+    L.istart[0] = (int64_t) rx * xl; L.istart[1] = (int64_t) ry * ylr; L.istart[2] = 0;
+    L.isize[0] = xl; L.isize[1] = ylr; L.isize[2] = N;
     L.istrides[0] = L.plane_elems; L.istrides[1] = N + 2; L.istrides[2] = 1;
-    L.ostart[0] = 0; L.ostart[1] = (int64_t) geom->rank * yl; L.ostart[2] = 0;
-    L.osize[0] = N; L.osize[1] = yl; L.osize[2] = nzc;
-    L.ostrides[0] = (int64_t) yl * nzc; L.ostrides[1] = nzc; L.ostrides[2] = 1;
-    L.real_elems = (xl + L.ihalo) * L.plane_elems;
-    L.complex_elems = N * (int64_t) yl * nzc;
-    L.allocsize = std::max(L.real_elems, 2 * L.complex_elems);
+    L.ostart[0] = 0; L.ostart[1] = (int64_t) rx * yl; L.ostart[2] = (int64_t) ry * nzl;
+    L.osize[0] = N; L.osize[1] = yl; L.osize[2] = nzl;
+    L.ovalid_z = std::max<int64_t>(0, std::min<int64_t>(nzl, nzc - (int64_t) ry * nzl));
+    L.ostrides[0] = (int64_t) yl * nzl; L.ostrides[1] = nzl; L.ostrides[2] = 1;
+    L.real_elems = (xl + hx) * L.plane_elems;
+    L.complex_elems = N * (int64_t) yl * nzl;
+    // every stage buffer: the real slab, the k-space block, and the two exchange layouts
+    L.chunk_a_elems = 2 * (int64_t) xl * ylr * nzl;                  // [ry'][x_loc][y_loc][kz_loc]: Ny chunks
+    L.chunk_b_elems = 2 * (int64_t) xl * yl * nzl;                   // [rx'][x_loc][ky_loc][kz_loc]: Nx chunks
+    L.allocsize = std::max(std::max(L.real_elems, 2 * L.complex_elems), (int64_t) Ny * L.chunk_a_elems);
     L.Norm = (double) N * (double) N * (double) N;
 
     MeshGeo &g = p->mg;
-    g.N = (int) N; g.xl = xl; g.xstart = geom->rank * xl; g.xplanes = xl + (int) L.ihalo;
-    g.periodic_x = P == 1; g.yl = yl; g.ystart = geom->rank * yl; g.nzc = nzc;
+    g.N = (int) N; g.xl = xl; g.xstart = rx * xl; g.xplanes = xl + hx;
+    g.periodic_x = Nx == 1; g.yl = yl; g.ystart = rx * yl; g.nzc = nzc;
+    g.nzl = nzl; g.zstart = ry * nzl;
+    g.ylr = ylr; g.yrstart = ry * ylr; g.yplanes = ylr + hy; g.periodic_y = Ny == 1;
     g.str0 = L.plane_elems; g.str1 = N + 2;
     g.inv_cell = 1.0 / (geom->BoxSize / N);
     g.ntx = (g.xplanes + TILE_X - 1) / TILE_X;
-    g.nty = ((int) N + TILE_Y - 1) / TILE_Y;
+    g.nty = (g.yplanes + TILE_Y - 1) / TILE_Y;
     g.ntz = ((int) N + TILE_Z - 1) / TILE_Z;
     p->ntiles = g.ntx * g.nty * g.ntz;
 
@@ -244,7 +261,7 @@ void fpmhip_plan_destroy(fpmhip_plan *p)
     for (int i = 0; i < BUF_COUNT; i++) if (p->buf[i]) (void) hipFree(p->buf[i]);
     void *ptrs[] = {p->host_stage.x, p->host_stage.acc, p->host_stage.mass, p->host_stage.pot,
                     p->d_twiddle, p->d_tab, p->d_fac, p->sx, p->sy, p->sz, p->smass, p->sidx, p->tile_cnt,
-                    p->tile_off, p->tile_cur, p->scan_tmp, p->d_scalar, p->d_decic, p->d_bins, p->dec_key_in, p->dec_key_out, p->dec_idx, p->dec_counts, p->dec_tmp};
+                    p->tile_off, p->tile_cur, p->scan_tmp, p->d_scalar, p->d_decic, p->d_bins, p->dec_key_in, p->dec_idx, p->dec_tmp};
     for (void *q : ptrs) if (q) (void) hipFree(q);
     if (p->h_pinned) (void) hipHostFree(p->h_pinned);
     for (auto &e : p->ev_used) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
@@ -290,7 +307,7 @@ void *fpmhip_plane_ptr(fpmhip_plan *p, void *mesh, int64_t ix)
 int64_t fpmhip_exchange_chunk_elems(const fpmhip_plan *p)
 {
     if (!p) return -1;
-    return 2 * (int64_t) p->mg.xl * p->mg.yl * p->mg.nzc;
+    return p->lay.chunk_b_elems;
 }
 
 static const char *stage_names[FPMHIP_T_COUNT] = {"sort", "paint", "r2c", "dealias", "transfer",

@@ -27,11 +27,22 @@ template <typename PL, typename F> struct RowCfg {
 // Forward z pass.  A workgroup takes RW adjacent rows; the row is read as M complex numbers z[n] = x[2n] + i x[2n+1],
 // transformed with the register / LDS FFT core and untangled:
 //   X[k] = E[k] + W_N^k O[k],  E = (Z[k] + conj Z[M-k]) / 2,  O = (Z[k] - conj Z[M-k]) / 2i.
-template <typename PL, typename F>
+// Pencils (PEN): the real rows sit in planes of `prows` rows of which the first `ylr` are transformed (the last is the
+// y halo row), and the half spectrum is stored straight into the (y <-> kz) exchange chunks [kz block][row][nzl]
+// (the pack is fused into the store); the backward kernel reads them the same way.
+struct RowGeo {
+    long long pitch;     // complex units between consecutive rows of the real mesh (= N/2 + 1)
+    int ylr, prows;      // rows per x plane that are transformed / present
+    int nzl;             // kz entries per exchange chunk
+    long long chunk;     // complex units per exchange chunk
+};
+
+template <typename PL, bool PEN, typename F>
 __global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_r2c_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ out,
-                                                       long long pitch, int nrows,
+                                                       RowGeo rg, int nrows,
                                                        const double *__restrict__ tw_global)
 {
+    const long long pitch = rg.pitch;
     using CF = RowCfg<PL, F>;
     constexpr int M = PL::N, RW = CF::RW, T = PL::T, E = PL::E;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -41,7 +52,7 @@ __global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_r2c_kernel(co
     const int c = threadIdx.x % RW, tau = threadIdx.x / RW;
     const long long row = (long long) blockIdx.x * RW + c;
     const bool live = row < nrows;
-    const C2<F> *src = in + row * pitch;
+    const C2<F> *src = in + (PEN ? ((row / rg.ylr) * rg.prows + row % rg.ylr) * pitch : row * pitch);
     C2<F> v[vmax(E)];
 #pragma unroll
     for (int j = 0; j < E; j++) v[in_slot<PL>(j)] = live ? src[tau + T * j] : C2<F>{0, 0};
@@ -53,7 +64,8 @@ __global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_r2c_kernel(co
 #pragma unroll
     for (int j = 0; j < E; j++) lds[(tau + T * j) * RW + c] = v[j];
     __syncthreads();
-    C2<F> *dst = out + row * pitch;
+    C2<F> *dst = out + (PEN ? row * rg.nzl : row * pitch);
+    auto at = [&](int k) -> C2<F> & { return PEN ? dst[(k / rg.nzl) * rg.chunk + k % rg.nzl] : dst[k]; };
 #pragma unroll
     for (int j = 0; j < E; j++) {
         const int k = tau + T * j;
@@ -65,8 +77,8 @@ __global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_r2c_kernel(co
         const C2<F> o = {d.y, -d.x};                           // d / i
         const C2<F> x = cadd(e, cmul(twn[k], o));
         if (live) {
-            dst[k] = x;
-            if (k == 0) dst[M] = C2<F>{a.x - a.y, 0};          // X[N/2] = Re Z0 - Im Z0
+            at(k) = x;
+            if (k == 0) at(M) = C2<F>{a.x - a.y, 0};           // X[N/2] = Re Z0 - Im Z0
         }
     }
 }
@@ -75,10 +87,11 @@ __global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_r2c_kernel(co
 // place row by row.  The inverse of rowfft_r2c_kernel: with X the half spectrum of a real row,
 //   Z'[k] = (X[k] + conj X[M-k]) + i conj(W_N^k) (X[k] - conj X[M-k]),   z' = IFFT_M(Z') (unnormalised),
 // and the row is z'[n] = x[2n] + i x[2n+1].
-template <typename PL, typename F>
-__global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_c2r_kernel(C2<F> *__restrict__ buf, long long pitch, int nrows,
+template <typename PL, bool PEN, typename F>
+__global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_c2r_kernel(const C2<F> *in, C2<F> *out, RowGeo rg, int nrows,
                                                        const double *__restrict__ tw_global)
 {
+    const long long pitch = rg.pitch;
     using CF = RowCfg<PL, F>;
     constexpr int M = PL::N, RW = CF::RW, T = PL::T, E = PL::E;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -88,11 +101,12 @@ __global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_c2r_kernel(C2
     const int c = threadIdx.x % RW, tau = threadIdx.x / RW;
     const long long row = (long long) blockIdx.x * RW + c;
     const bool live = row < nrows;
-    C2<F> *src = buf + row * pitch;
+    const C2<F> *src = in + (PEN ? row * rg.nzl : row * pitch);
+    auto at = [&](int k) -> C2<F> { return PEN ? src[(k / rg.nzl) * rg.chunk + k % rg.nzl] : src[k]; };
     C2<F> x[E];
 #pragma unroll
-    for (int j = 0; j < E; j++) x[j] = live ? src[tau + T * j] : C2<F>{0, 0};
-    C2<F> xm = (live && tau == 0) ? src[M] : C2<F>{0, 0};
+    for (int j = 0; j < E; j++) x[j] = live ? at(tau + T * j) : C2<F>{0, 0};
+    C2<F> xm = (live && tau == 0) ? at(M) : C2<F>{0, 0};
     // a c2r transform reads only the real parts of X[0] and X[N/2] (FFTW, pocketfft and rocFFT all do): with the
     // exact i k gradient (3_2, EASTWOOD, NAIVE) the Nyquist entry of a row does carry an imaginary part
     if (tau == 0) { x[0].y = 0; xm.y = 0; }
@@ -117,8 +131,9 @@ __global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_c2r_kernel(C2
     __syncthreads();                                           // everyone has read its partner
     fft_core<PL, +1, RW, false>(v, lds, tw, tau, c);
     if (live) {
+        C2<F> *dst = out + (PEN ? ((row / rg.ylr) * rg.prows + row % rg.ylr) * pitch : row * pitch);
 #pragma unroll
-        for (int j = 0; j < E; j++) src[tau + T * j] = v[j];
+        for (int j = 0; j < E; j++) dst[tau + T * j] = v[j];
     }
 }
 
@@ -151,24 +166,36 @@ bool rowfft_supported(int N)
     return false;
 }
 
+// Geometry of the z passes for this plan: slab rows are contiguous and transform in place; pencil rows skip the y halo
+// row of every plane and the spectrum lives in the (y <-> kz) exchange chunks.
+static RowGeo row_geo(const fpmhip_plan *p)
+{
+    const MeshGeo &g = p->mg;
+    return RowGeo{(long long) g.nzc, g.ylr, g.yplanes, g.nzl, (long long) g.xl * g.ylr * g.nzl};
+}
+
 template <typename F>
 static int rowfft_launch(fpmhip_plan *p, const void *in_, void *out_, int x0, int nx)
 {
     StageTimer ktm(p, FPMHIP_T_K_ROWFFT);
     const MeshGeo &g = p->mg;
-    const long long nrows = (long long) nx * g.N;
-    const size_t off = (size_t) x0 * g.N * g.nzc * sizeof(C2<F>);
-    const void *in = (const char *) in_ + off;
-    void *out = (char *) out_ + off;
-#define CALL_ROW(PL)                                                                                    \
+    const bool pen = !g.periodic_y;
+    const long long nrows = (long long) nx * g.ylr;
+    const RowGeo rg = row_geo(p);
+    // the planes [x0, x0 + nx): real planes are yplanes rows apart, spectrum rows ylr * (nzl | nzc) apart
+    const void *in = (const char *) in_ + (size_t) x0 * g.yplanes * g.nzc * sizeof(C2<F>);
+    void *out = (char *) out_ + (size_t) x0 * g.ylr * (pen ? g.nzl : g.nzc) * sizeof(C2<F>);
+#define CALL_ROW_P(PL, PEN_)                                                                            \
     {                                                                                                   \
         using CF = RowCfg<PL, F>;                                                                       \
-        FPM_TRY(set_lds(rowfft_r2c_kernel<PL, F>, CF::lds));                                            \
-        rowfft_r2c_kernel<PL, F><<<(unsigned) ((nrows + CF::RW - 1) / CF::RW), CF::threads, CF::lds, p->stream>>>( \
-            (const C2<F> *) in, (C2<F> *) out, (long long) g.nzc, (int) nrows, p->d_twiddle);           \
+        FPM_TRY(set_lds(rowfft_r2c_kernel<PL, PEN_, F>, CF::lds));                                      \
+        rowfft_r2c_kernel<PL, PEN_, F><<<(unsigned) ((nrows + CF::RW - 1) / CF::RW), CF::threads, CF::lds, p->stream>>>( \
+            (const C2<F> *) in, (C2<F> *) out, rg, (int) nrows, p->d_twiddle);                          \
     }
+#define CALL_ROW(PL) if (pen) CALL_ROW_P(PL, true) else CALL_ROW_P(PL, false)
     ROWFFT_DISPATCH(g.N / 2, CALL_ROW)
 #undef CALL_ROW
+#undef CALL_ROW_P
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -181,29 +208,41 @@ int rowfft_r2c_range(fpmhip_plan *p, const void *in, void *out, int x0, int nx)
 }
 
 template <typename F>
-static int rowfft_c2r_launch(fpmhip_plan *p, void *buf_, int x0, int nx)
+static int rowfft_c2r_launch(fpmhip_plan *p, const void *in_, void *out_, int x0, int nx)
 {
     StageTimer ktm(p, FPMHIP_T_K_ZC2R);
     const MeshGeo &g = p->mg;
-    const long long nrows = (long long) nx * g.N;
-    void *buf = (char *) buf_ + (size_t) x0 * g.N * g.nzc * sizeof(C2<F>);
-#define CALL_ROWB(PL)                                                                                    \
+    const bool pen = !g.periodic_y;
+    const long long nrows = (long long) nx * g.ylr;
+    const RowGeo rg = row_geo(p);
+    const void *in = (const char *) in_ + (size_t) x0 * g.ylr * (pen ? g.nzl : g.nzc) * sizeof(C2<F>);
+    void *out = (char *) out_ + (size_t) x0 * g.yplanes * g.nzc * sizeof(C2<F>);
+#define CALL_ROWB_P(PL, PEN_)                                                                            \
     {                                                                                                    \
         using CF = RowCfg<PL, F>;                                                                        \
-        FPM_TRY(set_lds(rowfft_c2r_kernel<PL, F>, CF::lds));                                             \
-        rowfft_c2r_kernel<PL, F><<<(unsigned) ((nrows + CF::RW - 1) / CF::RW), CF::threads, CF::lds, p->stream>>>( \
-            (C2<F> *) buf, (long long) g.nzc, (int) nrows, p->d_twiddle);                                \
+        FPM_TRY(set_lds(rowfft_c2r_kernel<PL, PEN_, F>, CF::lds));                                       \
+        rowfft_c2r_kernel<PL, PEN_, F><<<(unsigned) ((nrows + CF::RW - 1) / CF::RW), CF::threads, CF::lds, p->stream>>>( \
+            (const C2<F> *) in, (C2<F> *) out, rg, (int) nrows, p->d_twiddle);                           \
     }
+#define CALL_ROWB(PL) if (pen) CALL_ROWB_P(PL, true) else CALL_ROWB_P(PL, false)
     ROWFFT_DISPATCH(g.N / 2, CALL_ROWB)
 #undef CALL_ROWB
+#undef CALL_ROWB_P
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
-// z pass backward (c2r), in place, on the planes [x0, x0 + nx)
+// z pass backward (c2r) on the planes [x0, x0 + nx): in place on a slab; on pencils from the exchange chunks `in`
+// into the real mesh `out`
 int rowfft_c2r_range(fpmhip_plan *p, void *buf, int x0, int nx)
 {
-    return p->f64 ? rowfft_c2r_launch<double>(p, buf, x0, nx) : rowfft_c2r_launch<float>(p, buf, x0, nx);
+    if (!p->mg.periodic_y) FPM_FAIL(-1, "internal: the in-place z pass is the slab form");
+    return p->f64 ? rowfft_c2r_launch<double>(p, buf, buf, x0, nx) : rowfft_c2r_launch<float>(p, buf, buf, x0, nx);
+}
+
+int rowfft_c2r_oop(fpmhip_plan *p, const void *in, void *out)
+{
+    return p->f64 ? rowfft_c2r_launch<double>(p, in, out, 0, p->mg.xl) : rowfft_c2r_launch<float>(p, in, out, 0, p->mg.xl);
 }
 
 }  // namespace fpm

@@ -35,6 +35,22 @@ class _SlabRank:
         self.group = group
         self.P, self.rank = pm.nranks, pm.rank
         self._pending = {}
+        self._axis_groups = None          # pencils: (row group = same rank_x, column group = same rank_y)
+
+    # -- pencils: the two sub-communicators of the process mesh (pm->Comm2D's rows and columns, pmpfft.c:117-136)
+    def _axis(self, axis):
+        """(group, my index in it, its size, global ranks of its members) for axis "y" (a row: same rank_x, the
+        (y <-> kz) exchange and the y halo) or "x" (a column: same rank_y, the (x <-> ky) exchange and the x halo)."""
+        pm = self.pm
+        Nx, Ny, rx, ry = pm.nranks_x, pm.nranks_y, pm.rank_x, pm.rank_y
+        members = [rx * Ny + j for j in range(Ny)] if axis == "y" else [i * Ny + ry for i in range(Nx)]
+        me = ry if axis == "y" else rx
+        if self._axis_groups is None and dist.is_available() and dist.is_initialized():
+            self._axis_groups = make_axis_groups(Nx, Ny, self.rank, self.group)
+        g = None
+        if self._axis_groups is not None:
+            g = self._axis_groups[0] if axis == "y" else self._axis_groups[1]
+        return g, me, len(members), members
 
     def run(self, gen):
         for req in gen:
@@ -50,6 +66,18 @@ class _SlabRank:
             return self._communicate_staged(req)
         if kind == "allreduce":
             dist.all_reduce(req[1], op=dist.ReduceOp.SUM, group=g)
+        elif kind == "alltoall_g":
+            _, recv, send, chunk, axis = req
+            ag, _, n, _ = self._axis(axis)
+            dist.all_to_all_single(recv[:n * chunk], send[:n * chunk], group=ag)
+        elif kind == "shift_g":
+            ops = []
+            for send, recv, direction, axis in req[1]:
+                _, me, n, members = self._axis(axis)
+                ops.append(dist.P2POp(dist.isend, send, _global_rank(g, members[(me + direction) % n]), group=g))
+                ops.append(dist.P2POp(dist.irecv, recv, _global_rank(g, members[(me - direction) % n]), group=g))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
         elif kind == "alltoall":
             n = self.pm.exchange_chunk_elems() * self.P
             dist.all_to_all_single(req[1][:n], req[2][:n], group=g)
@@ -87,7 +115,7 @@ class _SlabRank:
     # -- device tensors over a backend that only moves host memory (gloo): staged through the host, blocking.
     #    Lets the multi-rank code path run where RCCL cannot (e.g. every rank on one GPU); never used with nccl.
     def _host_staged(self, req):
-        t = req[1] if torch.is_tensor(req[1]) else (req[1][0][0] if req[0] == "shift" else None)
+        t = req[1] if torch.is_tensor(req[1]) else (req[1][0][0] if req[0] in ("shift", "shift_g") else None)
         return t is not None and t.is_cuda and dist.get_backend(self.group) == "gloo"
 
     def _communicate_staged(self, req):
@@ -97,6 +125,25 @@ class _SlabRank:
             h = req[1].cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=g)
             req[1].copy_(h)
+        elif kind == "alltoall_g":
+            _, recv, send, chunk, axis = req
+            ag, _, n, _ = self._axis(axis)
+            sh = send[:n * chunk].cpu()
+            rh = torch.empty_like(sh)
+            dist.all_to_all_single(rh, sh, group=ag)
+            recv[:n * chunk].copy_(rh)
+        elif kind == "shift_g":
+            ops, back = [], []
+            for send, recv, direction, axis in req[1]:
+                _, me, n, members = self._axis(axis)
+                hr = torch.empty(recv.shape, dtype=recv.dtype)
+                ops.append(dist.P2POp(dist.isend, send.cpu(), _global_rank(g, members[(me + direction) % n]), group=g))
+                ops.append(dist.P2POp(dist.irecv, hr, _global_rank(g, members[(me - direction) % n]), group=g))
+                back.append((recv, hr))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            for recv, hr in back:
+                recv.copy_(hr)
         elif kind in ("alltoall", "alltoall_start"):
             n = self.pm.exchange_chunk_elems() * self.P
             s = req[2][:n].cpu()
@@ -345,6 +392,164 @@ class SlabForce(_SlabRank):
         return delta_k if delta_k is not None else self.delta_k
 
 
+
+def make_axis_groups(Nx, Ny, rank, base_group=None):
+    """The row (same rank_x) and column (same rank_y) groups of rank `rank` on an Nx x Ny process mesh.  Collective:
+    every rank of `base_group` must call it (torch.distributed.new_group is)."""
+    to_global = (lambda r: r) if base_group is None or base_group is dist.group.WORLD else \
+        (lambda r: dist.get_global_rank(base_group, r))
+    rx, ry = rank // Ny, rank % Ny
+    row = col = None
+    for i in range(Nx):
+        g = dist.new_group([to_global(i * Ny + j) for j in range(Ny)])
+        if i == rx:
+            row = g
+    for j in range(Ny):
+        g = dist.new_group([to_global(i * Ny + j) for i in range(Nx)])
+        if j == ry:
+            col = g
+    return row, col
+
+
+class PencilForce(_SlabRank):
+    """fastpm_solver_compute_force (gravity.c:458-529) for rank (rank_x, rank_y) of an Nx x Ny process mesh -- the
+    reference's default decomposition (pmpfft.c:117-136: Nproc = {4, 2} for 8 ranks).  What differs from SlabForce:
+      * the particle ghosts become a mesh halo in x AND y (pmghosts.c:31-80 probes both): after the paint the extra x
+        plane goes to rank_x + 1 and then the extra y row to rank_y + 1 (the corner cell travels both hops); before the
+        readout the rows and planes come back in the opposite order;
+      * every transform needs TWO exchanges, as PFFT's does: "A" (y <-> kz) inside a row of Ny ranks between the z and
+        the y pass, "B" (x <-> ky) inside a column of Nx ranks between the y and the x pass.
+    The k-space half (softening, transfer, the fused x passes) is the slab code on a [x][ky_loc][kz_loc] block.
+    Requests: ("alltoall_g", recv, send, chunk_elems, axis) and ("shift_g", [(send, recv, direction, axis)]) with axis
+    "y" = my row, "x" = my column."""
+
+    def __init__(self, pm, group=None):
+        super().__init__(pm, group)
+        self.c = pm.alloc()
+        self.w = [pm.alloc() for _ in range(5)]
+        self.delta_k = None
+        L = pm.layout
+        self.tmp_plane = torch.zeros(int(L.plane_elems), dtype=self.c.dtype, device=self.c.device)
+        nrow = int(L.isize[0]) * (pm.Nmesh + 2)
+        self.row_s = torch.zeros(nrow, dtype=self.c.dtype, device=self.c.device)
+        self.row_r = torch.zeros(nrow, dtype=self.c.dtype, device=self.c.device)
+        self.scalar = torch.zeros(1, dtype=torch.float64, device=self.c.device)
+
+    def _a(self, recv, send):                     # exchange A: y <-> kz inside my row
+        if self.pm.nranks_y > 1:
+            yield ("alltoall_g", recv, send, int(self.pm.layout.chunk_a_elems), "y")
+        else:
+            recv.copy_(send)
+
+    def _b(self, recv, send):                     # exchange B: x <-> ky inside my column
+        if self.pm.nranks_x > 1:
+            yield ("alltoall_g", recv, send, int(self.pm.layout.chunk_b_elems), "x")
+        else:
+            recv.copy_(send)
+
+    def _halo_out(self, mesh):
+        """after the paint: x plane, then y row (pmghosts.c:247-307's reduction as mesh cells)"""
+        pm = self.pm
+        xl, ylr = int(pm.layout.isize[0]), int(pm.layout.isize[1])
+        if pm.nranks_x > 1:
+            yield ("shift_g", [(pm.plane(mesh, xl), self.tmp_plane, +1, "x")])
+            pm.plane_add(pm.plane(mesh, 0), self.tmp_plane)
+        if pm.nranks_y > 1:
+            pm.yrow(mesh, ylr, self.row_s, 0)
+            yield ("shift_g", [(self.row_s, self.row_r, +1, "y")])
+            pm.yrow(mesh, 0, self.row_r, 2)
+
+    def _halo_in(self, mesh):
+        """before a readout: y row, then x plane (which then carries the corner row)"""
+        pm = self.pm
+        xl, ylr = int(pm.layout.isize[0]), int(pm.layout.isize[1])
+        if pm.nranks_y > 1:
+            pm.yrow(mesh, 0, self.row_s, 0)
+            yield ("shift_g", [(self.row_s, self.row_r, -1, "y")])
+            pm.yrow(mesh, ylr, self.row_r, 1)
+        if pm.nranks_x > 1:
+            yield ("shift_g", [(pm.plane(mesh, 0), pm.plane(mesh, xl), -1, "x")])
+
+    def steps(self, store, kernel="1_4", dealias="none", delta_k=None):
+        pm = self.pm
+        kernel = _enum(KERNEL_TYPES, kernel)
+        dealias = _enum(SOFTENING_TYPES, dealias)
+        c, w = self.c, self.w
+        if delta_k is None:
+            if self.delta_k is None:
+                self.delta_k = pm.alloc()
+            delta_k = self.delta_k
+
+        self.scalar[0] = pm.total_mass(store)                              # gravity.c:330-342
+        yield ("allreduce", self.scalar)
+        mean_mass_per_cell = float(self.scalar.item()) / pm.Norm
+        pm.paint(c, store, 1.0 / mean_mass_per_cell)                       # gravity.c:336-345
+        yield from self._halo_out(c)
+
+        pm.fft_z_forward(c, w[0])                                          # gravity.c:351 pm_r2c
+        yield from self._a(w[1], w[0])
+        pm.fft_y_forward(w[1], w[0])
+        yield from self._b(delta_k, w[0])
+        fuse_x = dealias == 0
+        if not fuse_x:
+            pm.fft_x_forward(delta_k)
+            pm.apply_softening_transfer(dealias, delta_k)                  # gravity.c:476
+
+        if _gradorder(kernel) == 1:
+            # two meshes through the transposes: the x component and the potential (see SlabForce)
+            if fuse_x:
+                pm.fft_x_forward_transfer_backward(kernel, delta_k, 2, [w[0], w[1]])
+            else:
+                pm.transfer_fft_x_backward_potx(kernel, delta_k, w[0], w[1])
+            yield from self._b(w[2], w[1])                                 # potential
+            yield from self._b(w[3], w[0])                                 # x component
+            potmesh = w[4] if store.potential is not None else None       # gravity.c:487-492 rides along
+            pm.fft_y_backward_grad2(kernel, w[2], w[0], w[1], out_pot_a=potmesh)
+            pm.fft_y_backward(w[3], w[2])
+            # (x, y, z) in A layout: w[2], w[0], w[1]; real meshes: c, w[2], w[0]
+            yield from self._a(w[3], w[2])
+            pm.fft_z_backward(w[3], c)
+            yield from self._a(w[3], w[0])
+            pm.fft_z_backward(w[3], w[2])
+            yield from self._a(w[3], w[1])
+            pm.fft_z_backward(w[3], w[0])
+            meshes = [c, w[2], w[0]]
+            if potmesh is not None:
+                yield from self._a(w[3], potmesh)
+                pm.fft_z_backward(w[3], w[1])
+                meshes.append(w[1])
+        else:
+            # gravity.c:373-397 with the exact i k gradient: three components through the transposes
+            if fuse_x:
+                pm.fft_x_forward_transfer_backward(kernel, delta_k, 0, [w[0], w[1], w[2]])
+            else:
+                pm.transfer_fft_x_backward3(kernel, delta_k, [w[0], w[1], w[2]])
+            real = [c, w[0], w[1]]
+            for d in range(3):
+                yield from self._b(w[3], w[d])
+                pm.fft_y_backward(w[3], w[4])
+                yield from self._a(w[3], w[4])
+                pm.fft_z_backward(w[3], real[d])
+            meshes = list(real)
+            if store.potential is not None:
+                pm.gravity_apply_kernel_transfer(kernel, delta_k, w[2], FIELD_POTENTIAL)
+                pm.fft_x_backward(w[2])
+                yield from self._b(w[3], w[2])
+                pm.fft_y_backward(w[3], w[4])
+                yield from self._a(w[3], w[4])
+                pm.fft_z_backward(w[3], w[2])
+                meshes.append(w[2])
+        for f in meshes:
+            yield from self._halo_in(f)
+        pm.readout3(meshes[:3], store)
+        if store.potential is not None:
+            pm.readout(meshes[3], store, store.potential, 1, 0)
+
+    def compute_force(self, store, kernel="1_4", dealias="none", delta_k=None):
+        self.run(self.steps(store, kernel, dealias, delta_k))
+        return delta_k if delta_k is not None else self.delta_k
+
+
 class SlabTransforms(_SlabRank):
     """pm_r2c / pm_c2r (pmpfft.c:370-399) on x slabs as stand-alone calls: the (y,z) passes, one all-to-all, the x
     pass (and back).  r2c carries the 1 / Nmesh^3 like the reference's."""
@@ -585,6 +790,20 @@ def run_virtual_steps(forces, gens):
             for dst in range(P):
                 for src in range(P):
                     recvs[dst][src].copy_(sends[src][dst])
+        elif kind == "alltoall_g":
+            chunk, axis = reqs[0][3], reqs[0][4]
+            for dst in range(P):
+                _, me, n, members = forces[dst]._axis(axis)
+                for j, src in enumerate(members):
+                    reqs[dst][1][j * chunk:(j + 1) * chunk].copy_(reqs[src][2][me * chunk:(me + 1) * chunk])
+        elif kind == "shift_g":
+            nmsg = len(reqs[0][1])
+            for m in range(nmsg):
+                sends = [reqs[r][1][m][0].clone() for r in range(P)]
+                for r in range(P):
+                    _, direction, axis = reqs[r][1][m][1:]
+                    _, me, n, members = forces[r]._axis(axis)
+                    reqs[members[(me + direction) % n]][1][m][1].copy_(sends[r])
         elif kind == "wait":
             pass
         elif kind == "shift":

@@ -55,25 +55,28 @@ int fastpm_funck_init_from_string_hip(FastPMFuncKView *fk, const char *string)
     return 0;
 }
 
+/* Table lookup with the contract of fastpm_funck_eval (powerspectrum.c:391-425): f(0) = 1; the bracketing pair is found
+ * by bisection with the upper index moving on `k < k[m]`; between the pair the interpolation is linear in (log k, log f)
+ * when all four numbers are positive, linear in (k, f) otherwise; outside the table the end pair extrapolates. */
+static double lerp(double x, double x0, double x1, double y0, double y1)
+{
+    const double num = (x - x0) * y1 + (x1 - x) * y0;          /* this operation order is part of the contract */
+    return num / (x1 - x0);
+}
+
 double fastpm_funck_eval_hip(FastPMFuncKView *fk, double k)
 {
-    if (k == 0) return 1;                                       /* the 0 mode is ignored */
-    int l = 0, r = (int) fk->size - 1;
-    while (r - l > 1) {
-        int m = (r + l) / 2;
-        if (k < fk->k[m]) r = m; else l = m;
+    if (k == 0) return 1;
+    int lo = 0, hi = (int) fk->size - 1;
+    if (hi <= 0) return fk->f[0];
+    for (int mid = (lo + hi) / 2; hi - lo > 1; mid = (lo + hi) / 2) {
+        if (k < fk->k[mid]) hi = mid;
+        else lo = mid;
     }
-    double k2 = fk->k[r], k1 = fk->k[l], f2 = fk->f[r], f1 = fk->f[l];
-    if (l == r) return fk->f[l];
-    if (f1 <= 0 || f2 <= 0 || k1 == 0 || k2 == 0) {            /* linear where a logarithm does not exist */
-        double f = (k - k1) * f2 + (k2 - k) * f1;
-        f /= (k2 - k1);
-        return f;
-    }
-    k = log(k); f1 = log(f1); f2 = log(f2); k1 = log(k1); k2 = log(k2);
-    double f = (k - k1) * f2 + (k2 - k) * f1;
-    f /= (k2 - k1);
-    return exp(f);
+    const double k_lo = fk->k[lo], k_hi = fk->k[hi], f_lo = fk->f[lo], f_hi = fk->f[hi];
+    const int loglog = f_lo > 0 && f_hi > 0 && k_lo != 0 && k_hi != 0;
+    if (!loglog) return lerp(k, k_lo, k_hi, f_lo, f_hi);
+    return exp(lerp(log(k), log(k_lo), log(k_hi), log(f_lo), log(f_hi)));
 }
 
 void fastpm_powerspectrum_init_hip(FastPMPowerSpectrumView *ps, size_t size)
@@ -170,38 +173,42 @@ void fastpm_apply_decic_transfer_hip(PMView *pm, const void *from, void *to)
     fpmhip_free(d);
 }
 
+/* The dump the FORCE/AFTER handler writes (powerspectrum.c:149-168): one "k p N" row per bin, then the seven
+ * "# name value type" metadata rows in the order nbodykit's reader expects.  The strings ARE the file format. */
 void fastpm_powerspectrum_write_hip(FastPMPowerSpectrumView *ps, const char *filename, double N)
 {
-    FILE *fp = fopen(filename, "w");
-    if (!fp) {
+    FILE *out = fopen(filename, "w");
+    if (out == NULL) {
         fpm_raise_hip(-1, "cannot write the power spectrum to %s\n", filename);
         return;
     }
-    fprintf(fp, "# k p N \n");
-    for (size_t i = 0; i < ps->base.size; i++)
-        fprintf(fp, "%g %g %g\n", ps->base.k[i], ps->base.f[i], ps->Nmodes[i]);
-    const double *BoxSize = ps->pm->BoxSize;
-    fprintf(fp, "# metadata 7\n");
-    fprintf(fp, "# volume %g float64\n", ps->Volume);
-    fprintf(fp, "# shotnoise %g float64\n", ps->Volume / N);
-    fprintf(fp, "# N1 %g int\n", N);
-    fprintf(fp, "# N2 %g int\n", N);
-    fprintf(fp, "# Lz %g float64\n", BoxSize[2]);
-    fprintf(fp, "# Lx %g float64\n", BoxSize[0]);
-    fprintf(fp, "# Ly %g float64\n", BoxSize[1]);
-    fclose(fp);
+    fputs("# k p N \n", out);
+    const size_t nbins = ps->base.size;
+    for (size_t b = 0; b < nbins; b++) fprintf(out, "%g %g %g\n", ps->base.k[b], ps->base.f[b], ps->Nmodes[b]);
+    const struct { const char *fmt; double value; } meta[7] = {
+        {"# volume %g float64\n", ps->Volume},  {"# shotnoise %g float64\n", ps->Volume / N},
+        {"# N1 %g int\n", N},                   {"# N2 %g int\n", N},
+        {"# Lz %g float64\n", ps->pm->BoxSize[2]}, {"# Lx %g float64\n", ps->pm->BoxSize[0]},
+        {"# Ly %g float64\n", ps->pm->BoxSize[1]},
+    };
+    fprintf(out, "# metadata %d\n", 7);
+    for (int m = 0; m < 7; m++) fprintf(out, meta[m].fmt, meta[m].value);
+    fclose(out);
 }
 
+/* Mode-weighted mean power of the bins with k <= Nmax * k0 -- the number behind the log's "P(k<...)" line
+ * (powerspectrum.c:170-184).  Bin 0 is always included, whatever its k. */
 double fastpm_powerspectrum_large_scale_hip(FastPMPowerSpectrumView *ps, int Nmax)
 {
-    const double kmax = Nmax * ps->k0;
-    double Plin = 0, Nmodes = 0;
-    /* the first bin always counts (the zero mode itself was never binned) */
-    for (size_t i = 0; (i == 0) || (i < ps->base.size && ps->base.k[i] <= kmax); i++) {
-        Plin += ps->base.f[i] * ps->Nmodes[i];
-        Nmodes += ps->Nmodes[i];
+    const double kcut = Nmax * ps->k0;
+    size_t last = 0;                                            /* last bin that counts */
+    while (last + 1 < ps->base.size && ps->base.k[last + 1] <= kcut) last++;
+    double weighted = 0, modes = 0;
+    for (size_t b = 0; b <= last; b++) {
+        weighted += ps->base.f[b] * ps->Nmodes[b];
+        modes += ps->Nmodes[b];
     }
-    return Plin / Nmodes;
+    return weighted / modes;
 }
 
 double fastpm_powerspectrum_eval_hip(FastPMPowerSpectrumView *ps, double k)

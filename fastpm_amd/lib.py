@@ -14,7 +14,7 @@ class Geom(ctypes.Structure):
     _fields_ = [("Nmesh", ctypes.c_int64), ("BoxSize", ctypes.c_double), ("precision", ctypes.c_int32),
                 ("nranks", ctypes.c_int32), ("rank", ctypes.c_int32), ("device", ctypes.c_int32),
                 ("np_max", ctypes.c_int64), ("paint_mode", ctypes.c_int32), ("fft_mode", ctypes.c_int32),
-                ("gradient_mode", ctypes.c_int32)]
+                ("gradient_mode", ctypes.c_int32), ("nranks_y", ctypes.c_int32)]
 
 
 class Layout(ctypes.Structure):
@@ -24,7 +24,10 @@ class Layout(ctypes.Structure):
                 ("ihalo", ctypes.c_int64), ("plane_elems", ctypes.c_int64),
                 ("ostart", ctypes.c_int64 * 3), ("osize", ctypes.c_int64 * 3), ("ostrides", ctypes.c_int64 * 3),
                 ("real_elems", ctypes.c_int64), ("complex_elems", ctypes.c_int64),
-                ("allocsize", ctypes.c_int64), ("Norm", ctypes.c_double)]
+                ("allocsize", ctypes.c_int64), ("Norm", ctypes.c_double),
+                ("nranks_x", ctypes.c_int32), ("nranks_y", ctypes.c_int32), ("rank_x", ctypes.c_int32),
+                ("rank_y", ctypes.c_int32), ("ihalo_y", ctypes.c_int64), ("ovalid_z", ctypes.c_int64),
+                ("chunk_a_elems", ctypes.c_int64), ("chunk_b_elems", ctypes.c_int64)]
 
 
 class Particles(ctypes.Structure):
@@ -74,6 +77,12 @@ SYMBOLS = {
     "fpmhip_fft_x_forward": (_I, [_P, _P]),
     "fpmhip_fft_x_backward": (_I, [_P, _P]),
     "fpmhip_fft_yz_backward": (_I, [_P, _P, _P]),
+    "fpmhip_fft_z_forward": (_I, [_P, _P, _P]),
+    "fpmhip_fft_y_forward": (_I, [_P, _P, _P]),
+    "fpmhip_fft_y_backward": (_I, [_P, _P, _P]),
+    "fpmhip_fft_y_backward_grad2": (_I, [_P, _P, _P, _P, _P, _I]),
+    "fpmhip_fft_z_backward": (_I, [_P, _P, _P]),
+    "fpmhip_yrow": (_I, [_P, _P, _I64, _P, _I]),
     "fpmhip_softening": (_I, [_P, _P, _I]),
     "fpmhip_transfer": (_I, [_P, _P, _P, _I, _I]),
     "fpmhip_transfer_fft_x_backward3": (_I, [_P, _P, _P, _P, _P, _I]),

@@ -355,7 +355,7 @@ class PM:
     """One rank's particle mesh on one MI355X (struct PM + its plans)."""
 
     def __init__(self, Nmesh, BoxSize, precision=64, nranks=1, rank=0, device=None, np_max=0,
-                 paint_mode=PAINT_TILED, fft_mode=FFT_AUTO, gradient_mode=GRADIENT_KSPACE):
+                 paint_mode=PAINT_TILED, fft_mode=FFT_AUTO, gradient_mode=GRADIENT_KSPACE, nranks_y=1):
         self._L = _lib.load_library()
         self._plan = ctypes.c_void_p()
         if not torch.cuda.is_available():
@@ -364,7 +364,7 @@ class PM:
             device = torch.cuda.current_device()
         self.device = torch.device("cuda", int(device))
         g = _lib.Geom(int(Nmesh), float(BoxSize), int(precision), int(nranks), int(rank), int(self.device.index),
-                      int(np_max), int(paint_mode), int(fft_mode), int(gradient_mode))
+                      int(np_max), int(paint_mode), int(fft_mode), int(gradient_mode), int(nranks_y))
         self.gradient_mode = int(gradient_mode)
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream().cuda_stream
@@ -373,6 +373,8 @@ class PM:
         check(self._L.fpmhip_plan_layout(self._plan, ctypes.byref(self.layout)))
         self.Nmesh, self.BoxSize, self.precision = int(Nmesh), float(BoxSize), int(precision)
         self.nranks, self.rank = int(nranks), int(rank)
+        self.nranks_y, self.nranks_x = int(self.layout.nranks_y), int(self.layout.nranks_x)
+        self.rank_x, self.rank_y = int(self.layout.rank_x), int(self.layout.rank_y)
         self.dtype = torch.float64 if precision == 64 else torch.float32
         self.allocsize = int(self.layout.allocsize)
         self.Norm = float(self.layout.Norm)
@@ -402,10 +404,10 @@ class PM:
 
     # ---- views for tests / host handlers
     def real_view(self, buf):
-        """[x_loc (+halo)][y][N+2] view of a real-space mesh."""
+        """[x_loc (+halo)][y_loc (+halo)][N+2] view of a real-space mesh."""
         L = self.layout
         nx = L.isize[0] + L.ihalo
-        return buf[: nx * L.plane_elems].view(nx, self.Nmesh, self.Nmesh + 2)
+        return buf[: nx * L.plane_elems].view(nx, L.isize[1] + L.ihalo_y, self.Nmesh + 2)
 
     def complex_view(self, buf):
         """[x][y_loc][kz] complex view of a k-space mesh (fpmhip_layout.ostrides)."""
@@ -565,6 +567,28 @@ class PM:
 
     def fft_yz_backward(self, recv, canvas):
         check(self._L.fpmhip_fft_yz_backward(self._plan, _ptr(recv), _ptr(canvas)))
+
+    # ---- pencil stages (nranks_y > 1; they also work on slabs, where exchange A is the identity)
+    def fft_z_forward(self, canvas, send_a):
+        check(self._L.fpmhip_fft_z_forward(self._plan, _ptr(canvas), _ptr(send_a)))
+
+    def fft_y_forward(self, recv_a, send_b):
+        check(self._L.fpmhip_fft_y_forward(self._plan, _ptr(recv_a), _ptr(send_b)))
+
+    def fft_y_backward(self, recv_b, send_a):
+        check(self._L.fpmhip_fft_y_backward(self._plan, _ptr(recv_b), _ptr(send_a)))
+
+    def fft_y_backward_grad2(self, kernel, recv_b, out_y_a, out_z_a, out_pot_a=None):
+        check(self._L.fpmhip_fft_y_backward_grad2(self._plan, _ptr(recv_b), _ptr(out_y_a), _ptr(out_z_a),
+                                                  _ptr(out_pot_a) if out_pot_a is not None else None,
+                                                  _enum(KERNEL_TYPES, kernel)))
+
+    def fft_z_backward(self, recv_a, canvas):
+        check(self._L.fpmhip_fft_z_backward(self._plan, _ptr(recv_a), _ptr(canvas)))
+
+    def yrow(self, mesh, iy, buf, mode):
+        """mode 0 pack, 1 unpack, 2 add: row iy of the planes [0, isize[0]) <-> buf[isize[0] * (N + 2)]"""
+        check(self._L.fpmhip_yrow(self._plan, _ptr(mesh), int(iy), _ptr(buf), int(mode)))
 
     def ranged_fft(self):
         return bool(self._L.fpmhip_plan_ranged_fft(self._plan))

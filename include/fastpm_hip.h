@@ -80,6 +80,12 @@ typedef struct {
     int32_t paint_mode;   /* FPMHIP_PAINT_* */
     int32_t fft_mode;     /* FPMHIP_FFT_* */
     int32_t gradient_mode; /* FPMHIP_GRADIENT_* */
+    /* Process mesh Nproc = {nranks / nranks_y, nranks_y} (pmpfft.c:117-136; solver.h:71 NprocY): 0 or 1 = x slabs;
+     * > 1 = pencils, rank = rx * nranks_y + ry as MPI_Cart_create lays them out: the real mesh is split in x over
+     * Nproc[0] and in y over Nproc[1], the complex mesh [x][y_loc][kz_loc] in ky over Nproc[0] and in kz over
+     * Nproc[1] (the reference's ORegion, pmpfft.c:189-203, with x and z swapped; kz blocks of ceil((N/2+1) / Ny),
+     * the last one padded).  Nmesh must be divisible by both. */
+    int32_t nranks_y;
 } fpmhip_geom;
 
 /* What struct PM exposes to the hot path (pmpfft.h:43-70, pmapi.h:3-9).  Real strides are in
@@ -89,13 +95,19 @@ typedef struct {
     double  BoxSize;
     int32_t precision, nranks, rank, gradient_mode;   /* as given in fpmhip_geom */
     int64_t istart[3], isize[3], istrides[3];   /* IRegion; isize excludes z padding and halo */
-    int64_t ihalo;          /* extra x planes after the local slab (0 if nranks == 1, else 1) */
-    int64_t plane_elems;    /* reals in one x plane = Nmesh * (Nmesh + 2) */
+    int64_t ihalo;          /* extra x planes after the local slab (0 if Nproc[0] == 1, else 1) */
+    int64_t plane_elems;    /* reals in one x plane = (isize[1] + ihalo_y) * (Nmesh + 2) */
     int64_t ostart[3], osize[3], ostrides[3];   /* ORegion: [x][y_loc][kz], kz fastest */
     int64_t real_elems;     /* reals used by a real-space mesh incl. halo plane */
     int64_t complex_elems;  /* complex numbers in a k-space mesh */
     int64_t allocsize;      /* FastPMFloat elements every mesh buffer must hold */
     double  Norm;           /* Nmesh^3 (pmpfft.c:146-154) */
+    /* pencils (all equal to the slab values when nranks_y <= 1) */
+    int32_t nranks_x, nranks_y, rank_x, rank_y;
+    int64_t ihalo_y;        /* extra y rows after the local rows of every x plane (0 if nranks_y == 1, else 1) */
+    int64_t ovalid_z;       /* kz entries of osize[2] that are modes (the last kz block is padded to osize[2]) */
+    int64_t chunk_a_elems;  /* FastPMFloat elements per pair in the (y <-> kz) exchange inside a row of Nproc[1] ranks */
+    int64_t chunk_b_elems;  /* ... in the (x <-> ky) exchange inside a column of Nproc[0] ranks (= the slab exchange) */
 } fpmhip_layout;
 
 /* The columns of FastPMStore the force step reads and writes (api/fastpm/store.h:62-135). */
@@ -185,6 +197,29 @@ int fpmhip_fft_yz_forward(fpmhip_plan *plan, void *canvas_dev, void *send_dev);
 int fpmhip_fft_x_forward(fpmhip_plan *plan, void *recv_inplace_dev);
 int fpmhip_fft_x_backward(fpmhip_plan *plan, void *inplace_dev);
 int fpmhip_fft_yz_backward(fpmhip_plan *plan, void *recv_dev, void *canvas_dev);
+
+/* Pencils (fpmhip_geom.nranks_y > 1; the reference's default process mesh, pmpfft.c:117-136): TWO exchanges per
+ * transform, as PFFT does -- "A" swaps y and kz inside a row of Nproc[1] ranks (same x range), "B" swaps x and ky inside
+ * a column of Nproc[0] ranks (same kz range).  The (y, z) passes are separate stage calls around exchange A:
+ *   forward : fft_z_forward(canvas -> send_a) ; A ; fft_y_forward(recv_a -> send_b) ; B ; fft_x_forward / the fused form
+ *   backward: x backward (any of the fused forms) ; B ; fft_y_backward(recv_b -> send_a) ; A ; fft_z_backward(recv_a -> canvas)
+ * Exchange buffers: A = nranks_y chunks of layout.chunk_a_elems, chunk r to / from the rank with rank_y = r of the row;
+ * B = nranks_x chunks of layout.chunk_b_elems (= fpmhip_exchange_chunk_elems), chunk r to / from rank_x = r of the
+ * column.  With nranks_y = 1 exchange A is the identity (recv_a = send_a) and these calls equal fft_yz_*. */
+int fpmhip_fft_z_forward(fpmhip_plan *plan, void *canvas_dev, void *send_a_dev);
+int fpmhip_fft_y_forward(fpmhip_plan *plan, void *recv_a_dev, void *send_b_dev);
+int fpmhip_fft_y_backward(fpmhip_plan *plan, void *recv_b_dev, void *send_a_dev);
+int fpmhip_fft_y_backward_grad2(fpmhip_plan *plan, void *recv_b_dev, void *out_y_a_dev, void *out_z_a_dev,
+                                void *out_pot_a_dev, int kernel);
+int fpmhip_fft_z_backward(fpmhip_plan *plan, void *recv_a_dev, void *canvas_dev);
+/* Pencil halo in y (the y half of pm_ghosts_create / pm_ghosts_reduce, pmghosts.c:31-80, 247-307, as mesh rows): row
+ * `iy` of the planes [0, isize[0]) of a real mesh <-> a contiguous buffer of isize[0] * (Nmesh + 2) values.
+ * mode 0: pack (buffer = row), 1: unpack (row = buffer), 2: add (row += buffer).
+ *   after the paint : x first -- plane isize[0] (all rows) to rank_x + 1, added to its plane 0 (fpmhip_plane_add);
+ *                     then row isize[1] of the planes [0, isize[0]) to rank_y + 1, added to its row 0;
+ *   before a readout: y first -- row 0 from rank_y + 1 into row isize[1]; then plane 0 (with that row) from rank_x + 1
+ *                     into plane isize[0]. */
+int fpmhip_yrow(fpmhip_plan *plan, void *mesh_dev, int64_t iy, void *buf_dev, int mode);
 
 /* apply_softening_transfer (gravity.c:244-270), in place on delta_k */
 int fpmhip_softening(fpmhip_plan *plan, void *delta_k_dev, int softening);

@@ -107,7 +107,7 @@ def test_unowned_particle_is_an_error():
     N, L, P = 32, 48.0, 2
     pm = PM(N, L, 64, nranks=P, rank=0)
     st = Store(np.array([[L * 0.75, 1.0, 1.0]]))        # belongs to rank 1
-    with pytest.raises(FastPMHipError, match="outside this rank's slab"):
+    with pytest.raises(FastPMHipError, match="outside this rank's region"):
         pm.paint(pm.alloc(), st, 1.0)
     pm.destroy()
 
