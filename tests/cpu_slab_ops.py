@@ -281,3 +281,146 @@ class CpuSlabOps:
             ctypes.byref(self.g), int(kernel), O._p(delta_k.numpy()), O._p(out.numpy()),
             int(field == 3), int(field if field < 3 else 0))
         assert rc == 0
+
+
+class CpuPencilOps(CpuSlabOps):
+    """The same stand-in for rank (rx, ry) of an Nx x Ny process mesh (fastpm_amd.distributed.PencilForce): real
+    mesh [x_loc + halo][y_loc + halo][N + 2]; exchange A chunks [ry'][x_loc][y_loc][kz_loc]; exchange B chunks
+    [rx'][x_loc][ky_loc][kz_loc]; k-space block [x][ky_loc][kz_loc] with the last kz block padded."""
+
+    def __init__(self, Nmesh, BoxSize, nranks, rank, nranks_y, precision=64):
+        super().__init__(Nmesh, BoxSize, nranks, rank, precision)
+        N = self.Nmesh
+        Ny = self.nranks_y = int(nranks_y)
+        Nx = self.nranks_x = nranks // Ny
+        assert Nx * Ny == nranks and N % Nx == 0 and N % Ny == 0
+        self.rank_x, self.rank_y = rank // Ny, rank % Ny
+        self.xl = self.yl = N // Nx
+        self.ylr = N // Ny
+        self.nzl = -(-self.nzc // Ny)
+        self.nzv = max(0, min(self.nzl, self.nzc - self.rank_y * self.nzl))
+        hx, hy = int(Nx > 1), int(Ny > 1)
+        L = self.layout
+        L.isize = [self.xl, self.ylr, N]
+        L.ihalo, L.ihalo_y = hx, hy
+        L.plane_elems = (self.ylr + hy) * (N + 2)
+        L.real_elems = (self.xl + hx) * L.plane_elems
+        L.complex_elems = N * self.yl * self.nzl
+        L.chunk_a_elems = 2 * self.xl * self.ylr * self.nzl
+        L.chunk_b_elems = 2 * self.xl * self.yl * self.nzl
+        L.ovalid_z = self.nzv
+        self.allocsize = max(L.real_elems, 2 * L.complex_elems, Ny * L.chunk_a_elems)
+        g = self.g
+        g.ostart[:] = [0, self.rank_x * self.yl, self.rank_y * self.nzl]
+        g.osize[:] = [N, self.yl, self.nzv]
+        g.ostrides[:] = [self.yl * self.nzl, self.nzl, 1]
+        g.allocsize = self.allocsize
+
+    def exchange_chunk_elems(self):
+        return self.layout.chunk_b_elems
+
+    def _real(self, buf):
+        L = self.layout
+        nx, ny = self.xl + L.ihalo, self.ylr + L.ihalo_y
+        return buf.numpy()[: nx * L.plane_elems].reshape(nx, ny, self.Nmesh + 2)
+
+    def _cic(self, store):
+        N = self.Nmesh
+        inv = 1.0 / (self.BoxSize / N)
+        X = store.x.numpy() * inv
+        I = np.floor(X).astype(np.int64)
+        D = X - I
+        T = 1.0 - D
+        I0 = np.mod(I, N)
+        ix0 = I0[:, 0] - self.rank_x * self.xl
+        iy0 = I0[:, 1] - self.rank_y * self.ylr
+        assert ((ix0 >= 0) & (ix0 < self.xl) & (iy0 >= 0) & (iy0 < self.ylr)).all(), "particle outside its pencil"
+        ix = [ix0, ix0 + 1] if self.nranks_x > 1 else [ix0, np.mod(ix0 + 1, N)]
+        iy = [iy0, iy0 + 1] if self.nranks_y > 1 else [iy0, np.mod(iy0 + 1, N)]
+        iz = [I0[:, 2], np.mod(I0[:, 2] + 1, N)]
+        return ix, iy, iz, [T, D]
+
+    def yrow(self, mesh, iy, buf, mode):
+        m = self._real(mesh)[: self.xl, iy, :]
+        b = buf.numpy()[: self.xl * (self.Nmesh + 2)].reshape(self.xl, self.Nmesh + 2)
+        if mode == 0:
+            b[...] = m
+        elif mode == 1:
+            m[...] = b
+        else:
+            m += b
+
+    def decompose_order(self, store):
+        tgt = O.pos_to_rank(self.Nmesh, self.BoxSize, (self.nranks_x, self.nranks_y), store.x.numpy())
+        key = np.where(tgt == self.rank, 0, tgt + 1)
+        order = np.argsort(key, kind="stable").astype(np.int32)
+        counts = np.bincount(key, minlength=self.nranks + 1)
+        return torch.from_numpy(order), [int(c) for c in counts]
+
+    # ---- FFT stages: z | exchange A | y | exchange B | x
+    def _pad_z(self, a):
+        """[..., nzc] -> [Ny][..., nzl] kz blocks, the last one zero padded"""
+        Ny, nzl = self.nranks_y, self.nzl
+        out = np.zeros((Ny,) + a.shape[:-1] + (nzl,), dtype=self.C)
+        for r in range(Ny):
+            blk = a[..., r * nzl:(r + 1) * nzl]
+            out[r][..., : blk.shape[-1]] = blk
+        return out
+
+    def fft_z_forward(self, canvas, send_a):
+        N, xl, ylr = self.Nmesh, self.xl, self.ylr
+        a = scipy.fft.rfft(self._real(canvas)[:xl, :ylr, :N], axis=2)
+        self._cplx(send_a, (self.nranks_y, xl, ylr, self.nzl))[...] = self._pad_z(a)
+
+    def _natural_a(self, recv_a):
+        """[ry'][x_loc][y_loc][kz_loc] -> [x_loc][y][kz_loc]"""
+        r_ = self._cplx(recv_a, (self.nranks_y, self.xl, self.ylr, self.nzl))
+        return np.concatenate([r_[s] for s in range(self.nranks_y)], axis=1)
+
+    def _natural_b(self, recv_b):
+        """[rx'][x_loc][ky_loc][kz_loc] -> [x_loc][ky][kz_loc]"""
+        r_ = self._cplx(recv_b, (self.nranks_x, self.xl, self.yl, self.nzl))
+        return np.concatenate([r_[s] for s in range(self.nranks_x)], axis=1)
+
+    def _store_a(self, a, out_a):
+        o = self._cplx(out_a, (self.nranks_y, self.xl, self.ylr, self.nzl))
+        for r in range(self.nranks_y):
+            o[r] = a[:, r * self.ylr:(r + 1) * self.ylr, :]
+
+    def fft_y_forward(self, recv_a, send_b):
+        a = scipy.fft.fft(self._natural_a(recv_a).copy(), axis=1)
+        s = self._cplx(send_b, (self.nranks_x, self.xl, self.yl, self.nzl))
+        for r in range(self.nranks_x):
+            s[r] = a[:, r * self.yl:(r + 1) * self.yl, :]
+
+    def fft_y_backward(self, recv_b, send_a):
+        a = scipy.fft.ifft(self._natural_b(recv_b).copy(), axis=1, norm="forward")
+        self._store_a(a, send_a)
+
+    def fft_y_backward_grad2(self, kernel, recv_b, out_y_a, out_z_a, out_pot_a=None):
+        assert O.kernel_orders(int(kernel))[1] == 1
+        kf = O.k_tables(self.Nmesh, self.BoxSize)["k_finite"].astype(np.float64)
+        a = self._natural_b(recv_b).copy()
+        z0 = self.rank_y * self.nzl
+        kfz = np.zeros(self.nzl)
+        kfz[: self.nzv] = kf[z0:z0 + self.nzv]
+        for out, fac in ((out_y_a, kf[None, :, None]), (out_z_a, kfz[None, None, :])):
+            v = (1j * a * fac).astype(self.C)
+            self._store_a(scipy.fft.ifft(v, axis=1, norm="forward"), out)
+        if out_pot_a is not None:
+            self._store_a(scipy.fft.ifft(a, axis=1, norm="forward"), out_pot_a)
+
+    def fft_z_backward(self, recv_a, canvas):
+        N, xl, ylr, nzl = self.Nmesh, self.xl, self.ylr, self.nzl
+        r_ = self._cplx(recv_a, (self.nranks_y, xl, ylr, nzl))
+        a = np.concatenate([r_[s] for s in range(self.nranks_y)], axis=2)[:, :, : self.nzc]
+        canvas.zero_()
+        self._real(canvas)[:xl, :ylr, :N] = scipy.fft.irfft(a, n=N, axis=2, norm="forward")
+
+    def fft_x_forward(self, recv):
+        v = self._cplx(recv, (self.Nmesh, self.yl, self.nzl))
+        v[...] = scipy.fft.fft(v, axis=0) * (1.0 / self.Norm)
+
+    def fft_x_backward(self, buf):
+        v = self._cplx(buf, (self.Nmesh, self.yl, self.nzl))
+        v[...] = scipy.fft.ifft(v, axis=0, norm="forward")

@@ -177,3 +177,50 @@ def test_slab_decompose_over_gloo_matches_reference_order(oracle, tmp_path, worl
         assert int(d["np"]) == len(ref[r]["x"])
         for name in ("x", "v", "id"):
             assert np.array_equal(d[name], ref[r][name]), (r, name)
+
+
+def _pencil_worker(rank, world, port, N, L, x, out_dir, Ny, kernel, dealias):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from cpu_slab_ops import CpuPencilOps
+    from fastpm_amd.distributed import PencilForce
+    from fastpm_amd.pm import Store
+    Nx = world // Ny
+    h = L / N
+    own = ((np.floor(x[:, 0] / h).astype(np.int64) % N) // (N // Nx)) * Ny + (np.floor(x[:, 1] / h).astype(np.int64) % N) // (N // Ny)
+    idx = np.nonzero(own == rank)[0]
+    ops = CpuPencilOps(N, L, world, rank, Ny)
+    store = Store(x[idx], potential=True, device="cpu")
+    force = PencilForce(ops, dist.group.WORLD)
+    dk = force.compute_force(store, kernel=kernel, dealias=dealias)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), idx=idx, acc=store.acc.numpy(), pot=store.potential.numpy(),
+             dk=ops._cplx(dk, (N, ops.yl, ops.nzl))[:, :, : ops.nzv], y0=ops.rank_x * ops.yl, z0=ops.rank_y * ops.nzl)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,Ny,kernel,dealias", [(4, 2, "1_4", "none"), (4, 2, "3_2", "gaussian"), (2, 2, "1_4", "none"),
+                                                     (8, 2, "1_4", "none")])
+def test_pencil_force_over_gloo_matches_one_rank_oracle(oracle, tmp_path, world, Ny, kernel, dealias):
+    """fastpm_amd.distributed.PencilForce on an Nx x Ny process mesh (2 x 2; 1 x 2; the reference's 4 x 2 for 8 ranks,
+    pmpfft.c:117-136) over torch.distributed: the row / column sub-groups (new_group), the (y <-> kz) and (x <-> ky)
+    all-to-alls inside them, the x-plane and y-row halo hops incl. the corner cell, the mass all-reduce."""
+    N, nc, L = 16, 8, 24.0
+    x = util.load_b(nc, L, N, rms_cells=2.0)
+    pmo = oracle.PMOracle(N, L, 64)
+    ref = oracle.compute_force(pmo, x, kernel=oracle.KERNELS[kernel], softening=oracle.SOFTENINGS[dealias], potential=True)
+    mp.spawn(_pencil_worker, args=(world, _free_port(), N, L, x, str(tmp_path), Ny, kernel, dealias), nprocs=world, join=True)
+    acc = np.zeros_like(ref["acc"])
+    pot = np.zeros_like(ref["potential"])
+    dk = np.zeros((N, N, N // 2 + 1), dtype=np.complex128)
+    for r in range(world):
+        d = np.load(tmp_path / ("rank%d.npz" % r))
+        acc[d["idx"]] = d["acc"]
+        pot[d["idx"]] = d["pot"]
+        b = d["dk"]
+        dk[:, int(d["y0"]):int(d["y0"]) + b.shape[1], int(d["z0"]):int(d["z0"]) + b.shape[2]] = b
+    assert util.max_err(dk, util.oracle_k_to_xyk(pmo, ref["delta_k"])) <= 1e-13
+    assert util.rel_err(acc, ref["acc"]) <= 1e-6
+    assert util.rel_err(pot, ref["potential"]) <= 1e-6
