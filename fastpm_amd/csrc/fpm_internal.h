@@ -56,7 +56,7 @@ constexpr int TILE_CELLS = TILE_X * TILE_Y * TILE_Z;
 // clump puts thousands of particles into a few tiles and their atomics serialise per ADDRESS at the memory side.
 constexpr int BIN_PRIV = 8;
 
-enum { BUF_CANVAS = 0, BUF_DELTA_K, BUF_F0, BUF_F1, BUF_F2, BUF_XCHG, BUF_COUNT };
+enum { BUF_CANVAS = 0, BUF_DELTA_K, BUF_F0, BUF_F1, BUF_F2, BUF_XCHG, BUF_XCHG2, BUF_COUNT };
 
 // Geometry handed to kernels by value.
 struct MeshGeo {

@@ -5,7 +5,11 @@
  * fastpm_hip_slab_force with the MPI transport (fastpm_slab_mpi.c).
  *
  *   make mpi            (in this directory: needs mpi.h / libmpi, e.g. MPICH under /opt/conda)
- *   mpiexec -n P ./example_slab_mpi [nc] [B] [precision] [gradient_mode] [gpu_aware] [host_columns] [decompose]
+ *   mpiexec -n P ./example_slab_mpi [nc] [B] [precision] [gradient_mode] [gpu_aware] [host_columns] [decompose] [nprocy]
+ *
+ * nprocy > 1: the reference's pencil process mesh Nproc = {P / nprocy, nprocy} (pmpfft.c:117-136; its default for 8
+ * ranks is 4 x 2): every rank owns the particles whose (x, y) cell lies in its pencil and the force goes through
+ * fastpm_hip_mesh_force_species (x plane + y row halo, two exchanges per transform).
  *
  * decompose = 1: the particles start on the WRONG ranks (particle i on rank i mod P) with an id and a velocity
  * column beside x, and fastpm_hip_slab_decompose (fastpm_decompose, solver.c:571-592) brings every row to the rank
@@ -29,6 +33,12 @@
 #define CHECK(expr) do { if ((expr) != 0) { fprintf(stderr, "rank %d: %s failed: %s\n", rank, #expr, fpmhip_last_error()); \
                                             MPI_Abort(MPI_COMM_WORLD, 1); } } while (0)
 
+static int cell_of(double pos, double inv_cell, int N)
+{
+    int c = (int) floor(pos * inv_cell);
+    return c >= N ? c - N : c;
+}
+
 /* Every function of a transport on small device buffers with a known pattern: value (sender, receiver, row). */
 static int transport_selftest(const fastpm_hip_transport *t, fpmhip_plan *plan)
 {
@@ -47,6 +57,13 @@ static int transport_selftest(const fastpm_hip_transport *t, fpmhip_plan *plan)
     if (t->sendrecv(t->ctx, ds, (r + 1) % P, dr, (r + P - 1) % P, n * sizeof(double))) bad++;
     fpmhip_memcpy_d2h(plan, g, dr, n * sizeof(double));
     for (int i = 0; i < n; i++) if (g[i] != 1e6 * ((r + P - 1) % P) + i) { bad++; break; }
+    if (t->alltoall_members && P % 2 == 0) {
+        /* groups of two neighbours (2 j, 2 j + 1): what a row of a (P / 2) x 2 process mesh is */
+        const int members[2] = {r - r % 2, r - r % 2 + 1}, me = r % 2;
+        if (t->alltoall_members(t->ctx, ds, dr, n * sizeof(double), members, 2, me)) bad++;
+        fpmhip_memcpy_d2h(plan, g, dr, (size_t) 2 * n * sizeof(double));
+        for (int q = 0; q < 2; q++) for (int i = 0; i < n; i++) if (g[q * n + i] != 1e6 * members[q] + 1e3 * me + i) { bad++; break; }
+    }
     if (t->alltoall_counts && t->alltoallv) {
         int64_t *sc = malloc((size_t) 2 * P * sizeof(int64_t)), *rc = sc + P;
         for (int q = 0; q < P; q++) sc[q] = (r + 2 * q) % 5;             /* uneven, some zero */
@@ -82,9 +99,11 @@ int main(int argc, char **argv)
     const int gpu_aware = argc > 5 ? atoi(argv[5]) : 0;
     const int host_columns = argc > 6 ? atoi(argv[6]) : 0;
     const int decompose = argc > 7 ? atoi(argv[7]) : 0;
+    const int nprocy = argc > 8 && atoi(argv[8]) > 1 ? atoi(argv[8]) : 1;
+    const int nprocx = P / nprocy;
     const int Nmesh = nc * B;
     const double BoxSize = 3.0 * nc;
-    if (Nmesh % P) {
+    if (P % nprocy || Nmesh % nprocx || Nmesh % nprocy) {
         if (rank == 0) fprintf(stderr, "PM mesh is not divided by the process mesh.\n");      /* vpm.c:45-53 */
         MPI_Abort(MPI_COMM_WORLD, 1);
     }
@@ -97,6 +116,7 @@ int main(int argc, char **argv)
     g.rank = rank;
     g.device = rank % (fpmhip_device_count() > 0 ? fpmhip_device_count() : 1);
     g.gradient_mode = gradient_mode;
+    g.nranks_y = nprocy;
     fpmhip_plan *plan = NULL;
     CHECK(fpmhip_plan_create(&g, NULL, &plan));
     fastpm_hip_transport *t = gpu_aware == 2 ? fastpm_hip_rccl_transport_create(MPI_COMM_WORLD, g.device)
@@ -109,18 +129,18 @@ int main(int argc, char **argv)
     double (*x)[3] = malloc(ntot * sizeof(*x));
     long long *id = malloc(ntot * sizeof(*id));
     const double h = BoxSize / nc, A = 0.35 * h, k = 2 * M_PI / BoxSize, inv_cell = 1.0 / (BoxSize / Nmesh);
-    const int xl = Nmesh / P;
+    const int xl = Nmesh / nprocx, ylr = Nmesh / nprocy;
+#define OWNER(px_, py_) ((cell_of((px_), inv_cell, Nmesh) / xl) * nprocy + (nprocy > 1 ? cell_of((py_), inv_cell, Nmesh) / ylr : 0))
     size_t np = 0, i = 0;
     for (int ix = 0; ix < nc; ix++)
         for (int iy = 0; iy < nc; iy++)
             for (int iz = 0; iz < nc; iz++, i++) {
                 const double q[3] = {(ix + 0.5) * h, (iy + 0.5) * h, (iz + 0.5) * h};
                 const double px = fmod(q[0] + A * sin(2 * k * q[0]) * cos(k * q[1]) + BoxSize, BoxSize);
-                int cell = (int) floor(px * inv_cell);
-                if (cell >= Nmesh) cell -= Nmesh;
-                if (decompose ? (int) (i % (size_t) P) != rank : cell / xl != rank) continue;
+                const double py = fmod(q[1] + A * sin(3 * k * q[1]) * cos(k * q[2]) + BoxSize, BoxSize);
+                if (decompose ? (int) (i % (size_t) P) != rank : OWNER(px, py) != rank) continue;
                 x[np][0] = px;
-                x[np][1] = fmod(q[1] + A * sin(3 * k * q[1]) * cos(k * q[2]) + BoxSize, BoxSize);
+                x[np][1] = py;
                 x[np][2] = fmod(q[2] + A * sin(k * q[2]) * cos(2 * k * q[0]) + BoxSize, BoxSize);
                 id[np++] = (long long) i;
             }
@@ -146,11 +166,8 @@ int main(int argc, char **argv)
         CHECK(fpmhip_memcpy_d2h(plan, id, cid, np * sizeof(long long)));
         CHECK(fpmhip_memcpy_d2h(plan, v, cv, np * 3 * sizeof(float)));
         size_t bad = 0;
-        for (i = 0; i < np; i++) {
-            int cell = (int) floor(x[i][0] * inv_cell);
-            if (cell >= Nmesh) cell -= Nmesh;
-            if (cell / xl != rank || v[i][0] != (float) id[i] || v[i][1] != (float) id[i] + 0.5f || v[i][2] != -(float) id[i]) bad++;
-        }
+        for (i = 0; i < np; i++)
+            if (OWNER(x[i][0], x[i][1]) != rank || v[i][0] != (float) id[i] || v[i][1] != (float) id[i] + 0.5f || v[i][2] != -(float) id[i]) bad++;
         printf("decomposed %d np %zu bad %zu\n", rank, np, bad);
         free(v);
         fpmhip_free(cx); fpmhip_free(cid); fpmhip_free(cv);
@@ -167,7 +184,8 @@ int main(int argc, char **argv)
         void *delta_k = malloc((size_t) lay.allocsize * (precision / 8));       /* pm_alloc */
         part.x = &x[0][0];
         part.acc = &acc[0][0];
-        CHECK(fastpm_hip_slab_force_host(plan, t, &part, FASTPM_KERNEL_1_4, FASTPM_SOFTENING_NONE, delta_k));
+        CHECK(fastpm_hip_mesh_force_species_host(plan, t, &part, 1, FASTPM_KERNEL_1_4, FASTPM_SOFTENING_NONE,
+                                                 nprocy > 1 ? NULL : delta_k));
         /* ORegion of this rank: y rows [rank * N / P, ...), strides [y_loc][kz][x] (pmpfft.c:198-202) */
         const size_t nzc = Nmesh / 2 + 1, yl = Nmesh / P, n = yl * nzc * Nmesh;
         const size_t at = ((size_t) 1 * nzc + 2) * Nmesh + 3;                   /* (y_loc, kz, x) = (1, 2, 3) */
@@ -181,7 +199,7 @@ int main(int argc, char **argv)
             for (i = 0; i < 2 * n; i++) sum += (double) d[i] * d[i];
             re = d[2 * at]; im = d[2 * at + 1];
         }
-        printf("dk %d %.12g %.12g %.12g\n", rank, re, im, sum);
+        if (nprocy == 1) printf("dk %d %.12g %.12g %.12g\n", rank, re, im, sum);
         free(delta_k);
     } else {
         CHECK(fpmhip_malloc(&dx, (np ? np : 1) * 3 * sizeof(double)));
@@ -189,7 +207,7 @@ int main(int argc, char **argv)
         CHECK(fpmhip_memcpy_h2d(plan, dx, x, np * 3 * sizeof(double)));
         part.x = dx;
         part.acc = dacc;
-        CHECK(fastpm_hip_slab_force(plan, t, &part, FASTPM_KERNEL_1_4, FASTPM_SOFTENING_NONE, NULL));
+        CHECK(fastpm_hip_mesh_force_species(plan, t, &part, 1, FASTPM_KERNEL_1_4, FASTPM_SOFTENING_NONE, NULL));
         CHECK(fpmhip_memcpy_d2h(plan, acc, dacc, np * 3 * sizeof(float)));
     }
     double s[7] = {0, 0, 0, 0, 0, 0, (double) np};
@@ -203,7 +221,8 @@ int main(int argc, char **argv)
     MPI_Allreduce(MPI_IN_PLACE, first, 12, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD);
     if (rank == 0) {
         const double n = s[6];
-        printf("ranks %d np %.0f Nmesh %d precision %d gradient_mode %d\n", P, n, Nmesh, precision, gradient_mode);
+        printf("ranks %d np %.0f Nmesh %d precision %d gradient_mode %d process mesh %d x %d\n", P, n, Nmesh, precision,
+               gradient_mode, nprocx, nprocy);
         printf("acc std %.9g %.9g %.9g\n", sqrt(s[3] / n - pow(s[0] / n, 2)), sqrt(s[4] / n - pow(s[1] / n, 2)),
                sqrt(s[5] / n - pow(s[2] / n, 2)));
         for (int j = 0; j < 4; j++) printf("acc[%d] %.9g %.9g %.9g\n", j, first[j][0], first[j][1], first[j][2]);

@@ -10,7 +10,7 @@
 
 #define TRY(expr) do { int rc_ = (expr); if (rc_ != 0) return rc_; } while (0)
 
-enum { B_CANVAS = 0, B_DELTA_K = 1, B_F0 = 2, B_F1 = 3, B_F2 = 4, B_XCHG = 5 };   /* fpmhip_plan_buffer ids */
+enum { B_CANVAS = 0, B_DELTA_K = 1, B_F0 = 2, B_F1 = 3, B_F2 = 4, B_XCHG = 5, B_XCHG2 = 6 };   /* fpmhip_plan_buffer ids */
 
 static int exchange(fpmhip_plan *plan, const fastpm_hip_transport *t, const void *send, void *recv, size_t chunk_bytes)
 {
@@ -28,14 +28,51 @@ static int shift(fpmhip_plan *plan, const fastpm_hip_transport *t, void *mesh, i
                        (t->rank - dir + P) % P, (size_t) n * plane_bytes);
 }
 
+/* every species painted into one canvas (gravity.c:323-338): the mass all-reduce covers all of them */
+static int paint_species(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *sets, int nsets,
+                         double Norm, void *canvas)
+{
+    double total = 0;
+    for (int si = 0; si < nsets; si++) {
+        double m = 0;
+        TRY(fpmhip_total_mass(plan, &sets[si], &m));
+        total += m;
+    }
+    TRY(t->allreduce_sum(t->ctx, &total));
+    const double scale = 1.0 / (total / Norm);
+    TRY(fpmhip_paint(plan, &sets[0], scale, canvas));
+    for (int si = 1; si < nsets; si++) TRY(fpmhip_paint_add(plan, &sets[si], scale, canvas));
+    return 0;
+}
+
+/* every species read out of the three force meshes (gravity.c:387-395); the last painted one first: the tile binning
+ * the plan holds is its */
+static int readout_species(fpmhip_plan *plan, const fpmhip_particles *sets, int nsets, void *f0, void *f1, void *f2)
+{
+    for (int si = nsets - 1; si >= 0; si--) TRY(fpmhip_readout3(plan, &sets[si], f0, f1, f2));
+    return 0;
+}
+
+static int slab_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *sets, int nsets,
+                              int kernel, int softening, void *delta_k);
+
 int fastpm_hip_slab_force(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *p,
                           int kernel, int softening, void *delta_k)
 {
+    return fastpm_hip_mesh_force_species(plan, t, p, 1, kernel, softening, delta_k);
+}
+
+static int slab_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *sets, int nsets,
+                              int kernel, int softening, void *delta_k)
+{
+    const fpmhip_particles *p = &sets[0];
+    int any_pot = 0;
+    for (int si = 0; si < nsets; si++) any_pot |= sets[si].potential != NULL;
     fpmhip_layout lay;
     TRY(fpmhip_plan_layout(plan, &lay));
     if (lay.nranks != t->nranks || lay.rank != t->rank) return -1;
     if (lay.nranks == 1)            /* no ghosts, no transposes (pmghosts.c:67: rank == ThisTask always) */
-        return fpmhip_force(plan, p, kernel, softening, -1.0, delta_k);
+        return fpmhip_force_species(plan, sets, nsets, kernel, softening, -1.0, delta_k);
     int po, go, dfo, dc;
     TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));
     const int64_t xl = lay.isize[0];
@@ -47,10 +84,7 @@ int fastpm_hip_slab_force(fpmhip_plan *plan, const fastpm_hip_transport *t, cons
     if (!canvas || !work || !delta_k) return -2;
 
     /* gravity.c:330-345: total mass over all ranks, paint, normalise; the halo plane goes to rank + 1 */
-    double total = 0;
-    TRY(fpmhip_total_mass(plan, p, &total));
-    TRY(t->allreduce_sum(t->ctx, &total));
-    TRY(fpmhip_paint(plan, p, 1.0 / (total / lay.Norm), canvas));
+    TRY(paint_species(plan, t, sets, nsets, lay.Norm, canvas));
     void *tmp = work;                                           /* free until the forward transform */
     TRY(shift(plan, t, canvas, xl, 1, tmp, +1, plane_bytes));
     TRY(fpmhip_plane_add(plan, fpmhip_plane_ptr(plan, canvas, 0), tmp));
@@ -77,8 +111,9 @@ int fastpm_hip_slab_force(fpmhip_plan *plan, const fastpm_hip_transport *t, cons
         TRY(shift(plan, t, phi, 0, 1, fpmhip_plane_ptr(plan, phi, xl), -1, plane_bytes));
         TRY(shift(plan, t, phi, 1, 2, fpmhip_plane_ptr(plan, halo, 2), -1, plane_bytes));
         TRY(shift(plan, t, phi, xl - 2, 2, halo, +1, plane_bytes));
-        TRY(fpmhip_readout_grad(plan, p, phi, halo));
-        if (p->potential) TRY(fpmhip_readout1(plan, p, phi, p->potential, 1, 0));   /* gravity.c:487-492 */
+        for (int si = nsets - 1; si >= 0; si--) TRY(fpmhip_readout_grad(plan, &sets[si], phi, halo));
+        for (int si = 0; si < nsets; si++)                                          /* gravity.c:487-492 */
+            if (sets[si].potential) TRY(fpmhip_readout1(plan, &sets[si], phi, sets[si].potential, 1, 0));
         return 0;
     }
 
@@ -93,15 +128,17 @@ int fastpm_hip_slab_force(fpmhip_plan *plan, const fastpm_hip_transport *t, cons
         TRY(exchange(plan, t, f[1], work2, chunk_bytes));
         TRY(fpmhip_fft_yz_backward(plan, work, f[0]));
         /* the potential column rides along: no second transfer, x pass and all-to-all for it */
-        void *potmesh = p->potential ? fpmhip_plan_buffer(plan, B_DELTA_K) : NULL;
-        if (p->potential && (delta_k == potmesh || !potmesh)) potmesh = NULL;     /* the caller wants delta_k kept there */
+        void *potmesh = any_pot ? fpmhip_plan_buffer(plan, B_DELTA_K) : NULL;
+        if (any_pot && (delta_k == potmesh || !potmesh)) potmesh = NULL;          /* the caller wants delta_k kept there */
         TRY(fpmhip_fft_yz_backward_grad2(plan, work2, f[1], f[2], potmesh, kernel));
         if (potmesh) {
             for (int d = 0; d < 3; d++)
                 TRY(shift(plan, t, f[d], 0, 1, fpmhip_plane_ptr(plan, f[d], xl), -1, plane_bytes));
             TRY(shift(plan, t, potmesh, 0, 1, fpmhip_plane_ptr(plan, potmesh, xl), -1, plane_bytes));
-            TRY(fpmhip_readout3(plan, p, f[0], f[1], f[2]));
-            return fpmhip_readout1(plan, p, potmesh, p->potential, 1, 0);
+            TRY(readout_species(plan, sets, nsets, f[0], f[1], f[2]));
+            for (int si = 0; si < nsets; si++)
+                if (sets[si].potential) TRY(fpmhip_readout1(plan, &sets[si], potmesh, sets[si].potential, 1, 0));
+            return 0;
         }
     } else {
         if (fuse_x) {
@@ -117,16 +154,178 @@ int fastpm_hip_slab_force(fpmhip_plan *plan, const fastpm_hip_transport *t, cons
     }
     for (int d = 0; d < 3; d++)
         TRY(shift(plan, t, f[d], 0, 1, fpmhip_plane_ptr(plan, f[d], xl), -1, plane_bytes));
-    TRY(fpmhip_readout3(plan, p, f[0], f[1], f[2]));
-    if (p->potential) {                                         /* gravity.c:487-492 */
+    TRY(readout_species(plan, sets, nsets, f[0], f[1], f[2]));
+    if (any_pot) {                                              /* gravity.c:487-492 */
         TRY(fpmhip_transfer(plan, delta_k, f[0], kernel, FPMHIP_FIELD_POTENTIAL));
         TRY(fpmhip_fft_x_backward(plan, f[0]));
         TRY(exchange(plan, t, f[0], work, chunk_bytes));
         TRY(fpmhip_fft_yz_backward(plan, work, f[0]));
         TRY(shift(plan, t, f[0], 0, 1, fpmhip_plane_ptr(plan, f[0], xl), -1, plane_bytes));
-        TRY(fpmhip_readout1(plan, p, f[0], p->potential, 1, 0));
+        for (int si = 0; si < nsets; si++)
+            if (sets[si].potential) TRY(fpmhip_readout1(plan, &sets[si], f[0], sets[si].potential, 1, 0));
+    }
+    (void) p;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Pencils: Nproc = {Nx, Ny}, rank = rx * Ny + ry (MPI_Cart_create order, pmpfft.c:127-136).  The C twin of
+ * fastpm_amd/distributed.py::PencilForce.steps.
+ */
+typedef struct {
+    int Nx, Ny, rx, ry;
+    int row[64], col[64];       /* world ranks of my row (same rx; index = ry) and my column (same ry; index = rx) */
+} mesh_groups;
+
+/* exchange A (y <-> kz, inside my row) / B (x <-> ky, inside my column); a group of one is a plain copy */
+static int exchange_axis(fpmhip_plan *plan, const fastpm_hip_transport *t, const mesh_groups *g, int axis,
+                         const void *send, void *recv, size_t chunk_bytes)
+{
+    const int n = axis == 0 ? g->Ny : g->Nx;
+    if (n == 1) return fpmhip_memcpy_d2d(plan, recv, send, chunk_bytes);
+    if (!t->alltoall_members) return -1;
+    TRY(fpmhip_sync(plan));
+    return t->alltoall_members(t->ctx, send, recv, chunk_bytes, axis == 0 ? g->row : g->col, n, axis == 0 ? g->ry : g->rx);
+}
+
+static int neighbour(const mesh_groups *g, int axis, int dir)
+{
+    return axis == 0 ? g->row[(g->ry + dir + g->Ny) % g->Ny] : g->col[(g->rx + dir + g->Nx) % g->Nx];
+}
+
+/* after the paint: the extra x plane to rank_x + 1, then the extra y row to rank_y + 1 (the corner cell takes both hops) */
+static int halo_out(fpmhip_plan *plan, const fastpm_hip_transport *t, const mesh_groups *g, const fpmhip_layout *lay,
+                    void *mesh, void *scratch)
+{
+    const size_t es = (size_t) lay->precision / 8;
+    const size_t plane_bytes = (size_t) lay->plane_elems * es, row_bytes = (size_t) lay->isize[0] * (lay->Nmesh + 2) * es;
+    if (g->Nx > 1) {
+        TRY(fpmhip_sync(plan));
+        TRY(t->sendrecv(t->ctx, fpmhip_plane_ptr(plan, mesh, lay->isize[0]), neighbour(g, 1, +1), scratch,
+                        neighbour(g, 1, -1), plane_bytes));
+        TRY(fpmhip_plane_add(plan, fpmhip_plane_ptr(plan, mesh, 0), scratch));
+    }
+    if (g->Ny > 1) {
+        void *rs = scratch, *rr = (char *) scratch + row_bytes;
+        TRY(fpmhip_yrow(plan, mesh, lay->isize[1], rs, 0));
+        TRY(fpmhip_sync(plan));
+        TRY(t->sendrecv(t->ctx, rs, neighbour(g, 0, +1), rr, neighbour(g, 0, -1), row_bytes));
+        TRY(fpmhip_yrow(plan, mesh, 0, rr, 2));
     }
     return 0;
+}
+
+/* before a readout: row 0 of rank_y + 1 into my extra row, then plane 0 (with that row) of rank_x + 1 into my extra plane */
+static int halo_in(fpmhip_plan *plan, const fastpm_hip_transport *t, const mesh_groups *g, const fpmhip_layout *lay,
+                   void *mesh, void *scratch)
+{
+    const size_t es = (size_t) lay->precision / 8;
+    const size_t plane_bytes = (size_t) lay->plane_elems * es, row_bytes = (size_t) lay->isize[0] * (lay->Nmesh + 2) * es;
+    if (g->Ny > 1) {
+        void *rs = scratch, *rr = (char *) scratch + row_bytes;
+        TRY(fpmhip_yrow(plan, mesh, 0, rs, 0));
+        TRY(fpmhip_sync(plan));
+        TRY(t->sendrecv(t->ctx, rs, neighbour(g, 0, -1), rr, neighbour(g, 0, +1), row_bytes));
+        TRY(fpmhip_yrow(plan, mesh, lay->isize[1], rr, 1));
+    }
+    if (g->Nx > 1) {
+        TRY(fpmhip_sync(plan));
+        TRY(t->sendrecv(t->ctx, fpmhip_plane_ptr(plan, mesh, 0), neighbour(g, 1, -1),
+                        fpmhip_plane_ptr(plan, mesh, lay->isize[0]), neighbour(g, 1, +1), plane_bytes));
+    }
+    return 0;
+}
+
+static int pencil_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_layout *lay,
+                                const fpmhip_particles *sets, int nsets, int kernel, int softening, void *delta_k)
+{
+    if (lay->nranks_x > 64 || lay->nranks_y > 64) return -1;
+    mesh_groups g = {lay->nranks_x, lay->nranks_y, lay->rank_x, lay->rank_y, {0}, {0}};
+    for (int j = 0; j < g.Ny; j++) g.row[j] = g.rx * g.Ny + j;
+    for (int i = 0; i < g.Nx; i++) g.col[i] = i * g.Ny + g.ry;
+    int po, go, dfo, dc, any_pot = 0;
+    TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));
+    for (int si = 0; si < nsets; si++) any_pot |= sets[si].potential != NULL;
+    const size_t es = (size_t) lay->precision / 8;
+    const size_t a_bytes = (size_t) lay->chunk_a_elems * es, b_bytes = (size_t) lay->chunk_b_elems * es;
+    void *c = fpmhip_plan_buffer(plan, B_CANVAS);
+    void *w[5] = {fpmhip_plan_buffer(plan, B_F0), fpmhip_plan_buffer(plan, B_F1), fpmhip_plan_buffer(plan, B_F2),
+                  fpmhip_plan_buffer(plan, B_XCHG), fpmhip_plan_buffer(plan, B_XCHG2)};
+    if (!delta_k) delta_k = fpmhip_plan_buffer(plan, B_DELTA_K);
+    if (!c || !w[0] || !w[1] || !w[2] || !w[3] || !w[4] || !delta_k) return -2;
+
+    TRY(paint_species(plan, t, sets, nsets, lay->Norm, c));                       /* gravity.c:323-345 */
+    TRY(halo_out(plan, t, &g, lay, c, w[3]));
+    TRY(fpmhip_fft_z_forward(plan, c, w[0]));                                     /* gravity.c:351 pm_r2c */
+    TRY(exchange_axis(plan, t, &g, 0, w[0], w[1], a_bytes));
+    TRY(fpmhip_fft_y_forward(plan, w[1], w[0]));
+    TRY(exchange_axis(plan, t, &g, 1, w[0], delta_k, b_bytes));
+    const int fuse_x = softening == FPMHIP_SOFTENING_NONE;
+    if (!fuse_x) {
+        TRY(fpmhip_fft_x_forward(plan, delta_k));
+        TRY(fpmhip_softening(plan, delta_k, softening));                          /* gravity.c:476 */
+    }
+    void *mesh[4] = {NULL, NULL, NULL, NULL};
+    if (go == 1) {
+        /* two meshes through the transposes: the x component and the potential (fastpm_hip.h) */
+        if (fuse_x) TRY(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 2, w[0], w[1], NULL));
+        else TRY(fpmhip_transfer_fft_x_backward_potx(plan, delta_k, w[0], w[1], kernel));
+        TRY(exchange_axis(plan, t, &g, 1, w[1], w[2], b_bytes));                  /* potential */
+        TRY(exchange_axis(plan, t, &g, 1, w[0], w[3], b_bytes));                  /* x component */
+        void *potmesh = any_pot ? w[4] : NULL;                                    /* gravity.c:487-492 rides along */
+        TRY(fpmhip_fft_y_backward_grad2(plan, w[2], w[0], w[1], potmesh, kernel));
+        TRY(fpmhip_fft_y_backward(plan, w[3], w[2]));
+        TRY(exchange_axis(plan, t, &g, 0, w[2], w[3], a_bytes));
+        TRY(fpmhip_fft_z_backward(plan, w[3], c));
+        TRY(exchange_axis(plan, t, &g, 0, w[0], w[3], a_bytes));
+        TRY(fpmhip_fft_z_backward(plan, w[3], w[2]));
+        TRY(exchange_axis(plan, t, &g, 0, w[1], w[3], a_bytes));
+        TRY(fpmhip_fft_z_backward(plan, w[3], w[0]));
+        mesh[0] = c; mesh[1] = w[2]; mesh[2] = w[0];
+        if (potmesh) {
+            TRY(exchange_axis(plan, t, &g, 0, potmesh, w[3], a_bytes));
+            TRY(fpmhip_fft_z_backward(plan, w[3], w[1]));
+            mesh[3] = w[1];
+        }
+    } else {
+        /* gravity.c:373-397 with the exact i k gradient: three components through the transposes */
+        if (fuse_x) TRY(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 0, w[0], w[1], w[2]));
+        else TRY(fpmhip_transfer_fft_x_backward3(plan, delta_k, w[0], w[1], w[2], kernel));
+        void *real[3] = {c, w[0], w[1]};
+        for (int d = 0; d < 3; d++) {
+            TRY(exchange_axis(plan, t, &g, 1, w[d], w[3], b_bytes));
+            TRY(fpmhip_fft_y_backward(plan, w[3], w[4]));
+            TRY(exchange_axis(plan, t, &g, 0, w[4], w[3], a_bytes));
+            TRY(fpmhip_fft_z_backward(plan, w[3], real[d]));
+            mesh[d] = real[d];
+        }
+        if (any_pot) {
+            TRY(fpmhip_transfer(plan, delta_k, w[2], kernel, FPMHIP_FIELD_POTENTIAL));
+            TRY(fpmhip_fft_x_backward(plan, w[2]));
+            TRY(exchange_axis(plan, t, &g, 1, w[2], w[3], b_bytes));
+            TRY(fpmhip_fft_y_backward(plan, w[3], w[4]));
+            TRY(exchange_axis(plan, t, &g, 0, w[4], w[3], a_bytes));
+            TRY(fpmhip_fft_z_backward(plan, w[3], w[2]));
+            mesh[3] = w[2];
+        }
+    }
+    for (int d = 0; d < 4; d++)
+        if (mesh[d]) TRY(halo_in(plan, t, &g, lay, mesh[d], w[3]));
+    TRY(readout_species(plan, sets, nsets, mesh[0], mesh[1], mesh[2]));
+    for (int si = 0; si < nsets && mesh[3]; si++)
+        if (sets[si].potential) TRY(fpmhip_readout1(plan, &sets[si], mesh[3], sets[si].potential, 1, 0));
+    return 0;
+}
+
+int fastpm_hip_mesh_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *sets,
+                                  int nsets, int kernel, int softening, void *delta_k)
+{
+    if (!plan || !t || !sets || nsets < 1 || nsets > 6) return -1;
+    fpmhip_layout lay;
+    TRY(fpmhip_plan_layout(plan, &lay));
+    if (lay.nranks != t->nranks || lay.rank != t->rank) return -1;
+    if (lay.nranks_y > 1) return pencil_force_species(plan, t, &lay, sets, nsets, kernel, softening, delta_k);
+    return slab_force_species(plan, t, sets, nsets, kernel, softening, delta_k);
 }
 
 int fastpm_hip_slab_decompose(fpmhip_plan *plan, const fastpm_hip_transport *t, fastpm_hip_column *cols, int ncols,
@@ -169,6 +368,57 @@ int fastpm_hip_slab_decompose(fpmhip_plan *plan, const fastpm_hip_transport *t, 
     if (order) fpmhip_free(order);
     if (tmp) fpmhip_free(tmp);
     free(counts);
+    return rc;
+}
+
+int fastpm_hip_mesh_force_species_host(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *sets,
+                                       int nsets, int kernel, int softening, void *delta_k_host)
+{
+    if (!plan || !t || !sets || nsets < 1 || nsets > 6) return -1;
+    fpmhip_layout lay;
+    TRY(fpmhip_plan_layout(plan, &lay));
+    if (delta_k_host && lay.nranks_y > 1) return -1;            /* the reference layout export is a slab feature */
+    size_t np = 0;
+    int any_mass = 0, any_pot = 0;
+    for (int si = 0; si < nsets; si++) {
+        if (sets[si].np < 0 || (sets[si].np && (!sets[si].x || !sets[si].acc))) return -1;
+        np += (size_t) sets[si].np;
+        any_mass |= sets[si].mass != NULL;
+        any_pot |= sets[si].potential != NULL;
+    }
+    const size_t n1 = np ? np : 1;
+    void *dx = NULL, *dm = NULL, *da = NULL, *dp = NULL;
+    int rc = fpmhip_malloc(&dx, n1 * 3 * sizeof(double));
+    if (!rc) rc = fpmhip_malloc(&da, n1 * 3 * sizeof(float));
+    if (!rc && any_mass) rc = fpmhip_malloc(&dm, n1 * sizeof(float));
+    if (!rc && any_pot) rc = fpmhip_malloc(&dp, n1 * sizeof(float));
+    fpmhip_particles pd[6];
+    size_t off = 0;
+    for (int si = 0; si < nsets && !rc; si++) {                 /* the sets back to back in one device region */
+        const size_t n = (size_t) sets[si].np;
+        pd[si] = sets[si];
+        pd[si].x = (double *) dx + 3 * off;
+        pd[si].acc = (float *) da + 3 * off;
+        pd[si].mass = sets[si].mass ? (float *) dm + off : NULL;
+        pd[si].potential = sets[si].potential ? (float *) dp + off : NULL;
+        if (n) rc = fpmhip_memcpy_h2d(plan, (void *) pd[si].x, sets[si].x, n * 3 * sizeof(double));
+        if (!rc && n && sets[si].mass) rc = fpmhip_memcpy_h2d(plan, (void *) pd[si].mass, sets[si].mass, n * sizeof(float));
+        off += n;
+    }
+    if (!rc) {
+        void *dk = fpmhip_plan_buffer(plan, B_DELTA_K);
+        rc = dk ? fastpm_hip_mesh_force_species(plan, t, pd, nsets, kernel, softening, dk) : -2;
+        for (int si = 0; si < nsets && !rc; si++) {
+            const size_t n = (size_t) sets[si].np;
+            if (n) rc = fpmhip_memcpy_d2h(plan, sets[si].acc, pd[si].acc, n * 3 * sizeof(float));
+            if (!rc && n && sets[si].potential) rc = fpmhip_memcpy_d2h(plan, sets[si].potential, pd[si].potential, n * sizeof(float));
+        }
+        if (!rc && delta_k_host) rc = fpmhip_export_delta_k(plan, dk, delta_k_host);
+    }
+    if (dx) fpmhip_free(dx);
+    if (da) fpmhip_free(da);
+    if (dm) fpmhip_free(dm);
+    if (dp) fpmhip_free(dp);
     return rc;
 }
 
@@ -247,6 +497,21 @@ static int loop_alltoall(void *c_, const void *send, void *recv, size_t chunk)
     return rc;
 }
 
+static int loop_alltoall_members(void *c_, const void *send, void *recv, size_t chunk, const int *members, int n, int me)
+{
+    loop_ctx *c = c_;
+    loop_shared *s = c->sh;
+    int rc = 0;
+    s->send[c->rank] = send;
+    pthread_barrier_wait(&s->barrier);                 /* every rank is in SOME group's exchange at this point */
+    for (int j = 0; j < n && rc == 0; j++)
+        rc = fpmhip_memcpy_d2d(s->plan[c->rank], (char *) recv + (size_t) j * chunk,
+                               (const char *) s->send[members[j]] + (size_t) me * chunk, chunk);
+    if (rc == 0) rc = fpmhip_sync(s->plan[c->rank]);
+    pthread_barrier_wait(&s->barrier);
+    return rc;
+}
+
 static int loop_sendrecv(void *c_, const void *send, int dest, void *recv, int source, size_t bytes)
 {
     loop_ctx *c = c_;
@@ -280,6 +545,7 @@ fastpm_hip_transport *fastpm_hip_loopback_create(int nranks)
         t[r].nranks = nranks;
         t[r].allreduce_sum = loop_allreduce;
         t[r].alltoall = loop_alltoall;
+        t[r].alltoall_members = loop_alltoall_members;
         t[r].sendrecv = loop_sendrecv;
     }
     return t;

@@ -29,6 +29,11 @@ typedef struct {
     int (*alltoall)(void *ctx, const void *send_dev, void *recv_dev, size_t chunk_bytes);
     /* MPI_Sendrecv: send `bytes` to rank dest, receive `bytes` from rank source  (mesh halo planes) */
     int (*sendrecv)(void *ctx, const void *send_dev, int dest, void *recv_dev, int source, size_t bytes);
+    /* MPI_Alltoall inside a sub-communicator of the process mesh (a row or a column of pm->Comm2D, pmpfft.c:117-136):
+     * `members` lists the group's world ranks in group order, this rank is members[me]; chunk j of send goes to
+     * members[j], chunk j of recv comes from members[j].  Only pencils (nranks_y > 1) need it. */
+    int (*alltoall_members)(void *ctx, const void *send_dev, void *recv_dev, size_t chunk_bytes, const int *members,
+                            int nmembers, int me);
     /* -- only fastpm_hip_slab_decompose needs the two below; a transport without them leaves them NULL -- */
     /* MPI_Alltoall of one count per rank (host arrays of nranks entries)          store.c:570-572 */
     int (*alltoall_counts)(void *ctx, const int64_t *send_host, int64_t *recv_host);
@@ -60,6 +65,17 @@ int fastpm_hip_slab_decompose(fpmhip_plan *plan, const fastpm_hip_transport *t, 
  * Mesh buffers are the plan's own.  Returns 0, or the first nonzero code (fpmhip_last_error() has the text). */
 int fastpm_hip_slab_force(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *p_dev,
                           int kernel, int softening, void *delta_k_dev);
+
+/* The same for every species the solver holds (the loops of gravity.c:279-287, 323-338, 387-395) on ANY process mesh
+ * the plan was made for: x slabs (nranks_y <= 1, the sequence above) or pencils (nranks_y > 1: x plane and y row halo,
+ * the (y <-> kz) exchange inside a row and the (x <-> ky) exchange inside a column of the process mesh through
+ * t->alltoall_members -- what PFFT does on the reference's default Nproc, pmpfft.c:117-136). */
+int fastpm_hip_mesh_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *sets_dev,
+                                  int nsets, int kernel, int softening, void *delta_k_dev);
+/* ... with host-resident columns; delta_k_host as fastpm_hip_slab_force_host (slabs only: a pencil's k-space block is
+ * [x][ky_loc][kz_loc] with a padded last kz block, see fpmhip_layout) */
+int fastpm_hip_mesh_force_species_host(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *sets_host,
+                                       int nsets, int kernel, int softening, void *delta_k_host);
 
 /* The same with HOST-resident store columns and a host delta_k, as libfastpm holds them (the NTask > 1 twin of
  * fpmhip_force_host): x (and mass) go up, acc (and potential) come down, delta_k_host (nullable; allocsize

@@ -67,6 +67,37 @@ static int mpi_alltoall(void *ctx, const void *send_dev, void *recv_dev, size_t 
     return rc == MPI_SUCCESS ? 0 : -1;
 }
 
+/* the all-to-all of a row / column of the process mesh as point-to-point messages on the world communicator (what
+ * MPI_Alltoall on pm->Comm2D's sub-communicators does; no MPI_Comm_split needed for <= 64 members) */
+static int mpi_alltoall_members(void *ctx, const void *send_dev, void *recv_dev, size_t chunk_bytes, const int *members,
+                                int n, int me)
+{
+    mpi_ctx *c = ctx;
+    MPI_Datatype type;
+    int count, rc = MPI_SUCCESS;
+    if (n > 64 || split_count(chunk_bytes, &type, &count)) return -1;
+    const char *sbuf = send_dev;
+    char *rbuf = recv_dev;
+    const size_t total = chunk_bytes * (size_t) n;
+    if (!c->gpu_aware) {
+        if (stage_reserve(c, total) || fpmhip_memcpy_d2h(c->plan, c->hsend, send_dev, total)) { MPI_Type_free(&type); return -1; }
+        sbuf = c->hsend;
+        rbuf = c->hrecv;
+    }
+    MPI_Request req[128];
+    MPI_Status st[128];
+    int nreq = 0;
+    for (int j = 0; j < n && rc == MPI_SUCCESS; j++) {
+        rc = MPI_Irecv(rbuf + (size_t) j * chunk_bytes, count, type, members[j], 7, c->comm, &req[nreq++]);
+        if (rc == MPI_SUCCESS) rc = MPI_Isend(sbuf + (size_t) j * chunk_bytes, count, type, members[j], 7, c->comm, &req[nreq++]);
+    }
+    (void) me;
+    if (MPI_Waitall(nreq, req, st) != MPI_SUCCESS) rc = MPI_ERR_OTHER;
+    if (rc == MPI_SUCCESS && !c->gpu_aware && fpmhip_memcpy_h2d(c->plan, recv_dev, c->hrecv, total)) rc = MPI_ERR_OTHER;
+    MPI_Type_free(&type);
+    return rc == MPI_SUCCESS ? 0 : -1;
+}
+
 static int mpi_sendrecv(void *ctx, const void *send_dev, int dest, void *recv_dev, int source, size_t bytes)
 {
     mpi_ctx *c = ctx;
@@ -137,6 +168,7 @@ fastpm_hip_transport *fastpm_hip_mpi_transport_create(MPI_Comm comm, fpmhip_plan
     t->nranks = c->nranks;
     t->allreduce_sum = mpi_allreduce;
     t->alltoall = mpi_alltoall;
+    t->alltoall_members = mpi_alltoall_members;
     t->sendrecv = mpi_sendrecv;
     t->alltoall_counts = mpi_alltoall_counts;
     t->alltoallv = mpi_alltoallv;

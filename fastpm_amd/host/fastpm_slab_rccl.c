@@ -53,6 +53,20 @@ static int rccl_alltoall(void *ctx, const void *send, void *recv, size_t chunk_b
     return finish(c, ok);
 }
 
+/* a row / column of the process mesh: the same grouped sends and receives among its members only */
+static int rccl_alltoall_members(void *ctx, const void *send, void *recv, size_t chunk_bytes, const int *members, int n, int me)
+{
+    rccl_ctx *c = ctx;
+    (void) me;
+    int ok = OK_NCCL(ncclGroupStart());
+    for (int j = 0; j < n && ok; j++) {
+        ok = OK_NCCL(ncclSend((const char *) send + (size_t) j * chunk_bytes, chunk_bytes, ncclInt8, members[j], c->comm, c->stream))
+             && OK_NCCL(ncclRecv((char *) recv + (size_t) j * chunk_bytes, chunk_bytes, ncclInt8, members[j], c->comm, c->stream));
+    }
+    ok = OK_NCCL(ncclGroupEnd()) && ok;
+    return finish(c, ok);
+}
+
 static int rccl_sendrecv(void *ctx, const void *send, int dest, void *recv, int source, size_t bytes)
 {
     rccl_ctx *c = ctx;
@@ -106,6 +120,7 @@ fastpm_hip_transport *fastpm_hip_rccl_transport_create(MPI_Comm comm, int device
     t->ctx = c;
     t->allreduce_sum = rccl_allreduce;
     t->alltoall = rccl_alltoall;
+    t->alltoall_members = rccl_alltoall_members;
     t->sendrecv = rccl_sendrecv;
     t->alltoall_counts = rccl_alltoall_counts;
     t->alltoallv = rccl_alltoallv;

@@ -135,7 +135,7 @@ int  fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **pla
 void fpmhip_plan_destroy(fpmhip_plan *plan);
 int  fpmhip_plan_layout(const fpmhip_plan *plan, fpmhip_layout *out);
 int  fpmhip_plan_set_stream(fpmhip_plan *plan, void *stream);
-/* plan-owned mesh buffers: 0 = canvas, 1 = delta_k, 2..4 = force components, 5 = exchange */
+/* plan-owned mesh buffers: 0 = canvas, 1 = delta_k, 2..4 = force components, 5, 6 = exchange */
 void *fpmhip_plan_buffer(fpmhip_plan *plan, int which);
 int  fpmhip_sync(fpmhip_plan *plan);
 

@@ -231,7 +231,7 @@ def test_c_host_decic_powerspectrum_and_dump(oracle, tmp_path):
 class Transport(ctypes.Structure):
     _fields_ = [("ctx", ctypes.c_void_p), ("rank", ctypes.c_int), ("nranks", ctypes.c_int),
                 ("allreduce_sum", ctypes.c_void_p), ("alltoall", ctypes.c_void_p), ("sendrecv", ctypes.c_void_p),
-                ("alltoall_counts", ctypes.c_void_p), ("alltoallv", ctypes.c_void_p)]
+                ("alltoall_members", ctypes.c_void_p), ("alltoall_counts", ctypes.c_void_p), ("alltoallv", ctypes.c_void_p)]
 
 
 def test_host_library_exports_the_slab_force():
@@ -305,6 +305,64 @@ def test_c_host_slab_force_matches_one_rank_oracle(oracle, N, P, kernel, gradien
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("Nx,Ny,kernel", [(2, 2, "1_4"), (4, 2, "1_4"), (2, 2, "eastwood")])
+def test_c_host_pencil_force_two_species_matches_one_rank_oracle(oracle, Nx, Ny, kernel):
+    """fastpm_hip_mesh_force_species on the reference's default kind of process mesh (pencils, pmpfft.c:117-136): one
+    host thread per rank, TWO species painted into one mesh (gravity.c:323-338), the row / column exchanges through
+    the transport's alltoall_members, x-plane and y-row halo hops through sendrecv.  Must equal the one-rank oracle."""
+    import threading
+    import torch
+    from fastpm_amd import PM, Store
+    from fastpm_amd.lib import Particles
+    from fastpm_amd.pm import KERNEL_TYPES
+    H = _host()
+    H.fastpm_hip_loopback_create.restype = ctypes.POINTER(Transport)
+    H.fastpm_hip_loopback_create.argtypes = [ctypes.c_int]
+    H.fastpm_hip_loopback_bind.argtypes = [ctypes.POINTER(Transport), ctypes.c_void_p]
+    H.fastpm_hip_loopback_destroy.argtypes = [ctypes.POINTER(Transport)]
+    H.fastpm_hip_mesh_force_species.argtypes = [ctypes.c_void_p, ctypes.POINTER(Transport), ctypes.c_void_p, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    N, nc, L, P = 64, 32, 96.0, Nx * Ny
+    xa = util.load_b(nc, L, N)
+    xb = util.load_a(nc // 2, L, N, seed=77)
+    mb = np.random.default_rng(5).uniform(0.5, 1.5, len(xb)).astype(np.float32)
+    pmo = oracle.PMOracle(N, L, 64)
+    accs, _ = oracle.compute_force_species(pmo, [{"x": xa}, {"x": xb, "mass": mb, "M0": 0.25}], kernel=oracle.KERNELS[kernel])
+    h = L / N
+    own = lambda x: ((np.floor(x[:, 0] / h).astype(np.int64) % N) // (N // Nx)) * Ny + (np.floor(x[:, 1] / h).astype(np.int64) % N) // (N // Ny)
+    ia = [np.nonzero(own(xa) == r)[0] for r in range(P)]
+    ib = [np.nonzero(own(xb) == r)[0] for r in range(P)]
+    pms = [PM(N, L, 64, nranks=P, rank=r, nranks_y=Ny) for r in range(P)]
+    sa = [Store(xa[ia[r]]) for r in range(P)]
+    sb = [Store(xb[ib[r]], mass=mb[ib[r]], M0=0.25) for r in range(P)]
+    tr = H.fastpm_hip_loopback_create(P)
+    rcs = [None] * P
+
+    def rank_main(r):
+        torch.cuda.set_device(0)
+        H.fastpm_hip_loopback_bind(ctypes.byref(tr[r]), pms[r]._plan)
+        sets = (Particles * 2)(sa[r]._c(), sb[r]._c())
+        rcs[r] = H.fastpm_hip_mesh_force_species(pms[r]._plan, ctypes.byref(tr[r]), sets, 2, KERNEL_TYPES[kernel], 0, None)
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert all(not t.is_alive() for t in threads), "a rank hung"
+    torch.cuda.synchronize()
+    assert rcs == [0] * P, rcs
+    H.fastpm_hip_loopback_destroy(tr)
+    for stores, idx, ref in ((sa, ia, accs[0]), (sb, ib, accs[1])):
+        acc = np.zeros_like(ref)
+        for r in range(P):
+            acc[idx[r]] = stores[r].acc.cpu().numpy()
+        assert util.rel_err(acc, ref) <= 1e-6
+    for pm in pms:
+        pm.destroy()
+
+
+@pytest.mark.gpu
 def test_plain_c_program_runs_the_force(oracle, tmp_path):
     """fastpm_amd/host/example_force.c: gcc, no Python in the process -- the C host library and the HIP library
     only.  Its printed accelerations must be the oracle's for the same (closed-form) particle positions."""
@@ -340,10 +398,12 @@ MPI_ROOT = os.environ.get("FPM_MPI_ROOT", "/opt/conda")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("P,nc,B,precision,gradient_mode,host_columns,decompose", [
-    (2, 24, 2, 64, 0, 0, 0), (4, 24, 2, 64, 1, 0, 0), (3, 24, 2, 32, 0, 0, 0), (2, 24, 2, 64, 0, 1, 0),
-    (4, 24, 2, 32, 1, 1, 0), (2, 24, 2, 64, 0, 0, 1), (4, 24, 2, 64, 0, 1, 1), (3, 24, 2, 64, 1, 0, 1)])
-def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode, host_columns, decompose):
+@pytest.mark.parametrize("P,nc,B,precision,gradient_mode,host_columns,decompose,nprocy", [
+    (2, 24, 2, 64, 0, 0, 0, 1), (4, 24, 2, 64, 1, 0, 0, 1), (3, 24, 2, 32, 0, 0, 0, 1), (2, 24, 2, 64, 0, 1, 0, 1),
+    (4, 24, 2, 32, 1, 1, 0, 1), (2, 24, 2, 64, 0, 0, 1, 1), (4, 24, 2, 64, 0, 1, 1, 1), (3, 24, 2, 64, 1, 0, 1, 1),
+    # pencils, the reference's default kind of process mesh (pmpfft.c:117-136): 2 x 2, and 4 x 2 as it picks for 8 ranks
+    (4, 32, 2, 64, 0, 0, 0, 2), (4, 32, 2, 32, 0, 1, 1, 2), (8, 32, 2, 64, 0, 0, 1, 2)])
+def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode, host_columns, decompose, nprocy):
     """`mpiexec -n P example_slab_mpi`: P separate processes, plain C99, exchanging through MPI_Alltoall /
     MPI_Sendrecv / MPI_Allreduce on MPI_COMM_WORLD exactly where libfastpm's PFFT transposes, ghost exchange and
     mass all-reduce sit (the image's MPICH is not GPU-aware, so the transport stages through the host; on the
@@ -357,7 +417,7 @@ def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode
                     "MPI_LIB=" + os.path.join(MPI_ROOT, "lib")], check=True, capture_output=True)
     exe = os.path.join(ROOT, "fastpm_amd", "example_slab_mpi")
     r = subprocess.run([mpiexec, "-n", str(P), exe, str(nc), str(B), str(precision), str(gradient_mode), "0",
-                        str(host_columns), str(decompose)],
+                        str(host_columns), str(decompose), str(nprocy)],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     lines = {l.split()[0] + (l.split()[1] if l.startswith("acc std") else ""): l.split() for l in r.stdout.splitlines()}
@@ -384,7 +444,7 @@ def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode
     std = np.sqrt((ref ** 2).mean(0) - ref.mean(0) ** 2)
     got = np.array([float(v) for v in lines["accstd"][2:5]])
     tol = 1e-6 if precision == 64 else 2e-5
-    if host_columns:
+    if host_columns and nprocy == 1:
         # fastpm_hip_slab_force_host: every rank's delta_k slab is the reference's ORegion, [y_loc][kz][x]
         dko = pmo.complex_view(full["delta_k"]).astype(np.complex128)              # [y][kz][x]
         yl = nc * B // P
