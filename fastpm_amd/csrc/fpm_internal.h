@@ -156,6 +156,9 @@ struct fpmhip_plan {
     size_t dec_tmp_bytes = 0, dec_hist_bytes = 0;
     int64_t binned_ndup = 0;
 
+    // host callback at the boundaries of the top-level stages (fpmhip_set_stage_hook)
+    void (*stage_hook)(void *ctx, int stage, int enter) = nullptr;
+    void *stage_hook_ctx = nullptr;
     // timing
     bool timing = false;
     std::vector<fpm::EventPair> ev_used;
@@ -171,6 +174,7 @@ struct StageTimer {
     fpmhip_plan *p;
     EventPair ev;
     bool on;
+    int hooked = -1;
     StageTimer(fpmhip_plan *plan, int stage);
     ~StageTimer();
 };

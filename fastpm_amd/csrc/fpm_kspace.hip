@@ -284,27 +284,26 @@ __global__ __launch_bounds__(256) void yrow_kernel(F *__restrict__ mesh, F *__re
     else *cell = *cell + buf[i];
 }
 
-// [x][y_loc][kz] -> [y_loc][kz][x]  (the reference's PFFT-transposed ORegion, pmpfft.c:198-202).
-// 32 x 32 LDS tile transpose over (x, plane index).
-template <typename F>
-__global__ __launch_bounds__(256) void to_reference_layout_kernel(int N, long long plane,
-                                                                  const Cplx<F> *__restrict__ in,
-                                                                  Cplx<F> *__restrict__ out)
+// [x][y_loc][kz_loc] (row pitch nzl, nzv of them modes) <-> [y_loc][kz_loc valid][x]  (the reference's PFFT-transposed
+// ORegion, pmpfft.c:198-202).  32 x 32 LDS tile transpose over (x, q = iyl * nzv + iz).  TO_REF: ours -> reference.
+template <typename F, bool TO_REF>
+__global__ __launch_bounds__(256) void reference_layout_kernel(int N, int yl, int nzl, int nzv, Cplx<F> *__restrict__ ours,
+                                                               Cplx<F> *__restrict__ ref)
 {
     __shared__ Cplx<F> tile[32][33];
-    const long long p0 = (long long) blockIdx.x * 32;
+    const long long nq = (long long) yl * nzv;
+    const long long q0 = (long long) blockIdx.x * 32;
     const int x0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    auto at = [&](int x, long long q) -> Cplx<F> & { return ours[((long long) x * yl + q / nzv) * nzl + q % nzv]; };
     for (int r = ty; r < 32; r += 8) {
-        const int x = x0 + r;
-        const long long q = p0 + tx;
-        if (x < N && q < plane) tile[r][tx] = in[(long long) x * plane + q];
+        if (TO_REF) { const int x = x0 + r; const long long q = q0 + tx; if (x < N && q < nq) tile[r][tx] = at(x, q); }
+        else { const long long q = q0 + r; const int x = x0 + tx; if (x < N && q < nq) tile[tx][r] = ref[q * N + x]; }
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
-        const long long q = p0 + r;
-        const int x = x0 + tx;
-        if (x < N && q < plane) out[q * N + x] = tile[tx][r];
+        if (TO_REF) { const long long q = q0 + r; const int x = x0 + tx; if (x < N && q < nq) ref[q * N + x] = tile[tx][r]; }
+        else { const int x = x0 + r; const long long q = q0 + tx; if (x < N && q < nq) at(x, q) = tile[r][tx]; }
     }
 }
 
@@ -345,6 +344,22 @@ static double sinc_unnormed(double x)   // transfer.c:67-74
         return 1.0 - x2 / 6. + x2 * x2 / 120.;
     }
     return sin(x) / x;
+}
+
+// bytes of this rank's ORegion in the reference layout: [y_loc][kz_loc valid][x]
+static size_t ref_bytes(const fpmhip_plan *p) { return (size_t) 2 * p->mg.N * p->mg.yl * p->lay.ovalid_z * p->esize; }
+
+template <bool TO_REF>
+static int reference_layout(fpmhip_plan *p, void *ours, void *ref)
+{
+    const MeshGeo &g = p->mg;
+    const int nzv = (int) p->lay.ovalid_z;
+    if (nzv == 0) return 0;
+    dim3 grid(blocks_for((long long) g.yl * nzv, 32), blocks_for(g.N, 32));
+    if (p->f64) reference_layout_kernel<double, TO_REF><<<grid, 256, 0, p->stream>>>(g.N, g.yl, g.nzl, nzv, (Cplx<double> *) ours, (Cplx<double> *) ref);
+    else reference_layout_kernel<float, TO_REF><<<grid, 256, 0, p->stream>>>(g.N, g.yl, g.nzl, nzv, (Cplx<float> *) ours, (Cplx<float> *) ref);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 extern "C" {
@@ -576,18 +591,10 @@ int fpmhip_yrow(fpmhip_plan *p, void *mesh, int64_t iy, void *buf, int mode)
 int fpmhip_import_delta_k(fpmhip_plan *p, const void *host, void *delta_k)
 {
     if (!p || !delta_k || !host) FPM_FAIL(-1, "null argument");
-    if (p->lay.nranks_y > 1) FPM_FAIL(-1, "import / export of the reference layout: slabs only (a pencil's kz block is padded)");
     FPM_TRY(ensure_buffer(p, BUF_XCHG));
     if (delta_k == p->buf[BUF_XCHG]) FPM_FAIL(-1, "import target must not be the exchange buffer");
-    const MeshGeo &g = p->mg;
-    const long long plane = (long long) g.yl * g.nzl;
-    FPM_CHECK_HIP(hipMemcpyAsync(p->buf[BUF_XCHG], host, (size_t) 2 * p->lay.complex_elems * p->esize,
-                                 hipMemcpyHostToDevice, p->stream));
-    // [y_loc][kz][x] -> [x][y_loc][kz]: the same tile transpose with the roles of the axes swapped
-    dim3 grid(blocks_for(g.N, 32), blocks_for(plane, 32));
-    if (p->f64) to_reference_layout_kernel<double><<<grid, 256, 0, p->stream>>>((int) plane, g.N, (const Cplx<double> *) p->buf[BUF_XCHG], (Cplx<double> *) delta_k);
-    else to_reference_layout_kernel<float><<<grid, 256, 0, p->stream>>>((int) plane, g.N, (const Cplx<float> *) p->buf[BUF_XCHG], (Cplx<float> *) delta_k);
-    FPM_CHECK_HIP(hipGetLastError());
+    FPM_CHECK_HIP(hipMemcpyAsync(p->buf[BUF_XCHG], host, ref_bytes(p), hipMemcpyHostToDevice, p->stream));
+    FPM_TRY(reference_layout<false>(p, delta_k, p->buf[BUF_XCHG]));
     FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
     return 0;
 }
@@ -605,16 +612,10 @@ int fpmhip_transfer_host(fpmhip_plan *p, int kernel, const void *delta_k_host, v
 int fpmhip_export_delta_k(fpmhip_plan *p, const void *delta_k, void *host)
 {
     if (!p || !delta_k || !host) FPM_FAIL(-1, "null argument");
-    if (p->lay.nranks_y > 1) FPM_FAIL(-1, "import / export of the reference layout: slabs only (a pencil's kz block is padded)");
     FPM_TRY(ensure_buffer(p, BUF_XCHG));
-    const MeshGeo &g = p->mg;
-    const long long plane = (long long) g.yl * g.nzl;
-    dim3 grid(blocks_for(plane, 32), blocks_for(g.N, 32));
-    if (p->f64) to_reference_layout_kernel<double><<<grid, 256, 0, p->stream>>>(g.N, plane, (const Cplx<double> *) delta_k, (Cplx<double> *) p->buf[BUF_XCHG]);
-    else to_reference_layout_kernel<float><<<grid, 256, 0, p->stream>>>(g.N, plane, (const Cplx<float> *) delta_k, (Cplx<float> *) p->buf[BUF_XCHG]);
-    FPM_CHECK_HIP(hipGetLastError());
-    FPM_CHECK_HIP(hipMemcpyAsync(host, p->buf[BUF_XCHG], (size_t) 2 * p->lay.complex_elems * p->esize,
-                                 hipMemcpyDeviceToHost, p->stream));
+    if (delta_k == p->buf[BUF_XCHG]) FPM_FAIL(-1, "export source must not be the exchange buffer");
+    FPM_TRY(reference_layout<true>(p, const_cast<void *>(delta_k), p->buf[BUF_XCHG]));
+    FPM_CHECK_HIP(hipMemcpyAsync(host, p->buf[BUF_XCHG], ref_bytes(p), hipMemcpyDeviceToHost, p->stream));
     FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
     return 0;
 }

@@ -21,6 +21,11 @@ void set_error(const char *fmt, ...)
 
 StageTimer::StageTimer(fpmhip_plan *plan, int stage) : p(plan), on(plan->timing)
 {
+    if (p->stage_hook && stage < FPMHIP_T_K_COLFFT) {       // top-level stages only; wall clocks on the host side
+        (void) hipStreamSynchronize(p->stream);
+        p->stage_hook(p->stage_hook_ctx, stage, 1);
+        hooked = stage;
+    }
     if (!on) return;
     if (!p->ev_free.empty()) {
         ev = p->ev_free.back();
@@ -37,6 +42,10 @@ StageTimer::StageTimer(fpmhip_plan *plan, int stage) : p(plan), on(plan->timing)
 
 StageTimer::~StageTimer()
 {
+    if (hooked >= 0) {
+        (void) hipStreamSynchronize(p->stream);
+        p->stage_hook(p->stage_hook_ctx, hooked, 0);
+    }
     if (!on) return;
     (void) hipEventRecord(ev.b, p->stream);
     p->ev_used.push_back(ev);
@@ -318,6 +327,14 @@ const char *fpmhip_timing_name(int stage)
 {
     if (stage < 0 || stage >= FPMHIP_T_COUNT) return "?";
     return stage_names[stage];
+}
+
+int fpmhip_set_stage_hook(fpmhip_plan *p, void (*hook)(void *ctx, int stage, int enter), void *ctx)
+{
+    if (!p) FPM_FAIL(-1, "null plan");
+    p->stage_hook = hook;
+    p->stage_hook_ctx = ctx;
+    return 0;
 }
 
 int fpmhip_timing_enable(fpmhip_plan *p, int on)

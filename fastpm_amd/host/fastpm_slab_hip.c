@@ -377,7 +377,6 @@ int fastpm_hip_mesh_force_species_host(fpmhip_plan *plan, const fastpm_hip_trans
     if (!plan || !t || !sets || nsets < 1 || nsets > 6) return -1;
     fpmhip_layout lay;
     TRY(fpmhip_plan_layout(plan, &lay));
-    if (delta_k_host && lay.nranks_y > 1) return -1;            /* the reference layout export is a slab feature */
     size_t np = 0;
     int any_mass = 0, any_pot = 0;
     for (int si = 0; si < nsets; si++) {

@@ -1,0 +1,209 @@
+/*
+ * gravity_hip.c -- the translation unit that REPLACES libfastpm/gravity.c in libfastpm/Makefile's object list
+ * (libfastpm/Makefile:14-49).  It defines, with the reference's own signatures, the three public symbols of
+ * api/fastpm/gravity.h:5-22 and routes them to the MI355X library through the C ABI of include/fastpm_hip.h.
+ *
+ * This file is compiled INSIDE libfastpm (it needs the private struct PM of libfastpm/pmpfft.h): add
+ *     -I<repo>/include -I<repo>/fastpm_amd/host                            to CPPFLAGS,
+ *     -L<repo>/fastpm_amd -lfastpm_hip_mpi -lfastpm_hip_host -lfastpm_hip  to the link line,
+ * and list gravity_hip.o instead of gravity.o.  In this repository it cannot be linked (the reference needs GSL and
+ * PFFT, absent from the image); tests/test_boundary_compiles.py type-checks it against the reference's real headers
+ * with `gcc -fsyntax-only` wherever /root/reference exists, so a renamed struct member or a changed prototype fails
+ * a test here.  The same logic against view structs, compiled, linked and run on the GPU, is
+ * fastpm_gravity_hip.c / fastpm_slab_hip.c (tests/test_gpu_chost.py).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <mpi.h>
+
+#include <fastpm/libfastpm.h>
+#include <fastpm/prof.h>
+#include <fastpm/logging.h>
+
+#include "pmpfft.h"                 /* struct PM is private to libfastpm: this file lives inside it */
+
+#include <fastpm_hip.h>
+#include "fastpm_slab_hip.h"
+#include "fastpm_slab_mpi.h"
+
+/* One GPU plan (and, for NTask > 1, one transport on pm->Comm2D) per PM, made at the first force call on that PM.
+ * solver.c:100, 112, 132 and vpm.c:22-58 create every PM up front, one per pm_nc_factor entry; fastpm_find_pm hands
+ * the same PM * back for every step at that resolution, so the cache key is the pointer. */
+typedef struct PlanCache {
+    PM * pm;
+    fpmhip_plan * plan;
+    fastpm_hip_transport * transport;
+    struct PlanCache * next;
+} PlanCache;
+
+static PlanCache * plans = NULL;
+
+static PlanCache *
+plan_for(PM * pm)
+{
+    PlanCache * c;
+    for(c = plans; c; c = c->next) {
+        if(c->pm == pm) return c;
+    }
+    if(pm->Nmesh[0] != pm->Nmesh[1] || pm->Nmesh[0] != pm->Nmesh[2]) {
+        fastpm_raise(-1, "the MI355X force step needs a cubic mesh\n");
+    }
+    fpmhip_geom g;
+    memset(&g, 0, sizeof(g));
+    g.Nmesh = pm->Nmesh[0];
+    g.BoxSize = pm->BoxSize[0];
+    g.precision = 8 * (int) sizeof(FastPMFloat);       /* FASTPM_FFT_PRECISION */
+    g.nranks = pm->NTask;
+    g.nranks_y = pm->Nproc[1];                          /* pencils when NprocY != 1 (pmpfft.c:117-136) */
+    /* the rank that decides this process' IRegion / ORegion is its rank in the 2-d process mesh */
+    int rank2d = pm->ThisTask;
+    if(pm->NTask > 1) MPI_Comm_rank(pm->Comm2D, &rank2d);
+    g.rank = rank2d;
+    g.device = -1;                                      /* the launcher binds one GPU per rank */
+    c = malloc(sizeof(*c));
+    c->transport = NULL;
+    if(fpmhip_plan_create(&g, NULL, &c->plan)) {
+        fastpm_raise(-1, "%s\n", fpmhip_last_error());
+    }
+    if(pm->NTask > 1) {
+        /* the three exchanges of the force step as MPI calls on pm->Comm2D; FASTPM_HIP_GPU_AWARE_MPI=1 hands device
+         * pointers to MPI, =2 selects RCCL over xGMI (one rank per GPU), otherwise staged through the host */
+        const char * e = getenv("FASTPM_HIP_GPU_AWARE_MPI");
+        int mode = e ? atoi(e) : 0;
+        int device = 0;
+        if(mode == 2) {
+            fpmhip_layout lay;
+            fpmhip_plan_layout(c->plan, &lay);
+            device = rank2d % fpmhip_device_count();
+            c->transport = fastpm_hip_rccl_transport_create(pm->Comm2D, device);
+        } else {
+            c->transport = fastpm_hip_mpi_transport_create(pm->Comm2D, c->plan, mode);
+        }
+        if(!c->transport) fastpm_raise(-1, "no transport for the MI355X force step\n");
+    }
+    c->pm = pm;
+    c->next = plans;
+    plans = c;
+    return c;
+}
+
+void
+fastpm_kernel_type_get_orders(FastPMKernelType type,
+    int *potorder,
+    int *gradorder,
+    int *difforder,
+    int *deconvolveorder)
+{
+    if(fpmhip_kernel_type_get_orders(type, potorder, gradorder, difforder, deconvolveorder)) {
+        fastpm_raise(-1, "Wrong kernel type\n");
+    }
+}
+
+/* The reference times the force step stage by stage (gravity.c:276, 320, 344, 348, 369-372, 474): the library calls
+ * back at the stage boundaries (stream synchronised) and the same clocks tick. */
+enum { CLK_GHOSTS, CLK_PAINT, CLK_R2C, CLK_TRANSFER, CLK_C2R, CLK_READOUT, CLK_REDUCE, CLK_DEALIAS, CLK_COUNT };
+
+static void
+stage_clock(void * ctx, int stage, int enter)
+{
+    FastPMClock ** clk = ctx;
+    int which;
+    switch(stage) {
+        case FPMHIP_T_SORT:                              /* binning the particles is part of painting them */
+        case FPMHIP_T_PAINT:    which = CLK_PAINT; break;
+        case FPMHIP_T_R2C:      which = CLK_R2C; break;
+        case FPMHIP_T_DEALIAS:  which = CLK_DEALIAS; break;
+        case FPMHIP_T_TRANSFER:
+        case FPMHIP_T_XBACK3:   which = CLK_TRANSFER; break;  /* transfer fused with the x passes of r2c / c2r */
+        case FPMHIP_T_C2R:      which = CLK_C2R; break;
+        case FPMHIP_T_READOUT:  which = CLK_READOUT; break;
+        case FPMHIP_T_HALO:     which = CLK_GHOSTS; break;    /* the mesh halo stands where the ghosts stood */
+        case FPMHIP_T_PACK:     which = CLK_REDUCE; break;
+        default: return;
+    }
+    if(enter) fastpm_clock_in(clk[which]);
+    else fastpm_clock_out(clk[which]);
+}
+
+void
+fastpm_solver_compute_force(FastPMSolver * fastpm,
+    PM * pm,
+    FastPMPainter * painter,
+    FastPMSofteningType dealias,
+    FastPMKernelType kernel,
+    FastPMFloat * delta_k,
+    double Time)
+{
+    static const char * names[CLK_COUNT] = {"ghosts", "paint", "r2c", "transfer", "c2r", "readout", "reduce", "dealias"};
+    FastPMClock * clk[CLK_COUNT];
+    int i;
+    for(i = 0; i < CLK_COUNT; i ++) {
+        clk[i] = fastpm_clock_find(__FILE__, __func__, names[i]);
+    }
+    if(painter->support != 2) {
+        fastpm_raise(-1, "the MI355X force step implements the CIC painter (support 2), not support %d\n", painter->support);
+    }
+    if(fastpm->cosmology->ncdm_linearresponse) {
+        fastpm_raise(-1, "LRA neutrinos are not on the GPU path; link gravity.o instead\n");
+    }
+    (void) Time;
+
+    fpmhip_particles parts[FASTPM_SOLVER_NSPECIES];
+    int nsets = 0, si;
+    for(si = 0; si < FASTPM_SOLVER_NSPECIES; si ++) {          /* the species loop of gravity.c:279-287 */
+        FastPMStore * p = fastpm_solver_get_species(fastpm, si);
+        if(!p) continue;
+        memset(&parts[nsets], 0, sizeof(parts[nsets]));
+        parts[nsets].x = &p->x[0][0];
+        parts[nsets].mass = p->mass;
+        parts[nsets].M0 = p->meta.M0;
+        parts[nsets].np = (int64_t) p->np;
+        parts[nsets].acc = &p->acc[0][0];
+        parts[nsets].potential = p->potential;                  /* gravity.c:487-492 */
+        nsets ++;
+    }
+    if(nsets == 0) return;
+
+    PlanCache * c = plan_for(pm);
+    fpmhip_set_stage_hook(c->plan, stage_clock, clk);
+    int rc;
+    if(pm->NTask == 1) {
+        /* host columns up, acc down, delta_k in the ORegion layout the FORCE/AFTER handlers iterate with PMKIter */
+        rc = fpmhip_force_species_host(c->plan, parts, nsets, kernel, dealias, delta_k);
+    } else {
+        /* slabs (Nproc = {NTask, 1}) or pencils (Nproc = {Nx, Ny}): every species, the exchanges on pm->Comm2D */
+        rc = fastpm_hip_mesh_force_species_host(c->plan, c->transport, parts, nsets, kernel, dealias, delta_k);
+    }
+    fpmhip_set_stage_hook(c->plan, NULL, NULL);
+    if(rc) {
+        /* collective failure semantics of the reference: fastpm_raise aborts the communicator (logging.c:242-251) */
+        fastpm_raise(-1, "MI355X force step failed (%d): %s\n", rc, fpmhip_last_error());
+    }
+}
+
+void
+gravity_apply_kernel_transfer(FastPMKernelType kernel, PM * pm, FastPMFloat * delta_k, FastPMFloat * canvas, FastPMFieldDescr field)
+{
+    /* callers keep their meshes on the host in the ORegion layout (pm2lpt.c, pgdcorrection.c) */
+    int f;
+    switch(field.attribute) {
+        case COLUMN_ACC:
+            f = FPMHIP_FIELD_ACC_X + field.memb;
+            break;
+        case COLUMN_POTENTIAL:
+            f = FPMHIP_FIELD_POTENTIAL;
+            break;
+        case COLUMN_DENSITY:
+            f = FPMHIP_FIELD_DENSITY;
+            break;
+        case COLUMN_TIDAL:
+            f = FPMHIP_FIELD_TIDAL_XX + field.memb;
+            break;
+        default:
+            fastpm_raise(-1, "Unknown type for gravity attribute\n");
+            return;
+    }
+    if(fpmhip_transfer_host(plan_for(pm)->plan, kernel, delta_k, canvas, f)) {
+        fastpm_raise(-1, "%s\n", fpmhip_last_error());
+    }
+}

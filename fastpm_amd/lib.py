@@ -83,6 +83,7 @@ SYMBOLS = {
     "fpmhip_fft_y_backward_grad2": (_I, [_P, _P, _P, _P, _P, _I]),
     "fpmhip_fft_z_backward": (_I, [_P, _P, _P]),
     "fpmhip_yrow": (_I, [_P, _P, _I64, _P, _I]),
+    "fpmhip_set_stage_hook": (_I, [_P, _P, _P]),
     "fpmhip_softening": (_I, [_P, _P, _I]),
     "fpmhip_transfer": (_I, [_P, _P, _P, _I, _I]),
     "fpmhip_transfer_fft_x_backward3": (_I, [_P, _P, _P, _P, _P, _I]),

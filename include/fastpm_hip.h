@@ -324,7 +324,9 @@ int fpmhip_ic_seed_table(int Nmesh, int seed, unsigned int *table_host);
 
 /* pm_check_values (pmapi.c:335-356): count of NaN / |v| > 1e15 entries.  Synchronises. */
 int fpmhip_check_values(fpmhip_plan *plan, const void *mesh_dev, int64_t *count_host);
-/* copy a k-space mesh to the host in the reference's PFFT-transposed layout [y][z][x], and back */
+/* copy a k-space mesh to the host in the reference's PFFT-transposed layout [y_loc][kz_loc][x] (pmpfft.c:189-203; on
+ * pencils kz_loc = this rank's layout.ovalid_z modes of the block starting at ostart[2] -- PFFT's default blocks of
+ * ceil((N/2+1) / Nproc[1])), and back */
 int fpmhip_export_delta_k(fpmhip_plan *plan, const void *delta_k_dev, void *delta_k_host);
 int fpmhip_import_delta_k(fpmhip_plan *plan, const void *delta_k_host, void *delta_k_dev);
 /* gravity_apply_kernel_transfer (api/fastpm/gravity.h:21-22, gravity.c:174-242) for callers whose
@@ -403,6 +405,10 @@ enum { FPMHIP_T_SORT = 0, FPMHIP_T_PAINT, FPMHIP_T_R2C, FPMHIP_T_DEALIAS, FPMHIP
        FPMHIP_T_K_YBACK2,    /* colfft_yback2_kernel: potential -> y and z components, y pass (1 read, 2 writes) */
        FPMHIP_T_COUNT };
 int fpmhip_timing_enable(fpmhip_plan *plan, int on);
+/* Host callback at the start (enter = 1) and the end (enter = 0) of every top-level stage (FPMHIP_T_SORT ..
+ * FPMHIP_T_XBACK3), with the plan's stream synchronised before each call: lets the binding drive the reference's wall
+ * clocks -- CLOCK / ENTER / LEAVE of gravity.c:276, 320, 344, 348, 369-372 -- stage by stage.  NULL removes it. */
+int fpmhip_set_stage_hook(fpmhip_plan *plan, void (*hook)(void *ctx, int stage, int enter), void *ctx);
 int fpmhip_timing_reset(fpmhip_plan *plan);
 /* Synchronises; total milliseconds and launch count of one stage since the last reset. */
 int fpmhip_timing_get(fpmhip_plan *plan, int stage, double *total_ms, int64_t *count);

@@ -1,0 +1,84 @@
+"""The drop-in boundary, type-checked against the REFERENCE's own headers.
+
+fastpm_amd/host/gravity_hip.c is the translation unit a libfastpm maintainer lists instead of gravity.o: it defines
+the three public symbols of api/fastpm/gravity.h:5-22 with the reference's signatures and reads the reference's
+structs (FastPMSolver, PM, FastPMPainter, FastPMStore, FastPMCosmology, FastPMFieldDescr, FastPMClock).  The
+reference cannot be built in this image (GSL, PFFT absent), but its headers are there: `gcc -fsyntax-only` with the
+reference's include paths checks every prototype and every member access.  GSL appears in those headers only as
+pointer members (api/fastpm/FDinterp.h:1-8), so three opaque typedefs written here stand in for <gsl/gsl_spline.h>;
+MPI is the image's MPICH.  Build-container only: skipped where /root/reference does not exist (the GPU box), and no
+reference file is copied anywhere."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+MPI_INC = os.path.join(os.environ.get("FPM_MPI_ROOT", "/opt/conda"), "include")
+
+needs_reference = pytest.mark.skipif(
+    not (os.path.isdir(os.path.join(REF, "api", "fastpm")) and os.path.exists(os.path.join(MPI_INC, "mpi.h"))),
+    reason="needs the reference's headers and an mpi.h (build container only)")
+
+
+def _syntax_only(tmp_path, source, extra=()):
+    gsl = tmp_path / "gsl"
+    gsl.mkdir(exist_ok=True)
+    (gsl / "gsl_spline.h").write_text(                         # type-only stand-in, see the module docstring
+        "typedef struct gsl_interp gsl_interp;\ntypedef struct gsl_interp_accel gsl_interp_accel;\n"
+        "typedef struct gsl_spline gsl_spline;\n")
+    cmd = ["gcc", "-std=gnu99", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(REF, "api"),
+           "-I" + os.path.join(REF, "libfastpm"), "-I" + str(tmp_path), "-I" + MPI_INC,
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "fastpm_amd", "host"), *extra, source]
+    return subprocess.run(cmd, capture_output=True, text=True)
+
+
+@needs_reference
+def test_gravity_hip_c_type_checks_against_the_reference_headers(tmp_path):
+    r = _syntax_only(tmp_path, os.path.join(ROOT, "fastpm_amd", "host", "gravity_hip.c"))
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+@needs_reference
+def test_the_three_public_symbols_have_the_reference_signatures(tmp_path):
+    """A second definition with the prototypes copied from OUR reading of gravity.h must be compatible with the
+    reference's declarations: conflicting types are a compile error."""
+    probe = tmp_path / "probe.c"
+    probe.write_text('''
+#include <mpi.h>
+#include <fastpm/libfastpm.h>
+#include "pmpfft.h"
+/* api/fastpm/gravity.h:5-22, restated: a mismatch with the header included above is "conflicting types" */
+void fastpm_kernel_type_get_orders(FastPMKernelType type, int *potorder, int *gradorder, int *difforder, int *deconvolveorder);
+void fastpm_solver_compute_force(FastPMSolver * fastpm, PM * pm, FastPMPainter * painter, FastPMSofteningType dealias,
+                                 FastPMKernelType kernel, FastPMFloat * delta_k, double Time);
+void gravity_apply_kernel_transfer(FastPMKernelType kernel, PM * pm, FastPMFloat * delta_k, FastPMFloat * canvas,
+                                   FastPMFieldDescr field);
+/* the members gravity_hip.c reads */
+static void members(FastPMSolver * s, PM * pm, FastPMPainter * pa, FastPMStore * st) {
+    (void) s->cosmology->ncdm_linearresponse; (void) pm->Nproc[1]; (void) pm->Comm2D; (void) pm->NTask;
+    (void) pm->ThisTask; (void) pm->Nmesh[0]; (void) pm->BoxSize[0]; (void) pa->support; (void) st->x[0][0];
+    (void) st->acc[0][0]; (void) st->mass; (void) st->potential; (void) st->meta.M0; (void) st->np;
+    (void) fastpm_solver_get_species(s, FASTPM_SPECIES_CDM);
+}
+int main(void) { (void) members; return FASTPM_SOLVER_NSPECIES == 6 ? 0 : 1; }
+''')
+    r = _syntax_only(tmp_path, str(probe), extra=("-Wno-unused-function",))
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+@needs_reference
+def test_a_wrong_member_would_be_caught(tmp_path):
+    """The check has teeth: the same file with one member renamed does not compile."""
+    src = open(os.path.join(ROOT, "fastpm_amd", "host", "gravity_hip.c")).read()
+    assert "pm->Nproc[1]" in src
+    bad = tmp_path / "gravity_bad.c"
+    bad.write_text(src.replace("pm->Nproc[1]", "pm->NprocY"))
+    r = _syntax_only(tmp_path, str(bad))
+    assert r.returncode != 0 and "NprocY" in r.stderr
+
+
+def test_integration_md_points_at_the_compiled_binding():
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "fastpm_amd/host/gravity_hip.c" in text

@@ -26,11 +26,21 @@ def test_header_symbols_are_exported_and_bound():
     assert L.fpmhip_version().startswith(b"fastpm_hip")
 
 
-def test_struct_layouts_match_header_sizes():
+def test_struct_layouts_match_header_sizes(tmp_path):
+    """ctypes mirrors (fastpm_amd/lib.py) against what the C compiler makes of include/fastpm_hip.h: sizes and the
+    offsets of the last members."""
+    import subprocess
     from fastpm_amd import lib
-    assert ctypes.sizeof(lib.Geom) == 56      # + gradient_mode, padded to 8
-    assert ctypes.sizeof(lib.Particles) == 48
-    assert ctypes.sizeof(lib.Layout) == 8 + 8 + 16 + 9 * 8 + 16 + 9 * 8 + 24 + 8
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "fastpm_hip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", '
+                   'sizeof(fpmhip_geom), sizeof(fpmhip_particles), sizeof(fpmhip_layout), offsetof(fpmhip_geom, nranks_y), '
+                   'offsetof(fpmhip_layout, chunk_b_elems), sizeof(fpmhip_kick_factor), sizeof(fpmhip_drift_factor)); return 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert got == [ctypes.sizeof(lib.Geom), ctypes.sizeof(lib.Particles), ctypes.sizeof(lib.Layout),
+                   lib.Geom.nranks_y.offset, lib.Layout.chunk_b_elems.offset, ctypes.sizeof(lib.KickFactor),
+                   ctypes.sizeof(lib.DriftFactor)]
 
 
 def test_kernel_orders_and_error_convention():
@@ -49,7 +59,7 @@ def test_no_cpu_fallback():
     with pytest.raises(FastPMHipError, match="no HIP device"):
         PM(16, 48.0)
     L = lib.load_library()
-    g = lib.Geom(16, 48.0, 64, 1, 0, -1, 0, 0, 0)
+    g = lib.Geom(16, 48.0, 64, 1, 0, -1, 0, 0, 0, 0, 1)
     plan = ctypes.c_void_p()
     assert L.fpmhip_plan_create(ctypes.byref(g), None, ctypes.byref(plan)) != 0
     assert b"device" in L.fpmhip_last_error()
