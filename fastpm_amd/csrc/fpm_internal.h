@@ -135,9 +135,18 @@ struct fpmhip_plan {
     float *smass = nullptr;
     int *sidx = nullptr;
     int ntiles = 0;
-    int *tile_cnt = nullptr;   // [2 * ntiles + 1] counts: own tiles then dup tiles
-    int *tile_off = nullptr;   // exclusive scan of tile_cnt (+ total at the end)
-    int *tile_cur = nullptr;   // scatter cursors
+    // slabs of the entry arrays per key (own tile t -> t, dup tile t -> ntiles + t), see fpm_particles.hip
+    int *bin_beg[2] = {nullptr, nullptr};   // [2 ntiles + 1] slab starts: [0] this call's, [1] laid out for the next call
+    int *bin_cap[2] = {nullptr, nullptr};   // [2 ntiles] slab capacities
+    int *bin_cnt = nullptr;                 // [2 ntiles + 1] entries per key (the scatter's cursors)
+    int *bin_off = nullptr, *bin_capv = nullptr, *bin_tmp = nullptr;   // exact offsets, capacities, scan scratch
+    int *order[2] = {nullptr, nullptr};     // [np] particle rows in tile order: [0] this call's, [1] the previous call's
+    int64_t order_cap = 0;
+    int64_t bin_alloc = 0, bin_grow = 0;    // entries the arrays hold; wanted after a reported overflow
+    int64_t layout_np = -1;                 // np the next-call layout and order[0] were made for
+    int *d_flags = nullptr, *h_flags = nullptr;   // device flags of the binning and their pinned host copy
+    hipEvent_t flags_event = nullptr;
+    bool flags_pending = false;
     void *scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
     int *h_pinned = nullptr;   // pinned scratch for small read-backs
@@ -184,6 +193,7 @@ int ensure_bins(fpmhip_plan *p, int64_t np, int64_t ndup, bool has_mass);
 
 // fpm_particles.hip
 int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt);
+int check_deferred(fpmhip_plan *p, bool wait);   // errors a binning reported after its call returned
 
 // fpm_fft.hip
 int fft_setup(fpmhip_plan *p);

@@ -155,32 +155,56 @@ __device__ __forceinline__ int wave_agg_resolve(const AggSlot &a)
     return __shfl(a.pend, a.leader) + a.rank;
 }
 
-// Pass A / C of the counting sort.  SCATTER = false: count entries per tile (own tiles in
-// cnt[0, ntiles), dup tiles in cnt[ntiles, 2 ntiles)).  SCATTER = true: place the entries.
+// ------------------------------------------------------------------------------------------
+// Tile binning.  Keys: own tile t -> t, dup tile t -> ntiles + t.  The entries of key k live in a SLAB
+// [beg[k], beg[k] + cap[k]) of the entry arrays, cnt[k] of them filled.
+//
+// Steady state (a layout from the previous call exists): ONE pass.  The particles are visited in the previous call's
+// tile order (order_prev), so a wave's 64 particles fall into one or two tiles whatever the order of the store's rows
+// is, the slab cursors are bumped by wave-aggregated atomics and the entries land in slabs sized from the previous
+// call's counts + 25 % + 32.  No count pass, no scan in front of the scatter, no host round trip.
+// A slab that overflows (the particles moved a lot, or they are other particles) raises a DEVICE flag, and the
+// exact two-pass path -- count, layout, scatter in natural order -- that is enqueued behind it, predicated on that
+// flag, redoes the binning in the same stream.  The first call on a plan runs the two-pass path unconditionally.
+// ------------------------------------------------------------------------------------------
+enum { FLAG_NEED_FULL = 0, FLAG_UNOWNED_FAST, FLAG_UNOWNED_FULL, FLAG_HARD_OVF, FLAG_TOTAL, FLAG_STALE, FLAG_COUNT };
+
 // A thread takes PPT particles (block-strided, so a wave still reads 64 consecutive rows): all
 // position loads first, then all atomics, then all stores -- the kernel is a chain of dependent
 // memory round trips per wave, and PPT independent chains overlap them.
 constexpr int BIN_PPT = 2;
 
-template <bool SCATTER, int PPT>
+// SCATTER = false: count entries per key.  SCATTER = true: place them.  ORDERED: particle j is order[j].
+// pred (nullable): run only if *pred != 0.  FULL: this is the exact path (overflow = the arrays are too small).
+template <bool SCATTER, bool ORDERED, bool FULL, int PPT>
 __global__ __launch_bounds__(256) void bin_kernel(MeshGeo g, int ntiles, const double *__restrict__ x,
                                                   const float *__restrict__ mass, long long np,
-                                                  int *__restrict__ cnt_or_cur,
+                                                  const int *__restrict__ order, const int *__restrict__ beg,
+                                                  const int *__restrict__ cap, int *__restrict__ cnt,
                                                   double *__restrict__ sx, double *__restrict__ sy,
                                                   double *__restrict__ sz, float *__restrict__ smass,
-                                                  int *__restrict__ sidx)
+                                                  int *__restrict__ sidx, int *__restrict__ flags,
+                                                  const int *__restrict__ pred)
 {
-    const long long i0 = (long long) blockIdx.x * (256 * PPT) + threadIdx.x;
+    if (pred && *pred == 0) return;
+    const long long j0 = (long long) blockIdx.x * (256 * PPT) + threadIdx.x;
     double px[PPT], py[PPT], pz[PPT];
     float pm[PPT];
+    int row[PPT];
     bool active[PPT];
 #pragma unroll
     for (int u = 0; u < PPT; u++) {
-        const long long i = i0 + u * 256;
-        active[u] = i < np;
+        const long long j = j0 + u * 256;
+        active[u] = j < np;
+        row[u] = 0;
+        if (active[u]) row[u] = ORDERED ? order[j] : (int) j;
+    }
+#pragma unroll
+    for (int u = 0; u < PPT; u++) {
         px[u] = py[u] = pz[u] = 0;
         pm[u] = 0;
         if (active[u]) {
+            const long long i = row[u];
             px[u] = x[3 * i + 0];
             py[u] = x[3 * i + 1];
             pz[u] = x[3 * i + 2];
@@ -195,8 +219,8 @@ __global__ __launch_bounds__(256) void bin_kernel(MeshGeo g, int ntiles, const d
         if (active[u]) {
             Cic c;
             if (!cic_setup(g, px[u], py[u], pz[u], c)) {
-                // not this rank's particle: flagged in the last counter slot, reported by the host
-                if (!SCATTER) atomicAdd(&cnt_or_cur[2 * ntiles * BIN_PRIV + 1], 1);
+                // not this rank's particle: counted, reported by the host (lazily in the steady state)
+                if (SCATTER) atomicAdd(&flags[FULL ? FLAG_UNOWNED_FULL : FLAG_UNOWNED_FAST], 1);
                 active[u] = false;
             }
             t0[0] = c.i0[0] / TILE_X; t0[1] = c.i0[1] / TILE_Y; t0[2] = c.i0[2] / TILE_Z;
@@ -207,9 +231,7 @@ __global__ __launch_bounds__(256) void bin_kernel(MeshGeo g, int ntiles, const d
         for (int c = 0; c < 8; c++) {
             const int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
             need[u][c] = active[u] && (!bx || t1[0] != t0[0]) && (!by || t1[1] != t0[1]) && (!bz || t1[2] != t0[2]);
-            // counter / cursor copy (blockIdx.x % BIN_PRIV) of the tile: layout [own | dup][tile][copy]
-            key[u][c] = ((c ? ntiles : 0) + tile_id(g, bx ? t1[0] : t0[0], by ? t1[1] : t0[1], bz ? t1[2] : t0[2])) * BIN_PRIV
-                        + (int) (blockIdx.x % BIN_PRIV);
+            key[u][c] = (c ? ntiles : 0) + tile_id(g, bx ? t1[0] : t0[0], by ? t1[1] : t0[1], bz ? t1[2] : t0[2]);
         }
     }
     if (!SCATTER) {
@@ -218,7 +240,7 @@ __global__ __launch_bounds__(256) void bin_kernel(MeshGeo g, int ntiles, const d
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 if (__ballot(need[u][c]) == 0) continue;
-                (void) wave_agg_inc<false>(cnt_or_cur, key[u][c], need[u][c]);
+                (void) wave_agg_inc<false>(cnt, key[u][c], need[u][c]);
             }
         return;
     }
@@ -229,20 +251,98 @@ __global__ __launch_bounds__(256) void bin_kernel(MeshGeo g, int ntiles, const d
         for (int c = 0; c < 8; c++) {
             a[u][c] = AggSlot{0, 0, 0};
             if (__ballot(need[u][c]) == 0) continue;
-            a[u][c] = wave_agg_issue(cnt_or_cur, key[u][c], need[u][c]);
+            a[u][c] = wave_agg_issue(cnt, key[u][c], need[u][c]);
         }
+    bool spilled = false;
 #pragma unroll
     for (int u = 0; u < PPT; u++)
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             if (__ballot(need[u][c]) == 0) continue;
-            const int slot = wave_agg_resolve(a[u][c]);
+            const int local = wave_agg_resolve(a[u][c]);
             if (need[u][c]) {
-                sx[slot] = px[u]; sy[slot] = py[u]; sz[slot] = pz[u];
-                if (smass) smass[slot] = pm[u];
-                sidx[slot] = (int) (i0 + u * 256);
+                const int k = key[u][c];
+                if (local < cap[k]) {
+                    const int slot = beg[k] + local;
+                    sx[slot] = px[u]; sy[slot] = py[u]; sz[slot] = pz[u];
+                    if (smass) smass[slot] = pm[u];
+                    sidx[slot] = row[u];
+                } else {
+                    spilled = true;
+                }
             }
         }
+    if (__ballot(spilled) && __lane_id() == 0) flags[FULL ? FLAG_HARD_OVF : FLAG_NEED_FULL] = 1;
+}
+
+// capacity of every slab from the counts: + 25 % + 32 while the arrays have room for that, the exact counts
+// otherwise; more entries than the arrays hold at all is the (lazily reported) hard overflow
+__global__ __launch_bounds__(256) void slab_caps_kernel(const int *__restrict__ cnt, const int *__restrict__ off, int nkeys,
+                                                        long long alloc, int *__restrict__ capv, int *__restrict__ flags,
+                                                        const int *__restrict__ pred)
+{
+    if (pred && *pred == 0) return;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = off[nkeys];
+    const bool slack = total + total / 4 + 33ll * nkeys <= alloc;
+    if (k == 0) {
+        flags[FLAG_TOTAL] = (int) total;
+        if (total > alloc) flags[FLAG_HARD_OVF] = 1;
+    }
+    if (k < nkeys) capv[k] = slack ? cnt[k] + cnt[k] / 4 + 32 : cnt[k];
+    if (k == nkeys) capv[k] = 0;
+}
+
+// the scanned capacities become a layout (and the counters restart from zero when the scatter is still to come)
+__global__ __launch_bounds__(256) void slab_commit_kernel(const int *__restrict__ beg_tmp, const int *__restrict__ capv,
+                                                          int nkeys, int *__restrict__ beg, int *__restrict__ cap,
+                                                          int *__restrict__ cnt_to_zero, const int *__restrict__ pred)
+{
+    if (pred && *pred == 0) return;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k <= nkeys) beg[k] = beg_tmp[k];
+    if (k < nkeys) {
+        cap[k] = capv[k];
+        if (cnt_to_zero) cnt_to_zero[k] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void zero_ints_kernel(int *__restrict__ a, int n, const int *__restrict__ pred)
+{
+    if (pred && *pred == 0) return;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) a[k] = 0;
+}
+
+// the own entries' particle rows in tile order, compact: what the next call walks, what fpmhip_tile_order returns,
+// and what the flat (not tile-staged) readouts iterate.  One wave per tile.
+__global__ __launch_bounds__(256) void tile_order_kernel(int ntiles, const int *__restrict__ beg, const int *__restrict__ cnt,
+                                                         const int *__restrict__ off, const int *__restrict__ sidx,
+                                                         int *__restrict__ order, const int *__restrict__ pred)
+{
+    if (pred && *pred == 0) return;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= ntiles) return;
+    const int b = beg[t], n = cnt[t], o = off[t];
+    for (int k = lane; k < n; k += 64) order[o + k] = sidx[b + k];
+}
+
+// Is the binning the plan holds still the binning of THESE positions?  One entry of every non-empty own tile is
+// compared, bit for bit, with the row it was copied from: any wholesale change of the positions behind the same pointer
+// (an in-place update, a new tensor at a recycled address) trips it, and the exact path enqueued behind it rebins in the
+// same stream.  (A caller that edits rows in place calls fpmhip_invalidate_binning.)
+__global__ __launch_bounds__(256) void verify_binning_kernel(int ntiles, const int *__restrict__ beg, const int *__restrict__ cnt,
+                                                             const double *__restrict__ sx, const double *__restrict__ sy,
+                                                             const double *__restrict__ sz, const int *__restrict__ sidx,
+                                                             const double *__restrict__ x, int *__restrict__ flags)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    const int n = cnt[t];
+    if (n == 0) return;
+    const int e = beg[t] + t % n;
+    const long long i = sidx[e];
+    if (sx[e] != x[3 * i] || sy[e] != x[3 * i + 1] || sz[e] != x[3 * i + 2]) flags[FLAG_STALE] = 1;
 }
 
 // XCD-aware block -> tile map: consecutive tiles (which share mesh rows in the readout) go to
@@ -261,7 +361,7 @@ __device__ __forceinline__ int xcd_remap(int b, int n)
 // transfer.c:212-220 with the same rounding points.
 template <typename F>
 __global__ __launch_bounds__(256) void paint_tiles_kernel(MeshGeo g, int ntiles,
-                                                          const int *__restrict__ off,
+                                                          const int *__restrict__ tbeg, const int *__restrict__ tcnt,
                                                           const double *__restrict__ sx,
                                                           const double *__restrict__ sy,
                                                           const double *__restrict__ sz,
@@ -283,7 +383,7 @@ __global__ __launch_bounds__(256) void paint_tiles_kernel(MeshGeo g, int ntiles,
 #pragma unroll
     for (int part = 0; part < 2; part++) {
         const int key = part * ntiles + t;
-        const int beg = off[key], end = off[key + 1];
+        const int beg = tbeg[key], end = beg + tcnt[key];
         for (int e = beg + threadIdx.x; e < end; e += 256) {
             Cic c;
             (void) cic_setup(g, sx[e], sy[e], sz[e], c);
@@ -562,13 +662,9 @@ __global__ __launch_bounds__(256) void readout_kernel(MeshGeo g, long long np,
     if (j >= np) return;
     double px, py, pz;
     long long row;
-    if (BINNED) {
-        px = sx[j]; py = sy[j]; pz = sz[j];
-        row = sidx[j];
-    } else {
-        px = x[3 * j]; py = x[3 * j + 1]; pz = x[3 * j + 2];
-        row = j;
-    }
+    row = BINNED ? sidx[j] : j;           // BINNED: sidx = the compact tile order; positions straight from the store
+    px = x[3 * row]; py = x[3 * row + 1]; pz = x[3 * row + 2];
+    (void) sx; (void) sy; (void) sz;
     Cic c;
     if (!cic_setup(g, px, py, pz, c)) return;
     const int ix[2] = {c.i0[0], c.i1[0]}, iy[2] = {c.i0[1], c.i1[1]}, iz[2] = {c.i0[2], c.i1[2]};
@@ -661,13 +757,9 @@ __global__ __launch_bounds__(256) void readout_grad_kernel(MeshGeo g, long long 
     if (j >= np) return;
     double px, py, pz;
     long long row;
-    if (BINNED) {
-        px = sx[j]; py = sy[j]; pz = sz[j];
-        row = sidx[j];
-    } else {
-        px = x[3 * j]; py = x[3 * j + 1]; pz = x[3 * j + 2];
-        row = j;
-    }
+    row = BINNED ? sidx[j] : j;           // BINNED: sidx = the compact tile order; positions straight from the store
+    px = x[3 * row]; py = x[3 * row + 1]; pz = x[3 * row + 2];
+    (void) sx; (void) sy; (void) sz;
     Cic c;
     if (!cic_setup(g, px, py, pz, c)) return;
     // plane bases and row / column offsets for the offsets -2 .. +3 around the base cell
@@ -698,7 +790,7 @@ __global__ __launch_bounds__(256) void readout_grad_kernel(MeshGeo g, long long 
 // three workgroups per CU), then every particle takes its 56 values from LDS.  Same arithmetic as
 // readout_grad_kernel (grad_cic), bit-identical results.  The default.
 template <typename F>
-__global__ __launch_bounds__(256) void readout_grad_tiles_kernel(MeshGeo g, int ntiles, const int *__restrict__ off,
+__global__ __launch_bounds__(256) void readout_grad_tiles_kernel(MeshGeo g, int ntiles, const int *__restrict__ tbeg, const int *__restrict__ tcnt,
                                                                  const double *__restrict__ sx,
                                                                  const double *__restrict__ sy,
                                                                  const double *__restrict__ sz,
@@ -710,7 +802,7 @@ __global__ __launch_bounds__(256) void readout_grad_tiles_kernel(MeshGeo g, int 
     extern __shared__ __align__(16) unsigned char smem_rg[];
     F *reg = (F *) smem_rg;                       // [RX][RY][RZ]
     const int t = xcd_remap(blockIdx.x, ntiles);
-    const int beg = off[t], end = off[t + 1];
+    const int beg = tbeg[t], end = beg + tcnt[t];
     if (beg == end) return;
     const int tz = t % g.ntz, ty = (t / g.ntz) % g.nty, tx = t / (g.ntz * g.nty);
     const int x0 = tx * TILE_X - 2, y0 = ty * TILE_Y - 2, z0 = tz * TILE_Z - 2;
@@ -737,7 +829,7 @@ __global__ __launch_bounds__(256) void readout_grad_tiles_kernel(MeshGeo g, int 
 // mesh row once per tile instead of once per particle wave (measured traffic of the direct-gather
 // kernel: 1.6x the algorithmic bytes).
 template <typename F>
-__global__ __launch_bounds__(256) void readout3_tiles_kernel(MeshGeo g, int ntiles, const int *__restrict__ off,
+__global__ __launch_bounds__(256) void readout3_tiles_kernel(MeshGeo g, int ntiles, const int *__restrict__ tbeg, const int *__restrict__ tcnt,
                                                              const double *__restrict__ sx,
                                                              const double *__restrict__ sy,
                                                              const double *__restrict__ sz,
@@ -749,7 +841,7 @@ __global__ __launch_bounds__(256) void readout3_tiles_kernel(MeshGeo g, int ntil
     extern __shared__ __align__(16) unsigned char smem_ro[];
     F *reg = (F *) smem_ro;                       // [3][RX][RY][RZ]
     const int t = xcd_remap(blockIdx.x, ntiles);
-    const int beg = off[t], end = off[t + 1];
+    const int beg = tbeg[t], end = beg + tcnt[t];
     if (beg == end) return;                       // empty tile: nothing to read out
     const int tz = t % g.ntz, ty = (t / g.ntz) % g.nty, tx = t / (g.ntz * g.nty);
     const int x0 = tx * TILE_X, y0 = ty * TILE_Y, z0 = tz * TILE_Z;
@@ -782,7 +874,7 @@ __global__ __launch_bounds__(256) void readout3_tiles_kernel(MeshGeo g, int ntil
 // instead of 64 KB: 7 instead of 2 workgroups per CU to hide the staging loads behind), at the price of reading the
 // tile's positions three times (L2) and 4-byte result stores.
 template <typename F>
-__global__ __launch_bounds__(256) void readout1of3_tiles_kernel(MeshGeo g, int ntiles, const int *__restrict__ off,
+__global__ __launch_bounds__(256) void readout1of3_tiles_kernel(MeshGeo g, int ntiles, const int *__restrict__ tbeg, const int *__restrict__ tcnt,
                                                                 const double *__restrict__ sx,
                                                                 const double *__restrict__ sy,
                                                                 const double *__restrict__ sz,
@@ -795,7 +887,7 @@ __global__ __launch_bounds__(256) void readout1of3_tiles_kernel(MeshGeo g, int n
     F *reg = (F *) smem_ro;                       // [RX][RY][RZ]
     const int b = xcd_remap(blockIdx.x, 3 * ntiles);
     const int t = b / 3, comp = b - 3 * t;
-    const int beg = off[t], end = off[t + 1];
+    const int beg = tbeg[t], end = beg + tcnt[t];
     if (beg == end) return;
     const int tz = t % g.ntz, ty = (t / g.ntz) % g.nty, tx = t / (g.ntz * g.nty);
     const int x0 = tx * TILE_X, y0 = ty * TILE_Y, z0 = tz * TILE_Z;
@@ -839,64 +931,151 @@ __global__ __launch_bounds__(256) void mass_sum_kernel(const float *__restrict__
 
 static inline unsigned blocks_for(long long n, int bs) { return (unsigned) ((n + bs - 1) / bs); }
 
-// tile offsets = the scanned counters at copy 0 of every tile (+ the grand total)
-__global__ __launch_bounds__(256) void tile_offsets_kernel(const int *__restrict__ scanned, int *__restrict__ off, int n)
+static int scan_ints(fpmhip_plan *p, const int *in, int *out, size_t n)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j <= n) off[j] = scanned[(long long) j * BIN_PRIV];
+    size_t tmp_bytes = 0;
+    FPM_CHECK_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, 0, n, rocprim::plus<int>(), p->stream));
+    if (tmp_bytes > p->scan_tmp_bytes) {
+        // (the old buffer may still be in use by a scan in flight: retire it in stream order)
+        if (p->scan_tmp) { FPM_CHECK_HIP(hipStreamSynchronize(p->stream)); FPM_CHECK_HIP(hipFree(p->scan_tmp)); }
+        FPM_CHECK_HIP(hipMalloc(&p->scan_tmp, tmp_bytes));
+        p->scan_tmp_bytes = tmp_bytes;
+    }
+    FPM_CHECK_HIP(rocprim::exclusive_scan(p->scan_tmp, tmp_bytes, in, out, 0, n, rocprim::plus<int>(), p->stream));
+    return 0;
+}
+
+// counts -> (beg, cap): exact offsets (kept in bin_off, with the total), slab capacities, their scan
+static int make_layout(fpmhip_plan *p, int *beg, int *cap, const int *pred, bool zero_counts)
+{
+    const int nkeys = 2 * p->ntiles;
+    FPM_TRY(scan_ints(p, p->bin_cnt, p->bin_off, (size_t) nkeys + 1));
+    slab_caps_kernel<<<blocks_for(nkeys + 1, 256), 256, 0, p->stream>>>(p->bin_cnt, p->bin_off, nkeys, p->bin_alloc,
+                                                                      p->bin_capv, p->d_flags, pred);
+    FPM_TRY(scan_ints(p, p->bin_capv, p->bin_tmp, (size_t) nkeys + 1));
+    slab_commit_kernel<<<blocks_for(nkeys + 1, 256), 256, 0, p->stream>>>(p->bin_tmp, p->bin_capv, nkeys, beg, cap,
+                                                                        zero_counts ? p->bin_cnt : nullptr, pred);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// the exact two-pass binning in natural order (unconditional, or predicated on the device flag `pred`)
+static int bin_full(fpmhip_plan *p, const fpmhip_particles *pt, const int *pred)
+{
+    const long long np = pt->np;
+    const int nt = p->ntiles, nkeys = 2 * nt;
+    const unsigned nb = blocks_for(np, 256 * BIN_PPT);
+    zero_ints_kernel<<<blocks_for(nkeys + 1, 256), 256, 0, p->stream>>>(p->bin_cnt, nkeys + 1, pred);
+    if (np > 0)
+        bin_kernel<false, false, true, BIN_PPT><<<nb, 256, 0, p->stream>>>(
+            p->mg, nt, pt->x, pt->mass, np, nullptr, nullptr, nullptr, p->bin_cnt, nullptr, nullptr, nullptr, nullptr,
+            nullptr, p->d_flags, pred);
+    FPM_TRY(make_layout(p, p->bin_beg[0], p->bin_cap[0], pred, true));
+    if (np > 0)
+        bin_kernel<true, false, true, BIN_PPT><<<nb, 256, 0, p->stream>>>(
+            p->mg, nt, pt->x, pt->mass, np, nullptr, p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
+            pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, pred);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// what every binning ends with: the next call's layout from this call's counts, and the compact tile order
+static int bin_finish(fpmhip_plan *p, const int *pred)
+{
+    const int nt = p->ntiles;
+    FPM_TRY(make_layout(p, p->bin_beg[1], p->bin_cap[1], pred, false));       // leaves the exact offsets in bin_off
+    tile_order_kernel<<<blocks_for(nt, 4), 256, 0, p->stream>>>(nt, p->bin_beg[0], p->bin_cnt, p->bin_off, p->sidx,
+                                                                 p->order[0], pred);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// the flags of an earlier binning, once they have arrived (never waits)
+int check_deferred(fpmhip_plan *p, bool wait)
+{
+    if (!p->flags_pending) return 0;
+    if (wait) FPM_CHECK_HIP(hipEventSynchronize(p->flags_event));
+    else if (hipEventQuery(p->flags_event) != hipSuccess) return 0;
+    p->flags_pending = false;
+    const int *f = p->h_flags;
+    const int unowned = f[FLAG_NEED_FULL] ? f[FLAG_UNOWNED_FULL] : f[FLAG_UNOWNED_FAST];
+    if (unowned != 0)
+        FPM_FAIL(-6, "%d particles are outside this rank's region x [%d, %d), y [%d, %d): decompose before the force "
+                     "(reference solver.c:449)", unowned, p->mg.xstart, p->mg.xstart + p->mg.xl, p->mg.yrstart,
+                 p->mg.yrstart + p->mg.ylr);
+    if (f[FLAG_STALE] != 0) {
+        p->binned_np = -1;
+        p->binned_x = nullptr;
+        FPM_FAIL(-7, "a readout reused the tile binning of positions that had changed behind the same pointer: its "
+                     "result is invalid (call fpmhip_invalidate_binning after modifying positions in place)");
+    }
+    if (f[FLAG_HARD_OVF] != 0) {
+        p->bin_grow = std::max<int64_t>(p->bin_grow, (int64_t) f[FLAG_TOTAL] + f[FLAG_TOTAL] / 2);
+        p->layout_np = -1;
+        FPM_FAIL(-5, "the tile binning of an earlier force call needed %d entries for %lld particles, more than the plan "
+                     "held (%lld): that call's result is invalid; the arrays grow on the next call", f[FLAG_TOTAL],
+                 (long long) p->binned_np, (long long) p->bin_alloc);
+    }
+    return 0;
+}
+
+static int post_flags(fpmhip_plan *p, bool wait)
+{
+    FPM_CHECK_HIP(hipMemcpyAsync(p->h_flags, p->d_flags, FLAG_COUNT * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    FPM_CHECK_HIP(hipEventRecord(p->flags_event, p->stream));
+    p->flags_pending = true;
+    return check_deferred(p, wait);
 }
 
 int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt)
 {
+    // the flags of the PREVIOUS binning must be read before this one overwrites them: waits for that binning (one
+    // call back in the stream), never for work enqueued since
+    FPM_TRY(check_deferred(p, true));
     StageTimer tm(p, FPMHIP_T_SORT);
     const long long np = pt->np;
-    const int nt = p->ntiles;
-    const int ncnt = 2 * nt * BIN_PRIV + 1;         // [own | dup][tile][copy] + the slot the scan total lands in
-    // own + dup entries (up to 8 per particle, ~1.3 on average at B = 2) are indexed with int32
-    if (np >= 1500000000ll) FPM_FAIL(-1, "np %lld exceeds the int32 index range of one rank's binned entries", np);
-    FPM_TRY(ensure_bins(p, np, np / 2 + 1024, pt->mass != nullptr));
-
-    // slot ncnt - 1 stays 0 (scan total lands there); slot ncnt counts unowned particles
-    FPM_CHECK_HIP(hipMemsetAsync(p->tile_cnt, 0, (ncnt + 1) * sizeof(int), p->stream));
-    if (np > 0)
-        bin_kernel<false, BIN_PPT><<<blocks_for(np, 256 * BIN_PPT), 256, 0, p->stream>>>(p->mg, nt, pt->x, pt->mass, np, p->tile_cnt,
-                                                                       nullptr, nullptr, nullptr, nullptr, nullptr);
-    // exclusive scan of the counts (+1 slot -> grand total): the cursors of the scatter pass; the tile offsets the
-    // paint and readout kernels use are its entries at copy 0
-    size_t tmp_bytes = 0;
-    FPM_CHECK_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, p->tile_cnt, p->tile_cur, 0, (size_t) ncnt,
-                                          rocprim::plus<int>(), p->stream));
-    if (tmp_bytes > p->scan_tmp_bytes) {
-        if (p->scan_tmp) FPM_CHECK_HIP(hipFree(p->scan_tmp));
-        FPM_CHECK_HIP(hipMalloc(&p->scan_tmp, tmp_bytes));
-        p->scan_tmp_bytes = tmp_bytes;
+    const int nt = p->ntiles, nkeys = 2 * nt;
+    // own + dup entries (up to 8 per particle, ~1.3 on average) are indexed with int32
+    if (np >= 1000000000ll) FPM_FAIL(-1, "np %lld exceeds the int32 index range of one rank's binned entries", np);
+    FPM_TRY(ensure_bins(p, np, 0, pt->mass != nullptr));
+    const bool have_layout = p->layout_np == np && np > 0;
+    FPM_CHECK_HIP(hipMemsetAsync(p->d_flags, 0, FLAG_COUNT * sizeof(int), p->stream));
+    const int *pred = nullptr;
+    if (have_layout) {
+        // ONE pass in the previous call's tile order into the slabs laid out from the previous call's counts
+        std::swap(p->bin_beg[0], p->bin_beg[1]);
+        std::swap(p->bin_cap[0], p->bin_cap[1]);
+        std::swap(p->order[0], p->order[1]);
+        FPM_CHECK_HIP(hipMemsetAsync(p->bin_cnt, 0, ((size_t) nkeys + 1) * sizeof(int), p->stream));
+        bin_kernel<true, true, false, BIN_PPT><<<blocks_for(np, 256 * BIN_PPT), 256, 0, p->stream>>>(
+            p->mg, nt, pt->x, pt->mass, np, p->order[1], p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
+            pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, nullptr);
+        pred = p->d_flags + FLAG_NEED_FULL;          // the exact path below runs only if a slab overflowed
+    } else {
+        FPM_CHECK_HIP(hipMemsetAsync(p->d_flags + FLAG_NEED_FULL, 1, 1, p->stream));    // = 1: the exact path is the one that ran
     }
-    FPM_CHECK_HIP(rocprim::exclusive_scan(p->scan_tmp, tmp_bytes, p->tile_cnt, p->tile_cur, 0, (size_t) ncnt,
-                                          rocprim::plus<int>(), p->stream));
-    tile_offsets_kernel<<<blocks_for(2 * nt + 1, 256), 256, 0, p->stream>>>(p->tile_cur, p->tile_off, 2 * nt);
-    // capacity check for the dup entries: one small read-back
-    FPM_CHECK_HIP(hipMemcpyAsync(p->h_pinned, p->tile_off + 2 * nt, sizeof(int), hipMemcpyDeviceToHost, p->stream));
-    FPM_CHECK_HIP(hipMemcpyAsync(p->h_pinned + 1, p->tile_cnt + ncnt, sizeof(int), hipMemcpyDeviceToHost, p->stream));
-    FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
-    const long long total = p->h_pinned[0];
-    if (p->h_pinned[1] != 0)
-        FPM_FAIL(-6, "%d particles are outside this rank's region x [%d, %d), y [%d, %d): decompose before the force "
-                     "(reference solver.c:449)", p->h_pinned[1], p->mg.xstart, p->mg.xstart + p->mg.xl, p->mg.yrstart,
-                 p->mg.yrstart + p->mg.ylr);
-    if (total < np) FPM_FAIL(-5, "internal: binned %lld entries for %lld particles", total, np);
-    const long long ndup = total - np;
-    if (total > p->bin_cap_own) FPM_TRY(ensure_bins(p, np, ndup, pt->mass != nullptr));
-
-    if (np > 0)
-        bin_kernel<true, BIN_PPT><<<blocks_for(np, 256 * BIN_PPT), 256, 0, p->stream>>>(p->mg, nt, pt->x, pt->mass, np, p->tile_cur,
-                                                                      p->sx, p->sy, p->sz,
-                                                                      pt->mass ? p->smass : nullptr, p->sidx);
-    FPM_CHECK_HIP(hipGetLastError());
+    FPM_TRY(bin_full(p, pt, pred));
+    FPM_TRY(bin_finish(p, nullptr));
     p->binned_x = pt->x;
     p->binned_mass = pt->mass;
     p->binned_np = np;
-    p->binned_ndup = ndup;
-    return 0;
+    p->layout_np = np;
+    // the first binning of a particle set reports its errors at once; later ones when their flags arrive
+    return post_flags(p, !have_layout);
+}
+
+// A readout that finds the plan's binning made for the same (x, np) reuses it -- and checks, on the device, that the
+// positions behind the pointer are still the ones that were binned (one entry per tile, bit for bit).  A mismatch is a
+// broken contract (positions modified in place without fpmhip_invalidate_binning); it is reported when the flag arrives.
+static int reuse_binning(fpmhip_plan *p, const fpmhip_particles *pt)
+{
+    FPM_TRY(check_deferred(p, true));
+    const int nt = p->ntiles;
+    FPM_CHECK_HIP(hipMemsetAsync(p->d_flags + FLAG_STALE, 0, sizeof(int), p->stream));
+    verify_binning_kernel<<<blocks_for(nt, 256), 256, 0, p->stream>>>(nt, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz,
+                                                                      p->sidx, pt->x, p->d_flags);
+    FPM_CHECK_HIP(hipGetLastError());
+    return post_flags(p, false);
 }
 
 template <typename F>
@@ -915,7 +1094,7 @@ static int paint_impl(fpmhip_plan *p, const fpmhip_particles *pt, double scale, 
     }
     FPM_TRY(bin_particles(p, pt));
     StageTimer tm(p, FPMHIP_T_PAINT);
-    paint_tiles_kernel<F><<<p->ntiles, 256, 0, p->stream>>>(p->mg, p->ntiles, p->tile_off, p->sx, p->sy, p->sz,
+    paint_tiles_kernel<F><<<p->ntiles, 256, 0, p->stream>>>(p->mg, p->ntiles, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz,
                                                              pt->mass ? p->smass : nullptr, pt->M0, scale, canvas,
                                                              accumulate);
     FPM_CHECK_HIP(hipGetLastError());
@@ -936,6 +1115,7 @@ static int readout_impl(fpmhip_plan *p, const fpmhip_particles *pt, const F *m0,
         return 0;
     }
     if (p->binned_x != pt->x || p->binned_np != np) FPM_TRY(bin_particles(p, pt));
+    else FPM_TRY(reuse_binning(p, pt));
     StageTimer tm(p, FPMHIP_T_READOUT);
     // measured on configs[1] (loads A / B / C; tools/ab_readout.sh):
     //   2 (fp64 default) LDS-staged, one workgroup per (tile, component)   0.96 / 1.03 / 1.89 ms
@@ -951,7 +1131,7 @@ static int readout_impl(fpmhip_plan *p, const fpmhip_particles *pt, const F *m0,
     const int lds_mode = lds_env >= 0 ? lds_env : (sizeof(F) == 8 ? 2 : 1);
     if (NC == 3 && nmemb == 3 && memb0 == 0 && lds_mode == 2) {
         const size_t lds = (size_t) (TILE_X + 1) * (TILE_Y + 1) * (TILE_Z + 1) * sizeof(F);
-        readout1of3_tiles_kernel<F><<<3 * p->ntiles, 256, lds, p->stream>>>(p->mg, p->ntiles, p->tile_off, p->sx,
+        readout1of3_tiles_kernel<F><<<3 * p->ntiles, 256, lds, p->stream>>>(p->mg, p->ntiles, p->bin_beg[0], p->bin_cnt, p->sx,
                                                                              p->sy, p->sz, p->sidx, m0, m1, m2, out);
         FPM_CHECK_HIP(hipGetLastError());
         return 0;
@@ -964,13 +1144,13 @@ static int readout_impl(fpmhip_plan *p, const fpmhip_particles *pt, const F *m0,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
             granted = true;
         }
-        readout3_tiles_kernel<F><<<p->ntiles, 256, lds, p->stream>>>(p->mg, p->ntiles, p->tile_off, p->sx, p->sy,
+        readout3_tiles_kernel<F><<<p->ntiles, 256, lds, p->stream>>>(p->mg, p->ntiles, p->bin_beg[0], p->bin_cnt, p->sx, p->sy,
                                                                       p->sz, p->sidx, m0, m1, m2, out);
         FPM_CHECK_HIP(hipGetLastError());
         return 0;
     }
     readout_kernel<F, NC, true><<<blocks_for(np, 256), 256, 0, p->stream>>>(
-        p->mg, np, p->sx, p->sy, p->sz, p->sidx, nullptr, m0, m1, m2, out, nmemb, memb0);
+        p->mg, np, nullptr, nullptr, nullptr, p->order[0], pt->x, m0, m1, m2, out, nmemb, memb0);
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -989,6 +1169,7 @@ static int readout_grad_impl(fpmhip_plan *p, const fpmhip_particles *pt, const F
         return 0;
     }
     if (p->binned_x != pt->x || p->binned_np != np) FPM_TRY(bin_particles(p, pt));
+    else FPM_TRY(reuse_binning(p, pt));
     StageTimer tm(p, FPMHIP_T_READOUT);
     // measured on configs[1] (loads A / B / C): LDS-staged 0.83 / 0.93 / 1.53 ms, direct gather of the
     // binned entries 1.58 / 1.85 / 2.91 ms.  FPMHIP_READOUT_GRAD=1 selects the direct kernel (A/B).
@@ -1001,13 +1182,13 @@ static int readout_grad_impl(fpmhip_plan *p, const fpmhip_particles *pt, const F
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
             granted = true;
         }
-        readout_grad_tiles_kernel<F><<<p->ntiles, 256, lds, p->stream>>>(p->mg, p->ntiles, p->tile_off, p->sx, p->sy,
+        readout_grad_tiles_kernel<F><<<p->ntiles, 256, lds, p->stream>>>(p->mg, p->ntiles, p->bin_beg[0], p->bin_cnt, p->sx, p->sy,
                                                                           p->sz, p->sidx, phi, halo, pt->acc, inv12h);
         FPM_CHECK_HIP(hipGetLastError());
         return 0;
     }
     readout_grad_kernel<F, true><<<blocks_for(np, 256), 256, 0, p->stream>>>(
-        p->mg, np, p->sx, p->sy, p->sz, p->sidx, nullptr, phi, halo, pt->acc, inv12h);
+        p->mg, np, nullptr, nullptr, nullptr, p->order[0], pt->x, phi, halo, pt->acc, inv12h);
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1053,7 +1234,7 @@ int fpmhip_tile_order(fpmhip_plan *p, const fpmhip_particles *pt, int *order)
     if (!order) FPM_FAIL(-1, "null output");
     if (p->geom.paint_mode == FPMHIP_PAINT_ATOMIC) FPM_FAIL(-1, "tile_order needs the tiled painter");
     FPM_TRY(bin_particles(p, pt));
-    FPM_CHECK_HIP(hipMemcpyAsync(order, p->sidx, (size_t) pt->np * sizeof(int), hipMemcpyDeviceToDevice, p->stream));
+    FPM_CHECK_HIP(hipMemcpyAsync(order, p->order[0], (size_t) pt->np * sizeof(int), hipMemcpyDeviceToDevice, p->stream));
     return fpmhip_invalidate_binning(p);          // the caller is about to permute the rows behind pt->x
 }
 

@@ -61,11 +61,15 @@ int ensure_buffer(fpmhip_plan *p, int which)
 
 int ensure_bins(fpmhip_plan *p, int64_t np, int64_t ndup, bool has_mass)
 {
-    // own entries and dup entries share the arrays: [0, np) own, [np, np + ndup) dups
-    int64_t need = np + ndup;
-    int64_t have = p->bin_cap_own;
-    if (need > have || (has_mass && !p->smass)) {
-        int64_t cap = need > have ? need + need / 8 + 1024 : have;
+    // entry arrays: every particle once + its dup entries (0.30 per particle for 8 x 8 x 32 tiles, whatever the
+    // load), in slabs with 25 % + 32 entries of slack per key
+    (void) ndup;
+    const int64_t nkeys = 2 * (int64_t) p->ntiles;
+    int64_t need = np + (3 * np) / 4 + 33 * nkeys + 4096;
+    if (p->bin_grow > need) need = p->bin_grow;
+    if (need > p->bin_alloc || (has_mass && !p->smass)) {
+        const int64_t cap = need > p->bin_alloc ? need + need / 16 : p->bin_alloc;
+        if (p->sx) FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
         if (p->sx) { (void) hipFree(p->sx); (void) hipFree(p->sy); (void) hipFree(p->sz); (void) hipFree(p->sidx); }
         if (p->smass) { (void) hipFree(p->smass); p->smass = nullptr; }
         p->sx = p->sy = p->sz = nullptr;
@@ -75,8 +79,19 @@ int ensure_bins(fpmhip_plan *p, int64_t np, int64_t ndup, bool has_mass)
         FPM_CHECK_HIP(hipMalloc(&p->sz, cap * sizeof(double)));
         FPM_CHECK_HIP(hipMalloc(&p->sidx, cap * sizeof(int)));
         if (has_mass) FPM_CHECK_HIP(hipMalloc(&p->smass, cap * sizeof(float)));
-        p->bin_cap_own = cap;
+        p->bin_alloc = cap;
         p->binned_np = -1;
+        p->layout_np = -1;
+    }
+    if (np > p->order_cap) {
+        if (p->order[0]) FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
+        for (int q = 0; q < 2; q++) {
+            if (p->order[q]) (void) hipFree(p->order[q]);
+            p->order[q] = nullptr;
+            FPM_CHECK_HIP(hipMalloc(&p->order[q], (np + np / 16 + 1024) * sizeof(int)));
+        }
+        p->order_cap = np + np / 16 + 1024;
+        p->layout_np = -1;
     }
     return 0;
 }
@@ -237,9 +252,18 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
         if (hipMalloc(&p->d_tab, 5 * N * sizeof(float)) != hipSuccess) { rc = -2; break; }
         if (hipMemcpy(p->d_tab, p->h_tab.data(), 5 * N * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { rc = -2; break; }
         if (hipMalloc(&p->d_fac, 3 * N * sizeof(double)) != hipSuccess) { rc = -2; break; }
-        if (hipMalloc(&p->tile_cnt, (2 * (size_t) p->ntiles * fpm::BIN_PRIV + 2) * sizeof(int)) != hipSuccess) { rc = -2; break; }
-        if (hipMalloc(&p->tile_off, (2 * (size_t) p->ntiles + 2) * sizeof(int)) != hipSuccess) { rc = -2; break; }
-        if (hipMalloc(&p->tile_cur, (2 * (size_t) p->ntiles * fpm::BIN_PRIV + 2) * sizeof(int)) != hipSuccess) { rc = -2; break; }
+        {
+            const size_t nk = 2 * (size_t) p->ntiles + 2;
+            int **arrs[] = {&p->bin_beg[0], &p->bin_beg[1], &p->bin_cap[0], &p->bin_cap[1], &p->bin_cnt, &p->bin_off,
+                            &p->bin_capv, &p->bin_tmp};
+            for (int **a : arrs) if (rc == 0 && hipMalloc(a, nk * sizeof(int)) != hipSuccess) rc = -2;
+            if (rc) break;
+            if (hipMemset(p->bin_cnt, 0, nk * sizeof(int)) != hipSuccess) { rc = -2; break; }
+        }
+        if (hipMalloc(&p->d_flags, 64 * sizeof(int)) != hipSuccess) { rc = -2; break; }
+        if (hipHostMalloc((void **) &p->h_flags, 64 * sizeof(int)) != hipSuccess) { rc = -2; break; }
+        memset(p->h_flags, 0, 64 * sizeof(int));
+        if (hipEventCreateWithFlags(&p->flags_event, hipEventDisableTiming) != hipSuccess) { rc = -2; break; }
         if (hipHostMalloc((void **) &p->h_pinned, 4096) != hipSuccess) { rc = -2; break; }
         if (hipMalloc(&p->d_scalar, 4096) != hipSuccess) { rc = -2; break; }
     } while (0);
@@ -254,7 +278,7 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
         return rc;
     }
     if (geom->np_max > 0) {
-        rc = ensure_bins(p, geom->np_max, geom->np_max / 2, false);
+        rc = ensure_bins(p, geom->np_max, 0, false);
         if (rc != 0) { fpmhip_plan_destroy(p); return rc; }
     }
     *out = p;
@@ -269,10 +293,13 @@ void fpmhip_plan_destroy(fpmhip_plan *p)
     fft_teardown(p);
     for (int i = 0; i < BUF_COUNT; i++) if (p->buf[i]) (void) hipFree(p->buf[i]);
     void *ptrs[] = {p->host_stage.x, p->host_stage.acc, p->host_stage.mass, p->host_stage.pot,
-                    p->d_twiddle, p->d_tab, p->d_fac, p->sx, p->sy, p->sz, p->smass, p->sidx, p->tile_cnt,
-                    p->tile_off, p->tile_cur, p->scan_tmp, p->d_scalar, p->d_decic, p->d_bins, p->dec_key_in, p->dec_idx, p->dec_tmp};
+                    p->d_twiddle, p->d_tab, p->d_fac, p->sx, p->sy, p->sz, p->smass, p->sidx, p->bin_beg[0], p->bin_beg[1],
+                    p->bin_cap[0], p->bin_cap[1], p->bin_cnt, p->bin_off, p->bin_capv, p->bin_tmp, p->order[0], p->order[1],
+                    p->d_flags, p->scan_tmp, p->d_scalar, p->d_decic, p->d_bins, p->dec_key_in, p->dec_idx, p->dec_tmp};
     for (void *q : ptrs) if (q) (void) hipFree(q);
     if (p->h_pinned) (void) hipHostFree(p->h_pinned);
+    if (p->h_flags) (void) hipHostFree(p->h_flags);
+    if (p->flags_event) (void) hipEventDestroy(p->flags_event);
     for (auto &e : p->ev_used) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
     for (auto &e : p->ev_free) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
     delete p;
@@ -304,7 +331,7 @@ int fpmhip_sync(fpmhip_plan *p)
 {
     if (!p) FPM_FAIL(-1, "null plan");
     FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
-    return 0;
+    return fpm::check_deferred(p, true);          // what a binning found out after its call had returned
 }
 
 void *fpmhip_plane_ptr(fpmhip_plan *p, void *mesh, int64_t ix)

@@ -605,6 +605,8 @@ class Slab2LPT(_SlabRank):
         from .pm import fastpm_kernel_type_get_orders
         pm = self.pm
         potorder, gradorder, difforder, _ = fastpm_kernel_type_get_orders(kernel)      # pm2lpt.c:17-18
+        if hasattr(pm, "invalidate_binning"):
+            pm.invalidate_binning()                 # the readouts below must bin THESE positions
         p = store
         if p.dx1 is None:
             p.dx1 = torch.zeros((p.np, 3), dtype=torch.float32, device=p.x.device)

@@ -167,8 +167,14 @@ int fpmhip_paint(fpmhip_plan *plan, const fpmhip_particles *p_dev, double scale,
 int fpmhip_paint_add(fpmhip_plan *plan, const fpmhip_particles *p_dev, double scale, void *canvas_dev);
 /* sum of fastpm_store_get_mass over the local particles (gravity.c:330-335) -> host double */
 int fpmhip_total_mass(fpmhip_plan *plan, const fpmhip_particles *p_dev, double *total_host);
-/* The readout reuses the tile binning of the last paint when (x, np) are unchanged; call this
- * if the positions behind the same pointer were modified in between. */
+/* The readout reuses the tile binning of the last paint when (x, np) are unchanged; call this if the positions behind
+ * the same pointer were modified in between.  (A reuse is checked on the device -- one entry per tile against the row
+ * it was copied from -- and a mismatch is reported as error -7 by the next call on the plan or by fpmhip_sync.)
+ *
+ * Errors that only the device knows (a particle outside this rank's region, -6; a stale binning, -7; entry arrays too
+ * small, -5) are reported by the call itself the first time a particle set of that size is binned and, from then on,
+ * when the flags have arrived: by the next binning on the plan or by fpmhip_sync -- no host round trip sits between the
+ * paint and the readout of a force call. */
 int fpmhip_invalidate_binning(fpmhip_plan *plan);
 /* order_dev[j] = the row of the j-th particle in tile order (int32[np]).  The counting sort behind paint / readout is
  * fastest on rows that are already spatially coherent (0.46 ms for 16.8 M particles in lattice or previous-step

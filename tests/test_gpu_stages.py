@@ -353,3 +353,62 @@ def test_fused_decic_powerspectrum_equals_the_two_calls(precision):
     assert torch.equal(a, b)
     assert np.array_equal(n1, n2) and np.allclose(k1, k2, rtol=1e-14) and np.allclose(p1, p2, rtol=1e-12)
     pm.destroy()
+
+
+def test_readout_of_stale_binning_is_reported():
+    """a readout reuses the tile binning of the last paint when (x, np) match.  If the positions behind the
+    pointer were rewritten in place the reuse is wrong; the device-side check (one entry per tile against the row it
+    came from) reports it as error -7 at the next synchronisation instead of silently gathering at stale positions."""
+    import torch
+    from fastpm_amd import PM, Store, FastPMHipError
+    N, L = 32, 48.0
+    pm = _pm(N, L, 64)
+    x = util.load_a(16, L, N)
+    st = Store(x)
+    mesh = pm.alloc()
+    pm.paint(mesh, st, 1.0)
+    out = torch.zeros(st.np, dtype=torch.float32, device="cuda")
+    pm.readout(mesh, st, out)                          # legitimate reuse
+    pm.sync()
+    st.x.copy_(torch.remainder(st.x + 5.0, L))         # same pointer, other positions, no invalidate
+    pm.readout(mesh, st, out)
+    with pytest.raises(FastPMHipError, match="stale|had changed"):
+        pm.sync()
+    pm.invalidate_binning()
+    pm.readout(mesh, st, out)                          # rebinned: fine again
+    pm.sync()
+    pm.destroy()
+
+
+def test_binning_follows_moving_particles_without_host_round_trips(oracle):
+    """The steady-state binning (one pass in the previous call's tile order into slabs laid out from the previous
+    counts) and its in-stream fallback (a slab overflows -> the exact two-pass path, predicated on a device flag):
+    paint after small moves, after a complete reshuffle of the rows, and after swapping in entirely different
+    positions of the same count -- always equal to the oracle's paint."""
+    import torch
+    from fastpm_amd import PM, Store
+    N, L, nc = 64, 96.0, 32
+    pm = _pm(N, L, 64)
+    pmo = oracle.PMOracle(N, L, 64)
+    rng = np.random.default_rng(3)
+    x = util.load_a(nc, L, N)
+    st = Store(x)
+    mesh = pm.alloc()
+
+    def check(xnow):
+        st.x.copy_(torch.from_numpy(xnow).cuda())
+        pm.paint(mesh, st, 1.0)
+        cv = pmo.alloc()
+        pmo.paint(cv, xnow)
+        torch.cuda.synchronize()
+        assert util.max_err(pm.real_view(mesh).cpu().numpy()[:, :, :N], pmo.real_view(cv)[:, :, :N]) <= 1e-13
+
+    check(x)
+    for _ in range(3):                                               # a few cells per step: the fast path
+        x = np.remainder(x + rng.normal(0, 0.5 * L / N, x.shape), L)
+        check(x)
+    check(x[rng.permutation(len(x))])                                # rows reshuffled: order_prev is a bad guide
+    check(util.load_c(nc, L))                                        # 10 % of the particles in 0.1 % of the volume
+    check(util.load_a(nc, L, N))                                     # and back
+    pm.sync()
+    pm.destroy()
