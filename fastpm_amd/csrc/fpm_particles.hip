@@ -155,6 +155,72 @@ __device__ __forceinline__ int wave_agg_resolve(const AggSlot &a)
     return __shfl(a.pend, a.leader) + a.rank;
 }
 
+// Block-level aggregation in front of the global cursors: a block's waves mostly hit the same few keys (a tile holds
+// ~8 waves' worth of particles), and atomics on one address serialise at the memory side.  Every wave-level group
+// adds its count to a small LDS hash table (returning LDS atomics) instead; after a barrier ONE global atomic per
+// distinct key of the block fetches the block's base; a group's slot is base + its LDS offset + the lane's rank.
+// A group that finds the table full (an incoherent load: every lane another tile) goes to the global cursor itself.
+constexpr int BIN_HASH = 256;
+
+struct BlockAgg {
+    int key[BIN_HASH], cnt[BIN_HASH], base[BIN_HASH];
+};
+
+__device__ __forceinline__ int block_agg_find(BlockAgg &t, int k)
+{
+    int h = (int) (((unsigned) k * 2654435761u) >> 24) & (BIN_HASH - 1);
+    for (int probe = 0; probe < 8; probe++) {
+        const int cur = atomicCAS(&t.key[h], -1, k);
+        if (cur == -1 || cur == k) return h;
+        h = (h + 1) & (BIN_HASH - 1);
+    }
+    return -1;
+}
+
+struct AggSlot2 {
+    int pend;     // leader lanes: the group's offset inside the block's share (or, slot < 0, inside the key's slab)
+    int slot;     // leader lanes: LDS table slot, -1 = went to the global cursor directly
+    int leader, rank;
+};
+
+template <bool RET>
+__device__ __forceinline__ AggSlot2 block_agg_issue(BlockAgg &t, int *counters, int key, bool active)
+{
+    AggSlot2 a{0, -1, 0, 0};
+    unsigned long long remaining = __ballot(active);
+    const int lane = __lane_id();
+    for (int round = 0; remaining && round < 24; round++) {
+        const int leader = __ffsll((long long) remaining) - 1;
+        const int k = __shfl(key, leader);
+        const bool mine = active && key == k;
+        const unsigned long long same = __ballot(mine);
+        if (lane == leader) {
+            const int n = __popcll(same);
+            const int sl = block_agg_find(t, k);
+            a.slot = sl;
+            if (sl >= 0) a.pend = atomicAdd(&t.cnt[sl], n);
+            else if (RET) a.pend = atomicAdd(&counters[k], n);
+            else (void) atomicAdd(&counters[k], n);
+        }
+        if (mine) {
+            a.leader = leader;
+            a.rank = __popcll(same & ((1ull << lane) - 1ull));
+        }
+        remaining &= ~same;
+        if (round >= 5 && __popcll(same) < 3) break;   // uniform: after 6 groups keep merging only while it pays
+    }
+    if (remaining & (1ull << lane)) {
+        const int sl = block_agg_find(t, key);
+        a.slot = sl;
+        if (sl >= 0) a.pend = atomicAdd(&t.cnt[sl], 1);
+        else if (RET) a.pend = atomicAdd(&counters[key], 1);
+        else (void) atomicAdd(&counters[key], 1);
+        a.leader = lane;
+        a.rank = 0;
+    }
+    return a;
+}
+
 // ------------------------------------------------------------------------------------------
 // Tile binning.  Keys: own tile t -> t, dup tile t -> ntiles + t.  The entries of key k live in a SLAB
 // [beg[k], beg[k] + cap[k]) of the entry arrays, cnt[k] of them filled.
@@ -187,7 +253,14 @@ __global__ __launch_bounds__(256) void bin_kernel(MeshGeo g, int ntiles, const d
                                                   const int *__restrict__ pred)
 {
     if (pred && *pred == 0) return;
-    const long long j0 = (long long) blockIdx.x * (256 * PPT) + threadIdx.x;
+    __shared__ BlockAgg agg;
+    // a predicated launch uses a small grid that walks the virtual blocks (an idle one must cost next to nothing)
+    const long long nvb = (np + 256 * PPT - 1) / (256 * PPT);
+    for (long long vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < BIN_HASH; i += 256) { agg.key[i] = -1; agg.cnt[i] = 0; }
+    __syncthreads();
+    const long long j0 = vb * (256 * PPT) + threadIdx.x;
     double px[PPT], py[PPT], pz[PPT];
     float pm[PPT];
     int row[PPT];
@@ -240,26 +313,36 @@ __global__ __launch_bounds__(256) void bin_kernel(MeshGeo g, int ntiles, const d
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 if (__ballot(need[u][c]) == 0) continue;
-                (void) wave_agg_inc<false>(cnt, key[u][c], need[u][c]);
+                (void) block_agg_issue<false>(agg, cnt, key[u][c], need[u][c]);
             }
-        return;
+        __syncthreads();
+        for (int i = threadIdx.x; i < BIN_HASH; i += 256)
+            if (agg.key[i] >= 0) (void) atomicAdd(&cnt[agg.key[i]], agg.cnt[i]);
+        continue;
     }
-    AggSlot a[PPT][8];
+    AggSlot2 a[PPT][8];
 #pragma unroll
     for (int u = 0; u < PPT; u++)
 #pragma unroll
         for (int c = 0; c < 8; c++) {
-            a[u][c] = AggSlot{0, 0, 0};
+            a[u][c] = AggSlot2{0, -1, 0, 0};
             if (__ballot(need[u][c]) == 0) continue;
-            a[u][c] = wave_agg_issue(cnt, key[u][c], need[u][c]);
+            a[u][c] = block_agg_issue<true>(agg, cnt, key[u][c], need[u][c]);
         }
+    __syncthreads();
+    for (int i = threadIdx.x; i < BIN_HASH; i += 256) {
+        const bool used = agg.key[i] >= 0;
+        if (used) agg.base[i] = atomicAdd(&cnt[agg.key[i]], agg.cnt[i]);      // one global atomic per key and block
+    }
+    __syncthreads();
     bool spilled = false;
 #pragma unroll
     for (int u = 0; u < PPT; u++)
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             if (__ballot(need[u][c]) == 0) continue;
-            const int local = wave_agg_resolve(a[u][c]);
+            const int lslot = __shfl(a[u][c].slot, a[u][c].leader);
+            const int local = __shfl(a[u][c].pend, a[u][c].leader) + a[u][c].rank + (lslot >= 0 ? agg.base[lslot] : 0);
             if (need[u][c]) {
                 const int k = key[u][c];
                 if (local < cap[k]) {
@@ -273,6 +356,7 @@ __global__ __launch_bounds__(256) void bin_kernel(MeshGeo g, int ntiles, const d
             }
         }
     if (__ballot(spilled) && __lane_id() == 0) flags[FULL ? FLAG_HARD_OVF : FLAG_NEED_FULL] = 1;
+    }
 }
 
 // capacity of every slab from the counts: + 25 % + 32 while the arrays have room for that, the exact counts
@@ -964,7 +1048,7 @@ static int bin_full(fpmhip_plan *p, const fpmhip_particles *pt, const int *pred)
 {
     const long long np = pt->np;
     const int nt = p->ntiles, nkeys = 2 * nt;
-    const unsigned nb = blocks_for(np, 256 * BIN_PPT);
+    const unsigned nb = pred ? std::min(blocks_for(np, 256 * BIN_PPT), 2048u) : blocks_for(np, 256 * BIN_PPT);
     zero_ints_kernel<<<blocks_for(nkeys + 1, 256), 256, 0, p->stream>>>(p->bin_cnt, nkeys + 1, pred);
     if (np > 0)
         bin_kernel<false, false, true, BIN_PPT><<<nb, 256, 0, p->stream>>>(
@@ -1047,9 +1131,18 @@ int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt)
         std::swap(p->bin_cap[0], p->bin_cap[1]);
         std::swap(p->order[0], p->order[1]);
         FPM_CHECK_HIP(hipMemsetAsync(p->bin_cnt, 0, ((size_t) nkeys + 1) * sizeof(int), p->stream));
-        bin_kernel<true, true, false, BIN_PPT><<<blocks_for(np, 256 * BIN_PPT), 256, 0, p->stream>>>(
-            p->mg, nt, pt->x, pt->mass, np, p->order[1], p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
-            pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, nullptr);
+        // Walked in the previous call's tile order, a wave's particles fall into one or two tiles whatever the order of
+        // the store's rows is: 0.62 / 0.67 / 0.9 ms on loads A / B / C (16.8 M particles), against 0.56 / 0.75 / 2.6 ms
+        // walking the rows as they lie.  FPMHIP_BIN_ORDER=0 selects the latter (A/B).
+        static const bool ordered = !(getenv("FPMHIP_BIN_ORDER") && atoi(getenv("FPMHIP_BIN_ORDER")) == 0);
+        if (ordered)
+            bin_kernel<true, true, false, BIN_PPT><<<blocks_for(np, 256 * BIN_PPT), 256, 0, p->stream>>>(
+                p->mg, nt, pt->x, pt->mass, np, p->order[1], p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
+                pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, nullptr);
+        else
+            bin_kernel<true, false, false, BIN_PPT><<<blocks_for(np, 256 * BIN_PPT), 256, 0, p->stream>>>(
+                p->mg, nt, pt->x, pt->mass, np, nullptr, p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
+                pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, nullptr);
         pred = p->d_flags + FLAG_NEED_FULL;          // the exact path below runs only if a slab overflowed
     } else {
         FPM_CHECK_HIP(hipMemsetAsync(p->d_flags + FLAG_NEED_FULL, 1, 1, p->stream));    // = 1: the exact path is the one that ran
