@@ -51,6 +51,9 @@ int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets
             total_mass += m;
         }
     }
+    // the readouts below reuse the binning the paint of THIS call makes: no staleness check needed in between
+    struct Trust { fpmhip_plan *p; ~Trust() { p->bin_trusted = false; } } trust{p};
+    p->bin_trusted = true;
     const double mean_mass_per_cell = total_mass / p->lay.Norm;                           // gravity.c:342
     FPM_TRY(fpmhip_paint(p, pt, 1.0 / mean_mass_per_cell, canvas));                       // gravity.c:336-345
     for (int si = 1; si < nsets; si++) FPM_TRY(fpmhip_paint_add(p, &sets[si], 1.0 / mean_mass_per_cell, canvas));

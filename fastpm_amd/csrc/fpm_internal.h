@@ -147,6 +147,7 @@ struct fpmhip_plan {
     int *d_flags = nullptr, *h_flags = nullptr;   // device flags of the binning and their pinned host copy
     hipEvent_t flags_event = nullptr;
     bool flags_pending = false;
+    bool bin_trusted = false;               // inside fpmhip_force: the paint of this very call made the binning
     void *scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
     int *h_pinned = nullptr;   // pinned scratch for small read-backs

@@ -359,6 +359,166 @@ __global__ __launch_bounds__(256) void bin_kernel(MeshGeo g, int ntiles, const d
     }
 }
 
+// The scatter, restructured around what bounded it: with one wave-aggregation pass per (particle slot, corner class)
+// -- 16 of them -- the kernel spent its time ISSUING ballots and shuffles (0.46 ms with stores and global atomics
+// compiled out).  Only ~0.3 dup entries per particle exist, so: the own entries take one pass per particle slot, the
+// dup entries of the whole block are first compacted into an LDS list (block prefix sum over the per-lane counts) and
+// then take one pass per 256 LIST entries -- 3 passes instead of 16 on a typical block.  Positions wait in LDS.
+constexpr int BIN_BLOCK = 256 * BIN_PPT;
+
+// DCAP: dup entries a block can list.  The exact path takes the worst case (7 per particle); the steady-state kernel
+// takes 2 per particle (0.3 is typical) so that four blocks fit a CU, and hands a block with more to the exact path.
+template <int DCAP> struct ScatterLds {
+    BlockAgg agg;
+    double x[BIN_BLOCK], y[BIN_BLOCK], z[BIN_BLOCK];
+    float m[BIN_BLOCK];
+    int row[BIN_BLOCK];
+    int dlist[3 * DCAP];           // [D] (particle slot << 3) | class, [D] packed (table slot, offset), [D] key
+    int wsum[4];
+};
+template <bool FULL> constexpr int dup_cap() { return FULL ? 7 * BIN_BLOCK : 2 * BIN_BLOCK; }
+
+__device__ __forceinline__ int pack_slot(int lslot, int off) { return ((lslot + 1) << 21) | off; }
+
+template <bool ORDERED, bool FULL>
+__global__ __launch_bounds__(256) void bin_scatter_kernel(MeshGeo g, int ntiles, const double *__restrict__ x,
+                                                          const float *__restrict__ mass, long long np,
+                                                          const int *__restrict__ order, const int *__restrict__ beg,
+                                                          const int *__restrict__ cap, int *__restrict__ cnt,
+                                                          double *__restrict__ sx, double *__restrict__ sy,
+                                                          double *__restrict__ sz, float *__restrict__ smass,
+                                                          int *__restrict__ sidx, int *__restrict__ flags,
+                                                          const int *__restrict__ pred)
+{
+    if (pred && *pred == 0) return;
+    extern __shared__ __align__(16) unsigned char smem_bin[];
+    using LDS = ScatterLds<dup_cap<FULL>()>;
+    LDS &L = *(LDS *) smem_bin;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long nvb = (np + BIN_BLOCK - 1) / BIN_BLOCK;
+    for (long long vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < BIN_HASH; i += 256) { L.agg.key[i] = -1; L.agg.cnt[i] = 0; }
+        // 1. rows and positions
+        bool active[BIN_PPT];
+        int own_key[BIN_PPT], mask[BIN_PPT];
+#pragma unroll
+        for (int u = 0; u < BIN_PPT; u++) {
+            const long long j = vb * BIN_BLOCK + u * 256 + tid;
+            active[u] = j < np;
+            const int r = active[u] ? (ORDERED ? order[j] : (int) j) : 0;
+            L.row[u * 256 + tid] = r;
+        }
+#pragma unroll
+        for (int u = 0; u < BIN_PPT; u++) {
+            const long long i = L.row[u * 256 + tid];
+            double px = 0, py = 0, pz = 0;
+            if (active[u]) { px = x[3 * i]; py = x[3 * i + 1]; pz = x[3 * i + 2]; }
+            L.x[u * 256 + tid] = px; L.y[u * 256 + tid] = py; L.z[u * 256 + tid] = pz;
+            if (mass) L.m[u * 256 + tid] = active[u] ? mass[i] : 0.f;
+            own_key[u] = 0;
+            mask[u] = 0;
+            if (active[u]) {
+                Cic c;
+                if (!cic_setup(g, px, py, pz, c)) {
+                    atomicAdd(&flags[FULL ? FLAG_UNOWNED_FULL : FLAG_UNOWNED_FAST], 1);
+                    active[u] = false;
+                } else {
+                    const int t0[3] = {c.i0[0] / TILE_X, c.i0[1] / TILE_Y, c.i0[2] / TILE_Z};
+                    const int t1[3] = {c.i1[0] / TILE_X, c.i1[1] / TILE_Y, c.i1[2] / TILE_Z};
+                    own_key[u] = tile_id(g, t0[0], t0[1], t0[2]);
+                    const int dx = t1[0] != t0[0], dy = t1[1] != t0[1], dz = t1[2] != t0[2];
+#pragma unroll
+                    for (int cl = 1; cl < 8; cl++) {
+                        const int bx = (cl >> 2) & 1, by = (cl >> 1) & 1, bz = cl & 1;
+                        if ((!bx || dx) && (!by || dy) && (!bz || dz)) mask[u] |= 1 << cl;
+                    }
+                }
+            }
+        }
+        __syncthreads();                                   // the hash table is clean, the positions are in LDS
+        // 2. own entries: one aggregation pass per particle slot
+        int own_res[BIN_PPT];
+#pragma unroll
+        for (int u = 0; u < BIN_PPT; u++) {
+            own_res[u] = 0;
+            if (__ballot(active[u]) == 0) continue;
+            const AggSlot2 a = block_agg_issue<true>(L.agg, cnt, own_key[u], active[u]);
+            own_res[u] = pack_slot(__shfl(a.slot, a.leader), __shfl(a.pend, a.leader) + a.rank);
+        }
+        // 3. the block's dup entries, compacted: exclusive prefix over the per-thread counts
+        int nd = 0;
+#pragma unroll
+        for (int u = 0; u < BIN_PPT; u++) nd += __popc(mask[u]);
+        int incl = nd;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) L.wsum[wave] = incl;
+        __syncthreads();
+        int dbase = incl - nd;
+        for (int w = 0; w < wave; w++) dbase += L.wsum[w];
+        int D = L.wsum[0] + L.wsum[1] + L.wsum[2] + L.wsum[3];
+        bool spilled = false;
+        if (D > dup_cap<FULL>()) {           // (steady state only) too many dups for the list: the exact path redoes it
+            spilled = true;
+            D = 0;
+        }
+#pragma unroll
+        for (int u = 0; u < BIN_PPT; u++) {
+            int mm = D ? mask[u] : 0;
+            while (mm) {
+                const int cl = __ffs(mm) - 1;
+                mm &= mm - 1;
+                L.dlist[dbase++] = ((u * 256 + tid) << 3) | cl;
+            }
+        }
+        __syncthreads();
+        // 4. dup entries: one aggregation pass per 256 list entries; (table slot, offset) and the key join the entry
+        for (int e0 = 0; e0 < D; e0 += 256) {
+            const int e = e0 + tid;
+            const bool act = e < D;
+            int key = 0;
+            if (act) {
+                const int item = L.dlist[e];
+                const int pid = item >> 3, cl = item & 7;
+                Cic c;
+                (void) cic_setup(g, L.x[pid], L.y[pid], L.z[pid], c);
+                const int bx = (cl >> 2) & 1, by = (cl >> 1) & 1, bz = cl & 1;
+                key = ntiles + tile_id(g, (bx ? c.i1[0] : c.i0[0]) / TILE_X, (by ? c.i1[1] : c.i0[1]) / TILE_Y,
+                                       (bz ? c.i1[2] : c.i0[2]) / TILE_Z);
+            }
+            if (__ballot(act) == 0) continue;
+            const AggSlot2 a = block_agg_issue<true>(L.agg, cnt, key, act);
+            const int res = pack_slot(__shfl(a.slot, a.leader), __shfl(a.pend, a.leader) + a.rank);
+            if (act) { L.dlist[D + e] = res; L.dlist[2 * D + e] = key; }
+        }
+        __syncthreads();
+        for (int i = tid; i < BIN_HASH; i += 256)
+            if (L.agg.key[i] >= 0) L.agg.base[i] = atomicAdd(&cnt[L.agg.key[i]], L.agg.cnt[i]);   // one global atomic per key and block
+        __syncthreads();
+        // 5. stores
+        auto put = [&](int key, int res, int pid) {
+            const int lslot = (res >> 21) - 1, local = (res & ((1 << 21) - 1)) + (lslot >= 0 ? L.agg.base[lslot] : 0);
+            if (local < cap[key]) {
+                const int slot = beg[key] + local;
+                sx[slot] = L.x[pid]; sy[slot] = L.y[pid]; sz[slot] = L.z[pid];
+                if (smass) smass[slot] = L.m[pid];
+                sidx[slot] = L.row[pid];
+            } else {
+                spilled = true;
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < BIN_PPT; u++)
+            if (active[u]) put(own_key[u], own_res[u], u * 256 + tid);
+        for (int e = tid; e < D; e += 256) put(L.dlist[2 * D + e], L.dlist[D + e], L.dlist[e] >> 3);
+        if (__ballot(spilled) && lane == 0) flags[FULL ? FLAG_HARD_OVF : FLAG_NEED_FULL] = 1;
+    }
+}
+
 // capacity of every slab from the counts: + 25 % + 32 while the arrays have room for that, the exact counts
 // otherwise; more entries than the arrays hold at all is the (lazily reported) hard overflow
 __global__ __launch_bounds__(256) void slab_caps_kernel(const int *__restrict__ cnt, const int *__restrict__ off, int nkeys,
@@ -1056,7 +1216,7 @@ static int bin_full(fpmhip_plan *p, const fpmhip_particles *pt, const int *pred)
             nullptr, p->d_flags, pred);
     FPM_TRY(make_layout(p, p->bin_beg[0], p->bin_cap[0], pred, true));
     if (np > 0)
-        bin_kernel<true, false, true, BIN_PPT><<<nb, 256, 0, p->stream>>>(
+        bin_scatter_kernel<false, true><<<nb, 256, sizeof(ScatterLds<dup_cap<true>()>), p->stream>>>(
             p->mg, nt, pt->x, pt->mass, np, nullptr, p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
             pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, pred);
     FPM_CHECK_HIP(hipGetLastError());
@@ -1136,11 +1296,11 @@ int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt)
         // walking the rows as they lie.  FPMHIP_BIN_ORDER=0 selects the latter (A/B).
         static const bool ordered = !(getenv("FPMHIP_BIN_ORDER") && atoi(getenv("FPMHIP_BIN_ORDER")) == 0);
         if (ordered)
-            bin_kernel<true, true, false, BIN_PPT><<<blocks_for(np, 256 * BIN_PPT), 256, 0, p->stream>>>(
+            bin_scatter_kernel<true, false><<<blocks_for(np, BIN_BLOCK), 256, sizeof(ScatterLds<dup_cap<false>()>), p->stream>>>(
                 p->mg, nt, pt->x, pt->mass, np, p->order[1], p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
                 pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, nullptr);
         else
-            bin_kernel<true, false, false, BIN_PPT><<<blocks_for(np, 256 * BIN_PPT), 256, 0, p->stream>>>(
+            bin_scatter_kernel<false, false><<<blocks_for(np, BIN_BLOCK), 256, sizeof(ScatterLds<dup_cap<false>()>), p->stream>>>(
                 p->mg, nt, pt->x, pt->mass, np, nullptr, p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
                 pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, nullptr);
         pred = p->d_flags + FLAG_NEED_FULL;          // the exact path below runs only if a slab overflowed
@@ -1208,7 +1368,7 @@ static int readout_impl(fpmhip_plan *p, const fpmhip_particles *pt, const F *m0,
         return 0;
     }
     if (p->binned_x != pt->x || p->binned_np != np) FPM_TRY(bin_particles(p, pt));
-    else FPM_TRY(reuse_binning(p, pt));
+    else if (!p->bin_trusted) FPM_TRY(reuse_binning(p, pt));
     StageTimer tm(p, FPMHIP_T_READOUT);
     // measured on configs[1] (loads A / B / C; tools/ab_readout.sh):
     //   2 (fp64 default) LDS-staged, one workgroup per (tile, component)   0.96 / 1.03 / 1.89 ms
@@ -1262,7 +1422,7 @@ static int readout_grad_impl(fpmhip_plan *p, const fpmhip_particles *pt, const F
         return 0;
     }
     if (p->binned_x != pt->x || p->binned_np != np) FPM_TRY(bin_particles(p, pt));
-    else FPM_TRY(reuse_binning(p, pt));
+    else if (!p->bin_trusted) FPM_TRY(reuse_binning(p, pt));
     StageTimer tm(p, FPMHIP_T_READOUT);
     // measured on configs[1] (loads A / B / C): LDS-staged 0.83 / 0.93 / 1.53 ms, direct gather of the
     // binned entries 1.58 / 1.85 / 2.91 ms.  FPMHIP_READOUT_GRAD=1 selects the direct kernel (A/B).
