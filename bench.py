@@ -32,19 +32,22 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 WORKLOADS = {1: (256, 512), 2: (320, 640), 4: (400, 800), 8: (512, 1024)}
 
 
-def make_particles(nc, Nmesh, BoxSize, nranks, rank, device, seed=1234, sigma_cells=0.3):
+def make_particles(nc, Nmesh, BoxSize, nranks, rank, device, seed=1234, sigma_cells=0.3, nprocy=1):
     """Load A: lattice q = (i + 0.5) L / nc plus Gaussian displacement sigma = 0.3 cell,
     generated on the device, only the lattice planes of this rank's x slab.  The displacement is
     clamped to +-0.95 cell so that every particle stays in its slab (no decomposition needed:
     lattice points sit mid-way in 2-cell blocks and slab edges are at even cells)."""
-    assert nc % nranks == 0 and (Nmesh // nranks) % 2 == 0
+    nprocx = nranks // nprocy
+    rx, ry = rank // nprocy, rank % nprocy
+    assert nc % nprocx == 0 and (Nmesh // nprocx) % 2 == 0 and nc % nprocy == 0 and (Nmesh // nprocy) % 2 == 0
     h = BoxSize / Nmesh
-    npl = nc // nranks
+    npl, npy = nc // nprocx, nc // nprocy
     gen = torch.Generator(device=device)
     gen.manual_seed(seed + rank)
-    ix = torch.arange(rank * npl, (rank + 1) * npl, device=device, dtype=torch.float64)
+    ix = torch.arange(rx * npl, (rx + 1) * npl, device=device, dtype=torch.float64)
+    iy = torch.arange(ry * npy, (ry + 1) * npy, device=device, dtype=torch.float64)
     g = torch.arange(nc, device=device, dtype=torch.float64)
-    q = torch.stack(torch.meshgrid((ix + 0.5) * (BoxSize / nc), (g + 0.5) * (BoxSize / nc),
+    q = torch.stack(torch.meshgrid((ix + 0.5) * (BoxSize / nc), (iy + 0.5) * (BoxSize / nc),
                                    (g + 0.5) * (BoxSize / nc), indexing="ij"), dim=-1).reshape(-1, 3)
     d = torch.randn(q.shape, generator=gen, device=device, dtype=torch.float64) * (sigma_cells * h)
     d.clamp_(-0.95 * h, 0.95 * h)
@@ -236,6 +239,9 @@ def main():
     ap.add_argument("--alt", action="store_true",
                     help="run that extra leg on N > 1 GPUs too (off by default there: a second collective phase after "
                          "the measured one must never be what a scaling run hangs or times out in)")
+    ap.add_argument("--nprocy", type=int, default=1,
+                    help="N > 1 GPUs: process mesh (gpus / nprocy) x nprocy; 1 = x slabs (default), 2 on 8 GPUs = the "
+                         "reference's default 4 x 2 pencils (pmpfft.c:117-136)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary legs (host-resident store columns; the 1024^3 mesh the 2e8 target is quoted on)")
@@ -245,6 +251,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.nprocy > 1 and (world % args.nprocy != 0 or args.gradient == "real"):
+        raise SystemExit("--nprocy must divide the number of GPUs; the real-space gradient is a slab mode")
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
@@ -278,7 +286,7 @@ def main():
             raise SystemExit("--load b/c are single-GPU stress loads")
         x = make_particles_clustered(nc, Nmesh, BoxSize, device, args.load)
     else:
-        x = make_particles(nc, Nmesh, BoxSize, world, rank, device)
+        x = make_particles(nc, Nmesh, BoxSize, world, rank, device, nprocy=args.nprocy)
     np_local = x.shape[0]
     np_total = nc ** 3
     def barrier():
@@ -291,10 +299,15 @@ def main():
     def timed_run(gradient):
         """W untimed + K timed force calls in one gradient mode; max over ranks of the wall time."""
         pm = PM(Nmesh, BoxSize, precision=args.precision, nranks=world, rank=rank, np_max=np_local,
-                paint_mode=args.paint_mode, fft_mode=args.fft_mode, gradient_mode=1 if gradient == "real" else 0)
+                paint_mode=args.paint_mode, fft_mode=args.fft_mode, gradient_mode=1 if gradient == "real" else 0,
+                nranks_y=args.nprocy if world > 1 else 1)
         store = Store(x, device=device)
         delta_k = pm.alloc()
-        if world > 1:
+        if world > 1 and args.nprocy > 1:
+            from fastpm_amd.distributed import PencilForce
+            pf = PencilForce(pm, dist.group.WORLD)
+            step = lambda: pf.compute_force(store, kernel="1_4", dealias="none", delta_k=delta_k)
+        elif world > 1:
             from fastpm_amd.distributed import SlabForce
             holder = {"force": SlabForce(pm, dist.group.WORLD)}
             step = lambda: holder["force"].compute_force(store, kernel="1_4", dealias="none", delta_k=delta_k)
@@ -450,7 +463,7 @@ def main():
         if "sort" in stages:                      # two kernels + a scan behind one timer
             a = ab["sort"] / (tm["sort"][0] / tm["sort"][1] * 1e-3) / 1e9
             tr = pmc_traffic("sort", Nmesh, np_total, args, world)
-            per_kernel["sort"] = {"kernel": "fpm::bin_kernel x2 + scan", "frac": round(a / HBM_PEAK_GBS, 4),
+            per_kernel["sort"] = {"kernel": "fpm::bin_scatter_kernel + slab layout", "frac": round(a / HBM_PEAK_GBS, 4),
                                   "avg_launch_ms": stages["sort"]["avg_ms"], "launches_per_step": stages["sort"]["launches_per_step"],
                                   "traffic_over_alg": round(tr / ab["sort"], 3) if tr else None}
         worst = min(per_kernel, key=lambda n: per_kernel[n]["frac"])
@@ -468,7 +481,9 @@ def main():
                 "particles": np_total, "nmesh": Nmesh,
                 "load": {"a": "A: lattice + 0.3-cell Gaussian jitter", "b": "B: clustered, Zel'dovich-like rms 4 cells",
                          "c": "C: adversarial, 10 % of particles in 0.1 % of the volume"}[args.load],
-                "kernel": "1_4", "softening": "none", "decomposition": "slab %dx1" % world,
+                "kernel": "1_4", "softening": "none",
+                "decomposition": ("slab %dx1" % world) if args.nprocy <= 1 or world == 1 else
+                                 ("pencil %dx%d" % (world // args.nprocy, args.nprocy)),
                 "gradient": {"kspace": "k space, 3 inverse FFTs (the reference's arithmetic)",
                              "real": "real space, 1 inverse FFT + stencil readout (FPMHIP_GRADIENT_REAL)"}[args.gradient],
                 "paint_mode": "tiled" if args.paint_mode == 0 else "atomic",

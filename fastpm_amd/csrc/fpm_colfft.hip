@@ -286,7 +286,8 @@ template <typename K> static int set_lds(K kernel, size_t bytes)
     return 0;
 }
 
-#define FPM_CASE(n, ES_, BODY) case n: { using PL = typename Fac<n, ES_>::type; BODY(PL) } break;
+#define FPM_CASE(n, ES_, BODY) case n: { using PL = typename FPM_FAC_KIND<n, ES_>::type; BODY(PL) } break;
+#define FPM_FAC_KIND Fac
 #define COLFFT_DISPATCH(N_, ES_, BODY)                                                                              \
     switch (N_) {                                                                                                   \
         FPM_CASE(16, ES_, BODY) FPM_CASE(32, ES_, BODY) FPM_CASE(48, ES_, BODY) FPM_CASE(64, ES_, BODY)             \
@@ -379,7 +380,11 @@ static int yback2_launch(fpmhip_plan *p, const void *in, void *oy, void *oz, voi
             (const C2<F> *) in, (C2<F> *) oy, (C2<F> *) oz, (C2<F> *) op, im, om, ncols, tpb, ntiles, kt,    \
             p->d_twiddle, p->mg.zstart);                                                                     \
     }
+#undef FPM_FAC_KIND
+#define FPM_FAC_KIND FusedFac
     COLFFT_DISPATCH(p->mg.N, sizeof(F), CALL_Y2)
+#undef FPM_FAC_KIND
+#define FPM_FAC_KIND Fac
 #undef CALL_Y2
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
@@ -427,7 +432,11 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
     }
 #define CALL_X3_P(PL, P) if (fwd) CALL_X3_Q(PL, P, true) else CALL_X3_Q(PL, P, false)
 #define CALL_X3(PL) if (mode == 1) { CALL_X3_P(PL, 1) } else if (mode == 2) { CALL_X3_P(PL, 2) } else { CALL_X3_P(PL, 0) }
+#undef FPM_FAC_KIND
+#define FPM_FAC_KIND FusedFac
     COLFFT_DISPATCH(N, sizeof(F), CALL_X3)
+#undef FPM_FAC_KIND
+#define FPM_FAC_KIND Fac
 #undef CALL_X3
 #undef CALL_X3_P
 #undef CALL_X3_Q

@@ -351,9 +351,20 @@ FPM_FAC(1536, 0, 8, 8, 3, 8, 8)
 FPM_FAC(1536, 8, 8, 8, 3, 8, 8)
 FPM_FAC(1536, 4, 16, 16, 3, 8, 4)
 FPM_FAC(2048, 8, 16, 16, 16, 8, 1)
+#ifndef FPM_VARIANT_2048F_E32
 FPM_FAC(2048, 4, 16, 16, 16, 8, 1)
+#endif
 FPM_FAC(3072, 8, 16, 16, 3, 8, 8)
 FPM_FAC(3072, 4, 32, 16, 3, 8, 8)
+// The fused kernels (colfft_xback3 / colfft_yback2: several transforms per column load) may want another shape than
+// the plain pass of the same length; by default they share it.
+template <int N, int ES> struct FusedFac : Fac<N, ES> {};
+#ifdef FPM_VARIANT_1024_E16
+template <> struct FusedFac<1024, 8> { using type = FFTPlan<1024, 16, 16, 8, 8, 1>; };
+#endif
+#ifdef FPM_VARIANT_2048F_E32
+template <> struct Fac<2048, 4> { using type = FFTPlan<2048, 32, 16, 16, 8, 1>; };
+#endif
 #undef FPM_FAC_ALL
 #undef FPM_FAC
 

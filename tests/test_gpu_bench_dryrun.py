@@ -31,3 +31,17 @@ def test_multi_rank_bench_path(nranks, port, alt):
         assert d["other_gradient_mode"]["acc_max_abs_dev_over_max_abs_acc"] < 2e-7
     else:
         assert "other_gradient_mode" not in d
+
+
+def test_multi_rank_bench_path_on_pencils():
+    """`bench.py --gpus 4 --nprocy 2`: the 2 x 2 process mesh (PencilForce, row / column groups) through the same
+    dry-run transport."""
+    env = dict(os.environ, FPM_BENCH_BACKEND="gloo", FPM_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+                        "--master-addr", "127.0.0.1", "--master-port", "29614", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "4", "--nprocy", "2", "--steps", "2", "--warmup", "1", "--nc", "64", "--nmesh", "128"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 4 and d["finite"] and d["config"]["decomposition"] == "pencil 2x2"
+    assert d["momentum_residual"] < 1e-6 and d["value"] > 0

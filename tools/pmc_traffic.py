@@ -44,7 +44,7 @@ def main():
 
     N = nmesh
     stage = {
-        "sort": add(hbm("bin_kernel<false>"), hbm("bin_kernel<true>")),
+        "sort": hbm("bin_scatter_kernel<true, false>") or add(hbm("bin_kernel<false>"), hbm("bin_kernel<true>")),
         "paint": hbm("paint_tiles"),
         "readout": hbm("readout1of3_tiles") or hbm("readout3_tiles") or hbm("readout_grad_tiles") or hbm("readout_kernel") or hbm("readout_grad_kernel"),
         "xback3": hbm("xback3"),
