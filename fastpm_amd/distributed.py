@@ -56,6 +56,26 @@ class _SlabRank:
         for req in gen:
             self._communicate(req)
 
+    def _agreed(self, action):
+        """Run a rank-local stage call that may fail on THIS rank only (a particle outside the rank's region, an
+        allocation) and agree on the outcome before the next collective -- otherwise the other ranks wait in an exchange
+        this rank never enters.  The reference raises and MPI_Aborts (logging.c:242-251); here every rank raises."""
+        err = None
+        try:
+            action()
+        except Exception as e:                      # noqa: BLE001 -- whatever it is, the other ranks must hear of it
+            err = e
+        if getattr(self, "_errflag", None) is None:
+            ref = getattr(self, "scalar", None)
+            self._errflag = torch.zeros(1, dtype=torch.float64, device=ref.device if ref is not None else "cpu")
+        self._errflag[0] = 0.0 if err is None else 1.0
+        yield ("allreduce", self._errflag)
+        if float(self._errflag.item()) != 0:
+            if err is not None:
+                raise err
+            from .lib import FastPMHipError
+            raise FastPMHipError("another rank failed in this stage of the force step")
+
     def _communicate(self, req):
         kind = req[0]
         g = self.group
@@ -219,7 +239,7 @@ class SlabForce(_SlabRank):
         mean_mass_per_cell = total_mass / pm.Norm
 
         # gravity.c:336-345: paint + normalise; the halo plane goes to the next slab
-        pm.paint(self.canvas, store, 1.0 / mean_mass_per_cell)
+        yield from self._agreed(lambda: pm.paint(self.canvas, store, 1.0 / mean_mass_per_cell))
         yield ("shift", [(pm.plane(self.canvas, xl), self.tmp_plane, +1)])
         pm.plane_add(pm.plane(self.canvas, 0), self.tmp_plane)
 
@@ -483,7 +503,7 @@ class PencilForce(_SlabRank):
         self.scalar[0] = pm.total_mass(store)                              # gravity.c:330-342
         yield ("allreduce", self.scalar)
         mean_mass_per_cell = float(self.scalar.item()) / pm.Norm
-        pm.paint(c, store, 1.0 / mean_mass_per_cell)                       # gravity.c:336-345
+        yield from self._agreed(lambda: pm.paint(c, store, 1.0 / mean_mass_per_cell))   # gravity.c:336-345
         yield from self._halo_out(c)
 
         pm.fft_z_forward(c, w[0])                                          # gravity.c:351 pm_r2c

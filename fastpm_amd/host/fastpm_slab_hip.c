@@ -40,8 +40,14 @@ static int paint_species(fpmhip_plan *plan, const fastpm_hip_transport *t, const
     }
     TRY(t->allreduce_sum(t->ctx, &total));
     const double scale = 1.0 / (total / Norm);
-    TRY(fpmhip_paint(plan, &sets[0], scale, canvas));
-    for (int si = 1; si < nsets; si++) TRY(fpmhip_paint_add(plan, &sets[si], scale, canvas));
+    /* A failure here is rank-local (a particle outside this rank's region, an allocation): agree on it before the
+     * next collective, or the other ranks wait in an exchange this rank never enters.  The reference raises and
+     * MPI_Aborts (logging.c:242-251); every rank returning nonzero lets the binding do the same. */
+    int rc = fpmhip_paint(plan, &sets[0], scale, canvas);
+    for (int si = 1; si < nsets && !rc; si++) rc = fpmhip_paint_add(plan, &sets[si], scale, canvas);
+    double failed = rc != 0;
+    TRY(t->allreduce_sum(t->ctx, &failed));
+    if (failed != 0) return rc ? rc : -8;            /* -8: another rank failed in the paint */
     return 0;
 }
 
@@ -350,6 +356,10 @@ int fastpm_hip_slab_decompose(fpmhip_plan *plan, const fastpm_hip_transport *t, 
     int64_t nstay = counts[0], nrecv = 0;
     for (int r = 0; r < P && !rc; r++) nrecv += recv_counts[r];
     if (!rc && nstay + nrecv > np_upper) rc = -4;                                           /* store.c:591-597 */
+    {   /* rank-local failures (no room for the arrivals, an allocation) must stop EVERY rank before the row exchange */
+        double failed = rc != 0;
+        if (t->allreduce_sum(t->ctx, &failed) != 0 || failed != 0) rc = rc ? rc : -8;
+    }
     int maxrow = 0;
     for (int c = 0; c < ncols; c++) if (cols[c].rowbytes > maxrow) maxrow = cols[c].rowbytes;
     if (!rc) rc = fpmhip_malloc(&tmp, (size_t) (np ? np : 1) * maxrow);

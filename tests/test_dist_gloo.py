@@ -224,3 +224,39 @@ def test_pencil_force_over_gloo_matches_one_rank_oracle(oracle, tmp_path, world,
     assert util.max_err(dk, util.oracle_k_to_xyk(pmo, ref["delta_k"])) <= 1e-13
     assert util.rel_err(acc, ref["acc"]) <= 1e-6
     assert util.rel_err(pot, ref["potential"]) <= 1e-6
+
+
+def _failing_worker(rank, world, port, N, L, x, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cpu_slab_ops import CpuSlabOps
+    from fastpm_amd.distributed import SlabForce
+    from fastpm_amd.pm import Store
+    owner = (np.floor(x[:, 0] * (1.0 / (L / N))).astype(np.int64) % N) // (N // world)
+    mine = x[owner == rank]
+    if rank == 1:
+        mine = np.concatenate([mine, x[owner == 0][:1]])          # one particle that belongs to rank 0
+    store = Store(mine, device="cpu")
+    try:
+        SlabForce(CpuSlabOps(N, L, world, rank), dist.group.WORLD, chunks=1).compute_force(store, kernel="1_4")
+        outcome = "finished"
+    except Exception as e:                                          # noqa: BLE001
+        outcome = type(e).__name__ + ": " + str(e)
+    open(os.path.join(out_dir, "outcome%d.txt" % rank), "w").write(outcome)
+    dist.destroy_process_group()
+
+
+def test_a_rank_local_failure_stops_every_rank(tmp_path):
+    """rank 1 holds a particle outside its slab and fails in the paint; rank 0 must not wait forever in the
+    halo exchange that rank 1 never enters -- both ranks raise (the reference would MPI_Abort, logging.c:242-251)."""
+    N, nc, L = 16, 8, 24.0
+    x = util.load_a(nc, L, N)
+    ctx = mp.spawn(_failing_worker, args=(2, _free_port(), N, L, x, str(tmp_path)), nprocs=2, join=False)
+    import time
+    deadline = time.time() + 120
+    while not ctx.join(timeout=5):                      # join() returns as soon as ONE process has exited
+        assert time.time() < deadline, "the ranks hung"
+    out = [open(tmp_path / ("outcome%d.txt" % r)).read() for r in range(2)]
+    assert "outside its slab" in out[1], out
+    assert "another rank failed" in out[0], out
