@@ -518,12 +518,15 @@ static int powerspectrum_impl(fpmhip_plan *p, void *d1, const void *d2, bool dec
     const int plane = g.yl * g.nzl;
     dim3 grid(std::max(1u, std::min(blocks_for(plane, 256 * 8), 64u)), (unsigned) std::min(g.N, 32));
     const size_t lds = 3 * nbins * sizeof(double);
+    if (lds > 64 * 1024)          // Nmesh > 5460: the per-block LDS bins no longer fit the default dynamic LDS limit
+        FPM_FAIL(-1, "P(k) binning: Nmesh %d needs %zu bytes of LDS bins per workgroup (limit 65536)", g.N, lds);
 #define POWER(F, D)                                                                                          \
     power_kernel<F, D><<<grid, 256, lds, p->stream>>>(g, k0, (Cplx<F> *) d1, (const Cplx<F> *) d2, nbins, dbins, \
                                                       dbins + nbins, dbins + 2 * nbins, p->d_decic)
     if (p->f64) { if (decic) POWER(double, true); else POWER(double, false); }
     else { if (decic) POWER(float, true); else POWER(float, false); }
 #undef POWER
+    FPM_CHECK_HIP(hipGetLastError());
     std::vector<double> h(3 * nbins);
     FPM_CHECK_HIP(hipMemcpyAsync(h.data(), dbins, 3 * nbins * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     FPM_CHECK_HIP(hipStreamSynchronize(p->stream));

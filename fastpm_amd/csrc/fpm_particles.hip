@@ -1455,6 +1455,7 @@ static int check_particles(const fpmhip_plan *p, const fpmhip_particles *pt)
     if (!p || !pt) FPM_FAIL(-1, "null argument");
     if (pt->np < 0) FPM_FAIL(-1, "negative particle count");
     if (pt->np > 0 && !pt->x) FPM_FAIL(-1, "particles without positions");
+    (void) hipSetDevice(p->device);
     return 0;
 }
 

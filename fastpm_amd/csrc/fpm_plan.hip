@@ -21,6 +21,9 @@ void set_error(const char *fmt, ...)
 
 StageTimer::StageTimer(fpmhip_plan *plan, int stage) : p(plan), on(plan->timing)
 {
+    // every stage entry point builds one of these first: make the plan's device the calling thread's current device
+    // (a plan created in one host thread and driven from another would otherwise launch on that thread's default)
+    (void) hipSetDevice(p->device);
     if (p->stage_hook && stage < FPMHIP_T_K_COLFFT) {       // top-level stages only; wall clocks on the host side
         (void) hipStreamSynchronize(p->stream);
         p->stage_hook(p->stage_hook_ctx, stage, 1);
