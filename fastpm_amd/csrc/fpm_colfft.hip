@@ -93,7 +93,7 @@ __global__ __launch_bounds__((ColCfg<PL, F>::threads)) void colfft_kernel(const 
     const bool live = col < ncols;
     C2<F> v[vmax(E)];
 #pragma unroll
-    for (int j = 0; j < E; j++) v[in_slot<PL>(j)] = live ? in[col_addr(im, batch, tau + T * j, col)] : C2<F>{0, 0};
+    for (int j = 0; j < E; j++) v[in_slot<PL>(j)] = live ? ld_stream(&in[col_addr(im, batch, tau + T * j, col)]) : C2<F>{0, 0};
     stage_twiddles(tw, tw_global, PL::TWN);       // after the data loads are in flight
     __syncthreads();
     fft_core<PL, S, CW, CF::SP>(v, lds, tw, tau, c);
@@ -103,7 +103,7 @@ __global__ __launch_bounds__((ColCfg<PL, F>::threads)) void colfft_kernel(const 
             C2<F> r = v[j];
             // pmpfft.c:381-385 multiplies by a double 1 / Norm and rounds once
             if (scale != 1.0) { r.x = (F) (r.x * scale); r.y = (F) (r.y * scale); }
-            out[col_addr(om, batch, tau + T * j, col)] = r;
+            st_stream(&out[col_addr(om, batch, tau + T * j, col)], r);
         }
     }
 }
@@ -146,7 +146,7 @@ void colfft_xback3_kernel(const C2<F> *dk, C2<F> *__restrict__ o0, C2<F> *__rest
     const long long jstride = (long long) T * rstride;
     C2<F> b[E];
 #pragma unroll
-    for (int j = 0; j < E; j++) b[j] = live ? (dk + j * jstride)[toff] : C2<F>{0, 0};
+    for (int j = 0; j < E; j++) b[j] = live ? ld_stream(&(dk + j * jstride)[toff]) : C2<F>{0, 0};
     stage_twiddles(tw, tw_global, PL::TWN);
     if (FWD) {
         C2<F> v[vmax(E)];
@@ -158,7 +158,7 @@ void colfft_xback3_kernel(const C2<F> *dk, C2<F> *__restrict__ o0, C2<F> *__rest
         for (int j = 0; j < E; j++) {
             b[j] = v[j];
             if (fwd_scale != 1.0) { b[j].x = (F) (b[j].x * fwd_scale); b[j].y = (F) (b[j].y * fwd_scale); }   // as colfft_kernel
-            if (live) (dk_store + j * jstride)[toff] = b[j];
+            if (live) st_stream_x3(&(dk_store + j * jstride)[toff], b[j]);
         }
     }
     const int iyl = live ? col / nzl : 0, iz = (live ? col - iyl * nzl : 0) + zstart;     // kz block of a pencil
@@ -215,7 +215,7 @@ void colfft_xback3_kernel(const C2<F> *dk, C2<F> *__restrict__ o0, C2<F> *__rest
             C2<F> *dst = dir == 0 ? o0 : (dir == 1 ? o1 : o2);
             const unsigned toff_o = (unsigned) tau_o * (unsigned) rstride + (unsigned) col;
 #pragma unroll
-            for (int j = 0; j < E; j++) (dst + j * jstride)[toff_o] = v[j];
+            for (int j = 0; j < E; j++) st_stream_x3(&(dst + j * jstride)[toff_o], v[j]);
         }
     }
 }
@@ -243,7 +243,7 @@ void colfft_yback2_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ oy, 
     const bool live = col < ncols;
     C2<F> a[E];
 #pragma unroll
-    for (int j = 0; j < E; j++) a[j] = live ? in[col_addr(im, batch, tau + T * j, col)] : C2<F>{0, 0};
+    for (int j = 0; j < E; j++) a[j] = live ? ld_stream(&in[col_addr(im, batch, tau + T * j, col)]) : C2<F>{0, 0};
     stage_twiddles(tw, tw_global, PL::TWN);
     // op != nullptr: a third output, the potential itself (gravity.c:487-492 wants it read out too): its y pass
     // comes from the same read instead of a second transfer + x pass (+ all-to-all on slabs)
@@ -268,7 +268,7 @@ void colfft_yback2_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ oy, 
         if (live) {
             C2<F> *dst = dir == 0 ? op : (dir == 1 ? oy : oz);
 #pragma unroll
-            for (int j = 0; j < E; j++) dst[col_addr(om, batch, tau_o + T * j, col)] = v[j];
+            for (int j = 0; j < E; j++) st_stream(&dst[col_addr(om, batch, tau_o + T * j, col)], v[j]);
         }
     }
 }

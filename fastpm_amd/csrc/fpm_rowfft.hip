@@ -55,7 +55,7 @@ __global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_r2c_kernel(co
     const C2<F> *src = in + (PEN ? ((row / rg.ylr) * rg.prows + row % rg.ylr) * pitch : row * pitch);
     C2<F> v[vmax(E)];
 #pragma unroll
-    for (int j = 0; j < E; j++) v[in_slot<PL>(j)] = live ? src[tau + T * j] : C2<F>{0, 0};
+    for (int j = 0; j < E; j++) v[in_slot<PL>(j)] = live ? ld_stream(&src[tau + T * j]) : C2<F>{0, 0};
     stage_twiddles(tw, tw_global, PL::TWN, 2);       // W_M^i = W_N^{2i}
     stage_twiddles(twn, tw_global, M, 1);
     __syncthreads();
@@ -77,7 +77,7 @@ __global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_r2c_kernel(co
         const C2<F> o = {d.y, -d.x};                           // d / i
         const C2<F> x = cadd(e, cmul(twn[k], o));
         if (live) {
-            at(k) = x;
+            st_stream(&at(k), x);
             if (k == 0) at(M) = C2<F>{a.x - a.y, 0};           // X[N/2] = Re Z0 - Im Z0
         }
     }
@@ -102,7 +102,7 @@ __global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_c2r_kernel(co
     const long long row = (long long) blockIdx.x * RW + c;
     const bool live = row < nrows;
     const C2<F> *src = in + (PEN ? row * rg.nzl : row * pitch);
-    auto at = [&](int k) -> C2<F> { return PEN ? src[(k / rg.nzl) * rg.chunk + k % rg.nzl] : src[k]; };
+    auto at = [&](int k) -> C2<F> { return ld_stream(PEN ? &src[(k / rg.nzl) * rg.chunk + k % rg.nzl] : &src[k]); };
     C2<F> x[E];
 #pragma unroll
     for (int j = 0; j < E; j++) x[j] = live ? at(tau + T * j) : C2<F>{0, 0};
@@ -133,7 +133,7 @@ __global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_c2r_kernel(co
     if (live) {
         C2<F> *dst = out + (PEN ? ((row / rg.ylr) * rg.prows + row % rg.ylr) * pitch : row * pitch);
 #pragma unroll
-        for (int j = 0; j < E; j++) dst[tau + T * j] = v[j];
+        for (int j = 0; j < E; j++) st_stream(&dst[tau + T * j], v[j]);
     }
 }
 
