@@ -381,7 +381,7 @@ static int yback2_launch(fpmhip_plan *p, const void *in, void *oy, void *oz, voi
             p->d_twiddle, p->mg.zstart);                                                                     \
     }
 #undef FPM_FAC_KIND
-#define FPM_FAC_KIND FusedFac
+#define FPM_FAC_KIND FusedFacY
     COLFFT_DISPATCH(p->mg.N, sizeof(F), CALL_Y2)
 #undef FPM_FAC_KIND
 #define FPM_FAC_KIND Fac
@@ -433,7 +433,7 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
 #define CALL_X3_P(PL, P) if (fwd) CALL_X3_Q(PL, P, true) else CALL_X3_Q(PL, P, false)
 #define CALL_X3(PL) if (mode == 1) { CALL_X3_P(PL, 1) } else if (mode == 2) { CALL_X3_P(PL, 2) } else { CALL_X3_P(PL, 0) }
 #undef FPM_FAC_KIND
-#define FPM_FAC_KIND FusedFac
+#define FPM_FAC_KIND FusedFacX
     COLFFT_DISPATCH(N, sizeof(F), CALL_X3)
 #undef FPM_FAC_KIND
 #define FPM_FAC_KIND Fac

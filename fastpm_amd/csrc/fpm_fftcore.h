@@ -416,20 +416,20 @@ FPM_FAC(1536, 0, 8, 8, 3, 8, 8)
 FPM_FAC(1536, 8, 8, 8, 3, 8, 8)
 FPM_FAC(1536, 4, 16, 16, 3, 8, 4)
 FPM_FAC(2048, 8, 16, 16, 16, 8, 1)
-#ifndef FPM_VARIANT_2048F_E32
 FPM_FAC(2048, 4, 16, 16, 16, 8, 1)
-#endif
 FPM_FAC(3072, 8, 16, 16, 3, 8, 8)
 FPM_FAC(3072, 4, 32, 16, 3, 8, 8)
-// The fused kernels (colfft_xback3 / colfft_yback2: several transforms per column load) may want another shape than
-// the plain pass of the same length; by default they share it.
-template <int N, int ES> struct FusedFac : Fac<N, ES> {};
-#ifdef FPM_VARIANT_1024_E16
-template <> struct FusedFac<1024, 8> { using type = FFTPlan<1024, 16, 16, 8, 8, 1>; };
-#endif
-#ifdef FPM_VARIANT_2048F_E32
-template <> struct Fac<2048, 4> { using type = FFTPlan<2048, 32, 16, 16, 8, 1>; };
-#endif
+// The fused kernels (several transforms per column load) may want another shape than the plain pass of the same
+// length; by default they share it.  KIND 0: colfft_xback3_kernel, 1: colfft_yback2_kernel.
+//   N = 800 (the 4-GPU weak-scaling mesh), fp64: 13-wave workgroups force a 128-VGPR budget in which the radix-5 stages
+//   of E = 8 spill (76 - 84 bytes per lane); 16 * 5 * 5 * 2 with E = 16 runs 7 waves at up to 256 VGPRs without spills:
+//   colfft_yback2 5.86 -> 4.79 ms on an 800^3 mesh (colfft_xback3 5.53 -> 5.69 ms: it keeps E = 8).
+//   Tried and not adopted (tools/rank_share_bench.py, same-box A/B): E = 16 at N = 1024 fp64 (xback3 1.13 -> 1.14 ms,
+//   yback2 0.93 -> 1.07 ms on the 8-GPU slab), E = 32 at N = 2048 fp32 (xback3 9.75 -> 9.48, yback2 8.38 -> 9.05 ms).
+template <int N, int ES, int KIND> struct FusedFac : Fac<N, ES> {};
+template <> struct FusedFac<800, 8, 1> { using type = FFTPlan<800, 16, 16, 5, 5, 2>; };
+template <int N, int ES> using FusedFacX = FusedFac<N, ES, 0>;
+template <int N, int ES> using FusedFacY = FusedFac<N, ES, 1>;
 #undef FPM_FAC_ALL
 #undef FPM_FAC
 

@@ -10,7 +10,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 NC=${NC:-256}; NMESH=${NMESH:-512}
-B="python $REPO/bench.py --gradient $GRAD --no-cpu-baseline --no-alt --steps 10 --warmup 2 --nc $NC --nmesh $NMESH"
+B="python $REPO/bench.py --gradient $GRAD --no-cpu-baseline --no-alt --no-secondary --steps 10 --warmup 2 --nc $NC --nmesh $NMESH"
 rm -rf /tmp/prof_$GRAD
 rocprofv3 --kernel-trace --stats -d /tmp/prof_$GRAD/trace -o t -- $B > $OUT/${TAG}_${GRAD}_bench_under_rocprof.json 2>/tmp/prof_$GRAD.err
 rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_$GRAD/fetch -o f -- $B > /dev/null 2>>/tmp/prof_$GRAD.err
