@@ -68,7 +68,7 @@ def main():
     row("powerspectrum", timed(lambda: pm.powerspectrum_sums(dk)), pm.layout.complex_elems * 16, "one read (synchronises: bin sums to the host)")
     row("decic + powerspectrum fused", timed(lambda: pm.decic_powerspectrum(dk)), 2 * pm.layout.complex_elems * 16,
         "one read, one write (synchronises)")
-    row("decompose_order", timed(lambda: pm.decompose_order(st)), n * 24 + n * 8, "x in, order out (radix sort of owner keys; 1 rank: all stay)")
+    row("decompose_order", timed(lambda: pm.decompose_order(st)), n * 24 + n * 8, "x in, order out (stable partition by owner key; 1 rank: all stay)")
     order, _ = pm.decompose_order(st)
     row("gather_rows(x)", timed(lambda: pm.gather_rows(st.x, order)), n * 48 + n * 4, "permute one double[3] column")
     # 2LPT on the particle-resolution mesh (solver.c:112): 256^3 mesh, 256^3 particles on mesh points
