@@ -31,6 +31,9 @@ struct ColMap {
 
 __device__ __forceinline__ long long col_addr(const ColMap &m, int batch, int i, int col)
 {
+    // a map whose rows are not split (one rank; the side of a y pass that has no exchange) needs no division: the
+    // branch is uniform (kernel argument) and saves two integer divisions per element
+    if (m.rhi == 0) return (long long) batch * m.bstride + (long long) i * m.rlo + col;
     return (long long) batch * m.bstride + (long long) (i / m.rsplit) * m.rhi + (long long) (i % m.rsplit) * m.rlo + col;
 }
 
@@ -348,8 +351,14 @@ int colfft_y(fpmhip_plan *p, int dir, const void *in, void *out, int chunked)
 // The two sides of a y pass.  Real side ("A"): [ry'][x_loc][y_loc][kz_loc] -- what the (y <-> kz) exchange of a pencil
 // row delivers / takes; with Nproc[1] = 1 (slabs, one rank) y_loc = N and this is the natural [x_loc][y][kz].
 // k side ("B"): [rx'][x_loc][ky_loc][kz_loc] -- the (x <-> ky) exchange chunks; natural when Nproc[0] = 1.
-static ColMap ymap_a(const MeshGeo &g) { return ColMap{(long long) g.ylr * g.nzl, (long long) g.xl * g.ylr * g.nzl, g.nzl, g.ylr}; }
-static ColMap ymap_b(const MeshGeo &g) { return ColMap{(long long) g.yl * g.nzl, (long long) g.xl * g.yl * g.nzl, g.nzl, g.yl}; }
+static ColMap ymap_a(const MeshGeo &g)
+{
+    return ColMap{(long long) g.ylr * g.nzl, g.ylr == g.N ? 0 : (long long) g.xl * g.ylr * g.nzl, g.nzl, g.ylr};
+}
+static ColMap ymap_b(const MeshGeo &g)
+{
+    return ColMap{(long long) g.yl * g.nzl, g.yl == g.N ? 0 : (long long) g.xl * g.yl * g.nzl, g.nzl, g.yl};
+}
 
 // the same for the x planes [x0, x0 + nx) only
 int colfft_y_range(fpmhip_plan *p, int dir, const void *in, void *out, int chunked, int x0, int nx)
