@@ -70,8 +70,9 @@ template <typename PL, typename F, bool X3 = false> struct ColCfg {
 // allow one workgroup per CU, i.e. at most 3 waves on a SIMD, and with 128 VGPRs the radix-5 stages spilled 44 - 52
 // bytes per lane), 2 for the E >= 16 factorisations on <= 8 waves (one workgroup per CU: the E values of a column
 // that stay live across the transforms alone are 64 VGPRs in fp64).
-constexpr int fused_min_waves(int threads, int E)
+constexpr int fused_min_waves(int threads, int E, int esize = 8)
 {
+    if (E == 16 && esize == 4 && threads == 512) return 4;      // fp32, two 512-thread workgroups per CU (see FusedFac)
     return E >= 16 ? (threads > 512 ? (threads > 768 ? 4 : 3) : 2) : (threads > 512 && threads <= 768 ? 3 : 4);
 }
 
@@ -128,7 +129,7 @@ __global__ __launch_bounds__((ColCfg<PL, F>::threads)) void colfft_kernel(const 
 //   kernel first runs the forward x pass (x fwd_scale, as colfft_kernel would), stores delta_k over its input
 //   and carries on from registers -- delta_k is written once and never re-read (one mesh sweep less).
 template <typename PL, int MODE, bool FWD, typename F>
-__global__ __launch_bounds__((ColCfg<PL, F, true>::threads), (fused_min_waves(ColCfg<PL, F, true>::threads, PL::E)))
+__global__ __launch_bounds__((ColCfg<PL, F, true>::threads), (fused_min_waves(ColCfg<PL, F, true>::threads, PL::E, sizeof(F))))
 void colfft_xback3_kernel(const C2<F> *dk, C2<F> *__restrict__ o0, C2<F> *__restrict__ o1, C2<F> *__restrict__ o2,
                           long long rstride, int ncols, int nzl, int ystart, int zstart, int ntiles, const float *__restrict__ kk,
                           const float *__restrict__ kt, const double *__restrict__ tw_global, C2<F> *dk_store,
@@ -229,7 +230,7 @@ void colfft_xback3_kernel(const C2<F> *dk, C2<F> *__restrict__ o0, C2<F> *__rest
 // the potential, two writes; the same factors (the float32 k_finite table) as transfer_kernel, applied
 // after the x transform instead of before it -- they do not depend on kx.  Rows = ky, columns = kz.
 template <typename PL, typename F>
-__global__ __launch_bounds__((ColCfg<PL, F>::threads), (fused_min_waves(ColCfg<PL, F>::threads, PL::E)))
+__global__ __launch_bounds__((ColCfg<PL, F>::threads), (fused_min_waves(ColCfg<PL, F>::threads, PL::E, sizeof(F))))
 void colfft_yback2_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ oy, C2<F> *__restrict__ oz,
                           C2<F> *__restrict__ op, ColMap im, ColMap om, int ncols, int ntiles_per_batch, int ntiles,
                           const float *__restrict__ kt, const double *__restrict__ tw_global, int zstart)

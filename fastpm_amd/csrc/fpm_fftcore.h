@@ -428,6 +428,13 @@ FPM_FAC(3072, 4, 32, 16, 3, 8, 8)
 //   yback2 0.93 -> 1.07 ms on the 8-GPU slab), E = 32 at N = 2048 fp32 (xback3 9.75 -> 9.48, yback2 8.38 -> 9.05 ms).
 template <int N, int ES, int KIND> struct FusedFac : Fac<N, ES> {};
 template <> struct FusedFac<800, 8, 1> { using type = FFTPlan<800, 16, 16, 5, 5, 2>; };
+//   N = 512, fp32 (the reference's default mesh precision): colfft_xback3 with E = 16 is 512 threads at <= 128 VGPRs, TWO
+//   workgroups per CU instead of one 1024-thread workgroup: 0.667 -> 0.595 ms (colfft_yback2 in the same shape loses,
+//   0.49 -> 0.65 ms, and keeps E = 8).
+template <> struct FusedFac<512, 4, 0> { using type = FFTPlan<512, 16, 16, 8, 4, 1>; };
+//   N = 1024, fp32: the same (8 columns, 512 threads, two workgroups per CU): 0.86 - 0.92 -> 0.68 - 0.70 ms on the 8-GPU
+//   slab (tools/rank_share_bench.py 1024 32); colfft_yback2 in that shape: no change.
+template <> struct FusedFac<1024, 4, 0> { using type = FFTPlan<1024, 16, 16, 8, 8, 1>; };
 template <int N, int ES> using FusedFacX = FusedFac<N, ES, 0>;
 template <int N, int ES> using FusedFacY = FusedFac<N, ES, 1>;
 #undef FPM_FAC_ALL
