@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64) void fill_gadget_kernel(MeshGeo g, const unsign
     Ranlxd lower, own;
     lower.seed(conj ? table[(long long) ci * N + cj] : table[(long long) i * N + j]);
     own.seed(table[(long long) i * N + j]);
-    F *row = out + 2 * (((long long) i * g.yl + jl) * g.nzc);
+    F *row = out + 2 * (((long long) i * g.yl + jl) * g.nzl);
     const int half = N / 2;
     for (int k = 0; k <= half; k++) {
         const bool use_conj = conj && (k == 0 || k == half);
@@ -120,10 +120,10 @@ __global__ __launch_bounds__(64) void fill_gadget_kernel(MeshGeo g, const unsign
 }
 
 template <typename F>
-__global__ __launch_bounds__(256) void remove_variance_kernel(long long n, F *__restrict__ d)
+__global__ __launch_bounds__(256) void remove_variance_kernel(long long n, int nzl, int nzc, F *__restrict__ d)
 {
     const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
+    if (t >= n || t % nzl >= nzc) return;                        // (the padding of the aligned row pitch is left alone)
     const double a = d[2 * t], b = d[2 * t + 1];
     double re = 0, im = 0;
     if (!(a == 0 && b == 0)) {
@@ -178,10 +178,11 @@ __global__ __launch_bounds__(256) void induce_correlation_kernel(MeshGeo g, cons
     }
     const int ix = blockIdx.y;
     const int rem = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rem >= g.yl * g.nzc) return;
-    const int iyl = rem / g.nzc, iz = rem - iyl * g.nzc;
+    if (rem >= g.yl * g.nzl) return;
+    const int iyl = rem / g.nzl, iz = rem - iyl * g.nzl;
+    if (iz >= g.nzc) return;                                  // padding of the aligned row pitch
     const int iy = iyl + g.ystart;
-    const long long ind = ((long long) ix * g.yl + iyl) * g.nzc + iz;
+    const long long ind = ((long long) ix * g.yl + iyl) * g.nzl + iz;
     double k2 = 0;
     k2 += kk[ix];
     k2 += kk[iy];
@@ -253,10 +254,10 @@ int fpmhip_ic_remove_variance(fpmhip_plan *p, void *delta_k)
     if (p && p->lay.nranks_y > 1) FPM_FAIL(-1, "the initial-condition operators run on slabs (nranks_y = 1)");
     if (!p || !delta_k) FPM_FAIL(-1, "null argument");
     const MeshGeo &g = p->mg;
-    const long long n = (long long) g.N * g.yl * g.nzc;
+    const long long n = (long long) g.N * g.yl * g.nzl;
     const unsigned grid = (unsigned) ((n + 255) / 256);
-    if (p->f64) remove_variance_kernel<double><<<grid, 256, 0, p->stream>>>(n, (double *) delta_k);
-    else remove_variance_kernel<float><<<grid, 256, 0, p->stream>>>(n, (float *) delta_k);
+    if (p->f64) remove_variance_kernel<double><<<grid, 256, 0, p->stream>>>(n, g.nzl, g.nzc, (double *) delta_k);
+    else remove_variance_kernel<float><<<grid, 256, 0, p->stream>>>(n, g.nzl, g.nzc, (float *) delta_k);
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -274,7 +275,7 @@ int fpmhip_ic_induce_correlation(fpmhip_plan *p, void *delta_k, const double *k,
     if (e == hipSuccess) {
         const float *kk = p->d_tab + 2 * (size_t) g.N;             // the kk = k * k table, pmapi.c:262
         const double L = p->geom.BoxSize;
-        dim3 grid((unsigned) (((long long) g.yl * g.nzc + 255) / 256), (unsigned) g.N);
+        dim3 grid((unsigned) (((long long) g.yl * g.nzl + 255) / 256), (unsigned) g.N);
         const bool in_lds = size <= 4096;                          // 64 KB: the default dynamic LDS limit
         const size_t lds = in_lds ? 2 * (size_t) size * sizeof(double) : 0;
 #define INDUCE(F, L_)                                                                                             \

@@ -74,8 +74,9 @@ struct MeshGeo {
     int yrstart;       // first global y row
     int yplanes;       // rows present in a real plane: ylr + y halo
     int periodic_y;    // 1 if Nproc[1] == 1 (wrap in y inside the kernel)
-    long long str0;    // real strides: yplanes*(N+2)
-    long long str1;    // N+2
+    long long str0;    // real strides: yplanes * str1
+    long long str1;    // reals per row of the real mesh: N + 2, or 2 * rp with the aligned pitch (see fpm_plan.hip)
+    int rp;            // the same in complex units: the pitch the z passes read / write real rows with
     double inv_cell;   // 1.0 / (BoxSize / N), pmpfft.c:150-151
     int ntx, nty, ntz; // tile grid over [xplanes][N][N]
 };

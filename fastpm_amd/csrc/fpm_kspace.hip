@@ -581,7 +581,7 @@ int fpmhip_yrow(fpmhip_plan *p, void *mesh, int64_t iy, void *buf, int mode)
     const MeshGeo &g = p->mg;
     if (iy < 0 || iy >= g.yplanes || mode < 0 || mode > 2) FPM_FAIL(-1, "yrow: row %lld / mode %d out of range", (long long) iy, mode);
     StageTimer tm(p, FPMHIP_T_HALO);
-    const int rowlen = g.N + 2;
+    const int rowlen = (int) g.str1;
     const long long n = (long long) g.xl * rowlen;
 #define YROW(F, M) yrow_kernel<F, M><<<blocks_for(n, 256), 256, 0, p->stream>>>((F *) mesh, (F *) buf, g.str0, rowlen, iy * g.str1, g.xl)
     if (p->f64) { if (mode == 0) YROW(double, 0); else if (mode == 1) YROW(double, 1); else YROW(double, 2); }

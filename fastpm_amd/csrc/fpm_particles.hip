@@ -658,7 +658,8 @@ __global__ __launch_bounds__(256) void paint_tiles_kernel(MeshGeo g, int ntiles,
             F *row = canvas + (long long) gx * g.str0 + (long long) gy * g.str1;
             const F mine = (F) (tile[i] * scale);
             row[gz] = accumulate ? (F) (row[gz] + mine) : mine;      // further species add (gravity.c:326-338)
-            if (gz == g.N - 1 && !accumulate) { row[g.N] = 0; row[g.N + 1] = 0; }   // pm_clear'ed padding
+            if (gz == g.N - 1 && !accumulate)                                       // pm_clear'ed padding
+                for (int pz = g.N; pz < (int) g.str1; pz++) row[pz] = 0;
         }
     }
 }

@@ -208,7 +208,15 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
         FPM_FAIL(-1, "FPMHIP_GRADIENT_REAL is a slab-only mode (its stencil halo is two planes deep in x only)");
     const int rx = geom->rank / Ny, ry = geom->rank % Ny;            // MPI_Cart_create order, pmpfft.c:127-136
     const int xl = (int) (N / Nx), yl = (int) (N / Nx), ylr = (int) (N / Ny), nzc = (int) (N / 2 + 1);
-    const int nzl = (nzc + Ny - 1) / Ny;                             // kz block, the last one padded
+    // Row pitch.  With the hand-written passes every row of the k-space mesh (and of the real mesh, which the in-place z
+    // passes share it with) starts on a 128-byte line: N/2 + 1 complex values are 4112 B at N = 512 and every row segment
+    // a column pass touches would straddle two lines (tools/ubench/ypass_pitch.hip: the y-pass pattern runs 0.64 ms at
+    // pitch 257 and 0.50 ms at pitch 264 for 1R+1W, 0.80 vs 0.67 ms for 1R+2W).  The rocFFT plans keep the reference's
+    // N + 2 / N/2 + 1 pitches.
+    const bool aligned = geom->fft_mode == FPMHIP_FFT_AUTO && colfft_supported((int) N) && rowfft_supported((int) N);
+    const int align = aligned ? (int) (64 / (geom->precision / 8)) : 1;             // complex values per 128-B line
+    const int rp = (nzc + align - 1) / align * align;                               // real rows, in complex units
+    const int nzl = Ny == 1 ? rp : ((nzc + Ny - 1) / Ny + align - 1) / align * align;   // kz block, the last one padded
     const int hx = Nx > 1 ? 1 : 0, hy = Ny > 1 ? 1 : 0;
     fpmhip_layout &L = p->lay;
     memset(&L, 0, sizeof(L));
@@ -221,10 +229,10 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
     L.nranks_x = Nx; L.nranks_y = Ny; L.rank_x = rx; L.rank_y = ry;
     L.ihalo = hx;
     L.ihalo_y = hy;
-    L.plane_elems = (int64_t) (ylr + hy) * (N + 2);
+    L.plane_elems = (int64_t) (ylr + hy) * 2 * rp;
     L.istart[0] = (int64_t) rx * xl; L.istart[1] = (int64_t) ry * ylr; L.istart[2] = 0;
     L.isize[0] = xl; L.isize[1] = ylr; L.isize[2] = N;
-    L.istrides[0] = L.plane_elems; L.istrides[1] = N + 2; L.istrides[2] = 1;
+    L.istrides[0] = L.plane_elems; L.istrides[1] = 2 * rp; L.istrides[2] = 1;
     L.ostart[0] = 0; L.ostart[1] = (int64_t) rx * yl; L.ostart[2] = (int64_t) ry * nzl;
     L.osize[0] = N; L.osize[1] = yl; L.osize[2] = nzl;
     L.ovalid_z = std::max<int64_t>(0, std::min<int64_t>(nzl, nzc - (int64_t) ry * nzl));
@@ -242,7 +250,7 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
     g.periodic_x = Nx == 1; g.yl = yl; g.ystart = rx * yl; g.nzc = nzc;
     g.nzl = nzl; g.zstart = ry * nzl;
     g.ylr = ylr; g.yrstart = ry * ylr; g.yplanes = ylr + hy; g.periodic_y = Ny == 1;
-    g.str0 = L.plane_elems; g.str1 = N + 2;
+    g.str0 = L.plane_elems; g.str1 = 2 * rp; g.rp = rp;
     g.inv_cell = 1.0 / (geom->BoxSize / N);
     g.ntx = (g.xplanes + TILE_X - 1) / TILE_X;
     g.nty = (g.yplanes + TILE_Y - 1) / TILE_Y;

@@ -171,7 +171,7 @@ bool rowfft_supported(int N)
 static RowGeo row_geo(const fpmhip_plan *p)
 {
     const MeshGeo &g = p->mg;
-    return RowGeo{(long long) g.nzc, g.ylr, g.yplanes, g.nzl, (long long) g.xl * g.ylr * g.nzl};
+    return RowGeo{(long long) g.rp, g.ylr, g.yplanes, g.nzl, (long long) g.xl * g.ylr * g.nzl};
 }
 
 template <typename F>
@@ -183,8 +183,8 @@ static int rowfft_launch(fpmhip_plan *p, const void *in_, void *out_, int x0, in
     const long long nrows = (long long) nx * g.ylr;
     const RowGeo rg = row_geo(p);
     // the planes [x0, x0 + nx): real planes are yplanes rows apart, spectrum rows ylr * (nzl | nzc) apart
-    const void *in = (const char *) in_ + (size_t) x0 * g.yplanes * g.nzc * sizeof(C2<F>);
-    void *out = (char *) out_ + (size_t) x0 * g.ylr * (pen ? g.nzl : g.nzc) * sizeof(C2<F>);
+    const void *in = (const char *) in_ + (size_t) x0 * g.yplanes * g.rp * sizeof(C2<F>);
+    void *out = (char *) out_ + (size_t) x0 * g.ylr * g.nzl * sizeof(C2<F>);       // (slabs: nzl == rp, in place works)
 #define CALL_ROW_P(PL, PEN_)                                                                            \
     {                                                                                                   \
         using CF = RowCfg<PL, F>;                                                                       \
@@ -215,8 +215,8 @@ static int rowfft_c2r_launch(fpmhip_plan *p, const void *in_, void *out_, int x0
     const bool pen = !g.periodic_y;
     const long long nrows = (long long) nx * g.ylr;
     const RowGeo rg = row_geo(p);
-    const void *in = (const char *) in_ + (size_t) x0 * g.ylr * (pen ? g.nzl : g.nzc) * sizeof(C2<F>);
-    void *out = (char *) out_ + (size_t) x0 * g.yplanes * g.nzc * sizeof(C2<F>);
+    const void *in = (const char *) in_ + (size_t) x0 * g.ylr * g.nzl * sizeof(C2<F>);
+    void *out = (char *) out_ + (size_t) x0 * g.yplanes * g.rp * sizeof(C2<F>);
 #define CALL_ROWB_P(PL, PEN_)                                                                            \
     {                                                                                                    \
         using CF = RowCfg<PL, F>;                                                                        \

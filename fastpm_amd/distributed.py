@@ -450,7 +450,7 @@ class PencilForce(_SlabRank):
         self.delta_k = None
         L = pm.layout
         self.tmp_plane = torch.zeros(int(L.plane_elems), dtype=self.c.dtype, device=self.c.device)
-        nrow = int(L.isize[0]) * (pm.Nmesh + 2)
+        nrow = int(L.isize[0]) * int(getattr(L, "istrides", (0, pm.Nmesh + 2))[1])
         self.row_s = torch.zeros(nrow, dtype=self.c.dtype, device=self.c.device)
         self.row_r = torch.zeros(nrow, dtype=self.c.dtype, device=self.c.device)
         self.scalar = torch.zeros(1, dtype=torch.float64, device=self.c.device)

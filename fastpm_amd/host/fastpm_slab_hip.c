@@ -204,7 +204,7 @@ static int halo_out(fpmhip_plan *plan, const fastpm_hip_transport *t, const mesh
                     void *mesh, void *scratch)
 {
     const size_t es = (size_t) lay->precision / 8;
-    const size_t plane_bytes = (size_t) lay->plane_elems * es, row_bytes = (size_t) lay->isize[0] * (lay->Nmesh + 2) * es;
+    const size_t plane_bytes = (size_t) lay->plane_elems * es, row_bytes = (size_t) lay->isize[0] * (size_t) lay->istrides[1] * es;
     if (g->Nx > 1) {
         TRY(fpmhip_sync(plan));
         TRY(t->sendrecv(t->ctx, fpmhip_plane_ptr(plan, mesh, lay->isize[0]), neighbour(g, 1, +1), scratch,
@@ -226,7 +226,7 @@ static int halo_in(fpmhip_plan *plan, const fastpm_hip_transport *t, const mesh_
                    void *mesh, void *scratch)
 {
     const size_t es = (size_t) lay->precision / 8;
-    const size_t plane_bytes = (size_t) lay->plane_elems * es, row_bytes = (size_t) lay->isize[0] * (lay->Nmesh + 2) * es;
+    const size_t plane_bytes = (size_t) lay->plane_elems * es, row_bytes = (size_t) lay->isize[0] * (size_t) lay->istrides[1] * es;
     if (g->Ny > 1) {
         void *rs = scratch, *rr = (char *) scratch + row_bytes;
         TRY(fpmhip_yrow(plan, mesh, 0, rs, 0));

@@ -404,16 +404,18 @@ class PM:
 
     # ---- views for tests / host handlers
     def real_view(self, buf):
-        """[x_loc (+halo)][y_loc (+halo)][N+2] view of a real-space mesh."""
+        """[x_loc (+halo)][y_loc (+halo)][row pitch >= N + 2] view of a real-space mesh (values past N are padding)."""
         L = self.layout
         nx = L.isize[0] + L.ihalo
-        return buf[: nx * L.plane_elems].view(nx, L.isize[1] + L.ihalo_y, self.Nmesh + 2)
+        return buf[: nx * L.plane_elems].view(nx, L.isize[1] + L.ihalo_y, int(L.istrides[1]))
 
     def complex_view(self, buf):
-        """[x][y_loc][kz] complex view of a k-space mesh (fpmhip_layout.ostrides)."""
+        """[x][y_loc][kz] complex view of the MODES of a k-space mesh (fpmhip_layout.ostrides): the row pitch is
+        osize[2] >= ovalid_z (rows padded to whole 128-byte lines, a pencil's last kz block); the view stops at ovalid_z."""
         L = self.layout
         n = int(L.complex_elems)
-        return torch.view_as_complex(buf[: 2 * n].view(n, 2)).view(L.osize[0], L.osize[1], L.osize[2])
+        full = torch.view_as_complex(buf[: 2 * n].view(n, 2)).view(L.osize[0], L.osize[1], L.osize[2])
+        return full[:, :, : int(L.ovalid_z)]
 
     # ---- stages
     def total_mass(self, store):
@@ -533,7 +535,7 @@ class PM:
         """Host copy of delta_k in the reference's PFFT-transposed layout [y_loc][kz][x]."""
         L = self.layout
         cdt = np.complex128 if self.precision == 64 else np.complex64
-        out = np.empty((L.osize[1], L.osize[2], L.osize[0]), dtype=cdt)
+        out = np.empty((L.osize[1], L.ovalid_z, L.osize[0]), dtype=cdt)      # the reference layout holds the modes only
         check(self._L.fpmhip_export_delta_k(self._plan, _ptr(delta_k), out.ctypes.data_as(ctypes.c_void_p)))
         return out
 
@@ -587,7 +589,7 @@ class PM:
         check(self._L.fpmhip_fft_z_backward(self._plan, _ptr(recv_a), _ptr(canvas)))
 
     def yrow(self, mesh, iy, buf, mode):
-        """mode 0 pack, 1 unpack, 2 add: row iy of the planes [0, isize[0]) <-> buf[isize[0] * (N + 2)]"""
+        """mode 0 pack, 1 unpack, 2 add: row iy of the planes [0, isize[0]) <-> buf[isize[0] * istrides[1]]"""
         check(self._L.fpmhip_yrow(self._plan, _ptr(mesh), int(iy), _ptr(buf), int(mode)))
 
     def ranged_fft(self):
@@ -672,7 +674,7 @@ class PM:
         if want_delta_k and dk is None:
             L = self.layout
             cdt = np.complex128 if self.precision == 64 else np.complex64
-            dk = np.empty((L.osize[1], L.osize[2], L.osize[0]), dtype=cdt)
+            dk = np.empty((L.osize[1], L.ovalid_z, L.osize[0]), dtype=cdt)
         check(self._L.fpmhip_force_host(self._plan, ctypes.byref(c), _enum(KERNEL_TYPES, kernel),
                                         _enum(SOFTENING_TYPES, softening),
                                         None if dk is None else dk.ctypes.data_as(ctypes.c_void_p)))

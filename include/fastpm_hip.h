@@ -94,9 +94,12 @@ typedef struct {
     int64_t Nmesh;
     double  BoxSize;
     int32_t precision, nranks, rank, gradient_mode;   /* as given in fpmhip_geom */
-    int64_t istart[3], isize[3], istrides[3];   /* IRegion; isize excludes z padding and halo */
+    int64_t istart[3], isize[3], istrides[3];   /* IRegion; isize excludes z padding and halo.  istrides[1] = reals per
+                                                 * row: Nmesh + 2 (the reference's, pmpfft.c:181-187) with the rocFFT back
+                                                 * end; with the hand-written passes rows are padded to whole 128-byte
+                                                 * lines (2 * osize[2] on slabs), the values past Nmesh are padding */
     int64_t ihalo;          /* extra x planes after the local slab (0 if Nproc[0] == 1, else 1) */
-    int64_t plane_elems;    /* reals in one x plane = (isize[1] + ihalo_y) * (Nmesh + 2) */
+    int64_t plane_elems;    /* reals in one x plane = (isize[1] + ihalo_y) * istrides[1] */
     int64_t ostart[3], osize[3], ostrides[3];   /* ORegion: [x][y_loc][kz], kz fastest */
     int64_t real_elems;     /* reals used by a real-space mesh incl. halo plane */
     int64_t complex_elems;  /* complex numbers in a k-space mesh */
@@ -219,7 +222,7 @@ int fpmhip_fft_y_backward_grad2(fpmhip_plan *plan, void *recv_b_dev, void *out_y
                                 void *out_pot_a_dev, int kernel);
 int fpmhip_fft_z_backward(fpmhip_plan *plan, void *recv_a_dev, void *canvas_dev);
 /* Pencil halo in y (the y half of pm_ghosts_create / pm_ghosts_reduce, pmghosts.c:31-80, 247-307, as mesh rows): row
- * `iy` of the planes [0, isize[0]) of a real mesh <-> a contiguous buffer of isize[0] * (Nmesh + 2) values.
+ * `iy` of the planes [0, isize[0]) of a real mesh <-> a contiguous buffer of isize[0] * istrides[1] values.
  * mode 0: pack (buffer = row), 1: unpack (row = buffer), 2: add (row += buffer).
  *   after the paint : x first -- plane isize[0] (all rows) to rank_x + 1, added to its plane 0 (fpmhip_plane_add);
  *                     then row isize[1] of the planes [0, isize[0]) to rank_y + 1, added to its row 0;

@@ -84,7 +84,7 @@ def test_readout_bit_exact(oracle, precision):
         pmo.readout(meshes[d], x, out=ref, nmemb=3, memb=d)
     pm = _pm(N, L, precision)
     st = Store(x)
-    dev = [torch.from_numpy(m).to(pm.device) for m in meshes]
+    dev = [util.dev_real(pm, pmo, m) for m in meshes]
     pm.readout3(dev, st)
     torch.cuda.synchronize()
     assert np.array_equal(st.acc.cpu().numpy(), ref)
@@ -126,7 +126,7 @@ def test_fft_roundtrip_and_parity(oracle, precision):
     pmo.real_view(cv)[:, :, :N] = rng.normal(size=(N, N, N)).astype(pmo.F)
     ref_k = pmo.r2c(cv.copy())
     pm = _pm(N, L, precision)
-    d_cv = torch.from_numpy(cv).to(pm.device)
+    d_cv = util.dev_real(pm, pmo, cv)
     d_k = pm.alloc()
     pm.r2c(d_cv.clone(), d_k)
     torch.cuda.synchronize()
@@ -222,7 +222,7 @@ def test_binning_reuse_and_invalidate(oracle):
     rng = np.random.default_rng(9)
     mesh = pmo.alloc()
     mesh[:] = rng.normal(size=mesh.shape)
-    dmesh = torch.from_numpy(mesh).to(pm.device)
+    dmesh = util.dev_real(pm, pmo, mesh)
     x1, x2 = util.load_a(nc, L, N), util.load_b(nc, L, N)
     st = Store(x1)
     out = torch.zeros((len(x1), 1), dtype=torch.float32, device=pm.device)
@@ -256,10 +256,9 @@ def test_column_fft_backend_matches_rocfft_and_oracle(oracle, precision, N):
     pm = _pm(N, L, precision)
     pr = _pm(N, L, precision, fft_mode=FFT_ROCFFT)
     assert pm.staged_fft() and not pr.staged_fft()
-    d_cv = torch.from_numpy(cv).to(pm.device)
     k_own, k_roc = pm.alloc(), pr.alloc()
-    pm.r2c(d_cv.clone(), k_own)
-    pr.r2c(d_cv.clone(), k_roc)
+    pm.r2c(util.dev_real(pm, pmo, cv), k_own)         # (the two back ends differ in their row pitch)
+    pr.r2c(util.dev_real(pr, pmo, cv), k_roc)
     torch.cuda.synchronize()
     ko = util.oracle_k_to_xyk(pmo, ref_k)
     assert util.max_err(pm.complex_view(k_own).cpu().numpy(), ko) <= tol
@@ -269,8 +268,9 @@ def test_column_fft_backend_matches_rocfft_and_oracle(oracle, precision, N):
     pm.transfer_fft_x_backward3("1_4", k_own, outs)
     for d in range(3):
         pm.fft_yz_backward(outs[d], outs[d])
-        ref = pr.alloc()
-        pr.gravity_apply_kernel_transfer("1_4", k_own, ref, d)
+        ref, k_in = pr.alloc(), pr.alloc()
+        pr.complex_view(k_in).copy_(pm.complex_view(k_own))
+        pr.gravity_apply_kernel_transfer("1_4", k_in, ref, d)
         pr.c2r(ref)
         torch.cuda.synchronize()
         a, b = pm.real_view(outs[d]).cpu().numpy()[:, :, :N], pr.real_view(ref).cpu().numpy()[:, :, :N]

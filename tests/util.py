@@ -70,3 +70,13 @@ def max_err(a, b):
     b = np.asarray(b)
     s = np.abs(b).max()
     return np.abs(a - b).max() / (s if s > 0 else 1.0)
+
+
+def dev_real(pm, pmo, buf):
+    """An oracle real mesh ([x][y][N + 2], the reference's pitch) as a mesh buffer of the GPU plan, whose rows may be
+    padded to whole 128-byte lines (fpmhip_layout.istrides[1] >= N + 2)."""
+    import torch
+    d = pm.alloc()
+    src = np.ascontiguousarray(pmo.real_view(buf))
+    pm.real_view(d)[: src.shape[0], : src.shape[1], : src.shape[2]] = torch.from_numpy(src).to(d.device)
+    return d
