@@ -658,8 +658,15 @@ __global__ __launch_bounds__(256) void paint_tiles_kernel(MeshGeo g, int ntiles,
             F *row = canvas + (long long) gx * g.str0 + (long long) gy * g.str1;
             const F mine = (F) (tile[i] * scale);
             row[gz] = accumulate ? (F) (row[gz] + mine) : mine;      // further species add (gravity.c:326-338)
-            if (gz == g.N - 1 && !accumulate)                                       // pm_clear'ed padding
-                for (int pz = g.N; pz < (int) g.str1; pz++) row[pz] = 0;
+        }
+    }
+    // pm_clear'ed row padding (N .. row pitch): the tiles at the end of z zero it, all threads sharing the stores
+    if (tz == g.ntz - 1 && !accumulate) {
+        const int npad = (int) g.str1 - g.N;
+        for (int i = threadIdx.x; i < TILE_X * TILE_Y * npad; i += 256) {
+            const int pz = i % npad, ly = (i / npad) % TILE_Y, lx = i / (npad * TILE_Y);
+            const int gx = x0 + lx, gy = y0 + ly;
+            if (gx < g.xplanes && gy < g.yplanes) canvas[(long long) gx * g.str0 + (long long) gy * g.str1 + g.N + pz] = 0;
         }
     }
 }

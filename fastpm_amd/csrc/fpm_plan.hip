@@ -211,10 +211,14 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
     // Row pitch.  With the hand-written passes every row of the k-space mesh (and of the real mesh, which the in-place z
     // passes share it with) starts on a 128-byte line: N/2 + 1 complex values are 4112 B at N = 512 and every row segment
     // a column pass touches would straddle two lines (tools/ubench/ypass_pitch.hip: the y-pass pattern runs 0.64 ms at
-    // pitch 257 and 0.50 ms at pitch 264 for 1R+1W, 0.80 vs 0.67 ms for 1R+2W).  The rocFFT plans keep the reference's
+    // pitch 257 and 0.50 ms at pitch 264 for 1R+1W, 0.80 vs 0.67 ms for 1R+2W; in the step: colfft_yback2 0.88 -> 0.74 ms,
+    // 6.1 -> 5.97 ms per force on configs[1] although the mesh is 2.7 % larger).  The rocFFT plans keep the reference's
     // N + 2 / N/2 + 1 pitches.
-    const bool aligned = geom->fft_mode == FPMHIP_FFT_AUTO && colfft_supported((int) N) && rowfft_supported((int) N);
-    const int align = aligned ? (int) (64 / (geom->precision / 8)) : 1;             // complex values per 128-B line
+    // fp64 meshes only: on fp32 meshes a line is 16 complex values, the padding costs 5.8 % of the mesh at N = 512 and the
+    // row passes lose more (0.23 -> 0.27 ms) than the y passes gain: 3.83 -> 4.03 ms per force.
+    const bool aligned = geom->fft_mode == FPMHIP_FFT_AUTO && geom->precision == 64 && colfft_supported((int) N) &&
+                         rowfft_supported((int) N);
+    const int align = aligned ? 8 : 1;                                              // complex doubles per 128-B line
     const int rp = (nzc + align - 1) / align * align;                               // real rows, in complex units
     const int nzl = Ny == 1 ? rp : ((nzc + Ny - 1) / Ny + align - 1) / align * align;   // kz block, the last one padded
     const int hx = Nx > 1 ? 1 : 0, hy = Ny > 1 ? 1 : 0;
