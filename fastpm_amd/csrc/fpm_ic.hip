@@ -114,8 +114,11 @@ __global__ __launch_bounds__(64) void fill_gadget_kernel(MeshGeo g, const unsign
         if (use_conj) im *= -1;
         if (ci == i && cj == j && (k == 0 || k == half)) im = 0;                     // self-conjugate modes are real
         if (i == 0 && j == 0 && k == 0) { re = 0; im = 0; }
-        row[2 * k] = (F) re;
-        row[2 * k + 1] = (F) im;
+        const int kl = k - g.zstart;                         // a pencil keeps its kz block of the column (all of it on slabs)
+        if (kl >= 0 && kl < g.nzl) {
+            row[2 * kl] = (F) re;
+            row[2 * kl + 1] = (F) im;
+        }
     }
 }
 
@@ -123,7 +126,7 @@ template <typename F>
 __global__ __launch_bounds__(256) void remove_variance_kernel(long long n, int nzl, int nzc, F *__restrict__ d)
 {
     const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n || t % nzl >= nzc) return;                        // (the padding of the aligned row pitch is left alone)
+    if (t >= n || t % nzl >= nzc) return;         // nzc: the modes of this rank's rows (the row padding is left alone)
     const double a = d[2 * t], b = d[2 * t + 1];
     double re = 0, im = 0;
     if (!(a == 0 && b == 0)) {
@@ -179,10 +182,10 @@ __global__ __launch_bounds__(256) void induce_correlation_kernel(MeshGeo g, cons
     const int ix = blockIdx.y;
     const int rem = blockIdx.x * blockDim.x + threadIdx.x;
     if (rem >= g.yl * g.nzl) return;
-    const int iyl = rem / g.nzl, iz = rem - iyl * g.nzl;
-    if (iz >= g.nzc) return;                                  // padding of the aligned row pitch
+    const int iyl = rem / g.nzl, izl = rem - iyl * g.nzl, iz = izl + g.zstart;
+    if (iz >= g.nzc) return;                                  // row padding / the padding of a pencil's last kz block
     const int iy = iyl + g.ystart;
-    const long long ind = ((long long) ix * g.yl + iyl) * g.nzl + iz;
+    const long long ind = ((long long) ix * g.yl + iyl) * g.nzl + izl;
     double k2 = 0;
     k2 += kk[ix];
     k2 += kk[iy];
@@ -225,7 +228,6 @@ extern "C" {
 
 int fpmhip_ic_fill_gaussian(fpmhip_plan *p, void *delta_k, int seed)
 {
-    if (p && p->lay.nranks_y > 1) FPM_FAIL(-1, "the initial-condition operators run on slabs (nranks_y = 1)");
     if (!p || !delta_k) FPM_FAIL(-1, "null argument");
     const MeshGeo &g = p->mg;
     if (g.N % 2) FPM_FAIL(-1, "the gadget scheme needs an even mesh");
@@ -251,20 +253,19 @@ int fpmhip_ic_fill_gaussian(fpmhip_plan *p, void *delta_k, int seed)
 
 int fpmhip_ic_remove_variance(fpmhip_plan *p, void *delta_k)
 {
-    if (p && p->lay.nranks_y > 1) FPM_FAIL(-1, "the initial-condition operators run on slabs (nranks_y = 1)");
     if (!p || !delta_k) FPM_FAIL(-1, "null argument");
     const MeshGeo &g = p->mg;
     const long long n = (long long) g.N * g.yl * g.nzl;
     const unsigned grid = (unsigned) ((n + 255) / 256);
-    if (p->f64) remove_variance_kernel<double><<<grid, 256, 0, p->stream>>>(n, g.nzl, g.nzc, (double *) delta_k);
-    else remove_variance_kernel<float><<<grid, 256, 0, p->stream>>>(n, g.nzl, g.nzc, (float *) delta_k);
+    const int nzv = (int) p->lay.ovalid_z;
+    if (p->f64) remove_variance_kernel<double><<<grid, 256, 0, p->stream>>>(n, g.nzl, nzv, (double *) delta_k);
+    else remove_variance_kernel<float><<<grid, 256, 0, p->stream>>>(n, g.nzl, nzv, (float *) delta_k);
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 int fpmhip_ic_induce_correlation(fpmhip_plan *p, void *delta_k, const double *k, const double *pk, int size)
 {
-    if (p && p->lay.nranks_y > 1) FPM_FAIL(-1, "the initial-condition operators run on slabs (nranks_y = 1)");
     if (!p || !delta_k || !k || !pk) FPM_FAIL(-1, "null argument");
     if (size < 1) FPM_FAIL(-1, "empty power spectrum table");
     const MeshGeo &g = p->mg;

@@ -431,29 +431,17 @@ def make_axis_groups(Nx, Ny, rank, base_group=None):
     return row, col
 
 
-class PencilForce(_SlabRank):
-    """fastpm_solver_compute_force (gravity.c:458-529) for rank (rank_x, rank_y) of an Nx x Ny process mesh -- the
-    reference's default decomposition (pmpfft.c:117-136: Nproc = {4, 2} for 8 ranks).  What differs from SlabForce:
-      * the particle ghosts become a mesh halo in x AND y (pmghosts.c:31-80 probes both): after the paint the extra x
-        plane goes to rank_x + 1 and then the extra y row to rank_y + 1 (the corner cell travels both hops); before the
-        readout the rows and planes come back in the opposite order;
-      * every transform needs TWO exchanges, as PFFT's does: "A" (y <-> kz) inside a row of Ny ranks between the z and
-        the y pass, "B" (x <-> ky) inside a column of Nx ranks between the y and the x pass.
-    The k-space half (softening, transfer, the fused x passes) is the slab code on a [x][ky_loc][kz_loc] block.
-    Requests: ("alltoall_g", recv, send, chunk_elems, axis) and ("shift_g", [(send, recv, direction, axis)]) with axis
-    "y" = my row, "x" = my column."""
+class _PencilRank(_SlabRank):
+    """The two exchanges and the two-hop halo of a pencil decomposition, shared by PencilForce, Pencil2LPT and
+    PencilTransforms.  Needs self.tmp_plane, self.row_s, self.row_r."""
 
-    def __init__(self, pm, group=None):
-        super().__init__(pm, group)
-        self.c = pm.alloc()
-        self.w = [pm.alloc() for _ in range(5)]
-        self.delta_k = None
+    def _alloc_halo_buffers(self, like):
+        pm = self.pm
         L = pm.layout
-        self.tmp_plane = torch.zeros(int(L.plane_elems), dtype=self.c.dtype, device=self.c.device)
+        self.tmp_plane = torch.zeros(int(L.plane_elems), dtype=like.dtype, device=like.device)
         nrow = int(L.isize[0]) * int(getattr(L, "istrides", (0, pm.Nmesh + 2))[1])
-        self.row_s = torch.zeros(nrow, dtype=self.c.dtype, device=self.c.device)
-        self.row_r = torch.zeros(nrow, dtype=self.c.dtype, device=self.c.device)
-        self.scalar = torch.zeros(1, dtype=torch.float64, device=self.c.device)
+        self.row_s = torch.zeros(nrow, dtype=like.dtype, device=like.device)
+        self.row_r = torch.zeros(nrow, dtype=like.dtype, device=like.device)
 
     def _a(self, recv, send):                     # exchange A: y <-> kz inside my row
         if self.pm.nranks_y > 1:
@@ -489,6 +477,45 @@ class PencilForce(_SlabRank):
             pm.yrow(mesh, ylr, self.row_r, 1)
         if pm.nranks_x > 1:
             yield ("shift_g", [(pm.plane(mesh, 0), pm.plane(mesh, xl), -1, "x")])
+
+    # pm_r2c / pm_c2r (pmpfft.c:370-399) on pencils: z | A | y | B | x and back; wa / wb: two scratch meshes
+    def _pencil_r2c(self, real, out_k, wa, wb):
+        pm = self.pm
+        pm.fft_z_forward(real, wa)
+        yield from self._a(wb, wa)
+        pm.fft_y_forward(wb, wa)
+        yield from self._b(out_k, wa)
+        pm.fft_x_forward(out_k)
+
+    def _pencil_c2r(self, buf, wa, wb):
+        """in place as pm_c2r: buf holds the k-space block on entry, the real mesh on return"""
+        pm = self.pm
+        pm.fft_x_backward(buf)
+        yield from self._b(wb, buf)
+        pm.fft_y_backward(wb, wa)
+        yield from self._a(wb, wa)
+        pm.fft_z_backward(wb, buf)
+
+
+class PencilForce(_PencilRank):
+    """fastpm_solver_compute_force (gravity.c:458-529) for rank (rank_x, rank_y) of an Nx x Ny process mesh -- the
+    reference's default decomposition (pmpfft.c:117-136: Nproc = {4, 2} for 8 ranks).  What differs from SlabForce:
+      * the particle ghosts become a mesh halo in x AND y (pmghosts.c:31-80 probes both): after the paint the extra x
+        plane goes to rank_x + 1 and then the extra y row to rank_y + 1 (the corner cell travels both hops); before the
+        readout the rows and planes come back in the opposite order;
+      * every transform needs TWO exchanges, as PFFT's does: "A" (y <-> kz) inside a row of Ny ranks between the z and
+        the y pass, "B" (x <-> ky) inside a column of Nx ranks between the y and the x pass.
+    The k-space half (softening, transfer, the fused x passes) is the slab code on a [x][ky_loc][kz_loc] block.
+    Requests: ("alltoall_g", recv, send, chunk_elems, axis) and ("shift_g", [(send, recv, direction, axis)]) with axis
+    "y" = my row, "x" = my column."""
+
+    def __init__(self, pm, group=None):
+        super().__init__(pm, group)
+        self.c = pm.alloc()
+        self.w = [pm.alloc() for _ in range(5)]
+        self.delta_k = None
+        self._alloc_halo_buffers(self.c)
+        self.scalar = torch.zeros(1, dtype=torch.float64, device=self.c.device)
 
     def steps(self, store, kernel="1_4", dealias="none", delta_k=None):
         pm = self.pm
@@ -615,6 +642,12 @@ class Slab2LPT(_SlabRank):
         yield ("alltoall", self.work, buf)
         pm.fft_yz_backward(self.work, buf)
 
+    def _r2c(self, real, out_k):
+        pm = self.pm
+        pm.fft_yz_forward(real, self.work)
+        yield ("alltoall", out_k, self.work)
+        pm.fft_x_forward(out_k)
+
     def _readout(self, mesh, store, column, memb):
         pm = self.pm
         xl = pm.layout.isize[0]
@@ -653,9 +686,7 @@ class Slab2LPT(_SlabRank):
             pm.diff(workspace, D2[d], difforder)
             yield from self._c2r(workspace)
             pm.mesh_fma(source, workspace, workspace, 1)
-        pm.fft_yz_forward(source, self.work)                                           # :122-123 pm_r2c
-        yield ("alltoall", workspace, self.work)
-        pm.fft_x_forward(workspace)
+        yield from self._r2c(source, workspace)                                        # :122-123 pm_r2c
         source.copy_(workspace)
         for d in range(3):                                                             # :125-141
             pm.laplace(source, workspace, potorder)
@@ -668,6 +699,48 @@ class Slab2LPT(_SlabRank):
 
     def solve(self, store, delta_k, kernel="1_4"):
         self.run(self.steps(store, delta_k, kernel))
+
+
+class Pencil2LPT(Slab2LPT, _PencilRank):
+    """pm_2lpt_solve (pm2lpt.c:14-164) on an Nx x Ny process mesh: Slab2LPT's sequence with every transform going
+    z | A | y | B | x (and back) and the two-hop halo before each readout."""
+
+    def __init__(self, pm, group=None):
+        _SlabRank.__init__(self, pm, group)
+        self.source, self.workspace = pm.alloc(), pm.alloc()
+        self.field = [pm.alloc() for _ in range(3)]
+        self.wa, self.wb = pm.alloc(), pm.alloc()
+        self._alloc_halo_buffers(self.source)
+
+    def _c2r(self, buf):
+        yield from self._pencil_c2r(buf, self.wa, self.wb)
+
+    def _r2c(self, real, out_k):
+        yield from self._pencil_r2c(real, out_k, self.wa, self.wb)
+
+    def _readout(self, mesh, store, column, memb):
+        yield from self._halo_in(mesh)
+        self.pm.readout(mesh, store, column, 3, memb)
+
+
+class PencilTransforms(_PencilRank):
+    """pm_r2c / pm_c2r (pmpfft.c:370-399) on pencils as stand-alone calls; r2c carries the 1 / Nmesh^3."""
+
+    def __init__(self, pm, group=None):
+        super().__init__(pm, group)
+        self.wa, self.wb = pm.alloc(), pm.alloc()
+
+    def r2c_steps(self, canvas, delta_k):
+        yield from self._pencil_r2c(canvas, delta_k, self.wa, self.wb)
+
+    def c2r_steps(self, buf):
+        yield from self._pencil_c2r(buf, self.wa, self.wb)
+
+    def r2c(self, canvas, delta_k):
+        self.run(self.r2c_steps(canvas, delta_k))
+
+    def c2r(self, buf):
+        self.run(self.c2r_steps(buf))
 
 
 class SlabDecompose:

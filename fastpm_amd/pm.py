@@ -185,7 +185,7 @@ def pm_2lpt_solve(pm, delta_k, p, shift=(0.0, 0.0, 0.0), kernel="1_4"):
     the device: fills p.dx1 and p.dx2 (float [np][3]) from the linear density delta_k (k-space mesh in
     the plan's layout).  12 c2r + 1 r2c on the same operators as the force step."""
     if pm.nranks != 1:
-        raise FastPMHipError("pm_2lpt_solve is the one-rank form; use fastpm_amd.distributed.Slab2LPT on slabs")
+        raise FastPMHipError("pm_2lpt_solve is the one-rank form; use fastpm_amd.distributed.Slab2LPT / Pencil2LPT")
     potorder, gradorder, difforder, _ = fastpm_kernel_type_get_orders(kernel)          # pm2lpt.c:17-18
     L = pm._L
     shift = (ctypes.c_double * 3)(*[float(v) for v in shift])

@@ -142,3 +142,114 @@ def test_pencil_decompose_matches_the_reference_order(oracle, Nx, Ny):
         pms[r].paint(pms[r].alloc(), stores[r], 1.0)           # every particle sits in its pencil: the paint accepts it
     for pm in pms:
         pm.destroy()
+
+
+@pytest.mark.parametrize("Nx,Ny", [(2, 2), (4, 2), (1, 4)])
+@pytest.mark.parametrize("precision", [64, 32])
+def test_initial_field_on_pencils_is_the_one_rank_field(Nx, Ny, precision):
+    """The gadget scheme's point (initialcondition.c:144-150) on an Nx x Ny process mesh: every rank fills, whitens
+    and colours its [x][ky_loc][kz_loc] block; the blocks tile the one-rank field bit for bit (the padded kz columns
+    of the last row rank stay zero)."""
+    from fastpm_amd import PM, fastpm_ic_fill_gaussiank, fastpm_ic_induce_correlation, fastpm_ic_remove_variance
+    from oracle import reference_run as R
+    N, L, seed = 32, 256.0, 100
+    power = R.PowerTable()
+
+    def field(pm, stage):
+        dk = pm.alloc()
+        fastpm_ic_fill_gaussiank(pm, dk, seed)
+        if stage >= 1:
+            fastpm_ic_remove_variance(pm, dk)
+        if stage >= 2:
+            fastpm_ic_induce_correlation(pm, dk, power.k, power.f)
+        return dk
+    one = PM(N, L, precision)
+    for stage in range(3):
+        whole = one.complex_view(field(one, stage)).cpu().numpy()
+        pms = [PM(N, L, precision, nranks=Nx * Ny, rank=r, nranks_y=Ny) for r in range(Nx * Ny)]
+        dks = [field(pm, stage) for pm in pms]
+        got = _assemble_dk(pms, dks, N, Nx, Ny)
+        assert np.array_equal(got.astype(whole.dtype), whole), stage
+        for pm, d in zip(pms, dks):
+            nv = int(pm.layout.ovalid_z)
+            osz = [int(v) for v in pm.layout.osize]
+            full = d.cpu().numpy()[:2 * int(pm.layout.complex_elems)].reshape(osz[0], osz[1], osz[2], 2)
+            assert np.all(full[:, :, nv:] == 0)                        # the padded kz columns stay zero
+            pm.destroy()
+    one.destroy()
+
+
+from test_gpu_2lpt import _linear_delta_k  # noqa: E402  (a smooth Hermitian delta(k) in the oracle's layout)
+
+
+@pytest.mark.parametrize("Nx,Ny,kernel", [(2, 2, "1_4"), (4, 2, "3_4"), (1, 2, "1_4_diff0")])
+def test_2lpt_on_virtual_pencils(oracle, Nx, Ny, kernel):
+    """distributed.Pencil2LPT: pm_2lpt_solve (pm2lpt.c:14-164) with its 12 c2r and 1 r2c going z | A | y | B | x and
+    the two-hop halo before each of the 6 readouts; the ranks of the process mesh together reproduce the one-rank
+    oracle's dx1 / dx2."""
+    import torch
+    from fastpm_amd import PM, Store
+    from fastpm_amd.distributed import Pencil2LPT, run_virtual_steps
+    N, nc, L = 32, 16, 48.0
+    P = Nx * Ny
+    pmo = oracle.PMOracle(N, L, 64)
+    dk = _linear_delta_k(pmo, 11)
+    q = util.lattice(nc, L)
+    ref1, ref2 = oracle.pm_2lpt_solve(pmo, dk, q, shift=(0.0, 0.0, 0.0), kernel=oracle.KERNELS[kernel])
+    own = _owner(q, N, L, Nx, Ny)
+    idx = [np.nonzero(own == r)[0] for r in range(P)]
+    dkx = util.oracle_k_to_xyk(pmo, dk)
+    pms = [PM(N, L, 64, nranks=P, rank=r, nranks_y=Ny) for r in range(P)]
+    dks = []
+    for pm in pms:
+        Lr = pm.layout
+        d = pm.alloc()
+        nv = int(Lr.ovalid_z)
+        blk = dkx[:, Lr.ostart[1]:Lr.ostart[1] + Lr.osize[1], Lr.ostart[2]:Lr.ostart[2] + nv]
+        pm.complex_view(d).copy_(torch.from_numpy(np.ascontiguousarray(blk)).cuda())
+        dks.append(d)
+    stores = [Store(q[idx[r]], v=np.zeros((len(idx[r]), 3), dtype=np.float32)) for r in range(P)]
+    ranks = [Pencil2LPT(pm) for pm in pms]
+    run_virtual_steps(ranks, [rk.steps(st, d, kernel) for rk, st, d in zip(ranks, stores, dks)])
+    torch.cuda.synchronize()
+    dx1, dx2 = np.zeros_like(ref1), np.zeros_like(ref2)
+    for r in range(P):
+        dx1[idx[r]] = stores[r].dx1.cpu().numpy()
+        dx2[idx[r]] = stores[r].dx2.cpu().numpy()
+    assert util.rel_err(dx1, ref1) <= 1e-6
+    assert util.rel_err(dx2, ref2) <= 1e-6
+    for pm in pms:
+        pm.destroy()
+
+
+@pytest.mark.parametrize("Nx,Ny", [(2, 2), (2, 4)])
+def test_pencil_r2c_c2r_stand_alone(oracle, Nx, Ny):
+    """pm_r2c / pm_c2r (pmpfft.c:370-399) on pencils as stand-alone calls: the spectrum equals rfftn / N^3, c2r
+    returns the real mesh."""
+    import torch
+    from fastpm_amd import PM
+    from fastpm_amd.distributed import PencilTransforms, run_virtual_steps
+    N, L = 32, 48.0
+    P = Nx * Ny
+    rng = np.random.default_rng(5)
+    real = rng.standard_normal((N, N, N))
+    want = np.fft.rfftn(real) / N ** 3
+    pms = [PM(N, L, 64, nranks=P, rank=r, nranks_y=Ny) for r in range(P)]
+    xl, yl = N // Nx, N // Ny
+    meshes, dks = [], []
+    for pm in pms:
+        m = pm.alloc()
+        rv = pm.real_view(m)
+        x0, y0 = pm.rank_x * xl, pm.rank_y * yl
+        rv[:xl, :yl, :N].copy_(torch.from_numpy(np.ascontiguousarray(real[x0:x0 + xl, y0:y0 + yl])).cuda())
+        meshes.append(m)
+        dks.append(pm.alloc())
+    ranks = [PencilTransforms(pm) for pm in pms]
+    run_virtual_steps(ranks, [rk.r2c_steps(m, d) for rk, m, d in zip(ranks, meshes, dks)])
+    assert util.max_err(_assemble_dk(pms, dks, N, Nx, Ny), want) <= 1e-14
+    run_virtual_steps(ranks, [rk.c2r_steps(d) for rk, d in zip(ranks, dks)])
+    for pm, d in zip(pms, dks):
+        x0, y0 = pm.rank_x * xl, pm.rank_y * yl
+        got = pm.real_view(d)[:xl, :yl, :N].cpu().numpy()
+        assert np.abs(got - real[x0:x0 + xl, y0:y0 + yl]).max() <= 1e-12
+        pm.destroy()
