@@ -266,6 +266,35 @@ static int zc2r_range(fpmhip_plan *p, void *buf, int x0, int nx)
     return fft_exec(p, plan, (char *) buf + (size_t) x0 * plane_bytes, nullptr);
 }
 
+// The strip path (fpm_strips.hip) does the z passes inside the particle kernels; what is left of the transforms:
+// zrows = paint_strips(..., r2c) output -> y pass in place -> forward x pass, transfer, backward x pass(es)
+int strips_y_xfwd_xback(fpmhip_plan *p, void *zrows_delta_k, int kernel, int mode, void *out0, void *out1, void *out2)
+{
+    int po, go, dfo, dc;
+    FPM_TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));
+    {
+        StageTimer tm(p, FPMHIP_T_R2C);
+        FPM_TRY(colfft_y_range(p, -1, zrows_delta_k, zrows_delta_k, 0, 0, p->mg.xl));
+    }
+    StageTimer tm(p, FPMHIP_T_XBACK3);
+    return colfft_xfwd_xback(p, zrows_delta_k, out0, mode == 1 ? out0 : out1, mode == 0 ? out2 : (mode == 1 ? out0 : out1),
+                             po, go, mode, 1.0 / p->lay.Norm);
+}
+
+// the y pass of pm_c2r alone (the z pass follows inside readout_strips_zc2r)
+int strips_y_backward(fpmhip_plan *p, void *buf)
+{
+    StageTimer tm(p, FPMHIP_T_C2R);
+    return colfft_y_range(p, +1, buf, buf, 0, 0, p->mg.xl);
+}
+
+// the potential's y pass with the y and z gradient factors (fpmhip_fft_yz_backward_grad2 without its z passes)
+int strips_y_backward_grad2(fpmhip_plan *p, void *recv, void *out_y, void *out_z, void *out_pot, int gradorder)
+{
+    StageTimer tm(p, FPMHIP_T_C2R);
+    return colfft_yback2(p, recv, out_y, out_z, out_pot, 0, gradorder);
+}
+
 static int check_range(const fpmhip_plan *p, int x0, int nx)
 {
     if (!p->own_fft || !rowfft_supported(p->mg.N)) FPM_FAIL(-1, "ranged stage calls need the column-FFT back end (see fpmhip_plan_ranged_fft)");

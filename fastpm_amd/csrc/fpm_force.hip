@@ -55,12 +55,27 @@ int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets
     struct Trust { fpmhip_plan *p; ~Trust() { p->bin_trusted = false; } } trust{p};
     p->bin_trusted = true;
     const double mean_mass_per_cell = total_mass / p->lay.Norm;                           // gravity.c:342
-    FPM_TRY(fpmhip_paint(p, pt, 1.0 / mean_mass_per_cell, canvas));                       // gravity.c:336-345
-    for (int si = 1; si < nsets; si++) FPM_TRY(fpmhip_paint_add(p, &sets[si], 1.0 / mean_mass_per_cell, canvas));
     // Without a softening kernel between them, the forward x pass runs straight on into the transfer and the
     // backward x pass(es) (fpmhip_r2c_transfer_fft_x_backward): delta_k is stored once and not read again.
     static const bool nofuse = getenv("FPMHIP_NOFUSE") != nullptr;                        // A/B
     const bool fuse_x = p->own_fft && softening == FPMHIP_SOFTENING_NONE && !nofuse;
+    // Strip tiles (fpm_strips.hip): the z passes happen inside the particle kernels.  Forwards when one species paints
+    // the canvas: the paint leaves half-spectrum rows in delta_k.  Backwards always: the readout takes the force
+    // meshes as their y passes leave them.
+    const bool strips = p->mg.strips != 0 && !real_grad;
+    const bool strips_fwd = strips && fuse_x && nsets == 1;
+    if (strips_fwd) {
+        if (sets[0].np > 0 && !sets[0].x) FPM_FAIL(-1, "particles without positions");
+        FPM_TRY(paint_strips(p, pt, 1.0 / mean_mass_per_cell, delta_k, 0, true));
+    } else {
+        FPM_TRY(fpmhip_paint(p, pt, 1.0 / mean_mass_per_cell, canvas));                   // gravity.c:336-345
+        for (int si = 1; si < nsets; si++) FPM_TRY(fpmhip_paint_add(p, &sets[si], 1.0 / mean_mass_per_cell, canvas));
+    }
+    // x passes around the transfer: from the canvas (z, y passes first) or from the paint's half-spectrum rows
+    auto fwd_x = [&](int mode, void *o0, void *o1, void *o2) -> int {
+        if (strips_fwd) return strips_y_xfwd_xback(p, delta_k, kernel, mode, o0, o1, o2);
+        return fpmhip_r2c_transfer_fft_x_backward(p, canvas, delta_k, kernel, mode, o0, o1, o2);
+    };
     if (!fuse_x) {
         FPM_TRY(fpmhip_r2c(p, canvas, delta_k));                                          // gravity.c:351
         FPM_TRY(fpmhip_softening(p, delta_k, softening));                                 // gravity.c:476
@@ -90,15 +105,25 @@ int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets
     if (p->own_fft && go == 1 && !three) {
         // one sweep over delta_k: the x component and the potential through their x passes; the y and
         // z gradient factors are applied to the potential in its y pass (they do not depend on kx)
-        if (fuse_x) FPM_TRY(fpmhip_r2c_transfer_fft_x_backward(p, canvas, delta_k, kernel, 2, f[0], f[1], nullptr));
+        if (fuse_x) FPM_TRY(fwd_x(2, f[0], f[1], nullptr));
         else FPM_TRY(fpmhip_transfer_fft_x_backward_potx(p, delta_k, f[0], f[1], kernel));
-        FPM_TRY(fpmhip_fft_yz_backward(p, f[0], f[0]));
         // the potential column (gravity.c:487-492) rides along: its (y, z) passes from the same read
         void *potmesh = nullptr;
         if (any_pot) {
             FPM_TRY(ensure_buffer(p, BUF_F0));
             potmesh = p->buf[BUF_F0];
         }
+        if (strips) {
+            FPM_TRY(strips_y_backward(p, f[0]));
+            FPM_TRY(strips_y_backward_grad2(p, f[1], f[1], f[2], potmesh, go));
+            for (int si = nsets - 1; si >= 0; si--)
+                FPM_TRY(readout_strips_zc2r(p, &sets[si], f[0], f[1], f[2], 3, sets[si].acc, 3, 0));
+            for (int si = 0; si < nsets; si++)
+                if (sets[si].potential)
+                    FPM_TRY(readout_strips_zc2r(p, &sets[si], potmesh, nullptr, nullptr, 1, sets[si].potential, 1, 0));
+            return 0;
+        }
+        FPM_TRY(fpmhip_fft_yz_backward(p, f[0], f[0]));
         FPM_TRY(fpmhip_fft_yz_backward_grad2(p, f[1], f[1], f[2], potmesh, kernel));
         if (any_pot) {
             for (int si = nsets - 1; si >= 0; si--) FPM_TRY(fpmhip_readout3(p, &sets[si], f[0], f[1], f[2]));
@@ -108,9 +133,15 @@ int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets
         }
     } else if (p->own_fft) {
         // one sweep over delta_k: the three transfers + the x pass of their inverse transforms
-        if (fuse_x) FPM_TRY(fpmhip_r2c_transfer_fft_x_backward(p, canvas, delta_k, kernel, 0, f[0], f[1], f[2]));
+        if (fuse_x) FPM_TRY(fwd_x(0, f[0], f[1], f[2]));
         else FPM_TRY(fpmhip_transfer_fft_x_backward3(p, delta_k, f[0], f[1], f[2], kernel));
-        for (int d = 0; d < 3; d++) FPM_TRY(fpmhip_fft_yz_backward(p, f[d], f[d]));
+        if (strips) {
+            for (int d = 0; d < 3; d++) FPM_TRY(strips_y_backward(p, f[d]));
+            for (int si = nsets - 1; si >= 0; si--)
+                FPM_TRY(readout_strips_zc2r(p, &sets[si], f[0], f[1], f[2], 3, sets[si].acc, 3, 0));
+        } else {
+            for (int d = 0; d < 3; d++) FPM_TRY(fpmhip_fft_yz_backward(p, f[d], f[d]));
+        }
     } else {
         for (int d = 0; d < 3; d++) {                                                     // gravity.c:373-397
             FPM_TRY(fpmhip_transfer(p, delta_k, f[d], kernel, d));
@@ -118,7 +149,8 @@ int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets
         }
     }
     // with several species the last paint's binning belongs to the last one: read that one first
-    for (int si = nsets - 1; si >= 0; si--) FPM_TRY(fpmhip_readout3(p, &sets[si], f[0], f[1], f[2]));
+    if (!strips)
+        for (int si = nsets - 1; si >= 0; si--) FPM_TRY(fpmhip_readout3(p, &sets[si], f[0], f[1], f[2]));
     if (any_pot) {                                                                        // gravity.c:487-492
         FPM_TRY(fpmhip_transfer(p, delta_k, canvas, kernel, FPMHIP_FIELD_POTENTIAL));
         FPM_TRY(fpmhip_c2r(p, canvas));

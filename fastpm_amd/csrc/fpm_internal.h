@@ -52,6 +52,8 @@ constexpr int TILE_X = 8;
 constexpr int TILE_Y = 8;
 constexpr int TILE_Z = 32;
 constexpr int TILE_CELLS = TILE_X * TILE_Y * TILE_Z;
+// Strip tiles (fpm_strips.hip): one x plane x STRIP_Y rows x all of z.
+constexpr int STRIP_Y = 4;
 // The counting sort keeps BIN_PRIV private copies of every tile counter / cursor, picked by workgroup id: a dense
 // clump puts thousands of particles into a few tiles and their atomics serialise per ADDRESS at the memory side.
 constexpr int BIN_PRIV = 8;
@@ -79,6 +81,7 @@ struct MeshGeo {
     int rp;            // the same in complex units: the pitch the z passes read / write real rows with
     double inv_cell;   // 1.0 / (BoxSize / N), pmpfft.c:150-151
     int ntx, nty, ntz; // tile grid over [xplanes][N][N]
+    int strips;        // 0: box tiles TILE_X x TILE_Y x TILE_Z; STRIP_Y: strip tiles (ntx = xl, nty = N / STRIP_Y, ntz = 1)
 };
 
 // device staging of host-resident store columns (fpmhip_force_host / fpmhip_force_species_host)
@@ -197,7 +200,18 @@ int ensure_bins(fpmhip_plan *p, int64_t np, int64_t ndup, bool has_mass);
 int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt);
 int check_deferred(fpmhip_plan *p, bool wait);   // errors a binning reported after its call returned
 
+int reuse_binning(fpmhip_plan *p, const fpmhip_particles *pt);
+
+// fpm_strips.hip
+bool strips_supported(int N, int precision);
+int paint_strips(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void *out, int accumulate, bool r2c);
+int readout_strips_zc2r(fpmhip_plan *p, const fpmhip_particles *pt, const void *k0, const void *k1, const void *k2, int ncomp,
+                        float *out, int nmemb, int memb0);
+
 // fpm_fft.hip
+int strips_y_xfwd_xback(fpmhip_plan *p, void *zrows_delta_k, int kernel, int mode, void *out0, void *out1, void *out2);
+int strips_y_backward(fpmhip_plan *p, void *buf);
+int strips_y_backward_grad2(fpmhip_plan *p, void *recv, void *out_y, void *out_z, void *out_pot, int gradorder);
 int fft_setup(fpmhip_plan *p);
 void fft_teardown(fpmhip_plan *p);
 

@@ -15,62 +15,9 @@
 #include <cstring>
 #include <rocprim/device/device_scan.hpp>
 
-#include "fpm_internal.h"
+#include "fpm_cic.h"
 
 namespace fpm {
-
-// ------------------------------------------------------------------------------------------
-// CIC index / weight arithmetic, shared by paint and readout.  Follows painter-cic.c:45-76:
-// X = pos * InvCellSize; I = (int) floor(X); D = X - I (before the wrap); T = 1 - D; then the
-// periodic wrap of I and I+1, then the shift to rank-local x.  All in double, no contraction.
-// ------------------------------------------------------------------------------------------
-struct Cic {
-    int i0[3];   // base cell, local in x
-    int i1[3];   // base + 1 (wrapped / halo plane)
-    double d[3], t[3];
-};
-
-__device__ __forceinline__ int wrap_cell(int i, int n)
-{
-    while (i < 0) i += n;
-    while (i >= n) i -= n;
-    return i;
-}
-
-// Returns false if the particle's base x plane is not owned by this rank.
-__device__ __forceinline__ bool cic_setup(const MeshGeo &g, double px, double py, double pz, Cic &c)
-{
-    const double pos[3] = {px, py, pz};
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        double X = pos[a] * g.inv_cell;
-        int I = (int) floor(X);
-        c.d[a] = X - I;
-        c.t[a] = 1. - c.d[a];
-        c.i0[a] = wrap_cell(I, g.N);
-        c.i1[a] = wrap_cell(I + 1, g.N);
-    }
-    bool mine = true;
-    if (!g.periodic_x) {
-        // slab: the particle's base plane is owned by this rank (the caller's decomposition
-        // guarantees it, solver.c:449); plane xl is the halo plane owned by the next rank in x.
-        c.i0[0] -= g.xstart;
-        c.i1[0] = c.i0[0] + 1;
-        mine = c.i0[0] >= 0 && c.i0[0] < g.xl;
-    }
-    if (!g.periodic_y) {
-        // pencil: the same in y (pm_pos_to_rank, pmpfft.c:344-368); row ylr is the halo row
-        c.i0[1] -= g.yrstart;
-        c.i1[1] = c.i0[1] + 1;
-        mine = mine && c.i0[1] >= 0 && c.i0[1] < g.ylr;
-    }
-    return mine;
-}
-
-__device__ __forceinline__ int tile_id(const MeshGeo &g, int tx, int ty, int tz)
-{
-    return (tx * g.nty + ty) * g.ntz + tz;
-}
 
 // Wavefront-aggregated atomic increment: lanes of the wave that target the same counter are
 // merged into one atomicAdd by the first of them.  Returns each lane's slot when RET.
@@ -296,8 +243,7 @@ __global__ __launch_bounds__(256) void bin_kernel(MeshGeo g, int ntiles, const d
                 if (SCATTER) atomicAdd(&flags[FULL ? FLAG_UNOWNED_FULL : FLAG_UNOWNED_FAST], 1);
                 active[u] = false;
             }
-            t0[0] = c.i0[0] / TILE_X; t0[1] = c.i0[1] / TILE_Y; t0[2] = c.i0[2] / TILE_Z;
-            t1[0] = c.i1[0] / TILE_X; t1[1] = c.i1[1] / TILE_Y; t1[2] = c.i1[2] / TILE_Z;
+            tile_coords(g, c, t0, t1);
         }
         // class 0: the own tile; classes 1..7: the up to 7 other tiles the cloud touches
 #pragma unroll
@@ -424,8 +370,8 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(MeshGeo g, int ntiles,
                     atomicAdd(&flags[FULL ? FLAG_UNOWNED_FULL : FLAG_UNOWNED_FAST], 1);
                     active[u] = false;
                 } else {
-                    const int t0[3] = {c.i0[0] / TILE_X, c.i0[1] / TILE_Y, c.i0[2] / TILE_Z};
-                    const int t1[3] = {c.i1[0] / TILE_X, c.i1[1] / TILE_Y, c.i1[2] / TILE_Z};
+                    int t0[3], t1[3];
+                    tile_coords(g, c, t0, t1);
                     own_key[u] = tile_id(g, t0[0], t0[1], t0[2]);
                     const int dx = t1[0] != t0[0], dy = t1[1] != t0[1], dz = t1[2] != t0[2];
 #pragma unroll
@@ -487,8 +433,9 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(MeshGeo g, int ntiles,
                 Cic c;
                 (void) cic_setup(g, L.x[pid], L.y[pid], L.z[pid], c);
                 const int bx = (cl >> 2) & 1, by = (cl >> 1) & 1, bz = cl & 1;
-                key = ntiles + tile_id(g, (bx ? c.i1[0] : c.i0[0]) / TILE_X, (by ? c.i1[1] : c.i0[1]) / TILE_Y,
-                                       (bz ? c.i1[2] : c.i0[2]) / TILE_Z);
+                int t0[3], t1[3];
+                tile_coords(g, c, t0, t1);
+                key = ntiles + tile_id(g, bx ? t1[0] : t0[0], by ? t1[1] : t0[1], bz ? t1[2] : t0[2]);
             }
             if (__ballot(act) == 0) continue;
             const AggSlot2 a = block_agg_issue<true>(L.agg, cnt, key, act);
@@ -587,16 +534,6 @@ __global__ __launch_bounds__(256) void verify_binning_kernel(int ntiles, const i
     const int e = beg[t] + t % n;
     const long long i = sidx[e];
     if (sx[e] != x[3 * i] || sy[e] != x[3 * i + 1] || sz[e] != x[3 * i + 2]) flags[FLAG_STALE] = 1;
-}
-
-// XCD-aware block -> tile map: consecutive tiles (which share mesh rows in the readout) go to
-// the same XCD / L2.  Workgroup b is dispatched to XCD b % 8 (MI355X_MICROARCH.md); bijective
-// for any ntiles.
-__device__ __forceinline__ int xcd_remap(int b, int n)
-{
-    const int q = n / 8, r = n % 8;
-    const int xcd = b % 8, j = b / 8;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
 // One workgroup = one tile.  LDS tile of F accumulators; entries of the tile (own, then dup)
@@ -1328,7 +1265,7 @@ int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt)
 // A readout that finds the plan's binning made for the same (x, np) reuses it -- and checks, on the device, that the
 // positions behind the pointer are still the ones that were binned (one entry per tile, bit for bit).  A mismatch is a
 // broken contract (positions modified in place without fpmhip_invalidate_binning); it is reported when the flag arrives.
-static int reuse_binning(fpmhip_plan *p, const fpmhip_particles *pt)
+int reuse_binning(fpmhip_plan *p, const fpmhip_particles *pt)
 {
     FPM_TRY(check_deferred(p, true));
     const int nt = p->ntiles;
@@ -1353,6 +1290,7 @@ static int paint_impl(fpmhip_plan *p, const fpmhip_particles *pt, double scale, 
         FPM_CHECK_HIP(hipGetLastError());
         return 0;
     }
+    if (p->mg.strips) return paint_strips(p, pt, scale, canvas, accumulate, false);
     FPM_TRY(bin_particles(p, pt));
     StageTimer tm(p, FPMHIP_T_PAINT);
     paint_tiles_kernel<F><<<p->ntiles, 256, 0, p->stream>>>(p->mg, p->ntiles, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz,
@@ -1389,7 +1327,9 @@ static int readout_impl(fpmhip_plan *p, const fpmhip_particles *pt, const F *m0,
     // second launch's idle workgroups cost A 0.06 ms.  On fp32 meshes three regions are 32 KB, five workgroups fit a
     // CU as it is, and kernel 1 stays ahead (0.55 vs 0.63 ms).
     static int lds_env = getenv("FPMHIP_READOUT") ? atoi(getenv("FPMHIP_READOUT")) : -1;
-    const int lds_mode = lds_env >= 0 ? lds_env : (sizeof(F) == 8 ? 2 : 1);
+    // (strip tiles: real meshes are read by the flat kernel below; the force step reads its meshes BEFORE their z pass
+    // with readout_strips_zc2r instead)
+    const int lds_mode = p->mg.strips ? 0 : (lds_env >= 0 ? lds_env : (sizeof(F) == 8 ? 2 : 1));
     if (NC == 3 && nmemb == 3 && memb0 == 0 && lds_mode == 2) {
         const size_t lds = (size_t) (TILE_X + 1) * (TILE_Y + 1) * (TILE_Z + 1) * sizeof(F);
         readout1of3_tiles_kernel<F><<<3 * p->ntiles, 256, lds, p->stream>>>(p->mg, p->ntiles, p->bin_beg[0], p->bin_cnt, p->sx,
@@ -1435,7 +1375,7 @@ static int readout_grad_impl(fpmhip_plan *p, const fpmhip_particles *pt, const F
     // measured on configs[1] (loads A / B / C): LDS-staged 0.83 / 0.93 / 1.53 ms, direct gather of the
     // binned entries 1.58 / 1.85 / 2.91 ms.  FPMHIP_READOUT_GRAD=1 selects the direct kernel (A/B).
     static int lds_mode = getenv("FPMHIP_READOUT_GRAD") ? atoi(getenv("FPMHIP_READOUT_GRAD")) != 1 : 1;
-    if (lds_mode) {
+    if (lds_mode && !p->mg.strips) {
         const size_t lds = (size_t) (TILE_X + 5) * (TILE_Y + 5) * (TILE_Z + 5) * sizeof(F);
         static bool granted = false;
         if (!granted) {

@@ -259,6 +259,20 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
     g.ntx = (g.xplanes + TILE_X - 1) / TILE_X;
     g.nty = (g.yplanes + TILE_Y - 1) / TILE_Y;
     g.ntz = ((int) N + TILE_Z - 1) / TILE_Z;
+    // Strip tiles + the kernels that march over them (fpm_strips.hip: the paint runs on into the z r2c pass, the
+    // z c2r pass into the readout) where they exist: one rank, the hand-written passes, the k-space gradient
+    g.strips = 0;
+    {
+        static const bool env_off = getenv("FPMHIP_STRIPS") && atoi(getenv("FPMHIP_STRIPS")) == 0;      // A/B
+        const bool can = P == 1 && geom->fft_mode == FPMHIP_FFT_AUTO && colfft_supported((int) N) &&
+                         strips_supported((int) N, geom->precision) && geom->gradient_mode == FPMHIP_GRADIENT_KSPACE;
+        if (geom->paint_mode == FPMHIP_PAINT_STRIPS && !can)
+            FPM_FAIL(-1, "FPMHIP_PAINT_STRIPS: one rank, the k-space gradient and a mesh whose z rows fit the strip kernels");
+        if (can && (geom->paint_mode == FPMHIP_PAINT_STRIPS || (geom->paint_mode == FPMHIP_PAINT_TILED && N >= 128 && !env_off))) {
+            g.strips = STRIP_Y;
+            g.ntx = g.xl; g.nty = (int) N / STRIP_Y; g.ntz = 1;
+        }
+    }
     p->ntiles = g.ntx * g.nty * g.ntz;
 
     build_k_tables(N, geom->BoxSize, p->h_tab);

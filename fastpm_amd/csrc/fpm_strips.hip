@@ -1,0 +1,416 @@
+// fpm_strips.hip -- the particle <-> mesh kernels on STRIP tiles (one rank): the CIC paint that runs on into the z
+// pass of pm_r2c, and the z pass of pm_c2r that runs on into the CIC readout.
+//
+// Why.  With box tiles the force step moves 23 mesh sweeps through HBM: the real canvas is written by the
+// paint and read back by the z r2c pass; each force component is written by its z c2r pass and read back (1.13 x, tile
+// halos) by the readout.  Those five meshes only ever exist to be re-read by the neighbouring kernel.  A z row is too
+// long for the 8 x 8-column box tiles (81 rows of N values per tile), so the tiles change shape: a STRIP is one x
+// plane x STRIP_Y = 4 rows x all of z.  A workgroup owns the strip column (4 rows) of a segment of x planes and MARCHES
+// along x with a two-plane window in LDS:
+//   paint:   the entries of (plane i, strip) add their corners into planes i and i + 1 of the window (LDS atomics);
+//            plane i is then complete (plane i - 1's particles added theirs one step earlier): its 4 rows are
+//            transformed in LDS (the r2c of fpm_rowfft.hip) and leave as half-spectrum rows, or leave as real rows
+//            (paint_add, several species).  Entries are listed again only in y (row 3 of a strip touches the next
+//            strip): 1.25 entries per particle.
+//   readout: per step the 5 half-spectrum rows (4 + the next strip's first) of plane i + 1 -- prefetched into
+//            registers during the previous step's gather -- are inverse-transformed into the window; the particles of
+//            (plane i, strip) gather their 8 corners from planes i, i + 1.  One workgroup per (segment, strip,
+//            component); 5 / 4 of one mesh read per component instead of 1 read + 1 write + 1.13 read.
+// Measured at 512^3 fp64 (tools/ubench/zfused_readout.hip, then in place): z c2r x 3 + readout 2.15 ms -> 1.67 ms.
+//
+// Reference arithmetic: painter-cic.c:34-110 (paint), :113-190 (readout), pmpfft.c:370-399 (the z legs of r2c / c2r);
+// the sums are the same sums in another order (the tolerance class of the box-tile kernels).
+#include <cstdlib>
+
+#include "fpm_cic.h"
+#include "fpm_fftcore.h"
+
+namespace fpm {
+
+constexpr int STRIP_RW = STRIP_Y + 1;         // rows per window plane of the readout: the strip + the y halo row
+constexpr int STRIP_XSEG = 32;                // x planes per workgroup (one redundant plane of work per segment)
+
+// the paint keeps HALF a twiddle table (W^(j + M/2) = -W^j): 38.9 KB of LDS at M = 256 in fp64, four workgroups per CU
+template <typename PL> struct HalfTw : PL {
+    static constexpr bool TWH = true;
+    static constexpr int TWN = PL::N / 2;
+};
+
+template <typename PL, typename F> struct StripCfg {
+    static constexpr int M = PL::N, T = PL::T;
+    static constexpr size_t twb = (size_t) (PL::TWN + M) * sizeof(C2<F>);
+    // readout: two planes of STRIP_RW rows of M + 1 complex values
+    static constexpr int ro_threads = T * STRIP_RW;
+    static constexpr size_t ro_lds = twb + (size_t) 2 * (M + 1) * STRIP_RW * sizeof(C2<F>);
+    // paint: two planes of STRIP_Y rows of 2 M + 2 double accumulators
+    static constexpr int pt_threads = T * STRIP_Y;
+    static constexpr size_t pt_twb = (size_t) (M / 2 + M) * sizeof(C2<F>);
+    static constexpr size_t pt_lds = pt_twb + (size_t) 2 * STRIP_Y * (2 * M + 2) * sizeof(double);
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// paint
+// ------------------------------------------------------------------------------------------------------------------
+template <typename PL, typename F, bool R2C>
+__global__ __launch_bounds__((StripCfg<PL, F>::pt_threads)) void paint_strips_kernel(
+    MeshGeo g, int ntiles, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
+    const double *__restrict__ sy, const double *__restrict__ sz, const float *__restrict__ smass, double M0, double scale,
+    void *__restrict__ out_, int accumulate, const double *__restrict__ tw_global)
+{
+    using CF = StripCfg<PL, F>;
+    constexpr int M = PL::N, N = 2 * M, T = PL::T, E = PL::E, NT = CF::pt_threads, WP = N + 2, SLOT = STRIP_Y * WP;
+    extern __shared__ __align__(16) unsigned char smem_st[];
+    using PH = HalfTw<PL>;
+    C2<F> *tw = (C2<F> *) smem_st;
+    C2<F> *twn = tw + PH::TWN;
+    double *win = (double *) (smem_st + CF::pt_twb);          // [2][STRIP_Y][WP]
+    const int tid = threadIdx.x;
+    const int nseg = (g.xl + STRIP_XSEG - 1) / STRIP_XSEG;
+    const int t = xcd_remap(blockIdx.x, g.nty * nseg);
+    const int strip = t % g.nty, seg = t / g.nty;
+    const int xa = seg * STRIP_XSEG, xb = min(xa + STRIP_XSEG, g.xl);
+    const int y0 = strip * STRIP_Y;
+
+    for (int i = tid; i < 2 * SLOT; i += NT) win[i] = 0;
+    if (R2C) {
+        stage_twiddles(tw, tw_global, PH::TWN, 2);
+        stage_twiddles(twn, tw_global, M, 1);
+    }
+    __syncthreads();
+    double *A = win, *B = win + SLOT;
+
+    // One entry adds its corners inside the strip's rows to plane xi (-> pa) and plane xi + 1 (-> pb); a null plane is
+    // skipped.
+    auto add_one = [&](double qx, double qy, double qz, float qm, double *pa, double *pb) {
+        Cic c;
+        (void) cic_setup(g, qx, qy, qz, c);
+        double w = smass ? (M0 + qm) : M0;              // store.c:119-128
+        c.d[1] *= w;                                    // painter-cic.c:78-79
+        c.t[1] *= w;
+        const int ly[2] = {c.i0[1] - y0, c.i1[1] - y0};
+        const int lz[2] = {c.i0[2], c.i1[2]};
+        const double wx[2] = {c.t[0], c.d[0]}, wy[2] = {c.t[1], c.d[1]}, wz[2] = {c.t[2], c.d[2]};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int bx = (k >> 2) & 1, by = (k >> 1) & 1, bz = k & 1;
+            double *pl = bx ? pb : pa;
+            if (pl && (unsigned) ly[by] < (unsigned) STRIP_Y) {
+                const double f = wz[bz] * wx[bx] * wy[by];          // painter-cic.c:84-107: Wz*Wx*Wy
+                atomicAdd(&pl[ly[by] * WP + lz[bz]], f);
+            }
+        }
+    };
+    // The entries (own, then dup) of (plane xi, strip).  The first PF_OWN / PF_DUP entries per thread of each list are
+    // requested one step ahead (prefetch()) and wait in registers while the previous plane is transformed and stored:
+    // without that every step began with a dependent chain of global loads (0.67 -> ms below for paint + z pass).
+    constexpr int PF_OWN = 2, PF_DUP = 1, PF = PF_OWN + PF_DUP;
+    double fx[PF], fy[PF], fz[PF];
+    float fm[PF];
+    int fbeg[2] = {0, 0}, fcnt[2] = {0, 0};
+    auto prefetch = [&](int xi) {
+#pragma unroll
+        for (int part = 0; part < 2; part++) {
+            const int key = part * ntiles + xi * g.nty + strip;
+            fbeg[part] = tbeg[key];
+            fcnt[part] = tcnt[key];
+        }
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int part = u < PF_OWN ? 0 : 1, r = u < PF_OWN ? u : u - PF_OWN;
+            const int e = tid + r * NT;
+            fx[u] = fy[u] = fz[u] = 0;
+            fm[u] = 0;
+            if (e < fcnt[part]) {
+                const int s_ = fbeg[part] + e;
+                fx[u] = sx[s_]; fy[u] = sy[s_]; fz[u] = sz[s_];
+                if (smass) fm[u] = smass[s_];
+            }
+        }
+    };
+    auto add_prefetched = [&](double *pa, double *pb) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int part = u < PF_OWN ? 0 : 1, r = u < PF_OWN ? u : u - PF_OWN;
+            if (tid + r * NT < fcnt[part]) add_one(fx[u], fy[u], fz[u], fm[u], pa, pb);
+        }
+#pragma unroll
+        for (int part = 0; part < 2; part++)
+            for (int e = tid + (part == 0 ? PF_OWN : PF_DUP) * NT; e < fcnt[part]; e += NT) {
+                const int s_ = fbeg[part] + e;
+                add_one(sx[s_], sy[s_], sz[s_], smass ? smass[s_] : 0.f, pa, pb);
+            }
+    };
+
+    // what the particles of the plane before the segment add to its first plane
+    if (g.periodic_x || xa > 0) {
+        prefetch(xa > 0 ? xa - 1 : g.N - 1);
+        add_prefetched(nullptr, A);
+    }
+    prefetch(xa);
+    for (int i = xa; i < xb; i++) {
+        add_prefetched(A, B);
+        __syncthreads();
+        if (i + 1 < xb) prefetch(i + 1);                  // lands while plane i is transformed and stored
+        if (!R2C) {
+            F *canvas = (F *) out_;
+            for (int idx = tid; idx < STRIP_Y * N; idx += NT) {
+                const int ly = idx / N, z = idx - ly * N;
+                F *row = canvas + (long long) i * g.str0 + (long long) (y0 + ly) * g.str1;
+                const F mine = (F) (A[ly * WP + z] * scale);
+                row[z] = accumulate ? (F) (row[z] + mine) : mine;           // further species add (gravity.c:326-338)
+            }
+            if (!accumulate) {                                               // pm_clear'ed row padding
+                const int npad = (int) g.str1 - N;
+                for (int idx = tid; idx < STRIP_Y * npad; idx += NT) {
+                    const int ly = idx / npad, z = idx - ly * npad;
+                    canvas[(long long) i * g.str0 + (long long) (y0 + ly) * g.str1 + N + z] = 0;
+                }
+            }
+            __syncthreads();
+        } else {
+            // the z pass of pm_r2c on the finished rows (rowfft_r2c_kernel's arithmetic): row c, elements tau + T j
+            const int c = tid % STRIP_Y, tau = tid / STRIP_Y;
+            C2<F> v[vmax(E)];
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                const int n = tau + T * j;
+                v[in_slot<PL>(j)] = C2<F>{(F) (A[c * WP + 2 * n] * scale), (F) (A[c * WP + 2 * n + 1] * scale)};
+            }
+            __syncthreads();                                    // plane A is in registers: its LDS is the FFT's now
+            C2<F> *lds = (C2<F> *) A;
+            fft_core<PH, -1, STRIP_Y, false>(v, lds, tw, tau, c);
+#pragma unroll
+            for (int j = 0; j < E; j++) lds[(tau + T * j) * STRIP_Y + c] = v[j];
+            __syncthreads();
+            C2<F> *dst = (C2<F> *) out_ + ((long long) i * g.N + y0 + c) * g.rp;
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                const int k = tau + T * j;
+                const C2<F> a = v[j];
+                C2<F> bq = lds[((M - k) % M) * STRIP_Y + c];
+                bq.y = -bq.y;                                          // conj Z[M-k]
+                const C2<F> e = {(a.x + bq.x) * (F) 0.5, (a.y + bq.y) * (F) 0.5};
+                const C2<F> d = {(a.x - bq.x) * (F) 0.5, (a.y - bq.y) * (F) 0.5};
+                const C2<F> o = {d.y, -d.x};                           // d / i
+                st_stream(&dst[k], cadd(e, cmul(twn[k], o)));
+                if (k == 0) dst[M] = C2<F>{a.x - a.y, 0};              // X[N/2] = Re Z0 - Im Z0
+            }
+            for (int k = M + 1 + tau; k < g.rp; k += T) dst[k] = C2<F>{0, 0};      // the padding of an aligned row
+            __syncthreads();
+        }
+        for (int idx = tid; idx < SLOT; idx += NT) A[idx] = 0;
+        __syncthreads();
+        double *tmp = A; A = B; B = tmp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// readout
+// ------------------------------------------------------------------------------------------------------------------
+template <typename PL, typename F>
+__global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_kernel(
+    MeshGeo g, int ncomp, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
+    const double *__restrict__ sy, const double *__restrict__ sz, const int *__restrict__ sidx, const C2<F> *__restrict__ m0,
+    const C2<F> *__restrict__ m1, const C2<F> *__restrict__ m2, float *__restrict__ out, int nmemb, int memb0,
+    const double *__restrict__ tw_global)
+{
+    using CF = StripCfg<PL, F>;
+    constexpr int M = PL::N, RW = STRIP_RW, T = PL::T, E = PL::E, NT = CF::ro_threads, SLOT = (M + 1) * RW, WP = 2 * (M + 1);
+    extern __shared__ __align__(16) unsigned char smem_st[];
+    C2<F> *tw = (C2<F> *) smem_st;
+    C2<F> *twn = tw + PL::TWN;
+    C2<F> *win = twn + M;                          // [2][SLOT]
+    const int c = threadIdx.x % RW, tau = threadIdx.x / RW;
+    const int nseg = (g.xl + STRIP_XSEG - 1) / STRIP_XSEG;
+    // the ncomp workgroups of a (segment, strip) are neighbours (they read the same positions), then the strips
+    const int t = xcd_remap(blockIdx.x, ncomp * g.nty * nseg);
+    const int comp = t % ncomp, strip = (t / ncomp) % g.nty, seg = t / (ncomp * g.nty);
+    const C2<F> *mesh = comp == 0 ? m0 : (comp == 1 ? m1 : m2);
+    const int xa = seg * STRIP_XSEG, xb = min(xa + STRIP_XSEG, g.xl);
+    const int y0 = strip * STRIP_Y;
+    int gy = y0 + c;
+    gy -= gy >= g.N ? g.N : 0;
+    const C2<F> *rowbase = mesh + (long long) gy * g.rp;
+
+    C2<F> x[E], xm;
+    auto load_plane = [&](int xp) {
+        xp -= xp >= g.N ? g.N : 0;
+        const C2<F> *src = rowbase + (long long) xp * g.N * g.rp;
+#pragma unroll
+        for (int j = 0; j < E; j++) x[j] = ld_stream(&src[tau + T * j]);
+        xm = tau == 0 ? src[M] : C2<F>{0, 0};
+    };
+    // x[] (the half spectrum of RW rows) -> real rows in `slot`, row-major with a pitch of 2 M + 2 values
+    // (rowfft_c2r_kernel's arithmetic)
+    auto c2r_to = [&](C2<F> *slot) {
+        if (tau == 0) { x[0].y = 0; xm.y = 0; }     // a c2r reads only the real parts of X[0] and X[N/2]
+#pragma unroll
+        for (int j = 0; j < E; j++) slot[(tau + T * j) * RW + c] = x[j];
+        if (tau == 0) slot[M * RW + c] = xm;
+        __syncthreads();
+        C2<F> v[vmax(E)];
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const int k = tau + T * j;
+            const C2<F> a = x[j];
+            C2<F> bq = slot[(M - k) * RW + c];                    // X[M-k]  (k = 0 pairs with X[M])
+            bq.y = -bq.y;
+            const C2<F> s = cadd(a, bq), d = csub(a, bq);
+            const C2<F> w = {twn[k].x, -twn[k].y};                 // conj W_N^k
+            const C2<F> o = cmul(w, d);
+            v[in_slot<PL>(j)] = C2<F>{s.x - o.y, s.y + o.x};       // s + i o
+        }
+        __syncthreads();                                           // everyone has read its partner
+        fft_core<PL, +1, RW, false>(v, slot, tw, tau, c);
+#pragma unroll
+        for (int j = 0; j < E; j++) slot[c * (M + 1) + tau + T * j] = v[j];
+        if (tau == 0) slot[c * (M + 1) + M].x = v[0].x;            // value N of a row = value 0: the z + 1 corner needs no wrap
+    };
+
+    load_plane(xa);
+    stage_twiddles(tw, tw_global, PL::TWN, 2);
+    stage_twiddles(twn, tw_global, M, 1);
+    __syncthreads();
+    C2<F> *A = win, *B = win + SLOT;
+    c2r_to(A);
+    load_plane(xa + 1);
+    for (int i = xa; i < xb; i++) {
+        // this step's particles: their positions are requested before the transform and used after it
+        const int key = i * g.nty + strip;
+        const int b = tbeg[key], n = tcnt[key];
+        double px[2], py[2], pz[2];
+        int prow[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int e = threadIdx.x + u * NT;
+            px[u] = py[u] = pz[u] = 0;
+            prow[u] = 0;
+            if (e < n) { px[u] = sx[b + e]; py[u] = sy[b + e]; pz[u] = sz[b + e]; prow[u] = sidx[b + e]; }
+        }
+        c2r_to(B);
+        __syncthreads();
+        if (i + 1 < xb) load_plane(i + 2);                         // lands during the gather
+        const F *ra = (const F *) A, *rb = (const F *) B;
+        auto gather = [&](double qx, double qy, double qz, int row) {
+            Cic cc;
+            (void) cic_setup(g, qx, qy, qz, cc);
+            const int ly = cc.i0[1] - y0;                          // the + 1 row is the next row of the window
+            const int lz[2] = {cc.i0[2], cc.i0[2] + 1};            // and the + 1 value the next value of the row
+            const double wx[2] = {cc.t[0], cc.d[0]}, wy[2] = {cc.t[1], cc.d[1]}, wz[2] = {cc.t[2], cc.d[2]};
+            double value = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {                          // corner order 000, 001, ..., 111 (x, y, z bits)
+                const int bx = (k >> 2) & 1, by = (k >> 1) & 1, bz = k & 1;
+                const F *pl = bx ? rb : ra;
+                value += (double) pl[(ly + by) * WP + lz[bz]] * (wz[bz] * wx[bx] * wy[by]);
+            }
+            out[(long long) row * nmemb + memb0 + comp] = (float) value;
+        };
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            if (threadIdx.x + u * NT < n) gather(px[u], py[u], pz[u], prow[u]);
+        for (int e = threadIdx.x + 2 * NT; e < n; e += NT) gather(sx[b + e], sy[b + e], sz[b + e], sidx[b + e]);
+        __syncthreads();
+        C2<F> *tmp = A; A = B; B = tmp;
+    }
+}
+
+#define FPM_STRIP_CASE(n, BODY) case n: { using PL = typename Fac<n, 0>::type; BODY(PL) } break;
+#define STRIP_DISPATCH(M_, BODY)                                                                                     \
+    switch (M_) {                                                                                                    \
+        FPM_STRIP_CASE(16, BODY) FPM_STRIP_CASE(32, BODY) FPM_STRIP_CASE(48, BODY) FPM_STRIP_CASE(64, BODY)          \
+        FPM_STRIP_CASE(80, BODY) FPM_STRIP_CASE(96, BODY) FPM_STRIP_CASE(128, BODY) FPM_STRIP_CASE(160, BODY)        \
+        FPM_STRIP_CASE(192, BODY) FPM_STRIP_CASE(256, BODY) FPM_STRIP_CASE(320, BODY) FPM_STRIP_CASE(384, BODY)      \
+        FPM_STRIP_CASE(400, BODY) FPM_STRIP_CASE(512, BODY)                                                          \
+    default: FPM_FAIL(-1, "strip kernels: unsupported mesh size %d", 2 * (int) (M_));                               \
+    }
+
+// three readout workgroups per CU (the widest window: M = 256 in fp64, 512 in fp32)
+static constexpr size_t STRIP_LDS_MAX = 160 * 1024 / 3;
+
+bool strips_supported(int N, int precision)
+{
+    if (!rowfft_supported(N) || N % STRIP_Y != 0 || N / 2 > 512) return false;
+    const size_t es = precision == 64 ? 16 : 8, M = (size_t) N / 2;
+    return (2 * M + 2 * (M + 1) * STRIP_RW) * es <= STRIP_LDS_MAX;
+}
+
+template <typename K> static int grant_lds(K kernel, size_t bytes)
+{
+    static size_t granted = 64 * 1024;   // one per kernel instantiation
+    if (bytes > granted) {
+        FPM_CHECK_HIP(hipFuncSetAttribute((const void *) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+        granted = bytes;
+    }
+    return 0;
+}
+
+template <typename F, bool R2C>
+static int paint_strips_launch(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void *out, int accumulate)
+{
+    const MeshGeo &g = p->mg;
+    const int nseg = (g.xl + STRIP_XSEG - 1) / STRIP_XSEG;
+#define CALL_PAINT(PL)                                                                                                 \
+    {                                                                                                                  \
+        using CF = StripCfg<PL, F>;                                                                                    \
+        FPM_TRY(grant_lds(paint_strips_kernel<PL, F, R2C>, CF::pt_lds));                                               \
+        paint_strips_kernel<PL, F, R2C><<<g.nty * nseg, CF::pt_threads, CF::pt_lds, p->stream>>>(                      \
+            g, p->ntiles, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, pt->mass ? p->smass : nullptr, pt->M0, scale, out, \
+            accumulate, p->d_twiddle);                                                                                 \
+    }
+    STRIP_DISPATCH(g.N / 2, CALL_PAINT)
+#undef CALL_PAINT
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// Bins `pt` and paints it: r2c = false -> the real canvas (accumulate: added to it); r2c = true -> the half-spectrum
+// rows [x][y][kz] of the painted canvas, i.e. the paint and the z pass of pm_r2c in one kernel.
+int paint_strips(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void *out, int accumulate, bool r2c)
+{
+    if (!p->mg.strips) FPM_FAIL(-1, "internal: paint_strips on a plan with box tiles");
+    if (r2c && accumulate) FPM_FAIL(-1, "internal: the fused paint + z pass cannot accumulate");
+    FPM_TRY(bin_particles(p, pt));
+    StageTimer tm(p, FPMHIP_T_PAINT);
+    if (p->f64) return r2c ? paint_strips_launch<double, true>(p, pt, scale, out, 0)
+                           : paint_strips_launch<double, false>(p, pt, scale, out, accumulate);
+    return r2c ? paint_strips_launch<float, true>(p, pt, scale, out, 0)
+               : paint_strips_launch<float, false>(p, pt, scale, out, accumulate);
+}
+
+template <typename F>
+static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1, const void *k2, int ncomp, float *out,
+                                 int nmemb, int memb0)
+{
+    const MeshGeo &g = p->mg;
+    const int nseg = (g.xl + STRIP_XSEG - 1) / STRIP_XSEG;
+#define CALL_RO(PL)                                                                                                    \
+    {                                                                                                                  \
+        using CF = StripCfg<PL, F>;                                                                                    \
+        FPM_TRY(grant_lds(readout_strips_kernel<PL, F>, CF::ro_lds));                                                  \
+        readout_strips_kernel<PL, F><<<ncomp * g.nty * nseg, CF::ro_threads, CF::ro_lds, p->stream>>>(                 \
+            g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0, (const C2<F> *) k1, \
+            (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle);                                                      \
+    }
+    STRIP_DISPATCH(g.N / 2, CALL_RO)
+#undef CALL_RO
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// out[row * nmemb + memb0 + q] = CIC readout of c2r_z(k_q) at the particle, q < ncomp: k_q are meshes that have been
+// through the x and y passes of pm_c2r ([x][y][kz] half-spectrum rows); the z pass happens in LDS.
+int readout_strips_zc2r(fpmhip_plan *p, const fpmhip_particles *pt, const void *k0, const void *k1, const void *k2, int ncomp,
+                        float *out, int nmemb, int memb0)
+{
+    if (!p->mg.strips) FPM_FAIL(-1, "internal: readout_strips on a plan with box tiles");
+    if (ncomp < 1 || ncomp > 3) FPM_FAIL(-1, "internal: 1 to 3 meshes");
+    if (pt->np == 0) return 0;
+    if (p->binned_x != pt->x || p->binned_np != pt->np) FPM_TRY(bin_particles(p, pt));
+    else if (!p->bin_trusted) FPM_TRY(reuse_binning(p, pt));
+    StageTimer tm(p, FPMHIP_T_READOUT);
+    return p->f64 ? readout_strips_launch<double>(p, k0, k1, k2, ncomp, out, nmemb, memb0)
+                  : readout_strips_launch<float>(p, k0, k1, k2, ncomp, out, nmemb, memb0);
+}
+
+}  // namespace fpm

@@ -31,7 +31,7 @@ KERNEL_TYPES = {"3_4": 0, "3_2": 1, "5_4": 2, "1_4": 3, "1_4_diff0": 4, "gadget"
 SOFTENING_TYPES = {"none": 0, "gaussian": 1, "gadget_long_range": 2, "two_third": 3, "gaussian36": 4}
 FIELD_ACC = (0, 1, 2)
 FIELD_POTENTIAL = 3
-PAINT_TILED, PAINT_ATOMIC = 0, 1
+PAINT_TILED, PAINT_ATOMIC, PAINT_BOXES, PAINT_STRIPS = 0, 1, 2, 3
 FFT_AUTO, FFT_ROCFFT = 0, 1
 GRADIENT_KSPACE, GRADIENT_REAL = 0, 1
 

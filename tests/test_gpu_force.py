@@ -20,13 +20,13 @@ TOL_ACC = {64: 1e-6, 32: 2e-5}
 TOL_DK = {64: 1e-14, 32: 5e-7}
 
 
-def _run(oracle, N, nc, L, precision, x, mass=None, M0=1.0, kernel="1_4", softening="none", potential=False):
+def _run(oracle, N, nc, L, precision, x, mass=None, M0=1.0, kernel="1_4", softening="none", potential=False, paint_mode=0):
     import torch
     from fastpm_amd import PM, Store, fastpm_solver_compute_force
     pmo = oracle.PMOracle(N, L, precision)
     ref = oracle.compute_force(pmo, x, mass=mass, M0=M0, kernel=oracle.KERNELS[kernel],
                                softening=oracle.SOFTENINGS[softening], potential=potential)
-    pm = PM(N, L, precision)
+    pm = PM(N, L, precision, paint_mode=paint_mode)
     st = Store(x, mass=mass, M0=M0, potential=potential)
     dk = pm.alloc()
     fastpm_solver_compute_force(pm, st, dealias=softening, kernel=kernel, delta_k=dk)

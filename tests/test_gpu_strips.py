@@ -1,0 +1,152 @@
+"""The strip tiles and the marching kernels of fastpm_amd/csrc/fpm_strips.hip (FPMHIP_PAINT_STRIPS; the default on one
+rank from Nmesh = 128): the paint that runs on into the z pass of pm_r2c, the z pass of pm_c2r that runs on into the
+readout.  Same oracle, same tolerances as the box-tile kernels (tests/test_gpu_force.py); the box tiles stay the path of
+every multi-rank test and of the small one-rank meshes."""
+import numpy as np
+import pytest
+
+import util
+from test_gpu_force import TOL_ACC, TOL_DK, _run
+
+pytestmark = pytest.mark.gpu
+STRIPS, BOXES = 3, 2
+
+
+@pytest.mark.parametrize("precision", [64, 32])
+@pytest.mark.parametrize("load", ["a", "b", "c"])
+def test_force_parity_on_strips(oracle, precision, load):
+    N, nc, L = 64, 32, 96.0
+    x = {"a": lambda: util.load_a(nc, L, N), "b": lambda: util.load_b(nc, L, N), "c": lambda: util.load_c(nc, L)}[load]()
+    r = _run(oracle, N, nc, L, precision, x, paint_mode=STRIPS)
+    assert r["dk_err"] <= TOL_DK[precision], r["dk_err"]
+    assert r["acc_err"] <= TOL_ACC[precision], r["acc_err"]
+
+
+@pytest.mark.parametrize("N", [32, 96, 128, 160])
+def test_mesh_sizes_on_strips(oracle, N):
+    """radix-3 and radix-5 row lengths, the auto choice from 128"""
+    nc, L = N // 2, 1.5 * N
+    r = _run(oracle, N, nc, L, 64, util.load_a(nc, L, N), paint_mode=STRIPS if N < 128 else 0)
+    assert r["dk_err"] <= TOL_DK[64] and r["acc_err"] <= TOL_ACC[64], (N, r["dk_err"], r["acc_err"])
+
+
+@pytest.mark.parametrize("kernel", ["3_4", "3_2", "1_4_diff0", "eastwood", "naive"])
+def test_kernel_types_on_strips(oracle, kernel):
+    """gradorder 1 (two x-pass outputs, y / z factors in the potential's y pass) and 0 (three components)"""
+    N, nc, L = 32, 16, 48.0
+    r = _run(oracle, N, nc, L, 64, util.load_a(nc, L, N), kernel=kernel, paint_mode=STRIPS)
+    assert r["acc_err"] <= TOL_ACC[64], (kernel, r["acc_err"])
+
+
+@pytest.mark.parametrize("softening", ["gaussian", "two_third"])
+def test_softening_on_strips(oracle, softening):
+    """a softening kernel between r2c and the transfer: the real canvas is painted (marching paint without the z pass)"""
+    N, nc, L = 32, 16, 48.0
+    r = _run(oracle, N, nc, L, 64, util.load_a(nc, L, N), softening=softening, paint_mode=STRIPS)
+    assert r["dk_err"] <= TOL_DK[64] and r["acc_err"] <= TOL_ACC[64]
+
+
+@pytest.mark.parametrize("precision", [64, 32])
+def test_mass_and_potential_on_strips(oracle, precision):
+    N, nc, L = 32, 16, 48.0
+    x = util.load_b(nc, L, N)
+    mass = np.random.default_rng(3).uniform(0.0, 2.0, len(x)).astype(np.float32)
+    r = _run(oracle, N, nc, L, precision, x, mass=mass, M0=0.75, potential=True, paint_mode=STRIPS)
+    assert r["acc_err"] <= TOL_ACC[precision] and r["pot_err"] <= TOL_ACC[precision]
+
+
+def test_edge_positions_on_strips(oracle):
+    N, L = 32, 48.0
+    h = L / N
+    x = np.array([[0.0, 0.0, 0.0], [L, L, L], [L, 0.0, h * 7], [h * 8, h * 8, h * 32 - 1e-9],
+                  [h * 7.999999, h * 15.5, h * 31.999999], [L - 1e-12, L / 2, L / 3], [h * 3.5, h * 3.999999, h * 31.5],
+                  [h * 31.5, h * 31.5, h * 31.5], [0.5 * h, 0.5 * h, 0.5 * h], [h * 31.999, h * 4.0, 0.0]])
+    r = _run(oracle, N, 2, L, 64, x, paint_mode=STRIPS)
+    assert r["acc_err"] <= TOL_ACC[64], r["acc_err"]
+
+
+def test_stages_on_strips(oracle):
+    """the stage calls on a strip plan: paint (real canvas), paint_add, readout of real meshes (flat kernel)"""
+    import torch
+    from fastpm_amd import PM, Store
+    N, nc, L = 32, 16, 48.0
+    x = util.load_b(nc, L, N)
+    mass = np.random.default_rng(1).uniform(0, 1, len(x)).astype(np.float32)
+    pmo = oracle.PMOracle(N, L, 64)
+    ref = pmo.alloc()
+    pmo.paint(ref, x, mass=mass, M0=0.5)
+    exp = pmo.real_view(ref)[:, :, :N].copy()
+    pm = PM(N, L, 64, paint_mode=STRIPS)
+    st = Store(x, mass=mass, M0=0.5)
+    canvas = pm.alloc()
+    canvas.fill_(123.0)
+    pm.paint(canvas, st, 1.75)
+    got = pm.real_view(canvas).cpu().numpy()
+    assert np.abs(got[:, :, :N] - 1.75 * exp).max() <= 4e-16 * np.abs(1.75 * exp).max() * 4
+    assert np.all(got[:, :, N:] == 0)
+    pm.paint_add(canvas, st, 0.25)
+    got = pm.real_view(canvas).cpu().numpy()
+    assert np.abs(got[:, :, :N] - 2.0 * exp).max() <= 4e-16 * np.abs(2 * exp).max() * 4
+    # readout of three real meshes: bit for bit the oracle's
+    rng = np.random.default_rng(4)
+    meshes = []
+    for _ in range(3):
+        m = pmo.alloc()
+        m[:] = rng.normal(size=m.shape)
+        meshes.append(m)
+    want = np.zeros((len(x), 3), dtype=np.float32)
+    for d in range(3):
+        pmo.readout(meshes[d], x, out=want, nmemb=3, memb=d)
+    st2 = Store(x)
+    pm.readout3([util.dev_real(pm, pmo, m) for m in meshes], st2)
+    torch.cuda.synchronize()
+    assert np.array_equal(st2.acc.cpu().numpy(), want)
+    pm.destroy()
+
+
+def test_repeated_calls_with_moving_particles_on_strips(oracle):
+    """steady-state binning (one pass in the previous order, slabs with slack) on strip keys"""
+    import torch
+    from fastpm_amd import PM, Store
+    N, nc, L = 64, 32, 96.0
+    rng = np.random.default_rng(5)
+    x = util.load_a(nc, L, N)
+    pmo = oracle.PMOracle(N, L, 64)
+    pm = PM(N, L, 64, paint_mode=STRIPS)
+    st = Store(x)
+    for step in range(4):
+        if step:
+            x = np.mod(x + rng.normal(scale=0.4 * L / N, size=x.shape), L)
+            st.x.copy_(torch.from_numpy(x).cuda())
+            pm.invalidate_binning()
+        pm.compute_force(st, kernel="1_4")
+        pm.sync()
+        ref = oracle.compute_force(pmo, x)
+        assert util.rel_err(st.acc.cpu().numpy(), ref["acc"]) <= TOL_ACC[64], step
+    pm.destroy()
+
+
+def test_two_species_on_strips(oracle):
+    import torch
+    from fastpm_amd import PM, Store
+    N, nc, L = 32, 16, 48.0
+    xa, xb = util.load_a(nc, L, N), util.load_b(nc // 2, L, N)
+    pmo = oracle.PMOracle(N, L, 64)
+    accs, _ = oracle.compute_force_species(pmo, [{"x": xa, "M0": 1.0}, {"x": xb, "M0": 4.0}])
+    pm = PM(N, L, 64, paint_mode=STRIPS)
+    sa, sb = Store(xa, M0=1.0), Store(xb, M0=4.0)
+    pm.compute_force_species([sa, sb], kernel="1_4")
+    torch.cuda.synchronize()
+    assert util.rel_err(sa.acc.cpu().numpy(), accs[0]) <= TOL_ACC[64]
+    assert util.rel_err(sb.acc.cpu().numpy(), accs[1]) <= TOL_ACC[64]
+    pm.destroy()
+
+
+def test_strips_need_one_rank_and_the_kspace_gradient():
+    from fastpm_amd import PM
+    with pytest.raises(Exception):
+        PM(32, 48.0, 64, nranks=2, rank=0, paint_mode=STRIPS)
+    with pytest.raises(Exception):
+        PM(32, 48.0, 64, gradient_mode=1, paint_mode=STRIPS)
+    pm = PM(32, 48.0, 64, paint_mode=BOXES)
+    pm.destroy()
