@@ -228,7 +228,7 @@ def main():
     ap.add_argument("--precision", type=int, default=64)
     ap.add_argument("--nc", type=int, default=0, help="override particles per side")
     ap.add_argument("--nmesh", type=int, default=0, help="override mesh per side")
-    ap.add_argument("--paint-mode", type=int, default=0, help="0 tiled (default), 1 global atomics")
+    ap.add_argument("--paint-mode", type=int, default=0, help="0 tiled: strips where they exist, else boxes (default); 1 global atomics; 2 box tiles; 3 strip tiles")
     ap.add_argument("--fft-mode", type=int, default=0, help="0 auto (hand-written row and column passes), 1 rocFFT only")
     ap.add_argument("--load", default="a", choices=["a", "b", "c"],
                     help="a: lattice + 0.3-cell jitter (default); b: clustered (rms 4 cells); c: adversarial (1 GPU only)")
@@ -339,6 +339,7 @@ def main():
         return pm, store, dt, tm
 
     pm, store, dt, tm = timed_run(args.gradient)
+    strips = pm.strips()
 
     # extra leg, outside the timed region above and reported beside it: the same workload in the OTHER
     # gradient mode (same W and K, same bracket), and how far its accelerations are from the main run's
@@ -431,6 +432,11 @@ def main():
         ab = algorithmic_bytes(np_local, Nmesh, world, esize, args.gradient)
         if args.gradient == "real":
             KERNELS["readout"] = "fpm::readout_grad_tiles_kernel"
+        elif strips:
+            # the paint timer covers paint + z r2c pass, the readout timer z c2r pass + readout (fpm_strips.hip); their
+            # algorithmic bytes are the paint's and the readout's: the meshes between them never reach HBM
+            KERNELS["paint"] = "fpm::paint_strips_kernel"
+            KERNELS["readout"] = "fpm::readout_strips_kernel"
         elif args.precision == 64:
             KERNELS["readout"] = "fpm::readout1of3_tiles_kernel"
         stages = {}
@@ -486,7 +492,8 @@ def main():
                                  ("pencil %dx%d" % (world // args.nprocy, args.nprocy)),
                 "gradient": {"kspace": "k space, 3 inverse FFTs (the reference's arithmetic)",
                              "real": "real space, 1 inverse FFT + stencil readout (FPMHIP_GRADIENT_REAL)"}[args.gradient],
-                "paint_mode": "tiled" if args.paint_mode == 0 else "atomic",
+                "paint_mode": ("strip tiles: paint + z r2c pass and z c2r pass + readout in one kernel each" if strips
+                               else {0: "box tiles", 1: "atomic", 2: "box tiles"}.get(args.paint_mode, str(args.paint_mode))),
                 "fft": "hand-written row + column passes" if pm.column_fft() else "rocFFT"},
             "per_gpu": value / world, "finite": acc_ok, "momentum_residual": momentum_residual,
             # rank 0: time inside this library's kernels vs the rest of the step (for N > 1 the rest is

@@ -362,6 +362,11 @@ int fpmhip_plan_staged_fft(const fpmhip_plan *p)
     return p->lay.nranks > 1 || p->own_fft;
 }
 
+int fpmhip_plan_strips(const fpmhip_plan *p)
+{
+    return p && p->mg.strips ? 1 : 0;
+}
+
 int fpmhip_plan_column_fft(const fpmhip_plan *p)
 {
     return p && p->own_fft ? 1 : 0;

@@ -89,6 +89,7 @@ SYMBOLS = {
     "fpmhip_transfer_fft_x_backward3": (_I, [_P, _P, _P, _P, _P, _I]),
     "fpmhip_plan_staged_fft": (_I, [_P]),
     "fpmhip_plan_column_fft": (_I, [_P]),
+    "fpmhip_plan_strips": (_I, [_P]),
     "fpmhip_transfer_fft_x_backward_pot": (_I, [_P, _P, _P, _I]),
     "fpmhip_r2c_transfer_fft_x_backward": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "fpmhip_fft_x_forward_transfer_backward": (_I, [_P, _P, _I, _I, _P, _P, _P]),

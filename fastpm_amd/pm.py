@@ -612,6 +612,11 @@ class PM:
     def column_fft(self):
         return bool(self._L.fpmhip_plan_column_fft(self._plan))
 
+    def strips(self):
+        """True if the plan bins into strip tiles (one rank, Nmesh >= 128 by default): compute_force then paints into
+        half-spectrum rows and reads the force meshes out before their z pass (csrc/fpm_strips.hip)."""
+        return bool(self._L.fpmhip_plan_strips(self._plan))
+
     def transfer_fft_x_backward3(self, kernel, delta_k, outs):
         """The three ACC transfers + the x pass of their inverse FFTs from one read of delta_k."""
         check(self._L.fpmhip_transfer_fft_x_backward3(self._plan, _ptr(delta_k), _ptr(outs[0]), _ptr(outs[1]),

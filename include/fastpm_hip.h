@@ -291,6 +291,9 @@ int fpmhip_fft_yz_backward_grad2_range(fpmhip_plan *plan, void *recv_dev, void *
 /* 1 if the hand-written column-FFT back end is in use (FPMHIP_FFT_AUTO and a supported Nmesh): the
  * fused entry points fpmhip_transfer_fft_x_backward_potx / fpmhip_fft_yz_backward_grad2 need it */
 int fpmhip_plan_column_fft(const fpmhip_plan *plan);
+/* 1 if the plan bins the particles into strip tiles (see FPMHIP_PAINT_STRIPS): fpmhip_force then paints straight into
+ * half-spectrum rows and reads the force meshes out before their z pass; the stage calls behave as with box tiles */
+int fpmhip_plan_strips(const fpmhip_plan *plan);
 
 /* fastpm_readout_local (painter.c:358-374, painter-cic.c:113-190): one or three meshes.
  * readout3 writes acc[i][0..2]; readout1 writes out[i * nmemb + memb]. */

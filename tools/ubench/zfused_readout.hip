@@ -31,6 +31,8 @@ struct Geo {
     double inv_cell;
 };
 
+template <typename PL_> struct HalfTw : PL_ { static constexpr bool TWH = true; static constexpr int TWN = PL_::N / 2; };
+
 template <typename PL, int TY, typename F>
 __global__ __launch_bounds__((PL::T * (TY + 1))) void zfused_kernel(const C2<F> *__restrict__ m0, const C2<F> *__restrict__ m1,
                                                                     const C2<F> *__restrict__ m2, Geo g,
@@ -228,9 +230,9 @@ int main(int argc, char **argv)
 {
     const int N = 512;
     run<4>(N, 32, 256);
-    run<4, FFTPlan<256, 16, 16, 16, 1, 1>>(N, 32, 256);
-    run<4, FFTPlan<256, 4, 4, 4, 4, 4>>(N, 32, 256);
-    run<8, FFTPlan<256, 16, 16, 16, 1, 1>>(N, 32, 512);
-    run<2, FFTPlan<256, 4, 4, 4, 4, 4>>(N, 32, 128);
+    run<4, HalfTw<Fac<256, 0>::type>>(N, 32, 256);
+    run<8, HalfTw<Fac<256, 0>::type>>(N, 32, 512);
+    run<8, HalfTw<Fac<256, 0>::type>>(N, 64, 512);
+    run<8>(N, 32, 512);
     return 0;
 }
