@@ -498,6 +498,58 @@ __global__ __launch_bounds__(256) void slab_commit_kernel(const int *__restrict_
     }
 }
 
+// The layout of the predicated exact path in ONE kernel (one block): the two rocPRIM scans of make_layout cannot be
+// predicated, and the fallback they belong to runs once in a blue moon -- an idle launch of this kernel costs 5 us where
+// two scans and two small kernels cost 29.  Same results as slab_caps_kernel + scan + slab_commit_kernel.
+__global__ __launch_bounds__(1024) void layout_one_block_kernel(int *__restrict__ cnt, int nkeys, long long alloc,
+                                                                int *__restrict__ off, int *__restrict__ beg,
+                                                                int *__restrict__ cap, int zero_counts,
+                                                                int *__restrict__ flags, const int *__restrict__ pred)
+{
+    if (pred && *pred == 0) return;
+    __shared__ long long part[1024];
+    __shared__ long long total_s;
+    const int tid = threadIdx.x;
+    const int per = (nkeys + 1023) / 1024, k0 = min(tid * per, nkeys), k1 = min(k0 + per, nkeys);
+    auto block_exclusive = [&](long long mine) -> long long {       // also leaves the grand total in total_s
+        __syncthreads();
+        part[tid] = mine;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const long long v = tid >= o ? part[tid - o] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        if (tid == 1023) total_s = part[1023];
+        __syncthreads();
+        return part[tid] - mine;
+    };
+    long long s = 0;
+    for (int k = k0; k < k1; k++) s += cnt[k];
+    long long run = block_exclusive(s);
+    const long long total = total_s;
+    for (int k = k0; k < k1; k++) { off[k] = (int) run; run += cnt[k]; }
+    if (tid == 0) {
+        off[nkeys] = (int) total;
+        flags[FLAG_TOTAL] = (int) total;
+        if (total > alloc) flags[FLAG_HARD_OVF] = 1;
+    }
+    const bool slack = total + total / 4 + 33ll * nkeys <= alloc;
+    long long s2 = 0;
+    for (int k = k0; k < k1; k++) s2 += slack ? cnt[k] + cnt[k] / 4 + 32 : cnt[k];
+    run = block_exclusive(s2);
+    const long long total2 = total_s;
+    for (int k = k0; k < k1; k++) {
+        const int c = slack ? cnt[k] + cnt[k] / 4 + 32 : cnt[k];
+        beg[k] = (int) run;
+        cap[k] = c;
+        run += c;
+        if (zero_counts) cnt[k] = 0;
+    }
+    if (tid == 0) beg[nkeys] = (int) total2;
+}
+
 __global__ __launch_bounds__(256) void zero_ints_kernel(int *__restrict__ a, int n, const int *__restrict__ pred)
 {
     if (pred && *pred == 0) return;
@@ -1138,6 +1190,12 @@ static int scan_ints(fpmhip_plan *p, const int *in, int *out, size_t n)
 static int make_layout(fpmhip_plan *p, int *beg, int *cap, const int *pred, bool zero_counts)
 {
     const int nkeys = 2 * p->ntiles;
+    if (pred) {
+        layout_one_block_kernel<<<1, 1024, 0, p->stream>>>(p->bin_cnt, nkeys, p->bin_alloc, p->bin_off, beg, cap,
+                                                           zero_counts ? 1 : 0, p->d_flags, pred);
+        FPM_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     FPM_TRY(scan_ints(p, p->bin_cnt, p->bin_off, (size_t) nkeys + 1));
     slab_caps_kernel<<<blocks_for(nkeys + 1, 256), 256, 0, p->stream>>>(p->bin_cnt, p->bin_off, nkeys, p->bin_alloc,
                                                                       p->bin_capv, p->d_flags, pred);
@@ -1153,7 +1211,9 @@ static int bin_full(fpmhip_plan *p, const fpmhip_particles *pt, const int *pred)
 {
     const long long np = pt->np;
     const int nt = p->ntiles, nkeys = 2 * nt;
-    const unsigned nb = pred ? std::min(blocks_for(np, 256 * BIN_PPT), 2048u) : blocks_for(np, 256 * BIN_PPT);
+    // (an idle predicated launch should cost next to nothing: 256 blocks walk the virtual blocks -- with 2048 the exact
+    // scatter, whose 50 KB of LDS admit three blocks per CU, took 56 us to find out that it had nothing to do)
+    const unsigned nb = pred ? std::min(blocks_for(np, 256 * BIN_PPT), 256u) : blocks_for(np, 256 * BIN_PPT);
     zero_ints_kernel<<<blocks_for(nkeys + 1, 256), 256, 0, p->stream>>>(p->bin_cnt, nkeys + 1, pred);
     if (np > 0)
         bin_kernel<false, false, true, BIN_PPT><<<nb, 256, 0, p->stream>>>(

@@ -114,9 +114,14 @@ def test_repeated_calls_with_moving_particles_on_strips(oracle):
     pmo = oracle.PMOracle(N, L, 64)
     pm = PM(N, L, 64, paint_mode=STRIPS)
     st = Store(x)
-    for step in range(4):
-        if step:
+    for step in range(6):
+        if step == 4:
+            x = util.load_c(nc, L)              # other particles of the same count: slabs overflow, the in-stream exact path
+        elif step == 5:
+            x = util.load_a(nc, L, N)
+        elif step:
             x = np.mod(x + rng.normal(scale=0.4 * L / N, size=x.shape), L)
+        if step:
             st.x.copy_(torch.from_numpy(x).cuda())
             pm.invalidate_binning()
         pm.compute_force(st, kernel="1_4")
