@@ -288,20 +288,27 @@ __device__ __forceinline__ void butterflies(C2<F> *v, const C2<F> *tw, int tau)
 }
 
 // COMP: 0 = whole complex values (LDS holds C2<F>), 1 = real parts, 2 = imaginary parts (LDS holds F)
-template <int COMP, int CW, typename F> __device__ __forceinline__ void lds_put(void *lds, int idx, int c, C2<F> val)
+// SK: the exchange area's position of (idx, c) is idx * CW + c + SK * (idx / 32) -- a few elements of skew per 32
+// indices move the LDS bank conflicts of the strided gathers out of the way where CW is not a power of two
+// (fpm_strips.hip; 0 everywhere else)
+template <int CW, int SK> __device__ __forceinline__ int lds_pos(int idx, int c)
 {
-    if (COMP == 0) ((C2<F> *) lds)[idx * CW + c] = val;
-    else ((F *) lds)[idx * CW + c] = COMP == 1 ? val.x : val.y;
+    return idx * CW + c + (SK ? SK * (idx >> 5) : 0);
 }
-template <int COMP, int CW, typename F> __device__ __forceinline__ void lds_get(const void *lds, int idx, int c, C2<F> &val)
+template <int COMP, int CW, typename F, int SK = 0> __device__ __forceinline__ void lds_put(void *lds, int idx, int c, C2<F> val)
 {
-    if (COMP == 0) val = ((const C2<F> *) lds)[idx * CW + c];
-    else if (COMP == 1) val.x = ((const F *) lds)[idx * CW + c];
-    else val.y = ((const F *) lds)[idx * CW + c];
+    if (COMP == 0) ((C2<F> *) lds)[lds_pos<CW, SK>(idx, c)] = val;
+    else ((F *) lds)[lds_pos<CW, SK>(idx, c)] = COMP == 1 ? val.x : val.y;
+}
+template <int COMP, int CW, typename F, int SK = 0> __device__ __forceinline__ void lds_get(const void *lds, int idx, int c, C2<F> &val)
+{
+    if (COMP == 0) val = ((const C2<F> *) lds)[lds_pos<CW, SK>(idx, c)];
+    else if (COMP == 1) val.x = ((const F *) lds)[lds_pos<CW, SK>(idx, c)];
+    else val.y = ((const F *) lds)[lds_pos<CW, SK>(idx, c)];
 }
 
 // outputs of the stage of radix R (after PP) -> LDS index (kprev + PP*k)*M + t = b + (N/R)*k
-template <int R, int PP, int N, int E, int CW, int COMP, typename F>
+template <int R, int PP, int N, int E, int CW, int COMP, typename F, int SK = 0>
 __device__ __forceinline__ void scatter(const C2<F> *v, void *lds, int tau, int c)
 {
     constexpr int T = N / E, NBF = N / R, NB = (NBF + T - 1) / T;
@@ -310,12 +317,12 @@ __device__ __forceinline__ void scatter(const C2<F> *v, void *lds, int tau, int 
         const int b = tau + T * q;
         if (NBF % T != 0 && b >= NBF) continue;
 #pragma unroll
-        for (int k = 0; k < R; k++) lds_put<COMP, CW>(lds, b + NBF * k, c, v[q * R + k]);
+        for (int k = 0; k < R; k++) lds_put<COMP, CW, F, SK>(lds, b + NBF * k, c, v[q * R + k]);
     }
 }
 
 // inputs of the stage of radix R (after PP) <- LDS index kprev*MP + ts*M + t
-template <int R, int PP, int N, int E, int CW, int COMP, typename F>
+template <int R, int PP, int N, int E, int CW, int COMP, typename F, int SK = 0>
 __device__ __forceinline__ void gather(C2<F> *v, const void *lds, int tau, int c)
 {
     constexpr int T = N / E, MP = N / PP, M = MP / R, NBF = N / R, NB = (NBF + T - 1) / T;
@@ -325,7 +332,7 @@ __device__ __forceinline__ void gather(C2<F> *v, const void *lds, int tau, int c
         if (NBF % T != 0 && b >= NBF) continue;
         const int kprev = b / M, t = b % M;
 #pragma unroll
-        for (int ts = 0; ts < R; ts++) lds_get<COMP, CW>(lds, kprev * MP + ts * M + t, c, v[q * R + ts]);
+        for (int ts = 0; ts < R; ts++) lds_get<COMP, CW, F, SK>(lds, kprev * MP + ts * M + t, c, v[q * R + ts]);
     }
 }
 
@@ -333,29 +340,29 @@ __device__ __forceinline__ void gather(C2<F> *v, const void *lds, int tau, int c
 // real parts, then the imaginary parts, through an area of N * CW values of F; register slot i holds {new.x, old.y}
 // in between, so no second register set is needed.  The caller has made sure the LDS area is free (a barrier
 // since its last readers).
-template <int RA, int PPA, int RB, int N, int E, int CW, bool SP, typename F>
+template <int RA, int PPA, int RB, int N, int E, int CW, bool SP, typename F, int SK = 0>
 __device__ __forceinline__ void exchange(C2<F> *v, void *lds, int tau, int c)
 {
     if (!SP) {
-        scatter<RA, PPA, N, E, CW, 0>(v, lds, tau, c);
+        scatter<RA, PPA, N, E, CW, 0, F, SK>(v, lds, tau, c);
         __syncthreads();
-        gather<RB, PPA * RA, N, E, CW, 0>(v, lds, tau, c);
+        gather<RB, PPA * RA, N, E, CW, 0, F, SK>(v, lds, tau, c);
         __syncthreads();
     } else {
-        scatter<RA, PPA, N, E, CW, 1>(v, lds, tau, c);
+        scatter<RA, PPA, N, E, CW, 1, F, SK>(v, lds, tau, c);
         __syncthreads();
-        gather<RB, PPA * RA, N, E, CW, 1>(v, lds, tau, c);
+        gather<RB, PPA * RA, N, E, CW, 1, F, SK>(v, lds, tau, c);
         __syncthreads();
-        scatter<RA, PPA, N, E, CW, 2>(v, lds, tau, c);
+        scatter<RA, PPA, N, E, CW, 2, F, SK>(v, lds, tau, c);
         __syncthreads();
-        gather<RB, PPA * RA, N, E, CW, 2>(v, lds, tau, c);
+        gather<RB, PPA * RA, N, E, CW, 2, F, SK>(v, lds, tau, c);
         __syncthreads();
     }
 }
 
 // Full length-N transform of the E register values of each thread.  In: v[in_slot<PL>(j)] = row tau + T*j; out:
 // v[j] = row tau + T*j, natural order.  The LDS area must be free on entry (barrier) and is free on return.
-template <typename PL, int S, int CW, bool SP, typename F>
+template <typename PL, int S, int CW, bool SP, typename F, int SK = 0>
 __device__ __forceinline__ void fft_core(C2<F> *v, void *lds, const C2<F> *tw, int tau, int c)
 {
     constexpr int N = PL::N, E = PL::E, R1 = PL::R1, R2 = PL::R2, R3 = PL::R3, R4 = PL::R4;
@@ -363,13 +370,13 @@ __device__ __forceinline__ void fft_core(C2<F> *v, void *lds, const C2<F> *tw, i
     constexpr bool L1 = R2 == 1, L2 = R3 == 1, L3 = R4 == 1;
     butterflies<R1, 1, N, E, S, L1, TWH>(v, tw, tau);
     if (!L1) {
-        exchange<R1, 1, R2, N, E, CW, SP>(v, lds, tau, c);
+        exchange<R1, 1, R2, N, E, CW, SP, F, SK>(v, lds, tau, c);
         butterflies<R2, R1, N, E, S, L2, TWH>(v, tw, tau);
         if (!L2) {
-            exchange<R2, R1, R3, N, E, CW, SP>(v, lds, tau, c);
+            exchange<R2, R1, R3, N, E, CW, SP, F, SK>(v, lds, tau, c);
             butterflies<R3, R1 * R2, N, E, S, L3, TWH>(v, tw, tau);
             if (!L3) {
-                exchange<R3, R1 * R2, R4, N, E, CW, SP>(v, lds, tau, c);
+                exchange<R3, R1 * R2, R4, N, E, CW, SP, F, SK>(v, lds, tau, c);
                 butterflies<R4, R1 * R2 * R3, N, E, S, true, TWH>(v, tw, tau);
             }
         }

@@ -36,16 +36,28 @@ template <typename PL> struct HalfTw : PL {
     static constexpr int TWN = PL::N / 2;
 };
 
+// LDS layouts.  The window rows and the FFT exchange area share a slot; with 5 (or 4) rows side by side the plain
+// layouts put the strided accesses of the FFT on the same banks (rocprofv3 LDSBankConflict 44 % of the readout's and
+// 31 % of the paint's LDS cycles at M = 256 in fp64).  A bank model of the ds_*_b128 lane groups
+// (MI355X_MICROARCH.md) picked, for that size: readout -- 4 elements of skew per 32 exchange indices (SK) and rows of
+// 269 complex values: 11.3 -> 7.8 cycles per access set; paint -- rows of 520 values: 12 -> 10.  Other sizes keep
+// the plain layouts (correct, not tuned).
 template <typename PL, typename F> struct StripCfg {
     static constexpr int M = PL::N, T = PL::T;
+    static constexpr bool tuned = M == 256 && sizeof(F) == 8;
     static constexpr size_t twb = (size_t) (PL::TWN + M) * sizeof(C2<F>);
-    // readout: two planes of STRIP_RW rows of M + 1 complex values
+    // readout: two planes of STRIP_RW rows of ro_pitch complex values (>= M + 1: value N of a row repeats value 0)
     static constexpr int ro_threads = T * STRIP_RW;
-    static constexpr size_t ro_lds = twb + (size_t) 2 * (M + 1) * STRIP_RW * sizeof(C2<F>);
-    // paint: two planes of STRIP_Y rows of 2 M + 2 double accumulators
+    static constexpr int ro_sk = tuned ? 4 : 0;
+    static constexpr int ro_pitch = tuned ? 269 : M + 1;
+    static constexpr int ro_xchg = (M + 1) * STRIP_RW + ro_sk * (M / 32 + 1);       // elements of the exchange area
+    static constexpr int ro_slot = ro_pitch * STRIP_RW > ro_xchg ? ro_pitch * STRIP_RW : ro_xchg;
+    static constexpr size_t ro_lds = twb + (size_t) 2 * ro_slot * sizeof(C2<F>);
+    // paint: two planes of STRIP_Y rows of pt_pitch double accumulators
     static constexpr int pt_threads = T * STRIP_Y;
+    static constexpr int pt_pitch = tuned ? 520 : 2 * M + 2;
     static constexpr size_t pt_twb = (size_t) (M / 2 + M) * sizeof(C2<F>);
-    static constexpr size_t pt_lds = pt_twb + (size_t) 2 * STRIP_Y * (2 * M + 2) * sizeof(double);
+    static constexpr size_t pt_lds = pt_twb + (size_t) 2 * STRIP_Y * pt_pitch * sizeof(double);
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -58,7 +70,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads)) void paint_strips_ke
     void *__restrict__ out_, int accumulate, const double *__restrict__ tw_global)
 {
     using CF = StripCfg<PL, F>;
-    constexpr int M = PL::N, N = 2 * M, T = PL::T, E = PL::E, NT = CF::pt_threads, WP = N + 2, SLOT = STRIP_Y * WP;
+    constexpr int M = PL::N, N = 2 * M, T = PL::T, E = PL::E, NT = CF::pt_threads, WP = CF::pt_pitch, SLOT = STRIP_Y * WP;
     extern __shared__ __align__(16) unsigned char smem_st[];
     using PH = HalfTw<PL>;
     C2<F> *tw = (C2<F> *) smem_st;
@@ -215,7 +227,8 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
     const double *__restrict__ tw_global)
 {
     using CF = StripCfg<PL, F>;
-    constexpr int M = PL::N, RW = STRIP_RW, T = PL::T, E = PL::E, NT = CF::ro_threads, SLOT = (M + 1) * RW, WP = 2 * (M + 1);
+    constexpr int M = PL::N, RW = STRIP_RW, T = PL::T, E = PL::E, NT = CF::ro_threads, SLOT = CF::ro_slot, RP = CF::ro_pitch,
+                  WP = 2 * RP, SK = CF::ro_sk;
     extern __shared__ __align__(16) unsigned char smem_st[];
     C2<F> *tw = (C2<F> *) smem_st;
     C2<F> *twn = tw + PL::TWN;
@@ -245,15 +258,15 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
     auto c2r_to = [&](C2<F> *slot) {
         if (tau == 0) { x[0].y = 0; xm.y = 0; }     // a c2r reads only the real parts of X[0] and X[N/2]
 #pragma unroll
-        for (int j = 0; j < E; j++) slot[(tau + T * j) * RW + c] = x[j];
-        if (tau == 0) slot[M * RW + c] = xm;
+        for (int j = 0; j < E; j++) slot[lds_pos<RW, SK>(tau + T * j, c)] = x[j];
+        if (tau == 0) slot[lds_pos<RW, SK>(M, c)] = xm;
         __syncthreads();
         C2<F> v[vmax(E)];
 #pragma unroll
         for (int j = 0; j < E; j++) {
             const int k = tau + T * j;
             const C2<F> a = x[j];
-            C2<F> bq = slot[(M - k) * RW + c];                    // X[M-k]  (k = 0 pairs with X[M])
+            C2<F> bq = slot[lds_pos<RW, SK>(M - k, c)];            // X[M-k]  (k = 0 pairs with X[M])
             bq.y = -bq.y;
             const C2<F> s = cadd(a, bq), d = csub(a, bq);
             const C2<F> w = {twn[k].x, -twn[k].y};                 // conj W_N^k
@@ -261,10 +274,10 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
             v[in_slot<PL>(j)] = C2<F>{s.x - o.y, s.y + o.x};       // s + i o
         }
         __syncthreads();                                           // everyone has read its partner
-        fft_core<PL, +1, RW, false>(v, slot, tw, tau, c);
+        fft_core<PL, +1, RW, false, F, SK>(v, slot, tw, tau, c);
 #pragma unroll
-        for (int j = 0; j < E; j++) slot[c * (M + 1) + tau + T * j] = v[j];
-        if (tau == 0) slot[c * (M + 1) + M].x = v[0].x;            // value N of a row = value 0: the z + 1 corner needs no wrap
+        for (int j = 0; j < E; j++) slot[c * RP + tau + T * j] = v[j];
+        if (tau == 0) slot[c * RP + M].x = v[0].x;                 // value N of a row = value 0: the z + 1 corner needs no wrap
     };
 
     load_plane(xa);
