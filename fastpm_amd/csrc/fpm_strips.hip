@@ -16,7 +16,11 @@
 //            registers during the previous step's gather -- are inverse-transformed into the window; the particles of
 //            (plane i, strip) gather their 8 corners from planes i, i + 1.  One workgroup per (segment, strip,
 //            component); 5 / 4 of one mesh read per component instead of 1 read + 1 write + 1.13 read.
-// Measured at 512^3 fp64 (tools/ubench/zfused_readout.hip, then in place): z c2r x 3 + readout 2.15 ms -> 1.67 ms.
+// Measured at 512^3 fp64 (tools/ubench/zfused_readout.hip, then in place): z c2r x 3 + readout 2.15 ms -> 1.61 ms; paint + z
+// r2c 0.72 -> 0.57 ms.  Both kernels are bound by LDS traffic and issue, not by HBM (rocprofv3: VALUBusy 32 %,
+// LDSBankConflict 39 % after the layout changes below).  Tried, not adopted: strips of 8 rows (one readout workgroup
+// per CU: 2.0 ms), E = 16 / E = 4 factorisations (1.9 / 2.1 ms), twiddles read from global memory instead of LDS
+// (1.61 -> 1.85 ms).
 //
 // Reference arithmetic: painter-cic.c:34-110 (paint), :113-190 (readout), pmpfft.c:370-399 (the z legs of r2c / c2r);
 // the sums are the same sums in another order (the tolerance class of the box-tile kernels).
@@ -237,7 +241,9 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
     const int nseg = (g.xl + STRIP_XSEG - 1) / STRIP_XSEG;
     // the ncomp workgroups of a (segment, strip) are neighbours (they read the same positions), then the strips
     const int t = xcd_remap(blockIdx.x, ncomp * g.nty * nseg);
-    const int comp = t % ncomp, strip = (t / ncomp) % g.nty, seg = t / (ncomp * g.nty);
+    // last segment first: the y passes before this kernel walk the planes forwards, so their last planes are the ones
+    // the Infinity Cache still holds (1.635 -> 1.613 ms)
+    const int comp = t % ncomp, strip = (t / ncomp) % g.nty, seg = nseg - 1 - t / (ncomp * g.nty);
     const C2<F> *mesh = comp == 0 ? m0 : (comp == 1 ? m1 : m2);
     const int xa = seg * STRIP_XSEG, xb = min(xa + STRIP_XSEG, g.xl);
     const int y0 = strip * STRIP_Y;
