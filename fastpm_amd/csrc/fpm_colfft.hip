@@ -37,11 +37,14 @@ __device__ __forceinline__ long long col_addr(const ColMap &m, int batch, int i,
     return (long long) batch * m.bstride + (long long) (i / m.rsplit) * m.rhi + (long long) (i % m.rsplit) * m.rlo + col;
 }
 
-__device__ __forceinline__ int xcd_tile(int b, int n)
+// rev: every XCD walks its eighth of the tiles backwards (see row_block() in fpm_rowfft.hip: a pass that follows a
+// forward-walking producer then starts on what the Infinity Cache still holds)
+__device__ __forceinline__ int xcd_tile(int b, int n, int rev = 0)
 {
     const int q = n / 8, r = n % 8;
     const int xcd = b % 8, j = b / 8;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    const int cnt = q + (xcd < r);
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (rev ? cnt - 1 - j : j);
 }
 
 // Launch shape of the column kernels for one (length, precision).
@@ -83,7 +86,7 @@ constexpr int fused_min_waves(int threads, int E, int esize = 8)
 template <typename PL, int S, typename F>
 __global__ __launch_bounds__((ColCfg<PL, F>::threads)) void colfft_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ out,
                                                    ColMap im, ColMap om, int ncols, int ntiles_per_batch,
-                                                   int ntiles, const double *__restrict__ tw_global, double scale)
+                                                   int ntiles, const double *__restrict__ tw_global, double scale, int rev)
 {
     using CF = ColCfg<PL, F>;
     constexpr int CW = CF::CW, T = PL::T, E = PL::E;
@@ -91,7 +94,7 @@ __global__ __launch_bounds__((ColCfg<PL, F>::threads)) void colfft_kernel(const 
     C2<F> *tw = (C2<F> *) smem;                       // PL::TWN entries, then the exchange area
     void *lds = smem + CF::twb;
     const int c = threadIdx.x % CW, tau = threadIdx.x / CW;
-    const int tile = xcd_tile(blockIdx.x, ntiles);
+    const int tile = xcd_tile(blockIdx.x, ntiles, rev);
     const int batch = tile / ntiles_per_batch;
     const int col = (tile % ntiles_per_batch) * CW + c;
     const bool live = col < ncols;
@@ -316,13 +319,14 @@ static int colfft_launch(fpmhip_plan *p, int dir, const void *in, void *out, con
                          int nbatch, int ncols, double scale)
 {
     StageTimer ktm(p, FPMHIP_T_K_COLFFT);
+    const int rev = p->col_reverse;
 #define CALL_PLAIN_S(PL, S)                                                                                    \
     {                                                                                                          \
         using CF = ColCfg<PL, F>;                                                                              \
         const int tpb = (ncols + CF::CW - 1) / CF::CW, ntiles = tpb * nbatch;                                  \
         FPM_TRY(set_lds(colfft_kernel<PL, S, F>, CF::lds));                                                    \
         colfft_kernel<PL, S, F><<<ntiles, CF::threads, CF::lds, p->stream>>>(                                  \
-            (const C2<F> *) in, (C2<F> *) out, im, om, ncols, tpb, ntiles, p->d_twiddle, scale);               \
+            (const C2<F> *) in, (C2<F> *) out, im, om, ncols, tpb, ntiles, p->d_twiddle, scale, rev);          \
     }
 #define CALL_PLAIN(PL) if (dir < 0) CALL_PLAIN_S(PL, -1) else CALL_PLAIN_S(PL, +1)
     COLFFT_DISPATCH(p->mg.N, sizeof(F), CALL_PLAIN)

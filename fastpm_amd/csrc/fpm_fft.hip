@@ -274,7 +274,12 @@ int strips_y_xfwd_xback(fpmhip_plan *p, void *zrows_delta_k, int kernel, int mod
     FPM_TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));
     {
         StageTimer tm(p, FPMHIP_T_R2C);
-        FPM_TRY(colfft_y_range(p, -1, zrows_delta_k, zrows_delta_k, 0, 0, p->mg.xl));
+        // the paint marches its segments forwards: this pass starts on the planes it wrote last
+        static const bool rev = !(getenv("FPMHIP_YFWD_REV") && atoi(getenv("FPMHIP_YFWD_REV")) == 0);    // A/B
+        p->col_reverse = rev ? 1 : 0;
+        const int rc = colfft_y_range(p, -1, zrows_delta_k, zrows_delta_k, 0, 0, p->mg.xl);
+        p->col_reverse = 0;
+        FPM_TRY(rc);
     }
     StageTimer tm(p, FPMHIP_T_XBACK3);
     return colfft_xfwd_xback(p, zrows_delta_k, out0, mode == 1 ? out0 : out1, mode == 0 ? out2 : (mode == 1 ? out0 : out1),

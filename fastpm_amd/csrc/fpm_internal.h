@@ -126,6 +126,7 @@ struct fpmhip_plan {
     rocfft_plan p_zc2r_chunk = nullptr;    // z c2r for chunk_planes * N rows
     std::vector<std::pair<int, rocfft_plan>> zc2r_by_nx;   // z c2r for nx * N rows (ranged stage calls)
     double *d_twiddle = nullptr;   // e^{-2 pi i j / N}, j < N (re, im)
+    int col_reverse = 0;           // the next plain column pass walks its tiles backwards (xcd_tile)
     rocfft_execution_info fft_info = nullptr;
     void *fft_work = nullptr;
     size_t fft_work_bytes = 0;
