@@ -21,7 +21,8 @@
 // LDSBankConflict 39 % after the layout changes below).  Tried, not adopted: strips of 8 rows (one readout workgroup
 // per CU: 2.0 ms), E = 16 / E = 4 factorisations (1.9 / 2.1 ms), twiddles read from global memory instead of LDS
 // (1.61 -> 1.85 ms), twiddles as products of one table entry instead of 22 LDS reads per thread and step (1.61 -> 1.87 ms:
-// the fp64 multiplies cost more than the reads).
+// the fp64 multiplies cost more than the reads), the y passes of pm_c2r and this kernel on two streams, pipelined over 2 - 16 chunks
+// of x planes (5.20 -> 5.32 - 5.99 ms per force: the kernels compete for the CUs, the chunk launches add tails).
 //
 // Reference arithmetic: painter-cic.c:34-110 (paint), :113-190 (readout), pmpfft.c:370-399 (the z legs of r2c / c2r);
 // the sums are the same sums in another order (the tolerance class of the box-tile kernels).
