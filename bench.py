@@ -472,6 +472,16 @@ def main():
             per_kernel["sort"] = {"kernel": "fpm::bin_scatter_kernel + slab layout", "frac": round(a / HBM_PEAK_GBS, 4),
                                   "avg_launch_ms": stages["sort"]["avg_ms"], "launches_per_step": stages["sort"]["launches_per_step"],
                                   "traffic_over_alg": round(tr / ab["sort"], 3) if tr else None}
+        if strips:
+            # what the two marching kernels replace (box tiles: FPMHIP_STRIPS=0, profiles/r02_boxes_*): the same work took
+            # two / four kernels that moved these algorithmic bytes through HBM
+            s_nr = esize * Nmesh * Nmesh * (Nmesh + 2) // world
+            for n, rb, what in (("paint", ab["paint"] + 2 * s_nr, "paint_tiles_kernel + rowfft_r2c_kernel"),
+                                ("readout", ab["readout"] + 3 * 2 * s_nr, "3 x rowfft_c2r_kernel + readout1of3_tiles_kernel")):
+                if n in per_kernel:
+                    t_s = tm[n][0] / tm[n][1] * 1e-3
+                    per_kernel[n]["replaces"] = {"kernels": what, "their_alg_bytes": rb,
+                                                 "their_bytes_over_this_time_frac": round(rb / t_s / 1e9 / HBM_PEAK_GBS, 4)}
         worst = min(per_kernel, key=lambda n: per_kernel[n]["frac"])
         roofline["min_kernel"] = dict(per_kernel[worst], timer=worst)
         roofline["kernels"] = per_kernel

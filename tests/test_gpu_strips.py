@@ -155,3 +155,17 @@ def test_strips_need_one_rank_and_the_kspace_gradient():
         PM(32, 48.0, 64, gradient_mode=1, paint_mode=STRIPS)
     pm = PM(32, 48.0, 64, paint_mode=BOXES)
     pm.destroy()
+
+
+def test_one_particle_and_no_particles_on_strips(oracle):
+    import torch
+    from fastpm_amd import PM, Store
+    N, L = 32, 48.0
+    r = _run(oracle, N, 1, L, 64, np.array([[10.3, 20.1, 47.9]]), paint_mode=STRIPS)
+    assert np.abs(r["acc"]).max() <= 1e-5 and np.abs(r["ref"]["acc"]).max() <= 1e-5
+    pm = PM(N, L, 64, paint_mode=STRIPS)
+    assert pm.strips()
+    st = Store(np.zeros((0, 3)))
+    pm.compute_force(st, total_mass=1.0)
+    torch.cuda.synchronize()
+    pm.destroy()
