@@ -34,7 +34,9 @@ def main():
         kernel = str(rng.choice(kernels))
         soft = str(rng.choice(softs))
         fft_mode = int(rng.choice([0, 0, 1]))
-        paint_mode = int(rng.choice([0, 0, 1])) if P == 1 else 0
+        paint_mode = int(rng.choice([0, 0, 1, 2, 3, 3])) if P == 1 else 0
+        if paint_mode == 3 and (grad or fft_mode or N not in (32, 64, 96, 128, 160)):      # strip tiles: where they exist
+            paint_mode = 0
         nc = max(2, int(N * rng.choice([0.25, 0.5, 0.5, 1.0])))
         L = float(rng.uniform(0.5, 4.0) * N)
         load = str(rng.choice(["a", "b", "c", "few"]))
