@@ -356,12 +356,13 @@ bool strips_supported(int N, int precision)
     return (2 * M + 2 * (M + 1) * STRIP_RW) * es <= STRIP_LDS_MAX;
 }
 
-template <typename K> static int grant_lds(K kernel, size_t bytes)
+template <typename K> static int grant_lds(K kernel, size_t bytes, int device)
 {
-    static size_t granted = 64 * 1024;   // one per kernel instantiation
-    if (bytes > granted) {
+    static size_t granted[64] = {};      // per kernel instantiation and device (the attribute is set per device)
+    size_t &g = granted[device & 63];
+    if (bytes > 64 * 1024 && bytes > g) {
         FPM_CHECK_HIP(hipFuncSetAttribute((const void *) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
-        granted = bytes;
+        g = bytes;
     }
     return 0;
 }
@@ -374,7 +375,7 @@ static int paint_strips_launch(fpmhip_plan *p, const fpmhip_particles *pt, doubl
 #define CALL_PAINT(PL)                                                                                                 \
     {                                                                                                                  \
         using CF = StripCfg<PL, F>;                                                                                    \
-        FPM_TRY(grant_lds(paint_strips_kernel<PL, F, R2C>, CF::pt_lds));                                               \
+        FPM_TRY(grant_lds(paint_strips_kernel<PL, F, R2C>, CF::pt_lds, p->device));                                    \
         paint_strips_kernel<PL, F, R2C><<<g.nty * nseg, CF::pt_threads, CF::pt_lds, p->stream>>>(                      \
             g, p->ntiles, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, pt->mass ? p->smass : nullptr, pt->M0, scale, out, \
             accumulate, p->d_twiddle);                                                                                 \
@@ -408,7 +409,7 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
 #define CALL_RO(PL)                                                                                                    \
     {                                                                                                                  \
         using CF = StripCfg<PL, F>;                                                                                    \
-        FPM_TRY(grant_lds(readout_strips_kernel<PL, F>, CF::ro_lds));                                                  \
+        FPM_TRY(grant_lds(readout_strips_kernel<PL, F>, CF::ro_lds, p->device));                                       \
         readout_strips_kernel<PL, F><<<ncomp * g.nty * nseg, CF::ro_threads, CF::ro_lds, p->stream>>>(                 \
             g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0, (const C2<F> *) k1, \
             (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle);                                                      \
