@@ -260,7 +260,9 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
     g.nty = (g.yplanes + TILE_Y - 1) / TILE_Y;
     g.ntz = ((int) N + TILE_Z - 1) / TILE_Z;
     // Strip tiles + the kernels that march over them (fpm_strips.hip: the paint runs on into the z r2c pass, the
-    // z c2r pass into the readout) where they exist: one rank, the hand-written passes, the k-space gradient
+    // z c2r pass into the readout) where they exist: one rank, the hand-written passes, the k-space gradient; by
+    // default from N = 320 (measured per force, strips / boxes: N = 128 0.44 / 0.29 ms -- 128 marching workgroups do not
+    // fill the chip --, 256 0.89 / 0.90, 320 1.61 / 1.66, 384 2.51 / 2.68, 512 5.2 / 5.85)
     g.strips = 0;
     {
         static const bool env_off = getenv("FPMHIP_STRIPS") && atoi(getenv("FPMHIP_STRIPS")) == 0;      // A/B
@@ -268,7 +270,7 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
                          strips_supported((int) N, geom->precision) && geom->gradient_mode == FPMHIP_GRADIENT_KSPACE;
         if (geom->paint_mode == FPMHIP_PAINT_STRIPS && !can)
             FPM_FAIL(-1, "FPMHIP_PAINT_STRIPS: one rank, the k-space gradient and a mesh whose z rows fit the strip kernels");
-        if (can && (geom->paint_mode == FPMHIP_PAINT_STRIPS || (geom->paint_mode == FPMHIP_PAINT_TILED && N >= 128 && !env_off))) {
+        if (can && (geom->paint_mode == FPMHIP_PAINT_STRIPS || (geom->paint_mode == FPMHIP_PAINT_TILED && N >= 320 && !env_off))) {
             g.strips = STRIP_Y;
             g.ntx = g.xl; g.nty = (int) N / STRIP_Y; g.ntz = 1;
         }

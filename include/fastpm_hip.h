@@ -48,7 +48,7 @@ enum { FPMHIP_FIELD_ACC_X = 0, FPMHIP_FIELD_ACC_Y = 1, FPMHIP_FIELD_ACC_Z = 2, F
        FPMHIP_FIELD_TIDAL_XY, FPMHIP_FIELD_TIDAL_YZ, FPMHIP_FIELD_TIDAL_ZX };     /* (gravity.c:211-233) */
 /* paint algorithm */
 enum { FPMHIP_PAINT_TILED = 0,      /* tile-binned particles, LDS-staged tiles, no global atomics: strips where they exist
-                                     * (one rank, Nmesh >= 128, k-space gradient, hand-written FFT passes), boxes otherwise */
+                                     * (one rank, Nmesh >= 320, k-space gradient, hand-written FFT passes), boxes otherwise */
        FPMHIP_PAINT_ATOMIC = 1,     /* one global atomicAdd per corner (baseline for A/B evidence) */
        FPMHIP_PAINT_BOXES = 2,      /* always the 8 x 8 x 32-cell box tiles */
        FPMHIP_PAINT_STRIPS = 3 };   /* always the strip tiles (1 plane x 4 rows x Nmesh cells, marching kernels: the paint

@@ -1,5 +1,5 @@
 """The strip tiles and the marching kernels of fastpm_amd/csrc/fpm_strips.hip (FPMHIP_PAINT_STRIPS; the default on one
-rank from Nmesh = 128): the paint that runs on into the z pass of pm_r2c, the z pass of pm_c2r that runs on into the
+rank from Nmesh = 320): the paint that runs on into the z pass of pm_r2c, the z pass of pm_c2r that runs on into the
 readout.  Same oracle, same tolerances as the box-tile kernels (tests/test_gpu_force.py); the box tiles stay the path of
 every multi-rank test and of the small one-rank meshes."""
 import numpy as np
@@ -24,9 +24,9 @@ def test_force_parity_on_strips(oracle, precision, load):
 
 @pytest.mark.parametrize("N", [32, 96, 128, 160])
 def test_mesh_sizes_on_strips(oracle, N):
-    """radix-3 and radix-5 row lengths, the auto choice from 128"""
+    """radix-3 and radix-5 row lengths"""
     nc, L = N // 2, 1.5 * N
-    r = _run(oracle, N, nc, L, 64, util.load_a(nc, L, N), paint_mode=STRIPS if N < 128 else 0)
+    r = _run(oracle, N, nc, L, 64, util.load_a(nc, L, N), paint_mode=STRIPS)
     assert r["dk_err"] <= TOL_DK[64] and r["acc_err"] <= TOL_ACC[64], (N, r["dk_err"], r["acc_err"])
 
 
@@ -144,6 +144,17 @@ def test_two_species_on_strips(oracle):
     torch.cuda.synchronize()
     assert util.rel_err(sa.acc.cpu().numpy(), accs[0]) <= TOL_ACC[64]
     assert util.rel_err(sb.acc.cpu().numpy(), accs[1]) <= TOL_ACC[64]
+    pm.destroy()
+
+
+def test_strips_are_the_default_from_320():
+    from fastpm_amd import PM
+    for N, want in ((256, False), (320, True), (640, False)):        # 640 in fp64: the two-plane window does not fit
+        pm = PM(N, 1.5 * N, 64)
+        assert pm.strips() == want, N
+        pm.destroy()
+    pm = PM(640, 960.0, 32)
+    assert pm.strips()
     pm.destroy()
 
 
