@@ -24,6 +24,10 @@
 // the fp64 multiplies cost more than the reads), the y passes of pm_c2r and this kernel on two streams, pipelined over 2 - 16 chunks
 // of x planes (5.20 -> 5.32 - 5.99 ms per force: the kernels compete for the CUs, the chunk launches add tails).
 //
+// Where the paint's 0.575 ms go (phases compiled out one at a time): LDS atomics + CIC arithmetic 0.19, FFT core 0.165,
+// stores 0.08, the rest (window reads, partner exchange, zeroing, 9 barriers per step, prefetch) 0.15; HBM floor of its
+// 1.7 GB: 0.3.
+//
 // Reference arithmetic: painter-cic.c:34-110 (paint), :113-190 (readout), pmpfft.c:370-399 (the z legs of r2c / c2r);
 // the sums are the same sums in another order (the tolerance class of the box-tile kernels).
 #include <cstdlib>
