@@ -19,89 +19,14 @@
 
 namespace fpm {
 
-// Wavefront-aggregated atomic increment: lanes of the wave that target the same counter are
-// merged into one atomicAdd by the first of them.  Returns each lane's slot when RET.
-template <bool RET>
-__device__ __forceinline__ int wave_agg_inc(int *counters, int key, bool active)
-{
-    int slot = -1;
-    unsigned long long remaining = __ballot(active);
-    const int lane = __lane_id();
-    // Spatially coherent input (the normal case: lattice order, or the order a previous decompose
-    // left) has a handful of distinct tiles per wave.  After 6 merged groups the merging goes on only
-    // while groups still have 3 or more lanes (a clustered load spreads a wave over ~20 tiles: 1.36 ->
-    // 1.03 ms); then every lane still waiting issues its own atomic (random order would otherwise loop
-    // up to 64 times: 3.9 ms instead of 0.6 ms of binning on a shuffled 16.8 M-particle load).  Giving up
-    // as soon as ONE group is small is worse: lanes of the larger groups behind it then collide on the
-    // same counters one by one (clustered load 2.6 ms).
-    for (int round = 0; remaining && round < 24; round++) {
-        int leader = __ffsll((long long) remaining) - 1;
-        int k = __shfl(key, leader);
-        bool mine = active && key == k;
-        unsigned long long same = __ballot(mine);
-        int cnt = __popcll(same);
-        int base = 0;
-        if (lane == leader) {
-            if (RET) base = atomicAdd(&counters[k], cnt);
-            else (void) atomicAdd(&counters[k], cnt);
-        }
-        if (RET) {
-            base = __shfl(base, leader);
-            if (mine) slot = base + __popcll(same & ((1ull << lane) - 1ull));
-        }
-        remaining &= ~same;
-        if (round >= 5 && cnt < 3) break;      // uniform: after 6 groups keep merging only while it pays
-    }
-    if (remaining & (1ull << lane)) {
-        if (RET) slot = atomicAdd(&counters[key], 1);
-        else (void) atomicAdd(&counters[key], 1);
-    }
-    return slot;
-}
-
-// The same for the scatter pass, split in two so that no atomic's return value is waited for before
-// the next atomic is issued: issue() merges the lanes of a class that target the same cursor, the
-// group's first lane issues ONE returning atomicAdd and keeps the (pending) result in its own register;
-// every lane remembers its group's leader and its rank inside the group.  resolve() then fetches the
-// base from the leader's register.  A wave issues the atomics of all 8 corner classes back to back
-// (up to ~20 dependent round trips of ~1-2 us each before: 0.46 ms -> see DESIGN.md for the scatter pass).
-struct AggSlot {
-    int pend;     // leader lanes: the returned base (in flight until first use)
-    int leader;   // lane that holds my group's base
-    int rank;     // my position inside the group
-};
-
-__device__ __forceinline__ AggSlot wave_agg_issue(int *counters, int key, bool active)
-{
-    AggSlot a{0, 0, 0};
-    unsigned long long remaining = __ballot(active);
-    const int lane = __lane_id();
-    for (int round = 0; remaining && round < 24; round++) {
-        const int leader = __ffsll((long long) remaining) - 1;
-        const int k = __shfl(key, leader);
-        const bool mine = active && key == k;
-        const unsigned long long same = __ballot(mine);
-        if (lane == leader) a.pend = atomicAdd(&counters[k], __popcll(same));
-        if (mine) {
-            a.leader = leader;
-            a.rank = __popcll(same & ((1ull << lane) - 1ull));
-        }
-        remaining &= ~same;
-        if (round >= 5 && __popcll(same) < 3) break;   // uniform: after 6 groups keep merging only while it pays
-    }
-    if (remaining & (1ull << lane)) {
-        a.pend = atomicAdd(&counters[key], 1);
-        a.leader = lane;
-        a.rank = 0;
-    }
-    return a;
-}
-
-__device__ __forceinline__ int wave_agg_resolve(const AggSlot &a)
-{
-    return __shfl(a.pend, a.leader) + a.rank;
-}
-
+// Wave-level aggregation: lanes of a wave that target the same key are merged (ballot on the leader's key), the
+// group's first lane acts for all of them and every lane remembers its group's leader and its rank inside the group.
+// Spatially coherent input has a handful of distinct keys per wave.  After 6 merged groups the merging goes on only
+// while groups still have 3 or more lanes (a clustered load spreads a wave over ~20 tiles); then every lane still
+// waiting acts for itself (random order would otherwise loop up to 64 times: 3.9 ms instead of 0.6 ms of binning on a
+// shuffled 16.8 M-particle load).  Giving up as soon as ONE group is small is worse: lanes of the larger groups behind
+// it then collide on the same counters one by one.
+//
 // Block-level aggregation in front of the global cursors: a block's waves mostly hit the same few keys (a tile holds
 // ~8 waves' worth of particles), and atomics on one address serialise at the memory side.  Every wave-level group
 // adds its count to a small LDS hash table (returning LDS atomics) instead; after a barrier ONE global atomic per
@@ -187,121 +112,43 @@ enum { FLAG_NEED_FULL = 0, FLAG_UNOWNED_FAST, FLAG_UNOWNED_FULL, FLAG_HARD_OVF, 
 // memory round trips per wave, and PPT independent chains overlap them.
 constexpr int BIN_PPT = 2;
 
-// SCATTER = false: count entries per key.  SCATTER = true: place them.  ORDERED: particle j is order[j].
-// pred (nullable): run only if *pred != 0.  FULL: this is the exact path (overflow = the arrays are too small).
-template <bool SCATTER, bool ORDERED, bool FULL, int PPT>
-__global__ __launch_bounds__(256) void bin_kernel(MeshGeo g, int ntiles, const double *__restrict__ x,
-                                                  const float *__restrict__ mass, long long np,
-                                                  const int *__restrict__ order, const int *__restrict__ beg,
-                                                  const int *__restrict__ cap, int *__restrict__ cnt,
-                                                  double *__restrict__ sx, double *__restrict__ sy,
-                                                  double *__restrict__ sz, float *__restrict__ smass,
-                                                  int *__restrict__ sidx, int *__restrict__ flags,
-                                                  const int *__restrict__ pred)
+// Count pass of the exact path: entries per key.  pred (nullable): run only if *pred != 0.
+template <int PPT>
+__global__ __launch_bounds__(256) void bin_count_kernel(MeshGeo g, int ntiles, const double *__restrict__ x, long long np,
+                                                        int *__restrict__ cnt, const int *__restrict__ pred)
 {
     if (pred && *pred == 0) return;
     __shared__ BlockAgg agg;
     // a predicated launch uses a small grid that walks the virtual blocks (an idle one must cost next to nothing)
     const long long nvb = (np + 256 * PPT - 1) / (256 * PPT);
     for (long long vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < BIN_HASH; i += 256) { agg.key[i] = -1; agg.cnt[i] = 0; }
-    __syncthreads();
-    const long long j0 = vb * (256 * PPT) + threadIdx.x;
-    double px[PPT], py[PPT], pz[PPT];
-    float pm[PPT];
-    int row[PPT];
-    bool active[PPT];
+        __syncthreads();
+        for (int i = threadIdx.x; i < BIN_HASH; i += 256) { agg.key[i] = -1; agg.cnt[i] = 0; }
+        __syncthreads();
+        const long long j0 = vb * (256 * PPT) + threadIdx.x;
 #pragma unroll
-    for (int u = 0; u < PPT; u++) {
-        const long long j = j0 + u * 256;
-        active[u] = j < np;
-        row[u] = 0;
-        if (active[u]) row[u] = ORDERED ? order[j] : (int) j;
-    }
-#pragma unroll
-    for (int u = 0; u < PPT; u++) {
-        px[u] = py[u] = pz[u] = 0;
-        pm[u] = 0;
-        if (active[u]) {
-            const long long i = row[u];
-            px[u] = x[3 * i + 0];
-            py[u] = x[3 * i + 1];
-            pz[u] = x[3 * i + 2];
-            if (SCATTER && mass) pm[u] = mass[i];
-        }
-    }
-    bool need[PPT][8];
-    int key[PPT][8];
-#pragma unroll
-    for (int u = 0; u < PPT; u++) {
-        int t0[3] = {0, 0, 0}, t1[3] = {0, 0, 0};
-        if (active[u]) {
-            Cic c;
-            if (!cic_setup(g, px[u], py[u], pz[u], c)) {
-                // not this rank's particle: counted, reported by the host (lazily in the steady state)
-                if (SCATTER) atomicAdd(&flags[FULL ? FLAG_UNOWNED_FULL : FLAG_UNOWNED_FAST], 1);
-                active[u] = false;
+        for (int u = 0; u < PPT; u++) {
+            const long long j = j0 + u * 256;
+            bool active = j < np;
+            int t0[3] = {0, 0, 0}, t1[3] = {0, 0, 0};
+            if (active) {
+                Cic c;
+                active = cic_setup(g, x[3 * j], x[3 * j + 1], x[3 * j + 2], c);      // not this rank's: the scatter pass reports it
+                tile_coords(g, c, t0, t1);
             }
-            tile_coords(g, c, t0, t1);
-        }
-        // class 0: the own tile; classes 1..7: the up to 7 other tiles the cloud touches
+            // class 0: the own tile; classes 1..7: the up to 7 other tiles the cloud touches
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const int bx = (c >> 2) & 1, by = (c >> 1) & 1, bz = c & 1;
-            need[u][c] = active[u] && (!bx || t1[0] != t0[0]) && (!by || t1[1] != t0[1]) && (!bz || t1[2] != t0[2]);
-            key[u][c] = (c ? ntiles : 0) + tile_id(g, bx ? t1[0] : t0[0], by ? t1[1] : t0[1], bz ? t1[2] : t0[2]);
-        }
-    }
-    if (!SCATTER) {
-#pragma unroll
-        for (int u = 0; u < PPT; u++)
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                if (__ballot(need[u][c]) == 0) continue;
-                (void) block_agg_issue<false>(agg, cnt, key[u][c], need[u][c]);
+            for (int cl = 0; cl < 8; cl++) {
+                const int bx = (cl >> 2) & 1, by = (cl >> 1) & 1, bz = cl & 1;
+                const bool need = active && (!bx || t1[0] != t0[0]) && (!by || t1[1] != t0[1]) && (!bz || t1[2] != t0[2]);
+                if (__ballot(need) == 0) continue;
+                const int key = (cl ? ntiles : 0) + tile_id(g, bx ? t1[0] : t0[0], by ? t1[1] : t0[1], bz ? t1[2] : t0[2]);
+                (void) block_agg_issue<false>(agg, cnt, key, need);
             }
+        }
         __syncthreads();
         for (int i = threadIdx.x; i < BIN_HASH; i += 256)
             if (agg.key[i] >= 0) (void) atomicAdd(&cnt[agg.key[i]], agg.cnt[i]);
-        continue;
-    }
-    AggSlot2 a[PPT][8];
-#pragma unroll
-    for (int u = 0; u < PPT; u++)
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            a[u][c] = AggSlot2{0, -1, 0, 0};
-            if (__ballot(need[u][c]) == 0) continue;
-            a[u][c] = block_agg_issue<true>(agg, cnt, key[u][c], need[u][c]);
-        }
-    __syncthreads();
-    for (int i = threadIdx.x; i < BIN_HASH; i += 256) {
-        const bool used = agg.key[i] >= 0;
-        if (used) agg.base[i] = atomicAdd(&cnt[agg.key[i]], agg.cnt[i]);      // one global atomic per key and block
-    }
-    __syncthreads();
-    bool spilled = false;
-#pragma unroll
-    for (int u = 0; u < PPT; u++)
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            if (__ballot(need[u][c]) == 0) continue;
-            const int lslot = __shfl(a[u][c].slot, a[u][c].leader);
-            const int local = __shfl(a[u][c].pend, a[u][c].leader) + a[u][c].rank + (lslot >= 0 ? agg.base[lslot] : 0);
-            if (need[u][c]) {
-                const int k = key[u][c];
-                if (local < cap[k]) {
-                    const int slot = beg[k] + local;
-                    sx[slot] = px[u]; sy[slot] = py[u]; sz[slot] = pz[u];
-                    if (smass) smass[slot] = pm[u];
-                    sidx[slot] = row[u];
-                } else {
-                    spilled = true;
-                }
-            }
-        }
-    if (__ballot(spilled) && __lane_id() == 0) flags[FULL ? FLAG_HARD_OVF : FLAG_NEED_FULL] = 1;
     }
 }
 
@@ -1216,9 +1063,7 @@ static int bin_full(fpmhip_plan *p, const fpmhip_particles *pt, const int *pred)
     const unsigned nb = pred ? std::min(blocks_for(np, 256 * BIN_PPT), 256u) : blocks_for(np, 256 * BIN_PPT);
     zero_ints_kernel<<<blocks_for(nkeys + 1, 256), 256, 0, p->stream>>>(p->bin_cnt, nkeys + 1, pred);
     if (np > 0)
-        bin_kernel<false, false, true, BIN_PPT><<<nb, 256, 0, p->stream>>>(
-            p->mg, nt, pt->x, pt->mass, np, nullptr, nullptr, nullptr, p->bin_cnt, nullptr, nullptr, nullptr, nullptr,
-            nullptr, p->d_flags, pred);
+        bin_count_kernel<BIN_PPT><<<nb, 256, 0, p->stream>>>(p->mg, nt, pt->x, np, p->bin_cnt, pred);
     FPM_TRY(make_layout(p, p->bin_beg[0], p->bin_cap[0], pred, true));
     if (np > 0)
         bin_scatter_kernel<false, true><<<nb, 256, sizeof(ScatterLds<dup_cap<true>()>), p->stream>>>(
