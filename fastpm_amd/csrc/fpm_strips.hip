@@ -22,7 +22,9 @@
 // per CU: 2.0 ms), E = 16 / E = 4 factorisations (1.9 / 2.1 ms), twiddles read from global memory instead of LDS
 // (1.61 -> 1.85 ms), twiddles as products of one table entry instead of 22 LDS reads per thread and step (1.61 -> 1.87 ms:
 // the fp64 multiplies cost more than the reads), the y passes of pm_c2r and this kernel on two streams, pipelined over 2 - 16 chunks
-// of x planes (5.20 -> 5.32 - 5.99 ms per force: the kernels compete for the CUs, the chunk launches add tails).
+// of x planes (5.20 -> 5.32 - 5.99 ms per force: the kernels compete for the CUs, the chunk launches add tails), ONE plane in
+// LDS (a particle's sum split where the planes change, half sums waiting in registers: 29 KB of LDS, but 168 - 190
+// VGPRs: 1.64 ms at two waves per SIMD, 1.92 ms at three), 8-row strips on that one-plane kernel (1.95 ms).
 //
 // Where the paint's 0.575 ms go (phases compiled out one at a time): LDS atomics + CIC arithmetic 0.19, FFT core 0.165,
 // stores 0.08, the rest (window reads, partner exchange, zeroing, 9 barriers per step, prefetch) 0.15; HBM floor of its
