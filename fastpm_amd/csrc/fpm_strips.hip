@@ -57,18 +57,18 @@ template <typename PL> struct HalfTw : PL {
 // the plain layouts (correct, not tuned).
 template <typename PL, typename F> struct StripCfg {
     static constexpr int M = PL::N, T = PL::T;
-    static constexpr bool tuned = M == 256 && sizeof(F) == 8;
+    static constexpr bool tuned = M == 256 && sizeof(F) == 8, tuned32 = M == 256 && sizeof(F) == 4;
     static constexpr size_t twb = (size_t) (PL::TWN + M) * sizeof(C2<F>);
     // readout: two planes of STRIP_RW rows of ro_pitch complex values (>= M + 1: value N of a row repeats value 0)
     static constexpr int ro_threads = T * STRIP_RW;
     static constexpr int ro_sk = tuned ? 4 : 0;
-    static constexpr int ro_pitch = tuned ? 269 : M + 1;
+    static constexpr int ro_pitch = tuned || tuned32 ? 269 : M + 1;      // (fp32, b64 accesses: row stores 4.2 -> 0.83 cycles)
     static constexpr int ro_xchg = (M + 1) * STRIP_RW + ro_sk * (M / 32 + 1);       // elements of the exchange area
     static constexpr int ro_slot = ro_pitch * STRIP_RW > ro_xchg ? ro_pitch * STRIP_RW : ro_xchg;
     static constexpr size_t ro_lds = twb + (size_t) 2 * ro_slot * sizeof(C2<F>);
     // paint: two planes of STRIP_Y rows of pt_pitch double accumulators
     static constexpr int pt_threads = T * STRIP_Y;
-    static constexpr int pt_pitch = tuned ? 520 : 2 * M + 2;
+    static constexpr int pt_pitch = tuned || tuned32 ? 520 : 2 * M + 2;   // (the accumulators are double in both precisions)
     static constexpr size_t pt_twb = (size_t) (M / 2 + M) * sizeof(C2<F>);
     static constexpr size_t pt_lds = pt_twb + (size_t) 2 * STRIP_Y * pt_pitch * sizeof(double);
 };
