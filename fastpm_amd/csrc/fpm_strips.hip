@@ -51,24 +51,30 @@ template <typename PL> struct HalfTw : PL {
 
 // LDS layouts.  The window rows and the FFT exchange area share a slot; with 5 (or 4) rows side by side the plain
 // layouts put the strided accesses of the FFT on the same banks (rocprofv3 LDSBankConflict 44 % of the readout's and
-// 31 % of the paint's LDS cycles at M = 256 in fp64).  A bank model of the ds_*_b128 lane groups
-// (MI355X_MICROARCH.md) picked, for that size: readout -- 4 elements of skew per 32 exchange indices (SK) and rows of
-// 269 complex values: 11.3 -> 7.8 cycles per access set; paint -- rows of 520 values: 12 -> 10.  Other sizes keep
-// the plain layouts (correct, not tuned).
+// 31 % of the paint's LDS cycles at M = 256 in fp64).  A bank model of the ds_*_b128 / _b64 lane groups
+// (MI355X_MICROARCH.md) picked: readout -- rows 13 (mod 16) values apart (269 for M = 256: the row stores 2.5 -> 0.83
+// cycles in fp64, 4.2 -> 0.83 in fp32) and, at M = 256 in fp64, 4 elements of skew per 32 exchange indices (SK): 11.3 ->
+// 7.8 cycles per access set, 1.73 -> 1.64 ms; paint -- rows 4 (mod 16) complex values apart (520 doubles): 12 -> 10.
+constexpr int strip_pitch(int M, int rem)            // the smallest pitch >= M + 1 that is `rem` modulo 16
+{
+    int p = M + 1;
+    while (p % 16 != rem) p++;
+    return p;
+}
+
 template <typename PL, typename F> struct StripCfg {
     static constexpr int M = PL::N, T = PL::T;
-    static constexpr bool tuned = M == 256 && sizeof(F) == 8, tuned32 = M == 256 && sizeof(F) == 4;
     static constexpr size_t twb = (size_t) (PL::TWN + M) * sizeof(C2<F>);
     // readout: two planes of STRIP_RW rows of ro_pitch complex values (>= M + 1: value N of a row repeats value 0)
     static constexpr int ro_threads = T * STRIP_RW;
-    static constexpr int ro_sk = tuned ? 4 : 0;
-    static constexpr int ro_pitch = tuned || tuned32 ? 269 : M + 1;      // (fp32, b64 accesses: row stores 4.2 -> 0.83 cycles)
+    static constexpr int ro_sk = M == 256 && sizeof(F) == 8 ? 4 : 0;
+    static constexpr int ro_pitch = strip_pitch(M, 13);
     static constexpr int ro_xchg = (M + 1) * STRIP_RW + ro_sk * (M / 32 + 1);       // elements of the exchange area
     static constexpr int ro_slot = ro_pitch * STRIP_RW > ro_xchg ? ro_pitch * STRIP_RW : ro_xchg;
     static constexpr size_t ro_lds = twb + (size_t) 2 * ro_slot * sizeof(C2<F>);
     // paint: two planes of STRIP_Y rows of pt_pitch double accumulators
     static constexpr int pt_threads = T * STRIP_Y;
-    static constexpr int pt_pitch = tuned || tuned32 ? 520 : 2 * M + 2;   // (the accumulators are double in both precisions)
+    static constexpr int pt_pitch = 2 * strip_pitch(M, 4);
     static constexpr size_t pt_twb = (size_t) (M / 2 + M) * sizeof(C2<F>);
     static constexpr size_t pt_lds = pt_twb + (size_t) 2 * STRIP_Y * pt_pitch * sizeof(double);
 };
@@ -360,7 +366,7 @@ bool strips_supported(int N, int precision)
 {
     if (!rowfft_supported(N) || N % STRIP_Y != 0 || N / 2 > 512) return false;
     const size_t es = precision == 64 ? 16 : 8, M = (size_t) N / 2;
-    return (2 * M + 2 * (M + 1) * STRIP_RW) * es <= STRIP_LDS_MAX;
+    return (2 * M + 2 * (size_t) strip_pitch((int) M, 13) * STRIP_RW) * es <= STRIP_LDS_MAX;      // = StripCfg::ro_lds
 }
 
 template <typename K> static int grant_lds(K kernel, size_t bytes, int device)
