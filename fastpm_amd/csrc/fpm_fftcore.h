@@ -383,6 +383,49 @@ __device__ __forceinline__ void fft_core(C2<F> *v, void *lds, const C2<F> *tw, i
     }
 }
 
+// ---- the z passes: a real row of N = 2 M values <-> its half spectrum X[0 .. M], through the M-point core ----
+// (used by fpm_rowfft.hip and, inside the particle kernels, by fpm_strips.hip; thread (tau, c) holds elements
+// tau + T j of row c, the rows exchange through `lds` laid out lds_pos<RW, SK>)
+//
+// r2c, after the forward core on z[n] = x[2n] + i x[2n+1]:  X[k] = E + W_N^k O,  E = (Z[k] + conj Z[M-k]) / 2,
+// O = (Z[k] - conj Z[M-k]) / 2i.  a = Z[k], b = Z[M-k], wk = W_N^k.
+template <typename F> __device__ __forceinline__ C2<F> r2c_untangle(C2<F> a, C2<F> b, C2<F> wk)
+{
+    b.y = -b.y;                                            // conj Z[M-k]
+    const C2<F> e = {(a.x + b.x) * (F) 0.5, (a.y + b.y) * (F) 0.5};
+    const C2<F> d = {(a.x - b.x) * (F) 0.5, (a.y - b.y) * (F) 0.5};
+    const C2<F> o = {d.y, -d.x};                           // d / i
+    return cadd(e, cmul(wk, o));
+}
+
+// c2r, in front of the inverse core:  Z'[k] = (X[k] + conj X[M-k]) + i conj(W_N^k) (X[k] - conj X[M-k]).
+// x[j] = X[tau + T j] and xm = X[M] (threads with tau == 0) come in registers; v[in_slot(j)] leaves for the core.
+// A c2r transform reads only the real parts of X[0] and X[N/2] (FFTW, pocketfft and rocFFT all do): with the exact
+// i k gradient (3_2, EASTWOOD, NAIVE) the Nyquist entry of a row does carry an imaginary part.
+// Two barriers; the lds area is free again on return.
+template <typename PL, int RW, int SK, typename F>
+__device__ __forceinline__ void c2r_prepare(C2<F> *v, C2<F> *x, C2<F> xm, C2<F> *lds, const C2<F> *twn, int tau, int c)
+{
+    constexpr int M = PL::N, T = PL::T, E = PL::E;
+    if (tau == 0) { x[0].y = 0; xm.y = 0; }
+#pragma unroll
+    for (int j = 0; j < E; j++) lds[lds_pos<RW, SK>(tau + T * j, c)] = x[j];
+    if (tau == 0) lds[lds_pos<RW, SK>(M, c)] = xm;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        const int k = tau + T * j;
+        const C2<F> a = x[j];
+        C2<F> bq = lds[lds_pos<RW, SK>(M - k, c)];         // X[M-k]  (k = 0 pairs with X[M])
+        bq.y = -bq.y;
+        const C2<F> s = cadd(a, bq), d = csub(a, bq);
+        const C2<F> w = {twn[k].x, -twn[k].y};             // conj W_N^k
+        const C2<F> o = cmul(w, d);
+        v[in_slot<PL>(j)] = C2<F>{s.x - o.y, s.y + o.x};   // s + i o
+    }
+    __syncthreads();                                       // everyone has read its partner
+}
+
 // W_N^j, j < PL::TWN, from the plan's double table (stride: every `step`-th entry -- the row passes of N = 2M use
 // W_M^j = W_N^{2j})
 template <typename F>

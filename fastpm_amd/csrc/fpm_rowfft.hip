@@ -85,14 +85,8 @@ __global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_r2c_kernel(co
     for (int j = 0; j < E; j++) {
         const int k = tau + T * j;
         const C2<F> a = v[j];
-        C2<F> bq = lds[((M - k) % M) * RW + c];
-        bq.y = -bq.y;                                          // conj Z[M-k]
-        const C2<F> e = {(a.x + bq.x) * (F) 0.5, (a.y + bq.y) * (F) 0.5};
-        const C2<F> d = {(a.x - bq.x) * (F) 0.5, (a.y - bq.y) * (F) 0.5};
-        const C2<F> o = {d.y, -d.x};                           // d / i
-        const C2<F> x = cadd(e, cmul(twn[k], o));
         if (live) {
-            st_stream(&at(k), x);
+            st_stream(&at(k), r2c_untangle(a, lds[((M - k) % M) * RW + c], twn[k]));
             if (k == 0) at(M) = C2<F>{a.x - a.y, 0};           // X[N/2] = Re Z0 - Im Z0
         }
     }
@@ -121,29 +115,11 @@ __global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_c2r_kernel(co
     C2<F> x[E];
 #pragma unroll
     for (int j = 0; j < E; j++) x[j] = live ? at(tau + T * j) : C2<F>{0, 0};
-    C2<F> xm = (live && tau == 0) ? at(M) : C2<F>{0, 0};
-    // a c2r transform reads only the real parts of X[0] and X[N/2] (FFTW, pocketfft and rocFFT all do): with the
-    // exact i k gradient (3_2, EASTWOOD, NAIVE) the Nyquist entry of a row does carry an imaginary part
-    if (tau == 0) { x[0].y = 0; xm.y = 0; }
+    const C2<F> xm = (live && tau == 0) ? at(M) : C2<F>{0, 0};
     stage_twiddles(tw, tw_global, PL::TWN, 2);
-    stage_twiddles(twn, tw_global, M, 1);
-#pragma unroll
-    for (int j = 0; j < E; j++) lds[(tau + T * j) * RW + c] = x[j];
-    if (tau == 0) lds[M * RW + c] = xm;
-    __syncthreads();
+    stage_twiddles(twn, tw_global, M, 1);                      // (read behind c2r_prepare's first barrier)
     C2<F> v[vmax(E)];
-#pragma unroll
-    for (int j = 0; j < E; j++) {
-        const int k = tau + T * j;
-        const C2<F> a = x[j];
-        C2<F> bq = lds[(M - k) * RW + c];                    // X[M-k]  (k = 0 pairs with X[M])
-        bq.y = -bq.y;
-        const C2<F> s = cadd(a, bq), d = csub(a, bq);
-        const C2<F> w = {twn[k].x, -twn[k].y};                 // conj W_N^k
-        const C2<F> o = cmul(w, d);
-        v[in_slot<PL>(j)] = C2<F>{s.x - o.y, s.y + o.x};       // s + i o
-    }
-    __syncthreads();                                           // everyone has read its partner
+    c2r_prepare<PL, RW, 0>(v, x, xm, lds, twn, tau, c);
     fft_core<PL, +1, RW, false>(v, lds, tw, tau, c);
     if (live) {
         C2<F> *dst = out + (PEN ? ((row / rg.ylr) * rg.prows + row % rg.ylr) * pitch : row * pitch);

@@ -218,12 +218,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads)) void paint_strips_ke
             for (int j = 0; j < E; j++) {
                 const int k = tau + T * j;
                 const C2<F> a = v[j];
-                C2<F> bq = lds[((M - k) % M) * STRIP_Y + c];
-                bq.y = -bq.y;                                          // conj Z[M-k]
-                const C2<F> e = {(a.x + bq.x) * (F) 0.5, (a.y + bq.y) * (F) 0.5};
-                const C2<F> d = {(a.x - bq.x) * (F) 0.5, (a.y - bq.y) * (F) 0.5};
-                const C2<F> o = {d.y, -d.x};                           // d / i
-                st_stream(&dst[k], cadd(e, cmul(twn[k], o)));
+                st_stream(&dst[k], r2c_untangle(a, lds[((M - k) % M) * STRIP_Y + c], twn[k]));
                 if (k == 0) dst[M] = C2<F>{a.x - a.y, 0};              // X[N/2] = Re Z0 - Im Z0
             }
             for (int k = M + 1 + tau; k < g.rp; k += T) dst[k] = C2<F>{0, 0};      // the padding of an aligned row
@@ -277,24 +272,8 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
     // x[] (the half spectrum of RW rows) -> real rows in `slot`, row-major with a pitch of 2 M + 2 values
     // (rowfft_c2r_kernel's arithmetic)
     auto c2r_to = [&](C2<F> *slot) {
-        if (tau == 0) { x[0].y = 0; xm.y = 0; }     // a c2r reads only the real parts of X[0] and X[N/2]
-#pragma unroll
-        for (int j = 0; j < E; j++) slot[lds_pos<RW, SK>(tau + T * j, c)] = x[j];
-        if (tau == 0) slot[lds_pos<RW, SK>(M, c)] = xm;
-        __syncthreads();
         C2<F> v[vmax(E)];
-#pragma unroll
-        for (int j = 0; j < E; j++) {
-            const int k = tau + T * j;
-            const C2<F> a = x[j];
-            C2<F> bq = slot[lds_pos<RW, SK>(M - k, c)];            // X[M-k]  (k = 0 pairs with X[M])
-            bq.y = -bq.y;
-            const C2<F> s = cadd(a, bq), d = csub(a, bq);
-            const C2<F> w = {twn[k].x, -twn[k].y};                 // conj W_N^k
-            const C2<F> o = cmul(w, d);
-            v[in_slot<PL>(j)] = C2<F>{s.x - o.y, s.y + o.x};       // s + i o
-        }
-        __syncthreads();                                           // everyone has read its partner
+        c2r_prepare<PL, RW, SK>(v, x, xm, slot, twn, tau, c);
         fft_core<PL, +1, RW, false, F, SK>(v, slot, tw, tau, c);
 #pragma unroll
         for (int j = 0; j < E; j++) slot[c * RP + tau + T * j] = v[j];
