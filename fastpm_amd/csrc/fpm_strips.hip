@@ -24,7 +24,9 @@
 // the fp64 multiplies cost more than the reads), the y passes of pm_c2r and this kernel on two streams, pipelined over 2 - 16 chunks
 // of x planes (5.20 -> 5.32 - 5.99 ms per force: the kernels compete for the CUs, the chunk launches add tails), ONE plane in
 // LDS (a particle's sum split where the planes change, half sums waiting in registers: 29 KB of LDS, but 168 - 190
-// VGPRs: 1.64 ms at two waves per SIMD, 1.92 ms at three), 8-row strips on that one-plane kernel (1.95 ms).
+// VGPRs: 1.64 ms at two waves per SIMD, 1.92 ms at three), 8-row strips on that one-plane kernel (1.95 ms), all threads of a
+// row in ONE wave with a region of LDS per row, so that the FFT stages need no workgroup barrier at all (2 instead of 8
+// barriers per step, the same modelled bank conflicts: 1.62 -> 1.81 ms).
 //
 // Where the paint's 0.575 ms go (phases compiled out one at a time): LDS atomics + CIC arithmetic 0.19, FFT core 0.165,
 // stores 0.08, the rest (window reads, partner exchange, zeroing, 9 barriers per step, prefetch) 0.15; HBM floor of its
