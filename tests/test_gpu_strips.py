@@ -180,3 +180,29 @@ def test_one_particle_and_no_particles_on_strips(oracle):
     pm.compute_force(st, total_mass=1.0)
     torch.cuda.synchronize()
     pm.destroy()
+
+
+@pytest.mark.parametrize("N,precision", [(384, 64), (512, 64), (640, 32), (768, 32), (800, 32), (1024, 32)])
+def test_largest_strip_meshes_agree_with_box_tiles(N, precision):
+    """Every row length whose window fits (N <= 512 in fp64, <= 1024 in fp32; radix-3 and radix-5 rows among them): the
+    strip path against the box path of the same library (itself held to the oracle at the sizes the oracle can do)."""
+    import torch
+    from fastpm_amd import PM, Store
+    nc, L = 64, 1.5 * N
+    x = util.load_b(nc, L, N, rms_cells=3.0)
+    acc = {}
+    for mode in (BOXES, STRIPS):
+        pm = PM(N, L, precision, paint_mode=mode)
+        assert pm.strips() == (mode == STRIPS)
+        st = Store(x, potential=True)
+        dk = pm.alloc()
+        pm.compute_force(st, kernel="1_4", delta_k=dk)
+        torch.cuda.synchronize()
+        acc[mode] = (st.acc.cpu().numpy(), st.potential.cpu().numpy(), pm.complex_view(dk)[:8, :8, :8].cpu().numpy())
+        pm.destroy()
+        del st, dk
+        torch.cuda.empty_cache()
+    tol = 1e-6 if precision == 64 else 2e-5
+    assert util.rel_err(acc[STRIPS][0], acc[BOXES][0]) <= tol
+    assert util.rel_err(acc[STRIPS][1], acc[BOXES][1]) <= tol
+    assert np.abs(acc[STRIPS][2] - acc[BOXES][2]).max() <= (1e-14 if precision == 64 else 5e-7) * np.abs(acc[BOXES][2]).max()
