@@ -157,6 +157,9 @@ __global__ __launch_bounds__(256) void bin_count_kernel(MeshGeo g, int ntiles, c
 // compiled out).  Only ~0.3 dup entries per particle exist, so: the own entries take one pass per particle slot, the
 // dup entries of the whole block are first compacted into an LDS list (block prefix sum over the per-lane counts) and
 // then take one pass per 256 LIST entries -- 3 passes instead of 16 on a typical block.  Positions wait in LDS.
+// (Round 2 also measured the opposite extreme -- no merging at all, every entry one compare-and-swap + one returning LDS
+// atomic on the block's hash table, entries kept in registers: strip tiles 0.435 -> 0.41 ms, but box tiles, whose dup
+// entries spread over up to 7 keys per particle, 0.475 -> 0.54 ms (load C 0.72 -> 0.82): not adopted.)
 constexpr int BIN_BLOCK = 256 * BIN_PPT;
 
 // DCAP: dup entries a block can list.  The exact path takes the worst case (7 per particle); the steady-state kernel
