@@ -60,7 +60,10 @@ def test_paint(oracle, precision, load):
     got = pm.real_view(cv).cpu().numpy()
     exp = pmo.real_view(ref)
     eps = np.finfo(pmo.F).eps
-    assert np.abs(got[:, :, :N] - exp[:, :, :N]).max() <= 4 * eps * np.abs(exp).max() * (1 if precision == 64 else 8)
+    # (the adds of a cell arrive in another order on every run -- LDS atomics -- and the oracle adds sequentially: on the
+    # clumped load a cell sums hundreds of weights, and 4 eps of the largest cell was measured to be a coin flip
+    # (2.84e-14 against 2.78e-14); 16 eps is still a last-digits bound)
+    assert np.abs(got[:, :, :N] - exp[:, :, :N]).max() <= 16 * eps * np.abs(exp).max() * (1 if precision == 64 else 8)
     assert np.all(got[:, :, N:] == 0)               # z padding cleared
     assert np.isclose(got[:, :, :N].sum(dtype=np.float64), 1.75 * (0.5 * len(x) + mass.sum(dtype=np.float64)), rtol=1e-6)
     pm.destroy()
