@@ -71,6 +71,7 @@ int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets
         FPM_TRY(fpmhip_paint(p, pt, 1.0 / mean_mass_per_cell, canvas));                   // gravity.c:336-345
         for (int si = 1; si < nsets; si++) FPM_TRY(fpmhip_paint_add(p, &sets[si], 1.0 / mean_mass_per_cell, canvas));
     }
+    FPM_TRY(fpmhip_check_point(p, strips_fwd ? delta_k : canvas, "After painting"));          // gravity.c:350
     // x passes around the transfer: from the canvas (z, y passes first) or from the paint's half-spectrum rows
     auto fwd_x = [&](int mode, void *o0, void *o1, void *o2) -> int {
         if (strips_fwd) return strips_y_xfwd_xback(p, delta_k, kernel, mode, o0, o1, o2);
@@ -80,6 +81,17 @@ int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets
         FPM_TRY(fpmhip_r2c(p, canvas, delta_k));                                          // gravity.c:351
         FPM_TRY(fpmhip_softening(p, delta_k, softening));                                 // gravity.c:476
     }
+    // gravity.c:352 "After r2c", :381 / :383 around every c2r: the fused step holds delta_k only after the fused x pass
+    // and the force meshes only right before their readout (strips: before the z pass inside it -- a NaN or an overflow
+    // in a row's half spectrum is one in the row)
+    auto check_meshes = [&](void *m0, void *m1, void *m2) -> int {
+        if (!p->check_hook) return 0;
+        FPM_TRY(fpmhip_check_point(p, delta_k, "After r2c"));
+        void *m[3] = {m0, m1, m2};
+        const char *names[3] = {"After c2r 0", "After c2r 1", "After c2r 2"};
+        for (int d = 0; d < 3; d++) if (m[d]) FPM_TRY(fpmhip_check_point(p, m[d], names[d]));
+        return 0;
+    };
 
     bool any_pot = false;
     for (int si = 0; si < nsets; si++) any_pot = any_pot || sets[si].potential != nullptr;
@@ -93,6 +105,7 @@ int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets
             FPM_TRY(fpmhip_transfer(p, delta_k, canvas, kernel, FPMHIP_FIELD_POTENTIAL));
             FPM_TRY(fpmhip_c2r(p, canvas));
         }
+        FPM_TRY(check_meshes(canvas, nullptr, nullptr));
         for (int si = nsets - 1; si >= 0; si--) FPM_TRY(fpmhip_readout_grad(p, &sets[si], canvas, nullptr));
         for (int si = 0; si < nsets; si++)                                                // gravity.c:487-492
             if (sets[si].potential) FPM_TRY(fpmhip_readout1(p, &sets[si], canvas, sets[si].potential, 1, 0));
@@ -116,6 +129,7 @@ int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets
         if (strips) {
             FPM_TRY(strips_y_backward(p, f[0]));
             FPM_TRY(strips_y_backward_grad2(p, f[1], f[1], f[2], potmesh, go));
+            FPM_TRY(check_meshes(f[0], f[1], f[2]));
             for (int si = nsets - 1; si >= 0; si--)
                 FPM_TRY(readout_strips_zc2r(p, &sets[si], f[0], f[1], f[2], 3, sets[si].acc, 3, 0));
             for (int si = 0; si < nsets; si++)
@@ -126,6 +140,7 @@ int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets
         FPM_TRY(fpmhip_fft_yz_backward(p, f[0], f[0]));
         FPM_TRY(fpmhip_fft_yz_backward_grad2(p, f[1], f[1], f[2], potmesh, kernel));
         if (any_pot) {
+            FPM_TRY(check_meshes(f[0], f[1], f[2]));
             for (int si = nsets - 1; si >= 0; si--) FPM_TRY(fpmhip_readout3(p, &sets[si], f[0], f[1], f[2]));
             for (int si = 0; si < nsets; si++)
                 if (sets[si].potential) FPM_TRY(fpmhip_readout1(p, &sets[si], potmesh, sets[si].potential, 1, 0));
@@ -137,6 +152,7 @@ int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets
         else FPM_TRY(fpmhip_transfer_fft_x_backward3(p, delta_k, f[0], f[1], f[2], kernel));
         if (strips) {
             for (int d = 0; d < 3; d++) FPM_TRY(strips_y_backward(p, f[d]));
+            FPM_TRY(check_meshes(f[0], f[1], f[2]));
             for (int si = nsets - 1; si >= 0; si--)
                 FPM_TRY(readout_strips_zc2r(p, &sets[si], f[0], f[1], f[2], 3, sets[si].acc, 3, 0));
         } else {
@@ -149,8 +165,10 @@ int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets
         }
     }
     // with several species the last paint's binning belongs to the last one: read that one first
-    if (!strips)
+    if (!strips) {
+        FPM_TRY(check_meshes(f[0], f[1], f[2]));
         for (int si = nsets - 1; si >= 0; si--) FPM_TRY(fpmhip_readout3(p, &sets[si], f[0], f[1], f[2]));
+    }
     if (any_pot) {                                                                        // gravity.c:487-492
         FPM_TRY(fpmhip_transfer(p, delta_k, canvas, kernel, FPMHIP_FIELD_POTENTIAL));
         FPM_TRY(fpmhip_c2r(p, canvas));
@@ -214,7 +232,18 @@ int fpmhip_force_species_host(fpmhip_plan *p, const fpmhip_particles *sets, int 
         off += ph.np;
     }
     FPM_TRY(ensure_buffer(p, BUF_DELTA_K));
-    FPM_TRY(fpmhip_force_species(p, pd, nsets, kernel, softening, -1.0, p->buf[BUF_DELTA_K]));
+    // The steady-state binning reports what only the device knows (a slab overflow beyond the arrays, a particle outside
+    // the rank's region) AFTER its call returned; this entry point synchronises anyway, so it asks here -- the caller
+    // reads acc on the host next, and an invalid result must not leave with rc = 0.  One overflow is repaired in place:
+    // the arrays grow (check_deferred left the size) and the step runs again.
+    for (int attempt = 0; ; attempt++) {
+        FPM_TRY(fpmhip_force_species(p, pd, nsets, kernel, softening, -1.0, p->buf[BUF_DELTA_K]));
+        FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
+        const int rc = fpm::check_deferred(p, true);
+        if (rc == -5 && attempt == 0) continue;
+        if (rc != 0) return rc;
+        break;
+    }
     for (int si = 0; si < nsets; si++) {
         const fpmhip_particles &ph = sets[si];
         if (ph.np == 0) continue;

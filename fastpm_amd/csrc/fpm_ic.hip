@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64) void fill_gadget_kernel(MeshGeo g, const unsign
         if (ci == i && cj == j && (k == 0 || k == half)) im = 0;                     // self-conjugate modes are real
         if (i == 0 && j == 0 && k == 0) { re = 0; im = 0; }
         const int kl = k - g.zstart;                         // a pencil keeps its kz block of the column (all of it on slabs)
-        if (kl >= 0 && kl < g.nzl) {
+        if (kl >= 0 && kl < g.nzv) {
             row[2 * kl] = (F) re;
             row[2 * kl + 1] = (F) im;
         }
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void induce_correlation_kernel(MeshGeo g, cons
     const int rem = blockIdx.x * blockDim.x + threadIdx.x;
     if (rem >= g.yl * g.nzl) return;
     const int iyl = rem / g.nzl, izl = rem - iyl * g.nzl, iz = izl + g.zstart;
-    if (iz >= g.nzc) return;                                  // row padding / the padding of a pencil's last kz block
+    if (izl >= g.nzv) return;                                 // row padding
     const int iy = iyl + g.ystart;
     const long long ind = ((long long) ix * g.yl + iyl) * g.nzl + izl;
     double k2 = 0;

@@ -70,8 +70,10 @@ struct MeshGeo {
     int yl;            // local ky rows in k space (N / Nproc[0])
     int ystart;
     int nzc;           // N/2 + 1
-    int nzl;           // local kz entries = the k-space row pitch: nzc on slabs, ceil(nzc / Nproc[1]) on pencils
-    int zstart;        // first global kz of this rank
+    int nzl;           // the k-space row pitch: >= nzc on slabs, >= zblk on pencils (rows padded to whole 128-byte lines)
+    int zstart;        // first global kz of this rank = rank_y * zblk
+    int zblk;          // kz modes per rank: nzc on slabs, PFFT's default block ceil(nzc / Nproc[1]) on pencils
+    int nzv;           // modes this rank's rows hold: min(zblk, nzc - zstart); entries [nzv, nzl) of a row are padding
     int ylr;           // local y rows of the real mesh (N / Nproc[1])
     int yrstart;       // first global y row
     int yplanes;       // rows present in a real plane: ylr + y halo
@@ -174,6 +176,9 @@ struct fpmhip_plan {
     // host callback at the boundaries of the top-level stages (fpmhip_set_stage_hook)
     void (*stage_hook)(void *ctx, int stage, int enter) = nullptr;
     void *stage_hook_ctx = nullptr;
+    // pm_check_values at the reference's points (fpmhip_set_check_hook / fpmhip_check_point)
+    void (*check_hook)(void *ctx, const char *label, int64_t count) = nullptr;
+    void *check_hook_ctx = nullptr;
     // timing
     bool timing = false;
     std::vector<fpm::EventPair> ev_used;

@@ -18,14 +18,14 @@ template <typename F> struct Cplx { F re, im; };
 static inline unsigned blocks_for(long long n, int bs) { return (unsigned) ((n + bs - 1) / bs); }
 
 // grid: x = blocks over the (y_loc, kz) plane, y = ix.  Decodes the plane index.
-// (row pitch nzl, global kz = local + zstart; the padding entries of a pencil's last kz block are left alone)
+// (row pitch nzl, global kz = local + zstart; the padding entries [nzv, nzl) of a row are left alone)
 #define KSPACE_INDEX(g)                                                         \
     const int ix = blockIdx.y;                                                  \
     const int rem = blockIdx.x * blockDim.x + threadIdx.x;                      \
     if (rem >= (g).yl * (g).nzl) return;                                        \
     const int iyl = rem / (g).nzl, izl = rem - iyl * (g).nzl;                   \
     const int iy = iyl + (g).ystart, iz = izl + (g).zstart;                     \
-    if (iz >= (g).nzc) return;                                                  \
+    if (izl >= (g).nzv) return;                                                 \
     const long long ind = ((long long) ix * (g).yl + iyl) * (g).nzl + izl;      \
     (void) iy; (void) iz;
 
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void power_kernel(MeshGeo g, double k0, Cplx<F
     for (int rem = blockIdx.x * blockDim.x + threadIdx.x; rem < plane; rem += gridDim.x * blockDim.x) {
         const int iyl = rem / g.nzl, izl = rem - iyl * g.nzl;
         const int iy = iyl + g.ystart, iz = izl + g.zstart;
-        if (iz >= g.nzc) continue;
+        if (izl >= g.nzv) continue;
         const long long ind = ((long long) ix * g.yl + iyl) * g.nzl + izl;
         long long kk = 0;
         int ik = ix; if (ik > N / 2) ik -= N; kk += (long long) ik * ik;
@@ -560,6 +560,26 @@ int fpmhip_check_values(fpmhip_plan *p, const void *mesh, int64_t *count)
     FPM_CHECK_HIP(hipMemcpyAsync(p->h_pinned, d, sizeof(*d), hipMemcpyDeviceToHost, p->stream));
     FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
     *count = (int64_t) * (unsigned long long *) p->h_pinned;
+    return 0;
+}
+
+// pm_check_values at the points gravity.c:350, 352, 381, 383 has them: with a hook set, a check point counts the NaN /
+// |v| > 1e15 entries of the mesh the step holds there and reports (label, count); without one it costs nothing.
+int fpmhip_set_check_hook(fpmhip_plan *p, void (*hook)(void *ctx, const char *label, int64_t count), void *ctx)
+{
+    if (!p) FPM_FAIL(-1, "null plan");
+    p->check_hook = hook;
+    p->check_hook_ctx = ctx;
+    return 0;
+}
+
+int fpmhip_check_point(fpmhip_plan *p, const void *mesh, const char *label)
+{
+    if (!p) FPM_FAIL(-1, "null plan");
+    if (!p->check_hook || !mesh) return 0;
+    int64_t n = 0;
+    FPM_TRY(fpmhip_check_values(p, mesh, &n));
+    p->check_hook(p->check_hook_ctx, label ? label : "", n);
     return 0;
 }
 

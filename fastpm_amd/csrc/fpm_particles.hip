@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(MeshGeo g, int ntiles,
                                                           double *__restrict__ sx, double *__restrict__ sy,
                                                           double *__restrict__ sz, float *__restrict__ smass,
                                                           int *__restrict__ sidx, int *__restrict__ flags,
-                                                          const int *__restrict__ pred)
+                                                          const int *__restrict__ pred, long long alloc)
 {
     if (pred && *pred == 0) return;
     extern __shared__ __align__(16) unsigned char smem_bin[];
@@ -299,7 +299,9 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(MeshGeo g, int ntiles,
         // 5. stores
         auto put = [&](int key, int res, int pid) {
             const int lslot = (res >> 21) - 1, local = (res & ((1 << 21) - 1)) + (lslot >= 0 ? L.agg.base[lslot] : 0);
-            if (local < cap[key]) {
+            // (a hard overflow lays the slabs out past the end of the arrays -- FLAG_HARD_OVF is up, the call's result is
+            // declared invalid and the arrays grow; nothing may be written out of bounds meanwhile)
+            if (local < cap[key] && (long long) beg[key] + local < alloc) {
                 const int slot = beg[key] + local;
                 sx[slot] = L.x[pid]; sy[slot] = L.y[pid]; sz[slot] = L.z[pid];
                 if (smass) smass[slot] = L.m[pid];
@@ -330,7 +332,8 @@ __global__ __launch_bounds__(256) void slab_caps_kernel(const int *__restrict__ 
         flags[FLAG_TOTAL] = (int) total;
         if (total > alloc) flags[FLAG_HARD_OVF] = 1;
     }
-    if (k < nkeys) capv[k] = slack ? cnt[k] + cnt[k] / 4 + 32 : cnt[k];
+    // more entries than the arrays hold at all: every slab is empty, the scatter stores nothing, the binning is void
+    if (k < nkeys) capv[k] = total > alloc ? 0 : (slack ? cnt[k] + cnt[k] / 4 + 32 : cnt[k]);
     if (k == nkeys) capv[k] = 0;
 }
 
@@ -387,11 +390,12 @@ __global__ __launch_bounds__(1024) void layout_one_block_kernel(int *__restrict_
     }
     const bool slack = total + total / 4 + 33ll * nkeys <= alloc;
     long long s2 = 0;
-    for (int k = k0; k < k1; k++) s2 += slack ? cnt[k] + cnt[k] / 4 + 32 : cnt[k];
+    const bool hard = total > alloc;            // every slab empty: the scatter stores nothing (see slab_caps_kernel)
+    for (int k = k0; k < k1; k++) s2 += hard ? 0 : (slack ? cnt[k] + cnt[k] / 4 + 32 : cnt[k]);
     run = block_exclusive(s2);
     const long long total2 = total_s;
     for (int k = k0; k < k1; k++) {
-        const int c = slack ? cnt[k] + cnt[k] / 4 + 32 : cnt[k];
+        const int c = hard ? 0 : (slack ? cnt[k] + cnt[k] / 4 + 32 : cnt[k]);
         beg[k] = (int) run;
         cap[k] = c;
         run += c;
@@ -422,8 +426,8 @@ __global__ __launch_bounds__(256) void tile_order_kernel(int ntiles, const int *
 
 // Is the binning the plan holds still the binning of THESE positions?  One entry of every non-empty own tile is
 // compared, bit for bit, with the row it was copied from: any wholesale change of the positions behind the same pointer
-// (an in-place update, a new tensor at a recycled address) trips it, and the exact path enqueued behind it rebins in the
-// same stream.  (A caller that edits rows in place calls fpmhip_invalidate_binning.)
+// (an in-place update, a new tensor at a recycled address) trips FLAG_STALE, which is reported (-7) when it arrives: the
+// readout that reused the binning is void.  (A caller that edits rows in place calls fpmhip_invalidate_binning.)
 __global__ __launch_bounds__(256) void verify_binning_kernel(int ntiles, const int *__restrict__ beg, const int *__restrict__ cnt,
                                                              const double *__restrict__ sx, const double *__restrict__ sy,
                                                              const double *__restrict__ sz, const int *__restrict__ sidx,
@@ -1071,7 +1075,10 @@ static int bin_full(fpmhip_plan *p, const fpmhip_particles *pt, const int *pred)
     if (np > 0)
         bin_scatter_kernel<false, true><<<nb, 256, sizeof(ScatterLds<dup_cap<true>()>), p->stream>>>(
             p->mg, nt, pt->x, pt->mass, np, nullptr, p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
-            pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, pred);
+            pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, pred, (long long) p->bin_alloc);
+    // a hard overflow (more entries than the arrays hold): the cursors ran past slabs that hold nothing -- the kernels
+    // that consume the binning (paint, readout, tile order) must find empty tiles, not counts without entries
+    zero_ints_kernel<<<blocks_for(nkeys + 1, 256), 256, 0, p->stream>>>(p->bin_cnt, nkeys + 1, p->d_flags + FLAG_HARD_OVF);
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1096,6 +1103,8 @@ int check_deferred(fpmhip_plan *p, bool wait)
     p->flags_pending = false;
     const int *f = p->h_flags;
     const int unowned = f[FLAG_NEED_FULL] ? f[FLAG_UNOWNED_FULL] : f[FLAG_UNOWNED_FAST];
+    // after any of these the tile order of that binning is incomplete (rows were dropped): the next call must not walk it
+    if (unowned != 0 || f[FLAG_STALE] != 0 || f[FLAG_HARD_OVF] != 0) p->layout_np = -1;
     if (unowned != 0)
         FPM_FAIL(-6, "%d particles are outside this rank's region x [%d, %d), y [%d, %d): decompose before the force "
                      "(reference solver.c:449)", unowned, p->mg.xstart, p->mg.xstart + p->mg.xl, p->mg.yrstart,
@@ -1108,7 +1117,8 @@ int check_deferred(fpmhip_plan *p, bool wait)
     }
     if (f[FLAG_HARD_OVF] != 0) {
         p->bin_grow = std::max<int64_t>(p->bin_grow, (int64_t) f[FLAG_TOTAL] + f[FLAG_TOTAL] / 2);
-        p->layout_np = -1;
+        p->binned_np = -1;
+        p->binned_x = nullptr;
         FPM_FAIL(-5, "the tile binning of an earlier force call needed %d entries for %lld particles, more than the plan "
                      "held (%lld): that call's result is invalid; the arrays grow on the next call", f[FLAG_TOTAL],
                  (long long) p->binned_np, (long long) p->bin_alloc);
@@ -1124,11 +1134,24 @@ static int post_flags(fpmhip_plan *p, bool wait)
     return check_deferred(p, wait);
 }
 
+static int bin_particles_once(fpmhip_plan *p, const fpmhip_particles *pt, bool *waited);
+
 int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt)
 {
     // the flags of the PREVIOUS binning must be read before this one overwrites them: waits for that binning (one
     // call back in the stream), never for work enqueued since
     FPM_TRY(check_deferred(p, true));
+    bool waited = false;
+    int rc = bin_particles_once(p, pt, &waited);
+    // a binning whose flags were awaited (the first one of a particle set) and that needed more entries than the
+    // arrays hold is redone at once with larger arrays (check_deferred left the wanted size in bin_grow): the caller
+    // never sees the overflow.  Lazily reported ones (steady state) surface in the next call / fpmhip_sync.
+    if (rc == -5 && waited) rc = bin_particles_once(p, pt, &waited);
+    return rc;
+}
+
+static int bin_particles_once(fpmhip_plan *p, const fpmhip_particles *pt, bool *waited)
+{
     StageTimer tm(p, FPMHIP_T_SORT);
     const long long np = pt->np;
     const int nt = p->ntiles, nkeys = 2 * nt;
@@ -1151,11 +1174,11 @@ int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt)
         if (ordered)
             bin_scatter_kernel<true, false><<<blocks_for(np, BIN_BLOCK), 256, sizeof(ScatterLds<dup_cap<false>()>), p->stream>>>(
                 p->mg, nt, pt->x, pt->mass, np, p->order[1], p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
-                pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, nullptr);
+                pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, nullptr, (long long) p->bin_alloc);
         else
             bin_scatter_kernel<false, false><<<blocks_for(np, BIN_BLOCK), 256, sizeof(ScatterLds<dup_cap<false>()>), p->stream>>>(
                 p->mg, nt, pt->x, pt->mass, np, nullptr, p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
-                pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, nullptr);
+                pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, nullptr, (long long) p->bin_alloc);
         pred = p->d_flags + FLAG_NEED_FULL;          // the exact path below runs only if a slab overflowed
     } else {
         FPM_CHECK_HIP(hipMemsetAsync(p->d_flags + FLAG_NEED_FULL, 1, 1, p->stream));    // = 1: the exact path is the one that ran
@@ -1167,6 +1190,7 @@ int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt)
     p->binned_np = np;
     p->layout_np = np;
     // the first binning of a particle set reports its errors at once; later ones when their flags arrive
+    *waited = !have_layout;
     return post_flags(p, !have_layout);
 }
 

@@ -220,7 +220,11 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
                          rowfft_supported((int) N);
     const int align = aligned ? 8 : 1;                                              // complex doubles per 128-B line
     const int rp = (nzc + align - 1) / align * align;                               // real rows, in complex units
-    const int nzl = Ny == 1 ? rp : ((nzc + Ny - 1) / Ny + align - 1) / align * align;   // kz block, the last one padded
+    // Pencils: the kz axis is cut into PFFT's default blocks of zblk = ceil(nzc / Ny) MODES (what pm->ORegion says on
+    // the reference side: rank ry holds kz in [ry * zblk, min(nzc, (ry + 1) * zblk))); the rows that hold a block are
+    // padded to whole 128-byte lines (pitch nzl >= zblk) -- the pitch is ours, the split is the reference's.
+    const int zblk = Ny == 1 ? nzc : (nzc + Ny - 1) / Ny;
+    const int nzl = Ny == 1 ? rp : (zblk + align - 1) / align * align;
     const int hx = Nx > 1 ? 1 : 0, hy = Ny > 1 ? 1 : 0;
     fpmhip_layout &L = p->lay;
     memset(&L, 0, sizeof(L));
@@ -237,9 +241,9 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
     L.istart[0] = (int64_t) rx * xl; L.istart[1] = (int64_t) ry * ylr; L.istart[2] = 0;
     L.isize[0] = xl; L.isize[1] = ylr; L.isize[2] = N;
     L.istrides[0] = L.plane_elems; L.istrides[1] = 2 * rp; L.istrides[2] = 1;
-    L.ostart[0] = 0; L.ostart[1] = (int64_t) rx * yl; L.ostart[2] = (int64_t) ry * nzl;
+    L.ostart[0] = 0; L.ostart[1] = (int64_t) rx * yl; L.ostart[2] = (int64_t) ry * zblk;
     L.osize[0] = N; L.osize[1] = yl; L.osize[2] = nzl;
-    L.ovalid_z = std::max<int64_t>(0, std::min<int64_t>(nzl, nzc - (int64_t) ry * nzl));
+    L.ovalid_z = std::max<int64_t>(0, std::min<int64_t>(zblk, nzc - (int64_t) ry * zblk));
     L.ostrides[0] = (int64_t) yl * nzl; L.ostrides[1] = nzl; L.ostrides[2] = 1;
     L.real_elems = (xl + hx) * L.plane_elems;
     L.complex_elems = N * (int64_t) yl * nzl;
@@ -252,7 +256,7 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
     MeshGeo &g = p->mg;
     g.N = (int) N; g.xl = xl; g.xstart = rx * xl; g.xplanes = xl + hx;
     g.periodic_x = Nx == 1; g.yl = yl; g.ystart = rx * yl; g.nzc = nzc;
-    g.nzl = nzl; g.zstart = ry * nzl;
+    g.nzl = nzl; g.zstart = ry * zblk; g.zblk = zblk; g.nzv = (int) L.ovalid_z;
     g.ylr = ylr; g.yrstart = ry * ylr; g.yplanes = ylr + hy; g.periodic_y = Ny == 1;
     g.str0 = L.plane_elems; g.str1 = 2 * rp; g.rp = rp;
     g.inv_cell = 1.0 / (geom->BoxSize / N);

@@ -47,7 +47,8 @@ __device__ __forceinline__ int row_block(int b, int n, int order)
 struct RowGeo {
     long long pitch;     // complex units between consecutive rows of the real mesh (= N/2 + 1)
     int ylr, prows;      // rows per x plane that are transformed / present
-    int nzl;             // kz entries per exchange chunk
+    int nzl;             // row pitch of the exchange chunks
+    int zblk;            // kz modes per exchange chunk (entries [zblk, nzl) of a chunk row are padding)
     long long chunk;     // complex units per exchange chunk
     int order;           // row_block()
 };
@@ -80,7 +81,7 @@ __global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_r2c_kernel(co
     for (int j = 0; j < E; j++) lds[(tau + T * j) * RW + c] = v[j];
     __syncthreads();
     C2<F> *dst = out + (PEN ? row * rg.nzl : row * pitch);
-    auto at = [&](int k) -> C2<F> & { return PEN ? dst[(k / rg.nzl) * rg.chunk + k % rg.nzl] : dst[k]; };
+    auto at = [&](int k) -> C2<F> & { return PEN ? dst[(k / rg.zblk) * rg.chunk + k % rg.zblk] : dst[k]; };
 #pragma unroll
     for (int j = 0; j < E; j++) {
         const int k = tau + T * j;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_c2r_kernel(co
     const long long row = (long long) row_block(blockIdx.x, gridDim.x, rg.order) * RW + c;
     const bool live = row < nrows;
     const C2<F> *src = in + (PEN ? row * rg.nzl : row * pitch);
-    auto at = [&](int k) -> C2<F> { return ld_stream(PEN ? &src[(k / rg.nzl) * rg.chunk + k % rg.nzl] : &src[k]); };
+    auto at = [&](int k) -> C2<F> { return ld_stream(PEN ? &src[(k / rg.zblk) * rg.chunk + k % rg.zblk] : &src[k]); };
     C2<F> x[E];
 #pragma unroll
     for (int j = 0; j < E; j++) x[j] = live ? at(tau + T * j) : C2<F>{0, 0};
@@ -162,7 +163,7 @@ bool rowfft_supported(int N)
 static RowGeo row_geo(const fpmhip_plan *p, int order)
 {
     const MeshGeo &g = p->mg;
-    return RowGeo{(long long) g.rp, g.ylr, g.yplanes, g.nzl, (long long) g.xl * g.ylr * g.nzl, order};
+    return RowGeo{(long long) g.rp, g.ylr, g.yplanes, g.nzl, g.zblk, (long long) g.xl * g.ylr * g.nzl, order};
 }
 
 template <typename F>

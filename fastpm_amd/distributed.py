@@ -76,6 +76,15 @@ class _SlabRank:
             from .lib import FastPMHipError
             raise FastPMHipError("another rank failed in this stage of the force step")
 
+    late_check = True
+
+    def _late_agreement(self):
+        """What only the device knows about a steady-state step's binning (a particle outside the rank's region, a slab
+        overflow) is reported after the paint's agreement point: synchronise, ask, and agree once more at the end of the
+        step -- no rank leaves with an invalid acc while its peers carry on into the next collective."""
+        if self.late_check and self.P > 1:
+            self.run(self._agreed(getattr(self.pm, "sync", lambda: None)))
+
     def _communicate(self, req):
         kind = req[0]
         g = self.group
@@ -409,6 +418,7 @@ class SlabForce(_SlabRank):
     # -- execution over torch.distributed -------------------------------------------------------
     def compute_force(self, store, kernel="1_4", dealias="none", delta_k=None):
         self.run(self.steps(store, kernel, dealias, delta_k))
+        self._late_agreement()
         return delta_k if delta_k is not None else self.delta_k
 
 
@@ -594,6 +604,7 @@ class PencilForce(_PencilRank):
 
     def compute_force(self, store, kernel="1_4", dealias="none", delta_k=None):
         self.run(self.steps(store, kernel, dealias, delta_k))
+        self._late_agreement()
         return delta_k if delta_k is not None else self.delta_k
 
 

@@ -11,6 +11,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "fastpm_gravity_hip.h"
 
@@ -44,6 +45,7 @@ int main(int argc, char **argv)
     cdm.x = x;
     cdm.acc = acc;
     cdm.meta.M0 = 1.0;
+    strcpy(cdm.name, "1");                                      /* the CDM store's name in the reference's log lines */
     FastPMSolverView solver = {0};
     solver.species[FASTPM_SPECIES_CDM] = &cdm;
     solver.has_species[FASTPM_SPECIES_CDM] = 1;

@@ -3,6 +3,7 @@
  * libfastpm/gravity.c.  No arithmetic happens here: it checks what the reference checks, marshals
  * the store columns into the C-ABI call and maps errors to the reference's raise-and-abort.
  */
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -13,8 +14,9 @@
 static void default_handler(int code, const char *message, void *userdata)
 {
     (void) userdata;
+    if (code == 0) { fputs(message, stdout); return; }         /* fastpm_info: a log line (logging.c:73-99) */
     fprintf(stderr, "fastpm_hip raise(%d): %s\n", code, message);
-    if (code != 0) abort();                                   /* logging.c:100-103 */
+    abort();                                                   /* logging.c:100-103 */
 }
 
 static fpm_msg_handler g_handler = default_handler;
@@ -83,6 +85,35 @@ void fastpm_kernel_type_get_orders_hip(FastPMKernelType type, int *potorder, int
         fpm_raise(-1, "Wrong kernel type\n");                  /* gravity.c:169 */
 }
 
+/* fastpm_store_summary(p, COLUMN_ACC, comm, "<s->", ...) for one rank (store.c:807-908): host code in the reference,
+ * host code here -- the acc column has just arrived in host memory. */
+static void acc_summary(const FastPMStoreView *p, double *amin, double *astd, double *amean, double *amax)
+{
+    double rmin[3] = {1e20, 1e20, 1e20}, rmax[3] = {-1e20, -1e20, -1e20}, s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
+    for (size_t i = 0; i < p->np; i++)
+        for (int d = 0; d < 3; d++) {
+            const double v = p->acc[i][d];
+            s1[d] += v;
+            s2[d] += v * v;
+            rmin[d] = fmin(rmin[d], v);
+            rmax[d] = fmax(rmax[d], v);
+        }
+    const double n = (double) p->np;
+    for (int d = 0; d < 3; d++) {
+        amin[d] = rmin[d];
+        amax[d] = rmax[d];
+        amean[d] = s1[d] / n;
+        astd[d] = sqrt(s2[d] / n - pow(s1[d] / n, 2));
+    }
+}
+
+static void check_line(void *ctx, const char *label, int64_t count)      /* pmapi.c:335-356 */
+{
+    const PMView *pm = ctx;
+    if (count != 0)
+        fpm_raise_hip(0, "%s: Task %d has %td field values that are out of bounds\n", label, pm->ThisTask, (ptrdiff_t) count);
+}
+
 void fastpm_solver_compute_force_hip(FastPMSolverView *fastpm, PMView *pm, FastPMPainterView *painter,
                                      FastPMSofteningType dealias, FastPMKernelType kernel,
                                      void *delta_k, double Time)
@@ -109,5 +140,24 @@ void fastpm_solver_compute_force_hip(FastPMSolverView *fastpm, PMView *pm, FastP
         fpm_raise(-1, "no particle species in the solver\n");
         return;
     }
-    HIP_OR_RAISE(fpmhip_force_species_host(pm->plan, parts, nspecies, (int) kernel, (int) dealias, delta_k));
+    {
+        const char *e = getenv("FASTPM_HIP_CHECK_VALUES");      /* gravity.c:350, 352, 381, 383 */
+        if (!e || atoi(e) != 0) fpmhip_set_check_hook(pm->plan, check_line, pm);
+    }
+    const int rc = fpmhip_force_species_host(pm->plan, parts, nspecies, (int) kernel, (int) dealias, delta_k);
+    fpmhip_set_check_hook(pm->plan, NULL, NULL);
+    HIP_OR_RAISE(rc);
+    /* gravity.c:398-417: the ghost block has no counterpart (the mesh halo already brought the ghosts' share home), the
+     * local block and the "+g" block print the same, final, numbers -- as they do in the reference, which summarises
+     * p twice before pm_ghosts_reduce */
+    for (int si = 0; si < FASTPM_SOLVER_NSPECIES; si++) {
+        if (!fastpm->has_species[si] || !fastpm->species[si]) continue;
+        const FastPMStoreView *p = fastpm->species[si];
+        double acc_std[3], acc_mean[3], acc_min[3], acc_max[3];
+        acc_summary(p, acc_min, acc_std, acc_mean, acc_max);
+        for (int d = 0; d < 3; d++)
+            fpm_raise_hip(0, "p%s    acc[%d]: %g %g %g %g\n", p->name, d, acc_min[d], acc_std[d], acc_mean[d], acc_max[d]);
+        for (int d = 0; d < 3; d++)
+            fpm_raise_hip(0, "p%s+g  acc[%d]: %g %g %g %g\n", p->name, d, acc_min[d], acc_std[d], acc_mean[d], acc_max[d]);
+    }
 }

@@ -41,6 +41,7 @@ typedef struct {
     float *potential;          /* NULL unless the column is allocated (gravity.c:490) */
     float *mass;               /* NULL -> every particle weighs meta.M0 (store.c:119-128) */
     struct { double M0; } meta;
+    char name[32];             /* store.h:75: the species' name in the log lines ("1" for CDM: FASTPM_SPECIES_CDM) */
 } FastPMStoreView;
 
 /* struct PM as the path sees it (pmpfft.h:43-70) + the GPU plan made at pm_init time */
@@ -75,7 +76,10 @@ void fastpm_kernel_type_get_orders_hip(FastPMKernelType type, int *potorder, int
                                        int *difforder, int *deconvolveorder);
 /* Same arguments and effects as fastpm_solver_compute_force (gravity.c:457-529): overwrites
  * species->acc (and ->potential when the CDM store has that column), fills delta_k (host,
- * pm->allocsize FastPMFloat, reference ORegion layout) with delta(k)/N^3 after softening. */
+ * pm->allocsize FastPMFloat, reference ORegion layout) with delta(k)/N^3 after softening; the log side effects too:
+ * per species the lines `p%s    acc[%d]: min std mean max` and `p%s+g  acc[%d]: ...` of gravity.c:402-417 (through
+ * the message handler, code 0 = fastpm_info) and, unless FASTPM_HIP_CHECK_VALUES=0, pm_check_values' line
+ * `<label>: Task %d has %td field values that are out of bounds` (pmapi.c:335-356) where a mesh holds NaN / overflow. */
 void fastpm_solver_compute_force_hip(FastPMSolverView *fastpm, PMView *pm, FastPMPainterView *painter,
                                      FastPMSofteningType dealias, FastPMKernelType kernel,
                                      void *delta_k, double Time);

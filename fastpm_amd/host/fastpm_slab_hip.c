@@ -62,6 +62,15 @@ static int readout_species(fpmhip_plan *plan, const fpmhip_particles *sets, int 
 static int slab_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *sets, int nsets,
                               int kernel, int softening, void *delta_k);
 
+/* pm_check_values "After r2c" and "After c2r %d" (gravity.c:352, 383) on what the fused step holds before the readout */
+static int check_force_meshes(fpmhip_plan *plan, void *delta_k, void *const *f)
+{
+    static const char *names[3] = {"After c2r 0", "After c2r 1", "After c2r 2"};
+    TRY(fpmhip_check_point(plan, delta_k, "After r2c"));
+    for (int d = 0; d < 3; d++) TRY(fpmhip_check_point(plan, f[d], names[d]));
+    return 0;
+}
+
 int fastpm_hip_slab_force(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *p,
                           int kernel, int softening, void *delta_k)
 {
@@ -94,6 +103,7 @@ static int slab_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, 
     void *tmp = work;                                           /* free until the forward transform */
     TRY(shift(plan, t, canvas, xl, 1, tmp, +1, plane_bytes));
     TRY(fpmhip_plane_add(plan, fpmhip_plane_ptr(plan, canvas, 0), tmp));
+    TRY(fpmhip_check_point(plan, canvas, "After painting"));     /* gravity.c:350 (no-ops without a check hook) */
 
     /* gravity.c:351 pm_r2c, gravity.c:476 softening */
     TRY(fpmhip_fft_yz_forward(plan, canvas, work));
@@ -141,6 +151,7 @@ static int slab_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, 
             for (int d = 0; d < 3; d++)
                 TRY(shift(plan, t, f[d], 0, 1, fpmhip_plane_ptr(plan, f[d], xl), -1, plane_bytes));
             TRY(shift(plan, t, potmesh, 0, 1, fpmhip_plane_ptr(plan, potmesh, xl), -1, plane_bytes));
+            TRY(check_force_meshes(plan, delta_k, f));
             TRY(readout_species(plan, sets, nsets, f[0], f[1], f[2]));
             for (int si = 0; si < nsets; si++)
                 if (sets[si].potential) TRY(fpmhip_readout1(plan, &sets[si], potmesh, sets[si].potential, 1, 0));
@@ -160,6 +171,7 @@ static int slab_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, 
     }
     for (int d = 0; d < 3; d++)
         TRY(shift(plan, t, f[d], 0, 1, fpmhip_plane_ptr(plan, f[d], xl), -1, plane_bytes));
+    TRY(check_force_meshes(plan, delta_k, f));
     TRY(readout_species(plan, sets, nsets, f[0], f[1], f[2]));
     if (any_pot) {                                              /* gravity.c:487-492 */
         TRY(fpmhip_transfer(plan, delta_k, f[0], kernel, FPMHIP_FIELD_POTENTIAL));
@@ -262,6 +274,7 @@ static int pencil_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t
 
     TRY(paint_species(plan, t, sets, nsets, lay->Norm, c));                       /* gravity.c:323-345 */
     TRY(halo_out(plan, t, &g, lay, c, w[3]));
+    TRY(fpmhip_check_point(plan, c, "After painting"));                           /* gravity.c:350 */
     TRY(fpmhip_fft_z_forward(plan, c, w[0]));                                     /* gravity.c:351 pm_r2c */
     TRY(exchange_axis(plan, t, &g, 0, w[0], w[1], a_bytes));
     TRY(fpmhip_fft_y_forward(plan, w[1], w[0]));
@@ -317,6 +330,7 @@ static int pencil_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t
     }
     for (int d = 0; d < 4; d++)
         if (mesh[d]) TRY(halo_in(plan, t, &g, lay, mesh[d], w[3]));
+    TRY(check_force_meshes(plan, delta_k, mesh));
     TRY(readout_species(plan, sets, nsets, mesh[0], mesh[1], mesh[2]));
     for (int si = 0; si < nsets && mesh[3]; si++)
         if (sets[si].potential) TRY(fpmhip_readout1(plan, &sets[si], mesh[3], sets[si].potential, 1, 0));
@@ -330,8 +344,18 @@ int fastpm_hip_mesh_force_species(fpmhip_plan *plan, const fastpm_hip_transport 
     fpmhip_layout lay;
     TRY(fpmhip_plan_layout(plan, &lay));
     if (lay.nranks != t->nranks || lay.rank != t->rank) return -1;
-    if (lay.nranks_y > 1) return pencil_force_species(plan, t, &lay, sets, nsets, kernel, softening, delta_k);
-    return slab_force_species(plan, t, sets, nsets, kernel, softening, delta_k);
+    int rc = lay.nranks_y > 1 ? pencil_force_species(plan, t, &lay, sets, nsets, kernel, softening, delta_k)
+                              : slab_force_species(plan, t, sets, nsets, kernel, softening, delta_k);
+    if (lay.nranks > 1 && rc == 0) {
+        /* What only the device knows about this step's binning (a particle outside the rank's region on a steady-state
+         * step, a slab overflow) arrives after the paint's agreement point: ask for it now and agree again, so that no
+         * rank leaves with rc = 0 and an invalid acc while its peers carry on into the next collective.  (A nonzero rc
+         * here was agreed on in the paint: every rank has one.) */
+        const int late = fpmhip_sync(plan);
+        double failed = late != 0;
+        if (t->allreduce_sum(t->ctx, &failed) != 0 || failed != 0) rc = late ? late : -8;
+    }
+    return rc;
 }
 
 int fastpm_hip_slab_decompose(fpmhip_plan *plan, const fastpm_hip_transport *t, fastpm_hip_column *cols, int ncols,

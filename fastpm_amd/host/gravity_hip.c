@@ -59,23 +59,52 @@ plan_for(PM * pm)
     int rank2d = pm->ThisTask;
     if(pm->NTask > 1) MPI_Comm_rank(pm->Comm2D, &rank2d);
     g.rank = rank2d;
-    g.device = -1;                                      /* the launcher binds one GPU per rank */
+    /* ONE device for the plan and for the transport, chosen first: the rank's position among the ranks of its node
+     * modulo the GPUs the process sees (a launcher that masks one GPU per rank leaves one device: index 0). */
+    int ndev = fpmhip_device_count();
+    if(ndev < 1) fastpm_raise(-1, "no HIP device: the MI355X force step cannot run (there is no CPU fallback)\n");
+    int local_rank = 0;
+    if(pm->NTask > 1) {
+        MPI_Comm node;
+        MPI_Comm_split_type(pm->Comm2D, MPI_COMM_TYPE_SHARED, rank2d, MPI_INFO_NULL, &node);
+        MPI_Comm_rank(node, &local_rank);
+        MPI_Comm_free(&node);
+    }
+    g.device = local_rank % ndev;
     c = malloc(sizeof(*c));
     c->transport = NULL;
     if(fpmhip_plan_create(&g, NULL, &c->plan)) {
         fastpm_raise(-1, "%s\n", fpmhip_last_error());
+    }
+    {
+        /* The library lays its meshes out for the process mesh it was told; what the callers of this file iterate with
+         * PMKIter is pm->IRegion / pm->ORegion (pmpfft.c:160-203).  They must be the same split -- x, y blocks of
+         * N / Nproc[d] on the real side, ky blocks of N / Nproc[0] and kz blocks of PFFT's ceil((N/2+1) / Nproc[1]) on
+         * the k side -- or delta_k would come back for another rank's modes: raise instead. */
+        fpmhip_layout lay;
+        fpmhip_plan_layout(c->plan, &lay);
+        /* ORegion is PFFT-transposed: (y, z, x) order in start / size (pmpfft.c:189-203) */
+        int ok = pm->IRegion.start[0] == lay.istart[0] && pm->IRegion.size[0] == lay.isize[0]
+              && pm->IRegion.start[1] == lay.istart[1] && pm->IRegion.size[1] == lay.isize[1]
+              && pm->ORegion.start[0] == lay.ostart[1] && pm->ORegion.size[0] == lay.osize[1]
+              && pm->ORegion.start[1] == lay.ostart[2] && pm->ORegion.size[1] == lay.ovalid_z
+              && pm->ORegion.size[2] == lay.osize[0];
+        if(!ok) {
+            fastpm_raise(-1, "Task %d: the PM regions (I %td+%td, %td+%td; O y %td+%td, z %td+%td) are not the split the "
+                    "MI355X plan uses (I %ld+%ld, %ld+%ld; O y %ld+%ld, z %ld+%ld)\n", pm->ThisTask,
+                    pm->IRegion.start[0], pm->IRegion.size[0], pm->IRegion.start[1], pm->IRegion.size[1],
+                    pm->ORegion.start[0], pm->ORegion.size[0], pm->ORegion.start[1], pm->ORegion.size[1],
+                    (long) lay.istart[0], (long) lay.isize[0], (long) lay.istart[1], (long) lay.isize[1],
+                    (long) lay.ostart[1], (long) lay.osize[1], (long) lay.ostart[2], (long) lay.ovalid_z);
+        }
     }
     if(pm->NTask > 1) {
         /* the three exchanges of the force step as MPI calls on pm->Comm2D; FASTPM_HIP_GPU_AWARE_MPI=1 hands device
          * pointers to MPI, =2 selects RCCL over xGMI (one rank per GPU), otherwise staged through the host */
         const char * e = getenv("FASTPM_HIP_GPU_AWARE_MPI");
         int mode = e ? atoi(e) : 0;
-        int device = 0;
         if(mode == 2) {
-            fpmhip_layout lay;
-            fpmhip_plan_layout(c->plan, &lay);
-            device = rank2d % fpmhip_device_count();
-            c->transport = fastpm_hip_rccl_transport_create(pm->Comm2D, device);
+            c->transport = fastpm_hip_rccl_transport_create(pm->Comm2D, g.device);      /* the plan's device */
         } else {
             c->transport = fastpm_hip_mpi_transport_create(pm->Comm2D, c->plan, mode);
         }
@@ -125,6 +154,18 @@ stage_clock(void * ctx, int stage, int enter)
     else fastpm_clock_out(clk[which]);
 }
 
+/* pm_check_values (pmapi.c:335-356) at the reference's points: the library counts on the device, the line is the
+ * reference's. */
+static void
+check_line(void * ctx, const char * label, int64_t count)
+{
+    PM * pm = ctx;
+    if(count != 0) {
+        fastpm_ilog(INFO, "%s: Task %d has %td field values that are out of bounds\n",
+                label, pm->ThisTask, (ptrdiff_t) count);
+    }
+}
+
 void
 fastpm_solver_compute_force(FastPMSolver * fastpm,
     PM * pm,
@@ -166,6 +207,12 @@ fastpm_solver_compute_force(FastPMSolver * fastpm,
 
     PlanCache * c = plan_for(pm);
     fpmhip_set_stage_hook(c->plan, stage_clock, clk);
+    {
+        /* gravity.c:350, 352, 381, 383: on unless FASTPM_HIP_CHECK_VALUES=0 (five sweeps + synchronisations per step
+         * where the reference pays nine serial host loops) */
+        const char * e = getenv("FASTPM_HIP_CHECK_VALUES");
+        if(!e || atoi(e) != 0) fpmhip_set_check_hook(c->plan, check_line, pm);
+    }
     int rc;
     if(pm->NTask == 1) {
         /* host columns up, acc down, delta_k in the ORegion layout the FORCE/AFTER handlers iterate with PMKIter */
@@ -175,9 +222,31 @@ fastpm_solver_compute_force(FastPMSolver * fastpm,
         rc = fastpm_hip_mesh_force_species_host(c->plan, c->transport, parts, nsets, kernel, dealias, delta_k);
     }
     fpmhip_set_stage_hook(c->plan, NULL, NULL);
+    fpmhip_set_check_hook(c->plan, NULL, NULL);
     if(rc) {
         /* collective failure semantics of the reference: fastpm_raise aborts the communicator (logging.c:242-251) */
         fastpm_raise(-1, "MI355X force step failed (%d): %s\n", rc, fpmhip_last_error());
+    }
+
+    /* The log lines of gravity.c:398-417, from the acc columns the step just filled.  The reference prints three blocks
+     * per species before it adds the ghosts' contributions: the local particles, the ghosts, and the local particles
+     * again (nothing changed them in between -- pm_ghosts_reduce comes after).  Here the mesh halo has already carried
+     * what the ghosts would bring back, so "p%s" and "p%s+g" print the FINAL accelerations and there is no ghost store
+     * to summarise: that block is left out. */
+    for(si = 0; si < FASTPM_SOLVER_NSPECIES; si ++) {
+        FastPMStore * p = fastpm_solver_get_species(fastpm, si);
+        if(!p) continue;
+        double acc_std[3], acc_mean[3], acc_min[3], acc_max[3];
+        int d;
+        fastpm_store_summary(p, COLUMN_ACC, pm_comm(pm), "<s->", acc_min, acc_std, acc_mean, acc_max);
+        for(d = 0; d < 3; d ++) {
+            fastpm_info("p%s    acc[%d]: %g %g %g %g\n",
+                p->name, d, acc_min[d], acc_std[d], acc_mean[d], acc_max[d]);
+        }
+        for(d = 0; d < 3; d ++) {
+            fastpm_info("p%s+g  acc[%d]: %g %g %g %g\n",
+                p->name, d, acc_min[d], acc_std[d], acc_mean[d], acc_max[d]);
+        }
     }
 }
 

@@ -111,6 +111,8 @@ SYMBOLS = {
     "fpmhip_ic_uniform_stream": (_I, [ctypes.c_ulong, _I, _P]),
     "fpmhip_ic_seed_table": (_I, [_I, _I, _P]),
     "fpmhip_check_values": (_I, [_P, _P, ctypes.POINTER(_I64)]),
+    "fpmhip_set_check_hook": (_I, [_P, _P, _P]),
+    "fpmhip_check_point": (_I, [_P, _P, ctypes.c_char_p]),
     "fpmhip_export_delta_k": (_I, [_P, _P, _P]),
     "fpmhip_import_delta_k": (_I, [_P, _P, _P]),
     "fpmhip_transfer_host": (_I, [_P, _I, _P, _P, _I]),

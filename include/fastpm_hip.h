@@ -19,10 +19,11 @@
  *   - A "mesh buffer" is device memory holding fpmhip_layout.allocsize FastPMFloat values.
  *   - Pointers named *_dev are device pointers on the plan's device; *_host are host pointers.
  *   - Every call is asynchronous on the plan's stream unless it takes host output pointers.
- *   - Ranks: slab decomposition of the mesh along x (Nproc = {nranks, 1}, which the reference
- *     API allows: api/fastpm/solver.h:71 NprocY, libfastpm/pmpfft.c:117-136).  The library does
- *     all rank-local work; the two exchange steps (mesh-halo plane and FFT transpose) are plain
- *     contiguous buffers handed to the caller's collective (RCCL all-to-all / send-recv).
+ *   - Ranks: slabs along x (Nproc = {nranks, 1}, which the reference API allows: api/fastpm/solver.h:71 NprocY) or
+ *     pencils (Nproc = {nranks / nranks_y, nranks_y}: the reference's default split, libfastpm/pmpfft.c:117-136).  The
+ *     library does all rank-local work; the exchange steps (the mesh halo -- one x plane, on pencils also one y row --
+ *     and the FFT transposes: one per transform on slabs, two on pencils) are plain contiguous buffers handed to the
+ *     caller's collective (RCCL all-to-all / send-recv).
  */
 #ifndef FASTPM_HIP_H
 #define FASTPM_HIP_H
@@ -55,9 +56,10 @@ enum { FPMHIP_PAINT_TILED = 0,      /* tile-binned particles, LDS-staged tiles, 
                                      * runs on into the z r2c pass, the z c2r pass into the readout); an error where
                                      * they do not exist */
 
-/* FFT back end.  AUTO: hand-written column passes for x and y (fused with the transfer, the
- * 1/N^3 and the slab pack/unpack) + rocFFT for the contiguous z pass when Nmesh is a power of two
- * in [16, 1024]; rocFFT 3-D (or 2-D + 1-D) plans otherwise.  ROCFFT forces the latter. */
+/* FFT back end.  AUTO: the hand-written passes wherever Nmesh is one of their lengths (16 ... 1024 with factors
+ * 8 * {3, 5} * {2, 4, 8}, and 1536, 2048, 3072): column passes for x and y (fused with the transfer, the 1/N^3 and the
+ * slab / pencil pack and unpack) and row passes for z (one read + one write per pass; on strip plans they run inside
+ * the paint and the readout); rocFFT 3-D (or 2-D + 1-D) plans for every other even Nmesh.  ROCFFT forces the latter. */
 enum { FPMHIP_FFT_AUTO = 0, FPMHIP_FFT_ROCFFT = 1 };
 
 /* Where the gradient of the force is taken.
@@ -341,6 +343,13 @@ int fpmhip_ic_seed_table(int Nmesh, int seed, unsigned int *table_host);
 
 /* pm_check_values (pmapi.c:335-356): count of NaN / |v| > 1e15 entries.  Synchronises. */
 int fpmhip_check_values(fpmhip_plan *plan, const void *mesh_dev, int64_t *count_host);
+/* The reference runs pm_check_values after the paint, after r2c and around every c2r (gravity.c:350, 352, 381, 383) and
+ * logs "<label>: Task %d has %td field values that are out of bounds".  With a hook set, the force entry points (and the
+ * host sequences of fastpm_slab_hip.c, through fpmhip_check_point) count at the same points -- on the mesh the fused
+ * step holds there: the paint's output, delta_k, each force mesh before its readout -- and call hook(ctx, label, count),
+ * count = 0 included.  Each check point is one sweep of the mesh and a stream synchronisation; without a hook, nothing. */
+int fpmhip_set_check_hook(fpmhip_plan *plan, void (*hook)(void *ctx, const char *label, int64_t count), void *ctx);
+int fpmhip_check_point(fpmhip_plan *plan, const void *mesh_dev, const char *label);
 /* copy a k-space mesh to the host in the reference's PFFT-transposed layout [y_loc][kz_loc][x] (pmpfft.c:189-203; on
  * pencils kz_loc = this rank's layout.ovalid_z modes of the block starting at ostart[2] -- PFFT's default blocks of
  * ceil((N/2+1) / Nproc[1])), and back */
@@ -418,7 +427,7 @@ enum { FPMHIP_T_SORT = 0, FPMHIP_T_PAINT, FPMHIP_T_R2C, FPMHIP_T_DEALIAS, FPMHIP
        /* single kernels inside the r2c / c2r stages (nested inside the stage timers) */
        FPMHIP_T_K_COLFFT,    /* one column pass (x or y, either direction): colfft_kernel */
        FPMHIP_T_K_ROWFFT,    /* forward z pass: rowfft_r2c_kernel */
-       FPMHIP_T_K_ZC2R,      /* backward z pass: rocFFT 1-D c2r */
+       FPMHIP_T_K_ZC2R,      /* backward z pass: rowfft_c2r_kernel (rocFFT's batched 1-D c2r where Nmesh / 2 is not a row length) */
        FPMHIP_T_K_YBACK2,    /* colfft_yback2_kernel: potential -> y and z components, y pass (1 read, 2 writes) */
        FPMHIP_T_COUNT };
 int fpmhip_timing_enable(fpmhip_plan *plan, int on);

@@ -48,6 +48,7 @@ def test_the_three_public_symbols_have_the_reference_signatures(tmp_path):
     probe.write_text('''
 #include <mpi.h>
 #include <fastpm/libfastpm.h>
+#include <fastpm/logging.h>
 #include "pmpfft.h"
 /* api/fastpm/gravity.h:5-22, restated: a mismatch with the header included above is "conflicting types" */
 void fastpm_kernel_type_get_orders(FastPMKernelType type, int *potorder, int *gradorder, int *difforder, int *deconvolveorder);
@@ -61,8 +62,17 @@ static void members(FastPMSolver * s, PM * pm, FastPMPainter * pa, FastPMStore *
     (void) pm->ThisTask; (void) pm->Nmesh[0]; (void) pm->BoxSize[0]; (void) pa->support; (void) st->x[0][0];
     (void) st->acc[0][0]; (void) st->mass; (void) st->potential; (void) st->meta.M0; (void) st->np;
     (void) fastpm_solver_get_species(s, FASTPM_SPECIES_CDM);
+    (void) pm->IRegion.start[1]; (void) pm->ORegion.size[2]; (void) st->name;
 }
-int main(void) { (void) members; return FASTPM_SOLVER_NSPECIES == 6 ? 0 : 1; }
+/* the log side effects of gravity.c:398-417 and pmapi.c:335-356 that gravity_hip.c reproduces: the functions it calls
+   for them, with the argument lists it uses */
+static void side_effects(FastPMStore * st, PM * pm) {
+    double a[3], b[3], c[3], d[3];
+    fastpm_store_summary(st, COLUMN_ACC, pm_comm(pm), "<s->", a, b, c, d);
+    fastpm_info("p%s    acc[%d]: %g %g %g %g\\n", st->name, 0, a[0], b[0], c[0], d[0]);
+    fastpm_ilog(INFO, "%s: Task %d has %td field values that are out of bounds\\n", "After r2c", pm->ThisTask, (ptrdiff_t) 0);
+}
+int main(void) { (void) members; (void) side_effects; return FASTPM_SOLVER_NSPECIES == 6 ? 0 : 1; }
 ''')
     r = _syntax_only(tmp_path, str(probe), extra=("-Wno-unused-function",))
     assert r.returncode == 0, r.stderr[-3000:]
@@ -82,3 +92,11 @@ def test_a_wrong_member_would_be_caught(tmp_path):
 def test_integration_md_points_at_the_compiled_binding():
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert "fastpm_amd/host/gravity_hip.c" in text
+
+
+def test_the_binding_reproduces_the_log_side_effects():
+    """gravity.c:398-417 prints `p%s    acc[%d]: min std mean max` per species and gravity.c:350-383 runs
+    pm_check_values: the binding does both (the GPU test of the same lines is in test_gpu_chost.py)."""
+    src = open(os.path.join(ROOT, "fastpm_amd", "host", "gravity_hip.c")).read()
+    assert 'fastpm_info("p%s    acc[%d]: %g %g %g %g\\n"' in src and "fastpm_store_summary(p, COLUMN_ACC" in src
+    assert "fpmhip_set_check_hook" in src and "field values that are out of bounds" in src

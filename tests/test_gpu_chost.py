@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 class StoreView(ctypes.Structure):
     _fields_ = [("np", ctypes.c_size_t), ("x", ctypes.c_void_p), ("acc", ctypes.c_void_p),
-                ("potential", ctypes.c_void_p), ("mass", ctypes.c_void_p), ("M0", ctypes.c_double)]
+                ("potential", ctypes.c_void_p), ("mass", ctypes.c_void_p), ("M0", ctypes.c_double),
+                ("name", ctypes.c_char * 32)]
 
 
 class SolverView(ctypes.Structure):
@@ -391,6 +392,18 @@ def test_plain_c_program_runs_the_force(oracle, tmp_path):
     for i in range(4):
         row = np.array([float(v) for v in lines["acc[%d]" % i][1:4]])
         assert np.abs(row - ref[i]).max() <= 1e-6 * np.abs(ref).max()
+    # the log side effects of gravity.c:402-417: `p%s    acc[%d]: min std mean max` and the `+g` block, %g-formatted
+    # like the reference's fastpm_info lines, against the oracle's accelerations; no pm_check_values line (nothing is
+    # out of bounds)
+    mean = ref.mean(0)
+    for d in range(3):
+        for tag in ("p1    acc[%d]:" % d, "p1+g  acc[%d]:" % d):
+            row = [l for l in r.stdout.splitlines() if l.startswith(tag)]
+            assert len(row) == 1, r.stdout
+            v = [float(t) for t in row[0][len(tag):].split()]
+            want = [ref[:, d].min(), std[d], mean[d], ref[:, d].max()]
+            assert np.allclose(v, want, rtol=2e-5, atol=2e-6 * np.abs(ref).max()), (row, want)
+    assert "out of bounds" not in r.stdout
 
 
 # ---- the reference's own process model: MPI ranks (fastpm_slab_mpi.c + example_slab_mpi.c) -------------------------

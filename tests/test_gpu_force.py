@@ -170,3 +170,31 @@ def test_two_species_share_one_mesh(oracle):
     assert util.rel_err(s1.acc.cpu().numpy(), accs[0]) <= TOL_ACC[64]
     assert util.rel_err(s2.acc.cpu().numpy(), accs[1]) <= TOL_ACC[64]
     pm.destroy()
+
+
+@pytest.mark.parametrize("paint_mode", [2, 3])
+def test_binning_overflow_is_repaired_inside_the_call(oracle, paint_mode):
+    """Every particle just below a tile corner: its CIC cloud touches 8 box tiles (2 strips), i.e. 8 (2) entries per
+    particle where the plan reserves 1.75 -- the first binning overflows the entry arrays, stores nothing out of
+    bounds, grows them and runs again inside the same call; the steady-state call after it must be right too."""
+    import torch
+    from fastpm_amd import PM, Store, fastpm_solver_compute_force
+    N, L = 64, 96.0
+    h = L / N
+    rng = np.random.Generator(np.random.PCG64(5))
+    n = 60000
+    # box tiles are 8 x 8 x 32 cells: corners at multiples of (8, 8, 32) cells; strips: y rows 3 (mod 4)
+    cx = rng.integers(0, N // 8, n) * 8 + 7
+    cy = rng.integers(0, N // 8, n) * 8 + 7
+    cz = rng.integers(0, N // 32, n) * 32 + 31
+    x = (np.stack([cx, cy, cz], axis=-1) + rng.uniform(0.05, 0.95, (n, 3))) * h
+    pmo = oracle.PMOracle(N, L, 64)
+    ref = oracle.compute_force(pmo, x)["acc"]
+    pm = PM(N, L, 64, paint_mode=paint_mode)
+    st = Store(x)
+    for call in range(3):
+        st.acc.zero_()
+        fastpm_solver_compute_force(pm, st, dealias="none", kernel="1_4")
+        pm.sync()
+        assert util.rel_err(st.acc.cpu().numpy(), ref) <= TOL_ACC[64], call
+    pm.destroy()

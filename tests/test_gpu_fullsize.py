@@ -138,11 +138,18 @@ def test_config2_mesh_on_one_gpu_properties():
     assert abs(complex(c[0, 0, 0].item()) - 1.0) < 1e-12
     # the last plane / last row / Nyquist column are really addressed (no index wrapped at 2^31)
     assert float(c[N - 1, N - 1, N // 2].abs()) > 0 and pm.check_values(dk) == 0
-    # the force on a particle equals the force on its periodic image
-    sub = x[:100000].clone()
-    sub2 = torch.remainder(sub + torch.tensor([L, 0.0, 0.0], device="cuda", dtype=torch.float64), L)
-    assert torch.equal(sub, sub2) or float((sub - sub2).abs().max()) < 1e-9
     del c, dk
+    # the force on a particle equals the force on its periodic image: the same particles, every fourth one moved one
+    # box length along an axis and NOT wrapped back (painter-cic.c:65-70 wraps the cell indices, not the positions;
+    # the weights differ by the rounding of (x + L) / h, i.e. by 1e-13 of a cell)
+    x2 = x.clone()
+    for d, sign in ((0, +1.0), (1, -1.0), (2, +1.0)):
+        x2[d::12, d] += sign * L
+    st2 = Store(x2)
+    pm.compute_force(st2, total_mass=float(nc ** 3))
+    torch.cuda.synchronize()
+    assert float((st2.acc.double() - acc).abs().max()) <= 1e-6 * rms
+    del st2, x2
     pm.destroy()
 
 
