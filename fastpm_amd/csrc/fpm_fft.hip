@@ -601,6 +601,41 @@ int fpmhip_fft_y_forward(fpmhip_plan *p, void *recv_a, void *send_b)
     return colfft_y(p, -1, recv_a, send_b, 1);
 }
 
+// The y passes alone for the x planes [x0, x0 + nx): what the strip plans of a slab decomposition pipeline around their
+// all-to-all, range by range (the z passes happen inside fpmhip_paint_zr2c / fpmhip_readout3_zc2r).
+int fpmhip_fft_y_forward_range(fpmhip_plan *p, void *zrows, void *send_b, int x0, int nx)
+{
+    if (!p || !zrows || !send_b) FPM_FAIL(-1, "null argument");
+    FPM_TRY(check_range(p, x0, nx));
+    if (p->lay.nranks > 1 && zrows == send_b) FPM_FAIL(-1, "fft_y_forward: input and output must differ when nranks > 1");
+    StageTimer tm(p, FPMHIP_T_R2C);
+    return colfft_y_range(p, -1, zrows, send_b, 1, x0, nx);
+}
+
+int fpmhip_fft_y_backward_range(fpmhip_plan *p, void *recv_b, void *zrows, int x0, int nx)
+{
+    if (!p || !recv_b || !zrows) FPM_FAIL(-1, "null argument");
+    FPM_TRY(check_range(p, x0, nx));
+    if (p->lay.nranks > 1 && recv_b == zrows) FPM_FAIL(-1, "fft_y_backward: input and output must differ when nranks > 1");
+    StageTimer tm(p, FPMHIP_T_C2R);
+    return colfft_y_range(p, +1, recv_b, zrows, 1, x0, nx);
+}
+
+int fpmhip_fft_y_backward_grad2_range(fpmhip_plan *p, void *recv_b, void *out_y, void *out_z, void *out_pot, int kernel,
+                                      int x0, int nx)
+{
+    if (!p || !recv_b || !out_y || !out_z) FPM_FAIL(-1, "null argument");
+    FPM_TRY(check_range(p, x0, nx));
+    int po, go, dfo, dc;
+    FPM_TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));
+    if (go != 1) FPM_FAIL(-1, "fft_y_backward_grad2 is for kernels with gradorder = 1");
+    if (out_y == out_z || (p->lay.nranks > 1 && (recv_b == out_y || recv_b == out_z)))
+        FPM_FAIL(-1, "input and outputs must be different buffers");
+    if (out_pot && (out_pot == out_y || out_pot == out_z || out_pot == recv_b)) FPM_FAIL(-1, "out_pot must be a buffer of its own");
+    StageTimer tm(p, FPMHIP_T_C2R);
+    return colfft_yback2_range(p, recv_b, out_y, out_z, out_pot, 1, go, x0, nx);
+}
+
 int fpmhip_fft_y_backward(fpmhip_plan *p, void *recv_b, void *send_a)
 {
     if (!p || !recv_b || !send_a) FPM_FAIL(-1, "null argument");

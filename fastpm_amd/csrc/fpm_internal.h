@@ -172,6 +172,9 @@ struct fpmhip_plan {
     int64_t dec_cap = 0;
     size_t dec_tmp_bytes = 0, dec_hist_bytes = 0;
     int64_t binned_ndup = 0;
+    // strip plans: half sums of the marching readout (fpm_strips.hip), one double per own entry and force component
+    double *ro_part = nullptr;
+    int64_t ro_part_elems = 0;
 
     // host callback at the boundaries of the top-level stages (fpmhip_set_stage_hook)
     void (*stage_hook)(void *ctx, int stage, int enter) = nullptr;

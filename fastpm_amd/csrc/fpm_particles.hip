@@ -329,7 +329,9 @@ __global__ __launch_bounds__(256) void slab_caps_kernel(const int *__restrict__ 
     const long long total = off[nkeys];
     const bool slack = total + total / 4 + 33ll * nkeys <= alloc;
     if (k == 0) {
-        flags[FLAG_TOTAL] = (int) total;
+        // (the layout for the NEXT call runs through here again, after a hard overflow with the counts zeroed: keep the
+        // larger total -- it is what the arrays must grow to)
+        if ((int) total > flags[FLAG_TOTAL]) flags[FLAG_TOTAL] = (int) total;
         if (total > alloc) flags[FLAG_HARD_OVF] = 1;
     }
     // more entries than the arrays hold at all: every slab is empty, the scatter stores nothing, the binning is void
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(1024) void layout_one_block_kernel(int *__restrict_
     for (int k = k0; k < k1; k++) { off[k] = (int) run; run += cnt[k]; }
     if (tid == 0) {
         off[nkeys] = (int) total;
-        flags[FLAG_TOTAL] = (int) total;
+        if ((int) total > flags[FLAG_TOTAL]) flags[FLAG_TOTAL] = (int) total;
         if (total > alloc) flags[FLAG_HARD_OVF] = 1;
     }
     const bool slack = total + total / 4 + 33ll * nkeys <= alloc;
@@ -1117,11 +1119,12 @@ int check_deferred(fpmhip_plan *p, bool wait)
     }
     if (f[FLAG_HARD_OVF] != 0) {
         p->bin_grow = std::max<int64_t>(p->bin_grow, (int64_t) f[FLAG_TOTAL] + f[FLAG_TOTAL] / 2);
+        const long long np_was = p->binned_np;
         p->binned_np = -1;
         p->binned_x = nullptr;
         FPM_FAIL(-5, "the tile binning of an earlier force call needed %d entries for %lld particles, more than the plan "
                      "held (%lld): that call's result is invalid; the arrays grow on the next call", f[FLAG_TOTAL],
-                 (long long) p->binned_np, (long long) p->bin_alloc);
+                 np_was, (long long) p->bin_alloc);
     }
     return 0;
 }

@@ -86,6 +86,15 @@ int ensure_bins(fpmhip_plan *p, int64_t np, int64_t ndup, bool has_mass)
         p->binned_np = -1;
         p->layout_np = -1;
     }
+    if (p->mg.strips) {
+        // own entries live in the slabs of the own keys, laid out first: at most np + 25 % + 32 per tile of them
+        const int64_t own = np + np / 4 + 33 * (int64_t) p->ntiles + 64;
+        if (own > p->ro_part_elems) {
+            if (p->ro_part) { FPM_CHECK_HIP(hipStreamSynchronize(p->stream)); (void) hipFree(p->ro_part); p->ro_part = nullptr; }
+            FPM_CHECK_HIP(hipMalloc(&p->ro_part, (size_t) 3 * (own + own / 16) * sizeof(double)));
+            p->ro_part_elems = own + own / 16;
+        }
+    }
     if (np > p->order_cap) {
         if (p->order[0]) FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
         for (int q = 0; q < 2; q++) {
@@ -264,16 +273,17 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
     g.nty = (g.yplanes + TILE_Y - 1) / TILE_Y;
     g.ntz = ((int) N + TILE_Z - 1) / TILE_Z;
     // Strip tiles + the kernels that march over them (fpm_strips.hip: the paint runs on into the z r2c pass, the
-    // z c2r pass into the readout) where they exist: one rank, the hand-written passes, the k-space gradient; by
+    // z c2r pass into the readout) where they exist: one rank or x slabs, the hand-written passes, the k-space gradient; by
     // default from N = 320 (measured per force, strips / boxes: N = 128 0.44 / 0.29 ms -- 128 marching workgroups do not
     // fill the chip --, 256 0.89 / 0.90, 320 1.61 / 1.66, 384 2.51 / 2.68, 512 5.2 / 5.85)
     g.strips = 0;
     {
         static const bool env_off = getenv("FPMHIP_STRIPS") && atoi(getenv("FPMHIP_STRIPS")) == 0;      // A/B
-        const bool can = P == 1 && geom->fft_mode == FPMHIP_FFT_AUTO && colfft_supported((int) N) &&
+        // one rank or x slabs (the halo plane then travels as half-spectrum rows: the z pass is linear)
+        const bool can = Ny == 1 && geom->fft_mode == FPMHIP_FFT_AUTO && colfft_supported((int) N) &&
                          strips_supported((int) N, geom->precision) && geom->gradient_mode == FPMHIP_GRADIENT_KSPACE;
         if (geom->paint_mode == FPMHIP_PAINT_STRIPS && !can)
-            FPM_FAIL(-1, "FPMHIP_PAINT_STRIPS: one rank, the k-space gradient and a mesh whose z rows fit the strip kernels");
+            FPM_FAIL(-1, "FPMHIP_PAINT_STRIPS: one rank or x slabs, the k-space gradient and a mesh whose z rows fit the strip kernels");
         if (can && (geom->paint_mode == FPMHIP_PAINT_STRIPS || (geom->paint_mode == FPMHIP_PAINT_TILED && N >= 320 && !env_off))) {
             g.strips = STRIP_Y;
             g.ntx = g.xl; g.nty = (int) N / STRIP_Y; g.ntz = 1;
@@ -330,7 +340,7 @@ void fpmhip_plan_destroy(fpmhip_plan *p)
     void *ptrs[] = {p->host_stage.x, p->host_stage.acc, p->host_stage.mass, p->host_stage.pot,
                     p->d_twiddle, p->d_tab, p->d_fac, p->sx, p->sy, p->sz, p->smass, p->sidx, p->bin_beg[0], p->bin_beg[1],
                     p->bin_cap[0], p->bin_cap[1], p->bin_cnt, p->bin_off, p->bin_capv, p->bin_tmp, p->order[0], p->order[1],
-                    p->d_flags, p->scan_tmp, p->d_scalar, p->d_decic, p->d_bins, p->dec_key_in, p->dec_idx, p->dec_tmp};
+                    p->d_flags, p->scan_tmp, p->d_scalar, p->d_decic, p->d_bins, p->dec_key_in, p->dec_idx, p->dec_tmp, p->ro_part};
     for (void *q : ptrs) if (q) (void) hipFree(q);
     if (p->h_pinned) (void) hipHostFree(p->h_pinned);
     if (p->h_flags) (void) hipHostFree(p->h_flags);

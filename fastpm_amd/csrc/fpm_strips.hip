@@ -74,6 +74,7 @@ template <typename PL, typename F> struct StripCfg {
     static constexpr int ro_xchg = (M + 1) * STRIP_RW + ro_sk * (M / 32 + 1);       // elements of the exchange area
     static constexpr int ro_slot = ro_pitch * STRIP_RW > ro_xchg ? ro_pitch * STRIP_RW : ro_xchg;
     static constexpr size_t ro_lds = twb + (size_t) 2 * ro_slot * sizeof(C2<F>);
+    static constexpr size_t ro1_lds = twb + (size_t) ro_slot * sizeof(C2<F>);       // the marching readout: ONE plane
     // paint: two planes of STRIP_Y rows of pt_pitch double accumulators
     static constexpr int pt_threads = T * STRIP_Y;
     static constexpr int pt_pitch = 2 * strip_pitch(M, 4);
@@ -174,14 +175,18 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads)) void paint_strips_ke
             }
     };
 
-    // what the particles of the plane before the segment add to its first plane
+    // what the particles of the plane before the segment add to its first plane (on a slab's first plane that is the
+    // neighbour's halo plane, added after the kernel: fpmhip_plane_add)
     if (g.periodic_x || xa > 0) {
         prefetch(xa > 0 ? xa - 1 : g.N - 1);
         add_prefetched(nullptr, A);
     }
     prefetch(xa);
-    for (int i = xa; i < xb; i++) {
-        add_prefetched(A, B);
+    // a slab's last segment also sends out the halo plane xl: what its last plane's particles add to the next rank's
+    // first plane
+    const int xend = xb + ((!g.periodic_x && xb == g.xl) ? 1 : 0);
+    for (int i = xa; i < xend; i++) {
+        if (i < xb) add_prefetched(A, B);
         __syncthreads();
         if (i + 1 < xb) prefetch(i + 1);                  // lands while plane i is transformed and stored
         if (!R2C) {
@@ -215,7 +220,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads)) void paint_strips_ke
 #pragma unroll
             for (int j = 0; j < E; j++) lds[(tau + T * j) * STRIP_Y + c] = v[j];
             __syncthreads();
-            C2<F> *dst = (C2<F> *) out_ + ((long long) i * g.N + y0 + c) * g.rp;
+            C2<F> *dst = (C2<F> *) out_ + ((long long) i * g.yplanes + y0 + c) * g.rp;
 #pragma unroll
             for (int j = 0; j < E; j++) {
                 const int k = tau + T * j;
@@ -264,9 +269,9 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
     const C2<F> *rowbase = mesh + (long long) gy * g.rp;
 
     C2<F> x[E], xm;
-    auto load_plane = [&](int xp) {
-        xp -= xp >= g.N ? g.N : 0;
-        const C2<F> *src = rowbase + (long long) xp * g.N * g.rp;
+    auto load_plane = [&](int xp) {                // plane xl of a slab is the halo plane the next rank sent
+        if (g.periodic_x) xp -= xp >= g.N ? g.N : 0;
+        const C2<F> *src = rowbase + (long long) xp * g.yplanes * g.rp;
 #pragma unroll
         for (int j = 0; j < E; j++) x[j] = ld_stream(&src[tau + T * j]);
         xm = tau == 0 ? src[M] : C2<F>{0, 0};
@@ -330,25 +335,162 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// readout with ONE plane in LDS (the default)
+// ------------------------------------------------------------------------------------------------------------------
+// The two-plane window above is what limits the kernel to three workgroups per CU at M = 256 in fp64 and to ONE at M = 512
+// (the 1024^3 mesh).  A particle of plane i needs the planes i and i + 1, but not at the same time: its sum runs over the
+// corners in the order 000, 001, 010, 011 | 100, 101, 110, 111 (painter-cic.c:159-186), i.e. first the four corners of
+// plane i, then the four of plane i + 1.  So the window holds ONE plane; while it holds plane i the particles of plane i
+// take their first four terms ("start") and the particles of plane i - 1 -- started one step earlier -- their last four
+// ("finish"), the same additions in the same order.  The half sums of the first PF particles per thread wait in registers
+// together with the positions; what a dense tile has beyond that waits in a global scratch row per component (written and
+// read back one step later: L2).  LDS per workgroup: 29.5 KB at M = 256 in fp64 (two planes: 51 KB), 58 KB at M = 512.
+template <typename PL, typename F>
+__global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), 3) void readout_march_kernel(
+    MeshGeo g, int ncomp, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
+    const double *__restrict__ sy, const double *__restrict__ sz, const int *__restrict__ sidx, const C2<F> *__restrict__ m0,
+    const C2<F> *__restrict__ m1, const C2<F> *__restrict__ m2, float *__restrict__ out, int nmemb, int memb0,
+    const double *__restrict__ tw_global, double *__restrict__ part_all, long long part_stride)
+{
+    using CF = StripCfg<PL, F>;
+    constexpr int M = PL::N, RW = STRIP_RW, T = PL::T, E = PL::E, NT = CF::ro_threads, RP = CF::ro_pitch, WP = 2 * RP,
+                  SK = CF::ro_sk;
+    extern __shared__ __align__(16) unsigned char smem_st[];
+    C2<F> *tw = (C2<F> *) smem_st;
+    C2<F> *twn = tw + PL::TWN;
+    C2<F> *S = twn + M;                            // [ro_slot]: the FFT exchange area, then RW real rows of the plane
+    const int tid = threadIdx.x, c = tid % RW, tau = tid / RW;
+    const int nseg = (g.xl + STRIP_XSEG - 1) / STRIP_XSEG;
+    const int t = xcd_remap(blockIdx.x, ncomp * g.nty * nseg);
+    const int comp = t % ncomp, strip = (t / ncomp) % g.nty, seg = nseg - 1 - t / (ncomp * g.nty);      // last segment first
+    const C2<F> *mesh = comp == 0 ? m0 : (comp == 1 ? m1 : m2);
+    double *part = part_all + comp * part_stride;
+    const int xa = seg * STRIP_XSEG, xb = min(xa + STRIP_XSEG, g.xl);
+    const int y0 = strip * STRIP_Y;
+    int gy = y0 + c;
+    gy -= gy >= g.N ? g.N : 0;
+    const C2<F> *rowbase = mesh + (long long) gy * g.rp;
+    const long long pstride = (long long) g.yplanes * g.rp;
+
+    C2<F> x[E], xm;
+    auto load_plane = [&](int xp) {                // plane xl of a slab is the halo plane the next rank sent
+        if (g.periodic_x) xp -= xp >= g.N ? g.N : 0;
+        const C2<F> *src = rowbase + (long long) xp * pstride;
+#pragma unroll
+        for (int j = 0; j < E; j++) x[j] = ld_stream(&src[tau + T * j]);
+        xm = tau == 0 ? src[M] : C2<F>{0, 0};
+    };
+    auto c2r_plane = [&]() {                       // x[] -> the RW real rows of the plane in S (rowfft_c2r_kernel's arithmetic)
+        C2<F> v[vmax(E)];
+        c2r_prepare<PL, RW, SK>(v, x, xm, S, twn, tau, c);
+        fft_core<PL, +1, RW, false, F, SK>(v, S, tw, tau, c);
+#pragma unroll
+        for (int j = 0; j < E; j++) S[c * RP + tau + T * j] = v[j];
+        if (tau == 0) S[c * RP + M].x = v[0].x;                    // value N of a row = value 0: the z + 1 corner needs no wrap
+    };
+    // acc + the four corners of the window's plane (x bit `bx`), in the reference's order
+    const F *rs = (const F *) S;
+    auto half = [&](double qx, double qy, double qz, int bx, double acc) -> double {
+        Cic cc;
+        (void) cic_setup(g, qx, qy, qz, cc);
+        const int ly = cc.i0[1] - y0, lz = cc.i0[2];
+        const double wxb = bx ? cc.d[0] : cc.t[0];
+        const double wy[2] = {cc.t[1], cc.d[1]}, wz[2] = {cc.t[2], cc.d[2]};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int by = (k >> 1) & 1, bz = k & 1;
+            acc += (double) rs[(ly + by) * WP + lz + bz] * (wz[bz] * wxb * wy[by]);
+        }
+        return acc;
+    };
+    constexpr int PF = 2;
+    double px[PF], py[PF], pz[PF], pv[PF], qx[PF], qy[PF], qz[PF];
+    int prow[PF], qrow[PF];
+    int pb = 0, pn = 0, qb = 0, qn = 0;            // p: the particles that finish this step; q: those that start
+    auto fetch_q = [&](int xi) {
+        const int key = xi * g.nty + strip;
+        qb = tbeg[key];
+        qn = tcnt[key];
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int e = tid + u * NT;
+            qx[u] = qy[u] = qz[u] = 0;
+            qrow[u] = 0;
+            if (e < qn) { qx[u] = sx[qb + e]; qy[u] = sy[qb + e]; qz[u] = sz[qb + e]; qrow[u] = sidx[qb + e]; }
+        }
+    };
+    auto start_q = [&]() {                         // q -> p with the first four terms
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            px[u] = qx[u]; py[u] = qy[u]; pz[u] = qz[u]; prow[u] = qrow[u];
+            pv[u] = tid + u * NT < qn ? half(qx[u], qy[u], qz[u], 0, 0.0) : 0.0;
+        }
+        for (int e = tid + PF * NT; e < qn; e += NT) part[qb + e] = half(sx[qb + e], sy[qb + e], sz[qb + e], 0, 0.0);
+        pb = qb;
+        pn = qn;
+    };
+    auto finish_p = [&]() {
+#pragma unroll
+        for (int u = 0; u < PF; u++)
+            if (tid + u * NT < pn)
+                out[(long long) prow[u] * nmemb + memb0 + comp] = (float) half(px[u], py[u], pz[u], 1, pv[u]);
+        for (int e = tid + PF * NT; e < pn; e += NT)
+            out[(long long) sidx[pb + e] * nmemb + memb0 + comp] = (float) half(sx[pb + e], sy[pb + e], sz[pb + e], 1, part[pb + e]);
+    };
+
+    load_plane(xa);
+    fetch_q(xa);
+    stage_twiddles(tw, tw_global, PL::TWN, 2);
+    stage_twiddles(twn, tw_global, M, 1);
+    __syncthreads();
+    c2r_plane();
+    __syncthreads();
+    load_plane(xa + 1);
+    start_q();
+    for (int i = xa; i < xb; i++) {                // the window goes from plane i to plane i + 1
+        if (i + 1 < xb) fetch_q(i + 1);            // needed after the transform
+        __syncthreads();                           // every gather from plane i is done
+        c2r_plane();
+        __syncthreads();
+        if (i + 1 < xb) load_plane(i + 2);         // lands during the gathers
+        finish_p();
+        if (i + 1 < xb) start_q();
+    }
+}
+
 #define FPM_STRIP_CASE(n, BODY) case n: { using PL = typename Fac<n, 0>::type; BODY(PL) } break;
 #define STRIP_DISPATCH(M_, BODY)                                                                                     \
     switch (M_) {                                                                                                    \
         FPM_STRIP_CASE(16, BODY) FPM_STRIP_CASE(32, BODY) FPM_STRIP_CASE(48, BODY) FPM_STRIP_CASE(64, BODY)          \
         FPM_STRIP_CASE(80, BODY) FPM_STRIP_CASE(96, BODY) FPM_STRIP_CASE(128, BODY) FPM_STRIP_CASE(160, BODY)        \
         FPM_STRIP_CASE(192, BODY) FPM_STRIP_CASE(256, BODY) FPM_STRIP_CASE(320, BODY) FPM_STRIP_CASE(384, BODY)      \
-        FPM_STRIP_CASE(400, BODY) FPM_STRIP_CASE(512, BODY)                                                          \
+        FPM_STRIP_CASE(400, BODY) FPM_STRIP_CASE(512, BODY) FPM_STRIP_CASE(640, BODY) FPM_STRIP_CASE(768, BODY)      \
+        FPM_STRIP_CASE(800, BODY) FPM_STRIP_CASE(1024, BODY)                                                         \
     default: FPM_FAIL(-1, "strip kernels: unsupported mesh size %d", 2 * (int) (M_));                               \
     }
 
-// three readout workgroups per CU (the widest window: M = 256 in fp64, 512 in fp32)
-static constexpr size_t STRIP_LDS_MAX = 160 * 1024 / 3;
+// two marching workgroups per CU: the one-plane readout window and the two-plane paint window of the widest row
+// (M = 512 in fp64: 58 KB and 78 KB; M = 1024 in fp32: 57 KB and 78 KB)
+static constexpr size_t STRIP_LDS_MAX = 160 * 1024 / 2;
 
 bool strips_supported(int N, int precision)
 {
-    if (!rowfft_supported(N) || N % STRIP_Y != 0 || N / 2 > 512) return false;
+    if (!rowfft_supported(N) || N % STRIP_Y != 0 || N / 2 > 1024) return false;
     const size_t es = precision == 64 ? 16 : 8, M = (size_t) N / 2;
-    return (2 * M + 2 * (size_t) strip_pitch((int) M, 13) * STRIP_RW) * es <= STRIP_LDS_MAX;      // = StripCfg::ro_lds
+    const size_t ro = (2 * M + (size_t) strip_pitch((int) M, 13) * STRIP_RW) * es;                      // ~ StripCfg::ro1_lds
+    const size_t pt = (M / 2 + M) * es + (size_t) 2 * STRIP_Y * 2 * strip_pitch((int) M, 4) * sizeof(double);   // = pt_lds
+    return ro <= STRIP_LDS_MAX && pt <= STRIP_LDS_MAX;
 }
+
+// where the two-plane readout (A/B: FPMHIP_RO_WIN=2) still fits a CU's LDS
+template <typename F> struct StripTwoPlanes {
+    static bool fits(int M, int per_cu)
+    {
+        return (2 * (size_t) M + 2 * ((size_t) strip_pitch(M, 13) * STRIP_RW + 64)) * sizeof(C2<F>) <= 160 * 1024 / (size_t) per_cu;
+    }
+};
 
 template <typename K> static int grant_lds(K kernel, size_t bytes, int device)
 {
@@ -400,13 +542,29 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
 {
     const MeshGeo &g = p->mg;
     const int nseg = (g.xl + STRIP_XSEG - 1) / STRIP_XSEG;
+    // Two planes of real rows in LDS where three workgroups per CU still fit them (M <= 256 in fp64, 512 in fp32: one
+    // cic_setup per particle and component), ONE plane beyond (M = 512 in fp64 -- the 1024^3 mesh -- would be 100 KB, one
+    // workgroup per CU; a particle's sum then runs over two steps).  Measured at 512^3: fp64 1.643 / 1.643 ms, fp32
+    // 0.93 / 0.98 ms (two / one plane); FPMHIP_RO_WIN = 1 | 2 forces either (A/B).
+    static const int win_env = getenv("FPMHIP_RO_WIN") ? atoi(getenv("FPMHIP_RO_WIN")) : 0;
+    const bool two_planes = win_env == 2 ? StripTwoPlanes<F>::fits(g.N / 2, 1)
+                                         : (win_env == 1 ? false : StripTwoPlanes<F>::fits(g.N / 2, 3));
+    // the half sums of a dense tile's entries beyond the first two per thread: one double per own entry and component
+    const long long part_stride = p->ro_part_elems;
 #define CALL_RO(PL)                                                                                                    \
     {                                                                                                                  \
         using CF = StripCfg<PL, F>;                                                                                    \
-        FPM_TRY(grant_lds(readout_strips_kernel<PL, F>, CF::ro_lds, p->device));                                       \
-        readout_strips_kernel<PL, F><<<ncomp * g.nty * nseg, CF::ro_threads, CF::ro_lds, p->stream>>>(                 \
-            g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0, (const C2<F> *) k1, \
-            (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle);                                                      \
+        if (two_planes) {                                                                                              \
+            FPM_TRY(grant_lds(readout_strips_kernel<PL, F>, CF::ro_lds, p->device));                                   \
+            readout_strips_kernel<PL, F><<<ncomp * g.nty * nseg, CF::ro_threads, CF::ro_lds, p->stream>>>(             \
+                g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                 \
+                (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle);                              \
+        } else {                                                                                                       \
+            FPM_TRY(grant_lds(readout_march_kernel<PL, F>, CF::ro1_lds, p->device));                                   \
+            readout_march_kernel<PL, F><<<ncomp * g.nty * nseg, CF::ro_threads, CF::ro1_lds, p->stream>>>(             \
+                g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                 \
+                (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride);     \
+        }                                                                                                              \
     }
     STRIP_DISPATCH(g.N / 2, CALL_RO)
 #undef CALL_RO
@@ -430,3 +588,40 @@ int readout_strips_zc2r(fpmhip_plan *p, const fpmhip_particles *pt, const void *
 }
 
 }  // namespace fpm
+
+using namespace fpm;
+
+extern "C" {
+
+// The stage calls of a strip plan, for the sequences that drive the stages around their exchanges (slabs: the mesh
+// halo and the transposes -- fastpm_amd/distributed.py, fastpm_amd/host/fastpm_slab_hip.c).
+int fpmhip_paint_zr2c(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void *zrows)
+{
+    if (!p || !pt || !zrows) FPM_FAIL(-1, "null argument");
+    if (pt->np < 0 || (pt->np > 0 && !pt->x)) FPM_FAIL(-1, "particles without positions");
+    if (!p->mg.strips) FPM_FAIL(-1, "fpmhip_paint_zr2c needs a strip plan (fpmhip_plan_strips)");
+    (void) hipSetDevice(p->device);
+    return paint_strips(p, pt, scale, zrows, 0, true);
+}
+
+int fpmhip_readout3_zc2r(fpmhip_plan *p, const fpmhip_particles *pt, const void *k0, const void *k1, const void *k2)
+{
+    if (!p || !pt || !k0 || !k1 || !k2) FPM_FAIL(-1, "null argument");
+    if (pt->np < 0 || (pt->np > 0 && (!pt->x || !pt->acc))) FPM_FAIL(-1, "particles without positions or an acc column");
+    if (!p->mg.strips) FPM_FAIL(-1, "fpmhip_readout3_zc2r needs a strip plan (fpmhip_plan_strips)");
+    (void) hipSetDevice(p->device);
+    return readout_strips_zc2r(p, pt, k0, k1, k2, 3, pt->acc, 3, 0);
+}
+
+int fpmhip_readout1_zc2r(fpmhip_plan *p, const fpmhip_particles *pt, const void *k, float *out, int nmemb, int memb)
+{
+    if (!p || !pt || !k || (!out && pt->np > 0)) FPM_FAIL(-1, "null argument");
+    if (pt->np < 0 || (pt->np > 0 && !pt->x)) FPM_FAIL(-1, "particles without positions");
+    if (memb < 0 || memb >= nmemb) FPM_FAIL(-1, "memb %d greater than nmemb %d", memb, nmemb);          // store.c:83-85
+    if (!p->mg.strips) FPM_FAIL(-1, "fpmhip_readout1_zc2r needs a strip plan (fpmhip_plan_strips)");
+    (void) hipSetDevice(p->device);
+    return readout_strips_zc2r(p, pt, k, nullptr, nullptr, 1, out, nmemb, memb);
+}
+
+}  // extern "C"
+

@@ -247,19 +247,36 @@ class SlabForce(_SlabRank):
         total_mass = float(self.scalar.item())
         mean_mass_per_cell = total_mass / pm.Norm
 
+        # Strip plans (csrc/fpm_strips.hip; the default from Nmesh = 320): the paint runs on into the z pass of pm_r2c and
+        # the z pass of pm_c2r into the readout, so between the particle kernels and the y passes the meshes are
+        # half-spectrum rows -- and the halo plane travels in that form (the z pass is linear).  Same sequence, other
+        # stage calls; with a softening kernel the forward half keeps the real canvas (as on one rank).
+        strips = getattr(pm, "strips", lambda: False)() and not (self.real_gradient and _gradorder(kernel) == 1) \
+            and not self.three_transposes
+        strips_fwd = strips and dealias == 0
+        bwd = pm.fft_y_backward if strips else pm.fft_yz_backward
+        bwd_range = pm.fft_y_backward_range if strips else pm.fft_yz_backward_range
+        bwd_grad2 = pm.fft_y_backward_grad2 if strips else pm.fft_yz_backward_grad2
+        bwd_grad2_range = pm.fft_y_backward_grad2_range if strips else pm.fft_yz_backward_grad2_range
+        readout3 = pm.readout3_zc2r if strips else pm.readout3
+        readout1 = pm.readout_zc2r if strips else pm.readout
+
         # gravity.c:336-345: paint + normalise; the halo plane goes to the next slab
-        yield from self._agreed(lambda: pm.paint(self.canvas, store, 1.0 / mean_mass_per_cell))
+        paint = pm.paint_zr2c if strips_fwd else pm.paint
+        yield from self._agreed(lambda: paint(self.canvas, store, 1.0 / mean_mass_per_cell))
         yield ("shift", [(pm.plane(self.canvas, xl), self.tmp_plane, +1)])
         pm.plane_add(pm.plane(self.canvas, 0), self.tmp_plane)
 
         # gravity.c:351 pm_r2c: 2-D (y,z) transforms, transpose, 1-D x transform (x 1/Norm)
         ranges = self._ranges()
+        fwd = pm.fft_y_forward if strips_fwd else pm.fft_yz_forward
+        fwd_range = pm.fft_y_forward_range if strips_fwd else pm.fft_yz_forward_range
         if len(ranges) == 1:
-            pm.fft_yz_forward(self.canvas, self.work)
+            fwd(self.canvas, self.work)
             yield ("alltoall", delta_k, self.work)
         else:
             for i, (x0, nx) in enumerate(ranges):           # range i is on xGMI while range i + 1 is transformed
-                pm.fft_yz_forward_range(self.canvas, self.work, x0, nx)
+                fwd_range(self.canvas, self.work, x0, nx)
                 yield ("alltoall_range_start", delta_k, self.work, x0, nx, ("fwd", i))
             for i in range(len(ranges)):
                 yield ("wait", ("fwd", i))
@@ -298,15 +315,15 @@ class SlabForce(_SlabRank):
                 potmesh = self.potmesh
             for i, (x0, nx) in enumerate(ranges):
                 yield ("wait", ("pot", i))
-                pm.fft_yz_backward_grad2_range(kernel, self.work2, self.force[2], self.extra, x0, nx, out_pot=potmesh)
+                bwd_grad2_range(kernel, self.work2, self.force[2], self.extra, x0, nx, out_pot=potmesh)
             for i, (x0, nx) in enumerate(ranges):
                 yield ("wait", ("x", i))
-                pm.fft_yz_backward_range(self.work, self.force[1], x0, nx)
+                bwd_range(self.work, self.force[1], x0, nx)
             meshes = [self.force[1], self.force[2], self.extra] + ([potmesh] if potmesh is not None else [])
             yield ("shift", [(pm.plane(f, 0), pm.plane(f, xl), -1) for f in meshes])
-            pm.readout3(meshes[:3], store)
+            readout3(meshes[:3], store)
             if potmesh is not None:
-                pm.readout(potmesh, store, store.potential, 1, 0)
+                readout1(potmesh, store, store.potential, 1, 0)
             return
         if _gradorder(kernel) == 1 and pm.column_fft() and not self.three_transposes:
             # gravity.c:373-397 with TWO meshes through the transpose instead of three: the x component
@@ -326,14 +343,14 @@ class SlabForce(_SlabRank):
                     self.potmesh = pm.alloc()
                 potmesh = self.potmesh
             yield ("wait", 1)
-            pm.fft_yz_backward_grad2(kernel, self.work2, self.force[1], self.force[2], out_pot=potmesh)
+            bwd_grad2(kernel, self.work2, self.force[1], self.force[2], potmesh)
             yield ("wait", 0)
-            pm.fft_yz_backward(self.work, self.force[0])
+            bwd(self.work, self.force[0])
             meshes = list(self.force) + ([potmesh] if potmesh is not None else [])
             yield ("shift", [(pm.plane(f, 0), pm.plane(f, xl), -1) for f in meshes])
-            pm.readout3(self.force, store)
+            readout3(self.force, store)
             if potmesh is not None:
-                pm.readout(potmesh, store, store.potential, 1, 0)
+                readout1(potmesh, store, store.potential, 1, 0)
             return
 
         # gravity.c:373-397: per component transfer -> c2r.  The three transfers and the x passes
@@ -347,15 +364,15 @@ class SlabForce(_SlabRank):
         yield ("alltoall_start", self.work, self.force[0], 0)
         yield ("alltoall_start", self.work2, self.force[1], 1)
         yield ("wait", 0)
-        pm.fft_yz_backward(self.work, self.force[0])
+        bwd(self.work, self.force[0])
         yield ("alltoall_start", self.work, self.force[2], 2)      # ordered after the pass above
         yield ("wait", 1)
-        pm.fft_yz_backward(self.work2, self.force[1])
+        bwd(self.work2, self.force[1])
         yield ("wait", 2)
-        pm.fft_yz_backward(self.work, self.force[2])
+        bwd(self.work, self.force[2])
         # the plane each boundary particle's cloud reaches into comes from the next slab
         yield ("shift", [(pm.plane(f, 0), pm.plane(f, xl), -1) for f in self.force])
-        pm.readout3(self.force, store)
+        readout3(self.force, store)
 
         if store.potential is not None:                                   # gravity.c:487-492
             f = self.force[0]

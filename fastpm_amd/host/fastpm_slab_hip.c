@@ -30,7 +30,7 @@ static int shift(fpmhip_plan *plan, const fastpm_hip_transport *t, void *mesh, i
 
 /* every species painted into one canvas (gravity.c:323-338): the mass all-reduce covers all of them */
 static int paint_species(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *sets, int nsets,
-                         double Norm, void *canvas)
+                         double Norm, void *canvas, int zr2c)
 {
     double total = 0;
     for (int si = 0; si < nsets; si++) {
@@ -43,7 +43,7 @@ static int paint_species(fpmhip_plan *plan, const fastpm_hip_transport *t, const
     /* A failure here is rank-local (a particle outside this rank's region, an allocation): agree on it before the
      * next collective, or the other ranks wait in an exchange this rank never enters.  The reference raises and
      * MPI_Aborts (logging.c:242-251); every rank returning nonzero lets the binding do the same. */
-    int rc = fpmhip_paint(plan, &sets[0], scale, canvas);
+    int rc = zr2c ? fpmhip_paint_zr2c(plan, &sets[0], scale, canvas) : fpmhip_paint(plan, &sets[0], scale, canvas);
     for (int si = 1; si < nsets && !rc; si++) rc = fpmhip_paint_add(plan, &sets[si], scale, canvas);
     double failed = rc != 0;
     TRY(t->allreduce_sum(t->ctx, &failed));
@@ -52,11 +52,17 @@ static int paint_species(fpmhip_plan *plan, const fastpm_hip_transport *t, const
 }
 
 /* every species read out of the three force meshes (gravity.c:387-395); the last painted one first: the tile binning
- * the plan holds is its */
+ * the plan holds is its.  zc2r: the meshes are half-spectrum rows, the z pass of pm_c2r happens inside the readout. */
+static int readout_species_z(fpmhip_plan *plan, const fpmhip_particles *sets, int nsets, void *f0, void *f1, void *f2, int zc2r)
+{
+    for (int si = nsets - 1; si >= 0; si--)
+        TRY(zc2r ? fpmhip_readout3_zc2r(plan, &sets[si], f0, f1, f2) : fpmhip_readout3(plan, &sets[si], f0, f1, f2));
+    return 0;
+}
+
 static int readout_species(fpmhip_plan *plan, const fpmhip_particles *sets, int nsets, void *f0, void *f1, void *f2)
 {
-    for (int si = nsets - 1; si >= 0; si--) TRY(fpmhip_readout3(plan, &sets[si], f0, f1, f2));
-    return 0;
+    return readout_species_z(plan, sets, nsets, f0, f1, f2, 0);
 }
 
 static int slab_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *sets, int nsets,
@@ -98,15 +104,23 @@ static int slab_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, 
     if (!delta_k) delta_k = fpmhip_plan_buffer(plan, B_DELTA_K);
     if (!canvas || !work || !delta_k) return -2;
 
+    /* Strip plans (fpmhip_plan_strips; csrc/fpm_strips.hip): the paint runs on into the z pass of pm_r2c and the z pass of
+     * pm_c2r into the readout -- between the particle kernels and the y passes the meshes are half-spectrum rows, and the
+     * halo plane travels in that form (the z pass is linear).  Forwards for one species without a softening kernel (as
+     * on one rank, fpm_force.hip), backwards whenever the gradient is taken in k space. */
+    const int strips = fpmhip_plan_strips(plan) && !(lay.gradient_mode == FPMHIP_GRADIENT_REAL && go == 1);
+    const int strips_fwd = strips && nsets == 1 && softening == FPMHIP_SOFTENING_NONE;
+
     /* gravity.c:330-345: total mass over all ranks, paint, normalise; the halo plane goes to rank + 1 */
-    TRY(paint_species(plan, t, sets, nsets, lay.Norm, canvas));
+    TRY(paint_species(plan, t, sets, nsets, lay.Norm, canvas, strips_fwd));
     void *tmp = work;                                           /* free until the forward transform */
     TRY(shift(plan, t, canvas, xl, 1, tmp, +1, plane_bytes));
     TRY(fpmhip_plane_add(plan, fpmhip_plane_ptr(plan, canvas, 0), tmp));
     TRY(fpmhip_check_point(plan, canvas, "After painting"));     /* gravity.c:350 (no-ops without a check hook) */
 
     /* gravity.c:351 pm_r2c, gravity.c:476 softening */
-    TRY(fpmhip_fft_yz_forward(plan, canvas, work));
+    if (strips_fwd) TRY(fpmhip_fft_y_forward(plan, canvas, work));
+    else TRY(fpmhip_fft_yz_forward(plan, canvas, work));
     TRY(exchange(plan, t, work, delta_k, chunk_bytes));
     /* without a softening kernel the forward x pass runs on into the transfer and the backward x pass(es) */
     const int fuse_x = softening == FPMHIP_SOFTENING_NONE && fpmhip_plan_column_fft(plan);
@@ -142,19 +156,33 @@ static int slab_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, 
         else TRY(fpmhip_transfer_fft_x_backward_potx(plan, delta_k, f[0], f[1], kernel));
         TRY(exchange(plan, t, f[0], work, chunk_bytes));
         TRY(exchange(plan, t, f[1], work2, chunk_bytes));
-        TRY(fpmhip_fft_yz_backward(plan, work, f[0]));
+        if (strips) TRY(fpmhip_fft_y_backward(plan, work, f[0]));
+        else TRY(fpmhip_fft_yz_backward(plan, work, f[0]));
         /* the potential column rides along: no second transfer, x pass and all-to-all for it */
         void *potmesh = any_pot ? fpmhip_plan_buffer(plan, B_DELTA_K) : NULL;
         if (any_pot && (delta_k == potmesh || !potmesh)) potmesh = NULL;          /* the caller wants delta_k kept there */
-        TRY(fpmhip_fft_yz_backward_grad2(plan, work2, f[1], f[2], potmesh, kernel));
-        if (potmesh) {
+        if (strips) TRY(fpmhip_fft_y_backward_grad2(plan, work2, f[1], f[2], potmesh, kernel));
+        else TRY(fpmhip_fft_yz_backward_grad2(plan, work2, f[1], f[2], potmesh, kernel));
+        if (potmesh || strips) {
             for (int d = 0; d < 3; d++)
                 TRY(shift(plan, t, f[d], 0, 1, fpmhip_plane_ptr(plan, f[d], xl), -1, plane_bytes));
-            TRY(shift(plan, t, potmesh, 0, 1, fpmhip_plane_ptr(plan, potmesh, xl), -1, plane_bytes));
+            if (potmesh) TRY(shift(plan, t, potmesh, 0, 1, fpmhip_plane_ptr(plan, potmesh, xl), -1, plane_bytes));
             TRY(check_force_meshes(plan, delta_k, f));
-            TRY(readout_species(plan, sets, nsets, f[0], f[1], f[2]));
+            TRY(readout_species_z(plan, sets, nsets, f[0], f[1], f[2], strips));
+            for (int si = 0; si < nsets && potmesh; si++)
+                if (sets[si].potential)
+                    TRY(strips ? fpmhip_readout1_zc2r(plan, &sets[si], potmesh, sets[si].potential, 1, 0)
+                               : fpmhip_readout1(plan, &sets[si], potmesh, sets[si].potential, 1, 0));
+            if (potmesh || !any_pot) return 0;
+            /* strips, a potential column, and the caller's delta_k sits where the potential would have ridden along: the
+             * potential takes the reference's own route below (transfer -> c2r -> readout of a real mesh) */
+            TRY(fpmhip_transfer(plan, delta_k, f[0], kernel, FPMHIP_FIELD_POTENTIAL));
+            TRY(fpmhip_fft_x_backward(plan, f[0]));
+            TRY(exchange(plan, t, f[0], work, chunk_bytes));
+            TRY(fpmhip_fft_yz_backward(plan, work, f[0]));
+            TRY(shift(plan, t, f[0], 0, 1, fpmhip_plane_ptr(plan, f[0], xl), -1, plane_bytes));
             for (int si = 0; si < nsets; si++)
-                if (sets[si].potential) TRY(fpmhip_readout1(plan, &sets[si], potmesh, sets[si].potential, 1, 0));
+                if (sets[si].potential) TRY(fpmhip_readout1(plan, &sets[si], f[0], sets[si].potential, 1, 0));
             return 0;
         }
     } else {
@@ -166,13 +194,14 @@ static int slab_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, 
             TRY(fpmhip_transfer(plan, delta_k, f[d], kernel, d));
             TRY(fpmhip_fft_x_backward(plan, f[d]));
             TRY(exchange(plan, t, f[d], work, chunk_bytes));
-            TRY(fpmhip_fft_yz_backward(plan, work, f[d]));
+            if (strips) TRY(fpmhip_fft_y_backward(plan, work, f[d]));
+            else TRY(fpmhip_fft_yz_backward(plan, work, f[d]));
         }
     }
     for (int d = 0; d < 3; d++)
         TRY(shift(plan, t, f[d], 0, 1, fpmhip_plane_ptr(plan, f[d], xl), -1, plane_bytes));
     TRY(check_force_meshes(plan, delta_k, f));
-    TRY(readout_species(plan, sets, nsets, f[0], f[1], f[2]));
+    TRY(readout_species_z(plan, sets, nsets, f[0], f[1], f[2], strips));
     if (any_pot) {                                              /* gravity.c:487-492 */
         TRY(fpmhip_transfer(plan, delta_k, f[0], kernel, FPMHIP_FIELD_POTENTIAL));
         TRY(fpmhip_fft_x_backward(plan, f[0]));
@@ -272,7 +301,7 @@ static int pencil_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t
     if (!delta_k) delta_k = fpmhip_plan_buffer(plan, B_DELTA_K);
     if (!c || !w[0] || !w[1] || !w[2] || !w[3] || !w[4] || !delta_k) return -2;
 
-    TRY(paint_species(plan, t, sets, nsets, lay->Norm, c));                       /* gravity.c:323-345 */
+    TRY(paint_species(plan, t, sets, nsets, lay->Norm, c, 0));                    /* gravity.c:323-345 */
     TRY(halo_out(plan, t, &g, lay, c, w[3]));
     TRY(fpmhip_check_point(plan, c, "After painting"));                           /* gravity.c:350 */
     TRY(fpmhip_fft_z_forward(plan, c, w[0]));                                     /* gravity.c:351 pm_r2c */

@@ -90,6 +90,12 @@ SYMBOLS = {
     "fpmhip_plan_staged_fft": (_I, [_P]),
     "fpmhip_plan_column_fft": (_I, [_P]),
     "fpmhip_plan_strips": (_I, [_P]),
+    "fpmhip_paint_zr2c": (_I, [_P, ctypes.POINTER(Particles), _D, _P]),
+    "fpmhip_readout3_zc2r": (_I, [_P, ctypes.POINTER(Particles), _P, _P, _P]),
+    "fpmhip_readout1_zc2r": (_I, [_P, ctypes.POINTER(Particles), _P, _P, _I, _I]),
+    "fpmhip_fft_y_forward_range": (_I, [_P, _P, _P, _I, _I]),
+    "fpmhip_fft_y_backward_range": (_I, [_P, _P, _P, _I, _I]),
+    "fpmhip_fft_y_backward_grad2_range": (_I, [_P, _P, _P, _P, _P, _I, _I, _I]),
     "fpmhip_transfer_fft_x_backward_pot": (_I, [_P, _P, _P, _I]),
     "fpmhip_r2c_transfer_fft_x_backward": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "fpmhip_fft_x_forward_transfer_backward": (_I, [_P, _P, _I, _I, _P, _P, _P]),

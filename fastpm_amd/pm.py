@@ -606,6 +606,29 @@ class PM:
                                                          _ptr(out_pot) if out_pot is not None else None,
                                                          _enum(KERNEL_TYPES, kernel), int(x0), int(nx)))
 
+    # ---- strip plans: the particle kernels that take the z passes with them (csrc/fpm_strips.hip), as stage calls
+    def paint_zr2c(self, zrows, store, scale=1.0):
+        """paint x scale + the z pass of pm_r2c: half-spectrum rows [x_loc (+ halo plane)][y][kz]"""
+        check(self._L.fpmhip_paint_zr2c(self._plan, ctypes.byref(store._c()), float(scale), _ptr(zrows)))
+
+    def readout3_zc2r(self, meshes, store):
+        """the z pass of pm_c2r + the readout of the three ACC components; meshes: after the x and y passes"""
+        check(self._L.fpmhip_readout3_zc2r(self._plan, ctypes.byref(store._c()), *[_ptr(m) for m in meshes]))
+
+    def readout_zc2r(self, mesh, store, out, nmemb=1, memb=0):
+        check(self._L.fpmhip_readout1_zc2r(self._plan, ctypes.byref(store._c()), _ptr(mesh), _ptr(out), int(nmemb), int(memb)))
+
+    def fft_y_forward_range(self, zrows, send, x0, nx):
+        check(self._L.fpmhip_fft_y_forward_range(self._plan, _ptr(zrows), _ptr(send), int(x0), int(nx)))
+
+    def fft_y_backward_range(self, recv, zrows, x0, nx):
+        check(self._L.fpmhip_fft_y_backward_range(self._plan, _ptr(recv), _ptr(zrows), int(x0), int(nx)))
+
+    def fft_y_backward_grad2_range(self, kernel, recv, out_y, out_z, x0, nx, out_pot=None):
+        check(self._L.fpmhip_fft_y_backward_grad2_range(self._plan, _ptr(recv), _ptr(out_y), _ptr(out_z),
+                                                        _ptr(out_pot) if out_pot is not None else None,
+                                                        _enum(KERNEL_TYPES, kernel), int(x0), int(nx)))
+
     def staged_fft(self):
         return bool(self._L.fpmhip_plan_staged_fft(self._plan))
 

@@ -419,6 +419,31 @@ int fpmhip_lpt_evolve(fpmhip_plan *plan, double *x_dev, float *v_dev, const floa
 int fpmhip_store_summary(fpmhip_plan *plan, const float *column_dev, int nmemb, int64_t np,
                          double *rmin_host, double *rmax_host, double *rsum1_host, double *rsum2_host);
 
+/* ---- strip plans (fpmhip_plan_strips() != 0: one rank or x slabs, from Nmesh = 320 by default): the particle kernels
+ *      that take the z passes of the transforms with them.  The meshes between them are in the layout BETWEEN the z and
+ *      the y pass -- [x_loc (+1 halo plane)][y][kz] half-spectrum rows at the real mesh's row pitch -- so the mesh halo
+ *      of a slab travels in that form (the z pass is linear: adding the neighbour's halo plane before or after it is
+ *      the same sum).  Sequence on slabs (fastpm_slab_hip.c, distributed.py):
+ *        paint_zr2c -> halo plane xl to rank + 1, fpmhip_plane_add onto its plane 0 -> fft_y_forward (-> the exchange
+ *        chunks) -> all-to-all -> fft_x_forward_transfer_backward -> all-to-all(s) -> fft_y_backward / _grad2 -> plane 0
+ *        of each mesh from rank + 1 into the halo plane -> readout3_zc2r. ---- */
+/* pm_clear + fastpm_paint_local x scale + the z pass of pm_r2c (painter.c:320-339, transfer.c:212-220, pmpfft.c:370-388):
+ * zrows_dev (a mesh buffer) receives the half-spectrum rows of the painted canvas, the halo plane included */
+int fpmhip_paint_zr2c(fpmhip_plan *plan, const fpmhip_particles *p_dev, double scale, void *zrows_dev);
+/* the z pass of pm_c2r + fastpm_readout_local of the three ACC components (pmpfft.c:390-399, painter.c:358-374): k0..k2 are
+ * meshes that have been through the x and y passes (fpmhip_fft_y_backward / _grad2), halo plane filled on slabs */
+int fpmhip_readout3_zc2r(fpmhip_plan *plan, const fpmhip_particles *p_dev, const void *k0_dev, const void *k1_dev,
+                         const void *k2_dev);
+/* ... of one mesh into out[i * nmemb + memb] (the potential column, gravity.c:487-492) */
+int fpmhip_readout1_zc2r(fpmhip_plan *plan, const fpmhip_particles *p_dev, const void *k_dev, float *out_dev, int nmemb,
+                         int memb);
+/* the y passes alone, for the x planes [x0, x0 + nx): forward from half-spectrum rows into the exchange chunks, backward
+ * from the received chunks into half-spectrum rows (plain, or the potential -> y and z components [+ the potential]) */
+int fpmhip_fft_y_forward_range(fpmhip_plan *plan, void *zrows_dev, void *send_dev, int x0, int nx);
+int fpmhip_fft_y_backward_range(fpmhip_plan *plan, void *recv_dev, void *zrows_dev, int x0, int nx);
+int fpmhip_fft_y_backward_grad2_range(fpmhip_plan *plan, void *recv_dev, void *out_y_dev, void *out_z_dev,
+                                      void *out_pot_dev, int kernel, int x0, int nx);
+
 /* ---- per-stage timing with HIP events on the plan's stream (the reference's CLOCK names,
  *      gravity.c:276,320,344,348,369-372,474) ---- */
 enum { FPMHIP_T_SORT = 0, FPMHIP_T_PAINT, FPMHIP_T_R2C, FPMHIP_T_DEALIAS, FPMHIP_T_TRANSFER,

@@ -243,9 +243,11 @@ def test_host_library_exports_the_slab_force():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,P,kernel,gradient_mode", [(32, 2, "1_4", 0), (48, 4, "1_4", 0), (32, 2, "eastwood", 0),
-                                                      (48, 4, "1_4", 1), (40, 2, "3_4", 1)])
-def test_c_host_slab_force_matches_one_rank_oracle(oracle, N, P, kernel, gradient_mode):
+@pytest.mark.parametrize("N,P,kernel,gradient_mode,paint_mode", [
+    (32, 2, "1_4", 0, 0), (48, 4, "1_4", 0, 0), (32, 2, "eastwood", 0, 0), (48, 4, "1_4", 1, 0), (40, 2, "3_4", 1, 0),
+    # strip tiles on the slabs (fpmhip_paint_zr2c / fpmhip_readout3_zc2r, the halo planes as half-spectrum rows)
+    (32, 2, "1_4", 0, 3), (64, 4, "1_4", 0, 3), (64, 2, "eastwood", 0, 3)])
+def test_c_host_slab_force_matches_one_rank_oracle(oracle, N, P, kernel, gradient_mode, paint_mode):
     """The C99 slab sequence with an in-process transport: P host threads, one plan each on the same GPU,
     exchanging through fastpm_hip_loopback (pthread barrier + device-to-device copies) exactly where
     libfastpm would call MPI.  Must equal the one-rank oracle (decomposition invariance)."""
@@ -267,7 +269,8 @@ def test_c_host_slab_force_matches_one_rank_oracle(oracle, N, P, kernel, gradien
                                gradient="real" if gradient_mode else "kspace")
     owner = (np.floor(x[:, 0] * (1.0 / (L / N))).astype(np.int64) % N) // (N // P)
     idx = [np.nonzero(owner == r)[0] for r in range(P)]
-    pms = [PM(N, L, 64, nranks=P, rank=r, gradient_mode=gradient_mode) for r in range(P)]
+    pms = [PM(N, L, 64, nranks=P, rank=r, gradient_mode=gradient_mode, paint_mode=paint_mode) for r in range(P)]
+    assert all(pm.strips() == (paint_mode == 3) for pm in pms)
     stores = [Store(x[idx[r]], potential=True) for r in range(P)]
     dks = [pm.alloc() for pm in pms]
     tr = H.fastpm_hip_loopback_create(P)

@@ -19,7 +19,10 @@ def _split(x, N, L, P):
 @pytest.mark.parametrize("P", [2, 4])
 @pytest.mark.parametrize("load", ["a", "b"])
 @pytest.mark.parametrize("precision", [64, 32])
-def test_virtual_ranks_match_one_rank_oracle(oracle, P, load, precision):
+@pytest.mark.parametrize("paint_mode", [0, 3])
+def test_virtual_ranks_match_one_rank_oracle(oracle, P, load, precision, paint_mode):
+    """paint_mode 3: strip tiles on the slabs -- the paint leaves half-spectrum rows (its halo plane travels in that
+    form), the readout takes the force meshes before their z pass (fpm_strips.hip)"""
     import torch
     from fastpm_amd import PM, Store
     from fastpm_amd.distributed import SlabForce, run_virtual
@@ -28,7 +31,8 @@ def test_virtual_ranks_match_one_rank_oracle(oracle, P, load, precision):
     pmo = oracle.PMOracle(N, L, precision)
     ref = oracle.compute_force(pmo, x, potential=True)
     idx = _split(x, N, L, P)
-    pms = [PM(N, L, precision, nranks=P, rank=r) for r in range(P)]
+    pms = [PM(N, L, precision, nranks=P, rank=r, paint_mode=paint_mode) for r in range(P)]
+    assert all(pm.strips() == (paint_mode == 3) for pm in pms)
     stores = [Store(x[idx[r]], potential=True) for r in range(P)]
     forces = [SlabForce(pm) for pm in pms]
     dks = [pm.alloc() for pm in pms]
@@ -174,6 +178,40 @@ def test_virtual_ranks_with_an_empty_rank(oracle):
         pm.destroy()
 
 
+@pytest.mark.parametrize("kernel,dealias", [("1_4", "gaussian"), ("eastwood", "none"), ("3_2", "two_third"), ("5_4", "none")])
+@pytest.mark.parametrize("P", [2, 4])
+def test_strip_plans_on_slabs_every_branch(oracle, kernel, dealias, P):
+    """strip tiles on slabs through the branches of the sequence: a softening kernel (the real canvas is painted, the
+    readout still takes half-spectrum rows), gradorder-0 kernels (three components through the transposes), a potential
+    column; 64 planes = two marching segments on P = 2, a slab of 16 planes on P = 4"""
+    import torch
+    from fastpm_amd import PM, Store
+    from fastpm_amd.distributed import SlabForce, run_virtual
+    N, nc, L = 64, 32, 96.0
+    x = util.load_b(nc, L, N)
+    pmo = oracle.PMOracle(N, L, 64)
+    ref = oracle.compute_force(pmo, x, kernel=oracle.KERNELS[kernel], softening=oracle.SOFTENINGS[dealias], potential=True)
+    idx = _split(x, N, L, P)
+    pms = [PM(N, L, 64, nranks=P, rank=r, paint_mode=3) for r in range(P)]
+    stores = [Store(x[idx[r]], potential=True) for r in range(P)]
+    dks = [pm.alloc() for pm in pms]
+    forces = [SlabForce(pm, chunks=2) for pm in pms]
+    for call in range(2):                                         # the second call: steady-state binning
+        run_virtual(forces, stores, kernel=kernel, dealias=dealias, delta_ks=dks)
+    torch.cuda.synchronize()
+    acc = np.zeros_like(ref["acc"])
+    pot = np.zeros_like(ref["potential"])
+    for r in range(P):
+        acc[idx[r]] = stores[r].acc.cpu().numpy()
+        pot[idx[r]] = stores[r].potential.cpu().numpy()
+    dk = np.concatenate([pm.complex_view(d).cpu().numpy() for pm, d in zip(pms, dks)], axis=1)
+    assert util.max_err(dk, util.oracle_k_to_xyk(pmo, ref["delta_k"])) <= 1e-14
+    assert util.rel_err(acc, ref["acc"]) <= 1e-6
+    assert util.rel_err(pot, ref["potential"]) <= 1e-6
+    for pm in pms:
+        pm.destroy()
+
+
 @pytest.mark.parametrize("chunks", [1, 2, 4, 8])
 def test_pipelined_exchanges_give_the_same_force(oracle, chunks):
     """SlabForce(chunks=c): the transposes cut into c plane ranges (ranged (y,z) passes, per-range exchange).
@@ -186,8 +224,8 @@ def test_pipelined_exchanges_give_the_same_force(oracle, chunks):
     pmo = oracle.PMOracle(N, L, 64)
     ref = oracle.compute_force(pmo, x, potential=True)
     idx = _split(x, N, L, P)
-    for gradient_mode in (0, 1):
-        pms = [PM(N, L, 64, nranks=P, rank=r, gradient_mode=gradient_mode) for r in range(P)]
+    for gradient_mode, paint_mode in ((0, 0), (1, 0), (0, 3)):
+        pms = [PM(N, L, 64, nranks=P, rank=r, gradient_mode=gradient_mode, paint_mode=paint_mode) for r in range(P)]
         stores = [Store(x[idx[r]], potential=True) for r in range(P)]
         forces = [SlabForce(pm, chunks=chunks) for pm in pms]
         assert len(forces[0]._ranges()) == chunks

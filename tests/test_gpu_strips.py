@@ -8,8 +8,11 @@ import pytest
 import util
 from test_gpu_force import TOL_ACC, TOL_DK, _run
 
+import os
+
 pytestmark = pytest.mark.gpu
 STRIPS, BOXES = 3, 2
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("precision", [64, 32])
@@ -149,7 +152,7 @@ def test_two_species_on_strips(oracle):
 
 def test_strips_are_the_default_from_320():
     from fastpm_amd import PM
-    for N, want in ((256, False), (320, True), (640, False)):        # 640 in fp64: the two-plane window does not fit
+    for N, want in ((256, False), (320, True), (640, True)):         # 640 in fp64: the one-plane readout window
         pm = PM(N, 1.5 * N, 64)
         assert pm.strips() == want, N
         pm.destroy()
@@ -158,12 +161,15 @@ def test_strips_are_the_default_from_320():
     pm.destroy()
 
 
-def test_strips_need_one_rank_and_the_kspace_gradient():
+def test_strips_need_slabs_and_the_kspace_gradient():
     from fastpm_amd import PM
     with pytest.raises(Exception):
-        PM(32, 48.0, 64, nranks=2, rank=0, paint_mode=STRIPS)
+        PM(32, 48.0, 64, nranks=4, rank=0, nranks_y=2, paint_mode=STRIPS)          # pencils: box tiles
     with pytest.raises(Exception):
         PM(32, 48.0, 64, gradient_mode=1, paint_mode=STRIPS)
+    pm = PM(32, 48.0, 64, nranks=2, rank=0, paint_mode=STRIPS)                      # x slabs: yes (test_gpu_slab.py)
+    assert pm.strips()
+    pm.destroy()
     pm = PM(32, 48.0, 64, paint_mode=BOXES)
     pm.destroy()
 
@@ -182,10 +188,13 @@ def test_one_particle_and_no_particles_on_strips(oracle):
     pm.destroy()
 
 
-@pytest.mark.parametrize("N,precision", [(384, 64), (512, 64), (640, 32), (768, 32), (800, 32), (1024, 32)])
+@pytest.mark.parametrize("N,precision", [(384, 64), (512, 64), (640, 32), (768, 32), (800, 32), (1024, 32),
+                                         (640, 64), (768, 64), (800, 64), (1024, 64)])
 def test_largest_strip_meshes_agree_with_box_tiles(N, precision):
-    """Every row length whose window fits (N <= 512 in fp64, <= 1024 in fp32; radix-3 and radix-5 rows among them): the
-    strip path against the box path of the same library (itself held to the oracle at the sizes the oracle can do)."""
+    """Every row length the strip kernels take (two-plane readout window: N <= 512 in fp64, <= 1024 in fp32; the one-plane
+    window beyond, up to N = 1024 in fp64 -- the mesh of configs[2]; the paint's two-plane window of double accumulators
+    ends there in either precision; radix-3 and radix-5 rows among them): the strip path against the box path of the same library (itself held to the oracle at the sizes the oracle
+    can do)."""
     import torch
     from fastpm_amd import PM, Store
     nc, L = 64, 1.5 * N
@@ -206,3 +215,28 @@ def test_largest_strip_meshes_agree_with_box_tiles(N, precision):
     assert util.rel_err(acc[STRIPS][0], acc[BOXES][0]) <= tol
     assert util.rel_err(acc[STRIPS][1], acc[BOXES][1]) <= tol
     assert np.abs(acc[STRIPS][2] - acc[BOXES][2]).max() <= (1e-14 if precision == 64 else 5e-7) * np.abs(acc[BOXES][2]).max()
+
+
+@pytest.mark.parametrize("win", [1, 2])
+@pytest.mark.parametrize("precision", [64, 32])
+def test_both_readout_windows_against_the_oracle(oracle, tmp_path, win, precision):
+    """FPMHIP_RO_WIN = 1: the marching readout with ONE plane in LDS (a particle's sum runs over two steps; what the
+    meshes beyond N = 512 in fp64 take), = 2: two planes.  The switch is read once per process: a child process.  Load C
+    puts thousands of particles into a few strip tiles: the half sums beyond the first two entries per thread wait in
+    the global scratch rows."""
+    import subprocess
+    import sys
+    N, nc, L = 64, 32, 96.0
+    x = util.load_c(nc, L)
+    np.save(tmp_path / "x.npy", x)
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); from fastpm_amd import PM, Store\n"
+            "x = np.load(%r); pm = PM(%d, %r, %d, paint_mode=3); st = Store(x, potential=True)\n"
+            "for i in range(2): pm.compute_force(st, kernel='1_4')\n"
+            "torch.cuda.synchronize(); np.save(%r, st.acc.cpu().numpy()); np.save(%r, st.potential.cpu().numpy())\n"
+            % (ROOT, str(tmp_path / "x.npy"), N, L, precision, str(tmp_path / "acc.npy"), str(tmp_path / "pot.npy")))
+    import os
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FPMHIP_RO_WIN=str(win)), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = oracle.compute_force(oracle.PMOracle(N, L, precision), x, potential=True)
+    assert util.rel_err(np.load(tmp_path / "acc.npy"), ref["acc"]) <= TOL_ACC[precision]
+    assert util.rel_err(np.load(tmp_path / "pot.npy"), ref["potential"]) <= TOL_ACC[precision]
