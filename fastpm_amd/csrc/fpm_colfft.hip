@@ -29,6 +29,16 @@ struct ColMap {
     int rsplit;
 };
 
+// Address map of the fused x kernels: row i = tau + T j of a column lives at jb[j] + (tau / xl) * kchunk + (tau % xl) * rs
+// (+ batch * bstride + column): the k-space block as Nproc[0] sender chunks of xl rows, rows rs apart inside a chunk
+// (fpmhip_layout.okblock; xl = N, one chunk, in the plain layout).  jb[j] = ((T j) / xl) * kchunk + ((T j) % xl) * rs is
+// made on the host: the chunks and T nest (fpm_plan.hip), so the two parts never carry into each other.
+struct XMap {
+    long long jb[32];
+    long long rs, kchunk, bstride;
+    int xl, ncols, tpb, kyb;
+};
+
 __device__ __forceinline__ long long col_addr(const ColMap &m, int batch, int i, int col)
 {
     // a map whose rows are not split (one rank; the side of a y pass that has no exchange) needs no division: the
@@ -134,9 +144,9 @@ __global__ __launch_bounds__((ColCfg<PL, F>::threads)) void colfft_kernel(const 
 template <typename PL, int MODE, bool FWD, typename F>
 __global__ __launch_bounds__((ColCfg<PL, F, true>::threads), (fused_min_waves(ColCfg<PL, F, true>::threads, PL::E, sizeof(F))))
 void colfft_xback3_kernel(const C2<F> *dk, C2<F> *__restrict__ o0, C2<F> *__restrict__ o1, C2<F> *__restrict__ o2,
-                          long long rstride, int ncols, int nzl, int ystart, int zstart, int ntiles, const float *__restrict__ kk,
+                          XMap xm, int nzl, int ystart, int zstart, int ntiles, const float *__restrict__ kk,
                           const float *__restrict__ kt, const double *__restrict__ tw_global, C2<F> *dk_store,
-                          double fwd_scale)
+                          double fwd_scale, int linear)
 {
     using CF = ColCfg<PL, F, true>;
     constexpr int CW = CF::CW, T = PL::T, E = PL::E, N = PL::N;
@@ -144,16 +154,20 @@ void colfft_xback3_kernel(const C2<F> *dk, C2<F> *__restrict__ o0, C2<F> *__rest
     C2<F> *tw = (C2<F> *) smem;
     void *lds = smem + CF::twb;
     const int c = threadIdx.x % CW, tau = threadIdx.x / CW;
-    const int tile = xcd_tile(blockIdx.x, ntiles);
-    const int col = tile * CW + c;
-    const bool live = col < ncols;
-    // uniform 64-bit row base (SGPRs) + one 32-bit per-thread element offset: keeps the load and store addresses
-    // out of the VGPR budget (tau * rstride + col < 2^32 for every supported mesh: T * N * (N/2+1) at most)
-    const unsigned toff = (unsigned) tau * (unsigned) rstride + (unsigned) col;
-    const long long jstride = (long long) T * rstride;
+    const int tile = linear ? (int) blockIdx.x : xcd_tile(blockIdx.x, ntiles);
+    // k-space blocks (fpmhip_layout.okblock): a tile lies inside ONE block of kyb ky rows (= all of them in the plain
+    // layout: one batch)
+    const int batch = tile / xm.tpb;
+    const int col = (tile - batch * xm.tpb) * CW + c;
+    const bool live = col < xm.ncols;
+    // uniform 64-bit row base per register slot j (SGPRs, from the kernel arguments) + one 32-bit per-thread element
+    // offset: keeps the load and store addresses out of the VGPR budget (every offset inside one k-space block is
+    // < 2^32 for every supported mesh: N * N * (N/2+1) / nranks at most)
+    const int tq = tau / xm.xl, tr = tau - tq * xm.xl;
+    const unsigned toff = (unsigned) ((long long) tq * xm.kchunk + (long long) tr * xm.rs + (long long) batch * xm.bstride + col);
     C2<F> b[E];
 #pragma unroll
-    for (int j = 0; j < E; j++) b[j] = live ? ld_stream(&(dk + j * jstride)[toff]) : C2<F>{0, 0};
+    for (int j = 0; j < E; j++) b[j] = live ? ld_stream(&(dk + xm.jb[j])[toff]) : C2<F>{0, 0};
     stage_twiddles(tw, tw_global, PL::TWN);
     if (FWD) {
         C2<F> v[vmax(E)];
@@ -165,11 +179,11 @@ void colfft_xback3_kernel(const C2<F> *dk, C2<F> *__restrict__ o0, C2<F> *__rest
         for (int j = 0; j < E; j++) {
             b[j] = v[j];
             if (fwd_scale != 1.0) { b[j].x = (F) (b[j].x * fwd_scale); b[j].y = (F) (b[j].y * fwd_scale); }   // as colfft_kernel
-            if (live) st_stream_x3(&(dk_store + j * jstride)[toff], b[j]);
+            if (live) st_stream_x3(&(dk_store + xm.jb[j])[toff], b[j]);
         }
     }
-    const int iyl = live ? col / nzl : 0, iz = (live ? col - iyl * nzl : 0) + zstart;     // kz block of a pencil
-    const int iy = iyl + ystart;
+    const int iyb = live ? col / nzl : 0, iz = (live ? col - iyb * nzl : 0) + zstart;     // kz block of a pencil
+    const int iy = batch * xm.kyb + iyb + ystart;
     const double kky = kk[iy], kkz = kk[iz];
     const bool yz_self = iy == (N - iy) % N && iz == (N - iz) % N;
     // raw delta_k -> b (laplace and sign, transfer.c:171-183, gravity.c:17)
@@ -220,9 +234,10 @@ void colfft_xback3_kernel(const C2<F> *dk, C2<F> *__restrict__ o0, C2<F> *__rest
         fft_core<PL, +1, CW, CF::SP>(v, lds, tw, tau, c);
         if (live) {
             C2<F> *dst = dir == 0 ? o0 : (dir == 1 ? o1 : o2);
-            const unsigned toff_o = (unsigned) tau_o * (unsigned) rstride + (unsigned) col;
+            const int tqo = tau_o / xm.xl, tro = tau_o - tqo * xm.xl;
+            const unsigned toff_o = (unsigned) ((long long) tqo * xm.kchunk + (long long) tro * xm.rs + (long long) batch * xm.bstride + col);
 #pragma unroll
-            for (int j = 0; j < E; j++) st_stream_x3(&(dst + j * jstride)[toff_o], v[j]);
+            for (int j = 0; j < E; j++) st_stream_x3(&(dst + xm.jb[j])[toff_o], v[j]);
         }
     }
 }
@@ -341,9 +356,16 @@ int colfft_x(fpmhip_plan *p, int dir, const void *in, void *out, double scale)
 {
     const MeshGeo &g = p->mg;
     const long long plane = (long long) g.yl * g.nzl;
-    ColMap m{0, 0, plane, g.N};
-    return p->f64 ? colfft_launch<double>(p, dir, in, out, m, m, 1, (int) plane, scale)
-                  : colfft_launch<float>(p, dir, in, out, m, m, 1, (int) plane, scale);
+    if (g.kyb == g.yl) {
+        ColMap m{0, 0, plane, g.N};
+        return p->f64 ? colfft_launch<double>(p, dir, in, out, m, m, 1, (int) plane, scale)
+                      : colfft_launch<float>(p, dir, in, out, m, m, 1, (int) plane, scale);
+    }
+    // k-space blocks (fpmhip_layout.okblock): one batch per block of kyb ky rows; row ix at (ix / xl) * chunk + (ix % xl) * rs
+    const long long rs = (long long) g.kyb * g.nzl;
+    ColMap m{(long long) g.xl * rs, g.xl == g.N ? 0 : g.kchunk, rs, g.xl};
+    return p->f64 ? colfft_launch<double>(p, dir, in, out, m, m, g.yl / g.kyb, (int) rs, scale)
+                  : colfft_launch<float>(p, dir, in, out, m, m, g.yl / g.kyb, (int) rs, scale);
 }
 
 // y pass on [x_loc][y][kz] planes.  chunked != 0: the OTHER side of the pass is the slab exchange
@@ -362,6 +384,9 @@ static ColMap ymap_a(const MeshGeo &g)
 }
 static ColMap ymap_b(const MeshGeo &g)
 {
+    // row ky = s' * yl + kb * kyb + r of x plane xi: s' * chunk + kb * (xl * kyb * nzl) + xi * kyb * nzl + r * nzl, and
+    // chunk = (yl / kyb) * (xl * kyb * nzl): the block index ky / kyb runs straight through the chunks
+    if (g.kyb != g.yl) return ColMap{(long long) g.kyb * g.nzl, (long long) g.xl * g.kyb * g.nzl, g.nzl, g.kyb};
     return ColMap{(long long) g.yl * g.nzl, g.yl == g.N ? 0 : (long long) g.xl * g.yl * g.nzl, g.nzl, g.yl};
 }
 
@@ -433,16 +458,33 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
     const MeshGeo &g = p->mg;
     const int N = g.N;
     const long long plane = (long long) g.yl * g.nzl;
+    const bool blocked = g.kyb != g.yl;
     const float *kk = p->d_tab + (2 + potorder) * (size_t) N;
     const float *kt = p->d_tab + gradorder * (size_t) N;
+    static const int x3_linear_env = getenv("FPMHIP_X3_LINEAR") ? atoi(getenv("FPMHIP_X3_LINEAR")) : -1;     // A/B
+    const int x3_linear = x3_linear_env >= 0 ? x3_linear_env : 0;
 #define CALL_X3_Q(PL, P, Q)                                                                                  \
     {                                                                                                        \
         using CF = ColCfg<PL, F, true>;                                                                      \
-        const int ntiles = (int) ((plane + CF::CW - 1) / CF::CW);                                            \
+        XMap xm;                                                                                             \
+        xm.rs = blocked ? (long long) g.kyb * g.nzl : plane;                                                 \
+        xm.xl = blocked ? g.xl : N;                                                                          \
+        xm.kchunk = blocked ? g.kchunk : 0;                                                                  \
+        xm.bstride = blocked ? (long long) g.xl * g.kyb * g.nzl : 0;                                         \
+        xm.ncols = blocked ? g.kyb * g.nzl : (int) plane;                                                    \
+        xm.kyb = g.kyb;                                                                                      \
+        xm.tpb = (xm.ncols + CF::CW - 1) / CF::CW;                                                           \
+        if (blocked && g.xl % PL::T != 0 && PL::T % g.xl != 0)                                               \
+            FPM_FAIL(-1, "internal: the k-space chunks (%d rows) and the x kernel's %d threads per column do not nest", g.xl, PL::T); \
+        for (int j = 0; j < 32; j++) {                                                                       \
+            const long long tj = (long long) PL::T * j;                                                      \
+            xm.jb[j] = (tj / xm.xl) * xm.kchunk + (tj % xm.xl) * xm.rs;                                      \
+        }                                                                                                    \
+        const int ntiles = xm.tpb * (blocked ? g.yl / g.kyb : 1);                                            \
         FPM_TRY(set_lds(colfft_xback3_kernel<PL, P, Q, F>, CF::lds));                                        \
         colfft_xback3_kernel<PL, P, Q, F><<<ntiles, CF::threads, CF::lds, p->stream>>>(                      \
-            (const C2<F> *) dk, (C2<F> *) o0, (C2<F> *) o1, (C2<F> *) o2, plane, (int) plane, g.nzl,        \
-            g.ystart, g.zstart, ntiles, kk, kt, p->d_twiddle, (C2<F> *) dk, fwd_scale);                      \
+            (const C2<F> *) dk, (C2<F> *) o0, (C2<F> *) o1, (C2<F> *) o2, xm, g.nzl,                         \
+            g.ystart, g.zstart, ntiles, kk, kt, p->d_twiddle, (C2<F> *) dk, fwd_scale, x3_linear);           \
     }
 #define CALL_X3_P(PL, P) if (fwd) CALL_X3_Q(PL, P, true) else CALL_X3_Q(PL, P, false)
 #define CALL_X3(PL) if (mode == 1) { CALL_X3_P(PL, 1) } else if (mode == 2) { CALL_X3_P(PL, 2) } else { CALL_X3_P(PL, 0) }

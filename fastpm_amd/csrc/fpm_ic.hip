@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64) void fill_gadget_kernel(MeshGeo g, const unsign
     Ranlxd lower, own;
     lower.seed(conj ? table[(long long) ci * N + cj] : table[(long long) i * N + j]);
     own.seed(table[(long long) i * N + j]);
-    F *row = out + 2 * (((long long) i * g.yl + jl) * g.nzl);
+    F *row = out + 2 * kidx(g, i, jl, 0);
     const int half = N / 2;
     for (int k = 0; k <= half; k++) {
         const bool use_conj = conj && (k == 0 || k == half);
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void induce_correlation_kernel(MeshGeo g, cons
     const int iyl = rem / g.nzl, izl = rem - iyl * g.nzl, iz = izl + g.zstart;
     if (izl >= g.nzv) return;                                 // row padding
     const int iy = iyl + g.ystart;
-    const long long ind = ((long long) ix * g.yl + iyl) * g.nzl + izl;
+    const long long ind = kidx(g, ix, iyl, izl);
     double k2 = 0;
     k2 += kk[ix];
     k2 += kk[iy];

@@ -74,6 +74,8 @@ struct MeshGeo {
     int zstart;        // first global kz of this rank = rank_y * zblk
     int zblk;          // kz modes per rank: nzc on slabs, PFFT's default block ceil(nzc / Nproc[1]) on pencils
     int nzv;           // modes this rank's rows hold: min(zblk, nzc - zstart); entries [nzv, nzl) of a row are padding
+    int kyb;           // ky rows per block of the k-space layout (= yl: plain [x][ky_loc][kz]); see kidx() in fpm_cic.h
+    long long kchunk;  // complex values per sender chunk of the k-space block: xl * yl * nzl
     int ylr;           // local y rows of the real mesh (N / Nproc[1])
     int yrstart;       // first global y row
     int yplanes;       // rows present in a real plane: ylr + y halo
@@ -85,6 +87,15 @@ struct MeshGeo {
     int ntx, nty, ntz; // tile grid over [xplanes][N][N]
     int strips;        // 0: box tiles TILE_X x TILE_Y x TILE_Z; STRIP_Y: strip tiles (ntx = xl, nty = N / STRIP_Y, ntz = 1)
 };
+
+// Element (ix, ky_loc, kz_loc) of a k-space block (fpmhip_layout.okblock): the block is Nproc[0] sender chunks, each
+// [ky_loc / kyb][x_loc][kyb][nzl]; with kyb = yl that is the plain [x][ky_loc][kz_loc].
+__host__ __device__ __forceinline__ long long kidx(const MeshGeo &g, int ix, int iyl, int izl)
+{
+    if (g.kyb == g.yl) return ((long long) ix * g.yl + iyl) * g.nzl + izl;
+    const int s = ix / g.xl, xi = ix - s * g.xl, kb = iyl / g.kyb, r = iyl - kb * g.kyb;
+    return (long long) s * g.kchunk + (((long long) kb * g.xl + xi) * g.kyb + r) * g.nzl + izl;
+}
 
 // device staging of host-resident store columns (fpmhip_force_host / fpmhip_force_species_host)
 struct HostStage {

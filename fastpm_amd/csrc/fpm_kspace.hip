@@ -26,7 +26,7 @@ static inline unsigned blocks_for(long long n, int bs) { return (unsigned) ((n +
     const int iyl = rem / (g).nzl, izl = rem - iyl * (g).nzl;                   \
     const int iy = iyl + (g).ystart, iz = izl + (g).zstart;                     \
     if (izl >= (g).nzv) return;                                                 \
-    const long long ind = ((long long) ix * (g).yl + iyl) * (g).nzl + izl;      \
+    const long long ind = kidx(g, ix, iyl, izl);                                \
     (void) iy; (void) iz;
 
 // gravity_apply_kernel_transfer for COLUMN_ACC / COLUMN_POTENTIAL in one pass, keeping the
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void power_kernel(MeshGeo g, double k0, Cplx<F
         const int iyl = rem / g.nzl, izl = rem - iyl * g.nzl;
         const int iy = iyl + g.ystart, iz = izl + g.zstart;
         if (izl >= g.nzv) continue;
-        const long long ind = ((long long) ix * g.yl + iyl) * g.nzl + izl;
+        const long long ind = kidx(g, ix, iyl, izl);
         long long kk = 0;
         int ik = ix; if (ik > N / 2) ik -= N; kk += (long long) ik * ik;
         ik = iy; if (ik > N / 2) ik -= N; kk += (long long) ik * ik;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void yrow_kernel(F *__restrict__ mesh, F *__re
 // [x][y_loc][kz_loc] (row pitch nzl, nzv of them modes) <-> [y_loc][kz_loc valid][x]  (the reference's PFFT-transposed
 // ORegion, pmpfft.c:198-202).  32 x 32 LDS tile transpose over (x, q = iyl * nzv + iz).  TO_REF: ours -> reference.
 template <typename F, bool TO_REF>
-__global__ __launch_bounds__(256) void reference_layout_kernel(int N, int yl, int nzl, int nzv, Cplx<F> *__restrict__ ours,
+__global__ __launch_bounds__(256) void reference_layout_kernel(MeshGeo g, int N, int yl, int nzl, int nzv, Cplx<F> *__restrict__ ours,
                                                                Cplx<F> *__restrict__ ref)
 {
     __shared__ Cplx<F> tile[32][33];
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void reference_layout_kernel(int N, int yl, in
     const long long q0 = (long long) blockIdx.x * 32;
     const int x0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    auto at = [&](int x, long long q) -> Cplx<F> & { return ours[((long long) x * yl + q / nzv) * nzl + q % nzv]; };
+    auto at = [&](int x, long long q) -> Cplx<F> & { return ours[kidx(g, x, (int) (q / nzv), (int) (q % nzv))]; };
     for (int r = ty; r < 32; r += 8) {
         if (TO_REF) { const int x = x0 + r; const long long q = q0 + tx; if (x < N && q < nq) tile[r][tx] = at(x, q); }
         else { const long long q = q0 + r; const int x = x0 + tx; if (x < N && q < nq) tile[tx][r] = ref[q * N + x]; }
@@ -356,8 +356,8 @@ static int reference_layout(fpmhip_plan *p, void *ours, void *ref)
     const int nzv = (int) p->lay.ovalid_z;
     if (nzv == 0) return 0;
     dim3 grid(blocks_for((long long) g.yl * nzv, 32), blocks_for(g.N, 32));
-    if (p->f64) reference_layout_kernel<double, TO_REF><<<grid, 256, 0, p->stream>>>(g.N, g.yl, g.nzl, nzv, (Cplx<double> *) ours, (Cplx<double> *) ref);
-    else reference_layout_kernel<float, TO_REF><<<grid, 256, 0, p->stream>>>(g.N, g.yl, g.nzl, nzv, (Cplx<float> *) ours, (Cplx<float> *) ref);
+    if (p->f64) reference_layout_kernel<double, TO_REF><<<grid, 256, 0, p->stream>>>(g, g.N, g.yl, g.nzl, nzv, (Cplx<double> *) ours, (Cplx<double> *) ref);
+    else reference_layout_kernel<float, TO_REF><<<grid, 256, 0, p->stream>>>(g, g.N, g.yl, g.nzl, nzv, (Cplx<float> *) ours, (Cplx<float> *) ref);
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -266,6 +266,32 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
     g.N = (int) N; g.xl = xl; g.xstart = rx * xl; g.xplanes = xl + hx;
     g.periodic_x = Nx == 1; g.yl = yl; g.ystart = rx * yl; g.nzc = nzc;
     g.nzl = nzl; g.zstart = ry * zblk; g.zblk = zblk; g.nzv = (int) L.ovalid_z;
+    // k-space blocks (fpmhip_layout.okblock).  Automatic: only for the long columns (N >= 1536) of the hand-written
+    // passes, ~128 KB between consecutive x; the fused x kernels address a thread's rows tau + T j as a per-j uniform
+    // base + a 32-bit thread offset, which needs the sender chunks (xl rows) and T to nest.
+    {
+        int kyb = yl;
+        const bool own = geom->fft_mode == FPMHIP_FFT_AUTO && colfft_supported((int) N);
+        // FPMHIP_KY_BLOCK = n: blocks of n rows wherever the plan would have chosen for itself and n fits (runs the whole
+        // test suite on the blocked layout)
+        static const int env_kb = getenv("FPMHIP_KY_BLOCK") ? atoi(getenv("FPMHIP_KY_BLOCK")) : 0;
+        if (geom->ky_block == 0 && env_kb > 0 && own && yl % env_kb == 0 && (8 % Nx == 0 || Nx % 32 == 0)) {
+            kyb = env_kb;
+        } else if (geom->ky_block > 0) {
+            if (!own || yl % geom->ky_block != 0 || !(8 % Nx == 0 || Nx % 32 == 0)) {
+                delete p;
+                FPM_FAIL(-1, "ky_block %d: needs the hand-written FFT passes, must divide the %d local ky rows, Nproc[0] a divisor of 8", geom->ky_block, yl);
+            }
+            kyb = geom->ky_block;
+        } else if (geom->ky_block == 0 && own && N >= 1536 && (8 % Nx == 0 || Nx % 32 == 0)) {
+            const size_t row_bytes = (size_t) nzl * 2 * p->esize;
+            kyb = 1;
+            while (kyb * 2 <= yl && yl % (kyb * 2) == 0 && (size_t) kyb * 2 * row_bytes <= 160 * 1024) kyb *= 2;
+        }
+        g.kyb = kyb;
+        g.kchunk = (long long) xl * yl * nzl;
+        L.okblock = kyb;
+    }
     g.ylr = ylr; g.yrstart = ry * ylr; g.yplanes = ylr + hy; g.periodic_y = Ny == 1;
     g.str0 = L.plane_elems; g.str1 = 2 * rp; g.rp = rp;
     g.inv_cell = 1.0 / (geom->BoxSize / N);

@@ -422,6 +422,10 @@ class SlabForce(_SlabRank):
         c = int(self.chunks)
         if c <= 1 or self.P == 1 or not getattr(pm, "ranged_fft", lambda: False)() or xl % c != 0:
             return [(0, xl)]
+        # k-space blocks (fpmhip_layout.okblock, the meshes from Nmesh = 1536): a plane range of an exchange chunk
+        # [ky_loc / kb][x_loc][kb][kz] is ky_loc / kb separate pieces -- whole-slab exchanges there
+        if int(getattr(pm.layout, "okblock", 0) or pm.layout.osize[1]) != int(pm.layout.osize[1]):
+            return [(0, xl)]
         return [(i * (xl // c), xl // c) for i in range(c)]
 
     def _backward(self, delta_k, kernel, field, out):

@@ -14,7 +14,7 @@ class Geom(ctypes.Structure):
     _fields_ = [("Nmesh", ctypes.c_int64), ("BoxSize", ctypes.c_double), ("precision", ctypes.c_int32),
                 ("nranks", ctypes.c_int32), ("rank", ctypes.c_int32), ("device", ctypes.c_int32),
                 ("np_max", ctypes.c_int64), ("paint_mode", ctypes.c_int32), ("fft_mode", ctypes.c_int32),
-                ("gradient_mode", ctypes.c_int32), ("nranks_y", ctypes.c_int32)]
+                ("gradient_mode", ctypes.c_int32), ("nranks_y", ctypes.c_int32), ("ky_block", ctypes.c_int32)]
 
 
 class Layout(ctypes.Structure):
@@ -27,7 +27,7 @@ class Layout(ctypes.Structure):
                 ("allocsize", ctypes.c_int64), ("Norm", ctypes.c_double),
                 ("nranks_x", ctypes.c_int32), ("nranks_y", ctypes.c_int32), ("rank_x", ctypes.c_int32),
                 ("rank_y", ctypes.c_int32), ("ihalo_y", ctypes.c_int64), ("ovalid_z", ctypes.c_int64),
-                ("chunk_a_elems", ctypes.c_int64), ("chunk_b_elems", ctypes.c_int64)]
+                ("chunk_a_elems", ctypes.c_int64), ("chunk_b_elems", ctypes.c_int64), ("okblock", ctypes.c_int64)]
 
 
 class Particles(ctypes.Structure):

@@ -355,7 +355,7 @@ class PM:
     """One rank's particle mesh on one MI355X (struct PM + its plans)."""
 
     def __init__(self, Nmesh, BoxSize, precision=64, nranks=1, rank=0, device=None, np_max=0,
-                 paint_mode=PAINT_TILED, fft_mode=FFT_AUTO, gradient_mode=GRADIENT_KSPACE, nranks_y=1):
+                 paint_mode=PAINT_TILED, fft_mode=FFT_AUTO, gradient_mode=GRADIENT_KSPACE, nranks_y=1, ky_block=0):
         self._L = _lib.load_library()
         self._plan = ctypes.c_void_p()
         if not torch.cuda.is_available():
@@ -364,7 +364,7 @@ class PM:
             device = torch.cuda.current_device()
         self.device = torch.device("cuda", int(device))
         g = _lib.Geom(int(Nmesh), float(BoxSize), int(precision), int(nranks), int(rank), int(self.device.index),
-                      int(np_max), int(paint_mode), int(fft_mode), int(gradient_mode), int(nranks_y))
+                      int(np_max), int(paint_mode), int(fft_mode), int(gradient_mode), int(nranks_y), int(ky_block))
         self.gradient_mode = int(gradient_mode)
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream().cuda_stream
@@ -414,8 +414,31 @@ class PM:
         osize[2] >= ovalid_z (rows padded to whole 128-byte lines, a pencil's last kz block); the view stops at ovalid_z."""
         L = self.layout
         n = int(L.complex_elems)
-        full = torch.view_as_complex(buf[: 2 * n].view(n, 2)).view(L.osize[0], L.osize[1], L.osize[2])
-        return full[:, :, : int(L.ovalid_z)]
+        flat = torch.view_as_complex(buf[: 2 * n].view(n, 2))
+        kb = int(getattr(L, "okblock", 0)) or int(L.osize[1])
+        if kb == int(L.osize[1]):
+            return flat.view(L.osize[0], L.osize[1], L.osize[2])[:, :, : int(L.ovalid_z)]
+        # k-space blocks (fpmhip_layout.okblock): [sender chunk][ky_loc / kb][x_loc][kb][kz] -- not a strided view of
+        # [x][ky_loc][kz]: a gathered COPY (write with complex_store)
+        return self._kblocks(flat).permute(0, 2, 1, 3, 4).reshape(L.osize[0], L.osize[1], L.osize[2])[:, :, : int(L.ovalid_z)]
+
+    def _kblocks(self, flat):
+        L = self.layout
+        kb, xl = int(L.okblock), int(L.isize[0])
+        return flat.view(int(L.osize[0]) // xl, int(L.osize[1]) // kb, xl, kb, int(L.osize[2]))
+
+    def complex_store(self, buf, values):
+        """buf <- values, a [x][y_loc][kz (modes)] complex array, whatever the k-space layout of the plan is"""
+        L = self.layout
+        v = torch.as_tensor(values, device=buf.device)
+        kb = int(getattr(L, "okblock", 0)) or int(L.osize[1])
+        if kb == int(L.osize[1]):
+            self.complex_view(buf).copy_(v)
+            return
+        n = int(L.complex_elems)
+        blocks = self._kblocks(torch.view_as_complex(buf[: 2 * n].view(n, 2)))
+        xl, nz = int(L.isize[0]), int(L.ovalid_z)
+        blocks[..., :nz].copy_(v.reshape(int(L.osize[0]) // xl, xl, int(L.osize[1]) // kb, kb, nz).permute(0, 2, 1, 3, 4))
 
     # ---- stages
     def total_mass(self, store):
@@ -538,6 +561,12 @@ class PM:
         out = np.empty((L.osize[1], L.ovalid_z, L.osize[0]), dtype=cdt)      # the reference layout holds the modes only
         check(self._L.fpmhip_export_delta_k(self._plan, _ptr(delta_k), out.ctypes.data_as(ctypes.c_void_p)))
         return out
+
+    def import_delta_k(self, delta_k_host, delta_k):
+        """delta_k (device, the plan's layout) <- a host mesh in the reference's layout [y_loc][kz][x]"""
+        src = np.ascontiguousarray(delta_k_host)
+        check(self._L.fpmhip_import_delta_k(self._plan, src.ctypes.data_as(ctypes.c_void_p), _ptr(delta_k)))
+        return delta_k
 
     def gravity_apply_kernel_transfer_host(self, kernel, delta_k_host, field):
         """gravity_apply_kernel_transfer on host meshes in the reference layout [y_loc][kz][x]."""

@@ -93,6 +93,10 @@ typedef struct {
      * Nproc[1] (the reference's ORegion, pmpfft.c:189-203, with x and z swapped; kz blocks of ceil((N/2+1) / Ny),
      * the last one padded).  Nmesh must be divisible by both. */
     int32_t nranks_y;
+    /* ky rows per block of the k-space layout (see fpmhip_layout.okblock): 0 = the library's choice (blocks only where the
+     * x pass would otherwise walk columns of >= 1536 rows megabytes apart), > 0 = that many rows (must divide the
+     * local ky rows; tests), < 0 = never */
+    int32_t ky_block;
 } fpmhip_geom;
 
 /* What struct PM exposes to the hot path (pmpfft.h:43-70, pmapi.h:3-9).  Real strides are in
@@ -118,6 +122,15 @@ typedef struct {
     int64_t ovalid_z;       /* kz entries of osize[2] that are modes (the last kz block is padded to osize[2]) */
     int64_t chunk_a_elems;  /* FastPMFloat elements per pair in the (y <-> kz) exchange inside a row of Nproc[1] ranks */
     int64_t chunk_b_elems;  /* ... in the (x <-> ky) exchange inside a column of Nproc[0] ranks (= the slab exchange) */
+    /* The k-space block is kept as the (x <-> ky) exchange delivers it: Nproc[0] chunks, one per sender s = x / isize[0],
+     * each [ky_loc / okblock][x_loc][okblock][osize[2]]: element (x, ky_loc, kz_loc) sits at
+     *   (x / x_loc) * chunk + ((ky_loc / okblock) * x_loc + x % x_loc) * okblock * osize[2] + (ky_loc % okblock) * osize[2] + kz_loc
+     * (x_loc = isize[0], chunk = x_loc * osize[1] * osize[2] complex values).  okblock == osize[1] (every mesh below
+     * Nmesh = 1536) is the plain [x][ky_loc][kz_loc] of ostrides.  Long columns take small blocks: consecutive x then
+     * lie ~128 KB apart instead of megabytes (a 2048-row column 4.2 MB apart touches 2048 pages per tile and the x pass
+     * runs at 0.12 of the HBM peak; blocked: 0.5, tools/ubench/xstride.hip).  fpmhip_export / import_delta_k and every
+     * k-space stage call know the layout; hosts that index delta_k themselves go through this formula. */
+    int64_t okblock;
 } fpmhip_layout;
 
 /* The columns of FastPMStore the force step reads and writes (api/fastpm/store.h:62-135). */

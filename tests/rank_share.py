@@ -38,9 +38,9 @@ class ReplicatedSlabForce:
     """fastpm_solver_compute_force (gravity.c:458-529) for rank `rank` of P slabs of an N^3 mesh in the replicated
     universe, every stage call at full per-rank size through the C ABI; kernel 1_4, no softening (the default)."""
 
-    def __init__(self, N, L, P, rank, precision):
+    def __init__(self, N, L, P, rank, precision, paint_mode=0):
         from fastpm_amd import PM
-        self.pm = PM(N, L, precision, nranks=P, rank=rank)
+        self.pm = PM(N, L, precision, nranks=P, rank=rank, paint_mode=paint_mode)
         self.N, self.L, self.P, self.rank = N, L, P, rank
         pm = self.pm
         # the k-space block of rank s carries rank s's ky range: its x passes run on a plan of rank s (tables only)
@@ -60,10 +60,13 @@ class ReplicatedSlabForce:
         ce = pm.exchange_chunk_elems()
         # gravity.c:330-345: all ranks hold the same mass
         mean = P * pm.total_mass(store) / pm.Norm
-        pm.paint(self.canvas, store, 1.0 / mean)
+        # strip plans (the default from Nmesh = 320): the z passes happen inside the particle kernels, the meshes in
+        # between -- halo planes included -- are half-spectrum rows (fpm_strips.hip)
+        strips = pm.strips()
+        (pm.paint_zr2c if strips else pm.paint)(self.canvas, store, 1.0 / mean)
         self.tmp.copy_(pm.plane(self.canvas, xl))               # the previous slab's halo plane = our own
         pm.plane_add(pm.plane(self.canvas, 0), self.tmp)
-        pm.fft_yz_forward(self.canvas, self.send)               # -> [s][x_loc][y_loc][kz]
+        (pm.fft_y_forward if strips else pm.fft_yz_forward)(self.canvas, self.send)     # -> [s][x_loc][y_loc][kz]
         fy, fz = self.canvas, self.send                         # free again after the k-space loop
         for s in range(P):
             chunk = self.send[s * ce:(s + 1) * ce]
@@ -72,15 +75,15 @@ class ReplicatedSlabForce:
             self.kpm[s].fft_x_forward_transfer_backward(kernel, self.block, 2, [self.fx, self.pot])
             self.w1[s * ce:(s + 1) * ce].copy_(self.fx[r * ce:(r + 1) * ce])      # what rank s sends back to r
             self.w2[s * ce:(s + 1) * ce].copy_(self.pot[r * ce:(r + 1) * ce])
-        pm.fft_yz_backward_grad2(kernel, self.w2, fy, fz)
-        pm.fft_yz_backward(self.w1, self.fx)
+        (pm.fft_y_backward_grad2 if strips else pm.fft_yz_backward_grad2)(kernel, self.w2, fy, fz)
+        (pm.fft_y_backward if strips else pm.fft_yz_backward)(self.w1, self.fx)
         for f in (self.fx, fy, fz):                              # the next slab's plane 0 = our own
             pm.plane(f, xl).copy_(pm.plane(f, 0))
-        pm.readout3([self.fx, fy, fz], store)
+        (pm.readout3_zc2r if strips else pm.readout3)([self.fx, fy, fz], store)
         return store.acc
 
 
-def run_rank_share(N, P, precision, rank=3, ncube=None, timing=False):
+def run_rank_share(N, P, precision, rank=3, ncube=None, timing=False, paint_mode=0):
     """Returns (acc of the slab's particles [P*P*n][3], acc of the small cubic problem [n][3], pm timings)."""
     from fastpm_amd import PM, Store
     Ncube = N // P
@@ -95,7 +98,7 @@ def run_rank_share(N, P, precision, rank=3, ncube=None, timing=False):
     ref = st.acc.clone()
     small.destroy()
     x = replicate_into_slab(xc, Lcube, P, rank)
-    run = ReplicatedSlabForce(N, L, P, rank, precision)
+    run = ReplicatedSlabForce(N, L, P, rank, precision, paint_mode)
     store = Store(x)
     if timing:
         run(store)                                               # warm-up: allocations, LDS grants

@@ -22,11 +22,22 @@ def _rel(a, b):
     return float((a - b).abs().max() / b.abs().max())
 
 
-def _chunks(pm, buf, P, yl):
-    """[rank][x_loc][y_loc][kz] view of an exchange buffer, the modes only (rows are padded to whole 128-byte lines)"""
-    nzl, nzv = int(pm.layout.osize[2]), int(pm.layout.ovalid_z)
+def _chunk_blocks(pm, buf, P, yl):
+    """the exchange buffer as [rank][ky_loc / kb][x_loc][kb][kz pitch] (fpmhip_layout.okblock; kb = y_loc: plain chunks)"""
     import torch
-    return torch.view_as_complex(buf[: 2 * P * XL * yl * nzl].view(-1, 2)).view(P, XL, yl, nzl)[..., :nzv]
+    nzl, kb = int(pm.layout.osize[2]), int(pm.layout.okblock)
+    return torch.view_as_complex(buf[: 2 * P * XL * yl * nzl].view(-1, 2)).view(P, yl // kb, XL, kb, nzl)
+
+
+def _chunks(pm, buf, P, yl):
+    """[rank][x_loc][y_loc][kz] copy of an exchange buffer, the modes only (rows are padded to whole 128-byte lines)"""
+    nzl, nzv = int(pm.layout.osize[2]), int(pm.layout.ovalid_z)
+    return _chunk_blocks(pm, buf, P, yl).permute(0, 2, 1, 3, 4).reshape(P, XL, yl, nzl)[..., :nzv]
+
+
+def _chunks_store(pm, buf, P, yl, values):
+    nzv, kb = int(pm.layout.ovalid_z), int(pm.layout.okblock)
+    _chunk_blocks(pm, buf, P, yl)[..., :nzv].copy_(values.reshape(P, XL, yl // kb, kb, nzv).permute(0, 2, 1, 3, 4))
 
 
 @pytest.mark.parametrize("precision", [64, 32])
@@ -62,10 +73,10 @@ def test_long_staged_passes_against_torch_fft(N, precision):
     blk = torch.randn(N, yl, nzc, 2, generator=g, device="cuda", dtype=pm.dtype)
     cblk = torch.view_as_complex(blk).to(torch.complex128)
     recv = pm.alloc()
-    pm.complex_view(recv).copy_(torch.view_as_complex(blk))
+    pm.complex_store(recv, torch.view_as_complex(blk))
     pm.fft_x_forward(recv)
     assert _rel(pm.complex_view(recv).to(torch.complex128), torch.fft.fft(cblk, dim=0) / pm.Norm) <= tol
-    pm.complex_view(recv).copy_(torch.view_as_complex(blk))
+    pm.complex_store(recv, torch.view_as_complex(blk))
     pm.fft_x_backward(recv)
     assert _rel(pm.complex_view(recv).to(torch.complex128), torch.fft.ifft(cblk, dim=0) * N) <= tol
     assert cdt is not None
@@ -85,7 +96,7 @@ def test_long_fused_kernels_equal_what_they_fuse(N, precision, oracle):
     g = torch.Generator(device="cuda").manual_seed(7 * N + precision)
     blk = torch.view_as_complex(torch.randn(N, yl, nzc, 2, generator=g, device="cuda", dtype=pm.dtype))
     dk = pm.alloc()
-    pm.complex_view(dk).copy_(blk)
+    pm.complex_store(dk, blk)
     cv = pm.complex_view
 
     FIELD = {"acc_x": 0, "acc_y": 1, "acc_z": 2, "potential": 3}
@@ -110,7 +121,7 @@ def test_long_fused_kernels_equal_what_they_fuse(N, precision, oracle):
 
     # forward x pass fused in front: recv -> delta_k (stored) -> transfer -> backward x passes
     raw = pm.alloc()
-    pm.complex_view(raw).copy_(blk * pm.Norm)               # so that delta_k = FFT_x(raw) / Norm has unit scale
+    pm.complex_store(raw, blk * pm.Norm)               # so that delta_k = FFT_x(raw) / Norm has unit scale
     expect_dk = pm.alloc()
     expect_dk.copy_(raw)
     pm.fft_x_forward(expect_dk)
@@ -129,7 +140,7 @@ def test_long_fused_kernels_equal_what_they_fuse(N, precision, oracle):
     P = N // XL
     pot = torch.view_as_complex(torch.randn(P, XL, yl, nzc, 2, generator=g, device="cuda", dtype=pm.dtype))
     recv = pm.alloc()
-    _chunks(pm, recv, P, yl).copy_(pot)
+    _chunks_store(pm, recv, P, yl, pot)
     oy, oz, op = pm.alloc(), pm.alloc(), pm.alloc()
     pm.fft_yz_backward_grad2("1_4", recv, oy, oz, out_pot=op)
     plain = pm.alloc()
@@ -143,7 +154,7 @@ def test_long_fused_kernels_equal_what_they_fuse(N, precision, oracle):
     for comp, fac in ((oy, kt[:, None]), (oz, kt[None, :nzc])):
         a = nat * 1j * fac
         a = torch.complex(a.real.to(F), a.imag.to(F))                                    # the rounding of gravity.c:58-60
-        _chunks(pm, recv, P, yl).copy_(a.view(XL, P, yl, nzc).permute(1, 0, 2, 3))
+        _chunks_store(pm, recv, P, yl, a.view(XL, P, yl, nzc).permute(1, 0, 2, 3))
         pm.fft_yz_backward(recv, plain)
         sc = float(real(plain).abs().max())
         assert float((real(comp) - real(plain)).abs().max()) <= tol * sc

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-rank compute of the 8-GPU configs at full per-rank size on ONE GPU (tests/rank_share.py: the replicated
 universe), with per-kernel HIP-event timings against the HBM roofline.  Run it under rocprofv3 for the profile
-summaries in profiles/.    usage: rank_share_bench.py N [precision] [ncube]"""
+summaries in profiles/.    usage: rank_share_bench.py N [precision] [ncube | 0] [paint_mode]"""
 import json
 import os
 import sys
@@ -15,9 +15,10 @@ import rank_share  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 precision = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-ncube = int(sys.argv[3]) if len(sys.argv) > 3 else None
+ncube = int(sys.argv[3]) if len(sys.argv) > 3 and int(sys.argv[3]) > 0 else None
+paint_mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0        # 0: strips where they exist; 2: box tiles (A/B)
 P = 8
-acc, ref, t = rank_share.run_rank_share(N, P, precision, ncube=ncube, timing=True)
+acc, ref, t = rank_share.run_rank_share(N, P, precision, ncube=ncube, timing=True, paint_mode=paint_mode)
 n = ref.shape[0]
 rms = float(ref.double().pow(2).mean().sqrt())
 err = float((acc.view(P * P, n, 3).double() - ref.double()[None]).abs().max()) / rms
