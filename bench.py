@@ -199,6 +199,28 @@ def cpu_baseline(ncores, x_dev, Nmesh, BoxSize, acc_dev, pm):
             "sample": "1 force call of the full workload (%d particles, %d^3 fp64 mesh) in %.2f s with %d OpenMP "
                       "threads + scipy.fft workers on %d host cores (oracle/pm_oracle.c); width chosen by a "
                       "1/8-scale sweep: %s" % (len(x), Nmesh, dt, nth, ncores, ", ".join(tried))}
+    # the reference's own habit (tests/testfunctions.sh:1-5): P MPI ranks x 1 OpenMP thread.  P forked processes on x
+    # slabs, every rank-local stage (ghosts, region-clipped paint, transfer, readout, ghost reduction) in its own
+    # single-threaded process, the distributed DFT on P cores (oracle/ranks_baseline.py); P = 4 as the reference's tests
+    # run it, and the widest P this host and mesh allow up to 32
+    try:
+        from oracle import ranks_baseline
+        legs = []
+        for P in sorted({4, max(p_ for p_ in (4, 8, 16, 32) if p_ <= ncores and Nmesh % p_ == 0)}):
+            t0 = time.perf_counter()
+            acc_r, phases = ranks_baseline.force_ranks_x_1thread(Nmesh, BoxSize, x, P)
+            wall = time.perf_counter() - t0
+            t_force = sum(v for k, v in phases.items() if not k.startswith("decompose"))
+            legs.append({"ranks": P, "threads_per_rank": 1, "cores": P, "value": len(x) / t_force, "unit": "particle-updates/s",
+                         "force_call_s": round(t_force, 3), "wall_s_incl_decompose_and_forks": round(wall, 3),
+                         "phases_s": {k.split(" ")[0]: round(v, 3) for k, v in phases.items()},
+                         "acc_max_err_over_rms_vs_threads_leg": float(np.abs(acc_r - ref["acc"]).max() / np.sqrt((ref["acc"].astype(np.float64) ** 2).mean()))})
+        base["ranks_x_1thread"] = legs
+        base["ranks_x_1thread_note"] = ("P processes x 1 OpenMP thread on x slabs with particle ghosts, as the reference's "
+                                        "tests launch it (OMP_NUM_THREADS=1, mpirun -n 4); the DFT on P pocketfft threads "
+                                        "without PFFT's MPI transposes; `value` above is the 1 process x T threads leg")
+    except Exception as e:
+        base["ranks_x_1thread"] = {"error": repr(e)}
     parity = {"sample": "GPU vs CPU oracle on the full workload's particles",
               "pk_rel_err_max_to_half_nyquist": pk_err, "acc_max_err_over_rms": acc_err}
     # the reference's own golden numbers (tests/run-test-lightcone.check): its 64^3 regression run with every
@@ -243,6 +265,9 @@ def main():
                     help="N > 1 GPUs: process mesh (gpus / nprocy) x nprocy; 1 = x slabs (default), 2 on 8 GPUs = the "
                          "reference's default 4 x 2 pencils (pmpfft.c:117-136)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--static", action="store_true",
+                    help="time every step on the SAME positions (the binning's best case; the default alternates between "
+                         "two position sets 0.05 cell apart)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary legs (host-resident store columns; the 1024^3 mesh the 2e8 target is quoted on)")
     args = ap.parse_args()
@@ -302,15 +327,33 @@ def main():
                 paint_mode=args.paint_mode, fft_mode=args.fft_mode, gradient_mode=1 if gradient == "real" else 0,
                 nranks_y=args.nprocy if world > 1 else 1)
         store = Store(x, device=device)
+        # ... and the same particles a moment later: each one displaced by a seeded Gaussian of 0.05 cell, clamped so that
+        # it keeps its slab / pencil.  The timed steps alternate between the two position sets (the acc / potential
+        # columns are shared): every binning then finds particles that moved since the previous call -- the steady
+        # state of a run (one-pass binning in the previous tile order into slabs with slack) instead of its best case,
+        # identical positions call after call
+        gen2 = torch.Generator(device=device)
+        gen2.manual_seed(4321 + rank)
+        hcell = BoxSize / Nmesh
+        xb = torch.remainder(x + (torch.randn(x.shape, generator=gen2, device=device, dtype=torch.float64) * (0.05 * hcell))
+                             .clamp_(-0.04 * hcell, 0.04 * hcell), BoxSize).contiguous() if args.load == "a" and not args.static else x
+        store_b = Store(xb, device=device)
+        store_b.acc, store_b.potential = store.acc, store.potential
+        stores = [store, store_b]
+        turn = [0]
+
+        def next_store():
+            turn[0] ^= 1
+            return stores[turn[0]]
         delta_k = pm.alloc()
         if world > 1 and args.nprocy > 1:
             from fastpm_amd.distributed import PencilForce
             pf = PencilForce(pm, dist.group.WORLD)
-            step = lambda: pf.compute_force(store, kernel="1_4", dealias="none", delta_k=delta_k)
+            step = lambda: pf.compute_force(next_store(), kernel="1_4", dealias="none", delta_k=delta_k)
         elif world > 1:
             from fastpm_amd.distributed import SlabForce
             holder = {"force": SlabForce(pm, dist.group.WORLD)}
-            step = lambda: holder["force"].compute_force(store, kernel="1_4", dealias="none", delta_k=delta_k)
+            step = lambda: holder["force"].compute_force(next_store(), kernel="1_4", dealias="none", delta_k=delta_k)
             try:                                   # one untimed call first: if the pipelined exchange (plane ranges as
                 step()                             # coalesced isend / irecv batches) is refused by this RCCL build,
                 torch.cuda.synchronize()           # every rank sees the same error and takes the plain
@@ -318,7 +361,7 @@ def main():
                 notes.append("pipelined exchange failed (%r); running with chunks=1" % (e,))
                 holder["force"] = SlabForce(pm, dist.group.WORLD, chunks=1)
         else:
-            step = lambda: pm.compute_force(store, kernel="1_4", softening="none", delta_k=delta_k,
+            step = lambda: pm.compute_force(next_store(), kernel="1_4", softening="none", delta_k=delta_k,
                                             total_mass=float(np_total))
         for _ in range(args.warmup):
             step()
@@ -498,6 +541,8 @@ def main():
                 "load": {"a": "A: lattice + 0.3-cell Gaussian jitter", "b": "B: clustered, Zel'dovich-like rms 4 cells",
                          "c": "C: adversarial, 10 % of particles in 0.1 % of the volume"}[args.load],
                 "kernel": "1_4", "softening": "none",
+                "timed_steps": ("every step on the same positions (--static)" if args.static or args.load != "a" else
+                                "alternate between two position sets 0.05 cell apart: every binning finds moved particles"),
                 "decomposition": ("slab %dx1" % world) if args.nprocy <= 1 or world == 1 else
                                  ("pencil %dx%d" % (world // args.nprocy, args.nprocy)),
                 "gradient": {"kspace": "k space, 3 inverse FFTs (the reference's arithmetic)",

@@ -138,6 +138,9 @@ __global__ __launch_bounds__((ColCfg<PL, F>::threads)) void colfft_kernel(const 
 // MODE 2: two outputs, o0 = the x component and o1 = the potential: the y and z gradient factors depend
 //         on ky / kz only, commute with the x transform and are applied by colfft_yback2_kernel after the
 //         transpose -- one mesh less to write here and, on slabs, one all-to-all less.
+// MODE 3: one output, o0 = the x component alone.  At N = 3072 the two-output form spills (E = 16 / 32 values per thread
+//         held across the transforms: 444 / 716 bytes per lane) and MODE 1 (with FWD) + MODE 3 in two launches are
+//         faster than MODE 2 in one: 60.7 -> 50.9 ms per rank in fp64, 38.9 -> 34.6 ms in fp32.
 // FWD (one rank, no softening between r2c and transfer): `dk` holds the output of the forward y pass; the
 //   kernel first runs the forward x pass (x fwd_scale, as colfft_kernel would), stores delta_k over its input
 //   and carries on from registers -- delta_k is written once and never re-read (one mesh sweep less).
@@ -207,7 +210,7 @@ void colfft_xback3_kernel(const C2<F> *dk, C2<F> *__restrict__ o0, C2<F> *__rest
         b[j].y = (F) (aim * -1.0);
     }
 #pragma unroll 1
-    for (int dir = 0; dir < (MODE == 0 ? 3 : MODE); dir++) {
+    for (int dir = 0; dir < (MODE == 0 ? 3 : (MODE == 3 ? 1 : MODE)); dir++) {
         C2<F> v[vmax(E)];
         // an opaque copy of tau per iteration: keeps the compiler from hoisting the table values,
         // flags and store addresses of all three iterations above the loop, where they would have
@@ -247,11 +250,15 @@ void colfft_xback3_kernel(const C2<F> *dk, C2<F> *__restrict__ o0, C2<F> *__rest
 // with the rounding of gravity.c:58-60 applied to a:  ((F) (-a.im * k), (F) (a.re * k)).  One read of
 // the potential, two writes; the same factors (the float32 k_finite table) as transfer_kernel, applied
 // after the x transform instead of before it -- they do not depend on kx.  Rows = ky, columns = kz.
-template <typename PL, typename F>
+// ONE: a launch makes ONE of the outputs (`only`: 0 = the potential, 1 = y, 2 = z).  Where the input values cannot stay in
+// registers across the transforms (N = 3072: E = 16 / 32 values per thread, 428 / 776 bytes of spills per lane, the pass
+// at 0.12 of the HBM peak) two or three such launches -- each with the register needs of a plain pass -- are faster than
+// one that reads the potential once: 46 -> ms below at 3072^3 fp32 per rank.
+template <typename PL, typename F, bool ONE = false>
 __global__ __launch_bounds__((ColCfg<PL, F>::threads), (fused_min_waves(ColCfg<PL, F>::threads, PL::E, sizeof(F))))
 void colfft_yback2_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ oy, C2<F> *__restrict__ oz,
                           C2<F> *__restrict__ op, ColMap im, ColMap om, int ncols, int ntiles_per_batch, int ntiles,
-                          const float *__restrict__ kt, const double *__restrict__ tw_global, int zstart)
+                          const float *__restrict__ kt, const double *__restrict__ tw_global, int zstart, int only)
 {
     using CF = ColCfg<PL, F>;
     constexpr int CW = CF::CW, T = PL::T, E = PL::E;
@@ -270,10 +277,10 @@ void colfft_yback2_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ oy, 
     // op != nullptr: a third output, the potential itself (gravity.c:487-492 wants it read out too): its y pass
     // comes from the same read instead of a second transfer + x pass (+ all-to-all on slabs)
 #pragma unroll 1
-    for (int dir = op ? 0 : 1; dir < 3; dir++) {
+    for (int dir = ONE ? only : (op ? 0 : 1); dir < (ONE ? only + 1 : 3); dir++) {
         C2<F> v[vmax(E)];
         int tau_o = tau;                     // see colfft_xback3_kernel
-        asm volatile("" : "+v"(tau_o));
+        if (!ONE) asm volatile("" : "+v"(tau_o));
 #pragma unroll
         for (int j = 0; j < E; j++) {
             C2<F> &d = v[in_slot<PL>(j)];
@@ -410,14 +417,26 @@ static int yback2_launch(fpmhip_plan *p, const void *in, void *oy, void *oz, voi
 {
     StageTimer ktm(p, FPMHIP_T_K_YBACK2);
     const float *kt = p->d_tab + gradorder * (size_t) p->mg.N;
+    // one output per launch where the two-output kernel spills (see the kernel); FPMHIP_YBACK_ONE = 0 | 1 forces (A/B)
+    static const int one_env = getenv("FPMHIP_YBACK_ONE") ? atoi(getenv("FPMHIP_YBACK_ONE")) : -1;
+    const bool one = one_env >= 0 ? one_env != 0 : p->mg.N >= 3072;
 #define CALL_Y2(PL)                                                                                          \
     {                                                                                                        \
         using CF = ColCfg<PL, F>;                                                                            \
         const int tpb = (ncols + CF::CW - 1) / CF::CW, ntiles = tpb * nbatch;                                \
-        FPM_TRY(set_lds(colfft_yback2_kernel<PL, F>, CF::lds));                                              \
-        colfft_yback2_kernel<PL, F><<<ntiles, CF::threads, CF::lds, p->stream>>>(                            \
-            (const C2<F> *) in, (C2<F> *) oy, (C2<F> *) oz, (C2<F> *) op, im, om, ncols, tpb, ntiles, kt,    \
-            p->d_twiddle, p->mg.zstart);                                                                     \
+        if (one) {                                                                                           \
+            FPM_TRY(set_lds(colfft_yback2_kernel<PL, F, true>, CF::lds));                                    \
+            const int order[3] = {0, 2, 1};          /* y last: on one rank it may overwrite the input */         \
+            for (int q = op ? 0 : 1; q < 3; q++)                                                             \
+                colfft_yback2_kernel<PL, F, true><<<ntiles, CF::threads, CF::lds, p->stream>>>(              \
+                    (const C2<F> *) in, (C2<F> *) oy, (C2<F> *) oz, (C2<F> *) op, im, om, ncols, tpb, ntiles, kt, \
+                    p->d_twiddle, p->mg.zstart, order[q]);                                                   \
+        } else {                                                                                             \
+            FPM_TRY(set_lds(colfft_yback2_kernel<PL, F>, CF::lds));                                          \
+            colfft_yback2_kernel<PL, F><<<ntiles, CF::threads, CF::lds, p->stream>>>(                        \
+                (const C2<F> *) in, (C2<F> *) oy, (C2<F> *) oz, (C2<F> *) op, im, om, ncols, tpb, ntiles, kt, \
+                p->d_twiddle, p->mg.zstart, 0);                                                              \
+        }                                                                                                    \
     }
 #undef FPM_FAC_KIND
 #define FPM_FAC_KIND FusedFacY
@@ -461,6 +480,9 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
     const bool blocked = g.kyb != g.yl;
     const float *kk = p->d_tab + (2 + potorder) * (size_t) N;
     const float *kt = p->d_tab + gradorder * (size_t) N;
+    // two launches (MODE 1, then MODE 3) where the two-output kernel spills; FPMHIP_X3_SPLIT = 0 | 1 forces (A/B)
+    static const int split_env = getenv("FPMHIP_X3_SPLIT") ? atoi(getenv("FPMHIP_X3_SPLIT")) : -1;
+    const bool split = (split_env >= 0 ? split_env != 0 : N >= 3072) && o0 != dk && o1 != dk && o0 != o1;
     static const int x3_linear_env = getenv("FPMHIP_X3_LINEAR") ? atoi(getenv("FPMHIP_X3_LINEAR")) : -1;     // A/B
     const int x3_linear = x3_linear_env >= 0 ? x3_linear_env : 0;
 #define CALL_X3_Q(PL, P, Q)                                                                                  \
@@ -487,7 +509,18 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
             g.ystart, g.zstart, ntiles, kk, kt, p->d_twiddle, (C2<F> *) dk, fwd_scale, x3_linear);           \
     }
 #define CALL_X3_P(PL, P) if (fwd) CALL_X3_Q(PL, P, true) else CALL_X3_Q(PL, P, false)
-#define CALL_X3(PL) if (mode == 1) { CALL_X3_P(PL, 1) } else if (mode == 2) { CALL_X3_P(PL, 2) } else { CALL_X3_P(PL, 0) }
+#define CALL_X3(PL)                                                                                          \
+    if (mode == 1) { CALL_X3_P(PL, 1) }                                                                      \
+    else if (mode == 2 && split) {                                                                           \
+        /* the potential first (with the forward x pass when asked: delta_k then sits in dk), then the x component */ \
+        void *keep0 = o0;                                                                                    \
+        o0 = o1;                                                                                             \
+        CALL_X3_P(PL, 1)                                                                                     \
+        o0 = keep0;                                                                                          \
+        CALL_X3_Q(PL, 3, false)                                                                              \
+    }                                                                                                        \
+    else if (mode == 2) { CALL_X3_P(PL, 2) }                                                                 \
+    else { CALL_X3_P(PL, 0) }
 #undef FPM_FAC_KIND
 #define FPM_FAC_KIND FusedFacX
     COLFFT_DISPATCH(N, sizeof(F), CALL_X3)

@@ -267,11 +267,15 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
     g.periodic_x = Nx == 1; g.yl = yl; g.ystart = rx * yl; g.nzc = nzc;
     g.nzl = nzl; g.zstart = ry * zblk; g.zblk = zblk; g.nzv = (int) L.ovalid_z;
     // k-space blocks (fpmhip_layout.okblock).  Automatic: only for the long columns (N >= 1536) of the hand-written
-    // passes, ~128 KB between consecutive x; the fused x kernels address a thread's rows tau + T j as a per-j uniform
+    // passes, ~256 KB between consecutive x (per-rank compute of the 2048^3 fp64 slab: 72.2 / 65.6 / 63.7 / 64.7 / 71.4 ms
+    // with blocks of 4 / 8 / 16 / 32 / 64 rows -- small blocks cost the y passes, large ones the x passes); the fused x kernels address a thread's rows tau + T j as a per-j uniform
     // base + a 32-bit thread offset, which needs the sender chunks (xl rows) and T to nest.
     {
         int kyb = yl;
-        const bool own = geom->fft_mode == FPMHIP_FFT_AUTO && colfft_supported((int) N);
+        // Nx > 1 only: the y passes write the blocks, and on one rank they run IN PLACE (input and output in the same
+        // buffer in two different layouts would overwrite rows other workgroups have yet to read); with an exchange
+        // between the passes the input and the output are different buffers (the stage calls insist on it)
+        const bool own = geom->fft_mode == FPMHIP_FFT_AUTO && colfft_supported((int) N) && Nx > 1;
         // FPMHIP_KY_BLOCK = n: blocks of n rows wherever the plan would have chosen for itself and n fits (runs the whole
         // test suite on the blocked layout)
         static const int env_kb = getenv("FPMHIP_KY_BLOCK") ? atoi(getenv("FPMHIP_KY_BLOCK")) : 0;
@@ -280,13 +284,13 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
         } else if (geom->ky_block > 0) {
             if (!own || yl % geom->ky_block != 0 || !(8 % Nx == 0 || Nx % 32 == 0)) {
                 delete p;
-                FPM_FAIL(-1, "ky_block %d: needs the hand-written FFT passes, must divide the %d local ky rows, Nproc[0] a divisor of 8", geom->ky_block, yl);
+                FPM_FAIL(-1, "ky_block %d: needs the hand-written FFT passes, Nproc[0] > 1 (a divisor of 8), and must divide the %d local ky rows", geom->ky_block, yl);
             }
             kyb = geom->ky_block;
         } else if (geom->ky_block == 0 && own && N >= 1536 && (8 % Nx == 0 || Nx % 32 == 0)) {
             const size_t row_bytes = (size_t) nzl * 2 * p->esize;
             kyb = 1;
-            while (kyb * 2 <= yl && yl % (kyb * 2) == 0 && (size_t) kyb * 2 * row_bytes <= 160 * 1024) kyb *= 2;
+            while (kyb * 2 <= yl && yl % (kyb * 2) == 0 && (size_t) kyb * 2 * row_bytes <= 320 * 1024) kyb *= 2;
         }
         g.kyb = kyb;
         g.kchunk = (long long) xl * yl * nzl;

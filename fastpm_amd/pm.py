@@ -507,12 +507,18 @@ class PM:
         check(self._L.fpmhip_powerspectrum(self._plan, _ptr(d1), _ptr(d2) if d2 is not None else None, cp(k), cp(p), cp(n)))
         return k, p, n
 
-    def decic_powerspectrum(self, delta_k):
-        """apply_decic_transfer(delta_k, delta_k) + powerspectrum(delta_k) in one sweep; returns (k, P, Nmodes)."""
+    def decic_powerspectrum_sums(self, delta_k):
+        """apply_decic_transfer(delta_k, delta_k) + the raw bin sums of powerspectrum.c:78-106 (this rank's modes; the
+        reference all-reduces them, :108-119) in one sweep"""
         nb = self.Nmesh // 2
         k, p, n = (np.zeros(nb) for _ in range(3))
         cp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         check(self._L.fpmhip_decic_powerspectrum(self._plan, _ptr(delta_k), cp(k), cp(p), cp(n)))
+        return k, p, n
+
+    def decic_powerspectrum(self, delta_k):
+        """apply_decic_transfer(delta_k, delta_k) + powerspectrum(delta_k) in one sweep; returns (k, P, Nmodes)."""
+        k, p, n = self.decic_powerspectrum_sums(delta_k)
         nz = n != 0
         k[nz] /= n[nz]
         p[nz] /= n[nz]

@@ -21,7 +21,7 @@ class GpuOps:
         else:
             dk = pm.alloc()
             ctype = np.complex128 if pm.precision == 64 else np.complex64
-            pm.complex_view(dk).copy_(torch.from_numpy(np.ascontiguousarray(dk_xyk.astype(ctype))).cuda())
+            pm.complex_store(dk, torch.from_numpy(np.ascontiguousarray(dk_xyk.astype(ctype))).cuda())
         st = Store(q, v=np.zeros((len(q), 3), dtype=np.float32))
         pm_2lpt_solve(pm, dk, st, kernel="1_4")
         torch.cuda.synchronize()
@@ -108,7 +108,7 @@ class SlabGpuOps(GpuOps):
         dks, stores = [], []
         for r, pm in enumerate(self.pms):
             d = pm.alloc()
-            pm.complex_view(d).copy_(torch.from_numpy(np.ascontiguousarray(dk_xyk[:, r * yl:(r + 1) * yl, :].astype(np.complex128))).cuda())
+            pm.complex_store(d, torch.from_numpy(np.ascontiguousarray(dk_xyk[:, r * yl:(r + 1) * yl, :].astype(np.complex128))).cuda())
             dks.append(d)
             stores.append(Store(q[idx[r]]))
         run_virtual_steps(self.lpts, [l.steps(s, d, "1_4") for l, s, d in zip(self.lpts, stores, dks)])

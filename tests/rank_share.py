@@ -54,8 +54,9 @@ class ReplicatedSlabForce:
         for q in self.kpm:
             q.destroy()
 
-    def __call__(self, store, kernel="1_4"):
+    def __call__(self, store, kernel="1_4", pk=False):
         pm, P, r = self.pm, self.P, self.rank
+        self.pk_sums = None
         xl = int(pm.layout.isize[0])
         ce = pm.exchange_chunk_elems()
         # gravity.c:330-345: all ranks hold the same mass
@@ -73,6 +74,9 @@ class ReplicatedSlabForce:
             for j in range(P):                                  # the block of rank s: P copies of chunk s along x
                 self.block[j * ce:(j + 1) * ce].copy_(chunk)
             self.kpm[s].fft_x_forward_transfer_backward(kernel, self.block, 2, [self.fx, self.pot])
+            if pk:      # solver.c:471 + the FORCE/AFTER handler (src/fastpm.c:1734): de-CIC and bin rank s's delta_k
+                sums = self.kpm[s].decic_powerspectrum_sums(self.block)
+                self.pk_sums = sums if self.pk_sums is None else tuple(a + b for a, b in zip(self.pk_sums, sums))
             self.w1[s * ce:(s + 1) * ce].copy_(self.fx[r * ce:(r + 1) * ce])      # what rank s sends back to r
             self.w2[s * ce:(s + 1) * ce].copy_(self.pot[r * ce:(r + 1) * ce])
         (pm.fft_y_backward_grad2 if strips else pm.fft_yz_backward_grad2)(kernel, self.w2, fy, fz)
@@ -117,3 +121,112 @@ def run_rank_share(N, P, precision, rank=3, ncube=None, timing=False, paint_mode
                 t[k] = (a[0] + ms, a[1] + cnt)
     run.destroy()
     return acc, ref, t
+
+
+# ---- sequences of steps at per-rank size: configs[3] (COLA, 2048^3) and configs[4] (variable mesh B = 1 -> 3, P(k) every
+# step) in the replicated universe.  The particles of the slab MOVE (kick, drift, wrap) with the forces the slab computed;
+# what leaves the slab through one face enters through the other (the neighbour is a copy of this rank), so the count
+# stays put and the steady-state binning of later steps walks particles that have changed tiles.
+def _eds_factors(mode, ai, ac, af, n=32):
+    """32-sample kick / drift tables as factors.c:233-371 lays them out, with Einstein-de Sitter integrals standing in for
+    the GSL growth functions (as tests/test_gpu_step.py): plausible magnitudes, exact structure (COLA terms included)."""
+    import numpy as np
+    from fastpm_amd import DriftFactor, KickFactor
+    i = np.arange(n)
+    a = ai * (1.0 * (n - 1 - i) / (n - 1)) + af * (1.0 * i / (n - 1))                       # factors.c:276-277
+    dyyy = -2.0 * (a ** -0.5 - ai ** -0.5)
+    dda = -3.0 * (a ** 0.5 - ai ** 0.5)
+    Dv1, Dv2 = a ** 1.5 - ai ** 1.5, -3.0 / 7 * 2 * (a ** 2.5 - ai ** 2.5)
+    da1, da2 = a - ai, -3.0 / 7 * (a ** 2 - ai ** 2)
+    kick = KickFactor(mode, ai, ac, af, dda, Dv1, Dv2, q1=ac, q2=ac * ac * (1.0 + 7.0 / 3.0))
+    drift = DriftFactor(mode, ai, ac, af, dyyy, da1, da2, Dv1=ac ** 1.5, Dv2=-6.0 / 7 * ac ** 2.5)
+    return kick, drift
+
+
+def run_rank_share_sequence(meshes, P, precision, mode="cola", rank=3, nc_total=None, a0=0.1, a1=1.0, pk_dir=None,
+                            force_amp=1.0):
+    """len(meshes) force evaluations of ONE rank of P slabs with K D (wrap) F K between them (solver.c:289-296 without the
+    second half drift: one drift per step), on the mesh sizes `meshes` (a variable-mesh run switches plans, vpm.c:9-58).
+    nc_total: particles per side of the whole box (default meshes[0] / 2).  Returns a list of per-step records: parity of
+    the slab's accelerations against the small cubic problem evolved alongside, wall time of the slab's force call, and
+    (pk_dir) the P(k) sums over every rank's k-space block with the `# k p N` file the reference writes per step."""
+    import os
+    import numpy as np
+    from fastpm_amd import PM, Store, fastpm_drift_store, fastpm_kick_store
+    from fastpm_amd.pm import fastpm_powerspectrum_write
+    nc_total = nc_total or meshes[0] // 2
+    ncube = nc_total // P
+    Lcube = 3.0 * ncube
+    L = Lcube * P
+    xc = cube_particles(ncube, meshes[0] // P, Lcube, sigma_cells=0.3)
+    n = xc.shape[0]
+    gen = torch.Generator(device="cuda").manual_seed(99)
+    # 2LPT-like displacement columns (COLA reads them in every kick and drift): smooth, a fraction of a cell
+    ph = 2 * np.pi / Lcube
+    dx1c = (0.2 * torch.stack([torch.sin(ph * xc[:, 1]), torch.sin(ph * xc[:, 2]), torch.sin(ph * xc[:, 0])], dim=1)).float()
+    dx2c = (0.05 * torch.stack([torch.cos(ph * xc[:, 2]), torch.cos(ph * xc[:, 0]), torch.cos(ph * xc[:, 1])], dim=1)).float()
+    cube = Store(xc, v=torch.zeros(n, 3, dtype=torch.float32, device="cuda"), dx1=dx1c, dx2=dx2c, a_x=a0, a_v=a0)
+    slab = Store(replicate_into_slab(xc, Lcube, P, rank), v=torch.zeros(P * P * n, 3, dtype=torch.float32, device="cuda"),
+                 dx1=dx1c.repeat(P * P, 1), dx2=dx2c.repeat(P * P, 1), a_x=a0, a_v=a0)
+    del gen
+    steps = np.linspace(a0, a1, len(meshes))
+    runner, runner_N, small = None, None, None
+    records = []
+    for i, (a, N) in enumerate(zip(steps, meshes)):
+        if runner_N != N:                                            # fastpm_find_pm: another mesh from here on
+            if runner is not None:
+                runner.destroy()
+                small.destroy()
+                del runner, small
+                torch.cuda.empty_cache()
+            runner, runner_N = ReplicatedSlabForce(N, L, P, rank, precision), N
+            small = PM(N // P, Lcube, precision)
+        dkc = small.alloc() if pk_dir else None
+        small.compute_force(cube, kernel="1_4", softening="none", delta_k=dkc)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        runner(slab, pk=pk_dir is not None)
+        ev1.record()
+        torch.cuda.synchronize()
+        rms = float(cube.acc.double().pow(2).mean().sqrt())
+        err = float((slab.acc.view(P * P, n, 3).double() - cube.acc.double()[None]).abs().max()) / rms
+        xerr = float((torch.remainder(slab.x.view(P * P, n, 3), Lcube) - cube.x[None]).abs().max()) / (L / N)
+        rec = {"step": i, "a": float(a), "Nmesh": int(N), "force_ms": ev0.elapsed_time(ev1), "acc_err_over_rms": err,
+               "x_dev_cells": min(xerr, abs(xerr - Lcube / (L / N)))}
+        if pk_dir:
+            # the whole box's spectrum = the sum of every rank's bins (MPI_Allreduce in the reference, powerspectrum.c:
+            # 108-119); in the replicated universe only wavenumbers that are multiples of P carry power: the sum of
+            # w |delta_k|^2 over all modes must be that of the small cube's mesh (Parseval), mode for mode
+            ksum, psum, nsum = runner.pk_sums
+            small.apply_decic_transfer(dkc, dkc)
+            kc, pc, nc_ = small.powerspectrum_sums(dkc)
+            rec["pk_total_power_rel_err"] = abs(psum.sum() / pc.sum() - 1.0)
+            nz = nsum != 0
+            k, p = ksum.copy(), psum.copy()
+            k[nz] /= nsum[nz]
+            p[nz] *= L ** 3 / nsum[nz]
+            os.makedirs(pk_dir, exist_ok=True)
+            fn = os.path.join(pk_dir, "powerspec_%0.4f.txt" % a)
+            fastpm_powerspectrum_write(runner.pm, k, p, nsum, fn, float(nc_total) ** 3)
+            rec["pk_file"] = fn
+            rec["pk_nmodes_total"] = float(nsum.sum())
+        records.append(rec)
+        if i + 1 == len(meshes):
+            break
+        af = float(steps[i + 1])
+        ac = float(np.sqrt(a * af))                                  # timemachine.c:68-88: geometric half step
+        kick, drift = _eds_factors(mode, float(a), ac, af)
+        for st, pm_, box in ((cube, small, Lcube), (slab, runner.pm, L)):
+            if force_amp != 1.0:
+                st.acc.mul_(force_amp)
+            fastpm_kick_store(pm_, kick, st, st, af)                 # K: a -> af with the force at a
+            fastpm_drift_store(pm_, drift, st, st, af)               # D
+            if st is cube:
+                st.x.copy_(torch.remainder(st.x, Lcube))
+            else:                                                    # decompose: x back into this rank's slab (its
+                st.x[:, 0] = rank * Lcube + torch.remainder(st.x[:, 0] - rank * Lcube, Lcube)   # neighbours are copies)
+                st.x[:, 1:] = torch.remainder(st.x[:, 1:], L)
+            pm_.invalidate_binning()
+    runner.destroy()
+    small.destroy()
+    return records

@@ -37,7 +37,7 @@ def test_2lpt_solve_and_evolve(oracle, kernel, shift):
     ref1, ref2 = oracle.pm_2lpt_solve(pmo, dk, q, shift=shift, kernel=oracle.KERNELS[kernel])
     pm = PM(N, L, 64)
     d_dk = pm.alloc()
-    pm.complex_view(d_dk).copy_(torch.from_numpy(np.ascontiguousarray(util.oracle_k_to_xyk(pmo, dk))).cuda())
+    pm.complex_store(d_dk, torch.from_numpy(np.ascontiguousarray(util.oracle_k_to_xyk(pmo, dk))).cuda())
     st = Store(q, v=np.zeros_like(q, dtype=np.float32))
     pm_2lpt_solve(pm, d_dk, st, shift=shift, kernel=kernel)
     torch.cuda.synchronize()
@@ -77,7 +77,7 @@ def test_2lpt_on_virtual_slabs(oracle, N, P, kernel):
     dks = []
     for r, pm in enumerate(pms):
         d = pm.alloc()
-        pm.complex_view(d).copy_(torch.from_numpy(np.ascontiguousarray(dkx[:, r * yl:(r + 1) * yl, :])).cuda())
+        pm.complex_store(d, torch.from_numpy(np.ascontiguousarray(dkx[:, r * yl:(r + 1) * yl, :])).cuda())
         dks.append(d)
     stores = [Store(q[idx[r]], v=np.zeros((len(idx[r]), 3), dtype=np.float32)) for r in range(P)]
     ranks = [Slab2LPT(pm) for pm in pms]

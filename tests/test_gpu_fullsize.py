@@ -194,3 +194,57 @@ def test_one_rank_of_the_8_gpu_configs_at_full_per_rank_size(N, precision, ncube
     rms = float(ref.double().pow(2).mean().sqrt())
     err = float((acc.view(64, n, 3).double() - ref.double()[None]).abs().max()) / rms
     assert err <= tol, err
+
+
+# ---- configs[3] / configs[4] as SEQUENCES at per-rank size (tests/rank_share.py::run_rank_share_sequence) ----
+def _need_bytes(N, precision, np_slab):
+    return 7.6 * (N // 8) * N * (N + 2) * (precision // 8) + 120.0 * np_slab
+
+
+def test_config3_cola_steps_at_per_rank_size():
+    """configs[3]: 1024^3 particles on a 2048^3 mesh, COLA stepping (factors.c:136-171 kick, :72-110 drift with the dx1 /
+    dx2 terms), ONE rank's 134 M particles through four force evaluations with K D F K in between: the particles move,
+    leave and re-enter the slab, the later binnings run in their steady state (previous tile order, slabs with slack,
+    the in-stream exact path where a slab overflows).  Every step's accelerations against the small cubic problem
+    evolved alongside."""
+    import gc
+    import torch
+    import rank_share
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < _need_bytes(2048, 64, 134217728):
+        pytest.skip("needs %.0f GB of device memory" % (_need_bytes(2048, 64, 134217728) / 1e9))
+    recs = rank_share.run_rank_share_sequence([2048] * 4, 8, 64, mode="cola", force_amp=30.0)
+    assert len(recs) == 4
+    for r in recs:
+        assert r["acc_err_over_rms"] <= 5e-5, r                   # (float32 v columns integrated over the steps)
+        assert r["x_dev_cells"] <= 1e-4, r                        # the 64 copies and the cube stay together
+    assert recs[-1]["force_ms"] < 4 * recs[0]["force_ms"]          # no step falls off a cliff (rebinning included)
+
+
+def test_config4_variable_mesh_steps_with_pk_at_per_rank_size(tmp_path):
+    """configs[4]: 1024^3 particles, force mesh B = 1 -> 2 -> 3 (vpm.c:9-58: another PM from a_start on), P(k) dumped at
+    every step (src/fastpm.c:1710-1776).  ONE rank's 134 M particles: the B = 1 leg -- 8 particles per cell of the B = 2
+    runs, 4096 per strip tile -- on the 1024^3 mesh, then the 2048^3 and the 3072^3 mesh, in fp64 where 217 GB fit."""
+    import gc
+    import torch
+    import rank_share
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    precision = 64 if free >= _need_bytes(3072, 64, 134217728) else 32
+    if free < _need_bytes(3072, precision, 134217728):
+        pytest.skip("needs %.0f GB of device memory" % (_need_bytes(3072, precision, 134217728) / 1e9))
+    meshes = [1024, 1024, 2048, 2048, 3072]
+    recs = rank_share.run_rank_share_sequence(meshes, 8, precision, mode="fastpm", nc_total=1024, pk_dir=str(tmp_path),
+                                              force_amp=30.0)
+    tol = 1e-5 if precision == 64 else 1e-4
+    for r, N in zip(recs, meshes):
+        assert r["Nmesh"] == N and r["acc_err_over_rms"] <= tol, r
+        assert r["pk_total_power_rel_err"] <= (1e-10 if precision == 64 else 1e-4), r
+        # every mode inside the sphere |k| < k_Nyquist counted (kz = 0 and Nyquist planes once, the others twice)
+        assert 0.5 * float(N) ** 3 < r["pk_nmodes_total"] < float(N) ** 3, r
+        text = open(r["pk_file"]).read().splitlines()
+        assert text[0] == "# k p N " and text[-8] == "# metadata 7" and text[-5] == "# N1 %g int" % (1024.0 ** 3)
+        assert len(text) == 1 + N // 2 + 8

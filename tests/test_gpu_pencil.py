@@ -206,7 +206,7 @@ def test_2lpt_on_virtual_pencils(oracle, Nx, Ny, kernel):
         d = pm.alloc()
         nv = int(Lr.ovalid_z)
         blk = dkx[:, Lr.ostart[1]:Lr.ostart[1] + Lr.osize[1], Lr.ostart[2]:Lr.ostart[2] + nv]
-        pm.complex_view(d).copy_(torch.from_numpy(np.ascontiguousarray(blk)).cuda())
+        pm.complex_store(d, torch.from_numpy(np.ascontiguousarray(blk)).cuda())
         dks.append(d)
     stores = [Store(q[idx[r]], v=np.zeros((len(idx[r]), 3), dtype=np.float32)) for r in range(P)]
     ranks = [Pencil2LPT(pm) for pm in pms]
