@@ -291,9 +291,26 @@ __device__ __forceinline__ void butterflies(C2<F> *v, const C2<F> *tw, int tau)
 // SK: the exchange area's position of (idx, c) is idx * CW + c + SK * (idx / 32) -- a few elements of skew per 32
 // indices move the LDS bank conflicts of the strided gathers out of the way where CW is not a power of two
 // (fpm_strips.hip; 0 everywhere else)
+// CW < 0: row-major, row c at c * (-CW) (the strip kernels' wave-local exchange: every row has its own region)
 template <int CW, int SK> __device__ __forceinline__ int lds_pos(int idx, int c)
 {
+    if (CW < 0) return c * (-CW) + idx;
     return idx * CW + c + (SK ? SK * (idx >> 5) : 0);
+}
+
+// Synchronisation between the LDS writes and reads of an exchange.  WS (wave-local): every row's threads sit in ONE
+// wave and its exchange region is its own, so the wave's own program order is all that is needed -- LDS instructions of
+// a wave execute in order; the fence keeps the compiler from moving them.  The waves of a workgroup then run through
+// their transforms independently instead of meeting at 6 workgroup barriers per transform.
+template <bool WS> __device__ __forceinline__ void fft_sync()
+{
+    if (WS) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
 }
 template <int COMP, int CW, typename F, int SK = 0> __device__ __forceinline__ void lds_put(void *lds, int idx, int c, C2<F> val)
 {
@@ -340,14 +357,14 @@ __device__ __forceinline__ void gather(C2<F> *v, const void *lds, int tau, int c
 // real parts, then the imaginary parts, through an area of N * CW values of F; register slot i holds {new.x, old.y}
 // in between, so no second register set is needed.  The caller has made sure the LDS area is free (a barrier
 // since its last readers).
-template <int RA, int PPA, int RB, int N, int E, int CW, bool SP, typename F, int SK = 0>
+template <int RA, int PPA, int RB, int N, int E, int CW, bool SP, typename F, int SK = 0, bool WS = false>
 __device__ __forceinline__ void exchange(C2<F> *v, void *lds, int tau, int c)
 {
     if (!SP) {
         scatter<RA, PPA, N, E, CW, 0, F, SK>(v, lds, tau, c);
-        __syncthreads();
+        fft_sync<WS>();
         gather<RB, PPA * RA, N, E, CW, 0, F, SK>(v, lds, tau, c);
-        __syncthreads();
+        fft_sync<WS>();
     } else {
         scatter<RA, PPA, N, E, CW, 1, F, SK>(v, lds, tau, c);
         __syncthreads();
@@ -362,7 +379,7 @@ __device__ __forceinline__ void exchange(C2<F> *v, void *lds, int tau, int c)
 
 // Full length-N transform of the E register values of each thread.  In: v[in_slot<PL>(j)] = row tau + T*j; out:
 // v[j] = row tau + T*j, natural order.  The LDS area must be free on entry (barrier) and is free on return.
-template <typename PL, int S, int CW, bool SP, typename F, int SK = 0>
+template <typename PL, int S, int CW, bool SP, typename F, int SK = 0, bool WS = false>
 __device__ __forceinline__ void fft_core(C2<F> *v, void *lds, const C2<F> *tw, int tau, int c)
 {
     constexpr int N = PL::N, E = PL::E, R1 = PL::R1, R2 = PL::R2, R3 = PL::R3, R4 = PL::R4;
@@ -370,13 +387,13 @@ __device__ __forceinline__ void fft_core(C2<F> *v, void *lds, const C2<F> *tw, i
     constexpr bool L1 = R2 == 1, L2 = R3 == 1, L3 = R4 == 1;
     butterflies<R1, 1, N, E, S, L1, TWH>(v, tw, tau);
     if (!L1) {
-        exchange<R1, 1, R2, N, E, CW, SP, F, SK>(v, lds, tau, c);
+        exchange<R1, 1, R2, N, E, CW, SP, F, SK, WS>(v, lds, tau, c);
         butterflies<R2, R1, N, E, S, L2, TWH>(v, tw, tau);
         if (!L2) {
-            exchange<R2, R1, R3, N, E, CW, SP, F, SK>(v, lds, tau, c);
+            exchange<R2, R1, R3, N, E, CW, SP, F, SK, WS>(v, lds, tau, c);
             butterflies<R3, R1 * R2, N, E, S, L3, TWH>(v, tw, tau);
             if (!L3) {
-                exchange<R3, R1 * R2, R4, N, E, CW, SP, F, SK>(v, lds, tau, c);
+                exchange<R3, R1 * R2, R4, N, E, CW, SP, F, SK, WS>(v, lds, tau, c);
                 butterflies<R4, R1 * R2 * R3, N, E, S, true, TWH>(v, tw, tau);
             }
         }
@@ -403,7 +420,7 @@ template <typename F> __device__ __forceinline__ C2<F> r2c_untangle(C2<F> a, C2<
 // A c2r transform reads only the real parts of X[0] and X[N/2] (FFTW, pocketfft and rocFFT all do): with the exact
 // i k gradient (3_2, EASTWOOD, NAIVE) the Nyquist entry of a row does carry an imaginary part.
 // Two barriers; the lds area is free again on return.
-template <typename PL, int RW, int SK, typename F>
+template <typename PL, int RW, int SK, typename F, bool WS = false>
 __device__ __forceinline__ void c2r_prepare(C2<F> *v, C2<F> *x, C2<F> xm, C2<F> *lds, const C2<F> *twn, int tau, int c)
 {
     constexpr int M = PL::N, T = PL::T, E = PL::E;
@@ -411,7 +428,7 @@ __device__ __forceinline__ void c2r_prepare(C2<F> *v, C2<F> *x, C2<F> xm, C2<F> 
 #pragma unroll
     for (int j = 0; j < E; j++) lds[lds_pos<RW, SK>(tau + T * j, c)] = x[j];
     if (tau == 0) lds[lds_pos<RW, SK>(M, c)] = xm;
-    __syncthreads();
+    fft_sync<WS>();
 #pragma unroll
     for (int j = 0; j < E; j++) {
         const int k = tau + T * j;
@@ -423,7 +440,7 @@ __device__ __forceinline__ void c2r_prepare(C2<F> *v, C2<F> *x, C2<F> xm, C2<F> 
         const C2<F> o = cmul(w, d);
         v[in_slot<PL>(j)] = C2<F>{s.x - o.y, s.y + o.x};   // s + i o
     }
-    __syncthreads();                                       // everyone has read its partner
+    fft_sync<WS>();                                       // everyone has read its partner
 }
 
 // W_N^j, j < PL::TWN, from the plan's double table (stride: every `step`-th entry -- the row passes of N = 2M use

@@ -85,6 +85,9 @@ template <typename PL, typename F> struct StripCfg {
 // ------------------------------------------------------------------------------------------------------------------
 // paint
 // ------------------------------------------------------------------------------------------------------------------
+// (Round 3 tried the readout's wave-local z pass here too -- every row's threads in one wave, the transform in the row's own
+// LDS region, two workgroup barriers per plane instead of nine: 0.58 -> 0.63 ms at 512^3 fp64, 4.3 -> 5.4 ms at 1024^3.
+// With two waves per workgroup there is little to decouple, and the row-major exchange costs the reads of the window.)
 template <typename PL, typename F, bool R2C>
 __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads)) void paint_strips_kernel(
     MeshGeo g, int ntiles, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
@@ -240,7 +243,8 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads)) void paint_strips_ke
 // ------------------------------------------------------------------------------------------------------------------
 // readout
 // ------------------------------------------------------------------------------------------------------------------
-template <typename PL, typename F>
+// WS: every row's threads in one wave, the FFT exchanges wave-local (fft_sync in fpm_fftcore.h) in a region per row
+template <typename PL, typename F, bool WS>
 __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_kernel(
     MeshGeo g, int ncomp, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
     const double *__restrict__ sy, const double *__restrict__ sz, const int *__restrict__ sidx, const C2<F> *__restrict__ m0,
@@ -254,7 +258,8 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
     C2<F> *tw = (C2<F> *) smem_st;
     C2<F> *twn = tw + PL::TWN;
     C2<F> *win = twn + M;                          // [2][SLOT]
-    const int c = threadIdx.x % RW, tau = threadIdx.x / RW;
+    constexpr int CWX = WS ? -RP : RW, SKX = WS ? 0 : SK;
+    const int c = WS ? threadIdx.x / T : threadIdx.x % RW, tau = WS ? threadIdx.x % T : threadIdx.x / RW;
     const int nseg = (g.xl + STRIP_XSEG - 1) / STRIP_XSEG;
     // the ncomp workgroups of a (segment, strip) are neighbours (they read the same positions), then the strips
     const int t = xcd_remap(blockIdx.x, ncomp * g.nty * nseg);
@@ -280,8 +285,8 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
     // (rowfft_c2r_kernel's arithmetic)
     auto c2r_to = [&](C2<F> *slot) {
         C2<F> v[vmax(E)];
-        c2r_prepare<PL, RW, SK>(v, x, xm, slot, twn, tau, c);
-        fft_core<PL, +1, RW, false, F, SK>(v, slot, tw, tau, c);
+        c2r_prepare<PL, CWX, SKX, F, WS>(v, x, xm, slot, twn, tau, c);
+        fft_core<PL, +1, CWX, false, F, SKX, WS>(v, slot, tw, tau, c);
 #pragma unroll
         for (int j = 0; j < E; j++) slot[c * RP + tau + T * j] = v[j];
         if (tau == 0) slot[c * RP + M].x = v[0].x;                 // value N of a row = value 0: the z + 1 corner needs no wrap
@@ -347,8 +352,11 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
 // ("finish"), the same additions in the same order.  The half sums of the first PF particles per thread wait in registers
 // together with the positions; what a dense tile has beyond that waits in a global scratch row per component (written and
 // read back one step later: L2).  LDS per workgroup: 29.5 KB at M = 256 in fp64 (two planes: 51 KB), 58 KB at M = 512.
-template <typename PL, typename F>
-__global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), 3) void readout_march_kernel(
+#ifndef FPM_RO_MINW
+#define FPM_RO_MINW 3
+#endif
+template <typename PL, typename F, bool WS>
+__global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? FPM_RO_MINW : 3)) void readout_march_kernel(
     MeshGeo g, int ncomp, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
     const double *__restrict__ sy, const double *__restrict__ sz, const int *__restrict__ sidx, const C2<F> *__restrict__ m0,
     const C2<F> *__restrict__ m1, const C2<F> *__restrict__ m2, float *__restrict__ out, int nmemb, int memb0,
@@ -361,7 +369,8 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), 3) void readout_marc
     C2<F> *tw = (C2<F> *) smem_st;
     C2<F> *twn = tw + PL::TWN;
     C2<F> *S = twn + M;                            // [ro_slot]: the FFT exchange area, then RW real rows of the plane
-    const int tid = threadIdx.x, c = tid % RW, tau = tid / RW;
+    constexpr int CWX = WS ? -RP : RW, SKX = WS ? 0 : SK;
+    const int tid = threadIdx.x, c = WS ? tid / T : tid % RW, tau = WS ? tid % T : tid / RW;
     const int nseg = (g.xl + STRIP_XSEG - 1) / STRIP_XSEG;
     const int t = xcd_remap(blockIdx.x, ncomp * g.nty * nseg);
     const int comp = t % ncomp, strip = (t / ncomp) % g.nty, seg = nseg - 1 - t / (ncomp * g.nty);      // last segment first
@@ -384,8 +393,8 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), 3) void readout_marc
     };
     auto c2r_plane = [&]() {                       // x[] -> the RW real rows of the plane in S (rowfft_c2r_kernel's arithmetic)
         C2<F> v[vmax(E)];
-        c2r_prepare<PL, RW, SK>(v, x, xm, S, twn, tau, c);
-        fft_core<PL, +1, RW, false, F, SK>(v, S, tw, tau, c);
+        c2r_prepare<PL, CWX, SKX, F, WS>(v, x, xm, S, twn, tau, c);
+        fft_core<PL, +1, CWX, false, F, SKX, WS>(v, S, tw, tau, c);
 #pragma unroll
         for (int j = 0; j < E; j++) S[c * RP + tau + T * j] = v[j];
         if (tau == 0) S[c * RP + M].x = v[0].x;                    // value N of a row = value 0: the z + 1 corner needs no wrap
@@ -542,32 +551,42 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
 {
     const MeshGeo &g = p->mg;
     const int nseg = (g.xl + STRIP_XSEG - 1) / STRIP_XSEG;
-    // Two planes of real rows in LDS where three workgroups per CU still fit them (M <= 256 in fp64, 512 in fp32: one
-    // cic_setup per particle and component), ONE plane beyond (M = 512 in fp64 -- the 1024^3 mesh -- would be 100 KB, one
-    // workgroup per CU; a particle's sum then runs over two steps).  Measured at 512^3: fp64 1.643 / 1.643 ms, fp32
-    // 0.93 / 0.98 ms (two / one plane); FPMHIP_RO_WIN = 1 | 2 forces either (A/B).
+    // ONE plane in LDS with wave-local transforms (WS) wherever a row's threads fit one wave (T = M / 8 divides 64: the
+    // power-of-two meshes): the waves of a workgroup go through their c2r transforms independently, two workgroup
+    // barriers per plane instead of eight, four workgroups per CU at M = 256 in fp64.  Other row lengths: two planes
+    // where three workgroups per CU still fit them (one cic_setup per particle and component), one plane beyond.
+    // Measured per force at 512^3 (readout alone), fp64: two planes 1.63 ms, one plane 1.64, one plane + WS 1.27 (two
+    // planes + WS 1.77); fp32: 0.92 / 1.00 / 0.93 (1.05); at 1024^3 fp64 one plane 16.2 -> 15.6 ms with WS, fp32 two
+    // planes 9.2, one plane + WS 8.9.  FPMHIP_RO_WIN = 1 | 2 and FPMHIP_RO_WS = 0 | 1 force either (A/B).
     static const int win_env = getenv("FPMHIP_RO_WIN") ? atoi(getenv("FPMHIP_RO_WIN")) : 0;
+    static const int ws_env = getenv("FPMHIP_RO_WS") ? atoi(getenv("FPMHIP_RO_WS")) : -1;
+    const int T_ = g.N / 2 / 8;                               // threads per row of the E = 8 row plans
+    const bool ws_ok = 64 % T_ == 0;
     const bool two_planes = win_env == 2 ? StripTwoPlanes<F>::fits(g.N / 2, 1)
-                                         : (win_env == 1 ? false : StripTwoPlanes<F>::fits(g.N / 2, 3));
+                          : (win_env == 1 ? false : (!ws_ok && StripTwoPlanes<F>::fits(g.N / 2, 3)));
+    const bool use_ws = ws_ok && (ws_env >= 0 ? ws_env != 0 : !two_planes);
     // the half sums of a dense tile's entries beyond the first two per thread: one double per own entry and component
     const long long part_stride = p->ro_part_elems;
-#define CALL_RO(PL)                                                                                                    \
+#define CALL_RO_W(PL, WS_)                                                                                             \
     {                                                                                                                  \
         using CF = StripCfg<PL, F>;                                                                                    \
         if (two_planes) {                                                                                              \
-            FPM_TRY(grant_lds(readout_strips_kernel<PL, F>, CF::ro_lds, p->device));                                   \
-            readout_strips_kernel<PL, F><<<ncomp * g.nty * nseg, CF::ro_threads, CF::ro_lds, p->stream>>>(             \
+            FPM_TRY(grant_lds(readout_strips_kernel<PL, F, WS_>, CF::ro_lds, p->device));                              \
+            readout_strips_kernel<PL, F, WS_><<<ncomp * g.nty * nseg, CF::ro_threads, CF::ro_lds, p->stream>>>(        \
                 g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                 \
                 (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle);                              \
         } else {                                                                                                       \
-            FPM_TRY(grant_lds(readout_march_kernel<PL, F>, CF::ro1_lds, p->device));                                   \
-            readout_march_kernel<PL, F><<<ncomp * g.nty * nseg, CF::ro_threads, CF::ro1_lds, p->stream>>>(             \
+            FPM_TRY(grant_lds(readout_march_kernel<PL, F, WS_>, CF::ro1_lds, p->device));                              \
+            readout_march_kernel<PL, F, WS_><<<ncomp * g.nty * nseg, CF::ro_threads, CF::ro1_lds, p->stream>>>(        \
                 g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                 \
                 (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride);     \
         }                                                                                                              \
     }
+#define CALL_RO(PL)                                                                                                    \
+    if (64 % PL::T == 0 && use_ws) CALL_RO_W(PL, (64 % PL::T == 0)) else CALL_RO_W(PL, false)
     STRIP_DISPATCH(g.N / 2, CALL_RO)
 #undef CALL_RO
+#undef CALL_RO_W
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }

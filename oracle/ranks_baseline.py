@@ -50,6 +50,54 @@ def _fork_all(P, fn):
     return time.perf_counter() - t0
 
 
+class _Ranks:
+    """P rank processes forked ONCE (before the meshes are touched: forking a process with gigabytes of mapped pages
+    costs more than a phase), each with one OpenMP thread, running the phases the parent names -- barrier in, barrier
+    out, like the ranks of an MPI job between collectives."""
+
+    def __init__(self, P, phases):
+        import multiprocessing as mp
+        ctx = mp.get_context("fork")
+        self.P, self.names = P, list(phases)
+        self.go, self.done = ctx.Barrier(P + 1), ctx.Barrier(P + 1)
+        self.cmd, self.arg, self.failed = ctx.Value("i", -1), ctx.Value("i", 0), ctx.Value("i", 0)
+        fns = [phases[n] for n in self.names]
+
+        def loop(r):
+            os.environ["OMP_NUM_THREADS"] = "1"
+            O.lib().orc_set_threads(1)
+            while True:
+                self.go.wait()
+                k = self.cmd.value
+                if k < 0:
+                    os._exit(0)
+                try:
+                    fns[k](r, self.arg.value)
+                except BaseException:                  # noqa: BLE001
+                    with self.failed.get_lock():
+                        self.failed.value += 1
+                self.done.wait()
+
+        self.procs = [ctx.Process(target=loop, args=(r,), daemon=True) for r in range(P)]
+        for p_ in self.procs:
+            p_.start()
+
+    def run(self, name, arg=0):
+        self.cmd.value, self.arg.value = self.names.index(name), arg
+        t0 = time.perf_counter()
+        self.go.wait()
+        self.done.wait()
+        if self.failed.value:
+            raise RuntimeError("%d rank processes failed in phase %s" % (self.failed.value, name))
+        return time.perf_counter() - t0
+
+    def close(self):
+        self.cmd.value = -1
+        self.go.wait()
+        for p_ in self.procs:
+            p_.join()
+
+
 def force_ranks_x_1thread(N, BoxSize, x, P, precision=64):
     """-> (acc [np][3] float32 in the order of x, dict of phase wall times in seconds)"""
     x = np.ascontiguousarray(x, dtype=np.float64)
@@ -83,8 +131,18 @@ def force_ranks_x_1thread(N, BoxSize, x, P, precision=64):
         ghosts.append(np.concatenate(gx) if gx else np.zeros((0, 3)))
     canvases = [_shared((pms[r].allocsize,), F) for r in range(P)]
     mean = float(len(x)) / pms[0].Norm
+    import scipy.fft
+    C = pms[0].C
+    nzc = N // 2 + 1
+    full = _shared((N, N, N), F)                                       # the assembled real mesh
+    ck = _shared((N, N, nzc), C)                                       # its transform, [x][y][kz]
+    dks = [_shared((pms[r].allocsize,), F) for r in range(P)]
+    acc_l = [_shared((len(local[r]), 3), np.float32) for r in range(P)]
+    acc_g = [_shared((max(len(ghosts[r]), 1), 3), np.float32) for r in range(P)]
+    xr = lambda r: slice(int(pms[r].g.istart[0]), int(pms[r].g.istart[0] + pms[r].g.isize[0]))
+    yr = lambda r: slice(int(pms[r].g.ostart[1]), int(pms[r].g.ostart[1] + pms[r].g.osize[1]))
 
-    def paint(r):
+    def paint(r, _):
         pm = pms[r]
         canvases[r][:] = 0
         pm.paint(canvases[r], local[r])
@@ -92,57 +150,52 @@ def force_ranks_x_1thread(N, BoxSize, x, P, precision=64):
             pm.paint(canvases[r], ghosts[r])
         pm.scale(canvases[r], 1.0 / mean)
 
-    t["paint"] = _fork_all(P, paint)
-    import scipy.fft
-    C = pms[0].C
-    nzc = N // 2 + 1
-    full = _shared((N, N, N), F)                                       # the assembled real mesh
-    ck = _shared((N, N, nzc), C)                                       # its transform, [x][y][kz]
-    dks = [_shared((pms[r].allocsize,), F) for r in range(P)]
-    xr = lambda r: slice(int(pms[r].g.istart[0]), int(pms[r].g.istart[0] + pms[r].g.isize[0]))
-    yr = lambda r: slice(int(pms[r].g.ostart[1]), int(pms[r].g.ostart[1] + pms[r].g.osize[1]))
-
     # pm_r2c (pmpfft.c:370-388): every rank hands in its slab, the DFT runs on P cores, every rank takes its transposed
     # ORegion block [y_loc][kz][x] and scales it by 1 / Norm
-    def slab_in(r):
+    def slab_in(r, _):
         full[xr(r)] = pms[r].real_view(canvases[r])[:, :, :N]
 
-    def block_out(r):
+    def block_out(r, _):
         dks[r][:] = 0
         pms[r].complex_view(dks[r])[...] = np.transpose(ck[:, yr(r), :], (1, 2, 0))
         pms[r].scale(dks[r], 1 / pms[r].Norm)
 
-    t["r2c"] = _fork_all(P, slab_in)
-    t0 = time.perf_counter()
-    ck[...] = scipy.fft.rfftn(full, workers=P)
-    t["r2c"] += time.perf_counter() - t0
-    t["r2c"] += _fork_all(P, block_out)
-    acc_l = [_shared((len(local[r]), 3), np.float32) for r in range(P)]
-    acc_g = [_shared((max(len(ghosts[r]), 1), 3), np.float32) for r in range(P)]
-    t["transfer"] = t["c2r"] = t["readout"] = 0.0
-    for d in range(3):
-        t["transfer"] += _fork_all(P, lambda r: pms[r].kernel_transfer(O.KERNELS["1_4"], dks[r], canvases[r], memb=d))
+    def transfer(r, d):
+        pms[r].kernel_transfer(O.KERNELS["1_4"], dks[r], canvases[r], memb=d)
 
-        # pm_c2r (pmpfft.c:390-399), unnormalised
-        def block_in(r):
-            ck[:, yr(r), :] = np.transpose(pms[r].complex_view(canvases[r]), (2, 0, 1))
+    # pm_c2r (pmpfft.c:390-399), unnormalised
+    def block_in(r, _):
+        ck[:, yr(r), :] = np.transpose(pms[r].complex_view(canvases[r]), (2, 0, 1))
 
-        def slab_out(r):
-            canvases[r][:] = 0
-            pms[r].real_view(canvases[r])[:, :, :N] = full[xr(r)]
+    def slab_out(r, _):
+        canvases[r][:] = 0
+        pms[r].real_view(canvases[r])[:, :, :N] = full[xr(r)]
 
-        t["c2r"] += _fork_all(P, block_in)
+    def readout(r, d):
+        pms[r].readout(canvases[r], local[r], out=acc_l[r], nmemb=3, memb=d)
+        if len(ghosts[r]):
+            pms[r].readout(canvases[r], ghosts[r], out=acc_g[r][:len(ghosts[r])], nmemb=3, memb=d)
+
+    ranks = _Ranks(P, {"paint": paint, "slab_in": slab_in, "block_out": block_out, "transfer": transfer,
+                       "block_in": block_in, "slab_out": slab_out, "readout": readout})
+    try:
+        t["paint"] = ranks.run("paint")
+        t["r2c"] = ranks.run("slab_in")
         t0 = time.perf_counter()
-        full[...] = scipy.fft.irfftn(ck, s=(N, N, N), norm="forward", workers=P)
-        t["c2r"] += time.perf_counter() - t0
-        t["c2r"] += _fork_all(P, slab_out)
-
-        def readout(r):
-            pms[r].readout(canvases[r], local[r], out=acc_l[r], nmemb=3, memb=d)
-            if len(ghosts[r]):
-                pms[r].readout(canvases[r], ghosts[r], out=acc_g[r][:len(ghosts[r])], nmemb=3, memb=d)
-
-        t["readout"] += _fork_all(P, readout)
+        ck[...] = scipy.fft.rfftn(full, workers=P)
+        t["r2c"] += time.perf_counter() - t0
+        t["r2c"] += ranks.run("block_out")
+        t["transfer"] = t["c2r"] = t["readout"] = 0.0
+        for d in range(3):
+            t["transfer"] += ranks.run("transfer", d)
+            t["c2r"] += ranks.run("block_in")
+            t0 = time.perf_counter()
+            full[...] = scipy.fft.irfftn(ck, s=(N, N, N), norm="forward", workers=P)
+            t["c2r"] += time.perf_counter() - t0
+            t["c2r"] += ranks.run("slab_out")
+            t["readout"] += ranks.run("readout", d)
+    finally:
+        ranks.close()
     t0 = time.perf_counter()
     # pm_ghosts_reduce (pmghosts.c:247-307): the ghosts of rank r arrived in sender order; each sender adds its own back
     off = np.zeros(P, dtype=np.int64)

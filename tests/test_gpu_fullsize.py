@@ -242,7 +242,7 @@ def test_config4_variable_mesh_steps_with_pk_at_per_rank_size(tmp_path):
     tol = 1e-5 if precision == 64 else 1e-4
     for r, N in zip(recs, meshes):
         assert r["Nmesh"] == N and r["acc_err_over_rms"] <= tol, r
-        assert r["pk_total_power_rel_err"] <= (1e-10 if precision == 64 else 1e-4), r
+        assert r["pk_total_power_rel_err"] <= (1e-8 if precision == 64 else 1e-4), r
         # every mode inside the sphere |k| < k_Nyquist counted (kz = 0 and Nyquist planes once, the others twice)
         assert 0.5 * float(N) ** 3 < r["pk_nmodes_total"] < float(N) ** 3, r
         text = open(r["pk_file"]).read().splitlines()
