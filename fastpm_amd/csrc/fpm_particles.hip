@@ -318,6 +318,117 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(MeshGeo g, int ntiles,
     }
 }
 
+// The steady-state scatter for STRIP tiles without a workgroup: every wave on its own.  The block kernel above meets at
+// five workgroup barriers per 512 particles (staging, prefix sums, the block's hash table, its global atomics), and the
+// kernel spends 76 % of its wave cycles parked (profiles/r02_sq_counters.md); strips list a particle at most twice (own
+// tile, and the strip above when its cloud reaches it), so there is no dup list to compact: two aggregation rounds per
+// particle slot.  A round finds, for every lane, the first lane with its key and its rank among them (ballots only); then
+// ALL the groups' leaders fetch their slab cursors with one returning atomic instruction, so the wave waits for memory
+// three times (rows, positions, cursors) whatever the number of tiles it touches.
+__device__ __forceinline__ void wave_groups(int key, bool active, int &leader, int &rank, int &count)
+{
+    unsigned long long remaining = __ballot(active);
+    const int lane = __lane_id();
+    leader = lane;
+    rank = 0;
+    count = active ? 1 : 0;
+    for (int round = 0; remaining && round < 8; round++) {
+        const int l = __ffsll((long long) remaining) - 1;
+        const int k = __shfl(key, l);
+        const unsigned long long same = __ballot(active && key == k);
+        if (active && key == k) {
+            leader = l;
+            rank = __popcll(same & ((1ull << lane) - 1ull));
+            count = __popcll(same);
+        }
+        remaining &= ~same;
+    }
+    // (more than 8 distinct keys in a wave -- an incoherent load: the lanes left over act for themselves)
+}
+
+template <bool ORDERED>
+__global__ __launch_bounds__(256) void bin_scatter_wave_kernel(MeshGeo g, int ntiles, const double *__restrict__ x,
+                                                               const float *__restrict__ mass, long long np,
+                                                               const int *__restrict__ order, const int *__restrict__ beg,
+                                                               const int *__restrict__ cap, int *__restrict__ cnt,
+                                                               double *__restrict__ sx, double *__restrict__ sy,
+                                                               double *__restrict__ sz, float *__restrict__ smass,
+                                                               int *__restrict__ sidx, int *__restrict__ flags, long long alloc)
+{
+    const int lane = threadIdx.x & 63;
+    const long long j0 = ((long long) blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 * BIN_PPT) + lane;
+    int row[BIN_PPT];
+    bool active[BIN_PPT];
+#pragma unroll
+    for (int u = 0; u < BIN_PPT; u++) {
+        const long long j = j0 + u * 64;
+        active[u] = j < np;
+        row[u] = active[u] ? (ORDERED ? order[j] : (int) j) : 0;
+    }
+    double px[BIN_PPT], py[BIN_PPT], pz[BIN_PPT];
+    float pm[BIN_PPT];
+#pragma unroll
+    for (int u = 0; u < BIN_PPT; u++) {
+        px[u] = py[u] = pz[u] = 0;
+        pm[u] = 0;
+        if (active[u]) {
+            const long long i = row[u];
+            px[u] = x[3 * i]; py[u] = x[3 * i + 1]; pz[u] = x[3 * i + 2];
+            if (mass) pm[u] = mass[i];
+        }
+    }
+    // keys: slot 2 u = the own tile, slot 2 u + 1 = the strip above (when the cloud reaches it)
+    int key[2 * BIN_PPT];
+    bool need[2 * BIN_PPT];
+    bool spilled = false;
+#pragma unroll
+    for (int u = 0; u < BIN_PPT; u++) {
+        key[2 * u] = key[2 * u + 1] = 0;
+        need[2 * u] = need[2 * u + 1] = false;
+        if (active[u]) {
+            Cic c;
+            if (!cic_setup(g, px[u], py[u], pz[u], c)) {
+                atomicAdd(&flags[FLAG_UNOWNED_FAST], 1);
+                active[u] = false;
+            } else {
+                int t0[3], t1[3];
+                tile_coords(g, c, t0, t1);
+                key[2 * u] = tile_id(g, t0[0], t0[1], 0);
+                need[2 * u] = true;
+                if (t1[1] != t0[1]) {
+                    key[2 * u + 1] = ntiles + tile_id(g, t0[0], t1[1], 0);
+                    need[2 * u + 1] = true;
+                }
+            }
+        }
+    }
+    int leader[2 * BIN_PPT], rank[2 * BIN_PPT], base[2 * BIN_PPT], kb[2 * BIN_PPT], kc[2 * BIN_PPT];
+#pragma unroll
+    for (int q = 0; q < 2 * BIN_PPT; q++) {
+        int count;
+        wave_groups(key[q], need[q], leader[q], rank[q], count);
+        base[q] = 0;
+        kb[q] = kc[q] = 0;
+        if (need[q]) { kb[q] = beg[key[q]]; kc[q] = cap[key[q]]; }
+        if (need[q] && leader[q] == lane) base[q] = atomicAdd(&cnt[key[q]], count);      // every group's leader at once
+    }
+#pragma unroll
+    for (int q = 0; q < 2 * BIN_PPT; q++) {
+        const int local = __shfl(base[q], leader[q]) + rank[q];
+        if (!need[q]) continue;
+        const int u = q >> 1;
+        if (local < kc[q] && (long long) kb[q] + local < alloc) {
+            const int slot = kb[q] + local;
+            sx[slot] = px[u]; sy[slot] = py[u]; sz[slot] = pz[u];
+            if (smass) smass[slot] = pm[u];
+            sidx[slot] = row[u];
+        } else {
+            spilled = true;
+        }
+    }
+    if (__ballot(spilled) && lane == 0) flags[FLAG_NEED_FULL] = 1;
+}
+
 // capacity of every slab from the counts: + 25 % + 32 while the arrays have room for that, the exact counts
 // otherwise; more entries than the arrays hold at all is the (lazily reported) hard overflow
 __global__ __launch_bounds__(256) void slab_caps_kernel(const int *__restrict__ cnt, const int *__restrict__ off, int nkeys,
@@ -1174,7 +1285,16 @@ static int bin_particles_once(fpmhip_plan *p, const fpmhip_particles *pt, bool *
         // the store's rows is: 0.62 / 0.67 / 0.9 ms on loads A / B / C (16.8 M particles), against 0.56 / 0.75 / 2.6 ms
         // walking the rows as they lie.  FPMHIP_BIN_ORDER=0 selects the latter (A/B).
         static const bool ordered = !(getenv("FPMHIP_BIN_ORDER") && atoi(getenv("FPMHIP_BIN_ORDER")) == 0);
-        if (ordered)
+        static const int wave_env = getenv("FPMHIP_BIN_WAVE") ? atoi(getenv("FPMHIP_BIN_WAVE")) : 1;      // A/B
+        if (p->mg.strips && wave_env && ordered)
+            bin_scatter_wave_kernel<true><<<blocks_for(np, 256 * BIN_PPT), 256, 0, p->stream>>>(
+                p->mg, nt, pt->x, pt->mass, np, p->order[1], p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
+                pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, (long long) p->bin_alloc);
+        else if (p->mg.strips && wave_env)
+            bin_scatter_wave_kernel<false><<<blocks_for(np, 256 * BIN_PPT), 256, 0, p->stream>>>(
+                p->mg, nt, pt->x, pt->mass, np, nullptr, p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
+                pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, (long long) p->bin_alloc);
+        else if (ordered)
             bin_scatter_kernel<true, false><<<blocks_for(np, BIN_BLOCK), 256, sizeof(ScatterLds<dup_cap<false>()>), p->stream>>>(
                 p->mg, nt, pt->x, pt->mass, np, p->order[1], p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
                 pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, nullptr, (long long) p->bin_alloc);

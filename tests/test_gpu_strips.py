@@ -217,13 +217,14 @@ def test_largest_strip_meshes_agree_with_box_tiles(N, precision):
     assert np.abs(acc[STRIPS][2] - acc[BOXES][2]).max() <= (1e-14 if precision == 64 else 5e-7) * np.abs(acc[BOXES][2]).max()
 
 
-@pytest.mark.parametrize("win", [1, 2])
+@pytest.mark.parametrize("win,ws", [(1, 1), (1, 0), (2, 0), (2, 1)])
 @pytest.mark.parametrize("precision", [64, 32])
-def test_both_readout_windows_against_the_oracle(oracle, tmp_path, win, precision):
-    """FPMHIP_RO_WIN = 1: the marching readout with ONE plane in LDS (a particle's sum runs over two steps; what the
-    meshes beyond N = 512 in fp64 take), = 2: two planes.  The switch is read once per process: a child process.  Load C
-    puts thousands of particles into a few strip tiles: the half sums beyond the first two entries per thread wait in
-    the global scratch rows."""
+def test_both_readout_windows_against_the_oracle(oracle, tmp_path, win, ws, precision):
+    """FPMHIP_RO_WIN = 1: the marching readout with ONE plane in LDS (a particle's sum runs over two steps; the default
+    on the power-of-two meshes), = 2: two planes; FPMHIP_RO_WS = 1: the z transforms wave-local (a row's threads in one
+    wave, no workgroup barriers inside a transform), = 0: through workgroup barriers.  The switches are read once per
+    process: a child process.  Load C puts thousands of particles into a few strip tiles: the half sums beyond the first
+    two entries per thread wait in the global scratch rows."""
     import subprocess
     import sys
     N, nc, L = 64, 32, 96.0
@@ -235,7 +236,8 @@ def test_both_readout_windows_against_the_oracle(oracle, tmp_path, win, precisio
             "torch.cuda.synchronize(); np.save(%r, st.acc.cpu().numpy()); np.save(%r, st.potential.cpu().numpy())\n"
             % (ROOT, str(tmp_path / "x.npy"), N, L, precision, str(tmp_path / "acc.npy"), str(tmp_path / "pot.npy")))
     import os
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FPMHIP_RO_WIN=str(win)), capture_output=True, text=True)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FPMHIP_RO_WIN=str(win), FPMHIP_RO_WS=str(ws)),
+                       capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     ref = oracle.compute_force(oracle.PMOracle(N, L, precision), x, potential=True)
     assert util.rel_err(np.load(tmp_path / "acc.npy"), ref["acc"]) <= TOL_ACC[precision]
