@@ -117,7 +117,7 @@ STAGES_OF_KERNELS = {"k_colfft": "r2c/c2r", "k_rowfft": "r2c", "k_zc2r": "c2r", 
 
 
 
-PMC_PROFILE_TAG = "r02"          # profiles/<tag>_<gradient>_traffic.json: the committed PMC passes of this round
+PMC_PROFILE_TAG = "r03"          # profiles/<tag>_<gradient>_traffic.json: the committed PMC passes of this round
 
 
 def workload_label(nc, Nmesh, precision, world, own_fft):
@@ -479,7 +479,8 @@ def main():
             # the paint timer covers paint + z r2c pass, the readout timer z c2r pass + readout (fpm_strips.hip); their
             # algorithmic bytes are the paint's and the readout's: the meshes between them never reach HBM
             KERNELS["paint"] = "fpm::paint_strips_kernel"
-            KERNELS["readout"] = "fpm::readout_strips_kernel"
+            # (one plane in LDS + wave-local z transforms on the power-of-two meshes; two planes elsewhere: fpm_strips.hip)
+            KERNELS["readout"] = "fpm::readout_march_kernel" if 64 % max(Nmesh // 16, 1) == 0 else "fpm::readout_strips_kernel"
         elif args.precision == 64:
             KERNELS["readout"] = "fpm::readout1of3_tiles_kernel"
         stages = {}
@@ -512,7 +513,7 @@ def main():
         if "sort" in stages:                      # two kernels + a scan behind one timer
             a = ab["sort"] / (tm["sort"][0] / tm["sort"][1] * 1e-3) / 1e9
             tr = pmc_traffic("sort", Nmesh, np_total, args, world)
-            per_kernel["sort"] = {"kernel": "fpm::bin_scatter_kernel + slab layout", "frac": round(a / HBM_PEAK_GBS, 4),
+            per_kernel["sort"] = {"kernel": ("fpm::bin_scatter_wave_kernel" if strips else "fpm::bin_scatter_kernel") + " + slab layout", "frac": round(a / HBM_PEAK_GBS, 4),
                                   "avg_launch_ms": stages["sort"]["avg_ms"], "launches_per_step": stages["sort"]["launches_per_step"],
                                   "traffic_over_alg": round(tr / ab["sort"], 3) if tr else None}
         if strips:
