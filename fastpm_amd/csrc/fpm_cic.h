@@ -54,6 +54,30 @@ __device__ __forceinline__ bool cic_setup(const MeshGeo &g, double px, double py
     return mine;
 }
 
+// Strip entries (g.strips) do not keep the position but what cic_setup makes of it: the three fractional parts D = X - I
+// (the exact doubles of painter-cic.c:45-55) in sx / sy / sz and the base cell (iy, iz) packed in scell -- the x plane is the
+// tile's.  The marching kernels are bound by instruction issue (profiles/r03_sq_counters.md: the readout issues 90 % of
+// its SIMD slots), and a particle is visited up to six times (three components, two planes each): the multiply, floor,
+// conversions and wraps of cic_setup are paid once, at binning time.
+__device__ __forceinline__ int strip_cell(const Cic &c) { return (c.i0[1] << 12) | c.i0[2]; }
+
+struct StripEntry {
+    double d[3], t[3];
+    int iy0, iy1, iz0, iz1;
+};
+__device__ __forceinline__ StripEntry strip_entry(const MeshGeo &g, double dx, double dy, double dz, int cell)
+{
+    StripEntry e;
+    e.d[0] = dx; e.d[1] = dy; e.d[2] = dz;
+#pragma unroll
+    for (int a = 0; a < 3; a++) e.t[a] = 1. - e.d[a];            // painter-cic.c:56-60
+    e.iy0 = cell >> 12;
+    e.iz0 = cell & 4095;
+    e.iy1 = e.iy0 + 1 == g.N ? 0 : e.iy0 + 1;                    // painter-cic.c:65-70 (strips: y and z periodic)
+    e.iz1 = e.iz0 + 1 == g.N ? 0 : e.iz0 + 1;
+    return e;
+}
+
 __device__ __forceinline__ int tile_id(const MeshGeo &g, int tx, int ty, int tz)
 {
     return (tx * g.nty + ty) * g.ntz + tz;

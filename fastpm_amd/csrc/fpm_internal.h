@@ -152,6 +152,8 @@ struct fpmhip_plan {
     double *sx = nullptr, *sy = nullptr, *sz = nullptr;  // own entries [0, np), dup entries after
     float *smass = nullptr;
     int *sidx = nullptr;
+    int2 *scell = nullptr;      // strip plans: (particle row, base cell iy << 12 | iz) of every entry in ONE 8-byte word
+                                // (sidx is not written there); sx / sy / sz then hold D
     int ntiles = 0;
     // slabs of the entry arrays per key (own tile t -> t, dup tile t -> ntiles + t), see fpm_particles.hip
     int *bin_beg[2] = {nullptr, nullptr};   // [2 ntiles + 1] slab starts: [0] this call's, [1] laid out for the next call

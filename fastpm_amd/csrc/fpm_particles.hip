@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(MeshGeo g, int ntiles,
                                                           double *__restrict__ sx, double *__restrict__ sy,
                                                           double *__restrict__ sz, float *__restrict__ smass,
                                                           int *__restrict__ sidx, int *__restrict__ flags,
-                                                          const int *__restrict__ pred, long long alloc)
+                                                          const int *__restrict__ pred, long long alloc, int2 *__restrict__ scell)
 {
     if (pred && *pred == 0) return;
     extern __shared__ __align__(16) unsigned char smem_bin[];
@@ -303,9 +303,16 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(MeshGeo g, int ntiles,
             // declared invalid and the arrays grow; nothing may be written out of bounds meanwhile)
             if (local < cap[key] && (long long) beg[key] + local < alloc) {
                 const int slot = beg[key] + local;
-                sx[slot] = L.x[pid]; sy[slot] = L.y[pid]; sz[slot] = L.z[pid];
+                if (g.strips) {                       // strip entries: D and the base cell (fpm_cic.h: strip_cell)
+                    Cic c;
+                    (void) cic_setup(g, L.x[pid], L.y[pid], L.z[pid], c);
+                    sx[slot] = c.d[0]; sy[slot] = c.d[1]; sz[slot] = c.d[2];
+                    scell[slot] = make_int2(L.row[pid], strip_cell(c));
+                } else {
+                    sx[slot] = L.x[pid]; sy[slot] = L.y[pid]; sz[slot] = L.z[pid];
+                    sidx[slot] = L.row[pid];
+                }
                 if (smass) smass[slot] = L.m[pid];
-                sidx[slot] = L.row[pid];
             } else {
                 spilled = true;
             }
@@ -353,7 +360,8 @@ __global__ __launch_bounds__(256) void bin_scatter_wave_kernel(MeshGeo g, int nt
                                                                const int *__restrict__ cap, int *__restrict__ cnt,
                                                                double *__restrict__ sx, double *__restrict__ sy,
                                                                double *__restrict__ sz, float *__restrict__ smass,
-                                                               int *__restrict__ sidx, int *__restrict__ flags, long long alloc)
+                                                               int *__restrict__ sidx, int *__restrict__ flags, long long alloc,
+                                                               int2 *__restrict__ scell)
 {
     const int lane = threadIdx.x & 63;
     const long long j0 = ((long long) blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 * BIN_PPT) + lane;
@@ -378,19 +386,22 @@ __global__ __launch_bounds__(256) void bin_scatter_wave_kernel(MeshGeo g, int nt
         }
     }
     // keys: slot 2 u = the own tile, slot 2 u + 1 = the strip above (when the cloud reaches it)
-    int key[2 * BIN_PPT];
+    int key[2 * BIN_PPT], cell[BIN_PPT];
     bool need[2 * BIN_PPT];
     bool spilled = false;
 #pragma unroll
     for (int u = 0; u < BIN_PPT; u++) {
         key[2 * u] = key[2 * u + 1] = 0;
         need[2 * u] = need[2 * u + 1] = false;
+        cell[u] = 0;
         if (active[u]) {
             Cic c;
             if (!cic_setup(g, px[u], py[u], pz[u], c)) {
                 atomicAdd(&flags[FLAG_UNOWNED_FAST], 1);
                 active[u] = false;
             } else {
+                px[u] = c.d[0]; py[u] = c.d[1]; pz[u] = c.d[2];      // the entries carry D and the base cell (fpm_cic.h)
+                cell[u] = strip_cell(c);
                 int t0[3], t1[3];
                 tile_coords(g, c, t0, t1);
                 key[2 * u] = tile_id(g, t0[0], t0[1], 0);
@@ -420,8 +431,8 @@ __global__ __launch_bounds__(256) void bin_scatter_wave_kernel(MeshGeo g, int nt
         if (local < kc[q] && (long long) kb[q] + local < alloc) {
             const int slot = kb[q] + local;
             sx[slot] = px[u]; sy[slot] = py[u]; sz[slot] = pz[u];
+            scell[slot] = make_int2(row[u], cell[u]);       // row and base cell in one 8-byte store
             if (smass) smass[slot] = pm[u];
-            sidx[slot] = row[u];
         } else {
             spilled = true;
         }
@@ -528,31 +539,39 @@ __global__ __launch_bounds__(256) void zero_ints_kernel(int *__restrict__ a, int
 // and what the flat (not tile-staged) readouts iterate.  One wave per tile.
 __global__ __launch_bounds__(256) void tile_order_kernel(int ntiles, const int *__restrict__ beg, const int *__restrict__ cnt,
                                                          const int *__restrict__ off, const int *__restrict__ sidx,
-                                                         int *__restrict__ order, const int *__restrict__ pred)
+                                                         const int2 *__restrict__ scell, int *__restrict__ order,
+                                                         const int *__restrict__ pred)
 {
     if (pred && *pred == 0) return;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (t >= ntiles) return;
     const int b = beg[t], n = cnt[t], o = off[t];
-    for (int k = lane; k < n; k += 64) order[o + k] = sidx[b + k];
+    for (int k = lane; k < n; k += 64) order[o + k] = scell ? scell[b + k].x : sidx[b + k];      // strip entries: (row, cell)
 }
 
 // Is the binning the plan holds still the binning of THESE positions?  One entry of every non-empty own tile is
 // compared, bit for bit, with the row it was copied from: any wholesale change of the positions behind the same pointer
 // (an in-place update, a new tensor at a recycled address) trips FLAG_STALE, which is reported (-7) when it arrives: the
 // readout that reused the binning is void.  (A caller that edits rows in place calls fpmhip_invalidate_binning.)
-__global__ __launch_bounds__(256) void verify_binning_kernel(int ntiles, const int *__restrict__ beg, const int *__restrict__ cnt,
+__global__ __launch_bounds__(256) void verify_binning_kernel(MeshGeo g, int ntiles, const int *__restrict__ beg, const int *__restrict__ cnt,
                                                              const double *__restrict__ sx, const double *__restrict__ sy,
                                                              const double *__restrict__ sz, const int *__restrict__ sidx,
-                                                             const double *__restrict__ x, int *__restrict__ flags)
+                                                             const int2 *__restrict__ scell, const double *__restrict__ x,
+                                                             int *__restrict__ flags)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
     const int n = cnt[t];
     if (n == 0) return;
     const int e = beg[t] + t % n;
-    const long long i = sidx[e];
-    if (sx[e] != x[3 * i] || sy[e] != x[3 * i + 1] || sz[e] != x[3 * i + 2]) flags[FLAG_STALE] = 1;
+    const long long i = g.strips ? scell[e].x : sidx[e];
+    double want[3] = {x[3 * i], x[3 * i + 1], x[3 * i + 2]};
+    if (g.strips) {                                   // strip entries hold D, not the position
+        Cic c;
+        (void) cic_setup(g, want[0], want[1], want[2], c);
+        want[0] = c.d[0]; want[1] = c.d[1]; want[2] = c.d[2];
+    }
+    if (sx[e] != want[0] || sy[e] != want[1] || sz[e] != want[2]) flags[FLAG_STALE] = 1;
 }
 
 // One workgroup = one tile.  LDS tile of F accumulators; entries of the tile (own, then dup)
@@ -1188,7 +1207,7 @@ static int bin_full(fpmhip_plan *p, const fpmhip_particles *pt, const int *pred)
     if (np > 0)
         bin_scatter_kernel<false, true><<<nb, 256, sizeof(ScatterLds<dup_cap<true>()>), p->stream>>>(
             p->mg, nt, pt->x, pt->mass, np, nullptr, p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
-            pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, pred, (long long) p->bin_alloc);
+            pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, pred, (long long) p->bin_alloc, p->scell);
     // a hard overflow (more entries than the arrays hold): the cursors ran past slabs that hold nothing -- the kernels
     // that consume the binning (paint, readout, tile order) must find empty tiles, not counts without entries
     zero_ints_kernel<<<blocks_for(nkeys + 1, 256), 256, 0, p->stream>>>(p->bin_cnt, nkeys + 1, p->d_flags + FLAG_HARD_OVF);
@@ -1202,7 +1221,7 @@ static int bin_finish(fpmhip_plan *p, const int *pred)
     const int nt = p->ntiles;
     FPM_TRY(make_layout(p, p->bin_beg[1], p->bin_cap[1], pred, false));       // leaves the exact offsets in bin_off
     tile_order_kernel<<<blocks_for(nt, 4), 256, 0, p->stream>>>(nt, p->bin_beg[0], p->bin_cnt, p->bin_off, p->sidx,
-                                                                 p->order[0], pred);
+                                                                 p->mg.strips ? p->scell : nullptr, p->order[0], pred);
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1289,19 +1308,19 @@ static int bin_particles_once(fpmhip_plan *p, const fpmhip_particles *pt, bool *
         if (p->mg.strips && wave_env && ordered)
             bin_scatter_wave_kernel<true><<<blocks_for(np, 256 * BIN_PPT), 256, 0, p->stream>>>(
                 p->mg, nt, pt->x, pt->mass, np, p->order[1], p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
-                pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, (long long) p->bin_alloc);
+                pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, (long long) p->bin_alloc, p->scell);
         else if (p->mg.strips && wave_env)
             bin_scatter_wave_kernel<false><<<blocks_for(np, 256 * BIN_PPT), 256, 0, p->stream>>>(
                 p->mg, nt, pt->x, pt->mass, np, nullptr, p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
-                pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, (long long) p->bin_alloc);
+                pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, (long long) p->bin_alloc, p->scell);
         else if (ordered)
             bin_scatter_kernel<true, false><<<blocks_for(np, BIN_BLOCK), 256, sizeof(ScatterLds<dup_cap<false>()>), p->stream>>>(
                 p->mg, nt, pt->x, pt->mass, np, p->order[1], p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
-                pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, nullptr, (long long) p->bin_alloc);
+                pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, nullptr, (long long) p->bin_alloc, p->scell);
         else
             bin_scatter_kernel<false, false><<<blocks_for(np, BIN_BLOCK), 256, sizeof(ScatterLds<dup_cap<false>()>), p->stream>>>(
                 p->mg, nt, pt->x, pt->mass, np, nullptr, p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
-                pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, nullptr, (long long) p->bin_alloc);
+                pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, nullptr, (long long) p->bin_alloc, p->scell);
         pred = p->d_flags + FLAG_NEED_FULL;          // the exact path below runs only if a slab overflowed
     } else {
         FPM_CHECK_HIP(hipMemsetAsync(p->d_flags + FLAG_NEED_FULL, 1, 1, p->stream));    // = 1: the exact path is the one that ran
@@ -1325,8 +1344,8 @@ int reuse_binning(fpmhip_plan *p, const fpmhip_particles *pt)
     FPM_TRY(check_deferred(p, true));
     const int nt = p->ntiles;
     FPM_CHECK_HIP(hipMemsetAsync(p->d_flags + FLAG_STALE, 0, sizeof(int), p->stream));
-    verify_binning_kernel<<<blocks_for(nt, 256), 256, 0, p->stream>>>(nt, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz,
-                                                                      p->sidx, pt->x, p->d_flags);
+    verify_binning_kernel<<<blocks_for(nt, 256), 256, 0, p->stream>>>(p->mg, nt, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz,
+                                                                      p->sidx, p->scell, pt->x, p->d_flags);
     FPM_CHECK_HIP(hipGetLastError());
     return post_flags(p, false);
 }

@@ -74,6 +74,7 @@ int ensure_bins(fpmhip_plan *p, int64_t np, int64_t ndup, bool has_mass)
         const int64_t cap = need > p->bin_alloc ? need + need / 16 : p->bin_alloc;
         if (p->sx) FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
         if (p->sx) { (void) hipFree(p->sx); (void) hipFree(p->sy); (void) hipFree(p->sz); (void) hipFree(p->sidx); }
+        if (p->scell) { (void) hipFree(p->scell); p->scell = nullptr; }
         if (p->smass) { (void) hipFree(p->smass); p->smass = nullptr; }
         p->sx = p->sy = p->sz = nullptr;
         p->sidx = nullptr;
@@ -81,6 +82,7 @@ int ensure_bins(fpmhip_plan *p, int64_t np, int64_t ndup, bool has_mass)
         FPM_CHECK_HIP(hipMalloc(&p->sy, cap * sizeof(double)));
         FPM_CHECK_HIP(hipMalloc(&p->sz, cap * sizeof(double)));
         FPM_CHECK_HIP(hipMalloc(&p->sidx, cap * sizeof(int)));
+        if (p->mg.strips) FPM_CHECK_HIP(hipMalloc(&p->scell, cap * sizeof(int2)));
         if (has_mass) FPM_CHECK_HIP(hipMalloc(&p->smass, cap * sizeof(float)));
         p->bin_alloc = cap;
         p->binned_np = -1;
@@ -370,7 +372,7 @@ void fpmhip_plan_destroy(fpmhip_plan *p)
     void *ptrs[] = {p->host_stage.x, p->host_stage.acc, p->host_stage.mass, p->host_stage.pot,
                     p->d_twiddle, p->d_tab, p->d_fac, p->sx, p->sy, p->sz, p->smass, p->sidx, p->bin_beg[0], p->bin_beg[1],
                     p->bin_cap[0], p->bin_cap[1], p->bin_cnt, p->bin_off, p->bin_capv, p->bin_tmp, p->order[0], p->order[1],
-                    p->d_flags, p->scan_tmp, p->d_scalar, p->d_decic, p->d_bins, p->dec_key_in, p->dec_idx, p->dec_tmp, p->ro_part};
+                    p->d_flags, p->scan_tmp, p->d_scalar, p->d_decic, p->d_bins, p->dec_key_in, p->dec_idx, p->dec_tmp, p->ro_part, p->scell};
     for (void *q : ptrs) if (q) (void) hipFree(q);
     if (p->h_pinned) (void) hipHostFree(p->h_pinned);
     if (p->h_flags) (void) hipHostFree(p->h_flags);

@@ -92,7 +92,7 @@ template <typename PL, typename F, bool R2C>
 __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads)) void paint_strips_kernel(
     MeshGeo g, int ntiles, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
     const double *__restrict__ sy, const double *__restrict__ sz, const float *__restrict__ smass, double M0, double scale,
-    void *__restrict__ out_, int accumulate, const double *__restrict__ tw_global)
+    void *__restrict__ out_, int accumulate, const double *__restrict__ tw_global, const int2 *__restrict__ scell)
 {
     using CF = StripCfg<PL, F>;
     constexpr int M = PL::N, N = 2 * M, T = PL::T, E = PL::E, NT = CF::pt_threads, WP = CF::pt_pitch, SLOT = STRIP_Y * WP;
@@ -118,14 +118,14 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads)) void paint_strips_ke
 
     // One entry adds its corners inside the strip's rows to plane xi (-> pa) and plane xi + 1 (-> pb); a null plane is
     // skipped.
-    auto add_one = [&](double qx, double qy, double qz, float qm, double *pa, double *pb) {
-        Cic c;
-        (void) cic_setup(g, qx, qy, qz, c);
+    // (qx, qy, qz) = the entry's D, qc its base cell: what cic_setup made of the position at binning time (fpm_cic.h)
+    auto add_one = [&](double qx, double qy, double qz, float qm, int qc, double *pa, double *pb) {
+        StripEntry c = strip_entry(g, qx, qy, qz, qc);
         double w = smass ? (M0 + qm) : M0;              // store.c:119-128
         c.d[1] *= w;                                    // painter-cic.c:78-79
         c.t[1] *= w;
-        const int ly[2] = {c.i0[1] - y0, c.i1[1] - y0};
-        const int lz[2] = {c.i0[2], c.i1[2]};
+        const int ly[2] = {c.iy0 - y0, c.iy1 - y0};
+        const int lz[2] = {c.iz0, c.iz1};
         const double wx[2] = {c.t[0], c.d[0]}, wy[2] = {c.t[1], c.d[1]}, wz[2] = {c.t[2], c.d[2]};
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -143,6 +143,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads)) void paint_strips_ke
     constexpr int PF_OWN = 2, PF_DUP = 1, PF = PF_OWN + PF_DUP;
     double fx[PF], fy[PF], fz[PF];
     float fm[PF];
+    int fc[PF];
     int fbeg[2] = {0, 0}, fcnt[2] = {0, 0};
     auto prefetch = [&](int xi) {
 #pragma unroll
@@ -157,9 +158,11 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads)) void paint_strips_ke
             const int e = tid + r * NT;
             fx[u] = fy[u] = fz[u] = 0;
             fm[u] = 0;
+            fc[u] = 0;
             if (e < fcnt[part]) {
                 const int s_ = fbeg[part] + e;
                 fx[u] = sx[s_]; fy[u] = sy[s_]; fz[u] = sz[s_];
+                fc[u] = scell[s_].y;
                 if (smass) fm[u] = smass[s_];
             }
         }
@@ -168,13 +171,13 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads)) void paint_strips_ke
 #pragma unroll
         for (int u = 0; u < PF; u++) {
             const int part = u < PF_OWN ? 0 : 1, r = u < PF_OWN ? u : u - PF_OWN;
-            if (tid + r * NT < fcnt[part]) add_one(fx[u], fy[u], fz[u], fm[u], pa, pb);
+            if (tid + r * NT < fcnt[part]) add_one(fx[u], fy[u], fz[u], fm[u], fc[u], pa, pb);
         }
 #pragma unroll
         for (int part = 0; part < 2; part++)
             for (int e = tid + (part == 0 ? PF_OWN : PF_DUP) * NT; e < fcnt[part]; e += NT) {
                 const int s_ = fbeg[part] + e;
-                add_one(sx[s_], sy[s_], sz[s_], smass ? smass[s_] : 0.f, pa, pb);
+                add_one(sx[s_], sy[s_], sz[s_], smass ? smass[s_] : 0.f, scell[s_].y, pa, pb);
             }
     };
 
@@ -249,7 +252,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
     MeshGeo g, int ncomp, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
     const double *__restrict__ sy, const double *__restrict__ sz, const int *__restrict__ sidx, const C2<F> *__restrict__ m0,
     const C2<F> *__restrict__ m1, const C2<F> *__restrict__ m2, float *__restrict__ out, int nmemb, int memb0,
-    const double *__restrict__ tw_global)
+    const double *__restrict__ tw_global, const int2 *__restrict__ scell)
 {
     using CF = StripCfg<PL, F>;
     constexpr int M = PL::N, RW = STRIP_RW, T = PL::T, E = PL::E, NT = CF::ro_threads, SLOT = CF::ro_slot, RP = CF::ro_pitch,
@@ -304,23 +307,26 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
         const int key = i * g.nty + strip;
         const int b = tbeg[key], n = tcnt[key];
         double px[2], py[2], pz[2];
-        int prow[2];
+        int prow[2], pc[2];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int e = threadIdx.x + u * NT;
             px[u] = py[u] = pz[u] = 0;
-            prow[u] = 0;
-            if (e < n) { px[u] = sx[b + e]; py[u] = sy[b + e]; pz[u] = sz[b + e]; prow[u] = sidx[b + e]; }
+            prow[u] = pc[u] = 0;
+            if (e < n) {
+                px[u] = sx[b + e]; py[u] = sy[b + e]; pz[u] = sz[b + e];
+                const int2 rc = scell[b + e];                      // (row, base cell)
+                prow[u] = rc.x; pc[u] = rc.y;
+            }
         }
         c2r_to(B);
         __syncthreads();
         if (i + 1 < xb) load_plane(i + 2);                         // lands during the gather
         const F *ra = (const F *) A, *rb = (const F *) B;
-        auto gather = [&](double qx, double qy, double qz, int row) {
-            Cic cc;
-            (void) cic_setup(g, qx, qy, qz, cc);
-            const int ly = cc.i0[1] - y0;                          // the + 1 row is the next row of the window
-            const int lz[2] = {cc.i0[2], cc.i0[2] + 1};            // and the + 1 value the next value of the row
+        auto gather = [&](double qx, double qy, double qz, int qc, int row) {      // the entry's D and base cell (fpm_cic.h)
+            const StripEntry cc = strip_entry(g, qx, qy, qz, qc);
+            const int ly = cc.iy0 - y0;                            // the + 1 row is the next row of the window
+            const int lz[2] = {cc.iz0, cc.iz0 + 1};                // and the + 1 value the next value of the row
             const double wx[2] = {cc.t[0], cc.d[0]}, wy[2] = {cc.t[1], cc.d[1]}, wz[2] = {cc.t[2], cc.d[2]};
             double value = 0;
 #pragma unroll
@@ -333,8 +339,11 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
         };
 #pragma unroll
         for (int u = 0; u < 2; u++)
-            if (threadIdx.x + u * NT < n) gather(px[u], py[u], pz[u], prow[u]);
-        for (int e = threadIdx.x + 2 * NT; e < n; e += NT) gather(sx[b + e], sy[b + e], sz[b + e], sidx[b + e]);
+            if (threadIdx.x + u * NT < n) gather(px[u], py[u], pz[u], pc[u], prow[u]);
+        for (int e = threadIdx.x + 2 * NT; e < n; e += NT) {
+            const int2 rc = scell[b + e];
+            gather(sx[b + e], sy[b + e], sz[b + e], rc.y, rc.x);
+        }
         __syncthreads();
         C2<F> *tmp = A; A = B; B = tmp;
     }
@@ -360,7 +369,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? FPM_RO_MINW : 
     MeshGeo g, int ncomp, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
     const double *__restrict__ sy, const double *__restrict__ sz, const int *__restrict__ sidx, const C2<F> *__restrict__ m0,
     const C2<F> *__restrict__ m1, const C2<F> *__restrict__ m2, float *__restrict__ out, int nmemb, int memb0,
-    const double *__restrict__ tw_global, double *__restrict__ part_all, long long part_stride)
+    const double *__restrict__ tw_global, double *__restrict__ part_all, long long part_stride, const int2 *__restrict__ scell)
 {
     using CF = StripCfg<PL, F>;
     constexpr int M = PL::N, RW = STRIP_RW, T = PL::T, E = PL::E, NT = CF::ro_threads, RP = CF::ro_pitch, WP = 2 * RP,
@@ -401,10 +410,9 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? FPM_RO_MINW : 
     };
     // acc + the four corners of the window's plane (x bit `bx`), in the reference's order
     const F *rs = (const F *) S;
-    auto half = [&](double qx, double qy, double qz, int bx, double acc) -> double {
-        Cic cc;
-        (void) cic_setup(g, qx, qy, qz, cc);
-        const int ly = cc.i0[1] - y0, lz = cc.i0[2];
+    auto half = [&](double qx, double qy, double qz, int qc, int bx, double acc) -> double {      // D and base cell of the entry
+        const StripEntry cc = strip_entry(g, qx, qy, qz, qc);
+        const int ly = cc.iy0 - y0, lz = cc.iz0;
         const double wxb = bx ? cc.d[0] : cc.t[0];
         const double wy[2] = {cc.t[1], cc.d[1]}, wz[2] = {cc.t[2], cc.d[2]};
 #pragma unroll
@@ -416,7 +424,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? FPM_RO_MINW : 
     };
     constexpr int PF = 2;
     double px[PF], py[PF], pz[PF], pv[PF], qx[PF], qy[PF], qz[PF];
-    int prow[PF], qrow[PF];
+    int prow[PF], qrow[PF], pc[PF], qc[PF];
     int pb = 0, pn = 0, qb = 0, qn = 0;            // p: the particles that finish this step; q: those that start
     auto fetch_q = [&](int xi) {
         const int key = xi * g.nty + strip;
@@ -426,17 +434,21 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? FPM_RO_MINW : 
         for (int u = 0; u < PF; u++) {
             const int e = tid + u * NT;
             qx[u] = qy[u] = qz[u] = 0;
-            qrow[u] = 0;
-            if (e < qn) { qx[u] = sx[qb + e]; qy[u] = sy[qb + e]; qz[u] = sz[qb + e]; qrow[u] = sidx[qb + e]; }
+            qrow[u] = qc[u] = 0;
+            if (e < qn) {
+                qx[u] = sx[qb + e]; qy[u] = sy[qb + e]; qz[u] = sz[qb + e];
+                const int2 rc = scell[qb + e];                     // (row, base cell)
+                qrow[u] = rc.x; qc[u] = rc.y;
+            }
         }
     };
     auto start_q = [&]() {                         // q -> p with the first four terms
 #pragma unroll
         for (int u = 0; u < PF; u++) {
-            px[u] = qx[u]; py[u] = qy[u]; pz[u] = qz[u]; prow[u] = qrow[u];
-            pv[u] = tid + u * NT < qn ? half(qx[u], qy[u], qz[u], 0, 0.0) : 0.0;
+            px[u] = qx[u]; py[u] = qy[u]; pz[u] = qz[u]; prow[u] = qrow[u]; pc[u] = qc[u];
+            pv[u] = tid + u * NT < qn ? half(qx[u], qy[u], qz[u], qc[u], 0, 0.0) : 0.0;
         }
-        for (int e = tid + PF * NT; e < qn; e += NT) part[qb + e] = half(sx[qb + e], sy[qb + e], sz[qb + e], 0, 0.0);
+        for (int e = tid + PF * NT; e < qn; e += NT) part[qb + e] = half(sx[qb + e], sy[qb + e], sz[qb + e], scell[qb + e].y, 0, 0.0);
         pb = qb;
         pn = qn;
     };
@@ -444,9 +456,11 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? FPM_RO_MINW : 
 #pragma unroll
         for (int u = 0; u < PF; u++)
             if (tid + u * NT < pn)
-                out[(long long) prow[u] * nmemb + memb0 + comp] = (float) half(px[u], py[u], pz[u], 1, pv[u]);
-        for (int e = tid + PF * NT; e < pn; e += NT)
-            out[(long long) sidx[pb + e] * nmemb + memb0 + comp] = (float) half(sx[pb + e], sy[pb + e], sz[pb + e], 1, part[pb + e]);
+                out[(long long) prow[u] * nmemb + memb0 + comp] = (float) half(px[u], py[u], pz[u], pc[u], 1, pv[u]);
+        for (int e = tid + PF * NT; e < pn; e += NT) {
+            const int2 rc = scell[pb + e];
+            out[(long long) rc.x * nmemb + memb0 + comp] = (float) half(sx[pb + e], sy[pb + e], sz[pb + e], rc.y, 1, part[pb + e]);
+        }
     };
 
     load_plane(xa);
@@ -523,7 +537,7 @@ static int paint_strips_launch(fpmhip_plan *p, const fpmhip_particles *pt, doubl
         FPM_TRY(grant_lds(paint_strips_kernel<PL, F, R2C>, CF::pt_lds, p->device));                                    \
         paint_strips_kernel<PL, F, R2C><<<g.nty * nseg, CF::pt_threads, CF::pt_lds, p->stream>>>(                      \
             g, p->ntiles, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, pt->mass ? p->smass : nullptr, pt->M0, scale, out, \
-            accumulate, p->d_twiddle);                                                                                 \
+            accumulate, p->d_twiddle, p->scell);                                                                       \
     }
     STRIP_DISPATCH(g.N / 2, CALL_PAINT)
 #undef CALL_PAINT
@@ -574,12 +588,13 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
             FPM_TRY(grant_lds(readout_strips_kernel<PL, F, WS_>, CF::ro_lds, p->device));                              \
             readout_strips_kernel<PL, F, WS_><<<ncomp * g.nty * nseg, CF::ro_threads, CF::ro_lds, p->stream>>>(        \
                 g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                 \
-                (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle);                              \
+                (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->scell);                    \
         } else {                                                                                                       \
             FPM_TRY(grant_lds(readout_march_kernel<PL, F, WS_>, CF::ro1_lds, p->device));                              \
             readout_march_kernel<PL, F, WS_><<<ncomp * g.nty * nseg, CF::ro_threads, CF::ro1_lds, p->stream>>>(        \
                 g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                 \
-                (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride);     \
+                (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride,      \
+                p->scell);                                                                                             \
         }                                                                                                              \
     }
 #define CALL_RO(PL)                                                                                                    \
