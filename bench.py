@@ -478,7 +478,7 @@ def main():
         elif strips:
             # the paint timer covers paint + z r2c pass, the readout timer z c2r pass + readout (fpm_strips.hip); their
             # algorithmic bytes are the paint's and the readout's: the meshes between them never reach HBM
-            KERNELS["paint"] = "fpm::paint_strips_kernel"
+            KERNELS["paint"] = "fpm::paint_march_kernel"
             # (one plane in LDS + wave-local z transforms on the power-of-two meshes; two planes elsewhere: fpm_strips.hip)
             KERNELS["readout"] = "fpm::readout_march_kernel" if 64 % max(Nmesh // 16, 1) == 0 else "fpm::readout_strips_kernel"
         elif args.precision == 64:

@@ -419,7 +419,7 @@ static int yback2_launch(fpmhip_plan *p, const void *in, void *oy, void *oz, voi
     const float *kt = p->d_tab + gradorder * (size_t) p->mg.N;
     // one output per launch where the two-output kernel spills (see the kernel); FPMHIP_YBACK_ONE = 0 | 1 forces (A/B)
     static const int one_env = getenv("FPMHIP_YBACK_ONE") ? atoi(getenv("FPMHIP_YBACK_ONE")) : -1;
-    const bool one = one_env >= 0 ? one_env != 0 : p->mg.N >= 3072;
+    const bool one = one_env >= 0 ? one_env != 0 : (p->mg.N >= 3072 || (p->mg.N >= 2048 && sizeof(F) == 4));    // (fp32 at 2048: 172 B of spills)
 #define CALL_Y2(PL)                                                                                          \
     {                                                                                                        \
         using CF = ColCfg<PL, F>;                                                                            \

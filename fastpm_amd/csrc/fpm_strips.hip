@@ -7,15 +7,22 @@
 // long for the 8 x 8-column box tiles (81 rows of N values per tile), so the tiles change shape: a STRIP is one x
 // plane x STRIP_Y = 4 rows x all of z.  A workgroup owns the strip column (4 rows) of a segment of x planes and MARCHES
 // along x with a two-plane window in LDS:
-//   paint:   the entries of (plane i, strip) add their corners into planes i and i + 1 of the window (LDS atomics);
-//            plane i is then complete (plane i - 1's particles added theirs one step earlier): its 4 rows are
-//            transformed in LDS (the r2c of fpm_rowfft.hip) and leave as half-spectrum rows, or leave as real rows
-//            (paint_add, several species).  Entries are listed again only in y (row 3 of a strip touches the next
-//            strip): 1.25 entries per particle.
+//   paint:   plane i receives the x + 0 corners of the entries of (plane i, strip) and the x + 1 corners of the entries
+//            of plane i - 1 (LDS atomics into a ONE-plane window; round 2 kept two planes and visited an entry once);
+//            the finished plane's 4 rows are transformed in LDS (the r2c of fpm_rowfft.hip) and leave as half-spectrum
+//            rows, or leave as real rows (paint_add, several species).  Entries are listed again only in y (row 3 of a
+//            strip touches the next strip): 1.25 entries per particle.
 //   readout: per step the 5 half-spectrum rows (4 + the next strip's first) of plane i + 1 -- prefetched into
 //            registers during the previous step's gather -- are inverse-transformed into the window; the particles of
-//            (plane i, strip) gather their 8 corners from planes i, i + 1.  One workgroup per (segment, strip,
-//            component); 5 / 4 of one mesh read per component instead of 1 read + 1 write + 1.13 read.
+//            (plane i, strip) gather their 8 corners from planes i, i + 1 (two planes in LDS), or -- the default on the
+//            power-of-two meshes -- take the corners of plane i in one step and those of plane i + 1 in the next (ONE
+//            plane in LDS).  One workgroup per (segment, strip, component); 5 / 4 of one mesh read per component instead
+//            of 1 read + 1 write + 1.13 read.
+// Round 3: both kernels turned out to be bound by workgroup barriers and instruction issue, not by HBM, LDS or occupancy
+// alone: with ONE plane in LDS (more workgroups per CU) AND the z transforms wave-local (a row's threads in one wave, its
+// exchange region its own: fft_sync in fpm_fftcore.h) the readout went 1.63 -> 1.27 ms and the paint 0.50 -> 0.44 ms at
+// 512^3 fp64 -- either change alone gained nothing; entries that carry D and the base cell instead of the position
+// (fpm_cic.h) took another 0.08 / 0.06 ms of instructions out.
 // Measured at 512^3 fp64 (tools/ubench/zfused_readout.hip, then in place): z c2r x 3 + readout 2.15 ms -> 1.61 ms; paint + z
 // r2c 0.72 -> 0.57 ms.  Both kernels are bound by LDS traffic and issue, not by HBM (rocprofv3: VALUBusy 32 %,
 // LDSBankConflict 39 % after the layout changes below).  Tried, not adopted: strips of 8 rows (one readout workgroup
@@ -75,21 +82,31 @@ template <typename PL, typename F> struct StripCfg {
     static constexpr int ro_slot = ro_pitch * STRIP_RW > ro_xchg ? ro_pitch * STRIP_RW : ro_xchg;
     static constexpr size_t ro_lds = twb + (size_t) 2 * ro_slot * sizeof(C2<F>);
     static constexpr size_t ro1_lds = twb + (size_t) ro_slot * sizeof(C2<F>);       // the marching readout: ONE plane
-    // paint: two planes of STRIP_Y rows of pt_pitch double accumulators
+    // paint: one plane of STRIP_Y rows of pt_pitch double accumulators
     static constexpr int pt_threads = T * STRIP_Y;
     static constexpr int pt_pitch = 2 * strip_pitch(M, 4);
     static constexpr size_t pt_twb = (size_t) (M / 2 + M) * sizeof(C2<F>);
-    static constexpr size_t pt_lds = pt_twb + (size_t) 2 * STRIP_Y * pt_pitch * sizeof(double);
+    static constexpr size_t pt1_lds = pt_twb + (size_t) STRIP_Y * pt_pitch * sizeof(double);      // one plane
 };
 
 // ------------------------------------------------------------------------------------------------------------------
 // paint
 // ------------------------------------------------------------------------------------------------------------------
-// (Round 3 tried the readout's wave-local z pass here too -- every row's threads in one wave, the transform in the row's own
-// LDS region, two workgroup barriers per plane instead of nine: 0.58 -> 0.63 ms at 512^3 fp64, 4.3 -> 5.4 ms at 1024^3.
-// With two waves per workgroup there is little to decouple, and the row-major exchange costs the reads of the window.)
-template <typename PL, typename F, bool R2C>
-__global__ __launch_bounds__((StripCfg<PL, F>::pt_threads)) void paint_strips_kernel(
+// ------------------------------------------------------------------------------------------------------------------
+// paint with ONE plane in LDS and a wave-local z pass (the r2c form on the power-of-two meshes; round 3)
+// ------------------------------------------------------------------------------------------------------------------
+// What the readout gained from -- more workgroups per CU AND waves that do not wait for each other -- applied to the paint.
+// The window holds ONE plane of accumulators; plane i receives the x + 0 corners of the entries of plane i and the x + 1
+// corners of the entries of plane i - 1, so every entry is visited twice, in consecutive steps (its D and base cell wait
+// in registers; a paint needs no half sums).  Then every row's threads -- one wave, or half of one -- take their row
+// through the r2c transform inside the row's own LDS region and clear it again: two workgroup barriers per plane (around
+// the atomics) instead of nine.  22.6 KB of LDS at M = 256 in fp64 (two planes: 38.9 KB): six workgroups per CU.
+// Measured (paint + z r2c), two planes -> one plane -> one plane + WS: 0.50 -> 0.44 -> 0.44 ms at 512^3 fp64, 4.04 ->
+// 3.18 -> 3.13 ms at 1024^3, 0.40 -> 0.30 -> 0.29 ms at 512^3 fp32.  (WS on the two-plane kernel alone: 0.58 -> 0.63 ms.)
+// R2C = false (several species, a softening kernel in front of the transfer): the finished plane leaves as real rows,
+// canvas = (F) (sum * scale) or canvas += that (gravity.c:326-345, transfer.c:212-220).
+template <typename PL, typename F, bool R2C, bool WS>
+__global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), 3) void paint_march_kernel(
     MeshGeo g, int ntiles, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
     const double *__restrict__ sy, const double *__restrict__ sz, const float *__restrict__ smass, double M0, double scale,
     void *__restrict__ out_, int accumulate, const double *__restrict__ tw_global, const int2 *__restrict__ scell)
@@ -100,101 +117,103 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads)) void paint_strips_ke
     using PH = HalfTw<PL>;
     C2<F> *tw = (C2<F> *) smem_st;
     C2<F> *twn = tw + PH::TWN;
-    double *win = (double *) (smem_st + CF::pt_twb);          // [2][STRIP_Y][WP]
+    C2<F> *out = (C2<F> *) out_;
+    double *A = (double *) (smem_st + CF::pt_twb);            // [STRIP_Y][WP]
     const int tid = threadIdx.x;
     const int nseg = (g.xl + STRIP_XSEG - 1) / STRIP_XSEG;
     const int t = xcd_remap(blockIdx.x, g.nty * nseg);
     const int strip = t % g.nty, seg = t / g.nty;
     const int xa = seg * STRIP_XSEG, xb = min(xa + STRIP_XSEG, g.xl);
     const int y0 = strip * STRIP_Y;
+    // the z pass: row c, elements tau + T j
+    const int c = WS ? tid / T : tid % STRIP_Y, tau = WS ? tid % T : tid / STRIP_Y;
+    constexpr int RPC = (int) (WP * sizeof(double) / sizeof(C2<F>));        // a window row in complex values (>= M + 1)
+    constexpr int CWX = WS ? -RPC : STRIP_Y;
 
-    for (int i = tid; i < 2 * SLOT; i += NT) win[i] = 0;
+    for (int i = tid; i < SLOT; i += NT) A[i] = 0;
     if (R2C) {
         stage_twiddles(tw, tw_global, PH::TWN, 2);
         stage_twiddles(twn, tw_global, M, 1);
     }
-    __syncthreads();
-    double *A = win, *B = win + SLOT;
 
-    // One entry adds its corners inside the strip's rows to plane xi (-> pa) and plane xi + 1 (-> pb); a null plane is
-    // skipped.
-    // (qx, qy, qz) = the entry's D, qc its base cell: what cic_setup made of the position at binning time (fpm_cic.h)
-    auto add_one = [&](double qx, double qy, double qz, float qm, int qc, double *pa, double *pb) {
-        StripEntry c = strip_entry(g, qx, qy, qz, qc);
-        double w = smass ? (M0 + qm) : M0;              // store.c:119-128
-        c.d[1] *= w;                                    // painter-cic.c:78-79
-        c.t[1] *= w;
-        const int ly[2] = {c.iy0 - y0, c.iy1 - y0};
-        const int lz[2] = {c.iz0, c.iz1};
-        const double wx[2] = {c.t[0], c.d[0]}, wy[2] = {c.t[1], c.d[1]}, wz[2] = {c.t[2], c.d[2]};
+    // the four corners with x bit `bx` of one entry (its D in q*, base cell in qc) into the window
+    auto add_half = [&](double qx, double qy, double qz, float qm, int qc, int bx) {
+        StripEntry e = strip_entry(g, qx, qy, qz, qc);
+        const double w = smass ? (M0 + qm) : M0;            // store.c:119-128
+        e.d[1] *= w;                                         // painter-cic.c:78-79
+        e.t[1] *= w;
+        const int ly[2] = {e.iy0 - y0, e.iy1 - y0};
+        const int lz[2] = {e.iz0, e.iz1};
+        const double wxb = bx ? e.d[0] : e.t[0], wy[2] = {e.t[1], e.d[1]}, wz[2] = {e.t[2], e.d[2]};
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int bx = (k >> 2) & 1, by = (k >> 1) & 1, bz = k & 1;
-            double *pl = bx ? pb : pa;
-            if (pl && (unsigned) ly[by] < (unsigned) STRIP_Y) {
-                const double f = wz[bz] * wx[bx] * wy[by];          // painter-cic.c:84-107: Wz*Wx*Wy
-                atomicAdd(&pl[ly[by] * WP + lz[bz]], f);
-            }
+        for (int k = 0; k < 4; k++) {
+            const int by = (k >> 1) & 1, bz = k & 1;
+            if ((unsigned) ly[by] < (unsigned) STRIP_Y)
+                atomicAdd(&A[ly[by] * WP + lz[bz]], wz[bz] * wxb * wy[by]);        // painter-cic.c:84-107: Wz*Wx*Wy
         }
     };
-    // The entries (own, then dup) of (plane xi, strip).  The first PF_OWN / PF_DUP entries per thread of each list are
-    // requested one step ahead (prefetch()) and wait in registers while the previous plane is transformed and stored:
-    // without that every step began with a dependent chain of global loads (0.67 -> ms below for paint + z pass).
+    // The entries (own, then dup) of (plane xi, strip): the first PF_OWN / PF_DUP per thread of each list are requested
+    // one step ahead and stay in registers for their second visit; what a dense tile has beyond them is read again.
     constexpr int PF_OWN = 2, PF_DUP = 1, PF = PF_OWN + PF_DUP;
-    double fx[PF], fy[PF], fz[PF];
-    float fm[PF];
-    int fc[PF];
-    int fbeg[2] = {0, 0}, fcnt[2] = {0, 0};
-    auto prefetch = [&](int xi) {
+    struct Ent {
+        double x[PF], y[PF], z[PF];
+        float m[PF];
+        int cell[PF];
+        int beg[2], cnt[2];
+    };
+    Ent cur, prev;
+    auto fetch = [&](Ent &e, int xi) {
 #pragma unroll
         for (int part = 0; part < 2; part++) {
             const int key = part * ntiles + xi * g.nty + strip;
-            fbeg[part] = tbeg[key];
-            fcnt[part] = tcnt[key];
+            e.beg[part] = tbeg[key];
+            e.cnt[part] = tcnt[key];
         }
 #pragma unroll
         for (int u = 0; u < PF; u++) {
             const int part = u < PF_OWN ? 0 : 1, r = u < PF_OWN ? u : u - PF_OWN;
-            const int e = tid + r * NT;
-            fx[u] = fy[u] = fz[u] = 0;
-            fm[u] = 0;
-            fc[u] = 0;
-            if (e < fcnt[part]) {
-                const int s_ = fbeg[part] + e;
-                fx[u] = sx[s_]; fy[u] = sy[s_]; fz[u] = sz[s_];
-                fc[u] = scell[s_].y;
-                if (smass) fm[u] = smass[s_];
+            const int k = tid + r * NT;
+            e.x[u] = e.y[u] = e.z[u] = 0;
+            e.m[u] = 0;
+            e.cell[u] = 0;
+            if (k < e.cnt[part]) {
+                const int s_ = e.beg[part] + k;
+                e.x[u] = sx[s_]; e.y[u] = sy[s_]; e.z[u] = sz[s_];
+                e.cell[u] = scell[s_].y;
+                if (smass) e.m[u] = smass[s_];
             }
         }
     };
-    auto add_prefetched = [&](double *pa, double *pb) {
+    auto none = [&](Ent &e) { e.cnt[0] = e.cnt[1] = 0; e.beg[0] = e.beg[1] = 0; };
+    auto add_ent = [&](const Ent &e, int bx) {
 #pragma unroll
         for (int u = 0; u < PF; u++) {
             const int part = u < PF_OWN ? 0 : 1, r = u < PF_OWN ? u : u - PF_OWN;
-            if (tid + r * NT < fcnt[part]) add_one(fx[u], fy[u], fz[u], fm[u], fc[u], pa, pb);
+            if (tid + r * NT < e.cnt[part]) add_half(e.x[u], e.y[u], e.z[u], e.m[u], e.cell[u], bx);
         }
 #pragma unroll
         for (int part = 0; part < 2; part++)
-            for (int e = tid + (part == 0 ? PF_OWN : PF_DUP) * NT; e < fcnt[part]; e += NT) {
-                const int s_ = fbeg[part] + e;
-                add_one(sx[s_], sy[s_], sz[s_], smass ? smass[s_] : 0.f, scell[s_].y, pa, pb);
+            for (int k = tid + (part == 0 ? PF_OWN : PF_DUP) * NT; k < e.cnt[part]; k += NT) {
+                const int s_ = e.beg[part] + k;
+                add_half(sx[s_], sy[s_], sz[s_], smass ? smass[s_] : 0.f, scell[s_].y, bx);
             }
     };
 
-    // what the particles of the plane before the segment add to its first plane (on a slab's first plane that is the
-    // neighbour's halo plane, added after the kernel: fpmhip_plane_add)
-    if (g.periodic_x || xa > 0) {
-        prefetch(xa > 0 ? xa - 1 : g.N - 1);
-        add_prefetched(nullptr, A);
-    }
-    prefetch(xa);
-    // a slab's last segment also sends out the halo plane xl: what its last plane's particles add to the next rank's
-    // first plane
+    // what the plane before the segment adds to its first plane comes from that plane's entries (on a slab's first plane
+    // from the neighbour's halo plane, added after the kernel: fpmhip_plane_add)
+    if (g.periodic_x || xa > 0) fetch(prev, xa > 0 ? xa - 1 : g.N - 1);
+    else none(prev);
+    fetch(cur, xa);
+    __syncthreads();                                          // the window is clear, the twiddles are staged
+    // a slab's last segment also sends out the halo plane xl: the x + 1 corners of its last plane's entries
     const int xend = xb + ((!g.periodic_x && xb == g.xl) ? 1 : 0);
     for (int i = xa; i < xend; i++) {
-        if (i < xb) add_prefetched(A, B);
+        add_ent(prev, 1);
+        if (i < xb) add_ent(cur, 0);
         __syncthreads();
-        if (i + 1 < xb) prefetch(i + 1);                  // lands while plane i is transformed and stored
+        prev = cur;
+        if (i + 1 < xb) fetch(cur, i + 1);                    // lands while plane i is transformed and stored
+        else none(cur);
         if (!R2C) {
             F *canvas = (F *) out_;
             for (int idx = tid; idx < STRIP_Y * N; idx += NT) {
@@ -211,35 +230,39 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads)) void paint_strips_ke
                 }
             }
             __syncthreads();
-        } else {
-            // the z pass of pm_r2c on the finished rows (rowfft_r2c_kernel's arithmetic): row c, elements tau + T j
-            const int c = tid % STRIP_Y, tau = tid / STRIP_Y;
-            C2<F> v[vmax(E)];
-#pragma unroll
-            for (int j = 0; j < E; j++) {
-                const int n = tau + T * j;
-                v[in_slot<PL>(j)] = C2<F>{(F) (A[c * WP + 2 * n] * scale), (F) (A[c * WP + 2 * n + 1] * scale)};
-            }
-            __syncthreads();                                    // plane A is in registers: its LDS is the FFT's now
-            C2<F> *lds = (C2<F> *) A;
-            fft_core<PH, -1, STRIP_Y, false>(v, lds, tw, tau, c);
-#pragma unroll
-            for (int j = 0; j < E; j++) lds[(tau + T * j) * STRIP_Y + c] = v[j];
+            for (int idx = tid; idx < SLOT; idx += NT) A[idx] = 0;
             __syncthreads();
-            C2<F> *dst = (C2<F> *) out_ + ((long long) i * g.yplanes + y0 + c) * g.rp;
-#pragma unroll
-            for (int j = 0; j < E; j++) {
-                const int k = tau + T * j;
-                const C2<F> a = v[j];
-                st_stream(&dst[k], r2c_untangle(a, lds[((M - k) % M) * STRIP_Y + c], twn[k]));
-                if (k == 0) dst[M] = C2<F>{a.x - a.y, 0};              // X[N/2] = Re Z0 - Im Z0
-            }
-            for (int k = M + 1 + tau; k < g.rp; k += T) dst[k] = C2<F>{0, 0};      // the padding of an aligned row
-            __syncthreads();
+            continue;
         }
-        for (int idx = tid; idx < SLOT; idx += NT) A[idx] = 0;
+        // the z pass of pm_r2c on the finished rows (rowfft_r2c_kernel's arithmetic)
+        C2<F> v[vmax(E)];
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const int n = tau + T * j;
+            v[in_slot<PL>(j)] = C2<F>{(F) (A[c * WP + 2 * n] * scale), (F) (A[c * WP + 2 * n + 1] * scale)};
+        }
+        fft_sync<WS>();                                       // the row is in registers: its LDS is the transform's now
+        C2<F> *lds = (C2<F> *) A;
+        fft_core<PH, -1, CWX, false, F, 0, WS>(v, lds, tw, tau, c);
+#pragma unroll
+        for (int j = 0; j < E; j++) lds[lds_pos<CWX, 0>(tau + T * j, c)] = v[j];
+        fft_sync<WS>();
+        C2<F> *dst = out + ((long long) i * g.yplanes + y0 + c) * g.rp;
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const int k = tau + T * j;
+            const C2<F> a = v[j];
+            st_stream(&dst[k], r2c_untangle(a, lds[lds_pos<CWX, 0>((M - k) % M, c)], twn[k]));
+            if (k == 0) dst[M] = C2<F>{a.x - a.y, 0};                  // X[N/2] = Re Z0 - Im Z0
+        }
+        for (int k = M + 1 + tau; k < g.rp; k += T) dst[k] = C2<F>{0, 0};          // the padding of an aligned row
+        fft_sync<WS>();
+        if (WS) {
+            for (int idx = tau; idx < WP; idx += T) A[c * WP + idx] = 0;          // a row's threads clear their own row
+        } else {
+            for (int idx = tid; idx < SLOT; idx += NT) A[idx] = 0;
+        }
         __syncthreads();
-        double *tmp = A; A = B; B = tmp;
     }
 }
 
@@ -494,8 +517,8 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? FPM_RO_MINW : 
     default: FPM_FAIL(-1, "strip kernels: unsupported mesh size %d", 2 * (int) (M_));                               \
     }
 
-// two marching workgroups per CU: the one-plane readout window and the two-plane paint window of the widest row
-// (M = 512 in fp64: 58 KB and 78 KB; M = 1024 in fp32: 57 KB and 78 KB)
+// two marching workgroups per CU: the one-plane windows of the readout and of the paint of the widest row
+// (M = 512 in fp64: 58 KB and 45 KB; M = 1024 in fp32: 57 KB and 78 KB)
 static constexpr size_t STRIP_LDS_MAX = 160 * 1024 / 2;
 
 bool strips_supported(int N, int precision)
@@ -503,7 +526,7 @@ bool strips_supported(int N, int precision)
     if (!rowfft_supported(N) || N % STRIP_Y != 0 || N / 2 > 1024) return false;
     const size_t es = precision == 64 ? 16 : 8, M = (size_t) N / 2;
     const size_t ro = (2 * M + (size_t) strip_pitch((int) M, 13) * STRIP_RW) * es;                      // ~ StripCfg::ro1_lds
-    const size_t pt = (M / 2 + M) * es + (size_t) 2 * STRIP_Y * 2 * strip_pitch((int) M, 4) * sizeof(double);   // = pt_lds
+    const size_t pt = (M / 2 + M) * es + (size_t) STRIP_Y * 2 * strip_pitch((int) M, 4) * sizeof(double);       // = pt1_lds
     return ro <= STRIP_LDS_MAX && pt <= STRIP_LDS_MAX;
 }
 
@@ -531,16 +554,21 @@ static int paint_strips_launch(fpmhip_plan *p, const fpmhip_particles *pt, doubl
 {
     const MeshGeo &g = p->mg;
     const int nseg = (g.xl + STRIP_XSEG - 1) / STRIP_XSEG;
-#define CALL_PAINT(PL)                                                                                                 \
+    // the z pass wave-local where a row's threads fit one wave (the power-of-two meshes); FPMHIP_PT_WS = 0: A/B
+    static const int ws_env = getenv("FPMHIP_PT_WS") ? atoi(getenv("FPMHIP_PT_WS")) : 1;
+#define CALL_PM_W(PL, WS_)                                                                                             \
     {                                                                                                                  \
         using CF = StripCfg<PL, F>;                                                                                    \
-        FPM_TRY(grant_lds(paint_strips_kernel<PL, F, R2C>, CF::pt_lds, p->device));                                    \
-        paint_strips_kernel<PL, F, R2C><<<g.nty * nseg, CF::pt_threads, CF::pt_lds, p->stream>>>(                      \
+        FPM_TRY(grant_lds(paint_march_kernel<PL, F, R2C, WS_>, CF::pt1_lds, p->device));                               \
+        paint_march_kernel<PL, F, R2C, WS_><<<g.nty * nseg, CF::pt_threads, CF::pt1_lds, p->stream>>>(                 \
             g, p->ntiles, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, pt->mass ? p->smass : nullptr, pt->M0, scale, out, \
             accumulate, p->d_twiddle, p->scell);                                                                       \
     }
-    STRIP_DISPATCH(g.N / 2, CALL_PAINT)
-#undef CALL_PAINT
+#define CALL_PM(PL)                                                                                                    \
+    if (R2C && 64 % PL::T == 0 && ws_env) CALL_PM_W(PL, (R2C && 64 % PL::T == 0)) else CALL_PM_W(PL, false)
+    STRIP_DISPATCH(g.N / 2, CALL_PM)
+#undef CALL_PM
+#undef CALL_PM_W
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }

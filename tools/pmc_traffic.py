@@ -45,7 +45,7 @@ def main():
     N = nmesh
     stage = {
         "sort": hbm("bin_scatter_wave_kernel") or hbm("bin_scatter_kernel<true, false>") or add(hbm("bin_kernel<false>"), hbm("bin_kernel<true>")),
-        "paint": hbm("paint_strips") or hbm("paint_tiles"),
+        "paint": hbm("paint_march") or hbm("paint_strips") or hbm("paint_tiles"),
         "readout": hbm("readout_march") or hbm("readout_strips") or hbm("readout1of3_tiles") or hbm("readout3_tiles") or hbm("readout_grad_tiles") or hbm("readout_kernel") or hbm("readout_grad_kernel"),
         "xback3": hbm("xback3"),
         "k_yback2": hbm("yback2"),
