@@ -424,7 +424,8 @@ class SlabForce(_SlabRank):
             return [(0, xl)]
         # k-space blocks (fpmhip_layout.okblock, the meshes from Nmesh = 1536): a plane range of an exchange chunk
         # [ky_loc / kb][x_loc][kb][kz] is ky_loc / kb separate pieces -- whole-slab exchanges there
-        if int(getattr(pm.layout, "okblock", 0) or pm.layout.osize[1]) != int(pm.layout.osize[1]):
+        kb = int(getattr(pm.layout, "okblock", 0) or 0)
+        if kb and kb != int(pm.layout.osize[1]):
             return [(0, xl)]
         return [(i * (xl // c), xl // c) for i in range(c)]
 
