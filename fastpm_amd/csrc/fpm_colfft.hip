@@ -47,6 +47,42 @@ __device__ __forceinline__ long long col_addr(const ColMap &m, int batch, int i,
     return (long long) batch * m.bstride + (long long) (i / m.rsplit) * m.rhi + (long long) (i % m.rsplit) * m.rlo + col;
 }
 
+// The kernels' form of a ColMap: row i = tau + T j of a column lives at jb[j] + toff(tau) (+ batch * bstride + column),
+// jb[j] = ((T j) / rsplit) * rhi + ((T j) % rsplit) * rlo made on the host -- uniform 64-bit row bases (SGPRs, from the
+// kernel arguments) + ONE 32-bit per-thread element offset, instead of a 64-bit multiply (or, on the split maps of the
+// slab / pencil exchanges, an integer division: ~30 VALU instructions) per element: at E = 32 values per thread the
+// address arithmetic was half of the y passes' VALU instructions.  nest: rsplit and T nest (one divides the other), so
+// that the two parts never carry into each other, and every offset fits 32 bits; otherwise the kernels fall back to
+// col_addr().
+struct RowMap {
+    long long jb[32];
+    ColMap m;
+    int nest;
+};
+
+static RowMap make_rowmap(const ColMap &m, int T, int E, int ncols)
+{
+    RowMap r{};
+    r.m = m;
+    const bool nests = m.rhi == 0 || m.rsplit % T == 0 || T % m.rsplit == 0;
+    for (int j = 0; j < 32; j++) {
+        const long long tj = (long long) T * (j < E ? j : 0);
+        r.jb[j] = m.rhi == 0 ? tj * m.rlo : (tj / m.rsplit) * m.rhi + (tj % m.rsplit) * m.rlo;
+    }
+    const long long tmax = m.rhi == 0 ? (long long) (T - 1) * m.rlo
+                                      : (long long) ((T - 1) / m.rsplit) * m.rhi + (long long) (m.rsplit - 1) * m.rlo;
+    static const int nest_env = getenv("FPMHIP_COL_NEST") ? atoi(getenv("FPMHIP_COL_NEST")) : 1;       // 0: col_addr() everywhere (A/B)
+    r.nest = nest_env && nests && tmax + ncols < 0xffffffffLL;
+    return r;
+}
+
+__device__ __forceinline__ unsigned row_toff(const RowMap &r, int tau, int col)
+{
+    if (r.m.rhi == 0) return (unsigned) ((long long) tau * r.m.rlo + col);
+    const int tq = tau / r.m.rsplit, tr = tau - tq * r.m.rsplit;
+    return (unsigned) ((long long) tq * r.m.rhi + (long long) tr * r.m.rlo + col);
+}
+
 // rev: every XCD walks its eighth of the tiles backwards (see row_block() in fpm_rowfft.hip: a pass that follows a
 // forward-walking producer then starts on what the Infinity Cache still holds)
 __device__ __forceinline__ int xcd_tile(int b, int n, int rev = 0)
@@ -66,12 +102,17 @@ __device__ __forceinline__ int xcd_tile(int b, int n, int rev = 0)
 //   X3 : the same for colfft_xback3_kernel, which keeps 8 columns at N = 1024 (three transforms per column load: it
 //        is not waiting on memory the way the plain and two-transform passes are; 10.05 ms with 4 columns, 9.85 with 8).
 //   SP : real / imaginary parts exchanged one after the other when N * CW complex values (+ twiddles) exceed the LDS.
+#ifndef FPM_LONG_CW_HALF
+#define FPM_LONG_CW_HALF 0
+#endif
 template <typename PL, typename F, bool X3 = false> struct ColCfg {
     static constexpr int N = PL::N;
-    static constexpr int CW = sizeof(F) == 8 ? ((X3 ? N > 1024 : N >= 1024) ? 4 : 8) : (N <= 512 ? 16 : 8);
+    static constexpr int CW0 = sizeof(F) == 8 ? ((X3 ? N > 1024 : N >= 1024) ? 4 : 8) : (N <= 512 ? 16 : 8);
+    static constexpr bool halve = FPM_LONG_CW_HALF && (sizeof(F) == 8 ? N >= 3072 : N >= 2048);
+    static constexpr int CW = halve ? CW0 / 2 : CW0;
     static constexpr size_t full = (size_t) N * CW * sizeof(C2<F>);
     static constexpr size_t twb = (size_t) PL::TWN * sizeof(C2<F>);
-    static constexpr bool SP = full + twb > 150 * 1024;
+    static constexpr bool SP = full + twb > (halve ? 80 : 150) * 1024;
     static constexpr size_t lds = (SP ? full / 2 : full) + twb;
     static constexpr int threads = PL::T * CW;
     static_assert(threads <= 1024, "workgroup too large");
@@ -86,6 +127,7 @@ template <typename PL, typename F, bool X3 = false> struct ColCfg {
 constexpr int fused_min_waves(int threads, int E, int esize = 8)
 {
     if (E == 16 && esize == 4 && threads == 512) return 4;      // fp32, two 512-thread workgroups per CU (see FusedFac)
+    if (FPM_LONG_CW_HALF && E >= 16 && threads == 384) return 3;
     return E >= 16 ? (threads > 512 ? (threads > 768 ? 4 : 3) : 2) : (threads > 512 && threads <= 768 ? 3 : 4);
 }
 
@@ -93,9 +135,15 @@ constexpr int fused_min_waves(int threads, int E, int esize = 8)
 // One tile per workgroup (61 VGPRs, 2 workgroups/CU at N = 512): measured 0.47 ms per 2.16 GB
 // pass = the speed of a contiguous device copy of the same bytes (tools/ubench/wr_pattern.hip).
 // A persistent variant with register prefetch of the next tile needed 178 VGPRs and ran slower.
-template <typename PL, int S, typename F>
+// PERS (where ONE workgroup owns a CU and the exchange is not split: N = 2048, and N = 1024 / 1536 in fp64 with 8 columns):
+// the workgroup walks tiles -- the stores of a tile drain while the loads of the next are in flight, the twiddles are
+// staged once and no workgroup launch sits between two tiles.  The row bases then come from LDS (64 values behind the
+// exchange area): as loop invariants in 128 SGPRs they spilled.  Measured per rank at 2048^3 (tools/env_sweep.sh
+// FPMHIP_COL_PERSIST "0 1"): plain pass 4.9 -> 4.6 ms (fp64), 2.78 -> 2.6 (fp32), colfft_yback2 9.2 -> 8.8; at N = 3072
+// (split exchange, 12-wave workgroups) the same loop LOSES (10.7 -> 13.2 ms, 23.3 -> 29.2) and is not used.
+template <typename PL, int S, typename F, bool PERS>
 __global__ __launch_bounds__((ColCfg<PL, F>::threads)) void colfft_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ out,
-                                                   ColMap im, ColMap om, int ncols, int ntiles_per_batch,
+                                                   RowMap im, RowMap om, int ncols, int ntiles_per_batch,
                                                    int ntiles, const double *__restrict__ tw_global, double scale, int rev)
 {
     using CF = ColCfg<PL, F>;
@@ -103,25 +151,61 @@ __global__ __launch_bounds__((ColCfg<PL, F>::threads)) void colfft_kernel(const 
     extern __shared__ __align__(16) unsigned char smem[];
     C2<F> *tw = (C2<F> *) smem;                       // PL::TWN entries, then the exchange area
     void *lds = smem + CF::twb;
-    const int c = threadIdx.x % CW, tau = threadIdx.x / CW;
-    const int tile = xcd_tile(blockIdx.x, ntiles, rev);
-    const int batch = tile / ntiles_per_batch;
-    const int col = (tile % ntiles_per_batch) * CW + c;
-    const bool live = col < ncols;
-    C2<F> v[vmax(E)];
-#pragma unroll
-    for (int j = 0; j < E; j++) v[in_slot<PL>(j)] = live ? ld_stream(&in[col_addr(im, batch, tau + T * j, col)]) : C2<F>{0, 0};
-    stage_twiddles(tw, tw_global, PL::TWN);       // after the data loads are in flight
-    __syncthreads();
-    fft_core<PL, S, CW, CF::SP>(v, lds, tw, tau, c);
-    if (live) {
-#pragma unroll
-        for (int j = 0; j < E; j++) {
-            C2<F> r = v[j];
-            // pmpfft.c:381-385 multiplies by a double 1 / Norm and rounds once
-            if (scale != 1.0) { r.x = (F) (r.x * scale); r.y = (F) (r.y * scale); }
-            st_stream(&out[col_addr(om, batch, tau + T * j, col)], r);
+    const long long *jbl = (const long long *) (smem + CF::lds);
+    if (PERS) {
+        if (threadIdx.x < 64) {
+            const ColMap &m = threadIdx.x < 32 ? im.m : om.m;
+            const long long tj = (long long) T * (threadIdx.x % 32);
+            ((long long *) (smem + CF::lds))[threadIdx.x] = m.rhi == 0 ? tj * m.rlo : (tj / m.rsplit) * m.rhi + (tj % m.rsplit) * m.rlo;
         }
+        stage_twiddles(tw, tw_global, PL::TWN);
+        __syncthreads();
+    }
+#pragma unroll 1
+    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
+        // (PERS) an opaque copy of the thread's coordinates per tile: nothing derived from them -- LDS positions, element
+        // offsets -- is hoisted out of the loop to live in registers across the transforms
+        int c = threadIdx.x % CW, tau = threadIdx.x / CW;
+        if (PERS) asm volatile("" : "+v"(c), "+v"(tau));
+        const int tile = xcd_tile(vb, ntiles, rev);
+        const int batch = tile / ntiles_per_batch;
+        const int col = (tile % ntiles_per_batch) * CW + c;
+        const bool live = col < ncols;
+        C2<F> v[vmax(E)];
+        if (im.nest) {
+            const C2<F> *src = in + (long long) batch * im.m.bstride;
+            const unsigned toff = row_toff(im, tau, col);
+#pragma unroll
+            for (int j = 0; j < E; j++)
+                v[in_slot<PL>(j)] = live ? ld_stream(&(src + (PERS ? jbl[j] : im.jb[j]))[toff]) : C2<F>{0, 0};
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; j++) v[in_slot<PL>(j)] = live ? ld_stream(&in[col_addr(im.m, batch, tau + T * j, col)]) : C2<F>{0, 0};
+        }
+        if (!PERS) {
+            stage_twiddles(tw, tw_global, PL::TWN);       // after the data loads are in flight
+            __syncthreads();
+        }
+#ifndef FPM_COL_SKIP_FFT
+        fft_core<PL, S, CW, CF::SP>(v, lds, tw, tau, c);
+#endif
+        if (live) {
+            // pmpfft.c:381-385 multiplies by a double 1 / Norm and rounds once
+            if (scale != 1.0) {
+#pragma unroll
+                for (int j = 0; j < E; j++) { v[j].x = (F) (v[j].x * scale); v[j].y = (F) (v[j].y * scale); }
+            }
+            if (om.nest) {
+                C2<F> *dst = out + (long long) batch * om.m.bstride;
+                const unsigned toff = row_toff(om, tau, col);
+#pragma unroll
+                for (int j = 0; j < E; j++) st_stream(&(dst + (PERS ? jbl[32 + j] : om.jb[j]))[toff], v[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < E; j++) st_stream(&out[col_addr(om.m, batch, tau + T * j, col)], v[j]);
+            }
+        }
+        if (!PERS) break;
     }
 }
 
@@ -254,10 +338,11 @@ void colfft_xback3_kernel(const C2<F> *dk, C2<F> *__restrict__ o0, C2<F> *__rest
 // registers across the transforms (N = 3072: E = 16 / 32 values per thread, 428 / 776 bytes of spills per lane, the pass
 // at 0.12 of the HBM peak) two or three such launches -- each with the register needs of a plain pass -- are faster than
 // one that reads the potential once: 46 -> ms below at 3072^3 fp32 per rank.
-template <typename PL, typename F, bool ONE = false>
+// PERS: as colfft_kernel's.
+template <typename PL, typename F, bool ONE = false, bool PERS = false>
 __global__ __launch_bounds__((ColCfg<PL, F>::threads), (fused_min_waves(ColCfg<PL, F>::threads, PL::E, sizeof(F))))
 void colfft_yback2_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ oy, C2<F> *__restrict__ oz,
-                          C2<F> *__restrict__ op, ColMap im, ColMap om, int ncols, int ntiles_per_batch, int ntiles,
+                          C2<F> *__restrict__ op, RowMap im, RowMap om, int ncols, int ntiles_per_batch, int ntiles,
                           const float *__restrict__ kt, const double *__restrict__ tw_global, int zstart, int only)
 {
     using CF = ColCfg<PL, F>;
@@ -265,40 +350,69 @@ void colfft_yback2_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ oy, 
     extern __shared__ __align__(16) unsigned char smem[];
     C2<F> *tw = (C2<F> *) smem;
     void *lds = smem + CF::twb;
-    const int c = threadIdx.x % CW, tau = threadIdx.x / CW;
-    const int tile = xcd_tile(blockIdx.x, ntiles);
-    const int batch = tile / ntiles_per_batch;
-    const int col = (tile % ntiles_per_batch) * CW + c;
-    const bool live = col < ncols;
-    C2<F> a[E];
-#pragma unroll
-    for (int j = 0; j < E; j++) a[j] = live ? ld_stream(&in[col_addr(im, batch, tau + T * j, col)]) : C2<F>{0, 0};
-    stage_twiddles(tw, tw_global, PL::TWN);
-    // op != nullptr: a third output, the potential itself (gravity.c:487-492 wants it read out too): its y pass
-    // comes from the same read instead of a second transfer + x pass (+ all-to-all on slabs)
+    const long long *jbl = (const long long *) (smem + CF::lds);
+    if (PERS) {
+        if (threadIdx.x < 64) {
+            const ColMap &m = threadIdx.x < 32 ? im.m : om.m;
+            const long long tj = (long long) T * (threadIdx.x % 32);
+            ((long long *) (smem + CF::lds))[threadIdx.x] = m.rhi == 0 ? tj * m.rlo : (tj / m.rsplit) * m.rhi + (tj % m.rsplit) * m.rlo;
+        }
+        stage_twiddles(tw, tw_global, PL::TWN);
+    }
 #pragma unroll 1
-    for (int dir = ONE ? only : (op ? 0 : 1); dir < (ONE ? only + 1 : 3); dir++) {
-        C2<F> v[vmax(E)];
-        int tau_o = tau;                     // see colfft_xback3_kernel
-        if (!ONE) asm volatile("" : "+v"(tau_o));
+    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
+        int c = threadIdx.x % CW, tau = threadIdx.x / CW;
+        if (PERS) asm volatile("" : "+v"(c), "+v"(tau));
+        const int tile = xcd_tile(vb, ntiles);
+        const int batch = tile / ntiles_per_batch;
+        const int col = (tile % ntiles_per_batch) * CW + c;
+        const bool live = col < ncols;
+        if (PERS) __syncthreads();            // the row bases (first tile); nobody still reads the exchange area
+        C2<F> a[E];
+        if (im.nest) {
+            const C2<F> *src = in + (long long) batch * im.m.bstride;
+            const unsigned toff = row_toff(im, tau, col);
 #pragma unroll
-        for (int j = 0; j < E; j++) {
-            C2<F> &d = v[in_slot<PL>(j)];
-            if (dir == 0) {
-                d = a[j];
-            } else {
-                const double k_finite = dir == 1 ? kt[tau_o + T * j] : kt[live ? col + zstart : 0];
-                d.x = (F) (-a[j].y * k_finite);
-                d.y = (F) (a[j].x * k_finite);
+            for (int j = 0; j < E; j++) a[j] = live ? ld_stream(&(src + (PERS ? jbl[j] : im.jb[j]))[toff]) : C2<F>{0, 0};
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; j++) a[j] = live ? ld_stream(&in[col_addr(im.m, batch, tau + T * j, col)]) : C2<F>{0, 0};
+        }
+        if (!PERS) stage_twiddles(tw, tw_global, PL::TWN);
+        // op != nullptr: a third output, the potential itself (gravity.c:487-492 wants it read out too): its y pass
+        // comes from the same read instead of a second transfer + x pass (+ all-to-all on slabs)
+#pragma unroll 1
+        for (int dir = ONE ? only : (op ? 0 : 1); dir < (ONE ? only + 1 : 3); dir++) {
+            C2<F> v[vmax(E)];
+            int tau_o = tau;                     // see colfft_xback3_kernel
+            if (!ONE) asm volatile("" : "+v"(tau_o));
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                C2<F> &d = v[in_slot<PL>(j)];
+                if (dir == 0) {
+                    d = a[j];
+                } else {
+                    const double k_finite = dir == 1 ? kt[tau_o + T * j] : kt[live ? col + zstart : 0];
+                    d.x = (F) (-a[j].y * k_finite);
+                    d.y = (F) (a[j].x * k_finite);
+                }
+            }
+            __syncthreads();
+            fft_core<PL, +1, CW, CF::SP>(v, lds, tw, tau, c);
+            if (live) {
+                C2<F> *dst = dir == 0 ? op : (dir == 1 ? oy : oz);
+                if (om.nest) {
+                    dst += (long long) batch * om.m.bstride;
+                    const unsigned toff = row_toff(om, tau_o, col);
+#pragma unroll
+                    for (int j = 0; j < E; j++) st_stream(&(dst + (PERS ? jbl[32 + j] : om.jb[j]))[toff], v[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < E; j++) st_stream(&dst[col_addr(om.m, batch, tau_o + T * j, col)], v[j]);
+                }
             }
         }
-        __syncthreads();
-        fft_core<PL, +1, CW, CF::SP>(v, lds, tw, tau, c);
-        if (live) {
-            C2<F> *dst = dir == 0 ? op : (dir == 1 ? oy : oz);
-#pragma unroll
-            for (int j = 0; j < E; j++) st_stream(&dst[col_addr(om, batch, tau_o + T * j, col)], v[j]);
-        }
+        if (!PERS) break;
     }
 }
 
@@ -336,6 +450,18 @@ bool colfft_supported(int N)
     return false;
 }
 
+// Workgroups of a persistent launch: as many as are resident at once (256 CUs x what LDS and the wave slots admit), where
+// that is ONE per CU; the full grid otherwise.  FPMHIP_COL_PERSIST = 0: never (A/B).
+static int persist_grid(int ntiles, size_t lds, int threads)
+{
+    static const int mode = getenv("FPMHIP_COL_PERSIST") ? atoi(getenv("FPMHIP_COL_PERSIST")) : 1;
+    const int by_lds = (int) ((160 * 1024) / (lds ? lds : 1)), by_waves = 2048 / threads;
+    const int per_cu = by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves;
+    if (mode == 0 || per_cu > 1) return ntiles;
+    const int resident = 256 * per_cu;
+    return ntiles < resident ? ntiles : resident;
+}
+
 template <typename F>
 static int colfft_launch(fpmhip_plan *p, int dir, const void *in, void *out, const ColMap &im, const ColMap &om,
                          int nbatch, int ncols, double scale)
@@ -346,9 +472,23 @@ static int colfft_launch(fpmhip_plan *p, int dir, const void *in, void *out, con
     {                                                                                                          \
         using CF = ColCfg<PL, F>;                                                                              \
         const int tpb = (ncols + CF::CW - 1) / CF::CW, ntiles = tpb * nbatch;                                  \
-        FPM_TRY(set_lds(colfft_kernel<PL, S, F>, CF::lds));                                                    \
-        colfft_kernel<PL, S, F><<<ntiles, CF::threads, CF::lds, p->stream>>>(                                  \
-            (const C2<F> *) in, (C2<F> *) out, im, om, ncols, tpb, ntiles, p->d_twiddle, scale, rev);          \
+        const int grid = persist_grid(ntiles, CF::lds, CF::threads);                                           \
+        bool done = false;                                                                                     \
+        if constexpr (CF::lds > 80 * 1024 && !CF::SP) {                                                                   \
+            if (grid < ntiles) {                                                                               \
+                FPM_TRY(set_lds(colfft_kernel<PL, S, F, true>, CF::lds + 512));                                \
+                colfft_kernel<PL, S, F, true><<<grid, CF::threads, CF::lds + 512, p->stream>>>(                \
+                    (const C2<F> *) in, (C2<F> *) out, make_rowmap(im, PL::T, PL::E, ncols),                   \
+                    make_rowmap(om, PL::T, PL::E, ncols), ncols, tpb, ntiles, p->d_twiddle, scale, rev);       \
+                done = true;                                                                                   \
+            }                                                                                                  \
+        }                                                                                                      \
+        if (!done) {                                                                                           \
+            FPM_TRY(set_lds(colfft_kernel<PL, S, F, false>, CF::lds));                                         \
+            colfft_kernel<PL, S, F, false><<<ntiles, CF::threads, CF::lds, p->stream>>>(                       \
+                (const C2<F> *) in, (C2<F> *) out, make_rowmap(im, PL::T, PL::E, ncols),                       \
+                make_rowmap(om, PL::T, PL::E, ncols), ncols, tpb, ntiles, p->d_twiddle, scale, rev);           \
+        }                                                                                                      \
     }
 #define CALL_PLAIN(PL) if (dir < 0) CALL_PLAIN_S(PL, -1) else CALL_PLAIN_S(PL, +1)
     COLFFT_DISPATCH(p->mg.N, sizeof(F), CALL_PLAIN)
@@ -424,17 +564,36 @@ static int yback2_launch(fpmhip_plan *p, const void *in, void *oy, void *oz, voi
     {                                                                                                        \
         using CF = ColCfg<PL, F>;                                                                            \
         const int tpb = (ncols + CF::CW - 1) / CF::CW, ntiles = tpb * nbatch;                                \
+        const RowMap rim = make_rowmap(im, PL::T, PL::E, ncols), rom = make_rowmap(om, PL::T, PL::E, ncols); \
+        const int grid = persist_grid(ntiles, CF::lds, CF::threads);                                         \
+        const int order[3] = {0, 2, 1};              /* y last: on one rank it may overwrite the input */         \
+        if constexpr (CF::lds > 80 * 1024 && !CF::SP) {                                                                 \
+            if (grid < ntiles) {                                                                             \
+                if (one) {                                                                                   \
+                    FPM_TRY(set_lds(colfft_yback2_kernel<PL, F, true, true>, CF::lds + 512));                \
+                    for (int q = op ? 0 : 1; q < 3; q++)                                                     \
+                        colfft_yback2_kernel<PL, F, true, true><<<grid, CF::threads, CF::lds + 512, p->stream>>>( \
+                            (const C2<F> *) in, (C2<F> *) oy, (C2<F> *) oz, (C2<F> *) op, rim, rom, ncols, tpb, ntiles, kt, \
+                            p->d_twiddle, p->mg.zstart, order[q]);                                           \
+                } else {                                                                                     \
+                    FPM_TRY(set_lds(colfft_yback2_kernel<PL, F, false, true>, CF::lds + 512));               \
+                    colfft_yback2_kernel<PL, F, false, true><<<grid, CF::threads, CF::lds + 512, p->stream>>>( \
+                        (const C2<F> *) in, (C2<F> *) oy, (C2<F> *) oz, (C2<F> *) op, rim, rom, ncols, tpb, ntiles, kt, \
+                        p->d_twiddle, p->mg.zstart, 0);                                                      \
+                }                                                                                            \
+                break;                                                                                       \
+            }                                                                                                \
+        }                                                                                                    \
         if (one) {                                                                                           \
             FPM_TRY(set_lds(colfft_yback2_kernel<PL, F, true>, CF::lds));                                    \
-            const int order[3] = {0, 2, 1};          /* y last: on one rank it may overwrite the input */         \
             for (int q = op ? 0 : 1; q < 3; q++)                                                             \
                 colfft_yback2_kernel<PL, F, true><<<ntiles, CF::threads, CF::lds, p->stream>>>(              \
-                    (const C2<F> *) in, (C2<F> *) oy, (C2<F> *) oz, (C2<F> *) op, im, om, ncols, tpb, ntiles, kt, \
+                    (const C2<F> *) in, (C2<F> *) oy, (C2<F> *) oz, (C2<F> *) op, rim, rom, ncols, tpb, ntiles, kt, \
                     p->d_twiddle, p->mg.zstart, order[q]);                                                   \
         } else {                                                                                             \
             FPM_TRY(set_lds(colfft_yback2_kernel<PL, F>, CF::lds));                                          \
             colfft_yback2_kernel<PL, F><<<ntiles, CF::threads, CF::lds, p->stream>>>(                        \
-                (const C2<F> *) in, (C2<F> *) oy, (C2<F> *) oz, (C2<F> *) op, im, om, ncols, tpb, ntiles, kt, \
+                (const C2<F> *) in, (C2<F> *) oy, (C2<F> *) oz, (C2<F> *) op, rim, rom, ncols, tpb, ntiles, kt, \
                 p->d_twiddle, p->mg.zstart, 0);                                                              \
         }                                                                                                    \
     }
