@@ -53,7 +53,10 @@ constexpr int TILE_Y = 8;
 constexpr int TILE_Z = 32;
 constexpr int TILE_CELLS = TILE_X * TILE_Y * TILE_Z;
 // Strip tiles (fpm_strips.hip): one x plane x STRIP_Y rows x all of z.
-constexpr int STRIP_Y = 4;
+#ifndef FPM_STRIP_Y
+#define FPM_STRIP_Y 4
+#endif
+constexpr int STRIP_Y = FPM_STRIP_Y;
 // The counting sort keeps BIN_PRIV private copies of every tile counter / cursor, picked by workgroup id: a dense
 // clump puts thousands of particles into a few tiles and their atomics serialise per ADDRESS at the memory side.
 constexpr int BIN_PRIV = 8;
