@@ -1216,6 +1216,8 @@ static int bin_full(fpmhip_plan *p, const fpmhip_particles *pt, const int *pred)
 }
 
 // what every binning ends with: the next call's layout from this call's counts, and the compact tile order
+// (nothing in this call's paint / transforms / readout reads it; on a side stream beside the paint the binning stage drops
+// 0.36 -> 0.31 ms at 512^3 and the paint pays it back, 0.445 -> 0.48 ms: 4.55 vs 4.58 ms per force -- not kept)
 static int bin_finish(fpmhip_plan *p, const int *pred)
 {
     const int nt = p->ntiles;
