@@ -384,6 +384,10 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
 // ("finish"), the same additions in the same order.  The half sums of the first PF particles per thread wait in registers
 // together with the positions; what a dense tile has beyond that waits in a global scratch row per component (written and
 // read back one step later: L2).  LDS per workgroup: 29.5 KB at M = 256 in fp64 (two planes: 51 KB), 58 KB at M = 512.
+// Round 3, tried on this kernel and not adopted: no table of the M-th roots (W_M^j = W_N^(2j) read from the z pass' table at
+// stride 2: 8 KB of LDS less at M = 512 in fp64, 50 KB per workgroup) -- 1.19 -> 1.235 ms at 512^3, 14.6 -> 15.0 ms at 1024^3,
+// and a third workgroup per CU would also need <= 128 VGPRs (FPM_RO_MINW=4: 46 - 56 spilled, 2.3 / 22.6 ms); strips of 8 rows
+// (-DFPM_STRIP_Y=8: five waves at the plane's two barriers, 1.19 -> 1.75 ms).
 #ifndef FPM_RO_MINW
 #define FPM_RO_MINW 3
 #endif

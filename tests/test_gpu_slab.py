@@ -53,6 +53,37 @@ def test_virtual_ranks_match_one_rank_oracle(oracle, P, load, precision, paint_m
         pm.destroy()
 
 
+@pytest.mark.parametrize("N,P", [(48, 3), (96, 3), (64, 4), (80, 5)])
+@pytest.mark.parametrize("precision", [64, 32])
+def test_virtual_ranks_row_maps_nested_and_general(oracle, N, P, precision):
+    """The y passes address the exchange chunks through per-slot row bases when a chunk's y_loc rows and the kernel's T =
+    N / 8 threads per column nest (64 / 4: 16 and 8), and through col_addr()'s division per element when they do not
+    (48 / 3: 16 and 6; 96 / 3: 32 and 12; 80 / 5: 16 and 10) -- fpm_colfft.hip RowMap."""
+    import torch
+    from fastpm_amd import PM, Store
+    from fastpm_amd.distributed import SlabForce, run_virtual
+    nc, L = N // 2, 1.5 * N
+    x = util.load_b(nc, L, N, rms_cells=1.5)
+    pmo = oracle.PMOracle(N, L, precision)
+    ref = oracle.compute_force(pmo, x)
+    idx = _split(x, N, L, P)
+    pms = [PM(N, L, precision, nranks=P, rank=r) for r in range(P)]
+    assert all(pm.column_fft() for pm in pms)
+    stores = [Store(x[idx[r]]) for r in range(P)]
+    dks = [pm.alloc() for pm in pms]
+    run_virtual([SlabForce(pm) for pm in pms], stores, delta_ks=dks)
+    torch.cuda.synchronize()
+    acc = np.zeros_like(ref["acc"])
+    for r in range(P):
+        acc[idx[r]] = stores[r].acc.cpu().numpy()
+    dk = np.concatenate([pm.complex_view(d).cpu().numpy() for pm, d in zip(pms, dks)], axis=1)
+    tol_acc, tol_dk = (1e-6, 1e-14) if precision == 64 else (2e-5, 5e-7)
+    assert util.max_err(dk, util.oracle_k_to_xyk(pmo, ref["delta_k"])) <= tol_dk
+    assert util.rel_err(acc, ref["acc"]) <= tol_acc
+    for pm in pms:
+        pm.destroy()
+
+
 @pytest.mark.parametrize("N,P", [(24, 2), (48, 4), (40, 2), (32, 2)])
 def test_virtual_ranks_rocfft_backend(oracle, N, P):
     """The rocFFT slab path (2-D batched plans + pack/unpack kernels + strided 1-D x plans): what
