@@ -88,6 +88,7 @@ struct MeshGeo {
     int rp;            // the same in complex units: the pitch the z passes read / write real rows with
     double inv_cell;   // 1.0 / (BoxSize / N), pmpfft.c:150-151
     int ntx, nty, ntz; // tile grid over [xplanes][N][N]
+    int xseg;          // strip plans: x planes a marching workgroup walks (fpm_strips.hip)
     int strips;        // 0: box tiles TILE_X x TILE_Y x TILE_Z; STRIP_Y: strip tiles (ntx = xl, nty = N / STRIP_Y, ntz = 1)
 };
 

@@ -318,6 +318,8 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
             FPM_FAIL(-1, "FPMHIP_PAINT_STRIPS: one rank or x slabs, the k-space gradient and a mesh whose z rows fit the strip kernels");
         if (can && (geom->paint_mode == FPMHIP_PAINT_STRIPS || (geom->paint_mode == FPMHIP_PAINT_TILED && N >= 320 && !env_off))) {
             g.strips = STRIP_Y;
+            static const int xseg_env = getenv("FPMHIP_XSEG") ? atoi(getenv("FPMHIP_XSEG")) : 0;      // A/B
+            g.xseg = xseg_env > 0 ? xseg_env : 0;                    // 0: chosen per launch (fpm_strips.hip choose_xseg)
             g.ntx = g.xl; g.nty = (int) N / STRIP_Y; g.ntz = 1;
         }
     }

@@ -42,6 +42,7 @@
 //
 // Reference arithmetic: painter-cic.c:34-110 (paint), :113-190 (readout), pmpfft.c:370-399 (the z legs of r2c / c2r);
 // the sums are the same sums in another order (the tolerance class of the box-tile kernels).
+#include <cmath>
 #include <cstdlib>
 
 #include "fpm_cic.h"
@@ -50,7 +51,7 @@
 namespace fpm {
 
 constexpr int STRIP_RW = STRIP_Y + 1;         // rows per window plane of the readout: the strip + the y halo row
-constexpr int STRIP_XSEG = 32;                // x planes per workgroup (one redundant plane of work per segment)
+// x planes per workgroup (one redundant plane of work per segment): MeshGeo::xseg, set with the plan (fpm_plan.hip)
 
 // the paint keeps HALF a twiddle table (W^(j + M/2) = -W^j): 38.9 KB of LDS at M = 256 in fp64, four workgroups per CU
 template <typename PL> struct HalfTw : PL {
@@ -120,10 +121,10 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), 3) void paint_march_
     C2<F> *out = (C2<F> *) out_;
     double *A = (double *) (smem_st + CF::pt_twb);            // [STRIP_Y][WP]
     const int tid = threadIdx.x;
-    const int nseg = (g.xl + STRIP_XSEG - 1) / STRIP_XSEG;
+    const int nseg = (g.xl + g.xseg - 1) / g.xseg;
     const int t = xcd_remap(blockIdx.x, g.nty * nseg);
     const int strip = t % g.nty, seg = t / g.nty;
-    const int xa = seg * STRIP_XSEG, xb = min(xa + STRIP_XSEG, g.xl);
+    const int xa = seg * g.xseg, xb = min(xa + g.xseg, g.xl);
     const int y0 = strip * STRIP_Y;
     // the z pass: row c, elements tau + T j
     const int c = WS ? tid / T : tid % STRIP_Y, tau = WS ? tid % T : tid / STRIP_Y;
@@ -286,14 +287,14 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
     C2<F> *win = twn + M;                          // [2][SLOT]
     constexpr int CWX = WS ? -RP : RW, SKX = WS ? 0 : SK;
     const int c = WS ? threadIdx.x / T : threadIdx.x % RW, tau = WS ? threadIdx.x % T : threadIdx.x / RW;
-    const int nseg = (g.xl + STRIP_XSEG - 1) / STRIP_XSEG;
+    const int nseg = (g.xl + g.xseg - 1) / g.xseg;
     // the ncomp workgroups of a (segment, strip) are neighbours (they read the same positions), then the strips
     const int t = xcd_remap(blockIdx.x, ncomp * g.nty * nseg);
     // last segment first: the y passes before this kernel walk the planes forwards, so their last planes are the ones
     // the Infinity Cache still holds (1.635 -> 1.613 ms)
     const int comp = t % ncomp, strip = (t / ncomp) % g.nty, seg = nseg - 1 - t / (ncomp * g.nty);
     const C2<F> *mesh = comp == 0 ? m0 : (comp == 1 ? m1 : m2);
-    const int xa = seg * STRIP_XSEG, xb = min(xa + STRIP_XSEG, g.xl);
+    const int xa = seg * g.xseg, xb = min(xa + g.xseg, g.xl);
     const int y0 = strip * STRIP_Y;
     int gy = y0 + c;
     gy -= gy >= g.N ? g.N : 0;
@@ -407,12 +408,12 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? FPM_RO_MINW : 
     C2<F> *S = twn + M;                            // [ro_slot]: the FFT exchange area, then RW real rows of the plane
     constexpr int CWX = WS ? -RP : RW, SKX = WS ? 0 : SK;
     const int tid = threadIdx.x, c = WS ? tid / T : tid % RW, tau = WS ? tid % T : tid / RW;
-    const int nseg = (g.xl + STRIP_XSEG - 1) / STRIP_XSEG;
+    const int nseg = (g.xl + g.xseg - 1) / g.xseg;
     const int t = xcd_remap(blockIdx.x, ncomp * g.nty * nseg);
     const int comp = t % ncomp, strip = (t / ncomp) % g.nty, seg = nseg - 1 - t / (ncomp * g.nty);      // last segment first
     const C2<F> *mesh = comp == 0 ? m0 : (comp == 1 ? m1 : m2);
     double *part = part_all + comp * part_stride;
-    const int xa = seg * STRIP_XSEG, xb = min(xa + STRIP_XSEG, g.xl);
+    const int xa = seg * g.xseg, xb = min(xa + g.xseg, g.xl);
     const int y0 = strip * STRIP_Y;
     int gy = y0 + c;
     gy -= gy >= g.N ? g.N : 0;
@@ -553,17 +554,47 @@ template <typename K> static int grant_lds(K kernel, size_t bytes, int device)
     return 0;
 }
 
+// x planes per marching workgroup.  A segment costs one redundant plane of work (and a prologue), so long segments are
+// cheaper per plane -- but the launch should be close to a whole number of rounds of what is resident at once (256 CUs x
+// the occupancy of the kernel): the fp64 paint of 512^3 is 2048 workgroups of 32 planes against 1536 resident ones, 1.33
+// rounds (0.44 ms; 16 planes, 2.67 rounds: 0.40 ms), the fp32 one 2048 against 2048 (0.29 ms; 16 planes: 0.31); the
+// readout of 1024^3 is 48 rounds at 32 planes (14.6 ms; 128 planes: 14.3).  Picks the length with the best modelled
+// efficiency  rounds / ceil(rounds) x xs / (xs + 1).  FPMHIP_XSEG forces a length (A/B).
+template <typename K>
+static int choose_xseg(const MeshGeo &g, K kernel, int threads, size_t lds, int wgs_per_plane_column, int lo, int hi, int *occ_cache)
+{
+    if (g.xseg > 0) return g.xseg;
+    if (*occ_cache == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *) kernel, threads, lds) != hipSuccess || nb < 1) nb = 1;
+        *occ_cache = nb;
+    }
+    const double resident = 256.0 * *occ_cache;
+    int best = 32;
+    double best_eff = -1;
+    for (int xs = hi; xs >= lo; xs /= 2) {
+        const double rounds = (double) wgs_per_plane_column * ((g.xl + xs - 1) / xs) / resident;
+        if (xs > 32 && rounds < 8) continue;         // (few long rounds end in a long tail: the readout of 512^3 at 64 planes,
+                                                     // 3 rounds instead of 6, runs 1.19 -> 1.22 ms)
+        const double eff = rounds / std::ceil(rounds) * xs / (xs + 1.0);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = xs; }
+    }
+    return best;
+}
+
 template <typename F, bool R2C>
 static int paint_strips_launch(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void *out, int accumulate)
 {
-    const MeshGeo &g = p->mg;
-    const int nseg = (g.xl + STRIP_XSEG - 1) / STRIP_XSEG;
+    MeshGeo g = p->mg;
     // the z pass wave-local where a row's threads fit one wave (the power-of-two meshes); FPMHIP_PT_WS = 0: A/B
     static const int ws_env = getenv("FPMHIP_PT_WS") ? atoi(getenv("FPMHIP_PT_WS")) : 1;
 #define CALL_PM_W(PL, WS_)                                                                                             \
     {                                                                                                                  \
         using CF = StripCfg<PL, F>;                                                                                    \
         FPM_TRY(grant_lds(paint_march_kernel<PL, F, R2C, WS_>, CF::pt1_lds, p->device));                               \
+        static int occ = 0;                                                                                            \
+        g.xseg = choose_xseg(g, paint_march_kernel<PL, F, R2C, WS_>, CF::pt_threads, CF::pt1_lds, g.nty, 8, 64, &occ); \
+        const int nseg = (g.xl + g.xseg - 1) / g.xseg;                                                                 \
         paint_march_kernel<PL, F, R2C, WS_><<<g.nty * nseg, CF::pt_threads, CF::pt1_lds, p->stream>>>(                 \
             g, p->ntiles, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, pt->mass ? p->smass : nullptr, pt->M0, scale, out, \
             accumulate, p->d_twiddle, p->scell);                                                                       \
@@ -595,8 +626,7 @@ template <typename F>
 static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1, const void *k2, int ncomp, float *out,
                                  int nmemb, int memb0)
 {
-    const MeshGeo &g = p->mg;
-    const int nseg = (g.xl + STRIP_XSEG - 1) / STRIP_XSEG;
+    MeshGeo g = p->mg;
     // ONE plane in LDS with wave-local transforms (WS) wherever a row's threads fit one wave (T = M / 8 divides 64: the
     // power-of-two meshes): the waves of a workgroup go through their c2r transforms independently, two workgroup
     // barriers per plane instead of eight, four workgroups per CU at M = 256 in fp64.  Other row lengths: two planes
@@ -616,13 +646,18 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
 #define CALL_RO_W(PL, WS_)                                                                                             \
     {                                                                                                                  \
         using CF = StripCfg<PL, F>;                                                                                    \
+        static int occ2 = 0, occ1 = 0;                                                                                 \
         if (two_planes) {                                                                                              \
             FPM_TRY(grant_lds(readout_strips_kernel<PL, F, WS_>, CF::ro_lds, p->device));                              \
+            g.xseg = choose_xseg(g, readout_strips_kernel<PL, F, WS_>, CF::ro_threads, CF::ro_lds, ncomp * g.nty, 16, 128, &occ2); \
+            const int nseg = (g.xl + g.xseg - 1) / g.xseg;                                                             \
             readout_strips_kernel<PL, F, WS_><<<ncomp * g.nty * nseg, CF::ro_threads, CF::ro_lds, p->stream>>>(        \
                 g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                 \
                 (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->scell);                    \
         } else {                                                                                                       \
             FPM_TRY(grant_lds(readout_march_kernel<PL, F, WS_>, CF::ro1_lds, p->device));                              \
+            g.xseg = choose_xseg(g, readout_march_kernel<PL, F, WS_>, CF::ro_threads, CF::ro1_lds, ncomp * g.nty, 16, 128, &occ1); \
+            const int nseg = (g.xl + g.xseg - 1) / g.xseg;                                                             \
             readout_march_kernel<PL, F, WS_><<<ncomp * g.nty * nseg, CF::ro_threads, CF::ro1_lds, p->stream>>>(        \
                 g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                 \
                 (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride,      \
