@@ -294,7 +294,7 @@ __device__ __forceinline__ void butterflies(C2<F> *v, const C2<F> *tw, int tau)
 // CW < 0: row-major, row c at c * (-CW) (the strip kernels' wave-local exchange: every row has its own region)
 template <int CW, int SK> __device__ __forceinline__ int lds_pos(int idx, int c)
 {
-    if (CW < 0) return c * (-CW) + idx;
+    if (CW < 0) return c * (-CW) + idx + (SK ? SK * (idx >> 5) : 0);
     return idx * CW + c + (SK ? SK * (idx >> 5) : 0);
 }
 

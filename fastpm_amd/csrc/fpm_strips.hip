@@ -78,7 +78,12 @@ template <typename PL, typename F> struct StripCfg {
     // readout: two planes of STRIP_RW rows of ro_pitch complex values (>= M + 1: value N of a row repeats value 0)
     static constexpr int ro_threads = T * STRIP_RW;
     static constexpr int ro_sk = M == 256 && sizeof(F) == 8 ? 4 : 0;
-    static constexpr int ro_pitch = strip_pitch(M, 13);
+    // wave-local exchange (a row's region its own, row-major), fp32: 2 elements of skew per 32 indices take the strided
+    // gathers of the later stages off each other's banks (tools/lds_bank_model.py: 336 -> 224 LDS cycles per row pair and
+    // plane): readout 0.85 -> 0.815 ms at 512^3 fp32.  In fp64 the same skew (modelled 544 -> 432) LOSES, 1.19 -> 1.23 ms at
+    // 512^3 and 14.25 -> 14.7 at 1024^3: not applied there.
+    static constexpr int ws_sk = sizeof(F) == 4 ? 2 : 0;
+    static constexpr int ro_pitch = strip_pitch(M + ws_sk * (M / 32), 13);
     static constexpr int ro_xchg = (M + 1) * STRIP_RW + ro_sk * (M / 32 + 1);       // elements of the exchange area
     static constexpr int ro_slot = ro_pitch * STRIP_RW > ro_xchg ? ro_pitch * STRIP_RW : ro_xchg;
     static constexpr size_t ro_lds = twb + (size_t) 2 * ro_slot * sizeof(C2<F>);
@@ -285,7 +290,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
     C2<F> *tw = (C2<F> *) smem_st;
     C2<F> *twn = tw + PL::TWN;
     C2<F> *win = twn + M;                          // [2][SLOT]
-    constexpr int CWX = WS ? -RP : RW, SKX = WS ? 0 : SK;
+    constexpr int CWX = WS ? -RP : RW, SKX = WS ? CF::ws_sk : SK;
     const int c = WS ? threadIdx.x / T : threadIdx.x % RW, tau = WS ? threadIdx.x % T : threadIdx.x / RW;
     const int nseg = (g.xl + g.xseg - 1) / g.xseg;
     // the ncomp workgroups of a (segment, strip) are neighbours (they read the same positions), then the strips
@@ -406,7 +411,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? FPM_RO_MINW : 
     C2<F> *tw = (C2<F> *) smem_st;
     C2<F> *twn = tw + PL::TWN;
     C2<F> *S = twn + M;                            // [ro_slot]: the FFT exchange area, then RW real rows of the plane
-    constexpr int CWX = WS ? -RP : RW, SKX = WS ? 0 : SK;
+    constexpr int CWX = WS ? -RP : RW, SKX = WS ? CF::ws_sk : SK;
     const int tid = threadIdx.x, c = WS ? tid / T : tid % RW, tau = WS ? tid % T : tid / RW;
     const int nseg = (g.xl + g.xseg - 1) / g.xseg;
     const int t = xcd_remap(blockIdx.x, ncomp * g.nty * nseg);
@@ -530,7 +535,7 @@ bool strips_supported(int N, int precision)
 {
     if (!rowfft_supported(N) || N % STRIP_Y != 0 || N / 2 > 1024) return false;
     const size_t es = precision == 64 ? 16 : 8, M = (size_t) N / 2;
-    const size_t ro = (2 * M + (size_t) strip_pitch((int) M, 13) * STRIP_RW) * es;                      // ~ StripCfg::ro1_lds
+    const size_t ro = (2 * M + (size_t) strip_pitch((int) (M + (precision == 64 ? 0 : 2) * (M / 32)), 13) * STRIP_RW) * es;     // ~ StripCfg::ro1_lds
     const size_t pt = (M / 2 + M) * es + (size_t) STRIP_Y * 2 * strip_pitch((int) M, 4) * sizeof(double);       // = pt1_lds
     return ro <= STRIP_LDS_MAX && pt <= STRIP_LDS_MAX;
 }
@@ -539,7 +544,7 @@ bool strips_supported(int N, int precision)
 template <typename F> struct StripTwoPlanes {
     static bool fits(int M, int per_cu)
     {
-        return (2 * (size_t) M + 2 * ((size_t) strip_pitch(M, 13) * STRIP_RW + 64)) * sizeof(C2<F>) <= 160 * 1024 / (size_t) per_cu;
+        return (2 * (size_t) M + 2 * ((size_t) strip_pitch(M + (sizeof(F) == 4 ? 2 : 0) * (M / 32), 13) * STRIP_RW + 64)) * sizeof(C2<F>) <= 160 * 1024 / (size_t) per_cu;
     }
 };
 
