@@ -397,8 +397,13 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
 #ifndef FPM_RO_MINW
 #define FPM_RO_MINW 3
 #endif
-template <typename PL, typename F, bool WS>
-__global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? FPM_RO_MINW : 3)) void readout_march_kernel(
+// LATE (the long rows, M >= 512): a plane's rows are requested right before their transform instead of a step ahead, and the
+// next plane's entries after it -- neither set of registers is held across the transform, the kernel fits 128 VGPRs
+// without spills (166 otherwise), and with that budget it runs 14.3 -> 13.0 ms at 1024^3 fp64 although the 58 KB of LDS
+// still admit only two workgroups per CU (a third one, with the M-th roots read out of the z pass' table: 13.8 ms).  At
+// M = 256 the same order loses (1.20 -> 1.28 ms at 512^3): the prefetch matters more where the transform is short.
+template <typename PL, typename F, bool WS, bool LATE = false>
+__global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FPM_RO_MINW) : 3)) void readout_march_kernel(
     MeshGeo g, int ncomp, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
     const double *__restrict__ sy, const double *__restrict__ sz, const int *__restrict__ sidx, const C2<F> *__restrict__ m0,
     const C2<F> *__restrict__ m1, const C2<F> *__restrict__ m2, float *__restrict__ out, int nmemb, int memb0,
@@ -503,14 +508,16 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? FPM_RO_MINW : 
     __syncthreads();
     c2r_plane();
     __syncthreads();
-    load_plane(xa + 1);
+    if (!LATE) load_plane(xa + 1);
     start_q();
     for (int i = xa; i < xb; i++) {                // the window goes from plane i to plane i + 1
-        if (i + 1 < xb) fetch_q(i + 1);            // needed after the transform
+        if (!LATE && i + 1 < xb) fetch_q(i + 1);   // needed after the transform
+        if (LATE) load_plane(i + 1);
         __syncthreads();                           // every gather from plane i is done
         c2r_plane();
         __syncthreads();
-        if (i + 1 < xb) load_plane(i + 2);         // lands during the gathers
+        if (LATE && i + 1 < xb) fetch_q(i + 1);
+        if (!LATE && i + 1 < xb) load_plane(i + 2);         // lands during the gathers
         finish_p();
         if (i + 1 < xb) start_q();
     }
@@ -646,12 +653,14 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
     const bool two_planes = win_env == 2 ? StripTwoPlanes<F>::fits(g.N / 2, 1)
                           : (win_env == 1 ? false : (!ws_ok && StripTwoPlanes<F>::fits(g.N / 2, 3)));
     const bool use_ws = ws_ok && (ws_env >= 0 ? ws_env != 0 : !two_planes);
+    static const int late_env = getenv("FPMHIP_RO_LATE") ? atoi(getenv("FPMHIP_RO_LATE")) : 1;        // 0: A/B
+    const bool late = late_env != 0;
     // the half sums of a dense tile's entries beyond the first two per thread: one double per own entry and component
     const long long part_stride = p->ro_part_elems;
 #define CALL_RO_W(PL, WS_)                                                                                             \
     {                                                                                                                  \
         using CF = StripCfg<PL, F>;                                                                                    \
-        static int occ2 = 0, occ1 = 0;                                                                                 \
+        static int occ2 = 0, occ1 = 0, occ0 = 0;                                                                       \
         if (two_planes) {                                                                                              \
             FPM_TRY(grant_lds(readout_strips_kernel<PL, F, WS_>, CF::ro_lds, p->device));                              \
             g.xseg = choose_xseg(g, readout_strips_kernel<PL, F, WS_>, CF::ro_threads, CF::ro_lds, ncomp * g.nty, 16, 128, &occ2); \
@@ -659,6 +668,14 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
             readout_strips_kernel<PL, F, WS_><<<ncomp * g.nty * nseg, CF::ro_threads, CF::ro_lds, p->stream>>>(        \
                 g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                 \
                 (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->scell);                    \
+        } else if (WS_ && PL::N >= 512 && late) {                                                                      \
+            FPM_TRY(grant_lds(readout_march_kernel<PL, F, WS_, (WS_ && PL::N >= 512)>, CF::ro1_lds, p->device));       \
+            g.xseg = choose_xseg(g, readout_march_kernel<PL, F, WS_, (WS_ && PL::N >= 512)>, CF::ro_threads, CF::ro1_lds, ncomp * g.nty, 16, 128, &occ0); \
+            const int nseg = (g.xl + g.xseg - 1) / g.xseg;                                                             \
+            readout_march_kernel<PL, F, WS_, (WS_ && PL::N >= 512)><<<ncomp * g.nty * nseg, CF::ro_threads, CF::ro1_lds, p->stream>>>( \
+                g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                 \
+                (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride,      \
+                p->scell);                                                                                             \
         } else {                                                                                                       \
             FPM_TRY(grant_lds(readout_march_kernel<PL, F, WS_>, CF::ro1_lds, p->device));                              \
             g.xseg = choose_xseg(g, readout_march_kernel<PL, F, WS_>, CF::ro_threads, CF::ro1_lds, ncomp * g.nty, 16, 128, &occ1); \
