@@ -523,6 +523,8 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FP
     }
 }
 
+// (M = 1024 with the E = 16 plan -- a row's 64 threads in one wave, wave-local transforms there too -- spills 56 - 90 VGPRs in the
+// readout: one rank of the 2048^3 fp32 mesh 34.4 -> 44 ms; the E = 8 plans with workgroup barriers stay)
 #define FPM_STRIP_CASE(n, BODY) case n: { using PL = typename Fac<n, 0>::type; BODY(PL) } break;
 #define STRIP_DISPATCH(M_, BODY)                                                                                     \
     switch (M_) {                                                                                                    \
