@@ -111,8 +111,12 @@ template <typename PL, typename F> struct StripCfg {
 // 3.18 -> 3.13 ms at 1024^3, 0.40 -> 0.30 -> 0.29 ms at 512^3 fp32.  (WS on the two-plane kernel alone: 0.58 -> 0.63 ms.)
 // R2C = false (several species, a softening kernel in front of the transfer): the finished plane leaves as real rows,
 // canvas = (F) (sum * scale) or canvas += that (gravity.c:326-345, transfer.c:212-220).
+// (FPM_PT_MINW = 4, a 128-VGPR budget: 24 - 30 spilled in fp64, paint 0.41 -> 0.68 ms at 512^3, 3.1 -> 5.1 ms at 1024^3)
+#ifndef FPM_PT_MINW
+#define FPM_PT_MINW 3
+#endif
 template <typename PL, typename F, bool R2C, bool WS>
-__global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), 3) void paint_march_kernel(
+__global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), FPM_PT_MINW) void paint_march_kernel(
     MeshGeo g, int ntiles, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
     const double *__restrict__ sy, const double *__restrict__ sz, const float *__restrict__ smass, double M0, double scale,
     void *__restrict__ out_, int accumulate, const double *__restrict__ tw_global, const int2 *__restrict__ scell)
