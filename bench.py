@@ -245,8 +245,8 @@ def cpu_baseline(ncores, x_dev, Nmesh, BoxSize, acc_dev, pm):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", type=int, default=64)
     ap.add_argument("--nc", type=int, default=0, help="override particles per side")
     ap.add_argument("--nmesh", type=int, default=0, help="override mesh per side")
