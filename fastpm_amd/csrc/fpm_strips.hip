@@ -112,11 +112,14 @@ template <typename PL, typename F> struct StripCfg {
 // R2C = false (several species, a softening kernel in front of the transfer): the finished plane leaves as real rows,
 // canvas = (F) (sum * scale) or canvas += that (gravity.c:326-345, transfer.c:212-220).
 // (FPM_PT_MINW = 4, a 128-VGPR budget: 24 - 30 spilled in fp64, paint 0.41 -> 0.68 ms at 512^3, 3.1 -> 5.1 ms at 1024^3)
+// fp32 at M = 1024: 128 VGPRs (the kernel takes 134 on its own): the eight waves of a workgroup then fit a CU twice (16 wave
+// slots instead of 12; at M = 320 the same budget spills, 0.70 -> 1.03 ms at 640^3): paint + z r2c of one rank of the 2048^3 fp32 mesh 3.8 -> 2.9 ms.  (The LATE order of the readout at M = 1024,
+// ten waves per workgroup, with 96 / 128 VGPRs: 10.4 -> 19.4 / 11.6 ms.)
 #ifndef FPM_PT_MINW
 #define FPM_PT_MINW 3
 #endif
 template <typename PL, typename F, bool R2C, bool WS>
-__global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), FPM_PT_MINW) void paint_march_kernel(
+__global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), (sizeof(F) == 4 && PL::N == 1024 ? 4 : FPM_PT_MINW)) void paint_march_kernel(
     MeshGeo g, int ntiles, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
     const double *__restrict__ sy, const double *__restrict__ sz, const float *__restrict__ smass, double M0, double scale,
     void *__restrict__ out_, int accumulate, const double *__restrict__ tw_global, const int2 *__restrict__ scell)
