@@ -12,11 +12,16 @@ namespace fpm {
 // Rows per workgroup: 8, or 4 when 8 rows of M complex values (+ two twiddle tables) are more than half of a CU's
 // LDS (fp64: M >= 512, i.e. N >= 1024: 82 KB -> one workgroup per CU; 4 rows are 49 KB -> three) or more than 1024
 // threads (fp32, M = 1536).
-template <typename F> constexpr int row_width(int M) { return sizeof(F) == 8 ? (M >= 512 ? 4 : 8) : (M > 1024 ? 4 : 8); }
+// (fp64, M = 1024 -- the 2048^3 mesh: the backward pass with TWO rows per group, 65 KB, two workgroups per CU: 4.22 -> 3.52
+// ms per rank; the forward pass loses with two, 4.03 -> 4.26, and so do both at M = 1536)
+template <typename F> constexpr int row_width(int M, bool c2r)
+{
+    return sizeof(F) == 8 ? (M >= 512 ? (c2r && M == 1024 ? 2 : 4) : 8) : (M > 1024 ? 4 : 8);
+}
 
-template <typename PL, typename F> struct RowCfg {
+template <typename PL, typename F, bool C2R> struct RowCfg {
     static constexpr int M = PL::N;
-    static constexpr int RW = row_width<F>(M);
+    static constexpr int RW = row_width<F>(M, C2R);
     static constexpr int threads = PL::T * RW;
     static constexpr size_t twb = (size_t) (PL::TWN + M) * sizeof(C2<F>);         // W_M^j (maybe half), W_N^k (k < M)
     static constexpr size_t lds = twb + (size_t) (M + 1) * RW * sizeof(C2<F>);
@@ -53,43 +58,59 @@ struct RowGeo {
     int order;           // row_block()
 };
 
-template <typename PL, bool PEN, typename F>
-__global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_r2c_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ out,
-                                                       RowGeo rg, int nrows,
+// PERS: the workgroup walks row groups (grid = what is resident at once): the two twiddle tables -- as many bytes as the 4
+// rows of a group at M = 1024 in fp64 -- are staged once instead of once per group, and the stores of a group drain under
+// the loads of the next.
+template <typename PL, bool PEN, typename F, bool PERS>
+__global__ __launch_bounds__((RowCfg<PL, F, false>::threads)) void rowfft_r2c_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ out,
+                                                       RowGeo rg, int nrows, int ngroups,
                                                        const double *__restrict__ tw_global)
 {
     const long long pitch = rg.pitch;
-    using CF = RowCfg<PL, F>;
+    using CF = RowCfg<PL, F, false>;
     constexpr int M = PL::N, RW = CF::RW, T = PL::T, E = PL::E;
     extern __shared__ __align__(16) unsigned char smem[];
     C2<F> *tw = (C2<F> *) smem;        // W_M^j, j < PL::TWN
     C2<F> *twn = tw + PL::TWN;         // W_N^k, k < M  (N = 2M)
     C2<F> *lds = twn + M;
-    const int c = threadIdx.x % RW, tau = threadIdx.x / RW;
-    const long long row = (long long) row_block(blockIdx.x, gridDim.x, rg.order) * RW + c;
-    const bool live = row < nrows;
-    const C2<F> *src = in + (PEN ? ((row / rg.ylr) * rg.prows + row % rg.ylr) * pitch : row * pitch);
-    C2<F> v[vmax(E)];
+    if (PERS) {
+        stage_twiddles(tw, tw_global, PL::TWN, 2);
+        stage_twiddles(twn, tw_global, M, 1);
+        __syncthreads();
+    }
+#pragma unroll 1
+    for (int vb = blockIdx.x; vb < ngroups; vb += gridDim.x) {
+        int c = threadIdx.x % RW, tau = threadIdx.x / RW;
+        if (PERS) asm volatile("" : "+v"(c), "+v"(tau));      // nothing derived from them is hoisted out of the loop
+        const long long row = (long long) row_block(vb, ngroups, rg.order) * RW + c;
+        const bool live = row < nrows;
+        const C2<F> *src = in + (PEN ? ((row / rg.ylr) * rg.prows + row % rg.ylr) * pitch : row * pitch);
+        C2<F> v[vmax(E)];
 #pragma unroll
-    for (int j = 0; j < E; j++) v[in_slot<PL>(j)] = live ? ld_stream(&src[tau + T * j]) : C2<F>{0, 0};
-    stage_twiddles(tw, tw_global, PL::TWN, 2);       // W_M^i = W_N^{2i}
-    stage_twiddles(twn, tw_global, M, 1);
-    __syncthreads();
-    fft_core<PL, -1, RW, false>(v, lds, tw, tau, c);
-    // exchange so that every thread can pair Z[k] with Z[M - k]
-#pragma unroll
-    for (int j = 0; j < E; j++) lds[(tau + T * j) * RW + c] = v[j];
-    __syncthreads();
-    C2<F> *dst = out + (PEN ? row * rg.nzl : row * pitch);
-    auto at = [&](int k) -> C2<F> & { return PEN ? dst[(k / rg.zblk) * rg.chunk + k % rg.zblk] : dst[k]; };
-#pragma unroll
-    for (int j = 0; j < E; j++) {
-        const int k = tau + T * j;
-        const C2<F> a = v[j];
-        if (live) {
-            st_stream(&at(k), r2c_untangle(a, lds[((M - k) % M) * RW + c], twn[k]));
-            if (k == 0) at(M) = C2<F>{a.x - a.y, 0};           // X[N/2] = Re Z0 - Im Z0
+        for (int j = 0; j < E; j++) v[in_slot<PL>(j)] = live ? ld_stream(&src[tau + T * j]) : C2<F>{0, 0};
+        if (!PERS) {
+            stage_twiddles(tw, tw_global, PL::TWN, 2);       // W_M^i = W_N^{2i}
+            stage_twiddles(twn, tw_global, M, 1);
+            __syncthreads();
         }
+        fft_core<PL, -1, RW, false>(v, lds, tw, tau, c);
+        // exchange so that every thread can pair Z[k] with Z[M - k]
+#pragma unroll
+        for (int j = 0; j < E; j++) lds[(tau + T * j) * RW + c] = v[j];
+        __syncthreads();
+        C2<F> *dst = out + (PEN ? row * rg.nzl : row * pitch);
+        auto at = [&](int k) -> C2<F> & { return PEN ? dst[(k / rg.zblk) * rg.chunk + k % rg.zblk] : dst[k]; };
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const int k = tau + T * j;
+            const C2<F> a = v[j];
+            if (live) {
+                st_stream(&at(k), r2c_untangle(a, lds[((M - k) % M) * RW + c], twn[k]));
+                if (k == 0) at(M) = C2<F>{a.x - a.y, 0};           // X[N/2] = Re Z0 - Im Z0
+            }
+        }
+        if (!PERS) break;
+        __syncthreads();                                      // the partners are read: the exchange area is free again
     }
 }
 
@@ -97,36 +118,66 @@ __global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_r2c_kernel(co
 // place row by row.  The inverse of rowfft_r2c_kernel: with X the half spectrum of a real row,
 //   Z'[k] = (X[k] + conj X[M-k]) + i conj(W_N^k) (X[k] - conj X[M-k]),   z' = IFFT_M(Z') (unnormalised),
 // and the row is z'[n] = x[2n] + i x[2n+1].
-template <typename PL, bool PEN, typename F>
-__global__ __launch_bounds__((RowCfg<PL, F>::threads)) void rowfft_c2r_kernel(const C2<F> *in, C2<F> *out, RowGeo rg, int nrows,
-                                                       const double *__restrict__ tw_global)
+template <typename PL, bool PEN, typename F, bool PERS>
+__global__ __launch_bounds__((RowCfg<PL, F, true>::threads)) void rowfft_c2r_kernel(const C2<F> *in, C2<F> *out, RowGeo rg, int nrows,
+                                                       int ngroups, const double *__restrict__ tw_global)
 {
     const long long pitch = rg.pitch;
-    using CF = RowCfg<PL, F>;
+    using CF = RowCfg<PL, F, true>;
     constexpr int M = PL::N, RW = CF::RW, T = PL::T, E = PL::E;
     extern __shared__ __align__(16) unsigned char smem[];
     C2<F> *tw = (C2<F> *) smem;
     C2<F> *twn = tw + PL::TWN;
     C2<F> *lds = twn + M;                      // (M + 1) * RW: the half spectrum, then the FFT exchange area
-    const int c = threadIdx.x % RW, tau = threadIdx.x / RW;
-    const long long row = (long long) row_block(blockIdx.x, gridDim.x, rg.order) * RW + c;
-    const bool live = row < nrows;
-    const C2<F> *src = in + (PEN ? row * rg.nzl : row * pitch);
-    auto at = [&](int k) -> C2<F> { return ld_stream(PEN ? &src[(k / rg.zblk) * rg.chunk + k % rg.zblk] : &src[k]); };
-    C2<F> x[E];
-#pragma unroll
-    for (int j = 0; j < E; j++) x[j] = live ? at(tau + T * j) : C2<F>{0, 0};
-    const C2<F> xm = (live && tau == 0) ? at(M) : C2<F>{0, 0};
-    stage_twiddles(tw, tw_global, PL::TWN, 2);
-    stage_twiddles(twn, tw_global, M, 1);                      // (read behind c2r_prepare's first barrier)
-    C2<F> v[vmax(E)];
-    c2r_prepare<PL, RW, 0>(v, x, xm, lds, twn, tau, c);
-    fft_core<PL, +1, RW, false>(v, lds, tw, tau, c);
-    if (live) {
-        C2<F> *dst = out + (PEN ? ((row / rg.ylr) * rg.prows + row % rg.ylr) * pitch : row * pitch);
-#pragma unroll
-        for (int j = 0; j < E; j++) st_stream(&dst[tau + T * j], v[j]);
+    if (PERS) {
+        stage_twiddles(tw, tw_global, PL::TWN, 2);
+        stage_twiddles(twn, tw_global, M, 1);
+        __syncthreads();
     }
+#pragma unroll 1
+    for (int vb = blockIdx.x; vb < ngroups; vb += gridDim.x) {
+        int c = threadIdx.x % RW, tau = threadIdx.x / RW;
+        if (PERS) asm volatile("" : "+v"(c), "+v"(tau));
+        const long long row = (long long) row_block(vb, ngroups, rg.order) * RW + c;
+        const bool live = row < nrows;
+        const C2<F> *src = in + (PEN ? row * rg.nzl : row * pitch);
+        auto at = [&](int k) -> C2<F> { return ld_stream(PEN ? &src[(k / rg.zblk) * rg.chunk + k % rg.zblk] : &src[k]); };
+        C2<F> x[E];
+#pragma unroll
+        for (int j = 0; j < E; j++) x[j] = live ? at(tau + T * j) : C2<F>{0, 0};
+        const C2<F> xm = (live && tau == 0) ? at(M) : C2<F>{0, 0};
+        if (!PERS) {
+            stage_twiddles(tw, tw_global, PL::TWN, 2);
+            stage_twiddles(twn, tw_global, M, 1);                      // (read behind c2r_prepare's first barrier)
+        }
+        C2<F> v[vmax(E)];
+        c2r_prepare<PL, RW, 0>(v, x, xm, lds, twn, tau, c);
+        fft_core<PL, +1, RW, false>(v, lds, tw, tau, c);
+        if (live) {
+            C2<F> *dst = out + (PEN ? ((row / rg.ylr) * rg.prows + row % rg.ylr) * pitch : row * pitch);
+#pragma unroll
+            for (int j = 0; j < E; j++) st_stream(&dst[tau + T * j], v[j]);
+        }
+        if (!PERS) break;
+    }
+}
+
+// Workgroups of a persistent launch: what is resident at once, where the tables are a large part of a workgroup's LDS (few
+// rows per group: the long rows); the full grid otherwise.  FPMHIP_ROW_PERSIST = 0: never, 2: every length (A/B).
+template <typename K> static unsigned row_grid(K kernel, int threads, size_t lds, unsigned ngroups, bool *pers, int *occ_cache)
+{
+    static const int mode = getenv("FPMHIP_ROW_PERSIST") ? atoi(getenv("FPMHIP_ROW_PERSIST")) : 1;
+    *pers = false;
+    if (mode == 0 || (mode == 1 && lds <= 60 * 1024)) return ngroups;
+    if (*occ_cache == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *) kernel, threads, lds) != hipSuccess || nb < 1) nb = 1;
+        *occ_cache = nb;
+    }
+    const unsigned resident = 256u * (unsigned) *occ_cache;
+    if (ngroups <= resident) return ngroups;
+    *pers = true;
+    return resident;
 }
 
 template <typename K> static int set_lds(K kernel, size_t bytes)
@@ -180,10 +231,20 @@ static int rowfft_launch(fpmhip_plan *p, const void *in_, void *out_, int x0, in
     void *out = (char *) out_ + (size_t) x0 * g.ylr * g.nzl * sizeof(C2<F>);       // (slabs: nzl == rp, in place works)
 #define CALL_ROW_P(PL, PEN_)                                                                            \
     {                                                                                                   \
-        using CF = RowCfg<PL, F>;                                                                       \
-        FPM_TRY(set_lds(rowfft_r2c_kernel<PL, PEN_, F>, CF::lds));                                      \
-        rowfft_r2c_kernel<PL, PEN_, F><<<(unsigned) ((nrows + CF::RW - 1) / CF::RW), CF::threads, CF::lds, p->stream>>>( \
-            (const C2<F> *) in, (C2<F> *) out, rg, (int) nrows, p->d_twiddle);                          \
+        using CF = RowCfg<PL, F, false>;                                                                       \
+        const unsigned ngroups = (unsigned) ((nrows + CF::RW - 1) / CF::RW);                            \
+        static int occ = 0;                                                                             \
+        bool pers = false;                                                                              \
+        FPM_TRY(set_lds(rowfft_r2c_kernel<PL, PEN_, F, true>, CF::lds));                                \
+        const unsigned grid = row_grid(rowfft_r2c_kernel<PL, PEN_, F, true>, CF::threads, CF::lds, ngroups, &pers, &occ); \
+        if (pers) {                                                                                     \
+            rowfft_r2c_kernel<PL, PEN_, F, true><<<grid, CF::threads, CF::lds, p->stream>>>(            \
+                (const C2<F> *) in, (C2<F> *) out, rg, (int) nrows, (int) ngroups, p->d_twiddle);       \
+        } else {                                                                                        \
+            FPM_TRY(set_lds(rowfft_r2c_kernel<PL, PEN_, F, false>, CF::lds));                           \
+            rowfft_r2c_kernel<PL, PEN_, F, false><<<ngroups, CF::threads, CF::lds, p->stream>>>(        \
+                (const C2<F> *) in, (C2<F> *) out, rg, (int) nrows, (int) ngroups, p->d_twiddle);       \
+        }                                                                                               \
     }
 #define CALL_ROW(PL) if (pen) CALL_ROW_P(PL, true) else CALL_ROW_P(PL, false)
     ROWFFT_DISPATCH(g.N / 2, CALL_ROW)
@@ -213,10 +274,20 @@ static int rowfft_c2r_launch(fpmhip_plan *p, const void *in_, void *out_, int x0
     void *out = (char *) out_ + (size_t) x0 * g.yplanes * g.rp * sizeof(C2<F>);
 #define CALL_ROWB_P(PL, PEN_)                                                                            \
     {                                                                                                    \
-        using CF = RowCfg<PL, F>;                                                                        \
-        FPM_TRY(set_lds(rowfft_c2r_kernel<PL, PEN_, F>, CF::lds));                                       \
-        rowfft_c2r_kernel<PL, PEN_, F><<<(unsigned) ((nrows + CF::RW - 1) / CF::RW), CF::threads, CF::lds, p->stream>>>( \
-            (const C2<F> *) in, (C2<F> *) out, rg, (int) nrows, p->d_twiddle);                           \
+        using CF = RowCfg<PL, F, true>;                                                                        \
+        const unsigned ngroups = (unsigned) ((nrows + CF::RW - 1) / CF::RW);                             \
+        static int occ = 0;                                                                              \
+        bool pers = false;                                                                               \
+        FPM_TRY(set_lds(rowfft_c2r_kernel<PL, PEN_, F, true>, CF::lds));                                 \
+        const unsigned grid = row_grid(rowfft_c2r_kernel<PL, PEN_, F, true>, CF::threads, CF::lds, ngroups, &pers, &occ); \
+        if (pers) {                                                                                      \
+            rowfft_c2r_kernel<PL, PEN_, F, true><<<grid, CF::threads, CF::lds, p->stream>>>(             \
+                (const C2<F> *) in, (C2<F> *) out, rg, (int) nrows, (int) ngroups, p->d_twiddle);        \
+        } else {                                                                                         \
+            FPM_TRY(set_lds(rowfft_c2r_kernel<PL, PEN_, F, false>, CF::lds));                            \
+            rowfft_c2r_kernel<PL, PEN_, F, false><<<ngroups, CF::threads, CF::lds, p->stream>>>(         \
+                (const C2<F> *) in, (C2<F> *) out, rg, (int) nrows, (int) ngroups, p->d_twiddle);        \
+        }                                                                                                \
     }
 #define CALL_ROWB(PL) if (pen) CALL_ROWB_P(PL, true) else CALL_ROWB_P(PL, false)
     ROWFFT_DISPATCH(g.N / 2, CALL_ROWB)
