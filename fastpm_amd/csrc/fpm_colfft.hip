@@ -142,6 +142,7 @@ constexpr int fused_min_waves(int threads, int E, int esize = 8)
 // FPMHIP_COL_PERSIST "0 1"): plain pass 4.9 -> 4.6 ms (fp64), 2.78 -> 2.6 (fp32), colfft_yback2 9.2 -> 8.8; at N = 3072
 // (split exchange, 12-wave workgroups) the same loop LOSES (10.7 -> 13.2 ms, 23.3 -> 29.2) and is not used; so it does
 // where two workgroups share a CU (N = 512 fp64: plain pass 0.43 -> 0.46 ms, y pass 0.72 -> 0.73; N = 1024: 3.5 -> 4.2, 6.3 -> 8.5).
+// (N = 1024 with HALF a twiddle table, so that the row bases fit beside two workgroups' tiles: plain pass 3.49 -> 4.0 ms, y pass 6.1 -> 6.9.)
 // colfft_xback3_kernel in the same form loses too (2048^3 fp64 per rank 11.1 -> 12.8 ms, 1024^3 on one GPU 9.6 -> 10.4): not kept.
 template <typename PL, int S, typename F, bool PERS>
 __global__ __launch_bounds__((ColCfg<PL, F>::threads)) void colfft_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ out,
