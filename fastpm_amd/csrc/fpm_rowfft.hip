@@ -16,7 +16,8 @@ namespace fpm {
 // ms per rank; the forward pass loses with two, 4.03 -> 4.26, and so do both at M = 1536)
 template <typename F> constexpr int row_width(int M, bool c2r)
 {
-    return sizeof(F) == 8 ? (M >= 512 ? (c2r && M == 1024 ? 2 : 4) : 8) : (M > 1024 ? 4 : 8);
+    // (fp32, M = 1536: the forward pass with two rows per group, three workgroups per CU: 7.6 -> 6.8 ms per rank; backward: no change)
+    return sizeof(F) == 8 ? (M >= 512 ? (c2r && M == 1024 ? 2 : 4) : 8) : (M > 1024 ? (c2r ? 4 : 2) : 8);
 }
 
 template <typename PL, typename F, bool C2R> struct RowCfg {
