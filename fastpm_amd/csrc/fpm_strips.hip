@@ -408,7 +408,8 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
 // next plane's entries after it -- neither set of registers is held across the transform, the kernel fits 128 VGPRs
 // without spills (166 otherwise), and with that budget it runs 14.3 -> 13.0 ms at 1024^3 fp64 although the 58 KB of LDS
 // still admit only two workgroups per CU (a third one, with the M-th roots read out of the z pass' table: 13.8 ms).  At
-// M = 256 the same order loses (1.20 -> 1.28 ms at 512^3): the prefetch matters more where the transform is short.
+// M = 256 the same order loses in fp64 (1.18 -> 1.26 ms at 512^3: the prefetch matters more where the transform is short)
+// and wins in fp32 (0.816 -> 0.783 ms), where it is on as well.  (With 8-row strips, five-wave workgroups: 1.56 ms.)
 template <typename PL, typename F, bool WS, bool LATE = false>
 __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FPM_RO_MINW) : 3)) void readout_march_kernel(
     MeshGeo g, int ncomp, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
@@ -677,11 +678,11 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
             readout_strips_kernel<PL, F, WS_><<<ncomp * g.nty * nseg, CF::ro_threads, CF::ro_lds, p->stream>>>(        \
                 g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                 \
                 (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->scell);                    \
-        } else if (WS_ && PL::N >= 512 && late) {                                                                      \
-            FPM_TRY(grant_lds(readout_march_kernel<PL, F, WS_, (WS_ && PL::N >= 512)>, CF::ro1_lds, p->device));       \
-            g.xseg = choose_xseg(g, readout_march_kernel<PL, F, WS_, (WS_ && PL::N >= 512)>, CF::ro_threads, CF::ro1_lds, ncomp * g.nty, 16, 128, &occ0); \
+        } else if (WS_ && (PL::N >= 512 || (PL::N == 256 && sizeof(F) == 4)) && late) {                                                                      \
+            FPM_TRY(grant_lds(readout_march_kernel<PL, F, WS_, (WS_ && (PL::N >= 512 || (PL::N == 256 && sizeof(F) == 4)))>, CF::ro1_lds, p->device));       \
+            g.xseg = choose_xseg(g, readout_march_kernel<PL, F, WS_, (WS_ && (PL::N >= 512 || (PL::N == 256 && sizeof(F) == 4)))>, CF::ro_threads, CF::ro1_lds, ncomp * g.nty, 16, 128, &occ0); \
             const int nseg = (g.xl + g.xseg - 1) / g.xseg;                                                             \
-            readout_march_kernel<PL, F, WS_, (WS_ && PL::N >= 512)><<<ncomp * g.nty * nseg, CF::ro_threads, CF::ro1_lds, p->stream>>>( \
+            readout_march_kernel<PL, F, WS_, (WS_ && (PL::N >= 512 || (PL::N == 256 && sizeof(F) == 4)))><<<ncomp * g.nty * nseg, CF::ro_threads, CF::ro1_lds, p->stream>>>( \
                 g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                 \
                 (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride,      \
                 p->scell);                                                                                             \
