@@ -188,7 +188,7 @@ def test_one_particle_and_no_particles_on_strips(oracle):
     pm.destroy()
 
 
-@pytest.mark.parametrize("N,precision", [(384, 64), (512, 64), (640, 32), (768, 32), (800, 32), (1024, 32),
+@pytest.mark.parametrize("N,precision", [(384, 64), (512, 64), (512, 32), (640, 32), (768, 32), (800, 32), (1024, 32),
                                          (640, 64), (768, 64), (800, 64), (1024, 64), (1536, 32), (2048, 32)])
 def test_largest_strip_meshes_agree_with_box_tiles(N, precision):
     """Every row length the strip kernels take (two-plane readout window: N <= 512 in fp64, <= 1024 in fp32; the one-plane
