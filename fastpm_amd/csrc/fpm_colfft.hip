@@ -135,7 +135,7 @@ constexpr int fused_min_waves(int threads, int E, int esize = 8)
 // One tile per workgroup (61 VGPRs, 2 workgroups/CU at N = 512): measured 0.47 ms per 2.16 GB
 // pass = the speed of a contiguous device copy of the same bytes (tools/ubench/wr_pattern.hip).
 // A persistent variant with register prefetch of the next tile needed 178 VGPRs and ran slower.
-// PERS (where ONE workgroup owns a CU and the exchange is not split: N = 2048, and N = 1024 / 1536 in fp64 with 8 columns):
+// PERS (where ONE workgroup owns a CU and the exchange is not split: N = 1536 in fp64 and N = 2048):
 // the workgroup walks tiles -- the stores of a tile drain while the loads of the next are in flight, the twiddles are
 // staged once and no workgroup launch sits between two tiles.  The row bases then come from LDS (64 values behind the
 // exchange area): as loop invariants in 128 SGPRs they spilled.  Measured per rank at 2048^3 (tools/env_sweep.sh
