@@ -407,7 +407,8 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
 // LATE (the long rows, M >= 512): a plane's rows are requested right before their transform instead of a step ahead, and the
 // next plane's entries after it -- neither set of registers is held across the transform, the kernel fits 128 VGPRs
 // without spills (166 otherwise), and with that budget it runs 14.3 -> 13.0 ms at 1024^3 fp64 although the 58 KB of LDS
-// still admit only two workgroups per CU (a third one, with the M-th roots read out of the z pass' table: 13.8 ms).  At
+// still admit only two workgroups per CU (a third one, with the M-th roots read out of the z pass' table: 13.8 ms; with half
+// a table of them and rows 5 (mod 16) apart, 53.6 KB: 13.0, no change).  At
 // M = 256 the same order loses in fp64 (1.18 -> 1.26 ms at 512^3: the prefetch matters more where the transform is short)
 // and wins in fp32 (0.816 -> 0.783 ms), where it is on as well.  (With 8-row strips, five-wave workgroups: 1.56 ms.)
 template <typename PL, typename F, bool WS, bool LATE = false>
