@@ -218,7 +218,8 @@ def cpu_baseline(ncores, x_dev, Nmesh, BoxSize, acc_dev, pm):
         base["ranks_x_1thread"] = legs
         base["ranks_x_1thread_note"] = ("P processes x 1 OpenMP thread on x slabs with particle ghosts, as the reference's "
                                         "tests launch it (OMP_NUM_THREADS=1, mpirun -n 4); the DFT on P pocketfft threads "
-                                        "without PFFT's MPI transposes; `value` above is the 1 process x T threads leg")
+                                        "without PFFT's MPI transposes, so this leg is a LOWER BOUND on the reference's time "
+                                        "(an upper bound on its rate); `value` above is the 1 process x T threads leg")
     except Exception as e:
         base["ranks_x_1thread"] = {"error": repr(e)}
     parity = {"sample": "GPU vs CPU oracle on the full workload's particles",
@@ -242,6 +243,100 @@ def cpu_baseline(ncores, x_dev, Nmesh, BoxSize, acc_dev, pm):
     return base, parity
 
 
+def resident_dropin_leg(xh, Nmesh, BoxSize, precision, np_total, nsteps=6):
+    """K D D (wrap) F [de-CIC + P(k)] K steps of a C host whose store columns are HOST memory, through the resident
+    twins (fastpm_amd/host/fastpm_resident_hip.c): per-call host clocks and the bytes that crossed PCIe."""
+    import ctypes
+    from fastpm_amd import chost
+    H = chost.host_library()
+    pmv = H.fastpm_create_pm_hip(Nmesh, BoxSize, precision)
+    rng = np.random.default_rng(3)
+    st = chost.HostStore(xh, v=(rng.standard_normal(xh.shape) * 1e-3).astype(np.float32), a_x=0.1, a_v=0.1)
+    sv = chost.solver_view(st)
+    painter = chost.PainterView(0, 2)
+    lay_bytes = (Nmesh * Nmesh * (Nmesh + 2)) * (precision // 8)
+    dk = np.zeros(lay_bytes // 8, dtype=np.float64)                 # pm->allocsize FastPMFloat, host
+    t = np.linspace(0.0, 1e-3, 32)
+    kv = chost.kick_factor_view(0, 0.1, 0.5, 1.0, t, t, t)
+    dv = chost.drift_factor_view(0, 0.1, 0.5, 1.0, t * 10, t, t)
+    box = (ctypes.c_double * 3)(BoxSize, BoxSize, BoxSize)
+    force = lambda: H.fastpm_solver_compute_force_resident_hip(ctypes.byref(sv), pmv, ctypes.byref(painter), 0, 3, dk.ctypes.data, 1.0)
+    H.fastpm_hip_mirror_reset_stats()
+    t0 = time.perf_counter()
+    force()                                                         # x goes up here, once
+    first = time.perf_counter() - t0
+    a, da = 0.1, 0.9 / (nsteps + 1)
+    tf, ts, tk = [], [], []
+    up0 = chost.mirror_stats().h2d_bytes
+    for i in range(nsteps + 1):
+        s0 = time.perf_counter()
+        H.fastpm_kick_store_resident_hip(pmv, ctypes.byref(kv), ctypes.byref(st.view), ctypes.byref(st.view), a + da / 2)
+        H.fastpm_drift_store_resident_hip(pmv, ctypes.byref(dv), ctypes.byref(st.view), ctypes.byref(st.view), a + da / 2)
+        H.fastpm_drift_store_resident_hip(pmv, ctypes.byref(dv), ctypes.byref(st.view), ctypes.byref(st.view), a + da)
+        H.fastpm_store_wrap_resident_hip(pmv, ctypes.byref(st.view), box)
+        f0 = time.perf_counter()
+        force()
+        f1 = time.perf_counter()
+        H.fastpm_apply_decic_transfer_resident_hip(pmv, dk.ctypes.data, dk.ctypes.data)
+        ps = chost.PowerSpectrumView()
+        H.fastpm_powerspectrum_init_from_delta_resident_hip(ctypes.byref(ps), pmv, dk.ctypes.data, dk.ctypes.data)
+        H.fastpm_powerspectrum_destroy_hip(ctypes.byref(ps))
+        k1 = time.perf_counter()
+        H.fastpm_kick_store_resident_hip(pmv, ctypes.byref(kv), ctypes.byref(st.view), ctypes.byref(st.view), a + da)
+        torch.cuda.synchronize()
+        s1 = time.perf_counter()
+        if i > 0:                                                   # the first step uploads v
+            tf.append(f1 - f0); ts.append(s1 - s0); tk.append(k1 - f1)
+        if i == 0:
+            up1 = chost.mirror_stats().h2d_bytes
+        a += da
+    stats = chost.mirror_stats()
+    st.sync("acc")
+    finite = bool(np.isfinite(st.acc).all())
+    st.release()
+    H.fastpm_hip_mirror_release(dk.ctypes.data)
+    H.fastpm_free_pm_hip(pmv)
+    fm, sm = float(np.mean(tf)), float(np.mean(ts))
+    return {"entry": "fastpm_solver_compute_force_resident_hip (+ kick / drift / wrap / de-CIC / P(k) twins)",
+            "force_ms_per_call": round(fm * 1e3, 3), "value": np_total / fm, "unit": "particle-updates/s",
+            "kddfk_step_ms": round(sm * 1e3, 3), "decic_pk_ms": round(float(np.mean(tk)) * 1e3, 3),
+            "steps_timed": len(tf), "first_force_ms_with_upload": round(first * 1e3, 3),
+            "pcie_bytes": {"first_force_up": int(up0), "first_step_up": int(up1 - up0),
+                           "later_steps_up": int(stats.h2d_bytes - up1), "all_steps_down": int(stats.d2h_bytes)},
+            "finite": finite,
+            "note": "store columns in host memory, device twins behind them: x up once, v up once, then no particle "
+                    "column and no delta_k crosses PCIe; the call waits for the GPU and checks device-side errors"}
+
+
+def device_identity(dev_index):
+    """PCI address + name of the HIP device this rank computes on (one string per rank in `comm.devices`)."""
+    p = torch.cuda.get_device_properties(dev_index)
+    dom, bus, devid = (getattr(p, a, None) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    pci = "%04x:%02x:%02x.0" % (dom, bus, devid) if None not in (dom, bus, devid) else "pci-unknown"
+    uuid = str(getattr(p, "uuid", "")) or "uuid-unknown"
+    return "%s|%s|%s|%s" % (os.uname().nodename, pci, uuid, p.name)
+
+
+def comm_identity(world, rank, backend, dev_index, dist):
+    """{backend, world_size, devices, distinct_devices, rccl_version, measured}: gathered over the job's own process group."""
+    mine = device_identity(dev_index)
+    devices = [mine]
+    if world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, mine)
+    try:
+        v = torch.cuda.nccl.version()
+        rccl = ".".join(str(i) for i in v) if isinstance(v, tuple) else str(v)
+    except Exception as e:
+        rccl = "unknown (%r)" % (e,)
+    shared = bool(os.environ.get("FPM_BENCH_SHARE_GPU"))
+    distinct = len(set(devices))
+    measured = world == 1 or (backend == "nccl" and not shared and distinct == world)
+    return {"backend": ("nccl (RCCL)" if backend == "nccl" else backend) if world > 1 else "none (one rank)",
+            "world_size": world, "devices": devices, "distinct_devices": distinct, "rccl_version": rccl,
+            "share_gpu_dry_run": shared, "measured": measured}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -257,10 +352,11 @@ def main():
     ap.add_argument("--gradient", default="kspace", choices=["kspace", "real"],
                     help="kspace (default): the reference's arithmetic, 3 inverse FFTs; real: FPMHIP_GRADIENT_REAL, "
                          "1 inverse FFT of the potential + stencil readout (acc within 2e-7 max|acc| of kspace)")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra leg that times the other gradient mode")
+    ap.add_argument("--no-alt", action="store_true", help="(accepted for old command lines; the extra leg is off by default)")
     ap.add_argument("--alt", action="store_true",
-                    help="run that extra leg on N > 1 GPUs too (off by default there: a second collective phase after "
-                         "the measured one must never be what a scaling run hangs or times out in)")
+                    help="also time the OTHER gradient mode (FPMHIP_GRADIENT_REAL: not the reference's arithmetic, outside "
+                         "SURVEY section 8) after the measured run and report it beside the headline number; off by default "
+                         "for every N")
     ap.add_argument("--nprocy", type=int, default=1,
                     help="N > 1 GPUs: process mesh (gpus / nprocy) x nprocy; 1 = x slabs (default), 2 on 8 GPUs = the "
                          "reference's default 4 x 2 pencils (pmpfft.c:117-136)")
@@ -295,6 +391,10 @@ def main():
             dist.init_process_group(backend)
 
     from fastpm_amd import PM, Store
+
+    # who took part: every rank's device identity, gathered once, so that a multi-GPU line can be audited from its JSON
+    # alone ("did RCCL see N ranks on N distinct GPUs").  A line from the dry-run mode above carries no `value`.
+    comm = comm_identity(world, rank, backend, dev_index, dist)
 
     nc, Nmesh = WORKLOADS.get(world, (None, None))
     if args.nc:
@@ -387,7 +487,7 @@ def main():
     # extra leg, outside the timed region above and reported beside it: the same workload in the OTHER
     # gradient mode (same W and K, same bracket), and how far its accelerations are from the main run's
     alt = None
-    if not args.no_alt and (world == 1 or args.alt):
+    if args.alt and not args.no_alt:
         try:
             other = "real" if args.gradient == "kspace" else "kspace"
             pm2, store2, dt2, tm2 = timed_run(other)
@@ -425,9 +525,17 @@ def main():
                                          "value": np_total / th, "unit": "particle-updates/s",
                                          "bytes_over_pcie_per_call": 36 * np_total,
                                          "note": "x (24 B/particle) host->device, acc (12 B/particle) device->host inside the call"}
-            del xh, acch
+            del acch
+            # ... and the RESIDENT drop-in: the same host-memory store columns, but every
+            # function either side of the force replaced as well (fastpm_kick_store / fastpm_drift_store /
+            # fastpm_store_wrap / de-CIC / P(k): the view-struct twins of factors_hip.c, store_hip.c, transfer_hip.c in
+            # libfastpm_hip_host.so), so the columns live in device twins and a K D D F K step moves no particle column
+            # over PCIe.  `force_ms_per_call` is the call the metric counts, host clock around the C function (it
+            # waits for the step and asks for device-side errors before it returns).
+            secondary["host_columns"]["resident_dropin"] = resident_dropin_leg(xh, Nmesh, BoxSize, args.precision, np_total)
+            del xh
         except Exception as e:
-            secondary["host_columns"] = {"error": repr(e)}
+            secondary.setdefault("host_columns", {})["error"] = repr(e)
         try:
             nc2, N2 = 512, 1024
             if (nc, Nmesh) != (nc2, N2) and torch.cuda.mem_get_info()[0] > 60e9:
@@ -499,6 +607,8 @@ def main():
         roofline = {"kernel": KERNELS[dom], "timer": dom, "launches_per_step": tm[dom][1] / args.steps,
                     "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, Nmesh, np_total, args, world),
+                    "traffic_source": "profiles/%s_%s_traffic.json: a committed rocprofv3 --pmc pass of this same command "
+                                      "(tools/profile_round.sh), NOT measured in this run" % (PMC_PROFILE_TAG, args.gradient),
                     "alg_bytes_per_launch": ab[dom], "avg_launch_ms": round(avg_s * 1e3, 4)}
         # every kernel of the step against the roofline, per launch (the dominant one above is the best-placed of
         # them: it sums three launches); min_kernel = the lowest fraction, with its PMC traffic ratio
@@ -563,6 +673,16 @@ def main():
         roofline["step_frac"] = round(b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         roofline["step_alg_bytes"] = b_alg
         out["exposed_comm_ms_per_step"] = round(ms_per_step - out["kernel_ms_per_step"], 3) if world > 1 else 0.0
+        out["comm"] = comm
+        if not comm["measured"]:
+            # ranks sharing a GPU and / or exchanges staged through the host over gloo: a dry run of the code path.  Such
+            # a line must never be read as a measurement: it carries no value, only what the dry run took
+            out["dry_run"] = {"ms_per_step": out["ms_per_step"], "would_be_value": out["value"],
+                              "why": "FPM_BENCH_SHARE_GPU / backend %s / %d distinct devices for %d ranks: not a measurement"
+                                     % (backend, comm["distinct_devices"], world)}
+            out["value"] = None
+            out["per_gpu"] = None
+            out["roofline"]["frac"] = None
         if alt is not None:
             out["other_gradient_mode"] = alt
         if secondary:

@@ -665,6 +665,14 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
             xm.jb[j] = (tj / xm.xl) * xm.kchunk + (tj % xm.xl) * xm.rs;                                      \
         }                                                                                                    \
         const int ntiles = xm.tpb * (blocked ? g.yl / g.kyb : 1);                                            \
+        /* the kernel folds a thread's row, batch and column into ONE 32-bit offset (like make_rowmap's nest test) */  \
+        {                                                                                                    \
+            const long long last = (long long) PL::T - 1;                                                      \
+            const long long omax = (last / xm.xl) * xm.kchunk + (last % xm.xl) * xm.rs                        \
+                                   + (blocked ? (long long) (g.yl / g.kyb - 1) * xm.bstride : 0) + xm.ncols; \
+            if (omax >= (1LL << 32))                                                                         \
+                FPM_FAIL(-1, "fused x pass: a k-space block of %lld complex values does not fit the kernel's 32-bit element offsets (use more ranks)", omax); \
+        }                                                                                                    \
         FPM_TRY(set_lds(colfft_xback3_kernel<PL, P, Q, F>, CF::lds));                                        \
         colfft_xback3_kernel<PL, P, Q, F><<<ntiles, CF::threads, CF::lds, p->stream>>>(                      \
             (const C2<F> *) dk, (C2<F> *) o0, (C2<F> *) o1, (C2<F> *) o2, xm, g.nzl,                         \

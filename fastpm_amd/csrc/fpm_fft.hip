@@ -304,6 +304,11 @@ static int check_range(const fpmhip_plan *p, int x0, int nx)
 {
     if (!p->own_fft || !rowfft_supported(p->mg.N)) FPM_FAIL(-1, "ranged stage calls need the column-FFT back end (see fpmhip_plan_ranged_fft)");
     if (x0 < 0 || nx < 1 || x0 + nx > p->mg.xl) FPM_FAIL(-1, "plane range [%d, %d) outside the slab of %d planes", x0, x0 + nx, p->mg.xl);
+    // k-space blocks (fpmhip_layout.okblock != osize[1]): the planes [x0, x0 + nx) of an exchange chunk
+    // [ky_loc / kb][x_loc][kb][kz] are ky_loc / kb separate pieces, not the one contiguous block a ranged exchange
+    // sends -- a partial range would put the wrong bytes on the wire.  Whole-slab calls stay valid.
+    if (p->mg.kyb != p->mg.yl && (x0 != 0 || nx != p->mg.xl))
+        FPM_FAIL(-1, "plane ranges are not offered on the blocked k-space layout (okblock %d of %d ky rows): exchange whole slabs (fpmhip_plan_ranged_fft returns 0)", p->mg.kyb, p->mg.yl);
     return 0;
 }
 
@@ -315,7 +320,9 @@ extern "C" {
 
 int fpmhip_plan_ranged_fft(const fpmhip_plan *p)
 {
-    return p && p->own_fft && rowfft_supported(p->mg.N) ? 1 : 0;
+    // 0 on the blocked k-space layout (fpmhip_layout.okblock != osize[1], chosen for Nmesh >= 1536 on several x ranks): a
+    // plane range of an exchange chunk is not contiguous there (check_range above)
+    return p && p->own_fft && rowfft_supported(p->mg.N) && p->mg.kyb == p->mg.yl ? 1 : 0;
 }
 
 // The (y, z) halves of the slab transforms for the x planes [x0, x0 + nx) only, so that the all-to-all of one

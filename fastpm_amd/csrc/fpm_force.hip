@@ -67,9 +67,15 @@ int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets
     if (strips_fwd) {
         if (sets[0].np > 0 && !sets[0].x) FPM_FAIL(-1, "particles without positions");
         FPM_TRY(paint_strips(p, pt, 1.0 / mean_mass_per_cell, delta_k, 0, true));
-    } else {
+    } else if (nsets == 1) {
         FPM_TRY(fpmhip_paint(p, pt, 1.0 / mean_mass_per_cell, canvas));                   // gravity.c:336-345
-        for (int si = 1; si < nsets; si++) FPM_TRY(fpmhip_paint_add(p, &sets[si], 1.0 / mean_mass_per_cell, canvas));
+    } else {
+        // several species: every species' sums go into the canvas unscaled and the canvas is scaled ONCE, the
+        // reference's arithmetic (gravity.c:326-338 paint, :342-345 one fastpm_apply_multiply_transfer) -- one rounding
+        // of the mesh dtype per species add and one for the scale, not two per species
+        FPM_TRY(fpmhip_paint(p, pt, 1.0, canvas));
+        for (int si = 1; si < nsets; si++) FPM_TRY(fpmhip_paint_add(p, &sets[si], 1.0, canvas));
+        FPM_TRY(fpmhip_mesh_scale(p, canvas, 1.0 / mean_mass_per_cell));
     }
     FPM_TRY(fpmhip_check_point(p, strips_fwd ? delta_k : canvas, "After painting"));          // gravity.c:350
     // x passes around the transfer: from the canvas (z, y passes first) or from the paint's half-spectrum rows

@@ -571,6 +571,10 @@ __global__ __launch_bounds__(256) void verify_binning_kernel(MeshGeo g, int ntil
         Cic c;
         (void) cic_setup(g, want[0], want[1], want[2], c);
         want[0] = c.d[0]; want[1] = c.d[1]; want[2] = c.d[2];
+        // ... and the base cell: a shift by whole cells (a periodic re-wrap, a translation by n cells) leaves every D
+        // bit-identical; the entry's packed (iy, iz) and the x plane / strip of the tile it sits in must still be the
+        // particle's (own tile t = ix * nty + iy / STRIP_Y)
+        if (scell[e].y != strip_cell(c) || t != c.i0[0] * g.nty + c.i0[1] / STRIP_Y) flags[FLAG_STALE] = 1;
     }
     if (sx[e] != want[0] || sy[e] != want[1] || sz[e] != want[2]) flags[FLAG_STALE] = 1;
 }

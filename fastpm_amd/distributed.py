@@ -78,12 +78,30 @@ class _SlabRank:
 
     late_check = True
 
-    def _late_agreement(self):
+    def _late_agreement(self, err=None):
         """What only the device knows about a steady-state step's binning (a particle outside the rank's region, a slab
         overflow) is reported after the paint's agreement point: synchronise, ask, and agree once more at the end of the
-        step -- no rank leaves with an invalid acc while its peers carry on into the next collective."""
+        step -- no rank leaves with an invalid acc while its peers carry on into the next collective.  `err`: what this
+        rank's sequence raised, if anything -- the all-reduce is entered all the same (a failure that was agreed on
+        earlier was raised on every rank; a rank-local one after the paint must not leave the peers waiting here)."""
         if self.late_check and self.P > 1:
-            self.run(self._agreed(getattr(self.pm, "sync", lambda: None)))
+            def action():
+                if err is not None:
+                    raise err
+                getattr(self.pm, "sync", lambda: None)()
+            self.run(self._agreed(action))
+        elif err is not None:
+            raise err
+
+    def _run_step(self, gen):
+        """One force step: the sequence, then the end-of-step agreement on every rank whether or not the sequence
+        failed here."""
+        err = None
+        try:
+            self.run(gen)
+        except Exception as e:                      # noqa: BLE001 -- re-raised by the agreement below
+            err = e
+        self._late_agreement(err)
 
     def _communicate(self, req):
         kind = req[0]
@@ -439,8 +457,7 @@ class SlabForce(_SlabRank):
 
     # -- execution over torch.distributed -------------------------------------------------------
     def compute_force(self, store, kernel="1_4", dealias="none", delta_k=None):
-        self.run(self.steps(store, kernel, dealias, delta_k))
-        self._late_agreement()
+        self._run_step(self.steps(store, kernel, dealias, delta_k))
         return delta_k if delta_k is not None else self.delta_k
 
 
@@ -625,8 +642,7 @@ class PencilForce(_PencilRank):
             pm.readout(meshes[3], store, store.potential, 1, 0)
 
     def compute_force(self, store, kernel="1_4", dealias="none", delta_k=None):
-        self.run(self.steps(store, kernel, dealias, delta_k))
-        self._late_agreement()
+        self._run_step(self.steps(store, kernel, dealias, delta_k))
         return delta_k if delta_k is not None else self.delta_k
 
 

@@ -4,6 +4,7 @@
 #include <math.h>
 
 #include "fastpm_factors_hip.h"
+#include "fastpm_resident_hip.h"
 
 void fpm_raise_hip(int code, const char *fmt, ...);            /* fastpm_gravity_hip.c */
 
@@ -11,8 +12,8 @@ void fpm_raise_hip(int code, const char *fmt, ...);            /* fastpm_gravity
 
 /* One lookup for three tables sampled uniformly on [ai, af]: the end points exactly, linear in between
  * (factors.c:38-69 and :112-134 are this with different member names). */
-static int lookup3(double ai, double af_, int nsamples, const double *t0, const double *t1, const double *t2, double a,
-                   double out[3])
+int fastpm_hip_lookup3(double ai, double af_, int nsamples, const double *t0, const double *t1, const double *t2, double a,
+                       double out[3])
 {
     if (a == af_) { out[0] = t0[nsamples - 1]; out[1] = t1[nsamples - 1]; out[2] = t2[nsamples - 1]; return 0; }
     if (a == ai) { out[0] = t0[0]; out[1] = t1[0]; out[2] = t2[0]; return 0; }
@@ -29,8 +30,8 @@ static int lookup3(double ai, double af_, int nsamples, const double *t0, const 
 static int kick_scalars(FastPMKickFactorView *kick, double a_from, double a_to, fpmhip_kick_factor *k)
 {
     double f[3], i[3];
-    if (lookup3(kick->ai, kick->af, kick->nsamples, kick->dda, kick->Dv1, kick->Dv2, a_to, f) ||
-        lookup3(kick->ai, kick->af, kick->nsamples, kick->dda, kick->Dv1, kick->Dv2, a_from, i)) {
+    if (fastpm_hip_lookup3(kick->ai, kick->af, kick->nsamples, kick->dda, kick->Dv1, kick->Dv2, a_to, f) ||
+        fastpm_hip_lookup3(kick->ai, kick->af, kick->nsamples, kick->dda, kick->Dv1, kick->Dv2, a_from, i)) {
         fpm_raise_hip(-1, "kick beyond factor's available range. ");       /* factors.c:128 */
         return -1;
     }
@@ -47,8 +48,8 @@ static int kick_scalars(FastPMKickFactorView *kick, double a_from, double a_to, 
 static int drift_scalars(FastPMDriftFactorView *drift, double a_from, double a_to, fpmhip_drift_factor *d)
 {
     double f[3], i[3];
-    if (lookup3(drift->ai, drift->af, drift->nsamples, drift->dyyy, drift->da1, drift->da2, a_to, f) ||
-        lookup3(drift->ai, drift->af, drift->nsamples, drift->dyyy, drift->da1, drift->da2, a_from, i)) {
+    if (fastpm_hip_lookup3(drift->ai, drift->af, drift->nsamples, drift->dyyy, drift->da1, drift->da2, a_to, f) ||
+        fastpm_hip_lookup3(drift->ai, drift->af, drift->nsamples, drift->dyyy, drift->da1, drift->da2, a_from, i)) {
         fpm_raise_hip(-1, "drift beyond factor's available range. ");      /* factors.c:63 */
         return -1;
     }

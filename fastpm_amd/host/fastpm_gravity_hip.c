@@ -141,8 +141,8 @@ void fastpm_solver_compute_force_hip(FastPMSolverView *fastpm, PMView *pm, FastP
         return;
     }
     {
-        const char *e = getenv("FASTPM_HIP_CHECK_VALUES");      /* gravity.c:350, 352, 381, 383 */
-        if (!e || atoi(e) != 0) fpmhip_set_check_hook(pm->plan, check_line, pm);
+        const char *e = getenv("FASTPM_HIP_CHECK_VALUES");      /* gravity.c:350, 352, 381, 383: opt in (five sweeps) */
+        if (e && atoi(e) != 0) fpmhip_set_check_hook(pm->plan, check_line, pm);
     }
     const int rc = fpmhip_force_species_host(pm->plan, parts, nspecies, (int) kernel, (int) dealias, delta_k);
     fpmhip_set_check_hook(pm->plan, NULL, NULL);

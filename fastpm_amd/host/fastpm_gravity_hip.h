@@ -78,7 +78,7 @@ void fastpm_kernel_type_get_orders_hip(FastPMKernelType type, int *potorder, int
  * species->acc (and ->potential when the CDM store has that column), fills delta_k (host,
  * pm->allocsize FastPMFloat, reference ORegion layout) with delta(k)/N^3 after softening; the log side effects too:
  * per species the lines `p%s    acc[%d]: min std mean max` and `p%s+g  acc[%d]: ...` of gravity.c:402-417 (through
- * the message handler, code 0 = fastpm_info) and, unless FASTPM_HIP_CHECK_VALUES=0, pm_check_values' line
+ * the message handler, code 0 = fastpm_info) and, with FASTPM_HIP_CHECK_VALUES=1, pm_check_values' line
  * `<label>: Task %d has %td field values that are out of bounds` (pmapi.c:335-356) where a mesh holds NaN / overflow. */
 void fastpm_solver_compute_force_hip(FastPMSolverView *fastpm, PMView *pm, FastPMPainterView *painter,
                                      FastPMSofteningType dealias, FastPMKernelType kernel,

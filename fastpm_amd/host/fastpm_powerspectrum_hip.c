@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include "fastpm_powerspectrum_hip.h"
+#include "fastpm_resident_hip.h"
 
 void fpm_raise_hip(int code, const char *fmt, ...);            /* fastpm_gravity_hip.c */
 
@@ -148,6 +149,17 @@ void fastpm_powerspectrum_init_from_delta_hip(FastPMPowerSpectrumView *ps, PMVie
     HIP_OR_RAISE(fpmhip_powerspectrum(pm->plan, d1, d2 ? d2 : d1, ps->base.k, ps->base.f, ps->Nmodes));
     fpmhip_free(d1);
     if (d2) fpmhip_free(d2);
+    ps_finish(ps);
+}
+
+/* the same from the device twins of the meshes (fastpm_resident_hip.h): no copy when the force call or the de-CIC
+ * before it left the mesh on the device */
+void fastpm_powerspectrum_init_from_delta_resident_hip(FastPMPowerSpectrumView *ps, PMView *pm, const void *delta1_k,
+                                                       const void *delta2_k)
+{
+    ps_prepare(ps, pm);
+    const int rc = fastpm_hip_resident_powerspectrum(pm->plan, delta1_k, delta2_k, ps->base.k, ps->base.f, ps->Nmodes);
+    if (rc) fpm_raise_hip(-1, "%s\n", rc == -9 ? fastpm_hip_mirror_error() : fpmhip_last_error());
     ps_finish(ps);
 }
 

@@ -43,8 +43,15 @@ static int paint_species(fpmhip_plan *plan, const fastpm_hip_transport *t, const
     /* A failure here is rank-local (a particle outside this rank's region, an allocation): agree on it before the
      * next collective, or the other ranks wait in an exchange this rank never enters.  The reference raises and
      * MPI_Aborts (logging.c:242-251); every rank returning nonzero lets the binding do the same. */
-    int rc = zr2c ? fpmhip_paint_zr2c(plan, &sets[0], scale, canvas) : fpmhip_paint(plan, &sets[0], scale, canvas);
-    for (int si = 1; si < nsets && !rc; si++) rc = fpmhip_paint_add(plan, &sets[si], scale, canvas);
+    int rc;
+    if (nsets == 1) {
+        rc = zr2c ? fpmhip_paint_zr2c(plan, &sets[0], scale, canvas) : fpmhip_paint(plan, &sets[0], scale, canvas);
+    } else {
+        /* several species: unscaled sums into the canvas, ONE scaling pass (gravity.c:326-345), halo plane included */
+        rc = zr2c ? -1 : fpmhip_paint(plan, &sets[0], 1.0, canvas);
+        for (int si = 1; si < nsets && !rc; si++) rc = fpmhip_paint_add(plan, &sets[si], 1.0, canvas);
+        if (!rc) rc = fpmhip_mesh_scale(plan, canvas, scale);
+    }
     double failed = rc != 0;
     TRY(t->allreduce_sum(t->ctx, &failed));
     if (failed != 0) return rc ? rc : -8;            /* -8: another rank failed in the paint */
@@ -375,14 +382,16 @@ int fastpm_hip_mesh_force_species(fpmhip_plan *plan, const fastpm_hip_transport 
     if (lay.nranks != t->nranks || lay.rank != t->rank) return -1;
     int rc = lay.nranks_y > 1 ? pencil_force_species(plan, t, &lay, sets, nsets, kernel, softening, delta_k)
                               : slab_force_species(plan, t, sets, nsets, kernel, softening, delta_k);
-    if (lay.nranks > 1 && rc == 0) {
+    if (lay.nranks > 1) {
         /* What only the device knows about this step's binning (a particle outside the rank's region on a steady-state
          * step, a slab overflow) arrives after the paint's agreement point: ask for it now and agree again, so that no
-         * rank leaves with rc = 0 and an invalid acc while its peers carry on into the next collective.  (A nonzero rc
-         * here was agreed on in the paint: every rank has one.) */
-        const int late = fpmhip_sync(plan);
-        double failed = late != 0;
-        if (t->allreduce_sum(t->ctx, &failed) != 0 || failed != 0) rc = late ? late : -8;
+         * rank leaves with rc = 0 and an invalid acc while its peers carry on into the next collective.  EVERY rank
+         * enters this all-reduce, whatever its rc: a failure agreed on in the paint left every rank with one, and a
+         * rank-local failure after it (an allocation, a kernel launch, a transport error) must not leave the peers
+         * waiting here for a rank that returned early. */
+        const int late = rc == 0 ? fpmhip_sync(plan) : 0;
+        double failed = rc != 0 || late != 0;
+        if (t->allreduce_sum(t->ctx, &failed) != 0 || failed != 0) rc = rc ? rc : (late ? late : -8);
     }
     return rc;
 }

@@ -12,6 +12,7 @@
  * a test here.  The same logic against view structs, compiled, linked and run on the GPU, is
  * fastpm_gravity_hip.c / fastpm_slab_hip.c (tests/test_gpu_chost.py).
  */
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #include <mpi.h>
@@ -25,6 +26,24 @@
 #include <fastpm_hip.h>
 #include "fastpm_slab_hip.h"
 #include "fastpm_slab_mpi.h"
+#include "fastpm_mirror_hip.h"
+#include "fastpm_hip_binding.h"
+
+/* Defined by factors_hip.c.  When that object is linked in, fastpm_kick_store / fastpm_drift_store run on the device
+ * twins of the store's columns, so this file may leave acc (and x) on the device: the RESIDENT mode.  Without it the
+ * kick runs on the host and acc must be in host memory when this function returns: the host-column entry points. */
+extern const int fastpm_hip_factors_resident __attribute__((weak));
+
+int
+fastpm_hip_resident_enabled(void)
+{
+    static int enabled = -1;
+    if(enabled < 0) {
+        const char * e = getenv("FASTPM_HIP_RESIDENT");          /* 0: host columns in every call, as round 3 */
+        enabled = (&fastpm_hip_factors_resident != NULL) && !(e && atoi(e) == 0);
+    }
+    return enabled;
+}
 
 /* One GPU plan (and, for NTask > 1, one transport on pm->Comm2D) per PM, made at the first force call on that PM.
  * solver.c:100, 112, 132 and vpm.c:22-58 create every PM up front, one per pm_nc_factor entry; fastpm_find_pm hands
@@ -37,13 +56,14 @@ typedef struct PlanCache {
 } PlanCache;
 
 static PlanCache * plans = NULL;
+static PlanCache * current = NULL;      /* the PM of the latest force call: kick / drift / wrap have no PM argument */
 
 static PlanCache *
 plan_for(PM * pm)
 {
     PlanCache * c;
     for(c = plans; c; c = c->next) {
-        if(c->pm == pm) return c;
+        if(c->pm == pm) { current = c; return c; }
     }
     if(pm->Nmesh[0] != pm->Nmesh[1] || pm->Nmesh[0] != pm->Nmesh[2]) {
         fastpm_raise(-1, "the MI355X force step needs a cubic mesh\n");
@@ -113,7 +133,26 @@ plan_for(PM * pm)
     c->pm = pm;
     c->next = plans;
     plans = c;
+    current = c;
     return c;
+}
+
+fpmhip_plan *
+fastpm_hip_plan_for(PM * pm)
+{
+    return plan_for(pm)->plan;
+}
+
+fpmhip_plan *
+fastpm_hip_current_plan(void)
+{
+    return current ? current->plan : NULL;
+}
+
+PM *
+fastpm_hip_current_pm(void)
+{
+    return current ? current->pm : NULL;
 }
 
 void
@@ -190,7 +229,7 @@ fastpm_solver_compute_force(FastPMSolver * fastpm,
     (void) Time;
 
     fpmhip_particles parts[FASTPM_SOLVER_NSPECIES];
-    int nsets = 0, si;
+    int nsets = 0, si, any_pgdc = 0;
     for(si = 0; si < FASTPM_SOLVER_NSPECIES; si ++) {          /* the species loop of gravity.c:279-287 */
         FastPMStore * p = fastpm_solver_get_species(fastpm, si);
         if(!p) continue;
@@ -201,6 +240,7 @@ fastpm_solver_compute_force(FastPMSolver * fastpm,
         parts[nsets].np = (int64_t) p->np;
         parts[nsets].acc = &p->acc[0][0];
         parts[nsets].potential = p->potential;                  /* gravity.c:487-492 */
+        if(p->pgdc) any_pgdc = 1;                               /* fastpm_pgdc_calculate reads delta_k on the host next */
         nsets ++;
     }
     if(nsets == 0) return;
@@ -208,13 +248,46 @@ fastpm_solver_compute_force(FastPMSolver * fastpm,
     PlanCache * c = plan_for(pm);
     fpmhip_set_stage_hook(c->plan, stage_clock, clk);
     {
-        /* gravity.c:350, 352, 381, 383: on unless FASTPM_HIP_CHECK_VALUES=0 (five sweeps + synchronisations per step
-         * where the reference pays nine serial host loops) */
+        /* gravity.c:350, 352, 381, 383.  Off unless FASTPM_HIP_CHECK_VALUES=1: each of the five check points is a sweep of
+         * the mesh and a stream synchronisation that the timed force step does not have (the reference pays nine serial
+         * host loops per step for them) */
         const char * e = getenv("FASTPM_HIP_CHECK_VALUES");
-        if(!e || atoi(e) != 0) fpmhip_set_check_hook(c->plan, check_line, pm);
+        if(e && atoi(e) != 0) fpmhip_set_check_hook(c->plan, check_line, pm);
     }
+    const int resident = fastpm_hip_resident_enabled();
     int rc;
-    if(pm->NTask == 1) {
+    if(resident) {
+        /* every column has a device twin (fastpm_resident_hip.h): x goes up once, acc stays where the kick reads it;
+         * the potential column comes home (an output column); delta_k stays on the device for the de-CIC and the P(k)
+         * of solver.c:471 and src/fastpm.c:1734 (transfer_hip.c) unless FASTPM_HIP_SYNC_DELTA_K=1 */
+        unsigned flags = FASTPM_HIP_SYNC_POTENTIAL;
+        const char * e = getenv("FASTPM_HIP_SYNC_DELTA_K");
+        if((e && atoi(e) != 0) || any_pgdc) flags |= FASTPM_HIP_SYNC_DELTA_K;
+        if(pm->NTask == 1) {
+            rc = fastpm_hip_resident_force(c->plan, parts, nsets, kernel, dealias, delta_k, flags);
+        } else {
+            fpmhip_particles dev[FASTPM_SOLVER_NSPECIES];
+            void * dk = fastpm_hip_kmesh_out(c->plan, delta_k);
+            rc = dk ? 0 : -9;
+            for(si = 0; si < nsets && !rc; si ++) {
+                const size_t np = (size_t) parts[si].np;
+                dev[si] = parts[si];
+                if(np == 0) continue;
+                dev[si].x = fastpm_hip_dev_in(c->plan, parts[si].x, np * 24);
+                dev[si].acc = fastpm_hip_dev_out(c->plan, parts[si].acc, np * 12);
+                if(parts[si].mass) dev[si].mass = fastpm_hip_dev_in(c->plan, parts[si].mass, np * 4);
+                if(parts[si].potential) dev[si].potential = fastpm_hip_dev_out(c->plan, parts[si].potential, np * 4);
+                if(!dev[si].x || !dev[si].acc || (parts[si].mass && !dev[si].mass)
+                        || (parts[si].potential && !dev[si].potential)) rc = -9;
+            }
+            /* slabs or pencils, every species, the exchanges on pm->Comm2D; ends with the agreement on late errors */
+            if(!rc) rc = fastpm_hip_mesh_force_species(c->plan, c->transport, dev, nsets, kernel, dealias, dk);
+            for(si = 0; si < nsets && !rc; si ++) {
+                if(parts[si].potential && parts[si].np > 0) rc = fastpm_hip_host_sync(parts[si].potential);
+            }
+            if(!rc && (flags & FASTPM_HIP_SYNC_DELTA_K)) rc = fastpm_hip_host_sync(delta_k);
+        }
+    } else if(pm->NTask == 1) {
         /* host columns up, acc down, delta_k in the ORegion layout the FORCE/AFTER handlers iterate with PMKIter */
         rc = fpmhip_force_species_host(c->plan, parts, nsets, kernel, dealias, delta_k);
     } else {
@@ -225,7 +298,7 @@ fastpm_solver_compute_force(FastPMSolver * fastpm,
     fpmhip_set_check_hook(c->plan, NULL, NULL);
     if(rc) {
         /* collective failure semantics of the reference: fastpm_raise aborts the communicator (logging.c:242-251) */
-        fastpm_raise(-1, "MI355X force step failed (%d): %s\n", rc, fpmhip_last_error());
+        fastpm_raise(-1, "MI355X force step failed (%d): %s\n", rc, rc == -9 ? fastpm_hip_mirror_error() : fpmhip_last_error());
     }
 
     /* The log lines of gravity.c:398-417, from the acc columns the step just filled.  The reference prints three blocks
@@ -238,7 +311,27 @@ fastpm_solver_compute_force(FastPMSolver * fastpm,
         if(!p) continue;
         double acc_std[3], acc_mean[3], acc_min[3], acc_max[3];
         int d;
-        fastpm_store_summary(p, COLUMN_ACC, pm_comm(pm), "<s->", acc_min, acc_std, acc_mean, acc_max);
+        if(resident) {
+            /* fastpm_store_summary (store.c:807-908) with its particle loop on the device twin of acc */
+            double rmin[3] = {1e20, 1e20, 1e20}, rmax[3] = {-1e20, -1e20, -1e20}, rsum1[3] = {0, 0, 0}, rsum2[3] = {0, 0, 0};
+            if(p->np > 0 && fastpm_hip_resident_summary(c->plan, &p->acc[0][0], 3, (int64_t) p->np, rmin, rmax, rsum1, rsum2)) {
+                fastpm_raise(-1, "%s\n", fpmhip_last_error());
+            }
+            uint64_t Ntot = p->np;
+            MPI_Allreduce(MPI_IN_PLACE, rsum1, 3, MPI_DOUBLE, MPI_SUM, pm_comm(pm));
+            MPI_Allreduce(MPI_IN_PLACE, rsum2, 3, MPI_DOUBLE, MPI_SUM, pm_comm(pm));
+            MPI_Allreduce(MPI_IN_PLACE, rmin, 3, MPI_DOUBLE, MPI_MIN, pm_comm(pm));
+            MPI_Allreduce(MPI_IN_PLACE, rmax, 3, MPI_DOUBLE, MPI_MAX, pm_comm(pm));
+            MPI_Allreduce(MPI_IN_PLACE, &Ntot, 1, MPI_LONG, MPI_SUM, pm_comm(pm));
+            for(d = 0; d < 3; d ++) {
+                acc_min[d] = rmin[d];
+                acc_max[d] = rmax[d];
+                acc_mean[d] = rsum1[d] / Ntot;
+                acc_std[d] = sqrt(rsum2[d] / Ntot - pow(rsum1[d] / Ntot, 2));
+            }
+        } else {
+            fastpm_store_summary(p, COLUMN_ACC, pm_comm(pm), "<s->", acc_min, acc_std, acc_mean, acc_max);
+        }
         for(d = 0; d < 3; d ++) {
             fastpm_info("p%s    acc[%d]: %g %g %g %g\n",
                 p->name, d, acc_min[d], acc_std[d], acc_mean[d], acc_max[d]);

@@ -164,7 +164,19 @@ int  fpmhip_sync(fpmhip_plan *plan);
 
 /* ---- the whole force step, one rank (nranks == 1): gravity.c:458-529 ----
  * delta_k_dev (nullable) receives delta(k)/N^3 after softening, before de-CIC, in the plan's
- * k layout (fpmhip_layout.ostrides).  total_mass < 0 -> computed here (gravity.c:330-341). */
+ * k layout (fpmhip_layout.ostrides).  total_mass < 0 -> computed here (gravity.c:330-341).
+ *
+ * ERROR CONTRACT of the device-pointer entries (fpmhip_force, fpmhip_force_species, the stage calls): they enqueue and
+ * return; nothing in them waits for the GPU.  What only the device can know about THIS call's particles -- a particle
+ * outside the rank's region (-6), a stale binning reused (-7), a slab overflow beyond the entry arrays (-5) -- is
+ * reported by the call itself only the first time a particle set of that size is binned; in the steady state it is
+ * reported LAZILY: by fpmhip_sync(plan) (which waits for the stream and returns the pending code), or failing that by
+ * the next call on the plan that bins particles.  A return of 0 therefore means "accepted", not "acc is valid": a caller
+ * that keeps its columns resident and consumes acc on the device (the fast path) must call fpmhip_sync(plan) -- one
+ * stream wait, no copy -- before it treats the step as good; on -5 the arrays have been grown and the same call may be
+ * repeated.  The host-column entries (fpmhip_force_host, fpmhip_force_species_host) and the resident host layer
+ * (fastpm_amd/host/fastpm_resident_hip.c) do exactly that inside the call, repair one overflow themselves and never
+ * return 0 with an invalid acc. */
 int fpmhip_force(fpmhip_plan *plan, const fpmhip_particles *p_dev, int kernel, int softening,
                  double total_mass, void *delta_k_dev);
 /* The same for several particle species painted into one mesh (the species loops of
@@ -297,7 +309,11 @@ int fpmhip_plan_staged_fft(const fpmhip_plan *plan);
 /* The (y, z) halves for the x planes [x0, x0 + nx) of the slab only: the exchange of one plane range can be in
  * flight while the next range is transformed.  Within an exchange chunk the planes of one range are contiguous:
  * range (x0, nx) of the chunk for rank r starts r * fpmhip_exchange_chunk_elems() + x0 * (chunk / xl) elements
- * into the buffer.  Available when fpmhip_plan_ranged_fft() is 1 (column-FFT back end, Nmesh / 2 supported). */
+ * into the buffer.  Available when fpmhip_plan_ranged_fft() is 1: column-FFT back end, Nmesh / 2 supported, AND the
+ * plain k-space layout (fpmhip_layout.okblock == osize[1]).  On the blocked layout (Nmesh >= 1536 on several x ranks) a
+ * plane range of an exchange chunk [ky_loc / okblock][x_loc][okblock][kz] is ky_loc / okblock separate pieces:
+ * fpmhip_plan_ranged_fft() returns 0 there and every *_range call with a partial range fails (-1) instead of handing a
+ * pipelined exchange the wrong bytes; exchange whole slabs (x0 = 0, nx = x_loc stays valid). */
 int fpmhip_plan_ranged_fft(const fpmhip_plan *plan);
 int fpmhip_fft_yz_forward_range(fpmhip_plan *plan, void *canvas_dev, void *send_dev, int x0, int nx);
 int fpmhip_fft_yz_backward_range(fpmhip_plan *plan, void *recv_dev, void *canvas_dev, int x0, int nx);

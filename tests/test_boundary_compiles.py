@@ -35,9 +35,60 @@ def _syntax_only(tmp_path, source, extra=()):
 
 
 @needs_reference
-def test_gravity_hip_c_type_checks_against_the_reference_headers(tmp_path):
-    r = _syntax_only(tmp_path, os.path.join(ROOT, "fastpm_amd", "host", "gravity_hip.c"))
+@pytest.mark.parametrize("tu", ["gravity_hip.c", "factors_hip.c", "store_hip.c", "transfer_hip.c"])
+def test_the_binding_type_checks_against_the_reference_headers(tmp_path, tu):
+    """gravity_hip.c (the force) and, round 4, the resident drop-in beside it: factors_hip.c (fastpm_kick_store /
+    fastpm_drift_store), store_hip.c (fastpm_store_wrap / _decompose / _summary + the sync calls), transfer_hip.c
+    (fastpm_apply_decic_transfer / fastpm_powerspectrum_init_from_delta)."""
+    r = _syntax_only(tmp_path, os.path.join(ROOT, "fastpm_amd", "host", tu))
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+@needs_reference
+def test_the_resident_symbols_have_the_reference_signatures(tmp_path):
+    """Prototypes restated from OUR reading of factors.c:175-197, 373-392, store.c:446-475, 485-488, 807-812,
+    transfer.c:77-78 and powerspectrum.c:35: a mismatch with the reference's headers is "conflicting types"; and the
+    members the new translation units read."""
+    probe = tmp_path / "probe2.c"
+    probe.write_text('''
+#include <mpi.h>
+#include <fastpm/libfastpm.h>
+#include <fastpm/logging.h>
+#include <fastpm/transfer.h>
+#include "pmpfft.h"
+void fastpm_kick_store(FastPMKickFactor * kick, FastPMStore * pi, FastPMStore * po, double af);
+void fastpm_drift_store(FastPMDriftFactor * drift, FastPMStore * pi, FastPMStore * po, double af);
+void fastpm_store_wrap(FastPMStore * p, double BoxSize[3]);
+int fastpm_store_decompose(FastPMStore * p, fastpm_store_target_func target_func, void * data, MPI_Comm comm);
+void fastpm_store_summary(FastPMStore * p, FastPMColumnTags attribute, MPI_Comm comm, const char * fmt, ...);
+void fastpm_apply_decic_transfer(PM * pm, FastPMFloat * from, FastPMFloat * to);
+void fastpm_powerspectrum_init_from_delta(FastPMPowerSpectrum * ps, PM * pm, const FastPMFloat * delta1_k, const FastPMFloat * delta2_k);
+static void members(FastPMKickFactor * k, FastPMDriftFactor * d, FastPMStore * p, FastPMPowerSpectrum * ps) {
+    (void) k->forcemode; (void) k->ai; (void) k->af; (void) k->nsamples; (void) k->q1; (void) k->q2;
+    (void) k->dda[31]; (void) k->Dv1[31]; (void) k->Dv2[31];
+    (void) d->forcemode; (void) d->ai; (void) d->af; (void) d->nsamples; (void) d->Dv1; (void) d->Dv2;
+    (void) d->dyyy[31]; (void) d->da1[31]; (void) d->da2[31];
+    (void) p->v[0][0]; (void) p->dx1[0][0]; (void) p->dx2[0][0]; (void) p->pgdc; (void) p->meta.a_x; (void) p->meta.a_v;
+    (void) p->columns[31]; (void) p->_column_info[31].attribute; (void) p->_column_info[0].dtype[0];
+    (void) p->_column_info[0].nmemb; (void) p->attributes; (void) p->np_upper;
+    (void) ps->base.k[0]; (void) ps->base.f[0]; (void) ps->base.size; (void) ps->Nmodes[0]; (void) ps->edges[0];
+    (void) ps->Volume; (void) ps->k0; (void) ps->pm->Comm2D;
+    (void) fastpm_store_find_column_id(p, COLUMN_ACC);
+}
+int main(void) { (void) members; return FASTPM_FORCE_COLA == 2 && FASTPM_FORCE_ZA == 4 ? 0 : 1; }
+''')
+    r = _syntax_only(tmp_path, str(probe), extra=("-Wno-unused-function",))
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+@needs_reference
+def test_a_wrong_member_in_the_resident_files_would_be_caught(tmp_path):
+    src = open(os.path.join(ROOT, "fastpm_amd", "host", "factors_hip.c")).read()
+    assert "pi->meta.a_v" in src
+    bad = tmp_path / "factors_bad.c"
+    bad.write_text(src.replace("pi->meta.a_v", "pi->meta.a_vel"))
+    r = _syntax_only(tmp_path, str(bad))
+    assert r.returncode != 0 and "a_vel" in r.stderr
 
 
 @needs_reference
@@ -100,3 +151,9 @@ def test_the_binding_reproduces_the_log_side_effects():
     src = open(os.path.join(ROOT, "fastpm_amd", "host", "gravity_hip.c")).read()
     assert 'fastpm_info("p%s    acc[%d]: %g %g %g %g\\n"' in src and "fastpm_store_summary(p, COLUMN_ACC" in src
     assert "fpmhip_set_check_hook" in src and "field values that are out of bounds" in src
+
+
+def test_the_resident_files_are_named_in_integration_md():
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for tu in ("factors_hip.c", "store_hip.c", "transfer_hip.c", "fastpm_hip_store_sync", "-Dfastpm_kick_store=fastpm_kick_store_cpu"):
+        assert tu in text, tu

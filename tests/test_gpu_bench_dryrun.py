@@ -26,7 +26,12 @@ def test_multi_rank_bench_path(nranks, port, alt):
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == nranks and d["finite"] and d["scaling"] == "weak" and d["config"]["particles"] == 64 ** 3
     assert d["momentum_residual"] < 1e-6
-    assert d["value"] > 0 and d["roofline"]["bound"] == "hbm"
+    # a dry run is never a measurement: the line says who took part and carries no value
+    assert d["value"] is None and d["per_gpu"] is None and d["dry_run"]["would_be_value"] > 0
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] is None
+    c = d["comm"]
+    assert c["backend"] == "gloo" and c["world_size"] == nranks and len(c["devices"]) == nranks
+    assert c["distinct_devices"] == 1 and c["share_gpu_dry_run"] and not c["measured"]
     if alt:
         assert d["other_gradient_mode"]["acc_max_abs_dev_over_max_abs_acc"] < 2e-7
     else:
@@ -44,4 +49,5 @@ def test_multi_rank_bench_path_on_pencils():
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 4 and d["finite"] and d["config"]["decomposition"] == "pencil 2x2"
-    assert d["momentum_residual"] < 1e-6 and d["value"] > 0
+    assert d["momentum_residual"] < 1e-6 and d["value"] is None and d["dry_run"]["would_be_value"] > 0
+    assert d["comm"]["world_size"] == 4 and not d["comm"]["measured"]

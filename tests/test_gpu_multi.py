@@ -112,3 +112,7 @@ def test_bench_line_on_real_gpus(P, nprocy):
     assert d["momentum_residual"] < 1e-6
     assert d["exposed_comm_ms_per_step"] >= 0 and d["kernel_ms_per_step"] > 0
     assert d["roofline"]["kernels"] and all(0 < k["frac"] < 1 for k in d["roofline"]["kernels"].values())
+    # the line is auditable on its own: RCCL, P ranks, P distinct devices (PCI addresses), the library's version
+    c = d["comm"]
+    assert c["backend"].startswith("nccl") and c["world_size"] == P and c["measured"] and not c["share_gpu_dry_run"]
+    assert len(c["devices"]) == P and c["distinct_devices"] == P and c["rccl_version"] and "dry_run" not in d

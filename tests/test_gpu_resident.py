@@ -1,0 +1,201 @@
+"""The RESIDENT drop-in on the GPU (fastpm_amd/host/fastpm_resident_hip.c = the view-struct twin of gravity_hip.c's
+resident branch, factors_hip.c, store_hip.c, transfer_hip.c): a C host that keeps its FastPMStore columns in HOST memory
+runs K D D (wrap) F K steps through the replaced functions; the columns live in device twins, and what crosses PCIe is
+counted.  Checked against the CPU oracle operator by operator, and against the same run with the columns synced home
+after every call."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import util
+from fastpm_amd import chost
+
+pytestmark = pytest.mark.gpu
+
+MODES = {"fastpm": 0, "pm": 1, "cola": 2}
+
+
+def _tables(rng):
+    t = lambda s: np.sort(rng.uniform(0, s, 32))
+    return [t(0.02), t(0.5), t(0.5)], [t(0.3), t(0.5), t(0.5)]
+
+
+def _run(oracle, mode, precision, sync_every_call, nsteps=3, potential=True):
+    H = chost.host_library()
+    N, nc, L = 64, 32, 96.0
+    rng = np.random.default_rng(5)
+    x0 = util.load_a(nc, L, N)
+    n = len(x0)
+    v0 = rng.normal(0, 0.2, (n, 3)).astype(np.float32)
+    dx1 = rng.normal(0, 0.3, (n, 3)).astype(np.float32)
+    dx2 = rng.normal(0, 0.05, (n, 3)).astype(np.float32)
+    kt, dt = _tables(rng)
+    ai, af = 0.1, 0.4
+    q1, q2, Dv1, Dv2 = 0.3, 0.05, 0.2, 0.03
+    fm = MODES[mode]
+    kv = chost.kick_factor_view(fm, ai, 0.2, af, *kt, q1=q1, q2=q2)
+    dv = chost.drift_factor_view(fm, ai, 0.2, af, *dt, Dv1=Dv1, Dv2=Dv2)
+    pm = H.fastpm_create_pm_hip(N, L, precision)
+    pmo = oracle.PMOracle(N, L, precision)
+    st = chost.HostStore(x0, v=v0, dx1=dx1, dx2=dx2, potential=potential, a_x=ai, a_v=ai)
+    sv = chost.solver_view(st)
+    painter = chost.PainterView(0, 2)
+    dk = np.zeros(pmo.allocsize, dtype=np.float64 if precision == 64 else np.float32)
+    box = (ctypes.c_double * 3)(L, L, L)
+    H.fastpm_hip_mirror_reset_stats()
+    log = []
+
+    # the oracle's copy of the run: same operators, the GPU's acc fed to its kicks so that v and x can be compared bit
+    # for bit (the force itself is compared with its tolerance at every step)
+    ox, ov = x0.copy(), v0.copy()
+    a_x = a_v = ai
+    acc_err = []
+
+    def force():
+        H.fastpm_solver_compute_force_resident_hip(ctypes.byref(sv), pm, ctypes.byref(painter), 0, 3, dk.ctypes.data, 1.0)
+        log.append(("F", chost.mirror_stats().h2d_bytes, chost.mirror_stats().d2h_bytes))
+        if sync_every_call:
+            st.sync("acc")
+            ref = oracle.compute_force(pmo, ox, potential=potential)
+            acc_err.append(util.rel_err(st.acc, ref["acc"]))
+            if potential:
+                acc_err.append(util.rel_err(st.potential, ref["potential"]))      # came home inside the call
+
+    def kick(a_to):
+        nonlocal ov, a_v
+        H.fastpm_kick_store_resident_hip(pm, ctypes.byref(kv), ctypes.byref(st.view), ctypes.byref(st.view), a_to)
+        if sync_every_call:
+            f = np.subtract(oracle.factor_lookup(ai, af, kt, a_to), oracle.factor_lookup(ai, af, kt, a_v))
+            ov = oracle.kick(fm, f[0], f[1], f[2], q1, q2, st.acc, ov, dx1, dx2)
+            st.sync("v")
+            assert np.array_equal(st.v, ov)
+        a_v = a_to
+        assert st.view.a_v == a_to
+
+    def drift(a_to):
+        nonlocal ox, a_x
+        H.fastpm_drift_store_resident_hip(pm, ctypes.byref(dv), ctypes.byref(st.view), ctypes.byref(st.view), a_to)
+        if sync_every_call:
+            f = np.subtract(oracle.factor_lookup(ai, af, dt, a_to), oracle.factor_lookup(ai, af, dt, a_x))
+            ox = oracle.drift(fm, f[0], f[1], f[2], Dv1, Dv2, ox, ov, dx1, dx2)
+            st.sync("x")
+            assert np.array_equal(st.x, ox)
+        a_x = a_to
+        assert st.view.a_x == a_to
+
+    def wrap():
+        nonlocal ox
+        H.fastpm_store_wrap_resident_hip(pm, ctypes.byref(st.view), box)
+        if sync_every_call:
+            ox = oracle.store_wrap(ox, L)
+            st.sync("x")
+            assert np.array_equal(st.x, ox)
+
+    force()
+    a = ai
+    for _ in range(nsteps):                         # solver.c:289-296: K D D F K with the half steps in between
+        h = (af - ai) / nsteps
+        kick(a + h / 2)
+        drift(a + h / 2)
+        drift(a + h)
+        wrap()
+        force()
+        kick(a + h)
+        a += h
+    stats = chost.mirror_stats()
+    # what the caller does with delta_k next: de-CIC in place + P(k) from the twin (solver.c:471, src/fastpm.c:1734)
+    before = (stats.h2d_bytes, stats.d2h_bytes)
+    H.fastpm_apply_decic_transfer_resident_hip(pm, dk.ctypes.data, dk.ctypes.data)
+    ps = chost.PowerSpectrumView()
+    H.fastpm_powerspectrum_init_from_delta_resident_hip(ctypes.byref(ps), pm, dk.ctypes.data, dk.ctypes.data)
+    s2 = chost.mirror_stats()
+    assert (s2.h2d_bytes, s2.d2h_bytes) == before                  # the mesh never left the device
+    nb = N // 2
+    pk = (np.ctypeslib.as_array(ps.base.k, (nb,)).copy(), np.ctypeslib.as_array(ps.base.f, (nb,)).copy(),
+          np.ctypeslib.as_array(ps.Nmodes, (nb,)).copy())
+    H.fastpm_powerspectrum_destroy_hip(ctypes.byref(ps))
+    assert np.isnan(dk[0])                                         # tagged: a host read without a sync would trip
+    assert H.fastpm_hip_host_sync(dk.ctypes.data) == 0             # a host handler asks for it
+    st.sync("all")
+    out = {"x": st.x.copy(), "v": st.v.copy(), "acc": st.acc.copy(), "pot": None if st.potential is None else st.potential.copy(),
+           "dk": dk.copy(), "pk": pk, "log": log, "stats": stats, "acc_err": acc_err, "np": n, "ox": ox, "pmo": pmo}
+    st.release()
+    H.fastpm_hip_mirror_release(dk.ctypes.data)
+    H.fastpm_free_pm_hip(pm)
+    return out
+
+
+@pytest.mark.parametrize("mode,precision", [("fastpm", 64), ("cola", 64), ("pm", 32)])
+def test_resident_steps_equal_the_oracle_operator_by_operator(oracle, mode, precision):
+    r = _run(oracle, mode, precision, sync_every_call=True)
+    tol = 1e-6 if precision == 64 else 2e-5
+    assert r["acc_err"] and max(r["acc_err"]) <= tol, r["acc_err"]
+    # delta_k of the last force, de-CIC'ed on the device, exported on request in the reference's layout; its P(k)
+    pmo = r["pmo"]
+    ref = oracle.compute_force(pmo, r["ox"])        # (x after the last wrap = the positions of the last force)
+    dko = pmo.alloc()
+    pmo.decic(ref["delta_k"], dko)
+    dk_tol = 1e-14 if precision == 64 else 2e-6
+    assert util.max_err(pmo.complex_view(r["dk"]), pmo.complex_view(dko)) <= dk_tol
+    kr, pr, nr = oracle.powerspectrum_finalize(*pmo.powerspectrum_sums(dko), 96.0)
+    k, p, nm = r["pk"]
+    good = nm > 0
+    assert np.array_equal(nm, nr) and np.allclose(k[good], kr[good], rtol=1e-12)
+    assert np.allclose(p[good], pr[good], rtol=1e-11 if precision == 64 else 1e-4)
+
+
+@pytest.mark.parametrize("mode", ["fastpm", "cola"])
+def test_resident_steps_move_no_particle_column_over_pcie(oracle, mode):
+    a = _run(oracle, mode, 64, sync_every_call=True)
+    b = _run(oracle, mode, 64, sync_every_call=False)
+    for key in ("x", "v", "acc", "pot", "dk"):
+        assert np.array_equal(a[key], b[key]), key              # the syncs are observers: same bits without them
+    n = b["np"]
+    cola = mode == "cola"
+    # uploads: x once (first force), then v (first kick) and, for COLA, dx1 and dx2 -- each exactly once, ever
+    first_force_h2d = b["log"][0][1]
+    assert first_force_h2d == 24 * n
+    assert b["stats"].h2d_bytes == 24 * n + 12 * n + (24 * n if cola else 0)
+    assert b["log"][-1][1] == b["stats"].h2d_bytes == b["log"][1][1]     # nothing went up after the first step's kick
+    # downloads inside the steps: the potential column (4 B / particle) per force and nothing else
+    assert b["stats"].d2h_bytes == 4 * n * len(b["log"])
+
+
+def test_a_different_output_store_gets_its_column_on_the_host(oracle):
+    """fastpm_set_species_snapshot (solver.c:647-700) drifts / kicks INTO another store and converts units on the host
+    right after: with pi != po the output column goes home inside the call and the host copy is the live one."""
+    H = chost.host_library()
+    N, L = 32, 48.0
+    rng = np.random.default_rng(9)
+    x = util.load_a(16, L, N)
+    v = rng.normal(0, 0.3, x.shape).astype(np.float32)
+    kt, dt = _tables(rng)
+    kv = chost.kick_factor_view(0, 0.1, 0.2, 0.4, *kt)
+    dv = chost.drift_factor_view(0, 0.1, 0.2, 0.4, *dt)
+    pm = H.fastpm_create_pm_hip(N, L, 64)
+    p = chost.HostStore(x, v=v, a_x=0.1, a_v=0.1)
+    po = chost.HostStore(x, v=v, a_x=0.1, a_v=0.1)
+    po.view.x = p.view.x                              # "steal columns, but velocity" (solver.c:660-664)
+    sv = chost.solver_view(p)
+    dk = np.zeros(oracle.PMOracle(N, L, 64).allocsize)
+    H.fastpm_solver_compute_force_resident_hip(ctypes.byref(sv), pm, ctypes.byref(chost.PainterView(0, 2)), 0, 3,
+                                               dk.ctypes.data, 1.0)
+    H.fastpm_drift_store_resident_hip(pm, ctypes.byref(dv), ctypes.byref(p.view), ctypes.byref(po.view), 0.3)
+    H.fastpm_kick_store_resident_hip(pm, ctypes.byref(kv), ctypes.byref(p.view), ctypes.byref(po.view), 0.3)
+    f = np.subtract(oracle.factor_lookup(0.1, 0.4, dt, 0.3), oracle.factor_lookup(0.1, 0.4, dt, 0.1))
+    assert np.array_equal(p.x, oracle.drift(0, f[0], f[1], f[2], 0, 0, x, v))          # already on the host
+    assert not H.fastpm_hip_host_is_stale(p.x.ctypes.data) and not H.fastpm_hip_host_is_stale(po.v.ctypes.data)
+    p.sync("acc")
+    f = np.subtract(oracle.factor_lookup(0.1, 0.4, kt, 0.3), oracle.factor_lookup(0.1, 0.4, kt, 0.1))
+    assert np.array_equal(po.v, oracle.kick(0, f[0], f[1], f[2], 0, 0, p.acc, v))
+    assert np.array_equal(p.v, v) and po.view.a_v == 0.3 and p.view.a_v == 0.1
+    # the host rescales po->v (km/s): its copy is the live one -- a later device use uploads it again
+    po.v *= 2
+    before = chost.mirror_stats().h2d_bytes
+    H.fastpm_kick_store_resident_hip(pm, ctypes.byref(kv), ctypes.byref(po.view), ctypes.byref(po.view), 0.35)
+    assert chost.mirror_stats().h2d_bytes - before >= po.v.nbytes
+    for s in (p, po):
+        s.release()
+    H.fastpm_hip_mirror_release(dk.ctypes.data)
+    H.fastpm_free_pm_hip(pm)
