@@ -249,6 +249,7 @@ def resident_dropin_leg(xh, Nmesh, BoxSize, precision, np_total, nsteps=6):
     import ctypes
     from fastpm_amd import chost
     H = chost.host_library()
+    msgs = chost.Messages()             # the log lines of gravity.c:398-417 are collected, not printed: stdout is ONE JSON line
     pmv = H.fastpm_create_pm_hip(Nmesh, BoxSize, precision)
     rng = np.random.default_rng(3)
     st = chost.HostStore(xh, v=(rng.standard_normal(xh.shape) * 1e-3).astype(np.float32), a_x=0.1, a_v=0.1)
@@ -296,6 +297,8 @@ def resident_dropin_leg(xh, Nmesh, BoxSize, precision, np_total, nsteps=6):
     st.release()
     H.fastpm_hip_mirror_release(dk.ctypes.data)
     H.fastpm_free_pm_hip(pmv)
+    msgs.close()
+    msgs.check()
     fm, sm = float(np.mean(tf)), float(np.mean(ts))
     return {"entry": "fastpm_solver_compute_force_resident_hip (+ kick / drift / wrap / de-CIC / P(k) twins)",
             "force_ms_per_call": round(fm * 1e3, 3), "value": np_total / fm, "unit": "particle-updates/s",
@@ -303,7 +306,7 @@ def resident_dropin_leg(xh, Nmesh, BoxSize, precision, np_total, nsteps=6):
             "steps_timed": len(tf), "first_force_ms_with_upload": round(first * 1e3, 3),
             "pcie_bytes": {"first_force_up": int(up0), "first_step_up": int(up1 - up0),
                            "later_steps_up": int(stats.h2d_bytes - up1), "all_steps_down": int(stats.d2h_bytes)},
-            "finite": finite,
+            "finite": finite, "log_lines_per_force": len(msgs.info) // (nsteps + 2),
             "note": "store columns in host memory, device twins behind them: x up once, v up once, then no particle "
                     "column and no delta_k crosses PCIe; the call waits for the GPU and checks device-side errors"}
 

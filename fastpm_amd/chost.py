@@ -104,6 +104,29 @@ def host_library():
     return H
 
 
+_HANDLER = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p)
+
+
+class Messages:
+    """fpm_set_msg_handler (the fastpm_set_msg_handler analogue, logging.c:59-104): collects what the C host would
+    print -- code 0 = fastpm_info log lines, anything else = a raise (the default handler prints it and abort()s)."""
+
+    def __init__(self):
+        self.info, self.raised = [], []
+        self._cb = _HANDLER(self._on)
+        host_library().fpm_set_msg_handler(self._cb, None)
+
+    def _on(self, code, msg, userdata):
+        (self.info if code == 0 else self.raised).append((code, msg.decode(errors="replace")))
+
+    def check(self):
+        if self.raised:
+            raise RuntimeError("C host raised: %r" % (self.raised,))
+
+    def close(self):
+        host_library().fpm_set_msg_handler(None, None)
+
+
 def mirror_stats():
     s = MirrorStats()
     host_library().fastpm_hip_mirror_get_stats(ctypes.byref(s))

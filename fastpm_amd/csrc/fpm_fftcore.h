@@ -353,14 +353,72 @@ __device__ __forceinline__ void gather(C2<F> *v, const void *lds, int tau, int c
     }
 }
 
+// ---- the wave-local exchanges of the strip kernels with a skewed layout (round 4) ----
+// In the row-major regions of the wave-local transforms (CW < 0) the strided gathers of the later stages land on a few
+// banks: at N = 512 in fp64 the last gather takes 256 LDS cycles per row where 32 are the floor (tools/lds_bank_model.py;
+// SQ_LDS_BANK_CONFLICT: a quarter of the marching readout's run time).  Element idx at idx + (idx >> SH) -- one element
+// of padding per 2^SH -- spreads them, and an exchange's layout is its own (written and read back inside the exchange):
+// SH is chosen PER EXCHANGE.  Round 3's skew went through lds_pos(idx) with idx a run-time sum, i.e. a shift and an add
+// per access, and lost in fp64 what the banks returned.  Here the position is split at compile time into a per-thread base
+// (one shift + add per butterfly) and a constant per register slot, which is exact under the conditions asserted below --
+// the addresses stay base + immediate offset as in the plain layout.
+template <int N, int E, int PPA, int RA, int RB, int ES> constexpr int xshift()
+{
+    // fp64 (16-byte elements), E = 8 plans; modelled gather cycles per row, plain -> skewed:
+    //   512 = 8.8.8: 64 -> 32 and 256 -> 32;  256 = 8.8.4: 128 -> 32 and 128 -> 32;  128 = 8.8.2: 128 -> 64, second plain
+    if (ES != 16 || E != 8) return 0;
+    if (N == 512) return 3;
+    if (N == 256) return PPA == 1 ? 3 : 5;
+    if (N == 128) return PPA == 1 ? 3 : 0;
+    return 0;
+}
+
+template <int R, int PP, int N, int E, int CW, int SH, typename F>
+__device__ __forceinline__ void scatter_sk(const C2<F> *v, C2<F> *lds, int tau, int c)
+{
+    constexpr int T = N / E, NBF = N / R, NB = NBF / T;
+    static_assert(CW < 0 && NBF % T == 0 && NBF % (1 << SH) == 0, "skewed scatter: row-major region, whole blocks per slot");
+#pragma unroll
+    for (int q = 0; q < NB; q++) {
+        const int b = tau + T * q;
+        C2<F> *base = lds + c * (-CW) + b + (b >> SH);
+#pragma unroll
+        for (int k = 0; k < R; k++) base[k * (NBF + (NBF >> SH))] = v[q * R + k];
+    }
+}
+
+template <int R, int PP, int N, int E, int CW, int SH, typename F>
+__device__ __forceinline__ void gather_sk(C2<F> *v, const C2<F> *lds, int tau, int c)
+{
+    constexpr int T = N / E, MP = N / PP, M = MP / R, NBF = N / R, NB = NBF / T, BLK = 1 << SH;
+    // (A + ts M) >> SH == (A >> SH) + ((ts M) >> SH) for A = kprev MP + t, t < M: M a multiple of the block; or the
+    // butterfly's MP values inside one block; or blocks of whole t ranges (M | BLK | MP)
+    static_assert(CW < 0 && NBF % T == 0 && (M % BLK == 0 || BLK % MP == 0 || (BLK % M == 0 && MP % BLK == 0)),
+                  "skewed gather: the slot offsets must be compile-time constants");
+#pragma unroll
+    for (int q = 0; q < NB; q++) {
+        const int b = tau + T * q;
+        const int A = (b / M) * MP + b % M;
+        const C2<F> *base = lds + c * (-CW) + A + (A >> SH);
+#pragma unroll
+        for (int ts = 0; ts < R; ts++) v[q * R + ts] = base[ts * M + ((ts * M) >> SH)];
+    }
+}
+
 // LDS transposition between the stage of radix RA (after PPA) and the stage of radix RB (after PPA * RA).  SP: the
 // real parts, then the imaginary parts, through an area of N * CW values of F; register slot i holds {new.x, old.y}
 // in between, so no second register set is needed.  The caller has made sure the LDS area is free (a barrier
 // since its last readers).
-template <int RA, int PPA, int RB, int N, int E, int CW, bool SP, typename F, int SK = 0, bool WS = false>
+template <int RA, int PPA, int RB, int N, int E, int CW, bool SP, typename F, int SK = 0, bool WS = false, bool XS = false>
 __device__ __forceinline__ void exchange(C2<F> *v, void *lds, int tau, int c)
 {
-    if (!SP) {
+    constexpr int SH = XS ? xshift<N, E, PPA, RA, RB, (int) sizeof(C2<F>)>() : 0;
+    if constexpr (XS && SH > 0) {
+        scatter_sk<RA, PPA, N, E, CW, SH, F>(v, (C2<F> *) lds, tau, c);
+        fft_sync<WS>();
+        gather_sk<RB, PPA * RA, N, E, CW, SH, F>(v, (const C2<F> *) lds, tau, c);
+        fft_sync<WS>();
+    } else if constexpr (!SP) {
         scatter<RA, PPA, N, E, CW, 0, F, SK>(v, lds, tau, c);
         fft_sync<WS>();
         gather<RB, PPA * RA, N, E, CW, 0, F, SK>(v, lds, tau, c);
@@ -379,21 +437,22 @@ __device__ __forceinline__ void exchange(C2<F> *v, void *lds, int tau, int c)
 
 // Full length-N transform of the E register values of each thread.  In: v[in_slot<PL>(j)] = row tau + T*j; out:
 // v[j] = row tau + T*j, natural order.  The LDS area must be free on entry (barrier) and is free on return.
-template <typename PL, int S, int CW, bool SP, typename F, int SK = 0, bool WS = false>
+template <typename PL, int S, int CW, bool SP, typename F, int SK = 0, bool WS = false, bool XS = false>
 __device__ __forceinline__ void fft_core(C2<F> *v, void *lds, const C2<F> *tw, int tau, int c)
 {
+    static_assert(!XS || (WS && CW < 0 && !SP), "skewed exchanges are for the wave-local row-major regions");
     constexpr int N = PL::N, E = PL::E, R1 = PL::R1, R2 = PL::R2, R3 = PL::R3, R4 = PL::R4;
     constexpr bool TWH = PL::TWH;
     constexpr bool L1 = R2 == 1, L2 = R3 == 1, L3 = R4 == 1;
     butterflies<R1, 1, N, E, S, L1, TWH>(v, tw, tau);
     if (!L1) {
-        exchange<R1, 1, R2, N, E, CW, SP, F, SK, WS>(v, lds, tau, c);
+        exchange<R1, 1, R2, N, E, CW, SP, F, SK, WS, XS>(v, lds, tau, c);
         butterflies<R2, R1, N, E, S, L2, TWH>(v, tw, tau);
         if (!L2) {
-            exchange<R2, R1, R3, N, E, CW, SP, F, SK, WS>(v, lds, tau, c);
+            exchange<R2, R1, R3, N, E, CW, SP, F, SK, WS, XS>(v, lds, tau, c);
             butterflies<R3, R1 * R2, N, E, S, L3, TWH>(v, tw, tau);
             if (!L3) {
-                exchange<R3, R1 * R2, R4, N, E, CW, SP, F, SK, WS>(v, lds, tau, c);
+                exchange<R3, R1 * R2, R4, N, E, CW, SP, F, SK, WS, XS>(v, lds, tau, c);
                 butterflies<R4, R1 * R2 * R3, N, E, S, true, TWH>(v, tw, tau);
             }
         }

@@ -65,6 +65,15 @@ template <typename PL> struct HalfTw : PL {
 // (MI355X_MICROARCH.md) picked: readout -- rows 13 (mod 16) values apart (269 for M = 256: the row stores 2.5 -> 0.83
 // cycles in fp64, 4.2 -> 0.83 in fp32) and, at M = 256 in fp64, 4 elements of skew per 32 exchange indices (SK): 11.3 ->
 // 7.8 cycles per access set, 1.73 -> 1.64 ms; paint -- rows 4 (mod 16) complex values apart (520 doubles): 12 -> 10.
+// FPM_XSKEW (default 1): the per-exchange skewed layout of the wave-local transforms in fp64 (fpm_fftcore.h: xshift);
+// a row's region then spans up to M + M / 8 values.  0: the plain layout of round 3 (A/B builds).
+#ifndef FPM_XSKEW
+#define FPM_XSKEW 1
+#endif
+constexpr int strip_xspan(int M, int elem_bytes)     // values a row's exchange region needs
+{
+    return FPM_XSKEW && elem_bytes == 16 && (M == 128 || M == 256 || M == 512) ? M + M / 8 : M;
+}
 constexpr int strip_pitch(int M, int rem)            // the smallest pitch >= M + 1 that is `rem` modulo 16
 {
     int p = M + 1;
@@ -72,6 +81,7 @@ constexpr int strip_pitch(int M, int rem)            // the smallest pitch >= M 
     return p;
 }
 
+constexpr int vmax_i(int a, int b) { return a > b ? a : b; }
 template <typename PL, typename F> struct StripCfg {
     static constexpr int M = PL::N, T = PL::T;
     static constexpr size_t twb = (size_t) (PL::TWN + M) * sizeof(C2<F>);
@@ -83,14 +93,15 @@ template <typename PL, typename F> struct StripCfg {
     // plane): readout 0.85 -> 0.815 ms at 512^3 fp32.  In fp64 the same skew (modelled 544 -> 432) LOSES, 1.19 -> 1.23 ms at
     // 512^3 and 14.25 -> 14.7 at 1024^3: not applied there.
     static constexpr int ws_sk = sizeof(F) == 4 ? 2 : 0;
-    static constexpr int ro_pitch = strip_pitch(M + ws_sk * (M / 32), 13);
+    static constexpr bool xs = FPM_XSKEW && sizeof(F) == 8;         // skewed wave-local exchanges
+    static constexpr int ro_pitch = strip_pitch(vmax_i(M + ws_sk * (M / 32), strip_xspan(M, (int) sizeof(C2<F>))), 13);
     static constexpr int ro_xchg = (M + 1) * STRIP_RW + ro_sk * (M / 32 + 1);       // elements of the exchange area
     static constexpr int ro_slot = ro_pitch * STRIP_RW > ro_xchg ? ro_pitch * STRIP_RW : ro_xchg;
     static constexpr size_t ro_lds = twb + (size_t) 2 * ro_slot * sizeof(C2<F>);
     static constexpr size_t ro1_lds = twb + (size_t) ro_slot * sizeof(C2<F>);       // the marching readout: ONE plane
     // paint: one plane of STRIP_Y rows of pt_pitch double accumulators
     static constexpr int pt_threads = T * STRIP_Y;
-    static constexpr int pt_pitch = 2 * strip_pitch(M, 4);
+    static constexpr int pt_pitch = 2 * strip_pitch(strip_xspan(M, (int) sizeof(C2<F>)), 4);
     static constexpr size_t pt_twb = (size_t) (M / 2 + M) * sizeof(C2<F>);
     static constexpr size_t pt1_lds = pt_twb + (size_t) STRIP_Y * pt_pitch * sizeof(double);      // one plane
 };
@@ -256,7 +267,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), (sizeof(F) == 4 && P
         }
         fft_sync<WS>();                                       // the row is in registers: its LDS is the transform's now
         C2<F> *lds = (C2<F> *) A;
-        fft_core<PH, -1, CWX, false, F, 0, WS>(v, lds, tw, tau, c);
+        fft_core<PH, -1, CWX, false, F, 0, WS, (WS && CF::xs)>(v, lds, tw, tau, c);
 #pragma unroll
         for (int j = 0; j < E; j++) lds[lds_pos<CWX, 0>(tau + T * j, c)] = v[j];
         fft_sync<WS>();
@@ -404,6 +415,11 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
 #ifndef FPM_RO_MINW
 #define FPM_RO_MINW 3
 #endif
+// timing probes of readout_march_kernel (wrong results; build-time only): 1 no CIC arithmetic / LDS gathers, 2 no FFT core,
+// 3 no z transform at all, 4 no mesh loads
+#ifndef FPM_RO_PROBE
+#define FPM_RO_PROBE 0
+#endif
 // LATE (the long rows, M >= 512): a plane's rows are requested right before their transform instead of a step ahead, and the
 // next plane's entries after it -- neither set of registers is held across the transform, the kernel fits 128 VGPRs
 // without spills (166 otherwise), and with that budget it runs 14.3 -> 13.0 ms at 1024^3 fp64 although the 58 KB of LDS
@@ -443,14 +459,28 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FP
     auto load_plane = [&](int xp) {                // plane xl of a slab is the halo plane the next rank sent
         if (g.periodic_x) xp -= xp >= g.N ? g.N : 0;
         const C2<F> *src = rowbase + (long long) xp * pstride;
+#if FPM_RO_PROBE == 4
+        (void) src;
+#pragma unroll
+        for (int j = 0; j < E; j++) x[j] = C2<F>{(F) xp, (F) j};
+        xm = C2<F>{0, 0};
+#else
 #pragma unroll
         for (int j = 0; j < E; j++) x[j] = ld_stream(&src[tau + T * j]);
         xm = tau == 0 ? src[M] : C2<F>{0, 0};
+#endif
     };
     auto c2r_plane = [&]() {                       // x[] -> the RW real rows of the plane in S (rowfft_c2r_kernel's arithmetic)
         C2<F> v[vmax(E)];
+#if FPM_RO_PROBE == 3
+#pragma unroll
+        for (int j = 0; j < E; j++) v[j] = x[j];
+#else
         c2r_prepare<PL, CWX, SKX, F, WS>(v, x, xm, S, twn, tau, c);
-        fft_core<PL, +1, CWX, false, F, SKX, WS>(v, S, tw, tau, c);
+#if FPM_RO_PROBE != 2
+        fft_core<PL, +1, CWX, false, F, SKX, WS, (WS && CF::xs)>(v, S, tw, tau, c);
+#endif
+#endif
 #pragma unroll
         for (int j = 0; j < E; j++) S[c * RP + tau + T * j] = v[j];
         if (tau == 0) S[c * RP + M].x = v[0].x;                    // value N of a row = value 0: the z + 1 corner needs no wrap
@@ -458,6 +488,9 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FP
     // acc + the four corners of the window's plane (x bit `bx`), in the reference's order
     const F *rs = (const F *) S;
     auto half = [&](double qx, double qy, double qz, int qc, int bx, double acc) -> double {      // D and base cell of the entry
+#if FPM_RO_PROBE == 1
+        return acc + qx + qy + qz + qc + bx;
+#endif
         const StripEntry cc = strip_entry(g, qx, qy, qz, qc);
         const int ly = cc.iy0 - y0, lz = cc.iz0;
         const double wxb = bx ? cc.d[0] : cc.t[0];
@@ -532,6 +565,169 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FP
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// readout with ONE plane in LDS and TWO ROWS PER TRANSFORM (round 4; the power-of-two meshes up to N = 512)
+// ------------------------------------------------------------------------------------------------------------------
+// The one-plane kernel above is bound by LDS traffic (profiles/r03_sq_counters.md: bank-conflict cycles alone are a quarter
+// of its run time): a row of N = 2 M reals goes through an M-point complex transform whose input must first be put together
+// from X[k] and conj X[M - k] -- one more trip of the whole row through LDS (c2r_prepare) and a second table of roots.
+// Two real rows a, b are ONE complex row z = a + i b: its spectrum is Z[k] = A[k] + i B[k] for k <= M and
+// Z[N - k] = conj A[k] + i conj B[k] above, both formed in registers from the half spectra as they arrive from HBM; one
+// N-point inverse transform then leaves a in the real parts and b in the imaginary parts.  Per row pair: two exchanges
+// of N values through LDS and N reals stored per row, where two M-point c2r transforms take four exchanges of M
+// values, two prepare trips and 2 M complex stores: 0.71 of the LDS bytes, 0.67 of the table reads, no second table.
+// A pair's T = N / 8 threads are one wave at N = 512 (two rows of 32 threads each before), the transform stays
+// wave-local; the strip's fifth (halo) row is paired with nothing (its wave runs with B = 0).
+template <typename PL2, typename F> struct PairCfg {
+    static constexpr int N2 = PL2::N, M = N2 / 2, T2 = PL2::T, E = PL2::E;
+    static constexpr int NPAIR = (STRIP_RW + 1) / 2;
+    static constexpr int threads = T2 * NPAIR;
+    static constexpr int sk = sizeof(F) == 4 ? 2 : 0;               // as StripCfg::ws_sk
+    // complex values per real row (2 RP reals >= N + 1; a pair's region of 2 RP values holds the skewed exchange)
+    static constexpr int RP = strip_pitch(vmax_i(M + sk * (M / 32), (strip_xspan(N2, (int) sizeof(C2<F>)) + 1) / 2), 13);
+    static constexpr int slot = 2 * RP * NPAIR;                     // a pair's region: 2 RP complex = its two real rows
+    static constexpr size_t twb = (size_t) PL2::TWN * sizeof(C2<F>);
+    static constexpr size_t lds = twb + (size_t) slot * sizeof(C2<F>);
+    static_assert(64 % T2 == 0 && E % 2 == 0 && T2 * (E / 2) == M, "a pair's threads must sit in one wave");
+};
+
+template <typename PL2, typename F, bool LATE>
+__global__ __launch_bounds__((PairCfg<PL2, F>::threads), FPM_RO_MINW) void readout_pair_kernel(
+    MeshGeo g, int ncomp, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
+    const double *__restrict__ sy, const double *__restrict__ sz, const C2<F> *__restrict__ m0,
+    const C2<F> *__restrict__ m1, const C2<F> *__restrict__ m2, float *__restrict__ out, int nmemb, int memb0,
+    const double *__restrict__ tw_global, double *__restrict__ part_all, long long part_stride, const int2 *__restrict__ scell)
+{
+    using CF = PairCfg<PL2, F>;
+    constexpr int N2 = CF::N2, M = CF::M, RW = STRIP_RW, T = CF::T2, E = CF::E, NT = CF::threads, RP = CF::RP, WP = 2 * RP;
+    extern __shared__ __align__(16) unsigned char smem_st[];
+    C2<F> *tw = (C2<F> *) smem_st;
+    C2<F> *S = tw + PL2::TWN;                      // [slot]: a pair's exchange area, then its two real rows
+    constexpr int CWX = -2 * RP, SKX = CF::sk;
+    const int tid = threadIdx.x, c = tid / T, tau = tid % T;
+    const bool has_b = 2 * c + 1 < RW;
+    const int nseg = (g.xl + g.xseg - 1) / g.xseg;
+    const int t = xcd_remap(blockIdx.x, ncomp * g.nty * nseg);
+    const int comp = t % ncomp, strip = (t / ncomp) % g.nty, seg = nseg - 1 - t / (ncomp * g.nty);      // last segment first
+    const C2<F> *mesh = comp == 0 ? m0 : (comp == 1 ? m1 : m2);
+    double *part = part_all + comp * part_stride;
+    const int xa_ = seg * g.xseg, xb_ = min(xa_ + g.xseg, g.xl);
+    const int y0 = strip * STRIP_Y;
+    int gya = y0 + 2 * c, gyb = y0 + 2 * c + 1;
+    gya -= gya >= g.N ? g.N : 0;
+    gyb -= gyb >= g.N ? g.N : 0;
+    const C2<F> *rowa = mesh + (long long) gya * g.rp, *rowb = mesh + (long long) gyb * g.rp;
+    const long long pstride = (long long) g.yplanes * g.rp;
+
+    C2<F> ha[E], hb[E];                            // A[k], B[k] (k < M) and A[N - k], B[N - k] (k >= M), k = tau + T j
+    auto load_plane = [&](int xp) {                // plane xl of a slab is the halo plane the next rank sent
+        if (g.periodic_x) xp -= xp >= g.N ? g.N : 0;
+        const C2<F> *sa = rowa + (long long) xp * pstride, *sb = rowb + (long long) xp * pstride;
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const int k = tau + T * j, kk = j < E / 2 ? k : N2 - k;
+            ha[j] = ld_stream(&sa[kk]);
+            hb[j] = has_b ? ld_stream(&sb[kk]) : C2<F>{0, 0};
+        }
+    };
+    auto c2r_plane = [&]() {                       // ha, hb -> the pair's two real rows in S
+        C2<F> v[vmax(E)];
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            C2<F> a = ha[j], b = hb[j];
+            // like every c2r, only the real parts of X[0] and X[N/2] are read (fpm_fftcore.h: c2r_prepare)
+            if (tau == 0 && (j == 0 || j == E / 2)) { a.y = 0; b.y = 0; }
+            v[in_slot<PL2>(j)] = j < E / 2 ? C2<F>{a.x - b.y, a.y + b.x}          // A + i B
+                                           : C2<F>{a.x + b.y, b.x - a.y};         // conj A + i conj B
+        }
+        fft_core<PL2, +1, CWX, false, F, SKX, true, (FPM_XSKEW && sizeof(F) == 8)>(v, S, tw, tau, c);
+        F *ra_ = (F *) S + (2 * c) * WP, *rb_ = ra_ + WP;
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            ra_[tau + T * j] = v[j].x;
+            if (has_b) rb_[tau + T * j] = v[j].y;
+        }
+        if (tau == 0) {                            // value N of a row = value 0: the z + 1 corner needs no wrap
+            ra_[N2] = v[0].x;
+            if (has_b) rb_[N2] = v[0].y;
+        }
+    };
+    // acc + the four corners of the window's plane (x bit `bx`), in the reference's order
+    const F *rs = (const F *) S;
+    auto half = [&](double qx, double qy, double qz, int qc, int bx, double acc) -> double {      // D and base cell of the entry
+        const StripEntry cc = strip_entry(g, qx, qy, qz, qc);
+        const int ly = cc.iy0 - y0, lz = cc.iz0;
+        const double wxb = bx ? cc.d[0] : cc.t[0];
+        const double wy[2] = {cc.t[1], cc.d[1]}, wz[2] = {cc.t[2], cc.d[2]};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int by = (k >> 1) & 1, bz = k & 1;
+            acc += (double) rs[(ly + by) * WP + lz + bz] * (wz[bz] * wxb * wy[by]);
+        }
+        return acc;
+    };
+    constexpr int PF = 2;
+    double px[PF], py[PF], pz[PF], pv[PF], qx[PF], qy[PF], qz[PF];
+    int prow[PF], qrow[PF], pc[PF], qc[PF];
+    int pb = 0, pn = 0, qb = 0, qn = 0;            // p: the particles that finish this step; q: those that start
+    auto fetch_q = [&](int xi) {
+        const int key = xi * g.nty + strip;
+        qb = tbeg[key];
+        qn = tcnt[key];
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int e = tid + u * NT;
+            qx[u] = qy[u] = qz[u] = 0;
+            qrow[u] = qc[u] = 0;
+            if (e < qn) {
+                qx[u] = sx[qb + e]; qy[u] = sy[qb + e]; qz[u] = sz[qb + e];
+                const int2 rc = scell[qb + e];                     // (row, base cell)
+                qrow[u] = rc.x; qc[u] = rc.y;
+            }
+        }
+    };
+    auto start_q = [&]() {                         // q -> p with the first four terms
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            px[u] = qx[u]; py[u] = qy[u]; pz[u] = qz[u]; prow[u] = qrow[u]; pc[u] = qc[u];
+            pv[u] = tid + u * NT < qn ? half(qx[u], qy[u], qz[u], qc[u], 0, 0.0) : 0.0;
+        }
+        for (int e = tid + PF * NT; e < qn; e += NT) part[qb + e] = half(sx[qb + e], sy[qb + e], sz[qb + e], scell[qb + e].y, 0, 0.0);
+        pb = qb;
+        pn = qn;
+    };
+    auto finish_p = [&]() {
+#pragma unroll
+        for (int u = 0; u < PF; u++)
+            if (tid + u * NT < pn)
+                out[(long long) prow[u] * nmemb + memb0 + comp] = (float) half(px[u], py[u], pz[u], pc[u], 1, pv[u]);
+        for (int e = tid + PF * NT; e < pn; e += NT) {
+            const int2 rc = scell[pb + e];
+            out[(long long) rc.x * nmemb + memb0 + comp] = (float) half(sx[pb + e], sy[pb + e], sz[pb + e], rc.y, 1, part[pb + e]);
+        }
+    };
+
+    load_plane(xa_);
+    fetch_q(xa_);
+    stage_twiddles(tw, tw_global, PL2::TWN, 1);
+    __syncthreads();
+    c2r_plane();
+    __syncthreads();
+    if (!LATE) load_plane(xa_ + 1);
+    start_q();
+    for (int i = xa_; i < xb_; i++) {              // the window goes from plane i to plane i + 1
+        if (!LATE && i + 1 < xb_) fetch_q(i + 1);  // needed after the transform
+        if (LATE) load_plane(i + 1);
+        __syncthreads();                           // every gather from plane i is done
+        c2r_plane();
+        __syncthreads();
+        if (LATE && i + 1 < xb_) fetch_q(i + 1);
+        if (!LATE && i + 1 < xb_) load_plane(i + 2);        // lands during the gathers
+        finish_p();
+        if (i + 1 < xb_) start_q();
+    }
+}
+
 // (M = 1024 with the E = 16 plan -- a row's 64 threads in one wave, wave-local transforms there too -- spills 56 - 90 VGPRs in the
 // readout: one rank of the 2048^3 fp32 mesh 34.4 -> 44 ms; the E = 8 plans with workgroup barriers stay)
 #define FPM_STRIP_CASE(n, BODY) case n: { using PL = typename Fac<n, 0>::type; BODY(PL) } break;
@@ -553,8 +749,10 @@ bool strips_supported(int N, int precision)
 {
     if (!rowfft_supported(N) || N % STRIP_Y != 0 || N / 2 > 1024) return false;
     const size_t es = precision == 64 ? 16 : 8, M = (size_t) N / 2;
-    const size_t ro = (2 * M + (size_t) strip_pitch((int) (M + (precision == 64 ? 0 : 2) * (M / 32)), 13) * STRIP_RW) * es;     // ~ StripCfg::ro1_lds
-    const size_t pt = (M / 2 + M) * es + (size_t) STRIP_Y * 2 * strip_pitch((int) M, 4) * sizeof(double);       // = pt1_lds
+    const int xs = strip_xspan((int) M, (int) es);
+    const size_t skw = M + (precision == 64 ? 0 : 2) * (M / 32);
+    const size_t ro = (2 * M + (size_t) strip_pitch((int) (skw > (size_t) xs ? skw : (size_t) xs), 13) * STRIP_RW) * es;     // ~ StripCfg::ro1_lds
+    const size_t pt = (M / 2 + M) * es + (size_t) STRIP_Y * 2 * strip_pitch(xs, 4) * sizeof(double);       // = pt1_lds
     return ro <= STRIP_LDS_MAX && pt <= STRIP_LDS_MAX;
 }
 
@@ -645,6 +843,36 @@ int paint_strips(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void 
                : paint_strips_launch<float, false>(p, pt, scale, out, accumulate);
 }
 
+// the paired-row readout where a pair's N / 8 threads fit one wave: the power-of-two meshes up to N = 512
+template <int M, typename F, bool OK = (M <= 256 && (M & (M - 1)) == 0)> struct PairLaunch {
+    static constexpr bool ok = false;
+    static int go(fpmhip_plan *, MeshGeo &, const void *, const void *, const void *, int, float *, int, int) { return -1; }
+};
+template <int M, typename F> struct PairLaunch<M, F, true> {
+    static constexpr bool ok = true;
+    static int go(fpmhip_plan *p, MeshGeo &g, const void *k0, const void *k1, const void *k2, int ncomp, float *out, int nmemb,
+                  int memb0)
+    {
+        static const int late_env = getenv("FPMHIP_RO_PAIR_LATE") ? atoi(getenv("FPMHIP_RO_PAIR_LATE")) : 1;
+        return late_env ? go_<true>(p, g, k0, k1, k2, ncomp, out, nmemb, memb0) : go_<false>(p, g, k0, k1, k2, ncomp, out, nmemb, memb0);
+    }
+    template <bool LATE_>
+    static int go_(fpmhip_plan *p, MeshGeo &g, const void *k0, const void *k1, const void *k2, int ncomp, float *out, int nmemb,
+                   int memb0)
+    {
+        using PL2 = typename Fac<2 * M, 0>::type;
+        using CF = PairCfg<PL2, F>;
+        static int occ = 0;
+        FPM_TRY(grant_lds(readout_pair_kernel<PL2, F, LATE_>, CF::lds, p->device));
+        g.xseg = choose_xseg(g, readout_pair_kernel<PL2, F, LATE_>, CF::threads, CF::lds, ncomp * g.nty, 16, 128, &occ);
+        const int nseg = (g.xl + g.xseg - 1) / g.xseg;
+        readout_pair_kernel<PL2, F, LATE_><<<ncomp * g.nty * nseg, CF::threads, CF::lds, p->stream>>>(
+            g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, (const C2<F> *) k0, (const C2<F> *) k1,
+            (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, p->ro_part_elems, p->scell);
+        return 0;
+    }
+};
+
 template <typename F>
 static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1, const void *k2, int ncomp, float *out,
                                  int nmemb, int memb0)
@@ -666,13 +894,18 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
     const bool use_ws = ws_ok && (ws_env >= 0 ? ws_env != 0 : !two_planes);
     static const int late_env = getenv("FPMHIP_RO_LATE") ? atoi(getenv("FPMHIP_RO_LATE")) : 1;        // 0: A/B
     const bool late = late_env != 0;
+    // two rows per transform (readout_pair_kernel): FPMHIP_RO_PAIR = 0 | 1 forces (A/B)
+    static const int pair_env = getenv("FPMHIP_RO_PAIR") ? atoi(getenv("FPMHIP_RO_PAIR")) : -1;
+    const bool pair = pair_env >= 0 ? pair_env != 0 : false;
     // the half sums of a dense tile's entries beyond the first two per thread: one double per own entry and component
     const long long part_stride = p->ro_part_elems;
 #define CALL_RO_W(PL, WS_)                                                                                             \
     {                                                                                                                  \
         using CF = StripCfg<PL, F>;                                                                                    \
         static int occ2 = 0, occ1 = 0, occ0 = 0;                                                                       \
-        if (two_planes) {                                                                                              \
+        if (WS_ && !two_planes && pair && PairLaunch<PL::N, F>::ok) {                                                  \
+            FPM_TRY((PairLaunch<PL::N, F>::go(p, g, k0, k1, k2, ncomp, out, nmemb, memb0)));                           \
+        } else if (two_planes) {                                                                                       \
             FPM_TRY(grant_lds(readout_strips_kernel<PL, F, WS_>, CF::ro_lds, p->device));                              \
             g.xseg = choose_xseg(g, readout_strips_kernel<PL, F, WS_>, CF::ro_threads, CF::ro_lds, ncomp * g.nty, 16, 128, &occ2); \
             const int nseg = (g.xl + g.xseg - 1) / g.xseg;                                                             \

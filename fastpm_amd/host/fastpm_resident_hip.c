@@ -159,8 +159,10 @@ static void tag_host(Twin *t)
 {
     /* a quiet NaN whose payload spells the library and a generation number: pm_check_values (pmapi.c:335-356) counts it
      * if host code reads the mesh without fastpm_hip_host_sync; anything that rewrites the buffer destroys it */
-    t->tag[0] = 0x7ff8464d48495021ULL;
-    t->tag[1] = 0x7ff8000000000000ULL | (++generation & 0xffffffffffffULL);
+    /* (every 32-bit half is a float NaN too: an fp32 mesh shows four of them) */
+    ++generation;
+    t->tag[0] = 0x7ff8464d7fc84950ULL;
+    t->tag[1] = ((0x7ff80000ULL | ((generation >> 20) & 0xfffffULL)) << 32) | 0x7fc00000ULL | (generation & 0xfffffULL);
     memcpy((void *) t->host, t->tag, sizeof(t->tag));
 }
 

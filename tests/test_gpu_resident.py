@@ -45,6 +45,7 @@ def _run(oracle, mode, precision, sync_every_call, nsteps=3, potential=True):
     box = (ctypes.c_double * 3)(L, L, L)
     H.fastpm_hip_mirror_reset_stats()
     log = []
+    msgs = chost.Messages()
 
     # the oracle's copy of the run: same operators, the GPU's acc fed to its kicks so that v and x can be compared bit
     # for bit (the force itself is compared with its tolerance at every step)
@@ -93,16 +94,16 @@ def _run(oracle, mode, precision, sync_every_call, nsteps=3, potential=True):
             assert np.array_equal(st.x, ox)
 
     force()
-    a = ai
-    for _ in range(nsteps):                         # solver.c:289-296: K D D F K with the half steps in between
-        h = (af - ai) / nsteps
-        kick(a + h / 2)
-        drift(a + h / 2)
-        drift(a + h)
+    edges = np.linspace(ai, af, nsteps + 1)
+    edges[-1] = af                                  # the table's end point exactly (factors.c:41-46, 116-121)
+    for a0, a1 in zip(edges[:-1], edges[1:]):       # solver.c:289-296: K D D F K with the half steps in between
+        ah = 0.5 * (a0 + a1)
+        kick(ah)
+        drift(ah)
+        drift(a1)
         wrap()
         force()
-        kick(a + h)
-        a += h
+        kick(a1)
     stats = chost.mirror_stats()
     # what the caller does with delta_k next: de-CIC in place + P(k) from the twin (solver.c:471, src/fastpm.c:1734)
     before = (stats.h2d_bytes, stats.d2h_bytes)
@@ -123,6 +124,11 @@ def _run(oracle, mode, precision, sync_every_call, nsteps=3, potential=True):
     st.release()
     H.fastpm_hip_mirror_release(dk.ctypes.data)
     H.fastpm_free_pm_hip(pm)
+    msgs.close()
+    msgs.check()
+    # gravity.c:398-417: six acc lines per species and force call, from the device summary
+    assert len(msgs.info) == 6 * len(log) and msgs.info[0][1].startswith("p1    acc[0]: ")
+    out["acc_lines"] = [m for _, m in msgs.info[-6:]]
     return out
 
 
@@ -139,6 +145,11 @@ def test_resident_steps_equal_the_oracle_operator_by_operator(oracle, mode, prec
     dk_tol = 1e-14 if precision == 64 else 2e-6
     assert util.max_err(pmo.complex_view(r["dk"]), pmo.complex_view(dko)) <= dk_tol
     kr, pr, nr = oracle.powerspectrum_finalize(*pmo.powerspectrum_sums(dko), 96.0)
+    acc = r["acc"].astype(np.float64)
+    for d in range(3):                                            # `p%s    acc[%d]: min std mean max`, %g-formatted
+        got = [float(v) for v in r["acc_lines"][d].split(":")[1].split()]
+        want = [acc[:, d].min(), acc[:, d].std(), acc[:, d].mean(), acc[:, d].max()]
+        assert np.allclose(got, want, rtol=2e-5, atol=2e-6 * np.abs(acc).max()), (got, want)
     k, p, nm = r["pk"]
     good = nm > 0
     assert np.array_equal(nm, nr) and np.allclose(k[good], kr[good], rtol=1e-12)
@@ -179,6 +190,7 @@ def test_a_different_output_store_gets_its_column_on_the_host(oracle):
     po.view.x = p.view.x                              # "steal columns, but velocity" (solver.c:660-664)
     sv = chost.solver_view(p)
     dk = np.zeros(oracle.PMOracle(N, L, 64).allocsize)
+    msgs = chost.Messages()
     H.fastpm_solver_compute_force_resident_hip(ctypes.byref(sv), pm, ctypes.byref(chost.PainterView(0, 2)), 0, 3,
                                                dk.ctypes.data, 1.0)
     H.fastpm_drift_store_resident_hip(pm, ctypes.byref(dv), ctypes.byref(p.view), ctypes.byref(po.view), 0.3)
@@ -195,6 +207,8 @@ def test_a_different_output_store_gets_its_column_on_the_host(oracle):
     before = chost.mirror_stats().h2d_bytes
     H.fastpm_kick_store_resident_hip(pm, ctypes.byref(kv), ctypes.byref(po.view), ctypes.byref(po.view), 0.35)
     assert chost.mirror_stats().h2d_bytes - before >= po.v.nbytes
+    msgs.close()
+    msgs.check()
     for s in (p, po):
         s.release()
     H.fastpm_hip_mirror_release(dk.ctypes.data)
