@@ -366,7 +366,11 @@ template <int N, int E, int PPA, int RA, int RB, int ES> constexpr int xshift()
 {
     // fp64 (16-byte elements), E = 8 plans; modelled gather cycles per row, plain -> skewed:
     //   512 = 8.8.8: 64 -> 32 and 256 -> 32;  256 = 8.8.4: 128 -> 32 and 128 -> 32;  128 = 8.8.2: 128 -> 64, second plain
-    if (ES != 16 || E != 8) return 0;
+    if (E != 8) return 0;
+    // fp32 (8-byte elements, ds_*_b64; the readout only -- the paint loses with it): 512: gathers 64 -> 16 and 128 -> 16;
+    // 256: 128 -> 16 and 64 -> 16
+    if (ES == 8 && (N == 512 || N == 256)) return PPA == 1 ? 3 : 5;
+    if (ES != 16) return 0;
     if (N == 512) return 3;
     if (N == 256) return PPA == 1 ? 3 : 5;
     if (N == 128) return PPA == 1 ? 3 : 0;

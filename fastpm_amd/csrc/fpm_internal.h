@@ -171,6 +171,7 @@ struct fpmhip_plan {
     int *d_flags = nullptr, *h_flags = nullptr;   // device flags of the binning and their pinned host copy
     hipEvent_t flags_event = nullptr;
     bool flags_pending = false;
+    bool prebinned = false;                 // the leapfrog binned the moved particles on the way (bin_particles_leap)
     bool bin_trusted = false;               // inside fpmhip_force: the paint of this very call made the binning
     void *scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
@@ -224,6 +225,8 @@ int ensure_bins(fpmhip_plan *p, int64_t np, int64_t ndup, bool has_mass);
 
 // fpm_particles.hip
 int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt);
+struct LeapArgs;
+int bin_particles_leap(fpmhip_plan *p, const fpmhip_particles *pt, const LeapArgs &la);    // 1: not available, nothing done
 int check_deferred(fpmhip_plan *p, bool wait);   // errors a binning reported after its call returned
 
 int reuse_binning(fpmhip_plan *p, const fpmhip_particles *pt);

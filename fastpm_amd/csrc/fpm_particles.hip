@@ -16,6 +16,7 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include "fpm_cic.h"
+#include "fpm_stepmath.h"
 
 namespace fpm {
 
@@ -354,7 +355,11 @@ __device__ __forceinline__ void wave_groups(int key, bool active, int &leader, i
     // (more than 8 distinct keys in a wave -- an incoherent load: the lanes left over act for themselves)
 }
 
-template <bool ORDERED>
+// LEAP (round 4): the particle's K D D (wrap) update of the leapfrog (fpm_stepmath.h: leap_one, the arithmetic of
+// leapfrog_kernel) is applied to the row on its way into the tiles -- v and x are read, updated and written back here, the
+// new position goes straight on into cic_setup -- so the force call that follows starts at its paint: the drift and
+// the binning share one walk over the rows (x is read once instead of twice, one launch instead of two).
+template <bool ORDERED, bool LEAP = false>
 __global__ __launch_bounds__(256) void bin_scatter_wave_kernel(MeshGeo g, int ntiles, const double *__restrict__ x,
                                                                const float *__restrict__ mass, long long np,
                                                                const int *__restrict__ order, const int *__restrict__ beg,
@@ -362,7 +367,8 @@ __global__ __launch_bounds__(256) void bin_scatter_wave_kernel(MeshGeo g, int nt
                                                                double *__restrict__ sx, double *__restrict__ sy,
                                                                double *__restrict__ sz, float *__restrict__ smass,
                                                                int *__restrict__ sidx, int *__restrict__ flags, long long alloc,
-                                                               int2 *__restrict__ scell)
+                                                               int2 *__restrict__ scell, LeapArgs la = LeapArgs(),
+                                                               double *__restrict__ x_out = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const long long j0 = ((long long) blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 * BIN_PPT) + lane;
@@ -382,8 +388,15 @@ __global__ __launch_bounds__(256) void bin_scatter_wave_kernel(MeshGeo g, int nt
         pm[u] = 0;
         if (active[u]) {
             const long long i = row[u];
-            px[u] = x[3 * i]; py[u] = x[3 * i + 1]; pz[u] = x[3 * i + 2];
+            const Row3d xr = *(const Row3d *) (x + 3 * i);
+            px[u] = xr.a; py[u] = xr.b; pz[u] = xr.c;
             if (mass) pm[u] = mass[i];
+            if (LEAP) {
+                double q[3] = {px[u], py[u], pz[u]};
+                leap_row(la, i, q);
+                px[u] = q[0]; py[u] = q[1]; pz[u] = q[2];
+                *(Row3d *) (x_out + 3 * i) = Row3d{q[0], q[1], q[2]};
+            }
         }
     }
     // keys: slot 2 u = the own tile, slot 2 u + 1 = the strip above (when the cloud reaches it)
@@ -1278,6 +1291,11 @@ static int bin_particles_once(fpmhip_plan *p, const fpmhip_particles *pt, bool *
 
 int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt)
 {
+    // the leapfrog that moved these particles binned them on the way (bin_particles_leap): nothing to do
+    if (p->prebinned) {
+        p->prebinned = false;
+        if (p->binned_x == pt->x && p->binned_np == pt->np && p->binned_mass == pt->mass) return 0;
+    }
     // the flags of the PREVIOUS binning must be read before this one overwrites them: waits for that binning (one
     // call back in the stream), never for work enqueued since
     FPM_TRY(check_deferred(p, true));
@@ -1288,6 +1306,50 @@ int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt)
     // never sees the overflow.  Lazily reported ones (steady state) surface in the next call / fpmhip_sync.
     if (rc == -5 && waited) rc = bin_particles_once(p, pt, &waited);
     return rc;
+}
+
+// The steady-state binning with the leapfrog applied to every row on its way into the tiles (LEAP above).  Returns 1
+// when the fused walk is not available -- no layout from a previous binning of this many particles, box tiles, the
+// A/B switches -- and nothing has been touched: the caller runs the stand-alone leapfrog kernel instead.
+int bin_particles_leap(fpmhip_plan *p, const fpmhip_particles *pt, const LeapArgs &la)
+{
+    static const bool ordered = !(getenv("FPMHIP_BIN_ORDER") && atoi(getenv("FPMHIP_BIN_ORDER")) == 0);
+    static const int wave_env = getenv("FPMHIP_BIN_WAVE") ? atoi(getenv("FPMHIP_BIN_WAVE")) : 1;
+    static const int leap_env = getenv("FPMHIP_BIN_LEAP") ? atoi(getenv("FPMHIP_BIN_LEAP")) : 1;      // 0: A/B
+    const long long np = pt->np;
+    p->prebinned = false;
+    if (!leap_env || !p->mg.strips || !wave_env || !ordered || p->lay.nranks != 1 || np <= 0 || p->layout_np != np) return 1;
+    FPM_TRY(check_deferred(p, true));           // the flags of the previous binning, before this one overwrites them
+    if (p->layout_np != np) return 1;           // (a reported failure resets the layout)
+    StageTimer tm(p, FPMHIP_T_SORT);
+    const int nt = p->ntiles, nkeys = 2 * nt;
+    FPM_TRY(ensure_bins(p, np, 0, pt->mass != nullptr));
+    FPM_CHECK_HIP(hipMemsetAsync(p->d_flags, 0, FLAG_COUNT * sizeof(int), p->stream));
+    std::swap(p->bin_beg[0], p->bin_beg[1]);
+    std::swap(p->bin_cap[0], p->bin_cap[1]);
+    std::swap(p->order[0], p->order[1]);
+    FPM_CHECK_HIP(hipMemsetAsync(p->bin_cnt, 0, ((size_t) nkeys + 1) * sizeof(int), p->stream));
+    // rows as they lie (the columns stream, coalesced, as in the stand-alone leapfrog) or in the previous tile order (a
+    // wave's particles in one or two tiles whatever the order of the rows): FPMHIP_LEAP_ORDER = 0 | 1
+    static const int leap_order = getenv("FPMHIP_LEAP_ORDER") ? atoi(getenv("FPMHIP_LEAP_ORDER")) : 0;
+    if (leap_order)
+        bin_scatter_wave_kernel<true, true><<<blocks_for(np, 256 * BIN_PPT), 256, 0, p->stream>>>(
+            p->mg, nt, pt->x, pt->mass, np, p->order[1], p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
+            pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, (long long) p->bin_alloc, p->scell, la, const_cast<double *>(pt->x));
+    else
+        bin_scatter_wave_kernel<false, true><<<blocks_for(np, 256 * BIN_PPT), 256, 0, p->stream>>>(
+            p->mg, nt, pt->x, pt->mass, np, nullptr, p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
+            pt->mass ? p->smass : nullptr, p->sidx, p->d_flags, (long long) p->bin_alloc, p->scell, la, const_cast<double *>(pt->x));
+    FPM_CHECK_HIP(hipGetLastError());
+    // a slab that overflowed: the exact path, predicated on the device flag, bins the (already updated) positions again
+    FPM_TRY(bin_full(p, pt, p->d_flags + FLAG_NEED_FULL));
+    FPM_TRY(bin_finish(p, nullptr));
+    p->binned_x = pt->x;
+    p->binned_mass = pt->mass;
+    p->binned_np = np;
+    p->layout_np = np;
+    p->prebinned = true;
+    return post_flags(p, false);
 }
 
 static int bin_particles_once(fpmhip_plan *p, const fpmhip_particles *pt, bool *waited)

@@ -10,51 +10,11 @@
 #include <cmath>
 
 #include "fpm_internal.h"
+#include "fpm_stepmath.h"
 
 namespace fpm {
 
 static inline unsigned blocks_for(long long n, int bs) { return (unsigned) ((n + bs - 1) / bs); }
-
-// The element updates, shared by the stand-alone kernels and the fused leapfrog kernel (same arithmetic).
-__device__ __forceinline__ float kick_one(float acc, float v, float dx1, float dx2, const fpmhip_kick_factor &k)
-{
-    float ax = acc;                                                     // factors.c:153
-    if (k.forcemode == FPMHIP_FORCE_COLA) ax += (dx1 * k.q1 + dx2 * k.q2);          // :154-156 (double sum -> float)
-    float out = v + ax * k.dda;                                         // :157 float + float*double -> float
-    if (k.forcemode == FPMHIP_FORCE_COLA) out += (dx1 * k.Dv1 + dx2 * k.Dv2);       // :158-160
-    return out;
-}
-
-__device__ __forceinline__ double drift_one(double x, float v, float dx1, float dx2, const fpmhip_drift_factor &f)
-{
-    double out;
-    switch (f.forcemode) {                                              // factors.c:90-108
-    case FPMHIP_FORCE_2LPT:
-        out = x + dx1 * f.da1 + dx2 * f.da2;
-        break;
-    case FPMHIP_FORCE_ZA:
-        out = x + dx1 * f.da1;
-        break;
-    case FPMHIP_FORCE_COLA: {
-        double vv = v - (dx1 * f.Dv1 + dx2 * f.Dv2);
-        out = x + vv * f.dyyy;
-        out += dx1 * f.da1 + dx2 * f.da2;
-        break;
-    }
-    default:   // FASTPM, PM
-        out = x + v * f.dyyy;
-        break;
-    }
-    return out;
-}
-
-__device__ __forceinline__ double wrap_one(double x, double BoxSize)
-{
-    double x1 = remainder(x, BoxSize);                                  // store.c:454
-    while (x1 < 0) x1 += BoxSize;
-    while (x1 > BoxSize) x1 -= BoxSize;
-    return x1;
-}
 
 // one thread per (particle, component): the three components are independent
 __global__ __launch_bounds__(256) void kick_kernel(const float *__restrict__ acc, const float *__restrict__ v,
@@ -224,6 +184,32 @@ int fpmhip_leapfrog(fpmhip_plan *p, const float *acc, float *v, double *x, const
     return 0;
 }
 
+// fpmhip_leapfrog and the binning of the NEXT force call in one walk over the rows (steady state on one rank with strip
+// tiles; otherwise the stand-alone leapfrog kernel, and the force call bins as usual).  Same v and x, bit for bit.
+int fpmhip_leapfrog_bin(fpmhip_plan *p, const fpmhip_particles *pt, float *v, const float *dx1, const float *dx2, int nkick,
+                        const fpmhip_kick_factor *kick0, const fpmhip_kick_factor *kick1, const fpmhip_drift_factor *drift0,
+                        const fpmhip_drift_factor *drift1, int wrap)
+{
+    if (!p || !pt || !kick0 || !drift0 || !drift1) FPM_FAIL(-1, "null argument");
+    const int64_t np = pt->np;
+    if (np < 0 || (np > 0 && (!pt->acc || !v || !pt->x))) FPM_FAIL(-1, "null argument");
+    if (nkick < 1 || nkick > 2 || (nkick == 2 && !kick1)) FPM_FAIL(-1, "nkick must be 1 or 2 (with kick1)");
+    const int m = kick0->forcemode;
+    if (m != FPMHIP_FORCE_FASTPM && m != FPMHIP_FORCE_PM && m != FPMHIP_FORCE_COLA) FPM_FAIL(-1, "leapfrog: force mode %d has no kick", m);
+    if (drift0->forcemode != m || drift1->forcemode != m || (nkick == 2 && kick1->forcemode != m)) FPM_FAIL(-1, "leapfrog: mixed force modes");
+    if (m == FPMHIP_FORCE_COLA && np > 0 && (!dx1 || !dx2)) FPM_FAIL(-1, "COLA needs dx1 and dx2 (solver.c:83-87)");
+    if (np == 0) return 0;
+    (void) hipSetDevice(p->device);
+    LeapArgs la;
+    la.acc = pt->acc; la.v = v; la.dx1 = dx1; la.dx2 = dx2; la.nkick = nkick; la.ndrift = 2;
+    la.k0 = *kick0; la.k1 = nkick == 2 ? *kick1 : *kick0; la.d0 = *drift0; la.d1 = *drift1;
+    la.wrap_box = wrap ? p->geom.BoxSize : 0.0;
+    // the positions are about to move: a binning of the old ones must not be mistaken for theirs
+    const int rc = bin_particles_leap(p, pt, la);
+    if (rc != 1) return rc;
+    return fpmhip_leapfrog(p, pt->acc, v, const_cast<double *>(pt->x), dx1, dx2, np, nkick, kick0, kick1, drift0, drift1, wrap);
+}
+
 int fpmhip_wrap(fpmhip_plan *p, double *x, int64_t np)
 {
     if (!p || (np > 0 && !x)) FPM_FAIL(-1, "null argument");
@@ -233,6 +219,23 @@ int fpmhip_wrap(fpmhip_plan *p, double *x, int64_t np)
     p->binned_np = -1;
     p->binned_x = nullptr;
     return 0;
+}
+
+// fastpm_store_wrap and the tile binning of the force call that follows it (solver.c:583 then :455) in one walk over
+// the rows; see fpmhip_leapfrog_bin.  Elsewhere: fpmhip_wrap.
+int fpmhip_wrap_bin(fpmhip_plan *p, const fpmhip_particles *pt)
+{
+    if (!p || !pt || pt->np < 0 || (pt->np > 0 && !pt->x)) FPM_FAIL(-1, "null argument");
+    if (pt->np == 0) return 0;
+    (void) hipSetDevice(p->device);
+    LeapArgs la;
+    la.acc = nullptr; la.v = nullptr; la.dx1 = la.dx2 = nullptr; la.nkick = 0; la.ndrift = 0;
+    la.k0 = la.k1 = fpmhip_kick_factor();
+    la.d0 = la.d1 = fpmhip_drift_factor();
+    la.wrap_box = p->geom.BoxSize;
+    const int rc = bin_particles_leap(p, pt, la);
+    if (rc != 1) return rc;
+    return fpmhip_wrap(p, const_cast<double *>(pt->x), pt->np);
 }
 
 int fpmhip_lpt_evolve(fpmhip_plan *p, double *x, float *v, const float *dx1, const float *dx2, int64_t np,

@@ -70,9 +70,16 @@ template <typename PL> struct HalfTw : PL {
 #ifndef FPM_XSKEW
 #define FPM_XSKEW 1
 #endif
-constexpr int strip_xspan(int M, int elem_bytes)     // values a row's exchange region needs
+// fp32: the readout only, M = 256 / 512 (0.787 -> 0.769 ms at 512^3, 8.5 -> 8.1 ms at 1024^3; the paint loses 8 % with it).
+constexpr bool strip_xs(int M, int elem_bytes, bool paint)
 {
-    return FPM_XSKEW && elem_bytes == 16 && (M == 128 || M == 256 || M == 512) ? M + M / 8 : M;
+    if (!FPM_XSKEW) return false;
+    if (elem_bytes == 16) return M == 128 || M == 256 || M == 512;
+    return !paint && (M == 256 || M == 512);
+}
+constexpr int strip_xspan(int M, int elem_bytes, bool paint)     // values a row's exchange region needs
+{
+    return strip_xs(M, elem_bytes, paint) ? M + M / 8 : M;
 }
 constexpr int strip_pitch(int M, int rem)            // the smallest pitch >= M + 1 that is `rem` modulo 16
 {
@@ -92,16 +99,16 @@ template <typename PL, typename F> struct StripCfg {
     // gathers of the later stages off each other's banks (tools/lds_bank_model.py: 336 -> 224 LDS cycles per row pair and
     // plane): readout 0.85 -> 0.815 ms at 512^3 fp32.  In fp64 the same skew (modelled 544 -> 432) LOSES, 1.19 -> 1.23 ms at
     // 512^3 and 14.25 -> 14.7 at 1024^3: not applied there.
-    static constexpr int ws_sk = sizeof(F) == 4 ? 2 : 0;
-    static constexpr bool xs = FPM_XSKEW && sizeof(F) == 8;         // skewed wave-local exchanges
-    static constexpr int ro_pitch = strip_pitch(vmax_i(M + ws_sk * (M / 32), strip_xspan(M, (int) sizeof(C2<F>))), 13);
+    static constexpr int ws_sk = sizeof(F) == 4 && !strip_xs(M, 8, false) ? 2 : 0;
+    static constexpr bool ro_xs = strip_xs(M, (int) sizeof(C2<F>), false), pt_xs = strip_xs(M, (int) sizeof(C2<F>), true);
+    static constexpr int ro_pitch = strip_pitch(vmax_i(M + ws_sk * (M / 32), strip_xspan(M, (int) sizeof(C2<F>), false)), 13);
     static constexpr int ro_xchg = (M + 1) * STRIP_RW + ro_sk * (M / 32 + 1);       // elements of the exchange area
     static constexpr int ro_slot = ro_pitch * STRIP_RW > ro_xchg ? ro_pitch * STRIP_RW : ro_xchg;
     static constexpr size_t ro_lds = twb + (size_t) 2 * ro_slot * sizeof(C2<F>);
     static constexpr size_t ro1_lds = twb + (size_t) ro_slot * sizeof(C2<F>);       // the marching readout: ONE plane
     // paint: one plane of STRIP_Y rows of pt_pitch double accumulators
     static constexpr int pt_threads = T * STRIP_Y;
-    static constexpr int pt_pitch = 2 * strip_pitch(strip_xspan(M, (int) sizeof(C2<F>)), 4);
+    static constexpr int pt_pitch = 2 * strip_pitch(strip_xspan(M, (int) sizeof(C2<F>), true), 4);
     static constexpr size_t pt_twb = (size_t) (M / 2 + M) * sizeof(C2<F>);
     static constexpr size_t pt1_lds = pt_twb + (size_t) STRIP_Y * pt_pitch * sizeof(double);      // one plane
 };
@@ -267,7 +274,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), (sizeof(F) == 4 && P
         }
         fft_sync<WS>();                                       // the row is in registers: its LDS is the transform's now
         C2<F> *lds = (C2<F> *) A;
-        fft_core<PH, -1, CWX, false, F, 0, WS, (WS && CF::xs)>(v, lds, tw, tau, c);
+        fft_core<PH, -1, CWX, false, F, 0, WS, (WS && CF::pt_xs)>(v, lds, tw, tau, c);
 #pragma unroll
         for (int j = 0; j < E; j++) lds[lds_pos<CWX, 0>(tau + T * j, c)] = v[j];
         fft_sync<WS>();
@@ -478,7 +485,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FP
 #else
         c2r_prepare<PL, CWX, SKX, F, WS>(v, x, xm, S, twn, tau, c);
 #if FPM_RO_PROBE != 2
-        fft_core<PL, +1, CWX, false, F, SKX, WS, (WS && CF::xs)>(v, S, tw, tau, c);
+        fft_core<PL, +1, CWX, false, F, SKX, WS, (WS && CF::ro_xs)>(v, S, tw, tau, c);
 #endif
 #endif
 #pragma unroll
@@ -582,9 +589,9 @@ template <typename PL2, typename F> struct PairCfg {
     static constexpr int N2 = PL2::N, M = N2 / 2, T2 = PL2::T, E = PL2::E;
     static constexpr int NPAIR = (STRIP_RW + 1) / 2;
     static constexpr int threads = T2 * NPAIR;
-    static constexpr int sk = sizeof(F) == 4 ? 2 : 0;               // as StripCfg::ws_sk
+    static constexpr int sk = sizeof(F) == 4 && !strip_xs(N2, 8, false) ? 2 : 0;               // as StripCfg::ws_sk
     // complex values per real row (2 RP reals >= N + 1; a pair's region of 2 RP values holds the skewed exchange)
-    static constexpr int RP = strip_pitch(vmax_i(M + sk * (M / 32), (strip_xspan(N2, (int) sizeof(C2<F>)) + 1) / 2), 13);
+    static constexpr int RP = strip_pitch(vmax_i(M + sk * (M / 32), (strip_xspan(N2, (int) sizeof(C2<F>), false) + 1) / 2), 13);
     static constexpr int slot = 2 * RP * NPAIR;                     // a pair's region: 2 RP complex = its two real rows
     static constexpr size_t twb = (size_t) PL2::TWN * sizeof(C2<F>);
     static constexpr size_t lds = twb + (size_t) slot * sizeof(C2<F>);
@@ -599,7 +606,7 @@ __global__ __launch_bounds__((PairCfg<PL2, F>::threads), FPM_RO_MINW) void reado
     const double *__restrict__ tw_global, double *__restrict__ part_all, long long part_stride, const int2 *__restrict__ scell)
 {
     using CF = PairCfg<PL2, F>;
-    constexpr int N2 = CF::N2, M = CF::M, RW = STRIP_RW, T = CF::T2, E = CF::E, NT = CF::threads, RP = CF::RP, WP = 2 * RP;
+    constexpr int N2 = CF::N2, RW = STRIP_RW, T = CF::T2, E = CF::E, NT = CF::threads, RP = CF::RP, WP = 2 * RP;
     extern __shared__ __align__(16) unsigned char smem_st[];
     C2<F> *tw = (C2<F> *) smem_st;
     C2<F> *S = tw + PL2::TWN;                      // [slot]: a pair's exchange area, then its two real rows
@@ -640,7 +647,7 @@ __global__ __launch_bounds__((PairCfg<PL2, F>::threads), FPM_RO_MINW) void reado
             v[in_slot<PL2>(j)] = j < E / 2 ? C2<F>{a.x - b.y, a.y + b.x}          // A + i B
                                            : C2<F>{a.x + b.y, b.x - a.y};         // conj A + i conj B
         }
-        fft_core<PL2, +1, CWX, false, F, SKX, true, (FPM_XSKEW && sizeof(F) == 8)>(v, S, tw, tau, c);
+        fft_core<PL2, +1, CWX, false, F, SKX, true, strip_xs(N2, (int) sizeof(C2<F>), false)>(v, S, tw, tau, c);
         F *ra_ = (F *) S + (2 * c) * WP, *rb_ = ra_ + WP;
 #pragma unroll
         for (int j = 0; j < E; j++) {
@@ -749,10 +756,10 @@ bool strips_supported(int N, int precision)
 {
     if (!rowfft_supported(N) || N % STRIP_Y != 0 || N / 2 > 1024) return false;
     const size_t es = precision == 64 ? 16 : 8, M = (size_t) N / 2;
-    const int xs = strip_xspan((int) M, (int) es);
-    const size_t skw = M + (precision == 64 ? 0 : 2) * (M / 32);
-    const size_t ro = (2 * M + (size_t) strip_pitch((int) (skw > (size_t) xs ? skw : (size_t) xs), 13) * STRIP_RW) * es;     // ~ StripCfg::ro1_lds
-    const size_t pt = (M / 2 + M) * es + (size_t) STRIP_Y * 2 * strip_pitch(xs, 4) * sizeof(double);       // = pt1_lds
+    const int xs_ro = strip_xspan((int) M, (int) es, false), xs_pt = strip_xspan((int) M, (int) es, true);
+    const size_t skw = M + (precision == 64 || strip_xs((int) M, 8, false) ? 0 : 2) * (M / 32);
+    const size_t ro = (2 * M + (size_t) strip_pitch((int) (skw > (size_t) xs_ro ? skw : (size_t) xs_ro), 13) * STRIP_RW) * es;     // ~ StripCfg::ro1_lds
+    const size_t pt = (M / 2 + M) * es + (size_t) STRIP_Y * 2 * strip_pitch(xs_pt, 4) * sizeof(double);       // = pt1_lds
     return ro <= STRIP_LDS_MAX && pt <= STRIP_LDS_MAX;
 }
 

@@ -101,7 +101,8 @@ int fastpm_hip_resident_kick(fpmhip_plan *plan, const fpmhip_kick_factor *kick, 
                              const float *dx1, const float *dx2, float *v_out, int64_t np, int own_output);
 int fastpm_hip_resident_drift(fpmhip_plan *plan, const fpmhip_drift_factor *drift, const double *x_in, const float *v,
                               const float *dx1, const float *dx2, double *x_out, int64_t np, int own_output);
-int fastpm_hip_resident_wrap(fpmhip_plan *plan, double *x, int64_t np);                           /* store.c:446-475 */
+/* store.c:446-475, and the tile binning of the force call that follows it (mass: the column that call will pass) */
+int fastpm_hip_resident_wrap(fpmhip_plan *plan, double *x, const float *mass, int64_t np);
 int fastpm_hip_resident_decic(fpmhip_plan *plan, const void *from, void *to);                     /* transfer.c:77-113 */
 /* powerspectrum.c:35-111 before its Allreduce: the raw bin sums (Nmesh / 2 bins) */
 int fastpm_hip_resident_powerspectrum(fpmhip_plan *plan, const void *delta1_k, const void *delta2_k, double *ksum,

@@ -361,13 +361,19 @@ int fastpm_hip_resident_drift(fpmhip_plan *plan, const fpmhip_drift_factor *drif
     return own_output ? hand_to_host(x_out) : 0;
 }
 
-int fastpm_hip_resident_wrap(fpmhip_plan *plan, double *x, int64_t np)
+int fastpm_hip_resident_wrap(fpmhip_plan *plan, double *x, const float *mass, int64_t np)
 {
     if (!plan) return -1;
     if (np == 0) return 0;
-    double *dx;
-    NEED(dx = fastpm_hip_dev_inout(plan, x, (size_t) np * 24));
-    return fpmhip_wrap(plan, dx, np);
+    /* fastpm_store_wrap is the last thing that moves a particle before the force (fastpm_decompose, solver.c:583, then
+     * :455): the tile binning of that force call is made in the same walk over the rows (fpmhip_wrap_bin; a plain wrap
+     * where that is not on offer) */
+    fpmhip_particles p;
+    memset(&p, 0, sizeof(p));
+    NEED(p.x = fastpm_hip_dev_inout(plan, x, (size_t) np * 24));
+    if (mass) NEED(p.mass = fastpm_hip_dev_in(plan, mass, (size_t) np * 4));
+    p.np = np;
+    return fpmhip_wrap_bin(plan, &p);
 }
 
 int fastpm_hip_resident_decic(fpmhip_plan *plan, const void *from, void *to)
@@ -541,7 +547,7 @@ void fastpm_store_wrap_resident_hip(PMView *pm, FastPMResidentStoreView *p, doub
             fpm_raise_hip(-1, "fastpm_store_wrap: BoxSize[%d] = %g is not the plan's %g\n", d, BoxSize[d], pm->BoxSize[d]);
             return;
         }
-    raise_rc(fastpm_hip_resident_wrap(pm->plan, COL3(p, x), (int64_t) p->np));
+    raise_rc(fastpm_hip_resident_wrap(pm->plan, COL3(p, x), p->mass, (int64_t) p->np));
 }
 
 static void each_column(FastPMResidentStoreView *p, unsigned columns, int sync)

@@ -45,7 +45,7 @@ fastpm_store_wrap(FastPMStore * p, double BoxSize[3])
         return;
     }
     /* (the reference raises for |x| > 10000 BoxSize, store.c:461-473; remainder() on the device wraps any finite x) */
-    const int rc = fastpm_hip_resident_wrap(plan, &p->x[0][0], (int64_t) p->np);
+    const int rc = fastpm_hip_resident_wrap(plan, &p->x[0][0], p->mass, (int64_t) p->np);
     if(rc) fastpm_raise(-1, "fastpm_store_wrap on the MI355X failed (%d): %s\n", rc, rc == -9 ? fastpm_hip_mirror_error() : fpmhip_last_error());
 }
 

@@ -126,7 +126,10 @@ SYMBOLS = {
     "fpmhip_drift": (_I, [_P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(DriftFactor)]),
     "fpmhip_leapfrog": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I, ctypes.POINTER(KickFactor), ctypes.POINTER(KickFactor),
                              ctypes.POINTER(DriftFactor), ctypes.POINTER(DriftFactor), _I]),
+    "fpmhip_leapfrog_bin": (_I, [_P, ctypes.POINTER(Particles), _P, _P, _P, _I, ctypes.POINTER(KickFactor),
+                                 ctypes.POINTER(KickFactor), ctypes.POINTER(DriftFactor), ctypes.POINTER(DriftFactor), _I]),
     "fpmhip_wrap": (_I, [_P, _P, _I64]),
+    "fpmhip_wrap_bin": (_I, [_P, ctypes.POINTER(Particles)]),
     "fpmhip_decompose_order": (_I, [_P, _P, _I64, _P, ctypes.POINTER(_I64)]),
     "fpmhip_gather_rows": (_I, [_P, _P, _P, _P, _I64, _I]),
     "fpmhip_laplace": (_I, [_P, _P, _P, _I]),

@@ -153,10 +153,12 @@ def fastpm_drift_store(pm, drift, pi, po, af):
     po.a_x = af
 
 
-def fastpm_leapfrog_store(pm, kicks, drifts, p, wrap=True):
+def fastpm_leapfrog_store(pm, kicks, drifts, p, wrap=True, bin_for_force=False):
     """kick(s), two drifts and the wrap of one leapfrog step in one pass over the columns (fpmhip_leapfrog): `kicks`
     = [(KickFactor, af)] or two of them, `drifts` = [(DriftFactor, af), (DriftFactor, af)]; the same looked-up factor
-    differences as fastpm_kick_store / fastpm_drift_store, bit-identical columns."""
+    differences as fastpm_kick_store / fastpm_drift_store, bit-identical columns.  bin_for_force: fpmhip_leapfrog_bin --
+    the tile binning of the force call that follows is made in the same walk over the rows (one rank, strip tiles, steady
+    state; elsewhere the plain leapfrog)."""
     ks = []
     a_v = p.a_v
     for kick, af in kicks:
@@ -169,15 +171,25 @@ def fastpm_leapfrog_store(pm, kicks, drifts, p, wrap=True):
         f, i = drift.lookup(af), drift.lookup(a_x)
         ds.append(_lib.DriftFactor(drift.forcemode, 0, f[0] - i[0], f[1] - i[1], f[2] - i[2], drift.Dv1, drift.Dv2))
         a_x = af
-    check(pm._L.fpmhip_leapfrog(pm._plan, _ptr(p.acc), _ptr(p.v), _ptr(p.x), _ptr(p.dx1), _ptr(p.dx2), p.np, len(ks),
-                                ctypes.byref(ks[0]), ctypes.byref(ks[-1]), ctypes.byref(ds[0]), ctypes.byref(ds[1]),
-                                int(bool(wrap))))
+    if bin_for_force:
+        check(pm._L.fpmhip_leapfrog_bin(pm._plan, ctypes.byref(p._c()), _ptr(p.v), _ptr(p.dx1), _ptr(p.dx2), len(ks),
+                                        ctypes.byref(ks[0]), ctypes.byref(ks[-1]), ctypes.byref(ds[0]), ctypes.byref(ds[1]),
+                                        int(bool(wrap))))
+    else:
+        check(pm._L.fpmhip_leapfrog(pm._plan, _ptr(p.acc), _ptr(p.v), _ptr(p.x), _ptr(p.dx1), _ptr(p.dx2), p.np, len(ks),
+                                    ctypes.byref(ks[0]), ctypes.byref(ks[-1]), ctypes.byref(ds[0]), ctypes.byref(ds[1]),
+                                    int(bool(wrap))))
     p.a_v, p.a_x = a_v, a_x
 
 
-def fastpm_store_wrap(pm, p):
-    """fastpm_store_wrap(p, BoxSize), store.c:446-475, in place on the device column."""
-    check(pm._L.fpmhip_wrap(pm._plan, _ptr(p.x), p.np))
+def fastpm_store_wrap(pm, p, bin_for_force=False):
+    """fastpm_store_wrap(p, BoxSize), store.c:446-475, in place on the device column.  bin_for_force: fpmhip_wrap_bin --
+    the wrap is the last thing that moves a particle before the force (solver.c:583, :455): the tile binning of that force
+    call is made in the same walk over the rows."""
+    if bin_for_force:
+        check(pm._L.fpmhip_wrap_bin(pm._plan, ctypes.byref(p._c())))
+    else:
+        check(pm._L.fpmhip_wrap(pm._plan, _ptr(p.x), p.np))
 
 
 def pm_2lpt_solve(pm, delta_k, p, shift=(0.0, 0.0, 0.0), kernel="1_4"):

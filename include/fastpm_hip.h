@@ -414,6 +414,16 @@ int fpmhip_leapfrog(fpmhip_plan *plan, const float *acc_dev, float *v_dev, doubl
                     const float *dx2_dev, int64_t np, int nkick, const fpmhip_kick_factor *kick0,
                     const fpmhip_kick_factor *kick1, const fpmhip_drift_factor *drift0,
                     const fpmhip_drift_factor *drift1, int wrap);
+/* The same, and the tile binning of the NEXT force call made in the same walk over the rows (round 4): p_dev->x, ->acc,
+ * ->mass, ->np as the force call will pass them, x updated in place.  In the steady state of a one-rank run on strip tiles
+ * (a previous force call has binned this many particles) every particle's new position goes from the leapfrog's registers
+ * straight into its tile -- the following fpmhip_force / fpmhip_force_species / fpmhip_paint* on the same (x, np, mass)
+ * starts at its paint; anywhere else this is fpmhip_leapfrog and the force call bins as usual.  v and x are bit-identical
+ * to fpmhip_leapfrog's either way.  Any later change of the positions (fpmhip_drift, fpmhip_wrap, ...) drops the binning. */
+int fpmhip_wrap_bin(fpmhip_plan *plan, const fpmhip_particles *p_dev);      /* fpmhip_wrap + that binning */
+int fpmhip_leapfrog_bin(fpmhip_plan *plan, const fpmhip_particles *p_dev, float *v_dev, const float *dx1_dev,
+                        const float *dx2_dev, int nkick, const fpmhip_kick_factor *kick0, const fpmhip_kick_factor *kick1,
+                        const fpmhip_drift_factor *drift0, const fpmhip_drift_factor *drift1, int wrap);
 
 /* ---- "next" row 3: the device half of fastpm_store_decompose (store.c:485-657), slabs ----
  * Owner rank of every particle (FastPMTargetPM, store.c:476-483) and the reference's stable order:

@@ -180,3 +180,80 @@ def test_fused_leapfrog_is_bit_identical_to_the_separate_calls(mode, nkick):
     assert torch.equal(a.v, b.v) and torch.equal(a.x, b.x)
     assert a.a_v == b.a_v and a.a_x == b.a_x
     pm.destroy()
+
+
+@pytest.mark.parametrize("mode,nkick,precision,mass", [("fastpm", 1, 64, False), ("cola", 2, 64, False), ("pm", 1, 32, True)])
+def test_leapfrog_that_bins_for_the_next_force_gives_the_same_bits(mode, nkick, precision, mass):
+    """fpmhip_leapfrog_bin: the K (K) D D wrap run applied to every row on its way into the tiles of the NEXT force call
+    (one walk over the rows instead of a leapfrog pass and a binning pass).  Three K D D F steps side by side with the
+    plain leapfrog + a force call that bins for itself: v, x and acc must be bit-identical at every step -- the
+    update is the same arithmetic (fpm_stepmath.h) and the tiles receive the same entries."""
+    import torch
+    from fastpm_amd import PM, DriftFactor, KickFactor, Store, fastpm_leapfrog_store
+    rng = np.random.default_rng(17)
+    N, nc, L = 64, 32, 96.0                     # strips need Nmesh >= 64 with paint_mode = 3
+    x = util.load_b(nc, L, N)
+    n = len(x)
+    cols = dict(v=rng.normal(0, 0.5, (n, 3)).astype(np.float32), dx1=rng.normal(0, 0.3, (n, 3)).astype(np.float32),
+                dx2=rng.normal(0, 0.1, (n, 3)).astype(np.float32))
+    m = rng.uniform(0.0, 0.5, n).astype(np.float32) if mass else None
+    t = lambda s: np.sort(rng.uniform(0, s, 32))
+    k0 = KickFactor(mode, 0.1, 0.1, 0.4, t(0.05), t(0.3), t(0.3), q1=0.3, q2=0.05)
+    d0 = DriftFactor(mode, 0.1, 0.15, 0.4, t(1.5), t(0.3), t(0.3), Dv1=0.2, Dv2=0.03)
+    runs = []
+    for fused in (False, True):
+        pm = PM(N, L, precision, paint_mode=3)
+        assert pm.strips()
+        st = Store(x, mass=m, a_x=0.1, a_v=0.1, **cols)
+        pm.compute_force(st)
+        snaps = []
+        a = 0.1
+        for step in range(3):
+            kicks = [(k0, a + 0.05)] + ([(k0, a + 0.1)] if nkick == 2 else [])
+            fastpm_leapfrog_store(pm, kicks, [(d0, a + 0.05), (d0, a + 0.1)], st, bin_for_force=fused)
+            pm.compute_force(st)
+            pm.sync()                               # what only the device knows about the binning: nothing must be pending
+            snaps.append((st.x.clone(), st.v.clone(), st.acc.clone()))
+            a += 0.1
+            st.a_v = a
+        tm = None
+        runs.append(snaps)
+        pm.destroy()
+    for (xa, va, aa), (xb, vb, ab) in zip(*runs):
+        assert torch.equal(xa, xb) and torch.equal(va, vb) and torch.equal(aa, ab)
+    assert torch.isfinite(runs[1][-1][2]).all()
+
+
+def test_a_prebinned_step_starts_at_the_paint_and_any_later_move_drops_it():
+    """The force call after fpmhip_leapfrog_bin launches no binning (stage timer `sort` counts one launch -- the fused
+    walk -- per step, not two); a drift in between invalidates the binning and the force bins again."""
+    import torch
+    from fastpm_amd import PM, DriftFactor, KickFactor, Store, fastpm_drift_store, fastpm_leapfrog_store
+    rng = np.random.default_rng(3)
+    N, nc, L = 64, 32, 96.0
+    x = util.load_a(nc, L, N)
+    t = lambda s: np.sort(rng.uniform(0, s, 32))
+    k0 = KickFactor("fastpm", 0.1, 0.1, 0.4, t(0.05), t(0.3), t(0.3))
+    d0 = DriftFactor("fastpm", 0.1, 0.15, 0.4, t(1.5), t(0.3), t(0.3))
+    pm = PM(N, L, 64, paint_mode=3)
+    st = Store(x, v=rng.normal(0, 0.5, x.shape).astype(np.float32), a_x=0.1, a_v=0.1)
+    pm.compute_force(st)
+    pm.compute_force(st)
+    pm.timing_enable(True)
+    pm.timing_reset()
+    fastpm_leapfrog_store(pm, [(k0, 0.15)], [(d0, 0.15), (d0, 0.2)], st, bin_for_force=True)
+    pm.compute_force(st)
+    assert pm.timings()["sort"][1] == 1                    # the fused walk; the force call did not bin
+    ref = st.acc.clone()
+    pm.timing_reset()
+    fastpm_leapfrog_store(pm, [(k0, 0.25)], [(d0, 0.25), (d0, 0.3)], st, bin_for_force=True)
+    fastpm_drift_store(pm, d0, st, st, 0.35)               # the positions move again: the binning is dropped
+    pm.compute_force(st)
+    assert pm.timings()["sort"][1] == 2
+    pm.timing_enable(False)
+    st2 = Store(st.x.cpu().numpy())
+    pm2 = PM(N, L, 64, paint_mode=3)
+    pm2.compute_force(st2)
+    assert torch.equal(st.acc, st2.acc) and not torch.equal(ref, st.acc)
+    pm.destroy()
+    pm2.destroy()

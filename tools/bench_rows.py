@@ -114,6 +114,19 @@ def main():
                                                           fastpm_leapfrog_store(pm, [(kf, 0.15)], [(df, 0.15), (df, 0.2)], st))),
         n * 84, "acc, v, x in; v, x out")
     out["kddfk_step_fused_ms"] = round(timed(step_fused, reps=5, warm=1), 3)
+
+    def step_binned():                                   # ... and the binning of the force call made by that same pass
+        st.a_v = st.a_x = 0.1
+        fastpm_leapfrog_store(pm, [(kf, 0.15)], [(df, 0.15), (df, 0.2)], st, bin_for_force=True)
+        pm.compute_force(st, delta_k=dk)
+        pm.decic_powerspectrum(dk)
+        st.a_v = 0.1
+        fastpm_kick_store(pm, kf, st, st, 0.2)
+    out["kddfk_step_fused_binned_ms"] = round(timed(step_binned, reps=5, warm=1), 3)
+    row("leapfrog + binning of the next force (one walk over the rows)",
+        timed(lambda: (setattr(st, "a_v", 0.1), setattr(st, "a_x", 0.1),
+                       fastpm_leapfrog_store(pm, [(kf, 0.15)], [(df, 0.15), (df, 0.2)], st, bin_for_force=True))),
+        n * (84 + 28), "acc, v, x in; v, x, entries out")
     out["kddfk_particle_steps_per_s"] = round(n / ms * 1e3)
     print(json.dumps(out))
 
