@@ -89,7 +89,19 @@ struct MeshGeo {
     double inv_cell;   // 1.0 / (BoxSize / N), pmpfft.c:150-151
     int ntx, nty, ntz; // tile grid over [xplanes][N][N]
     int xseg;          // strip plans: x planes a marching workgroup walks (fpm_strips.hip)
+    int ntyo;          // strip plans: strips that own particles (= nty; pencils: nty - 1, the last strip is the y halo row's)
     int strips;        // 0: box tiles TILE_X x TILE_Y x TILE_Z; STRIP_Y: strip tiles (ntx = xl, nty = N / STRIP_Y, ntz = 1)
+};
+
+// Pencil plans with strip tiles (round 4): the marching kernels write / read the half-spectrum rows where the (y <-> kz)
+// exchange "A" wants / leaves them -- row (x, y) cut into kz blocks, block b at b * chunk + (x * ylr + y) * nzl -- so no
+// pack or unpack pass exists; the rows that belong to the neighbours (plane xl, row ylr) live in small buffers of plain
+// rows of rp complex values: hx = plane xl as [ylr + 1][rp] (its last row is the corner), hy = row ylr of the planes
+// [0, xl) as [xl][rp].
+struct PenIO {
+    int on;
+    long long chunk;            // complex values per exchange-A chunk (fpmhip_layout.chunk_a_elems / 2)
+    void *hx[3], *hy[3];        // per mesh (the paint uses [0])
 };
 
 // Element (ix, ky_loc, kz_loc) of a k-space block (fpmhip_layout.okblock): the block is Nproc[0] sender chunks, each

@@ -140,7 +140,8 @@ template <typename PL, typename F, bool R2C, bool WS>
 __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), (sizeof(F) == 4 && PL::N == 1024 ? 4 : FPM_PT_MINW)) void paint_march_kernel(
     MeshGeo g, int ntiles, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
     const double *__restrict__ sy, const double *__restrict__ sz, const float *__restrict__ smass, double M0, double scale,
-    void *__restrict__ out_, int accumulate, const double *__restrict__ tw_global, const int2 *__restrict__ scell)
+    void *__restrict__ out_, int accumulate, const double *__restrict__ tw_global, const int2 *__restrict__ scell,
+    PenIO pen)
 {
     using CF = StripCfg<PL, F>;
     constexpr int M = PL::N, N = 2 * M, T = PL::T, E = PL::E, NT = CF::pt_threads, WP = CF::pt_pitch, SLOT = STRIP_Y * WP;
@@ -249,6 +250,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), (sizeof(F) == 4 && P
             F *canvas = (F *) out_;
             for (int idx = tid; idx < STRIP_Y * N; idx += NT) {
                 const int ly = idx / N, z = idx - ly * N;
+                if (y0 + ly >= g.yplanes) continue;                    // pencils: the strip of the y halo row has one row
                 F *row = canvas + (long long) i * g.str0 + (long long) (y0 + ly) * g.str1;
                 const F mine = (F) (A[ly * WP + z] * scale);
                 row[z] = accumulate ? (F) (row[z] + mine) : mine;           // further species add (gravity.c:326-338)
@@ -257,6 +259,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), (sizeof(F) == 4 && P
                 const int npad = (int) g.str1 - N;
                 for (int idx = tid; idx < STRIP_Y * npad; idx += NT) {
                     const int ly = idx / npad, z = idx - ly * npad;
+                    if (y0 + ly >= g.yplanes) continue;
                     canvas[(long long) i * g.str0 + (long long) (y0 + ly) * g.str1 + N + z] = 0;
                 }
             }
@@ -278,15 +281,29 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), (sizeof(F) == 4 && P
 #pragma unroll
         for (int j = 0; j < E; j++) lds[lds_pos<CWX, 0>(tau + T * j, c)] = v[j];
         fft_sync<WS>();
-        C2<F> *dst = out + ((long long) i * g.yplanes + y0 + c) * g.rp;
+        // where the row lives: the plain [x][y][rp] rows, or (pencils) the exchange-A chunks / the halo buffers (PenIO)
+        const int yrow = y0 + c;
+        C2<F> *dst = out + ((long long) i * g.yplanes + yrow) * g.rp;
+        bool chunked = false, live = true;
+        if (pen.on) {
+            live = yrow <= g.ylr;                                      // the y halo row's strip has one row
+            if (!g.periodic_x && i == g.xl) dst = (C2<F> *) pen.hx[0] + (long long) min(yrow, g.ylr) * g.rp;
+            else if (yrow >= g.ylr) dst = (C2<F> *) pen.hy[0] + (long long) i * g.rp;
+            else { dst = out + ((long long) i * g.ylr + yrow) * g.nzl; chunked = true; }
+        }
+        auto at = [&](int k) -> C2<F> * { return chunked ? dst + (k / g.zblk) * pen.chunk + k % g.zblk : dst + k; };
 #pragma unroll
         for (int j = 0; j < E; j++) {
             const int k = tau + T * j;
             const C2<F> a = v[j];
-            st_stream(&dst[k], r2c_untangle(a, lds[lds_pos<CWX, 0>((M - k) % M, c)], twn[k]));
-            if (k == 0) dst[M] = C2<F>{a.x - a.y, 0};                  // X[N/2] = Re Z0 - Im Z0
+            const C2<F> val = r2c_untangle(a, lds[lds_pos<CWX, 0>((M - k) % M, c)], twn[k]);
+            if (live) {
+                st_stream(at(k), val);
+                if (k == 0) *at(M) = C2<F>{a.x - a.y, 0};              // X[N/2] = Re Z0 - Im Z0
+            }
         }
-        for (int k = M + 1 + tau; k < g.rp; k += T) dst[k] = C2<F>{0, 0};          // the padding of an aligned row
+        if (live && !chunked)
+            for (int k = M + 1 + tau; k < g.rp; k += T) dst[k] = C2<F>{0, 0};      // the padding of an aligned row
         fft_sync<WS>();
         if (WS) {
             for (int idx = tau; idx < WP; idx += T) A[c * WP + idx] = 0;          // a row's threads clear their own row
@@ -811,7 +828,8 @@ static int choose_xseg(const MeshGeo &g, K kernel, int threads, size_t lds, int 
 }
 
 template <typename F, bool R2C>
-static int paint_strips_launch(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void *out, int accumulate)
+static int paint_strips_launch(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void *out, int accumulate,
+                               const PenIO &pen)
 {
     MeshGeo g = p->mg;
     // the z pass wave-local where a row's threads fit one wave (the power-of-two meshes); FPMHIP_PT_WS = 0: A/B
@@ -825,7 +843,7 @@ static int paint_strips_launch(fpmhip_plan *p, const fpmhip_particles *pt, doubl
         const int nseg = (g.xl + g.xseg - 1) / g.xseg;                                                                 \
         paint_march_kernel<PL, F, R2C, WS_><<<g.nty * nseg, CF::pt_threads, CF::pt1_lds, p->stream>>>(                 \
             g, p->ntiles, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, pt->mass ? p->smass : nullptr, pt->M0, scale, out, \
-            accumulate, p->d_twiddle, p->scell);                                                                       \
+            accumulate, p->d_twiddle, p->scell, pen);                                                                  \
     }
 #define CALL_PM(PL)                                                                                                    \
     if (R2C && 64 % PL::T == 0 && ws_env) CALL_PM_W(PL, (R2C && 64 % PL::T == 0)) else CALL_PM_W(PL, false)
@@ -838,16 +856,20 @@ static int paint_strips_launch(fpmhip_plan *p, const fpmhip_particles *pt, doubl
 
 // Bins `pt` and paints it: r2c = false -> the real canvas (accumulate: added to it); r2c = true -> the half-spectrum
 // rows [x][y][kz] of the painted canvas, i.e. the paint and the z pass of pm_r2c in one kernel.
-int paint_strips(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void *out, int accumulate, bool r2c)
+int paint_strips(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void *out, int accumulate, bool r2c,
+                 const PenIO *pen_)
 {
     if (!p->mg.strips) FPM_FAIL(-1, "internal: paint_strips on a plan with box tiles");
     if (r2c && accumulate) FPM_FAIL(-1, "internal: the fused paint + z pass cannot accumulate");
+    PenIO pen = {};
+    if (pen_) pen = *pen_;
+    if (r2c && !p->mg.periodic_y && !pen.on) FPM_FAIL(-1, "internal: on pencils the fused paint + z pass writes the exchange chunks (fpmhip_paint_zr2c_pen)");
     FPM_TRY(bin_particles(p, pt));
     StageTimer tm(p, FPMHIP_T_PAINT);
-    if (p->f64) return r2c ? paint_strips_launch<double, true>(p, pt, scale, out, 0)
-                           : paint_strips_launch<double, false>(p, pt, scale, out, accumulate);
-    return r2c ? paint_strips_launch<float, true>(p, pt, scale, out, 0)
-               : paint_strips_launch<float, false>(p, pt, scale, out, accumulate);
+    if (p->f64) return r2c ? paint_strips_launch<double, true>(p, pt, scale, out, 0, pen)
+                           : paint_strips_launch<double, false>(p, pt, scale, out, accumulate, pen);
+    return r2c ? paint_strips_launch<float, true>(p, pt, scale, out, 0, pen)
+               : paint_strips_launch<float, false>(p, pt, scale, out, accumulate, pen);
 }
 
 // the paired-row readout where a pair's N / 8 threads fit one wave: the power-of-two meshes up to N = 512
