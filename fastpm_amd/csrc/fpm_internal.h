@@ -203,6 +203,8 @@ struct fpmhip_plan {
     size_t dec_tmp_bytes = 0, dec_hist_bytes = 0;
     int64_t binned_ndup = 0;
     // strip plans: half sums of the marching readout (fpm_strips.hip), one double per own entry and force component
+    void *scratch = nullptr;                // fpmhip_plan_scratch
+    size_t scratch_bytes = 0;
     double *ro_part = nullptr;
     int64_t ro_part_elems = 0;
 
@@ -245,9 +247,10 @@ int reuse_binning(fpmhip_plan *p, const fpmhip_particles *pt);
 
 // fpm_strips.hip
 bool strips_supported(int N, int precision);
-int paint_strips(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void *out, int accumulate, bool r2c);
+int paint_strips(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void *out, int accumulate, bool r2c,
+                 const PenIO *pen = nullptr);
 int readout_strips_zc2r(fpmhip_plan *p, const fpmhip_particles *pt, const void *k0, const void *k1, const void *k2, int ncomp,
-                        float *out, int nmemb, int memb0);
+                        float *out, int nmemb, int memb0, const PenIO *pen = nullptr);
 
 // fpm_fft.hip
 int strips_y_xfwd_xback(fpmhip_plan *p, void *zrows_delta_k, int kernel, int mode, void *out0, void *out1, void *out2);

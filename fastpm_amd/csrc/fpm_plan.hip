@@ -309,18 +309,23 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
     // default from N = 320 (measured per force, strips / boxes: N = 128 0.44 / 0.29 ms -- 128 marching workgroups do not
     // fill the chip --, 256 0.89 / 0.90, 320 1.61 / 1.66, 384 2.51 / 2.68, 512 5.2 / 5.85)
     g.strips = 0;
+    g.ntyo = g.nty;
     {
         static const bool env_off = getenv("FPMHIP_STRIPS") && atoi(getenv("FPMHIP_STRIPS")) == 0;      // A/B
         // one rank or x slabs (the halo plane then travels as half-spectrum rows: the z pass is linear)
-        const bool can = Ny == 1 && geom->fft_mode == FPMHIP_FFT_AUTO && colfft_supported((int) N) &&
+        // pencils (round 4): the marching kernels write / read the exchange-A chunks directly (PenIO); the strip grid
+        // then has one more strip per plane, the y halo row's, and the local rows must be whole strips
+        static const bool pen_off = getenv("FPMHIP_PEN_STRIPS") && atoi(getenv("FPMHIP_PEN_STRIPS")) == 0;      // A/B
+        const bool pen_ok = Ny == 1 || (!pen_off && ylr % STRIP_Y == 0);
+        const bool can = pen_ok && geom->fft_mode == FPMHIP_FFT_AUTO && colfft_supported((int) N) &&
                          strips_supported((int) N, geom->precision) && geom->gradient_mode == FPMHIP_GRADIENT_KSPACE;
         if (geom->paint_mode == FPMHIP_PAINT_STRIPS && !can)
-            FPM_FAIL(-1, "FPMHIP_PAINT_STRIPS: one rank or x slabs, the k-space gradient and a mesh whose z rows fit the strip kernels");
+            FPM_FAIL(-1, "FPMHIP_PAINT_STRIPS: the k-space gradient, a mesh whose z rows fit the strip kernels and (pencils) local rows in whole strips");
         if (can && (geom->paint_mode == FPMHIP_PAINT_STRIPS || (geom->paint_mode == FPMHIP_PAINT_TILED && N >= 320 && !env_off))) {
             g.strips = STRIP_Y;
             static const int xseg_env = getenv("FPMHIP_XSEG") ? atoi(getenv("FPMHIP_XSEG")) : 0;      // A/B
             g.xseg = xseg_env > 0 ? xseg_env : 0;                    // 0: chosen per launch (fpm_strips.hip choose_xseg)
-            g.ntx = g.xl; g.nty = (int) N / STRIP_Y; g.ntz = 1;
+            g.ntx = g.xl; g.ntyo = ylr / STRIP_Y; g.nty = g.ntyo + (Ny > 1 ? 1 : 0); g.ntz = 1;
         }
     }
     p->ntiles = g.ntx * g.nty * g.ntz;
@@ -374,7 +379,7 @@ void fpmhip_plan_destroy(fpmhip_plan *p)
     void *ptrs[] = {p->host_stage.x, p->host_stage.acc, p->host_stage.mass, p->host_stage.pot,
                     p->d_twiddle, p->d_tab, p->d_fac, p->sx, p->sy, p->sz, p->smass, p->sidx, p->bin_beg[0], p->bin_beg[1],
                     p->bin_cap[0], p->bin_cap[1], p->bin_cnt, p->bin_off, p->bin_capv, p->bin_tmp, p->order[0], p->order[1],
-                    p->d_flags, p->scan_tmp, p->d_scalar, p->d_decic, p->d_bins, p->dec_key_in, p->dec_idx, p->dec_tmp, p->ro_part, p->scell};
+                    p->d_flags, p->scan_tmp, p->d_scalar, p->d_decic, p->d_bins, p->dec_key_in, p->dec_idx, p->dec_tmp, p->ro_part, p->scell, p->scratch};
     for (void *q : ptrs) if (q) (void) hipFree(q);
     if (p->h_pinned) (void) hipHostFree(p->h_pinned);
     if (p->h_flags) (void) hipHostFree(p->h_flags);
@@ -404,6 +409,20 @@ void *fpmhip_plan_buffer(fpmhip_plan *p, int which)
     if (!p) return nullptr;
     if (ensure_buffer(p, which) != 0) return nullptr;
     return p->buf[which];
+}
+
+// a plan-owned scratch allocation for the host sequences (the halo rows of a pencil strip plan): grown on demand, freed
+// with the plan; the contents do not survive a larger request
+void *fpmhip_plan_scratch(fpmhip_plan *p, size_t bytes)
+{
+    if (!p) return nullptr;
+    if (bytes > p->scratch_bytes) {
+        (void) hipSetDevice(p->device);
+        if (p->scratch) { (void) hipStreamSynchronize(p->stream); (void) hipFree(p->scratch); p->scratch = nullptr; p->scratch_bytes = 0; }
+        if (hipMalloc(&p->scratch, bytes) != hipSuccess) { set_error("plan scratch of %zu bytes: %s", bytes, hipGetErrorString(hipGetLastError())); return nullptr; }
+        p->scratch_bytes = bytes;
+    }
+    return p->scratch;
 }
 
 int fpmhip_sync(fpmhip_plan *p)

@@ -44,6 +44,7 @@
 // the sums are the same sums in another order (the tolerance class of the box-tile kernels).
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #include "fpm_cic.h"
 #include "fpm_fftcore.h"
@@ -456,7 +457,8 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FP
     MeshGeo g, int ncomp, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
     const double *__restrict__ sy, const double *__restrict__ sz, const int *__restrict__ sidx, const C2<F> *__restrict__ m0,
     const C2<F> *__restrict__ m1, const C2<F> *__restrict__ m2, float *__restrict__ out, int nmemb, int memb0,
-    const double *__restrict__ tw_global, double *__restrict__ part_all, long long part_stride, const int2 *__restrict__ scell)
+    const double *__restrict__ tw_global, double *__restrict__ part_all, long long part_stride, const int2 *__restrict__ scell,
+    PenIO pen)
 {
     using CF = StripCfg<PL, F>;
     constexpr int M = PL::N, RW = STRIP_RW, T = PL::T, E = PL::E, NT = CF::ro_threads, RP = CF::ro_pitch, WP = 2 * RP,
@@ -468,8 +470,8 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FP
     constexpr int CWX = WS ? -RP : RW, SKX = WS ? CF::ws_sk : SK;
     const int tid = threadIdx.x, c = WS ? tid / T : tid % RW, tau = WS ? tid % T : tid / RW;
     const int nseg = (g.xl + g.xseg - 1) / g.xseg;
-    const int t = xcd_remap(blockIdx.x, ncomp * g.nty * nseg);
-    const int comp = t % ncomp, strip = (t / ncomp) % g.nty, seg = nseg - 1 - t / (ncomp * g.nty);      // last segment first
+    const int t = xcd_remap(blockIdx.x, ncomp * g.ntyo * nseg);
+    const int comp = t % ncomp, strip = (t / ncomp) % g.ntyo, seg = nseg - 1 - t / (ncomp * g.ntyo);      // last segment first
     const C2<F> *mesh = comp == 0 ? m0 : (comp == 1 ? m1 : m2);
     double *part = part_all + comp * part_stride;
     const int xa = seg * g.xseg, xb = min(xa + g.xseg, g.xl);
@@ -480,8 +482,24 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FP
     const long long pstride = (long long) g.yplanes * g.rp;
 
     C2<F> x[E], xm;
+    // pencils (PenIO): the rows are where the (y <-> kz) exchange left them, cut into kz blocks; plane xl and row ylr are
+    // the neighbours' rows, in their own small buffers
+    const int yrow = y0 + c;
+    const C2<F> *phx = (const C2<F> *) pen.hx[comp], *phy = (const C2<F> *) pen.hy[comp];
     auto load_plane = [&](int xp) {                // plane xl of a slab is the halo plane the next rank sent
         if (g.periodic_x) xp -= xp >= g.N ? g.N : 0;
+        if (pen.on) {
+            const C2<F> *src;
+            bool chunked = false;
+            if (!g.periodic_x && xp == g.xl) src = phx + (long long) yrow * g.rp;
+            else if (yrow == g.ylr) src = phy + (long long) xp * g.rp;
+            else { src = mesh + ((long long) xp * g.ylr + yrow) * g.nzl; chunked = true; }
+            auto at = [&](int k) -> const C2<F> * { return chunked ? src + (k / g.zblk) * pen.chunk + k % g.zblk : src + k; };
+#pragma unroll
+            for (int j = 0; j < E; j++) x[j] = ld_stream(at(tau + T * j));
+            xm = tau == 0 ? *at(M) : C2<F>{0, 0};
+            return;
+        }
         const C2<F> *src = rowbase + (long long) xp * pstride;
 #if FPM_RO_PROBE == 4
         (void) src;
@@ -904,7 +922,7 @@ template <int M, typename F> struct PairLaunch<M, F, true> {
 
 template <typename F>
 static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1, const void *k2, int ncomp, float *out,
-                                 int nmemb, int memb0)
+                                 int nmemb, int memb0, const PenIO &pen)
 {
     MeshGeo g = p->mg;
     // ONE plane in LDS with wave-local transforms (WS) wherever a row's threads fit one wave (T = M / 8 divides 64: the
@@ -918,14 +936,15 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
     static const int ws_env = getenv("FPMHIP_RO_WS") ? atoi(getenv("FPMHIP_RO_WS")) : -1;
     const int T_ = g.N / 2 / 8;                               // threads per row of the E = 8 row plans
     const bool ws_ok = 64 % T_ == 0;
-    const bool two_planes = win_env == 2 ? StripTwoPlanes<F>::fits(g.N / 2, 1)
+    // (pencils: the marching one-plane kernel is the one that reads the exchange chunks)
+    const bool two_planes = pen.on ? false : win_env == 2 ? StripTwoPlanes<F>::fits(g.N / 2, 1)
                           : (win_env == 1 ? false : (!ws_ok && StripTwoPlanes<F>::fits(g.N / 2, 3)));
     const bool use_ws = ws_ok && (ws_env >= 0 ? ws_env != 0 : !two_planes);
     static const int late_env = getenv("FPMHIP_RO_LATE") ? atoi(getenv("FPMHIP_RO_LATE")) : 1;        // 0: A/B
     const bool late = late_env != 0;
     // two rows per transform (readout_pair_kernel): FPMHIP_RO_PAIR = 0 | 1 forces (A/B)
     static const int pair_env = getenv("FPMHIP_RO_PAIR") ? atoi(getenv("FPMHIP_RO_PAIR")) : -1;
-    const bool pair = pair_env >= 0 ? pair_env != 0 : false;
+    const bool pair = !pen.on && (pair_env >= 0 ? pair_env != 0 : false);
     // the half sums of a dense tile's entries beyond the first two per thread: one double per own entry and component
     const long long part_stride = p->ro_part_elems;
 #define CALL_RO_W(PL, WS_)                                                                                             \
@@ -943,20 +962,20 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
                 (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->scell);                    \
         } else if (WS_ && (PL::N >= 512 || (PL::N == 256 && sizeof(F) == 4)) && late) {                                                                      \
             FPM_TRY(grant_lds(readout_march_kernel<PL, F, WS_, (WS_ && (PL::N >= 512 || (PL::N == 256 && sizeof(F) == 4)))>, CF::ro1_lds, p->device));       \
-            g.xseg = choose_xseg(g, readout_march_kernel<PL, F, WS_, (WS_ && (PL::N >= 512 || (PL::N == 256 && sizeof(F) == 4)))>, CF::ro_threads, CF::ro1_lds, ncomp * g.nty, 16, 128, &occ0); \
+            g.xseg = choose_xseg(g, readout_march_kernel<PL, F, WS_, (WS_ && (PL::N >= 512 || (PL::N == 256 && sizeof(F) == 4)))>, CF::ro_threads, CF::ro1_lds, ncomp * g.ntyo, 16, 128, &occ0); \
             const int nseg = (g.xl + g.xseg - 1) / g.xseg;                                                             \
-            readout_march_kernel<PL, F, WS_, (WS_ && (PL::N >= 512 || (PL::N == 256 && sizeof(F) == 4)))><<<ncomp * g.nty * nseg, CF::ro_threads, CF::ro1_lds, p->stream>>>( \
+            readout_march_kernel<PL, F, WS_, (WS_ && (PL::N >= 512 || (PL::N == 256 && sizeof(F) == 4)))><<<ncomp * g.ntyo * nseg, CF::ro_threads, CF::ro1_lds, p->stream>>>( \
                 g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                 \
                 (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride,      \
-                p->scell);                                                                                             \
+                p->scell, pen);                                                                                        \
         } else {                                                                                                       \
             FPM_TRY(grant_lds(readout_march_kernel<PL, F, WS_>, CF::ro1_lds, p->device));                              \
-            g.xseg = choose_xseg(g, readout_march_kernel<PL, F, WS_>, CF::ro_threads, CF::ro1_lds, ncomp * g.nty, 16, 128, &occ1); \
+            g.xseg = choose_xseg(g, readout_march_kernel<PL, F, WS_>, CF::ro_threads, CF::ro1_lds, ncomp * g.ntyo, 16, 128, &occ1); \
             const int nseg = (g.xl + g.xseg - 1) / g.xseg;                                                             \
-            readout_march_kernel<PL, F, WS_><<<ncomp * g.nty * nseg, CF::ro_threads, CF::ro1_lds, p->stream>>>(        \
+            readout_march_kernel<PL, F, WS_><<<ncomp * g.ntyo * nseg, CF::ro_threads, CF::ro1_lds, p->stream>>>(        \
                 g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                 \
                 (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride,      \
-                p->scell);                                                                                             \
+                p->scell, pen);                                                                                        \
         }                                                                                                              \
     }
 #define CALL_RO(PL)                                                                                                    \
@@ -971,16 +990,59 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
 // out[row * nmemb + memb0 + q] = CIC readout of c2r_z(k_q) at the particle, q < ncomp: k_q are meshes that have been
 // through the x and y passes of pm_c2r ([x][y][kz] half-spectrum rows); the z pass happens in LDS.
 int readout_strips_zc2r(fpmhip_plan *p, const fpmhip_particles *pt, const void *k0, const void *k1, const void *k2, int ncomp,
-                        float *out, int nmemb, int memb0)
+                        float *out, int nmemb, int memb0, const PenIO *pen_)
 {
+    PenIO pen = {};
+    if (pen_) pen = *pen_;
+    if (!p->mg.periodic_y && !pen.on) FPM_FAIL(-1, "internal: on pencils the z pass + readout reads the exchange chunks (fpmhip_readout3_zc2r_pen)");
     if (!p->mg.strips) FPM_FAIL(-1, "internal: readout_strips on a plan with box tiles");
     if (ncomp < 1 || ncomp > 3) FPM_FAIL(-1, "internal: 1 to 3 meshes");
     if (pt->np == 0) return 0;
     if (p->binned_x != pt->x || p->binned_np != pt->np) FPM_TRY(bin_particles(p, pt));
     else if (!p->bin_trusted) FPM_TRY(reuse_binning(p, pt));
     StageTimer tm(p, FPMHIP_T_READOUT);
-    return p->f64 ? readout_strips_launch<double>(p, k0, k1, k2, ncomp, out, nmemb, memb0)
-                  : readout_strips_launch<float>(p, k0, k1, k2, ncomp, out, nmemb, memb0);
+    return p->f64 ? readout_strips_launch<double>(p, k0, k1, k2, ncomp, out, nmemb, memb0, pen)
+                  : readout_strips_launch<float>(p, k0, k1, k2, ncomp, out, nmemb, memb0, pen);
+}
+
+// Plain half-spectrum rows <-> the exchange-A chunks of a pencil plan (PenIO): rows[r][k], k <= N/2, is row
+// (x, y) = (0, r) [which = 0: plane 0, r < ylr] or (r, 0) [which = 1: row 0 of the planes r < xl].  op 0: A += rows (the
+// neighbour's halo plane / halo row after the paint); op 1: rows = A (what the neighbour needs before the readout).
+template <typename F>
+__global__ __launch_bounds__(256) void pen_rows_kernel(MeshGeo g, long long chunk, C2<F> *__restrict__ A, C2<F> *__restrict__ rows,
+                                                       int nrows, int which, int op)
+{
+    const int nk = g.N / 2 + 1;
+    const long long idx = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long) nrows * nk) return;
+    const int r = (int) (idx / nk), k = (int) (idx - (long long) r * nk);
+    const int x = which ? r : 0, y = which ? 0 : r;
+    C2<F> *a = A + (k / g.zblk) * chunk + ((long long) x * g.ylr + y) * g.nzl + k % g.zblk;
+    C2<F> *b = rows + (long long) r * g.rp + k;
+    if (op == 0) { a->x += b->x; a->y += b->y; }
+    else *b = *a;
+}
+
+template <typename F>
+__global__ __launch_bounds__(256) void row_add_kernel(C2<F> *__restrict__ dst, const C2<F> *__restrict__ src, long long n)
+{
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { dst[i].x += src[i].x; dst[i].y += src[i].y; }
+}
+
+static int pen_io(fpmhip_plan *p, void *const *hx, void *const *hy, int n, PenIO *pen)
+{
+    if (!p->mg.strips || p->mg.periodic_y) FPM_FAIL(-1, "this call is for pencil plans (nranks_y > 1) with strip tiles");
+    memset(pen, 0, sizeof(*pen));
+    pen->on = 1;
+    pen->chunk = p->lay.chunk_a_elems / 2;
+    for (int i = 0; i < n; i++) {
+        if (!hy || !hy[i]) FPM_FAIL(-1, "null y-halo rows");
+        if (!p->mg.periodic_x && (!hx || !hx[i])) FPM_FAIL(-1, "null x-halo plane");
+        pen->hx[i] = hx ? hx[i] : nullptr;
+        pen->hy[i] = hy[i];
+    }
+    return 0;
 }
 
 }  // namespace fpm
@@ -988,6 +1050,67 @@ int readout_strips_zc2r(fpmhip_plan *p, const fpmhip_particles *pt, const void *
 using namespace fpm;
 
 extern "C" {
+
+// ---- pencil plans with strip tiles: the marching kernels on the exchange-A chunks (PenIO, fpm_internal.h) ----
+int fpmhip_paint_zr2c_pen(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void *a_send, void *hx, void *hy)
+{
+    if (!p || !pt || !a_send) FPM_FAIL(-1, "null argument");
+    if (pt->np < 0 || (pt->np > 0 && !pt->x)) FPM_FAIL(-1, "particles without positions");
+    (void) hipSetDevice(p->device);
+    PenIO pen;
+    FPM_TRY(pen_io(p, &hx, &hy, 1, &pen));
+    return paint_strips(p, pt, scale, a_send, 0, true, &pen);
+}
+
+int fpmhip_readout3_zc2r_pen(fpmhip_plan *p, const fpmhip_particles *pt, const void *k0, const void *k1, const void *k2,
+                             void *const *hx, void *const *hy)
+{
+    if (!p || !pt || !k0 || !k1 || !k2) FPM_FAIL(-1, "null argument");
+    if (pt->np < 0 || (pt->np > 0 && (!pt->x || !pt->acc))) FPM_FAIL(-1, "particles without positions or an acc column");
+    (void) hipSetDevice(p->device);
+    PenIO pen;
+    FPM_TRY(pen_io(p, hx, hy, 3, &pen));
+    return readout_strips_zc2r(p, pt, k0, k1, k2, 3, pt->acc, 3, 0, &pen);
+}
+
+int fpmhip_readout1_zc2r_pen(fpmhip_plan *p, const fpmhip_particles *pt, const void *k, void *hx, void *hy, float *out,
+                             int nmemb, int memb)
+{
+    if (!p || !pt || !k || (!out && pt->np > 0)) FPM_FAIL(-1, "null argument");
+    if (pt->np < 0 || (pt->np > 0 && !pt->x)) FPM_FAIL(-1, "particles without positions");
+    if (memb < 0 || memb >= nmemb) FPM_FAIL(-1, "memb %d greater than nmemb %d", memb, nmemb);
+    (void) hipSetDevice(p->device);
+    PenIO pen;
+    FPM_TRY(pen_io(p, &hx, &hy, 1, &pen));
+    return readout_strips_zc2r(p, pt, k, nullptr, nullptr, 1, out, nmemb, memb, &pen);
+}
+
+int fpmhip_pen_halo_rows(fpmhip_plan *p, void *a_chunks, void *rows, int which, int op)
+{
+    if (!p || !a_chunks || !rows) FPM_FAIL(-1, "null argument");
+    if (!p->mg.strips || p->mg.periodic_y) FPM_FAIL(-1, "fpmhip_pen_halo_rows is for pencil plans with strip tiles");
+    if (which < 0 || which > 1 || op < 0 || op > 1) FPM_FAIL(-1, "which / op out of range");
+    (void) hipSetDevice(p->device);
+    StageTimer tm(p, FPMHIP_T_HALO);
+    const int nrows = which ? p->mg.xl : p->mg.ylr;
+    const long long n = (long long) nrows * (p->mg.N / 2 + 1);
+    const long long chunk = p->lay.chunk_a_elems / 2;
+    if (p->f64) pen_rows_kernel<double><<<(unsigned) ((n + 255) / 256), 256, 0, p->stream>>>(p->mg, chunk, (C2<double> *) a_chunks, (C2<double> *) rows, nrows, which, op);
+    else pen_rows_kernel<float><<<(unsigned) ((n + 255) / 256), 256, 0, p->stream>>>(p->mg, chunk, (C2<float> *) a_chunks, (C2<float> *) rows, nrows, which, op);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int fpmhip_row_add(fpmhip_plan *p, void *dst, const void *src, int64_t ncomplex)
+{
+    if (!p || !dst || !src || ncomplex < 0) FPM_FAIL(-1, "null argument");
+    if (ncomplex == 0) return 0;
+    (void) hipSetDevice(p->device);
+    if (p->f64) row_add_kernel<double><<<(unsigned) ((ncomplex + 255) / 256), 256, 0, p->stream>>>((C2<double> *) dst, (const C2<double> *) src, ncomplex);
+    else row_add_kernel<float><<<(unsigned) ((ncomplex + 255) / 256), 256, 0, p->stream>>>((C2<float> *) dst, (const C2<float> *) src, ncomplex);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 
 // The stage calls of a strip plan, for the sequences that drive the stages around their exchanges (slabs: the mesh
 // halo and the transposes -- fastpm_amd/distributed.py, fastpm_amd/host/fastpm_slab_hip.c).

@@ -579,6 +579,14 @@ class PencilForce(_PencilRank):
         self.scalar[0] = pm.total_mass(store)                              # gravity.c:330-342
         yield ("allreduce", self.scalar)
         mean_mass_per_cell = float(self.scalar.item()) / pm.Norm
+        fuse_x = dealias == 0
+        # Strip tiles (round 4): the paint runs on into the z pass and writes the exchange-A chunks itself, the readout
+        # reads the received chunks and runs the z pass -- no real mesh, no pack / unpack pass; the halo plane and the
+        # halo rows travel as half-spectrum rows (the z pass is linear).  With a softening kernel the real canvas stays.
+        strips = bool(getattr(pm, "strips", lambda: False)()) and fuse_x and pm.nranks_y > 1 and _gradorder(kernel) == 1
+        if strips:
+            yield from self._strip_steps(store, kernel, delta_k, mean_mass_per_cell)
+            return
         yield from self._agreed(lambda: pm.paint(c, store, 1.0 / mean_mass_per_cell))   # gravity.c:336-345
         yield from self._halo_out(c)
 
@@ -586,7 +594,6 @@ class PencilForce(_PencilRank):
         yield from self._a(w[1], w[0])
         pm.fft_y_forward(w[1], w[0])
         yield from self._b(delta_k, w[0])
-        fuse_x = dealias == 0
         if not fuse_x:
             pm.fft_x_forward(delta_k)
             pm.apply_softening_transfer(dealias, delta_k)                  # gravity.c:476
@@ -640,6 +647,67 @@ class PencilForce(_PencilRank):
         pm.readout3(meshes[:3], store)
         if store.potential is not None:
             pm.readout(meshes[3], store, store.potential, 1, 0)
+
+    def _strip_halo_buffers(self, nmesh):
+        """per mesh: hx sent / received (plane x_loc: [y_loc + 1][rp]) and hy sent / received (row y_loc: [x_loc][rp])"""
+        if getattr(self, "_hbuf", None) is None or len(self._hbuf) < nmesh:
+            pm = self.pm
+            L = pm.layout
+            xl, ylr, rp2 = int(L.isize[0]), int(L.isize[1]), int(L.istrides[1])
+            mk = lambda n: torch.zeros(n, dtype=self.c.dtype, device=self.c.device)
+            self._hbuf = [dict(hxs=mk((ylr + 1) * rp2), hxr=mk((ylr + 1) * rp2), hys=mk(xl * rp2), hyr=mk(xl * rp2))
+                          for _ in range(nmesh)]
+        return self._hbuf
+
+    def _strip_steps(self, store, kernel, delta_k, mean_mass_per_cell):
+        pm = self.pm
+        c, w = self.c, self.w
+        L = pm.layout
+        xl, ylr, rp2 = int(L.isize[0]), int(L.isize[1]), int(L.istrides[1])
+        rp = rp2 // 2
+        has_x, has_pot = pm.nranks_x > 1, store.potential is not None
+        hb = self._strip_halo_buffers(4 if has_pot else 3)
+        h0 = hb[0]
+        # paint + z r2c into the exchange-A chunks (w[0]); plane x_loc -> hxs, row y_loc -> hys
+        yield from self._agreed(lambda: pm.paint_zr2c_pen(w[0], store, 1.0 / mean_mass_per_cell,
+                                                          h0["hxs"] if has_x else None, h0["hys"]))
+        if has_x:                                                          # x plane first: it carries the corner row
+            yield ("shift_g", [(h0["hxs"], h0["hxr"], +1, "x")])
+            pm.pen_halo_rows(w[0], h0["hxr"], 0, 0)
+            pm.row_add(h0["hys"][:rp2], h0["hxr"][ylr * rp2:], rp)
+        yield ("shift_g", [(h0["hys"], h0["hyr"], +1, "y")])
+        pm.pen_halo_rows(w[0], h0["hyr"], 1, 0)
+        yield from self._a(w[1], w[0])                                     # pm_r2c from its y pass on
+        pm.fft_y_forward(w[1], w[0])
+        yield from self._b(delta_k, w[0])
+        pm.fft_x_forward_transfer_backward(kernel, delta_k, 2, [w[0], w[1]])
+        yield from self._b(w[2], w[1])                                     # potential
+        yield from self._b(w[3], w[0])                                     # x component
+        potmesh = w[4] if has_pot else None                                # gravity.c:487-492 rides along
+        pm.fft_y_backward_grad2(kernel, w[2], w[0], w[1], out_pot_a=potmesh)
+        pm.fft_y_backward(w[3], w[2])
+        # (x, y, z [, potential]) in A layout: w[2], w[0], w[1] [, w[4]]; the received chunks ARE the meshes the readout takes
+        yield from self._a(c, w[2])
+        yield from self._a(w[3], w[0])
+        yield from self._a(w[2], w[1])
+        meshes = [c, w[3], w[2]]
+        if has_pot:
+            yield from self._a(w[0], w[4])
+            meshes.append(w[0])
+        # the neighbours' rows: y first, then the x plane with the fresh corner row
+        for m, h in zip(meshes, hb):
+            pm.pen_halo_rows(m, h["hys"], 1, 1)
+        yield ("shift_g", [(h["hys"], h["hyr"], -1, "y") for h in hb[:len(meshes)]])
+        if has_x:
+            for m, h in zip(meshes, hb):
+                pm.pen_halo_rows(m, h["hxs"], 0, 1)
+                h["hxs"][ylr * rp2:(ylr + 1) * rp2].copy_(h["hyr"][:rp2])
+            yield ("shift_g", [(h["hxs"], h["hxr"], -1, "x") for h in hb[:len(meshes)]])
+        hx = [(h["hxr"] if has_x else None) for h in hb]
+        hy = [h["hyr"] for h in hb]
+        pm.readout3_zc2r_pen(meshes[:3], store, hx[:3], hy[:3])
+        if has_pot:
+            pm.readout_zc2r_pen(meshes[3], store, hx[3], hy[3], store.potential, 1, 0)
 
     def compute_force(self, store, kernel="1_4", dealias="none", delta_k=None):
         self._run_step(self.steps(store, kernel, dealias, delta_k))

@@ -290,6 +290,80 @@ static int halo_in(fpmhip_plan *plan, const fastpm_hip_transport *t, const mesh_
     return 0;
 }
 
+/* the force step on a pencil plan with strip tiles; c, w: the plan's mesh buffers as pencil_force_species names them */
+static int pencil_strip_force(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_layout *lay, const mesh_groups *g,
+                              const fpmhip_particles *set, int kernel, void *delta_k, void *c, void **w)
+{
+    const size_t es = (size_t) lay->precision / 8;
+    const size_t a_bytes = (size_t) lay->chunk_a_elems * es, b_bytes = (size_t) lay->chunk_b_elems * es;
+    const int64_t xl = lay->isize[0], ylr = lay->isize[1], rp2 = lay->istrides[1];
+    const size_t row_bytes = (size_t) rp2 * es, hx_bytes = (size_t) (ylr + 1) * row_bytes, hy_bytes = (size_t) xl * row_bytes;
+    const int has_x = g->Nx > 1, has_pot = set->potential != NULL, nm = has_pot ? 4 : 3;
+    /* per mesh: hx sent | hx received | hy sent | hy received */
+    const size_t per = 2 * hx_bytes + 2 * hy_bytes;
+    char *hb = fpmhip_plan_scratch(plan, 4 * per);
+    if (!hb) return -2;
+    char *hxs[4], *hxr[4], *hys[4], *hyr[4];
+    for (int m = 0; m < 4; m++) {
+        hxs[m] = hb + m * per; hxr[m] = hxs[m] + hx_bytes; hys[m] = hxr[m] + hx_bytes; hyr[m] = hys[m] + hy_bytes;
+    }
+    /* gravity.c:330-345: total mass over the ranks, then paint x 1 / mean mass per cell; a rank-local failure (a
+     * particle outside this rank's region) is agreed on before the next collective */
+    double total = 0;
+    TRY(fpmhip_total_mass(plan, set, &total));
+    TRY(t->allreduce_sum(t->ctx, &total));
+    int rc = fpmhip_paint_zr2c_pen(plan, set, 1.0 / (total / lay->Norm), w[0], has_x ? hxs[0] : NULL, hys[0]);
+    double failed = rc != 0;
+    TRY(t->allreduce_sum(t->ctx, &failed));
+    if (failed != 0) return rc ? rc : -8;
+    if (has_x) {                                    /* the x plane first: it carries the corner row */
+        TRY(fpmhip_sync(plan));
+        TRY(t->sendrecv(t->ctx, hxs[0], neighbour(g, 1, +1), hxr[0], neighbour(g, 1, -1), hx_bytes));
+        TRY(fpmhip_pen_halo_rows(plan, w[0], hxr[0], 0, 0));
+        TRY(fpmhip_row_add(plan, hys[0], hxr[0] + (size_t) ylr * row_bytes, rp2 / 2));
+    }
+    TRY(fpmhip_sync(plan));
+    TRY(t->sendrecv(t->ctx, hys[0], neighbour(g, 0, +1), hyr[0], neighbour(g, 0, -1), hy_bytes));
+    TRY(fpmhip_pen_halo_rows(plan, w[0], hyr[0], 1, 0));
+    TRY(fpmhip_check_point(plan, w[0], "After painting"));                        /* gravity.c:350 */
+    TRY(exchange_axis(plan, t, g, 0, w[0], w[1], a_bytes));                       /* pm_r2c from its y pass on */
+    TRY(fpmhip_fft_y_forward(plan, w[1], w[0]));
+    TRY(exchange_axis(plan, t, g, 1, w[0], delta_k, b_bytes));
+    TRY(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 2, w[0], w[1], NULL));
+    TRY(exchange_axis(plan, t, g, 1, w[1], w[2], b_bytes));                       /* potential */
+    TRY(exchange_axis(plan, t, g, 1, w[0], w[3], b_bytes));                       /* x component */
+    void *potmesh = has_pot ? w[4] : NULL;                                        /* gravity.c:487-492 rides along */
+    TRY(fpmhip_fft_y_backward_grad2(plan, w[2], w[0], w[1], potmesh, kernel));
+    TRY(fpmhip_fft_y_backward(plan, w[3], w[2]));
+    /* (x, y, z [, potential]) in A layout: w[2], w[0], w[1] [, w[4]]; the received chunks are what the readout takes */
+    void *mesh[4] = {c, w[3], w[2], has_pot ? w[0] : NULL};
+    TRY(exchange_axis(plan, t, g, 0, w[2], c, a_bytes));
+    TRY(exchange_axis(plan, t, g, 0, w[0], w[3], a_bytes));
+    TRY(exchange_axis(plan, t, g, 0, w[1], w[2], a_bytes));
+    if (has_pot) TRY(exchange_axis(plan, t, g, 0, w[4], w[0], a_bytes));
+    /* the neighbours' rows: y first, then the x plane with the fresh corner row */
+    for (int m = 0; m < nm; m++) {
+        TRY(fpmhip_pen_halo_rows(plan, mesh[m], hys[m], 1, 1));
+        TRY(fpmhip_sync(plan));
+        TRY(t->sendrecv(t->ctx, hys[m], neighbour(g, 0, -1), hyr[m], neighbour(g, 0, +1), hy_bytes));
+        if (has_x) {
+            TRY(fpmhip_pen_halo_rows(plan, mesh[m], hxs[m], 0, 1));
+            TRY(fpmhip_memcpy_d2d(plan, hxs[m] + (size_t) ylr * row_bytes, hyr[m], row_bytes));
+            TRY(fpmhip_sync(plan));
+            TRY(t->sendrecv(t->ctx, hxs[m], neighbour(g, 1, -1), hxr[m], neighbour(g, 1, +1), hx_bytes));
+        }
+    }
+    {
+        void *cm[4] = {mesh[0], mesh[1], mesh[2], NULL};
+        TRY(check_force_meshes(plan, delta_k, cm));
+    }
+    void *hx3[3] = {has_x ? hxr[0] : NULL, has_x ? hxr[1] : NULL, has_x ? hxr[2] : NULL}, *hy3[3] = {hyr[0], hyr[1], hyr[2]};
+    TRY(fpmhip_readout3_zc2r_pen(plan, set, mesh[0], mesh[1], mesh[2], hx3, hy3));
+    if (has_pot)
+        TRY(fpmhip_readout1_zc2r_pen(plan, set, mesh[3], has_x ? hxr[3] : NULL, hyr[3], set->potential, 1, 0));
+    return 0;
+}
+
 static int pencil_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_layout *lay,
                                 const fpmhip_particles *sets, int nsets, int kernel, int softening, void *delta_k)
 {
@@ -307,6 +381,12 @@ static int pencil_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t
                   fpmhip_plan_buffer(plan, B_XCHG), fpmhip_plan_buffer(plan, B_XCHG2)};
     if (!delta_k) delta_k = fpmhip_plan_buffer(plan, B_DELTA_K);
     if (!c || !w[0] || !w[1] || !w[2] || !w[3] || !w[4] || !delta_k) return -2;
+
+    /* Strip tiles on pencils (fpmhip_plan_strips; one species, no softening kernel, gradorder 1): the paint runs on
+     * into the z pass and writes the exchange-A chunks, the readout reads the received chunks -- see the sequence in
+     * include/fastpm_hip.h (fpmhip_paint_zr2c_pen) and distributed.PencilForce._strip_steps */
+    if (fpmhip_plan_strips(plan) && nsets == 1 && softening == FPMHIP_SOFTENING_NONE && go == 1 && g.Ny > 1)
+        return pencil_strip_force(plan, t, lay, &g, &sets[0], kernel, delta_k, c, w);
 
     TRY(paint_species(plan, t, sets, nsets, lay->Norm, c, 0));                    /* gravity.c:323-345 */
     TRY(halo_out(plan, t, &g, lay, c, w[3]));

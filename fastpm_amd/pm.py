@@ -665,6 +665,30 @@ class PM:
     def readout_zc2r(self, mesh, store, out, nmemb=1, memb=0):
         check(self._L.fpmhip_readout1_zc2r(self._plan, ctypes.byref(store._c()), _ptr(mesh), _ptr(out), int(nmemb), int(memb)))
 
+    # -- pencils with strip tiles: the marching kernels on the exchange-A chunks (include/fastpm_hip.h) ----------------
+    def paint_zr2c_pen(self, a_send, store, scale, hx, hy):
+        check(self._L.fpmhip_paint_zr2c_pen(self._plan, ctypes.byref(store._c()), float(scale), _ptr(a_send),
+                                            _ptr(hx) if hx is not None else None, _ptr(hy)))
+
+    def _ptrs(self, bufs):
+        arr = (ctypes.c_void_p * len(bufs))(*[(_ptr(b) if b is not None else None) for b in bufs])
+        return arr
+
+    def readout3_zc2r_pen(self, meshes, store, hx, hy):
+        check(self._L.fpmhip_readout3_zc2r_pen(self._plan, ctypes.byref(store._c()), *[_ptr(m) for m in meshes[:3]],
+                                               self._ptrs(hx), self._ptrs(hy)))
+
+    def readout_zc2r_pen(self, mesh, store, hx, hy, out, nmemb=1, memb=0):
+        check(self._L.fpmhip_readout1_zc2r_pen(self._plan, ctypes.byref(store._c()), _ptr(mesh),
+                                               _ptr(hx) if hx is not None else None, _ptr(hy), _ptr(out), int(nmemb), int(memb)))
+
+    def pen_halo_rows(self, a_chunks, rows, which, op):
+        """which 0: plane 0 (rows y < y_loc), 1: row 0 of the planes x < x_loc; op 0: chunks += rows, 1: rows = chunks"""
+        check(self._L.fpmhip_pen_halo_rows(self._plan, _ptr(a_chunks), _ptr(rows), int(which), int(op)))
+
+    def row_add(self, dst, src, ncomplex):
+        check(self._L.fpmhip_row_add(self._plan, _ptr(dst), _ptr(src), int(ncomplex)))
+
     def fft_y_forward_range(self, zrows, send, x0, nx):
         check(self._L.fpmhip_fft_y_forward_range(self._plan, _ptr(zrows), _ptr(send), int(x0), int(nx)))
 

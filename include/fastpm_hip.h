@@ -160,6 +160,8 @@ int  fpmhip_plan_layout(const fpmhip_plan *plan, fpmhip_layout *out);
 int  fpmhip_plan_set_stream(fpmhip_plan *plan, void *stream);
 /* plan-owned mesh buffers: 0 = canvas, 1 = delta_k, 2..4 = force components, 5, 6 = exchange */
 void *fpmhip_plan_buffer(fpmhip_plan *plan, int which);
+/* a plan-owned device scratch of at least `bytes` (grown on demand, freed with the plan; a larger request may move it) */
+void *fpmhip_plan_scratch(fpmhip_plan *plan, size_t bytes);
 int  fpmhip_sync(fpmhip_plan *plan);
 
 /* ---- the whole force step, one rank (nranks == 1): gravity.c:458-529 ----
@@ -476,6 +478,25 @@ int fpmhip_readout3_zc2r(fpmhip_plan *plan, const fpmhip_particles *p_dev, const
 /* ... of one mesh into out[i * nmemb + memb] (the potential column, gravity.c:487-492) */
 int fpmhip_readout1_zc2r(fpmhip_plan *plan, const fpmhip_particles *p_dev, const void *k_dev, float *out_dev, int nmemb,
                          int memb);
+/* ---- the same on PENCILS (nranks_y > 1; fpmhip_plan_strips() != 0 when the local rows are whole strips): the marching
+ *      kernels write / read the half-spectrum rows where the (y <-> kz) exchange "A" wants / leaves them -- row (x, y) cut
+ *      into kz blocks, block b at b * (chunk_a_elems / 2) + (x * y_loc + y) * osize[2] complex values -- so neither a pack
+ *      nor an unpack pass exists.  The rows that belong to the neighbours travel as plain rows of `rp` = istrides[1] / 2
+ *      complex values: hx = plane x_loc as [y_loc + 1][rp] (its last row is the corner; unused when nranks_x == 1),
+ *      hy = row y_loc of the planes [0, x_loc) as [x_loc][rp].  Sequence (distributed.PencilForce, fastpm_slab_hip.c):
+ *        paint_zr2c_pen -> hx to rank_x + 1: pen_halo_rows(A, hx', 0, add) and row_add(hy[0], hx'[y_loc]) -> hy to
+ *        rank_y + 1: pen_halo_rows(A, hy', 1, add) -> exchange A -> fft_y_forward ... fft_y_backward* -> exchange A ->
+ *        per force mesh: pen_halo_rows(R, hy, 1, extract) to rank_y - 1; pen_halo_rows(R, hx, 0, extract) + its corner row
+ *        = the hy just received for plane 0, to rank_x - 1 -> readout3_zc2r_pen(R0, R1, R2, hx[3], hy[3]). ---- */
+int fpmhip_paint_zr2c_pen(fpmhip_plan *plan, const fpmhip_particles *p_dev, double scale, void *a_send_dev, void *hx_dev,
+                          void *hy_dev);
+int fpmhip_readout3_zc2r_pen(fpmhip_plan *plan, const fpmhip_particles *p_dev, const void *k0_dev, const void *k1_dev,
+                             const void *k2_dev, void *const *hx_dev, void *const *hy_dev);
+int fpmhip_readout1_zc2r_pen(fpmhip_plan *plan, const fpmhip_particles *p_dev, const void *k_dev, void *hx_dev, void *hy_dev,
+                             float *out_dev, int nmemb, int memb);
+/* which = 0: plane 0 (rows y < y_loc), 1: row 0 of the planes x < x_loc; op = 0: chunks += rows, 1: rows = chunks */
+int fpmhip_pen_halo_rows(fpmhip_plan *plan, void *a_chunks_dev, void *rows_dev, int which, int op);
+int fpmhip_row_add(fpmhip_plan *plan, void *dst_dev, const void *src_dev, int64_t ncomplex);
 /* the y passes alone, for the x planes [x0, x0 + nx): forward from half-spectrum rows into the exchange chunks, backward
  * from the received chunks into half-spectrum rows (plain, or the potential -> y and z components [+ the potential]) */
 int fpmhip_fft_y_forward_range(fpmhip_plan *plan, void *zrows_dev, void *send_dev, int x0, int nx);

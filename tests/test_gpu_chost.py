@@ -367,6 +367,65 @@ def test_c_host_pencil_force_two_species_matches_one_rank_oracle(oracle, Nx, Ny,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("Nx,Ny,precision", [(2, 2, 64), (4, 2, 64), (1, 2, 32)])
+def test_c_host_pencil_force_with_strip_tiles_matches_one_rank_oracle(oracle, Nx, Ny, precision):
+    """pencil_strip_force (fastpm_slab_hip.c): one species on a pencil plan with strip tiles -- the paint writes the
+    exchange-A chunks, the halo plane / rows travel as half-spectrum rows through sendrecv, the readout reads the received
+    chunks; with the potential column; one host thread per rank.  Two calls (steady-state binning)."""
+    import threading
+    import torch
+    from fastpm_amd import PM, Store
+    from fastpm_amd.pm import KERNEL_TYPES
+    H = _host()
+    H.fastpm_hip_loopback_create.restype = ctypes.POINTER(Transport)
+    H.fastpm_hip_loopback_create.argtypes = [ctypes.c_int]
+    H.fastpm_hip_loopback_bind.argtypes = [ctypes.POINTER(Transport), ctypes.c_void_p]
+    H.fastpm_hip_loopback_destroy.argtypes = [ctypes.POINTER(Transport)]
+    H.fastpm_hip_mesh_force_species.argtypes = [ctypes.c_void_p, ctypes.POINTER(Transport), ctypes.c_void_p, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    N, nc, L, P = 64, 32, 96.0, Nx * Ny
+    x = util.load_b(nc, L, N)
+    pmo = oracle.PMOracle(N, L, precision)
+    ref = oracle.compute_force(pmo, x, potential=True)
+    h = L / N
+    own = ((np.floor(x[:, 0] / h).astype(np.int64) % N) // (N // Nx)) * Ny + (np.floor(x[:, 1] / h).astype(np.int64) % N) // (N // Ny)
+    idx = [np.nonzero(own == r)[0] for r in range(P)]
+    pms = [PM(N, L, precision, nranks=P, rank=r, nranks_y=Ny, paint_mode=3) for r in range(P)]
+    assert all(pm.strips() for pm in pms)
+    stores = [Store(x[idx[r]], potential=True) for r in range(P)]
+    tol = 1e-6 if precision == 64 else 2e-5
+    for call in range(2):
+        tr = H.fastpm_hip_loopback_create(P)
+        rcs = [None] * P
+
+        def rank_main(r):
+            torch.cuda.set_device(0)
+            H.fastpm_hip_loopback_bind(ctypes.byref(tr[r]), pms[r]._plan)
+            part = stores[r]._c()
+            rcs[r] = H.fastpm_hip_mesh_force_species(pms[r]._plan, ctypes.byref(tr[r]), ctypes.byref(part), 1,
+                                                     KERNEL_TYPES["1_4"], 0, None)
+
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+        assert all(not t.is_alive() for t in threads), "a rank hung"
+        torch.cuda.synchronize()
+        assert rcs == [0] * P, rcs
+        H.fastpm_hip_loopback_destroy(tr)
+        acc = np.zeros_like(ref["acc"])
+        pot = np.zeros_like(ref["potential"])
+        for r in range(P):
+            acc[idx[r]] = stores[r].acc.cpu().numpy()
+            pot[idx[r]] = stores[r].potential.cpu().numpy()
+            stores[r].acc.zero_()
+        assert util.rel_err(acc, ref["acc"]) <= tol and util.rel_err(pot, ref["potential"]) <= tol
+    for pm in pms:
+        pm.destroy()
+
+
+@pytest.mark.gpu
 def test_plain_c_program_runs_the_force(oracle, tmp_path):
     """fastpm_amd/host/example_force.c: gcc, no Python in the process -- the C host library and the HIP library
     only.  Its printed accelerations must be the oracle's for the same (closed-form) particle positions."""

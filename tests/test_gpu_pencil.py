@@ -253,3 +253,94 @@ def test_pencil_r2c_c2r_stand_alone(oracle, Nx, Ny):
         got = pm.real_view(d)[:xl, :yl, :N].cpu().numpy()
         assert np.abs(got - real[x0:x0 + xl, y0:y0 + yl]).max() <= 1e-12
         pm.destroy()
+
+
+# ---- strip tiles on pencils (round 4): the marching kernels on the exchange-A chunks ---------------------------------
+@pytest.mark.parametrize("Nx,Ny,N,precision", [(2, 2, 32, 64), (4, 2, 32, 64), (1, 2, 32, 64), (2, 4, 64, 64), (2, 2, 64, 32),
+                                               (4, 2, 64, 32)])
+def test_virtual_pencil_ranks_with_strip_tiles_match_the_one_rank_oracle(oracle, Nx, Ny, N, precision):
+    """PM(..., nranks_y = Ny, paint_mode = 3): the paint writes the half-spectrum rows straight into the (y <-> kz)
+    exchange chunks (plane x_loc and row y_loc into their halo buffers), the readout reads the received chunks and runs
+    the z pass -- no real mesh between the particle kernels and the y passes.  Two force calls (the second in the
+    binning's steady state), accelerations, potential and delta_k against the ONE-rank oracle."""
+    import torch
+    from fastpm_amd import PM, Store
+    from fastpm_amd.distributed import PencilForce, run_virtual
+    nc, L = N // 2, 1.5 * N
+    P = Nx * Ny
+    x = util.load_b(nc, L, N, rms_cells=2.0)
+    pmo = oracle.PMOracle(N, L, precision)
+    ref = oracle.compute_force(pmo, x, potential=True)
+    own = _owner(x, N, L, Nx, Ny)
+    idx = [np.nonzero(own == r)[0] for r in range(P)]
+    pms = [PM(N, L, precision, nranks=P, rank=r, nranks_y=Ny, paint_mode=3) for r in range(P)]
+    assert all(pm.strips() for pm in pms)
+    stores = [Store(x[idx[r]], potential=True) for r in range(P)]
+    forces = [PencilForce(pm) for pm in pms]
+    dks = [pm.alloc() for pm in pms]
+    tol_acc, tol_dk = (1e-6, 1e-14) if precision == 64 else (2e-5, 5e-7)
+    for call in range(2):
+        for s in stores:
+            s.acc.zero_()
+            s.potential.zero_()
+        run_virtual(forces, stores, kernel="1_4", dealias="none", delta_ks=dks)
+        torch.cuda.synchronize()
+        acc = np.zeros_like(ref["acc"])
+        pot = np.zeros_like(ref["potential"])
+        for r in range(P):
+            acc[idx[r]] = stores[r].acc.cpu().numpy()
+            pot[idx[r]] = stores[r].potential.cpu().numpy()
+        assert util.max_err(_assemble_dk(pms, dks, N, Nx, Ny), util.oracle_k_to_xyk(pmo, ref["delta_k"])) <= tol_dk
+        assert util.rel_err(acc, ref["acc"]) <= tol_acc, call
+        assert util.rel_err(pot, ref["potential"]) <= tol_acc, call
+    assert all(getattr(f, "_hbuf", None) for f in forces)          # the strip sequence ran (its halo-row buffers exist)
+    for pm in pms:
+        pm.destroy()
+
+
+@pytest.mark.parametrize("kernel,dealias", [("3_4", "none"), ("eastwood", "none"), ("1_4", "gaussian")])
+def test_strip_plans_on_pencils_keep_the_real_canvas_where_they_must(oracle, kernel, dealias):
+    """gradorder 0 kernels and softening kernels on a strip plan: the real canvas (painted by the marching kernel's
+    real-row form, one live row in the y halo row's strip), the box-path sequence, the flat readout."""
+    import torch
+    from fastpm_amd import PM, Store
+    from fastpm_amd.distributed import PencilForce, run_virtual
+    N, nc, L, Nx, Ny = 64, 32, 96.0, 2, 2
+    x = util.load_a(nc, L, N)
+    pmo = oracle.PMOracle(N, L, 64)
+    ref = oracle.compute_force(pmo, x, kernel=oracle.KERNELS[kernel], softening=oracle.SOFTENINGS[dealias])
+    own = _owner(x, N, L, Nx, Ny)
+    idx = [np.nonzero(own == r)[0] for r in range(4)]
+    pms = [PM(N, L, 64, nranks=4, rank=r, nranks_y=Ny, paint_mode=3) for r in range(4)]
+    stores = [Store(x[idx[r]]) for r in range(4)]
+    run_virtual([PencilForce(pm) for pm in pms], stores, kernel=kernel, dealias=dealias)
+    torch.cuda.synchronize()
+    acc = np.zeros_like(ref["acc"])
+    for r in range(4):
+        acc[idx[r]] = stores[r].acc.cpu().numpy()
+    assert util.rel_err(acc, ref["acc"]) <= 1e-6
+    for pm in pms:
+        pm.destroy()
+
+
+def test_strip_tiles_on_the_reference_4x2_mesh_at_128(oracle):
+    import torch
+    from fastpm_amd import PM, Store
+    from fastpm_amd.distributed import PencilForce, run_virtual
+    N, nc, L, Nx, Ny = 128, 64, 192.0, 4, 2
+    x = util.load_b(nc, L, N, rms_cells=3.0)
+    pmo = oracle.PMOracle(N, L, 64, threads=8)
+    ref = oracle.compute_force(pmo, x)
+    own = _owner(x, N, L, Nx, Ny)
+    idx = [np.nonzero(own == r)[0] for r in range(8)]
+    pms = [PM(N, L, 64, nranks=8, rank=r, nranks_y=Ny, paint_mode=3) for r in range(8)]
+    assert all(pm.strips() for pm in pms)
+    stores = [Store(x[idx[r]]) for r in range(8)]
+    run_virtual([PencilForce(pm) for pm in pms], stores)
+    torch.cuda.synchronize()
+    acc = np.zeros_like(ref["acc"])
+    for r in range(8):
+        acc[idx[r]] = stores[r].acc.cpu().numpy()
+    assert util.rel_err(acc, ref["acc"]) <= 1e-6
+    for pm in pms:
+        pm.destroy()
