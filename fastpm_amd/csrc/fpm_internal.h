@@ -100,6 +100,7 @@ struct MeshGeo {
 // [0, xl) as [xl][rp].
 struct PenIO {
     int on;
+    unsigned inv24;             // floor(2^24 / zblk) + 1: k / zblk = (k * inv24) >> 24 for k zblk < 2^24
     long long chunk;            // complex values per exchange-A chunk (fpmhip_layout.chunk_a_elems / 2)
     void *hx[3], *hy[3];        // per mesh (the paint uses [0])
 };

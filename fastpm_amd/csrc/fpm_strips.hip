@@ -114,6 +114,30 @@ template <typename PL, typename F> struct StripCfg {
     static constexpr size_t pt1_lds = pt_twb + (size_t) STRIP_Y * pt_pitch * sizeof(double);      // one plane
 };
 
+// Pencil plans (PenIO): element k of a chunked row sits at k + b (chunk - zblk), b = k / zblk its kz block.  A thread's
+// elements are k = tau + T j with j known at compile time, and zblk >= T (host-checked), so b is a wave-UNIFORM number per
+// slot (scalar ALU) plus one comparison; with one row per wave (T = 64) the row base is uniform too and the access is
+// SGPR base + one 32-bit VGPR offset per element (host-checked to fit) -- eight address registers instead of sixteen,
+// which is what keeps the M = 512 kernels inside their 128-VGPR budget.
+template <typename P> __device__ __forceinline__ P *uniform_ptr(P *p)
+{
+    const unsigned long long v = (unsigned long long) p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) v), hi = __builtin_amdgcn_readfirstlane((unsigned) (v >> 32));
+    return (P *) (((unsigned long long) hi << 32) | lo);
+}
+template <int T, typename F>
+__device__ __forceinline__ C2<F> *pen_elem(C2<F> *row, bool chunked, int kbase, int tau, int zblk, unsigned inv24, unsigned jump)
+{
+    // kbase = T j (or M): uniform; the element is k = kbase + tau
+    const unsigned k = (unsigned) (kbase + tau);
+    unsigned off = k;
+    if (chunked) {
+        const unsigned B = ((unsigned) kbase * inv24) >> 24;                     // kbase / zblk, scalar
+        off = k + (B + (k >= (B + 1) * (unsigned) zblk ? 1u : 0u)) * jump;
+    }
+    return (C2<F> *) ((char *) row + (size_t) (off * (unsigned) sizeof(C2<F>)));
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // paint
 // ------------------------------------------------------------------------------------------------------------------
@@ -137,7 +161,7 @@ template <typename PL, typename F> struct StripCfg {
 #ifndef FPM_PT_MINW
 #define FPM_PT_MINW 3
 #endif
-template <typename PL, typename F, bool R2C, bool WS>
+template <typename PL, typename F, bool R2C, bool WS, bool PEN = false>
 __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), (sizeof(F) == 4 && PL::N == 1024 ? 4 : FPM_PT_MINW)) void paint_march_kernel(
     MeshGeo g, int ntiles, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
     const double *__restrict__ sy, const double *__restrict__ sz, const float *__restrict__ smass, double M0, double scale,
@@ -251,7 +275,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), (sizeof(F) == 4 && P
             F *canvas = (F *) out_;
             for (int idx = tid; idx < STRIP_Y * N; idx += NT) {
                 const int ly = idx / N, z = idx - ly * N;
-                if (y0 + ly >= g.yplanes) continue;                    // pencils: the strip of the y halo row has one row
+                if (PEN && y0 + ly >= g.yplanes) continue;             // pencils: the strip of the y halo row has one row
                 F *row = canvas + (long long) i * g.str0 + (long long) (y0 + ly) * g.str1;
                 const F mine = (F) (A[ly * WP + z] * scale);
                 row[z] = accumulate ? (F) (row[z] + mine) : mine;           // further species add (gravity.c:326-338)
@@ -260,7 +284,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), (sizeof(F) == 4 && P
                 const int npad = (int) g.str1 - N;
                 for (int idx = tid; idx < STRIP_Y * npad; idx += NT) {
                     const int ly = idx / npad, z = idx - ly * npad;
-                    if (y0 + ly >= g.yplanes) continue;
+                    if (PEN && y0 + ly >= g.yplanes) continue;
                     canvas[(long long) i * g.str0 + (long long) (y0 + ly) * g.str1 + N + z] = 0;
                 }
             }
@@ -286,24 +310,29 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), (sizeof(F) == 4 && P
         const int yrow = y0 + c;
         C2<F> *dst = out + ((long long) i * g.yplanes + yrow) * g.rp;
         bool chunked = false, live = true;
-        if (pen.on) {
+        if constexpr (PEN) {
             live = yrow <= g.ylr;                                      // the y halo row's strip has one row
             if (!g.periodic_x && i == g.xl) dst = (C2<F> *) pen.hx[0] + (long long) min(yrow, g.ylr) * g.rp;
             else if (yrow >= g.ylr) dst = (C2<F> *) pen.hy[0] + (long long) i * g.rp;
             else { dst = out + ((long long) i * g.ylr + yrow) * g.nzl; chunked = true; }
         }
-        auto at = [&](int k) -> C2<F> * { return chunked ? dst + (k / g.zblk) * pen.chunk + k % g.zblk : dst + k; };
+        if constexpr (PEN && WS && T == 64) dst = uniform_ptr(dst);      // one row per wave
+        const unsigned pjump = PEN ? (unsigned) (pen.chunk - g.zblk) : 0u;
+        auto at = [&](int kbase, int t_) -> C2<F> * {                  // element kbase + t_, kbase uniform
+            if constexpr (PEN) return pen_elem<T, F>(dst, chunked, kbase, t_, g.zblk, pen.inv24, pjump);
+            return dst + kbase + t_;
+        };
 #pragma unroll
         for (int j = 0; j < E; j++) {
             const int k = tau + T * j;
             const C2<F> a = v[j];
             const C2<F> val = r2c_untangle(a, lds[lds_pos<CWX, 0>((M - k) % M, c)], twn[k]);
-            if (live) {
-                st_stream(at(k), val);
-                if (k == 0) *at(M) = C2<F>{a.x - a.y, 0};              // X[N/2] = Re Z0 - Im Z0
+            if (!PEN || live) {
+                st_stream(at(T * j, tau), val);
+                if (k == 0) *at(M, 0) = C2<F>{a.x - a.y, 0};           // X[N/2] = Re Z0 - Im Z0
             }
         }
-        if (live && !chunked)
+        if (!PEN || (live && !chunked))
             for (int k = M + 1 + tau; k < g.rp; k += T) dst[k] = C2<F>{0, 0};      // the padding of an aligned row
         fft_sync<WS>();
         if (WS) {
@@ -452,7 +481,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
 // a table of them and rows 5 (mod 16) apart, 53.6 KB: 13.0, no change).  At
 // M = 256 the same order loses in fp64 (1.18 -> 1.26 ms at 512^3: the prefetch matters more where the transform is short)
 // and wins in fp32 (0.816 -> 0.783 ms), where it is on as well.  (With 8-row strips, five-wave workgroups: 1.56 ms.)
-template <typename PL, typename F, bool WS, bool LATE = false>
+template <typename PL, typename F, bool WS, bool LATE = false, bool PEN = false>
 __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FPM_RO_MINW) : 3)) void readout_march_kernel(
     MeshGeo g, int ncomp, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
     const double *__restrict__ sy, const double *__restrict__ sz, const int *__restrict__ sidx, const C2<F> *__restrict__ m0,
@@ -485,19 +514,21 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FP
     // pencils (PenIO): the rows are where the (y <-> kz) exchange left them, cut into kz blocks; plane xl and row ylr are
     // the neighbours' rows, in their own small buffers
     const int yrow = y0 + c;
-    const C2<F> *phx = (const C2<F> *) pen.hx[comp], *phy = (const C2<F> *) pen.hy[comp];
+    const C2<F> *phx = PEN ? (const C2<F> *) pen.hx[comp] : nullptr, *phy = PEN ? (const C2<F> *) pen.hy[comp] : nullptr;
     auto load_plane = [&](int xp) {                // plane xl of a slab is the halo plane the next rank sent
         if (g.periodic_x) xp -= xp >= g.N ? g.N : 0;
-        if (pen.on) {
+        if constexpr (PEN) {
             const C2<F> *src;
             bool chunked = false;
             if (!g.periodic_x && xp == g.xl) src = phx + (long long) yrow * g.rp;
             else if (yrow == g.ylr) src = phy + (long long) xp * g.rp;
             else { src = mesh + ((long long) xp * g.ylr + yrow) * g.nzl; chunked = true; }
-            auto at = [&](int k) -> const C2<F> * { return chunked ? src + (k / g.zblk) * pen.chunk + k % g.zblk : src + k; };
+            if constexpr (WS && T == 64) src = uniform_ptr(src);         // one row per wave
+            const unsigned pjump = (unsigned) (pen.chunk - g.zblk);
 #pragma unroll
-            for (int j = 0; j < E; j++) x[j] = ld_stream(at(tau + T * j));
-            xm = tau == 0 ? *at(M) : C2<F>{0, 0};
+            for (int j = 0; j < E; j++)
+                x[j] = ld_stream(pen_elem<T, F>(const_cast<C2<F> *>(src), chunked, T * j, tau, g.zblk, pen.inv24, pjump));
+            xm = tau == 0 ? *pen_elem<T, F>(const_cast<C2<F> *>(src), chunked, M, 0, g.zblk, pen.inv24, pjump) : C2<F>{0, 0};
             return;
         }
         const C2<F> *src = rowbase + (long long) xp * pstride;
@@ -852,14 +883,15 @@ static int paint_strips_launch(fpmhip_plan *p, const fpmhip_particles *pt, doubl
     MeshGeo g = p->mg;
     // the z pass wave-local where a row's threads fit one wave (the power-of-two meshes); FPMHIP_PT_WS = 0: A/B
     static const int ws_env = getenv("FPMHIP_PT_WS") ? atoi(getenv("FPMHIP_PT_WS")) : 1;
-#define CALL_PM_W(PL, WS_)                                                                                             \
+#define CALL_PM_W(PL, WS_) if (g.periodic_y) CALL_PM_P(PL, WS_, false) else CALL_PM_P(PL, WS_, true)
+#define CALL_PM_P(PL, WS_, PEN_)                                                                                       \
     {                                                                                                                  \
         using CF = StripCfg<PL, F>;                                                                                    \
-        FPM_TRY(grant_lds(paint_march_kernel<PL, F, R2C, WS_>, CF::pt1_lds, p->device));                               \
+        FPM_TRY(grant_lds(paint_march_kernel<PL, F, R2C, WS_, PEN_>, CF::pt1_lds, p->device));                         \
         static int occ = 0;                                                                                            \
-        g.xseg = choose_xseg(g, paint_march_kernel<PL, F, R2C, WS_>, CF::pt_threads, CF::pt1_lds, g.nty, 8, 64, &occ); \
+        g.xseg = choose_xseg(g, paint_march_kernel<PL, F, R2C, WS_, PEN_>, CF::pt_threads, CF::pt1_lds, g.nty, 8, 64, &occ); \
         const int nseg = (g.xl + g.xseg - 1) / g.xseg;                                                                 \
-        paint_march_kernel<PL, F, R2C, WS_><<<g.nty * nseg, CF::pt_threads, CF::pt1_lds, p->stream>>>(                 \
+        paint_march_kernel<PL, F, R2C, WS_, PEN_><<<g.nty * nseg, CF::pt_threads, CF::pt1_lds, p->stream>>>(           \
             g, p->ntiles, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, pt->mass ? p->smass : nullptr, pt->M0, scale, out, \
             accumulate, p->d_twiddle, p->scell, pen);                                                                  \
     }
@@ -868,6 +900,7 @@ static int paint_strips_launch(fpmhip_plan *p, const fpmhip_particles *pt, doubl
     STRIP_DISPATCH(g.N / 2, CALL_PM)
 #undef CALL_PM
 #undef CALL_PM_W
+#undef CALL_PM_P
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -947,7 +980,8 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
     const bool pair = !pen.on && (pair_env >= 0 ? pair_env != 0 : false);
     // the half sums of a dense tile's entries beyond the first two per thread: one double per own entry and component
     const long long part_stride = p->ro_part_elems;
-#define CALL_RO_W(PL, WS_)                                                                                             \
+#define CALL_RO_W(PL, WS_) if (pen.on) CALL_RO_P(PL, WS_, true) else CALL_RO_P(PL, WS_, false)
+#define CALL_RO_P(PL, WS_, PEN_)                                                                                       \
     {                                                                                                                  \
         using CF = StripCfg<PL, F>;                                                                                    \
         static int occ2 = 0, occ1 = 0, occ0 = 0;                                                                       \
@@ -961,18 +995,18 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
                 g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                 \
                 (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->scell);                    \
         } else if (WS_ && (PL::N >= 512 || (PL::N == 256 && sizeof(F) == 4)) && late) {                                                                      \
-            FPM_TRY(grant_lds(readout_march_kernel<PL, F, WS_, (WS_ && (PL::N >= 512 || (PL::N == 256 && sizeof(F) == 4)))>, CF::ro1_lds, p->device));       \
-            g.xseg = choose_xseg(g, readout_march_kernel<PL, F, WS_, (WS_ && (PL::N >= 512 || (PL::N == 256 && sizeof(F) == 4)))>, CF::ro_threads, CF::ro1_lds, ncomp * g.ntyo, 16, 128, &occ0); \
+            FPM_TRY(grant_lds(readout_march_kernel<PL, F, WS_, (WS_ && (PL::N >= 512 || (PL::N == 256 && sizeof(F) == 4))), PEN_>, CF::ro1_lds, p->device));       \
+            g.xseg = choose_xseg(g, readout_march_kernel<PL, F, WS_, (WS_ && (PL::N >= 512 || (PL::N == 256 && sizeof(F) == 4))), PEN_>, CF::ro_threads, CF::ro1_lds, ncomp * g.ntyo, 16, 128, &occ0); \
             const int nseg = (g.xl + g.xseg - 1) / g.xseg;                                                             \
-            readout_march_kernel<PL, F, WS_, (WS_ && (PL::N >= 512 || (PL::N == 256 && sizeof(F) == 4)))><<<ncomp * g.ntyo * nseg, CF::ro_threads, CF::ro1_lds, p->stream>>>( \
+            readout_march_kernel<PL, F, WS_, (WS_ && (PL::N >= 512 || (PL::N == 256 && sizeof(F) == 4))), PEN_><<<ncomp * g.ntyo * nseg, CF::ro_threads, CF::ro1_lds, p->stream>>>( \
                 g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                 \
                 (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride,      \
                 p->scell, pen);                                                                                        \
         } else {                                                                                                       \
-            FPM_TRY(grant_lds(readout_march_kernel<PL, F, WS_>, CF::ro1_lds, p->device));                              \
-            g.xseg = choose_xseg(g, readout_march_kernel<PL, F, WS_>, CF::ro_threads, CF::ro1_lds, ncomp * g.ntyo, 16, 128, &occ1); \
+            FPM_TRY(grant_lds(readout_march_kernel<PL, F, WS_, false, PEN_>, CF::ro1_lds, p->device));                              \
+            g.xseg = choose_xseg(g, readout_march_kernel<PL, F, WS_, false, PEN_>, CF::ro_threads, CF::ro1_lds, ncomp * g.ntyo, 16, 128, &occ1); \
             const int nseg = (g.xl + g.xseg - 1) / g.xseg;                                                             \
-            readout_march_kernel<PL, F, WS_><<<ncomp * g.ntyo * nseg, CF::ro_threads, CF::ro1_lds, p->stream>>>(        \
+            readout_march_kernel<PL, F, WS_, false, PEN_><<<ncomp * g.ntyo * nseg, CF::ro_threads, CF::ro1_lds, p->stream>>>(        \
                 g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                 \
                 (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride,      \
                 p->scell, pen);                                                                                        \
@@ -983,6 +1017,7 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
     STRIP_DISPATCH(g.N / 2, CALL_RO)
 #undef CALL_RO
 #undef CALL_RO_W
+#undef CALL_RO_P
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1036,6 +1071,11 @@ static int pen_io(fpmhip_plan *p, void *const *hx, void *const *hy, int n, PenIO
     memset(pen, 0, sizeof(*pen));
     pen->on = 1;
     pen->chunk = p->lay.chunk_a_elems / 2;
+    pen->inv24 = (1u << 24) / (unsigned) p->mg.zblk + 1;
+    if ((long long) (p->mg.N / 2 + 1) * p->mg.zblk >= (1ll << 24)) FPM_FAIL(-1, "internal: kz block too long for the 24-bit reciprocal");
+    // the kernels' 32-bit byte offsets inside a row's chunks, and one block boundary at most per register slot
+    if ((long long) p->lay.nranks_y * pen->chunk * (long long) (2 * p->esize) >= (1ll << 32) || p->mg.zblk < p->mg.N / 16)
+        FPM_FAIL(-1, "pencil strip plans: the exchange chunks of a row must lie within 4 GB and a kz block must hold N / 16 modes");
     for (int i = 0; i < n; i++) {
         if (!hy || !hy[i]) FPM_FAIL(-1, "null y-halo rows");
         if (!p->mg.periodic_x && (!hx || !hx[i])) FPM_FAIL(-1, "null x-halo plane");

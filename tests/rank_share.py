@@ -123,6 +123,137 @@ def run_rank_share(N, P, precision, rank=3, ncube=None, timing=False, paint_mode
     return acc, ref, t
 
 
+# ---- ONE rank of a PENCIL decomposition (Nx x Ny, the reference's default 4 x 2 for 8 ranks, pmpfft.c:117-136) ---------
+# The universe is periodic with period L / Nx (Ny divides Nx): a rank's brick of N/Nx x N/Ny x N cells is 1 x Nx/Ny x Nx
+# copies of one cube, every rank's brick is the same, so
+#   * the neighbours' halo plane / halo row are this rank's own;
+#   * in exchange A (y <-> kz inside a row) rank (rx, t) receives, from every rank of its row, this rank's own send chunk t;
+#   * in exchange B (x <-> ky inside a column) rank (s, t) receives, from every rank of its column, the send chunk s of
+#     rank (rx, t) -- which this GPU has just computed: it plays every (s, t) in turn (Ny forward / backward y passes,
+#     Nx * Ny fused x passes instead of one each) and keeps what those ranks would send back to (rx, ry).
+# The accelerations must equal the small cube's for every copy.
+def replicate_into_brick(xc, Lcube, Nx, Ny, rx, ry):
+    cy = Nx // Ny
+    sy = (torch.arange(cy, device=xc.device, dtype=torch.float64) + ry * cy) * Lcube
+    sz = torch.arange(Nx, device=xc.device, dtype=torch.float64) * Lcube
+    off = torch.stack(torch.meshgrid(torch.full((1,), rx * Lcube, device=xc.device, dtype=torch.float64), sy, sz,
+                                     indexing="ij"), dim=-1).reshape(-1, 1, 3)
+    return (xc[None, :, :] + off).reshape(-1, 3).contiguous()
+
+
+class ReplicatedPencilForce:
+    def __init__(self, N, L, Nx, Ny, rx, ry, precision, paint_mode=0):
+        from fastpm_amd import PM
+        P = Nx * Ny
+        mk = lambda s, t, pmode: PM(N, L, precision, nranks=P, rank=s * Ny + t, nranks_y=Ny, paint_mode=pmode)
+        self.pm = mk(rx, ry, paint_mode)
+        self.Nx, self.Ny, self.rx, self.ry = Nx, Ny, rx, ry
+        self.kpm = {(s, t): (self.pm if (s, t) == (rx, ry) else mk(s, t, 2)) for s in range(Nx) for t in range(Ny)}
+        pm = self.pm
+        names = "a_send a_recv b_send block fx pot wbx wbp ax ay az r0 r1 r2".split()
+        self.b = {n: pm.alloc() for n in names}
+        L_ = pm.layout
+        xl, ylr, rp2 = int(L_.isize[0]), int(L_.isize[1]), int(L_.istrides[1])
+        mkh = lambda n: torch.zeros(n, dtype=pm.dtype, device="cuda")
+        self.h = [dict(hx=mkh((ylr + 1) * rp2), hy=mkh(xl * rp2)) for _ in range(3)]
+        self.tmp = mkh(int(L_.plane_elems))
+        self.row = mkh(xl * rp2)
+
+    def destroy(self):
+        for q in self.kpm.values():
+            q.destroy()
+
+    def __call__(self, store, kernel="1_4"):
+        pm, Nx, Ny, rx, ry, b = self.pm, self.Nx, self.Ny, self.rx, self.ry, self.b
+        L = pm.layout
+        xl, ylr, rp2 = int(L.isize[0]), int(L.isize[1]), int(L.istrides[1])
+        ca, cb = int(L.chunk_a_elems), int(L.chunk_b_elems)
+        mean = Nx * Ny * pm.total_mass(store) / pm.Norm                  # gravity.c:330-345: every rank holds the same mass
+        strips = pm.strips()
+        h0 = self.h[0]
+        if strips:
+            pm.paint_zr2c_pen(b["a_send"], store, 1.0 / mean, h0["hx"], h0["hy"])
+            pm.pen_halo_rows(b["a_send"], h0["hx"], 0, 0)                # the previous rank's plane x_loc = our own
+            pm.row_add(h0["hy"][:rp2], h0["hx"][ylr * rp2:], rp2 // 2)   # ... its corner row
+            pm.pen_halo_rows(b["a_send"], h0["hy"], 1, 0)
+        else:
+            c = b["r0"]
+            pm.paint(c, store, 1.0 / mean)
+            self.tmp.copy_(pm.plane(c, xl))
+            pm.plane_add(pm.plane(c, 0), self.tmp)
+            pm.yrow(c, ylr, self.row, 0)
+            pm.yrow(c, 0, self.row, 2)
+            pm.fft_z_forward(c, b["a_send"])
+        R = [b["r0"], b["r1"], b["r2"]]
+        for t in range(Ny):
+            kt = self.kpm[(rx, t)]
+            for j in range(Ny):                                          # exchange A as rank (rx, t) sees it
+                b["a_recv"][j * ca:(j + 1) * ca].copy_(b["a_send"][t * ca:(t + 1) * ca])
+            kt.fft_y_forward(b["a_recv"], b["b_send"])
+            for s in range(Nx):
+                for j in range(Nx):                                      # exchange B as rank (s, t) sees it
+                    b["block"][j * cb:(j + 1) * cb].copy_(b["b_send"][s * cb:(s + 1) * cb])
+                self.kpm[(s, t)].fft_x_forward_transfer_backward(kernel, b["block"], 2, [b["fx"], b["pot"]])
+                b["wbx"][s * cb:(s + 1) * cb].copy_(b["fx"][rx * cb:(rx + 1) * cb])      # what (s, t) sends back to (rx, t)
+                b["wbp"][s * cb:(s + 1) * cb].copy_(b["pot"][rx * cb:(rx + 1) * cb])
+            kt.fft_y_backward_grad2(kernel, b["wbp"], b["ay"], b["az"])
+            kt.fft_y_backward(b["wbx"], b["ax"])
+            for m, src in zip(R, (b["ax"], b["ay"], b["az"])):           # what (rx, t) sends to (rx, ry) in exchange A
+                m[t * ca:(t + 1) * ca].copy_(src[ry * ca:(ry + 1) * ca])
+        if strips:
+            for m, h in zip(R, self.h):                                  # the neighbours' rows = our own
+                pm.pen_halo_rows(m, h["hy"], 1, 1)
+                pm.pen_halo_rows(m, h["hx"], 0, 1)
+                h["hx"][ylr * rp2:(ylr + 1) * rp2].copy_(h["hy"][:rp2])
+            pm.readout3_zc2r_pen(R, store, [h["hx"] for h in self.h], [h["hy"] for h in self.h])
+        else:
+            real = [b["ax"], b["ay"], b["az"]]
+            for m, f in zip(R, real):
+                pm.fft_z_backward(m, f)
+                pm.yrow(f, 0, self.row, 0)
+                pm.yrow(f, ylr, self.row, 1)
+                pm.plane(f, xl).copy_(pm.plane(f, 0))
+            pm.readout3(real, store)
+        return store.acc
+
+
+def run_pencil_share(N, Nx, Ny, precision, rx=1, ry=1, ncube=None, timing=False, paint_mode=0):
+    """(acc of the brick's particles, acc of the small cubic problem [n][3], timings, copies)"""
+    from fastpm_amd import PM, Store
+    Ncube = N // Nx
+    ncube = ncube or Ncube // 2
+    Lcube = 3.0 * ncube
+    L = Lcube * Nx
+    xc = cube_particles(ncube, Ncube, Lcube)
+    small = PM(Ncube, Lcube, precision)
+    st = Store(xc)
+    small.compute_force(st, kernel="1_4", softening="none")
+    torch.cuda.synchronize()
+    ref = st.acc.clone()
+    small.destroy()
+    x = replicate_into_brick(xc, Lcube, Nx, Ny, rx, ry)
+    run = ReplicatedPencilForce(N, L, Nx, Ny, rx, ry, precision, paint_mode)
+    store = Store(x)
+    if timing:
+        run(store)
+        run.pm.invalidate_binning()
+        for q in run.kpm.values():
+            q.timing_enable(True)
+            q.timing_reset()
+    acc = run(store).clone()
+    torch.cuda.synchronize()
+    t = None
+    if timing:
+        t = {}
+        for q in run.kpm.values():
+            for k, (ms, cnt) in q.timings().items():
+                a = t.get(k, (0.0, 0))
+                t[k] = (a[0] + ms, a[1] + cnt)
+    strips = run.pm.strips()
+    run.destroy()
+    return acc, ref, t, (Nx // Ny) * Nx, strips
+
+
 # ---- sequences of steps at per-rank size: configs[3] (COLA, 2048^3) and configs[4] (variable mesh B = 1 -> 3, P(k) every
 # step) in the replicated universe.  The particles of the slab MOVE (kick, drift, wrap) with the forces the slab computed;
 # what leaves the slab through one face enters through the other (the neighbour is a copy of this rank), so the count

@@ -248,3 +248,22 @@ def test_config4_variable_mesh_steps_with_pk_at_per_rank_size(tmp_path):
         text = open(r["pk_file"]).read().splitlines()
         assert text[0] == "# k p N " and text[-8] == "# metadata 7" and text[-5] == "# N1 %g int" % (1024.0 ** 3)
         assert len(text) == 1 + N // 2 + 8
+
+
+@pytest.mark.parametrize("N,precision,paint_mode", [(256, 64, 3), (256, 64, 2), (256, 32, 3), (1024, 64, 0)])
+def test_one_pencil_rank_of_the_4x2_mesh_at_per_rank_size(N, precision, paint_mode):
+    """Rank (1, 1) of the reference's 4 x 2 process mesh (pmpfft.c:117-136) in a universe periodic with period L/4
+    (tests/rank_share.py: ReplicatedPencilForce): every stage kernel at the brick's true geometry -- at N = 1024 that of
+    configs[2] on pencils, 16.8 M particles, strip tiles (the marching kernels on the exchange chunks) -- and the
+    accelerations of all 8 copies of the cube equal to the small cubic problem's."""
+    import torch
+    import rank_share
+    need = 16 * (N ** 3 // 8) * (precision // 8) * 1.2
+    if torch.cuda.mem_get_info()[0] < need:
+        pytest.skip("needs %.0f GB of free device memory" % (need / 1e9))
+    acc, ref, _, copies, strips = rank_share.run_pencil_share(N, 4, 2, precision, paint_mode=paint_mode)
+    assert strips == (paint_mode != 2)
+    n = ref.shape[0]
+    rms = float(ref.double().pow(2).mean().sqrt())
+    err = float((acc.view(copies, n, 3).double() - ref.double()[None]).abs().max()) / rms
+    assert err <= (2e-7 if precision == 64 else 1e-5), err
