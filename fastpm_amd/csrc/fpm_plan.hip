@@ -317,7 +317,7 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
         // then has one more strip per plane, the y halo row's, and the local rows must be whole strips
         static const bool pen_off = getenv("FPMHIP_PEN_STRIPS") && atoi(getenv("FPMHIP_PEN_STRIPS")) == 0;      // A/B
         // (the kernels address a row's kz blocks with 32-bit byte offsets and expect one block boundary per register slot)
-        const bool pen_ok = Ny == 1 || (!pen_off && ylr % STRIP_Y == 0 && zblk >= N / 16 &&
+        const bool pen_ok = Ny == 1 || (!pen_off && (N & (N - 1)) == 0 && ylr % STRIP_Y == 0 && zblk >= N / 16 &&
                                         (long long) Ny * L.chunk_a_elems * (long long) p->esize < (1ll << 32));
         const bool can = pen_ok && geom->fft_mode == FPMHIP_FFT_AUTO && colfft_supported((int) N) &&
                          strips_supported((int) N, geom->precision) && geom->gradient_mode == FPMHIP_GRADIENT_KSPACE;

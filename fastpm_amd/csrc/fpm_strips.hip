@@ -470,7 +470,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
 #define FPM_RO_MINW 3
 #endif
 // timing probes of readout_march_kernel (wrong results; build-time only): 1 no CIC arithmetic / LDS gathers, 2 no FFT core,
-// 3 no z transform at all, 4 no mesh loads
+// 3 no z transform at all, 4 no mesh loads, 5 no acc stores, 6 no entry loads, 7 = 3 + 4
 #ifndef FPM_RO_PROBE
 #define FPM_RO_PROBE 0
 #endif
@@ -532,7 +532,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FP
             return;
         }
         const C2<F> *src = rowbase + (long long) xp * pstride;
-#if FPM_RO_PROBE == 4
+#if FPM_RO_PROBE == 4 || FPM_RO_PROBE == 7
         (void) src;
 #pragma unroll
         for (int j = 0; j < E; j++) x[j] = C2<F>{(F) xp, (F) j};
@@ -545,7 +545,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FP
     };
     auto c2r_plane = [&]() {                       // x[] -> the RW real rows of the plane in S (rowfft_c2r_kernel's arithmetic)
         C2<F> v[vmax(E)];
-#if FPM_RO_PROBE == 3
+#if FPM_RO_PROBE == 3 || FPM_RO_PROBE == 7
 #pragma unroll
         for (int j = 0; j < E; j++) v[j] = x[j];
 #else
@@ -589,9 +589,14 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FP
             qx[u] = qy[u] = qz[u] = 0;
             qrow[u] = qc[u] = 0;
             if (e < qn) {
+#if FPM_RO_PROBE == 6
+                qx[u] = 0.25; qy[u] = 0.5; qz[u] = 0.75;
+                qrow[u] = qb + e; qc[u] = ((y0 + (e & 3)) << 12) | (e & 255);
+#else
                 qx[u] = sx[qb + e]; qy[u] = sy[qb + e]; qz[u] = sz[qb + e];
                 const int2 rc = scell[qb + e];                     // (row, base cell)
                 qrow[u] = rc.x; qc[u] = rc.y;
+#endif
             }
         }
     };
@@ -608,8 +613,13 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FP
     auto finish_p = [&]() {
 #pragma unroll
         for (int u = 0; u < PF; u++)
-            if (tid + u * NT < pn)
-                out[(long long) prow[u] * nmemb + memb0 + comp] = (float) half(px[u], py[u], pz[u], pc[u], 1, pv[u]);
+            if (tid + u * NT < pn) {
+                const float val = (float) half(px[u], py[u], pz[u], pc[u], 1, pv[u]);
+#if FPM_RO_PROBE == 5
+                if (val == 1.2345e-30f)
+#endif
+                out[(long long) prow[u] * nmemb + memb0 + comp] = val;
+            }
         for (int e = tid + PF * NT; e < pn; e += NT) {
             const int2 rc = scell[pb + e];
             out[(long long) rc.x * nmemb + memb0 + comp] = (float) half(sx[pb + e], sy[pb + e], sz[pb + e], rc.y, 1, part[pb + e]);
@@ -883,7 +893,11 @@ static int paint_strips_launch(fpmhip_plan *p, const fpmhip_particles *pt, doubl
     MeshGeo g = p->mg;
     // the z pass wave-local where a row's threads fit one wave (the power-of-two meshes); FPMHIP_PT_WS = 0: A/B
     static const int ws_env = getenv("FPMHIP_PT_WS") ? atoi(getenv("FPMHIP_PT_WS")) : 1;
-#define CALL_PM_W(PL, WS_) if (g.periodic_y) CALL_PM_P(PL, WS_, false) else CALL_PM_P(PL, WS_, true)
+// (pencil instantiations: the power-of-two meshes only -- fpm_plan.hip offers strip tiles on pencils there)
+#define CALL_PM_W(PL, WS_)                                                                                             \
+    if (g.periodic_y) CALL_PM_P(PL, WS_, false)                                                                        \
+    else if constexpr ((PL::N & (PL::N - 1)) == 0) CALL_PM_P(PL, WS_, true)                                            \
+    else FPM_FAIL(-1, "internal: no pencil strip kernels for Nmesh = %d", 2 * PL::N);
 #define CALL_PM_P(PL, WS_, PEN_)                                                                                       \
     {                                                                                                                  \
         using CF = StripCfg<PL, F>;                                                                                    \
@@ -924,7 +938,8 @@ int paint_strips(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void 
 }
 
 // the paired-row readout where a pair's N / 8 threads fit one wave: the power-of-two meshes up to N = 512
-template <int M, typename F, bool OK = (M <= 256 && (M & (M - 1)) == 0)> struct PairLaunch {
+// (an A/B kernel: instantiated for the mesh it was measured on only, N = 512)
+template <int M, typename F, bool OK = (M == 256)> struct PairLaunch {
     static constexpr bool ok = false;
     static int go(fpmhip_plan *, MeshGeo &, const void *, const void *, const void *, int, float *, int, int) { return -1; }
 };
@@ -980,7 +995,10 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
     const bool pair = !pen.on && (pair_env >= 0 ? pair_env != 0 : false);
     // the half sums of a dense tile's entries beyond the first two per thread: one double per own entry and component
     const long long part_stride = p->ro_part_elems;
-#define CALL_RO_W(PL, WS_) if (pen.on) CALL_RO_P(PL, WS_, true) else CALL_RO_P(PL, WS_, false)
+#define CALL_RO_W(PL, WS_)                                                                                             \
+    if (!pen.on) CALL_RO_P(PL, WS_, false)                                                                             \
+    else if constexpr ((PL::N & (PL::N - 1)) == 0) CALL_RO_P(PL, WS_, true)                                            \
+    else FPM_FAIL(-1, "internal: no pencil strip kernels for Nmesh = %d", 2 * PL::N);
 #define CALL_RO_P(PL, WS_, PEN_)                                                                                       \
     {                                                                                                                  \
         using CF = StripCfg<PL, F>;                                                                                    \
