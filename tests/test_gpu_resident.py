@@ -160,8 +160,11 @@ def test_resident_steps_equal_the_oracle_operator_by_operator(oracle, mode, prec
 def test_resident_steps_move_no_particle_column_over_pcie(oracle, mode):
     a = _run(oracle, mode, 64, sync_every_call=True)
     b = _run(oracle, mode, 64, sync_every_call=False)
-    for key in ("x", "v", "acc", "pot", "dk"):
-        assert np.array_equal(a[key], b[key]), key              # the syncs are observers: same bits without them
+    # the syncs are observers: the same run without them (equal up to the order of the paint's LDS atomics -- the scatter's
+    # cursor order differs from run to run --, i.e. a few ulp of the fp64 mesh and at most a last-bit flip of a float acc)
+    for key, tol in (("x", 1e-7), ("v", 1e-5), ("acc", 1e-6), ("pot", 1e-6), ("dk", 1e-12)):
+        scale = np.sqrt(np.mean(np.square(a[key], dtype=np.float64)))
+        assert np.abs(a[key].astype(np.float64) - b[key]).max() <= tol * scale, key
     n = b["np"]
     cola = mode == "cola"
     # uploads: x once (first force), then v (first kick) and, for COLA, dx1 and dx2 -- each exactly once, ever

@@ -161,10 +161,15 @@ def test_strips_are_the_default_from_320():
     pm.destroy()
 
 
-def test_strips_need_slabs_and_the_kspace_gradient():
+def test_strips_need_whole_strips_and_the_kspace_gradient():
     from fastpm_amd import PM
+    pm = PM(32, 48.0, 64, nranks=4, rank=0, nranks_y=2, paint_mode=STRIPS)          # pencils: yes since round 4
+    assert pm.strips()                                                             # (test_gpu_pencil.py)
+    pm.destroy()
     with pytest.raises(Exception):
-        PM(32, 48.0, 64, nranks=4, rank=0, nranks_y=2, paint_mode=STRIPS)          # pencils: box tiles
+        PM(48, 72.0, 64, nranks=4, rank=0, nranks_y=2, paint_mode=STRIPS)          # ... on the power-of-two meshes
+    with pytest.raises(Exception):
+        PM(32, 48.0, 64, nranks=16, rank=0, nranks_y=16, paint_mode=STRIPS)        # ... with local rows in whole strips
     with pytest.raises(Exception):
         PM(32, 48.0, 64, gradient_mode=1, paint_mode=STRIPS)
     pm = PM(32, 48.0, 64, nranks=2, rank=0, paint_mode=STRIPS)                      # x slabs: yes (test_gpu_slab.py)

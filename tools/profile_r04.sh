@@ -19,6 +19,17 @@ for cfg in "1024 64" "2048 64" "2048 32" "3072 32 128" "3072 64 128"; do
   T=$(find /tmp/prof_rs -name '*.db' | head -1)
   python $REPO/tools/rocprof_summary.py $T $OUT/r04_rankshare_${tag}_rocprof_stats.md
 done
+# 3b. ONE rank of the reference's 4 x 2 PENCIL mesh (tests/rank_share.py: ReplicatedPencilForce): strip tiles at 1024^3
+#     (the marching kernels on the exchange chunks), box tiles at 2048^3 fp64 (no strips at M = 1024 in fp64), and the
+#     1024^3 share on box tiles for the A/B
+for cfg in "1024 64 0 0 pencil" "1024 64 0 2 pencil" "2048 64 0 0 pencil"; do
+  set -- $cfg
+  tag=pencil_$1_$2; [ "$4" = "2" ] && tag=${tag}_boxes
+  rm -rf /tmp/prof_rs
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_rs -o t -- python $REPO/tools/rank_share_bench.py $cfg > $OUT/r04_rankshare_$tag.json 2>/tmp/prof_rs.err
+  T=$(find /tmp/prof_rs -name '*.db' | head -1)
+  python $REPO/tools/rocprof_summary.py $T $OUT/r04_rankshare_${tag}_rocprof_stats.md
+done
 # 4. the bench lines (default, fp32, clustered / adversarial loads, box tiles)
 cd $REPO
 python bench.py --steps 20 --warmup 5 > $OUT/r04_bench.json 2>/dev/null
