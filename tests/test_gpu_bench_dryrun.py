@@ -51,3 +51,19 @@ def test_multi_rank_bench_path_on_pencils():
     assert d["n_gpus"] == 4 and d["finite"] and d["config"]["decomposition"] == "pencil 2x2"
     assert d["momentum_residual"] < 1e-6 and d["value"] is None and d["dry_run"]["would_be_value"] > 0
     assert d["comm"]["world_size"] == 4 and not d["comm"]["measured"]
+
+
+def test_multi_rank_bench_path_on_pencils_with_strip_tiles():
+    """The same on a strip plan (`--paint-mode 3`): PencilForce._strip_steps -- the marching kernels on the exchange chunks,
+    the halo plane / rows as half-spectrum rows through grouped isend / irecv -- over torch.distributed processes."""
+    env = dict(os.environ, FPM_BENCH_BACKEND="gloo", FPM_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+                        "--master-addr", "127.0.0.1", "--master-port", "29615", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "4", "--nprocy", "2", "--steps", "2", "--warmup", "1", "--nc", "64", "--nmesh", "128",
+                        "--paint-mode", "3"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 4 and d["finite"] and d["config"]["decomposition"] == "pencil 2x2"
+    assert d["config"]["paint_mode"].startswith("strip tiles")
+    assert d["momentum_residual"] < 1e-6 and d["value"] is None and d["dry_run"]["would_be_value"] > 0
