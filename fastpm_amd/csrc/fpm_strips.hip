@@ -579,10 +579,17 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FP
     double px[PF], py[PF], pz[PF], pv[PF], qx[PF], qy[PF], qz[PF];
     int prow[PF], qrow[PF], pc[PF], qc[PF];
     int pb = 0, pn = 0, qb = 0, qn = 0;            // p: the particles that finish this step; q: those that start
-    auto fetch_q = [&](int xi) {
+    // (the slab of a tile is looked up a step before its entries are requested: the entry loads then go out at once,
+    // instead of behind a scalar load and the wait -- for the LDS counter too -- that comes with it)
+    int kb_next = 0, kn_next = 0;
+    auto fetch_key = [&](int xi) {
         const int key = xi * g.nty + strip;
-        qb = tbeg[key];
-        qn = tcnt[key];
+        kb_next = tbeg[key];
+        kn_next = tcnt[key];
+    };
+    auto fetch_q = [&](int xi) {
+        qb = kb_next;
+        qn = kn_next;
 #pragma unroll
         for (int u = 0; u < PF; u++) {
             const int e = tid + u * NT;
@@ -599,6 +606,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FP
 #endif
             }
         }
+        if (xi + 1 < xb) fetch_key(xi + 1);
     };
     auto start_q = [&]() {                         // q -> p with the first four terms
 #pragma unroll
@@ -627,6 +635,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FP
     };
 
     load_plane(xa);
+    fetch_key(xa);
     fetch_q(xa);
     stage_twiddles(tw, tw_global, PL::TWN, 2);
     stage_twiddles(twn, tw_global, M, 1);
@@ -811,6 +820,17 @@ __global__ __launch_bounds__((PairCfg<PL2, F>::threads), FPM_RO_MINW) void reado
     }
 }
 
+// Round 4, measured and NOT kept (the kernel is not in the tree): the rows of the next plane by LDS-DMA.  The timing probes
+// say the marching readout is bound by the bytes it has in flight (a workgroup requests a plane only after its transform: the
+// values would not fit the 168 VGPRs across it).  gfx950's global_load_lds_dwordx4 writes a wave's 64 x 16 bytes straight
+// into LDS, so a variant staged the half-spectrum rows of plane i + 2 in 20 KB of LDS from the moment c2r_prepare had read
+// plane i + 1 out of it (prepare then reads X[k] and X[M - k] from the staging area and loses its eight 16-byte stores; the
+// instruction's immediate offset moves the global AND the LDS address, so a wave requests 64 consecutive elements of one
+// row per instruction).  Results at 512^3 fp64: correct, and slower -- 1.66 ms at three workgroups per CU (168-VGPR budget: 16
+// spilled VGPRs, and every scratch reload behind a DMA request is an s_waitcnt vmcnt(0) that waits for the DMA as well: the
+// loads return in order), 1.40 ms without spills at two workgroups per CU (192 VGPRs) against 1.11 ms for the kernel above;
+// one run in four also left an acc sum 1e-9 off (a hand-over between the DMA writes and the staged reads that the
+// compiler's waitcnt insertion did not cover was suspected and not run down).
 // (M = 1024 with the E = 16 plan -- a row's 64 threads in one wave, wave-local transforms there too -- spills 56 - 90 VGPRs in the
 // readout: one rank of the 2048^3 fp32 mesh 34.4 -> 44 ms; the E = 8 plans with workgroup barriers stay)
 #define FPM_STRIP_CASE(n, BODY) case n: { using PL = typename Fac<n, 0>::type; BODY(PL) } break;
