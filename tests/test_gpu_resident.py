@@ -216,3 +216,34 @@ def test_a_different_output_store_gets_its_column_on_the_host(oracle):
         s.release()
     H.fastpm_hip_mirror_release(dk.ctypes.data)
     H.fastpm_free_pm_hip(pm)
+
+
+def test_resident_force_with_two_species_and_masses(oracle):
+    """gravity.c:279-287, 323-338, 387-395 through the resident branch: two stores (one with a mass column) painted into one
+    mesh, every column behind its own device twin; a second call moves nothing but the potential-less acc... nothing."""
+    H = chost.host_library()
+    N, nc, L = 64, 32, 96.0
+    xa = util.load_b(nc, L, N)
+    xb = util.load_a(nc // 2, L, N, seed=77)
+    mb = np.random.default_rng(5).uniform(0.5, 1.5, len(xb)).astype(np.float32)
+    pmo = oracle.PMOracle(N, L, 64)
+    accs, _ = oracle.compute_force_species(pmo, [{"x": xa}, {"x": xb, "mass": mb, "M0": 0.25}])
+    pm = H.fastpm_create_pm_hip(N, L, 64)
+    sa = chost.HostStore(xa, name=b"1")
+    sb = chost.HostStore(xb, mass=mb, M0=0.25, name=b"0")
+    sv = chost.solver_view(sa, sb)
+    msgs = chost.Messages()
+    H.fastpm_hip_mirror_reset_stats()
+    for call in range(2):
+        H.fastpm_solver_compute_force_resident_hip(ctypes.byref(sv), pm, ctypes.byref(chost.PainterView(0, 2)), 0, 3, None, 1.0)
+    msgs.close()
+    msgs.check()
+    s = chost.mirror_stats()
+    assert s.h2d_bytes == 24 * (len(xa) + len(xb)) + 4 * len(xb) and s.d2h_bytes == 0      # x, x, mass: once
+    assert len(msgs.info) == 2 * 12                                     # six acc lines per species and call
+    for st, ref in ((sa, accs[0]), (sb, accs[1])):
+        assert np.all(st.acc == 0)                                      # still on the device ...
+        st.sync("acc")
+        assert util.rel_err(st.acc, ref) <= 1e-6                        # ... until a host consumer asks
+        st.release()
+    H.fastpm_free_pm_hip(pm)
