@@ -474,6 +474,16 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
 #ifndef FPM_RO_PROBE
 #define FPM_RO_PROBE 0
 #endif
+// experiments (build-time): FPM_RO_PF = particles per thread whose entry and half sum wait in registers (2; 0: all through
+// the global scratch row -- 124 VGPRs, 1.14 -> 1.40 ms at 512^3 fp64); FPM_RO_EARLY = 1: the next plane's rows are requested
+// right after c2r_prepare instead of after the transform (spills with PF = 2 and 1: 2.3 ms; with PF = 0 1.42 ms: the rows'
+// time in flight is not what the kernel waits for either)
+#ifndef FPM_RO_PF
+#define FPM_RO_PF 2
+#endif
+#ifndef FPM_RO_EARLY
+#define FPM_RO_EARLY 0
+#endif
 // LATE (the long rows, M >= 512): a plane's rows are requested right before their transform instead of a step ahead, and the
 // next plane's entries after it -- neither set of registers is held across the transform, the kernel fits 128 VGPRs
 // without spills (166 otherwise), and with that budget it runs 14.3 -> 13.0 ms at 1024^3 fp64 although the 58 KB of LDS
@@ -543,6 +553,9 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FP
         xm = tau == 0 ? src[M] : C2<F>{0, 0};
 #endif
     };
+#if FPM_RO_EARLY
+    int early_xp = -1;
+#endif
     auto c2r_plane = [&]() {                       // x[] -> the RW real rows of the plane in S (rowfft_c2r_kernel's arithmetic)
         C2<F> v[vmax(E)];
 #if FPM_RO_PROBE == 3 || FPM_RO_PROBE == 7
@@ -550,6 +563,9 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FP
         for (int j = 0; j < E; j++) v[j] = x[j];
 #else
         c2r_prepare<PL, CWX, SKX, F, WS>(v, x, xm, S, twn, tau, c);
+#if FPM_RO_EARLY
+        if (!LATE && early_xp >= 0) load_plane(early_xp);      // x[] is free again: the next plane's rows fly under the FFT core too
+#endif
 #if FPM_RO_PROBE != 2
         fft_core<PL, +1, CWX, false, F, SKX, WS, (WS && CF::ro_xs)>(v, S, tw, tau, c);
 #endif
@@ -575,9 +591,9 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FP
         }
         return acc;
     };
-    constexpr int PF = 2;
-    double px[PF], py[PF], pz[PF], pv[PF], qx[PF], qy[PF], qz[PF];
-    int prow[PF], qrow[PF], pc[PF], qc[PF];
+    constexpr int PF = FPM_RO_PF;
+    double px[PF + 1], py[PF + 1], pz[PF + 1], pv[PF + 1], qx[PF + 1], qy[PF + 1], qz[PF + 1];
+    int prow[PF + 1], qrow[PF + 1], pc[PF + 1], qc[PF + 1];
     int pb = 0, pn = 0, qb = 0, qn = 0;            // p: the particles that finish this step; q: those that start
     // (the slab of a tile is looked up a step before its entries are requested: the entry loads then go out at once,
     // instead of behind a scalar load and the wait -- for the LDS counter too -- that comes with it)
@@ -640,18 +656,24 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FP
     stage_twiddles(tw, tw_global, PL::TWN, 2);
     stage_twiddles(twn, tw_global, M, 1);
     __syncthreads();
+#if FPM_RO_EARLY
+    early_xp = LATE ? -1 : xa + 1;
+#endif
     c2r_plane();
     __syncthreads();
-    if (!LATE) load_plane(xa + 1);
+    if (!LATE && !FPM_RO_EARLY) load_plane(xa + 1);
     start_q();
     for (int i = xa; i < xb; i++) {                // the window goes from plane i to plane i + 1
         if (!LATE && i + 1 < xb) fetch_q(i + 1);   // needed after the transform
         if (LATE) load_plane(i + 1);
         __syncthreads();                           // every gather from plane i is done
+#if FPM_RO_EARLY
+        early_xp = (!LATE && i + 1 < xb) ? i + 2 : -1;
+#endif
         c2r_plane();
         __syncthreads();
         if (LATE && i + 1 < xb) fetch_q(i + 1);
-        if (!LATE && i + 1 < xb) load_plane(i + 2);         // lands during the gathers
+        if (!LATE && !FPM_RO_EARLY && i + 1 < xb) load_plane(i + 2);         // lands during the gathers
         finish_p();
         if (i + 1 < xb) start_q();
     }
