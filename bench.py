@@ -363,6 +363,10 @@ def main():
     ap.add_argument("--nprocy", type=int, default=1,
                     help="N > 1 GPUs: process mesh (gpus / nprocy) x nprocy; 1 = x slabs (default), 2 on 8 GPUs = the "
                          "reference's default 4 x 2 pencils (pmpfft.c:117-136)")
+    ap.add_argument("--wire", default="mesh", choices=["mesh", "f32"],
+                    help="N > 1: the dtype the FFT transposes cross xGMI in -- mesh (default: the mesh's own) or f32 (an fp64 "
+                         "mesh's chunks narrowed to float32 on the wire: half the bytes; the deviation of acc from the "
+                         "full-width run is measured after the timed region and printed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--static", action="store_true",
                     help="time every step on the SAME positions (the binning's best case; the default alternates between "
@@ -452,10 +456,13 @@ def main():
         if world > 1 and args.nprocy > 1:
             from fastpm_amd.distributed import PencilForce
             pf = PencilForce(pm, dist.group.WORLD)
+            pf.wire = torch.float32 if args.wire == "f32" else None
+            holder = {"force": pf}
             step = lambda: pf.compute_force(next_store(), kernel="1_4", dealias="none", delta_k=delta_k)
         elif world > 1:
             from fastpm_amd.distributed import SlabForce
             holder = {"force": SlabForce(pm, dist.group.WORLD)}
+            holder["force"].wire = torch.float32 if args.wire == "f32" else None
             step = lambda: holder["force"].compute_force(next_store(), kernel="1_4", dealias="none", delta_k=delta_k)
             try:                                   # one untimed call first: if the pipelined exchange (plane ranges as
                 step()                             # coalesced isend / irecv batches) is refused by this RCCL build,
@@ -463,6 +470,7 @@ def main():
             except Exception as e:                 # one-all_to_all_single-per-transpose path instead
                 notes.append("pipelined exchange failed (%r); running with chunks=1" % (e,))
                 holder["force"] = SlabForce(pm, dist.group.WORLD, chunks=1)
+                holder["force"].wire = torch.float32 if args.wire == "f32" else None
         else:
             step = lambda: pm.compute_force(next_store(), kernel="1_4", softening="none", delta_k=delta_k,
                                             total_mass=float(np_total))
@@ -478,6 +486,19 @@ def main():
         dt = time.perf_counter() - t0
         tm = pm.timings()
         pm.timing_enable(False)
+        if world > 1 and args.wire == "f32" and args.precision == 64:
+            # what the narrow wire costs: the same positions once more at full width, outside the timed region
+            st_ = stores[turn[0]]
+            a32 = st_.acc.clone()
+            holder["force"].wire = None
+            step_again = lambda: holder["force"].compute_force(st_, kernel="1_4", dealias="none", delta_k=delta_k)
+            step_again()
+            torch.cuda.synchronize()
+            dev = torch.stack([(a32 - st_.acc).abs().max(), st_.acc.abs().max()]).to(torch.float64)
+            dev = dev if backend == "nccl" else dev.cpu()
+            dist.all_reduce(dev, op=dist.ReduceOp.MAX)
+            notes.append({"wire": "f32", "acc_max_abs_dev_over_max_abs_acc_vs_full_width": float(dev[0] / dev[1])})
+            holder["force"].wire = torch.float32
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -663,7 +684,9 @@ def main():
                              "real": "real space, 1 inverse FFT + stencil readout (FPMHIP_GRADIENT_REAL)"}[args.gradient],
                 "paint_mode": ("strip tiles: paint + z r2c pass and z c2r pass + readout in one kernel each" if strips
                                else {0: "box tiles", 1: "atomic", 2: "box tiles"}.get(args.paint_mode, str(args.paint_mode))),
-                "fft": "hand-written row + column passes" if pm.column_fft() else "rocFFT"},
+                "fft": "hand-written row + column passes" if pm.column_fft() else "rocFFT",
+                "wire": ("float32 on the wire for the fp64 mesh's transposes (--wire f32)" if args.wire == "f32" and world > 1 and args.precision == 64
+                         else "the mesh dtype")},
             "per_gpu": value / world, "finite": acc_ok, "momentum_residual": momentum_residual,
             # rank 0: time inside this library's kernels vs the rest of the step (for N > 1 the rest is
             # the RCCL all-to-alls / halo shifts that are not hidden behind compute)

@@ -103,14 +103,34 @@ class _SlabRank:
             err = e
         self._late_agreement(err)
 
+    # A narrower WIRE FORMAT for the transposes of an fp64 mesh (round 4, off by default: `wire = torch.float32`): the
+    # chunks cross xGMI as float32 -- half the bytes of the exchanges that bound every N > 1 step -- and
+    # are widened again on arrival; every piece, this rank's own included, takes the same rounding, so the result does not
+    # depend on the decomposition.  What it costs in accuracy is printed by bench.py --wire f32 (acc within ~1e-7 of max|acc|:
+    # the rounding of a float32 mesh at the transposes only).  The halo planes / rows keep the mesh dtype.
+    wire = None
+
+    def _narrow(self, t):
+        return t.to(self.wire) if self.wire is not None and t.dtype == torch.float64 else None
+
+    def _finish(self, tag):
+        for dst, src in self._widen.pop(tag, []):
+            dst.copy_(src)
+
     def _communicate(self, req):
         kind = req[0]
         g = self.group
+        if not hasattr(self, "_widen"):
+            self._widen = {}
         if kind == "wait" and not self._pending.get(req[1]):
             self._pending.pop(req[1], None)
+            self._finish(req[1])
             return
         if self._host_staged(req):
             return self._communicate_staged(req)
+        if self.wire is not None and kind in ("alltoall_g", "alltoall", "alltoall_start", "alltoall_range_start") \
+                and req[2].dtype == torch.float64:
+            return self._communicate_narrow(req)
         if kind == "allreduce":
             dist.all_reduce(req[1], op=dist.ReduceOp.SUM, group=g)
         elif kind == "alltoall_g":
@@ -146,6 +166,7 @@ class _SlabRank:
         elif kind == "wait":
             for w in self._pending.pop(req[1]):
                 w.wait()
+            self._finish(req[1])
         elif kind == "shift":
             ops = []
             for send, recv, direction in req[1]:
@@ -157,6 +178,47 @@ class _SlabRank:
                 w.wait()
         else:
             raise ValueError(kind)
+
+    def _communicate_narrow(self, req):
+        """the transposes with the chunks narrowed to self.wire on the way out and widened on arrival"""
+        kind = req[0]
+        g = self.group
+        if kind == "alltoall_g":
+            _, recv, send, chunk, axis = req
+            ag, _, n, _ = self._axis(axis)
+            s = send[:n * chunk].to(self.wire)
+            r = torch.empty_like(s)
+            dist.all_to_all_single(r, s, group=ag)
+            recv[:n * chunk].copy_(r)
+        elif kind in ("alltoall", "alltoall_start"):
+            n = self.pm.exchange_chunk_elems() * self.P
+            s = req[2][:n].to(self.wire)
+            r = torch.empty_like(s)
+            if kind == "alltoall":
+                dist.all_to_all_single(r, s, group=g)
+                req[1][:n].copy_(r)
+            else:
+                self._pending[req[3]] = [dist.all_to_all_single(r, s, group=g, async_op=True)]
+                self._widen[req[3]] = [(req[1][:n], r)]
+                self._keep = getattr(self, "_keep", {})
+                self._keep[req[3]] = s                      # the send buffer must outlive the exchange
+        else:                                               # alltoall_range_start
+            _, recv, send, x0, nx, tag = req
+            ops, widen, keep = [], [], []
+            for r_, (s, d) in enumerate(zip(_range_views(self.pm, send, x0, nx), _range_views(self.pm, recv, x0, nx))):
+                s32 = s.to(self.wire)
+                if r_ == self.rank:
+                    d.copy_(s32)                            # the same rounding as every other piece
+                else:
+                    d32 = torch.empty_like(s32)
+                    ops.append(dist.P2POp(dist.isend, s32, _global_rank(g, r_), group=g))
+                    ops.append(dist.P2POp(dist.irecv, d32, _global_rank(g, r_), group=g))
+                    widen.append((d, d32))
+                    keep.append(s32)
+            self._pending[tag] = dist.batch_isend_irecv(ops) if ops else []
+            self._widen[tag] = widen
+            self._keep = getattr(self, "_keep", {})
+            self._keep[tag] = keep
 
 
     # -- device tensors over a backend that only moves host memory (gloo): staged through the host, blocking.
@@ -175,7 +237,8 @@ class _SlabRank:
         elif kind == "alltoall_g":
             _, recv, send, chunk, axis = req
             ag, _, n, _ = self._axis(axis)
-            sh = send[:n * chunk].cpu()
+            sh = send[:n * chunk]
+            sh = (sh if self._narrow(sh) is None else self._narrow(sh)).cpu()
             rh = torch.empty_like(sh)
             dist.all_to_all_single(rh, sh, group=ag)
             recv[:n * chunk].copy_(rh)
@@ -193,7 +256,8 @@ class _SlabRank:
                 recv.copy_(hr)
         elif kind in ("alltoall", "alltoall_start"):
             n = self.pm.exchange_chunk_elems() * self.P
-            s = req[2][:n].cpu()
+            s = req[2][:n]
+            s = (s if self._narrow(s) is None else self._narrow(s)).cpu()
             r = torch.empty_like(s)
             dist.all_to_all_single(r, s, group=g)
             req[1][:n].copy_(r)
@@ -202,7 +266,7 @@ class _SlabRank:
         elif kind == "alltoall_range_start":
             _, recv, send, x0, nx, tag = req
             sv, rv = _range_views(self.pm, send, x0, nx), _range_views(self.pm, recv, x0, nx)
-            s = torch.cat([v.cpu() for v in sv])
+            s = torch.cat([(v if self._narrow(v) is None else self._narrow(v)).cpu() for v in sv])
             r = torch.empty_like(s)
             dist.all_to_all_single(r, s, group=g)
             for v, piece in zip(rv, r.chunk(self.P)):

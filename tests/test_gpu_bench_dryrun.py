@@ -67,3 +67,18 @@ def test_multi_rank_bench_path_on_pencils_with_strip_tiles():
     assert d["n_gpus"] == 4 and d["finite"] and d["config"]["decomposition"] == "pencil 2x2"
     assert d["config"]["paint_mode"].startswith("strip tiles")
     assert d["momentum_residual"] < 1e-6 and d["value"] is None and d["dry_run"]["would_be_value"] > 0
+
+
+def test_multi_rank_bench_path_with_a_float32_wire():
+    """`--wire f32`: the transposes of the fp64 mesh cross the wire as float32 (pipelined plane ranges included); the line
+    says so and prints how far the accelerations are from the full-width run."""
+    env = dict(os.environ, FPM_BENCH_BACKEND="gloo", FPM_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29616", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--nc", "64", "--nmesh", "128", "--wire", "f32"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["finite"] and d["config"]["wire"].startswith("float32") and d["momentum_residual"] < 1e-5
+    w = [n for n in d["notes"] if isinstance(n, dict) and n.get("wire") == "f32"]
+    assert w and 0 < w[0]["acc_max_abs_dev_over_max_abs_acc_vs_full_width"] < 5e-6
