@@ -304,11 +304,9 @@ static int check_range(const fpmhip_plan *p, int x0, int nx)
 {
     if (!p->own_fft || !rowfft_supported(p->mg.N)) FPM_FAIL(-1, "ranged stage calls need the column-FFT back end (see fpmhip_plan_ranged_fft)");
     if (x0 < 0 || nx < 1 || x0 + nx > p->mg.xl) FPM_FAIL(-1, "plane range [%d, %d) outside the slab of %d planes", x0, x0 + nx, p->mg.xl);
-    // k-space blocks (fpmhip_layout.okblock != osize[1]): the planes [x0, x0 + nx) of an exchange chunk
-    // [ky_loc / kb][x_loc][kb][kz] are ky_loc / kb separate pieces, not the one contiguous block a ranged exchange
-    // sends -- a partial range would put the wrong bytes on the wire.  Whole-slab calls stay valid.
-    if (p->mg.kyb != p->mg.yl && (x0 != 0 || nx != p->mg.xl))
-        FPM_FAIL(-1, "plane ranges are not offered on the blocked k-space layout (okblock %d of %d ky rows): exchange whole slabs (fpmhip_plan_ranged_fft returns 0)", p->mg.kyb, p->mg.yl);
+    // (k-space blocks, fpmhip_layout.okblock != osize[1]: the planes [x0, x0 + nx) of an exchange chunk
+    // [ky_loc / kb][x_loc][kb][kz] are ky_loc / kb separate pieces -- fpmhip_range_pieces says where; the passes
+    // themselves address planes, whatever the layout)
     return 0;
 }
 
@@ -320,9 +318,32 @@ extern "C" {
 
 int fpmhip_plan_ranged_fft(const fpmhip_plan *p)
 {
-    // 0 on the blocked k-space layout (fpmhip_layout.okblock != osize[1], chosen for Nmesh >= 1536 on several x ranks): a
-    // plane range of an exchange chunk is not contiguous there (check_range above)
-    return p && p->own_fft && rowfft_supported(p->mg.N) && p->mg.kyb == p->mg.yl ? 1 : 0;
+    return p && p->own_fft && rowfft_supported(p->mg.N) ? 1 : 0;
+}
+
+// Where the planes [x0, x0 + nx) of ONE per-rank exchange chunk lie (mesh elements, relative to the chunk's start):
+// npieces contiguous pieces of piece_elems, stride_elems apart, the first at first_elem.  Plain layout [x_loc][y_loc][kz]:
+// one piece.  Blocked layout [ky_loc / kb][x_loc][kb][kz] (fpmhip_layout.okblock): ky_loc / kb pieces of nx * kb rows.
+int fpmhip_range_pieces(const fpmhip_plan *p, int x0, int nx, int64_t *first_elem, int64_t *piece_elems,
+                        int64_t *stride_elems, int *npieces)
+{
+    if (!p || !first_elem || !piece_elems || !stride_elems || !npieces) FPM_FAIL(-1, "null argument");
+    if (p->lay.nranks_y > 1) FPM_FAIL(-1, "plane ranges are a slab feature");
+    FPM_TRY(check_range(p, x0, nx));
+    const MeshGeo &g = p->mg;
+    const int64_t row = 2 * (int64_t) g.nzl;                 // mesh elements (reals) per k row
+    if (g.kyb == g.yl) {
+        *npieces = 1;
+        *first_elem = (int64_t) x0 * g.yl * row;
+        *piece_elems = (int64_t) nx * g.yl * row;
+        *stride_elems = (int64_t) g.xl * g.yl * row;
+    } else {
+        *npieces = g.yl / g.kyb;
+        *first_elem = (int64_t) x0 * g.kyb * row;
+        *piece_elems = (int64_t) nx * g.kyb * row;
+        *stride_elems = (int64_t) g.xl * g.kyb * row;
+    }
+    return 0;
 }
 
 // The (y, z) halves of the slab transforms for the x planes [x0, x0 + nx) only, so that the all-to-all of one

@@ -156,12 +156,13 @@ class _SlabRank:
             # shape all_to_all takes on RCCL anyway) + a local copy for this rank's own piece
             _, recv, send, x0, nx, tag = req
             ops = []
-            for r, (s, d) in enumerate(zip(_range_views(self.pm, send, x0, nx), _range_views(self.pm, recv, x0, nx))):
-                if r == self.rank:
-                    d.copy_(s)
-                else:
-                    ops.append(dist.P2POp(dist.isend, s, _global_rank(g, r), group=g))
-                    ops.append(dist.P2POp(dist.irecv, d, _global_rank(g, r), group=g))
+            for r, (ss, dd) in enumerate(zip(_range_views(self.pm, send, x0, nx), _range_views(self.pm, recv, x0, nx))):
+                for s, d in zip(ss, dd):
+                    if r == self.rank:
+                        d.copy_(s)
+                    else:
+                        ops.append(dist.P2POp(dist.isend, s, _global_rank(g, r), group=g))
+                        ops.append(dist.P2POp(dist.irecv, d, _global_rank(g, r), group=g))
             self._pending[tag] = dist.batch_isend_irecv(ops) if ops else []
         elif kind == "wait":
             for w in self._pending.pop(req[1]):
@@ -205,16 +206,17 @@ class _SlabRank:
         else:                                               # alltoall_range_start
             _, recv, send, x0, nx, tag = req
             ops, widen, keep = [], [], []
-            for r_, (s, d) in enumerate(zip(_range_views(self.pm, send, x0, nx), _range_views(self.pm, recv, x0, nx))):
-                s32 = s.to(self.wire)
-                if r_ == self.rank:
-                    d.copy_(s32)                            # the same rounding as every other piece
-                else:
-                    d32 = torch.empty_like(s32)
-                    ops.append(dist.P2POp(dist.isend, s32, _global_rank(g, r_), group=g))
-                    ops.append(dist.P2POp(dist.irecv, d32, _global_rank(g, r_), group=g))
-                    widen.append((d, d32))
-                    keep.append(s32)
+            for r_, (ss, dd) in enumerate(zip(_range_views(self.pm, send, x0, nx), _range_views(self.pm, recv, x0, nx))):
+                for s, d in zip(ss, dd):
+                    s32 = s.to(self.wire)
+                    if r_ == self.rank:
+                        d.copy_(s32)                        # the same rounding as every other piece
+                    else:
+                        d32 = torch.empty_like(s32)
+                        ops.append(dist.P2POp(dist.isend, s32, _global_rank(g, r_), group=g))
+                        ops.append(dist.P2POp(dist.irecv, d32, _global_rank(g, r_), group=g))
+                        widen.append((d, d32))
+                        keep.append(s32)
             self._pending[tag] = dist.batch_isend_irecv(ops) if ops else []
             self._widen[tag] = widen
             self._keep = getattr(self, "_keep", {})
@@ -266,11 +268,12 @@ class _SlabRank:
         elif kind == "alltoall_range_start":
             _, recv, send, x0, nx, tag = req
             sv, rv = _range_views(self.pm, send, x0, nx), _range_views(self.pm, recv, x0, nx)
-            s = torch.cat([(v if self._narrow(v) is None else self._narrow(v)).cpu() for v in sv])
+            s = torch.cat([(v if self._narrow(v) is None else self._narrow(v)).cpu() for vs in sv for v in vs])
             r = torch.empty_like(s)
             dist.all_to_all_single(r, s, group=g)
-            for v, piece in zip(rv, r.chunk(self.P)):
-                v.copy_(piece)
+            for vs, part in zip(rv, r.chunk(self.P)):
+                for v, piece in zip(vs, part.chunk(len(vs))):
+                    v.copy_(piece)
             self._pending[tag] = []
         elif kind == "shift":
             ops, back = [], []
@@ -504,11 +507,8 @@ class SlabForce(_SlabRank):
         c = int(self.chunks)
         if c <= 1 or self.P == 1 or not getattr(pm, "ranged_fft", lambda: False)() or xl % c != 0:
             return [(0, xl)]
-        # k-space blocks (fpmhip_layout.okblock, the meshes from Nmesh = 1536): a plane range of an exchange chunk
-        # [ky_loc / kb][x_loc][kb][kz] is ky_loc / kb separate pieces -- whole-slab exchanges there
-        kb = int(getattr(pm.layout, "okblock", 0) or 0)
-        if kb and kb != int(pm.layout.osize[1]):
-            return [(0, xl)]
+        # (k-space blocks -- fpmhip_layout.okblock, the meshes from Nmesh = 1536: a plane range of an exchange chunk
+        # [ky_loc / kb][x_loc][kb][kz] is ky_loc / kb separate pieces, which _range_views hands to the exchange one by one)
         return [(i * (xl // c), xl // c) for i in range(c)]
 
     def _backward(self, delta_k, kernel, field, out):
@@ -1001,10 +1001,13 @@ def run_virtual_decompose(decomposers, stores):
 
 
 def _range_views(pm, buf, x0, nx):
-    """The planes [x0, x0 + nx) of each of the P per-rank chunks of an exchange buffer."""
+    """The planes [x0, x0 + nx) of each of the P per-rank chunks of an exchange buffer: per rank a LIST of contiguous
+    pieces -- one on the plain k-space layout; on the blocked layout (fpmhip_layout.okblock, Nmesh >= 1536) a chunk is
+    [ky_loc / kb][x_loc][kb][kz] and the range is ky_loc / kb pieces (fpmhip_range_pieces)."""
     chunk = pm.exchange_chunk_elems()
-    row = chunk // int(pm.layout.isize[0])
-    return [buf[r * chunk + x0 * row: r * chunk + (x0 + nx) * row] for r in range(pm.nranks)]
+    first, piece, stride, npieces = pm.range_pieces(x0, nx)
+    return [[buf[r * chunk + first + i * stride: r * chunk + first + i * stride + piece] for i in range(npieces)]
+            for r in range(pm.nranks)]
 
 
 def _gradorder(kernel):
@@ -1065,7 +1068,8 @@ def run_virtual_steps(forces, gens):
             recvs = [_range_views(pm, r[1], x0, nx) for r in reqs]
             for dst in range(P):
                 for src in range(P):
-                    recvs[dst][src].copy_(sends[src][dst])
+                    for dv, sv_ in zip(recvs[dst][src], sends[src][dst]):
+                        dv.copy_(sv_)
         elif kind == "alltoall_g":
             chunk, axis = reqs[0][3], reqs[0][4]
             for dst in range(P):

@@ -128,6 +128,8 @@ SYMBOLS = {
                              ctypes.POINTER(DriftFactor), ctypes.POINTER(DriftFactor), _I]),
     "fpmhip_leapfrog_bin": (_I, [_P, ctypes.POINTER(Particles), _P, _P, _P, _I, ctypes.POINTER(KickFactor),
                                  ctypes.POINTER(KickFactor), ctypes.POINTER(DriftFactor), ctypes.POINTER(DriftFactor), _I]),
+    "fpmhip_range_pieces": (_I, [_P, _I, _I, ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I64),
+                                 ctypes.POINTER(_I)]),
     "fpmhip_plan_scratch": (_P, [_P, ctypes.c_size_t]),
     "fpmhip_paint_zr2c_pen": (_I, [_P, ctypes.POINTER(Particles), _D, _P, _P, _P]),
     "fpmhip_readout3_zc2r_pen": (_I, [_P, ctypes.POINTER(Particles), _P, _P, _P, ctypes.POINTER(_P), ctypes.POINTER(_P)]),

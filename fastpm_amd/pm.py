@@ -642,6 +642,15 @@ class PM:
     def ranged_fft(self):
         return bool(self._L.fpmhip_plan_ranged_fft(self._plan))
 
+    def range_pieces(self, x0, nx):
+        """(first, piece, stride, npieces) in mesh elements, relative to the start of a per-rank exchange chunk: the planes
+        [x0, x0 + nx) of a chunk are npieces contiguous pieces of `piece` elements, `stride` apart (fpmhip_range_pieces)"""
+        v = [ctypes.c_int64() for _ in range(3)]
+        n = ctypes.c_int()
+        check(self._L.fpmhip_range_pieces(self._plan, int(x0), int(nx), ctypes.byref(v[0]), ctypes.byref(v[1]),
+                                          ctypes.byref(v[2]), ctypes.byref(n)))
+        return int(v[0].value), int(v[1].value), int(v[2].value), int(n.value)
+
     def fft_yz_forward_range(self, canvas, send, x0, nx):
         check(self._L.fpmhip_fft_yz_forward_range(self._plan, _ptr(canvas), _ptr(send), int(x0), int(nx)))
 

@@ -311,12 +311,16 @@ int fpmhip_plan_staged_fft(const fpmhip_plan *plan);
 /* The (y, z) halves for the x planes [x0, x0 + nx) of the slab only: the exchange of one plane range can be in
  * flight while the next range is transformed.  Within an exchange chunk the planes of one range are contiguous:
  * range (x0, nx) of the chunk for rank r starts r * fpmhip_exchange_chunk_elems() + x0 * (chunk / xl) elements
- * into the buffer.  Available when fpmhip_plan_ranged_fft() is 1: column-FFT back end, Nmesh / 2 supported, AND the
- * plain k-space layout (fpmhip_layout.okblock == osize[1]).  On the blocked layout (Nmesh >= 1536 on several x ranks) a
- * plane range of an exchange chunk [ky_loc / okblock][x_loc][okblock][kz] is ky_loc / okblock separate pieces:
- * fpmhip_plan_ranged_fft() returns 0 there and every *_range call with a partial range fails (-1) instead of handing a
- * pipelined exchange the wrong bytes; exchange whole slabs (x0 = 0, nx = x_loc stays valid). */
+ * into the buffer -- ON THE PLAIN k-space layout (fpmhip_layout.okblock == osize[1]).  On the blocked layout (Nmesh >= 1536
+ * on several x ranks) a chunk is [ky_loc / okblock][x_loc][okblock][kz] and a plane range of it is ky_loc / okblock
+ * separate pieces: ask fpmhip_range_pieces() where the range lies and exchange THOSE pieces (distributed.py:
+ * _range_views); a ranged exchange that assumes one contiguous block would put the wrong bytes on the wire there.
+ * Available when fpmhip_plan_ranged_fft() is 1 (column-FFT back end, Nmesh / 2 supported). */
 int fpmhip_plan_ranged_fft(const fpmhip_plan *plan);
+/* the planes [x0, x0 + nx) of ONE per-rank exchange chunk: *npieces contiguous pieces of *piece_elems mesh elements,
+ * *stride_elems apart, the first *first_elem elements into the chunk (one piece on the plain layout) */
+int fpmhip_range_pieces(const fpmhip_plan *plan, int x0, int nx, int64_t *first_elem, int64_t *piece_elems,
+                        int64_t *stride_elems, int *npieces);
 int fpmhip_fft_yz_forward_range(fpmhip_plan *plan, void *canvas_dev, void *send_dev, int x0, int nx);
 int fpmhip_fft_yz_backward_range(fpmhip_plan *plan, void *recv_dev, void *canvas_dev, int x0, int nx);
 int fpmhip_fft_yz_backward_grad2_range(fpmhip_plan *plan, void *recv_dev, void *out_y_dev, void *out_z_dev,

@@ -56,6 +56,10 @@ class CpuSlabOps:
     def exchange_chunk_elems(self):
         return 2 * self.xl * self.yl * self.nzc
 
+    def range_pieces(self, x0, nx):
+        row = 2 * self.yl * self.nzc                            # plain layout: one piece (fpmhip_range_pieces)
+        return x0 * row, nx * row, self.xl * row, 1
+
     def _real(self, buf):
         nx = self.xl + self.layout.ihalo
         return buf.numpy()[: nx * self.layout.plane_elems].reshape(nx, self.Nmesh, self.Nmesh + 2)

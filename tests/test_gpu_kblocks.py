@@ -44,6 +44,11 @@ def test_slabs_and_pencils(oracle, Nx, Ny, kb, paint_mode, chunks):
     stores = [Store(x[idx[r]], potential=True) for r in range(P)]
     dks = [pm.alloc() for pm in pms]
     forces = [PencilForce(pm) if Ny > 1 else SlabForce(pm, chunks=chunks) for pm in pms]
+    if Ny == 1 and chunks > 1:
+        # plane-range pipelining ON the blocked layout: each range of an exchange chunk is ky_loc / kb pieces
+        assert len(forces[0]._ranges()) == chunks
+        yl = int(pms[0].layout.osize[1])
+        assert pms[0].range_pieces(0, 1)[3] == yl // kb and (yl // kb > 1 or kb == yl)
     run_virtual(forces, stores, kernel="1_4", dealias="none", delta_ks=dks)
     torch.cuda.synchronize()
     acc = np.zeros_like(ref["acc"])

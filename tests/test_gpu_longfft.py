@@ -45,16 +45,15 @@ def _chunks_store(pm, buf, P, yl, values):
 def test_long_staged_passes_against_torch_fft(N, precision):
     import torch
     pm = _pm(N, precision)
-    # plane ranges are offered only on the plain k-space layout: on the blocked one (these lengths on several x ranks) a
-    # range of an exchange chunk is not contiguous and the ranged calls refuse partial ranges
+    # plane ranges are offered on both k-space layouts; on the blocked one (these lengths on several x ranks) a range of an
+    # exchange chunk is ky_loc / kb pieces, which fpmhip_range_pieces describes
     blocked = int(pm.layout.okblock) != int(pm.layout.osize[1])
-    assert pm.column_fft() and pm.ranged_fft() == (not blocked)
-    if blocked:
-        from fastpm_amd.lib import FastPMHipError
-        a, b = pm.alloc(), pm.alloc()
-        with pytest.raises(FastPMHipError, match="blocked k-space layout"):
-            pm.fft_yz_forward_range(a, b, 0, XL // 2)
-        del a, b
+    assert pm.column_fft() and pm.ranged_fft()
+    first, piece, stride, npieces = pm.range_pieces(XL // 4, XL // 2)
+    row = 2 * int(pm.layout.osize[2])
+    kb, yl_ = int(pm.layout.okblock), int(pm.layout.osize[1])
+    assert (first, piece, stride, npieces) == ((XL // 4) * kb * row, (XL // 2) * kb * row, XL * kb * row, yl_ // kb)
+    assert (npieces > 1) == blocked
     nzc, P, yl = N // 2 + 1, N // XL, XL
     cdt = torch.complex128 if precision == 64 else torch.complex64
     tol = 2e-14 if precision == 64 else 2e-6
