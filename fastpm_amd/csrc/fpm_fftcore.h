@@ -366,6 +366,8 @@ template <int N, int E, int PPA, int RA, int RB, int ES> constexpr int xshift()
 {
     // fp64 (16-byte elements), E = 8 plans; modelled gather cycles per row, plain -> skewed:
     //   512 = 8.8.8: 64 -> 32 and 256 -> 32;  256 = 8.8.4: 128 -> 32 and 128 -> 32;  128 = 8.8.2: 128 -> 64, second plain
+    //   1024 = 16.8.8 (E = 16, one wave per row; fp64): gathers 128 -> 64 and 512 -> 64
+    if (E == 16) return N == 1024 && ES == 16 ? 3 : 0;
     if (E != 8) return 0;
     // fp32 (8-byte elements, ds_*_b64; the readout only -- the paint loses with it): 512: gathers 64 -> 16 and 128 -> 16;
     // 256: 128 -> 16 and 64 -> 16

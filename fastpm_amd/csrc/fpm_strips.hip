@@ -72,15 +72,18 @@ template <typename PL> struct HalfTw : PL {
 #define FPM_XSKEW 1
 #endif
 // fp32: the readout only, M = 256 / 512 (0.787 -> 0.769 ms at 512^3, 8.5 -> 8.1 ms at 1024^3; the paint loses 8 % with it).
-constexpr bool strip_xs(int M, int elem_bytes, bool paint)
+constexpr bool strip_xs(int M, int elem_bytes, bool paint, int E = 8)
 {
     if (!FPM_XSKEW) return false;
+    // one wave per row of M = 1024 (E = 16 values per thread, 16.8.8; fp64 readout): the last gather 512 -> 64 modelled cycles
+    if (E == 16) return M == 1024 && elem_bytes == 16 && !paint;
+    if (E != 8) return false;
     if (elem_bytes == 16) return M == 128 || M == 256 || M == 512;
     return !paint && (M == 256 || M == 512);
 }
-constexpr int strip_xspan(int M, int elem_bytes, bool paint)     // values a row's exchange region needs
+constexpr int strip_xspan(int M, int elem_bytes, bool paint, int E = 8)     // values a row's exchange region needs
 {
-    return strip_xs(M, elem_bytes, paint) ? M + M / 8 : M;
+    return strip_xs(M, elem_bytes, paint, E) ? M + M / 8 : M;
 }
 constexpr int strip_pitch(int M, int rem)            // the smallest pitch >= M + 1 that is `rem` modulo 16
 {
@@ -100,16 +103,16 @@ template <typename PL, typename F> struct StripCfg {
     // gathers of the later stages off each other's banks (tools/lds_bank_model.py: 336 -> 224 LDS cycles per row pair and
     // plane): readout 0.85 -> 0.815 ms at 512^3 fp32.  In fp64 the same skew (modelled 544 -> 432) LOSES, 1.19 -> 1.23 ms at
     // 512^3 and 14.25 -> 14.7 at 1024^3: not applied there.
-    static constexpr int ws_sk = sizeof(F) == 4 && !strip_xs(M, 8, false) ? 2 : 0;
-    static constexpr bool ro_xs = strip_xs(M, (int) sizeof(C2<F>), false), pt_xs = strip_xs(M, (int) sizeof(C2<F>), true);
-    static constexpr int ro_pitch = strip_pitch(vmax_i(M + ws_sk * (M / 32), strip_xspan(M, (int) sizeof(C2<F>), false)), 13);
+    static constexpr int ws_sk = sizeof(F) == 4 && !strip_xs(M, 8, false, PL::E) ? 2 : 0;
+    static constexpr bool ro_xs = strip_xs(M, (int) sizeof(C2<F>), false, PL::E), pt_xs = strip_xs(M, (int) sizeof(C2<F>), true, PL::E);
+    static constexpr int ro_pitch = strip_pitch(vmax_i(M + ws_sk * (M / 32), strip_xspan(M, (int) sizeof(C2<F>), false, PL::E)), 13);
     static constexpr int ro_xchg = (M + 1) * STRIP_RW + ro_sk * (M / 32 + 1);       // elements of the exchange area
     static constexpr int ro_slot = ro_pitch * STRIP_RW > ro_xchg ? ro_pitch * STRIP_RW : ro_xchg;
     static constexpr size_t ro_lds = twb + (size_t) 2 * ro_slot * sizeof(C2<F>);
     static constexpr size_t ro1_lds = twb + (size_t) ro_slot * sizeof(C2<F>);       // the marching readout: ONE plane
     // paint: one plane of STRIP_Y rows of pt_pitch double accumulators
     static constexpr int pt_threads = T * STRIP_Y;
-    static constexpr int pt_pitch = 2 * strip_pitch(strip_xspan(M, (int) sizeof(C2<F>), true), 4);
+    static constexpr int pt_pitch = 2 * strip_pitch(strip_xspan(M, (int) sizeof(C2<F>), true, PL::E), 4);
     static constexpr size_t pt_twb = (size_t) (M / 2 + M) * sizeof(C2<F>);
     static constexpr size_t pt1_lds = pt_twb + (size_t) STRIP_Y * pt_pitch * sizeof(double);      // one plane
 };
@@ -481,6 +484,19 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
 #ifndef FPM_RO_PF
 #define FPM_RO_PF 2
 #endif
+// experiment: one WAVE per row at M = 256 (E = 4 values per thread, 4.4.4.4, three exchanges): FPMHIP_RO_E4=1
+#ifndef FPM_RO_E4_MINW
+#define FPM_RO_E4_MINW 4
+#endif
+#ifndef FPM_RO_E4_PF
+#define FPM_RO_E4_PF 1
+#endif
+#ifndef FPM_RO_E16_PF
+#define FPM_RO_E16_PF 4
+#endif
+#ifndef FPM_RO_E4_LATE
+#define FPM_RO_E4_LATE false
+#endif
 #ifndef FPM_RO_EARLY
 #define FPM_RO_EARLY 0
 #endif
@@ -492,7 +508,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
 // M = 256 the same order loses in fp64 (1.18 -> 1.26 ms at 512^3: the prefetch matters more where the transform is short)
 // and wins in fp32 (0.816 -> 0.783 ms), where it is on as well.  (With 8-row strips, five-wave workgroups: 1.56 ms.)
 template <typename PL, typename F, bool WS, bool LATE = false, bool PEN = false>
-__global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FPM_RO_MINW) : 3)) void readout_march_kernel(
+__global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (PL::E == 4 ? FPM_RO_E4_MINW : PL::E == 16 ? (sizeof(F) == 8 ? 1 : 2) : WS ? (LATE ? 4 : FPM_RO_MINW) : 3)) void readout_march_kernel(
     MeshGeo g, int ncomp, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
     const double *__restrict__ sy, const double *__restrict__ sz, const int *__restrict__ sidx, const C2<F> *__restrict__ m0,
     const C2<F> *__restrict__ m1, const C2<F> *__restrict__ m2, float *__restrict__ out, int nmemb, int memb0,
@@ -591,7 +607,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (WS ? (LATE ? 4 : FP
         }
         return acc;
     };
-    constexpr int PF = FPM_RO_PF;
+    constexpr int PF = PL::E == 4 ? FPM_RO_E4_PF : PL::E == 16 ? FPM_RO_E16_PF : FPM_RO_PF;
     double px[PF + 1], py[PF + 1], pz[PF + 1], pv[PF + 1], qx[PF + 1], qy[PF + 1], qz[PF + 1];
     int prow[PF + 1], qrow[PF + 1], pc[PF + 1], qc[PF + 1];
     int pb = 0, pn = 0, qb = 0, qn = 0;            // p: the particles that finish this step; q: those that start
@@ -867,18 +883,23 @@ __global__ __launch_bounds__((PairCfg<PL2, F>::threads), FPM_RO_MINW) void reado
     }
 
 // two marching workgroups per CU: the one-plane windows of the readout and of the paint of the widest row
-// (M = 512 in fp64: 58 KB and 45 KB; M = 1024 in fp32: 57 KB and 78 KB)
-static constexpr size_t STRIP_LDS_MAX = 160 * 1024 / 2;
+// (M = 512 in fp64: 58 KB and 45 KB; M = 1024 in fp32: 57 KB and 78 KB) -- and, since round 4, ONE per CU for M = 1024 in
+// fp64 (the 2048^3 mesh: 126 KB and 90 KB): even so the marching kernels beat the box tiles + separate z passes there
+// (one rank of eight, ms: paint + z r2c 6.5 -> 4.8, z c2r x 3 + readout 18.0 -> 12.8, binning 3.6 -> 2.8).
+// FPMHIP_STRIP_LDS_KB = 80 restores the old cap (A/B).
+static constexpr size_t STRIP_LDS_MAX = 160 * 1024;
 
 bool strips_supported(int N, int precision)
 {
     if (!rowfft_supported(N) || N % STRIP_Y != 0 || N / 2 > 1024) return false;
     const size_t es = precision == 64 ? 16 : 8, M = (size_t) N / 2;
-    const int xs_ro = strip_xspan((int) M, (int) es, false), xs_pt = strip_xspan((int) M, (int) es, true);
+    const int xs_ro = strip_xspan((int) M, (int) es, false, M == 1024 ? 16 : 8), xs_pt = strip_xspan((int) M, (int) es, true);
     const size_t skw = M + (precision == 64 || strip_xs((int) M, 8, false) ? 0 : 2) * (M / 32);
     const size_t ro = (2 * M + (size_t) strip_pitch((int) (skw > (size_t) xs_ro ? skw : (size_t) xs_ro), 13) * STRIP_RW) * es;     // ~ StripCfg::ro1_lds
     const size_t pt = (M / 2 + M) * es + (size_t) STRIP_Y * 2 * strip_pitch(xs_pt, 4) * sizeof(double);       // = pt1_lds
-    return ro <= STRIP_LDS_MAX && pt <= STRIP_LDS_MAX;
+    // FPMHIP_STRIP_LDS_KB (A/B): the cap per workgroup
+    static const size_t cap = getenv("FPMHIP_STRIP_LDS_KB") ? (size_t) atoi(getenv("FPMHIP_STRIP_LDS_KB")) * 1024 : STRIP_LDS_MAX;
+    return ro <= cap && pt <= cap;
 }
 
 // where the two-plane readout (A/B: FPMHIP_RO_WIN=2) still fits a CU's LDS
@@ -1073,6 +1094,38 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
         }                                                                                                              \
     }
 #define CALL_RO(PL)                                                                                                    \
+    if constexpr (PL::N == 256 && sizeof(F) == 8) {                                                                    \
+        static const int e4_env = getenv("FPMHIP_RO_E4") ? atoi(getenv("FPMHIP_RO_E4")) : 0;                           \
+        if (e4_env && !pen.on && use_ws) {                                                                             \
+            using PX = FFTPlan<256, 4, 4, 4, 4, 4>;                                                                    \
+            using CF = StripCfg<PX, F>;                                                                                \
+            static int occ4 = 0;                                                                                       \
+            FPM_TRY(grant_lds(readout_march_kernel<PX, F, true, FPM_RO_E4_LATE, false>, CF::ro1_lds, p->device));      \
+            g.xseg = choose_xseg(g, readout_march_kernel<PX, F, true, FPM_RO_E4_LATE, false>, CF::ro_threads, CF::ro1_lds, ncomp * g.ntyo, 16, 128, &occ4); \
+            const int nseg = (g.xl + g.xseg - 1) / g.xseg;                                                             \
+            readout_march_kernel<PX, F, true, FPM_RO_E4_LATE, false><<<ncomp * g.ntyo * nseg, CF::ro_threads, CF::ro1_lds, p->stream>>>( \
+                g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                 \
+                (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride,      \
+                p->scell, pen);                                                                                        \
+            break;                                                                                                     \
+        }                                                                                                              \
+    }                                                                                                                  \
+    if constexpr (PL::N == 1024) {                                                                                     \
+        static const int e16_env = getenv("FPMHIP_RO_E16") ? atoi(getenv("FPMHIP_RO_E16")) : (sizeof(F) == 8);                      \
+        if (e16_env && !pen.on && !two_planes && ws_env != 0) {                                                        \
+            using PX = FFTPlan<1024, 16, 16, 8, 8, 1>;                                                                 \
+            using CF = StripCfg<PX, F>;                                                                                \
+            static int occ16 = 0;                                                                                      \
+            FPM_TRY(grant_lds(readout_march_kernel<PX, F, true, true, false>, CF::ro1_lds, p->device));                \
+            g.xseg = choose_xseg(g, readout_march_kernel<PX, F, true, true, false>, CF::ro_threads, CF::ro1_lds, ncomp * g.ntyo, 16, 128, &occ16); \
+            const int nseg = (g.xl + g.xseg - 1) / g.xseg;                                                             \
+            readout_march_kernel<PX, F, true, true, false><<<ncomp * g.ntyo * nseg, CF::ro_threads, CF::ro1_lds, p->stream>>>( \
+                g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                 \
+                (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride,      \
+                p->scell, pen);                                                                                        \
+            break;                                                                                                     \
+        }                                                                                                              \
+    }                                                                                                                  \
     if (64 % PL::T == 0 && use_ws) CALL_RO_W(PL, (64 % PL::T == 0)) else CALL_RO_W(PL, false)
     STRIP_DISPATCH(g.N / 2, CALL_RO)
 #undef CALL_RO

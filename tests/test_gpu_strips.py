@@ -197,8 +197,9 @@ def test_one_particle_and_no_particles_on_strips(oracle):
                                          (640, 64), (768, 64), (800, 64), (1024, 64), (1536, 32), (2048, 32)])
 def test_largest_strip_meshes_agree_with_box_tiles(N, precision):
     """Every row length the strip kernels take (two-plane readout window: N <= 512 in fp64, <= 1024 in fp32; the one-plane
-    window beyond, up to N = 1024 in fp64 -- the mesh of configs[2] -- and N = 2048 in fp32; radix-3 and radix-5 rows among
-    them): the strip path against the box path of the same library (itself held to the oracle at the sizes the oracle
+    window beyond, up to N = 2048 in fp32 -- in fp64 a 2048^3 mesh does not fit one GPU: its strip kernels, one wave per row of
+    1024 complex values, are held to the small cube by the rank share of tests/test_gpu_fullsize.py --; radix-3 and radix-5
+    rows among them): the strip path against the box path of the same library (itself held to the oracle at the sizes the oracle
     can do)."""
     import torch
     from fastpm_amd import PM, Store
