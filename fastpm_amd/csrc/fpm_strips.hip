@@ -480,11 +480,22 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
 // experiments (build-time): FPM_RO_PF = particles per thread whose entry and half sum wait in registers (2; 0: all through
 // the global scratch row -- 124 VGPRs, 1.14 -> 1.40 ms at 512^3 fp64); FPM_RO_EARLY = 1: the next plane's rows are requested
 // right after c2r_prepare instead of after the transform (spills with PF = 2 and 1: 2.3 ms; with PF = 0 1.42 ms: the rows'
-// time in flight is not what the kernel waits for either)
+// time in flight is not what the kernel waits for either); PF = 3 at M = 512 in fp64, with a 128- or a 168-VGPR budget: 11.3 ->
+// 16.5 / 14.1 ms at 1024^3 (spills), PF = 4: 15.0
 #ifndef FPM_RO_PF
 #define FPM_RO_PF 2
 #endif
-// experiment: one WAVE per row at M = 256 (E = 4 values per thread, 4.4.4.4, three exchanges): FPMHIP_RO_E4=1
+// A/B: one WAVE per row at M = 256 (E = 4 values per thread, 4.4.4.4, three exchanges, five waves per workgroup at 98
+// VGPRs): FPMHIP_RO_E4=1 -- 1.12 -> 1.59 ms at 512^3 fp64 (1.33 in the LATE order): more waves with fewer registers each
+// is not what the kernel lacks.
+// M = 1024 (the 2048^3 mesh), fp64: one wave per row with E = 16 (16.8.8, two exchanges, skewed: xshift) -- 236 VGPRs, ONE
+// workgroup of five waves per CU (126 KB of LDS) -- against two waves per row with E = 8 and workgroup barriers inside the
+// transform: 15.1 -> 12.8 ms on one rank of eight; FPM_RO_E16_PF = entries per thread in registers there (a tile holds 1024
+// particles on average: 1 / 2 / 4 / 6 / 8 -> 15.6 / 14.5 / 12.8 / 18.5 / 28.5 ms).  In fp32 the same shape is 10.4 -> 9.8 ms;
+// against a float64 transform of the same rows both shapes are 1.2e-7 (rms) off, but the E = 8 kernel repeats the box path's
+// arithmetic bit for bit (tests/test_gpu_strips.py holds it to that) and E = 16 rounds differently (2e-5 of max |acc| on a
+// sparse load), so fp32 keeps E = 8 (FPMHIP_RO_E16=1 forces the other).  The paint in that
+// shape loses (4.8 -> 5.6 ms): not kept.
 #ifndef FPM_RO_E4_MINW
 #define FPM_RO_E4_MINW 4
 #endif
