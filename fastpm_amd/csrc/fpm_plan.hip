@@ -316,9 +316,11 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
         // pencils (round 4): the marching kernels write / read the exchange-A chunks directly (PenIO); the strip grid
         // then has one more strip per plane, the y halo row's, and the local rows must be whole strips
         static const bool pen_off = getenv("FPMHIP_PEN_STRIPS") && atoi(getenv("FPMHIP_PEN_STRIPS")) == 0;      // A/B
-        // (the kernels address a row's kz blocks with 32-bit byte offsets and expect one block boundary per register slot)
+        // (the kernels address a row's kz blocks with 32-bit byte offsets -- element offsets at N = 2048 -- and expect one
+        // block boundary per register slot)
+        const long long pen_span = (long long) Ny * L.chunk_a_elems * (long long) p->esize;            // bytes
         const bool pen_ok = Ny == 1 || (!pen_off && (N & (N - 1)) == 0 && ylr % STRIP_Y == 0 && zblk >= N / 16 &&
-                                        (long long) Ny * L.chunk_a_elems * (long long) p->esize < (1ll << 32));
+                                        pen_span < (N == 2048 ? (1ll << 32) * 2 * (long long) p->esize : (1ll << 32)));
         const bool can = pen_ok && geom->fft_mode == FPMHIP_FFT_AUTO && colfft_supported((int) N) &&
                          strips_supported((int) N, geom->precision) && geom->gradient_mode == FPMHIP_GRADIENT_KSPACE;
         if (geom->paint_mode == FPMHIP_PAINT_STRIPS && !can)

@@ -128,7 +128,9 @@ template <typename P> __device__ __forceinline__ P *uniform_ptr(P *p)
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) v), hi = __builtin_amdgcn_readfirstlane((unsigned) (v >> 32));
     return (P *) (((unsigned long long) hi << 32) | lo);
 }
-template <int T, typename F>
+// BIG (M = 1024: a 4 x 2 rank of the 2048^3 fp64 mesh has 4.3 GB per kz block): the offset counts ELEMENTS in 32 bits and
+// is widened for the address -- two more VALU operations per access, which only the kernels with per-lane row pointers take.
+template <int T, typename F, bool BIG = false>
 __device__ __forceinline__ C2<F> *pen_elem(C2<F> *row, bool chunked, int kbase, int tau, int zblk, unsigned inv24, unsigned jump)
 {
     // kbase = T j (or M): uniform; the element is k = kbase + tau
@@ -138,6 +140,7 @@ __device__ __forceinline__ C2<F> *pen_elem(C2<F> *row, bool chunked, int kbase, 
         const unsigned B = ((unsigned) kbase * inv24) >> 24;                     // kbase / zblk, scalar
         off = k + (B + (k >= (B + 1) * (unsigned) zblk ? 1u : 0u)) * jump;
     }
+    if (BIG) return row + off;
     return (C2<F> *) ((char *) row + (size_t) (off * (unsigned) sizeof(C2<F>)));
 }
 
@@ -322,7 +325,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), (sizeof(F) == 4 && P
         if constexpr (PEN && WS && T == 64) dst = uniform_ptr(dst);      // one row per wave
         const unsigned pjump = PEN ? (unsigned) (pen.chunk - g.zblk) : 0u;
         auto at = [&](int kbase, int t_) -> C2<F> * {                  // element kbase + t_, kbase uniform
-            if constexpr (PEN) return pen_elem<T, F>(dst, chunked, kbase, t_, g.zblk, pen.inv24, pjump);
+            if constexpr (PEN) return pen_elem<T, F, (M == 1024)>(dst, chunked, kbase, t_, g.zblk, pen.inv24, pjump);
             return dst + kbase + t_;
         };
 #pragma unroll
@@ -564,8 +567,8 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (PL::E == 4 ? FPM_RO
             const unsigned pjump = (unsigned) (pen.chunk - g.zblk);
 #pragma unroll
             for (int j = 0; j < E; j++)
-                x[j] = ld_stream(pen_elem<T, F>(const_cast<C2<F> *>(src), chunked, T * j, tau, g.zblk, pen.inv24, pjump));
-            xm = tau == 0 ? *pen_elem<T, F>(const_cast<C2<F> *>(src), chunked, M, 0, g.zblk, pen.inv24, pjump) : C2<F>{0, 0};
+                x[j] = ld_stream(pen_elem<T, F, (M == 1024)>(const_cast<C2<F> *>(src), chunked, T * j, tau, g.zblk, pen.inv24, pjump));
+            xm = tau == 0 ? *pen_elem<T, F, (M == 1024)>(const_cast<C2<F> *>(src), chunked, M, 0, g.zblk, pen.inv24, pjump) : C2<F>{0, 0};
             return;
         }
         const C2<F> *src = rowbase + (long long) xp * pstride;
@@ -1104,6 +1107,18 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
                 p->scell, pen);                                                                                        \
         }                                                                                                              \
     }
+#define CALL_RO_E16(PX, PEN_)                                                                                          \
+    {                                                                                                                  \
+        using CF = StripCfg<PX, F>;                                                                                    \
+        static int occ16 = 0;                                                                                          \
+        FPM_TRY(grant_lds(readout_march_kernel<PX, F, true, true, PEN_>, CF::ro1_lds, p->device));                     \
+        g.xseg = choose_xseg(g, readout_march_kernel<PX, F, true, true, PEN_>, CF::ro_threads, CF::ro1_lds, ncomp * g.ntyo, 16, 128, &occ16); \
+        const int nseg = (g.xl + g.xseg - 1) / g.xseg;                                                                 \
+        readout_march_kernel<PX, F, true, true, PEN_><<<ncomp * g.ntyo * nseg, CF::ro_threads, CF::ro1_lds, p->stream>>>( \
+            g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                     \
+            (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride,          \
+            p->scell, pen);                                                                                            \
+    }
 #define CALL_RO(PL)                                                                                                    \
     if constexpr (PL::N == 256 && sizeof(F) == 8) {                                                                    \
         static const int e4_env = getenv("FPMHIP_RO_E4") ? atoi(getenv("FPMHIP_RO_E4")) : 0;                           \
@@ -1122,24 +1137,17 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
         }                                                                                                              \
     }                                                                                                                  \
     if constexpr (PL::N == 1024) {                                                                                     \
-        static const int e16_env = getenv("FPMHIP_RO_E16") ? atoi(getenv("FPMHIP_RO_E16")) : (sizeof(F) == 8);                      \
-        if (e16_env && !pen.on && !two_planes && ws_env != 0) {                                                        \
+        static const int e16_env = getenv("FPMHIP_RO_E16") ? atoi(getenv("FPMHIP_RO_E16")) : (sizeof(F) == 8);         \
+        if (e16_env && !two_planes && ws_env != 0) {                                                                   \
             using PX = FFTPlan<1024, 16, 16, 8, 8, 1>;                                                                 \
-            using CF = StripCfg<PX, F>;                                                                                \
-            static int occ16 = 0;                                                                                      \
-            FPM_TRY(grant_lds(readout_march_kernel<PX, F, true, true, false>, CF::ro1_lds, p->device));                \
-            g.xseg = choose_xseg(g, readout_march_kernel<PX, F, true, true, false>, CF::ro_threads, CF::ro1_lds, ncomp * g.ntyo, 16, 128, &occ16); \
-            const int nseg = (g.xl + g.xseg - 1) / g.xseg;                                                             \
-            readout_march_kernel<PX, F, true, true, false><<<ncomp * g.ntyo * nseg, CF::ro_threads, CF::ro1_lds, p->stream>>>( \
-                g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                 \
-                (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride,      \
-                p->scell, pen);                                                                                        \
+            if (pen.on) CALL_RO_E16(PX, true) else CALL_RO_E16(PX, false)                                              \
             break;                                                                                                     \
         }                                                                                                              \
     }                                                                                                                  \
     if (64 % PL::T == 0 && use_ws) CALL_RO_W(PL, (64 % PL::T == 0)) else CALL_RO_W(PL, false)
     STRIP_DISPATCH(g.N / 2, CALL_RO)
 #undef CALL_RO
+#undef CALL_RO_E16
 #undef CALL_RO_W
 #undef CALL_RO_P
     FPM_CHECK_HIP(hipGetLastError());
@@ -1198,7 +1206,9 @@ static int pen_io(fpmhip_plan *p, void *const *hx, void *const *hy, int n, PenIO
     pen->inv24 = (1u << 24) / (unsigned) p->mg.zblk + 1;
     if ((long long) (p->mg.N / 2 + 1) * p->mg.zblk >= (1ll << 24)) FPM_FAIL(-1, "internal: kz block too long for the 24-bit reciprocal");
     // the kernels' 32-bit byte offsets inside a row's chunks, and one block boundary at most per register slot
-    if ((long long) p->lay.nranks_y * pen->chunk * (long long) (2 * p->esize) >= (1ll << 32) || p->mg.zblk < p->mg.N / 16)
+    // (N = 2048: element offsets, widened for the address -- pen_elem<.., BIG>)
+    const long long span = (long long) p->lay.nranks_y * pen->chunk * (long long) (2 * p->esize);
+    if (span >= (p->mg.N == 2048 ? (1ll << 32) * 2 * (long long) p->esize : (1ll << 32)) || p->mg.zblk < p->mg.N / 16)
         FPM_FAIL(-1, "pencil strip plans: the exchange chunks of a row must lie within 4 GB and a kz block must hold N / 16 modes");
     for (int i = 0; i < n; i++) {
         if (!hy || !hy[i]) FPM_FAIL(-1, "null y-halo rows");

@@ -250,11 +250,12 @@ def test_config4_variable_mesh_steps_with_pk_at_per_rank_size(tmp_path):
         assert len(text) == 1 + N // 2 + 8
 
 
-@pytest.mark.parametrize("N,precision,paint_mode", [(256, 64, 3), (256, 64, 2), (256, 32, 3), (1024, 64, 0)])
+@pytest.mark.parametrize("N,precision,paint_mode", [(256, 64, 3), (256, 64, 2), (256, 32, 3), (1024, 64, 0), (2048, 64, 0)])
 def test_one_pencil_rank_of_the_4x2_mesh_at_per_rank_size(N, precision, paint_mode):
     """Rank (1, 1) of the reference's 4 x 2 process mesh (pmpfft.c:117-136) in a universe periodic with period L/4
     (tests/rank_share.py: ReplicatedPencilForce): every stage kernel at the brick's true geometry -- at N = 1024 that of
-    configs[2] on pencils, 16.8 M particles, strip tiles (the marching kernels on the exchange chunks) -- and the
+    configs[2] on pencils, 16.8 M particles, strip tiles (the marching kernels on the exchange chunks), at N = 2048 that of
+    configs[3], 134 M particles, 4.3 GB per kz block (element offsets in the kernels, one wave per row of 1024 values) -- and the
     accelerations of all 8 copies of the cube equal to the small cubic problem's."""
     import torch
     import rank_share
@@ -266,4 +267,5 @@ def test_one_pencil_rank_of_the_4x2_mesh_at_per_rank_size(N, precision, paint_mo
     n = ref.shape[0]
     rms = float(ref.double().pow(2).mean().sqrt())
     err = float((acc.view(copies, n, 3).double() - ref.double()[None]).abs().max()) / rms
-    assert err <= (2e-7 if precision == 64 else 1e-5), err
+    # (float32 acc: the largest of 1.07e9 rounding errors, against the rms; the box-tile path gives the same 2.7e-7 at N = 2048)
+    assert err <= ((2e-7 if N <= 1024 else 4e-7) if precision == 64 else 1e-5), err

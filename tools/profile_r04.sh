@@ -20,7 +20,7 @@ for cfg in "1024 64" "2048 64" "2048 32" "3072 32 128" "3072 64 128"; do
   python $REPO/tools/rocprof_summary.py $T $OUT/r04_rankshare_${tag}_rocprof_stats.md
 done
 # 3b. ONE rank of the reference's 4 x 2 PENCIL mesh (tests/rank_share.py: ReplicatedPencilForce): strip tiles at 1024^3
-#     (the marching kernels on the exchange chunks), box tiles at 2048^3 fp64 (no strips at M = 1024 in fp64), and the
+#     (the marching kernels on the exchange chunks), strip tiles at 2048^3 fp64 too (M = 1024: one workgroup per CU), and the
 #     1024^3 share on box tiles for the A/B
 for cfg in "1024 64 0 0 pencil" "1024 64 0 2 pencil" "2048 64 0 0 pencil"; do
   set -- $cfg
