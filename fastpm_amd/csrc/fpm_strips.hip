@@ -499,11 +499,19 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
 // arithmetic bit for bit (tests/test_gpu_strips.py holds it to that) and E = 16 rounds differently (2e-5 of max |acc| on a
 // sparse load), so fp32 keeps E = 8 (FPMHIP_RO_E16=1 forces the other).  The paint in that
 // shape loses (4.8 -> 5.6 ms): not kept.
+// M = 1536 (the 3072^3 meshes of configs[4] at B = 3): one wave per row with E = 24 (8.3.8.8, three exchanges; half a twiddle
+// table as every plan beyond 1024): 252 VGPRs, one workgroup per CU, 86 KB of LDS in fp32 and 157 KB in fp64.  One rank of eight,
+// z c2r x 3 + readout: fp64 64.2 (box tiles) -> 47.0 ms, fp32 36.7 -> 35.2; the three-waves-per-row shape (E = 8, 960 threads, a
+// 128-VGPR budget: 91 spilled in fp64) takes 77.8 / 36.1 ms and stays as the A/B (FPMHIP_RO_E24=0).  8-row strips
+// (-DFPM_STRIP_Y=8) at M = 512 again, on this round's kernels: readout 11.3 -> 11.4 ms at 1024^3, paint 2.9 -> 3.5.
 #ifndef FPM_RO_E4_MINW
 #define FPM_RO_E4_MINW 4
 #endif
 #ifndef FPM_RO_E4_PF
 #define FPM_RO_E4_PF 1
+#endif
+#ifndef FPM_RO_E24_PF
+#define FPM_RO_E24_PF 2
 #endif
 #ifndef FPM_RO_E16_PF
 #define FPM_RO_E16_PF 4
@@ -522,7 +530,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
 // M = 256 the same order loses in fp64 (1.18 -> 1.26 ms at 512^3: the prefetch matters more where the transform is short)
 // and wins in fp32 (0.816 -> 0.783 ms), where it is on as well.  (With 8-row strips, five-wave workgroups: 1.56 ms.)
 template <typename PL, typename F, bool WS, bool LATE = false, bool PEN = false>
-__global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (PL::E == 4 ? FPM_RO_E4_MINW : PL::E == 16 ? (sizeof(F) == 8 ? 1 : 2) : WS ? (LATE ? 4 : FPM_RO_MINW) : 3)) void readout_march_kernel(
+__global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (PL::E == 4 ? FPM_RO_E4_MINW : PL::E >= 16 ? (sizeof(F) == 8 || PL::E == 24 ? 1 : 2) : WS ? (LATE ? 4 : FPM_RO_MINW) : 3)) void readout_march_kernel(
     MeshGeo g, int ncomp, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
     const double *__restrict__ sy, const double *__restrict__ sz, const int *__restrict__ sidx, const C2<F> *__restrict__ m0,
     const C2<F> *__restrict__ m1, const C2<F> *__restrict__ m2, float *__restrict__ out, int nmemb, int memb0,
@@ -621,7 +629,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (PL::E == 4 ? FPM_RO
         }
         return acc;
     };
-    constexpr int PF = PL::E == 4 ? FPM_RO_E4_PF : PL::E == 16 ? FPM_RO_E16_PF : FPM_RO_PF;
+    constexpr int PF = PL::E == 4 ? FPM_RO_E4_PF : PL::E == 16 ? FPM_RO_E16_PF : PL::E == 24 ? FPM_RO_E24_PF : FPM_RO_PF;
     double px[PF + 1], py[PF + 1], pz[PF + 1], pv[PF + 1], qx[PF + 1], qy[PF + 1], qz[PF + 1];
     int prow[PF + 1], qrow[PF + 1], pc[PF + 1], qc[PF + 1];
     int pb = 0, pn = 0, qb = 0, qn = 0;            // p: the particles that finish this step; q: those that start
@@ -892,24 +900,26 @@ __global__ __launch_bounds__((PairCfg<PL2, F>::threads), FPM_RO_MINW) void reado
         FPM_STRIP_CASE(80, BODY) FPM_STRIP_CASE(96, BODY) FPM_STRIP_CASE(128, BODY) FPM_STRIP_CASE(160, BODY)        \
         FPM_STRIP_CASE(192, BODY) FPM_STRIP_CASE(256, BODY) FPM_STRIP_CASE(320, BODY) FPM_STRIP_CASE(384, BODY)      \
         FPM_STRIP_CASE(400, BODY) FPM_STRIP_CASE(512, BODY) FPM_STRIP_CASE(640, BODY) FPM_STRIP_CASE(768, BODY)      \
-        FPM_STRIP_CASE(800, BODY) FPM_STRIP_CASE(1024, BODY)                                                         \
+        FPM_STRIP_CASE(800, BODY) FPM_STRIP_CASE(1024, BODY) FPM_STRIP_CASE(1536, BODY)                              \
     default: FPM_FAIL(-1, "strip kernels: unsupported mesh size %d", 2 * (int) (M_));                               \
     }
 
 // two marching workgroups per CU: the one-plane windows of the readout and of the paint of the widest row
 // (M = 512 in fp64: 58 KB and 45 KB; M = 1024 in fp32: 57 KB and 78 KB) -- and, since round 4, ONE per CU for M = 1024 in
 // fp64 (the 2048^3 mesh: 126 KB and 90 KB): even so the marching kernels beat the box tiles + separate z passes there
-// (one rank of eight, ms: paint + z r2c 6.5 -> 4.8, z c2r x 3 + readout 18.0 -> 12.8, binning 3.6 -> 2.8).
+// (one rank of eight, ms: paint + z r2c 6.5 -> 4.8, z c2r x 3 + readout 18.0 -> 12.8, binning 3.6 -> 2.8), and for M = 1536
+// (the 3072^3 meshes: 86 / 117 KB in fp32, 157 / 135 KB in fp64; per rank 136.4 -> 128.8 ms in fp32, 211.1 -> 186.2 in fp64).
 // FPMHIP_STRIP_LDS_KB = 80 restores the old cap (A/B).
 static constexpr size_t STRIP_LDS_MAX = 160 * 1024;
 
 bool strips_supported(int N, int precision)
 {
-    if (!rowfft_supported(N) || N % STRIP_Y != 0 || N / 2 > 1024) return false;
+    if (!rowfft_supported(N) || N % STRIP_Y != 0 || N / 2 > 1536) return false;
     const size_t es = precision == 64 ? 16 : 8, M = (size_t) N / 2;
     const int xs_ro = strip_xspan((int) M, (int) es, false, M == 1024 ? 16 : 8), xs_pt = strip_xspan((int) M, (int) es, true);
     const size_t skw = M + (precision == 64 || strip_xs((int) M, 8, false) ? 0 : 2) * (M / 32);
-    const size_t ro = (2 * M + (size_t) strip_pitch((int) (skw > (size_t) xs_ro ? skw : (size_t) xs_ro), 13) * STRIP_RW) * es;     // ~ StripCfg::ro1_lds
+    const size_t twn = M > 1024 ? M / 2 : M;                                                   // FFTPlan::TWN (half a table beyond 1024)
+    const size_t ro = (twn + M + (size_t) strip_pitch((int) (skw > (size_t) xs_ro ? skw : (size_t) xs_ro), 13) * STRIP_RW) * es;   // ~ StripCfg::ro1_lds
     const size_t pt = (M / 2 + M) * es + (size_t) STRIP_Y * 2 * strip_pitch(xs_pt, 4) * sizeof(double);       // = pt1_lds
     // FPMHIP_STRIP_LDS_KB (A/B): the cap per workgroup
     static const size_t cap = getenv("FPMHIP_STRIP_LDS_KB") ? (size_t) atoi(getenv("FPMHIP_STRIP_LDS_KB")) * 1024 : STRIP_LDS_MAX;
@@ -1133,6 +1143,14 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
                 g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, p->sidx, (const C2<F> *) k0,                 \
                 (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride,      \
                 p->scell, pen);                                                                                        \
+            break;                                                                                                     \
+        }                                                                                                              \
+    }                                                                                                                  \
+    if constexpr (PL::N == 1536) {                                                                                     \
+        static const int e24_env = getenv("FPMHIP_RO_E24") ? atoi(getenv("FPMHIP_RO_E24")) : 1;                        \
+        if (e24_env && !pen.on && !two_planes && ws_env != 0) {                                                        \
+            using PX = FFTPlan<1536, 24, 8, 3, 8, 8>;                                                                  \
+            CALL_RO_E16(PX, false)                                                                                     \
             break;                                                                                                     \
         }                                                                                                              \
     }                                                                                                                  \
