@@ -718,6 +718,185 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (PL::E == 4 ? FPM_RO
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// readout with ONE plane in LDS and the THREE COMPONENTS in one workgroup (round 4; the default at N = 256, 512, 1024)
+// ------------------------------------------------------------------------------------------------------------------
+// readout_march_kernel runs one workgroup per (segment, strip, COMPONENT): the entries of a tile are read three times, the
+// D / base cell / weights of a particle formed six times, and acc leaves as three 4-byte scatters per row.  Here a
+// workgroup holds the plane of all three force meshes -- 3 x RW rows, each still transformed by its own threads inside one
+// wave -- and a thread takes a particle through the three sums at once: entries and weights once per visit, one 12-byte
+// store.  The price is LDS (3 x the rows: 75 KB at M = 256 in fp64, two workgroups of eight waves per CU; 157 KB at M = 512,
+// ONE workgroup of fifteen waves) and the 128-VGPR budget those wave counts force, i.e. the LATE order.  Arithmetic per
+// component as in readout_march_kernel (same products, same order): bit-identical results.
+// Measured (z c2r x 3 + readout, ms; one workgroup per component -> this kernel): 512^3 fp64 1.11 -> 1.06, 1024^3 fp64 11.34 ->
+// 9.60, 512^3 fp32 0.767 -> 0.669 (rows a step ahead; LATE 0.707), 1024^3 fp32 8.10 -> 6.40; clustered load C at 512^3 fp64
+// 2.16 -> 1.76.  FPM_RO3_PF = 2 (two entries per thread in registers) spills: 1.34 / 10.9 ms.  With the rows a step ahead
+// the fp64 kernels spill 23 VGPRs at the 128 budget (1.39 ms).
+#ifndef FPM_RO3_PF
+#define FPM_RO3_PF 1
+#endif
+template <typename PL, typename F, bool LATE, bool PEN = false>
+__global__ __launch_bounds__((3 * StripCfg<PL, F>::ro_threads), 4) void readout_march3_kernel(
+    MeshGeo g, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
+    const double *__restrict__ sy, const double *__restrict__ sz, const C2<F> *__restrict__ m0, const C2<F> *__restrict__ m1,
+    const C2<F> *__restrict__ m2, float *__restrict__ out, int nmemb, int memb0, const double *__restrict__ tw_global,
+    double *__restrict__ part_all, long long part_stride, const int2 *__restrict__ scell, PenIO pen)
+{
+    using CF = StripCfg<PL, F>;
+    constexpr int M = PL::N, RW = STRIP_RW, T = PL::T, E = PL::E, NT = 3 * CF::ro_threads, RP = CF::ro_pitch, WP = 2 * RP;
+    static_assert(64 % T == 0, "a row's threads sit in one wave");
+    extern __shared__ __align__(16) unsigned char smem_st[];
+    C2<F> *tw = (C2<F> *) smem_st;
+    C2<F> *twn = tw + PL::TWN;
+    C2<F> *S = twn + M;                            // [3 RW][RP]: row cg's exchange region, then its real values
+    constexpr int CWX = -RP, SKX = CF::ws_sk;
+    const int tid = threadIdx.x, cg = tid / T, tau = tid % T, comp = cg / RW, c = cg % RW;
+    const int nseg = (g.xl + g.xseg - 1) / g.xseg;
+    const int t = xcd_remap(blockIdx.x, g.ntyo * nseg);
+    const int strip = t % g.ntyo, seg = nseg - 1 - t / g.ntyo;                    // last segment first
+    const C2<F> *mesh = comp == 0 ? m0 : (comp == 1 ? m1 : m2);
+    const int xa = seg * g.xseg, xb = min(xa + g.xseg, g.xl);
+    const int y0 = strip * STRIP_Y;
+    int gy = y0 + c;
+    gy -= gy >= g.N ? g.N : 0;
+    const C2<F> *rowbase = mesh + (long long) gy * g.rp;
+    const long long pstride = (long long) g.yplanes * g.rp;
+
+    C2<F> x[E], xm;
+    const int yrow = y0 + c;                       // pencils (PenIO): as in readout_march_kernel
+    const C2<F> *phx = PEN ? (const C2<F> *) pen.hx[comp] : nullptr, *phy = PEN ? (const C2<F> *) pen.hy[comp] : nullptr;
+    auto load_plane = [&](int xp) {
+        if (g.periodic_x) xp -= xp >= g.N ? g.N : 0;
+        if constexpr (PEN) {
+            const C2<F> *src;
+            bool chunked = false;
+            if (!g.periodic_x && xp == g.xl) src = phx + (long long) yrow * g.rp;
+            else if (yrow == g.ylr) src = phy + (long long) xp * g.rp;
+            else { src = mesh + ((long long) xp * g.ylr + yrow) * g.nzl; chunked = true; }
+            if constexpr (T == 64) src = uniform_ptr(src);               // one row per wave
+            const unsigned pjump = (unsigned) (pen.chunk - g.zblk);
+#pragma unroll
+            for (int j = 0; j < E; j++)
+                x[j] = ld_stream(pen_elem<T, F>(const_cast<C2<F> *>(src), chunked, T * j, tau, g.zblk, pen.inv24, pjump));
+            xm = tau == 0 ? *pen_elem<T, F>(const_cast<C2<F> *>(src), chunked, M, 0, g.zblk, pen.inv24, pjump) : C2<F>{0, 0};
+            return;
+        }
+        const C2<F> *src = rowbase + (long long) xp * pstride;
+#pragma unroll
+        for (int j = 0; j < E; j++) x[j] = ld_stream(&src[tau + T * j]);
+        xm = tau == 0 ? src[M] : C2<F>{0, 0};
+    };
+    auto c2r_plane = [&]() {
+        C2<F> v[vmax(E)];
+        c2r_prepare<PL, CWX, SKX, F, true>(v, x, xm, S, twn, tau, cg);
+        fft_core<PL, +1, CWX, false, F, SKX, true, CF::ro_xs>(v, S, tw, tau, cg);
+#pragma unroll
+        for (int j = 0; j < E; j++) S[cg * RP + tau + T * j] = v[j];
+        if (tau == 0) S[cg * RP + M].x = v[0].x;
+    };
+    const F *rs = (const F *) S;
+    // a[m] + the four corners of component m's plane (x bit `bx`), in the reference's order; the entry formed once
+    auto half3 = [&](double qx, double qy, double qz, int qc, int bx, double *a) {
+        const StripEntry cc = strip_entry(g, qx, qy, qz, qc);
+        const int ly = cc.iy0 - y0, lz = cc.iz0;
+        const double wxb = bx ? cc.d[0] : cc.t[0];
+        const double wy[2] = {cc.t[1], cc.d[1]}, wz[2] = {cc.t[2], cc.d[2]};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int by = (k >> 1) & 1, bz = k & 1;
+            const double w = wz[bz] * wxb * wy[by];
+#pragma unroll
+            for (int m = 0; m < 3; m++) a[m] += (double) rs[(m * RW + ly + by) * WP + lz + bz] * w;
+        }
+    };
+    struct F3 { float a, b, c; };
+    auto store3 = [&](int row, const double *a) {
+        float *o = out + (long long) row * nmemb + memb0;
+        if (nmemb == 3) *(F3 *) o = F3{(float) a[0], (float) a[1], (float) a[2]};
+        else { o[0] = (float) a[0]; o[1] = (float) a[1]; o[2] = (float) a[2]; }
+    };
+    constexpr int PF = FPM_RO3_PF;
+    double px[PF + 1], py[PF + 1], pz[PF + 1], pv[PF + 1][3], qx[PF + 1], qy[PF + 1], qz[PF + 1];
+    int prow[PF + 1], qrow[PF + 1], pc[PF + 1], qc[PF + 1];
+    int pb = 0, pn = 0, qb = 0, qn = 0;
+    int kb_next = 0, kn_next = 0;
+    auto fetch_key = [&](int xi) {
+        const int key = xi * g.nty + strip;
+        kb_next = tbeg[key];
+        kn_next = tcnt[key];
+    };
+    auto fetch_q = [&](int xi) {
+        qb = kb_next;
+        qn = kn_next;
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int e = tid + u * NT;
+            qx[u] = qy[u] = qz[u] = 0;
+            qrow[u] = qc[u] = 0;
+            if (e < qn) {
+                qx[u] = sx[qb + e]; qy[u] = sy[qb + e]; qz[u] = sz[qb + e];
+                const int2 rc = scell[qb + e];
+                qrow[u] = rc.x; qc[u] = rc.y;
+            }
+        }
+        if (xi + 1 < xb) fetch_key(xi + 1);
+    };
+    auto start_q = [&]() {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            px[u] = qx[u]; py[u] = qy[u]; pz[u] = qz[u]; prow[u] = qrow[u]; pc[u] = qc[u];
+            pv[u][0] = pv[u][1] = pv[u][2] = 0.0;
+            if (tid + u * NT < qn) half3(qx[u], qy[u], qz[u], qc[u], 0, pv[u]);
+        }
+        for (int e = tid + PF * NT; e < qn; e += NT) {
+            double a[3] = {0.0, 0.0, 0.0};
+            half3(sx[qb + e], sy[qb + e], sz[qb + e], scell[qb + e].y, 0, a);
+#pragma unroll
+            for (int m = 0; m < 3; m++) part_all[m * part_stride + qb + e] = a[m];
+        }
+        pb = qb;
+        pn = qn;
+    };
+    auto finish_p = [&]() {
+#pragma unroll
+        for (int u = 0; u < PF; u++)
+            if (tid + u * NT < pn) {
+                half3(px[u], py[u], pz[u], pc[u], 1, pv[u]);
+                store3(prow[u], pv[u]);
+            }
+        for (int e = tid + PF * NT; e < pn; e += NT) {
+            const int2 rc = scell[pb + e];
+            double a[3];
+#pragma unroll
+            for (int m = 0; m < 3; m++) a[m] = part_all[m * part_stride + pb + e];
+            half3(sx[pb + e], sy[pb + e], sz[pb + e], rc.y, 1, a);
+            store3(rc.x, a);
+        }
+    };
+
+    load_plane(xa);
+    fetch_key(xa);
+    fetch_q(xa);
+    stage_twiddles(tw, tw_global, PL::TWN, 2);
+    stage_twiddles(twn, tw_global, M, 1);
+    __syncthreads();
+    c2r_plane();
+    __syncthreads();
+    if (!LATE) load_plane(xa + 1);
+    start_q();
+    for (int i = xa; i < xb; i++) {
+        if (!LATE && i + 1 < xb) fetch_q(i + 1);
+        if (LATE) load_plane(i + 1);
+        __syncthreads();
+        c2r_plane();
+        __syncthreads();
+        if (LATE && i + 1 < xb) fetch_q(i + 1);
+        if (!LATE && i + 1 < xb) load_plane(i + 2);
+        finish_p();
+        if (i + 1 < xb) start_q();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // readout with ONE plane in LDS and TWO ROWS PER TRANSFORM (round 4; the power-of-two meshes up to N = 512)
 // ------------------------------------------------------------------------------------------------------------------
 // The one-plane kernel above is bound by LDS traffic (profiles/r03_sq_counters.md: bank-conflict cycles alone are a quarter
@@ -1024,6 +1203,38 @@ int paint_strips(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void 
                : paint_strips_launch<float, false>(p, pt, scale, out, accumulate, pen);
 }
 
+// the three-components-per-workgroup readout: the wave-local meshes it was measured on, N = 256 (configs[0]), 512 and 1024
+template <int M, typename F, bool OK = (M == 128 || M == 256 || M == 512)> struct Ro3Launch {
+    static constexpr bool ok = false;
+    static int go(fpmhip_plan *, MeshGeo &, const void *, const void *, const void *, float *, int, int, bool, const PenIO &) { return -1; }
+};
+template <int M, typename F> struct Ro3Launch<M, F, true> {
+    static constexpr bool ok = true;
+    template <bool LATE, bool PEN>
+    static int run(fpmhip_plan *p, MeshGeo &g, const void *k0, const void *k1, const void *k2, float *out, int nmemb, int memb0,
+                   const PenIO &pen)
+    {
+        using PL = typename Fac<M, 0>::type;
+        using CF = StripCfg<PL, F>;
+        constexpr size_t lds = CF::twb + (size_t) 3 * CF::ro_pitch * STRIP_RW * sizeof(C2<F>);
+        static int occ = 0;
+        FPM_TRY(grant_lds(readout_march3_kernel<PL, F, LATE, PEN>, lds, p->device));
+        g.xseg = choose_xseg(g, readout_march3_kernel<PL, F, LATE, PEN>, 3 * CF::ro_threads, lds, g.ntyo, 16, 128, &occ);
+        const int nseg = (g.xl + g.xseg - 1) / g.xseg;
+        readout_march3_kernel<PL, F, LATE, PEN><<<g.ntyo * nseg, 3 * CF::ro_threads, lds, p->stream>>>(
+            g, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, (const C2<F> *) k0, (const C2<F> *) k1, (const C2<F> *) k2, out,
+            nmemb, memb0, p->d_twiddle, p->ro_part, p->ro_part_elems, p->scell, pen);
+        return 0;
+    }
+    static int go(fpmhip_plan *p, MeshGeo &g, const void *k0, const void *k1, const void *k2, float *out, int nmemb, int memb0,
+                  bool late, const PenIO &pen)
+    {
+        if (pen.on) return run<true, true>(p, g, k0, k1, k2, out, nmemb, memb0, pen);      // (rows a step ahead: 52 VGPRs spilled)
+        return late ? run<true, false>(p, g, k0, k1, k2, out, nmemb, memb0, pen)
+                    : run<false, false>(p, g, k0, k1, k2, out, nmemb, memb0, pen);
+    }
+};
+
 // the paired-row readout where a pair's N / 8 threads fit one wave: the power-of-two meshes up to N = 512
 // (an A/B kernel: instantiated for the mesh it was measured on only, N = 512)
 template <int M, typename F, bool OK = (M == 256)> struct PairLaunch {
@@ -1080,6 +1291,9 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
     // two rows per transform (readout_pair_kernel): FPMHIP_RO_PAIR = 0 | 1 forces (A/B)
     static const int pair_env = getenv("FPMHIP_RO_PAIR") ? atoi(getenv("FPMHIP_RO_PAIR")) : -1;
     const bool pair = !pen.on && (pair_env >= 0 ? pair_env != 0 : false);
+    // the three components in one workgroup (readout_march3_kernel; the default where it is instantiated): FPMHIP_RO3 = 0
+    // (one workgroup per component, A/B) | 1 (LATE order) | 2 (rows a step ahead); default: LATE but for fp32 at M <= 256
+    static const int ro3 = getenv("FPMHIP_RO3") ? atoi(getenv("FPMHIP_RO3")) : -1;
     // the half sums of a dense tile's entries beyond the first two per thread: one double per own entry and component
     const long long part_stride = p->ro_part_elems;
 #define CALL_RO_W(PL, WS_)                                                                                             \
@@ -1090,7 +1304,10 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
     {                                                                                                                  \
         using CF = StripCfg<PL, F>;                                                                                    \
         static int occ2 = 0, occ1 = 0, occ0 = 0;                                                                       \
-        if (WS_ && !two_planes && pair && PairLaunch<PL::N, F>::ok) {                                                  \
+        if (WS_ && !two_planes && ro3 && ncomp == 3 && Ro3Launch<PL::N, F>::ok) {                                      \
+            const bool late3 = ro3 > 0 ? ro3 == 1 : !(sizeof(F) == 4 && PL::N <= 256);                                 \
+            FPM_TRY((Ro3Launch<PL::N, F>::go(p, g, k0, k1, k2, out, nmemb, memb0, late3, pen)));                       \
+        } else if (WS_ && !two_planes && pair && PairLaunch<PL::N, F>::ok) {                                           \
             FPM_TRY((PairLaunch<PL::N, F>::go(p, g, k0, k1, k2, ncomp, out, nmemb, memb0)));                           \
         } else if (two_planes) {                                                                                       \
             FPM_TRY(grant_lds(readout_strips_kernel<PL, F, WS_>, CF::ro_lds, p->device));                              \
