@@ -612,7 +612,9 @@ def main():
             # algorithmic bytes are the paint's and the readout's: the meshes between them never reach HBM
             KERNELS["paint"] = "fpm::paint_march_kernel"
             # (one plane in LDS + wave-local z transforms on the power-of-two meshes; two planes elsewhere: fpm_strips.hip)
-            KERNELS["readout"] = "fpm::readout_march_kernel" if 64 % max(Nmesh // 16, 1) == 0 else "fpm::readout_strips_kernel"
+            # (round 4: the three components in one workgroup at N = 256 / 512 / 1024 -- readout_march3_kernel)
+            march = "fpm::readout_march3_kernel" if Nmesh in (256, 512, 1024) and os.environ.get("FPMHIP_RO3") != "0" else "fpm::readout_march_kernel"
+            KERNELS["readout"] = march if 64 % max(Nmesh // 16, 1) == 0 else "fpm::readout_strips_kernel"
         elif args.precision == 64:
             KERNELS["readout"] = "fpm::readout1of3_tiles_kernel"
         stages = {}

@@ -734,6 +734,9 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (PL::E == 4 ? FPM_RO
 #ifndef FPM_RO3_PF
 #define FPM_RO3_PF 1
 #endif
+#ifndef FPM_RO3_EARLYQ
+#define FPM_RO3_EARLYQ 0
+#endif
 template <typename PL, typename F, bool LATE, bool PEN = false>
 __global__ __launch_bounds__((3 * StripCfg<PL, F>::ro_threads), 4) void readout_march3_kernel(
     MeshGeo g, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
@@ -884,12 +887,12 @@ __global__ __launch_bounds__((3 * StripCfg<PL, F>::ro_threads), 4) void readout_
     if (!LATE) load_plane(xa + 1);
     start_q();
     for (int i = xa; i < xb; i++) {
-        if (!LATE && i + 1 < xb) fetch_q(i + 1);
+        if ((!LATE || FPM_RO3_EARLYQ) && i + 1 < xb) fetch_q(i + 1);
         if (LATE) load_plane(i + 1);
         __syncthreads();
         c2r_plane();
         __syncthreads();
-        if (LATE && i + 1 < xb) fetch_q(i + 1);
+        if (LATE && !FPM_RO3_EARLYQ && i + 1 < xb) fetch_q(i + 1);
         if (!LATE && i + 1 < xb) load_plane(i + 2);
         finish_p();
         if (i + 1 < xb) start_q();
