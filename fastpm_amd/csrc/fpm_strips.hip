@@ -1206,7 +1206,12 @@ int paint_strips(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void 
                : paint_strips_launch<float, false>(p, pt, scale, out, accumulate, pen);
 }
 
-// the three-components-per-workgroup readout: the wave-local meshes it was measured on, N = 256 (configs[0]), 512 and 1024
+// the three-components-per-workgroup readout: the wave-local meshes it was measured on, N = 256 (configs[0]), 512 and 1024.
+// (Tried for N = 640 / 768 / 800 -- rows of T = 40 / 48 / 50 threads, one wave per row with the lanes beyond T idle in the
+// transform, so that the one-plane wave-local kernels and this one apply: the radix-5 / radix-3 plans need 60 - 130 VGPRs more
+// than the 128 this kernel has, and even the per-component kernel, which fits, is slower than the two-plane kernel with
+// workgroup barriers those meshes use: readout 2.54 -> 5.7 (7.6 with three components) ms at 640^3, 7.0 -> 11.2 (13.0) at 800^3,
+// 4.5 -> 8.5 (6.5) at 768^3 in fp64; the paint gains 8 - 13 % in that shape at 768 / 800 and nothing at 640.  Not kept.)
 template <int M, typename F, bool OK = (M == 128 || M == 256 || M == 512)> struct Ro3Launch {
     static constexpr bool ok = false;
     static int go(fpmhip_plan *, MeshGeo &, const void *, const void *, const void *, float *, int, int, bool, const PenIO &) { return -1; }
