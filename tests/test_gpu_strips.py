@@ -248,3 +248,34 @@ def test_both_readout_windows_against_the_oracle(oracle, tmp_path, win, ws, prec
     ref = oracle.compute_force(oracle.PMOracle(N, L, precision), x, potential=True)
     assert util.rel_err(np.load(tmp_path / "acc.npy"), ref["acc"]) <= TOL_ACC[precision]
     assert util.rel_err(np.load(tmp_path / "pot.npy"), ref["potential"]) <= TOL_ACC[precision]
+
+
+@pytest.mark.parametrize("N,precision", [(256, 64), (256, 32), (512, 64), (1024, 32)])
+def test_three_components_per_workgroup_repeat_the_per_component_kernel(oracle, tmp_path, N, precision):
+    """readout_march3_kernel (one workgroup takes a tile through the three force components: the default at N = 256, 512,
+    1024) against readout_march_kernel (FPMHIP_RO3=0: one workgroup per component): the same products in the same order,
+    so acc must agree BIT FOR BIT, in the LATE order (FPMHIP_RO3=1) and with the rows a step ahead (= 2).  Load C puts
+    thousands of particles into a few strip tiles (the half sums beyond the first entry per thread wait in the global
+    scratch rows -- three per entry here); at N = 256 the oracle is asked as well.  Child processes: the switch is read once."""
+    import os
+    import subprocess
+    import sys
+    nc, L = 64, 1.5 * N
+    x = util.load_c(nc, L)
+    np.save(tmp_path / "x.npy", x)
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); from fastpm_amd import PM, Store\n"
+            "x = np.load(%r); pm = PM(%d, %r, %d, paint_mode=3); st = Store(x)\n"
+            "for i in range(2): pm.compute_force(st, kernel='1_4')\n"
+            "torch.cuda.synchronize(); np.save(sys.argv[1], st.acc.cpu().numpy())\n"
+            % (ROOT, str(tmp_path / "x.npy"), N, L, precision))
+    acc = {}
+    for mode in (0, 1, 2):
+        out = str(tmp_path / ("acc%d.npy" % mode))
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, FPMHIP_RO3=str(mode)), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        acc[mode] = np.load(out)
+    assert np.abs(acc[0]).max() > 0
+    assert np.array_equal(acc[1], acc[0]) and np.array_equal(acc[2], acc[0])
+    if N == 256:
+        ref = oracle.compute_force(oracle.PMOracle(N, L, precision), x)
+        assert util.rel_err(acc[1], ref["acc"]) <= TOL_ACC[precision]
