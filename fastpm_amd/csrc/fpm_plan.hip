@@ -325,7 +325,9 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
                          strips_supported((int) N, geom->precision) && geom->gradient_mode == FPMHIP_GRADIENT_KSPACE;
         if (geom->paint_mode == FPMHIP_PAINT_STRIPS && !can)
             FPM_FAIL(-1, "FPMHIP_PAINT_STRIPS: the k-space gradient, a mesh whose z rows fit the strip kernels and (pencils) local rows in whole strips");
-        if (can && (geom->paint_mode == FPMHIP_PAINT_STRIPS || (geom->paint_mode == FPMHIP_PAINT_TILED && N >= 320 && !env_off))) {
+        // (from Nmesh = 192: 0.51 -> 0.44 ms per force there, 0.89 -> 0.70 at 256^3 -- configs[0]'s mesh --; at 160 the two tie, at
+        // 96 the box tiles win, 0.255 vs 0.272)
+        if (can && (geom->paint_mode == FPMHIP_PAINT_STRIPS || (geom->paint_mode == FPMHIP_PAINT_TILED && N >= 192 && !env_off))) {
             g.strips = STRIP_Y;
             static const int xseg_env = getenv("FPMHIP_XSEG") ? atoi(getenv("FPMHIP_XSEG")) : 0;      // A/B
             g.xseg = xseg_env > 0 ? xseg_env : 0;                    // 0: chosen per launch (fpm_strips.hip choose_xseg)

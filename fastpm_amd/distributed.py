@@ -332,7 +332,7 @@ class SlabForce(_SlabRank):
         total_mass = float(self.scalar.item())
         mean_mass_per_cell = total_mass / pm.Norm
 
-        # Strip plans (csrc/fpm_strips.hip; the default from Nmesh = 320): the paint runs on into the z pass of pm_r2c and
+        # Strip plans (csrc/fpm_strips.hip; the default from Nmesh = 192): the paint runs on into the z pass of pm_r2c and
         # the z pass of pm_c2r into the readout, so between the particle kernels and the y passes the meshes are
         # half-spectrum rows -- and the halo plane travels in that form (the z pass is linear).  Same sequence, other
         # stage calls; with a softening kernel the forward half keeps the real canvas (as on one rank).

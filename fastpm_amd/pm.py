@@ -716,7 +716,7 @@ class PM:
         return bool(self._L.fpmhip_plan_column_fft(self._plan))
 
     def strips(self):
-        """True if the plan bins into strip tiles (one rank, Nmesh >= 320 by default): compute_force then paints into
+        """True if the plan bins into strip tiles (one rank or x slabs, Nmesh >= 192 by default): compute_force then paints into
         half-spectrum rows and reads the force meshes out before their z pass (csrc/fpm_strips.hip)."""
         return bool(self._L.fpmhip_plan_strips(self._plan))
 

@@ -49,7 +49,7 @@ enum { FPMHIP_FIELD_ACC_X = 0, FPMHIP_FIELD_ACC_Y = 1, FPMHIP_FIELD_ACC_Z = 2, F
        FPMHIP_FIELD_TIDAL_XY, FPMHIP_FIELD_TIDAL_YZ, FPMHIP_FIELD_TIDAL_ZX };     /* (gravity.c:211-233) */
 /* paint algorithm */
 enum { FPMHIP_PAINT_TILED = 0,      /* tile-binned particles, LDS-staged tiles, no global atomics: strips where they exist
-                                     * (one rank, Nmesh >= 320, k-space gradient, hand-written FFT passes), boxes otherwise */
+                                     * (one rank, Nmesh >= 192, k-space gradient, hand-written FFT passes), boxes otherwise */
        FPMHIP_PAINT_ATOMIC = 1,     /* one global atomicAdd per corner (baseline for A/B evidence) */
        FPMHIP_PAINT_BOXES = 2,      /* always the 8 x 8 x 32-cell box tiles */
        FPMHIP_PAINT_STRIPS = 3 };   /* always the strip tiles (1 plane x 4 rows x Nmesh cells, marching kernels: the paint
@@ -464,7 +464,7 @@ int fpmhip_lpt_evolve(fpmhip_plan *plan, double *x_dev, float *v_dev, const floa
 int fpmhip_store_summary(fpmhip_plan *plan, const float *column_dev, int nmemb, int64_t np,
                          double *rmin_host, double *rmax_host, double *rsum1_host, double *rsum2_host);
 
-/* ---- strip plans (fpmhip_plan_strips() != 0: one rank or x slabs, from Nmesh = 320 by default): the particle kernels
+/* ---- strip plans (fpmhip_plan_strips() != 0: one rank or x slabs, from Nmesh = 192 by default): the particle kernels
  *      that take the z passes of the transforms with them.  The meshes between them are in the layout BETWEEN the z and
  *      the y pass -- [x_loc (+1 halo plane)][y][kz] half-spectrum rows at the real mesh's row pitch -- so the mesh halo
  *      of a slab travels in that form (the z pass is linear: adding the neighbour's halo plane before or after it is

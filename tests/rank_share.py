@@ -61,7 +61,7 @@ class ReplicatedSlabForce:
         ce = pm.exchange_chunk_elems()
         # gravity.c:330-345: all ranks hold the same mass
         mean = P * pm.total_mass(store) / pm.Norm
-        # strip plans (the default from Nmesh = 320): the z passes happen inside the particle kernels, the meshes in
+        # strip plans (the default from Nmesh = 192): the z passes happen inside the particle kernels, the meshes in
         # between -- halo planes included -- are half-spectrum rows (fpm_strips.hip)
         strips = pm.strips()
         (pm.paint_zr2c if strips else pm.paint)(self.canvas, store, 1.0 / mean)

@@ -1,5 +1,5 @@
 """The strip tiles and the marching kernels of fastpm_amd/csrc/fpm_strips.hip (FPMHIP_PAINT_STRIPS; the default on one
-rank from Nmesh = 320): the paint that runs on into the z pass of pm_r2c, the z pass of pm_c2r that runs on into the
+rank from Nmesh = 192): the paint that runs on into the z pass of pm_r2c, the z pass of pm_c2r that runs on into the
 readout.  Same oracle, same tolerances as the box-tile kernels (tests/test_gpu_force.py); the box tiles stay the path of
 every multi-rank test and of the small one-rank meshes."""
 import numpy as np
@@ -150,9 +150,9 @@ def test_two_species_on_strips(oracle):
     pm.destroy()
 
 
-def test_strips_are_the_default_from_320():
+def test_strips_are_the_default_from_192():
     from fastpm_amd import PM
-    for N, want in ((256, False), (320, True), (640, True)):         # 640 in fp64: the one-plane readout window
+    for N, want in ((160, False), (192, True), (256, True), (320, True), (640, True)):         # 640 in fp64: the one-plane readout window
         pm = PM(N, 1.5 * N, 64)
         assert pm.strips() == want, N
         pm.destroy()
