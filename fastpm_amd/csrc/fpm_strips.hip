@@ -1212,6 +1212,11 @@ int paint_strips(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void 
 // than the 128 this kernel has, and even the per-component kernel, which fits, is slower than the two-plane kernel with
 // workgroup barriers those meshes use: readout 2.54 -> 5.7 (7.6 with three components) ms at 640^3, 7.0 -> 11.2 (13.0) at 800^3,
 // 4.5 -> 8.5 (6.5) at 768^3 in fp64; the paint gains 8 - 13 % in that shape at 768 / 800 and nothing at 640.  Not kept.)
+// (Tried for the long rows, M >= 1024, where three planes do not fit the LDS: the three components ONE AFTER THE OTHER through the
+// one-plane window of a single workgroup, the entries of the finishing and the starting particle set and their three half sums
+// waiting in registers across the three turns -- entries read once, six barriers per plane step.  The two particle sets cost 28
+// VGPRs per entry slot on top of the E = 16 transform's 236: 49 - 100 spilled; one rank of the 2048^3 mesh, fp64: readout 12.7 ->
+// 14.4 ms with one entry per thread in registers, 18.0 with two; fp32 (E = 8, two waves per row): 10.4 -> 10.6.  Not kept.)
 template <int M, typename F, bool OK = (M == 128 || M == 256 || M == 512)> struct Ro3Launch {
     static constexpr bool ok = false;
     static int go(fpmhip_plan *, MeshGeo &, const void *, const void *, const void *, float *, int, int, bool, const PenIO &) { return -1; }
