@@ -1236,6 +1236,9 @@ static int bin_full(fpmhip_plan *p, const fpmhip_particles *pt, const int *pred)
 // what every binning ends with: the next call's layout from this call's counts, and the compact tile order
 // (nothing in this call's paint / transforms / readout reads it; on a side stream beside the paint the binning stage drops
 // 0.36 -> 0.31 ms at 512^3 and the paint pays it back, 0.445 -> 0.48 ms: 4.55 vs 4.58 ms per force -- not kept)
+// (round 4, also not kept: the order written lazily by the three-component readout, which visits every own entry once -- a
+// 4-byte store per particle at the tile's exact offset: binning stage 0.39 -> 0.33 ms, readout 1.065 -> 1.093, 4.43 -> 4.40 ms
+// per force at 512^3; at 1024^3 2.73 -> 2.41 and 9.69 -> 9.94 ms, 38.3 -> 38.4: what the pass of its own costs, the readout pays)
 static int bin_finish(fpmhip_plan *p, const int *pred)
 {
     const int nt = p->ntiles;
