@@ -93,6 +93,16 @@ __device__ __forceinline__ int xcd_tile(int b, int n, int rev = 0)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (rev ? cnt - 1 - j : j);
 }
 
+// (F) (v * s) with the product in double, per lane (F = float, double or the fp32 column pair f32x2)
+template <typename F> __device__ __forceinline__ F mul_round(F v, double s)
+{
+    using L = Lane<F>;
+    F r = v;
+#pragma unroll
+    for (int l = 0; l < L::n; l++) L::set(r, l, (typename L::S) (L::get(v, l) * s));
+    return r;
+}
+
 // Launch shape of the column kernels for one (length, precision).
 //   CW : columns per workgroup.  One 128-byte line per row (8 complex doubles, 16 complex floats) while the
 //        workgroup fits 1024 threads and two of them fit a CU's LDS; 64-byte segments beyond that (fp64 from
@@ -180,10 +190,10 @@ __global__ __launch_bounds__((ColCfg<PL, F>::threads)) void colfft_kernel(const 
             const unsigned toff = row_toff(im, tau, col);
 #pragma unroll
             for (int j = 0; j < E; j++)
-                v[in_slot<PL>(j)] = live ? ld_stream(&(src + (PERS ? jbl[j] : im.jb[j]))[toff]) : C2<F>{0, 0};
+                v[in_slot<PL>(j)] = live ? ld_stream(&(src + (PERS ? jbl[j] : im.jb[j]))[toff]) : C2<F>{F(0), F(0)};
         } else {
 #pragma unroll
-            for (int j = 0; j < E; j++) v[in_slot<PL>(j)] = live ? ld_stream(&in[col_addr(im.m, batch, tau + T * j, col)]) : C2<F>{0, 0};
+            for (int j = 0; j < E; j++) v[in_slot<PL>(j)] = live ? ld_stream(&in[col_addr(im.m, batch, tau + T * j, col)]) : C2<F>{F(0), F(0)};
         }
         if (!PERS) {
             stage_twiddles(tw, tw_global, PL::TWN);       // after the data loads are in flight
@@ -196,7 +206,7 @@ __global__ __launch_bounds__((ColCfg<PL, F>::threads)) void colfft_kernel(const 
             // pmpfft.c:381-385 multiplies by a double 1 / Norm and rounds once
             if (scale != 1.0) {
 #pragma unroll
-                for (int j = 0; j < E; j++) { v[j].x = (F) (v[j].x * scale); v[j].y = (F) (v[j].y * scale); }
+                for (int j = 0; j < E; j++) { v[j].x = mul_round(v[j].x, scale); v[j].y = mul_round(v[j].y, scale); }
             }
             if (om.nest) {
                 C2<F> *dst = out + (long long) batch * om.m.bstride;
@@ -257,7 +267,7 @@ void colfft_xback3_kernel(const C2<F> *dk, C2<F> *__restrict__ o0, C2<F> *__rest
     const unsigned toff = (unsigned) ((long long) tq * xm.kchunk + (long long) tr * xm.rs + (long long) batch * xm.bstride + col);
     C2<F> b[E];
 #pragma unroll
-    for (int j = 0; j < E; j++) b[j] = live ? ld_stream(&(dk + xm.jb[j])[toff]) : C2<F>{0, 0};
+    for (int j = 0; j < E; j++) b[j] = live ? ld_stream(&(dk + xm.jb[j])[toff]) : C2<F>{F(0), F(0)};
     stage_twiddles(tw, tw_global, PL::TWN);
     if (FWD) {
         C2<F> v[vmax(E)];
@@ -268,33 +278,46 @@ void colfft_xback3_kernel(const C2<F> *dk, C2<F> *__restrict__ o0, C2<F> *__rest
 #pragma unroll
         for (int j = 0; j < E; j++) {
             b[j] = v[j];
-            if (fwd_scale != 1.0) { b[j].x = (F) (b[j].x * fwd_scale); b[j].y = (F) (b[j].y * fwd_scale); }   // as colfft_kernel
+            if (fwd_scale != 1.0) { b[j].x = mul_round(b[j].x, fwd_scale); b[j].y = mul_round(b[j].y, fwd_scale); }   // as colfft_kernel
             if (live) st_stream_x3(&(dk_store + xm.jb[j])[toff], b[j]);
         }
     }
-    const int iyb = live ? col / nzl : 0, iz = (live ? col - iyb * nzl : 0) + zstart;     // kz block of a pencil
+    // (nzl, col: in units of F's columns -- pairs of kz for f32x2; the lanes of a pair are kz = iz0 + l)
+    using LN = Lane<F>;
+    using SF = typename LN::S;
+    const int iyb = live ? col / nzl : 0, iz0 = (live ? col - iyb * nzl : 0) * LN::n + zstart;     // kz block of a pencil
     const int iy = batch * xm.kyb + iyb + ystart;
-    const double kky = kk[iy], kkz = kk[iz];
-    const bool yz_self = iy == (N - iy) % N && iz == (N - iz) % N;
+    const double kky = kk[iy];
+    double kkz[LN::n];
+    bool yz_self[LN::n];
+#pragma unroll
+    for (int l = 0; l < LN::n; l++) {
+        const int iz = iz0 + l;
+        kkz[l] = kk[iz];
+        yz_self[l] = iy == (N - iy) % N && iz == (N - iz) % N;
+    }
     // raw delta_k -> b (laplace and sign, transfer.c:171-183, gravity.c:17)
 #pragma unroll
     for (int j = 0; j < E; j++) {
         const int ix = tau + T * j;
-        double kk_finite = 0;
-        kk_finite += kk[ix];
-        kk_finite += kky;
-        kk_finite += kkz;
-        F are, aim;
-        if (kk_finite != 0) {
-            const double r = 1 / kk_finite;
-            are = (F) (b[j].x * r);
-            aim = (F) (b[j].y * r);
-        } else {
-            are = 0;
-            aim = 0;
+#pragma unroll
+        for (int l = 0; l < LN::n; l++) {
+            double kk_finite = 0;
+            kk_finite += kk[ix];
+            kk_finite += kky;
+            kk_finite += kkz[l];
+            SF are, aim;
+            if (kk_finite != 0) {
+                const double r = 1 / kk_finite;
+                are = (SF) (LN::get(b[j].x, l) * r);
+                aim = (SF) (LN::get(b[j].y, l) * r);
+            } else {
+                are = 0;
+                aim = 0;
+            }
+            LN::set(b[j].x, l, (SF) (are * -1.0));
+            LN::set(b[j].y, l, (SF) (aim * -1.0));
         }
-        b[j].x = (F) (are * -1.0);
-        b[j].y = (F) (aim * -1.0);
     }
 #pragma unroll 1
     for (int dir = 0; dir < (MODE == 0 ? 3 : (MODE == 3 ? 1 : MODE)); dir++) {
@@ -307,17 +330,22 @@ void colfft_xback3_kernel(const C2<F> *dk, C2<F> *__restrict__ o0, C2<F> *__rest
 #pragma unroll
         for (int j = 0; j < E; j++) {
             const int ix = tau_o + T * j;
-            const double k_finite = dir == 0 ? kt[ix] : (dir == 1 ? kt[iy] : kt[iz]);
-            const bool selfconj = yz_self && ix == (N - ix) % N;       // gravity.c:44-56
             C2<F> &d = v[in_slot<PL>(j)];
             if (MODE == 1 || (MODE == 2 && dir == 1)) {
                 d = b[j];
-            } else if (selfconj) {
-                d.x = 0;
-                d.y = 0;
             } else {
-                d.x = (F) (-b[j].y * k_finite);                        // gravity.c:58-60
-                d.y = (F) (b[j].x * k_finite);
+#pragma unroll
+                for (int l = 0; l < LN::n; l++) {
+                    const double k_finite = dir == 0 ? kt[ix] : (dir == 1 ? kt[iy] : kt[iz0 + l]);
+                    const bool selfconj = yz_self[l] && ix == (N - ix) % N;       // gravity.c:44-56
+                    if (selfconj) {
+                        LN::set(d.x, l, 0);
+                        LN::set(d.y, l, 0);
+                    } else {
+                        LN::set(d.x, l, (SF) (-LN::get(b[j].y, l) * k_finite));                        // gravity.c:58-60
+                        LN::set(d.y, l, (SF) (LN::get(b[j].x, l) * k_finite));
+                    }
+                }
             }
         }
         __syncthreads();
@@ -376,10 +404,10 @@ void colfft_yback2_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ oy, 
             const C2<F> *src = in + (long long) batch * im.m.bstride;
             const unsigned toff = row_toff(im, tau, col);
 #pragma unroll
-            for (int j = 0; j < E; j++) a[j] = live ? ld_stream(&(src + (PERS ? jbl[j] : im.jb[j]))[toff]) : C2<F>{0, 0};
+            for (int j = 0; j < E; j++) a[j] = live ? ld_stream(&(src + (PERS ? jbl[j] : im.jb[j]))[toff]) : C2<F>{F(0), F(0)};
         } else {
 #pragma unroll
-            for (int j = 0; j < E; j++) a[j] = live ? ld_stream(&in[col_addr(im.m, batch, tau + T * j, col)]) : C2<F>{0, 0};
+            for (int j = 0; j < E; j++) a[j] = live ? ld_stream(&in[col_addr(im.m, batch, tau + T * j, col)]) : C2<F>{F(0), F(0)};
         }
         if (!PERS) stage_twiddles(tw, tw_global, PL::TWN);
         // op != nullptr: a third output, the potential itself (gravity.c:487-492 wants it read out too): its y pass
@@ -395,9 +423,13 @@ void colfft_yback2_kernel(const C2<F> *__restrict__ in, C2<F> *__restrict__ oy, 
                 if (dir == 0) {
                     d = a[j];
                 } else {
-                    const double k_finite = dir == 1 ? kt[tau_o + T * j] : kt[live ? col + zstart : 0];
-                    d.x = (F) (-a[j].y * k_finite);
-                    d.y = (F) (a[j].x * k_finite);
+                    using LN = Lane<F>;
+#pragma unroll
+                    for (int l = 0; l < LN::n; l++) {                          // (col: pairs of kz for f32x2)
+                        const double k_finite = dir == 1 ? kt[tau_o + T * j] : kt[live ? col * LN::n + l + zstart : 0];
+                        LN::set(d.x, l, (typename LN::S) (-LN::get(a[j].y, l) * k_finite));
+                        LN::set(d.y, l, (typename LN::S) (LN::get(a[j].x, l) * k_finite));
+                    }
                 }
             }
             __syncthreads();
@@ -431,6 +463,30 @@ template <typename K> static int set_lds(K kernel, size_t bytes)
     }
     return 0;
 }
+
+// the maps and column counts of a launch in units of F's columns (pairs of fp32 columns for f32x2: every stride is a
+// multiple of the row pitch nzl, which is a whole number of 128-byte lines)
+template <typename F> static ColMap unit_map(const ColMap &m)
+{
+    constexpr int n = Lane<F>::n;
+    return ColMap{m.bstride / n, m.rhi / n, m.rlo / n, m.rsplit};
+}
+// fp32 meshes: two adjacent columns per thread (f32x2, fpm_fftcore.h) where it was measured to win -- the fused kernels
+// hold 2 x the values per thread and do half the memory / LDS instructions per byte; the plain pass, which only waits for
+// memory, loses the threads it gives up.  ms, scalar -> pairs (512^3 and 1024^3 on one GPU; one rank of eight at 2048^3 and
+// 3072^3):  colfft_xback3 0.70 -> 0.70, 7.41 -> 5.49, 8.06 -> 6.95, 38.5 -> 26.6;  colfft_yback2 0.49 -> 0.44, 5.44 -> 4.11,
+// 5.87 -> 5.17, 22.7 -> 21.0;  plain pass 0.203 -> 0.243, 1.95 -> 2.23, 2.59 -> 3.10, 10.7 -> 9.35.
+// FPMHIP_F32_PAIRS = 0: never (and the odd row pitch of round 3, fpm_plan.hip), = 2: every pass (A/B).
+enum { PAIRS_PLAIN = 0, PAIRS_YBACK2 = 1, PAIRS_XBACK3 = 2 };
+static bool f32_pairs(const fpmhip_plan *p, int kind)
+{
+    static const int mode = getenv("FPMHIP_F32_PAIRS") ? atoi(getenv("FPMHIP_F32_PAIRS")) : 1;
+    if (mode == 0 || p->f64 || p->mg.nzl % 2 != 0) return false;
+    if (mode == 2) return true;
+    const int N = p->mg.N;
+    return kind == PAIRS_XBACK3 ? N >= 256 : (kind == PAIRS_YBACK2 ? N >= 256 : N >= 3072);
+}
+#define FPM_BY_PRECISION(p, KIND, CALL_D, CALL_P, CALL_F) ((p)->f64 ? (CALL_D) : (f32_pairs(p, KIND) ? (CALL_P) : (CALL_F)))
 
 #define FPM_CASE(n, ES_, BODY) case n: { using PL = typename FPM_FAC_KIND<n, ES_>::type; BODY(PL) } break;
 #define FPM_FAC_KIND Fac
@@ -466,10 +522,12 @@ static int persist_grid(int ntiles, size_t lds, int threads)
 }
 
 template <typename F>
-static int colfft_launch(fpmhip_plan *p, int dir, const void *in, void *out, const ColMap &im, const ColMap &om,
-                         int nbatch, int ncols, double scale)
+static int colfft_launch(fpmhip_plan *p, int dir, const void *in, void *out, const ColMap &im_, const ColMap &om_,
+                         int nbatch, int ncols_, double scale)
 {
     StageTimer ktm(p, FPMHIP_T_K_COLFFT);
+    const ColMap im = unit_map<F>(im_), om = unit_map<F>(om_);
+    const int ncols = ncols_ / Lane<F>::n;
     const int rev = p->col_reverse;
 #define CALL_PLAIN_S(PL, S)                                                                                    \
     {                                                                                                          \
@@ -508,14 +566,16 @@ int colfft_x(fpmhip_plan *p, int dir, const void *in, void *out, double scale)
     const long long plane = (long long) g.yl * g.nzl;
     if (g.kyb == g.yl) {
         ColMap m{0, 0, plane, g.N};
-        return p->f64 ? colfft_launch<double>(p, dir, in, out, m, m, 1, (int) plane, scale)
-                      : colfft_launch<float>(p, dir, in, out, m, m, 1, (int) plane, scale);
+        return FPM_BY_PRECISION(p, PAIRS_PLAIN, colfft_launch<double>(p, dir, in, out, m, m, 1, (int) plane, scale),
+                                colfft_launch<f32x2>(p, dir, in, out, m, m, 1, (int) plane, scale),
+                                colfft_launch<float>(p, dir, in, out, m, m, 1, (int) plane, scale));
     }
     // k-space blocks (fpmhip_layout.okblock): one batch per block of kyb ky rows; row ix at (ix / xl) * chunk + (ix % xl) * rs
     const long long rs = (long long) g.kyb * g.nzl;
     ColMap m{(long long) g.xl * rs, g.xl == g.N ? 0 : g.kchunk, rs, g.xl};
-    return p->f64 ? colfft_launch<double>(p, dir, in, out, m, m, g.yl / g.kyb, (int) rs, scale)
-                  : colfft_launch<float>(p, dir, in, out, m, m, g.yl / g.kyb, (int) rs, scale);
+    return FPM_BY_PRECISION(p, PAIRS_PLAIN, colfft_launch<double>(p, dir, in, out, m, m, g.yl / g.kyb, (int) rs, scale),
+                            colfft_launch<f32x2>(p, dir, in, out, m, m, g.yl / g.kyb, (int) rs, scale),
+                            colfft_launch<float>(p, dir, in, out, m, m, g.yl / g.kyb, (int) rs, scale));
 }
 
 // y pass on [x_loc][y][kz] planes.  chunked != 0: the OTHER side of the pass is the slab exchange
@@ -550,15 +610,18 @@ int colfft_y_range(fpmhip_plan *p, int dir, const void *in, void *out, int chunk
     const size_t cb = 2 * p->esize;
     const char *inp = (const char *) in + (size_t) x0 * im.bstride * cb;
     char *outp = (char *) out + (size_t) x0 * om.bstride * cb;
-    return p->f64 ? colfft_launch<double>(p, dir, inp, outp, im, om, nx, g.nzl, 1.0)
-                  : colfft_launch<float>(p, dir, inp, outp, im, om, nx, g.nzl, 1.0);
+    return FPM_BY_PRECISION(p, PAIRS_PLAIN, colfft_launch<double>(p, dir, inp, outp, im, om, nx, g.nzl, 1.0),
+                            colfft_launch<f32x2>(p, dir, inp, outp, im, om, nx, g.nzl, 1.0),
+                            colfft_launch<float>(p, dir, inp, outp, im, om, nx, g.nzl, 1.0));
 }
 
 template <typename F>
-static int yback2_launch(fpmhip_plan *p, const void *in, void *oy, void *oz, void *op, const ColMap &im, const ColMap &om,
-                         int nbatch, int ncols, int gradorder)
+static int yback2_launch(fpmhip_plan *p, const void *in, void *oy, void *oz, void *op, const ColMap &im_, const ColMap &om_,
+                         int nbatch, int ncols_, int gradorder)
 {
     StageTimer ktm(p, FPMHIP_T_K_YBACK2);
+    const ColMap im = unit_map<F>(im_), om = unit_map<F>(om_);
+    const int ncols = ncols_ / Lane<F>::n;
     const float *kt = p->d_tab + gradorder * (size_t) p->mg.N;
     // one output per launch where the two-output kernel spills (see the kernel); FPMHIP_YBACK_ONE = 0 | 1 forces (A/B)
     static const int one_env = getenv("FPMHIP_YBACK_ONE") ? atoi(getenv("FPMHIP_YBACK_ONE")) : -1;
@@ -628,8 +691,9 @@ int colfft_yback2_range(fpmhip_plan *p, const void *in, void *oy, void *oz, void
     char *oyp = (char *) oy + (size_t) x0 * om.bstride * cb;
     char *ozp = (char *) oz + (size_t) x0 * om.bstride * cb;
     char *opp = op ? (char *) op + (size_t) x0 * om.bstride * cb : nullptr;
-    return p->f64 ? yback2_launch<double>(p, inp, oyp, ozp, opp, im, om, nx, g.nzl, gradorder)
-                  : yback2_launch<float>(p, inp, oyp, ozp, opp, im, om, nx, g.nzl, gradorder);
+    return FPM_BY_PRECISION(p, PAIRS_YBACK2, yback2_launch<double>(p, inp, oyp, ozp, opp, im, om, nx, g.nzl, gradorder),
+                            yback2_launch<f32x2>(p, inp, oyp, ozp, opp, im, om, nx, g.nzl, gradorder),
+                            yback2_launch<float>(p, inp, oyp, ozp, opp, im, om, nx, g.nzl, gradorder));
 }
 
 template <typename F>
@@ -638,7 +702,9 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
 {
     const MeshGeo &g = p->mg;
     const int N = g.N;
-    const long long plane = (long long) g.yl * g.nzl;
+    constexpr int LNn = Lane<F>::n;                           // columns per thread: every quantity below in those units
+    const int nzl_u = g.nzl / LNn;
+    const long long plane = (long long) g.yl * nzl_u;
     const bool blocked = g.kyb != g.yl;
     const float *kk = p->d_tab + (2 + potorder) * (size_t) N;
     const float *kt = p->d_tab + gradorder * (size_t) N;
@@ -651,11 +717,11 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
     {                                                                                                        \
         using CF = ColCfg<PL, F, true>;                                                                      \
         XMap xm;                                                                                             \
-        xm.rs = blocked ? (long long) g.kyb * g.nzl : plane;                                                 \
+        xm.rs = blocked ? (long long) g.kyb * nzl_u : plane;                                                 \
         xm.xl = blocked ? g.xl : N;                                                                          \
-        xm.kchunk = blocked ? g.kchunk : 0;                                                                  \
-        xm.bstride = blocked ? (long long) g.xl * g.kyb * g.nzl : 0;                                         \
-        xm.ncols = blocked ? g.kyb * g.nzl : (int) plane;                                                    \
+        xm.kchunk = blocked ? g.kchunk / LNn : 0;                                                            \
+        xm.bstride = blocked ? (long long) g.xl * g.kyb * nzl_u : 0;                                         \
+        xm.ncols = blocked ? g.kyb * nzl_u : (int) plane;                                                    \
         xm.kyb = g.kyb;                                                                                      \
         xm.tpb = (xm.ncols + CF::CW - 1) / CF::CW;                                                           \
         if (blocked && g.xl % PL::T != 0 && PL::T % g.xl != 0)                                               \
@@ -675,7 +741,7 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
         }                                                                                                    \
         FPM_TRY(set_lds(colfft_xback3_kernel<PL, P, Q, F>, CF::lds));                                        \
         colfft_xback3_kernel<PL, P, Q, F><<<ntiles, CF::threads, CF::lds, p->stream>>>(                      \
-            (const C2<F> *) dk, (C2<F> *) o0, (C2<F> *) o1, (C2<F> *) o2, xm, g.nzl,                         \
+            (const C2<F> *) dk, (C2<F> *) o0, (C2<F> *) o1, (C2<F> *) o2, xm, nzl_u,                         \
             g.ystart, g.zstart, ntiles, kk, kt, p->d_twiddle, (C2<F> *) dk, fwd_scale, x3_linear);           \
     }
 #define CALL_X3_P(PL, P) if (fwd) CALL_X3_Q(PL, P, true) else CALL_X3_Q(PL, P, false)
@@ -705,14 +771,16 @@ static int xback3_launch(fpmhip_plan *p, const void *dk, void *o0, void *o1, voi
 
 int colfft_xback3(fpmhip_plan *p, const void *dk, void *o0, void *o1, void *o2, int potorder, int gradorder)
 {
-    return p->f64 ? xback3_launch<double>(p, dk, o0, o1, o2, potorder, gradorder, 0)
-                  : xback3_launch<float>(p, dk, o0, o1, o2, potorder, gradorder, 0);
+    return FPM_BY_PRECISION(p, PAIRS_XBACK3, xback3_launch<double>(p, dk, o0, o1, o2, potorder, gradorder, 0),
+                            xback3_launch<f32x2>(p, dk, o0, o1, o2, potorder, gradorder, 0),
+                            xback3_launch<float>(p, dk, o0, o1, o2, potorder, gradorder, 0));
 }
 
 int colfft_xback_pot(fpmhip_plan *p, const void *dk, void *out, int potorder)
 {
-    return p->f64 ? xback3_launch<double>(p, dk, out, out, out, potorder, 0, 1)
-                  : xback3_launch<float>(p, dk, out, out, out, potorder, 0, 1);
+    return FPM_BY_PRECISION(p, PAIRS_XBACK3, xback3_launch<double>(p, dk, out, out, out, potorder, 0, 1),
+                            xback3_launch<f32x2>(p, dk, out, out, out, potorder, 0, 1),
+                            xback3_launch<float>(p, dk, out, out, out, potorder, 0, 1));
 }
 
 // forward x pass (x scale) + transfer + backward x pass(es) from ONE read of the forward y pass' output, which
@@ -720,14 +788,16 @@ int colfft_xback_pot(fpmhip_plan *p, const void *dk, void *out, int potorder)
 int colfft_xfwd_xback(fpmhip_plan *p, void *dk_inout, void *o0, void *o1, void *o2, int potorder, int gradorder,
                       int mode, double scale)
 {
-    return p->f64 ? xback3_launch<double>(p, dk_inout, o0, o1, o2, potorder, gradorder, mode, true, scale)
-                  : xback3_launch<float>(p, dk_inout, o0, o1, o2, potorder, gradorder, mode, true, scale);
+    return FPM_BY_PRECISION(p, PAIRS_XBACK3, xback3_launch<double>(p, dk_inout, o0, o1, o2, potorder, gradorder, mode, true, scale),
+                            xback3_launch<f32x2>(p, dk_inout, o0, o1, o2, potorder, gradorder, mode, true, scale),
+                            xback3_launch<float>(p, dk_inout, o0, o1, o2, potorder, gradorder, mode, true, scale));
 }
 
 int colfft_xback_potx(fpmhip_plan *p, const void *dk, void *out_x, void *out_pot, int potorder, int gradorder)
 {
-    return p->f64 ? xback3_launch<double>(p, dk, out_x, out_pot, out_pot, potorder, gradorder, 2)
-                  : xback3_launch<float>(p, dk, out_x, out_pot, out_pot, potorder, gradorder, 2);
+    return FPM_BY_PRECISION(p, PAIRS_XBACK3, xback3_launch<double>(p, dk, out_x, out_pot, out_pot, potorder, gradorder, 2),
+                            xback3_launch<f32x2>(p, dk, out_x, out_pot, out_pot, potorder, gradorder, 2),
+                            xback3_launch<float>(p, dk, out_x, out_pot, out_pot, potorder, gradorder, 2));
 }
 
 }  // namespace fpm

@@ -29,6 +29,25 @@ template <typename F> struct C2 { F x, y; };
 #endif
 typedef double fpm_v2d __attribute__((ext_vector_type(2)));
 typedef float fpm_v2f __attribute__((ext_vector_type(2)));
+typedef float fpm_v4f __attribute__((ext_vector_type(4)));
+// Two ADJACENT fp32 columns per thread (round 4; the column passes of fp32 meshes): the "real" type is a pair of floats,
+// C2<f32x2> = {(re0, re1), (im0, im1)} is 16 bytes -- the loads, stores and LDS exchanges of an fp32 pass are then the
+// 16-byte accesses of the fp64 pass (half as many instructions for the same bytes), the arithmetic is packed fp32
+// (v_pk_*), and the launch shapes are the ones tuned for fp64 (sizeof(F) == 8 everywhere they are chosen).  In memory the
+// two columns lie (re0, im0, re1, im1): ld_stream / st_stream transpose the 2 x 2 on the way.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename F> struct Lane {
+    static constexpr int n = 1;
+    using S = F;
+    static __device__ __forceinline__ S get(F v, int) { return v; }
+    static __device__ __forceinline__ void set(F &v, int, S s) { v = s; }
+};
+template <> struct Lane<f32x2> {
+    static constexpr int n = 2;
+    using S = float;
+    static __device__ __forceinline__ S get(f32x2 v, int l) { return l ? v.y : v.x; }
+    static __device__ __forceinline__ void set(f32x2 &v, int l, S s) { if (l) v.y = s; else v.x = s; }
+};
 __device__ __forceinline__ C2<double> ld_stream(const C2<double> *p)
 {
 #if FPM_NT & 1
@@ -45,6 +64,36 @@ __device__ __forceinline__ C2<float> ld_stream(const C2<float> *p)
     return {v.x, v.y};
 #else
     return *p;
+#endif
+}
+#ifndef FPM_NT_X3
+#define FPM_NT_X3 1        // (see st_stream_x3 below)
+#endif
+__device__ __forceinline__ C2<f32x2> ld_stream(const C2<f32x2> *p)
+{
+#if FPM_NT & 1
+    const fpm_v4f v = __builtin_nontemporal_load((const fpm_v4f *) p);
+#else
+    const fpm_v4f v = *(const fpm_v4f *) p;
+#endif
+    return {f32x2{v.x, v.z}, f32x2{v.y, v.w}};
+}
+__device__ __forceinline__ void st_stream(C2<f32x2> *p, C2<f32x2> v)
+{
+    const fpm_v4f w = {v.x.x, v.y.x, v.x.y, v.y.y};
+#if FPM_NT & 2
+    __builtin_nontemporal_store(w, (fpm_v4f *) p);
+#else
+    *(fpm_v4f *) p = w;
+#endif
+}
+__device__ __forceinline__ void st_stream_x3(C2<f32x2> *p, C2<f32x2> v)
+{
+    const fpm_v4f w = {v.x.x, v.y.x, v.x.y, v.y.y};
+#if FPM_NT_X3
+    __builtin_nontemporal_store(w, (fpm_v4f *) p);
+#else
+    *(fpm_v4f *) p = w;
 #endif
 }
 __device__ __forceinline__ void st_stream(C2<double> *p, C2<double> v)
@@ -91,6 +140,7 @@ template <typename F> __device__ __forceinline__ C2<F> csub(C2<F> a, C2<F> b) { 
 // bit, so the butterflies may contract (the CIC and transfer arithmetic elsewhere may not)
 __device__ __forceinline__ double ffma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float ffma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ f32x2 ffma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 template <typename F> __device__ __forceinline__ C2<F> cmul(C2<F> a, C2<F> b)
 {
     return {ffma(a.x, b.x, -(a.y * b.y)), ffma(a.x, b.y, a.y * b.x)};

@@ -229,7 +229,12 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
     // row passes lose more (0.23 -> 0.27 ms) than the y passes gain: 3.83 -> 4.03 ms per force.
     const bool aligned = geom->fft_mode == FPMHIP_FFT_AUTO && geom->precision == 64 && colfft_supported((int) N) &&
                          rowfft_supported((int) N);
-    const int align = aligned ? 8 : 1;                                              // complex doubles per 128-B line
+    // fp32 meshes (round 4): an EVEN pitch, so that the column passes can take two adjacent columns per thread (f32x2,
+    // fpm_fftcore.h): 258 instead of 257 complex values at N = 512, 0.4 % of the mesh.  FPMHIP_F32_PAIRS = 0: the old pitch.
+    static const bool pairs_env = !(getenv("FPMHIP_F32_PAIRS") && atoi(getenv("FPMHIP_F32_PAIRS")) == 0);
+    const bool even = pairs_env && geom->fft_mode == FPMHIP_FFT_AUTO && geom->precision == 32 && colfft_supported((int) N) &&
+                      rowfft_supported((int) N);
+    const int align = aligned ? 8 : (even ? 2 : 1);                                 // complex doubles per 128-B line
     const int rp = (nzc + align - 1) / align * align;                               // real rows, in complex units
     // Pencils: the kz axis is cut into PFFT's default blocks of zblk = ceil(nzc / Ny) MODES (what pm->ORegion says on
     // the reference side: rank ry holds kz in [ry * zblk, min(nzc, (ry + 1) * zblk))); the rows that hold a block are
