@@ -198,3 +198,35 @@ def test_binning_overflow_is_repaired_inside_the_call(oracle, paint_mode):
         pm.sync()
         assert util.rel_err(st.acc.cpu().numpy(), ref) <= TOL_ACC[64], call
     pm.destroy()
+
+
+@pytest.mark.parametrize("N,mode", [(256, 0), (256, 2), (64, 2), (96, 2)])
+def test_fp32_column_passes_scalar_and_in_pairs(oracle, tmp_path, N, mode):
+    """fp32 meshes: the column passes take two adjacent kz columns per thread (f32x2, fpm_fftcore.h) by default where that was
+    measured to win (the fused x and y passes from N = 256).  FPMHIP_F32_PAIRS = 0: the scalar kernels and the odd row
+    pitch everywhere; = 2: pairs in every column pass and at every size (a radix-3 length among them).  Both against the
+    oracle, every kernel type that has its own branch in the fused passes.  Child processes: the switch is read once."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    nc, L = 32, 1.5 * N
+    x = util.load_b(nc, L, N, rms_cells=2.0)
+    np.save(tmp_path / "x.npy", x)
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); from fastpm_amd import PM, Store, fastpm_solver_compute_force\n"
+            "x = np.load(%r); pm = PM(%d, %r, 32)\n"
+            "for kern in ('1_4', '3_4', 'naive'):\n"
+            "    st = Store(x, potential=True); dk = pm.alloc()\n"
+            "    fastpm_solver_compute_force(pm, st, kernel=kern, delta_k=dk); torch.cuda.synchronize()\n"
+            "    np.save(sys.argv[1] + kern + '.npy', np.concatenate([st.acc.cpu().numpy(), st.potential.cpu().numpy()[:, None]], axis=1))\n"
+            "assert (int(pm.layout.osize[2]) %% 2 == 0) == (%d != 0)\n"
+            % (ROOT, str(tmp_path / "x.npy"), N, L, mode))
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path / "out_")], env=dict(os.environ, FPMHIP_F32_PAIRS=str(mode)),
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    pmo = oracle.PMOracle(N, L, 32)
+    for kern in ("1_4", "3_4", "naive"):
+        ref = oracle.compute_force(pmo, x, kernel=oracle.KERNELS[kern], potential=True)
+        got = np.load(str(tmp_path / "out_") + kern + ".npy")
+        assert util.rel_err(got[:, :3], ref["acc"]) <= TOL_ACC[32], kern
+        assert util.rel_err(got[:, 3], ref["potential"]) <= TOL_ACC[32], kern
