@@ -328,8 +328,7 @@ int fpmhip_range_pieces(const fpmhip_plan *p, int x0, int nx, int64_t *first_ele
                         int64_t *stride_elems, int *npieces)
 {
     if (!p || !first_elem || !piece_elems || !stride_elems || !npieces) FPM_FAIL(-1, "null argument");
-    if (p->lay.nranks_y > 1) FPM_FAIL(-1, "plane ranges are a slab feature");
-    FPM_TRY(check_range(p, x0, nx));
+    FPM_TRY(check_range(p, x0, nx));        // (pencils: the chunks of the (x <-> ky) exchange "B", same form)
     const MeshGeo &g = p->mg;
     const int64_t row = 2 * (int64_t) g.nzl;                 // mesh elements (reals) per k row
     if (g.kyb == g.yl) {
@@ -343,6 +342,18 @@ int fpmhip_range_pieces(const fpmhip_plan *p, int x0, int nx, int64_t *first_ele
         *piece_elems = (int64_t) nx * g.kyb * row;
         *stride_elems = (int64_t) g.xl * g.kyb * row;
     }
+    return 0;
+}
+
+// Pencils: the same for a chunk of the (y <-> kz) exchange "A", [x_loc][y_loc][kz_loc] per member of the row: one piece.
+int fpmhip_range_pieces_a(const fpmhip_plan *p, int x0, int nx, int64_t *first_elem, int64_t *piece_elems)
+{
+    if (!p || !first_elem || !piece_elems) FPM_FAIL(-1, "null argument");
+    FPM_TRY(check_range(p, x0, nx));
+    const MeshGeo &g = p->mg;
+    const int64_t plane = 2 * (int64_t) g.ylr * g.nzl;       // mesh elements per x plane of a chunk
+    *first_elem = (int64_t) x0 * plane;
+    *piece_elems = (int64_t) nx * plane;
     return 0;
 }
 

@@ -1294,10 +1294,12 @@ static int bin_particles_once(fpmhip_plan *p, const fpmhip_particles *pt, bool *
 
 int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt)
 {
-    // the leapfrog that moved these particles binned them on the way (bin_particles_leap): nothing to do
+    // the leapfrog that moved these particles binned them on the way (bin_particles_leap): nothing to do but the check
+    // every reuse of a binning makes -- one entry per tile against the row it was copied from (a caller that rewrote x
+    // behind the same pointer in between, e.g. a host twin uploaded again, gets -7 instead of forces from stale tiles)
     if (p->prebinned) {
         p->prebinned = false;
-        if (p->binned_x == pt->x && p->binned_np == pt->np && p->binned_mass == pt->mass) return 0;
+        if (p->binned_x == pt->x && p->binned_np == pt->np && p->binned_mass == pt->mass) return reuse_binning(p, pt);
     }
     // the flags of the PREVIOUS binning must be read before this one overwrites them: waits for that binning (one
     // call back in the stream), never for work enqueued since

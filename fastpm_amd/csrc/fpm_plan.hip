@@ -415,6 +415,12 @@ int fpmhip_plan_set_stream(fpmhip_plan *p, void *stream)
     return 0;
 }
 
+// the hipStream_t every launch of the plan goes to (what a transport orders its exchanges against with events)
+void *fpmhip_plan_stream(const fpmhip_plan *p)
+{
+    return p ? (void *) p->stream : nullptr;
+}
+
 void *fpmhip_plan_buffer(fpmhip_plan *p, int which)
 {
     if (!p) return nullptr;

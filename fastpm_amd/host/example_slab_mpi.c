@@ -5,7 +5,10 @@
  * fastpm_hip_slab_force with the MPI transport (fastpm_slab_mpi.c).
  *
  *   make mpi            (in this directory: needs mpi.h / libmpi, e.g. MPICH under /opt/conda)
- *   mpiexec -n P ./example_slab_mpi [nc] [B] [precision] [gradient_mode] [gpu_aware] [host_columns] [decompose] [nprocy]
+ *   mpiexec -n P ./example_slab_mpi [nc] [B] [precision] [gradient_mode] [gpu_aware] [host_columns] [decompose] [nprocy] [chunks] [paint_mode]
+ *
+ * chunks: plane ranges per transpose of the pipelined sequence (fastpm_hip_transport.chunks; 0 = default 4, 1 = whole
+ * meshes non-blocking, -1 = the blocking sequence).
  *
  * nprocy > 1: the reference's pencil process mesh Nproc = {P / nprocy, nprocy} (pmpfft.c:117-136; its default for 8
  * ranks is 4 x 2): every rank owns the particles whose (x, y) cell lies in its pencil and the force goes through
@@ -82,6 +85,36 @@ static int transport_selftest(const fastpm_hip_transport *t, fpmhip_plan *plan)
             for (int d = 0; d < 3; d++) if (g[3 * o + d] != 1e6 * q + 1e3 * r + 10 * i + d) bad++;
         free(sc);
     }
+    if (t->xchg_begin && t->xchg_wait) {
+        /* the non-blocking pair: two pieces of 100 doubles, 300 apart, from the 50th double of every chunk; two tags in
+         * flight at once (the second in the group of two neighbours); everything outside the pieces stays as it was */
+        if (t->bind_plan && t->bind_plan(t->ctx, plan)) bad++;
+        for (int q = 0; q < P; q++) for (int i = 0; i < n; i++) { h[q * n + i] = 1e6 * r + 1e3 * q + i; g[q * n + i] = -1; }
+        fpmhip_memcpy_h2d(plan, ds, h, (size_t) P * n * sizeof(double));
+        fpmhip_memcpy_h2d(plan, dr, g, (size_t) P * n * sizeof(double));
+        void *dr2 = NULL;
+        if (fpmhip_malloc(&dr2, (size_t) 2 * n * sizeof(double))) return 100;
+        fpmhip_memcpy_h2d(plan, dr2, g, (size_t) 2 * n * sizeof(double));
+        const fastpm_hip_pieces pc = {n * sizeof(double), 50 * sizeof(double), 100 * sizeof(double), 300 * sizeof(double), 2};
+        const int members[2] = {r - r % 2, r - r % 2 + 1}, me = r % 2;
+        if (t->xchg_begin(t->ctx, ds, dr, &pc, NULL, P, r, 3)) bad++;
+        if (P % 2 == 0 && t->xchg_begin(t->ctx, ds, dr2, &pc, members, 2, me, 5)) bad++;
+        if (t->xchg_wait(t->ctx, 3)) bad++;
+        if (P % 2 == 0 && t->xchg_wait(t->ctx, 5)) bad++;
+        fpmhip_memcpy_d2h(plan, g, dr, (size_t) P * n * sizeof(double));
+        for (int q = 0; q < P; q++) for (int i = 0; i < n; i++) {
+            const int in = (i >= 50 && i < 150) || (i >= 350 && i < 450);
+            if (g[q * n + i] != (in ? 1e6 * q + 1e3 * r + i : -1)) { bad++; break; }
+        }
+        if (P % 2 == 0) {
+            fpmhip_memcpy_d2h(plan, g, dr2, (size_t) 2 * n * sizeof(double));
+            for (int q = 0; q < 2; q++) for (int i = 0; i < n; i++) {
+                const int in = (i >= 50 && i < 150) || (i >= 350 && i < 450);
+                if (g[q * n + i] != (in ? 1e6 * members[q] + 1e3 * me + i : -1)) { bad++; break; }
+            }
+        }
+        fpmhip_free(dr2);
+    }
     fpmhip_free(ds); fpmhip_free(dr); free(h);
     return bad;
 }
@@ -100,6 +133,8 @@ int main(int argc, char **argv)
     const int host_columns = argc > 6 ? atoi(argv[6]) : 0;
     const int decompose = argc > 7 ? atoi(argv[7]) : 0;
     const int nprocy = argc > 8 && atoi(argv[8]) > 1 ? atoi(argv[8]) : 1;
+    const int chunks = argc > 9 ? atoi(argv[9]) : 0;          /* plane ranges per transpose; 0: default, -1: blocking */
+    const int paint_mode = argc > 10 ? atoi(argv[10]) : 0;    /* FPMHIP_PAINT_*: 3 = strip tiles on a small mesh */
     const int nprocx = P / nprocy;
     const int Nmesh = nc * B;
     const double BoxSize = 3.0 * nc;
@@ -117,11 +152,13 @@ int main(int argc, char **argv)
     g.device = rank % (fpmhip_device_count() > 0 ? fpmhip_device_count() : 1);
     g.gradient_mode = gradient_mode;
     g.nranks_y = nprocy;
+    g.paint_mode = paint_mode;
     fpmhip_plan *plan = NULL;
     CHECK(fpmhip_plan_create(&g, NULL, &plan));
     fastpm_hip_transport *t = gpu_aware == 2 ? fastpm_hip_rccl_transport_create(MPI_COMM_WORLD, g.device)
                                              : fastpm_hip_mpi_transport_create(MPI_COMM_WORLD, plan, gpu_aware);
     if (!t) { fprintf(stderr, "rank %d: no transport\n", rank); MPI_Abort(MPI_COMM_WORLD, 1); }
+    t->chunks = chunks;
     printf("transport %d selftest bad %d\n", rank, transport_selftest(t, plan));
 
     /* this rank's particles: x cell in [rank * N / P, (rank + 1) * N / P) */

@@ -59,6 +59,47 @@ static void *fail(const char *what, const void *host)
     return NULL;
 }
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * DEFERRED particle updates (round 5).  libfastpm calls fastpm_kick_store, fastpm_drift_store x 2 and fastpm_store_wrap
+ * one after the other on the same store (solver.c:289-296, 583): K [K] D D wrap.  Each call here only RECORDS its factors;
+ * the wrap -- or anything else that touches one of the columns first -- runs the whole run as ONE walk over the rows
+ * (fpmhip_leapfrog_bin: 84 B per particle instead of 204, and the tile binning of the force that follows made on the
+ * way).  Same bits as the separate calls (tests/test_gpu_step.py, test_gpu_resident.py).  FASTPM_HIP_DEFER=0: every call
+ * runs at once, as in round 4.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    fpmhip_plan *plan;
+    int nk, nd, busy;
+    fpmhip_kick_factor k[2];
+    fpmhip_drift_factor d[2];
+    const float *acc, *dx1, *dx2;           /* host addresses: the keys of the twins */
+    float *v;
+    double *x;
+    int64_t np;
+} Pending;
+static Pending pend;
+
+static int defer_enabled(void)
+{
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("FASTPM_HIP_DEFER");
+        on = !(e && atoi(e) == 0);
+    }
+    return on;
+}
+
+static int flush_pending(int with_wrap, const float *mass);
+
+/* a twin is about to be looked at from outside the deferred run: if it is one of the run's columns, the run happens now */
+static int settle(const void *host)
+{
+    if ((pend.nk || pend.nd) && !pend.busy && host
+        && (host == pend.acc || host == pend.v || host == pend.x || host == pend.dx1 || host == pend.dx2))
+        return flush_pending(0, NULL);
+    return 0;
+}
+
 static Twin *find(const void *host)
 {
     for (Twin *t = twins; t; t = t->next)
@@ -110,6 +151,9 @@ static int upload(Twin *t, size_t bytes)
     stats.h2d_copies++;
     t->valid = bytes;
     t->state = ST_SAME;
+    /* a column rewritten behind an unchanged DEVICE pointer: if it is the position column the plan binned last
+     * (fpmhip_wrap_bin / fpmhip_leapfrog_bin leave the binning for the force that follows), that binning is stale */
+    if (t->kind == KIND_PLAIN && be == &default_backend) (void) fpmhip_invalidate_binning(t->plan);
     return 0;
 }
 
@@ -140,15 +184,25 @@ static void *twin_out(fpmhip_plan *plan, void *host, size_t bytes, int kind)
     if (t->state != ST_DEV_NEWER) t->valid = 0;            /* nothing on the device worth keeping across a regrow */
     if (reserve(t, bytes) != 0) return fail("device allocation failed", host);
     t->state = ST_DEV_NEWER;
-    if (bytes > t->valid) t->valid = bytes;
+    t->valid = bytes;           /* what this writer fills: a later sync copies that and no more (the store may have shrunk) */
     return t->dev;
 }
 
-void *fastpm_hip_dev_in(fpmhip_plan *plan, const void *host, size_t bytes) { return twin_in(plan, host, bytes, KIND_PLAIN); }
-void *fastpm_hip_dev_out(fpmhip_plan *plan, void *host, size_t bytes) { return twin_out(plan, host, bytes, KIND_PLAIN); }
+void *fastpm_hip_dev_in(fpmhip_plan *plan, const void *host, size_t bytes)
+{
+    if (settle(host)) return fail("a deferred particle update failed", host);
+    return twin_in(plan, host, bytes, KIND_PLAIN);
+}
+
+void *fastpm_hip_dev_out(fpmhip_plan *plan, void *host, size_t bytes)
+{
+    if (settle(host)) return fail("a deferred particle update failed", host);
+    return twin_out(plan, host, bytes, KIND_PLAIN);
+}
 
 void *fastpm_hip_dev_inout(fpmhip_plan *plan, void *host, size_t bytes)
 {
+    if (settle(host)) return fail("a deferred particle update failed", host);
     void *d = twin_in(plan, host, bytes, KIND_PLAIN);
     if (d) find(host)->state = ST_DEV_NEWER;
     return d;
@@ -201,6 +255,7 @@ void *fastpm_hip_kmesh_inout(fpmhip_plan *plan, void *host)
 
 int fastpm_hip_host_sync(const void *host)
 {
+    if (settle(host)) return -1;
     Twin *t = find(host);
     check_tag(t);
     if (!t || t->state != ST_DEV_NEWER) return 0;
@@ -216,6 +271,7 @@ int fastpm_hip_host_sync(const void *host)
 
 void fastpm_hip_host_touched(const void *host)
 {
+    (void) settle(host);            /* (what the host wrote over is lost either way; the other columns get their update) */
     Twin *t = find(host);
     if (t) t->state = ST_HOST_NEWER;
 }
@@ -229,6 +285,7 @@ int fastpm_hip_host_is_stale(const void *host)
 
 void fastpm_hip_mirror_release(const void *host)
 {
+    (void) settle(host);
     for (Twin **pp = &twins; *pp; pp = &(*pp)->next) {
         Twin *t = *pp;
         if (t->host != host) continue;
@@ -306,6 +363,54 @@ static int hand_to_host(void *host)
     return 0;
 }
 
+/* the recorded run, executed: the fused walk for K [K] D D (+ wrap), the stand-alone kernels for anything shorter */
+static int flush_pending(int with_wrap, const float *mass)
+{
+    if (!(pend.nk || pend.nd)) return 0;
+    Pending q = pend;
+    pend.busy = 1;
+    int rc = 0;
+    const size_t b = (size_t) q.np * 12;
+    const int m = q.nk ? q.k[0].forcemode : q.d[0].forcemode;
+    const int cola = m == FPMHIP_FORCE_COLA;
+    const float *dacc = NULL, *d1 = NULL, *d2 = NULL, *dm = NULL;
+    float *dv = NULL;
+    double *dx = NULL;
+#define NEEDQ(ptr) do { if (!rc && !(ptr)) rc = -9; } while (0)
+    if (q.nk) NEEDQ(dacc = twin_in(q.plan, q.acc, b, KIND_PLAIN));
+    if (q.dx1) NEEDQ(d1 = twin_in(q.plan, q.dx1, b, KIND_PLAIN));
+    if (q.dx2) NEEDQ(d2 = twin_in(q.plan, q.dx2, b, KIND_PLAIN));
+    if (q.v) {
+        NEEDQ(dv = twin_in(q.plan, q.v, b, KIND_PLAIN));
+        if (!rc && q.nk) find(q.v)->state = ST_DEV_NEWER;
+    }
+    if (q.nd || with_wrap) {
+        NEEDQ(dx = twin_in(q.plan, q.x, 2 * b, KIND_PLAIN));
+        if (!rc) find(q.x)->state = ST_DEV_NEWER;
+    }
+    if (with_wrap && mass) NEEDQ(dm = twin_in(q.plan, mass, (size_t) q.np * 4, KIND_PLAIN));
+#undef NEEDQ
+    (void) cola;
+    if (!rc && q.nk >= 1 && q.nd == 2) {
+        fpmhip_particles p;
+        memset(&p, 0, sizeof(p));
+        p.x = dx; p.acc = (float *) dacc; p.mass = dm; p.np = q.np;
+        rc = with_wrap ? fpmhip_leapfrog_bin(q.plan, &p, dv, d1, d2, q.nk, &q.k[0], &q.k[1], &q.d[0], &q.d[1], 1)
+                       : fpmhip_leapfrog(q.plan, dacc, dv, dx, d1, d2, q.np, q.nk, &q.k[0], &q.k[1], &q.d[0], &q.d[1], 0);
+    } else if (!rc) {
+        for (int i = 0; i < q.nk && !rc; i++) rc = fpmhip_kick(q.plan, dacc, dv, d1, d2, dv, q.np, &q.k[i]);
+        for (int i = 0; i < q.nd && !rc; i++) rc = fpmhip_drift(q.plan, dx, dv, d1, d2, dx, q.np, &q.d[i]);
+        if (!rc && with_wrap) {
+            fpmhip_particles p;
+            memset(&p, 0, sizeof(p));
+            p.x = dx; p.mass = dm; p.np = q.np;
+            rc = fpmhip_wrap_bin(q.plan, &p);
+        }
+    }
+    memset(&pend, 0, sizeof(pend));
+    return rc;
+}
+
 int fastpm_hip_resident_kick(fpmhip_plan *plan, const fpmhip_kick_factor *kick, const float *acc, const float *v_in,
                              const float *dx1, const float *dx2, float *v_out, int64_t np, int own_output)
 {
@@ -313,6 +418,28 @@ int fastpm_hip_resident_kick(fpmhip_plan *plan, const fpmhip_kick_factor *kick, 
     if (np == 0) return 0;
     const size_t b = (size_t) np * 12;
     const int cola = kick->forcemode == FPMHIP_FORCE_COLA;
+    if (cola && (!dx1 || !dx2)) return -1;
+    if (defer_enabled() && v_out == v_in && !own_output && acc
+        && (kick->forcemode == FPMHIP_FORCE_FASTPM || kick->forcemode == FPMHIP_FORCE_PM || cola)) {
+        /* K, or the K that follows a K on the same columns (the kick that closes a step and the one that opens the next) */
+        const int joins = pend.nk == 1 && pend.nd == 0 && pend.plan == plan && pend.acc == acc && pend.v == v_out
+                          && pend.np == np && pend.k[0].forcemode == kick->forcemode;
+        if (!joins) {
+            const int rc = flush_pending(0, NULL);
+            if (rc) return rc;
+            /* the twins exist (and carry the first upload) from this call on, so errors surface where they belong */
+            if (!fastpm_hip_dev_in(plan, acc, b) || !fastpm_hip_dev_in(plan, v_in, b)) return -9;
+            if (cola && (!fastpm_hip_dev_in(plan, dx1, b) || !fastpm_hip_dev_in(plan, dx2, b))) return -9;
+            pend.plan = plan; pend.acc = acc; pend.v = v_out; pend.np = np;
+            pend.dx1 = cola ? dx1 : NULL; pend.dx2 = cola ? dx2 : NULL;
+        }
+        pend.k[pend.nk++] = *kick;
+        return 0;
+    }
+    {
+        const int rc = flush_pending(0, NULL);
+        if (rc) return rc;
+    }
     const float *dacc, *dv, *d1 = NULL, *d2 = NULL;
     float *dvo;
     NEED(dacc = fastpm_hip_dev_in(plan, acc, b));
@@ -346,6 +473,20 @@ int fastpm_hip_resident_drift(fpmhip_plan *plan, const fpmhip_drift_factor *drif
     const float *dv = NULL, *d1 = NULL, *d2 = NULL;
     const double *dx;
     double *dxo;
+    if (defer_enabled() && x_out == x_in && !own_output && need_v && v && (!need_1 || (dx1 && dx2))
+        && (pend.nk >= 1 && pend.nd < 2 && pend.plan == plan && pend.v == v && pend.np == np
+            && pend.k[0].forcemode == m && (pend.nd == 0 || pend.x == x_out)
+            && (!need_1 || (pend.dx1 == dx1 && pend.dx2 == dx2)))) {
+        /* D after K [K], or the second D: joins the run */
+        if (pend.nd == 0 && !fastpm_hip_dev_in(plan, x_in, 2 * b)) return -9;
+        pend.x = x_out;
+        pend.d[pend.nd++] = *drift;
+        return 0;
+    }
+    {
+        const int rc = flush_pending(0, NULL);
+        if (rc) return rc;
+    }
     if (need_v) { if (!v) return -1; NEED(dv = fastpm_hip_dev_in(plan, v, b)); }
     if (need_1) { if (!dx1) return -1; NEED(d1 = fastpm_hip_dev_in(plan, dx1, b)); }
     if (need_2) { if (!dx2) return -1; NEED(d2 = fastpm_hip_dev_in(plan, dx2, b)); }
@@ -368,6 +509,8 @@ int fastpm_hip_resident_wrap(fpmhip_plan *plan, double *x, const float *mass, in
     /* fastpm_store_wrap is the last thing that moves a particle before the force (fastpm_decompose, solver.c:583, then
      * :455): the tile binning of that force call is made in the same walk over the rows (fpmhip_wrap_bin; a plain wrap
      * where that is not on offer) */
+    if ((pend.nk || pend.nd) && pend.plan == plan && pend.x == x && pend.np == np)
+        return flush_pending(1, mass);              /* K [K] D D wrap: one walk, binned for the force on the way */
     fpmhip_particles p;
     memset(&p, 0, sizeof(p));
     NEED(p.x = fastpm_hip_dev_inout(plan, x, (size_t) np * 24));
@@ -455,28 +598,51 @@ void fastpm_solver_compute_force_resident_hip(FastPMResidentSolverView *fastpm, 
         return;
     }
     unsigned flags = FASTPM_HIP_SYNC_POTENTIAL;
+    /* pm_check_values at gravity.c:350, 352, 381, 383.  FASTPM_HIP_CHECK_VALUES=1: at every call (five sweeps of a mesh
+     * and five stream waits per force); =0: never; unset (the default): the reference's diagnostics WITHOUT their cost --
+     * the acc summary the log lines below need anyway says whether anything went wrong (a NaN or an overflow in any mesh
+     * reaches every particle through the transforms), and only then the step is run again with the check points on */
+    int check = -1;
     {
         const char *e = getenv("FASTPM_HIP_SYNC_DELTA_K");
         if (e && atoi(e) != 0) flags |= FASTPM_HIP_SYNC_DELTA_K;
-        e = getenv("FASTPM_HIP_CHECK_VALUES");                  /* gravity.c:350, 352, 381, 383: opt in (five sweeps) */
-        if (e && atoi(e) != 0) fpmhip_set_check_hook(pm->plan, check_line, pm);
+        e = getenv("FASTPM_HIP_CHECK_VALUES");
+        if (e) check = atoi(e) != 0;
     }
-    const int rc = fastpm_hip_resident_force(pm->plan, parts, nspecies, (int) kernel, (int) dealias, delta_k, flags);
+    if (check > 0) fpmhip_set_check_hook(pm->plan, check_line, pm);
+    int rc = fastpm_hip_resident_force(pm->plan, parts, nspecies, (int) kernel, (int) dealias, delta_k, flags);
     fpmhip_set_check_hook(pm->plan, NULL, NULL);
     if (rc) { raise_rc(rc); return; }
     /* gravity.c:398-417 from the device summary (store.c:807-908 on one rank: no Allreduce) */
-    for (int si = 0; si < FASTPM_SOLVER_NSPECIES; si++) {
-        if (!fastpm->has_species[si] || !fastpm->species[si]) continue;
-        const FastPMResidentStoreView *p = fastpm->species[si];
-        if (p->np == 0) continue;
-        double rmin[3], rmax[3], s1[3], s2[3];
-        const int rs = fastpm_hip_resident_summary(pm->plan, &p->acc[0][0], 3, (int64_t) p->np, rmin, rmax, s1, s2);
-        if (rs) { raise_rc(rs); return; }
-        const double n = (double) p->np;
-        for (int pass = 0; pass < 2; pass++)
+    for (int attempt = 0; attempt < 2; attempt++) {
+        double rmin[FASTPM_SOLVER_NSPECIES][3], rmax[FASTPM_SOLVER_NSPECIES][3], s1[FASTPM_SOLVER_NSPECIES][3],
+               s2[FASTPM_SOLVER_NSPECIES][3];
+        int bad = 0;
+        for (int si = 0; si < FASTPM_SOLVER_NSPECIES; si++) {
+            if (!fastpm->has_species[si] || !fastpm->species[si] || fastpm->species[si]->np == 0) continue;
+            const FastPMResidentStoreView *p = fastpm->species[si];
+            const int rs = fastpm_hip_resident_summary(pm->plan, &p->acc[0][0], 3, (int64_t) p->np, rmin[si], rmax[si], s1[si], s2[si]);
+            if (rs) { raise_rc(rs); return; }
             for (int d = 0; d < 3; d++)
-                fpm_raise_hip(0, pass ? "p%s+g  acc[%d]: %g %g %g %g\n" : "p%s    acc[%d]: %g %g %g %g\n", p->name, d,
-                              rmin[d], sqrt(s2[d] / n - pow(s1[d] / n, 2)), s1[d] / n, rmax[d]);
+                bad |= !(isfinite(s1[si][d]) && isfinite(s2[si][d]) && fabs(rmin[si][d]) <= 1e15 && fabs(rmax[si][d]) <= 1e15);
+        }
+        if (bad && check < 0 && attempt == 0) {
+            fpmhip_set_check_hook(pm->plan, check_line, pm);
+            rc = fastpm_hip_resident_force(pm->plan, parts, nspecies, (int) kernel, (int) dealias, delta_k, flags);
+            fpmhip_set_check_hook(pm->plan, NULL, NULL);
+            if (rc) { raise_rc(rc); return; }
+            continue;
+        }
+        for (int si = 0; si < FASTPM_SOLVER_NSPECIES; si++) {
+            if (!fastpm->has_species[si] || !fastpm->species[si] || fastpm->species[si]->np == 0) continue;
+            const FastPMResidentStoreView *p = fastpm->species[si];
+            const double n = (double) p->np;
+            for (int pass = 0; pass < 2; pass++)
+                for (int d = 0; d < 3; d++)
+                    fpm_raise_hip(0, pass ? "p%s+g  acc[%d]: %g %g %g %g\n" : "p%s    acc[%d]: %g %g %g %g\n", p->name, d,
+                                  rmin[si][d], sqrt(s2[si][d] / n - pow(s1[si][d] / n, 2)), s1[si][d] / n, rmax[si][d]);
+        }
+        break;
     }
 }
 

@@ -1,6 +1,8 @@
 /*
- * fastpm_slab_hip.c -- see fastpm_slab_hip.h.  The sequence is fastpm_amd/distributed.py::SlabForce.steps in
- * C99, with blocking exchanges.
+ * fastpm_slab_hip.c -- see fastpm_slab_hip.h.  The sequence is fastpm_amd/distributed.py::SlabForce.steps /
+ * PencilForce.steps in C99.  Round 5: the transposes are NON-BLOCKING where the transport offers xchg_begin / xchg_wait
+ * (all three in-tree transports do) -- cut into plane ranges that overlap the (y, z) passes on slabs and forwards on
+ * pencils, by component backwards on pencils; a transport without them gets the blocking whole-mesh sequence.
  */
 #include <pthread.h>
 #include <stdlib.h>
@@ -26,6 +28,55 @@ static int shift(fpmhip_plan *plan, const fastpm_hip_transport *t, void *mesh, i
     TRY(fpmhip_sync(plan));
     return t->sendrecv(t->ctx, fpmhip_plane_ptr(plan, mesh, ix), (t->rank + dir + P) % P, recv,
                        (t->rank - dir + P) % P, (size_t) n * plane_bytes);
+}
+
+/* ---- non-blocking exchanges (fastpm_hip_transport.xchg_begin / xchg_wait): the C twin of the "alltoall_range_start" /
+ * "alltoall_start" / "wait" requests of fastpm_amd/distributed.py::SlabForce.steps ---- */
+enum { TAG_FWD = 0, TAG_POT = 16, TAG_X = 32, TAG_A = 48, TAG_Y = 60, TAG_Z = 61, TAG_XA = 62, TAG_PA = 63, MAX_RANGES = 12 };
+
+/* How the transposes of this step are cut: 0 = the transport has no non-blocking calls (or chunks < 0): the blocking
+ * whole-mesh sequence; 1 = whole meshes, non-blocking where two travel; c > 1 = c plane ranges per transpose, range i on
+ * the wire while range i + 1 goes through its (y, z) passes (SlabForce._ranges) */
+static int plane_ranges(fpmhip_plan *plan, const fastpm_hip_transport *t, int64_t xl)
+{
+    if (!t->xchg_begin || !t->xchg_wait) return 0;
+    int c = t->chunks;
+    if (c == 0) {
+        const char *e = getenv("FASTPM_HIP_CHUNKS");
+        c = e ? atoi(e) : 4;
+    }
+    if (c < 0) return 0;
+    if (c > MAX_RANGES) c = MAX_RANGES;
+    if (c <= 1 || !fpmhip_plan_ranged_fft(plan) || xl % c != 0) return 1;
+    return c;
+}
+
+/* the planes [x0, x0 + nx) of every chunk of an (x <-> ky) exchange -- the slab transpose, exchange "B" of a pencil
+ * column -- or, axis_a, of a (y <-> kz) exchange inside a pencil row; nx == 0: the whole chunks */
+static int pieces_of(fpmhip_plan *plan, const fpmhip_layout *lay, int axis_a, int x0, int nx, fastpm_hip_pieces *pc)
+{
+    const size_t es = (size_t) lay->precision / 8;
+    pc->chunk_bytes = (size_t) (axis_a ? lay->chunk_a_elems : lay->chunk_b_elems) * es;
+    if (nx == 0) {
+        pc->first_bytes = 0; pc->piece_bytes = pc->chunk_bytes; pc->stride_bytes = pc->chunk_bytes; pc->npieces = 1;
+        return 0;
+    }
+    int64_t first = 0, piece = 0, stride = 0;
+    int n = 1;
+    if (axis_a) TRY(fpmhip_range_pieces_a(plan, x0, nx, &first, &piece));
+    else TRY(fpmhip_range_pieces(plan, x0, nx, &first, &piece, &stride, &n));
+    pc->first_bytes = (size_t) first * es; pc->piece_bytes = (size_t) piece * es; pc->stride_bytes = (size_t) stride * es;
+    pc->npieces = n;
+    return 0;
+}
+
+/* slabs: all ranks are one group */
+static int begin_range(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_layout *lay, const void *send,
+                       void *recv, int x0, int nx, int tag)
+{
+    fastpm_hip_pieces pc;
+    TRY(pieces_of(plan, lay, 0, x0, nx, &pc));
+    return t->xchg_begin(t->ctx, send, recv, &pc, NULL, t->nranks, t->rank, tag);
 }
 
 /* every species painted into one canvas (gravity.c:323-338): the mass all-reduce covers all of them */
@@ -125,10 +176,22 @@ static int slab_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, 
     TRY(fpmhip_plane_add(plan, fpmhip_plane_ptr(plan, canvas, 0), tmp));
     TRY(fpmhip_check_point(plan, canvas, "After painting"));     /* gravity.c:350 (no-ops without a check hook) */
 
-    /* gravity.c:351 pm_r2c, gravity.c:476 softening */
-    if (strips_fwd) TRY(fpmhip_fft_y_forward(plan, canvas, work));
-    else TRY(fpmhip_fft_yz_forward(plan, canvas, work));
-    TRY(exchange(plan, t, work, delta_k, chunk_bytes));
+    /* gravity.c:351 pm_r2c, gravity.c:476 softening.  The transpose (pmpfft.c:377-396: PFFT's, which overlaps nothing)
+     * in nr plane ranges: range i is on the wire while range i + 1 goes through its (y, z) passes. */
+    const int nr = plane_ranges(plan, t, xl);
+    const int rx = nr > 1 ? (int) (xl / nr) : (int) xl;
+    if (nr > 1) {
+        for (int i = 0; i < nr; i++) {
+            if (strips_fwd) TRY(fpmhip_fft_y_forward_range(plan, canvas, work, i * rx, rx));
+            else TRY(fpmhip_fft_yz_forward_range(plan, canvas, work, i * rx, rx));
+            TRY(begin_range(plan, t, &lay, work, delta_k, i * rx, rx, TAG_FWD + i));
+        }
+        for (int i = 0; i < nr; i++) TRY(t->xchg_wait(t->ctx, TAG_FWD + i));
+    } else {
+        if (strips_fwd) TRY(fpmhip_fft_y_forward(plan, canvas, work));
+        else TRY(fpmhip_fft_yz_forward(plan, canvas, work));
+        TRY(exchange(plan, t, work, delta_k, chunk_bytes));
+    }
     /* without a softening kernel the forward x pass runs on into the transfer and the backward x pass(es) */
     const int fuse_x = softening == FPMHIP_SOFTENING_NONE && fpmhip_plan_column_fft(plan);
     if (!fuse_x) {
@@ -143,8 +206,20 @@ static int slab_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, 
         void *phi = canvas;
         if (fuse_x) TRY(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 1, phi, NULL, NULL));
         else TRY(fpmhip_transfer_fft_x_backward_pot(plan, delta_k, phi, kernel));
-        TRY(exchange(plan, t, phi, work, chunk_bytes));
-        TRY(fpmhip_fft_yz_backward(plan, work, phi));
+        if (nr > 1) {
+            /* the real-space potential must not land in the buffer later ranges are still being sent from */
+            void *phi2 = fpmhip_plan_buffer(plan, B_F2);
+            if (!phi2) return -2;
+            for (int i = 0; i < nr; i++) TRY(begin_range(plan, t, &lay, phi, work, i * rx, rx, TAG_POT + i));
+            for (int i = 0; i < nr; i++) {
+                TRY(t->xchg_wait(t->ctx, TAG_POT + i));
+                TRY(fpmhip_fft_yz_backward_range(plan, work, phi2, i * rx, rx));
+            }
+            phi = phi2;
+        } else {
+            TRY(exchange(plan, t, phi, work, chunk_bytes));
+            TRY(fpmhip_fft_yz_backward(plan, work, phi));
+        }
         TRY(shift(plan, t, phi, 0, 1, fpmhip_plane_ptr(plan, phi, xl), -1, plane_bytes));
         TRY(shift(plan, t, phi, 1, 2, fpmhip_plane_ptr(plan, halo, 2), -1, plane_bytes));
         TRY(shift(plan, t, phi, xl - 2, 2, halo, +1, plane_bytes));
@@ -161,15 +236,44 @@ static int slab_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, 
         /* two meshes through the transpose: the x component and the potential (see fastpm_hip.h) */
         if (fuse_x) TRY(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 2, f[0], f[1], NULL));
         else TRY(fpmhip_transfer_fft_x_backward_potx(plan, delta_k, f[0], f[1], kernel));
-        TRY(exchange(plan, t, f[0], work, chunk_bytes));
-        TRY(exchange(plan, t, f[1], work2, chunk_bytes));
-        if (strips) TRY(fpmhip_fft_y_backward(plan, work, f[0]));
-        else TRY(fpmhip_fft_yz_backward(plan, work, f[0]));
         /* the potential column rides along: no second transfer, x pass and all-to-all for it */
         void *potmesh = any_pot ? fpmhip_plan_buffer(plan, B_DELTA_K) : NULL;
         if (any_pot && (delta_k == potmesh || !potmesh)) potmesh = NULL;          /* the caller wants delta_k kept there */
-        if (strips) TRY(fpmhip_fft_y_backward_grad2(plan, work2, f[1], f[2], potmesh, kernel));
-        else TRY(fpmhip_fft_yz_backward_grad2(plan, work2, f[1], f[2], potmesh, kernel));
+        if (nr > 1) {
+            /* both transposes in plane ranges, the potential first: its y pass + two z passes (the larger share of the
+             * compute) run while the x component is still on the wire.  A range's outputs must not land in a buffer
+             * later ranges are still being sent from: y -> f[2], z -> a further mesh, x -> f[1], which is free once every
+             * range of the potential has arrived (distributed.py: SlabForce.steps) */
+            void *extra = fpmhip_plan_buffer(plan, B_XCHG2);
+            if (!extra) return -2;
+            for (int i = 0; i < nr; i++) TRY(begin_range(plan, t, &lay, f[1], work2, i * rx, rx, TAG_POT + i));
+            for (int i = 0; i < nr; i++) TRY(begin_range(plan, t, &lay, f[0], work, i * rx, rx, TAG_X + i));
+            for (int i = 0; i < nr; i++) {
+                TRY(t->xchg_wait(t->ctx, TAG_POT + i));
+                if (strips) TRY(fpmhip_fft_y_backward_grad2_range(plan, work2, f[2], extra, potmesh, kernel, i * rx, rx));
+                else TRY(fpmhip_fft_yz_backward_grad2_range(plan, work2, f[2], extra, potmesh, kernel, i * rx, rx));
+            }
+            for (int i = 0; i < nr; i++) {
+                TRY(t->xchg_wait(t->ctx, TAG_X + i));
+                if (strips) TRY(fpmhip_fft_y_backward_range(plan, work, f[1], i * rx, rx));
+                else TRY(fpmhip_fft_yz_backward_range(plan, work, f[1], i * rx, rx));
+            }
+            f[0] = f[1]; f[1] = f[2]; f[2] = extra;               /* (x, y, z); the canvas is free (scratch below) */
+        } else {
+            if (nr == 1) {                                        /* whole meshes, both on the wire at once */
+                TRY(begin_range(plan, t, &lay, f[1], work2, 0, 0, TAG_POT));
+                TRY(begin_range(plan, t, &lay, f[0], work, 0, 0, TAG_X));
+                TRY(t->xchg_wait(t->ctx, TAG_POT));
+            } else {
+                TRY(exchange(plan, t, f[0], work, chunk_bytes));
+                TRY(exchange(plan, t, f[1], work2, chunk_bytes));
+            }
+            if (strips) TRY(fpmhip_fft_y_backward_grad2(plan, work2, f[1], f[2], potmesh, kernel));
+            else TRY(fpmhip_fft_yz_backward_grad2(plan, work2, f[1], f[2], potmesh, kernel));
+            if (nr == 1) TRY(t->xchg_wait(t->ctx, TAG_X));
+            if (strips) TRY(fpmhip_fft_y_backward(plan, work, f[0]));
+            else TRY(fpmhip_fft_yz_backward(plan, work, f[0]));
+        }
         if (potmesh || strips) {
             for (int d = 0; d < 3; d++)
                 TRY(shift(plan, t, f[d], 0, 1, fpmhip_plane_ptr(plan, f[d], xl), -1, plane_bytes));
@@ -183,13 +287,13 @@ static int slab_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, 
             if (potmesh || !any_pot) return 0;
             /* strips, a potential column, and the caller's delta_k sits where the potential would have ridden along: the
              * potential takes the reference's own route below (transfer -> c2r -> readout of a real mesh) */
-            TRY(fpmhip_transfer(plan, delta_k, f[0], kernel, FPMHIP_FIELD_POTENTIAL));
-            TRY(fpmhip_fft_x_backward(plan, f[0]));
-            TRY(exchange(plan, t, f[0], work, chunk_bytes));
-            TRY(fpmhip_fft_yz_backward(plan, work, f[0]));
-            TRY(shift(plan, t, f[0], 0, 1, fpmhip_plane_ptr(plan, f[0], xl), -1, plane_bytes));
+            TRY(fpmhip_transfer(plan, delta_k, canvas, kernel, FPMHIP_FIELD_POTENTIAL));
+            TRY(fpmhip_fft_x_backward(plan, canvas));
+            TRY(exchange(plan, t, canvas, work, chunk_bytes));
+            TRY(fpmhip_fft_yz_backward(plan, work, canvas));
+            TRY(shift(plan, t, canvas, 0, 1, fpmhip_plane_ptr(plan, canvas, xl), -1, plane_bytes));
             for (int si = 0; si < nsets; si++)
-                if (sets[si].potential) TRY(fpmhip_readout1(plan, &sets[si], f[0], sets[si].potential, 1, 0));
+                if (sets[si].potential) TRY(fpmhip_readout1(plan, &sets[si], canvas, sets[si].potential, 1, 0));
             return 0;
         }
     } else {
@@ -197,12 +301,29 @@ static int slab_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, 
             TRY(fpmhip_fft_x_forward(plan, delta_k));
             TRY(fpmhip_softening(plan, delta_k, softening));
         }
-        for (int d = 0; d < 3; d++) {                           /* gravity.c:373-397 */
+        /* gravity.c:373-397, one transpose per component; non-blocking: component d + 1 is on the wire while the (y, z)
+         * passes of component d run (the landing zones alternate; a begin is ordered after the pass that last read its
+         * landing zone because it is ordered after everything on the plan's stream) */
+        void *land[3] = {work, work2, work};
+        for (int d = 0; d < 3; d++) {
             TRY(fpmhip_transfer(plan, delta_k, f[d], kernel, d));
             TRY(fpmhip_fft_x_backward(plan, f[d]));
+            if (nr >= 1) {
+                TRY(begin_range(plan, t, &lay, f[d], land[d], 0, 0, TAG_X + d));
+                if (d == 0) continue;
+                TRY(t->xchg_wait(t->ctx, TAG_X + d - 1));
+                if (strips) TRY(fpmhip_fft_y_backward(plan, land[d - 1], f[d - 1]));
+                else TRY(fpmhip_fft_yz_backward(plan, land[d - 1], f[d - 1]));
+                continue;
+            }
             TRY(exchange(plan, t, f[d], work, chunk_bytes));
             if (strips) TRY(fpmhip_fft_y_backward(plan, work, f[d]));
             else TRY(fpmhip_fft_yz_backward(plan, work, f[d]));
+        }
+        if (nr >= 1) {
+            TRY(t->xchg_wait(t->ctx, TAG_X + 2));
+            if (strips) TRY(fpmhip_fft_y_backward(plan, land[2], f[2]));
+            else TRY(fpmhip_fft_yz_backward(plan, land[2], f[2]));
         }
     }
     for (int d = 0; d < 3; d++)
@@ -210,13 +331,13 @@ static int slab_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, 
     TRY(check_force_meshes(plan, delta_k, f));
     TRY(readout_species_z(plan, sets, nsets, f[0], f[1], f[2], strips));
     if (any_pot) {                                              /* gravity.c:487-492 */
-        TRY(fpmhip_transfer(plan, delta_k, f[0], kernel, FPMHIP_FIELD_POTENTIAL));
-        TRY(fpmhip_fft_x_backward(plan, f[0]));
-        TRY(exchange(plan, t, f[0], work, chunk_bytes));
-        TRY(fpmhip_fft_yz_backward(plan, work, f[0]));
-        TRY(shift(plan, t, f[0], 0, 1, fpmhip_plane_ptr(plan, f[0], xl), -1, plane_bytes));
+        TRY(fpmhip_transfer(plan, delta_k, canvas, kernel, FPMHIP_FIELD_POTENTIAL));
+        TRY(fpmhip_fft_x_backward(plan, canvas));
+        TRY(exchange(plan, t, canvas, work, chunk_bytes));
+        TRY(fpmhip_fft_yz_backward(plan, work, canvas));
+        TRY(shift(plan, t, canvas, 0, 1, fpmhip_plane_ptr(plan, canvas, xl), -1, plane_bytes));
         for (int si = 0; si < nsets; si++)
-            if (sets[si].potential) TRY(fpmhip_readout1(plan, &sets[si], f[0], sets[si].potential, 1, 0));
+            if (sets[si].potential) TRY(fpmhip_readout1(plan, &sets[si], canvas, sets[si].potential, 1, 0));
     }
     (void) p;
     return 0;
@@ -240,6 +361,29 @@ static int exchange_axis(fpmhip_plan *plan, const fastpm_hip_transport *t, const
     if (!t->alltoall_members) return -1;
     TRY(fpmhip_sync(plan));
     return t->alltoall_members(t->ctx, send, recv, chunk_bytes, axis == 0 ? g->row : g->col, n, axis == 0 ? g->ry : g->rx);
+}
+
+/* the non-blocking form: the planes [x0, x0 + nx) of every chunk (nx == 0: whole chunks); a group of one copies on the
+ * plan's stream (ordered there: nothing to wait for) */
+static int begin_axis(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_layout *lay, const mesh_groups *g,
+                      int axis, const void *send, void *recv, int x0, int nx, int tag)
+{
+    const int n = axis == 0 ? g->Ny : g->Nx;
+    fastpm_hip_pieces pc;
+    TRY(pieces_of(plan, lay, axis == 0, x0, nx, &pc));
+    if (n == 1) {
+        for (int k = 0; k < pc.npieces; k++) {
+            const size_t o = pc.first_bytes + (size_t) k * pc.stride_bytes;
+            TRY(fpmhip_memcpy_d2d(plan, (char *) recv + o, (const char *) send + o, pc.piece_bytes));
+        }
+        return 0;
+    }
+    return t->xchg_begin(t->ctx, send, recv, &pc, axis == 0 ? g->row : g->col, n, axis == 0 ? g->ry : g->rx, tag);
+}
+
+static int wait_axis(const fastpm_hip_transport *t, const mesh_groups *g, int axis, int tag)
+{
+    return (axis == 0 ? g->Ny : g->Nx) == 1 ? 0 : t->xchg_wait(t->ctx, tag);
 }
 
 static int neighbour(const mesh_groups *g, int axis, int dir)
@@ -326,21 +470,57 @@ static int pencil_strip_force(fpmhip_plan *plan, const fastpm_hip_transport *t, 
     TRY(t->sendrecv(t->ctx, hys[0], neighbour(g, 0, +1), hyr[0], neighbour(g, 0, -1), hy_bytes));
     TRY(fpmhip_pen_halo_rows(plan, w[0], hyr[0], 1, 0));
     TRY(fpmhip_check_point(plan, w[0], "After painting"));                        /* gravity.c:350 */
-    TRY(exchange_axis(plan, t, g, 0, w[0], w[1], a_bytes));                       /* pm_r2c from its y pass on */
-    TRY(fpmhip_fft_y_forward(plan, w[1], w[0]));
-    TRY(exchange_axis(plan, t, g, 1, w[0], delta_k, b_bytes));
-    TRY(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 2, w[0], w[1], NULL));
-    TRY(exchange_axis(plan, t, g, 1, w[1], w[2], b_bytes));                       /* potential */
-    TRY(exchange_axis(plan, t, g, 1, w[0], w[3], b_bytes));                       /* x component */
-    void *potmesh = has_pot ? w[4] : NULL;                                        /* gravity.c:487-492 rides along */
-    TRY(fpmhip_fft_y_backward_grad2(plan, w[2], w[0], w[1], potmesh, kernel));
-    TRY(fpmhip_fft_y_backward(plan, w[3], w[2]));
-    /* (x, y, z [, potential]) in A layout: w[2], w[0], w[1] [, w[4]]; the received chunks are what the readout takes */
-    void *mesh[4] = {c, w[3], w[2], has_pot ? w[0] : NULL};
-    TRY(exchange_axis(plan, t, g, 0, w[2], c, a_bytes));
-    TRY(exchange_axis(plan, t, g, 0, w[0], w[3], a_bytes));
-    TRY(exchange_axis(plan, t, g, 0, w[1], w[2], a_bytes));
-    if (has_pot) TRY(exchange_axis(plan, t, g, 0, w[4], w[0], a_bytes));
+    void *mesh[4];                                  /* (x, y, z [, potential]) as the (y <-> kz) exchange delivers them */
+    const int nr = plane_ranges(plan, t, xl);
+    if (nr >= 1) {
+        /* pm_r2c from its y pass on (pmpfft.c:377-379), both of PFFT's transposes NON-BLOCKING.  Forwards in plane ranges:
+         * every range of exchange A is begun at once (the paint is one kernel); range i goes through its y pass and into
+         * exchange B while the later ranges of A are still on the wire. */
+        const int rx = nr > 1 ? (int) (xl / nr) : 0;
+        for (int i = 0; i < nr; i++) TRY(begin_axis(plan, t, lay, g, 0, w[0], w[1], i * rx, rx, TAG_A + i));
+        for (int i = 0; i < nr; i++) {
+            TRY(wait_axis(t, g, 0, TAG_A + i));
+            if (nr > 1) TRY(fpmhip_fft_y_forward_range(plan, w[1], w[2], i * rx, rx));
+            else TRY(fpmhip_fft_y_forward(plan, w[1], w[2]));
+            TRY(begin_axis(plan, t, lay, g, 1, w[2], delta_k, i * rx, rx, TAG_FWD + i));
+        }
+        for (int i = 0; i < nr; i++) TRY(wait_axis(t, g, 1, TAG_FWD + i));
+        TRY(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 2, w[0], w[1], NULL));
+        /* backwards (pmpfft.c:394-396) by COMPONENT: the potential's y pass (which makes the y and z components) runs
+         * while the x component is in exchange B, the x component's y pass while y and z are in exchange A.  A pass never
+         * writes where an exchange still reads or lands: see the buffer of every begin below. */
+        TRY(begin_axis(plan, t, lay, g, 1, w[1], w[2], 0, 0, TAG_POT));             /* potential */
+        TRY(begin_axis(plan, t, lay, g, 1, w[0], w[3], 0, 0, TAG_X));               /* x component */
+        TRY(wait_axis(t, g, 1, TAG_POT));                                           /* w[1] is free again */
+        TRY(fpmhip_fft_y_backward_grad2(plan, w[2], c, w[4], has_pot ? w[1] : NULL, kernel));   /* gravity.c:487-492 rides along */
+        TRY(begin_axis(plan, t, lay, g, 0, c, w[2], 0, 0, TAG_Y));
+        TRY(wait_axis(t, g, 1, TAG_X));                                             /* w[0] is free again */
+        TRY(begin_axis(plan, t, lay, g, 0, w[4], w[0], 0, 0, TAG_Z));
+        TRY(wait_axis(t, g, 0, TAG_Y));                                             /* c is free again */
+        TRY(fpmhip_fft_y_backward(plan, w[3], c));
+        TRY(begin_axis(plan, t, lay, g, 0, c, w[3], 0, 0, TAG_XA));
+        TRY(wait_axis(t, g, 0, TAG_Z));                                             /* w[4] is free again */
+        if (has_pot) TRY(begin_axis(plan, t, lay, g, 0, w[1], w[4], 0, 0, TAG_PA));
+        TRY(wait_axis(t, g, 0, TAG_XA));
+        if (has_pot) TRY(wait_axis(t, g, 0, TAG_PA));
+        mesh[0] = w[3]; mesh[1] = w[2]; mesh[2] = w[0]; mesh[3] = has_pot ? w[4] : NULL;
+    } else {
+        TRY(exchange_axis(plan, t, g, 0, w[0], w[1], a_bytes));                   /* pm_r2c from its y pass on */
+        TRY(fpmhip_fft_y_forward(plan, w[1], w[0]));
+        TRY(exchange_axis(plan, t, g, 1, w[0], delta_k, b_bytes));
+        TRY(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 2, w[0], w[1], NULL));
+        TRY(exchange_axis(plan, t, g, 1, w[1], w[2], b_bytes));                   /* potential */
+        TRY(exchange_axis(plan, t, g, 1, w[0], w[3], b_bytes));                   /* x component */
+        void *potmesh = has_pot ? w[4] : NULL;                                    /* gravity.c:487-492 rides along */
+        TRY(fpmhip_fft_y_backward_grad2(plan, w[2], w[0], w[1], potmesh, kernel));
+        TRY(fpmhip_fft_y_backward(plan, w[3], w[2]));
+        /* (x, y, z [, potential]) in A layout: w[2], w[0], w[1] [, w[4]]; the received chunks are what the readout takes */
+        mesh[0] = c; mesh[1] = w[3]; mesh[2] = w[2]; mesh[3] = has_pot ? w[0] : NULL;
+        TRY(exchange_axis(plan, t, g, 0, w[2], c, a_bytes));
+        TRY(exchange_axis(plan, t, g, 0, w[0], w[3], a_bytes));
+        TRY(exchange_axis(plan, t, g, 0, w[1], w[2], a_bytes));
+        if (has_pot) TRY(exchange_axis(plan, t, g, 0, w[4], w[0], a_bytes));
+    }
     /* the neighbours' rows: y first, then the x plane with the fresh corner row */
     for (int m = 0; m < nm; m++) {
         TRY(fpmhip_pen_halo_rows(plan, mesh[m], hys[m], 1, 1));
@@ -460,6 +640,7 @@ int fastpm_hip_mesh_force_species(fpmhip_plan *plan, const fastpm_hip_transport 
     fpmhip_layout lay;
     TRY(fpmhip_plan_layout(plan, &lay));
     if (lay.nranks != t->nranks || lay.rank != t->rank) return -1;
+    if (t->bind_plan) TRY(t->bind_plan(t->ctx, plan));          /* the stream the non-blocking exchanges are ordered on */
     int rc = lay.nranks_y > 1 ? pencil_force_species(plan, t, &lay, sets, nsets, kernel, softening, delta_k)
                               : slab_force_species(plan, t, sets, nsets, kernel, softening, delta_k);
     if (lay.nranks > 1) {
@@ -677,6 +858,45 @@ static int loop_sendrecv(void *c_, const void *send, int dest, void *recv, int s
     return rc;
 }
 
+/* xchg_begin: the copies are made inside the call (wait for what my stream has produced, publish, barrier, copy the
+ * pieces I receive out of the others' send buffers on my stream, wait, barrier); xchg_wait has nothing left to do.
+ * The SEQUENCE of begins and waits -- which buffer a pass may write while which ranges are in flight -- is what this
+ * exercises; the overlap itself needs a transport with a stream of its own (fastpm_slab_rccl.c). */
+static int loop_xchg_begin(void *c_, const void *send, void *recv, const fastpm_hip_pieces *pc, const int *members, int n,
+                           int me, int tag)
+{
+    loop_ctx *c = c_;
+    loop_shared *s = c->sh;
+    (void) tag;
+    int rc = fpmhip_sync(s->plan[c->rank]);
+    s->send[c->rank] = send;
+    pthread_barrier_wait(&s->barrier);
+    for (int j = 0; j < n && rc == 0; j++) {
+        const int src = members ? members[j] : j;
+        for (int k = 0; k < pc->npieces && rc == 0; k++) {
+            const size_t o = pc->first_bytes + (size_t) k * pc->stride_bytes;
+            rc = fpmhip_memcpy_d2d(s->plan[c->rank], (char *) recv + (size_t) j * pc->chunk_bytes + o,
+                                   (const char *) s->send[src] + (size_t) me * pc->chunk_bytes + o, pc->piece_bytes);
+        }
+    }
+    if (rc == 0) rc = fpmhip_sync(s->plan[c->rank]);
+    pthread_barrier_wait(&s->barrier);
+    return rc;
+}
+
+static int loop_xchg_wait(void *c_, int tag)
+{
+    (void) c_; (void) tag;
+    return 0;
+}
+
+static int loop_bind_plan(void *c_, fpmhip_plan *plan)
+{
+    loop_ctx *c = c_;
+    c->sh->plan[c->rank] = plan;
+    return 0;
+}
+
 fastpm_hip_transport *fastpm_hip_loopback_create(int nranks)
 {
     loop_shared *s = calloc(1, sizeof(*s));
@@ -698,6 +918,9 @@ fastpm_hip_transport *fastpm_hip_loopback_create(int nranks)
         t[r].alltoall = loop_alltoall;
         t[r].alltoall_members = loop_alltoall_members;
         t[r].sendrecv = loop_sendrecv;
+        t[r].xchg_begin = loop_xchg_begin;
+        t[r].xchg_wait = loop_xchg_wait;
+        t[r].bind_plan = loop_bind_plan;
     }
     return t;
 }

@@ -19,6 +19,7 @@ extern "C" {
 /* Blocking, MPI-like semantics: fastpm_hip_slab_force synchronises the plan's stream before each call, and
  * on return the receive buffer must be complete (or ordered before later work on the plan's stream).
  * Every function returns 0 on success. */
+struct fastpm_hip_pieces;
 typedef struct {
     void *ctx;
     int rank, nranks;
@@ -41,7 +42,35 @@ typedef struct {
      * rank r; recv_rows[r] rows arrive from rank r, stored back to back in rank order   store.c:611-621 */
     int (*alltoallv)(void *ctx, const void *send_dev, const int64_t *send_rows, void *recv_dev,
                      const int64_t *recv_rows, int rowbytes);
+    /* -- round 5: NON-BLOCKING exchanges of pieces, what the pipelined sequence is made of (PFFT overlaps nothing,
+     *    pmpfft.c:377-396; here the exchange of plane range i is on the wire while the plan's stream transforms range
+     *    i + 1).  A transport that leaves them NULL gets the blocking whole-mesh sequence. --
+     * xchg_begin: for every member j of the group (members == NULL: all ranks, nmembers = nranks, me = rank) the pieces
+     *   [first_bytes + k * stride_bytes, + piece_bytes), k < npieces, of chunk j of send go to members[j], and the same
+     *   pieces of chunk j of recv arrive from it -- a whole all-to-all is one piece of chunk_bytes.  Ordered AFTER
+     *   everything enqueued so far on the bound plan's stream; returns without waiting for the exchange.  `tag`
+     *   (0 <= tag < FASTPM_HIP_MAX_TAGS) names it; at most one exchange per tag is in flight.  Exchanges begun on a
+     *   transport start on the wire in the order they were begun.
+     * xchg_wait(tag): on return every LATER operation on the bound plan's stream is ordered after the exchange -- its
+     *   receives AND its sends (the send buffer may be overwritten).  Waits are issued in the order of the begins.
+     * bind_plan: the plan whose stream orders the exchanges (called by fastpm_hip_mesh_force_species on entry). */
+    int (*xchg_begin)(void *ctx, const void *send_dev, void *recv_dev, const struct fastpm_hip_pieces *pieces,
+                      const int *members, int nmembers, int me, int tag);
+    int (*xchg_wait)(void *ctx, int tag);
+    int (*bind_plan)(void *ctx, fpmhip_plan *plan);
+    /* plane ranges per transpose (SlabForce(chunks = ...) in the Python mirror): 0 = the default (FASTPM_HIP_CHUNKS in
+     * the environment, else 4), 1 = whole-mesh exchanges (still non-blocking where two meshes travel) */
+    int chunks;
 } fastpm_hip_transport;
+
+#define FASTPM_HIP_MAX_TAGS 64
+typedef struct fastpm_hip_pieces {
+    size_t chunk_bytes;     /* distance between the members' chunks, in send and in recv */
+    size_t first_bytes;     /* first piece, from the start of a chunk */
+    size_t piece_bytes;     /* contiguous bytes per piece */
+    size_t stride_bytes;    /* piece to piece */
+    int npieces;
+} fastpm_hip_pieces;
 
 /* One column of the store on the device: rows of rowbytes (4, 8, 12, 16, 24 or 36) bytes. */
 typedef struct {

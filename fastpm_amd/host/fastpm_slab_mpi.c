@@ -9,6 +9,17 @@
 
 #include "fastpm_slab_mpi.h"
 
+/* one non-blocking exchange in flight (xchg_begin ... xchg_wait) */
+typedef struct {
+    int active, n, nreq, nmsg;
+    MPI_Request *req;
+    MPI_Datatype type;
+    char *hsend, *hrecv;          /* host staging of this tag (gpu_aware == 0), grown on demand */
+    size_t hbytes;
+    void *recv_dev;
+    fastpm_hip_pieces pc;
+} mpi_pending;
+
 typedef struct {
     MPI_Comm comm;
     fpmhip_plan *plan;
@@ -16,6 +27,7 @@ typedef struct {
     int nranks;
     void *hsend, *hrecv;          /* host staging (gpu_aware == 0), grown on demand */
     size_t hbytes;
+    mpi_pending pend[FASTPM_HIP_MAX_TAGS];
 } mpi_ctx;
 
 static int stage_reserve(mpi_ctx *c, size_t bytes)
@@ -116,6 +128,84 @@ static int mpi_sendrecv(void *ctx, const void *send_dev, int dest, void *recv_de
     return rc == MPI_SUCCESS ? 0 : -1;
 }
 
+/* The non-blocking exchanges of the pipelined sequence (fastpm_slab_hip.h) as MPI_Isend / MPI_Irecv, one message per
+ * member (host staging: a member's pieces packed back to back) or per piece (device pointers handed to a GPU-aware MPI).
+ * begin waits for the plan's stream (MPI knows no streams), posts and returns: the messages are in flight while the
+ * caller enqueues the next range's passes; wait completes them and, staged, copies the pieces to the device. */
+static int mpi_xchg_begin(void *ctx, const void *send_dev, void *recv_dev, const fastpm_hip_pieces *pc, const int *members,
+                          int n, int me, int tag)
+{
+    mpi_ctx *c = ctx;
+    (void) me;
+    if (tag < 0 || tag >= FASTPM_HIP_MAX_TAGS || c->pend[tag].active) return -1;
+    mpi_pending *q = &c->pend[tag];
+    const size_t per = (size_t) pc->npieces * pc->piece_bytes;        /* bytes per member */
+    int count;
+    if (split_count(c->gpu_aware ? pc->piece_bytes : per, &q->type, &count)) return -1;
+    const int nmsg = c->gpu_aware ? n * pc->npieces : n;
+    q->req = malloc((size_t) 2 * nmsg * (sizeof(MPI_Request) + sizeof(MPI_Status)));
+    q->nmsg = 2 * nmsg;
+    q->nreq = 0; q->n = n; q->pc = *pc; q->recv_dev = recv_dev;
+    int rc = q->req ? MPI_SUCCESS : MPI_ERR_OTHER;
+    if (rc == MPI_SUCCESS && fpmhip_sync(c->plan)) rc = MPI_ERR_OTHER;
+    if (rc == MPI_SUCCESS && !c->gpu_aware) {
+        if (q->hbytes < per * (size_t) n) {
+            free(q->hsend); free(q->hrecv);
+            q->hsend = malloc(per * (size_t) n); q->hrecv = malloc(per * (size_t) n);
+            q->hbytes = q->hsend && q->hrecv ? per * (size_t) n : 0;
+            if (!q->hbytes) rc = MPI_ERR_OTHER;
+        }
+        for (int j = 0; j < n && rc == MPI_SUCCESS; j++)
+            for (int k = 0; k < pc->npieces && rc == MPI_SUCCESS; k++)
+                if (fpmhip_memcpy_d2h(c->plan, q->hsend + (size_t) j * per + (size_t) k * pc->piece_bytes,
+                                      (const char *) send_dev + (size_t) j * pc->chunk_bytes + pc->first_bytes
+                                          + (size_t) k * pc->stride_bytes, pc->piece_bytes)) rc = MPI_ERR_OTHER;
+    }
+    for (int j = 0; j < n && rc == MPI_SUCCESS; j++) {
+        const int peer = members ? members[j] : j;
+        if (!c->gpu_aware) {
+            rc = MPI_Irecv(q->hrecv + (size_t) j * per, count, q->type, peer, 100 + tag, c->comm, &q->req[q->nreq++]);
+            if (rc == MPI_SUCCESS) rc = MPI_Isend(q->hsend + (size_t) j * per, count, q->type, peer, 100 + tag, c->comm, &q->req[q->nreq++]);
+            continue;
+        }
+        for (int k = 0; k < pc->npieces && rc == MPI_SUCCESS; k++) {
+            const size_t o = (size_t) j * pc->chunk_bytes + pc->first_bytes + (size_t) k * pc->stride_bytes;
+            rc = MPI_Irecv((char *) recv_dev + o, count, q->type, peer, 100 + tag, c->comm, &q->req[q->nreq++]);
+            if (rc == MPI_SUCCESS) rc = MPI_Isend((char *) send_dev + o, count, q->type, peer, 100 + tag, c->comm, &q->req[q->nreq++]);
+        }
+    }
+    q->active = 1;                  /* even after a failure: wait frees what was posted */
+    return rc == MPI_SUCCESS ? 0 : -1;
+}
+
+static int mpi_xchg_wait(void *ctx, int tag)
+{
+    mpi_ctx *c = ctx;
+    if (tag < 0 || tag >= FASTPM_HIP_MAX_TAGS || !c->pend[tag].active) return -1;
+    mpi_pending *q = &c->pend[tag];
+    int rc = q->nreq ? MPI_Waitall(q->nreq, q->req, (MPI_Status *) (q->req + q->nmsg)) : MPI_SUCCESS;
+    if (rc == MPI_SUCCESS && !c->gpu_aware) {
+        const size_t per = (size_t) q->pc.npieces * q->pc.piece_bytes;
+        for (int j = 0; j < q->n && rc == MPI_SUCCESS; j++)
+            for (int k = 0; k < q->pc.npieces && rc == MPI_SUCCESS; k++)
+                if (fpmhip_memcpy_h2d(c->plan, (char *) q->recv_dev + (size_t) j * q->pc.chunk_bytes + q->pc.first_bytes
+                                                   + (size_t) k * q->pc.stride_bytes,
+                                      q->hrecv + (size_t) j * per + (size_t) k * q->pc.piece_bytes, q->pc.piece_bytes))
+                    rc = MPI_ERR_OTHER;
+    }
+    MPI_Type_free(&q->type);
+    free(q->req);
+    q->req = NULL;
+    q->active = 0;
+    return rc == MPI_SUCCESS ? 0 : -1;
+}
+
+static int mpi_bind_plan(void *ctx, fpmhip_plan *plan)
+{
+    ((mpi_ctx *) ctx)->plan = plan;
+    return 0;
+}
+
 static int mpi_alltoall_counts(void *ctx, const int64_t *send, int64_t *recv)
 {
     mpi_ctx *c = ctx;
@@ -172,6 +262,9 @@ fastpm_hip_transport *fastpm_hip_mpi_transport_create(MPI_Comm comm, fpmhip_plan
     t->sendrecv = mpi_sendrecv;
     t->alltoall_counts = mpi_alltoall_counts;
     t->alltoallv = mpi_alltoallv;
+    t->xchg_begin = mpi_xchg_begin;
+    t->xchg_wait = mpi_xchg_wait;
+    t->bind_plan = mpi_bind_plan;
     return t;
 }
 
@@ -181,6 +274,7 @@ void fastpm_hip_mpi_transport_destroy(fastpm_hip_transport *t)
     mpi_ctx *c = t->ctx;
     free(c->hsend);
     free(c->hrecv);
+    for (int i = 0; i < FASTPM_HIP_MAX_TAGS; i++) { free(c->pend[i].hsend); free(c->pend[i].hrecv); }
     free(c);
     free(t);
 }

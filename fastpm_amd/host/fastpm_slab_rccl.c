@@ -6,8 +6,8 @@
  * libfastpm is an MPI program and has the communicator.  One rank per GPU -- RCCL refuses two ranks on one device,
  * so on a one-GPU box this transport runs with one rank (tests/test_gpu_chost.py), where every send is to self.
  *
- * Blocking semantics, as the transport contract asks: every call ends with a synchronisation of the transport's
- * own stream.
+ * The blocking calls end with a synchronisation of the transport's own stream, as the contract asks; the non-blocking
+ * pair xchg_begin / xchg_wait (round 5) is ordered against the bound plan's stream with events and never waits on the host.
  */
 #define __HIP_PLATFORM_AMD__
 #include <hip/hip_runtime_api.h>
@@ -19,9 +19,13 @@
 typedef struct {
     MPI_Comm mpi;
     ncclComm_t comm;
-    hipStream_t stream;
+    hipStream_t stream;             /* the transport's own, NON-BLOCKING w.r.t. the null stream: exchanges overlap kernels */
     double *dscalar;
     int nranks;
+    fpmhip_plan *plan;              /* bound by fastpm_hip_mesh_force_species: its stream orders the non-blocking exchanges */
+    hipEvent_t ready;               /* the plan's stream has produced what an exchange sends */
+    hipEvent_t done[FASTPM_HIP_MAX_TAGS];       /* exchange `tag` has run on the transport's stream */
+    unsigned char have[FASTPM_HIP_MAX_TAGS], active[FASTPM_HIP_MAX_TAGS];
 } rccl_ctx;
 
 #define OK_HIP(e) ((e) == hipSuccess)
@@ -77,6 +81,55 @@ static int rccl_sendrecv(void *ctx, const void *send, int dest, void *recv, int 
     return finish(c, ok);
 }
 
+/* The non-blocking exchanges of the pipelined sequence (fastpm_slab_hip.h): no host wait anywhere --
+ *   begin: event on the plan's stream -> the transport's stream waits for it -> ONE group of ncclSend / ncclRecv for every
+ *          piece of every member -> event `done[tag]` on the transport's stream;
+ *   wait : the plan's stream waits for `done[tag]`.
+ * xGMI is point to point: a group of P - 1 sends and receives keeps every link of this GPU busy at once, and the groups
+ * of successive plane ranges run back to back on the transport's stream while the plan's stream transforms. */
+static int rccl_xchg_begin(void *ctx, const void *send, void *recv, const fastpm_hip_pieces *pc, const int *members, int n,
+                           int me, int tag)
+{
+    rccl_ctx *c = ctx;
+    (void) me;
+    if (tag < 0 || tag >= FASTPM_HIP_MAX_TAGS || c->active[tag]) return -1;
+    hipStream_t ps = c->plan ? (hipStream_t) fpmhip_plan_stream(c->plan) : NULL;
+    int ok = 1;
+    if (!c->have[tag]) {
+        ok = OK_HIP(hipEventCreateWithFlags(&c->done[tag], hipEventDisableTiming));
+        c->have[tag] = (unsigned char) ok;
+    }
+    ok = ok && OK_HIP(hipEventRecord(c->ready, ps)) && OK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
+    ok = ok && OK_NCCL(ncclGroupStart());
+    for (int j = 0; j < n && ok; j++) {
+        const int peer = members ? members[j] : j;
+        for (int k = 0; k < pc->npieces && ok; k++) {
+            const size_t o = (size_t) j * pc->chunk_bytes + pc->first_bytes + (size_t) k * pc->stride_bytes;
+            ok = OK_NCCL(ncclSend((const char *) send + o, pc->piece_bytes, ncclInt8, peer, c->comm, c->stream))
+                 && OK_NCCL(ncclRecv((char *) recv + o, pc->piece_bytes, ncclInt8, peer, c->comm, c->stream));
+        }
+    }
+    ok = OK_NCCL(ncclGroupEnd()) && ok;
+    ok = ok && OK_HIP(hipEventRecord(c->done[tag], c->stream));
+    c->active[tag] = (unsigned char) ok;
+    return ok ? 0 : -1;
+}
+
+static int rccl_xchg_wait(void *ctx, int tag)
+{
+    rccl_ctx *c = ctx;
+    if (tag < 0 || tag >= FASTPM_HIP_MAX_TAGS || !c->active[tag]) return -1;
+    c->active[tag] = 0;
+    hipStream_t ps = c->plan ? (hipStream_t) fpmhip_plan_stream(c->plan) : NULL;
+    return OK_HIP(hipStreamWaitEvent(ps, c->done[tag], 0)) ? 0 : -1;
+}
+
+static int rccl_bind_plan(void *ctx, fpmhip_plan *plan)
+{
+    ((rccl_ctx *) ctx)->plan = plan;
+    return 0;
+}
+
 static int rccl_alltoall_counts(void *ctx, const int64_t *send, int64_t *recv)
 {
     rccl_ctx *c = ctx;
@@ -114,7 +167,8 @@ fastpm_hip_transport *fastpm_hip_rccl_transport_create(MPI_Comm comm, int device
     if (t->rank == 0) ok = ok && OK_NCCL(ncclGetUniqueId(&id));
     MPI_Bcast(&id, (int) sizeof(id), MPI_BYTE, 0, comm);
     ok = ok && OK_NCCL(ncclCommInitRank(&c->comm, c->nranks, id, t->rank));
-    ok = ok && OK_HIP(hipStreamCreate(&c->stream));
+    ok = ok && OK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    ok = ok && OK_HIP(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
     ok = ok && OK_HIP(hipMalloc((void **) &c->dscalar, sizeof(double)));
     if (!ok) { free(t); free(c); return NULL; }
     t->ctx = c;
@@ -124,6 +178,9 @@ fastpm_hip_transport *fastpm_hip_rccl_transport_create(MPI_Comm comm, int device
     t->sendrecv = rccl_sendrecv;
     t->alltoall_counts = rccl_alltoall_counts;
     t->alltoallv = rccl_alltoallv;
+    t->xchg_begin = rccl_xchg_begin;
+    t->xchg_wait = rccl_xchg_wait;
+    t->bind_plan = rccl_bind_plan;
     return t;
 }
 
@@ -132,6 +189,8 @@ void fastpm_hip_rccl_transport_destroy(fastpm_hip_transport *t)
     if (!t) return;
     rccl_ctx *c = t->ctx;
     (void) hipStreamSynchronize(c->stream);
+    for (int i = 0; i < FASTPM_HIP_MAX_TAGS; i++) if (c->have[i]) (void) hipEventDestroy(c->done[i]);
+    (void) hipEventDestroy(c->ready);
     (void) hipFree(c->dscalar);
     (void) ncclCommDestroy(c->comm);
     (void) hipStreamDestroy(c->stream);

@@ -83,11 +83,12 @@ plan_for(PM * pm)
      * modulo the GPUs the process sees (a launcher that masks one GPU per rank leaves one device: index 0). */
     int ndev = fpmhip_device_count();
     if(ndev < 1) fastpm_raise(-1, "no HIP device: the MI355X force step cannot run (there is no CPU fallback)\n");
-    int local_rank = 0;
+    int local_rank = 0, node_size = 1;
     if(pm->NTask > 1) {
         MPI_Comm node;
         MPI_Comm_split_type(pm->Comm2D, MPI_COMM_TYPE_SHARED, rank2d, MPI_INFO_NULL, &node);
         MPI_Comm_rank(node, &local_rank);
+        MPI_Comm_size(node, &node_size);
         MPI_Comm_free(&node);
     }
     g.device = local_rank % ndev;
@@ -119,16 +120,22 @@ plan_for(PM * pm)
         }
     }
     if(pm->NTask > 1) {
-        /* the three exchanges of the force step as MPI calls on pm->Comm2D; FASTPM_HIP_GPU_AWARE_MPI=1 hands device
-         * pointers to MPI, =2 selects RCCL over xGMI (one rank per GPU), otherwise staged through the host */
+        /* The exchanges of the force step on pm->Comm2D.  DEFAULT: RCCL over xGMI -- grouped ncclSend / ncclRecv on a stream
+         * of the transport's own, the transposes cut into plane ranges that overlap the (y, z) passes (fastpm_slab_hip.c) --
+         * whenever every rank of every node has a GPU to itself (RCCL refuses two ranks on one device).  Otherwise MPI
+         * staged through the host.  FASTPM_HIP_GPU_AWARE_MPI overrides: 2 = RCCL, 1 = device pointers handed to a GPU-aware
+         * MPI, 0 = MPI staged through the host.  Every rank must take the same branch: the choice is agreed on. */
         const char * e = getenv("FASTPM_HIP_GPU_AWARE_MPI");
-        int mode = e ? atoi(e) : 0;
+        int mode = e ? atoi(e) : (ndev >= node_size ? 2 : 0);
+        MPI_Allreduce(MPI_IN_PLACE, &mode, 1, MPI_INT, e ? MPI_MAX : MPI_MIN, pm->Comm2D);
         if(mode == 2) {
             c->transport = fastpm_hip_rccl_transport_create(pm->Comm2D, g.device);      /* the plan's device */
         } else {
             c->transport = fastpm_hip_mpi_transport_create(pm->Comm2D, c->plan, mode);
         }
         if(!c->transport) fastpm_raise(-1, "no transport for the MI355X force step\n");
+        fastpm_info("MI355X force step: %d ranks, %s transport, %d GPU(s) per node for %d rank(s)\n", pm->NTask,
+                mode == 2 ? "RCCL (xGMI)" : mode == 1 ? "GPU-aware MPI" : "host-staged MPI", ndev, node_size);
     }
     c->pm = pm;
     c->next = plans;
@@ -247,15 +254,21 @@ fastpm_solver_compute_force(FastPMSolver * fastpm,
 
     PlanCache * c = plan_for(pm);
     fpmhip_set_stage_hook(c->plan, stage_clock, clk);
+    /* pm_check_values at gravity.c:350, 352, 381, 383.  FASTPM_HIP_CHECK_VALUES=1: at every call (each of the five check
+     * points is a sweep of a mesh and a stream synchronisation); =0: never; unset (the default): the reference's diagnostics
+     * without their cost -- the acc summary of the log lines below says whether anything went wrong (a NaN or an overflow
+     * in any mesh reaches every particle through the transforms), and only then the step runs again with the checks on. */
+    int check = -1;
     {
-        /* gravity.c:350, 352, 381, 383.  Off unless FASTPM_HIP_CHECK_VALUES=1: each of the five check points is a sweep of
-         * the mesh and a stream synchronisation that the timed force step does not have (the reference pays nine serial
-         * host loops per step for them) */
         const char * e = getenv("FASTPM_HIP_CHECK_VALUES");
-        if(e && atoi(e) != 0) fpmhip_set_check_hook(c->plan, check_line, pm);
+        if(e) check = atoi(e) != 0;
     }
     const int resident = fastpm_hip_resident_enabled();
-    int rc;
+    int rc, attempt;
+    double acc_std[FASTPM_SOLVER_NSPECIES][3], acc_mean[FASTPM_SOLVER_NSPECIES][3], acc_min[FASTPM_SOLVER_NSPECIES][3],
+           acc_max[FASTPM_SOLVER_NSPECIES][3];
+    for(attempt = 0; attempt < 2; attempt ++) {
+    if(check > 0 || attempt > 0) fpmhip_set_check_hook(c->plan, check_line, pm);
     if(resident) {
         /* every column has a device twin (fastpm_resident_hip.h): x goes up once, acc stays where the kick reads it;
          * the potential column comes home (an output column); delta_k stays on the device for the de-CIC and the P(k)
@@ -301,15 +314,12 @@ fastpm_solver_compute_force(FastPMSolver * fastpm,
         fastpm_raise(-1, "MI355X force step failed (%d): %s\n", rc, rc == -9 ? fastpm_hip_mirror_error() : fpmhip_last_error());
     }
 
-    /* The log lines of gravity.c:398-417, from the acc columns the step just filled.  The reference prints three blocks
-     * per species before it adds the ghosts' contributions: the local particles, the ghosts, and the local particles
-     * again (nothing changed them in between -- pm_ghosts_reduce comes after).  Here the mesh halo has already carried
-     * what the ghosts would bring back, so "p%s" and "p%s+g" print the FINAL accelerations and there is no ghost store
-     * to summarise: that block is left out. */
+    /* The numbers of the log lines of gravity.c:398-417, from the acc columns the step just filled (collective: every
+     * rank sees the same ones, so every rank takes the same decision about a second, checked run below) */
+    int bad = 0;
     for(si = 0; si < FASTPM_SOLVER_NSPECIES; si ++) {
         FastPMStore * p = fastpm_solver_get_species(fastpm, si);
         if(!p) continue;
-        double acc_std[3], acc_mean[3], acc_min[3], acc_max[3];
         int d;
         if(resident) {
             /* fastpm_store_summary (store.c:807-908) with its particle loop on the device twin of acc */
@@ -322,23 +332,39 @@ fastpm_solver_compute_force(FastPMSolver * fastpm,
             MPI_Allreduce(MPI_IN_PLACE, rsum2, 3, MPI_DOUBLE, MPI_SUM, pm_comm(pm));
             MPI_Allreduce(MPI_IN_PLACE, rmin, 3, MPI_DOUBLE, MPI_MIN, pm_comm(pm));
             MPI_Allreduce(MPI_IN_PLACE, rmax, 3, MPI_DOUBLE, MPI_MAX, pm_comm(pm));
-            MPI_Allreduce(MPI_IN_PLACE, &Ntot, 1, MPI_LONG, MPI_SUM, pm_comm(pm));
+            MPI_Allreduce(MPI_IN_PLACE, &Ntot, 1, MPI_UINT64_T, MPI_SUM, pm_comm(pm));
             for(d = 0; d < 3; d ++) {
-                acc_min[d] = rmin[d];
-                acc_max[d] = rmax[d];
-                acc_mean[d] = rsum1[d] / Ntot;
-                acc_std[d] = sqrt(rsum2[d] / Ntot - pow(rsum1[d] / Ntot, 2));
+                acc_min[si][d] = rmin[d];
+                acc_max[si][d] = rmax[d];
+                acc_mean[si][d] = rsum1[d] / Ntot;
+                acc_std[si][d] = sqrt(rsum2[d] / Ntot - pow(rsum1[d] / Ntot, 2));
             }
         } else {
-            fastpm_store_summary(p, COLUMN_ACC, pm_comm(pm), "<s->", acc_min, acc_std, acc_mean, acc_max);
+            fastpm_store_summary(p, COLUMN_ACC, pm_comm(pm), "<s->", acc_min[si], acc_std[si], acc_mean[si], acc_max[si]);
         }
         for(d = 0; d < 3; d ++) {
+            bad |= !(isfinite(acc_mean[si][d]) && isfinite(acc_std[si][d]) && fabs(acc_min[si][d]) <= 1e15
+                     && fabs(acc_max[si][d]) <= 1e15);
+        }
+    }
+    if(!(bad && check < 0)) break;
+    }   /* a second, checked run of the step: the "out of bounds" lines of pmapi.c:335-356 say where it went wrong */
+
+    /* The log lines of gravity.c:398-417.  The reference prints three blocks per species before it adds the ghosts'
+     * contributions: the local particles, the ghosts, and the local particles again (nothing changed them in between --
+     * pm_ghosts_reduce comes after).  Here the mesh halo has already carried what the ghosts would bring back, so "p%s"
+     * and "p%s+g" print the FINAL accelerations and there is no ghost store to summarise: that block is left out. */
+    for(si = 0; si < FASTPM_SOLVER_NSPECIES; si ++) {
+        FastPMStore * p = fastpm_solver_get_species(fastpm, si);
+        int d;
+        if(!p) continue;
+        for(d = 0; d < 3; d ++) {
             fastpm_info("p%s    acc[%d]: %g %g %g %g\n",
-                p->name, d, acc_min[d], acc_std[d], acc_mean[d], acc_max[d]);
+                p->name, d, acc_min[si][d], acc_std[si][d], acc_mean[si][d], acc_max[si][d]);
         }
         for(d = 0; d < 3; d ++) {
             fastpm_info("p%s+g  acc[%d]: %g %g %g %g\n",
-                p->name, d, acc_min[d], acc_std[d], acc_mean[d], acc_max[d]);
+                p->name, d, acc_min[si][d], acc_std[si][d], acc_mean[si][d], acc_max[si][d]);
         }
     }
 }

@@ -69,73 +69,54 @@ fastpm_store_decompose(FastPMStore * p, fastpm_store_target_func target_func, vo
 }
 
 /* fastpm_store_summary (store.c:807-908), which the FORCE/AFTER handler calls on the acc column every step
- * (src/fastpm.c:1718: "Force dispersion") and the drift / kick reports on x and v: the particle loop runs on the device
- * twin when that is the newer copy of a float column; otherwise on the host copy (brought home first if need be). */
-void
-fastpm_store_summary(FastPMStore * p,
-        FastPMColumnTags attribute,
-        MPI_Comm comm,
-        const char * fmt,
-        ...)
-{
-    va_list va;
-    va_start(va, fmt);
+ * (src/fastpm.c:1718: "Force dispersion") and the drift / kick reports on x and v.  Only ONE case is new here: a float
+ * column whose device twin is the newer copy -- its particle loop runs on the device (fpmhip_store_summary) and the five
+ * all-reduces follow.  Everything else is the reference's own function (store.o's definition, renamed by the -D flag
+ * above), called once per format letter because a variadic function cannot be forwarded. */
+void fastpm_store_summary_cpu(FastPMStore * p, FastPMColumnTags attribute, MPI_Comm comm, const char * fmt, ...);
 
-    int ci = fastpm_store_find_column_id(p, attribute);
-    size_t nmemb = p->_column_info[ci].nmemb;
-    double rmin[nmemb], rmax[nmemb], rsum1[nmemb], rsum2[nmemb];
-    size_t d;
-    ptrdiff_t i;
-    for(d = 0; d < nmemb; d ++) {
-        rmin[d] = 1e20;
-        rmax[d] = -1e20;
-        rsum1[d] = 0;
-        rsum2[d] = 0;
-    }
+void
+fastpm_store_summary(FastPMStore * p, FastPMColumnTags attribute, MPI_Comm comm, const char * fmt, ...)
+{
+    static const char letters[] = "-<>sSvV";                 /* store.c:872-905 */
+    const int ci = fastpm_store_find_column_id(p, attribute);
+    const int nmemb = (int) p->_column_info[ci].nmemb;
     fpmhip_plan * plan = fastpm_hip_current_plan();
-    if(plan && p->np > 0 && fastpm_hip_host_is_stale(p->columns[ci]) && !strcmp(p->_column_info[ci].dtype, "f4")) {
-        if(fastpm_hip_resident_summary(plan, (const float *) p->columns[ci], (int) nmemb, (int64_t) p->np, rmin, rmax, rsum1, rsum2)) {
+    /* collective decision: every rank must take the same branch (the branches differ in their MPI calls) */
+    int on_device = plan && fastpm_hip_host_is_stale(p->columns[ci]) && !strcmp(p->_column_info[ci].dtype, "f4") && nmemb <= 9;
+    MPI_Allreduce(MPI_IN_PLACE, &on_device, 1, MPI_INT, MPI_MIN, comm);
+    double part[4][9] = {{0}};                               /* min | max | sum | sum of squares, per member */
+    uint64_t Ntot = p->np;
+    int d;
+    if(on_device) {
+        for(d = 0; d < nmemb; d ++) { part[0][d] = 1e20; part[1][d] = -1e20; part[2][d] = part[3][d] = 0; }
+        if(p->np > 0 && fastpm_hip_resident_summary(plan, (const float *) p->columns[ci], nmemb, (int64_t) p->np,
+                                                   part[0], part[1], part[2], part[3])) {
             fastpm_raise(-1, "fastpm_store_summary on the MI355X failed: %s\n", fpmhip_last_error());
         }
+        MPI_Allreduce(MPI_IN_PLACE, part[0], nmemb, MPI_DOUBLE, MPI_MIN, comm);
+        MPI_Allreduce(MPI_IN_PLACE, part[1], nmemb, MPI_DOUBLE, MPI_MAX, comm);
+        MPI_Allreduce(MPI_IN_PLACE, part[2], 2 * 9, MPI_DOUBLE, MPI_SUM, comm);        /* both sums: rows 2 and 3 */
+        MPI_Allreduce(MPI_IN_PLACE, &Ntot, 1, MPI_UINT64_T, MPI_SUM, comm);
     } else {
-        if(NULL == p->_column_info[ci].to_double) {
-            fastpm_raise(-1, "Column %s didnot set to_double virtual function\n", p->_column_info[ci].name);
-        }
         fastpm_hip_store_sync(p, attribute);
-        for(i = 0; i < p->np; i ++) {
-            for(d = 0; d < nmemb; d ++) {
-                double value = p->_column_info[ci].to_double(p, i, ci, d);
-                rsum1[d] += value;
-                rsum2[d] += value * value;
-                rmin[d] = fmin(rmin[d], value);
-                rmax[d] = fmax(rmax[d], value);
-            }
-        }
     }
-    uint64_t Ntot = p->np;
-
-    MPI_Allreduce(MPI_IN_PLACE, rsum1, nmemb, MPI_DOUBLE, MPI_SUM, comm);
-    MPI_Allreduce(MPI_IN_PLACE, rsum2, nmemb, MPI_DOUBLE, MPI_SUM, comm);
-    MPI_Allreduce(MPI_IN_PLACE, rmin, nmemb, MPI_DOUBLE, MPI_MIN, comm);
-    MPI_Allreduce(MPI_IN_PLACE, rmax, nmemb, MPI_DOUBLE, MPI_MAX, comm);
-    MPI_Allreduce(MPI_IN_PLACE, &Ntot,   1, MPI_LONG,  MPI_SUM, comm);
-
-    /* one output array of three doubles per format character, the reference's letters (store.c:872-905) */
-    for(i = 0; i < (ptrdiff_t) strlen(fmt); i ++) {
-        double * dr = (double *) va_arg(va, void *);
-        for(d = 0; d < 3; d ++) {
-            const double mean = rsum1[d] / Ntot, var = rsum2[d] / Ntot - pow(mean, 2);
-            switch(fmt[i]) {
-                case '-': dr[d] = mean; break;
-                case '<': dr[d] = rmin[d]; break;
-                case '>': dr[d] = rmax[d]; break;
-                case 's': dr[d] = sqrt(var); break;
-                case 'S': dr[d] = sqrt(1.0 * Ntot / (Ntot - 1.)) * sqrt(var); break;
-                case 'v': dr[d] = var; break;
-                case 'V': dr[d] = (1.0 * Ntot / (Ntot - 1.)) * var; break;
-                default:
-                    fastpm_raise(-1, "Unknown format str. Use '<->sSvV'\n");
-            }
+    va_list va;
+    va_start(va, fmt);
+    for(; *fmt; fmt ++) {
+        double * out = va_arg(va, double *);
+        const char * which = strchr(letters, *fmt);
+        if(!which) fastpm_raise(-1, "Unknown format str. Use '<->sSvV'\n");
+        if(!on_device) {
+            const char one[2] = {*fmt, 0};
+            fastpm_store_summary_cpu(p, attribute, comm, one, out);
+            continue;
+        }
+        const double n = (double) Ntot, bessel = n / (n - 1.);
+        for(d = 0; d < 3; d ++) {                           /* the reference fills three members, whatever nmemb is */
+            const double mean = part[2][d] / n, var = part[3][d] / n - mean * mean;
+            const double stat[7] = {mean, part[0][d], part[1][d], sqrt(var), sqrt(bessel) * sqrt(var), var, bessel * var};
+            out[d] = stat[which - letters];
         }
     }
     va_end(va);

@@ -43,22 +43,14 @@ fastpm_apply_decic_transfer(PM * pm, FastPMFloat * from, FastPMFloat * to)
 void
 fastpm_powerspectrum_init_from_delta(FastPMPowerSpectrum * ps, PM * pm, const FastPMFloat * delta1_k, const FastPMFloat * delta2_k)
 {
-    /* the head of powerspectrum.c:35-60 */
+    /* the bins the reference sets up before its mode loop (powerspectrum.c:35-60): N/2 of them, k0 = 2 pi / L wide */
+    const double * L = pm_boxsize(pm);
+    size_t i;
     fastpm_powerspectrum_init(ps, pm_nmesh(pm)[0] / 2);
     ps->pm = pm;
-    double Volume = 1.0;
-    int d;
-    double k0 = 2 * M_PI / pm_boxsize(ps->pm)[0];
-    for(d = 0; d < 3; d ++) {
-        Volume *= pm_boxsize(pm)[d];
-    }
-    ps->Volume = Volume;
-    ps->k0 = k0;
-    memset(ps->edges, 0, sizeof(ps->edges[0]) * (ps->base.size + 1));
-    size_t i;
-    for(i = 0; i < ps->base.size + 1; i ++) {
-        ps->edges[i] = i * k0;
-    }
+    ps->Volume = L[0] * L[1] * L[2];
+    ps->k0 = 2 * M_PI / L[0];
+    for(i = 0; i <= ps->base.size; i ++) ps->edges[i] = i * ps->k0;
 
     /* the mode loop (:62-111) on the device: this rank's raw sums of w k, w Re(d1 conj d2), w per bin */
     fpmhip_plan * plan = fastpm_hip_plan_for(pm);
@@ -69,14 +61,13 @@ fastpm_powerspectrum_init_from_delta(FastPMPowerSpectrum * ps, PM * pm, const Fa
     if(!keep1) fastpm_hip_mirror_release(delta1_k);
     if(!keep2 && delta2_k != delta1_k) fastpm_hip_mirror_release(delta2_k);
 
-    MPI_Allreduce(MPI_IN_PLACE, ps->base.f, ps->base.size, MPI_DOUBLE, MPI_SUM, ps->pm->Comm2D);
-    MPI_Allreduce(MPI_IN_PLACE, ps->Nmodes, ps->base.size, MPI_DOUBLE, MPI_SUM, ps->pm->Comm2D);
-    MPI_Allreduce(MPI_IN_PLACE, ps->base.k, ps->base.size, MPI_DOUBLE, MPI_SUM, ps->pm->Comm2D);
-
-    for(i = 0; i < ps->base.size; i ++) {          /* :116-123 */
-        if(ps->Nmodes[i] == 0) continue;
-        ps->base.k[i] /= ps->Nmodes[i];
-        ps->base.f[i] /= ps->Nmodes[i];
-        ps->base.f[i] *= ps->Volume;
+    /* :108-123: sums over the ranks, then mean k, mean power x volume per populated bin */
+    double * sums[3] = {ps->base.k, ps->base.f, ps->Nmodes};
+    for(i = 0; i < 3; i ++) MPI_Allreduce(MPI_IN_PLACE, sums[i], ps->base.size, MPI_DOUBLE, MPI_SUM, pm->Comm2D);
+    for(i = 0; i < ps->base.size; i ++) {
+        const double n = ps->Nmodes[i];
+        if(n == 0) continue;
+        ps->base.k[i] /= n;
+        ps->base.f[i] = ps->base.f[i] / n * ps->Volume;          /* the reference's two roundings, in its order */
     }
 }

@@ -57,6 +57,7 @@ SYMBOLS = {
     "fpmhip_plan_destroy": (None, [_P]),
     "fpmhip_plan_layout": (_I, [_P, ctypes.POINTER(Layout)]),
     "fpmhip_plan_set_stream": (_I, [_P, _P]),
+    "fpmhip_plan_stream": (_P, [_P]),
     "fpmhip_plan_buffer": (_P, [_P, _I]),
     "fpmhip_sync": (_I, [_P]),
     "fpmhip_force": (_I, [_P, ctypes.POINTER(Particles), _I, _I, _D, _P]),
@@ -130,6 +131,7 @@ SYMBOLS = {
                                  ctypes.POINTER(KickFactor), ctypes.POINTER(DriftFactor), ctypes.POINTER(DriftFactor), _I]),
     "fpmhip_range_pieces": (_I, [_P, _I, _I, ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I64),
                                  ctypes.POINTER(_I)]),
+    "fpmhip_range_pieces_a": (_I, [_P, _I, _I, ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
     "fpmhip_plan_scratch": (_P, [_P, ctypes.c_size_t]),
     "fpmhip_paint_zr2c_pen": (_I, [_P, ctypes.POINTER(Particles), _D, _P, _P, _P]),
     "fpmhip_readout3_zc2r_pen": (_I, [_P, ctypes.POINTER(Particles), _P, _P, _P, ctypes.POINTER(_P), ctypes.POINTER(_P)]),

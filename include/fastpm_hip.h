@@ -158,6 +158,9 @@ int  fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **pla
 void fpmhip_plan_destroy(fpmhip_plan *plan);
 int  fpmhip_plan_layout(const fpmhip_plan *plan, fpmhip_layout *out);
 int  fpmhip_plan_set_stream(fpmhip_plan *plan, void *stream);
+/* the hipStream_t of the plan (NULL = the null stream): what a transport records / waits events on to order its
+ * non-blocking exchanges against the plan's kernels (fastpm_amd/host/fastpm_slab_hip.h: xchg_begin / xchg_wait) */
+void *fpmhip_plan_stream(const fpmhip_plan *plan);
 /* plan-owned mesh buffers: 0 = canvas, 1 = delta_k, 2..4 = force components, 5, 6 = exchange */
 void *fpmhip_plan_buffer(fpmhip_plan *plan, int which);
 /* a plan-owned device scratch of at least `bytes` (grown on demand, freed with the plan; a larger request may move it) */
@@ -321,6 +324,9 @@ int fpmhip_plan_ranged_fft(const fpmhip_plan *plan);
  * *stride_elems apart, the first *first_elem elements into the chunk (one piece on the plain layout) */
 int fpmhip_range_pieces(const fpmhip_plan *plan, int x0, int nx, int64_t *first_elem, int64_t *piece_elems,
                         int64_t *stride_elems, int *npieces);
+/* pencils: fpmhip_range_pieces describes a chunk of exchange "B" (x <-> ky); this one a chunk of exchange "A" (y <-> kz),
+ * [x_loc][y_loc][kz_loc] per member of the row -- always ONE piece */
+int fpmhip_range_pieces_a(const fpmhip_plan *plan, int x0, int nx, int64_t *first_elem, int64_t *piece_elems);
 int fpmhip_fft_yz_forward_range(fpmhip_plan *plan, void *canvas_dev, void *send_dev, int x0, int nx);
 int fpmhip_fft_yz_backward_range(fpmhip_plan *plan, void *recv_dev, void *canvas_dev, int x0, int nx);
 int fpmhip_fft_yz_backward_grad2_range(fpmhip_plan *plan, void *recv_dev, void *out_y_dev, void *out_z_dev,

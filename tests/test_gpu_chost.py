@@ -232,7 +232,10 @@ def test_c_host_decic_powerspectrum_and_dump(oracle, tmp_path):
 class Transport(ctypes.Structure):
     _fields_ = [("ctx", ctypes.c_void_p), ("rank", ctypes.c_int), ("nranks", ctypes.c_int),
                 ("allreduce_sum", ctypes.c_void_p), ("alltoall", ctypes.c_void_p), ("sendrecv", ctypes.c_void_p),
-                ("alltoall_members", ctypes.c_void_p), ("alltoall_counts", ctypes.c_void_p), ("alltoallv", ctypes.c_void_p)]
+                ("alltoall_members", ctypes.c_void_p), ("alltoall_counts", ctypes.c_void_p), ("alltoallv", ctypes.c_void_p),
+                # round 5: the non-blocking pair of the pipelined sequence, the plan binding, plane ranges per transpose
+                ("xchg_begin", ctypes.c_void_p), ("xchg_wait", ctypes.c_void_p), ("bind_plan", ctypes.c_void_p),
+                ("chunks", ctypes.c_int)]
 
 
 def test_host_library_exports_the_slab_force():
@@ -426,6 +429,99 @@ def test_c_host_pencil_force_with_strip_tiles_matches_one_rank_oracle(oracle, Nx
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("Nx,Ny,kernel,gradient_mode,paint_mode,ky_block,chunks,precision", [
+    # x slabs: plane ranges of every transpose overlap the (y, z) passes (slab_force_species)
+    (4, 1, "1_4", 0, 3, 0, 4, 64), (4, 1, "1_4", 0, 3, 0, 2, 32), (2, 1, "1_4", 0, 0, 0, 4, 64), (4, 1, "1_4", 1, 0, 0, 2, 64),
+    # ... on the blocked k-space layout (a range of a chunk = ky_loc / kb pieces, fpmhip_range_pieces)
+    (4, 1, "1_4", 0, 3, 2, 2, 64), (2, 1, "1_4", 0, 3, 4, 4, 64), (2, 1, "1_4", 0, 0, 8, 2, 64),
+    # the exact-gradient kernels: one transpose per component, component d + 1 on the wire under the passes of d
+    (2, 1, "eastwood", 0, 3, 0, 4, 64), (4, 1, "3_2", 0, 0, 0, 2, 64),
+    # whole meshes, non-blocking (chunks = 1); the blocking sequence (chunks = -1)
+    (2, 1, "1_4", 0, 3, 0, 1, 64), (4, 1, "1_4", 0, 3, 0, -1, 64),
+    # pencils with strip tiles (pencil_strip_force): exchange A in ranges forwards, by component backwards
+    (2, 2, "1_4", 0, 3, 0, 4, 64), (4, 2, "1_4", 0, 3, 0, 2, 64), (1, 2, "1_4", 0, 3, 0, 4, 32), (2, 2, "1_4", 0, 3, 4, 2, 64),
+    (2, 2, "1_4", 0, 3, 0, 1, 64), (4, 2, "1_4", 0, 3, 0, -1, 64)])
+def test_c_host_pipelined_exchanges_match_one_rank_oracle(oracle, Nx, Ny, kernel, gradient_mode, paint_mode, ky_block, chunks,
+                                                          precision):
+    """fastpm_hip_mesh_force_species with the NON-BLOCKING transport calls (xchg_begin / xchg_wait over fpmhip_range_pieces):
+    the sequence the drop-in runs for NTask > 1, one host thread per rank on the in-process transport, `chunks` plane ranges
+    per transpose.  Two calls (the second in the binning's steady state), potential column, delta_k: all equal to the
+    ONE-rank oracle -- the decomposition and the cut of the exchanges must not show."""
+    import threading
+    import torch
+    from fastpm_amd import PM, Store
+    from fastpm_amd.pm import KERNEL_TYPES
+    H = _host()
+    H.fastpm_hip_loopback_create.restype = ctypes.POINTER(Transport)
+    H.fastpm_hip_loopback_create.argtypes = [ctypes.c_int]
+    H.fastpm_hip_loopback_destroy.argtypes = [ctypes.POINTER(Transport)]
+    H.fastpm_hip_mesh_force_species.argtypes = [ctypes.c_void_p, ctypes.POINTER(Transport), ctypes.c_void_p, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    N, nc, L, P = 64, 32, 96.0, Nx * Ny
+    x = util.load_b(nc, L, N)
+    pmo = oracle.PMOracle(N, L, precision)
+    ref = oracle.compute_force(pmo, x, kernel=oracle.KERNELS[kernel], potential=True,
+                               gradient="real" if gradient_mode else "kspace")
+    h = L / N
+    own = ((np.floor(x[:, 0] / h).astype(np.int64) % N) // (N // Nx)) * Ny + (np.floor(x[:, 1] / h).astype(np.int64) % N) // (N // Ny)
+    idx = [np.nonzero(own == r)[0] for r in range(P)]
+    kw = {"ky_block": ky_block} if ky_block else {}
+    pms = [PM(N, L, precision, nranks=P, rank=r, nranks_y=Ny, gradient_mode=gradient_mode, paint_mode=paint_mode, **kw)
+           for r in range(P)]
+    assert all(pm.strips() == (paint_mode == 3) for pm in pms)
+    if ky_block:
+        assert all(int(pm.layout.okblock) == ky_block for pm in pms)
+    stores = [Store(x[idx[r]], potential=True) for r in range(P)]
+    dks = [pm.alloc() for pm in pms]
+    tol = 1e-6 if precision == 64 else 2e-5
+    for call in range(2):
+        tr = H.fastpm_hip_loopback_create(P)
+        rcs = [None] * P
+
+        def rank_main(r):
+            torch.cuda.set_device(0)
+            tr[r].chunks = chunks                   # (the plan is bound by the call itself: transport.bind_plan)
+            part = stores[r]._c()
+            rcs[r] = H.fastpm_hip_mesh_force_species(pms[r]._plan, ctypes.byref(tr[r]), ctypes.byref(part), 1,
+                                                     KERNEL_TYPES[kernel], 0, ctypes.c_void_p(dks[r].data_ptr()))
+
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+        assert all(not t.is_alive() for t in threads), "a rank hung"
+        torch.cuda.synchronize()
+        assert rcs == [0] * P, (rcs, fastpm_last_error())
+        H.fastpm_hip_loopback_destroy(tr)
+        acc = np.zeros_like(ref["acc"])
+        pot = np.zeros_like(ref["potential"])
+        for r in range(P):
+            acc[idx[r]] = stores[r].acc.cpu().numpy()
+            pot[idx[r]] = stores[r].potential.cpu().numpy()
+            stores[r].acc.zero_()
+            stores[r].potential.zero_()
+        if gradient_mode:
+            assert np.abs(acc - ref["acc"]).max() <= 1.5e-7 * np.abs(ref["acc"]).max()
+        else:
+            assert util.rel_err(acc, ref["acc"]) <= tol
+        assert util.rel_err(pot, ref["potential"]) <= tol
+        dko = util.oracle_k_to_xyk(pmo, ref["delta_k"])
+        for pm, d in zip(pms, dks):
+            Lr = pm.layout
+            nv = int(Lr.ovalid_z)
+            want = dko[:, Lr.ostart[1]:Lr.ostart[1] + Lr.osize[1], Lr.ostart[2]:Lr.ostart[2] + nv]
+            assert util.max_err(pm.complex_view(d).cpu().numpy(), want) <= (1e-14 if precision == 64 else 1e-5)
+    for pm in pms:
+        pm.destroy()
+
+
+def fastpm_last_error():
+    from fastpm_amd import lib
+    return lib.load_library().fpmhip_last_error()
+
+
+@pytest.mark.gpu
 def test_plain_c_program_runs_the_force(oracle, tmp_path):
     """fastpm_amd/host/example_force.c: gcc, no Python in the process -- the C host library and the HIP library
     only.  Its printed accelerations must be the oracle's for the same (closed-form) particle positions."""
@@ -473,12 +569,19 @@ MPI_ROOT = os.environ.get("FPM_MPI_ROOT", "/opt/conda")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("P,nc,B,precision,gradient_mode,host_columns,decompose,nprocy", [
-    (2, 24, 2, 64, 0, 0, 0, 1), (4, 24, 2, 64, 1, 0, 0, 1), (3, 24, 2, 32, 0, 0, 0, 1), (2, 24, 2, 64, 0, 1, 0, 1),
-    (4, 24, 2, 32, 1, 1, 0, 1), (2, 24, 2, 64, 0, 0, 1, 1), (4, 24, 2, 64, 0, 1, 1, 1), (3, 24, 2, 64, 1, 0, 1, 1),
+@pytest.mark.parametrize("P,nc,B,precision,gradient_mode,host_columns,decompose,nprocy,chunks", [
+    (2, 24, 2, 64, 0, 0, 0, 1, 0), (4, 24, 2, 64, 1, 0, 0, 1, 0), (3, 24, 2, 32, 0, 0, 0, 1, 0), (2, 24, 2, 64, 0, 1, 0, 1, 0),
+    (4, 24, 2, 32, 1, 1, 0, 1, 0), (2, 24, 2, 64, 0, 0, 1, 1, 0), (4, 24, 2, 64, 0, 1, 1, 1, 0), (3, 24, 2, 64, 1, 0, 1, 1, -1),
     # pencils, the reference's default kind of process mesh (pmpfft.c:117-136): 2 x 2, and 4 x 2 as it picks for 8 ranks
-    (4, 32, 2, 64, 0, 0, 0, 2), (4, 32, 2, 32, 0, 1, 1, 2), (8, 32, 2, 64, 0, 0, 1, 2)])
-def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode, host_columns, decompose, nprocy):
+    (4, 32, 2, 64, 0, 0, 0, 2, 0), (4, 32, 2, 32, 0, 1, 1, 2, 0), (8, 32, 2, 64, 0, 0, 1, 2, 0),
+    # round 5, the pipelined sequence over MPI_Isend / MPI_Irecv: strip tiles (Nmesh 64 = the smallest strip mesh that is a
+    # whole number of strips per rank), 2 and 4 plane ranges, slabs and 2 x 2 / 4 x 2 pencils, whole meshes, blocking
+    (4, 32, 2, 64, 0, 0, 0, 1, 32), (2, 32, 2, 32, 0, 0, 1, 1, 34), (4, 32, 2, 64, 1, 0, 0, 1, 4), (2, 32, 2, 64, 0, 1, 0, 1, 31),
+    (4, 32, 2, 64, 0, 0, 0, 2, 34), (8, 32, 2, 64, 0, 0, 1, 2, 32), (4, 32, 2, 64, 0, 0, 0, 2, 29)])
+def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode, host_columns, decompose, nprocy, chunks):
+    paint_mode = 0
+    if chunks >= 20:                 # 30 + c: strip tiles forced on the small mesh, c plane ranges (29: the blocking sequence)
+        paint_mode, chunks = 3, chunks - 30
     """`mpiexec -n P example_slab_mpi`: P separate processes, plain C99, exchanging through MPI_Alltoall /
     MPI_Sendrecv / MPI_Allreduce on MPI_COMM_WORLD exactly where libfastpm's PFFT transposes, ghost exchange and
     mass all-reduce sit (the image's MPICH is not GPU-aware, so the transport stages through the host; on the
@@ -492,7 +595,7 @@ def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode
                     "MPI_LIB=" + os.path.join(MPI_ROOT, "lib")], check=True, capture_output=True)
     exe = os.path.join(ROOT, "fastpm_amd", "example_slab_mpi")
     r = subprocess.run([mpiexec, "-n", str(P), exe, str(nc), str(B), str(precision), str(gradient_mode), "0",
-                        str(host_columns), str(decompose), str(nprocy)],
+                        str(host_columns), str(decompose), str(nprocy), str(chunks), str(paint_mode)],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     lines = {l.split()[0] + (l.split()[1] if l.startswith("acc std") else ""): l.split() for l in r.stdout.splitlines()}

@@ -247,3 +247,37 @@ def test_resident_force_with_two_species_and_masses(oracle):
         assert util.rel_err(st.acc, ref) <= 1e-6                        # ... until a host consumer asks
         st.release()
     H.fastpm_free_pm_hip(pm)
+
+
+def test_positions_rewritten_on_the_host_after_a_wrap_are_binned_again(oracle):
+    """fastpm_store_wrap bins for the force that follows (fpmhip_wrap_bin).  A host that then rewrites x -- touched, then a
+    new upload behind the SAME device pointer -- must get the force of the new positions, not of the stale tile binning
+    (the prebinned fast path skipped the staleness check)."""
+    H = chost.host_library()
+    N, nc, L = 192, 96, 288.0                                   # the smallest mesh that takes strip tiles by itself
+    x0 = util.load_a(nc, L, N)
+    pm = H.fastpm_create_pm_hip(N, L, 64)
+    pmo = oracle.PMOracle(N, L, 64)
+    st = chost.HostStore(x0, a_x=0.1, a_v=0.1)
+    sv = chost.solver_view(st)
+    painter = chost.PainterView(0, 2)
+    dk = np.zeros(pmo.allocsize, dtype=np.float64)
+    box = (ctypes.c_double * 3)(L, L, L)
+    msgs = chost.Messages()
+    force = lambda: H.fastpm_solver_compute_force_resident_hip(ctypes.byref(sv), pm, ctypes.byref(painter), 0, 3,
+                                                               dk.ctypes.data, 1.0)
+    force()                                                     # a layout exists: the next wrap takes the fused walk
+    H.fastpm_store_wrap_resident_hip(pm, ctypes.byref(st.view), box)
+    st.sync("x")
+    x1 = np.remainder(st.x + np.random.default_rng(3).normal(0, 0.4 * L / N, st.x.shape), L)
+    st.x[...] = x1                                              # host code moves the particles ...
+    st.touched("x")                                             # ... and says so
+    force()
+    assert not msgs.raised, msgs.raised
+    st.sync("acc")
+    ref = oracle.compute_force(pmo, x1)["acc"]
+    assert util.rel_err(st.acc, ref) <= 1e-6
+    st.release()
+    H.fastpm_hip_mirror_release(dk.ctypes.data)
+    msgs.close()
+    H.fastpm_free_pm_hip(pm)
