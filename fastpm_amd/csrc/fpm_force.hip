@@ -13,10 +13,90 @@ int fpmhip_force(fpmhip_plan *p, const fpmhip_particles *pt, int kernel, int sof
     return fpmhip_force_species(p, pt, 1, kernel, softening, total_mass, delta_k_out);
 }
 
+static int force_species_body(fpmhip_plan *p, const fpmhip_particles *sets, int nsets, int kernel, int softening,
+                              double total_mass, void *delta_k_out);
+
+// A force call is ~30 launches; on the small meshes (configs[0]: 256^3, a kernel every 10 - 20 us) the gaps between them are a
+// third of the call.  In the steady state -- the binning has a layout for this many particles, nothing waits on the host
+// inside the call -- the call's launches are CAPTURED (on a stream of the plan's own: the caller's may be the null stream,
+// which cannot capture), the executable graph of the previous call is updated with them (same topology, new arguments:
+// the binning's buffers alternate, the caller's pointers may change) and launched on the caller's stream.  The host
+// side of the call runs exactly as without the graph -- nothing about the plan's state is replayed from memory.
+// FPMHIP_GRAPH = 0 | 1 forces; default: Nmesh <= 384.
+static bool graph_wanted(const fpmhip_plan *p)
+{
+    static const int env = getenv("FPMHIP_GRAPH") ? atoi(getenv("FPMHIP_GRAPH")) : -1;
+    return env >= 0 ? env != 0 : p->mg.N <= 384;
+}
+
 // The species loop of gravity.c:279-287 (ghosts), :323-338 (paint every species into one canvas,
 // total mass over all of them) and :387-395 (read every species out of each force mesh).
 int fpmhip_force_species(fpmhip_plan *p, const fpmhip_particles *sets, int nsets, int kernel, int softening,
                          double total_mass, void *delta_k_out)
+{
+    if (!p || !sets || nsets < 1) FPM_FAIL(-1, "null argument");
+    bool graph = graph_wanted(p) && p->lay.nranks == 1 && p->own_fft && !p->timing && !p->stage_hook && !p->check_hook
+                 && !p->capturing && nsets <= 6 && p->geom.paint_mode != FPMHIP_PAINT_ATOMIC;
+    for (int si = 0; si < nsets && graph; si++) {
+        // a total mass that needs a read-back, an empty set, or a set the binning has no layout for: not the steady state
+        if ((total_mass < 0 && sets[si].mass) || sets[si].np <= 0) graph = false;
+    }
+    if (graph && !(p->layout_np == sets[nsets - 1].np || (p->prebinned && p->binned_np == sets[nsets - 1].np))) graph = false;
+    if (!graph) return force_species_body(p, sets, nsets, kernel, softening, total_mass, delta_k_out);
+
+    (void) hipSetDevice(p->device);
+    FPM_TRY(check_deferred(p, true));                       // the flags of the previous binning: a host wait, outside the capture
+    if (p->layout_np != sets[nsets - 1].np && !p->prebinned)      // (a reported failure resets the layout)
+        return force_species_body(p, sets, nsets, kernel, softening, total_mass, delta_k_out);
+    // every buffer the call may allocate on the way exists before the capture begins
+    FPM_TRY(ensure_buffer(p, BUF_CANVAS)); FPM_TRY(ensure_buffer(p, BUF_F1)); FPM_TRY(ensure_buffer(p, BUF_F2));
+    FPM_TRY(ensure_buffer(p, BUF_F0)); FPM_TRY(ensure_buffer(p, BUF_DELTA_K));
+    if (!p->cap_stream) FPM_CHECK_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
+    hipStream_t user = p->stream;
+    hipGraph_t g = nullptr;
+    p->stream = p->cap_stream;
+    p->capturing = true;
+    p->flags_record_deferred = false;
+    hipError_t e = hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeRelaxed);
+    int rc = e == hipSuccess ? force_species_body(p, sets, nsets, kernel, softening, total_mass, delta_k_out) : -1;
+    hipError_t e2 = e == hipSuccess ? hipStreamEndCapture(p->cap_stream, &g) : e;
+    p->capturing = false;
+    p->stream = user;
+    if (e != hipSuccess || e2 != hipSuccess || !g) {
+        if (g) (void) hipGraphDestroy(g);
+        p->flags_pending = false;
+        if (rc) return rc;
+        FPM_FAIL(-1, "hipGraph capture of the force call failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    }
+    if (rc) {                                               // the body refused (arguments): nothing has run
+        (void) hipGraphDestroy(g);
+        p->flags_pending = false;
+        return rc;
+    }
+    bool ready = false;
+    if (p->gexec) {
+        hipGraphNode_t bad = nullptr;
+        hipGraphExecUpdateResult res;
+        ready = hipGraphExecUpdate(p->gexec, g, &bad, &res) == hipSuccess;
+        if (!ready) { (void) hipGetLastError(); (void) hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
+    }
+    if (!ready) {
+        e = hipGraphInstantiate(&p->gexec, g, nullptr, nullptr, 0);
+        p->graph_rebuilds++;
+    }
+    if (e == hipSuccess) e = hipGraphLaunch(p->gexec, user);
+    (void) hipGraphDestroy(g);
+    if (e != hipSuccess) { p->flags_pending = false; FPM_FAIL(-1, "hipGraph launch of the force call failed: %s", hipGetErrorString(e)); }
+    p->graph_launches++;
+    if (p->flags_record_deferred) {
+        p->flags_record_deferred = false;
+        FPM_CHECK_HIP(hipEventRecord(p->flags_event, user));
+    }
+    return 0;
+}
+
+static int force_species_body(fpmhip_plan *p, const fpmhip_particles *sets, int nsets, int kernel, int softening,
+                              double total_mass, void *delta_k_out)
 {
     if (!p || !sets || nsets < 1) FPM_FAIL(-1, "null argument");
     if (nsets > 6) FPM_FAIL(-1, "at most FASTPM_SOLVER_NSPECIES = 6 species");

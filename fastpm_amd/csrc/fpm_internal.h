@@ -215,6 +215,13 @@ struct fpmhip_plan {
     // pm_check_values at the reference's points (fpmhip_set_check_hook / fpmhip_check_point)
     void (*check_hook)(void *ctx, const char *label, int64_t count) = nullptr;
     void *check_hook_ctx = nullptr;
+    // hipGraph of the steady-state force call (fpm_force.hip): the call's launches are captured on a stream of the plan's
+    // own, the executable graph of the previous call is UPDATED with them and launched on the plan's stream
+    hipStream_t cap_stream = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    bool capturing = false;                 // inside the capture: no event may be recorded or queried
+    bool flags_record_deferred = false;     // post_flags ran inside the capture: its event is recorded after the launch
+    int64_t graph_launches = 0, graph_rebuilds = 0;
     // timing
     bool timing = false;
     std::vector<fpm::EventPair> ev_used;

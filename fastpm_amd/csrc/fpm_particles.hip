@@ -1252,7 +1252,7 @@ static int bin_finish(fpmhip_plan *p, const int *pred)
 // the flags of an earlier binning, once they have arrived (never waits)
 int check_deferred(fpmhip_plan *p, bool wait)
 {
-    if (!p->flags_pending) return 0;
+    if (!p->flags_pending || p->capturing) return 0;    // (capturing: the flags' event is recorded after the graph's launch)
     if (wait) FPM_CHECK_HIP(hipEventSynchronize(p->flags_event));
     else if (hipEventQuery(p->flags_event) != hipSuccess) return 0;
     p->flags_pending = false;
@@ -1285,6 +1285,11 @@ int check_deferred(fpmhip_plan *p, bool wait)
 static int post_flags(fpmhip_plan *p, bool wait)
 {
     FPM_CHECK_HIP(hipMemcpyAsync(p->h_flags, p->d_flags, FLAG_COUNT * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    if (p->capturing) {                     // fpm_force.hip records the event behind the launch of the captured graph
+        p->flags_pending = true;
+        p->flags_record_deferred = true;
+        return 0;
+    }
     FPM_CHECK_HIP(hipEventRecord(p->flags_event, p->stream));
     p->flags_pending = true;
     return check_deferred(p, wait);

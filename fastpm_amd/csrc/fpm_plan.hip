@@ -395,6 +395,8 @@ void fpmhip_plan_destroy(fpmhip_plan *p)
     if (p->h_pinned) (void) hipHostFree(p->h_pinned);
     if (p->h_flags) (void) hipHostFree(p->h_flags);
     if (p->flags_event) (void) hipEventDestroy(p->flags_event);
+    if (p->gexec) (void) hipGraphExecDestroy(p->gexec);
+    if (p->cap_stream) (void) hipStreamDestroy(p->cap_stream);
     for (auto &e : p->ev_used) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
     for (auto &e : p->ev_free) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
     delete p;

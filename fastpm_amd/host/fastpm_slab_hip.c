@@ -434,6 +434,24 @@ static int halo_in(fpmhip_plan *plan, const fastpm_hip_transport *t, const mesh_
     return 0;
 }
 
+/* pm_r2c from its y pass on (pmpfft.c:377-379) with both of PFFT's transposes NON-BLOCKING, in nr plane ranges (nr == 1:
+ * whole meshes): every range of exchange A is begun at once (what fills send_a is done), range i goes through its y
+ * pass and into exchange B while the later ranges of A are still on the wire.  send_a -> recv_a -> [y] send_b -> delta_k. */
+static int pencil_forward_from_a(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_layout *lay,
+                                 const mesh_groups *g, int nr, void *send_a, void *recv_a, void *send_b, void *delta_k)
+{
+    const int rx = nr > 1 ? (int) (lay->isize[0] / nr) : 0;
+    for (int i = 0; i < nr; i++) TRY(begin_axis(plan, t, lay, g, 0, send_a, recv_a, i * rx, rx, TAG_A + i));
+    for (int i = 0; i < nr; i++) {
+        TRY(wait_axis(t, g, 0, TAG_A + i));
+        if (nr > 1) TRY(fpmhip_fft_y_forward_range(plan, recv_a, send_b, i * rx, rx));
+        else TRY(fpmhip_fft_y_forward(plan, recv_a, send_b));
+        TRY(begin_axis(plan, t, lay, g, 1, send_b, delta_k, i * rx, rx, TAG_FWD + i));
+    }
+    for (int i = 0; i < nr; i++) TRY(wait_axis(t, g, 1, TAG_FWD + i));
+    return 0;
+}
+
 /* the force step on a pencil plan with strip tiles; c, w: the plan's mesh buffers as pencil_force_species names them */
 static int pencil_strip_force(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_layout *lay, const mesh_groups *g,
                               const fpmhip_particles *set, int kernel, void *delta_k, void *c, void **w)
@@ -473,18 +491,7 @@ static int pencil_strip_force(fpmhip_plan *plan, const fastpm_hip_transport *t, 
     void *mesh[4];                                  /* (x, y, z [, potential]) as the (y <-> kz) exchange delivers them */
     const int nr = plane_ranges(plan, t, xl);
     if (nr >= 1) {
-        /* pm_r2c from its y pass on (pmpfft.c:377-379), both of PFFT's transposes NON-BLOCKING.  Forwards in plane ranges:
-         * every range of exchange A is begun at once (the paint is one kernel); range i goes through its y pass and into
-         * exchange B while the later ranges of A are still on the wire. */
-        const int rx = nr > 1 ? (int) (xl / nr) : 0;
-        for (int i = 0; i < nr; i++) TRY(begin_axis(plan, t, lay, g, 0, w[0], w[1], i * rx, rx, TAG_A + i));
-        for (int i = 0; i < nr; i++) {
-            TRY(wait_axis(t, g, 0, TAG_A + i));
-            if (nr > 1) TRY(fpmhip_fft_y_forward_range(plan, w[1], w[2], i * rx, rx));
-            else TRY(fpmhip_fft_y_forward(plan, w[1], w[2]));
-            TRY(begin_axis(plan, t, lay, g, 1, w[2], delta_k, i * rx, rx, TAG_FWD + i));
-        }
-        for (int i = 0; i < nr; i++) TRY(wait_axis(t, g, 1, TAG_FWD + i));
+        TRY(pencil_forward_from_a(plan, t, lay, g, nr, w[0], w[1], w[2], delta_k));
         TRY(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 2, w[0], w[1], NULL));
         /* backwards (pmpfft.c:394-396) by COMPONENT: the potential's y pass (which makes the y and z components) runs
          * while the x component is in exchange B, the x component's y pass while y and z are in exchange A.  A pass never
@@ -572,9 +579,14 @@ static int pencil_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t
     TRY(halo_out(plan, t, &g, lay, c, w[3]));
     TRY(fpmhip_check_point(plan, c, "After painting"));                           /* gravity.c:350 */
     TRY(fpmhip_fft_z_forward(plan, c, w[0]));                                     /* gravity.c:351 pm_r2c */
-    TRY(exchange_axis(plan, t, &g, 0, w[0], w[1], a_bytes));
-    TRY(fpmhip_fft_y_forward(plan, w[1], w[0]));
-    TRY(exchange_axis(plan, t, &g, 1, w[0], delta_k, b_bytes));
+    const int nr = plane_ranges(plan, t, lay->isize[0]);
+    if (nr >= 1) {
+        TRY(pencil_forward_from_a(plan, t, lay, &g, nr, w[0], w[1], w[2], delta_k));
+    } else {
+        TRY(exchange_axis(plan, t, &g, 0, w[0], w[1], a_bytes));
+        TRY(fpmhip_fft_y_forward(plan, w[1], w[0]));
+        TRY(exchange_axis(plan, t, &g, 1, w[0], delta_k, b_bytes));
+    }
     const int fuse_x = softening == FPMHIP_SOFTENING_NONE;
     if (!fuse_x) {
         TRY(fpmhip_fft_x_forward(plan, delta_k));
@@ -585,22 +597,50 @@ static int pencil_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t
         /* two meshes through the transposes: the x component and the potential (fastpm_hip.h) */
         if (fuse_x) TRY(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 2, w[0], w[1], NULL));
         else TRY(fpmhip_transfer_fft_x_backward_potx(plan, delta_k, w[0], w[1], kernel));
-        TRY(exchange_axis(plan, t, &g, 1, w[1], w[2], b_bytes));                  /* potential */
-        TRY(exchange_axis(plan, t, &g, 1, w[0], w[3], b_bytes));                  /* x component */
-        void *potmesh = any_pot ? w[4] : NULL;                                    /* gravity.c:487-492 rides along */
-        TRY(fpmhip_fft_y_backward_grad2(plan, w[2], w[0], w[1], potmesh, kernel));
-        TRY(fpmhip_fft_y_backward(plan, w[3], w[2]));
-        TRY(exchange_axis(plan, t, &g, 0, w[2], w[3], a_bytes));
-        TRY(fpmhip_fft_z_backward(plan, w[3], c));
-        TRY(exchange_axis(plan, t, &g, 0, w[0], w[3], a_bytes));
-        TRY(fpmhip_fft_z_backward(plan, w[3], w[2]));
-        TRY(exchange_axis(plan, t, &g, 0, w[1], w[3], a_bytes));
-        TRY(fpmhip_fft_z_backward(plan, w[3], w[0]));
-        mesh[0] = c; mesh[1] = w[2]; mesh[2] = w[0];
-        if (potmesh) {
-            TRY(exchange_axis(plan, t, &g, 0, potmesh, w[3], a_bytes));
-            TRY(fpmhip_fft_z_backward(plan, w[3], w[1]));
-            mesh[3] = w[1];
+        if (nr >= 1) {
+            /* pm_c2r x 3 (pmpfft.c:394-396) by COMPONENT, every transpose non-blocking: a pass runs while the next
+             * component is on the wire, and never writes where an exchange still reads or lands (the comments name the
+             * buffer each wait frees) */
+            TRY(begin_axis(plan, t, lay, &g, 1, w[1], w[2], 0, 0, TAG_POT));        /* potential */
+            TRY(begin_axis(plan, t, lay, &g, 1, w[0], w[3], 0, 0, TAG_X));          /* x component */
+            TRY(wait_axis(t, &g, 1, TAG_POT));                                      /* w[1] */
+            TRY(fpmhip_fft_y_backward_grad2(plan, w[2], c, w[4], any_pot ? w[1] : NULL, kernel));
+            TRY(begin_axis(plan, t, lay, &g, 0, c, w[2], 0, 0, TAG_Y));
+            TRY(wait_axis(t, &g, 1, TAG_X));                                        /* w[0] */
+            TRY(begin_axis(plan, t, lay, &g, 0, w[4], w[0], 0, 0, TAG_Z));
+            TRY(wait_axis(t, &g, 0, TAG_Y));                                        /* c; y has landed in w[2] */
+            TRY(fpmhip_fft_y_backward(plan, w[3], c));                              /* x; frees w[3] */
+            TRY(fpmhip_fft_z_backward(plan, w[2], w[3]));                           /* y in real space: w[3] */
+            TRY(begin_axis(plan, t, lay, &g, 0, c, w[2], 0, 0, TAG_XA));
+            TRY(wait_axis(t, &g, 0, TAG_Z));                                        /* w[4]; z has landed in w[0] */
+            TRY(fpmhip_fft_z_backward(plan, w[0], w[4]));                           /* z in real space: w[4] */
+            if (any_pot) TRY(begin_axis(plan, t, lay, &g, 0, w[1], w[0], 0, 0, TAG_PA));
+            TRY(wait_axis(t, &g, 0, TAG_XA));                                       /* c; x has landed in w[2] */
+            TRY(fpmhip_fft_z_backward(plan, w[2], c));                              /* x in real space: c */
+            mesh[0] = c; mesh[1] = w[3]; mesh[2] = w[4];
+            if (any_pot) {
+                TRY(wait_axis(t, &g, 0, TAG_PA));
+                TRY(fpmhip_fft_z_backward(plan, w[0], w[1]));
+                mesh[3] = w[1];
+            }
+        } else {
+            TRY(exchange_axis(plan, t, &g, 1, w[1], w[2], b_bytes));              /* potential */
+            TRY(exchange_axis(plan, t, &g, 1, w[0], w[3], b_bytes));              /* x component */
+            void *potmesh = any_pot ? w[4] : NULL;                                /* gravity.c:487-492 rides along */
+            TRY(fpmhip_fft_y_backward_grad2(plan, w[2], w[0], w[1], potmesh, kernel));
+            TRY(fpmhip_fft_y_backward(plan, w[3], w[2]));
+            TRY(exchange_axis(plan, t, &g, 0, w[2], w[3], a_bytes));
+            TRY(fpmhip_fft_z_backward(plan, w[3], c));
+            TRY(exchange_axis(plan, t, &g, 0, w[0], w[3], a_bytes));
+            TRY(fpmhip_fft_z_backward(plan, w[3], w[2]));
+            TRY(exchange_axis(plan, t, &g, 0, w[1], w[3], a_bytes));
+            TRY(fpmhip_fft_z_backward(plan, w[3], w[0]));
+            mesh[0] = c; mesh[1] = w[2]; mesh[2] = w[0];
+            if (potmesh) {
+                TRY(exchange_axis(plan, t, &g, 0, potmesh, w[3], a_bytes));
+                TRY(fpmhip_fft_z_backward(plan, w[3], w[1]));
+                mesh[3] = w[1];
+            }
         }
     } else {
         /* gravity.c:373-397 with the exact i k gradient: three components through the transposes */
@@ -625,7 +665,7 @@ static int pencil_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t
         }
     }
     for (int d = 0; d < 4; d++)
-        if (mesh[d]) TRY(halo_in(plan, t, &g, lay, mesh[d], w[3]));
+        if (mesh[d]) TRY(halo_in(plan, t, &g, lay, mesh[d], nr >= 1 && go == 1 ? w[2] : w[3]));    /* a free buffer as scratch */
     TRY(check_force_meshes(plan, delta_k, mesh));
     TRY(readout_species(plan, sets, nsets, mesh[0], mesh[1], mesh[2]));
     for (int si = 0; si < nsets && mesh[3]; si++)

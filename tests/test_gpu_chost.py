@@ -440,7 +440,9 @@ def test_c_host_pencil_force_with_strip_tiles_matches_one_rank_oracle(oracle, Nx
     (2, 1, "1_4", 0, 3, 0, 1, 64), (4, 1, "1_4", 0, 3, 0, -1, 64),
     # pencils with strip tiles (pencil_strip_force): exchange A in ranges forwards, by component backwards
     (2, 2, "1_4", 0, 3, 0, 4, 64), (4, 2, "1_4", 0, 3, 0, 2, 64), (1, 2, "1_4", 0, 3, 0, 4, 32), (2, 2, "1_4", 0, 3, 4, 2, 64),
-    (2, 2, "1_4", 0, 3, 0, 1, 64), (4, 2, "1_4", 0, 3, 0, -1, 64)])
+    (2, 2, "1_4", 0, 3, 0, 1, 64), (4, 2, "1_4", 0, 3, 0, -1, 64),
+    # pencils with box tiles (pencil_force_species): the same forward ranges, the three c2r by component
+    (2, 2, "1_4", 0, 0, 0, 4, 64), (4, 2, "1_4", 0, 0, 0, 2, 32), (2, 2, "1_4", 0, 0, 4, 1, 64), (2, 2, "eastwood", 0, 0, 0, 2, 64)])
 def test_c_host_pipelined_exchanges_match_one_rank_oracle(oracle, Nx, Ny, kernel, gradient_mode, paint_mode, ky_block, chunks,
                                                           precision):
     """fastpm_hip_mesh_force_species with the NON-BLOCKING transport calls (xchg_begin / xchg_wait over fpmhip_range_pieces):

@@ -281,3 +281,40 @@ def test_positions_rewritten_on_the_host_after_a_wrap_are_binned_again(oracle):
     H.fastpm_hip_mirror_release(dk.ctypes.data)
     msgs.close()
     H.fastpm_free_pm_hip(pm)
+
+
+def test_a_nan_in_the_mass_column_prints_the_reference_out_of_bounds_lines(oracle):
+    """pm_check_values (pmapi.c:335-356) at gravity.c:350, 352, 381, 383 is ON by default at no cost: the acc summary of the
+    log lines says that something went wrong, and only then the step runs again with the five check points counting.  A
+    healthy step prints none of them; FASTPM_HIP_CHECK_VALUES is not set here."""
+    import os
+    assert "FASTPM_HIP_CHECK_VALUES" not in os.environ
+    H = chost.host_library()
+    N, nc, L = 64, 32, 96.0
+    x0 = util.load_a(nc, L, N)
+    mass = np.ones(len(x0), dtype=np.float32)
+    pm = H.fastpm_create_pm_hip(N, L, 64)
+    pmo = oracle.PMOracle(N, L, 64)
+    st = chost.HostStore(x0, mass=mass, M0=0.0)
+    sv = chost.solver_view(st)
+    painter = chost.PainterView(0, 2)
+    dk = np.zeros(pmo.allocsize, dtype=np.float64)
+    msgs = chost.Messages()
+    force = lambda: H.fastpm_solver_compute_force_resident_hip(ctypes.byref(sv), pm, ctypes.byref(painter), 0, 3,
+                                                               dk.ctypes.data, 1.0)
+    force()
+    assert not msgs.raised and len(msgs.info) == 6 and not any("out of bounds" in m for _, m in msgs.info)
+    st.mass[12345] = np.nan                                     # one poisoned particle
+    st.touched("mass")
+    del msgs.info[:]
+    force()
+    assert not msgs.raised, msgs.raised
+    lines = [m for _, m in msgs.info]
+    for label in ("After painting", "After r2c", "After c2r 0", "After c2r 1", "After c2r 2"):
+        hit = [l for l in lines if l.startswith(label + ": Task 0 has ") and l.rstrip().endswith("field values that are out of bounds")]
+        assert len(hit) == 1, (label, lines)
+    assert sum(l.startswith("p1") for l in lines) == 6          # the acc lines follow, once
+    st.release()
+    H.fastpm_hip_mirror_release(dk.ctypes.data)
+    msgs.close()
+    H.fastpm_free_pm_hip(pm)
