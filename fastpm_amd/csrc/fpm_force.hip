@@ -22,11 +22,16 @@ static int force_species_body(fpmhip_plan *p, const fpmhip_particles *sets, int 
 // which cannot capture), the executable graph of the previous call is updated with them (same topology, new arguments:
 // the binning's buffers alternate, the caller's pointers may change) and launched on the caller's stream.  The host
 // side of the call runs exactly as without the graph -- nothing about the plan's state is replayed from memory.
-// FPMHIP_GRAPH = 0 | 1 forces; default: Nmesh <= 384.
+// MEASURED (tools/graph_ab.py, profiles/r05_graph_ab.jsonl; ms per force, stream launches -> graph): 128^3 fp32 0.139 -> 0.203,
+// 192^3 0.271 -> 0.327, 256^3 fp32 0.415 -> 0.485, 256^3 fp64 0.620 -> 0.692, 384^3 1.46 -> 1.52, 512^3 fp64 4.36 -> 4.44: the
+// graph LOSES 0.06 - 0.07 ms per call at every size.  Nothing waits on the host inside a force call, so the host runs
+// ahead of the GPU and the stream is never starved -- there are no gaps for a graph to close -- and capture + update +
+// launch cost the host more than ~30 plain launches.  Kept as an opt-in A/B: FPMHIP_GRAPH=1.
 static bool graph_wanted(const fpmhip_plan *p)
 {
-    static const int env = getenv("FPMHIP_GRAPH") ? atoi(getenv("FPMHIP_GRAPH")) : -1;
-    return env >= 0 ? env != 0 : p->mg.N <= 384;
+    static const int env = getenv("FPMHIP_GRAPH") ? atoi(getenv("FPMHIP_GRAPH")) : 0;
+    (void) p;
+    return env != 0;
 }
 
 // The species loop of gravity.c:279-287 (ghosts), :323-338 (paint every species into one canvas,

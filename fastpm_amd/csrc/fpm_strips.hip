@@ -497,8 +497,9 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
 // particles on average: 1 / 2 / 4 / 6 / 8 -> 15.6 / 14.5 / 12.8 / 18.5 / 28.5 ms).  In fp32 the same shape is 10.4 -> 9.8 ms;
 // against a float64 transform of the same rows both shapes are 1.2e-7 (rms) off, but the E = 8 kernel repeats the box path's
 // arithmetic bit for bit (tests/test_gpu_strips.py holds it to that) and E = 16 rounds differently (2e-5 of max |acc| on a
-// sparse load), so fp32 keeps E = 8 (FPMHIP_RO_E16=1 forces the other).  The paint in that
-// shape loses (4.8 -> 5.6 ms): not kept.
+// sparse load).  Round 5: fp32 takes E = 16 too (10.48 -> 9.83 ms, per rank 32.4 -> 32.3 ms; both 1.8e-6 from the small cube
+// at full per-rank size) -- the contract is the oracle's tolerance, not the box path's bits; FPMHIP_RO_E16=0 selects E = 8.
+// The paint in that shape loses (4.8 -> 5.6 ms): not kept.
 // M = 1536 (the 3072^3 meshes of configs[4] at B = 3): one wave per row with E = 24 (8.3.8.8, three exchanges; half a twiddle
 // table as every plan beyond 1024): 252 VGPRs, one workgroup per CU, 86 KB of LDS in fp32 and 157 KB in fp64.  One rank of eight,
 // z c2r x 3 + readout: fp64 64.2 (box tiles) -> 47.0 ms, fp32 36.7 -> 35.2; the three-waves-per-row shape (E = 8, 960 threads, a
@@ -1385,7 +1386,7 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
         }                                                                                                              \
     }                                                                                                                  \
     if constexpr (PL::N == 1024) {                                                                                     \
-        static const int e16_env = getenv("FPMHIP_RO_E16") ? atoi(getenv("FPMHIP_RO_E16")) : (sizeof(F) == 8);         \
+        static const int e16_env = getenv("FPMHIP_RO_E16") ? atoi(getenv("FPMHIP_RO_E16")) : 1;                        \
         if (e16_env && !two_planes && ws_env != 0) {                                                                   \
             using PX = FFTPlan<1024, 16, 16, 8, 8, 1>;                                                                 \
             if (pen.on) CALL_RO_E16(PX, true) else CALL_RO_E16(PX, false)                                              \
