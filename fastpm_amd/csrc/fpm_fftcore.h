@@ -285,9 +285,10 @@ template <typename PL> constexpr int in_slot(int j)
     return (j % (PL::E / PL::R1)) * PL::R1 + j / (PL::E / PL::R1);
 }
 
-template <int N, bool TWH, int S, typename F> __device__ __forceinline__ C2<F> load_tw(const C2<F> *tw, int j)
+// (TF: the table's element type -- F itself, or float under f32x2 values: one entry serves both lanes, half the LDS)
+template <int N, bool TWH, int S, typename F, typename TF> __device__ __forceinline__ C2<F> load_tw(const C2<TF> *tw, int j)
 {
-    C2<F> w;
+    C2<TF> w;
     if (TWH) {
         const bool hi = j >= N / 2;
         w = tw[hi ? j - N / 2 : j];
@@ -296,7 +297,7 @@ template <int N, bool TWH, int S, typename F> __device__ __forceinline__ C2<F> l
         w = tw[j];
     }
     if (S > 0) w.y = -w.y;              // the table holds e^{-2 pi i j / N}
-    return w;
+    return C2<F>{(F) w.x, (F) w.y};
 }
 
 // One Cooley-Tukey stage of radix R on this thread's values, in registers.
@@ -307,8 +308,8 @@ template <int N, bool TWH, int S, typename F> __device__ __forceinline__ C2<F> l
 //   in : values (kprev, ts*M + t), ts < R  [registers v[q*R + ts]]
 //   out: values (kprev + PP*k, t) * W_MP^{t k} in v[q*R + k] (to be scattered to LDS index b + (N/R)*k), or, for
 //        the last stage (M == 1), in register slot q + NB*k which is row tau + T*slot.
-template <int R, int PP, int N, int E, int S, bool LAST, bool TWH, typename F>
-__device__ __forceinline__ void butterflies(C2<F> *v, const C2<F> *tw, int tau)
+template <int R, int PP, int N, int E, int S, bool LAST, bool TWH, typename F, typename TF = F>
+__device__ __forceinline__ void butterflies(C2<F> *v, const C2<TF> *tw, int tau)
 {
     constexpr int T = N / E, MP = N / PP, M = MP / R, NBF = N / R, NB = (NBF + T - 1) / T;
     static_assert(!LAST || (NB * R == E && NBF % T == 0 && M == 1), "the last radix must be 2, 4, 8 or 16");
@@ -326,7 +327,7 @@ __device__ __forceinline__ void butterflies(C2<F> *v, const C2<F> *tw, int tau)
 #pragma unroll
         for (int k = 0; k < R; k++) {
             C2<F> val = w[k];
-            if (!LAST && k > 0) val = cmul(val, load_tw<N, TWH, S>(tw, t * k * PP));     // t k PP < N
+            if (!LAST && k > 0) val = cmul(val, load_tw<N, TWH, S, F>(tw, t * k * PP));  // t k PP < N
             if (LAST) out[q + NB * k] = val;
             else v[q * R + k] = val;
         }
@@ -493,8 +494,8 @@ __device__ __forceinline__ void exchange(C2<F> *v, void *lds, int tau, int c)
 
 // Full length-N transform of the E register values of each thread.  In: v[in_slot<PL>(j)] = row tau + T*j; out:
 // v[j] = row tau + T*j, natural order.  The LDS area must be free on entry (barrier) and is free on return.
-template <typename PL, int S, int CW, bool SP, typename F, int SK = 0, bool WS = false, bool XS = false>
-__device__ __forceinline__ void fft_core(C2<F> *v, void *lds, const C2<F> *tw, int tau, int c)
+template <typename PL, int S, int CW, bool SP, typename F, int SK = 0, bool WS = false, bool XS = false, typename TF = F>
+__device__ __forceinline__ void fft_core(C2<F> *v, void *lds, const C2<TF> *tw, int tau, int c)
 {
     static_assert(!XS || (WS && CW < 0 && !SP), "skewed exchanges are for the wave-local row-major regions");
     constexpr int N = PL::N, E = PL::E, R1 = PL::R1, R2 = PL::R2, R3 = PL::R3, R4 = PL::R4;
@@ -535,8 +536,8 @@ template <typename F> __device__ __forceinline__ C2<F> r2c_untangle(C2<F> a, C2<
 // A c2r transform reads only the real parts of X[0] and X[N/2] (FFTW, pocketfft and rocFFT all do): with the exact
 // i k gradient (3_2, EASTWOOD, NAIVE) the Nyquist entry of a row does carry an imaginary part.
 // Two barriers; the lds area is free again on return.
-template <typename PL, int RW, int SK, typename F, bool WS = false>
-__device__ __forceinline__ void c2r_prepare(C2<F> *v, C2<F> *x, C2<F> xm, C2<F> *lds, const C2<F> *twn, int tau, int c)
+template <typename PL, int RW, int SK, typename F, bool WS = false, typename TF = F>
+__device__ __forceinline__ void c2r_prepare(C2<F> *v, C2<F> *x, C2<F> xm, C2<F> *lds, const C2<TF> *twn, int tau, int c)
 {
     constexpr int M = PL::N, T = PL::T, E = PL::E;
     if (tau == 0) { x[0].y = 0; xm.y = 0; }
@@ -551,7 +552,7 @@ __device__ __forceinline__ void c2r_prepare(C2<F> *v, C2<F> *x, C2<F> xm, C2<F> 
         C2<F> bq = lds[lds_pos<RW, SK>(M - k, c)];         // X[M-k]  (k = 0 pairs with X[M])
         bq.y = -bq.y;
         const C2<F> s = cadd(a, bq), d = csub(a, bq);
-        const C2<F> w = {twn[k].x, -twn[k].y};             // conj W_N^k
+        const C2<F> w = {(F) twn[k].x, (F) -twn[k].y};     // conj W_N^k
         const C2<F> o = cmul(w, d);
         v[in_slot<PL>(j)] = C2<F>{s.x - o.y, s.y + o.x};   // s + i o
     }

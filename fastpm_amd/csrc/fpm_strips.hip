@@ -719,6 +719,182 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (PL::E == 4 ? FPM_RO
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// fp32 on the long rows: TWO ROWS per wave (round 5; M = 1024 and 1536, the 2048^3 / 3072^3 meshes of configs[3] / [4])
+// ------------------------------------------------------------------------------------------------------------------
+// At M >= 1024 a row is one wave with E = 16 / 24 values per thread, and the fp32 kernel issued as many instructions per
+// row as the fp64 one for half the bytes (3072^3: 35.5 ms in fp32, 46.6 in fp64; 0.17 of the HBM peak).  The column
+// passes met the same wall in round 4 and got out of it by giving a thread a PAIR of columns (f32x2); here a wave takes
+// a pair of ROWS: C2<f32x2> = {(re_a, re_b), (im_a, im_b)} is one 16-byte value, the transform is the fp64 kernel's
+// instruction stream in packed fp32 arithmetic, and the five rows of a window plane are three waves instead of five
+// (the third carries the halo row alone).  The twiddle tables stay float (one entry serves both lanes).  Same products
+// in the same order per row as readout_march_kernel<.., float, true, true>: bit-identical results (parity against the
+// small cube at per-rank size unchanged to the digit: 1.89e-6 / 6.72e-6).
+// MEASURED, one rank of eight (profiles/r05_rows2_ab.md), and NOT adopted -- an A/B behind FPMHIP_RO_ROWS2=1:
+//   2048^3 fp32  z c2r x 3 + readout  9.77 ms (one row per wave, E = 16, two workgroups per CU) -> 11.36 (335 VGPRs, no spills,
+//                one workgroup of three waves per CU); with a 256-VGPR cap for two workgroups: 12.0 (PF 3, 20 spilled) / 14.7 (PF 4, 43)
+//   3072^3 fp32  35.5 ms (E = 24, five waves) -> 39.5 (361 VGPRs, no spills, three waves)
+// Halving the transform's instructions per row bought nothing: what these kernels lack is not issue slots but waves in flight
+// -- three waves per CU hide less of the row loads and of the particles' scattered window reads than five do.  The fp32
+// column passes gained from pairs because their workgroups kept their wave count; here the pairs ARE the wave count.
+#ifndef FPM_RO2_PF16
+#define FPM_RO2_PF16 6
+#endif
+#ifndef FPM_RO2_MINW16
+#define FPM_RO2_MINW16 1
+#endif
+#ifndef FPM_RO2_PF24
+#define FPM_RO2_PF24 3
+#endif
+template <typename PL> struct Rows2Cfg {
+    using CX = StripCfg<PL, double>;               // 16-byte exchange elements: the fp64 kernel's layout of a row's region
+    static constexpr int M = PL::N, NPR = (STRIP_RW + 1) / 2, threads = PL::T * NPR, pitch = CX::ro_pitch;
+    static constexpr size_t twb = (size_t) (PL::TWN + M) * sizeof(C2<float>);
+    static constexpr size_t lds = twb + (size_t) NPR * pitch * sizeof(C2<f32x2>);
+};
+template <typename PL>
+__global__ __launch_bounds__((Rows2Cfg<PL>::threads), (PL::E == 16 ? FPM_RO2_MINW16 : 1)) void readout_march_rows2_kernel(
+    MeshGeo g, int ncomp, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
+    const double *__restrict__ sy, const double *__restrict__ sz, const C2<float> *__restrict__ m0,
+    const C2<float> *__restrict__ m1, const C2<float> *__restrict__ m2, float *__restrict__ out, int nmemb, int memb0,
+    const double *__restrict__ tw_global, double *__restrict__ part_all, long long part_stride, const int2 *__restrict__ scell)
+{
+    using F = float;
+    using FX = f32x2;
+    using R2 = Rows2Cfg<PL>;
+    using CX = typename R2::CX;
+    constexpr int M = PL::N, RW = STRIP_RW, T = PL::T, E = PL::E, NT = R2::threads, RP = R2::pitch, WP = 2 * RP;
+    static_assert(T == 64, "a pair of rows is one wave");
+    extern __shared__ __align__(16) unsigned char smem_st[];
+    C2<F> *tw = (C2<F> *) smem_st;
+    C2<F> *twn = tw + PL::TWN;
+    C2<FX> *SX = (C2<FX> *) (twn + M);             // [NPR][RP] 16-byte values: pair cp's exchange region ...
+    C2<F> *S = (C2<F> *) SX;                       // ... = the window rows 2 cp, 2 cp + 1 of RP complex floats each
+    constexpr int CWX = -RP;
+    const int tid = threadIdx.x, cp = tid / T, tau = tid % T, ca = 2 * cp, cb = 2 * cp + 1;
+    const bool has_b = cb < RW;
+    const int nseg = (g.xl + g.xseg - 1) / g.xseg;
+    const int t = xcd_remap(blockIdx.x, ncomp * g.ntyo * nseg);
+    const int comp = t % ncomp, strip = (t / ncomp) % g.ntyo, seg = nseg - 1 - t / (ncomp * g.ntyo);      // last segment first
+    const C2<F> *mesh = comp == 0 ? m0 : (comp == 1 ? m1 : m2);
+    double *part = part_all + comp * part_stride;
+    const int xa = seg * g.xseg, xb = min(xa + g.xseg, g.xl);
+    const int y0 = strip * STRIP_Y;
+    int gya = y0 + ca, gyb = y0 + (has_b ? cb : ca);
+    gya -= gya >= g.N ? g.N : 0;
+    gyb -= gyb >= g.N ? g.N : 0;
+    const C2<F> *rowa = uniform_ptr(mesh + (long long) gya * g.rp), *rowb = uniform_ptr(mesh + (long long) gyb * g.rp);
+    const long long pstride = (long long) g.yplanes * g.rp;
+
+    C2<FX> x[E], xm;
+    auto load_plane = [&](int xp) {                // plane xl of a slab is the halo plane the next rank sent
+        if (g.periodic_x) xp -= xp >= g.N ? g.N : 0;
+        const C2<F> *sa = rowa + (long long) xp * pstride, *sb = rowb + (long long) xp * pstride;
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const C2<F> a = ld_stream(&sa[tau + T * j]), b = ld_stream(&sb[tau + T * j]);
+            x[j] = C2<FX>{FX{a.x, b.x}, FX{a.y, b.y}};
+        }
+        const C2<F> am = tau == 0 ? sa[M] : C2<F>{0, 0}, bm = tau == 0 ? sb[M] : C2<F>{0, 0};
+        xm = C2<FX>{FX{am.x, bm.x}, FX{am.y, bm.y}};
+    };
+    auto c2r_plane = [&]() {                       // x[] -> the real rows ca, cb of the plane in S (rowfft_c2r_kernel's arithmetic per lane)
+        C2<FX> v[vmax(E)];
+        c2r_prepare<PL, CWX, CX::ws_sk, FX, true>(v, x, xm, SX, twn, tau, cp);
+        fft_core<PL, +1, CWX, false, FX, CX::ws_sk, true, CX::ro_xs>(v, SX, tw, tau, cp);
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            S[ca * RP + tau + T * j] = C2<F>{v[j].x.x, v[j].y.x};
+            if (has_b) S[cb * RP + tau + T * j] = C2<F>{v[j].x.y, v[j].y.y};
+        }
+        if (tau == 0) {                                            // value N of a row = value 0: the z + 1 corner needs no wrap
+            S[ca * RP + M].x = v[0].x.x;
+            if (has_b) S[cb * RP + M].x = v[0].x.y;
+        }
+    };
+    // acc + the four corners of the window's plane (x bit `bx`), in the reference's order
+    const F *rs = (const F *) S;
+    auto half = [&](double qx, double qy, double qz, int qc, int bx, double acc) -> double {      // D and base cell of the entry
+        const StripEntry cc = strip_entry(g, qx, qy, qz, qc);
+        const int ly = cc.iy0 - y0, lz = cc.iz0;
+        const double wxb = bx ? cc.d[0] : cc.t[0];
+        const double wy[2] = {cc.t[1], cc.d[1]}, wz[2] = {cc.t[2], cc.d[2]};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int by = (k >> 1) & 1, bz = k & 1;
+            acc += (double) rs[(ly + by) * WP + lz + bz] * (wz[bz] * wxb * wy[by]);
+        }
+        return acc;
+    };
+    constexpr int PF = E == 16 ? FPM_RO2_PF16 : FPM_RO2_PF24;
+    double px[PF], py[PF], pz[PF], pv[PF], qx[PF], qy[PF], qz[PF];
+    int prow[PF], qrow[PF], pc[PF], qc[PF];
+    int pb = 0, pn = 0, qb = 0, qn = 0;            // p: the particles that finish this step; q: those that start
+    int kb_next = 0, kn_next = 0;
+    auto fetch_key = [&](int xi) {
+        const int key = xi * g.nty + strip;
+        kb_next = tbeg[key];
+        kn_next = tcnt[key];
+    };
+    auto fetch_q = [&](int xi) {
+        qb = kb_next;
+        qn = kn_next;
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int e = tid + u * NT;
+            qx[u] = qy[u] = qz[u] = 0;
+            qrow[u] = qc[u] = 0;
+            if (e < qn) {
+                qx[u] = sx[qb + e]; qy[u] = sy[qb + e]; qz[u] = sz[qb + e];
+                const int2 rc = scell[qb + e];                     // (row, base cell)
+                qrow[u] = rc.x; qc[u] = rc.y;
+            }
+        }
+        if (xi + 1 < xb) fetch_key(xi + 1);
+    };
+    auto start_q = [&]() {                         // q -> p with the first four terms
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            px[u] = qx[u]; py[u] = qy[u]; pz[u] = qz[u]; prow[u] = qrow[u]; pc[u] = qc[u];
+            pv[u] = tid + u * NT < qn ? half(qx[u], qy[u], qz[u], qc[u], 0, 0.0) : 0.0;
+        }
+        for (int e = tid + PF * NT; e < qn; e += NT) part[qb + e] = half(sx[qb + e], sy[qb + e], sz[qb + e], scell[qb + e].y, 0, 0.0);
+        pb = qb;
+        pn = qn;
+    };
+    auto finish_p = [&]() {
+#pragma unroll
+        for (int u = 0; u < PF; u++)
+            if (tid + u * NT < pn)
+                out[(long long) prow[u] * nmemb + memb0 + comp] = (float) half(px[u], py[u], pz[u], pc[u], 1, pv[u]);
+        for (int e = tid + PF * NT; e < pn; e += NT) {
+            const int2 rc = scell[pb + e];
+            out[(long long) rc.x * nmemb + memb0 + comp] = (float) half(sx[pb + e], sy[pb + e], sz[pb + e], rc.y, 1, part[pb + e]);
+        }
+    };
+
+    // the LATE order of readout_march_kernel: a plane's rows are requested right before their transform, the next
+    // plane's entries after it -- neither set of registers is held across the transform
+    load_plane(xa);
+    fetch_key(xa);
+    fetch_q(xa);
+    stage_twiddles(tw, tw_global, PL::TWN, 2);
+    stage_twiddles(twn, tw_global, M, 1);
+    __syncthreads();
+    c2r_plane();
+    __syncthreads();
+    start_q();
+    for (int i = xa; i < xb; i++) {                // the window goes from plane i to plane i + 1
+        load_plane(i + 1);
+        __syncthreads();                           // every gather from plane i is done
+        c2r_plane();
+        __syncthreads();
+        if (i + 1 < xb) fetch_q(i + 1);
+        finish_p();
+        if (i + 1 < xb) start_q();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // readout with ONE plane in LDS and the THREE COMPONENTS in one workgroup (round 4; the default at N = 256, 512, 1024)
 // ------------------------------------------------------------------------------------------------------------------
 // readout_march_kernel runs one workgroup per (segment, strip, COMPONENT): the entries of a tile are read three times, the
@@ -1308,6 +1484,7 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
     // the three components in one workgroup (readout_march3_kernel; the default where it is instantiated): FPMHIP_RO3 = 0
     // (one workgroup per component, A/B) | 1 (LATE order) | 2 (rows a step ahead); default: LATE but for fp32 at M <= 256
     static const int ro3 = getenv("FPMHIP_RO3") ? atoi(getenv("FPMHIP_RO3")) : -1;
+    static const int rows2_env = getenv("FPMHIP_RO_ROWS2") ? atoi(getenv("FPMHIP_RO_ROWS2")) : 0;      // A/B, see the kernel
     // the half sums of a dense tile's entries beyond the first two per thread: one double per own entry and component
     const long long part_stride = p->ro_part_elems;
 #define CALL_RO_W(PL, WS_)                                                                                             \
@@ -1360,6 +1537,18 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
             (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride,          \
             p->scell, pen);                                                                                            \
     }
+/* fp32, M = 1024 / 1536: two rows per wave (readout_march_rows2_kernel): FPMHIP_RO_ROWS2 = 1 (A/B; measured slower) */ \
+#define CALL_RO_ROWS2(PX)                                                                                              \
+    {                                                                                                                  \
+        using R2 = Rows2Cfg<PX>;                                                                                       \
+        static int occ2r = 0;                                                                                          \
+        FPM_TRY(grant_lds(readout_march_rows2_kernel<PX>, R2::lds, p->device));                                        \
+        g.xseg = choose_xseg(g, readout_march_rows2_kernel<PX>, R2::threads, R2::lds, ncomp * g.ntyo, 16, 128, &occ2r); \
+        const int nseg = (g.xl + g.xseg - 1) / g.xseg;                                                                 \
+        readout_march_rows2_kernel<PX><<<ncomp * g.ntyo * nseg, R2::threads, R2::lds, p->stream>>>(                    \
+            g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, (const C2<float> *) k0, (const C2<float> *) k1,   \
+            (const C2<float> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride, p->scell);                \
+    }
 #define CALL_RO(PL)                                                                                                    \
     if constexpr (PL::N == 256 && sizeof(F) == 8) {                                                                    \
         static const int e4_env = getenv("FPMHIP_RO_E4") ? atoi(getenv("FPMHIP_RO_E4")) : 0;                           \
@@ -1381,6 +1570,7 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
         static const int e24_env = getenv("FPMHIP_RO_E24") ? atoi(getenv("FPMHIP_RO_E24")) : 1;                        \
         if (e24_env && !pen.on && !two_planes && ws_env != 0) {                                                        \
             using PX = FFTPlan<1536, 24, 8, 3, 8, 8>;                                                                  \
+            if constexpr (sizeof(F) == 4) { if (rows2_env) { CALL_RO_ROWS2(PX) break; } }                              \
             CALL_RO_E16(PX, false)                                                                                     \
             break;                                                                                                     \
         }                                                                                                              \
@@ -1389,6 +1579,7 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
         static const int e16_env = getenv("FPMHIP_RO_E16") ? atoi(getenv("FPMHIP_RO_E16")) : 1;                        \
         if (e16_env && !two_planes && ws_env != 0) {                                                                   \
             using PX = FFTPlan<1024, 16, 16, 8, 8, 1>;                                                                 \
+            if constexpr (sizeof(F) == 4) { if (rows2_env && !pen.on) { CALL_RO_ROWS2(PX) break; } }                   \
             if (pen.on) CALL_RO_E16(PX, true) else CALL_RO_E16(PX, false)                                              \
             break;                                                                                                     \
         }                                                                                                              \
@@ -1397,6 +1588,7 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
     STRIP_DISPATCH(g.N / 2, CALL_RO)
 #undef CALL_RO
 #undef CALL_RO_E16
+#undef CALL_RO_ROWS2
 #undef CALL_RO_W
 #undef CALL_RO_P
     FPM_CHECK_HIP(hipGetLastError());

@@ -278,6 +278,8 @@ void fastpm_hip_host_touched(const void *host)
 
 int fastpm_hip_host_is_stale(const void *host)
 {
+    /* a recorded, not yet executed update of this column counts: the device copy WILL be the newer one */
+    if (host && !pend.busy && ((pend.nk && host == pend.v) || (pend.nd && host == pend.x))) return 1;
     Twin *t = find(host);
     check_tag(t);
     return t && t->state == ST_DEV_NEWER;

@@ -37,8 +37,11 @@ fastpm_store_wrap(FastPMStore * p, double BoxSize[3])
 {
     fpmhip_plan * plan = fastpm_hip_resident_enabled() ? fastpm_hip_current_plan() : NULL;
     PM * pm = fastpm_hip_current_pm();
-    if(!plan || !p->x || BoxSize[0] != pm->BoxSize[0] || BoxSize[1] != pm->BoxSize[1] || BoxSize[2] != pm->BoxSize[2]) {
-        /* before the first force (2LPT, solver.c:237), or another box than the plan's: the host loop, on host data */
+    if(!plan || !p->x || BoxSize[0] != pm->BoxSize[0] || BoxSize[1] != pm->BoxSize[1] || BoxSize[2] != pm->BoxSize[2]
+            || !fastpm_hip_host_is_stale(&p->x[0][0])) {
+        /* before the first force (2LPT, solver.c:237), another box than the plan's, or positions whose LIVE copy is the
+         * host's -- an interpolated snapshot store (fastpm_set_species_snapshot, solver.c:647-700: its drift handed the
+         * column to the host, its writer reads po->x right after this wrap): the host loop, on host data */
         fastpm_hip_store_sync(p, COLUMN_POS);
         fastpm_store_wrap_cpu(p, BoxSize);
         fastpm_hip_store_touched(p, COLUMN_POS);

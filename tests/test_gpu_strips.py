@@ -288,3 +288,33 @@ def test_three_components_per_workgroup_repeat_the_per_component_kernel(oracle, 
     if N == 256:
         ref = oracle.compute_force(oracle.PMOracle(N, L, precision), x)
         assert util.rel_err(acc[1], ref["acc"]) <= TOL_ACC[precision]
+
+
+@pytest.mark.parametrize("N,precision,paint_mode", [(64, 64, 3), (64, 32, 0), (192, 32, 0)])
+def test_hipgraph_replay_of_the_force_call_is_the_same_force(oracle, tmp_path, N, precision, paint_mode):
+    """FPMHIP_GRAPH=1 (fpm_force.hip; an opt-in A/B: measured slower, profiles/r05_graph_ab.jsonl): the steady-state force
+    call captured on the plan's own stream, the executable graph updated and launched per call.  Same kernels, same
+    arguments: the accelerations of calls 3 and 4 (moved particles, alternating position sets) must be the oracle's, and
+    the plan must have launched graphs.  A child process: the switch is read once."""
+    import os
+    import subprocess
+    import sys
+    nc, L = N // 2, 1.5 * N
+    xa = util.load_a(nc, L, N)
+    xb = np.remainder(xa + np.random.default_rng(2).normal(0, 0.05 * L / N, xa.shape), L)
+    np.save(tmp_path / "xa.npy", xa)
+    np.save(tmp_path / "xb.npy", xb)
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); from fastpm_amd import PM, Store\n"
+            "xa, xb = np.load(%r), np.load(%r); pm = PM(%d, %r, %d, paint_mode=%d); sa, sb = Store(xa, potential=True), Store(xb, potential=True)\n"
+            "for i in range(4): pm.compute_force(sa if i %% 2 == 0 else sb, kernel='1_4', total_mass=float(len(xa)))\n"
+            "pm.sync(); np.save(%r, sa.acc.cpu().numpy()); np.save(%r, sb.acc.cpu().numpy()); np.save(%r, sb.potential.cpu().numpy())\n"
+            % (ROOT, str(tmp_path / "xa.npy"), str(tmp_path / "xb.npy"), N, L, precision, paint_mode,
+               str(tmp_path / "a.npy"), str(tmp_path / "b.npy"), str(tmp_path / "p.npy")))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FPMHIP_GRAPH="1"), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    pmo = oracle.PMOracle(N, L, precision)
+    ra, rb = oracle.compute_force(pmo, xa), oracle.compute_force(pmo, xb, potential=True)
+    assert util.rel_err(np.load(tmp_path / "a.npy"), ra["acc"]) <= TOL_ACC[precision]
+    assert util.rel_err(np.load(tmp_path / "b.npy"), rb["acc"]) <= TOL_ACC[precision]
+    # (an fp32 mesh holds the potential to ~1e-5 of its rms at N = 192: the same figure without the graph)
+    assert util.rel_err(np.load(tmp_path / "p.npy"), rb["potential"]) <= (TOL_ACC[64] if precision == 64 else 1e-4)
