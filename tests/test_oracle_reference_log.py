@@ -89,3 +89,14 @@ def test_ranlxd1_stream_is_a_uniform_48_bit_stream():
     assert (s >= 0).all() and (s < 1).all()
     assert np.all(s * 2.0 ** 48 == np.floor(s * 2.0 ** 48))          # 48-bit mantissas
     assert abs(s.mean() - 0.5) < 0.02
+
+
+def test_nbodykit_lua_rsd_factor_pins_the_expansion_rate():
+    """tests/run-test-nbodykit.sh:13 of the reference greps 'RSD factor.*1.140331e-02' (libfastpmio/io.c:254-256:
+    1 / (100 a E(a)) at the z = 0.5 output of tests/nbodykit.lua, Omega_m = 0.307494) -- the only other line of that test
+    that needs no FOF (its 'sigma8 0.815897' is the input-table line pinned above; the two 'Writing N objects.' lines count
+    FOF halos, out of scope).  It pins HubbleEa, which every growth factor and every kick / drift table of the runs above is
+    built from."""
+    cosmo = R.Cosmology(0.307494)
+    a = 1.0 / 1.5
+    assert "%e" % (1.0 / (100.0 * a * cosmo.E(a))) == "1.140331e-02"
