@@ -324,8 +324,9 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
         // (the kernels address a row's kz blocks with 32-bit byte offsets -- element offsets at N = 2048 -- and expect one
         // block boundary per register slot)
         const long long pen_span = (long long) Ny * L.chunk_a_elems * (long long) p->esize;            // bytes
-        const bool pen_ok = Ny == 1 || (!pen_off && (N & (N - 1)) == 0 && ylr % STRIP_Y == 0 && zblk >= N / 16 &&
-                                        pen_span < (N == 2048 ? (1ll << 32) * 2 * (long long) p->esize : (1ll << 32)));
+        // (round 5: N = 3072 too -- configs[4] at B = 3 on the reference's 4 x 2 -- with the one-wave-per-row kernels of M = 1536)
+        const bool pen_ok = Ny == 1 || (!pen_off && ((N & (N - 1)) == 0 || N == 3072) && ylr % STRIP_Y == 0 && zblk >= N / 16 &&
+                                        pen_span < (N >= 2048 ? (1ll << 32) * 2 * (long long) p->esize : (1ll << 32)));
         const bool can = pen_ok && geom->fft_mode == FPMHIP_FFT_AUTO && colfft_supported((int) N) &&
                          strips_supported((int) N, geom->precision) && geom->gradient_mode == FPMHIP_GRADIENT_KSPACE;
         if (geom->paint_mode == FPMHIP_PAINT_STRIPS && !can)

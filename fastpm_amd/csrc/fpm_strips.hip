@@ -325,7 +325,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), (sizeof(F) == 4 && P
         if constexpr (PEN && WS && T == 64) dst = uniform_ptr(dst);      // one row per wave
         const unsigned pjump = PEN ? (unsigned) (pen.chunk - g.zblk) : 0u;
         auto at = [&](int kbase, int t_) -> C2<F> * {                  // element kbase + t_, kbase uniform
-            if constexpr (PEN) return pen_elem<T, F, (M == 1024)>(dst, chunked, kbase, t_, g.zblk, pen.inv24, pjump);
+            if constexpr (PEN) return pen_elem<T, F, (M >= 1024)>(dst, chunked, kbase, t_, g.zblk, pen.inv24, pjump);
             return dst + kbase + t_;
         };
 #pragma unroll
@@ -576,8 +576,8 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (PL::E == 4 ? FPM_RO
             const unsigned pjump = (unsigned) (pen.chunk - g.zblk);
 #pragma unroll
             for (int j = 0; j < E; j++)
-                x[j] = ld_stream(pen_elem<T, F, (M == 1024)>(const_cast<C2<F> *>(src), chunked, T * j, tau, g.zblk, pen.inv24, pjump));
-            xm = tau == 0 ? *pen_elem<T, F, (M == 1024)>(const_cast<C2<F> *>(src), chunked, M, 0, g.zblk, pen.inv24, pjump) : C2<F>{0, 0};
+                x[j] = ld_stream(pen_elem<T, F, (M >= 1024)>(const_cast<C2<F> *>(src), chunked, T * j, tau, g.zblk, pen.inv24, pjump));
+            xm = tau == 0 ? *pen_elem<T, F, (M >= 1024)>(const_cast<C2<F> *>(src), chunked, M, 0, g.zblk, pen.inv24, pjump) : C2<F>{0, 0};
             return;
         }
         const C2<F> *src = rowbase + (long long) xp * pstride;
@@ -1342,7 +1342,7 @@ static int paint_strips_launch(fpmhip_plan *p, const fpmhip_particles *pt, doubl
 // (pencil instantiations: the power-of-two meshes only -- fpm_plan.hip offers strip tiles on pencils there)
 #define CALL_PM_W(PL, WS_)                                                                                             \
     if (g.periodic_y) CALL_PM_P(PL, WS_, false)                                                                        \
-    else if constexpr ((PL::N & (PL::N - 1)) == 0) CALL_PM_P(PL, WS_, true)                                            \
+    else if constexpr ((PL::N & (PL::N - 1)) == 0 || PL::N == 1536) CALL_PM_P(PL, WS_, true)                                            \
     else FPM_FAIL(-1, "internal: no pencil strip kernels for Nmesh = %d", 2 * PL::N);
 #define CALL_PM_P(PL, WS_, PEN_)                                                                                       \
     {                                                                                                                  \
@@ -1489,7 +1489,7 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
     const long long part_stride = p->ro_part_elems;
 #define CALL_RO_W(PL, WS_)                                                                                             \
     if (!pen.on) CALL_RO_P(PL, WS_, false)                                                                             \
-    else if constexpr ((PL::N & (PL::N - 1)) == 0) CALL_RO_P(PL, WS_, true)                                            \
+    else if constexpr ((PL::N & (PL::N - 1)) == 0 || PL::N == 1536) CALL_RO_P(PL, WS_, true)                                            \
     else FPM_FAIL(-1, "internal: no pencil strip kernels for Nmesh = %d", 2 * PL::N);
 #define CALL_RO_P(PL, WS_, PEN_)                                                                                       \
     {                                                                                                                  \
@@ -1568,10 +1568,10 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
     }                                                                                                                  \
     if constexpr (PL::N == 1536) {                                                                                     \
         static const int e24_env = getenv("FPMHIP_RO_E24") ? atoi(getenv("FPMHIP_RO_E24")) : 1;                        \
-        if (e24_env && !pen.on && !two_planes && ws_env != 0) {                                                        \
+        if (e24_env && !two_planes && ws_env != 0) {                                                                   \
             using PX = FFTPlan<1536, 24, 8, 3, 8, 8>;                                                                  \
-            if constexpr (sizeof(F) == 4) { if (rows2_env) { CALL_RO_ROWS2(PX) break; } }                              \
-            CALL_RO_E16(PX, false)                                                                                     \
+            if constexpr (sizeof(F) == 4) { if (rows2_env && !pen.on) { CALL_RO_ROWS2(PX) break; } }                   \
+            if (pen.on) CALL_RO_E16(PX, true) else CALL_RO_E16(PX, false)                                              \
             break;                                                                                                     \
         }                                                                                                              \
     }                                                                                                                  \
@@ -1649,7 +1649,7 @@ static int pen_io(fpmhip_plan *p, void *const *hx, void *const *hy, int n, PenIO
     // the kernels' 32-bit byte offsets inside a row's chunks, and one block boundary at most per register slot
     // (N = 2048: element offsets, widened for the address -- pen_elem<.., BIG>)
     const long long span = (long long) p->lay.nranks_y * pen->chunk * (long long) (2 * p->esize);
-    if (span >= (p->mg.N == 2048 ? (1ll << 32) * 2 * (long long) p->esize : (1ll << 32)) || p->mg.zblk < p->mg.N / 16)
+    if (span >= (p->mg.N >= 2048 ? (1ll << 32) * 2 * (long long) p->esize : (1ll << 32)) || p->mg.zblk < p->mg.N / 16)
         FPM_FAIL(-1, "pencil strip plans: the exchange chunks of a row must lie within 4 GB and a kz block must hold N / 16 modes");
     for (int i = 0; i < n; i++) {
         if (!hy || !hy[i]) FPM_FAIL(-1, "null y-halo rows");

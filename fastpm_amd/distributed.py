@@ -83,7 +83,9 @@ class _SlabRank:
         overflow) is reported after the paint's agreement point: synchronise, ask, and agree once more at the end of the
         step -- no rank leaves with an invalid acc while its peers carry on into the next collective.  `err`: what this
         rank's sequence raised, if anything -- the all-reduce is entered all the same (a failure that was agreed on
-        earlier was raised on every rank; a rank-local one after the paint must not leave the peers waiting here)."""
+        earlier was raised on every rank; a rank-local one after the LAST collective must not leave the peers waiting here.
+        A rank that fails between two collectives of the sequence is not covered: its exception ends the process and the
+        job, as fastpm_raise -> MPI_Abort ends the reference's)."""
         if self.late_check and self.P > 1:
             def action():
                 if err is not None:

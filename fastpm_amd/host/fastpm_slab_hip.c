@@ -688,8 +688,11 @@ int fastpm_hip_mesh_force_species(fpmhip_plan *plan, const fastpm_hip_transport 
          * step, a slab overflow) arrives after the paint's agreement point: ask for it now and agree again, so that no
          * rank leaves with rc = 0 and an invalid acc while its peers carry on into the next collective.  EVERY rank
          * enters this all-reduce, whatever its rc: a failure agreed on in the paint left every rank with one, and a
-         * rank-local failure after it (an allocation, a kernel launch, a transport error) must not leave the peers
-         * waiting here for a rank that returned early. */
+         * rank-local failure after the LAST collective of the sequence must not leave the peers waiting here for a rank
+         * that returned early.  (Not covered, by design: a rank that fails BETWEEN two collectives of the sequence -- a
+         * transport error, a launch failure -- comes straight here while its peers sit in the next exchange.  The binding
+         * turns the nonzero rc into fastpm_raise, which aborts the communicator as the reference's does,
+         * logging.c:242-251: that is what releases the peers.) */
         const int late = rc == 0 ? fpmhip_sync(plan) : 0;
         double failed = rc != 0 || late != 0;
         if (t->allreduce_sum(t->ctx, &failed) != 0 || failed != 0) rc = rc ? rc : (late ? late : -8);

@@ -250,7 +250,8 @@ def test_config4_variable_mesh_steps_with_pk_at_per_rank_size(tmp_path):
         assert len(text) == 1 + N // 2 + 8
 
 
-@pytest.mark.parametrize("N,precision,paint_mode", [(256, 64, 3), (256, 64, 2), (256, 32, 3), (1024, 64, 0), (2048, 64, 0)])
+@pytest.mark.parametrize("N,precision,paint_mode", [(256, 64, 3), (256, 64, 2), (256, 32, 3), (1024, 64, 0), (2048, 64, 0),
+                                                     (3072, 32, 0)])
 def test_one_pencil_rank_of_the_4x2_mesh_at_per_rank_size(N, precision, paint_mode):
     """Rank (1, 1) of the reference's 4 x 2 process mesh (pmpfft.c:117-136) in a universe periodic with period L/4
     (tests/rank_share.py: ReplicatedPencilForce): every stage kernel at the brick's true geometry -- at N = 1024 that of
@@ -261,14 +262,21 @@ def test_one_pencil_rank_of_the_4x2_mesh_at_per_rank_size(N, precision, paint_mo
     import rank_share
     import gc
     need = 16 * (N ** 3 // 8) * (precision // 8) * 1.2
+    if N == 3072:
+        # configs[4] at B = 3 on the reference's 4 x 2 (round 5: strip tiles there too, the one-wave-per-row kernels of M = 1536
+        # on the exchange chunks with element offsets): measured to fit (tools/rank_share_bench.py 3072 32 128 0 pencil,
+        # profiles/r05_rankshare_pencil_3072_32.json); the cube is 128^3 particles on 384^3 cells
+        need = 250e9
     gc.collect()
     torch.cuda.empty_cache()
     if torch.cuda.mem_get_info()[0] < need:
         pytest.skip("needs %.0f GB of free device memory" % (need / 1e9))
-    acc, ref, _, copies, strips = rank_share.run_pencil_share(N, 4, 2, precision, paint_mode=paint_mode)
+    acc, ref, _, copies, strips = rank_share.run_pencil_share(N, 4, 2, precision, paint_mode=paint_mode,
+                                                              ncube=128 if N == 3072 else None)
     assert strips == (paint_mode != 2)
     n = ref.shape[0]
     rms = float(ref.double().pow(2).mean().sqrt())
     err = float((acc.view(copies, n, 3).double() - ref.double()[None]).abs().max()) / rms
     # (float32 acc: the largest of 1.07e9 rounding errors, against the rms; the box-tile path gives the same 2.7e-7 at N = 2048)
-    assert err <= ((2e-7 if N <= 1024 else 4e-7) if precision == 64 else 1e-5), err
+    # (N = 3072 is the B = 3 load, one particle per 27 cells on an fp32 mesh: 5.0e-5 on strip AND on box tiles)
+    assert err <= ((2e-7 if N <= 1024 else 4e-7) if precision == 64 else (1e-5 if N < 3072 else 1e-4)), err
