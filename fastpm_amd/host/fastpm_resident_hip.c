@@ -301,6 +301,7 @@ void fastpm_hip_mirror_release(const void *host)
 
 void fastpm_hip_mirror_release_all(void)
 {
+    (void) flush_pending(0, NULL);          /* a recorded update runs on the twins it was recorded for, not on fresh uploads */
     while (twins) fastpm_hip_mirror_release(twins->host);
 }
 

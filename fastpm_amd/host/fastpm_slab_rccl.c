@@ -126,7 +126,11 @@ static int rccl_xchg_wait(void *ctx, int tag)
 
 static int rccl_bind_plan(void *ctx, fpmhip_plan *plan)
 {
-    ((rccl_ctx *) ctx)->plan = plan;
+    rccl_ctx *c = ctx;
+    c->plan = plan;
+    /* a new force call: exchanges a FAILED earlier call began and never waited for have long run on the transport's
+     * stream (or died with it); their tags are free again */
+    for (int i = 0; i < FASTPM_HIP_MAX_TAGS; i++) c->active[i] = 0;
     return 0;
 }
 
