@@ -157,6 +157,16 @@ static int upload(Twin *t, size_t bytes)
     return 0;
 }
 
+static int mirror_check(void)
+{
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("FASTPM_HIP_MIRROR_CHECK");
+        on = e && atoi(e) != 0;
+    }
+    return on;
+}
+
 static void *twin_in(fpmhip_plan *plan, const void *host, size_t bytes, int kind)
 {
     if (!plan) return fail("no plan", host);
@@ -170,6 +180,17 @@ static void *twin_in(fpmhip_plan *plan, const void *host, size_t bytes, int kind
     if (reserve(t, bytes) != 0) return fail("device allocation failed", host);
     if (t->state == ST_HOST_NEWER || (t->state == ST_SAME && bytes > t->valid)) {
         if (upload(t, bytes) != 0) return fail("upload failed", host);
+    } else if (t->state == ST_SAME && kind == KIND_PLAIN && mirror_check()) {
+        /* FASTPM_HIP_MIRROR_CHECK=1 (debug): a twin keyed on a host address cannot see the address being freed and handed
+         * out again (libfastpm's stack allocator does that) unless fastpm_store_destroy calls fastpm_hip_store_release, nor a
+         * host write that forgot fastpm_hip_store_touched: compare the ends of what the device holds with the host's */
+        unsigned char head[64], tail[64];
+        const size_t n = t->valid < 64 ? t->valid : 64;
+        if (be->d2h(plan, head, t->dev, n) != 0 || be->d2h(plan, tail, (const char *) t->dev + t->valid - n, n) != 0)
+            return fail("mirror check: read-back failed", host);
+        if (memcmp(head, host, n) != 0 || memcmp(tail, (const char *) host + t->valid - n, n) != 0)
+            return fail("mirror check: the host buffer changed behind a twin in state SAME (a missing fastpm_hip_store_touched / "
+                        "fastpm_hip_store_release, or the address was reused)", host);
     }
     return t->dev;
 }

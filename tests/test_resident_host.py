@@ -177,3 +177,33 @@ def test_host_library_exports_the_resident_layer():
                  "fastpm_hip_resident_decic", "fastpm_hip_resident_powerspectrum", "fastpm_hip_resident_summary",
                  "fastpm_hip_lookup3"):
         assert hasattr(H, name), name
+
+
+def test_mirror_check_notices_a_host_write_behind_a_twin(tmp_path):
+    """FASTPM_HIP_MIRROR_CHECK=1 (debug aid): plain-column twins are keyed on the host address alone -- a column
+    freed and handed out again at the same address, or written by host code that forgot fastpm_hip_store_touched, would be
+    served from the stale device copy.  With the check on, the next use compares the ends of the two copies and fails
+    loudly.  The switch is read once per process: a child process with the stand-in back end."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys, ctypes, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from fastpm_amd import chost\n"
+        "from test_resident_host import FakeDevice, PLAN\n"
+        "H = chost.host_library(); d = FakeDevice(); H.fastpm_hip_mirror_set_backend(ctypes.byref(d.backend))\n"
+        "x = np.arange(300, dtype=np.float64)\n"
+        "assert H.fastpm_hip_dev_in(PLAN, x.ctypes.data, x.nbytes)            # uploaded: SAME\n"
+        "assert H.fastpm_hip_dev_in(PLAN, x.ctypes.data, x.nbytes)            # unchanged: passes the check\n"
+        "x[-1] = -5.0                                                          # a host write nobody announced\n"
+        "p = H.fastpm_hip_dev_in(PLAN, x.ctypes.data, x.nbytes)\n"
+        "print('PTR', p, H.fastpm_hip_mirror_error().decode())\n"
+        "H.fastpm_hip_host_touched(x.ctypes.data)\n"
+        "assert H.fastpm_hip_dev_in(PLAN, x.ctypes.data, x.nbytes)            # announced: uploaded again\n"
+        "H.fastpm_hip_mirror_release_all(); H.fastpm_hip_mirror_set_backend(None)\n" % (os.path.dirname(here), here))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FASTPM_HIP_MIRROR_CHECK="1"), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("PTR")][0]
+    assert line.split()[1] == "None" and "mirror check" in line
