@@ -101,7 +101,10 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const char *__restrict
     long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const long long j = order[i];
-    if (ROWB % 8 == 0) {
+    if (ROWB < 4) {                               // the mask column (uint8, store.h:9) and anything int16
+#pragma unroll
+        for (int q = 0; q < ROWB; q++) dst[i * ROWB + q] = src[j * ROWB + q];
+    } else if (ROWB % 8 == 0) {
         const long long *s = (const long long *) (src + j * ROWB);
         long long *d = (long long *) (dst + i * ROWB);
 #pragma unroll
@@ -177,6 +180,8 @@ int fpmhip_gather_rows(fpmhip_plan *p, const void *src, void *dst, const int *or
     const unsigned nb = blocks_for(n, 256);
 #define GO(B) gather_rows_kernel<B><<<nb, 256, 0, p->stream>>>((const char *) src, (char *) dst, order, n)
     switch (rowbytes) {
+    case 1: GO(1); break;
+    case 2: GO(2); break;
     case 4: GO(4); break;
     case 8: GO(8); break;
     case 12: GO(12); break;

@@ -19,6 +19,8 @@
  * that owns its x cell before the force.
  *
  * gpu_aware: 0 = MPI with host staging, 1 = GPU-aware MPI (device pointers go to MPI), 2 = RCCL (one rank per GPU).
+ * host_columns = 2: the RESIDENT store -- columns in host memory, device twins behind them (fastpm_mirror_hip.h): with
+ * decompose = 1 the rows travel GPU to GPU (fastpm_hip_resident_decompose), the force runs on the twins.
  * host_columns = 1: the store columns and delta_k stay on the host, as in today's libfastpm
  * (fastpm_hip_slab_force_host); every rank then also prints one element and the square sum of its delta_k slab,
  * which is in the reference's ORegion layout [y_loc][kz][x].
@@ -31,6 +33,7 @@
 #include <stdlib.h>
 
 #include "fastpm_gravity_hip.h"
+#include "fastpm_mirror_hip.h"
 #include "fastpm_slab_mpi.h"
 
 #define CHECK(expr) do { if ((expr) != 0) { fprintf(stderr, "rank %d: %s failed: %s\n", rank, #expr, fpmhip_last_error()); \
@@ -182,7 +185,35 @@ int main(int argc, char **argv)
                 id[np++] = (long long) i;
             }
 
-    if (decompose) {
+    unsigned char *maskcol = NULL;
+    float (*vcol)[3] = NULL;
+    if (decompose && host_columns == 2) {
+        /* RESIDENT store (what store_hip.c's fastpm_store_decompose does for NTask > 1, round 5): the columns x | id | v |
+         * mask live in HOST memory with room for every particle, their device twins do the work
+         * (fastpm_hip_resident_decompose: rows GPU to GPU through the transport), and they come home only on a sync */
+        x = realloc(x, ntot * sizeof(*x));
+        id = realloc(id, ntot * sizeof(*id));
+        vcol = malloc(ntot * sizeof(*vcol));
+        maskcol = malloc(ntot);
+        for (i = 0; i < np; i++) {
+            vcol[i][0] = (float) id[i]; vcol[i][1] = (float) id[i] + 0.5f; vcol[i][2] = -(float) id[i];
+            maskcol[i] = (unsigned char) (id[i] % 251);
+        }
+        void *hc[4] = {x, id, vcol, maskcol};
+        const int rb[4] = {24, 8, 12, 1};
+        int64_t n64 = (int64_t) np;
+        fastpm_hip_mirror_reset_stats();
+        CHECK(fastpm_hip_resident_decompose(plan, t, hc, rb, 4, &n64, (int64_t) ntot));
+        fastpm_hip_mirror_stats st0;
+        fastpm_hip_mirror_get_stats(&st0);
+        np = (size_t) n64;
+        for (int c = 0; c < 4; c++) CHECK(fastpm_hip_host_sync(hc[c]));
+        size_t bad = 0;
+        for (i = 0; i < np; i++)
+            if (OWNER(x[i][0], x[i][1]) != rank || vcol[i][0] != (float) id[i] || vcol[i][1] != (float) id[i] + 0.5f
+                || vcol[i][2] != -(float) id[i] || maskcol[i] != (unsigned char) (id[i] % 251)) bad++;
+        printf("decomposed %d np %zu bad %zu resident d2h_before_sync %llu\n", rank, np, bad, (unsigned long long) st0.d2h_bytes);
+    } else if (decompose) {
         /* columns x | id | v on the device with room for every particle; v is a function of id, so a row that
          * lost its companions on the way would show */
         void *cx = NULL, *cid = NULL, *cv = NULL;
@@ -215,7 +246,14 @@ int main(int argc, char **argv)
     float (*acc)[3] = calloc(np ? np : 1, sizeof(*acc));
     part.M0 = 1.0;
     part.np = (int64_t) np;
-    if (host_columns) {
+    if (host_columns == 2) {
+        /* the resident force for NTask > 1 as gravity_hip.c makes it: twins in, the multi-rank sequence, acc home on a sync */
+        part.x = fastpm_hip_dev_in(plan, x, (np ? np : 1) * 24);
+        part.acc = fastpm_hip_dev_out(plan, acc, (np ? np : 1) * 12);
+        if (!part.x || !part.acc) { fprintf(stderr, "rank %d: %s\n", rank, fastpm_hip_mirror_error()); MPI_Abort(MPI_COMM_WORLD, 1); }
+        CHECK(fastpm_hip_mesh_force_species(plan, t, &part, 1, FASTPM_KERNEL_1_4, FASTPM_SOFTENING_NONE, NULL));
+        CHECK(fastpm_hip_host_sync(acc));
+    } else if (host_columns) {
         fpmhip_layout lay;
         CHECK(fpmhip_plan_layout(plan, &lay));
         void *delta_k = malloc((size_t) lay.allocsize * (precision / 8));       /* pm_alloc */
@@ -266,7 +304,8 @@ int main(int argc, char **argv)
     }
     printf("rank %d owns %zu particles on device %d\n", rank, np, g.device);
 
-    free(acc); free(x); free(id);
+    fastpm_hip_mirror_release_all();
+    free(acc); free(x); free(id); free(vcol); free(maskcol);
     if (dx) fpmhip_free(dx);
     if (dacc) fpmhip_free(dacc);
     if (gpu_aware == 2) fastpm_hip_rccl_transport_destroy(t);

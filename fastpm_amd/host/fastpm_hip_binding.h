@@ -14,6 +14,8 @@ fpmhip_plan * fastpm_hip_plan_for(PM * pm);
  * (factors.c:175-197, 373-392; store.c:446-475).  NULL before the first force. */
 fpmhip_plan * fastpm_hip_current_plan(void);
 PM * fastpm_hip_current_pm(void);
+/* the exchanges of that PM's process mesh (a fastpm_hip_transport, fastpm_slab_hip.h; NULL on one rank) */
+const void * fastpm_hip_current_transport(void);
 /* 1 when factors_hip.o is linked in and FASTPM_HIP_RESIDENT is not 0: columns stay on the device between the calls */
 int fastpm_hip_resident_enabled(void);
 

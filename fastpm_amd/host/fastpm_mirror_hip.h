@@ -103,6 +103,14 @@ int fastpm_hip_resident_drift(fpmhip_plan *plan, const fpmhip_drift_factor *drif
                               const float *dx1, const float *dx2, double *x_out, int64_t np, int own_output);
 /* store.c:446-475, and the tile binning of the force call that follows it (mass: the column that call will pass) */
 int fastpm_hip_resident_wrap(fpmhip_plan *plan, double *x, const float *mass, int64_t np);
+/* fastpm_store_decompose (store.c:485-657) for NTask > 1 with every column on its twin (round 5): host_cols[0] is x
+ * (rowbytes[0] = 24); every column holds np_upper rows of capacity on the host, and its twin gets that capacity.  The rows
+ * travel GPU to GPU through the transport (fastpm_slab_hip.h: alltoall_counts + one alltoallv per column); no column
+ * crosses PCIe.  On return *np is the new count, every twin holds the reference's order (stayed | from rank 0 | ...) and is
+ * the newer copy.  -4: the arrivals do not fit np_upper (agreed on by every rank; the reference returns -1 and its caller
+ * raises "Out of particle storage space", solver.c:589).  Does NOT wrap (its caller has, solver.c:583). */
+int fastpm_hip_resident_decompose(fpmhip_plan *plan, const void *transport, void *const *host_cols, const int *rowbytes,
+                                  int ncols, int64_t *np, int64_t np_upper);
 int fastpm_hip_resident_decic(fpmhip_plan *plan, const void *from, void *to);                     /* transfer.c:77-113 */
 /* powerspectrum.c:35-111 before its Allreduce: the raw bin sums (Nmesh / 2 bins) */
 int fastpm_hip_resident_powerspectrum(fpmhip_plan *plan, const void *delta1_k, const void *delta2_k, double *ksum,

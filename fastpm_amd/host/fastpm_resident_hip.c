@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include "fastpm_resident_hip.h"
+#include "fastpm_slab_hip.h"
 
 void fpm_raise_hip(int code, const char *fmt, ...);            /* fastpm_gravity_hip.c */
 
@@ -541,6 +542,46 @@ int fastpm_hip_resident_wrap(fpmhip_plan *plan, double *x, const float *mass, in
     if (mass) NEED(p.mass = fastpm_hip_dev_in(plan, mass, (size_t) np * 4));
     p.np = np;
     return fpmhip_wrap_bin(plan, &p);
+}
+
+/* a twin for an in-place update with room for cap_bytes: what the device copy holds (valid_bytes of it) is kept */
+static void *twin_inout_cap(fpmhip_plan *plan, void *host, size_t valid_bytes, size_t cap_bytes)
+{
+    if (!plan) return fail("no plan", host);
+    if (!host) return fail("null host pointer", host);
+    if (valid_bytes == 0) valid_bytes = 1;
+    if (cap_bytes < valid_bytes) cap_bytes = valid_bytes;
+    Twin *t = find_or_add(host, KIND_PLAIN, plan);
+    if (!t) return fail("out of host memory", host);
+    if (t->state == ST_DEV_NEWER && valid_bytes > t->valid)
+        return fail("the device holds the newer copy of fewer bytes than asked for (rows were added on the host "
+                    "without fastpm_hip_host_sync / fastpm_hip_host_touched)", host);
+    const void *before = t->dev;
+    if (reserve(t, cap_bytes) != 0) return fail("device allocation failed", host);
+    if (t->dev != before && t->state == ST_SAME) t->state = ST_HOST_NEWER;     /* a regrow keeps device-NEWER data only */
+    if (t->state == ST_HOST_NEWER || (t->state == ST_SAME && valid_bytes > t->valid)) {
+        if (upload(t, valid_bytes) != 0) return fail("upload failed", host);
+    }
+    t->state = ST_DEV_NEWER;
+    return t->dev;
+}
+
+int fastpm_hip_resident_decompose(fpmhip_plan *plan, const void *transport, void *const *host_cols, const int *rowbytes,
+                                  int ncols, int64_t *np, int64_t np_upper)
+{
+    if (!plan || !transport || !host_cols || !rowbytes || !np || ncols < 1 || ncols > 32 || rowbytes[0] != 24) return -1;
+    fastpm_hip_column cols[32];
+    for (int c = 0; c < ncols; c++) {
+        if (settle(host_cols[c])) return -9;
+        cols[c].rowbytes = rowbytes[c];
+        NEED(cols[c].data_dev = twin_inout_cap(plan, host_cols[c], (size_t) *np * rowbytes[c], (size_t) np_upper * rowbytes[c]));
+    }
+    int64_t n = *np;
+    const int rc = fastpm_hip_mesh_decompose(plan, (const fastpm_hip_transport *) transport, cols, ncols, &n, np_upper, 0);
+    if (rc) return rc;
+    for (int c = 0; c < ncols; c++) find(host_cols[c])->valid = (size_t) n * rowbytes[c];
+    *np = n;
+    return 0;
 }
 
 int fastpm_hip_resident_decic(fpmhip_plan *plan, const void *from, void *to)

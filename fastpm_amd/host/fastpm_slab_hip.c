@@ -703,9 +703,15 @@ int fastpm_hip_mesh_force_species(fpmhip_plan *plan, const fastpm_hip_transport 
 int fastpm_hip_slab_decompose(fpmhip_plan *plan, const fastpm_hip_transport *t, fastpm_hip_column *cols, int ncols,
                               int64_t *np_io, int64_t np_upper)
 {
+    return fastpm_hip_mesh_decompose(plan, t, cols, ncols, np_io, np_upper, 1);
+}
+
+int fastpm_hip_mesh_decompose(fpmhip_plan *plan, const fastpm_hip_transport *t, fastpm_hip_column *cols, int ncols,
+                              int64_t *np_io, int64_t np_upper, int wrap)
+{
     if (ncols < 1 || cols[0].rowbytes != 24) return -1;
     if (t->nranks == 1) {           /* every particle stays: fastpm_store_wrap is all that is left */
-        int rc1 = fpmhip_wrap(plan, cols[0].data_dev, *np_io);
+        int rc1 = wrap ? fpmhip_wrap(plan, cols[0].data_dev, *np_io) : 0;
         return rc1 ? rc1 : fpmhip_invalidate_binning(plan);
     }
     if (!t->alltoall_counts || !t->alltoallv) return -1;
@@ -715,7 +721,7 @@ int fastpm_hip_slab_decompose(fpmhip_plan *plan, const fastpm_hip_transport *t, 
     if (!counts) return -2;
     int64_t *recv_counts = counts + P + 1;
     void *order = NULL, *tmp = NULL;
-    int rc = fpmhip_wrap(plan, cols[0].data_dev, np);                    /* solver.c:583 */
+    int rc = wrap ? fpmhip_wrap(plan, cols[0].data_dev, np) : 0;         /* solver.c:583 */
     if (!rc) rc = fpmhip_malloc(&order, (size_t) (np ? np : 1) * sizeof(int));
     if (!rc) rc = fpmhip_decompose_order(plan, cols[0].data_dev, np, order, counts);      /* store.c:519-553 */
     if (!rc) rc = t->alltoall_counts(t->ctx, counts + 1, recv_counts);                   /* store.c:570-572 */

@@ -72,7 +72,7 @@ typedef struct fastpm_hip_pieces {
     int npieces;
 } fastpm_hip_pieces;
 
-/* One column of the store on the device: rows of rowbytes (4, 8, 12, 16, 24 or 36) bytes. */
+/* One column of the store on the device: rows of rowbytes (1, 2, 4, 8, 12, 16, 24 or 36) bytes. */
 typedef struct {
     void *data_dev;
     int rowbytes;
@@ -85,6 +85,11 @@ typedef struct {
  * the particles do not fit np_upper (the reference raises "need %td particles; %td allocated", store.c:591-597). */
 int fastpm_hip_slab_decompose(fpmhip_plan *plan, const fastpm_hip_transport *t, fastpm_hip_column *cols, int ncols,
                               int64_t *np, int64_t np_upper);
+/* The same on any process mesh of the plan (the owner is 2-d on pencils, pmpfft.c:344-368), with the wrap optional:
+ * wrap == 0 is fastpm_store_decompose alone (store.c:485-657) -- its caller has wrapped already (solver.c:583), and a
+ * second wrap is not a no-op on the bits (a position that the first one left at exactly BoxSize would move to 0). */
+int fastpm_hip_mesh_decompose(fpmhip_plan *plan, const fastpm_hip_transport *t, fastpm_hip_column *cols, int ncols,
+                              int64_t *np, int64_t np_upper, int wrap);
 
 /* The force step on this rank's slab: total mass all-reduce, paint, halo plane to rank+1, forward transform
  * around one all-to-all, softening, the backward half in the plan's gradient mode (two transposed meshes for

@@ -162,6 +162,12 @@ fastpm_hip_current_pm(void)
     return current ? current->pm : NULL;
 }
 
+const void *
+fastpm_hip_current_transport(void)
+{
+    return current ? current->transport : NULL;         /* NULL on one rank */
+}
+
 void
 fastpm_kernel_type_get_orders(FastPMKernelType type,
     int *potorder,

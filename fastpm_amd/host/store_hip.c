@@ -1,8 +1,10 @@
 /*
  * store_hip.c -- the FastPMStore side of the resident drop-in, with the reference's signatures:
  *   fastpm_store_wrap      (store.c:446-475)  on the device twin of the position column;
- *   fastpm_store_decompose (store.c:485-657)  a wrapper: the reference's host + MPI exchange runs unchanged between a
- *                          sync of every column to the host and a "host rewrote them" mark -- skipped on one rank, where
+ *   fastpm_store_decompose (store.c:485-657)  NTask > 1: the rows travel GPU to GPU between the columns' device twins
+ *                          (fastpm_hip_resident_decompose; round 5) for the force step's decomposition; anything else:
+ *                          the reference's host + MPI exchange unchanged between a sync of every column to the host and
+ *                          a "host rewrote them" mark -- skipped on one rank, where
  *                          every particle stays (pm_pos_to_rank is 0 for all of them, pmpfft.c:344-368) and the
  *                          columns never leave the device;
  *   fastpm_store_summary   (store.c:807-908)  the particle loop on the device twin of a float column (acc every step);
@@ -64,6 +66,47 @@ fastpm_store_decompose(FastPMStore * p, fastpm_store_target_func target_func, vo
             fastpm_raise(-1, "Particle buffer overrun detected np = %td > np_upper %td.\n", p->np, p->np_upper);
         }
         return 0;
+    }
+    /* NTask > 1, the decomposition of the force step (fastpm_decompose, solver.c:571-592: target = the owner of the
+     * particle's cell on `data` = the PM the next force runs on): the columns stay on their device twins and the rows
+     * travel GPU to GPU through the transport of that PM (round 5; before, every column went home, through the reference's
+     * host exchange and up again: ~100 B per particle over PCIe each way, several times the force itself).  Same result,
+     * row for row: [stayed | from rank 0 | from rank 1 ...], each part in its sender's order (store.c:519-560, 611-632).
+     * FASTPM_HIP_DEVICE_DECOMPOSE=0, another target function, a PM without a plan, or a column whose rows the device
+     * gather does not take: the host path below. */
+    {
+        const char * e = getenv("FASTPM_HIP_DEVICE_DECOMPOSE");
+        fpmhip_plan * plan = fastpm_hip_current_plan();
+        const void * transport = fastpm_hip_current_transport();
+        int device_path = !(e && atoi(e) == 0) && fastpm_hip_resident_enabled() && plan && transport && p->x
+                          && target_func == (fastpm_store_target_func) FastPMTargetPM && data == (void *) fastpm_hip_current_pm();
+        void * cols[32];
+        int rowbytes[32], ncols = 0, ci;
+        const int cx = FASTPM_STORE_COLUMN_INDEX(x);
+        if(device_path) {
+            cols[ncols] = p->columns[cx];                   /* the position column first: the owner is computed from it */
+            rowbytes[ncols ++] = (int) p->_column_info[cx].elsize;
+            for(ci = 0; ci < 32; ci ++) {
+                if(ci == cx || !p->columns[ci]) continue;
+                const int rb = (int) p->_column_info[ci].elsize;
+                if(rb != 1 && rb != 2 && rb != 4 && rb != 8 && rb != 12 && rb != 16 && rb != 24 && rb != 36) device_path = 0;
+                cols[ncols] = p->columns[ci];
+                rowbytes[ncols ++] = rb;
+            }
+        }
+        MPI_Allreduce(MPI_IN_PLACE, &device_path, 1, MPI_INT, MPI_MIN, comm);       /* every rank takes the same path */
+        if(device_path) {
+            if(fastpm_store_get_np_total(p, comm) == 0) return 0;                  /* store.c:490 */
+            if(p->np > p->np_upper) {
+                fastpm_raise(-1, "Particle buffer overrun detected np = %td > np_upper %td.\n", p->np, p->np_upper);
+            }
+            int64_t np = (int64_t) p->np;
+            const int rc = fastpm_hip_resident_decompose(plan, transport, cols, rowbytes, ncols, &np, (int64_t) p->np_upper);
+            if(rc == -4 || rc == -8) return -1;             /* no room on some rank: the caller raises (solver.c:589) */
+            if(rc) fastpm_raise(-1, "fastpm_store_decompose on the MI355X failed (%d): %s\n", rc, rc == -9 ? fastpm_hip_mirror_error() : fpmhip_last_error());
+            p->np = (size_t) np;
+            return 0;
+        }
     }
     fastpm_hip_store_sync(p, p->attributes);
     const int rc = fastpm_store_decompose_cpu(p, target_func, data, comm);

@@ -579,7 +579,12 @@ MPI_ROOT = os.environ.get("FPM_MPI_ROOT", "/opt/conda")
     # round 5, the pipelined sequence over MPI_Isend / MPI_Irecv: strip tiles (Nmesh 64 = the smallest strip mesh that is a
     # whole number of strips per rank), 2 and 4 plane ranges, slabs and 2 x 2 / 4 x 2 pencils, whole meshes, blocking
     (4, 32, 2, 64, 0, 0, 0, 1, 32), (2, 32, 2, 32, 0, 0, 1, 1, 34), (4, 32, 2, 64, 1, 0, 0, 1, 4), (2, 32, 2, 64, 0, 1, 0, 1, 31),
-    (4, 32, 2, 64, 0, 0, 0, 2, 34), (8, 32, 2, 64, 0, 0, 1, 2, 32), (4, 32, 2, 64, 0, 0, 0, 2, 29)])
+    (4, 32, 2, 64, 0, 0, 0, 2, 34), (8, 32, 2, 64, 0, 0, 1, 2, 32), (4, 32, 2, 64, 0, 0, 0, 2, 29),
+    # round 5, the RESIDENT store for NTask > 1 (host_columns = 2): columns in host memory, device twins behind them, the
+    # decomposition's rows GPU to GPU (fastpm_hip_resident_decompose = store_hip.c's fastpm_store_decompose), the force on
+    # the twins; slabs and 2 x 2 / 4 x 2 pencils, a 1-byte mask column among the columns
+    (2, 24, 2, 64, 0, 2, 1, 1, 0), (4, 32, 2, 64, 0, 2, 1, 1, 32), (4, 32, 2, 32, 0, 2, 1, 2, 0), (8, 32, 2, 64, 0, 2, 1, 2, 32),
+    (3, 24, 2, 64, 0, 2, 0, 1, 0)])
 def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode, host_columns, decompose, nprocy, chunks):
     paint_mode = 0
     if chunks >= 20:                 # 30 + c: strip tiles forced on the small mesh, c plane ranges (29: the blocking sequence)
@@ -610,6 +615,8 @@ def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode
         dec = [l.split() for l in r.stdout.splitlines() if l.startswith("decomposed ")]
         assert sorted(int(d[1]) for d in dec) == list(range(P))
         assert sum(int(d[3]) for d in dec) == nc ** 3 and all(int(d[5]) == 0 for d in dec)
+        if host_columns == 2:               # nothing came home before the explicit syncs
+            assert all(d[6] == "resident" and int(d[8]) == 0 for d in dec), dec
     L, h = 3.0 * nc, 3.0
     A, k = 0.35 * h, 2 * np.pi / L
     g = (np.arange(nc) + 0.5) * h
@@ -624,7 +631,7 @@ def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode
     std = np.sqrt((ref ** 2).mean(0) - ref.mean(0) ** 2)
     got = np.array([float(v) for v in lines["accstd"][2:5]])
     tol = 1e-6 if precision == 64 else 2e-5
-    if host_columns and nprocy == 1:
+    if host_columns == 1 and nprocy == 1:
         # fastpm_hip_slab_force_host: every rank's delta_k slab is the reference's ORegion, [y_loc][kz][x]
         dko = pmo.complex_view(full["delta_k"]).astype(np.complex128)              # [y][kz][x]
         yl = nc * B // P
