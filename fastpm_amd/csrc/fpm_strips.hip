@@ -511,6 +511,15 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
 #ifndef FPM_RO_E4_PF
 #define FPM_RO_E4_PF 1
 #endif
+#ifndef FPM_RO_E16_F32_MINW
+#define FPM_RO_E16_F32_MINW 2
+#endif
+#ifndef FPM_RO_E16_F32_PF
+#define FPM_RO_E16_F32_PF FPM_RO_E16_PF
+#endif
+#ifndef FPM_RO_E24_F32_2WG
+#define FPM_RO_E24_F32_2WG 0
+#endif
 #ifndef FPM_RO_E24_PF
 #define FPM_RO_E24_PF 2
 #endif
@@ -531,7 +540,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
 // M = 256 the same order loses in fp64 (1.18 -> 1.26 ms at 512^3: the prefetch matters more where the transform is short)
 // and wins in fp32 (0.816 -> 0.783 ms), where it is on as well.  (With 8-row strips, five-wave workgroups: 1.56 ms.)
 template <typename PL, typename F, bool WS, bool LATE = false, bool PEN = false>
-__global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (PL::E == 4 ? FPM_RO_E4_MINW : PL::E >= 16 ? (sizeof(F) == 8 || PL::E == 24 ? 1 : 2) : WS ? (LATE ? 4 : FPM_RO_MINW) : 3)) void readout_march_kernel(
+__global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (PL::E == 4 ? FPM_RO_E4_MINW : PL::E >= 16 ? (sizeof(F) == 8 || (PL::E == 24 && !FPM_RO_E24_F32_2WG) ? 1 : (PL::E == 16 ? FPM_RO_E16_F32_MINW : 2)) : WS ? (LATE ? 4 : FPM_RO_MINW) : 3)) void readout_march_kernel(
     MeshGeo g, int ncomp, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
     const double *__restrict__ sy, const double *__restrict__ sz, const int *__restrict__ sidx, const C2<F> *__restrict__ m0,
     const C2<F> *__restrict__ m1, const C2<F> *__restrict__ m2, float *__restrict__ out, int nmemb, int memb0,
@@ -630,7 +639,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (PL::E == 4 ? FPM_RO
         }
         return acc;
     };
-    constexpr int PF = PL::E == 4 ? FPM_RO_E4_PF : PL::E == 16 ? FPM_RO_E16_PF : PL::E == 24 ? FPM_RO_E24_PF : FPM_RO_PF;
+    constexpr int PF = PL::E == 4 ? FPM_RO_E4_PF : PL::E == 16 ? (sizeof(F) == 4 ? FPM_RO_E16_F32_PF : FPM_RO_E16_PF) : PL::E == 24 ? FPM_RO_E24_PF : FPM_RO_PF;
     double px[PF + 1], py[PF + 1], pz[PF + 1], pv[PF + 1], qx[PF + 1], qy[PF + 1], qz[PF + 1];
     int prow[PF + 1], qrow[PF + 1], pc[PF + 1], qc[PF + 1];
     int pb = 0, pn = 0, qb = 0, qn = 0;            // p: the particles that finish this step; q: those that start
