@@ -78,7 +78,10 @@ typedef struct {
     double *x;
     int64_t np;
 } Pending;
-static Pending pend;
+/* one recorded run per store (FASTPM_SOLVER_NSPECIES = 6: the solver kicks every species, then drifts every species,
+ * solver.c:289-296 via fastpm_do_kick / fastpm_do_drift -- the runs of different stores interleave) */
+#define NPEND 6
+static Pending pends[NPEND];
 
 static int defer_enabled(void)
 {
@@ -90,15 +93,49 @@ static int defer_enabled(void)
     return on;
 }
 
-static int flush_pending(int with_wrap, const float *mass);
+static int flush_pending(Pending *s, int with_wrap, const float *mass);
 
-/* a twin is about to be looked at from outside the deferred run: if it is one of the run's columns, the run happens now */
+static int pend_active(const Pending *s) { return (s->nk || s->nd) && !s->busy; }
+
+static int flush_all_pending(void)
+{
+    int rc = 0;
+    for (int i = 0; i < NPEND; i++)
+        if (pend_active(&pends[i])) { const int r = flush_pending(&pends[i], 0, NULL); rc = rc ? rc : r; }
+    return rc;
+}
+
+/* a twin is about to be looked at from outside the deferred runs: a run that holds it as one of its columns happens now */
 static int settle(const void *host)
 {
-    if ((pend.nk || pend.nd) && !pend.busy && host
-        && (host == pend.acc || host == pend.v || host == pend.x || host == pend.dx1 || host == pend.dx2))
-        return flush_pending(0, NULL);
-    return 0;
+    int rc = 0;
+    for (int i = 0; i < NPEND && host; i++) {
+        Pending *s = &pends[i];
+        if (pend_active(s) && (host == s->acc || host == s->v || host == s->x || host == s->dx1 || host == s->dx2)) {
+            const int r = flush_pending(s, 0, NULL);
+            rc = rc ? rc : r;
+        }
+    }
+    return rc;
+}
+
+/* the run that updates column `v` (kicks) / `x` (drifts), if one is recorded */
+static Pending *pend_of_v(const void *v)
+{
+    for (int i = 0; i < NPEND; i++) if (pend_active(&pends[i]) && pends[i].v == v) return &pends[i];
+    return NULL;
+}
+
+static Pending *pend_of_x(const void *x)
+{
+    for (int i = 0; i < NPEND; i++) if (pend_active(&pends[i]) && pends[i].nd && pends[i].x == x) return &pends[i];
+    return NULL;
+}
+
+static Pending *pend_free_slot(void)
+{
+    for (int i = 0; i < NPEND; i++) if (!pends[i].nk && !pends[i].nd && !pends[i].busy) return &pends[i];
+    return NULL;
 }
 
 static Twin *find(const void *host)
@@ -301,7 +338,8 @@ void fastpm_hip_host_touched(const void *host)
 int fastpm_hip_host_is_stale(const void *host)
 {
     /* a recorded, not yet executed update of this column counts: the device copy WILL be the newer one */
-    if (host && !pend.busy && ((pend.nk && host == pend.v) || (pend.nd && host == pend.x))) return 1;
+    for (int i = 0; i < NPEND && host; i++)
+        if (pend_active(&pends[i]) && ((pends[i].nk && host == pends[i].v) || (pends[i].nd && host == pends[i].x))) return 1;
     Twin *t = find(host);
     check_tag(t);
     return t && t->state == ST_DEV_NEWER;
@@ -323,7 +361,7 @@ void fastpm_hip_mirror_release(const void *host)
 
 void fastpm_hip_mirror_release_all(void)
 {
-    (void) flush_pending(0, NULL);          /* a recorded update runs on the twins it was recorded for, not on fresh uploads */
+    (void) flush_all_pending();             /* a recorded update runs on the twins it was recorded for, not on fresh uploads */
     while (twins) fastpm_hip_mirror_release(twins->host);
 }
 
@@ -389,11 +427,11 @@ static int hand_to_host(void *host)
 }
 
 /* the recorded run, executed: the fused walk for K [K] D D (+ wrap), the stand-alone kernels for anything shorter */
-static int flush_pending(int with_wrap, const float *mass)
+static int flush_pending(Pending *slot, int with_wrap, const float *mass)
 {
-    if (!(pend.nk || pend.nd)) return 0;
-    Pending q = pend;
-    pend.busy = 1;
+    if (!(slot->nk || slot->nd)) return 0;
+    Pending q = *slot;
+    slot->busy = 1;
     int rc = 0;
     const size_t b = (size_t) q.np * 12;
     const int m = q.nk ? q.k[0].forcemode : q.d[0].forcemode;
@@ -432,7 +470,7 @@ static int flush_pending(int with_wrap, const float *mass)
             rc = fpmhip_wrap_bin(q.plan, &p);
         }
     }
-    memset(&pend, 0, sizeof(pend));
+    memset(slot, 0, sizeof(*slot));
     return rc;
 }
 
@@ -447,23 +485,25 @@ int fastpm_hip_resident_kick(fpmhip_plan *plan, const fpmhip_kick_factor *kick, 
     if (defer_enabled() && v_out == v_in && !own_output && acc
         && (kick->forcemode == FPMHIP_FORCE_FASTPM || kick->forcemode == FPMHIP_FORCE_PM || cola)) {
         /* K, or the K that follows a K on the same columns (the kick that closes a step and the one that opens the next) */
-        const int joins = pend.nk == 1 && pend.nd == 0 && pend.plan == plan && pend.acc == acc && pend.v == v_out
-                          && pend.np == np && pend.k[0].forcemode == kick->forcemode;
+        Pending *s = pend_of_v(v_out);
+        const int joins = s && s->nk == 1 && s->nd == 0 && s->plan == plan && s->acc == acc && s->np == np
+                          && s->k[0].forcemode == kick->forcemode;
         if (!joins) {
-            const int rc = flush_pending(0, NULL);
-            if (rc) return rc;
-            /* the twins exist (and carry the first upload) from this call on, so errors surface where they belong */
+            /* the twins exist (and carry the first upload) from this call on, so errors surface where they belong; asking
+             * for them also settles any recorded run that holds one of these columns */
             if (!fastpm_hip_dev_in(plan, acc, b) || !fastpm_hip_dev_in(plan, v_in, b)) return -9;
             if (cola && (!fastpm_hip_dev_in(plan, dx1, b) || !fastpm_hip_dev_in(plan, dx2, b))) return -9;
-            pend.plan = plan; pend.acc = acc; pend.v = v_out; pend.np = np;
-            pend.dx1 = cola ? dx1 : NULL; pend.dx2 = cola ? dx2 : NULL;
+            s = pend_free_slot();
+            if (!s) {
+                const int rc = flush_all_pending();
+                if (rc) return rc;
+                s = pend_free_slot();
+            }
+            s->plan = plan; s->acc = acc; s->v = v_out; s->np = np;
+            s->dx1 = cola ? dx1 : NULL; s->dx2 = cola ? dx2 : NULL;
         }
-        pend.k[pend.nk++] = *kick;
+        s->k[s->nk++] = *kick;
         return 0;
-    }
-    {
-        const int rc = flush_pending(0, NULL);
-        if (rc) return rc;
     }
     const float *dacc, *dv, *d1 = NULL, *d2 = NULL;
     float *dvo;
@@ -498,20 +538,21 @@ int fastpm_hip_resident_drift(fpmhip_plan *plan, const fpmhip_drift_factor *drif
     const float *dv = NULL, *d1 = NULL, *d2 = NULL;
     const double *dx;
     double *dxo;
-    if (defer_enabled() && x_out == x_in && !own_output && need_v && v && (!need_1 || (dx1 && dx2))
-        && (pend.nk >= 1 && pend.nd < 2 && pend.plan == plan && pend.v == v && pend.np == np
-            && pend.k[0].forcemode == m && (pend.nd == 0 || pend.x == x_out)
-            && (!need_1 || (pend.dx1 == dx1 && pend.dx2 == dx2)))) {
-        /* D after K [K], or the second D: joins the run */
-        if (pend.nd == 0 && !fastpm_hip_dev_in(plan, x_in, 2 * b)) return -9;
-        pend.x = x_out;
-        pend.d[pend.nd++] = *drift;
+    Pending *s = defer_enabled() && x_out == x_in && !own_output && need_v && v && (!need_1 || (dx1 && dx2)) ? pend_of_v(v) : NULL;
+    if (s && s->nk >= 1 && s->nd < 2 && s->plan == plan && s->np == np && s->k[0].forcemode == m
+        && (s->nd == 0 || s->x == x_out) && (!need_1 || (s->dx1 == dx1 && s->dx2 == dx2))) {
+        /* D after K [K], or the second D: joins the run of this store (asking for x settles any OTHER run that holds it) */
+        if (s->nd == 0) {
+            s->busy = 1;
+            const void *dxx = fastpm_hip_dev_in(plan, x_in, 2 * b);
+            s->busy = 0;
+            if (!dxx) return -9;
+        }
+        s->x = x_out;
+        s->d[s->nd++] = *drift;
         return 0;
     }
-    {
-        const int rc = flush_pending(0, NULL);
-        if (rc) return rc;
-    }
+    /* (the twins asked for below settle the recorded runs that hold these columns) */
     if (need_v) { if (!v) return -1; NEED(dv = fastpm_hip_dev_in(plan, v, b)); }
     if (need_1) { if (!dx1) return -1; NEED(d1 = fastpm_hip_dev_in(plan, dx1, b)); }
     if (need_2) { if (!dx2) return -1; NEED(d2 = fastpm_hip_dev_in(plan, dx2, b)); }
@@ -534,8 +575,11 @@ int fastpm_hip_resident_wrap(fpmhip_plan *plan, double *x, const float *mass, in
     /* fastpm_store_wrap is the last thing that moves a particle before the force (fastpm_decompose, solver.c:583, then
      * :455): the tile binning of that force call is made in the same walk over the rows (fpmhip_wrap_bin; a plain wrap
      * where that is not on offer) */
-    if ((pend.nk || pend.nd) && pend.plan == plan && pend.x == x && pend.np == np)
-        return flush_pending(1, mass);              /* K [K] D D wrap: one walk, binned for the force on the way */
+    {
+        Pending *s = pend_of_x(x);
+        if (s && s->plan == plan && s->np == np)
+            return flush_pending(s, 1, mass);       /* K [K] D D wrap: one walk, binned for the force on the way */
+    }
     fpmhip_particles p;
     memset(&p, 0, sizeof(p));
     NEED(p.x = fastpm_hip_dev_inout(plan, x, (size_t) np * 24));
