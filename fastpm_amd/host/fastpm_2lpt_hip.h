@@ -27,6 +27,9 @@ void fastpm_ic_induce_correlation_hip(PMView *pm, void *delta_k_dev, FastPMPower
  * for the particles at p->x from the linear density delta_k_dev.  12 c2r + 1 r2c. */
 void pm_2lpt_solve_hip(PMView *pm, const void *delta_k_dev, FastPMDeviceStoreView *p, const double shift[3],
                        FastPMKernelType type);
+/* the same on plain device pointers; 0 or the first error code */
+int fastpm_hip_2lpt_solve_dev(fpmhip_plan *plan, const void *delta_k_dev, double *x_dev, float *dx1_dev, float *dx2_dev,
+                              int64_t np, const double shift[3], int type);
 /* pm_2lpt_evolve (pm2lpt.c:168-210) with the growth numbers from the caller's cosmology: x += D1 dx1 + D2 dx2,
  * v += Dv1 dx1 + Dv2 dx2; meta.a_x = meta.a_v = aout */
 void pm_2lpt_evolve_hip(PMView *pm, FastPMDeviceStoreView *p, double aout, double D1, double D2, double Dv1,

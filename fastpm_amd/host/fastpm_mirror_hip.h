@@ -111,6 +111,10 @@ int fastpm_hip_resident_wrap(fpmhip_plan *plan, double *x, const float *mass, in
  * raises "Out of particle storage space", solver.c:589).  Does NOT wrap (its caller has, solver.c:583). */
 int fastpm_hip_resident_decompose(fpmhip_plan *plan, const void *transport, void *const *host_cols, const int *rowbytes,
                                   int ncols, int64_t *np, int64_t np_upper);
+/* pm_2lpt_solve (pm2lpt.c:14-164), one rank, no dv1: delta_k's twin read, x's twin shifted there and back, dx1 / dx2 twins
+ * written (they stay on the device for pm_2lpt_evolve's host loop to ask for with fastpm_hip_host_sync) */
+int fastpm_hip_resident_2lpt(fpmhip_plan *plan, const void *delta_k_host, double *x, float *dx1, float *dx2, int64_t np,
+                             const double shift[3], int type);
 int fastpm_hip_resident_decic(fpmhip_plan *plan, const void *from, void *to);                     /* transfer.c:77-113 */
 /* powerspectrum.c:35-111 before its Allreduce: the raw bin sums (Nmesh / 2 bins) */
 int fastpm_hip_resident_powerspectrum(fpmhip_plan *plan, const void *delta1_k, const void *delta2_k, double *ksum,

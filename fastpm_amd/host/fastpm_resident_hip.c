@@ -10,6 +10,7 @@
 
 #include "fastpm_resident_hip.h"
 #include "fastpm_slab_hip.h"
+#include "fastpm_2lpt_hip.h"
 
 void fpm_raise_hip(int code, const char *fmt, ...);            /* fastpm_gravity_hip.c */
 
@@ -626,6 +627,23 @@ int fastpm_hip_resident_decompose(fpmhip_plan *plan, const void *transport, void
     for (int c = 0; c < ncols; c++) find(host_cols[c])->valid = (size_t) n * rowbytes[c];
     *np = n;
     return 0;
+}
+
+/* pm_2lpt_solve (pm2lpt.c:14-164) on one rank: delta_k's twin read (uploaded in the reference's ORegion layout the
+ * first time), x shifted there and back in place, dx1 / dx2 written */
+int fastpm_hip_resident_2lpt(fpmhip_plan *plan, const void *delta_k_host, double *x, float *dx1, float *dx2, int64_t np,
+                             const double shift[3], int type)
+{
+    if (!plan || !delta_k_host || !shift || (np > 0 && (!x || !dx1 || !dx2))) return -1;
+    if (np == 0) return 0;
+    const void *dk;
+    double *dx;
+    float *d1, *d2;
+    NEED(dk = fastpm_hip_kmesh_in(plan, delta_k_host));
+    NEED(dx = fastpm_hip_dev_inout(plan, x, (size_t) np * 24));
+    NEED(d1 = fastpm_hip_dev_out(plan, dx1, (size_t) np * 12));
+    NEED(d2 = fastpm_hip_dev_out(plan, dx2, (size_t) np * 12));
+    return fastpm_hip_2lpt_solve_dev(plan, dk, dx, d1, d2, np, shift, type);
 }
 
 int fastpm_hip_resident_decic(fpmhip_plan *plan, const void *from, void *to)

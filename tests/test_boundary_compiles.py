@@ -35,7 +35,7 @@ def _syntax_only(tmp_path, source, extra=()):
 
 
 @needs_reference
-@pytest.mark.parametrize("tu", ["gravity_hip.c", "factors_hip.c", "store_hip.c", "transfer_hip.c"])
+@pytest.mark.parametrize("tu", ["gravity_hip.c", "factors_hip.c", "store_hip.c", "transfer_hip.c", "pm2lpt_hip.c"])
 def test_the_binding_type_checks_against_the_reference_headers(tmp_path, tu):
     """gravity_hip.c (the force) and, round 4, the resident drop-in beside it: factors_hip.c (fastpm_kick_store /
     fastpm_drift_store), store_hip.c (fastpm_store_wrap / _decompose / _summary + the sync calls), transfer_hip.c

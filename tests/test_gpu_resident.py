@@ -385,3 +385,41 @@ def test_two_species_interleave_their_deferred_updates(oracle, mode):
         # (acc: the paint's LDS atomics reorder from run to run -- last-bit flips of the float32 column)
         assert util.rel_err(a0, a1) <= 1e-6
     assert np.isfinite(lazy[0][2]).all() and np.abs(lazy[1][2]).max() > 0
+
+
+@pytest.mark.parametrize("kernel,shift", [("1_4", (0.0, 0.0, 0.0)), ("3_4", (0.75, 0.75, 0.75))])
+def test_resident_2lpt_from_host_buffers(oracle, kernel, shift):
+    """pm2lpt_hip.c's path (fastpm_hip_resident_2lpt): delta_k in HOST memory in the reference's ORegion layout, x / dx1 /
+    dx2 host columns; the 12 c2r + 1 r2c and six readouts on the twins; dx1, dx2 against the oracle's pm_2lpt_solve
+    (pm2lpt.c:14-164), x back where it was."""
+    from test_gpu_2lpt import _linear_delta_k
+    from fastpm_amd.pm import KERNEL_TYPES
+    H = chost.host_library()
+    H.fastpm_hip_resident_2lpt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_int64, ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+
+    class PMViewC(ctypes.Structure):                                # PMView, fastpm_gravity_hip.h
+        _fields_ = [("Nmesh", ctypes.c_ssize_t * 3), ("BoxSize", ctypes.c_double * 3), ("NTask", ctypes.c_int),
+                    ("ThisTask", ctypes.c_int), ("Nproc", ctypes.c_int * 2), ("allocsize", ctypes.c_ssize_t),
+                    ("Norm", ctypes.c_double), ("plan", ctypes.c_void_p)]
+    N, nc, L = 32, 16, 48.0
+    pmo = oracle.PMOracle(N, L, 64)
+    dk = np.ascontiguousarray(_linear_delta_k(pmo, 5))              # the oracle's buffer IS the ORegion layout [y][z][x]
+    q = util.lattice(nc, L) + np.asarray(shift)
+    ref1, ref2 = oracle.pm_2lpt_solve(pmo, dk, q, shift=shift, kernel=oracle.KERNELS[kernel])
+    pm = H.fastpm_create_pm_hip(N, L, 64)
+    x = q.copy()
+    dx1, dx2 = np.zeros((len(q), 3), dtype=np.float32), np.zeros((len(q), 3), dtype=np.float32)
+    sh = (ctypes.c_double * 3)(*shift)
+    plan = ctypes.cast(pm, ctypes.POINTER(PMViewC)).contents.plan
+    assert plan and ctypes.cast(pm, ctypes.POINTER(PMViewC)).contents.Nmesh[0] == N
+    rc = H.fastpm_hip_resident_2lpt(plan, dk.ctypes.data, x.ctypes.data, dx1.ctypes.data, dx2.ctypes.data,
+                                    len(q), sh, KERNEL_TYPES[kernel])
+    assert rc == 0, chost.host_library().fastpm_hip_mirror_error()
+    for a in (x, dx1, dx2):
+        assert H.fastpm_hip_host_sync(a.ctypes.data) == 0
+    assert np.array_equal(x, (q - np.asarray(shift)) + np.asarray(shift))
+    assert util.rel_err(dx1, ref1) <= 1e-6 and util.rel_err(dx2, ref2) <= 1e-6
+    for a in (x, dx1, dx2, dk):
+        H.fastpm_hip_mirror_release(a.ctypes.data)
+    H.fastpm_free_pm_hip(pm)
