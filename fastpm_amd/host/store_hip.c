@@ -72,14 +72,21 @@ fastpm_store_decompose(FastPMStore * p, fastpm_store_target_func target_func, vo
      * travel GPU to GPU through the transport of that PM (round 5; before, every column went home, through the reference's
      * host exchange and up again: ~100 B per particle over PCIe each way, several times the force itself).  Same result,
      * row for row: [stayed | from rank 0 | from rank 1 ...], each part in its sender's order (store.c:519-560, 611-632).
-     * FASTPM_HIP_DEVICE_DECOMPOSE=0, another target function, a PM without a plan, or a column whose rows the device
-     * gather does not take: the host path below. */
+     * FASTPM_HIP_DEVICE_DECOMPOSE=0, another target function, or a column whose rows the device gather does not take: the
+     * host path below. */
     {
         const char * e = getenv("FASTPM_HIP_DEVICE_DECOMPOSE");
-        fpmhip_plan * plan = fastpm_hip_current_plan();
-        const void * transport = fastpm_hip_current_transport();
-        int device_path = !(e && atoi(e) == 0) && fastpm_hip_resident_enabled() && plan && transport && p->x
-                          && target_func == (fastpm_store_target_func) FastPMTargetPM && data == (void *) fastpm_hip_current_pm();
+        fpmhip_plan * plan = NULL;
+        const void * transport = NULL;
+        int device_path = !(e && atoi(e) == 0) && fastpm_hip_resident_enabled() && p->x && data
+                          && target_func == (fastpm_store_target_func) FastPMTargetPM;
+        if(device_path) {
+            /* the plan (and transport) of the PM the particles are decomposed FOR: made here if this is its first use (the
+             * first step, a switch of the variable force mesh, vpm.c:9-20) -- the force call that follows needs it anyway */
+            plan = fastpm_hip_plan_for((PM *) data);
+            transport = fastpm_hip_current_transport();
+            device_path = plan && transport;
+        }
         void * cols[32];
         int rowbytes[32], ncols = 0, ci;
         const int cx = FASTPM_STORE_COLUMN_INDEX(x);
