@@ -562,4 +562,61 @@ int fpmhip_memcpy_d2d(fpmhip_plan *p, void *dst, const void *src, size_t bytes)
     return 0;
 }
 
+// ---- streams and events for a C host that orders its own exchanges against the plan's kernels (a transport with a
+//      stream of its own: fastpm_amd/host/fastpm_slab_hip.c's asynchronous loopback; RCCL transports use HIP directly) ----
+int fpmhip_stream_create(void **stream)
+{
+    if (!stream) FPM_FAIL(-1, "null argument");
+    hipStream_t s;
+    FPM_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *) s;
+    return 0;
+}
+
+void fpmhip_stream_destroy(void *stream)
+{
+    if (stream) { (void) hipStreamSynchronize((hipStream_t) stream); (void) hipStreamDestroy((hipStream_t) stream); }
+}
+
+int fpmhip_stream_sync(void *stream)
+{
+    FPM_CHECK_HIP(hipStreamSynchronize((hipStream_t) stream));
+    return 0;
+}
+
+int fpmhip_event_create(void **event)
+{
+    if (!event) FPM_FAIL(-1, "null argument");
+    hipEvent_t e;
+    FPM_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *event = (void *) e;
+    return 0;
+}
+
+void fpmhip_event_destroy(void *event)
+{
+    if (event) (void) hipEventDestroy((hipEvent_t) event);
+}
+
+int fpmhip_event_record(void *event, void *stream)
+{
+    if (!event) FPM_FAIL(-1, "null argument");
+    FPM_CHECK_HIP(hipEventRecord((hipEvent_t) event, (hipStream_t) stream));
+    return 0;
+}
+
+int fpmhip_stream_wait_event(void *stream, void *event)
+{
+    if (!event) FPM_FAIL(-1, "null argument");
+    FPM_CHECK_HIP(hipStreamWaitEvent((hipStream_t) stream, (hipEvent_t) event, 0));
+    return 0;
+}
+
+int fpmhip_memcpy_d2d_on(void *stream, void *dst, const void *src, size_t bytes)
+{
+    if (!dst || !src) FPM_FAIL(-1, "null argument");
+    FPM_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t) stream));
+    return 0;
+}
+
 }  // extern "C"

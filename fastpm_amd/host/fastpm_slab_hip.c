@@ -846,9 +846,26 @@ typedef struct {
     int *dest;              /* [nranks] sendrecv destinations */
     double *value;          /* [nranks] */
     fpmhip_plan **plan;     /* [nranks] */
+    /* the asynchronous xchg pair: per rank and tag the posted send buffer and two events (what the rank's plan stream has
+     * produced; what its exchange stream has copied) */
+    int async;
+    const void **xsend;     /* [nranks][FASTPM_HIP_MAX_TAGS] */
+    void **ready, **done;   /* [nranks][FASTPM_HIP_MAX_TAGS] events, made on first use */
+    void **xstream;         /* [nranks] the ranks' exchange streams */
+    /* stress / negative control (tests): FASTPM_HIP_LOOPBACK_DELAY_MB = n puts a device copy of n MB in front of every
+     * exchange's copies -- the wire is slow, the plan's stream runs far ahead, and only the events keep the sequence right;
+     * FASTPM_HIP_LOOPBACK_FAULT = 1 then drops the event waits of xchg_wait: the result MUST come out wrong */
+    size_t delay_bytes;
+    int fault;
+    void **delay_buf;       /* [2 nranks] */
 } loop_shared;
 
-typedef struct { loop_shared *sh; int rank; } loop_ctx;
+typedef struct {
+    loop_shared *sh;
+    int rank;
+    /* what xchg_wait needs to know about the exchange begun under a tag: whose copies read my send buffer */
+    int nmem[FASTPM_HIP_MAX_TAGS], mem[FASTPM_HIP_MAX_TAGS][64];
+} loop_ctx;
 
 static int loop_allreduce(void *c_, double *v)
 {
@@ -939,6 +956,66 @@ static int loop_xchg_wait(void *c_, int tag)
     return 0;
 }
 
+/* ASYNCHRONOUS form (the default; FASTPM_HIP_LOOPBACK_ASYNC=0 selects the one above): what the RCCL transport does,
+ * played by device-to-device copies on one GPU -- a stream of the rank's own waits (event) for what the plan's stream has
+ * produced and for what the SENDERS' plan streams have produced, copies the pieces it receives, records `done`; xchg_wait
+ * lets the plan's stream wait for the `done` of every member of the group: its own receives and the others' reads of its
+ * send buffer.  No host wait for the GPU anywhere: the copies of range i really run beside the passes of range i + 1, and a
+ * sequence that lets a pass write a buffer an exchange still reads, or read one that has not landed, computes garbage here
+ * as it would over xGMI.  (The host threads do meet at a barrier -- an event must have been RECORDED before another rank's
+ * stream is told to wait for it -- which orders the enqueueing, not the execution.) */
+static int loop_event(void **slot)
+{
+    return *slot ? 0 : fpmhip_event_create(slot);
+}
+
+static int loop_xchg_begin_async(void *c_, const void *send, void *recv, const fastpm_hip_pieces *pc, const int *members,
+                                 int n, int me, int tag)
+{
+    loop_ctx *c = c_;
+    loop_shared *s = c->sh;
+    const int r = c->rank, T = FASTPM_HIP_MAX_TAGS;
+    if (tag < 0 || tag >= T || n > 64) return -1;
+    int rc = loop_event(&s->ready[r * T + tag]);
+    if (!rc) rc = loop_event(&s->done[r * T + tag]);
+    if (!rc && !s->xstream[r]) rc = fpmhip_stream_create(&s->xstream[r]);
+    if (!rc) rc = fpmhip_event_record(s->ready[r * T + tag], fpmhip_plan_stream(s->plan[r]));
+    s->xsend[r * T + tag] = send;
+    c->nmem[tag] = n;
+    for (int j = 0; j < n; j++) c->mem[tag][j] = members ? members[j] : j;
+    pthread_barrier_wait(&s->barrier);                 /* every rank's `ready` is recorded, every send buffer posted */
+    if (rc == 0 && s->delay_bytes) {
+        if (!s->delay_buf[2 * r]) rc = fpmhip_malloc(&s->delay_buf[2 * r], s->delay_bytes);
+        if (!rc && !s->delay_buf[2 * r + 1]) rc = fpmhip_malloc(&s->delay_buf[2 * r + 1], s->delay_bytes);
+        if (!rc) rc = fpmhip_memcpy_d2d_on(s->xstream[r], s->delay_buf[2 * r + 1], s->delay_buf[2 * r], s->delay_bytes);
+    }
+    for (int j = 0; j < n && rc == 0; j++) {
+        const int src = c->mem[tag][j];
+        rc = fpmhip_stream_wait_event(s->xstream[r], s->ready[src * T + tag]);
+        for (int k = 0; k < pc->npieces && rc == 0; k++) {
+            const size_t o = pc->first_bytes + (size_t) k * pc->stride_bytes;
+            rc = fpmhip_memcpy_d2d_on(s->xstream[r], (char *) recv + (size_t) j * pc->chunk_bytes + o,
+                                      (const char *) s->xsend[src * T + tag] + (size_t) me * pc->chunk_bytes + o, pc->piece_bytes);
+        }
+    }
+    if (rc == 0) rc = fpmhip_event_record(s->done[r * T + tag], s->xstream[r]);
+    return rc;
+}
+
+static int loop_xchg_wait_async(void *c_, int tag)
+{
+    loop_ctx *c = c_;
+    loop_shared *s = c->sh;
+    const int r = c->rank, T = FASTPM_HIP_MAX_TAGS;
+    if (tag < 0 || tag >= T) return -1;
+    pthread_barrier_wait(&s->barrier);                 /* every rank has enqueued its copies of this tag and recorded `done` */
+    int rc = 0;
+    for (int j = 0; j < c->nmem[tag] && rc == 0 && !s->fault; j++)
+        rc = fpmhip_stream_wait_event(fpmhip_plan_stream(s->plan[r]), s->done[c->mem[tag][j] * T + tag]);
+    pthread_barrier_wait(&s->barrier);                 /* nobody re-records an event of this tag before all have waited on it */
+    return rc;
+}
+
 static int loop_bind_plan(void *c_, fpmhip_plan *plan)
 {
     loop_ctx *c = c_;
@@ -955,6 +1032,21 @@ fastpm_hip_transport *fastpm_hip_loopback_create(int nranks)
     s->dest = calloc((size_t) nranks, sizeof(*s->dest));
     s->value = calloc((size_t) nranks, sizeof(*s->value));
     s->plan = calloc((size_t) nranks, sizeof(*s->plan));
+    {
+        const char *e = getenv("FASTPM_HIP_LOOPBACK_ASYNC");
+        s->async = !(e && atoi(e) == 0);
+    }
+    s->xsend = calloc((size_t) nranks * FASTPM_HIP_MAX_TAGS, sizeof(*s->xsend));
+    s->ready = calloc((size_t) nranks * FASTPM_HIP_MAX_TAGS, sizeof(*s->ready));
+    s->done = calloc((size_t) nranks * FASTPM_HIP_MAX_TAGS, sizeof(*s->done));
+    s->xstream = calloc((size_t) nranks, sizeof(*s->xstream));
+    s->delay_buf = calloc((size_t) 2 * nranks, sizeof(*s->delay_buf));
+    {
+        const char *e = getenv("FASTPM_HIP_LOOPBACK_DELAY_MB");
+        s->delay_bytes = e ? (size_t) atoi(e) << 20 : 0;
+        e = getenv("FASTPM_HIP_LOOPBACK_FAULT");
+        s->fault = e && atoi(e) != 0;
+    }
     fastpm_hip_transport *t = calloc((size_t) nranks, sizeof(*t));
     for (int r = 0; r < nranks; r++) {
         loop_ctx *c = calloc(1, sizeof(*c));
@@ -967,8 +1059,8 @@ fastpm_hip_transport *fastpm_hip_loopback_create(int nranks)
         t[r].alltoall = loop_alltoall;
         t[r].alltoall_members = loop_alltoall_members;
         t[r].sendrecv = loop_sendrecv;
-        t[r].xchg_begin = loop_xchg_begin;
-        t[r].xchg_wait = loop_xchg_wait;
+        t[r].xchg_begin = s->async ? loop_xchg_begin_async : loop_xchg_begin;
+        t[r].xchg_wait = s->async ? loop_xchg_wait_async : loop_xchg_wait;
         t[r].bind_plan = loop_bind_plan;
     }
     return t;
@@ -987,6 +1079,10 @@ void fastpm_hip_loopback_destroy(fastpm_hip_transport *all)
     const int n = s->nranks;
     for (int r = 0; r < n; r++) free(all[r].ctx);
     pthread_barrier_destroy(&s->barrier);
+    for (int r = 0; r < n; r++) if (s->xstream[r]) fpmhip_stream_destroy(s->xstream[r]);      /* (waits for the stream) */
+    for (int i = 0; i < n * FASTPM_HIP_MAX_TAGS; i++) { fpmhip_event_destroy(s->ready[i]); fpmhip_event_destroy(s->done[i]); }
+    for (int i = 0; i < 2 * n; i++) if (s->delay_buf[i]) fpmhip_free(s->delay_buf[i]);
+    free(s->xsend); free(s->ready); free(s->done); free(s->xstream); free(s->delay_buf);
     free(s->send); free(s->dest); free(s->value); free(s->plan); free(s);
     free(all);
 }

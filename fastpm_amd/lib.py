@@ -158,6 +158,14 @@ SYMBOLS = {
     "fpmhip_memset": (_I, [_P, _P, _I, ctypes.c_size_t]),
     "fpmhip_memcpy_h2d": (_I, [_P, _P, _P, ctypes.c_size_t]),
     "fpmhip_memcpy_d2d": (_I, [_P, _P, _P, ctypes.c_size_t]),
+    "fpmhip_stream_create": (_I, [ctypes.POINTER(_P)]),
+    "fpmhip_stream_destroy": (None, [_P]),
+    "fpmhip_stream_sync": (_I, [_P]),
+    "fpmhip_event_create": (_I, [ctypes.POINTER(_P)]),
+    "fpmhip_event_destroy": (None, [_P]),
+    "fpmhip_event_record": (_I, [_P, _P]),
+    "fpmhip_stream_wait_event": (_I, [_P, _P]),
+    "fpmhip_memcpy_d2d_on": (_I, [_P, _P, _P, ctypes.c_size_t]),
     "fpmhip_memcpy_d2h": (_I, [_P, _P, _P, ctypes.c_size_t]),
 }
 

@@ -543,6 +543,18 @@ int fpmhip_memcpy_h2d(fpmhip_plan *plan, void *dst_dev, const void *src_host, si
 int fpmhip_memcpy_d2h(fpmhip_plan *plan, void *dst_host, const void *src_dev, size_t bytes);
 /* device to device on the plan's stream, asynchronous (an in-process transport uses it) */
 int fpmhip_memcpy_d2d(fpmhip_plan *plan, void *dst_dev, const void *src_dev, size_t bytes);
+/* Streams and events (hipStream_t / hipEvent_t behind void *) for a C host that orders its own exchanges against the plan's
+ * kernels without waiting on the host -- what a transport's xchg_begin / xchg_wait are made of (fastpm_slab_hip.h): a
+ * non-blocking stream of the transport's own, an event recorded on fpmhip_plan_stream(plan) that the transport's stream
+ * waits for, device-to-device copies on that stream, an event the plan's stream waits for. */
+int  fpmhip_stream_create(void **stream);
+void fpmhip_stream_destroy(void *stream);
+int  fpmhip_stream_sync(void *stream);
+int  fpmhip_event_create(void **event);
+void fpmhip_event_destroy(void *event);
+int  fpmhip_event_record(void *event, void *stream);
+int  fpmhip_stream_wait_event(void *stream, void *event);
+int  fpmhip_memcpy_d2d_on(void *stream, void *dst_dev, const void *src_dev, size_t bytes);
 
 #ifdef __cplusplus
 }

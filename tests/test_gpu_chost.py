@@ -476,8 +476,13 @@ def test_c_host_pipelined_exchanges_match_one_rank_oracle(oracle, Nx, Ny, kernel
     stores = [Store(x[idx[r]], potential=True) for r in range(P)]
     dks = [pm.alloc() for pm in pms]
     tol = 1e-6 if precision == 64 else 2e-5
-    for call in range(2):
+    for call in range(3):
+        # calls 0 and 1: the ASYNCHRONOUS loopback (an exchange stream per rank, events against the plan's stream: the copies
+        # of a range run beside the passes of the next -- a misordered sequence computes garbage); call 2: the copies inside
+        # xchg_begin.  The switch is read at every create.
+        os.environ["FASTPM_HIP_LOOPBACK_ASYNC"] = "0" if call == 2 else "1"
         tr = H.fastpm_hip_loopback_create(P)
+        os.environ.pop("FASTPM_HIP_LOOPBACK_ASYNC")
         rcs = [None] * P
 
         def rank_main(r):
@@ -516,6 +521,73 @@ def test_c_host_pipelined_exchanges_match_one_rank_oracle(oracle, Nx, Ny, kernel
             assert util.max_err(pm.complex_view(d).cpu().numpy(), want) <= (1e-14 if precision == 64 else 1e-5)
     for pm in pms:
         pm.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Nx,Ny,paint_mode,chunks", [(4, 1, 3, 4), (2, 1, 0, 2), (2, 2, 3, 4), (4, 2, 0, 2)])
+def test_pipelined_exchanges_on_a_slow_wire_and_the_negative_control(oracle, Nx, Ny, paint_mode, chunks):
+    """The asynchronous loopback with a SLOW wire (FASTPM_HIP_LOOPBACK_DELAY_MB: a 192 MB device copy in front of every
+    exchange's copies, so the plan's stream runs milliseconds ahead of the exchange streams): only the events of xchg_begin /
+    xchg_wait keep a pass from reading a buffer that has not landed or from overwriting one that is still being read --
+    the forces must still be the one-rank oracle's.  Negative control: the same with the event waits of xchg_wait dropped
+    (FASTPM_HIP_LOOPBACK_FAULT=1) must NOT be -- the test double does detect a misordered sequence."""
+    import threading
+    import torch
+    from fastpm_amd import PM, Store
+    from fastpm_amd.pm import KERNEL_TYPES
+    H = _host()
+    H.fastpm_hip_loopback_create.restype = ctypes.POINTER(Transport)
+    H.fastpm_hip_loopback_create.argtypes = [ctypes.c_int]
+    H.fastpm_hip_loopback_destroy.argtypes = [ctypes.POINTER(Transport)]
+    H.fastpm_hip_mesh_force_species.argtypes = [ctypes.c_void_p, ctypes.POINTER(Transport), ctypes.c_void_p, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    N, nc, L, P = 64, 32, 96.0, Nx * Ny
+    x = util.load_b(nc, L, N)
+    ref = oracle.compute_force(oracle.PMOracle(N, L, 64), x)
+    h = L / N
+    own = ((np.floor(x[:, 0] / h).astype(np.int64) % N) // (N // Nx)) * Ny + (np.floor(x[:, 1] / h).astype(np.int64) % N) // (N // Ny)
+    idx = [np.nonzero(own == r)[0] for r in range(P)]
+    errs = {}
+    for fault in (0, 1):
+        # every rank's plan on a stream of its OWN (a plan takes the stream that is current when it is made): one rank's
+        # wait then orders nothing for the others, as on separate GPUs
+        streams = [torch.cuda.Stream() for _ in range(P)]
+        pms = []
+        for r in range(P):
+            with torch.cuda.stream(streams[r]):
+                pms.append(PM(N, L, 64, nranks=P, rank=r, nranks_y=Ny, paint_mode=paint_mode))
+        stores = [Store(x[idx[r]]) for r in range(P)]
+        torch.cuda.synchronize()                    # the columns are in place before any plan's stream reads them
+        os.environ.update(FASTPM_HIP_LOOPBACK_ASYNC="1", FASTPM_HIP_LOOPBACK_DELAY_MB="192", FASTPM_HIP_LOOPBACK_FAULT=str(fault))
+        tr = H.fastpm_hip_loopback_create(P)
+        for k in ("FASTPM_HIP_LOOPBACK_ASYNC", "FASTPM_HIP_LOOPBACK_DELAY_MB", "FASTPM_HIP_LOOPBACK_FAULT"):
+            os.environ.pop(k)
+        rcs = [None] * P
+
+        def rank_main(r):
+            torch.cuda.set_device(0)
+            tr[r].chunks = chunks
+            part = stores[r]._c()
+            rcs[r] = H.fastpm_hip_mesh_force_species(pms[r]._plan, ctypes.byref(tr[r]), ctypes.byref(part), 1,
+                                                     KERNEL_TYPES["1_4"], 0, None)
+
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=180)
+        assert all(not t.is_alive() for t in threads), "a rank hung"
+        torch.cuda.synchronize()
+        assert rcs == [0] * P, rcs
+        H.fastpm_hip_loopback_destroy(tr)
+        acc = np.zeros_like(ref["acc"])
+        for r in range(P):
+            acc[idx[r]] = stores[r].acc.cpu().numpy()
+        errs[fault] = util.rel_err(np.nan_to_num(acc), ref["acc"])
+        for pm in pms:
+            pm.destroy()
+    assert errs[0] <= 1e-6, errs
+    assert errs[1] > 1e-3, errs                       # the negative control: dropped waits are seen
 
 
 def fastpm_last_error():
