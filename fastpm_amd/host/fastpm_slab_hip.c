@@ -984,6 +984,9 @@ static int loop_xchg_begin_async(void *c_, const void *send, void *recv, const f
     c->nmem[tag] = n;
     for (int j = 0; j < n; j++) c->mem[tag][j] = members ? members[j] : j;
     pthread_barrier_wait(&s->barrier);                 /* every rank's `ready` is recorded, every send buffer posted */
+    /* my receive buffer is mine to overwrite only once MY plan's stream is done with it (what `begin is ordered after
+     * everything enqueued on the plan's stream` means for the receiving side): first of all waits */
+    if (rc == 0) rc = fpmhip_stream_wait_event(s->xstream[r], s->ready[r * T + tag]);
     if (rc == 0 && s->delay_bytes) {
         if (!s->delay_buf[2 * r]) rc = fpmhip_malloc(&s->delay_buf[2 * r], s->delay_bytes);
         if (!rc && !s->delay_buf[2 * r + 1]) rc = fpmhip_malloc(&s->delay_buf[2 * r + 1], s->delay_bytes);

@@ -526,7 +526,7 @@ def test_c_host_pipelined_exchanges_match_one_rank_oracle(oracle, Nx, Ny, kernel
 @pytest.mark.gpu
 @pytest.mark.parametrize("Nx,Ny,paint_mode,chunks", [(4, 1, 3, 4), (2, 1, 0, 2), (2, 2, 3, 4), (4, 2, 0, 2)])
 def test_pipelined_exchanges_on_a_slow_wire_and_the_negative_control(oracle, Nx, Ny, paint_mode, chunks):
-    """The asynchronous loopback with a SLOW wire (FASTPM_HIP_LOOPBACK_DELAY_MB: a 192 MB device copy in front of every
+    """The asynchronous loopback with a SLOW wire (FASTPM_HIP_LOOPBACK_DELAY_MB: a 2 GB device copy in front of every
     exchange's copies, so the plan's stream runs milliseconds ahead of the exchange streams): only the events of xchg_begin /
     xchg_wait keep a pass from reading a buffer that has not landed or from overwriting one that is still being read --
     the forces must still be the one-rank oracle's.  Negative control: the same with the event waits of xchg_wait dropped
@@ -548,7 +548,12 @@ def test_pipelined_exchanges_on_a_slow_wire_and_the_negative_control(oracle, Nx,
     own = ((np.floor(x[:, 0] / h).astype(np.int64) % N) // (N // Nx)) * Ny + (np.floor(x[:, 1] / h).astype(np.int64) % N) // (N // Ny)
     idx = [np.nonzero(own == r)[0] for r in range(P)]
     errs = {}
-    for fault in (0, 1):
+    # (a 2 GB copy is ~1 ms of HBM time alone and several with P exchange streams copying at once: longer than the host
+    # threads take to meet at the transport's barriers, so the plan streams really are ahead of the wire when they reach a
+    # wait; the dropped-waits run is repeated up to three times all the same -- it races by construction)
+    for fault in (0, 1, 1, 1):
+        if fault and errs.get(1, 0) > 1e-3:
+            break
         # every rank's plan on a stream of its OWN (a plan takes the stream that is current when it is made): one rank's
         # wait then orders nothing for the others, as on separate GPUs
         streams = [torch.cuda.Stream() for _ in range(P)]
@@ -558,7 +563,7 @@ def test_pipelined_exchanges_on_a_slow_wire_and_the_negative_control(oracle, Nx,
                 pms.append(PM(N, L, 64, nranks=P, rank=r, nranks_y=Ny, paint_mode=paint_mode))
         stores = [Store(x[idx[r]]) for r in range(P)]
         torch.cuda.synchronize()                    # the columns are in place before any plan's stream reads them
-        os.environ.update(FASTPM_HIP_LOOPBACK_ASYNC="1", FASTPM_HIP_LOOPBACK_DELAY_MB="192", FASTPM_HIP_LOOPBACK_FAULT=str(fault))
+        os.environ.update(FASTPM_HIP_LOOPBACK_ASYNC="1", FASTPM_HIP_LOOPBACK_DELAY_MB="2048", FASTPM_HIP_LOOPBACK_FAULT=str(fault))
         tr = H.fastpm_hip_loopback_create(P)
         for k in ("FASTPM_HIP_LOOPBACK_ASYNC", "FASTPM_HIP_LOOPBACK_DELAY_MB", "FASTPM_HIP_LOOPBACK_FAULT"):
             os.environ.pop(k)
@@ -583,7 +588,7 @@ def test_pipelined_exchanges_on_a_slow_wire_and_the_negative_control(oracle, Nx,
         acc = np.zeros_like(ref["acc"])
         for r in range(P):
             acc[idx[r]] = stores[r].acc.cpu().numpy()
-        errs[fault] = util.rel_err(np.nan_to_num(acc), ref["acc"])
+        errs[fault] = max(errs.get(fault, 0), util.rel_err(np.nan_to_num(acc), ref["acc"]))
         for pm in pms:
             pm.destroy()
     assert errs[0] <= 1e-6, errs
