@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- particle-updates/sec of the PM force step (fastpm_solver_compute_force) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N = 1: this process)
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+    python bench.py --gpus N --steps K --warmup W          (N = 1: this process; N > 1 with WORLD_SIZE unset: re-executes
+                                                            itself under torch.distributed.run --nproc-per-node N)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1, as the driver launches it)
 
 A "step" is one force call (reference libfastpm/gravity.c:458-529: paint -> r2c -> transfer ->
 3 x (c2r -> readout)) over one synthetic particle load already resident in HBM.
@@ -10,6 +11,9 @@ A "step" is one force call (reference libfastpm/gravity.c:458-529: paint -> r2c 
   N > 1 : weak scaling, ~256^3 particles per GPU, B = 2, slab-decomposed mesh, RCCL all-to-all:
           N = 2 -> 320^3 / 640^3, N = 4 -> 400^3 / 800^3, N = 8 -> 512^3 / 1024^3 (configs[2]).
 Prints ONE JSON line (rank 0).  value = particles of all ranks / max-over-ranks step time.
+N > 1 has two legs: `c_dropin` -- mpiexec -n N fastpm_amd/bench_slab_mpi: fastpm_hip_mesh_force_species over
+fastpm_slab_rccl.c, the C sequence gravity_hip.c calls (the headline with --host auto | c) -- and the Python mirror of the
+same sequence over torch.distributed (`python_mirror`; the headline with --host python or when the C leg cannot run).
 """
 import argparse
 import json
@@ -358,6 +362,73 @@ def resident_dropin_leg(xh, Nmesh, BoxSize, precision, np_total, nsteps=6):
                     "column and no delta_k crosses PCIe; the call waits for the GPU and checks device-side errors"}
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(args):
+    """`python3 bench.py --gpus N` with no WORLD_SIZE in the environment: one process per GPU under torch.distributed.run,
+    as the driver would launch it (the reference's habit: tests/testfunctions.sh:1-5, mpirun -n P).  Rank 0's JSON line
+    goes to this process' stdout.  Fewer visible GPUs than ranks: the ranks share the GPU and the exchanges are staged
+    through the host -- a dry run of the code path on a reduced workload whose line carries no value."""
+    import subprocess
+    env = dict(os.environ)
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    extra = []
+    if ndev < args.gpus and not env.get("FPM_BENCH_SHARE_GPU"):
+        env["FPM_BENCH_BACKEND"] = "gloo"
+        env["FPM_BENCH_SHARE_GPU"] = "1"
+        env["FPM_BENCH_AUTO_DRY_RUN"] = "%d visible GPU(s) for %d ranks" % (ndev, args.gpus)
+        if not args.nc and not args.nmesh:
+            extra = ["--nc", "128", "--nmesh", "256", "--steps", str(min(args.steps, 3)), "--warmup", str(min(args.warmup, 1))]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:] + extra
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in r.stdout.splitlines():              # stdout is ONE JSON line; anything else a library printed goes to stderr
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr)
+    return r.returncode
+
+
+def c_dropin_leg(world, nc, Nmesh, args, share_gpu):
+    """The force step as the DROP-IN runs it for NTask > 1 (rank 0 launches it; the torch ranks idle on a host barrier):
+    mpiexec -n N fastpm_amd/bench_slab_mpi -- resident decompose, then fastpm_hip_mesh_force_species
+    (fastpm_amd/host/fastpm_slab_hip.c, what gravity_hip.c:303 calls) over fastpm_slab_rccl.c, one MPI rank per GPU; the
+    main leg with the default plane ranges, short legs with whole meshes (chunks 1) and the blocking sequence (-1).
+    Ranks sharing a GPU (dry run): MPI staged through the host instead of RCCL."""
+    import subprocess
+    mpi_root = os.environ.get("FPM_MPI_ROOT", "/opt/conda")
+    mpiexec = os.path.join(mpi_root, "bin", "mpiexec")
+    exe = os.path.join(ROOT, "fastpm_amd", "bench_slab_mpi")
+    if not os.path.exists(mpiexec):
+        return {"error": "no mpiexec under %s (FPM_MPI_ROOT)" % mpi_root}
+    if not os.path.exists(exe):
+        return {"error": "fastpm_amd/bench_slab_mpi is not built (make -C fastpm_amd/host mpi; __graft_entry__.build())"}
+    cmd = [mpiexec, "-n", str(world), exe, str(nc), str(Nmesh), str(args.precision), "0" if share_gpu else "2",
+           str(args.nprocy), "0,1,-1", str(args.steps), str(args.warmup), "1" if share_gpu else "0", str(args.paint_mode)]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500)
+    except Exception as e:
+        return {"error": repr(e), "command": " ".join(cmd)}
+    wall = time.perf_counter() - t0
+    if r.returncode != 0:
+        return {"error": "rc %d" % r.returncode, "command": " ".join(cmd), "stderr_tail": r.stderr[-1500:], "stdout_tail": r.stdout[-500:]}
+    try:
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    except Exception as e:
+        return {"error": "no JSON line (%r)" % (e,), "command": " ".join(cmd), "stdout_tail": r.stdout[-1500:]}
+    d["command"] = " ".join(cmd)
+    d["wall_s"] = round(wall, 2)
+    d["measured"] = bool(d.get("transport") == 2 and not share_gpu and d.get("distinct_devices") == world and d.get("rccl_ranks") == world)
+    return d
+
+
 def device_identity(dev_index):
     """PCI address + name of the HIP device this rank computes on (one string per rank in `comm.devices`)."""
     p = torch.cuda.get_device_properties(dev_index)
@@ -414,6 +485,10 @@ def main():
                     help="N > 1: the dtype the FFT transposes cross xGMI in -- mesh (default: the mesh's own) or f32 (an fp64 "
                          "mesh's chunks narrowed to float32 on the wire: half the bytes; the deviation of acc from the "
                          "full-width run is measured after the timed region and printed)")
+    ap.add_argument("--host", default="auto", choices=["auto", "c", "python"],
+                    help="N > 1: which host code the headline number times -- c: fastpm_hip_mesh_force_species over "
+                         "fastpm_slab_rccl.c under mpiexec (the drop-in's own C sequence); python: its mirror over "
+                         "torch.distributed; auto (default): c when that leg ran, else python.  Both legs are in the line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--static", action="store_true",
                     help="time every step on the SAME positions (the binning's best case; the default alternates between "
@@ -421,6 +496,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary legs (host-resident store columns; the 1024^3 mesh the 2e8 target is quoted on)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -437,12 +515,24 @@ def main():
     dev_index = 0 if os.environ.get("FPM_BENCH_SHARE_GPU") else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    host_group = None
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)            # gloo prints "[Gloo] Rank 0 is connected to ..." on fd 1: stdout is ONE JSON line
+        os.dup2(2, 1)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
+            # a HOST-side group: the ranks wait on it while rank 0 runs the C leg (an nccl barrier would spin on the GPUs)
+            host_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=40))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=datetime.timedelta(minutes=40))
+            host_group = dist.group.WORLD
+        dist.barrier(group=host_group)      # (the connection messages come with the first collective)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
 
     from fastpm_amd import PM, Store
 
@@ -554,6 +644,19 @@ def main():
 
     pm, store, dt, tm = timed_run(args.gradient)
     strips = pm.strips()
+
+    # N > 1: the same workload through the C sequence the drop-in calls (mpiexec -n N fastpm_amd/bench_slab_mpi), launched
+    # by rank 0 while every torch rank idles on a HOST barrier -- its own processes, its own timing bracket
+    c_leg = None
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier(group=host_group)
+        if rank == 0:
+            if args.gradient != "kspace" or args.load != "a" or args.fft_mode != 0 or args.wire != "mesh":
+                c_leg = {"error": "not run: the C leg times the default sequence (k-space gradient, load A, own FFT passes, mesh-dtype wire)"}
+            else:
+                c_leg = c_dropin_leg(world, nc, Nmesh, args, bool(os.environ.get("FPM_BENCH_SHARE_GPU")))
+        dist.barrier(group=host_group)
 
     # extra leg, outside the timed region above and reported beside it: the same workload in the OTHER
     # gradient mode (same W and K, same bracket), and how far its accelerations are from the main run's
@@ -668,6 +771,24 @@ def main():
     momentum_residual = float(mom[:3].abs().max() / mom[3])
 
     if rank == 0:
+        # which host code the headline times (--host): the drop-in's C sequence where its leg ran, else the mirror
+        mirror = {"host": "fastpm_amd/distributed.py (SlabForce / PencilForce over torch.distributed): the Python mirror of the C sequence",
+                  "ms_per_step": dt / args.steps * 1e3, "value": np_total * args.steps / dt,
+                  "kernel_ms_per_step": round(sum(tm[n][0] for n in ("sort", "paint", "r2c", "dealias", "transfer", "c2r",
+                                                                     "readout", "halo", "pack", "xback3")) / args.steps, 3),
+                  "finite": acc_ok, "momentum_residual": momentum_residual}
+        mirror["exposed_comm_ms_per_step"] = round(mirror["ms_per_step"] - mirror["kernel_ms_per_step"], 3)
+        c_ok = bool(c_leg and "error" not in c_leg and c_leg.get("finite") and c_leg.get("legs"))
+        use_c = world > 1 and args.host != "python" and c_ok
+        if world > 1 and args.host == "c" and not c_ok:
+            notes.append("--host c: the C leg did not run (%s); the headline is the Python mirror's" % ((c_leg or {}).get("error"),))
+        if use_c:
+            main_leg = c_leg["legs"][0]
+            dt = main_leg["ms_per_step"] * 1e-3 * main_leg["steps"]
+            tm = {n: (v[0], v[1]) for n, v in main_leg["stages"].items()}
+            for n in ("sort", "paint", "r2c", "dealias", "transfer", "c2r", "readout", "halo", "pack", "xback3"):
+                tm.setdefault(n, (0.0, 0))
+            acc_ok, momentum_residual = bool(c_leg["finite"]), float(c_leg["momentum_residual"])
         ms_per_step = dt / args.steps * 1e3
         value = np_total * args.steps / dt
         ab = algorithmic_bytes(np_local, Nmesh, world, esize, args.gradient)
@@ -753,6 +874,9 @@ def main():
                 "kernel": "1_4", "softening": "none",
                 "timed_steps": ("every step on the same positions (--static)" if args.static or args.load != "a" else
                                 "alternate between two position sets 0.05 cell apart: every binning finds moved particles"),
+                "host": ("one rank: fpmhip_force through the C ABI" if world == 1 else
+                         "C: fastpm_hip_mesh_force_species (fastpm_slab_hip.c) under mpiexec, %s" % c_leg["entry"].split(" over ")[-1] if use_c
+                         else "Python mirror of the C sequence over torch.distributed (fastpm_amd/distributed.py)"),
                 "decomposition": ("slab %dx1" % world) if args.nprocy <= 1 or world == 1 else
                                  ("pencil %dx%d" % (world // args.nprocy, args.nprocy)),
                 "gradient": {"kspace": "k space, 3 inverse FFTs (the reference's arithmetic)",
@@ -774,6 +898,16 @@ def main():
         roofline["step_frac"] = round(b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         roofline["step_alg_bytes"] = b_alg
         out["exposed_comm_ms_per_step"] = round(ms_per_step - out["kernel_ms_per_step"], 3) if world > 1 else 0.0
+        if world > 1:
+            out["c_dropin"] = c_leg
+            out["python_mirror"] = mirror
+            comm["rccl_ranks"] = (c_leg or {}).get("rccl_ranks")          # ncclCommCount of the C transport's communicator
+            if use_c:
+                comm["measured"] = bool(c_leg["measured"])
+                comm["headline_leg"] = "c_dropin: %d MPI ranks on %d distinct devices" % (c_leg["ranks"], c_leg["distinct_devices"])
+        if os.environ.get("FPM_BENCH_AUTO_DRY_RUN"):
+            notes.append("self-launched with " + os.environ["FPM_BENCH_AUTO_DRY_RUN"] + ": the ranks share the GPU, exchanges staged "
+                         "through the host, reduced workload unless --nc / --nmesh were given -- a dry run of the code path")
         out["comm"] = comm
         if not comm["measured"]:
             # ranks sharing a GPU and / or exchanges staged through the host over gloo: a dry run of the code path.  Such

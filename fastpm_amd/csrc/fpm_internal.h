@@ -134,6 +134,7 @@ struct fpmhip_plan {
     fpm::MeshGeo mg;
     int device;
     hipStream_t stream;
+    long long sync_count = 0;   // host waits for the plan's stream through fpmhip_sync (fpmhip_plan_sync_count)
     bool f64;
     size_t esize;  // sizeof(FastPMFloat)
 

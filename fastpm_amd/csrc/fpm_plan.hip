@@ -162,6 +162,15 @@ int fpmhip_device_count(void)
     return n;
 }
 
+// "dddd:bb:dd.f" of a visible device: what tells two ranks' GPUs apart whatever the launcher masked
+int fpmhip_device_pci_bus_id(int device, char *out, int len)
+{
+    if (!out || len < 16) FPM_FAIL(-1, "fpmhip_device_pci_bus_id: buffer of at least 16 bytes");
+    memset(out, 0, (size_t) len);
+    FPM_CHECK_HIP(hipDeviceGetPCIBusId(out, len, device));
+    return 0;
+}
+
 // reference libfastpm/gravity.c:111-171
 int fpmhip_kernel_type_get_orders(int type, int *potorder, int *gradorder, int *difforder,
                                   int *deconvolveorder)
@@ -448,8 +457,16 @@ void *fpmhip_plan_scratch(fpmhip_plan *p, size_t bytes)
 int fpmhip_sync(fpmhip_plan *p)
 {
     if (!p) FPM_FAIL(-1, "null plan");
+    p->sync_count++;
     FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
     return fpm::check_deferred(p, true);          // what a binning found out after its call had returned
+}
+
+// how often the host has waited for the plan's stream through fpmhip_sync: what the multi-rank sequences are measured
+// by (fastpm_slab_hip.c: one wait per force call, the final agreement)
+long long fpmhip_plan_sync_count(const fpmhip_plan *p)
+{
+    return p ? p->sync_count : -1;
 }
 
 void *fpmhip_plane_ptr(fpmhip_plan *p, void *mesh, int64_t ix)

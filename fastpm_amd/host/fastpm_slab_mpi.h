@@ -27,6 +27,8 @@ void fastpm_hip_mpi_transport_destroy(fastpm_hip_transport *t);
  * broadcast, row counts).  One rank per GPU; `device` is this rank's GPU. */
 fastpm_hip_transport *fastpm_hip_rccl_transport_create(MPI_Comm comm, int device);
 void fastpm_hip_rccl_transport_destroy(fastpm_hip_transport *t);
+/* ncclCommCount of the communicator the transport built: the ranks RCCL itself counts (bench.py: comm.rccl_ranks) */
+int fastpm_hip_rccl_transport_ranks(const fastpm_hip_transport *t);
 
 #ifdef __cplusplus
 }

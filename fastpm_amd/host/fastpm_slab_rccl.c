@@ -188,6 +188,13 @@ fastpm_hip_transport *fastpm_hip_rccl_transport_create(MPI_Comm comm, int device
     return t;
 }
 
+int fastpm_hip_rccl_transport_ranks(const fastpm_hip_transport *t)
+{
+    int n = 0;
+    if (!t || !t->ctx) return -1;
+    return OK_NCCL(ncclCommCount(((const rccl_ctx *) t->ctx)->comm, &n)) ? n : -1;
+}
+
 void fastpm_hip_rccl_transport_destroy(fastpm_hip_transport *t)
 {
     if (!t) return;

@@ -52,6 +52,7 @@ SYMBOLS = {
     "fpmhip_version": (ctypes.c_char_p, []),
     "fpmhip_last_error": (ctypes.c_char_p, []),
     "fpmhip_device_count": (_I, []),
+    "fpmhip_device_pci_bus_id": (_I, [_I, ctypes.c_char_p, _I]),
     "fpmhip_kernel_type_get_orders": (_I, [_I, _PI, _PI, _PI, _PI]),
     "fpmhip_plan_create": (_I, [ctypes.POINTER(Geom), _P, ctypes.POINTER(_P)]),
     "fpmhip_plan_destroy": (None, [_P]),
@@ -60,6 +61,7 @@ SYMBOLS = {
     "fpmhip_plan_stream": (_P, [_P]),
     "fpmhip_plan_buffer": (_P, [_P, _I]),
     "fpmhip_sync": (_I, [_P]),
+    "fpmhip_plan_sync_count": (ctypes.c_longlong, [_P]),
     "fpmhip_force": (_I, [_P, ctypes.POINTER(Particles), _I, _I, _D, _P]),
     "fpmhip_force_species": (_I, [_P, ctypes.POINTER(Particles), _I, _I, _I, _D, _P]),
     "fpmhip_force_host": (_I, [_P, ctypes.POINTER(Particles), _I, _I, _P]),

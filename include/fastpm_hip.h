@@ -147,6 +147,9 @@ typedef struct {
 const char *fpmhip_version(void);
 const char *fpmhip_last_error(void);
 int fpmhip_device_count(void);
+/* PCI address ("0000:c5:00.0") of visible device `device` into out[len >= 16], zero padded: the identity a binding
+ * compares across the ranks of a node to learn whether every rank has a GPU to itself, whatever the launcher masked */
+int fpmhip_device_pci_bus_id(int device, char *out, int len);
 
 /* fastpm_kernel_type_get_orders, api/fastpm/gravity.h:5-10 / libfastpm/gravity.c:111-171 */
 int fpmhip_kernel_type_get_orders(int type, int *potorder, int *gradorder,
@@ -166,6 +169,9 @@ void *fpmhip_plan_buffer(fpmhip_plan *plan, int which);
 /* a plan-owned device scratch of at least `bytes` (grown on demand, freed with the plan; a larger request may move it) */
 void *fpmhip_plan_scratch(fpmhip_plan *plan, size_t bytes);
 int  fpmhip_sync(fpmhip_plan *plan);
+/* how many times the host has waited for the plan's stream through fpmhip_sync since the plan was made (the multi-rank
+ * sequences of fastpm_amd/host/fastpm_slab_hip.c are held to ONE per force call: the final agreement) */
+long long fpmhip_plan_sync_count(const fpmhip_plan *plan);
 
 /* ---- the whole force step, one rank (nranks == 1): gravity.c:458-529 ----
  * delta_k_dev (nullable) receives delta(k)/N^3 after softening, before de-CIC, in the plan's

@@ -116,3 +116,24 @@ def test_bench_line_on_real_gpus(P, nprocy):
     c = d["comm"]
     assert c["backend"].startswith("nccl") and c["world_size"] == P and c["measured"] and not c["share_gpu_dry_run"]
     assert len(c["devices"]) == P and c["distinct_devices"] == P and c["rccl_version"] and "dry_run" not in d
+    # both legs: the drop-in's C sequence over fastpm_slab_rccl.c (the headline) and its Python mirror
+    cd, m = d["c_dropin"], d["python_mirror"]
+    assert "error" not in cd, cd
+    assert cd["measured"] and cd["rccl_ranks"] == P and cd["distinct_devices"] == P and c["rccl_ranks"] == P
+    assert cd["finite"] and cd["momentum_residual"] < 1e-6 and cd["misplaced_after_decompose"] == 0
+    assert d["config"]["host"].startswith("C:") and d["ms_per_step"] == pytest.approx(cd["legs"][0]["ms_per_step"], rel=1e-6)
+    assert [l["chunks"] for l in cd["legs"]] == [0, 1, -1] and all(l["exposed_comm_ms_per_step"] > -0.5 for l in cd["legs"])
+    assert m["value"] > 0 and m["finite"]
+
+
+@pytest.mark.parametrize("P", [2, 8])
+def test_plain_python_bench_launches_itself_on_real_gpus(P):
+    """`python3 bench.py --gpus P` with no launcher: one measured line"""
+    if NGPU < P:
+        pytest.skip("needs %d GPUs" % P)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(P), "--steps", "3", "--warmup", "1",
+                        "--nc", "128", "--nmesh", "256"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == P and d["value"] > 0 and d["comm"]["measured"] and "dry_run" not in d
