@@ -91,7 +91,17 @@ struct MeshGeo {
     int xseg;          // strip plans: x planes a marching workgroup walks (fpm_strips.hip)
     int ntyo;          // strip plans: strips that own particles (= nty; pencils: nty - 1, the last strip is the y halo row's)
     int strips;        // 0: box tiles TILE_X x TILE_Y x TILE_Z; STRIP_Y: strip tiles (ntx = xl, nty = N / STRIP_Y, ntz = 1)
+    // fpmhip_plan_scale_from_device: the paint's factor 1 / mean mass per cell from a DEVICE double (the all-reduced total
+    // mass of a multi-rank step, gravity.c:341-345) instead of the host argument -- no host wait for the all-reduce
+    const double *dtotal;
+    double dnorm;
 };
+
+// the paint's scale: the host argument, or 1.0 / (total / Norm) formed on the device with the host's two roundings
+__device__ __forceinline__ double paint_scale(const MeshGeo &g, double scale_arg)
+{
+    return scale_arg < 0 ? 1.0 / (*g.dtotal / g.dnorm) : scale_arg;        // FPMHIP_SCALE_FROM_DEVICE
+}
 
 // Pencil plans with strip tiles (round 4): the marching kernels write / read the half-spectrum rows where the (y <-> kz)
 // exchange "A" wants / leaves them -- row (x, y) cut into kz blocks, block b at b * chunk + (x * ylr + y) * nzl -- so no

@@ -135,8 +135,10 @@ __global__ __launch_bounds__(256) void mesh_fma_kernel(F *__restrict__ acc, cons
 }
 
 template <typename F>
-__global__ __launch_bounds__(256) void mesh_scale_kernel(F *__restrict__ buf, long long n, double value)
+__global__ __launch_bounds__(256) void mesh_scale_kernel(F *__restrict__ buf, long long n, double value_arg,
+                                                         const double *__restrict__ dtotal, double dnorm)
 {
+    const double value = value_arg < 0 ? 1.0 / (*dtotal / dnorm) : value_arg;       // FPMHIP_SCALE_FROM_DEVICE
     long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long) gridDim.x * blockDim.x;
     for (; i < n; i += stride) buf[i] = (F) (buf[i] * value);
@@ -432,8 +434,9 @@ int fpmhip_mesh_scale(fpmhip_plan *p, void *buf, double value)
 {
     if (!p || !buf) FPM_FAIL(-1, "null argument");
     const long long n = p->lay.allocsize;                // transfer.c:212-220: the whole allocsize
-    if (p->f64) mesh_scale_kernel<double><<<2048, 256, 0, p->stream>>>((double *) buf, n, value);
-    else mesh_scale_kernel<float><<<2048, 256, 0, p->stream>>>((float *) buf, n, value);
+    if (value < 0 && !p->mg.dtotal) FPM_FAIL(-1, "FPMHIP_SCALE_FROM_DEVICE without fpmhip_plan_scale_from_device");
+    if (p->f64) mesh_scale_kernel<double><<<2048, 256, 0, p->stream>>>((double *) buf, n, value, p->mg.dtotal, p->mg.dnorm);
+    else mesh_scale_kernel<float><<<2048, 256, 0, p->stream>>>((float *) buf, n, value, p->mg.dtotal, p->mg.dnorm);
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -603,8 +603,9 @@ __global__ __launch_bounds__(256) void paint_tiles_kernel(MeshGeo g, int ntiles,
                                                           const double *__restrict__ sy,
                                                           const double *__restrict__ sz,
                                                           const float *__restrict__ smass, double M0,
-                                                          double scale, F *__restrict__ canvas, int accumulate)
+                                                          double scale_arg, F *__restrict__ canvas, int accumulate)
 {
+    const double scale = paint_scale(g, scale_arg);
     // accumulators are double for both mesh precisions: the reference adds the double weight to the
     // cell in double and rounds to FastPMFloat per add (painter-cic.c:24); one rounding at the end is
     // the same tolerance class, and ds_add_f64 runs 7x faster than ds_add_f32 here (measured
@@ -689,8 +690,10 @@ __global__ __launch_bounds__(256) void paint_atomic_kernel(MeshGeo g, const doub
 }
 
 template <typename F>
-__global__ __launch_bounds__(256) void scale_kernel(F *__restrict__ buf, long long n, double value)
+__global__ __launch_bounds__(256) void scale_kernel(F *__restrict__ buf, long long n, double value_arg,
+                                                    const double *__restrict__ dtotal = nullptr, double dnorm = 1.0)
 {
+    const double value = value_arg < 0 ? 1.0 / (*dtotal / dnorm) : value_arg;
     long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long) gridDim.x * blockDim.x;
     for (; i < n; i += stride) buf[i] = (F) (buf[i] * value);
@@ -1439,7 +1442,7 @@ static int paint_impl(fpmhip_plan *p, const fpmhip_particles *pt, double scale, 
         if (pt->np > 0)
             paint_atomic_kernel<F><<<blocks_for(pt->np, 256), 256, 0, p->stream>>>(p->mg, pt->x, pt->mass, pt->M0,
                                                                                     pt->np, canvas);
-        scale_kernel<F><<<2048, 256, 0, p->stream>>>(canvas, p->lay.real_elems, scale);
+        scale_kernel<F><<<2048, 256, 0, p->stream>>>(canvas, p->lay.real_elems, scale, p->mg.dtotal, p->mg.dnorm);
         FPM_CHECK_HIP(hipGetLastError());
         return 0;
     }
@@ -1562,10 +1565,17 @@ static int check_particles(const fpmhip_plan *p, const fpmhip_particles *pt)
 
 extern "C" {
 
+static int check_scale(fpmhip_plan *p, double scale)
+{
+    if (scale < 0 && !p->mg.dtotal) FPM_FAIL(-1, "FPMHIP_SCALE_FROM_DEVICE without fpmhip_plan_scale_from_device");
+    return 0;
+}
+
 int fpmhip_paint(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void *canvas)
 {
     FPM_TRY(check_particles(p, pt));
     if (!canvas) FPM_FAIL(-1, "null canvas");
+    FPM_TRY(check_scale(p, scale));
     return p->f64 ? paint_impl<double>(p, pt, scale, (double *) canvas, 0)
                   : paint_impl<float>(p, pt, scale, (float *) canvas, 0);
 }
@@ -1574,6 +1584,7 @@ int fpmhip_paint_add(fpmhip_plan *p, const fpmhip_particles *pt, double scale, v
 {
     FPM_TRY(check_particles(p, pt));
     if (!canvas) FPM_FAIL(-1, "null canvas");
+    FPM_TRY(check_scale(p, scale));
     return p->f64 ? paint_impl<double>(p, pt, scale, (double *) canvas, 1)
                   : paint_impl<float>(p, pt, scale, (float *) canvas, 1);
 }
@@ -1642,6 +1653,63 @@ int fpmhip_total_mass(fpmhip_plan *p, const fpmhip_particles *pt, double *total)
     FPM_CHECK_HIP(hipMemcpyAsync(p->h_pinned, p->d_scalar, sizeof(double), hipMemcpyDeviceToHost, p->stream));
     FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
     *total = *(double *) p->h_pinned;
+    return 0;
+}
+
+// ---- the scalars of a multi-rank step ON THE DEVICE (round 6; fastpm_amd/host/fastpm_slab_hip.c): the total mass is
+// summed, all-reduced by the transport on its own stream and read by the paint kernels without the host ever seeing it
+// (gravity.c:330-345 with the MPI_Allreduce of :341 between two kernels instead of between two host waits)
+__global__ void set_doubles_kernel(double *out, double a, double b, double c, double d)
+{
+    out[0] = a; out[1] = b; out[2] = c; out[3] = d;
+}
+
+double *fpmhip_plan_scalars(fpmhip_plan *p)
+{
+    return p ? p->d_scalar + 16 : nullptr;          // 8 doubles: [0, 4) what this rank contributes, [4, 8) the sums
+}
+
+int fpmhip_total_mass_dev(fpmhip_plan *p, const fpmhip_particles *sets, int nsets, double *out_dev)
+{
+    if (!p || !sets || nsets < 1 || !out_dev) FPM_FAIL(-1, "null argument");
+    double closed = 0;
+    for (int si = 0; si < nsets; si++) {
+        FPM_TRY(check_particles(p, &sets[si]));
+        if (!sets[si].mass) closed += (double) sets[si].np * sets[si].M0;
+    }
+    set_doubles_kernel<<<1, 1, 0, p->stream>>>(out_dev, closed, 0.0, 0.0, 0.0);
+    for (int si = 0; si < nsets; si++)
+        if (sets[si].mass && sets[si].np > 0)
+            mass_sum_kernel<<<1024, 256, 0, p->stream>>>(sets[si].mass, sets[si].M0, sets[si].np, out_dev);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// total_dev: where the all-reduced total mass will be when the paint kernels run; FPMHIP_SCALE_FROM_DEVICE as the scale
+// argument of fpmhip_paint* / fpmhip_mesh_scale then stands for 1.0 / (*total_dev / Norm).  NULL: host arguments only.
+int fpmhip_plan_scale_from_device(fpmhip_plan *p, const double *total_dev)
+{
+    if (!p) FPM_FAIL(-1, "null plan");
+    p->mg.dtotal = total_dev;
+    p->mg.dnorm = p->lay.Norm;
+    return 0;
+}
+
+__global__ void sum_rows_kernel(double *out, const double *rows, int nrows, int n)
+{
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        double s = 0;
+        for (int r = 0; r < nrows; r++) s += rows[(size_t) r * n + j];      // in rank order: the same bits on every rank
+        out[j] = s;
+    }
+}
+
+// out[j] = sum over r of rows[r][j] on `stream` (the in-process loopback transport's all-reduce)
+int fpmhip_sum_rows_on(void *stream, double *out_dev, const double *rows_dev, int nrows, int n)
+{
+    if (!out_dev || !rows_dev || nrows < 1 || n < 1) FPM_FAIL(-1, "null argument");
+    sum_rows_kernel<<<1, 64, 0, (hipStream_t) stream>>>(out_dev, rows_dev, nrows, n);
+    FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }
 

@@ -440,6 +440,22 @@ void *fpmhip_plan_buffer(fpmhip_plan *p, int which)
     return p->buf[which];
 }
 
+// Mesh buffers [0, nbuf) allocated: 0 = they all were already, 1 = this call made at least one (the first step on the
+// plan: the multi-rank sequences agree on the outcome once, BEFORE their first exchange, instead of finding a NULL
+// buffer between two collectives), -2 = an allocation failed.
+int fpmhip_plan_buffers_ready(fpmhip_plan *p, int nbuf)
+{
+    if (!p || nbuf < 0 || nbuf > BUF_COUNT) FPM_FAIL(-1, "bad argument");
+    int made = 0;
+    (void) hipSetDevice(p->device);
+    for (int i = 0; i < nbuf; i++) {
+        if (p->buf[i]) continue;
+        if (ensure_buffer(p, i) != 0) { (void) hipGetLastError(); FPM_FAIL(-2, "mesh buffer %d of %lld bytes: allocation failed", i, (long long) p->lay.allocsize * (long long) p->esize); }
+        made = 1;
+    }
+    return made;
+}
+
 // a plan-owned scratch allocation for the host sequences (the halo rows of a pencil strip plan): grown on demand, freed
 // with the plan; the contents do not survive a larger request
 void *fpmhip_plan_scratch(fpmhip_plan *p, size_t bytes)

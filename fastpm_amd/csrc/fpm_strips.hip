@@ -170,11 +170,12 @@ __device__ __forceinline__ C2<F> *pen_elem(C2<F> *row, bool chunked, int kbase, 
 template <typename PL, typename F, bool R2C, bool WS, bool PEN = false>
 __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), (sizeof(F) == 4 && PL::N == 1024 ? 4 : FPM_PT_MINW)) void paint_march_kernel(
     MeshGeo g, int ntiles, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
-    const double *__restrict__ sy, const double *__restrict__ sz, const float *__restrict__ smass, double M0, double scale,
+    const double *__restrict__ sy, const double *__restrict__ sz, const float *__restrict__ smass, double M0, double scale_arg,
     void *__restrict__ out_, int accumulate, const double *__restrict__ tw_global, const int2 *__restrict__ scell,
     PenIO pen)
 {
     using CF = StripCfg<PL, F>;
+    const double scale = paint_scale(g, scale_arg);
     constexpr int M = PL::N, N = 2 * M, T = PL::T, E = PL::E, NT = CF::pt_threads, WP = CF::pt_pitch, SLOT = STRIP_Y * WP;
     extern __shared__ __align__(16) unsigned char smem_st[];
     using PH = HalfTw<PL>;
@@ -1380,6 +1381,7 @@ int paint_strips(fpmhip_plan *p, const fpmhip_particles *pt, double scale, void 
                  const PenIO *pen_)
 {
     if (!p->mg.strips) FPM_FAIL(-1, "internal: paint_strips on a plan with box tiles");
+    if (scale < 0 && !p->mg.dtotal) FPM_FAIL(-1, "FPMHIP_SCALE_FROM_DEVICE without fpmhip_plan_scale_from_device");
     if (r2c && accumulate) FPM_FAIL(-1, "internal: the fused paint + z pass cannot accumulate");
     PenIO pen = {};
     if (pen_) pen = *pen_;

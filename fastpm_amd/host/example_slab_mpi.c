@@ -118,6 +118,32 @@ static int transport_selftest(const fastpm_hip_transport *t, fpmhip_plan *plan)
         }
         fpmhip_free(dr2);
     }
+    if (t->msgs_begin && t->allreduce_begin && t->xchg_wait) {
+        /* round 6, the event-ordered neighbour messages and scalars: two messages as one group (a ring shift up of the first
+         * 100 doubles, a ring shift down of the next 50), then the sum of (rank + 1, 2) over the ranks on the device */
+        if (t->bind_plan && t->bind_plan(t->ctx, plan)) bad++;
+        for (int i = 0; i < n; i++) { h[i] = 1e6 * r + i; g[i] = -1; }
+        fpmhip_memcpy_h2d(plan, ds, h, (size_t) n * sizeof(double));
+        fpmhip_memcpy_h2d(plan, dr, g, (size_t) n * sizeof(double));
+        const fastpm_hip_msg m[2] = {{ds, dr, 100 * sizeof(double), (r + 1) % P, (r + P - 1) % P},
+                                     {(char *) ds + 100 * sizeof(double), (char *) dr + 100 * sizeof(double), 50 * sizeof(double),
+                                      (r + P - 1) % P, (r + 1) % P}};
+        if (t->msgs_begin(t->ctx, m, 2, 7)) bad++;
+        if (t->xchg_wait(t->ctx, 7)) bad++;
+        fpmhip_memcpy_d2h(plan, g, dr, (size_t) n * sizeof(double));
+        for (int i = 0; i < n; i++) {
+            const double want = i < 100 ? 1e6 * ((r + P - 1) % P) + i : i < 150 ? 1e6 * ((r + 1) % P) + i : -1;
+            if (g[i] != want) { bad++; break; }
+        }
+        double *sc = fpmhip_plan_scalars(plan);
+        const double mine2[4] = {r + 1.0, 2.0, 0, 0};
+        fpmhip_memcpy_h2d(plan, sc, mine2, sizeof(mine2));
+        if (t->allreduce_begin(t->ctx, sc, sc + 4, 2, 9)) bad++;
+        if (t->xchg_wait(t->ctx, 9)) bad++;
+        double got[2] = {0, 0};
+        fpmhip_memcpy_d2h(plan, got, sc + 4, sizeof(got));
+        if (got[0] != P * (P + 1) / 2.0 || got[1] != 2.0 * P) bad++;
+    }
     fpmhip_free(ds); fpmhip_free(dr); free(h);
     return bad;
 }

@@ -3,6 +3,10 @@
  * PencilForce.steps in C99.  Round 5: the transposes are NON-BLOCKING where the transport offers xchg_begin / xchg_wait
  * (all three in-tree transports do) -- cut into plane ranges that overlap the (y, z) passes on slabs and forwards on
  * pencils, by component backwards on pencils; a transport without them gets the blocking whole-mesh sequence.
+ * Round 6: the halo planes / rows (msgs_begin: the force meshes' halos as ONE grouped exchange) and the total mass
+ * (allreduce_begin: summed, all-reduced and consumed on the device) are event-ordered too -- the host enqueues the whole
+ * force step and waits ONCE, at the final agreement; a rank whose compute fails keeps its exchanges going to that point, a
+ * rank whose transport fails aborts the communicator.
  */
 #include <pthread.h>
 #include <stdlib.h>
@@ -12,34 +16,78 @@
 
 #define TRY(expr) do { int rc_ = (expr); if (rc_ != 0) return rc_; } while (0)
 
-enum { B_CANVAS = 0, B_DELTA_K = 1, B_F0 = 2, B_F1 = 3, B_F2 = 4, B_XCHG = 5, B_XCHG2 = 6 };   /* fpmhip_plan_buffer ids */
+enum { B_CANVAS = 0, B_DELTA_K = 1, B_F0 = 2, B_F1 = 3, B_F2 = 4, B_XCHG = 5, B_XCHG2 = 6, B_COUNT = 7 };   /* fpmhip_plan_buffer ids */
 
-static int exchange(fpmhip_plan *plan, const fastpm_hip_transport *t, const void *send, void *recv, size_t chunk_bytes)
+/* ---- the state of one force call (round 6).  nb: the EVENT-ORDERED sequence -- every exchange (transposes, halo planes /
+ * rows, the total mass) is begun on the transport's stream and waited for by the plan's stream; the host enqueues the
+ * whole step and waits once, at the final agreement of fastpm_hip_mesh_force_species.  A compute call that fails on this
+ * rank (RUN) can then not leave the sequence -- its peers would wait in the next exchange for a rank that returned --:
+ * the rank remembers the code, skips its remaining kernels and keeps its exchanges going (XCH) to the agreement, where
+ * every rank learns of the failure.  A TRANSPORT call that fails has no such way out: the rank aborts the communicator
+ * (fastpm_hip_transport.abort: what fastpm_raise does in the reference, logging.c:242-251) and returns.
+ * !nb (a transport without the non-blocking calls, or chunks < 0): the blocking sequence, errors returned at once as
+ * before (the paint's failures agreed on by a host all-reduce). ---- */
+typedef struct {
+    fpmhip_plan *plan;
+    const fastpm_hip_transport *t;
+    int nb, rc, aborted;
+} seq;
+
+static int seq_abort(seq *q, int rc)
 {
-    TRY(fpmhip_sync(plan));
-    return t->alltoall(t->ctx, send, recv, chunk_bytes);
+    if (!q->aborted && q->t->abort) q->t->abort(q->t->ctx);
+    q->aborted = 1;
+    return rc;
 }
 
-/* planes [ix, ix + n) of `mesh` to rank + dir, received from rank - dir into planes starting at recv */
-static int shift(fpmhip_plan *plan, const fastpm_hip_transport *t, void *mesh, int64_t ix, int n, void *recv, int dir,
-                 size_t plane_bytes)
+#define RUN(expr) do { if (!q->rc) { int rc_ = (expr); if (rc_ != 0) { if (!q->nb) return rc_; q->rc = rc_; } } } while (0)
+#define XCH(expr) do { int rc_ = (expr); if (rc_ != 0) return seq_abort(q, rc_); } while (0)
+
+enum { TAG_FWD = 0, TAG_POT = 16, TAG_X = 32, TAG_A = 48, TAG_Y = 60, TAG_Z = 61, TAG_XA = 62, TAG_PA = 63,
+       TAG_HALO = 64, TAG_HALO2 = 65, TAG_SCALAR = 66, MAX_RANGES = 12 };
+
+static int exchange(seq *q, const void *send, void *recv, size_t chunk_bytes)
 {
-    const int P = t->nranks;
-    TRY(fpmhip_sync(plan));
-    return t->sendrecv(t->ctx, fpmhip_plane_ptr(plan, mesh, ix), (t->rank + dir + P) % P, recv,
-                       (t->rank - dir + P) % P, (size_t) n * plane_bytes);
+    RUN(fpmhip_sync(q->plan));
+    XCH(q->t->alltoall(q->t->ctx, send, recv, chunk_bytes));
+    return 0;
+}
+
+/* n neighbour messages as ONE exchange: event-ordered (msgs_begin + xchg_wait: no host wait) or, on a transport without
+ * it, one blocking sendrecv each behind a synchronisation of the plan's stream (pmghosts.c:203-245, 247-307) */
+static int neighbours(seq *q, const fastpm_hip_msg *m, int n, int tag)
+{
+    const fastpm_hip_transport *t = q->t;
+    if (n == 0) return 0;
+    if (q->nb) {
+        XCH(t->msgs_begin(t->ctx, m, n, tag));
+        XCH(t->xchg_wait(t->ctx, tag));
+        return 0;
+    }
+    for (int i = 0; i < n; i++) {
+        RUN(fpmhip_sync(q->plan));
+        XCH(t->sendrecv(t->ctx, m[i].send_dev, m[i].dest, m[i].recv_dev, m[i].source, m[i].bytes));
+    }
+    return 0;
+}
+
+/* slabs: planes [ix, ix + n) of `mesh` to rank + dir, received from rank - dir into recv */
+static fastpm_hip_msg plane_msg(seq *q, void *mesh, int64_t ix, int n, void *recv, int dir, size_t plane_bytes)
+{
+    const int P = q->t->nranks, r = q->t->rank;
+    fastpm_hip_msg m = {fpmhip_plane_ptr(q->plan, mesh, ix), recv, (size_t) n * plane_bytes, (r + dir + P) % P, (r - dir + P) % P};
+    return m;
 }
 
 /* ---- non-blocking exchanges (fastpm_hip_transport.xchg_begin / xchg_wait): the C twin of the "alltoall_range_start" /
  * "alltoall_start" / "wait" requests of fastpm_amd/distributed.py::SlabForce.steps ---- */
-enum { TAG_FWD = 0, TAG_POT = 16, TAG_X = 32, TAG_A = 48, TAG_Y = 60, TAG_Z = 61, TAG_XA = 62, TAG_PA = 63, MAX_RANGES = 12 };
 
-/* How the transposes of this step are cut: 0 = the transport has no non-blocking calls (or chunks < 0): the blocking
- * whole-mesh sequence; 1 = whole meshes, non-blocking where two travel; c > 1 = c plane ranges per transpose, range i on
- * the wire while range i + 1 goes through its (y, z) passes (SlabForce._ranges) */
+/* How the transposes of this step are cut: 0 = the transport has no non-blocking calls (or cannot overlap, or chunks < 0):
+ * the blocking whole-mesh sequence; 1 = whole meshes, non-blocking where two travel; c > 1 = c plane ranges per transpose,
+ * range i on the wire while range i + 1 goes through its (y, z) passes (SlabForce._ranges) */
 static int plane_ranges(fpmhip_plan *plan, const fastpm_hip_transport *t, int64_t xl)
 {
-    if (!t->xchg_begin || !t->xchg_wait) return 0;
+    if (!t->xchg_begin || !t->xchg_wait || t->no_overlap) return 0;
     int c = t->chunks;
     if (c == 0) {
         const char *e = getenv("FASTPM_HIP_CHUNKS");
@@ -57,10 +105,8 @@ static int pieces_of(fpmhip_plan *plan, const fpmhip_layout *lay, int axis_a, in
 {
     const size_t es = (size_t) lay->precision / 8;
     pc->chunk_bytes = (size_t) (axis_a ? lay->chunk_a_elems : lay->chunk_b_elems) * es;
-    if (nx == 0) {
-        pc->first_bytes = 0; pc->piece_bytes = pc->chunk_bytes; pc->stride_bytes = pc->chunk_bytes; pc->npieces = 1;
-        return 0;
-    }
+    pc->first_bytes = 0; pc->piece_bytes = pc->chunk_bytes; pc->stride_bytes = pc->chunk_bytes; pc->npieces = 1;
+    if (nx == 0) return 0;
     int64_t first = 0, piece = 0, stride = 0;
     int n = 1;
     if (axis_a) TRY(fpmhip_range_pieces_a(plan, x0, nx, &first, &piece));
@@ -71,30 +117,71 @@ static int pieces_of(fpmhip_plan *plan, const fpmhip_layout *lay, int axis_a, in
 }
 
 /* slabs: all ranks are one group */
-static int begin_range(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_layout *lay, const void *send,
-                       void *recv, int x0, int nx, int tag)
+static int begin_range(seq *q, const fpmhip_layout *lay, const void *send, void *recv, int x0, int nx, int tag)
 {
     fastpm_hip_pieces pc;
-    TRY(pieces_of(plan, lay, 0, x0, nx, &pc));
-    return t->xchg_begin(t->ctx, send, recv, &pc, NULL, t->nranks, t->rank, tag);
+    const int prc = pieces_of(q->plan, lay, 0, x0, nx, &pc);        /* (geometry only: the same outcome on every rank) */
+    if (prc) return prc;
+    XCH(q->t->xchg_begin(q->t->ctx, send, recv, &pc, NULL, q->t->nranks, q->t->rank, tag));
+    return 0;
 }
 
-/* every species painted into one canvas (gravity.c:323-338): the mass all-reduce covers all of them */
-static int paint_species(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *sets, int nsets,
-                         double Norm, void *canvas, int zr2c)
+static int wait_tag(seq *q, int tag)
 {
+    XCH(q->t->xchg_wait(q->t->ctx, tag));
+    return 0;
+}
+
+/* gravity.c:330-345: the total mass over all species and ranks, the paint x 1 / mean mass per cell.  Event-ordered: the
+ * local sum is formed on the device, all-reduced on the transport's stream and read by the paint kernels from device
+ * memory (FPMHIP_SCALE_FROM_DEVICE) -- the host never sees it.  Returns the scale argument for the paint calls. */
+static int total_mass_scale(seq *q, const fpmhip_particles *sets, int nsets, double Norm, double *scale)
+{
+    const fastpm_hip_transport *t = q->t;
+    if (q->nb) {
+        double *sc = fpmhip_plan_scalars(q->plan);
+        RUN(fpmhip_total_mass_dev(q->plan, sets, nsets, sc));
+        XCH(t->allreduce_begin(t->ctx, sc, sc + 4, 1, TAG_SCALAR));
+        XCH(t->xchg_wait(t->ctx, TAG_SCALAR));
+        RUN(fpmhip_plan_scale_from_device(q->plan, sc + 4));
+        *scale = FPMHIP_SCALE_FROM_DEVICE;
+        return 0;
+    }
     double total = 0;
     for (int si = 0; si < nsets; si++) {
         double m = 0;
-        TRY(fpmhip_total_mass(plan, &sets[si], &m));
+        TRY(fpmhip_total_mass(q->plan, &sets[si], &m));
         total += m;
     }
-    TRY(t->allreduce_sum(t->ctx, &total));
-    const double scale = 1.0 / (total / Norm);
-    /* A failure here is rank-local (a particle outside this rank's region, an allocation): agree on it before the
-     * next collective, or the other ranks wait in an exchange this rank never enters.  The reference raises and
-     * MPI_Aborts (logging.c:242-251); every rank returning nonzero lets the binding do the same. */
-    int rc;
+    XCH(t->allreduce_sum(t->ctx, &total));
+    *scale = 1.0 / (total / Norm);
+    return 0;
+}
+
+/* A failure of the paint is rank-local (a particle outside this rank's region, an allocation).  Blocking sequence: agree on
+ * it before the next collective, or the other ranks wait in an exchange this rank never enters (the reference raises and
+ * MPI_Aborts, logging.c:242-251; every rank returning nonzero lets the binding do the same).  Event-ordered sequence: the
+ * rank keeps its exchanges going (RUN / XCH above) and the failure is agreed on at the end of the step. */
+static int paint_agree(seq *q, int rc)
+{
+    if (q->nb) {
+        if (rc && !q->rc) q->rc = rc;
+        return 0;
+    }
+    double failed = rc != 0;
+    XCH(q->t->allreduce_sum(q->t->ctx, &failed));
+    if (failed != 0) return rc ? rc : -8;            /* -8: another rank failed in the paint */
+    return 0;
+}
+
+/* every species painted into one canvas (gravity.c:323-338): the mass all-reduce covers all of them */
+static int paint_species(seq *q, const fpmhip_particles *sets, int nsets, double Norm, void *canvas, int zr2c)
+{
+    fpmhip_plan *plan = q->plan;
+    double scale = 1.0;
+    TRY(total_mass_scale(q, sets, nsets, Norm, &scale));
+    int rc = q->rc;
+    if (rc) return paint_agree(q, rc);
     if (nsets == 1) {
         rc = zr2c ? fpmhip_paint_zr2c(plan, &sets[0], scale, canvas) : fpmhip_paint(plan, &sets[0], scale, canvas);
     } else {
@@ -103,35 +190,29 @@ static int paint_species(fpmhip_plan *plan, const fastpm_hip_transport *t, const
         for (int si = 1; si < nsets && !rc; si++) rc = fpmhip_paint_add(plan, &sets[si], 1.0, canvas);
         if (!rc) rc = fpmhip_mesh_scale(plan, canvas, scale);
     }
-    double failed = rc != 0;
-    TRY(t->allreduce_sum(t->ctx, &failed));
-    if (failed != 0) return rc ? rc : -8;            /* -8: another rank failed in the paint */
-    return 0;
+    return paint_agree(q, rc);
 }
 
 /* every species read out of the three force meshes (gravity.c:387-395); the last painted one first: the tile binning
  * the plan holds is its.  zc2r: the meshes are half-spectrum rows, the z pass of pm_c2r happens inside the readout. */
-static int readout_species_z(fpmhip_plan *plan, const fpmhip_particles *sets, int nsets, void *f0, void *f1, void *f2, int zc2r)
+static int readout_species_z(seq *q, const fpmhip_particles *sets, int nsets, void *f0, void *f1, void *f2, int zc2r)
 {
     for (int si = nsets - 1; si >= 0; si--)
-        TRY(zc2r ? fpmhip_readout3_zc2r(plan, &sets[si], f0, f1, f2) : fpmhip_readout3(plan, &sets[si], f0, f1, f2));
+        RUN(zc2r ? fpmhip_readout3_zc2r(q->plan, &sets[si], f0, f1, f2) : fpmhip_readout3(q->plan, &sets[si], f0, f1, f2));
     return 0;
 }
 
-static int readout_species(fpmhip_plan *plan, const fpmhip_particles *sets, int nsets, void *f0, void *f1, void *f2)
+static int readout_species(seq *q, const fpmhip_particles *sets, int nsets, void *f0, void *f1, void *f2)
 {
-    return readout_species_z(plan, sets, nsets, f0, f1, f2, 0);
+    return readout_species_z(q, sets, nsets, f0, f1, f2, 0);
 }
 
-static int slab_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *sets, int nsets,
-                              int kernel, int softening, void *delta_k);
-
 /* pm_check_values "After r2c" and "After c2r %d" (gravity.c:352, 383) on what the fused step holds before the readout */
-static int check_force_meshes(fpmhip_plan *plan, void *delta_k, void *const *f)
+static int check_force_meshes(seq *q, void *delta_k, void *const *f)
 {
     static const char *names[3] = {"After c2r 0", "After c2r 1", "After c2r 2"};
-    TRY(fpmhip_check_point(plan, delta_k, "After r2c"));
-    for (int d = 0; d < 3; d++) TRY(fpmhip_check_point(plan, f[d], names[d]));
+    RUN(fpmhip_check_point(q->plan, delta_k, "After r2c"));
+    for (int d = 0; d < 3; d++) RUN(fpmhip_check_point(q->plan, f[d], names[d]));
     return 0;
 }
 
@@ -141,17 +222,14 @@ int fastpm_hip_slab_force(fpmhip_plan *plan, const fastpm_hip_transport *t, cons
     return fastpm_hip_mesh_force_species(plan, t, p, 1, kernel, softening, delta_k);
 }
 
-static int slab_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *sets, int nsets,
-                              int kernel, int softening, void *delta_k)
+static int slab_force_species(seq *q, const fpmhip_particles *sets, int nsets, int kernel, int softening, void *delta_k)
 {
-    const fpmhip_particles *p = &sets[0];
+    fpmhip_plan *plan = q->plan;
+    const fastpm_hip_transport *t = q->t;
     int any_pot = 0;
     for (int si = 0; si < nsets; si++) any_pot |= sets[si].potential != NULL;
     fpmhip_layout lay;
     TRY(fpmhip_plan_layout(plan, &lay));
-    if (lay.nranks != t->nranks || lay.rank != t->rank) return -1;
-    if (lay.nranks == 1)            /* no ghosts, no transposes (pmghosts.c:67: rank == ThisTask always) */
-        return fpmhip_force_species(plan, sets, nsets, kernel, softening, -1.0, delta_k);
     int po, go, dfo, dc;
     TRY(fpmhip_kernel_type_get_orders(kernel, &po, &go, &dfo, &dc));
     const int64_t xl = lay.isize[0];
@@ -168,35 +246,41 @@ static int slab_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, 
      * on one rank, fpm_force.hip), backwards whenever the gradient is taken in k space. */
     const int strips = fpmhip_plan_strips(plan) && !(lay.gradient_mode == FPMHIP_GRADIENT_REAL && go == 1);
     const int strips_fwd = strips && nsets == 1 && softening == FPMHIP_SOFTENING_NONE;
+    const int nr = plane_ranges(plan, t, xl);
+    const int rx = nr > 1 ? (int) (xl / nr) : (int) xl;
 
     /* gravity.c:330-345: total mass over all ranks, paint, normalise; the halo plane goes to rank + 1 */
-    TRY(paint_species(plan, t, sets, nsets, lay.Norm, canvas, strips_fwd));
+    TRY(paint_species(q, sets, nsets, lay.Norm, canvas, strips_fwd));
     void *tmp = work;                                           /* free until the forward transform */
-    TRY(shift(plan, t, canvas, xl, 1, tmp, +1, plane_bytes));
-    TRY(fpmhip_plane_add(plan, fpmhip_plane_ptr(plan, canvas, 0), tmp));
-    TRY(fpmhip_check_point(plan, canvas, "After painting"));     /* gravity.c:350 (no-ops without a check hook) */
+    {
+        const fastpm_hip_msg m = plane_msg(q, canvas, xl, 1, tmp, +1, plane_bytes);
+        TRY(neighbours(q, &m, 1, TAG_HALO));
+    }
+    RUN(fpmhip_plane_add(plan, fpmhip_plane_ptr(plan, canvas, 0), tmp));
+    RUN(fpmhip_check_point(plan, canvas, "After painting"));     /* gravity.c:350 (no-ops without a check hook) */
 
     /* gravity.c:351 pm_r2c, gravity.c:476 softening.  The transpose (pmpfft.c:377-396: PFFT's, which overlaps nothing)
      * in nr plane ranges: range i is on the wire while range i + 1 goes through its (y, z) passes. */
-    const int nr = plane_ranges(plan, t, xl);
-    const int rx = nr > 1 ? (int) (xl / nr) : (int) xl;
     if (nr > 1) {
         for (int i = 0; i < nr; i++) {
-            if (strips_fwd) TRY(fpmhip_fft_y_forward_range(plan, canvas, work, i * rx, rx));
-            else TRY(fpmhip_fft_yz_forward_range(plan, canvas, work, i * rx, rx));
-            TRY(begin_range(plan, t, &lay, work, delta_k, i * rx, rx, TAG_FWD + i));
+            if (strips_fwd) RUN(fpmhip_fft_y_forward_range(plan, canvas, work, i * rx, rx));
+            else RUN(fpmhip_fft_yz_forward_range(plan, canvas, work, i * rx, rx));
+            TRY(begin_range(q, &lay, work, delta_k, i * rx, rx, TAG_FWD + i));
         }
-        for (int i = 0; i < nr; i++) TRY(t->xchg_wait(t->ctx, TAG_FWD + i));
+        for (int i = 0; i < nr; i++) TRY(wait_tag(q, TAG_FWD + i));
     } else {
-        if (strips_fwd) TRY(fpmhip_fft_y_forward(plan, canvas, work));
-        else TRY(fpmhip_fft_yz_forward(plan, canvas, work));
-        TRY(exchange(plan, t, work, delta_k, chunk_bytes));
+        if (strips_fwd) RUN(fpmhip_fft_y_forward(plan, canvas, work));
+        else RUN(fpmhip_fft_yz_forward(plan, canvas, work));
+        if (nr == 1) {
+            TRY(begin_range(q, &lay, work, delta_k, 0, 0, TAG_FWD));
+            TRY(wait_tag(q, TAG_FWD));
+        } else TRY(exchange(q, work, delta_k, chunk_bytes));
     }
     /* without a softening kernel the forward x pass runs on into the transfer and the backward x pass(es) */
     const int fuse_x = softening == FPMHIP_SOFTENING_NONE && fpmhip_plan_column_fft(plan);
     if (!fuse_x) {
-        TRY(fpmhip_fft_x_forward(plan, delta_k));
-        TRY(fpmhip_softening(plan, delta_k, softening));
+        RUN(fpmhip_fft_x_forward(plan, delta_k));
+        RUN(fpmhip_softening(plan, delta_k, softening));
     }
 
     if (lay.gradient_mode == FPMHIP_GRADIENT_REAL && go == 1) {
@@ -204,38 +288,44 @@ static int slab_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, 
         if (xl < 3) return -3;
         void *halo = fpmhip_plan_buffer(plan, B_F1);            /* 4 planes of side buffer */
         void *phi = canvas;
-        if (fuse_x) TRY(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 1, phi, NULL, NULL));
-        else TRY(fpmhip_transfer_fft_x_backward_pot(plan, delta_k, phi, kernel));
+        if (fuse_x) RUN(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 1, phi, NULL, NULL));
+        else RUN(fpmhip_transfer_fft_x_backward_pot(plan, delta_k, phi, kernel));
         if (nr > 1) {
             /* the real-space potential must not land in the buffer later ranges are still being sent from */
             void *phi2 = fpmhip_plan_buffer(plan, B_F2);
             if (!phi2) return -2;
-            for (int i = 0; i < nr; i++) TRY(begin_range(plan, t, &lay, phi, work, i * rx, rx, TAG_POT + i));
+            for (int i = 0; i < nr; i++) TRY(begin_range(q, &lay, phi, work, i * rx, rx, TAG_POT + i));
             for (int i = 0; i < nr; i++) {
-                TRY(t->xchg_wait(t->ctx, TAG_POT + i));
-                TRY(fpmhip_fft_yz_backward_range(plan, work, phi2, i * rx, rx));
+                TRY(wait_tag(q, TAG_POT + i));
+                RUN(fpmhip_fft_yz_backward_range(plan, work, phi2, i * rx, rx));
             }
             phi = phi2;
         } else {
-            TRY(exchange(plan, t, phi, work, chunk_bytes));
-            TRY(fpmhip_fft_yz_backward(plan, work, phi));
+            if (nr == 1) {
+                TRY(begin_range(q, &lay, phi, work, 0, 0, TAG_POT));
+                TRY(wait_tag(q, TAG_POT));
+            } else TRY(exchange(q, phi, work, chunk_bytes));
+            RUN(fpmhip_fft_yz_backward(plan, work, phi));
         }
-        TRY(shift(plan, t, phi, 0, 1, fpmhip_plane_ptr(plan, phi, xl), -1, plane_bytes));
-        TRY(shift(plan, t, phi, 1, 2, fpmhip_plane_ptr(plan, halo, 2), -1, plane_bytes));
-        TRY(shift(plan, t, phi, xl - 2, 2, halo, +1, plane_bytes));
-        for (int si = nsets - 1; si >= 0; si--) TRY(fpmhip_readout_grad(plan, &sets[si], phi, halo));
+        {
+            const fastpm_hip_msg m[3] = {plane_msg(q, phi, 0, 1, fpmhip_plane_ptr(plan, phi, xl), -1, plane_bytes),
+                                         plane_msg(q, phi, 1, 2, fpmhip_plane_ptr(plan, halo, 2), -1, plane_bytes),
+                                         plane_msg(q, phi, xl - 2, 2, halo, +1, plane_bytes)};
+            TRY(neighbours(q, m, 3, TAG_HALO));
+        }
+        for (int si = nsets - 1; si >= 0; si--) RUN(fpmhip_readout_grad(plan, &sets[si], phi, halo));
         for (int si = 0; si < nsets; si++)                                          /* gravity.c:487-492 */
-            if (sets[si].potential) TRY(fpmhip_readout1(plan, &sets[si], phi, sets[si].potential, 1, 0));
+            if (sets[si].potential) RUN(fpmhip_readout1(plan, &sets[si], phi, sets[si].potential, 1, 0));
         return 0;
     }
 
-    void *f[3] = {canvas, fpmhip_plan_buffer(plan, B_F1), fpmhip_plan_buffer(plan, B_F2)};
+    void *f[4] = {canvas, fpmhip_plan_buffer(plan, B_F1), fpmhip_plan_buffer(plan, B_F2), NULL};
     void *work2 = fpmhip_plan_buffer(plan, B_F0);
     if (!f[1] || !f[2] || !work2) return -2;
     if (go == 1 && fpmhip_plan_column_fft(plan)) {
         /* two meshes through the transpose: the x component and the potential (see fastpm_hip.h) */
-        if (fuse_x) TRY(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 2, f[0], f[1], NULL));
-        else TRY(fpmhip_transfer_fft_x_backward_potx(plan, delta_k, f[0], f[1], kernel));
+        if (fuse_x) RUN(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 2, f[0], f[1], NULL));
+        else RUN(fpmhip_transfer_fft_x_backward_potx(plan, delta_k, f[0], f[1], kernel));
         /* the potential column rides along: no second transfer, x pass and all-to-all for it */
         void *potmesh = any_pot ? fpmhip_plan_buffer(plan, B_DELTA_K) : NULL;
         if (any_pot && (delta_k == potmesh || !potmesh)) potmesh = NULL;          /* the caller wants delta_k kept there */
@@ -246,100 +336,118 @@ static int slab_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, 
              * range of the potential has arrived (distributed.py: SlabForce.steps) */
             void *extra = fpmhip_plan_buffer(plan, B_XCHG2);
             if (!extra) return -2;
-            for (int i = 0; i < nr; i++) TRY(begin_range(plan, t, &lay, f[1], work2, i * rx, rx, TAG_POT + i));
-            for (int i = 0; i < nr; i++) TRY(begin_range(plan, t, &lay, f[0], work, i * rx, rx, TAG_X + i));
+            for (int i = 0; i < nr; i++) TRY(begin_range(q, &lay, f[1], work2, i * rx, rx, TAG_POT + i));
+            for (int i = 0; i < nr; i++) TRY(begin_range(q, &lay, f[0], work, i * rx, rx, TAG_X + i));
             for (int i = 0; i < nr; i++) {
-                TRY(t->xchg_wait(t->ctx, TAG_POT + i));
-                if (strips) TRY(fpmhip_fft_y_backward_grad2_range(plan, work2, f[2], extra, potmesh, kernel, i * rx, rx));
-                else TRY(fpmhip_fft_yz_backward_grad2_range(plan, work2, f[2], extra, potmesh, kernel, i * rx, rx));
+                TRY(wait_tag(q, TAG_POT + i));
+                if (strips) RUN(fpmhip_fft_y_backward_grad2_range(plan, work2, f[2], extra, potmesh, kernel, i * rx, rx));
+                else RUN(fpmhip_fft_yz_backward_grad2_range(plan, work2, f[2], extra, potmesh, kernel, i * rx, rx));
             }
             for (int i = 0; i < nr; i++) {
-                TRY(t->xchg_wait(t->ctx, TAG_X + i));
-                if (strips) TRY(fpmhip_fft_y_backward_range(plan, work, f[1], i * rx, rx));
-                else TRY(fpmhip_fft_yz_backward_range(plan, work, f[1], i * rx, rx));
+                TRY(wait_tag(q, TAG_X + i));
+                if (strips) RUN(fpmhip_fft_y_backward_range(plan, work, f[1], i * rx, rx));
+                else RUN(fpmhip_fft_yz_backward_range(plan, work, f[1], i * rx, rx));
             }
             f[0] = f[1]; f[1] = f[2]; f[2] = extra;               /* (x, y, z); the canvas is free (scratch below) */
         } else {
             if (nr == 1) {                                        /* whole meshes, both on the wire at once */
-                TRY(begin_range(plan, t, &lay, f[1], work2, 0, 0, TAG_POT));
-                TRY(begin_range(plan, t, &lay, f[0], work, 0, 0, TAG_X));
-                TRY(t->xchg_wait(t->ctx, TAG_POT));
+                TRY(begin_range(q, &lay, f[1], work2, 0, 0, TAG_POT));
+                TRY(begin_range(q, &lay, f[0], work, 0, 0, TAG_X));
+                TRY(wait_tag(q, TAG_POT));
             } else {
-                TRY(exchange(plan, t, f[0], work, chunk_bytes));
-                TRY(exchange(plan, t, f[1], work2, chunk_bytes));
+                TRY(exchange(q, f[0], work, chunk_bytes));
+                TRY(exchange(q, f[1], work2, chunk_bytes));
             }
-            if (strips) TRY(fpmhip_fft_y_backward_grad2(plan, work2, f[1], f[2], potmesh, kernel));
-            else TRY(fpmhip_fft_yz_backward_grad2(plan, work2, f[1], f[2], potmesh, kernel));
-            if (nr == 1) TRY(t->xchg_wait(t->ctx, TAG_X));
-            if (strips) TRY(fpmhip_fft_y_backward(plan, work, f[0]));
-            else TRY(fpmhip_fft_yz_backward(plan, work, f[0]));
+            if (strips) RUN(fpmhip_fft_y_backward_grad2(plan, work2, f[1], f[2], potmesh, kernel));
+            else RUN(fpmhip_fft_yz_backward_grad2(plan, work2, f[1], f[2], potmesh, kernel));
+            if (nr == 1) TRY(wait_tag(q, TAG_X));
+            if (strips) RUN(fpmhip_fft_y_backward(plan, work, f[0]));
+            else RUN(fpmhip_fft_yz_backward(plan, work, f[0]));
         }
         if (potmesh || strips) {
-            for (int d = 0; d < 3; d++)
-                TRY(shift(plan, t, f[d], 0, 1, fpmhip_plane_ptr(plan, f[d], xl), -1, plane_bytes));
-            if (potmesh) TRY(shift(plan, t, potmesh, 0, 1, fpmhip_plane_ptr(plan, potmesh, xl), -1, plane_bytes));
-            TRY(check_force_meshes(plan, delta_k, f));
-            TRY(readout_species_z(plan, sets, nsets, f[0], f[1], f[2], strips));
+            /* ONE grouped exchange for the halo planes of the three force meshes [and the potential's] */
+            fastpm_hip_msg m[4];
+            f[3] = potmesh;
+            int nm = 0;
+            for (int d = 0; d < 4; d++)
+                if (f[d]) m[nm++] = plane_msg(q, f[d], 0, 1, fpmhip_plane_ptr(plan, f[d], xl), -1, plane_bytes);
+            TRY(neighbours(q, m, nm, TAG_HALO));
+            TRY(check_force_meshes(q, delta_k, f));
+            TRY(readout_species_z(q, sets, nsets, f[0], f[1], f[2], strips));
             for (int si = 0; si < nsets && potmesh; si++)
                 if (sets[si].potential)
-                    TRY(strips ? fpmhip_readout1_zc2r(plan, &sets[si], potmesh, sets[si].potential, 1, 0)
+                    RUN(strips ? fpmhip_readout1_zc2r(plan, &sets[si], potmesh, sets[si].potential, 1, 0)
                                : fpmhip_readout1(plan, &sets[si], potmesh, sets[si].potential, 1, 0));
             if (potmesh || !any_pot) return 0;
             /* strips, a potential column, and the caller's delta_k sits where the potential would have ridden along: the
              * potential takes the reference's own route below (transfer -> c2r -> readout of a real mesh) */
-            TRY(fpmhip_transfer(plan, delta_k, canvas, kernel, FPMHIP_FIELD_POTENTIAL));
-            TRY(fpmhip_fft_x_backward(plan, canvas));
-            TRY(exchange(plan, t, canvas, work, chunk_bytes));
-            TRY(fpmhip_fft_yz_backward(plan, work, canvas));
-            TRY(shift(plan, t, canvas, 0, 1, fpmhip_plane_ptr(plan, canvas, xl), -1, plane_bytes));
+            RUN(fpmhip_transfer(plan, delta_k, canvas, kernel, FPMHIP_FIELD_POTENTIAL));
+            RUN(fpmhip_fft_x_backward(plan, canvas));
+            if (nr >= 1) {
+                TRY(begin_range(q, &lay, canvas, work, 0, 0, TAG_POT));
+                TRY(wait_tag(q, TAG_POT));
+            } else TRY(exchange(q, canvas, work, chunk_bytes));
+            RUN(fpmhip_fft_yz_backward(plan, work, canvas));
+            {
+                const fastpm_hip_msg mp = plane_msg(q, canvas, 0, 1, fpmhip_plane_ptr(plan, canvas, xl), -1, plane_bytes);
+                TRY(neighbours(q, &mp, 1, TAG_HALO));
+            }
             for (int si = 0; si < nsets; si++)
-                if (sets[si].potential) TRY(fpmhip_readout1(plan, &sets[si], canvas, sets[si].potential, 1, 0));
+                if (sets[si].potential) RUN(fpmhip_readout1(plan, &sets[si], canvas, sets[si].potential, 1, 0));
             return 0;
         }
     } else {
         if (fuse_x) {
-            TRY(fpmhip_fft_x_forward(plan, delta_k));
-            TRY(fpmhip_softening(plan, delta_k, softening));
+            RUN(fpmhip_fft_x_forward(plan, delta_k));
+            RUN(fpmhip_softening(plan, delta_k, softening));
         }
         /* gravity.c:373-397, one transpose per component; non-blocking: component d + 1 is on the wire while the (y, z)
          * passes of component d run (the landing zones alternate; a begin is ordered after the pass that last read its
          * landing zone because it is ordered after everything on the plan's stream) */
         void *land[3] = {work, work2, work};
         for (int d = 0; d < 3; d++) {
-            TRY(fpmhip_transfer(plan, delta_k, f[d], kernel, d));
-            TRY(fpmhip_fft_x_backward(plan, f[d]));
+            RUN(fpmhip_transfer(plan, delta_k, f[d], kernel, d));
+            RUN(fpmhip_fft_x_backward(plan, f[d]));
             if (nr >= 1) {
-                TRY(begin_range(plan, t, &lay, f[d], land[d], 0, 0, TAG_X + d));
+                TRY(begin_range(q, &lay, f[d], land[d], 0, 0, TAG_X + d));
                 if (d == 0) continue;
-                TRY(t->xchg_wait(t->ctx, TAG_X + d - 1));
-                if (strips) TRY(fpmhip_fft_y_backward(plan, land[d - 1], f[d - 1]));
-                else TRY(fpmhip_fft_yz_backward(plan, land[d - 1], f[d - 1]));
+                TRY(wait_tag(q, TAG_X + d - 1));
+                if (strips) RUN(fpmhip_fft_y_backward(plan, land[d - 1], f[d - 1]));
+                else RUN(fpmhip_fft_yz_backward(plan, land[d - 1], f[d - 1]));
                 continue;
             }
-            TRY(exchange(plan, t, f[d], work, chunk_bytes));
-            if (strips) TRY(fpmhip_fft_y_backward(plan, work, f[d]));
-            else TRY(fpmhip_fft_yz_backward(plan, work, f[d]));
+            TRY(exchange(q, f[d], work, chunk_bytes));
+            if (strips) RUN(fpmhip_fft_y_backward(plan, work, f[d]));
+            else RUN(fpmhip_fft_yz_backward(plan, work, f[d]));
         }
         if (nr >= 1) {
-            TRY(t->xchg_wait(t->ctx, TAG_X + 2));
-            if (strips) TRY(fpmhip_fft_y_backward(plan, land[2], f[2]));
-            else TRY(fpmhip_fft_yz_backward(plan, land[2], f[2]));
+            TRY(wait_tag(q, TAG_X + 2));
+            if (strips) RUN(fpmhip_fft_y_backward(plan, land[2], f[2]));
+            else RUN(fpmhip_fft_yz_backward(plan, land[2], f[2]));
         }
     }
-    for (int d = 0; d < 3; d++)
-        TRY(shift(plan, t, f[d], 0, 1, fpmhip_plane_ptr(plan, f[d], xl), -1, plane_bytes));
-    TRY(check_force_meshes(plan, delta_k, f));
-    TRY(readout_species_z(plan, sets, nsets, f[0], f[1], f[2], strips));
-    if (any_pot) {                                              /* gravity.c:487-492 */
-        TRY(fpmhip_transfer(plan, delta_k, canvas, kernel, FPMHIP_FIELD_POTENTIAL));
-        TRY(fpmhip_fft_x_backward(plan, canvas));
-        TRY(exchange(plan, t, canvas, work, chunk_bytes));
-        TRY(fpmhip_fft_yz_backward(plan, work, canvas));
-        TRY(shift(plan, t, canvas, 0, 1, fpmhip_plane_ptr(plan, canvas, xl), -1, plane_bytes));
-        for (int si = 0; si < nsets; si++)
-            if (sets[si].potential) TRY(fpmhip_readout1(plan, &sets[si], canvas, sets[si].potential, 1, 0));
+    {
+        fastpm_hip_msg m[3];
+        for (int d = 0; d < 3; d++) m[d] = plane_msg(q, f[d], 0, 1, fpmhip_plane_ptr(plan, f[d], xl), -1, plane_bytes);
+        TRY(neighbours(q, m, 3, TAG_HALO));
     }
-    (void) p;
+    TRY(check_force_meshes(q, delta_k, f));
+    TRY(readout_species_z(q, sets, nsets, f[0], f[1], f[2], strips));
+    if (any_pot) {                                              /* gravity.c:487-492 */
+        RUN(fpmhip_transfer(plan, delta_k, canvas, kernel, FPMHIP_FIELD_POTENTIAL));
+        RUN(fpmhip_fft_x_backward(plan, canvas));
+        if (nr >= 1) {
+            TRY(begin_range(q, &lay, canvas, work, 0, 0, TAG_POT));
+            TRY(wait_tag(q, TAG_POT));
+        } else TRY(exchange(q, canvas, work, chunk_bytes));
+        RUN(fpmhip_fft_yz_backward(plan, work, canvas));
+        {
+            const fastpm_hip_msg mp = plane_msg(q, canvas, 0, 1, fpmhip_plane_ptr(plan, canvas, xl), -1, plane_bytes);
+            TRY(neighbours(q, &mp, 1, TAG_HALO));
+        }
+        for (int si = 0; si < nsets; si++)
+            if (sets[si].potential) RUN(fpmhip_readout1(plan, &sets[si], canvas, sets[si].potential, 1, 0));
+    }
     return 0;
 }
 
@@ -353,37 +461,43 @@ typedef struct {
 } mesh_groups;
 
 /* exchange A (y <-> kz, inside my row) / B (x <-> ky, inside my column); a group of one is a plain copy */
-static int exchange_axis(fpmhip_plan *plan, const fastpm_hip_transport *t, const mesh_groups *g, int axis,
-                         const void *send, void *recv, size_t chunk_bytes)
+static int exchange_axis(seq *q, const mesh_groups *g, int axis, const void *send, void *recv, size_t chunk_bytes)
 {
+    const fastpm_hip_transport *t = q->t;
     const int n = axis == 0 ? g->Ny : g->Nx;
-    if (n == 1) return fpmhip_memcpy_d2d(plan, recv, send, chunk_bytes);
+    if (n == 1) { RUN(fpmhip_memcpy_d2d(q->plan, recv, send, chunk_bytes)); return 0; }
     if (!t->alltoall_members) return -1;
-    TRY(fpmhip_sync(plan));
-    return t->alltoall_members(t->ctx, send, recv, chunk_bytes, axis == 0 ? g->row : g->col, n, axis == 0 ? g->ry : g->rx);
+    RUN(fpmhip_sync(q->plan));
+    XCH(t->alltoall_members(t->ctx, send, recv, chunk_bytes, axis == 0 ? g->row : g->col, n, axis == 0 ? g->ry : g->rx));
+    return 0;
 }
 
 /* the non-blocking form: the planes [x0, x0 + nx) of every chunk (nx == 0: whole chunks); a group of one copies on the
  * plan's stream (ordered there: nothing to wait for) */
-static int begin_axis(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_layout *lay, const mesh_groups *g,
-                      int axis, const void *send, void *recv, int x0, int nx, int tag)
+static int begin_axis(seq *q, const fpmhip_layout *lay, const mesh_groups *g, int axis, const void *send, void *recv,
+                      int x0, int nx, int tag)
 {
+    const fastpm_hip_transport *t = q->t;
     const int n = axis == 0 ? g->Ny : g->Nx;
     fastpm_hip_pieces pc;
-    TRY(pieces_of(plan, lay, axis == 0, x0, nx, &pc));
+    const int prc = pieces_of(q->plan, lay, axis == 0, x0, nx, &pc);
+    if (prc) return prc;
     if (n == 1) {
         for (int k = 0; k < pc.npieces; k++) {
             const size_t o = pc.first_bytes + (size_t) k * pc.stride_bytes;
-            TRY(fpmhip_memcpy_d2d(plan, (char *) recv + o, (const char *) send + o, pc.piece_bytes));
+            RUN(fpmhip_memcpy_d2d(q->plan, (char *) recv + o, (const char *) send + o, pc.piece_bytes));
         }
         return 0;
     }
-    return t->xchg_begin(t->ctx, send, recv, &pc, axis == 0 ? g->row : g->col, n, axis == 0 ? g->ry : g->rx, tag);
+    XCH(t->xchg_begin(t->ctx, send, recv, &pc, axis == 0 ? g->row : g->col, n, axis == 0 ? g->ry : g->rx, tag));
+    return 0;
 }
 
-static int wait_axis(const fastpm_hip_transport *t, const mesh_groups *g, int axis, int tag)
+static int wait_axis(seq *q, const mesh_groups *g, int axis, int tag)
 {
-    return (axis == 0 ? g->Ny : g->Nx) == 1 ? 0 : t->xchg_wait(t->ctx, tag);
+    if ((axis == 0 ? g->Ny : g->Nx) == 1) return 0;
+    XCH(q->t->xchg_wait(q->t->ctx, tag));
+    return 0;
 }
 
 static int neighbour(const mesh_groups *g, int axis, int dir)
@@ -391,45 +505,56 @@ static int neighbour(const mesh_groups *g, int axis, int dir)
     return axis == 0 ? g->row[(g->ry + dir + g->Ny) % g->Ny] : g->col[(g->rx + dir + g->Nx) % g->Nx];
 }
 
-/* after the paint: the extra x plane to rank_x + 1, then the extra y row to rank_y + 1 (the corner cell takes both hops) */
-static int halo_out(fpmhip_plan *plan, const fastpm_hip_transport *t, const mesh_groups *g, const fpmhip_layout *lay,
-                    void *mesh, void *scratch)
+/* a message to the neighbour at +dir along `axis` (0: inside my row, i.e. in y; 1: inside my column, i.e. in x) */
+static fastpm_hip_msg axis_msg(const mesh_groups *g, int axis, int dir, const void *send, void *recv, size_t bytes)
 {
+    fastpm_hip_msg m = {send, recv, bytes, neighbour(g, axis, dir), neighbour(g, axis, -dir)};
+    return m;
+}
+
+/* after the paint: the extra x plane to rank_x + 1, then the extra y row to rank_y + 1 (the corner cell takes both hops) */
+static int halo_out(seq *q, const mesh_groups *g, const fpmhip_layout *lay, void *mesh, void *scratch)
+{
+    fpmhip_plan *plan = q->plan;
     const size_t es = (size_t) lay->precision / 8;
     const size_t plane_bytes = (size_t) lay->plane_elems * es, row_bytes = (size_t) lay->isize[0] * (size_t) lay->istrides[1] * es;
     if (g->Nx > 1) {
-        TRY(fpmhip_sync(plan));
-        TRY(t->sendrecv(t->ctx, fpmhip_plane_ptr(plan, mesh, lay->isize[0]), neighbour(g, 1, +1), scratch,
-                        neighbour(g, 1, -1), plane_bytes));
-        TRY(fpmhip_plane_add(plan, fpmhip_plane_ptr(plan, mesh, 0), scratch));
+        const fastpm_hip_msg m = axis_msg(g, 1, +1, fpmhip_plane_ptr(plan, mesh, lay->isize[0]), scratch, plane_bytes);
+        TRY(neighbours(q, &m, 1, TAG_HALO));
+        RUN(fpmhip_plane_add(plan, fpmhip_plane_ptr(plan, mesh, 0), scratch));
     }
     if (g->Ny > 1) {
         void *rs = scratch, *rr = (char *) scratch + row_bytes;
-        TRY(fpmhip_yrow(plan, mesh, lay->isize[1], rs, 0));
-        TRY(fpmhip_sync(plan));
-        TRY(t->sendrecv(t->ctx, rs, neighbour(g, 0, +1), rr, neighbour(g, 0, -1), row_bytes));
-        TRY(fpmhip_yrow(plan, mesh, 0, rr, 2));
+        RUN(fpmhip_yrow(plan, mesh, lay->isize[1], rs, 0));
+        const fastpm_hip_msg m = axis_msg(g, 0, +1, rs, rr, row_bytes);
+        TRY(neighbours(q, &m, 1, TAG_HALO2));
+        RUN(fpmhip_yrow(plan, mesh, 0, rr, 2));
     }
     return 0;
 }
 
-/* before a readout: row 0 of rank_y + 1 into my extra row, then plane 0 (with that row) of rank_x + 1 into my extra plane */
-static int halo_in(fpmhip_plan *plan, const fastpm_hip_transport *t, const mesh_groups *g, const fpmhip_layout *lay,
-                   void *mesh, void *scratch)
+/* before a readout, for the nm meshes at once: row 0 of rank_y + 1 into my extra row (ONE grouped exchange), then plane 0
+ * (with that row) of rank_x + 1 into my extra plane (ONE grouped exchange).  scratch: 2 nm rows */
+static int halo_in(seq *q, const mesh_groups *g, const fpmhip_layout *lay, void *const *mesh, int nm, void *scratch)
 {
+    fpmhip_plan *plan = q->plan;
     const size_t es = (size_t) lay->precision / 8;
     const size_t plane_bytes = (size_t) lay->plane_elems * es, row_bytes = (size_t) lay->isize[0] * (size_t) lay->istrides[1] * es;
+    fastpm_hip_msg m[4];
     if (g->Ny > 1) {
-        void *rs = scratch, *rr = (char *) scratch + row_bytes;
-        TRY(fpmhip_yrow(plan, mesh, 0, rs, 0));
-        TRY(fpmhip_sync(plan));
-        TRY(t->sendrecv(t->ctx, rs, neighbour(g, 0, -1), rr, neighbour(g, 0, +1), row_bytes));
-        TRY(fpmhip_yrow(plan, mesh, lay->isize[1], rr, 1));
+        for (int d = 0; d < nm; d++) {
+            char *rs = (char *) scratch + (size_t) 2 * d * row_bytes;
+            RUN(fpmhip_yrow(plan, mesh[d], 0, rs, 0));
+            m[d] = axis_msg(g, 0, -1, rs, rs + row_bytes, row_bytes);
+        }
+        TRY(neighbours(q, m, nm, TAG_HALO));
+        for (int d = 0; d < nm; d++)
+            RUN(fpmhip_yrow(plan, mesh[d], lay->isize[1], (char *) scratch + (size_t) (2 * d + 1) * row_bytes, 1));
     }
     if (g->Nx > 1) {
-        TRY(fpmhip_sync(plan));
-        TRY(t->sendrecv(t->ctx, fpmhip_plane_ptr(plan, mesh, 0), neighbour(g, 1, -1),
-                        fpmhip_plane_ptr(plan, mesh, lay->isize[0]), neighbour(g, 1, +1), plane_bytes));
+        for (int d = 0; d < nm; d++)
+            m[d] = axis_msg(g, 1, -1, fpmhip_plane_ptr(plan, mesh[d], 0), fpmhip_plane_ptr(plan, mesh[d], lay->isize[0]), plane_bytes);
+        TRY(neighbours(q, m, nm, TAG_HALO2));
     }
     return 0;
 }
@@ -437,25 +562,27 @@ static int halo_in(fpmhip_plan *plan, const fastpm_hip_transport *t, const mesh_
 /* pm_r2c from its y pass on (pmpfft.c:377-379) with both of PFFT's transposes NON-BLOCKING, in nr plane ranges (nr == 1:
  * whole meshes): every range of exchange A is begun at once (what fills send_a is done), range i goes through its y
  * pass and into exchange B while the later ranges of A are still on the wire.  send_a -> recv_a -> [y] send_b -> delta_k. */
-static int pencil_forward_from_a(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_layout *lay,
-                                 const mesh_groups *g, int nr, void *send_a, void *recv_a, void *send_b, void *delta_k)
+static int pencil_forward_from_a(seq *q, const fpmhip_layout *lay, const mesh_groups *g, int nr, void *send_a, void *recv_a,
+                                 void *send_b, void *delta_k)
 {
+    fpmhip_plan *plan = q->plan;
     const int rx = nr > 1 ? (int) (lay->isize[0] / nr) : 0;
-    for (int i = 0; i < nr; i++) TRY(begin_axis(plan, t, lay, g, 0, send_a, recv_a, i * rx, rx, TAG_A + i));
+    for (int i = 0; i < nr; i++) TRY(begin_axis(q, lay, g, 0, send_a, recv_a, i * rx, rx, TAG_A + i));
     for (int i = 0; i < nr; i++) {
-        TRY(wait_axis(t, g, 0, TAG_A + i));
-        if (nr > 1) TRY(fpmhip_fft_y_forward_range(plan, recv_a, send_b, i * rx, rx));
-        else TRY(fpmhip_fft_y_forward(plan, recv_a, send_b));
-        TRY(begin_axis(plan, t, lay, g, 1, send_b, delta_k, i * rx, rx, TAG_FWD + i));
+        TRY(wait_axis(q, g, 0, TAG_A + i));
+        if (nr > 1) RUN(fpmhip_fft_y_forward_range(plan, recv_a, send_b, i * rx, rx));
+        else RUN(fpmhip_fft_y_forward(plan, recv_a, send_b));
+        TRY(begin_axis(q, lay, g, 1, send_b, delta_k, i * rx, rx, TAG_FWD + i));
     }
-    for (int i = 0; i < nr; i++) TRY(wait_axis(t, g, 1, TAG_FWD + i));
+    for (int i = 0; i < nr; i++) TRY(wait_axis(q, g, 1, TAG_FWD + i));
     return 0;
 }
 
 /* the force step on a pencil plan with strip tiles; c, w: the plan's mesh buffers as pencil_force_species names them */
-static int pencil_strip_force(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_layout *lay, const mesh_groups *g,
-                              const fpmhip_particles *set, int kernel, void *delta_k, void *c, void **w)
+static int pencil_strip_force(seq *q, const fpmhip_layout *lay, const mesh_groups *g, const fpmhip_particles *set, int kernel,
+                              void *delta_k, void *c, void **w, int nr)
 {
+    fpmhip_plan *plan = q->plan;
     const size_t es = (size_t) lay->precision / 8;
     const size_t a_bytes = (size_t) lay->chunk_a_elems * es, b_bytes = (size_t) lay->chunk_b_elems * es;
     const int64_t xl = lay->isize[0], ylr = lay->isize[1], rp2 = lay->istrides[1];
@@ -470,90 +597,95 @@ static int pencil_strip_force(fpmhip_plan *plan, const fastpm_hip_transport *t, 
         hxs[m] = hb + m * per; hxr[m] = hxs[m] + hx_bytes; hys[m] = hxr[m] + hx_bytes; hyr[m] = hys[m] + hy_bytes;
     }
     /* gravity.c:330-345: total mass over the ranks, then paint x 1 / mean mass per cell; a rank-local failure (a
-     * particle outside this rank's region) is agreed on before the next collective */
-    double total = 0;
-    TRY(fpmhip_total_mass(plan, set, &total));
-    TRY(t->allreduce_sum(t->ctx, &total));
-    int rc = fpmhip_paint_zr2c_pen(plan, set, 1.0 / (total / lay->Norm), w[0], has_x ? hxs[0] : NULL, hys[0]);
-    double failed = rc != 0;
-    TRY(t->allreduce_sum(t->ctx, &failed));
-    if (failed != 0) return rc ? rc : -8;
+     * particle outside this rank's region) is agreed on before the next collective (blocking sequence) or carried to the
+     * final agreement (event-ordered sequence) */
+    double scale = 1.0;
+    TRY(total_mass_scale(q, set, 1, lay->Norm, &scale));
+    TRY(paint_agree(q, q->rc ? q->rc : fpmhip_paint_zr2c_pen(plan, set, scale, w[0], has_x ? hxs[0] : NULL, hys[0])));
     if (has_x) {                                    /* the x plane first: it carries the corner row */
-        TRY(fpmhip_sync(plan));
-        TRY(t->sendrecv(t->ctx, hxs[0], neighbour(g, 1, +1), hxr[0], neighbour(g, 1, -1), hx_bytes));
-        TRY(fpmhip_pen_halo_rows(plan, w[0], hxr[0], 0, 0));
-        TRY(fpmhip_row_add(plan, hys[0], hxr[0] + (size_t) ylr * row_bytes, rp2 / 2));
+        const fastpm_hip_msg m = axis_msg(g, 1, +1, hxs[0], hxr[0], hx_bytes);
+        TRY(neighbours(q, &m, 1, TAG_HALO));
+        RUN(fpmhip_pen_halo_rows(plan, w[0], hxr[0], 0, 0));
+        RUN(fpmhip_row_add(plan, hys[0], hxr[0] + (size_t) ylr * row_bytes, rp2 / 2));
     }
-    TRY(fpmhip_sync(plan));
-    TRY(t->sendrecv(t->ctx, hys[0], neighbour(g, 0, +1), hyr[0], neighbour(g, 0, -1), hy_bytes));
-    TRY(fpmhip_pen_halo_rows(plan, w[0], hyr[0], 1, 0));
-    TRY(fpmhip_check_point(plan, w[0], "After painting"));                        /* gravity.c:350 */
+    {
+        const fastpm_hip_msg m = axis_msg(g, 0, +1, hys[0], hyr[0], hy_bytes);
+        TRY(neighbours(q, &m, 1, TAG_HALO2));
+    }
+    RUN(fpmhip_pen_halo_rows(plan, w[0], hyr[0], 1, 0));
+    RUN(fpmhip_check_point(plan, w[0], "After painting"));                        /* gravity.c:350 */
     void *mesh[4];                                  /* (x, y, z [, potential]) as the (y <-> kz) exchange delivers them */
-    const int nr = plane_ranges(plan, t, xl);
     if (nr >= 1) {
-        TRY(pencil_forward_from_a(plan, t, lay, g, nr, w[0], w[1], w[2], delta_k));
-        TRY(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 2, w[0], w[1], NULL));
+        TRY(pencil_forward_from_a(q, lay, g, nr, w[0], w[1], w[2], delta_k));
+        RUN(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 2, w[0], w[1], NULL));
         /* backwards (pmpfft.c:394-396) by COMPONENT: the potential's y pass (which makes the y and z components) runs
          * while the x component is in exchange B, the x component's y pass while y and z are in exchange A.  A pass never
          * writes where an exchange still reads or lands: see the buffer of every begin below. */
-        TRY(begin_axis(plan, t, lay, g, 1, w[1], w[2], 0, 0, TAG_POT));             /* potential */
-        TRY(begin_axis(plan, t, lay, g, 1, w[0], w[3], 0, 0, TAG_X));               /* x component */
-        TRY(wait_axis(t, g, 1, TAG_POT));                                           /* w[1] is free again */
-        TRY(fpmhip_fft_y_backward_grad2(plan, w[2], c, w[4], has_pot ? w[1] : NULL, kernel));   /* gravity.c:487-492 rides along */
-        TRY(begin_axis(plan, t, lay, g, 0, c, w[2], 0, 0, TAG_Y));
-        TRY(wait_axis(t, g, 1, TAG_X));                                             /* w[0] is free again */
-        TRY(begin_axis(plan, t, lay, g, 0, w[4], w[0], 0, 0, TAG_Z));
-        TRY(wait_axis(t, g, 0, TAG_Y));                                             /* c is free again */
-        TRY(fpmhip_fft_y_backward(plan, w[3], c));
-        TRY(begin_axis(plan, t, lay, g, 0, c, w[3], 0, 0, TAG_XA));
-        TRY(wait_axis(t, g, 0, TAG_Z));                                             /* w[4] is free again */
-        if (has_pot) TRY(begin_axis(plan, t, lay, g, 0, w[1], w[4], 0, 0, TAG_PA));
-        TRY(wait_axis(t, g, 0, TAG_XA));
-        if (has_pot) TRY(wait_axis(t, g, 0, TAG_PA));
+        TRY(begin_axis(q, lay, g, 1, w[1], w[2], 0, 0, TAG_POT));             /* potential */
+        TRY(begin_axis(q, lay, g, 1, w[0], w[3], 0, 0, TAG_X));               /* x component */
+        TRY(wait_axis(q, g, 1, TAG_POT));                                     /* w[1] is free again */
+        RUN(fpmhip_fft_y_backward_grad2(plan, w[2], c, w[4], has_pot ? w[1] : NULL, kernel));   /* gravity.c:487-492 rides along */
+        TRY(begin_axis(q, lay, g, 0, c, w[2], 0, 0, TAG_Y));
+        TRY(wait_axis(q, g, 1, TAG_X));                                       /* w[0] is free again */
+        TRY(begin_axis(q, lay, g, 0, w[4], w[0], 0, 0, TAG_Z));
+        TRY(wait_axis(q, g, 0, TAG_Y));                                       /* c is free again */
+        RUN(fpmhip_fft_y_backward(plan, w[3], c));
+        TRY(begin_axis(q, lay, g, 0, c, w[3], 0, 0, TAG_XA));
+        TRY(wait_axis(q, g, 0, TAG_Z));                                       /* w[4] is free again */
+        if (has_pot) TRY(begin_axis(q, lay, g, 0, w[1], w[4], 0, 0, TAG_PA));
+        TRY(wait_axis(q, g, 0, TAG_XA));
+        if (has_pot) TRY(wait_axis(q, g, 0, TAG_PA));
         mesh[0] = w[3]; mesh[1] = w[2]; mesh[2] = w[0]; mesh[3] = has_pot ? w[4] : NULL;
     } else {
-        TRY(exchange_axis(plan, t, g, 0, w[0], w[1], a_bytes));                   /* pm_r2c from its y pass on */
-        TRY(fpmhip_fft_y_forward(plan, w[1], w[0]));
-        TRY(exchange_axis(plan, t, g, 1, w[0], delta_k, b_bytes));
-        TRY(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 2, w[0], w[1], NULL));
-        TRY(exchange_axis(plan, t, g, 1, w[1], w[2], b_bytes));                   /* potential */
-        TRY(exchange_axis(plan, t, g, 1, w[0], w[3], b_bytes));                   /* x component */
-        void *potmesh = has_pot ? w[4] : NULL;                                    /* gravity.c:487-492 rides along */
-        TRY(fpmhip_fft_y_backward_grad2(plan, w[2], w[0], w[1], potmesh, kernel));
-        TRY(fpmhip_fft_y_backward(plan, w[3], w[2]));
+        TRY(exchange_axis(q, g, 0, w[0], w[1], a_bytes));                     /* pm_r2c from its y pass on */
+        RUN(fpmhip_fft_y_forward(plan, w[1], w[0]));
+        TRY(exchange_axis(q, g, 1, w[0], delta_k, b_bytes));
+        RUN(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 2, w[0], w[1], NULL));
+        TRY(exchange_axis(q, g, 1, w[1], w[2], b_bytes));                     /* potential */
+        TRY(exchange_axis(q, g, 1, w[0], w[3], b_bytes));                     /* x component */
+        void *potmesh = has_pot ? w[4] : NULL;                                /* gravity.c:487-492 rides along */
+        RUN(fpmhip_fft_y_backward_grad2(plan, w[2], w[0], w[1], potmesh, kernel));
+        RUN(fpmhip_fft_y_backward(plan, w[3], w[2]));
         /* (x, y, z [, potential]) in A layout: w[2], w[0], w[1] [, w[4]]; the received chunks are what the readout takes */
         mesh[0] = c; mesh[1] = w[3]; mesh[2] = w[2]; mesh[3] = has_pot ? w[0] : NULL;
-        TRY(exchange_axis(plan, t, g, 0, w[2], c, a_bytes));
-        TRY(exchange_axis(plan, t, g, 0, w[0], w[3], a_bytes));
-        TRY(exchange_axis(plan, t, g, 0, w[1], w[2], a_bytes));
-        if (has_pot) TRY(exchange_axis(plan, t, g, 0, w[4], w[0], a_bytes));
+        TRY(exchange_axis(q, g, 0, w[2], c, a_bytes));
+        TRY(exchange_axis(q, g, 0, w[0], w[3], a_bytes));
+        TRY(exchange_axis(q, g, 0, w[1], w[2], a_bytes));
+        if (has_pot) TRY(exchange_axis(q, g, 0, w[4], w[0], a_bytes));
     }
-    /* the neighbours' rows: y first, then the x plane with the fresh corner row */
-    for (int m = 0; m < nm; m++) {
-        TRY(fpmhip_pen_halo_rows(plan, mesh[m], hys[m], 1, 1));
-        TRY(fpmhip_sync(plan));
-        TRY(t->sendrecv(t->ctx, hys[m], neighbour(g, 0, -1), hyr[m], neighbour(g, 0, +1), hy_bytes));
+    /* the neighbours' rows, the nm meshes together: y first (ONE grouped exchange), then the x planes with the fresh corner
+     * rows (ONE grouped exchange) */
+    {
+        fastpm_hip_msg mm[4];
+        for (int m = 0; m < nm; m++) {
+            RUN(fpmhip_pen_halo_rows(plan, mesh[m], hys[m], 1, 1));
+            mm[m] = axis_msg(g, 0, -1, hys[m], hyr[m], hy_bytes);
+        }
+        TRY(neighbours(q, mm, nm, TAG_HALO));
         if (has_x) {
-            TRY(fpmhip_pen_halo_rows(plan, mesh[m], hxs[m], 0, 1));
-            TRY(fpmhip_memcpy_d2d(plan, hxs[m] + (size_t) ylr * row_bytes, hyr[m], row_bytes));
-            TRY(fpmhip_sync(plan));
-            TRY(t->sendrecv(t->ctx, hxs[m], neighbour(g, 1, -1), hxr[m], neighbour(g, 1, +1), hx_bytes));
+            for (int m = 0; m < nm; m++) {
+                RUN(fpmhip_pen_halo_rows(plan, mesh[m], hxs[m], 0, 1));
+                RUN(fpmhip_memcpy_d2d(plan, hxs[m] + (size_t) ylr * row_bytes, hyr[m], row_bytes));
+                mm[m] = axis_msg(g, 1, -1, hxs[m], hxr[m], hx_bytes);
+            }
+            TRY(neighbours(q, mm, nm, TAG_HALO2));
         }
     }
     {
         void *cm[4] = {mesh[0], mesh[1], mesh[2], NULL};
-        TRY(check_force_meshes(plan, delta_k, cm));
+        TRY(check_force_meshes(q, delta_k, cm));
     }
     void *hx3[3] = {has_x ? hxr[0] : NULL, has_x ? hxr[1] : NULL, has_x ? hxr[2] : NULL}, *hy3[3] = {hyr[0], hyr[1], hyr[2]};
-    TRY(fpmhip_readout3_zc2r_pen(plan, set, mesh[0], mesh[1], mesh[2], hx3, hy3));
+    RUN(fpmhip_readout3_zc2r_pen(plan, set, mesh[0], mesh[1], mesh[2], hx3, hy3));
     if (has_pot)
-        TRY(fpmhip_readout1_zc2r_pen(plan, set, mesh[3], has_x ? hxr[3] : NULL, hyr[3], set->potential, 1, 0));
+        RUN(fpmhip_readout1_zc2r_pen(plan, set, mesh[3], has_x ? hxr[3] : NULL, hyr[3], set->potential, 1, 0));
     return 0;
 }
 
-static int pencil_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_layout *lay,
-                                const fpmhip_particles *sets, int nsets, int kernel, int softening, void *delta_k)
+static int pencil_force_species(seq *q, const fpmhip_layout *lay, const fpmhip_particles *sets, int nsets, int kernel,
+                                int softening, void *delta_k, int nr)
 {
+    fpmhip_plan *plan = q->plan;
     if (lay->nranks_x > 64 || lay->nranks_y > 64) return -1;
     mesh_groups g = {lay->nranks_x, lay->nranks_y, lay->rank_x, lay->rank_y, {0}, {0}};
     for (int j = 0; j < g.Ny; j++) g.row[j] = g.rx * g.Ny + j;
@@ -573,103 +705,124 @@ static int pencil_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t
      * into the z pass and writes the exchange-A chunks, the readout reads the received chunks -- see the sequence in
      * include/fastpm_hip.h (fpmhip_paint_zr2c_pen) and distributed.PencilForce._strip_steps */
     if (fpmhip_plan_strips(plan) && nsets == 1 && softening == FPMHIP_SOFTENING_NONE && go == 1 && g.Ny > 1)
-        return pencil_strip_force(plan, t, lay, &g, &sets[0], kernel, delta_k, c, w);
+        return pencil_strip_force(q, lay, &g, &sets[0], kernel, delta_k, c, w, nr);
 
-    TRY(paint_species(plan, t, sets, nsets, lay->Norm, c, 0));                    /* gravity.c:323-345 */
-    TRY(halo_out(plan, t, &g, lay, c, w[3]));
-    TRY(fpmhip_check_point(plan, c, "After painting"));                           /* gravity.c:350 */
-    TRY(fpmhip_fft_z_forward(plan, c, w[0]));                                     /* gravity.c:351 pm_r2c */
-    const int nr = plane_ranges(plan, t, lay->isize[0]);
+    TRY(paint_species(q, sets, nsets, lay->Norm, c, 0));                          /* gravity.c:323-345 */
+    TRY(halo_out(q, &g, lay, c, w[3]));
+    RUN(fpmhip_check_point(plan, c, "After painting"));                           /* gravity.c:350 */
+    RUN(fpmhip_fft_z_forward(plan, c, w[0]));                                     /* gravity.c:351 pm_r2c */
     if (nr >= 1) {
-        TRY(pencil_forward_from_a(plan, t, lay, &g, nr, w[0], w[1], w[2], delta_k));
+        TRY(pencil_forward_from_a(q, lay, &g, nr, w[0], w[1], w[2], delta_k));
     } else {
-        TRY(exchange_axis(plan, t, &g, 0, w[0], w[1], a_bytes));
-        TRY(fpmhip_fft_y_forward(plan, w[1], w[0]));
-        TRY(exchange_axis(plan, t, &g, 1, w[0], delta_k, b_bytes));
+        TRY(exchange_axis(q, &g, 0, w[0], w[1], a_bytes));
+        RUN(fpmhip_fft_y_forward(plan, w[1], w[0]));
+        TRY(exchange_axis(q, &g, 1, w[0], delta_k, b_bytes));
     }
     const int fuse_x = softening == FPMHIP_SOFTENING_NONE;
     if (!fuse_x) {
-        TRY(fpmhip_fft_x_forward(plan, delta_k));
-        TRY(fpmhip_softening(plan, delta_k, softening));                          /* gravity.c:476 */
+        RUN(fpmhip_fft_x_forward(plan, delta_k));
+        RUN(fpmhip_softening(plan, delta_k, softening));                          /* gravity.c:476 */
     }
     void *mesh[4] = {NULL, NULL, NULL, NULL};
     if (go == 1) {
         /* two meshes through the transposes: the x component and the potential (fastpm_hip.h) */
-        if (fuse_x) TRY(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 2, w[0], w[1], NULL));
-        else TRY(fpmhip_transfer_fft_x_backward_potx(plan, delta_k, w[0], w[1], kernel));
+        if (fuse_x) RUN(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 2, w[0], w[1], NULL));
+        else RUN(fpmhip_transfer_fft_x_backward_potx(plan, delta_k, w[0], w[1], kernel));
         if (nr >= 1) {
             /* pm_c2r x 3 (pmpfft.c:394-396) by COMPONENT, every transpose non-blocking: a pass runs while the next
              * component is on the wire, and never writes where an exchange still reads or lands (the comments name the
              * buffer each wait frees) */
-            TRY(begin_axis(plan, t, lay, &g, 1, w[1], w[2], 0, 0, TAG_POT));        /* potential */
-            TRY(begin_axis(plan, t, lay, &g, 1, w[0], w[3], 0, 0, TAG_X));          /* x component */
-            TRY(wait_axis(t, &g, 1, TAG_POT));                                      /* w[1] */
-            TRY(fpmhip_fft_y_backward_grad2(plan, w[2], c, w[4], any_pot ? w[1] : NULL, kernel));
-            TRY(begin_axis(plan, t, lay, &g, 0, c, w[2], 0, 0, TAG_Y));
-            TRY(wait_axis(t, &g, 1, TAG_X));                                        /* w[0] */
-            TRY(begin_axis(plan, t, lay, &g, 0, w[4], w[0], 0, 0, TAG_Z));
-            TRY(wait_axis(t, &g, 0, TAG_Y));                                        /* c; y has landed in w[2] */
-            TRY(fpmhip_fft_y_backward(plan, w[3], c));                              /* x; frees w[3] */
-            TRY(fpmhip_fft_z_backward(plan, w[2], w[3]));                           /* y in real space: w[3] */
-            TRY(begin_axis(plan, t, lay, &g, 0, c, w[2], 0, 0, TAG_XA));
-            TRY(wait_axis(t, &g, 0, TAG_Z));                                        /* w[4]; z has landed in w[0] */
-            TRY(fpmhip_fft_z_backward(plan, w[0], w[4]));                           /* z in real space: w[4] */
-            if (any_pot) TRY(begin_axis(plan, t, lay, &g, 0, w[1], w[0], 0, 0, TAG_PA));
-            TRY(wait_axis(t, &g, 0, TAG_XA));                                       /* c; x has landed in w[2] */
-            TRY(fpmhip_fft_z_backward(plan, w[2], c));                              /* x in real space: c */
+            TRY(begin_axis(q, lay, &g, 1, w[1], w[2], 0, 0, TAG_POT));        /* potential */
+            TRY(begin_axis(q, lay, &g, 1, w[0], w[3], 0, 0, TAG_X));          /* x component */
+            TRY(wait_axis(q, &g, 1, TAG_POT));                                /* w[1] */
+            RUN(fpmhip_fft_y_backward_grad2(plan, w[2], c, w[4], any_pot ? w[1] : NULL, kernel));
+            TRY(begin_axis(q, lay, &g, 0, c, w[2], 0, 0, TAG_Y));
+            TRY(wait_axis(q, &g, 1, TAG_X));                                  /* w[0] */
+            TRY(begin_axis(q, lay, &g, 0, w[4], w[0], 0, 0, TAG_Z));
+            TRY(wait_axis(q, &g, 0, TAG_Y));                                  /* c; y has landed in w[2] */
+            RUN(fpmhip_fft_y_backward(plan, w[3], c));                        /* x; frees w[3] */
+            RUN(fpmhip_fft_z_backward(plan, w[2], w[3]));                     /* y in real space: w[3] */
+            TRY(begin_axis(q, lay, &g, 0, c, w[2], 0, 0, TAG_XA));
+            TRY(wait_axis(q, &g, 0, TAG_Z));                                  /* w[4]; z has landed in w[0] */
+            RUN(fpmhip_fft_z_backward(plan, w[0], w[4]));                     /* z in real space: w[4] */
+            if (any_pot) TRY(begin_axis(q, lay, &g, 0, w[1], w[0], 0, 0, TAG_PA));
+            TRY(wait_axis(q, &g, 0, TAG_XA));                                 /* c; x has landed in w[2] */
+            RUN(fpmhip_fft_z_backward(plan, w[2], c));                        /* x in real space: c */
             mesh[0] = c; mesh[1] = w[3]; mesh[2] = w[4];
             if (any_pot) {
-                TRY(wait_axis(t, &g, 0, TAG_PA));
-                TRY(fpmhip_fft_z_backward(plan, w[0], w[1]));
+                TRY(wait_axis(q, &g, 0, TAG_PA));
+                RUN(fpmhip_fft_z_backward(plan, w[0], w[1]));
                 mesh[3] = w[1];
             }
         } else {
-            TRY(exchange_axis(plan, t, &g, 1, w[1], w[2], b_bytes));              /* potential */
-            TRY(exchange_axis(plan, t, &g, 1, w[0], w[3], b_bytes));              /* x component */
-            void *potmesh = any_pot ? w[4] : NULL;                                /* gravity.c:487-492 rides along */
-            TRY(fpmhip_fft_y_backward_grad2(plan, w[2], w[0], w[1], potmesh, kernel));
-            TRY(fpmhip_fft_y_backward(plan, w[3], w[2]));
-            TRY(exchange_axis(plan, t, &g, 0, w[2], w[3], a_bytes));
-            TRY(fpmhip_fft_z_backward(plan, w[3], c));
-            TRY(exchange_axis(plan, t, &g, 0, w[0], w[3], a_bytes));
-            TRY(fpmhip_fft_z_backward(plan, w[3], w[2]));
-            TRY(exchange_axis(plan, t, &g, 0, w[1], w[3], a_bytes));
-            TRY(fpmhip_fft_z_backward(plan, w[3], w[0]));
+            TRY(exchange_axis(q, &g, 1, w[1], w[2], b_bytes));                /* potential */
+            TRY(exchange_axis(q, &g, 1, w[0], w[3], b_bytes));                /* x component */
+            void *potmesh = any_pot ? w[4] : NULL;                            /* gravity.c:487-492 rides along */
+            RUN(fpmhip_fft_y_backward_grad2(plan, w[2], w[0], w[1], potmesh, kernel));
+            RUN(fpmhip_fft_y_backward(plan, w[3], w[2]));
+            TRY(exchange_axis(q, &g, 0, w[2], w[3], a_bytes));
+            RUN(fpmhip_fft_z_backward(plan, w[3], c));
+            TRY(exchange_axis(q, &g, 0, w[0], w[3], a_bytes));
+            RUN(fpmhip_fft_z_backward(plan, w[3], w[2]));
+            TRY(exchange_axis(q, &g, 0, w[1], w[3], a_bytes));
+            RUN(fpmhip_fft_z_backward(plan, w[3], w[0]));
             mesh[0] = c; mesh[1] = w[2]; mesh[2] = w[0];
             if (potmesh) {
-                TRY(exchange_axis(plan, t, &g, 0, potmesh, w[3], a_bytes));
-                TRY(fpmhip_fft_z_backward(plan, w[3], w[1]));
+                TRY(exchange_axis(q, &g, 0, potmesh, w[3], a_bytes));
+                RUN(fpmhip_fft_z_backward(plan, w[3], w[1]));
                 mesh[3] = w[1];
             }
         }
     } else {
-        /* gravity.c:373-397 with the exact i k gradient: three components through the transposes */
-        if (fuse_x) TRY(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 0, w[0], w[1], w[2]));
-        else TRY(fpmhip_transfer_fft_x_backward3(plan, delta_k, w[0], w[1], w[2], kernel));
+        /* gravity.c:373-397 with the exact i k gradient: three components through the transposes (non-blocking where the
+         * transport offers it: no host wait, component after component) */
+        if (fuse_x) RUN(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 0, w[0], w[1], w[2]));
+        else RUN(fpmhip_transfer_fft_x_backward3(plan, delta_k, w[0], w[1], w[2], kernel));
         void *real[3] = {c, w[0], w[1]};
         for (int d = 0; d < 3; d++) {
-            TRY(exchange_axis(plan, t, &g, 1, w[d], w[3], b_bytes));
-            TRY(fpmhip_fft_y_backward(plan, w[3], w[4]));
-            TRY(exchange_axis(plan, t, &g, 0, w[4], w[3], a_bytes));
-            TRY(fpmhip_fft_z_backward(plan, w[3], real[d]));
+            if (nr >= 1) {
+                TRY(begin_axis(q, lay, &g, 1, w[d], w[3], 0, 0, TAG_X));
+                TRY(wait_axis(q, &g, 1, TAG_X));
+                RUN(fpmhip_fft_y_backward(plan, w[3], w[4]));
+                TRY(begin_axis(q, lay, &g, 0, w[4], w[3], 0, 0, TAG_XA));
+                TRY(wait_axis(q, &g, 0, TAG_XA));
+            } else {
+                TRY(exchange_axis(q, &g, 1, w[d], w[3], b_bytes));
+                RUN(fpmhip_fft_y_backward(plan, w[3], w[4]));
+                TRY(exchange_axis(q, &g, 0, w[4], w[3], a_bytes));
+            }
+            RUN(fpmhip_fft_z_backward(plan, w[3], real[d]));
             mesh[d] = real[d];
         }
         if (any_pot) {
-            TRY(fpmhip_transfer(plan, delta_k, w[2], kernel, FPMHIP_FIELD_POTENTIAL));
-            TRY(fpmhip_fft_x_backward(plan, w[2]));
-            TRY(exchange_axis(plan, t, &g, 1, w[2], w[3], b_bytes));
-            TRY(fpmhip_fft_y_backward(plan, w[3], w[4]));
-            TRY(exchange_axis(plan, t, &g, 0, w[4], w[3], a_bytes));
-            TRY(fpmhip_fft_z_backward(plan, w[3], w[2]));
+            RUN(fpmhip_transfer(plan, delta_k, w[2], kernel, FPMHIP_FIELD_POTENTIAL));
+            RUN(fpmhip_fft_x_backward(plan, w[2]));
+            if (nr >= 1) {
+                TRY(begin_axis(q, lay, &g, 1, w[2], w[3], 0, 0, TAG_X));
+                TRY(wait_axis(q, &g, 1, TAG_X));
+                RUN(fpmhip_fft_y_backward(plan, w[3], w[4]));
+                TRY(begin_axis(q, lay, &g, 0, w[4], w[3], 0, 0, TAG_XA));
+                TRY(wait_axis(q, &g, 0, TAG_XA));
+            } else {
+                TRY(exchange_axis(q, &g, 1, w[2], w[3], b_bytes));
+                RUN(fpmhip_fft_y_backward(plan, w[3], w[4]));
+                TRY(exchange_axis(q, &g, 0, w[4], w[3], a_bytes));
+            }
+            RUN(fpmhip_fft_z_backward(plan, w[3], w[2]));
             mesh[3] = w[2];
         }
     }
-    for (int d = 0; d < 4; d++)
-        if (mesh[d]) TRY(halo_in(plan, t, &g, lay, mesh[d], nr >= 1 && go == 1 ? w[2] : w[3]));    /* a free buffer as scratch */
-    TRY(check_force_meshes(plan, delta_k, mesh));
-    TRY(readout_species(plan, sets, nsets, mesh[0], mesh[1], mesh[2]));
+    {
+        void *hm[4];
+        int nm = 0;
+        for (int d = 0; d < 4; d++) if (mesh[d]) hm[nm++] = mesh[d];
+        /* a free buffer as scratch: 2 rows per mesh */
+        TRY(halo_in(q, &g, lay, hm, nm, nr >= 1 && go == 1 ? w[2] : w[3]));
+    }
+    TRY(check_force_meshes(q, delta_k, mesh));
+    TRY(readout_species(q, sets, nsets, mesh[0], mesh[1], mesh[2]));
     for (int si = 0; si < nsets && mesh[3]; si++)
-        if (sets[si].potential) TRY(fpmhip_readout1(plan, &sets[si], mesh[3], sets[si].potential, 1, 0));
+        if (sets[si].potential) RUN(fpmhip_readout1(plan, &sets[si], mesh[3], sets[si].potential, 1, 0));
     return 0;
 }
 
@@ -680,23 +833,38 @@ int fastpm_hip_mesh_force_species(fpmhip_plan *plan, const fastpm_hip_transport 
     fpmhip_layout lay;
     TRY(fpmhip_plan_layout(plan, &lay));
     if (lay.nranks != t->nranks || lay.rank != t->rank) return -1;
+    if (lay.nranks == 1)            /* no ghosts, no transposes (pmghosts.c:67: rank == ThisTask always) */
+        return fpmhip_force_species(plan, sets, nsets, kernel, softening, -1.0, delta_k);
     if (t->bind_plan) TRY(t->bind_plan(t->ctx, plan));          /* the stream the non-blocking exchanges are ordered on */
-    int rc = lay.nranks_y > 1 ? pencil_force_species(plan, t, &lay, sets, nsets, kernel, softening, delta_k)
-                              : slab_force_species(plan, t, sets, nsets, kernel, softening, delta_k);
-    if (lay.nranks > 1) {
-        /* What only the device knows about this step's binning (a particle outside the rank's region on a steady-state
-         * step, a slab overflow) arrives after the paint's agreement point: ask for it now and agree again, so that no
-         * rank leaves with rc = 0 and an invalid acc while its peers carry on into the next collective.  EVERY rank
-         * enters this all-reduce, whatever its rc: a failure agreed on in the paint left every rank with one, and a
-         * rank-local failure after the LAST collective of the sequence must not leave the peers waiting here for a rank
-         * that returned early.  (Not covered, by design: a rank that fails BETWEEN two collectives of the sequence -- a
-         * transport error, a launch failure -- comes straight here while its peers sit in the next exchange.  The binding
-         * turns the nonzero rc into fastpm_raise, which aborts the communicator as the reference's does,
-         * logging.c:242-251: that is what releases the peers.) */
-        const int late = rc == 0 ? fpmhip_sync(plan) : 0;
-        double failed = rc != 0 || late != 0;
-        if (t->allreduce_sum(t->ctx, &failed) != 0 || failed != 0) rc = rc ? rc : (late ? late : -8);
+    seq qs = {plan, t, 0, 0, 0}, *q = &qs;
+    {
+        /* Every mesh buffer the sequences use exists BEFORE the first exchange (a rank-local hipMalloc failure between two
+         * collectives would leave the peers waiting): made at the first step on the plan -- the same step on every rank --
+         * and agreed on there, once. */
+        const int made = fpmhip_plan_buffers_ready(plan, B_COUNT);
+        if (made != 0) {
+            double failed = made < 0;
+            if (t->allreduce_sum(t->ctx, &failed) != 0) return seq_abort(q, -1);
+            if (failed != 0) return made < 0 ? made : -8;
+        }
     }
+    const int nr = plane_ranges(plan, t, lay.isize[0]);
+    q->nb = nr >= 1 && t->msgs_begin && t->allreduce_begin;
+    int rc = lay.nranks_y > 1 ? pencil_force_species(q, &lay, sets, nsets, kernel, softening, delta_k, nr)
+                              : slab_force_species(q, sets, nsets, kernel, softening, delta_k);
+    if (q->aborted) return rc ? rc : -1;        /* the communicator is gone: nothing left to agree on */
+    if (rc == 0) rc = q->rc;
+    /* THE FINAL AGREEMENT, the one host wait of the event-ordered sequence.  What only the device knows about this step's
+     * binning (a particle outside the rank's region on a steady-state step, a slab overflow) arrives after everything
+     * else: ask for it now (fpmhip_sync waits for the step) and agree, so that no rank leaves with rc = 0 and an invalid
+     * acc while its peers carry on into the next collective.  EVERY rank enters this all-reduce, whatever its rc: a
+     * compute failure left the rank in the sequence (RUN / XCH), and a rank-local failure after the LAST exchange must not
+     * leave the peers waiting here for a rank that returned early. */
+    const int late = fpmhip_sync(plan);
+    if (rc == 0) rc = late;
+    double failed = rc != 0;
+    if (t->allreduce_sum(t->ctx, &failed) != 0) return seq_abort(q, rc ? rc : -1);
+    if (failed != 0 && rc == 0) rc = -8;
     return rc;
 }
 
@@ -839,9 +1007,56 @@ int fastpm_hip_slab_force_host(fpmhip_plan *plan, const fastpm_hip_transport *t,
  * I receive from the others' published send buffers (device-to-device on my plan's stream, then synchronise),
  * barrier (nobody reuses a send buffer before everyone has read it).
  */
+/* a barrier that can be BROKEN (fastpm_hip_transport.abort): every present and future waiter returns -1 */
+typedef struct {
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    int n, count, gen, broken;
+} loop_barrier;
+
+static void lb_init(loop_barrier *b, int n)
+{
+    pthread_mutex_init(&b->mu, NULL);
+    pthread_cond_init(&b->cv, NULL);
+    b->n = n; b->count = 0; b->gen = 0; b->broken = 0;
+}
+
+static int lb_wait(loop_barrier *b)
+{
+    pthread_mutex_lock(&b->mu);
+    if (!b->broken) {
+        const int gen = b->gen;
+        if (++b->count == b->n) {
+            b->count = 0;
+            b->gen++;
+            pthread_cond_broadcast(&b->cv);
+        } else {
+            while (b->gen == gen && !b->broken) pthread_cond_wait(&b->cv, &b->mu);
+        }
+    }
+    const int rc = b->broken ? -1 : 0;
+    pthread_mutex_unlock(&b->mu);
+    return rc;
+}
+
+static void lb_break(loop_barrier *b)
+{
+    pthread_mutex_lock(&b->mu);
+    b->broken = 1;
+    pthread_cond_broadcast(&b->cv);
+    pthread_mutex_unlock(&b->mu);
+}
+
+#define BARRIER(s) do { if (lb_wait(&(s)->barrier) != 0) return -1; } while (0)
+
+typedef struct {
+    fastpm_hip_msg m[FASTPM_HIP_MAX_MSGS];
+    int n;
+} loop_msgs;
+
 typedef struct {
     int nranks;
-    pthread_barrier_t barrier;
+    loop_barrier barrier;
     const void **send;      /* [nranks] published send pointers */
     int *dest;              /* [nranks] sendrecv destinations */
     double *value;          /* [nranks] */
@@ -856,8 +1071,10 @@ typedef struct {
      * exchange's copies -- the wire is slow, the plan's stream runs far ahead, and only the events keep the sequence right;
      * FASTPM_HIP_LOOPBACK_FAULT = 1 then drops the event waits of xchg_wait: the result MUST come out wrong */
     size_t delay_bytes;
-    int fault;
+    int fault;              /* 1: xchg_wait orders nothing; 2: rank 1's second xchg_begin fails (a transport error mid-sequence) */
     void **delay_buf;       /* [2 nranks] */
+    loop_msgs *xmsg;        /* [nranks][FASTPM_HIP_MAX_TAGS] the posted neighbour messages (msgs_begin) */
+    void **stage;           /* [nranks] 4 nranks doubles: the all-reduce gathers here */
 } loop_shared;
 
 typedef struct {
@@ -865,6 +1082,7 @@ typedef struct {
     int rank;
     /* what xchg_wait needs to know about the exchange begun under a tag: whose copies read my send buffer */
     int nmem[FASTPM_HIP_MAX_TAGS], mem[FASTPM_HIP_MAX_TAGS][64];
+    int nbegun;             /* xchg_begin calls so far (FASTPM_HIP_LOOPBACK_FAULT=2) */
 } loop_ctx;
 
 static int loop_allreduce(void *c_, double *v)
@@ -872,10 +1090,10 @@ static int loop_allreduce(void *c_, double *v)
     loop_ctx *c = c_;
     loop_shared *s = c->sh;
     s->value[c->rank] = *v;
-    pthread_barrier_wait(&s->barrier);
+    BARRIER(s);
     double sum = 0;
     for (int r = 0; r < s->nranks; r++) sum += s->value[r];
-    pthread_barrier_wait(&s->barrier);
+    BARRIER(s);
     *v = sum;
     return 0;
 }
@@ -886,12 +1104,12 @@ static int loop_alltoall(void *c_, const void *send, void *recv, size_t chunk)
     loop_shared *s = c->sh;
     int rc = 0;
     s->send[c->rank] = send;
-    pthread_barrier_wait(&s->barrier);
+    BARRIER(s);
     for (int src = 0; src < s->nranks && rc == 0; src++)
         rc = fpmhip_memcpy_d2d(s->plan[c->rank], (char *) recv + (size_t) src * chunk,
                                (const char *) s->send[src] + (size_t) c->rank * chunk, chunk);
     if (rc == 0) rc = fpmhip_sync(s->plan[c->rank]);
-    pthread_barrier_wait(&s->barrier);
+    BARRIER(s);
     return rc;
 }
 
@@ -901,12 +1119,12 @@ static int loop_alltoall_members(void *c_, const void *send, void *recv, size_t 
     loop_shared *s = c->sh;
     int rc = 0;
     s->send[c->rank] = send;
-    pthread_barrier_wait(&s->barrier);                 /* every rank is in SOME group's exchange at this point */
+    BARRIER(s);                 /* every rank is in SOME group's exchange at this point */
     for (int j = 0; j < n && rc == 0; j++)
         rc = fpmhip_memcpy_d2d(s->plan[c->rank], (char *) recv + (size_t) j * chunk,
                                (const char *) s->send[members[j]] + (size_t) me * chunk, chunk);
     if (rc == 0) rc = fpmhip_sync(s->plan[c->rank]);
-    pthread_barrier_wait(&s->barrier);
+    BARRIER(s);
     return rc;
 }
 
@@ -916,11 +1134,11 @@ static int loop_sendrecv(void *c_, const void *send, int dest, void *recv, int s
     loop_shared *s = c->sh;
     s->send[c->rank] = send;
     s->dest[c->rank] = dest;
-    pthread_barrier_wait(&s->barrier);
+    BARRIER(s);
     int rc = s->dest[source] == c->rank ? 0 : -1;
     if (rc == 0) rc = fpmhip_memcpy_d2d(s->plan[c->rank], recv, s->send[source], bytes);
     if (rc == 0) rc = fpmhip_sync(s->plan[c->rank]);
-    pthread_barrier_wait(&s->barrier);
+    BARRIER(s);
     return rc;
 }
 
@@ -936,7 +1154,7 @@ static int loop_xchg_begin(void *c_, const void *send, void *recv, const fastpm_
     (void) tag;
     int rc = fpmhip_sync(s->plan[c->rank]);
     s->send[c->rank] = send;
-    pthread_barrier_wait(&s->barrier);
+    BARRIER(s);
     for (int j = 0; j < n && rc == 0; j++) {
         const int src = members ? members[j] : j;
         for (int k = 0; k < pc->npieces && rc == 0; k++) {
@@ -946,7 +1164,7 @@ static int loop_xchg_begin(void *c_, const void *send, void *recv, const fastpm_
         }
     }
     if (rc == 0) rc = fpmhip_sync(s->plan[c->rank]);
-    pthread_barrier_wait(&s->barrier);
+    BARRIER(s);
     return rc;
 }
 
@@ -976,6 +1194,7 @@ static int loop_xchg_begin_async(void *c_, const void *send, void *recv, const f
     loop_shared *s = c->sh;
     const int r = c->rank, T = FASTPM_HIP_MAX_TAGS;
     if (tag < 0 || tag >= T || n > 64) return -1;
+    if (s->fault == 2 && r == 1 && ++c->nbegun == 2) return -1;      /* the injected transport failure */
     int rc = loop_event(&s->ready[r * T + tag]);
     if (!rc) rc = loop_event(&s->done[r * T + tag]);
     if (!rc && !s->xstream[r]) rc = fpmhip_stream_create(&s->xstream[r]);
@@ -983,7 +1202,7 @@ static int loop_xchg_begin_async(void *c_, const void *send, void *recv, const f
     s->xsend[r * T + tag] = send;
     c->nmem[tag] = n;
     for (int j = 0; j < n; j++) c->mem[tag][j] = members ? members[j] : j;
-    pthread_barrier_wait(&s->barrier);                 /* every rank's `ready` is recorded, every send buffer posted */
+    BARRIER(s);                 /* every rank's `ready` is recorded, every send buffer posted */
     /* my receive buffer is mine to overwrite only once MY plan's stream is done with it (what `begin is ordered after
      * everything enqueued on the plan's stream` means for the receiving side): first of all waits */
     if (rc == 0) rc = fpmhip_stream_wait_event(s->xstream[r], s->ready[r * T + tag]);
@@ -1011,12 +1230,85 @@ static int loop_xchg_wait_async(void *c_, int tag)
     loop_shared *s = c->sh;
     const int r = c->rank, T = FASTPM_HIP_MAX_TAGS;
     if (tag < 0 || tag >= T) return -1;
-    pthread_barrier_wait(&s->barrier);                 /* every rank has enqueued its copies of this tag and recorded `done` */
+    BARRIER(s);                 /* every rank has enqueued its copies of this tag and recorded `done` */
     int rc = 0;
-    for (int j = 0; j < c->nmem[tag] && rc == 0 && !s->fault; j++)
+    for (int j = 0; j < c->nmem[tag] && rc == 0 && s->fault != 1; j++)
         rc = fpmhip_stream_wait_event(fpmhip_plan_stream(s->plan[r]), s->done[c->mem[tag][j] * T + tag]);
-    pthread_barrier_wait(&s->barrier);                 /* nobody re-records an event of this tag before all have waited on it */
+    BARRIER(s);                 /* nobody re-records an event of this tag before all have waited on it */
     return rc;
+}
+
+/* msgs_begin, asynchronous: message i of every rank is one leg of the same pattern (rank r's message i goes to a rank whose
+ * message i comes from r -- the halo shifts are such), so the receiver copies out of the SOURCE's posted message i. */
+static int loop_msgs_begin_async(void *c_, const fastpm_hip_msg *m, int n, int tag)
+{
+    loop_ctx *c = c_;
+    loop_shared *s = c->sh;
+    const int r = c->rank, T = FASTPM_HIP_MAX_TAGS;
+    if (tag < 0 || tag >= T || n < 1 || n > FASTPM_HIP_MAX_MSGS) return -1;
+    int rc = loop_event(&s->ready[r * T + tag]);
+    if (!rc) rc = loop_event(&s->done[r * T + tag]);
+    if (!rc && !s->xstream[r]) rc = fpmhip_stream_create(&s->xstream[r]);
+    if (!rc) rc = fpmhip_event_record(s->ready[r * T + tag], fpmhip_plan_stream(s->plan[r]));
+    loop_msgs *mine = &s->xmsg[r * T + tag];
+    mine->n = n;
+    c->nmem[tag] = 0;
+    c->mem[tag][c->nmem[tag]++] = r;                   /* my receives */
+    for (int i = 0; i < n; i++) {
+        mine->m[i] = m[i];
+        c->mem[tag][c->nmem[tag]++] = m[i].dest;       /* whose copies read my send buffers */
+    }
+    BARRIER(s);
+    if (rc == 0) rc = fpmhip_stream_wait_event(s->xstream[r], s->ready[r * T + tag]);
+    if (rc == 0 && s->delay_bytes) {
+        if (!s->delay_buf[2 * r]) rc = fpmhip_malloc(&s->delay_buf[2 * r], s->delay_bytes);
+        if (!rc && !s->delay_buf[2 * r + 1]) rc = fpmhip_malloc(&s->delay_buf[2 * r + 1], s->delay_bytes);
+        if (!rc) rc = fpmhip_memcpy_d2d_on(s->xstream[r], s->delay_buf[2 * r + 1], s->delay_buf[2 * r], s->delay_bytes);
+    }
+    for (int i = 0; i < n && rc == 0; i++) {
+        const int src = m[i].source;
+        const loop_msgs *theirs = &s->xmsg[src * T + tag];
+        if (src < 0 || src >= s->nranks || theirs->n != n || theirs->m[i].dest != r || theirs->m[i].bytes != m[i].bytes) { rc = -1; break; }
+        rc = fpmhip_stream_wait_event(s->xstream[r], s->ready[src * T + tag]);
+        if (rc == 0) rc = fpmhip_memcpy_d2d_on(s->xstream[r], m[i].recv_dev, theirs->m[i].send_dev, m[i].bytes);
+    }
+    if (rc == 0) rc = fpmhip_event_record(s->done[r * T + tag], s->xstream[r]);
+    return rc;
+}
+
+/* allreduce_begin, asynchronous: every rank's exchange stream gathers the contributions into its own staging rows and sums
+ * them in rank order (the same bits everywhere) */
+static int loop_allreduce_begin_async(void *c_, const double *in, double *out, int n, int tag)
+{
+    loop_ctx *c = c_;
+    loop_shared *s = c->sh;
+    const int r = c->rank, T = FASTPM_HIP_MAX_TAGS, P = s->nranks;
+    if (tag < 0 || tag >= T || n < 1 || n > 4 || P > 64) return -1;
+    int rc = loop_event(&s->ready[r * T + tag]);
+    if (!rc) rc = loop_event(&s->done[r * T + tag]);
+    if (!rc && !s->xstream[r]) rc = fpmhip_stream_create(&s->xstream[r]);
+    if (!rc && !s->stage[r]) rc = fpmhip_malloc(&s->stage[r], (size_t) 4 * P * sizeof(double));
+    if (!rc) rc = fpmhip_event_record(s->ready[r * T + tag], fpmhip_plan_stream(s->plan[r]));
+    s->xsend[r * T + tag] = in;
+    c->nmem[tag] = P;
+    for (int j = 0; j < P; j++) c->mem[tag][j] = j;
+    BARRIER(s);
+    if (rc == 0) rc = fpmhip_stream_wait_event(s->xstream[r], s->ready[r * T + tag]);
+    for (int j = 0; j < P && rc == 0; j++) {
+        rc = fpmhip_stream_wait_event(s->xstream[r], s->ready[j * T + tag]);
+        if (rc == 0) rc = fpmhip_memcpy_d2d_on(s->xstream[r], (double *) s->stage[r] + (size_t) j * n, s->xsend[j * T + tag], (size_t) n * sizeof(double));
+    }
+    if (rc == 0) rc = fpmhip_sum_rows_on(s->xstream[r], out, s->stage[r], P, n);
+    if (rc == 0) rc = fpmhip_event_record(s->done[r * T + tag], s->xstream[r]);
+    return rc;
+}
+
+/* a rank gives up between two exchanges: the barrier breaks, every peer's present and later transport call returns -1
+ * (the GPU side cannot hang here: an event that was never recorded orders nothing) */
+static void loop_abort(void *c_)
+{
+    loop_ctx *c = c_;
+    lb_break(&c->sh->barrier);
 }
 
 static int loop_bind_plan(void *c_, fpmhip_plan *plan)
@@ -1030,7 +1322,7 @@ fastpm_hip_transport *fastpm_hip_loopback_create(int nranks)
 {
     loop_shared *s = calloc(1, sizeof(*s));
     s->nranks = nranks;
-    pthread_barrier_init(&s->barrier, NULL, (unsigned) nranks);
+    lb_init(&s->barrier, nranks);
     s->send = calloc((size_t) nranks, sizeof(*s->send));
     s->dest = calloc((size_t) nranks, sizeof(*s->dest));
     s->value = calloc((size_t) nranks, sizeof(*s->value));
@@ -1048,8 +1340,10 @@ fastpm_hip_transport *fastpm_hip_loopback_create(int nranks)
         const char *e = getenv("FASTPM_HIP_LOOPBACK_DELAY_MB");
         s->delay_bytes = e ? (size_t) atoi(e) << 20 : 0;
         e = getenv("FASTPM_HIP_LOOPBACK_FAULT");
-        s->fault = e && atoi(e) != 0;
+        s->fault = e ? atoi(e) : 0;
     }
+    s->xmsg = calloc((size_t) nranks * FASTPM_HIP_MAX_TAGS, sizeof(*s->xmsg));
+    s->stage = calloc((size_t) nranks, sizeof(*s->stage));
     fastpm_hip_transport *t = calloc((size_t) nranks, sizeof(*t));
     for (int r = 0; r < nranks; r++) {
         loop_ctx *c = calloc(1, sizeof(*c));
@@ -1065,6 +1359,11 @@ fastpm_hip_transport *fastpm_hip_loopback_create(int nranks)
         t[r].xchg_begin = s->async ? loop_xchg_begin_async : loop_xchg_begin;
         t[r].xchg_wait = s->async ? loop_xchg_wait_async : loop_xchg_wait;
         t[r].bind_plan = loop_bind_plan;
+        /* the event-ordered neighbour messages and scalars go with the asynchronous pair; FASTPM_HIP_LOOPBACK_ASYNC=0
+         * leaves them out: the sequences then take the blocking sendrecv / allreduce_sum at those points */
+        t[r].msgs_begin = s->async ? loop_msgs_begin_async : NULL;
+        t[r].allreduce_begin = s->async ? loop_allreduce_begin_async : NULL;
+        t[r].abort = loop_abort;
     }
     return t;
 }
@@ -1081,10 +1380,13 @@ void fastpm_hip_loopback_destroy(fastpm_hip_transport *all)
     loop_shared *s = ((loop_ctx *) all[0].ctx)->sh;
     const int n = s->nranks;
     for (int r = 0; r < n; r++) free(all[r].ctx);
-    pthread_barrier_destroy(&s->barrier);
     for (int r = 0; r < n; r++) if (s->xstream[r]) fpmhip_stream_destroy(s->xstream[r]);      /* (waits for the stream) */
     for (int i = 0; i < n * FASTPM_HIP_MAX_TAGS; i++) { fpmhip_event_destroy(s->ready[i]); fpmhip_event_destroy(s->done[i]); }
     for (int i = 0; i < 2 * n; i++) if (s->delay_buf[i]) fpmhip_free(s->delay_buf[i]);
+    for (int r = 0; r < n; r++) if (s->stage[r]) fpmhip_free(s->stage[r]);
+    free(s->xmsg); free(s->stage);
+    pthread_mutex_destroy(&s->barrier.mu);
+    pthread_cond_destroy(&s->barrier.cv);
     free(s->xsend); free(s->ready); free(s->done); free(s->xstream); free(s->delay_buf);
     free(s->send); free(s->dest); free(s->value); free(s->plan); free(s);
     free(all);

@@ -20,6 +20,7 @@ extern "C" {
  * on return the receive buffer must be complete (or ordered before later work on the plan's stream).
  * Every function returns 0 on success. */
 struct fastpm_hip_pieces;
+struct fastpm_hip_msg;
 typedef struct {
     void *ctx;
     int rank, nranks;
@@ -61,9 +62,34 @@ typedef struct {
     /* plane ranges per transpose (SlabForce(chunks = ...) in the Python mirror): 0 = the default (FASTPM_HIP_CHUNKS in
      * the environment, else 4), 1 = whole-mesh exchanges (still non-blocking where two meshes travel) */
     int chunks;
+    /* -- round 6: the neighbour messages and the scalars of a step WITHOUT a host wait, completed by xchg_wait(tag) like
+     *    the transposes (the ghost exchange pmghosts.c:203-245, 247-307 and the MPI_Allreduce of gravity.c:341 stop the
+     *    host; here the host enqueues the whole force step and waits once, at the final agreement).  A transport that
+     *    leaves them NULL gets the blocking sendrecv / allreduce_sum at those points. --
+     * msgs_begin: n <= FASTPM_HIP_MAX_MSGS messages as ONE group: message i sends msgs[i].bytes from send_dev to rank dest
+     *   and receives as many into recv_dev from rank source (the halo planes / rows of the 3 - 4 force meshes travel
+     *   together).  Ordered after everything enqueued on the bound plan's stream, like xchg_begin.
+     * allreduce_begin: out_dev[j] = sum over the ranks of in_dev[j], j < n <= 4, on the device, the same bits on every
+     *   rank; in_dev may be rewritten and out_dev read after xchg_wait(tag). */
+    int (*msgs_begin)(void *ctx, const struct fastpm_hip_msg *msgs, int n, int tag);
+    int (*allreduce_begin)(void *ctx, const double *in_dev, double *out_dev, int n, int tag);
+    /* A rank that cannot go on BETWEEN two exchanges (a transport call failed) calls this before it returns its error:
+     * the peers' pending and later calls on their transports must fail instead of waiting for this rank -- ncclCommAbort /
+     * MPI_Abort / the loopback's broken barrier (the reference: fastpm_raise -> MPI_Abort, logging.c:242-251). */
+    void (*abort)(void *ctx);
+    /* != 0: this transport cannot overlap an exchange with compute (MPI staged through the host): the sequences use the
+     * blocking whole-mesh exchanges on it, whatever `chunks` says */
+    int no_overlap;
 } fastpm_hip_transport;
 
-#define FASTPM_HIP_MAX_TAGS 64
+#define FASTPM_HIP_MAX_TAGS 80
+#define FASTPM_HIP_MAX_MSGS 8
+typedef struct fastpm_hip_msg {
+    const void *send_dev;
+    void *recv_dev;
+    size_t bytes;
+    int dest, source;
+} fastpm_hip_msg;
 typedef struct fastpm_hip_pieces {
     size_t chunk_bytes;     /* distance between the members' chunks, in send and in recv */
     size_t first_bytes;     /* first piece, from the start of a chunk */

@@ -202,8 +202,28 @@ static int mpi_xchg_wait(void *ctx, int tag)
 
 static int mpi_bind_plan(void *ctx, fpmhip_plan *plan)
 {
-    ((mpi_ctx *) ctx)->plan = plan;
+    mpi_ctx *c = ctx;
+    c->plan = plan;
+    /* a new force call: whatever a FAILED earlier call posted and never waited for is cancelled and completed here, so
+     * that its tag is free again and no request or staging buffer stays in flight */
+    for (int i = 0; i < FASTPM_HIP_MAX_TAGS; i++) {
+        mpi_pending *q = &c->pend[i];
+        if (!q->active) continue;
+        for (int k = 0; k < q->nreq; k++) (void) MPI_Cancel(&q->req[k]);
+        if (q->nreq) (void) MPI_Waitall(q->nreq, q->req, (MPI_Status *) (q->req + q->nmsg));
+        MPI_Type_free(&q->type);
+        free(q->req);
+        q->req = NULL;
+        q->nreq = 0;
+        q->active = 0;
+    }
     return 0;
+}
+
+/* the reference's way out of a failed rank: MPI_Abort on the communicator (fastpm_raise, logging.c:242-251) */
+static void mpi_abort(void *ctx)
+{
+    (void) MPI_Abort(((mpi_ctx *) ctx)->comm, 1);
 }
 
 static int mpi_alltoall_counts(void *ctx, const int64_t *send, int64_t *recv)
@@ -265,6 +285,15 @@ fastpm_hip_transport *fastpm_hip_mpi_transport_create(MPI_Comm comm, fpmhip_plan
     t->xchg_begin = mpi_xchg_begin;
     t->xchg_wait = mpi_xchg_wait;
     t->bind_plan = mpi_bind_plan;
+    t->abort = mpi_abort;
+    /* Staged through the host, an exchange cannot overlap compute: begin waits for the plan's stream and every copy is a
+     * blocking one -- plane ranges would only multiply the copies (n x npieces per range).  The sequences then use the
+     * blocking whole-mesh exchanges: one copy down, one MPI_Alltoall, one copy up per transpose.
+     * FASTPM_HIP_MPI_STAGED_RANGES=1 keeps the ranges all the same (tests: the MPI_Isend / MPI_Irecv path in real processes). */
+    {
+        const char *e = getenv("FASTPM_HIP_MPI_STAGED_RANGES");
+        t->no_overlap = !gpu_aware && !(e && atoi(e) != 0);
+    }
     return t;
 }
 

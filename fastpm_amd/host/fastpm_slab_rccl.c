@@ -7,7 +7,8 @@
  * so on a one-GPU box this transport runs with one rank (tests/test_gpu_chost.py), where every send is to self.
  *
  * The blocking calls end with a synchronisation of the transport's own stream, as the contract asks; the non-blocking
- * pair xchg_begin / xchg_wait (round 5) is ordered against the bound plan's stream with events and never waits on the host.
+ * pair xchg_begin / xchg_wait (round 5) is ordered against the bound plan's stream with events and never waits on the host;
+ * round 6: so are the neighbour messages (msgs_begin) and the total mass (allreduce_begin), and abort = ncclCommAbort.
  */
 #define __HIP_PLATFORM_AMD__
 #include <hip/hip_runtime_api.h>
@@ -26,6 +27,7 @@ typedef struct {
     hipEvent_t ready;               /* the plan's stream has produced what an exchange sends */
     hipEvent_t done[FASTPM_HIP_MAX_TAGS];       /* exchange `tag` has run on the transport's stream */
     unsigned char have[FASTPM_HIP_MAX_TAGS], active[FASTPM_HIP_MAX_TAGS];
+    int aborted;                    /* ncclCommAbort has run: the communicator is gone */
 } rccl_ctx;
 
 #define OK_HIP(e) ((e) == hipSuccess)
@@ -115,6 +117,54 @@ static int rccl_xchg_begin(void *ctx, const void *send, void *recv, const fastpm
     return ok ? 0 : -1;
 }
 
+/* the same ordering for up to FASTPM_HIP_MAX_MSGS neighbour messages as ONE group (the halo planes / rows of the force
+ * meshes travel together) ... */
+static int rccl_event_for(rccl_ctx *c, int tag)
+{
+    if (tag < 0 || tag >= FASTPM_HIP_MAX_TAGS || c->active[tag]) return 0;
+    if (!c->have[tag]) c->have[tag] = (unsigned char) OK_HIP(hipEventCreateWithFlags(&c->done[tag], hipEventDisableTiming));
+    return c->have[tag];
+}
+
+static int rccl_msgs_begin(void *ctx, const fastpm_hip_msg *m, int n, int tag)
+{
+    rccl_ctx *c = ctx;
+    if (n < 1 || n > FASTPM_HIP_MAX_MSGS || !rccl_event_for(c, tag)) return -1;
+    hipStream_t ps = c->plan ? (hipStream_t) fpmhip_plan_stream(c->plan) : NULL;
+    int ok = OK_HIP(hipEventRecord(c->ready, ps)) && OK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
+    ok = ok && OK_NCCL(ncclGroupStart());
+    for (int i = 0; i < n && ok; i++)
+        ok = OK_NCCL(ncclSend(m[i].send_dev, m[i].bytes, ncclInt8, m[i].dest, c->comm, c->stream))
+             && OK_NCCL(ncclRecv(m[i].recv_dev, m[i].bytes, ncclInt8, m[i].source, c->comm, c->stream));
+    ok = OK_NCCL(ncclGroupEnd()) && ok;
+    ok = ok && OK_HIP(hipEventRecord(c->done[tag], c->stream));
+    c->active[tag] = (unsigned char) ok;
+    return ok ? 0 : -1;
+}
+
+/* ... and for the scalars of the step: MPI_Allreduce(total mass), gravity.c:341, as an ncclAllReduce between two kernels
+ * of the plan's stream -- the host never sees the value (the paint kernels read it from out_dev) */
+static int rccl_allreduce_begin(void *ctx, const double *in, double *out, int n, int tag)
+{
+    rccl_ctx *c = ctx;
+    if (n < 1 || n > 4 || !rccl_event_for(c, tag)) return -1;
+    hipStream_t ps = c->plan ? (hipStream_t) fpmhip_plan_stream(c->plan) : NULL;
+    int ok = OK_HIP(hipEventRecord(c->ready, ps)) && OK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
+    ok = ok && OK_NCCL(ncclAllReduce(in, out, (size_t) n, ncclDouble, ncclSum, c->comm, c->stream));
+    ok = ok && OK_HIP(hipEventRecord(c->done[tag], c->stream));
+    c->active[tag] = (unsigned char) ok;
+    return ok ? 0 : -1;
+}
+
+/* this rank cannot go on: ncclCommAbort fails the peers' pending and later operations instead of leaving their streams
+ * waiting for receives that never come (the reference: fastpm_raise -> MPI_Abort, logging.c:242-251) */
+static void rccl_abort(void *ctx)
+{
+    rccl_ctx *c = ctx;
+    if (!c->aborted) (void) ncclCommAbort(c->comm);
+    c->aborted = 1;
+}
+
 static int rccl_xchg_wait(void *ctx, int tag)
 {
     rccl_ctx *c = ctx;
@@ -185,6 +235,9 @@ fastpm_hip_transport *fastpm_hip_rccl_transport_create(MPI_Comm comm, int device
     t->xchg_begin = rccl_xchg_begin;
     t->xchg_wait = rccl_xchg_wait;
     t->bind_plan = rccl_bind_plan;
+    t->msgs_begin = rccl_msgs_begin;
+    t->allreduce_begin = rccl_allreduce_begin;
+    t->abort = rccl_abort;
     return t;
 }
 
@@ -203,7 +256,7 @@ void fastpm_hip_rccl_transport_destroy(fastpm_hip_transport *t)
     for (int i = 0; i < FASTPM_HIP_MAX_TAGS; i++) if (c->have[i]) (void) hipEventDestroy(c->done[i]);
     (void) hipEventDestroy(c->ready);
     (void) hipFree(c->dscalar);
-    (void) ncclCommDestroy(c->comm);
+    if (!c->aborted) (void) ncclCommDestroy(c->comm);
     (void) hipStreamDestroy(c->stream);
     free(c);
     free(t);

@@ -69,6 +69,11 @@ SYMBOLS = {
     "fpmhip_paint": (_I, [_P, ctypes.POINTER(Particles), _D, _P]),
     "fpmhip_paint_add": (_I, [_P, ctypes.POINTER(Particles), _D, _P]),
     "fpmhip_total_mass": (_I, [_P, ctypes.POINTER(Particles), ctypes.POINTER(_D)]),
+    "fpmhip_plan_scalars": (_P, [_P]),
+    "fpmhip_total_mass_dev": (_I, [_P, ctypes.POINTER(Particles), _I, _P]),
+    "fpmhip_plan_scale_from_device": (_I, [_P, _P]),
+    "fpmhip_sum_rows_on": (_I, [_P, _P, _P, _I, _I]),
+    "fpmhip_plan_buffers_ready": (_I, [_P, _I]),
     "fpmhip_tile_order": (_I, [_P, ctypes.POINTER(Particles), _P]),
     "fpmhip_invalidate_binning": (_I, [_P]),
     "fpmhip_plane_ptr": (_P, [_P, _P, _I64]),

@@ -166,6 +166,8 @@ int  fpmhip_plan_set_stream(fpmhip_plan *plan, void *stream);
 void *fpmhip_plan_stream(const fpmhip_plan *plan);
 /* plan-owned mesh buffers: 0 = canvas, 1 = delta_k, 2..4 = force components, 5, 6 = exchange */
 void *fpmhip_plan_buffer(fpmhip_plan *plan, int which);
+/* mesh buffers [0, nbuf) allocated now: 0 = all existed, 1 = this call made some (the first step on the plan), -2 = failed */
+int  fpmhip_plan_buffers_ready(fpmhip_plan *plan, int nbuf);
 /* a plan-owned device scratch of at least `bytes` (grown on demand, freed with the plan; a larger request may move it) */
 void *fpmhip_plan_scratch(fpmhip_plan *plan, size_t bytes);
 int  fpmhip_sync(fpmhip_plan *plan);
@@ -213,6 +215,20 @@ int fpmhip_paint(fpmhip_plan *plan, const fpmhip_particles *p_dev, double scale,
 int fpmhip_paint_add(fpmhip_plan *plan, const fpmhip_particles *p_dev, double scale, void *canvas_dev);
 /* sum of fastpm_store_get_mass over the local particles (gravity.c:330-335) -> host double */
 int fpmhip_total_mass(fpmhip_plan *plan, const fpmhip_particles *p_dev, double *total_host);
+/* ---- the same WITHOUT a host wait (round 6; the multi-rank sequences of fastpm_amd/host/fastpm_slab_hip.c): the total
+ * mass of every species of this rank is summed into out_dev[0] on the plan's stream (out_dev[1..3] = 0), the transport
+ * all-reduces it on the device (fastpm_hip_transport.allreduce_begin: MPI_Allreduce of gravity.c:341 as an event-ordered
+ * ncclAllReduce), and the paint kernels form 1 / mean mass per cell from the device value themselves:
+ * fpmhip_plan_scale_from_device(plan, total_dev) names it, FPMHIP_SCALE_FROM_DEVICE as the `scale` argument of
+ * fpmhip_paint / fpmhip_paint_add / fpmhip_paint_zr2c[_pen] / fpmhip_mesh_scale stands for 1.0 / (*total_dev / Norm) --
+ * the host's expression with the host's two roundings.  fpmhip_plan_scalars: 8 plan-owned device doubles ([0, 4): this
+ * rank's contribution, [4, 8): the sums). */
+#define FPMHIP_SCALE_FROM_DEVICE (-1.0)
+double *fpmhip_plan_scalars(fpmhip_plan *plan);
+int fpmhip_total_mass_dev(fpmhip_plan *plan, const fpmhip_particles *sets_dev, int nsets, double *out_dev);
+int fpmhip_plan_scale_from_device(fpmhip_plan *plan, const double *total_dev);
+/* out_dev[j] = sum over r < nrows of rows_dev[r * n + j], in row order, on `stream` (a transport's device all-reduce) */
+int fpmhip_sum_rows_on(void *stream, double *out_dev, const double *rows_dev, int nrows, int n);
 /* The readout reuses the tile binning of the last paint when (x, np) are unchanged; call this if the positions behind
  * the same pointer were modified in between.  (A reuse is checked on the device -- one entry per tile against the row
  * it was copied from -- and a mismatch is reported as error -7 by the next call on the plan or by fpmhip_sync.)

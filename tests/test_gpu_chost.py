@@ -235,7 +235,10 @@ class Transport(ctypes.Structure):
                 ("alltoall_members", ctypes.c_void_p), ("alltoall_counts", ctypes.c_void_p), ("alltoallv", ctypes.c_void_p),
                 # round 5: the non-blocking pair of the pipelined sequence, the plan binding, plane ranges per transpose
                 ("xchg_begin", ctypes.c_void_p), ("xchg_wait", ctypes.c_void_p), ("bind_plan", ctypes.c_void_p),
-                ("chunks", ctypes.c_int)]
+                ("chunks", ctypes.c_int),
+                # round 6: neighbour messages and scalars without a host wait, the way out of a failed rank
+                ("msgs_begin", ctypes.c_void_p), ("allreduce_begin", ctypes.c_void_p), ("abort", ctypes.c_void_p),
+                ("no_overlap", ctypes.c_int)]
 
 
 def test_host_library_exports_the_slab_force():
@@ -476,6 +479,7 @@ def test_c_host_pipelined_exchanges_match_one_rank_oracle(oracle, Nx, Ny, kernel
     stores = [Store(x[idx[r]], potential=True) for r in range(P)]
     dks = [pm.alloc() for pm in pms]
     tol = 1e-6 if precision == 64 else 2e-5
+    sync_counts = [0] * P
     for call in range(3):
         # calls 0 and 1: the ASYNCHRONOUS loopback (an exchange stream per rank, events against the plan's stream: the copies
         # of a range run beside the passes of the next -- a misordered sequence computes garbage); call 2: the copies inside
@@ -501,6 +505,15 @@ def test_c_host_pipelined_exchanges_match_one_rank_oracle(oracle, Nx, Ny, kernel
         torch.cuda.synchronize()
         assert rcs == [0] * P, (rcs, fastpm_last_error())
         H.fastpm_hip_loopback_destroy(tr)
+        # round 6: with the event-ordered transport calls (the asynchronous loopback, chunks >= 1) the host waits for the
+        # plan's stream ONCE per force call -- the final agreement; halo planes / rows and the total mass no longer stop it
+        from fastpm_amd import lib
+        counts = [lib.load_library().fpmhip_plan_sync_count(pm._plan) for pm in pms]
+        if call == 1 and chunks >= 1:
+            assert [c - c0 for c, c0 in zip(counts, sync_counts)] == [1] * P, (counts, sync_counts)
+        elif call == 2:
+            assert all(c - c0 > 1 for c, c0 in zip(counts, sync_counts))      # the blocking sendrecv / allreduce_sum points
+        sync_counts = counts
         acc = np.zeros_like(ref["acc"])
         pot = np.zeros_like(ref["potential"])
         for r in range(P):
@@ -595,6 +608,59 @@ def test_pipelined_exchanges_on_a_slow_wire_and_the_negative_control(oracle, Nx,
     assert errs[1] > 1e-3, errs                       # the negative control: dropped waits are seen
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("Nx,Ny,paint_mode", [(4, 1, 3), (2, 2, 3), (2, 2, 0)])
+def test_a_rank_that_fails_between_two_exchanges_releases_its_peers(Nx, Ny, paint_mode):
+    """FASTPM_HIP_LOOPBACK_FAULT=2: rank 1's second xchg_begin fails (a transport error in the middle of the sequence, its
+    peers already inside later exchanges).  The rank aborts the transport (fastpm_hip_transport.abort -- ncclCommAbort /
+    MPI_Abort in the real ones; the reference: fastpm_raise -> MPI_Abort, logging.c:242-251) and EVERY thread must return
+    nonzero within the join timeout instead of waiting for a rank that left."""
+    import threading
+    import torch
+    from fastpm_amd import PM, Store
+    from fastpm_amd.pm import KERNEL_TYPES
+    H = _host()
+    H.fastpm_hip_loopback_create.restype = ctypes.POINTER(Transport)
+    H.fastpm_hip_loopback_create.argtypes = [ctypes.c_int]
+    H.fastpm_hip_loopback_destroy.argtypes = [ctypes.POINTER(Transport)]
+    H.fastpm_hip_mesh_force_species.argtypes = [ctypes.c_void_p, ctypes.POINTER(Transport), ctypes.c_void_p, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    N, nc, L, P = 64, 32, 96.0, Nx * Ny
+    x = util.load_b(nc, L, N)
+    h = L / N
+    own = ((np.floor(x[:, 0] / h).astype(np.int64) % N) // (N // Nx)) * Ny + (np.floor(x[:, 1] / h).astype(np.int64) % N) // (N // Ny)
+    idx = [np.nonzero(own == r)[0] for r in range(P)]
+    pms = [PM(N, L, 64, nranks=P, rank=r, nranks_y=Ny, paint_mode=paint_mode) for r in range(P)]
+    stores = [Store(x[idx[r]]) for r in range(P)]
+    for fault in ("0", "2"):                        # first a clean call (buffers made, binning in its steady state)
+        os.environ["FASTPM_HIP_LOOPBACK_FAULT"] = fault
+        tr = H.fastpm_hip_loopback_create(P)
+        os.environ.pop("FASTPM_HIP_LOOPBACK_FAULT")
+        rcs = [None] * P
+
+        def rank_main(r):
+            torch.cuda.set_device(0)
+            tr[r].chunks = 4
+            part = stores[r]._c()
+            rcs[r] = H.fastpm_hip_mesh_force_species(pms[r]._plan, ctypes.byref(tr[r]), ctypes.byref(part), 1,
+                                                     KERNEL_TYPES["1_4"], 0, None)
+
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=60)
+        assert all(not t.is_alive() for t in threads), "a rank is still waiting for the one that failed"
+        torch.cuda.synchronize()
+        if fault == "0":
+            assert rcs == [0] * P, rcs
+        else:
+            assert all(rc != 0 for rc in rcs), rcs
+        H.fastpm_hip_loopback_destroy(tr)
+    for pm in pms:
+        pm.destroy()
+
+
 def fastpm_last_error():
     from fastpm_amd import lib
     return lib.load_library().fpmhip_last_error()
@@ -680,7 +746,10 @@ def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode
     exe = os.path.join(ROOT, "fastpm_amd", "example_slab_mpi")
     r = subprocess.run([mpiexec, "-n", str(P), exe, str(nc), str(B), str(precision), str(gradient_mode), "0",
                         str(host_columns), str(decompose), str(nprocy), str(chunks), str(paint_mode)],
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=600,
+                       # round 6: staged through the host a transport declares no_overlap and gets the blocking whole-mesh
+                       # sequence; the cases that name plane ranges keep them (the MPI_Isend / MPI_Irecv path, real processes)
+                       env=dict(os.environ, FASTPM_HIP_MPI_STAGED_RANGES="1" if chunks > 0 else "0"))
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     lines = {l.split()[0] + (l.split()[1] if l.startswith("acc std") else ""): l.split() for l in r.stdout.splitlines()}
     assert lines["ranks"][1] == str(P) and float(lines["ranks"][3]) == nc ** 3        # every particle has one owner
