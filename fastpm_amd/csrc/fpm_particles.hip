@@ -1304,7 +1304,7 @@ int bin_particles(fpmhip_plan *p, const fpmhip_particles *pt)
 {
     // the leapfrog that moved these particles binned them on the way (bin_particles_leap): nothing to do but the check
     // every reuse of a binning makes -- one entry per tile against the row it was copied from (a caller that rewrote x
-    // behind the same pointer in between, e.g. a host twin uploaded again, gets -7 instead of forces from stale tiles)
+    // behind the same pointer in between gets -7, reported lazily: by fpmhip_sync at the end of the step or the next call)
     if (p->prebinned) {
         p->prebinned = false;
         if (p->binned_x == pt->x && p->binned_np == pt->np && p->binned_mass == pt->mass) return reuse_binning(p, pt);
@@ -1423,7 +1423,11 @@ static int bin_particles_once(fpmhip_plan *p, const fpmhip_particles *pt, bool *
 // broken contract (positions modified in place without fpmhip_invalidate_binning); it is reported when the flag arrives.
 int reuse_binning(fpmhip_plan *p, const fpmhip_particles *pt)
 {
-    FPM_TRY(check_deferred(p, true));
+    // NO host wait here (round 6): the flags of the binning being reused -- often the fused leapfrog walk enqueued a moment
+    // ago -- are still in d_flags (only FLAG_STALE is reset below) and travel again with this check's copy, so nothing is
+    // lost by not waiting for them; what has already arrived is looked at.  The stale check itself is LAZY: a caller that
+    // rewrote x behind the same pointer gets -7 from fpmhip_sync / the next call, not from this one.
+    FPM_TRY(check_deferred(p, false));
     const int nt = p->ntiles;
     FPM_CHECK_HIP(hipMemsetAsync(p->d_flags + FLAG_STALE, 0, sizeof(int), p->stream));
     verify_binning_kernel<<<blocks_for(nt, 256), 256, 0, p->stream>>>(p->mg, nt, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz,
@@ -1610,6 +1614,13 @@ int fpmhip_invalidate_binning(fpmhip_plan *p)
     p->binned_np = -1;
     p->binned_x = nullptr;
     return 0;
+}
+
+// ... only if the binning the plan holds was made from the positions at x_dev (a caller that rewrote ONE device buffer)
+int fpmhip_invalidate_binning_of(fpmhip_plan *p, const void *x_dev)
+{
+    if (!p) FPM_FAIL(-1, "null plan");
+    return p->binned_x == x_dev ? fpmhip_invalidate_binning(p) : 0;
 }
 
 int fpmhip_readout3(fpmhip_plan *p, const fpmhip_particles *pt, const void *m0, const void *m1, const void *m2)

@@ -192,7 +192,7 @@ static int upload(Twin *t, size_t bytes)
     t->state = ST_SAME;
     /* a column rewritten behind an unchanged DEVICE pointer: if it is the position column the plan binned last
      * (fpmhip_wrap_bin / fpmhip_leapfrog_bin leave the binning for the force that follows), that binning is stale */
-    if (t->kind == KIND_PLAIN && be == &default_backend) (void) fpmhip_invalidate_binning(t->plan);
+    if (t->kind == KIND_PLAIN && be == &default_backend) (void) fpmhip_invalidate_binning_of(t->plan, t->dev);
     return 0;
 }
 

@@ -83,12 +83,28 @@ plan_for(PM * pm)
      * modulo the GPUs the process sees (a launcher that masks one GPU per rank leaves one device: index 0). */
     int ndev = fpmhip_device_count();
     if(ndev < 1) fastpm_raise(-1, "no HIP device: the MI355X force step cannot run (there is no CPU fallback)\n");
-    int local_rank = 0, node_size = 1;
+    int local_rank = 0, node_size = 1, own_gpu = 1;
     if(pm->NTask > 1) {
         MPI_Comm node;
         MPI_Comm_split_type(pm->Comm2D, MPI_COMM_TYPE_SHARED, rank2d, MPI_INFO_NULL, &node);
         MPI_Comm_rank(node, &local_rank);
         MPI_Comm_size(node, &node_size);
+        g.device = local_rank % ndev;
+        /* Does every rank of this node compute on a GPU of its own?  Decided from the devices' IDENTITY (PCI address),
+         * gathered over the node -- not from the count a process sees: a launcher that masks one GPU per rank
+         * (ROCR_VISIBLE_DEVICES, --gpus-per-task=1) leaves ndev == 1 on every rank of an 8-GPU node. */
+        char mine[32], * all = malloc((size_t) node_size * 32);
+        int i, j;
+        memset(mine, 0, sizeof(mine));
+        if(fpmhip_device_pci_bus_id(g.device, mine, (int) sizeof(mine))) mine[0] = 0;
+        MPI_Allgather(mine, 32, MPI_CHAR, all, 32, MPI_CHAR, node);
+        for(i = 0; i < node_size; i ++) {
+            if(all[32 * i] == 0) own_gpu = 0;                   /* an address could not be read: assume the worst */
+            for(j = 0; j < i; j ++) {
+                if(memcmp(all + 32 * i, all + 32 * j, 32) == 0) own_gpu = 0;
+            }
+        }
+        free(all);
         MPI_Comm_free(&node);
     }
     g.device = local_rank % ndev;
@@ -122,20 +138,33 @@ plan_for(PM * pm)
     if(pm->NTask > 1) {
         /* The exchanges of the force step on pm->Comm2D.  DEFAULT: RCCL over xGMI -- grouped ncclSend / ncclRecv on a stream
          * of the transport's own, the transposes cut into plane ranges that overlap the (y, z) passes (fastpm_slab_hip.c) --
-         * whenever every rank of every node has a GPU to itself (RCCL refuses two ranks on one device).  Otherwise MPI
-         * staged through the host.  FASTPM_HIP_GPU_AWARE_MPI overrides: 2 = RCCL, 1 = device pointers handed to a GPU-aware
+         * whenever every rank of every node has a GPU to itself (RCCL refuses two ranks on one device; decided from the
+         * devices' PCI addresses above).  Otherwise, or when RCCL cannot be brought up, MPI staged through the host.  FASTPM_HIP_GPU_AWARE_MPI overrides: 2 = RCCL, 1 = device pointers handed to a GPU-aware
          * MPI, 0 = MPI staged through the host.  Every rank must take the same branch: the choice is agreed on. */
         const char * e = getenv("FASTPM_HIP_GPU_AWARE_MPI");
-        int mode = e ? atoi(e) : (ndev >= node_size ? 2 : 0);
+        int mode = e ? atoi(e) : (own_gpu ? 2 : 0);
         MPI_Allreduce(MPI_IN_PLACE, &mode, 1, MPI_INT, e ? MPI_MAX : MPI_MIN, pm->Comm2D);
         if(mode == 2) {
             c->transport = fastpm_hip_rccl_transport_create(pm->Comm2D, g.device);      /* the plan's device */
-        } else {
+            /* RCCL could not be brought up on some rank (ncclCommInitRank is collective: a failure anywhere fails it
+             * everywhere or leaves a rank without a communicator): agree, and fall back to MPI staged through the host
+             * on EVERY rank rather than raise */
+            int failed = c->transport == NULL;
+            MPI_Allreduce(MPI_IN_PLACE, &failed, 1, MPI_INT, MPI_MAX, pm->Comm2D);
+            if(failed) {
+                if(c->transport) fastpm_hip_rccl_transport_destroy(c->transport);
+                c->transport = NULL;
+                mode = 0;
+                fastpm_info("MI355X force step: the RCCL transport could not be created; falling back to host-staged MPI\n");
+            }
+        }
+        if(mode != 2) {
             c->transport = fastpm_hip_mpi_transport_create(pm->Comm2D, c->plan, mode);
         }
         if(!c->transport) fastpm_raise(-1, "no transport for the MI355X force step\n");
-        fastpm_info("MI355X force step: %d ranks, %s transport, %d GPU(s) per node for %d rank(s)\n", pm->NTask,
-                mode == 2 ? "RCCL (xGMI)" : mode == 1 ? "GPU-aware MPI" : "host-staged MPI", ndev, node_size);
+        fastpm_info("MI355X force step: %d ranks, %s transport, %d visible GPU(s) for %d rank(s) of this node, %s\n", pm->NTask,
+                mode == 2 ? "RCCL (xGMI)" : mode == 1 ? "GPU-aware MPI" : "host-staged MPI", ndev, node_size,
+                own_gpu ? "every rank on a GPU of its own" : "ranks share a GPU");
     }
     c->pm = pm;
     c->next = plans;

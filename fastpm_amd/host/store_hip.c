@@ -125,7 +125,7 @@ fastpm_store_decompose(FastPMStore * p, fastpm_store_target_func target_func, vo
  * (src/fastpm.c:1718: "Force dispersion") and the drift / kick reports on x and v.  Only ONE case is new here: a float
  * column whose device twin is the newer copy -- its particle loop runs on the device (fpmhip_store_summary) and the five
  * all-reduces follow.  Everything else is the reference's own function (store.o's definition, renamed by the -D flag
- * above), called once per format letter because a variadic function cannot be forwarded. */
+ * above), called ONCE with every format letter (a variadic function cannot be forwarded; its full format can be spelled out). */
 void fastpm_store_summary_cpu(FastPMStore * p, FastPMColumnTags attribute, MPI_Comm comm, const char * fmt, ...);
 
 void
@@ -151,8 +151,14 @@ fastpm_store_summary(FastPMStore * p, FastPMColumnTags attribute, MPI_Comm comm,
         MPI_Allreduce(MPI_IN_PLACE, part[1], nmemb, MPI_DOUBLE, MPI_MAX, comm);
         MPI_Allreduce(MPI_IN_PLACE, part[2], 2 * 9, MPI_DOUBLE, MPI_SUM, comm);        /* both sums: rows 2 and 3 */
         MPI_Allreduce(MPI_IN_PLACE, &Ntot, 1, MPI_UINT64_T, MPI_SUM, comm);
-    } else {
+    }
+    double host_stat[7][3];                                  /* the host path: every statistic, from ONE call */
+    if(!on_device) {
+        /* the reference's own function once, with every letter: one set of particle loops and all-reduces whatever the
+         * caller's format asks for (a variadic function cannot be forwarded, but its full format can be spelled out) */
         fastpm_hip_store_sync(p, attribute);
+        fastpm_store_summary_cpu(p, attribute, comm, letters, host_stat[0], host_stat[1], host_stat[2], host_stat[3],
+                                 host_stat[4], host_stat[5], host_stat[6]);
     }
     va_list va;
     va_start(va, fmt);
@@ -160,13 +166,12 @@ fastpm_store_summary(FastPMStore * p, FastPMColumnTags attribute, MPI_Comm comm,
         double * out = va_arg(va, double *);
         const char * which = strchr(letters, *fmt);
         if(!which) fastpm_raise(-1, "Unknown format str. Use '<->sSvV'\n");
-        if(!on_device) {
-            const char one[2] = {*fmt, 0};
-            fastpm_store_summary_cpu(p, attribute, comm, one, out);
-            continue;
-        }
         const double n = (double) Ntot, bessel = n / (n - 1.);
         for(d = 0; d < 3; d ++) {                           /* the reference fills three members, whatever nmemb is */
+            if(!on_device) {
+                out[d] = host_stat[which - letters][d];
+                continue;
+            }
             const double mean = part[2][d] / n, var = part[3][d] / n - mean * mean;
             const double stat[7] = {mean, part[0][d], part[1][d], sqrt(var), sqrt(bessel) * sqrt(var), var, bessel * var};
             out[d] = stat[which - letters];

@@ -76,6 +76,7 @@ SYMBOLS = {
     "fpmhip_plan_buffers_ready": (_I, [_P, _I]),
     "fpmhip_tile_order": (_I, [_P, ctypes.POINTER(Particles), _P]),
     "fpmhip_invalidate_binning": (_I, [_P]),
+    "fpmhip_invalidate_binning_of": (_I, [_P, _P]),
     "fpmhip_plane_ptr": (_P, [_P, _P, _I64]),
     "fpmhip_plane_add": (_I, [_P, _P, _P]),
     "fpmhip_r2c": (_I, [_P, _P, _P]),

@@ -238,6 +238,8 @@ int fpmhip_sum_rows_on(void *stream, double *out_dev, const double *rows_dev, in
  * when the flags have arrived: by the next binning on the plan or by fpmhip_sync -- no host round trip sits between the
  * paint and the readout of a force call. */
 int fpmhip_invalidate_binning(fpmhip_plan *plan);
+/* ... only when the binning the plan holds was made from the positions at x_dev (a device buffer that was rewritten) */
+int fpmhip_invalidate_binning_of(fpmhip_plan *plan, const void *x_dev);
 /* order_dev[j] = the row of the j-th particle in tile order (int32[np]).  The counting sort behind paint / readout is
  * fastest on rows that are already spatially coherent (0.46 ms for 16.8 M particles in lattice or previous-step
  * order, 3.2 ms in random order): permute every column of a freshly read / shuffled store once with

@@ -140,6 +140,60 @@ def test_a_wrong_member_would_be_caught(tmp_path):
     assert r.returncode != 0 and "NprocY" in r.stderr
 
 
+BINDING_TUS = ["gravity_hip.c", "factors_hip.c", "store_hip.c", "transfer_hip.c", "pm2lpt_hip.c"]
+LIBC = {"atoi", "free", "getenv", "malloc", "calloc", "realloc", "memcmp", "memset", "memcpy", "strchr", "strcmp", "strlen",
+        "pow", "sqrt", "fabs", "floor", "isfinite", "__stack_chk_fail", "_GLOBAL_OFFSET_TABLE_"}
+
+
+def _nm(path, flag):
+    out = subprocess.run(["nm", flag, path], capture_output=True, text=True, check=True).stdout
+    return {l.split()[-1] for l in out.splitlines() if l.split()}
+
+
+@needs_reference
+def test_the_binding_objects_close_over_known_libraries(tmp_path):
+    """The five translation units cannot be LINKED here (GSL / PFFT absent), but they can be compiled to objects, and an
+    object says what it would ask the linker for: every undefined symbol must be (i) an MPI call, (ii) libc / libm,
+    (iii) an fpmhip_* export of libfastpm_hip.so, (iv) a fastpm_hip_* symbol one of our host libraries or another of the
+    five objects defines, or (v) a name the reference's own headers declare (the `_cpu` names are the reference's
+    functions renamed with -D).  A typo in a call, or a helper that exists only in a header,
+    would otherwise surface at the maintainer's link line."""
+    import glob
+    import re
+    gsl = tmp_path / "gsl"
+    gsl.mkdir(exist_ok=True)
+    (gsl / "gsl_spline.h").write_text(
+        "typedef struct gsl_interp gsl_interp;\ntypedef struct gsl_interp_accel gsl_interp_accel;\n"
+        "typedef struct gsl_spline gsl_spline;\n")
+    objs = []
+    for tu in BINDING_TUS:
+        o = str(tmp_path / (tu[:-2] + ".o"))
+        r = subprocess.run(["gcc", "-std=gnu99", "-c", "-fPIC", "-Wall", "-Werror", "-I" + os.path.join(REF, "api"),
+                            "-I" + os.path.join(REF, "libfastpm"), "-I" + str(tmp_path), "-I" + MPI_INC,
+                            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "fastpm_amd", "host"),
+                            os.path.join(ROOT, "fastpm_amd", "host", tu), "-o", o], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        objs.append(o)
+    defined = set().union(*(_nm(o, "--defined-only") for o in objs))
+    ours = set()
+    for lib in ("libfastpm_hip.so", "libfastpm_hip_host.so", "libfastpm_hip_mpi.so"):
+        path = os.path.join(ROOT, "fastpm_amd", lib)
+        if not os.path.exists(path):
+            pytest.skip(lib + " is not built")
+        ours |= {s for s in _nm(path, "-D") if s.startswith(("fpmhip_", "fastpm_hip_"))}
+    ref_text = "".join(open(f, errors="replace").read() for f in glob.glob(os.path.join(REF, "api", "fastpm", "*.h"))
+                       + glob.glob(os.path.join(REF, "libfastpm", "*.h")))
+    ref_names = set(re.findall(r"[A-Za-z_]\w*", ref_text))
+    for o in objs:
+        for sym in sorted(_nm(o, "-u")):
+            base = sym[:-4] if sym.endswith("_cpu") else sym
+            ok = (sym.startswith("MPI_") or sym in LIBC or sym in ours or sym in defined
+                  or (not sym.startswith(("fpmhip_", "fastpm_hip_")) and base in ref_names))
+            assert ok, "%s needs %s: not MPI, libc, one of our exports, nor declared by the reference's headers" % (os.path.basename(o), sym)
+    # the three symbols the force binding exists for are DEFINED by it
+    assert {"fastpm_solver_compute_force", "fastpm_kernel_type_get_orders", "gravity_apply_kernel_transfer"} <= defined
+
+
 def test_integration_md_points_at_the_compiled_binding():
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert "fastpm_amd/host/gravity_hip.c" in text

@@ -72,7 +72,9 @@ def test_config1_properties():
     acc = st.acc.double()
     rms = float(acc.pow(2).mean().sqrt())
     assert torch.isfinite(acc).all() and rms > 0
-    assert float(acc.sum(0).abs().max()) / (rms * len(acc) ** 0.5) < 1e-3          # momentum conservation
+    # momentum conservation: |sum acc| against rms sqrt(Np).  An fp64 mesh leaves only the float32 rounding of the acc column
+    # (6e-8 relative per value, unbiased: ~3e-8 of rms sqrt(Np) at worst); measured 4e-9 (bench.py: 1.3e-12 of sum |acc|)
+    assert float(acc.sum(0).abs().max()) / (rms * len(acc) ** 0.5) < 3e-7
     c = pm.complex_view(dk)
     assert abs(complex(c[0, 0, 0].item()) - 1.0) < 1e-12                              # mean of 1 + delta
     pm.apply_decic_transfer(dk, dk)
@@ -133,7 +135,7 @@ def test_config2_mesh_on_one_gpu_properties():
     acc = st.acc.double()
     rms = float(acc.pow(2).mean().sqrt())
     assert torch.isfinite(acc).all() and rms > 0
-    assert float(acc.sum(0).abs().max()) / (rms * len(acc) ** 0.5) < 1e-3
+    assert float(acc.sum(0).abs().max()) / (rms * len(acc) ** 0.5) < 3e-7         # (see test_config1_properties)
     c = pm.complex_view(dk)
     assert abs(complex(c[0, 0, 0].item()) - 1.0) < 1e-12
     # the last plane / last row / Nyquist column are really addressed (no index wrapped at 2^31)
