@@ -103,6 +103,27 @@ __device__ __forceinline__ double paint_scale(const MeshGeo &g, double scale_arg
     return scale_arg < 0 ? 1.0 / (*g.dtotal / g.dnorm) : scale_arg;        // FPMHIP_SCALE_FROM_DEVICE
 }
 
+// STRIP ENTRY LAYOUT (round 6 A/B, profiles/r06_entry_layout_ab.md).  -DFPM_ENTRY_AOS=1: the four fields of a strip entry --
+// D_x, D_y, D_z, (row, base cell) -- are ONE 32-byte record {double x, y, z; int2 rc} (one sector per entry for the
+// binning's scattered stores, two dwordx4 accesses per entry in the marching kernels); 0 (default): four arrays of 8-byte
+// values (sx, sy, sz, scell).  The kernels go through ENT_X / ENT_Y / ENT_Z / ENT_RC; in the record layout sx points at the
+// records and sy / sz / scell are unused aliases.
+#ifndef FPM_ENTRY_AOS
+#define FPM_ENTRY_AOS 0
+#endif
+struct __attribute__((aligned(32))) EntryAos { double x, y, z; int2 rc; };
+#if FPM_ENTRY_AOS
+#define ENT_X(i) (((fpm::EntryAos *) (sx))[i].x)
+#define ENT_Y(i) (((fpm::EntryAos *) (sx))[i].y)
+#define ENT_Z(i) (((fpm::EntryAos *) (sx))[i].z)
+#define ENT_RC(i) (((fpm::EntryAos *) (sx))[i].rc)
+#else
+#define ENT_X(i) sx[i]
+#define ENT_Y(i) sy[i]
+#define ENT_Z(i) sz[i]
+#define ENT_RC(i) scell[i]
+#endif
+
 // Pencil plans with strip tiles (round 4): the marching kernels write / read the half-spectrum rows where the (y <-> kz)
 // exchange "A" wants / leaves them -- row (x, y) cut into kz blocks, block b at b * chunk + (x * ylr + y) * nzl -- so no
 // pack or unpack pass exists; the rows that belong to the neighbours (plane xl, row ylr) live in small buffers of plain

@@ -307,8 +307,8 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(MeshGeo g, int ntiles,
                 if (g.strips) {                       // strip entries: D and the base cell (fpm_cic.h: strip_cell)
                     Cic c;
                     (void) cic_setup(g, L.x[pid], L.y[pid], L.z[pid], c);
-                    sx[slot] = c.d[0]; sy[slot] = c.d[1]; sz[slot] = c.d[2];
-                    scell[slot] = make_int2(L.row[pid], strip_cell(c));
+                    ENT_X(slot) = c.d[0]; ENT_Y(slot) = c.d[1]; ENT_Z(slot) = c.d[2];
+                    ENT_RC(slot) = make_int2(L.row[pid], strip_cell(c));
                 } else {
                     sx[slot] = L.x[pid]; sy[slot] = L.y[pid]; sz[slot] = L.z[pid];
                     sidx[slot] = L.row[pid];
@@ -444,8 +444,8 @@ __global__ __launch_bounds__(256) void bin_scatter_wave_kernel(MeshGeo g, int nt
         const int u = q >> 1;
         if (local < kc[q] && (long long) kb[q] + local < alloc) {
             const int slot = kb[q] + local;
-            sx[slot] = px[u]; sy[slot] = py[u]; sz[slot] = pz[u];
-            scell[slot] = make_int2(row[u], cell[u]);       // row and base cell in one 8-byte store
+            ENT_X(slot) = px[u]; ENT_Y(slot) = py[u]; ENT_Z(slot) = pz[u];
+            ENT_RC(slot) = make_int2(row[u], cell[u]);       // row and base cell in one 8-byte store
             if (smass) smass[slot] = pm[u];
         } else {
             spilled = true;
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256) void tile_order_kernel(int ntiles, const int *
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (t >= ntiles) return;
     const int b = beg[t], n = cnt[t], o = off[t];
-    for (int k = lane; k < n; k += 64) order[o + k] = scell ? scell[b + k].x : sidx[b + k];      // strip entries: (row, cell)
+    for (int k = lane; k < n; k += 64) order[o + k] = scell ? scell[(FPM_ENTRY_AOS ? 4 : 1) * (b + k)].x : sidx[b + k];      // strip entries: (row, cell); in the record layout scell points at record 0's (row, cell), 32 bytes apart
 }
 
 // Is the binning the plan holds still the binning of THESE positions?  One entry of every non-empty own tile is
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256) void verify_binning_kernel(MeshGeo g, int ntil
     const int n = cnt[t];
     if (n == 0) return;
     const int e = beg[t] + t % n;
-    const long long i = g.strips ? scell[e].x : sidx[e];
+    const long long i = g.strips ? ENT_RC(e).x : sidx[e];
     double want[3] = {x[3 * i], x[3 * i + 1], x[3 * i + 2]};
     if (g.strips) {                                   // strip entries hold D, not the position
         Cic c;
@@ -587,9 +587,9 @@ __global__ __launch_bounds__(256) void verify_binning_kernel(MeshGeo g, int ntil
         // ... and the base cell: a shift by whole cells (a periodic re-wrap, a translation by n cells) leaves every D
         // bit-identical; the entry's packed (iy, iz) and the x plane / strip of the tile it sits in must still be the
         // particle's (own tile t = ix * nty + iy / STRIP_Y)
-        if (scell[e].y != strip_cell(c) || t != c.i0[0] * g.nty + c.i0[1] / STRIP_Y) flags[FLAG_STALE] = 1;
+        if (ENT_RC(e).y != strip_cell(c) || t != c.i0[0] * g.nty + c.i0[1] / STRIP_Y) flags[FLAG_STALE] = 1;
     }
-    if (sx[e] != want[0] || sy[e] != want[1] || sz[e] != want[2]) flags[FLAG_STALE] = 1;
+    if ((g.strips ? ENT_X(e) != want[0] || ENT_Y(e) != want[1] || ENT_Z(e) != want[2] : sx[e] != want[0] || sy[e] != want[1] || sz[e] != want[2])) flags[FLAG_STALE] = 1;
 }
 
 // One workgroup = one tile.  LDS tile of F accumulators; entries of the tile (own, then dup)

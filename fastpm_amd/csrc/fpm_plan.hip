@@ -73,16 +73,23 @@ int ensure_bins(fpmhip_plan *p, int64_t np, int64_t ndup, bool has_mass)
     if (need > p->bin_alloc || (has_mass && !p->smass)) {
         const int64_t cap = need > p->bin_alloc ? need + need / 16 : p->bin_alloc;
         if (p->sx) FPM_CHECK_HIP(hipStreamSynchronize(p->stream));
-        if (p->sx) { (void) hipFree(p->sx); (void) hipFree(p->sy); (void) hipFree(p->sz); (void) hipFree(p->sidx); }
-        if (p->scell) { (void) hipFree(p->scell); p->scell = nullptr; }
+        const bool aos = FPM_ENTRY_AOS && p->mg.strips;       // one array of 32-byte records behind sx (fpm_internal.h)
+        if (p->sx) { (void) hipFree(p->sx); if (!aos) { (void) hipFree(p->sy); (void) hipFree(p->sz); } (void) hipFree(p->sidx); }
+        if (p->scell && !aos) (void) hipFree(p->scell);
+        p->scell = nullptr;
         if (p->smass) { (void) hipFree(p->smass); p->smass = nullptr; }
         p->sx = p->sy = p->sz = nullptr;
         p->sidx = nullptr;
-        FPM_CHECK_HIP(hipMalloc(&p->sx, cap * sizeof(double)));
-        FPM_CHECK_HIP(hipMalloc(&p->sy, cap * sizeof(double)));
-        FPM_CHECK_HIP(hipMalloc(&p->sz, cap * sizeof(double)));
+        if (aos) {
+            FPM_CHECK_HIP(hipMalloc(&p->sx, cap * sizeof(EntryAos)));
+            p->sy = p->sx + 1; p->sz = p->sx + 2; p->scell = (int2 *) (p->sx + 3);      // never dereferenced as arrays
+        } else {
+            FPM_CHECK_HIP(hipMalloc(&p->sx, cap * sizeof(double)));
+            FPM_CHECK_HIP(hipMalloc(&p->sy, cap * sizeof(double)));
+            FPM_CHECK_HIP(hipMalloc(&p->sz, cap * sizeof(double)));
+            if (p->mg.strips) FPM_CHECK_HIP(hipMalloc(&p->scell, cap * sizeof(int2)));
+        }
         FPM_CHECK_HIP(hipMalloc(&p->sidx, cap * sizeof(int)));
-        if (p->mg.strips) FPM_CHECK_HIP(hipMalloc(&p->scell, cap * sizeof(int2)));
         if (has_mass) FPM_CHECK_HIP(hipMalloc(&p->smass, cap * sizeof(float)));
         p->bin_alloc = cap;
         p->binned_np = -1;
@@ -397,6 +404,7 @@ void fpmhip_plan_destroy(fpmhip_plan *p)
     (void) hipStreamSynchronize(p->stream);
     fft_teardown(p);
     for (int i = 0; i < BUF_COUNT; i++) if (p->buf[i]) (void) hipFree(p->buf[i]);
+    if (FPM_ENTRY_AOS && p->mg.strips) { p->sy = p->sz = nullptr; p->scell = nullptr; }      // aliases into the records behind sx
     void *ptrs[] = {p->host_stage.x, p->host_stage.acc, p->host_stage.mass, p->host_stage.pot,
                     p->d_twiddle, p->d_tab, p->d_fac, p->sx, p->sy, p->sz, p->smass, p->sidx, p->bin_beg[0], p->bin_beg[1],
                     p->bin_cap[0], p->bin_cap[1], p->bin_cnt, p->bin_off, p->bin_capv, p->bin_tmp, p->order[0], p->order[1],

@@ -242,8 +242,8 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), (sizeof(F) == 4 && P
             e.cell[u] = 0;
             if (k < e.cnt[part]) {
                 const int s_ = e.beg[part] + k;
-                e.x[u] = sx[s_]; e.y[u] = sy[s_]; e.z[u] = sz[s_];
-                e.cell[u] = scell[s_].y;
+                e.x[u] = ENT_X(s_); e.y[u] = ENT_Y(s_); e.z[u] = ENT_Z(s_);
+                e.cell[u] = ENT_RC(s_).y;
                 if (smass) e.m[u] = smass[s_];
             }
         }
@@ -259,7 +259,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), (sizeof(F) == 4 && P
         for (int part = 0; part < 2; part++)
             for (int k = tid + (part == 0 ? PF_OWN : PF_DUP) * NT; k < e.cnt[part]; k += NT) {
                 const int s_ = e.beg[part] + k;
-                add_half(sx[s_], sy[s_], sz[s_], smass ? smass[s_] : 0.f, scell[s_].y, bx);
+                add_half(ENT_X(s_), ENT_Y(s_), ENT_Z(s_), smass ? smass[s_] : 0.f, ENT_RC(s_).y, bx);
             }
     };
 
@@ -422,8 +422,8 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
             px[u] = py[u] = pz[u] = 0;
             prow[u] = pc[u] = 0;
             if (e < n) {
-                px[u] = sx[b + e]; py[u] = sy[b + e]; pz[u] = sz[b + e];
-                const int2 rc = scell[b + e];                      // (row, base cell)
+                px[u] = ENT_X(b + e); py[u] = ENT_Y(b + e); pz[u] = ENT_Z(b + e);
+                const int2 rc = ENT_RC(b + e);                      // (row, base cell)
                 prow[u] = rc.x; pc[u] = rc.y;
             }
         }
@@ -449,8 +449,8 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
         for (int u = 0; u < 2; u++)
             if (threadIdx.x + u * NT < n) gather(px[u], py[u], pz[u], pc[u], prow[u]);
         for (int e = threadIdx.x + 2 * NT; e < n; e += NT) {
-            const int2 rc = scell[b + e];
-            gather(sx[b + e], sy[b + e], sz[b + e], rc.y, rc.x);
+            const int2 rc = ENT_RC(b + e);
+            gather(ENT_X(b + e), ENT_Y(b + e), ENT_Z(b + e), rc.y, rc.x);
         }
         __syncthreads();
         C2<F> *tmp = A; A = B; B = tmp;
@@ -665,8 +665,8 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (PL::E == 4 ? FPM_RO
                 qx[u] = 0.25; qy[u] = 0.5; qz[u] = 0.75;
                 qrow[u] = qb + e; qc[u] = ((y0 + (e & 3)) << 12) | (e & 255);
 #else
-                qx[u] = sx[qb + e]; qy[u] = sy[qb + e]; qz[u] = sz[qb + e];
-                const int2 rc = scell[qb + e];                     // (row, base cell)
+                qx[u] = ENT_X(qb + e); qy[u] = ENT_Y(qb + e); qz[u] = ENT_Z(qb + e);
+                const int2 rc = ENT_RC(qb + e);                     // (row, base cell)
                 qrow[u] = rc.x; qc[u] = rc.y;
 #endif
             }
@@ -679,7 +679,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (PL::E == 4 ? FPM_RO
             px[u] = qx[u]; py[u] = qy[u]; pz[u] = qz[u]; prow[u] = qrow[u]; pc[u] = qc[u];
             pv[u] = tid + u * NT < qn ? half(qx[u], qy[u], qz[u], qc[u], 0, 0.0) : 0.0;
         }
-        for (int e = tid + PF * NT; e < qn; e += NT) part[qb + e] = half(sx[qb + e], sy[qb + e], sz[qb + e], scell[qb + e].y, 0, 0.0);
+        for (int e = tid + PF * NT; e < qn; e += NT) part[qb + e] = half(ENT_X(qb + e), ENT_Y(qb + e), ENT_Z(qb + e), ENT_RC(qb + e).y, 0, 0.0);
         pb = qb;
         pn = qn;
     };
@@ -694,8 +694,8 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (PL::E == 4 ? FPM_RO
                 out[(long long) prow[u] * nmemb + memb0 + comp] = val;
             }
         for (int e = tid + PF * NT; e < pn; e += NT) {
-            const int2 rc = scell[pb + e];
-            out[(long long) rc.x * nmemb + memb0 + comp] = (float) half(sx[pb + e], sy[pb + e], sz[pb + e], rc.y, 1, part[pb + e]);
+            const int2 rc = ENT_RC(pb + e);
+            out[(long long) rc.x * nmemb + memb0 + comp] = (float) half(ENT_X(pb + e), ENT_Y(pb + e), ENT_Z(pb + e), rc.y, 1, part[pb + e]);
         }
     };
 
@@ -854,8 +854,8 @@ __global__ __launch_bounds__((Rows2Cfg<PL>::threads), (PL::E == 16 ? FPM_RO2_MIN
             qx[u] = qy[u] = qz[u] = 0;
             qrow[u] = qc[u] = 0;
             if (e < qn) {
-                qx[u] = sx[qb + e]; qy[u] = sy[qb + e]; qz[u] = sz[qb + e];
-                const int2 rc = scell[qb + e];                     // (row, base cell)
+                qx[u] = ENT_X(qb + e); qy[u] = ENT_Y(qb + e); qz[u] = ENT_Z(qb + e);
+                const int2 rc = ENT_RC(qb + e);                     // (row, base cell)
                 qrow[u] = rc.x; qc[u] = rc.y;
             }
         }
@@ -867,7 +867,7 @@ __global__ __launch_bounds__((Rows2Cfg<PL>::threads), (PL::E == 16 ? FPM_RO2_MIN
             px[u] = qx[u]; py[u] = qy[u]; pz[u] = qz[u]; prow[u] = qrow[u]; pc[u] = qc[u];
             pv[u] = tid + u * NT < qn ? half(qx[u], qy[u], qz[u], qc[u], 0, 0.0) : 0.0;
         }
-        for (int e = tid + PF * NT; e < qn; e += NT) part[qb + e] = half(sx[qb + e], sy[qb + e], sz[qb + e], scell[qb + e].y, 0, 0.0);
+        for (int e = tid + PF * NT; e < qn; e += NT) part[qb + e] = half(ENT_X(qb + e), ENT_Y(qb + e), ENT_Z(qb + e), ENT_RC(qb + e).y, 0, 0.0);
         pb = qb;
         pn = qn;
     };
@@ -877,8 +877,8 @@ __global__ __launch_bounds__((Rows2Cfg<PL>::threads), (PL::E == 16 ? FPM_RO2_MIN
             if (tid + u * NT < pn)
                 out[(long long) prow[u] * nmemb + memb0 + comp] = (float) half(px[u], py[u], pz[u], pc[u], 1, pv[u]);
         for (int e = tid + PF * NT; e < pn; e += NT) {
-            const int2 rc = scell[pb + e];
-            out[(long long) rc.x * nmemb + memb0 + comp] = (float) half(sx[pb + e], sy[pb + e], sz[pb + e], rc.y, 1, part[pb + e]);
+            const int2 rc = ENT_RC(pb + e);
+            out[(long long) rc.x * nmemb + memb0 + comp] = (float) half(ENT_X(pb + e), ENT_Y(pb + e), ENT_Z(pb + e), rc.y, 1, part[pb + e]);
         }
     };
 
@@ -1023,8 +1023,8 @@ __global__ __launch_bounds__((3 * StripCfg<PL, F>::ro_threads), 4) void readout_
             qx[u] = qy[u] = qz[u] = 0;
             qrow[u] = qc[u] = 0;
             if (e < qn) {
-                qx[u] = sx[qb + e]; qy[u] = sy[qb + e]; qz[u] = sz[qb + e];
-                const int2 rc = scell[qb + e];
+                qx[u] = ENT_X(qb + e); qy[u] = ENT_Y(qb + e); qz[u] = ENT_Z(qb + e);
+                const int2 rc = ENT_RC(qb + e);
                 qrow[u] = rc.x; qc[u] = rc.y;
             }
         }
@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__((3 * StripCfg<PL, F>::ro_threads), 4) void readout_
         }
         for (int e = tid + PF * NT; e < qn; e += NT) {
             double a[3] = {0.0, 0.0, 0.0};
-            half3(sx[qb + e], sy[qb + e], sz[qb + e], scell[qb + e].y, 0, a);
+            half3(ENT_X(qb + e), ENT_Y(qb + e), ENT_Z(qb + e), ENT_RC(qb + e).y, 0, a);
 #pragma unroll
             for (int m = 0; m < 3; m++) part_all[m * part_stride + qb + e] = a[m];
         }
@@ -1054,11 +1054,11 @@ __global__ __launch_bounds__((3 * StripCfg<PL, F>::ro_threads), 4) void readout_
                 store3(prow[u], pv[u]);
             }
         for (int e = tid + PF * NT; e < pn; e += NT) {
-            const int2 rc = scell[pb + e];
+            const int2 rc = ENT_RC(pb + e);
             double a[3];
 #pragma unroll
             for (int m = 0; m < 3; m++) a[m] = part_all[m * part_stride + pb + e];
-            half3(sx[pb + e], sy[pb + e], sz[pb + e], rc.y, 1, a);
+            half3(ENT_X(pb + e), ENT_Y(pb + e), ENT_Z(pb + e), rc.y, 1, a);
             store3(rc.x, a);
         }
     };
@@ -1201,8 +1201,8 @@ __global__ __launch_bounds__((PairCfg<PL2, F>::threads), FPM_RO_MINW) void reado
             qx[u] = qy[u] = qz[u] = 0;
             qrow[u] = qc[u] = 0;
             if (e < qn) {
-                qx[u] = sx[qb + e]; qy[u] = sy[qb + e]; qz[u] = sz[qb + e];
-                const int2 rc = scell[qb + e];                     // (row, base cell)
+                qx[u] = ENT_X(qb + e); qy[u] = ENT_Y(qb + e); qz[u] = ENT_Z(qb + e);
+                const int2 rc = ENT_RC(qb + e);                     // (row, base cell)
                 qrow[u] = rc.x; qc[u] = rc.y;
             }
         }
@@ -1213,7 +1213,7 @@ __global__ __launch_bounds__((PairCfg<PL2, F>::threads), FPM_RO_MINW) void reado
             px[u] = qx[u]; py[u] = qy[u]; pz[u] = qz[u]; prow[u] = qrow[u]; pc[u] = qc[u];
             pv[u] = tid + u * NT < qn ? half(qx[u], qy[u], qz[u], qc[u], 0, 0.0) : 0.0;
         }
-        for (int e = tid + PF * NT; e < qn; e += NT) part[qb + e] = half(sx[qb + e], sy[qb + e], sz[qb + e], scell[qb + e].y, 0, 0.0);
+        for (int e = tid + PF * NT; e < qn; e += NT) part[qb + e] = half(ENT_X(qb + e), ENT_Y(qb + e), ENT_Z(qb + e), ENT_RC(qb + e).y, 0, 0.0);
         pb = qb;
         pn = qn;
     };
@@ -1223,8 +1223,8 @@ __global__ __launch_bounds__((PairCfg<PL2, F>::threads), FPM_RO_MINW) void reado
             if (tid + u * NT < pn)
                 out[(long long) prow[u] * nmemb + memb0 + comp] = (float) half(px[u], py[u], pz[u], pc[u], 1, pv[u]);
         for (int e = tid + PF * NT; e < pn; e += NT) {
-            const int2 rc = scell[pb + e];
-            out[(long long) rc.x * nmemb + memb0 + comp] = (float) half(sx[pb + e], sy[pb + e], sz[pb + e], rc.y, 1, part[pb + e]);
+            const int2 rc = ENT_RC(pb + e);
+            out[(long long) rc.x * nmemb + memb0 + comp] = (float) half(ENT_X(pb + e), ENT_Y(pb + e), ENT_Z(pb + e), rc.y, 1, part[pb + e]);
         }
     };
 
