@@ -16,6 +16,8 @@ fpmhip_plan * fastpm_hip_current_plan(void);
 PM * fastpm_hip_current_pm(void);
 /* the exchanges of that PM's process mesh (a fastpm_hip_transport, fastpm_slab_hip.h; NULL on one rank) */
 const void * fastpm_hip_current_transport(void);
+/* ... of ANY PM (its plan and transport made at the first use): pm_2lpt_solve runs on the IC mesh, not the force mesh */
+const void * fastpm_hip_transport_for(PM * pm);
 /* 1 when factors_hip.o is linked in and FASTPM_HIP_RESIDENT is not 0: columns stay on the device between the calls */
 int fastpm_hip_resident_enabled(void);
 

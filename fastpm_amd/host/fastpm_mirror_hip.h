@@ -115,6 +115,10 @@ int fastpm_hip_resident_decompose(fpmhip_plan *plan, const void *transport, void
  * written (they stay on the device for pm_2lpt_evolve's host loop to ask for with fastpm_hip_host_sync) */
 int fastpm_hip_resident_2lpt(fpmhip_plan *plan, const void *delta_k_host, double *x, float *dx1, float *dx2, int64_t np,
                              const double shift[3], int type);
+/* ... for NTask > 1 (round 6; shift = 0): fastpm_hip_mesh_2lpt_solve on the twins through the PM's transport; every rank
+ * calls it, whatever its np */
+int fastpm_hip_resident_2lpt_ranks(fpmhip_plan *plan, const void *transport, const void *delta_k_host, double *x, float *dx1,
+                                   float *dx2, int64_t np, int type);
 int fastpm_hip_resident_decic(fpmhip_plan *plan, const void *from, void *to);                     /* transfer.c:77-113 */
 /* powerspectrum.c:35-111 before its Allreduce: the raw bin sums (Nmesh / 2 bins) */
 int fastpm_hip_resident_powerspectrum(fpmhip_plan *plan, const void *delta1_k, const void *delta2_k, double *ksum,

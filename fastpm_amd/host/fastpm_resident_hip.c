@@ -646,6 +646,24 @@ int fastpm_hip_resident_2lpt(fpmhip_plan *plan, const void *delta_k_host, double
     return fastpm_hip_2lpt_solve_dev(plan, dk, dx, d1, d2, np, shift, type);
 }
 
+int fastpm_hip_resident_2lpt_ranks(fpmhip_plan *plan, const void *transport, const void *delta_k_host, double *x, float *dx1,
+                                   float *dx2, int64_t np, int type)
+{
+    if (!plan || !transport || !delta_k_host || np < 0 || (np > 0 && (!x || !dx1 || !dx2))) return -1;
+    /* (a rank without particles still takes part in every exchange: its twins are one-byte placeholders) */
+    static double none_x[3];
+    static float none_d1[3], none_d2[3];
+    const size_t n1 = np > 0 ? (size_t) np : 1;
+    const void *dk;
+    const double *dx;
+    float *d1, *d2;
+    NEED(dk = fastpm_hip_kmesh_in(plan, delta_k_host));
+    NEED(dx = fastpm_hip_dev_in(plan, np > 0 ? x : none_x, n1 * 24));
+    NEED(d1 = fastpm_hip_dev_out(plan, np > 0 ? dx1 : none_d1, n1 * 12));
+    NEED(d2 = fastpm_hip_dev_out(plan, np > 0 ? dx2 : none_d2, n1 * 12));
+    return fastpm_hip_mesh_2lpt_solve(plan, transport, dk, dx, d1, d2, np, type);
+}
+
 int fastpm_hip_resident_decic(fpmhip_plan *plan, const void *from, void *to)
 {
     if (!plan || !from || !to) return -1;

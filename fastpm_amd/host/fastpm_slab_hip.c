@@ -540,7 +540,7 @@ static int halo_in(seq *q, const mesh_groups *g, const fpmhip_layout *lay, void 
     fpmhip_plan *plan = q->plan;
     const size_t es = (size_t) lay->precision / 8;
     const size_t plane_bytes = (size_t) lay->plane_elems * es, row_bytes = (size_t) lay->isize[0] * (size_t) lay->istrides[1] * es;
-    fastpm_hip_msg m[4];
+    fastpm_hip_msg m[4] = {{0}};
     if (g->Ny > 1) {
         for (int d = 0; d < nm; d++) {
             char *rs = (char *) scratch + (size_t) 2 * d * row_bytes;
@@ -861,6 +861,190 @@ int fastpm_hip_mesh_force_species(fpmhip_plan *plan, const fastpm_hip_transport 
      * compute failure left the rank in the sequence (RUN / XCH), and a rank-local failure after the LAST exchange must not
      * leave the peers waiting here for a rank that returned early. */
     const int late = fpmhip_sync(plan);
+    if (rc == 0) rc = late;
+    double failed = rc != 0;
+    if (t->allreduce_sum(t->ctx, &failed) != 0) return seq_abort(q, rc ? rc : -1);
+    if (failed != 0 && rc == 0) rc = -8;
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------------------
+ * pm_2lpt_solve (pm2lpt.c:14-164) for NTask > 1 (round 6): the call order of the reference -- and of the one-rank
+ * fastpm_hip_2lpt_solve_dev, fastpm_2lpt_hip.c -- with every pm_c2r / pm_r2c split around its transposes and the mesh halo
+ * in front of every readout (the reference makes particle ghosts instead, pm2lpt.c:35-36).  The C twin of
+ * fastpm_amd/distributed.py::Slab2LPT / Pencil2LPT.  12 c2r + 1 r2c; the seven mesh buffers of the plan are its workspace
+ * (source | workspace | field[3] | two exchange meshes); event-ordered like the force: one host wait, at the agreement.
+ */
+typedef struct {
+    seq *q;
+    fpmhip_layout lay;
+    mesh_groups g;
+    int nr, pencil;
+    void *wa, *wb;              /* exchange scratch */
+    size_t plane_bytes, a_bytes, b_bytes;
+} lpt_ctx;
+
+/* one whole-mesh transpose: event-ordered where the transport offers it, else the blocking call */
+static int lpt_transpose(lpt_ctx *L, int axis, const void *send, void *recv, int tag)
+{
+    seq *q = L->q;
+    if (!L->pencil) {
+        if (L->nr >= 1) {
+            TRY(begin_range(q, &L->lay, send, recv, 0, 0, tag));
+            return wait_tag(q, tag);
+        }
+        return exchange(q, send, recv, L->b_bytes);
+    }
+    if (L->nr >= 1) {
+        TRY(begin_axis(q, &L->lay, &L->g, axis, send, recv, 0, 0, tag));
+        return wait_axis(q, &L->g, axis, tag);
+    }
+    return exchange_axis(q, &L->g, axis, send, recv, axis == 0 ? L->a_bytes : L->b_bytes);
+}
+
+/* pm_c2r (pmpfft.c:390-399), in place: buf holds the k-space block on entry, the real mesh on return */
+static int lpt_c2r(lpt_ctx *L, void *buf)
+{
+    seq *q = L->q;
+    fpmhip_plan *plan = q->plan;
+    RUN(fpmhip_fft_x_backward(plan, buf));
+    if (!L->pencil) {
+        TRY(lpt_transpose(L, 1, buf, L->wa, TAG_X));
+        RUN(fpmhip_fft_yz_backward(plan, L->wa, buf));
+        return 0;
+    }
+    TRY(lpt_transpose(L, 1, buf, L->wb, TAG_X));
+    RUN(fpmhip_fft_y_backward(plan, L->wb, L->wa));
+    TRY(lpt_transpose(L, 0, L->wa, L->wb, TAG_XA));
+    RUN(fpmhip_fft_z_backward(plan, L->wb, buf));
+    return 0;
+}
+
+/* pm_r2c (pmpfft.c:370-388; carries the 1 / Nmesh^3) */
+static int lpt_r2c(lpt_ctx *L, void *real, void *out_k)
+{
+    seq *q = L->q;
+    fpmhip_plan *plan = q->plan;
+    if (!L->pencil) {
+        RUN(fpmhip_fft_yz_forward(plan, real, L->wa));
+        TRY(lpt_transpose(L, 1, L->wa, out_k, TAG_FWD));
+    } else {
+        RUN(fpmhip_fft_z_forward(plan, real, L->wa));
+        TRY(lpt_transpose(L, 0, L->wa, L->wb, TAG_A));
+        RUN(fpmhip_fft_y_forward(plan, L->wb, L->wa));
+        TRY(lpt_transpose(L, 1, L->wa, out_k, TAG_FWD));
+    }
+    RUN(fpmhip_fft_x_forward(plan, out_k));
+    return 0;
+}
+
+/* fastpm_readout_local of one component into column[., memb] behind the neighbours' plane / row of the mesh */
+static int lpt_readout(lpt_ctx *L, void *mesh, const fpmhip_particles *part, float *column, int memb)
+{
+    seq *q = L->q;
+    if (!L->pencil) {
+        const fastpm_hip_msg m = plane_msg(q, mesh, 0, 1, fpmhip_plane_ptr(q->plan, mesh, L->lay.isize[0]), -1, L->plane_bytes);
+        TRY(neighbours(q, &m, 1, TAG_HALO));
+    } else {
+        void *one[1] = {mesh};
+        TRY(halo_in(q, &L->g, &L->lay, one, 1, L->wa));
+    }
+    RUN(fpmhip_readout1(q->plan, part, mesh, column, 3, memb));
+    return 0;
+}
+
+static int lpt_sequence(lpt_ctx *L, const void *delta_k, const fpmhip_particles *part, float *dx1, float *dx2, int type)
+{
+    seq *q = L->q;
+    fpmhip_plan *plan = q->plan;
+    int potorder, gradorder, difforder, deconvolveorder;
+    TRY(fpmhip_kernel_type_get_orders(type, &potorder, &gradorder, &difforder, &deconvolveorder));      /* pm2lpt.c:17-18 */
+    void *source = fpmhip_plan_buffer(plan, B_CANVAS), *workspace = fpmhip_plan_buffer(plan, B_DELTA_K);
+    void *field[3] = {fpmhip_plan_buffer(plan, B_F0), fpmhip_plan_buffer(plan, B_F1), fpmhip_plan_buffer(plan, B_F2)};
+    const size_t bytes = (size_t) L->lay.allocsize * ((size_t) L->lay.precision / 8);
+    static const int D1[3] = {1, 2, 0}, D2[3] = {2, 0, 1};
+    RUN(fpmhip_invalidate_binning(plan));                        /* the readouts below must bin THESE positions */
+    RUN(fpmhip_memset(plan, source, 0, bytes));                  /* pm_alloc'ed fresh, pm2lpt.c:40-48 */
+    for (int d = 0; d < 3; d++) {                                /* 1LPT, :62-87 */
+        RUN(fpmhip_laplace(plan, delta_k, workspace, potorder));
+        RUN(fpmhip_diff(plan, workspace, d, difforder));
+        TRY(lpt_c2r(L, workspace));
+        TRY(lpt_readout(L, workspace, part, dx1, d));
+    }
+    for (int d = 0; d < 3; d++) {                                /* diagonal terms, :90-96 */
+        RUN(fpmhip_laplace(plan, delta_k, field[d], potorder));
+        RUN(fpmhip_diff(plan, field[d], d, difforder));
+        RUN(fpmhip_diff(plan, field[d], d, difforder));
+        TRY(lpt_c2r(L, field[d]));
+    }
+    for (int d = 0; d < 3; d++)                                  /* :98-106 */
+        RUN(fpmhip_mesh_fma(plan, source, field[D1[d]], field[D2[d]], 0));
+    for (int d = 0; d < 3; d++) {                                /* off-diagonal, :108-121 */
+        RUN(fpmhip_laplace(plan, delta_k, workspace, potorder));
+        RUN(fpmhip_diff(plan, workspace, D1[d], difforder));
+        RUN(fpmhip_diff(plan, workspace, D2[d], difforder));
+        TRY(lpt_c2r(L, workspace));
+        RUN(fpmhip_mesh_fma(plan, source, workspace, workspace, 1));
+    }
+    TRY(lpt_r2c(L, source, workspace));                          /* :122-123 */
+    RUN(fpmhip_memcpy_d2d(plan, source, workspace, bytes));
+    for (int d = 0; d < 3; d++) {                                /* :125-141 */
+        RUN(fpmhip_laplace(plan, source, workspace, potorder));
+        RUN(fpmhip_diff(plan, workspace, d, difforder));
+        TRY(lpt_c2r(L, workspace));
+        RUN(fpmhip_mesh_scale(plan, workspace, 3.0 / 7));
+        TRY(lpt_readout(L, workspace, part, dx2, d));
+    }
+    RUN(fpmhip_invalidate_binning(plan));
+    return 0;
+}
+
+int fastpm_hip_mesh_2lpt_solve(fpmhip_plan *plan, const fastpm_hip_transport *t, const void *delta_k_dev, const double *x_dev,
+                               float *dx1_dev, float *dx2_dev, int64_t np, int type)
+{
+    if (!plan || !t || !delta_k_dev || np < 0 || (np > 0 && (!x_dev || !dx1_dev || !dx2_dev))) return -1;
+    fpmhip_layout lay;
+    TRY(fpmhip_plan_layout(plan, &lay));
+    if (lay.nranks != t->nranks || lay.rank != t->rank || lay.nranks < 2) return -1;
+    if (lay.nranks_x > 64 || lay.nranks_y > 64) return -1;
+    if (t->bind_plan) TRY(t->bind_plan(t->ctx, plan));
+    seq qs = {plan, t, 0, 0, 0}, *q = &qs;
+    {
+        const int made = fpmhip_plan_buffers_ready(plan, B_COUNT);                /* agreed on before the first exchange */
+        for (int b = 0; b < B_COUNT && made >= 0; b++)                            /* the plan's buffers are the workspace */
+            if (fpmhip_plan_buffer(plan, b) == delta_k_dev) return -1;
+        if (made != 0) {
+            double failed = made < 0;
+            if (t->allreduce_sum(t->ctx, &failed) != 0) return seq_abort(q, -1);
+            if (failed != 0) return made < 0 ? made : -8;
+        }
+    }
+    lpt_ctx L;
+    memset(&L, 0, sizeof(L));
+    L.q = q;
+    L.lay = lay;
+    L.pencil = lay.nranks_y > 1;
+    L.nr = plane_ranges(plan, t, lay.isize[0]) >= 1;            /* whole meshes: there is nothing to overlap a range with */
+    q->nb = L.nr >= 1 && t->msgs_begin && t->allreduce_begin;
+    L.g.Nx = lay.nranks_x; L.g.Ny = lay.nranks_y; L.g.rx = lay.rank_x; L.g.ry = lay.rank_y;
+    for (int j = 0; j < L.g.Ny; j++) L.g.row[j] = L.g.rx * L.g.Ny + j;
+    for (int i = 0; i < L.g.Nx; i++) L.g.col[i] = i * L.g.Ny + L.g.ry;
+    const size_t es = (size_t) lay.precision / 8;
+    L.plane_bytes = (size_t) lay.plane_elems * es;
+    L.a_bytes = (size_t) lay.chunk_a_elems * es;
+    L.b_bytes = (size_t) lay.chunk_b_elems * es;
+    L.wa = fpmhip_plan_buffer(plan, B_XCHG);
+    L.wb = fpmhip_plan_buffer(plan, B_XCHG2);
+    fpmhip_particles part;
+    memset(&part, 0, sizeof(part));
+    part.x = x_dev;
+    part.M0 = 1.0;
+    part.np = np;
+    part.acc = dx1_dev;                  /* not written: the readouts name their own column */
+    int rc = lpt_sequence(&L, delta_k_dev, &part, dx1_dev, dx2_dev, type);
+    if (q->aborted) return rc ? rc : -1;
+    if (rc == 0) rc = q->rc;
+    const int late = fpmhip_sync(plan);                          /* the one host wait; what only the device knew */
     if (rc == 0) rc = late;
     double failed = rc != 0;
     if (t->allreduce_sum(t->ctx, &failed) != 0) return seq_abort(q, rc ? rc : -1);

@@ -132,6 +132,12 @@ int fastpm_hip_slab_force(fpmhip_plan *plan, const fastpm_hip_transport *t, cons
  * t->alltoall_members -- what PFFT does on the reference's default Nproc, pmpfft.c:117-136). */
 int fastpm_hip_mesh_force_species(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *sets_dev,
                                   int nsets, int kernel, int softening, void *delta_k_dev);
+/* pm_2lpt_solve (pm2lpt.c:14-164; shift = 0, no scale-dependent growth) on ANY process mesh of the plan, NTask > 1 (round
+ * 6): dx1_dev / dx2_dev (float[np][3]) for the particles at x_dev -- each on the rank that owns its cell -- from the linear
+ * density delta_k_dev in the plan's k layout.  12 c2r + 1 r2c around their transposes, the mesh halo in front of each of
+ * the six readouts; the plan's seven mesh buffers are the workspace.  Event-ordered like the force step. */
+int fastpm_hip_mesh_2lpt_solve(fpmhip_plan *plan, const fastpm_hip_transport *t, const void *delta_k_dev, const double *x_dev,
+                               float *dx1_dev, float *dx2_dev, int64_t np, int type);
 /* ... with host-resident columns; delta_k_host as fastpm_hip_slab_force_host (slabs only: a pencil's k-space block is
  * [x][ky_loc][kz_loc] with a padded last kz block, see fpmhip_layout) */
 int fastpm_hip_mesh_force_species_host(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *sets_host,

@@ -197,6 +197,15 @@ fastpm_hip_current_transport(void)
     return current ? current->transport : NULL;         /* NULL on one rank */
 }
 
+const void *
+fastpm_hip_transport_for(PM * pm)
+{
+    PlanCache * was = current;
+    const void * t = plan_for(pm)->transport;
+    current = was;                                      /* kick / drift / wrap keep following the FORCE mesh */
+    return t;
+}
+
 void
 fastpm_kernel_type_get_orders(FastPMKernelType type,
     int *potorder,

@@ -931,3 +931,113 @@ def test_plain_c_program_prints_the_reference_lpt_lines(tmp_path, precision):
     table = os.path.join(ROOT, "tests", "golden", "reference_tests_powerspec.txt")
     r = subprocess.run([exe, table, "64", "512", "100", str(precision)], capture_output=True, text=True, check=True)
     assert r.stdout.splitlines() == ["dx1  : " + " ".join(R.CHECK["dx1"]), "dx2  : " + " ".join(R.CHECK["dx2"])]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,nprocy,precision,chunks", [(2, 1, 64, 0), (4, 1, 64, 1), (4, 2, 64, 0), (8, 2, 64, 0), (4, 2, 32, -1)])
+def test_mpi_ranks_print_the_reference_lpt_lines(P, nprocy, precision, chunks):
+    """`mpiexec -n P example_lpt_mpi` (round 6): pm_2lpt_solve for NTask > 1 in C99 -- fastpm_hip_mesh_2lpt_solve, the
+    reference's call order (pm2lpt.c:14-164) with its 12 c2r + 1 r2c split around the transposes and the mesh halo in front
+    of each of the six readouts -- on x slabs and 2 x 2 / 4 x 2 pencils, from seed 100 on every rank's own block of the field:
+    the "dx1  :" / "dx2  :" lines must BE the lines of tests/run-test-lightcone.check, whatever the decomposition."""
+    import subprocess
+    from oracle import reference_run as R
+    mpiexec = os.path.join(MPI_ROOT, "bin", "mpiexec")
+    if not (os.path.exists(mpiexec) and os.path.exists(os.path.join(MPI_ROOT, "include", "mpi.h"))):
+        pytest.skip("no MPI in this image")
+    host = os.path.join(ROOT, "fastpm_amd", "host")
+    subprocess.run(["make", "-C", host, "mpi", "MPI_INC=" + os.path.join(MPI_ROOT, "include"),
+                    "MPI_LIB=" + os.path.join(MPI_ROOT, "lib")], check=True, capture_output=True)
+    table = os.path.join(ROOT, "tests", "golden", "reference_tests_powerspec.txt")
+    nc = 64
+    r = subprocess.run([mpiexec, "-n", str(P), os.path.join(ROOT, "fastpm_amd", "example_lpt_mpi"), table, str(nc), "512",
+                        "100", str(precision), "0", str(nprocy), str(chunks)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, FASTPM_HIP_MPI_STAGED_RANGES="1" if chunks > 0 else "0"))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    out = r.stdout.splitlines()
+    assert out[:2] == ["dx1  : " + " ".join(R.CHECK["dx1"]), "dx2  : " + " ".join(R.CHECK["dx2"])], out
+    assert out[2].startswith("ranks %d process mesh %d x %d particles %d" % (P, P // nprocy, nprocy, nc ** 3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Nx,Ny,paint_mode", [(2, 1, 0), (4, 1, 3), (2, 2, 0), (2, 2, 3)])
+def test_c_host_2lpt_on_ranks_matches_the_one_rank_solve(Nx, Ny, paint_mode):
+    """fastpm_hip_mesh_2lpt_solve, one host thread per rank on the asynchronous in-process transport, against the ONE-rank
+    C sequence (fastpm_hip_2lpt_solve_dev, itself held to the reference's check lines): dx1 / dx2 of every particle; and the
+    host waits for the plan's stream ONCE in the call."""
+    import threading
+    import torch
+    from fastpm_amd import PM, lib
+    H = _host()
+    C = lib.load_library()
+    H.fastpm_hip_loopback_create.restype = ctypes.POINTER(Transport)
+    H.fastpm_hip_loopback_create.argtypes = [ctypes.c_int]
+    H.fastpm_hip_loopback_destroy.argtypes = [ctypes.POINTER(Transport)]
+    H.fastpm_hip_mesh_2lpt_solve.argtypes = [ctypes.c_void_p, ctypes.POINTER(Transport), ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]
+    H.fastpm_hip_2lpt_solve_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_int64, ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+    from fastpm_amd.pm import KERNEL_TYPES
+    N, L, P = 64, 512.0, Nx * Ny
+    g = np.arange(N) * (L / N)
+    q = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
+    table = np.loadtxt(os.path.join(ROOT, "tests", "golden", "reference_tests_powerspec.txt"))
+    kt, pt = np.ascontiguousarray(table[:, 0]), np.ascontiguousarray(table[:, 1])
+
+    def field(pm):
+        dk = pm.alloc()
+        dk.zero_()
+        assert C.fpmhip_ic_fill_gaussian(pm._plan, dk.data_ptr(), 100) == 0
+        assert C.fpmhip_ic_remove_variance(pm._plan, dk.data_ptr()) == 0
+        assert C.fpmhip_ic_induce_correlation(pm._plan, dk.data_ptr(), kt.ctypes.data, pt.ctypes.data, len(kt)) == 0
+        return dk
+
+    pm1 = PM(N, L, 64)
+    x1 = torch.from_numpy(q).cuda()
+    d1 = torch.zeros((len(q), 3), dtype=torch.float32, device="cuda")
+    d2 = torch.zeros_like(d1)
+    dk1 = field(pm1)
+    shift = (ctypes.c_double * 3)(0, 0, 0)
+    assert H.fastpm_hip_2lpt_solve_dev(pm1._plan, dk1.data_ptr(), x1.data_ptr(), d1.data_ptr(), d2.data_ptr(), len(q), shift,
+                                       KERNEL_TYPES["1_4"]) == 0
+    torch.cuda.synchronize()
+    ref1, ref2 = d1.cpu().numpy(), d2.cpu().numpy()
+    pm1.destroy()
+
+    cell = np.rint(q / (L / N)).astype(np.int64)
+    own = (cell[:, 0] // (N // Nx)) * Ny + cell[:, 1] // (N // Ny)
+    idx = [np.nonzero(own == r)[0] for r in range(P)]
+    pms = [PM(N, L, 64, nranks=P, rank=r, nranks_y=Ny, paint_mode=paint_mode) for r in range(P)]
+    dks = [field(pm) for pm in pms]
+    xs = [torch.from_numpy(q[idx[r]]).cuda() for r in range(P)]
+    o1 = [torch.zeros((len(idx[r]), 3), dtype=torch.float32, device="cuda") for r in range(P)]
+    o2 = [torch.zeros_like(o) for o in o1]
+    torch.cuda.synchronize()
+    for call in range(2):
+        tr = H.fastpm_hip_loopback_create(P)
+        rcs = [None] * P
+        before = [C.fpmhip_plan_sync_count(pm._plan) for pm in pms]
+
+        def rank_main(r):
+            torch.cuda.set_device(0)
+            rcs[r] = H.fastpm_hip_mesh_2lpt_solve(pms[r]._plan, ctypes.byref(tr[r]), dks[r].data_ptr(), xs[r].data_ptr(),
+                                                  o1[r].data_ptr(), o2[r].data_ptr(), len(idx[r]), KERNEL_TYPES["1_4"])
+
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=180)
+        assert all(not t.is_alive() for t in threads), "a rank hung"
+        torch.cuda.synchronize()
+        assert rcs == [0] * P, (rcs, fastpm_last_error())
+        H.fastpm_hip_loopback_destroy(tr)
+        if call == 1:
+            assert [C.fpmhip_plan_sync_count(pm._plan) - b for pm, b in zip(pms, before)] == [1] * P
+        got1, got2 = np.zeros_like(ref1), np.zeros_like(ref2)
+        for r in range(P):
+            got1[idx[r]] = o1[r].cpu().numpy()
+            got2[idx[r]] = o2[r].cpu().numpy()
+        assert util.rel_err(got1, ref1) <= 1e-6 and util.rel_err(got2, ref2) <= 1e-6
+    for pm in pms:
+        pm.destroy()
