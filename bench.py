@@ -407,10 +407,16 @@ def c_dropin_leg(world, nc, Nmesh, args, share_gpu):
     if not os.path.exists(exe):
         return {"error": "fastpm_amd/bench_slab_mpi is not built (make -C fastpm_amd/host mpi; __graft_entry__.build())"}
     cmd = [mpiexec, "-n", str(world), exe, str(nc), str(Nmesh), str(args.precision), "0" if share_gpu else "2",
-           str(args.nprocy), "0,1,-1", str(args.steps), str(args.warmup), "1" if share_gpu else "0", str(args.paint_mode)]
+           str(args.nprocy), "0,1,-1", str(args.steps), str(args.warmup), "1" if share_gpu else "0", str(args.paint_mode),
+           "1" if args.wire == "f32" else "0"]
+    if share_gpu and args.wire == "f32":
+        env_ranges = {"FASTPM_HIP_MPI_STAGED_RANGES": "1"}      # (staged MPI declares no_overlap: the wire wraps the non-blocking pair)
+    else:
+        env_ranges = {}
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(env_ranges)
     t0 = time.perf_counter()
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500)
@@ -652,8 +658,8 @@ def main():
         torch.cuda.synchronize()
         dist.barrier(group=host_group)
         if rank == 0:
-            if args.gradient != "kspace" or args.load != "a" or args.fft_mode != 0 or args.wire != "mesh":
-                c_leg = {"error": "not run: the C leg times the default sequence (k-space gradient, load A, own FFT passes, mesh-dtype wire)"}
+            if args.gradient != "kspace" or args.load != "a" or args.fft_mode != 0:
+                c_leg = {"error": "not run: the C leg times the default sequence (k-space gradient, load A, own FFT passes)"}
             else:
                 c_leg = c_dropin_leg(world, nc, Nmesh, args, bool(os.environ.get("FPM_BENCH_SHARE_GPU")))
         dist.barrier(group=host_group)

@@ -351,6 +351,22 @@ static double sinc_unnormed(double x)   // transfer.c:67-74
 // bytes of this rank's ORegion in the reference layout: [y_loc][kz_loc valid][x]
 static size_t ref_bytes(const fpmhip_plan *p) { return (size_t) 2 * p->mg.N * p->mg.yl * p->lay.ovalid_z * p->esize; }
 
+// ---- a float32 WIRE FORMAT for the transposes of an fp64 mesh (round 6, the C twin of distributed.py's `wire`): the pieces
+// an exchange is about to send are narrowed into a float buffer at the SAME element positions (offsets in elements do not
+// change, bytes halve), cross xGMI as float32 and are widened on arrival.  One thread per element, grid-stride.
+template <typename TO, typename FROM>
+__global__ __launch_bounds__(256) void convert_pieces_kernel(TO *__restrict__ dst, const FROM *__restrict__ src, long long chunk,
+                                                             long long first, long long piece, long long stride, int npieces,
+                                                             int nchunks)
+{
+    const long long per = piece * npieces, total = per * nchunks;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long) gridDim.x * blockDim.x) {
+        const long long c = i / per, r = i - c * per, k = r / piece, e = r - k * piece;
+        const long long at = c * chunk + first + k * stride + e;
+        dst[at] = (TO) src[at];
+    }
+}
+
 template <bool TO_REF>
 static int reference_layout(fpmhip_plan *p, void *ours, void *ref)
 {
@@ -437,6 +453,18 @@ int fpmhip_mesh_scale(fpmhip_plan *p, void *buf, double value)
     if (value < 0 && !p->mg.dtotal) FPM_FAIL(-1, "FPMHIP_SCALE_FROM_DEVICE without fpmhip_plan_scale_from_device");
     if (p->f64) mesh_scale_kernel<double><<<2048, 256, 0, p->stream>>>((double *) buf, n, value, p->mg.dtotal, p->mg.dnorm);
     else mesh_scale_kernel<float><<<2048, 256, 0, p->stream>>>((float *) buf, n, value, p->mg.dtotal, p->mg.dnorm);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int fpmhip_convert_pieces(fpmhip_plan *p, void *dst, const void *src, int64_t chunk_elems, int64_t first_elems,
+                                     int64_t piece_elems, int64_t stride_elems, int npieces, int nchunks, int to_f32)
+{
+    if (!p || !dst || !src || npieces < 1 || nchunks < 1 || piece_elems < 1) FPM_FAIL(-1, "bad argument");
+    const long long total = (long long) piece_elems * npieces * nchunks;
+    const unsigned blocks = (unsigned) std::min<long long>((total + 255) / 256, 8192);
+    if (to_f32) convert_pieces_kernel<float, double><<<blocks, 256, 0, p->stream>>>((float *) dst, (const double *) src, chunk_elems, first_elems, piece_elems, stride_elems, npieces, nchunks);
+    else convert_pieces_kernel<double, float><<<blocks, 256, 0, p->stream>>>((double *) dst, (const float *) src, chunk_elems, first_elems, piece_elems, stride_elems, npieces, nchunks);
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -150,6 +150,13 @@ int fastpm_hip_mesh_force_species_host(fpmhip_plan *plan, const fastpm_hip_trans
 int fastpm_hip_slab_force_host(fpmhip_plan *plan, const fastpm_hip_transport *t, const fpmhip_particles *p_host,
                                int kernel, int softening, void *delta_k_host);
 
+/* ---- a float32 WIRE FORMAT for the transposes of an fp64 mesh (fastpm_wire_hip.c, round 6): a transport that wraps
+ * `inner` (which must offer xchg_begin / xchg_wait and outlive the wrapper) -- the pieces of every transpose are narrowed to
+ * float32 on the way out and widened on arrival, half the bytes on xGMI, the mesh stays fp64 in HBM; halo planes / rows and
+ * scalars pass through unchanged.  Set `chunks` on the wrapper.  NULL when inner has no non-blocking pair. ---- */
+fastpm_hip_transport *fastpm_hip_wire_f32_create(const fastpm_hip_transport *inner);
+void fastpm_hip_wire_f32_destroy(fastpm_hip_transport *wrapper);
+
 /* ---- in-process loopback transport: all ranks are threads of ONE process (tests; a single-GPU dry run of a
  * multi-rank configuration).  create returns an array of nranks transports sharing one barrier. ---- */
 fastpm_hip_transport *fastpm_hip_loopback_create(int nranks);

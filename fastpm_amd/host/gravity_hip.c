@@ -162,6 +162,24 @@ plan_for(PM * pm)
             c->transport = fastpm_hip_mpi_transport_create(pm->Comm2D, c->plan, mode);
         }
         if(!c->transport) fastpm_raise(-1, "no transport for the MI355X force step\n");
+        {
+            /* FASTPM_HIP_WIRE=f32 (off by default): the transposes of an fp64 mesh cross the wire as float32, half the bytes
+             * (fastpm_wire_hip.c; acc within ~1e-7 of max |acc| of the full-width run).  Every rank or none. */
+            const char * w = getenv("FASTPM_HIP_WIRE");
+            int narrow = w && !strcmp(w, "f32") && sizeof(FastPMFloat) == 8;
+            MPI_Allreduce(MPI_IN_PLACE, &narrow, 1, MPI_INT, MPI_MIN, pm->Comm2D);
+            if(narrow) {
+                fastpm_hip_transport * wrapped = fastpm_hip_wire_f32_create(c->transport);
+                int ok = wrapped != NULL;
+                MPI_Allreduce(MPI_IN_PLACE, &ok, 1, MPI_INT, MPI_MIN, pm->Comm2D);
+                if(ok) {
+                    c->transport = wrapped;
+                    fastpm_info("MI355X force step: float32 wire format for the transposes of the fp64 mesh\n");
+                } else if(wrapped) {
+                    fastpm_hip_wire_f32_destroy(wrapped);
+                }
+            }
+        }
         fastpm_info("MI355X force step: %d ranks, %s transport, %d visible GPU(s) for %d rank(s) of this node, %s\n", pm->NTask,
                 mode == 2 ? "RCCL (xGMI)" : mode == 1 ? "GPU-aware MPI" : "host-staged MPI", ndev, node_size,
                 own_gpu ? "every rank on a GPU of its own" : "ranks share a GPU");

@@ -227,6 +227,11 @@ int fpmhip_total_mass(fpmhip_plan *plan, const fpmhip_particles *p_dev, double *
 double *fpmhip_plan_scalars(fpmhip_plan *plan);
 int fpmhip_total_mass_dev(fpmhip_plan *plan, const fpmhip_particles *sets_dev, int nsets, double *out_dev);
 int fpmhip_plan_scale_from_device(fpmhip_plan *plan, const double *total_dev);
+/* The pieces of an exchange ([first + k * stride, + piece), k < npieces, of each of nchunks chunks `chunk_elems` apart;
+ * all in mesh ELEMENTS) converted between double and float at the same element positions, on the plan's stream: the
+ * float32 wire format of fastpm_amd/host/fastpm_wire_hip.c (to_f32 != 0: dst float <- src double; 0: dst double <- src float) */
+int fpmhip_convert_pieces(fpmhip_plan *plan, void *dst_dev, const void *src_dev, int64_t chunk_elems, int64_t first_elems,
+                          int64_t piece_elems, int64_t stride_elems, int npieces, int nchunks, int to_f32);
 /* out_dev[j] = sum over r < nrows of rows_dev[r * n + j], in row order, on `stream` (a transport's device all-reduce) */
 int fpmhip_sum_rows_on(void *stream, double *out_dev, const double *rows_dev, int nrows, int n);
 /* The readout reuses the tile binning of the last paint when (x, np) are unchanged; call this if the positions behind

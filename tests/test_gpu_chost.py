@@ -661,6 +661,77 @@ def test_a_rank_that_fails_between_two_exchanges_releases_its_peers(Nx, Ny, pain
         pm.destroy()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("Nx,Ny,paint_mode,chunks", [(4, 1, 3, 4), (2, 1, 0, 1), (2, 2, 3, 2), (4, 2, 0, 2)])
+def test_c_host_float32_wire_for_the_transposes(oracle, Nx, Ny, paint_mode, chunks):
+    """fastpm_hip_wire_f32_create (fastpm_wire_hip.c, round 6): the wrapper transport narrows the pieces of every transpose of
+    an fp64 mesh to float32 on the way out and widens them on arrival -- half the bytes on the wire, the mesh fp64 in HBM.
+    Against the full-width run of the same sequence: the accelerations differ (the rounding of a float32 mesh at the
+    transposes) by less than 5e-6 of max |acc|, and stay within the fp32-mesh class of the one-rank oracle; the host still
+    waits once per call."""
+    import threading
+    import torch
+    from fastpm_amd import PM, Store, lib
+    from fastpm_amd.pm import KERNEL_TYPES
+    H = _host()
+    C = lib.load_library()
+    H.fastpm_hip_loopback_create.restype = ctypes.POINTER(Transport)
+    H.fastpm_hip_loopback_create.argtypes = [ctypes.c_int]
+    H.fastpm_hip_loopback_destroy.argtypes = [ctypes.POINTER(Transport)]
+    H.fastpm_hip_wire_f32_create.restype = ctypes.POINTER(Transport)
+    H.fastpm_hip_wire_f32_create.argtypes = [ctypes.POINTER(Transport)]
+    H.fastpm_hip_wire_f32_destroy.argtypes = [ctypes.POINTER(Transport)]
+    H.fastpm_hip_mesh_force_species.argtypes = [ctypes.c_void_p, ctypes.POINTER(Transport), ctypes.c_void_p, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    N, nc, L, P = 64, 32, 96.0, Nx * Ny
+    x = util.load_b(nc, L, N)
+    ref = oracle.compute_force(oracle.PMOracle(N, L, 64), x)
+    h = L / N
+    own = ((np.floor(x[:, 0] / h).astype(np.int64) % N) // (N // Nx)) * Ny + (np.floor(x[:, 1] / h).astype(np.int64) % N) // (N // Ny)
+    idx = [np.nonzero(own == r)[0] for r in range(P)]
+    pms = [PM(N, L, 64, nranks=P, rank=r, nranks_y=Ny, paint_mode=paint_mode) for r in range(P)]
+    stores = [Store(x[idx[r]]) for r in range(P)]
+    out = {}
+    for wire in (0, 1, 1):
+        tr = H.fastpm_hip_loopback_create(P)
+        wr = [H.fastpm_hip_wire_f32_create(ctypes.byref(tr[r])) if wire else None for r in range(P)]
+        assert not wire or all(bool(w) for w in wr)
+        rcs = [None] * P
+        before = [C.fpmhip_plan_sync_count(pm._plan) for pm in pms]
+
+        def rank_main(r):
+            torch.cuda.set_device(0)
+            t = wr[r] if wire else ctypes.pointer(tr[r])
+            t.contents.chunks = chunks
+            part = stores[r]._c()
+            rcs[r] = H.fastpm_hip_mesh_force_species(pms[r]._plan, t, ctypes.byref(part), 1, KERNEL_TYPES["1_4"], 0, None)
+
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+        assert all(not t.is_alive() for t in threads), "a rank hung"
+        torch.cuda.synchronize()
+        assert rcs == [0] * P, (rcs, fastpm_last_error())
+        counts = [C.fpmhip_plan_sync_count(pm._plan) - b for pm, b in zip(pms, before)]
+        if wire:
+            for w in wr:
+                H.fastpm_hip_wire_f32_destroy(w)          # (waits for the plan's stream before it frees the staging)
+        H.fastpm_hip_loopback_destroy(tr)
+        acc = np.zeros_like(ref["acc"])
+        for r in range(P):
+            acc[idx[r]] = stores[r].acc.cpu().numpy()
+        out[wire] = acc
+    assert counts == [1] * P, counts                     # (the second narrow call: steady state)
+    assert util.rel_err(out[0], ref["acc"]) <= 1e-6
+    dev = np.abs(out[1] - out[0]).max() / np.abs(out[0]).max()
+    assert 0 < dev < 5e-6, dev
+    assert util.rel_err(out[1], ref["acc"]) <= 2e-5
+    for pm in pms:
+        pm.destroy()
+
+
 def fastpm_last_error():
     from fastpm_amd import lib
     return lib.load_library().fpmhip_last_error()
