@@ -121,7 +121,7 @@ STAGES_OF_KERNELS = {"k_colfft": "r2c/c2r", "k_rowfft": "r2c", "k_zc2r": "c2r", 
 
 
 
-PMC_PROFILE_TAG = "r05"          # profiles/<tag>_<gradient>_traffic.json: the committed PMC passes of this round
+PMC_PROFILE_TAG = "r06"          # profiles/<tag>_<gradient>_traffic.json: the committed PMC passes of this round
 
 
 def workload_label(nc, Nmesh, precision, world, own_fft):
