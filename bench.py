@@ -408,7 +408,7 @@ def c_dropin_leg(world, nc, Nmesh, args, share_gpu):
         return {"error": "fastpm_amd/bench_slab_mpi is not built (make -C fastpm_amd/host mpi; __graft_entry__.build())"}
     cmd = [mpiexec, "-n", str(world), exe, str(nc), str(Nmesh), str(args.precision), "0" if share_gpu else "2",
            str(args.nprocy), "0,1,-1", str(args.steps), str(args.warmup), "1" if share_gpu else "0", str(args.paint_mode),
-           "1" if args.wire == "f32" else "0"]
+           "1" if args.wire == "f32" else "0", "2" if args.gradient == "xstencil" else "0"]
     if share_gpu and args.wire == "f32":
         env_ranges = {"FASTPM_HIP_MPI_STAGED_RANGES": "1"}      # (staged MPI declares no_overlap: the wire wraps the non-blocking pair)
     else:
@@ -476,9 +476,11 @@ def main():
     ap.add_argument("--fft-mode", type=int, default=0, help="0 auto (hand-written row and column passes), 1 rocFFT only")
     ap.add_argument("--load", default="a", choices=["a", "b", "c"],
                     help="a: lattice + 0.3-cell jitter (default); b: clustered (rms 4 cells); c: adversarial (1 GPU only)")
-    ap.add_argument("--gradient", default="kspace", choices=["kspace", "real"],
+    ap.add_argument("--gradient", default="kspace", choices=["kspace", "real", "xstencil"],
                     help="kspace (default): the reference's arithmetic, 3 inverse FFTs; real: FPMHIP_GRADIENT_REAL, "
-                         "1 inverse FFT of the potential + stencil readout (acc within 2e-7 max|acc| of kspace)")
+                         "1 inverse FFT of the potential + stencil readout (acc within 2e-7 max|acc| of kspace); xstencil: "
+                         "FPMHIP_GRADIENT_XSTENCIL, y and z as kspace, x from the potential's rows by the plane stencil -- two "
+                         "transposes per force on slabs (N > 1: the C leg runs it, the Python mirror stays on kspace)")
     ap.add_argument("--no-alt", action="store_true", help="(accepted for old command lines; the extra leg is off by default)")
     ap.add_argument("--alt", action="store_true",
                     help="also time the OTHER gradient mode (FPMHIP_GRADIENT_REAL: not the reference's arithmetic, outside "
@@ -510,8 +512,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.nprocy > 1 and (world % args.nprocy != 0 or args.gradient == "real"):
-        raise SystemExit("--nprocy must divide the number of GPUs; the real-space gradient is a slab mode")
+    if args.nprocy > 1 and (world % args.nprocy != 0 or args.gradient != "kspace"):
+        raise SystemExit("--nprocy must divide the number of GPUs; the real-space and x-stencil gradients are slab modes")
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
@@ -574,7 +576,8 @@ def main():
     def timed_run(gradient):
         """W untimed + K timed force calls in one gradient mode; max over ranks of the wall time."""
         pm = PM(Nmesh, BoxSize, precision=args.precision, nranks=world, rank=rank, np_max=np_local,
-                paint_mode=args.paint_mode, fft_mode=args.fft_mode, gradient_mode=1 if gradient == "real" else 0,
+                paint_mode=args.paint_mode, fft_mode=args.fft_mode,
+                gradient_mode={"kspace": 0, "real": 1, "xstencil": 2 if world == 1 else 0}[gradient],
                 nranks_y=args.nprocy if world > 1 else 1)
         store = Store(x, device=device)
         # ... and the same particles a moment later: each one displaced by a seeded Gaussian of 0.05 cell, clamped so that
@@ -658,7 +661,7 @@ def main():
         torch.cuda.synchronize()
         dist.barrier(group=host_group)
         if rank == 0:
-            if args.gradient != "kspace" or args.load != "a" or args.fft_mode != 0:
+            if args.gradient == "real" or args.load != "a" or args.fft_mode != 0:
                 c_leg = {"error": "not run: the C leg times the default sequence (k-space gradient, load A, own FFT passes)"}
             else:
                 c_leg = c_dropin_leg(world, nc, Nmesh, args, bool(os.environ.get("FPM_BENCH_SHARE_GPU")))
@@ -669,7 +672,7 @@ def main():
     alt = None
     if args.alt and not args.no_alt:
         try:
-            other = "real" if args.gradient == "kspace" else "kspace"
+            other = "real" if args.gradient != "real" else "kspace"
             pm2, store2, dt2, tm2 = timed_run(other)
             dev = torch.stack([(store2.acc - store.acc).abs().max(), store.acc.abs().max()]).to(torch.float64)
             if world > 1:
@@ -683,7 +686,7 @@ def main():
             del store2
             pm2.destroy()
         except Exception as e:        # the extra leg never takes the headline number down with it
-            alt = {"gradient": "real" if args.gradient == "kspace" else "kspace", "error": repr(e)}
+            alt = {"gradient": "real" if args.gradient != "real" else "kspace", "error": repr(e)}
 
     # secondary legs, outside the timed region and never part of `value` (N = 1 only):
     #   host_columns: fpmhip_force_host, the call an UNMODIFIED libfastpm makes (store columns in host memory: x goes up
@@ -721,7 +724,7 @@ def main():
             if (nc, Nmesh) != (nc2, N2) and torch.cuda.mem_get_info()[0] > 60e9:
                 x2 = make_particles(nc2, N2, 3.0 * nc2, 1, 0, device)
                 pm2 = PM(N2, 3.0 * nc2, precision=args.precision, np_max=x2.shape[0],
-                         gradient_mode=1 if args.gradient == "real" else 0)
+                         gradient_mode={"kspace": 0, "real": 1, "xstencil": 2}[args.gradient])
                 st2 = Store(x2, device=device)
                 x2_np, pm2_strips = int(x2.shape[0]), bool(pm2.strips())
                 dk2 = pm2.alloc()
@@ -737,7 +740,7 @@ def main():
                 t2 = (time.perf_counter() - t0) / 3
                 tm2b = pm2.timings()
                 ab2 = algorithmic_bytes(x2_np, N2, 1, esize, args.gradient)
-                b2 = 60 * x2_np + (12 if args.gradient == "kspace" else 6) * esize * N2 * N2 * (N2 + 2)
+                b2 = 60 * x2_np + (6 if args.gradient == "real" else 12) * esize * N2 * N2 * (N2 + 2)
                 secondary["mesh1024"] = {
                     "workload": workload_label(nc2, N2, args.precision, 1, pm2.column_fft()), "ms_per_step": round(t2 * 1e3, 3),
                     "value": nc2 ** 3 / t2, "unit": "particle-updates/s", "step_frac": round(b2 / t2 / 1e9 / HBM_PEAK_GBS, 4),
@@ -867,7 +870,7 @@ def main():
         roofline["kernels"] = per_kernel
         # 60 B per particle + 12 mesh sweeps (paint 1, r2c 2, 3 x (transfer 2 + readout 1)); the
         # real-space gradient needs 6 (paint 1, r2c 2, potential transfer + c2r 2, readout 1)
-        b_alg = 60 * np_local + (12 if args.gradient == "kspace" else 6) * esize * (Nmesh * Nmesh * (Nmesh + 2) // world)
+        b_alg = 60 * np_local + (6 if args.gradient == "real" else 12) * esize * (Nmesh * Nmesh * (Nmesh + 2) // world)
         out = {
             "metric": "particle-updates/sec (PM force step)", "value": value, "unit": "particle-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -886,7 +889,9 @@ def main():
                 "decomposition": ("slab %dx1" % world) if args.nprocy <= 1 or world == 1 else
                                  ("pencil %dx%d" % (world // args.nprocy, args.nprocy)),
                 "gradient": {"kspace": "k space, 3 inverse FFTs (the reference's arithmetic)",
-                             "real": "real space, 1 inverse FFT + stencil readout (FPMHIP_GRADIENT_REAL)"}[args.gradient],
+                             "real": "real space, 1 inverse FFT + stencil readout (FPMHIP_GRADIENT_REAL)",
+                             "xstencil": "y, z in k space, x by the plane stencil on the potential's rows (FPMHIP_GRADIENT_XSTENCIL)"
+                                         + ("" if world == 1 else ": the C leg; the Python mirror ran the k-space mode")}[args.gradient],
                 "paint_mode": ("strip tiles: paint + z r2c pass and z c2r pass + readout in one kernel each" if strips
                                else {0: "box tiles", 1: "atomic", 2: "box tiles"}.get(args.paint_mode, str(args.paint_mode))),
                 "fft": "hand-written row + column passes" if pm.column_fft() else "rocFFT",

@@ -206,6 +206,24 @@ static int force_species_body(fpmhip_plan *p, const fpmhip_particles *sets, int 
     // the canvas is free again after the out-of-place r2c: it carries the x component
     void *f[3] = {canvas, p->buf[BUF_F1], p->buf[BUF_F2]};
     static const int three = getenv("FPMHIP_XBACK3") ? atoi(getenv("FPMHIP_XBACK3")) : 0;   // A/B
+    if (p->geom.gradient_mode == FPMHIP_GRADIENT_XSTENCIL && strips && p->own_fft && go == 1) {
+        // FPMHIP_GRADIENT_XSTENCIL (fastpm_hip.h): ONE mesh through the backward x pass -- the potential --; its y pass makes
+        // the y and z components and passes the potential on; the x component's rows are the plane stencil of the
+        // potential's (fpmhip_xstencil_rows).  One rank: the same 15 sweeps as the default; it exists for the slabs.
+        FPM_TRY(ensure_buffer(p, BUF_F0));
+        void *phi = p->buf[BUF_F0];
+        if (fuse_x) FPM_TRY(fwd_x(1, f[1], nullptr, nullptr));
+        else FPM_TRY(fpmhip_transfer_fft_x_backward_pot(p, delta_k, f[1], kernel));
+        FPM_TRY(strips_y_backward_grad2(p, f[1], f[1], f[2], phi, go));
+        FPM_TRY(fpmhip_xstencil_rows(p, phi, nullptr, f[0]));
+        FPM_TRY(check_meshes(f[0], f[1], f[2]));
+        for (int si = nsets - 1; si >= 0; si--)
+            FPM_TRY(readout_strips_zc2r(p, &sets[si], f[0], f[1], f[2], 3, sets[si].acc, 3, 0));
+        for (int si = 0; si < nsets; si++)                                                // gravity.c:487-492
+            if (sets[si].potential)
+                FPM_TRY(readout_strips_zc2r(p, &sets[si], phi, nullptr, nullptr, 1, sets[si].potential, 1, 0));
+        return 0;
+    }
     if (p->own_fft && go == 1 && !three) {
         // one sweep over delta_k: the x component and the potential through their x passes; the y and
         // z gradient factors are applied to the potential in its y pass (they do not depend on kx)

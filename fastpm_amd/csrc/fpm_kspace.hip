@@ -367,6 +367,42 @@ __global__ __launch_bounds__(256) void convert_pieces_kernel(TO *__restrict__ ds
     }
 }
 
+// ---- FPMHIP_GRADIENT_XSTENCIL (round 6): the x component of the force as the 4-point central difference ACROSS x PLANES of the
+// potential's half-spectrum rows, (8 (phi[p+1] - phi[p-1]) - (phi[p+2] - phi[p-2])) / (12 h): the real-space twin of
+// i k_finite(kx) (pmapi.c:252-262); the stencil along x commutes with the z pass still to come.  A thread owns one complex
+// value of a plane and marches along x with the five planes of its window in registers: every plane is read once per
+// segment (+ 4 planes of prologue per XS_SEG) and the output written once.  Slabs: the planes -2, -1, xl+1, xl+2 come
+// from `halo` ([4][plane]); plane xl (the neighbour's plane 0) sits in the mesh's halo slot.
+constexpr int XS_SEG = 32;
+template <typename F>
+__global__ __launch_bounds__(256) void xstencil_rows_kernel(MeshGeo g, const Cplx<F> *__restrict__ phi, const Cplx<F> *__restrict__ halo,
+                                                            Cplx<F> *__restrict__ out, long long plane, int nplanes_out)
+{
+    const long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= plane) return;
+    const int xa = blockIdx.y * XS_SEG, xb = min(xa + XS_SEG, nplanes_out);
+    auto at = [&](int q) -> Cplx<F> {
+        if (g.periodic_x) {
+            q += q < 0 ? g.N : 0;
+            q -= q >= g.N ? g.N : 0;
+            return phi[(long long) q * plane + e];
+        }
+        if (q < 0) return halo[(long long) (q + 2) * plane + e];
+        if (q > g.xl) return halo[(long long) (q - g.xl + 1) * plane + e];
+        return phi[(long long) q * plane + e];
+    };
+    const double c1 = (2.0 / 3.0) * g.inv_cell, c2 = -g.inv_cell / 12.0;
+    Cplx<F> m2 = at(xa - 2), m1 = at(xa - 1), c0 = at(xa), p1 = at(xa + 1);
+    for (int x = xa; x < xb; x++) {
+        const Cplx<F> p2 = at(x + 2);
+        Cplx<F> r;
+        r.re = (F) (c1 * ((double) p1.re - (double) m1.re) + c2 * ((double) p2.re - (double) m2.re));
+        r.im = (F) (c1 * ((double) p1.im - (double) m1.im) + c2 * ((double) p2.im - (double) m2.im));
+        out[(long long) x * plane + e] = r;
+        m2 = m1; m1 = c0; c0 = p1; p1 = p2;
+    }
+}
+
 template <bool TO_REF>
 static int reference_layout(fpmhip_plan *p, void *ours, void *ref)
 {
@@ -453,6 +489,22 @@ int fpmhip_mesh_scale(fpmhip_plan *p, void *buf, double value)
     if (value < 0 && !p->mg.dtotal) FPM_FAIL(-1, "FPMHIP_SCALE_FROM_DEVICE without fpmhip_plan_scale_from_device");
     if (p->f64) mesh_scale_kernel<double><<<2048, 256, 0, p->stream>>>((double *) buf, n, value, p->mg.dtotal, p->mg.dnorm);
     else mesh_scale_kernel<float><<<2048, 256, 0, p->stream>>>((float *) buf, n, value, p->mg.dtotal, p->mg.dnorm);
+    FPM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int fpmhip_xstencil_rows(fpmhip_plan *p, const void *phi_rows, const void *halo4, void *fx_rows)
+{
+    if (!p || !phi_rows || !fx_rows || phi_rows == fx_rows) FPM_FAIL(-1, "null argument, or in place");
+    const MeshGeo &g = p->mg;
+    if (!g.periodic_y) FPM_FAIL(-1, "fpmhip_xstencil_rows: one rank or x slabs");
+    if (!g.periodic_x && (!halo4 || g.xl < 3)) FPM_FAIL(-1, "fpmhip_xstencil_rows on a slab: the four halo planes, and at least three planes per rank");
+    const long long plane = (long long) g.yplanes * g.rp;             // complex values per plane of half-spectrum rows
+    const int nout = g.xplanes;                                        // the slab's halo plane xl is made here too
+    StageTimer tm(p, FPMHIP_T_C2R);
+    dim3 grid((unsigned) ((plane + 255) / 256), (unsigned) ((nout + XS_SEG - 1) / XS_SEG));
+    if (p->f64) xstencil_rows_kernel<double><<<grid, 256, 0, p->stream>>>(g, (const Cplx<double> *) phi_rows, (const Cplx<double> *) halo4, (Cplx<double> *) fx_rows, plane, nout);
+    else xstencil_rows_kernel<float><<<grid, 256, 0, p->stream>>>(g, (const Cplx<float> *) phi_rows, (const Cplx<float> *) halo4, (Cplx<float> *) fx_rows, plane, nout);
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }

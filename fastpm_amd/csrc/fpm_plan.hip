@@ -344,7 +344,13 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
         const bool pen_ok = Ny == 1 || (!pen_off && ((N & (N - 1)) == 0 || N == 3072) && ylr % STRIP_Y == 0 && zblk >= N / 16 &&
                                         pen_span < (N >= 2048 ? (1ll << 32) * 2 * (long long) p->esize : (1ll << 32)));
         const bool can = pen_ok && geom->fft_mode == FPMHIP_FFT_AUTO && colfft_supported((int) N) &&
-                         strips_supported((int) N, geom->precision) && geom->gradient_mode == FPMHIP_GRADIENT_KSPACE;
+                         strips_supported((int) N, geom->precision) && geom->gradient_mode != FPMHIP_GRADIENT_REAL;
+        // FPMHIP_GRADIENT_XSTENCIL works on the half-spectrum rows of the strip path: one rank or x slabs of >= 3 planes
+        if (geom->gradient_mode == FPMHIP_GRADIENT_XSTENCIL &&
+            !(can && Ny == 1 && (Nx == 1 || xl >= 3) && N >= 16 && !env_off &&
+              (geom->paint_mode == FPMHIP_PAINT_STRIPS || (geom->paint_mode == FPMHIP_PAINT_TILED && N >= 192))))
+            FPM_FAIL(-1, "FPMHIP_GRADIENT_XSTENCIL: a strip plan (Nmesh >= 192, or FPMHIP_PAINT_STRIPS) on one rank or x slabs "
+                         "(got Nmesh = %lld, %d x %d ranks, paint_mode %d)", (long long) N, Nx, Ny, geom->paint_mode);
         if (geom->paint_mode == FPMHIP_PAINT_STRIPS && !can)
             FPM_FAIL(-1, "FPMHIP_PAINT_STRIPS: the k-space gradient, a mesh whose z rows fit the strip kernels and (pencils) local rows in whole strips");
         // (from Nmesh = 192: 0.51 -> 0.44 ms per force there, 0.89 -> 0.70 at 256^3 -- configs[0]'s mesh --; at 160 the two tie, at

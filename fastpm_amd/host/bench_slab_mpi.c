@@ -7,7 +7,7 @@
  * (grouped ncclSend / ncclRecv over xGMI; the PFFT transposes pmpfft.c:377-396, MPI_Alltoallv_sparse pmpfft.c:490-604 and
  * the ghost exchange pmghosts.c:203-307 are what these exchanges replace).
  *
- *   mpiexec -n P ./bench_slab_mpi nc Nmesh precision transport nprocy chunks steps warmup [share_gpu] [paint_mode] [wire_f32]
+ *   mpiexec -n P ./bench_slab_mpi nc Nmesh precision transport nprocy chunks steps warmup [share_gpu] [paint_mode] [wire_f32] [gradient_mode]
  *
  * transport: 2 = RCCL (one rank per GPU; the measured configuration), 1 = GPU-aware MPI, 0 = MPI staged through the host
  * (the dry run of the code path on a one-GPU box: share_gpu = 1 puts every rank on device 0 -- never a measurement).
@@ -80,7 +80,7 @@ int main(int argc, char **argv)
     MPI_Comm_rank(MPI_COMM_WORLD, &rank);
     MPI_Comm_size(MPI_COMM_WORLD, &P);
     if (argc < 9) {
-        if (rank == 0) fprintf(stderr, "usage: bench_slab_mpi nc Nmesh precision transport nprocy chunks steps warmup [share_gpu] [paint_mode] [wire_f32]\n");
+        if (rank == 0) fprintf(stderr, "usage: bench_slab_mpi nc Nmesh precision transport nprocy chunks steps warmup [share_gpu] [paint_mode] [wire_f32] [gradient_mode]\n");
         MPI_Abort(MPI_COMM_WORLD, 2);
     }
     const int nc = atoi(argv[1]), Nmesh = atoi(argv[2]), precision = atoi(argv[3]), transport = atoi(argv[4]);
@@ -97,6 +97,7 @@ int main(int argc, char **argv)
     const int share_gpu = argc > 9 ? atoi(argv[9]) : 0;
     const int paint_mode = argc > 10 ? atoi(argv[10]) : 0;      /* FPMHIP_PAINT_*: 3 = strip tiles on a small mesh */
     const int wire_f32 = argc > 11 ? atoi(argv[11]) : 0;        /* 1: the transposes of an fp64 mesh as float32 (fastpm_wire_hip.c) */
+    const int gradient_mode = argc > 12 ? atoi(argv[12]) : 0;   /* FPMHIP_GRADIENT_*: 2 = XSTENCIL, two transposes per force */
     const int nprocx = P / nprocy;
     const double BoxSize = 3.0 * nc;
     if (P % nprocy || Nmesh % nprocx || Nmesh % nprocy || nc % nprocx || nc % nprocy) {
@@ -119,6 +120,7 @@ int main(int argc, char **argv)
     g.device = share_gpu ? 0 : rank % ndev;
     g.nranks_y = nprocy;
     g.paint_mode = paint_mode;
+    g.gradient_mode = gradient_mode;
     fpmhip_plan *plan = NULL;
     CHECK(fpmhip_plan_create(&g, NULL, &plan));
     fastpm_hip_transport *t = transport == 2 ? fastpm_hip_rccl_transport_create(MPI_COMM_WORLD, g.device)
@@ -258,10 +260,10 @@ int main(int argc, char **argv)
         printf("{\"entry\": \"fastpm_hip_mesh_force_species (fastpm_slab_hip.c) over %s\", \"ranks\": %d, \"process_mesh\": [%d, %d], "
                "\"nc\": %d, \"nmesh\": %d, \"precision\": %d, \"particles\": %.0f, \"misplaced_after_decompose\": %.0f, "
                "\"decompose_ms\": %.3f, \"decompose_d2h_bytes\": %.0f, \"strips\": %d, "
-               "\"transport\": %d, \"rccl_ranks\": %d, \"distinct_devices\": %d, \"share_gpu\": %d, \"wire\": \"%s\", \"devices\": [",
+               "\"transport\": %d, \"rccl_ranks\": %d, \"distinct_devices\": %d, \"share_gpu\": %d, \"wire\": \"%s\", \"gradient_mode\": %d, \"devices\": [",
                transport == 2 ? "fastpm_slab_rccl.c (RCCL)" : transport == 1 ? "fastpm_slab_mpi.c (GPU-aware MPI)" : "fastpm_slab_mpi.c (host-staged MPI)",
                P, nprocx, nprocy, nc, Nmesh, precision, tot[0], tot[1], decompose_ms, tot[2], fpmhip_plan_strips(plan),
-               transport, rccl_ranks, distinct, share_gpu, t != inner ? "f32" : "mesh");
+               transport, rccl_ranks, distinct, share_gpu, t != inner ? "f32" : "mesh", gradient_mode);
         for (int i = 0; i < P; i++) printf("%s\"%.63s\"", i ? ", " : "", all + 64 * i);
         printf("], \"finite\": %s, \"momentum_residual\": %.3e, \"legs\": [", s[4] == 0 ? "true" : "false", mom);
         for (int l = 0; l < nlegs; l++) {

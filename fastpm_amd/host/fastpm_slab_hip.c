@@ -319,6 +319,51 @@ static int slab_force_species(seq *q, const fpmhip_particles *sets, int nsets, i
         return 0;
     }
 
+    if (lay.gradient_mode == FPMHIP_GRADIENT_XSTENCIL && go == 1 && strips && fpmhip_plan_column_fft(plan)) {
+        /* FPMHIP_GRADIENT_XSTENCIL (round 6): ONE mesh back through the transpose -- the potential; its y pass makes the y and z
+         * components and passes the potential's half-spectrum rows on; the x component's rows are the 4-point stencil of
+         * those across planes (fpmhip_xstencil_rows), for which two planes of the potential come from either neighbour with
+         * the force meshes' halo planes in ONE grouped exchange.  TWO transposes per force where the default sends three. */
+        if (xl < 3) return -3;
+        void *pot = fpmhip_plan_buffer(plan, B_F1), *land = fpmhip_plan_buffer(plan, B_F0);
+        void *fy = fpmhip_plan_buffer(plan, B_F2), *fz = fpmhip_plan_buffer(plan, B_XCHG2);
+        void *phi = canvas, *fx = work;                         /* both free since the forward transpose has landed */
+        if (!pot || !land || !fy || !fz) return -2;
+        if (fuse_x) RUN(fpmhip_fft_x_forward_transfer_backward(plan, delta_k, kernel, 1, pot, NULL, NULL));
+        else RUN(fpmhip_transfer_fft_x_backward_pot(plan, delta_k, pot, kernel));
+        if (nr > 1) {
+            for (int i = 0; i < nr; i++) TRY(begin_range(q, &lay, pot, land, i * rx, rx, TAG_POT + i));
+            for (int i = 0; i < nr; i++) {
+                TRY(wait_tag(q, TAG_POT + i));
+                RUN(fpmhip_fft_y_backward_grad2_range(plan, land, fy, fz, phi, kernel, i * rx, rx));
+            }
+        } else {
+            if (nr == 1) {
+                TRY(begin_range(q, &lay, pot, land, 0, 0, TAG_POT));
+                TRY(wait_tag(q, TAG_POT));
+            } else TRY(exchange(q, pot, land, chunk_bytes));
+            RUN(fpmhip_fft_y_backward_grad2(plan, land, fy, fz, phi, kernel));
+        }
+        void *halo = pot;                                       /* four planes of side buffer: the send buffer is free again */
+        {
+            const fastpm_hip_msg m[5] = {plane_msg(q, phi, 0, 1, fpmhip_plane_ptr(plan, phi, xl), -1, plane_bytes),
+                                         plane_msg(q, phi, 1, 2, fpmhip_plane_ptr(plan, halo, 2), -1, plane_bytes),
+                                         plane_msg(q, phi, xl - 2, 2, halo, +1, plane_bytes),
+                                         plane_msg(q, fy, 0, 1, fpmhip_plane_ptr(plan, fy, xl), -1, plane_bytes),
+                                         plane_msg(q, fz, 0, 1, fpmhip_plane_ptr(plan, fz, xl), -1, plane_bytes)};
+            TRY(neighbours(q, m, 5, TAG_HALO));
+        }
+        RUN(fpmhip_xstencil_rows(plan, phi, halo, fx));
+        {
+            void *cm[3] = {fx, fy, fz};
+            TRY(check_force_meshes(q, delta_k, cm));
+        }
+        TRY(readout_species_z(q, sets, nsets, fx, fy, fz, 1));
+        for (int si = 0; si < nsets; si++)                                          /* gravity.c:487-492: the potential is there */
+            if (sets[si].potential) RUN(fpmhip_readout1_zc2r(plan, &sets[si], phi, sets[si].potential, 1, 0));
+        return 0;
+    }
+
     void *f[4] = {canvas, fpmhip_plan_buffer(plan, B_F1), fpmhip_plan_buffer(plan, B_F2), NULL};
     void *work2 = fpmhip_plan_buffer(plan, B_F0);
     if (!f[1] || !f[2] || !work2) return -2;

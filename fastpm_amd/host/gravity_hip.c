@@ -110,8 +110,21 @@ plan_for(PM * pm)
     g.device = local_rank % ndev;
     c = malloc(sizeof(*c));
     c->transport = NULL;
+    {
+        /* FASTPM_HIP_GRADIENT = kspace (default: the reference's arithmetic) | xstencil | real: the opt-in comm-volume levers
+         * (fastpm_hip.h: FPMHIP_GRADIENT_XSTENCIL sends two meshes back through the transposes instead of three, on the strip
+         * tiles, slabs; FPMHIP_GRADIENT_REAL one, on box tiles, slabs).  A mode this PM's geometry does not admit (pencils, a
+         * small mesh) is refused by the plan for geometric reasons -- the same on every rank -- and the k-space mode runs. */
+        const char * e = getenv("FASTPM_HIP_GRADIENT");
+        g.gradient_mode = !e ? FPMHIP_GRADIENT_KSPACE : !strcmp(e, "xstencil") ? FPMHIP_GRADIENT_XSTENCIL
+                        : !strcmp(e, "real") ? FPMHIP_GRADIENT_REAL : FPMHIP_GRADIENT_KSPACE;
+    }
     if(fpmhip_plan_create(&g, NULL, &c->plan)) {
-        fastpm_raise(-1, "%s\n", fpmhip_last_error());
+        if(g.gradient_mode == FPMHIP_GRADIENT_KSPACE) fastpm_raise(-1, "%s\n", fpmhip_last_error());
+        fastpm_info("MI355X force step: FASTPM_HIP_GRADIENT is not available on this mesh (%s); using the k-space gradient\n",
+                fpmhip_last_error());
+        g.gradient_mode = FPMHIP_GRADIENT_KSPACE;
+        if(fpmhip_plan_create(&g, NULL, &c->plan)) fastpm_raise(-1, "%s\n", fpmhip_last_error());
     }
     {
         /* The library lays its meshes out for the process mesh it was told; what the callers of this file iterate with

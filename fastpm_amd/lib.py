@@ -73,6 +73,7 @@ SYMBOLS = {
     "fpmhip_total_mass_dev": (_I, [_P, ctypes.POINTER(Particles), _I, _P]),
     "fpmhip_plan_scale_from_device": (_I, [_P, _P]),
     "fpmhip_sum_rows_on": (_I, [_P, _P, _P, _I, _I]),
+    "fpmhip_xstencil_rows": (_I, [_P, _P, _P, _P]),
     "fpmhip_convert_pieces": (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _I, _I, _I]),
     "fpmhip_plan_buffers_ready": (_I, [_P, _I]),
     "fpmhip_tile_order": (_I, [_P, ctypes.POINTER(Particles), _P]),

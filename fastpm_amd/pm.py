@@ -33,7 +33,7 @@ FIELD_ACC = (0, 1, 2)
 FIELD_POTENTIAL = 3
 PAINT_TILED, PAINT_ATOMIC, PAINT_BOXES, PAINT_STRIPS = 0, 1, 2, 3
 FFT_AUTO, FFT_ROCFFT = 0, 1
-GRADIENT_KSPACE, GRADIENT_REAL = 0, 1
+GRADIENT_KSPACE, GRADIENT_REAL, GRADIENT_XSTENCIL = 0, 1, 2
 
 
 def _enum(table, v):

@@ -73,7 +73,17 @@ enum { FPMHIP_FFT_AUTO = 0, FPMHIP_FFT_ROCFFT = 1 };
  *   identical.  Used only for kernels with gradorder = 1 (1_4, 3_4, 5_4, GADGET, 1_4_DIFF0); the
  *   others (exact i k gradient) always take the KSPACE route.  With nranks > 1 it needs 2 all-to-alls
  *   per force instead of 4, plus four extra halo planes of the potential. */
-enum { FPMHIP_GRADIENT_KSPACE = 0, FPMHIP_GRADIENT_REAL = 1 };
+enum { FPMHIP_GRADIENT_KSPACE = 0, FPMHIP_GRADIENT_REAL = 1,
+       /* FPMHIP_GRADIENT_XSTENCIL (round 6, opt-in; strip plans on one rank and x slabs, kernels with gradorder = 1): the y
+        * and z components as KSPACE makes them (the reference's float32 tables and roundings), the X component from the
+        * potential by the 4-point stencil whose transform i k_finite(kx) is, applied ACROSS x PLANES to the potential's
+        * half-spectrum rows (fpmhip_xstencil_rows; the z pass is linear).  ONE mesh -- the potential -- then goes through
+        * the backward x pass and, with nranks > 1, through the transpose: TWO transposes per force instead of three on the
+        * strip tiles (REAL takes two as well, on box tiles), plus four halo planes of the potential.  On one GPU the mesh
+        * sweeps stay 15 (the stencil pass stands where the x component's y pass stood): it is a comm-volume lever.  acc_x
+        * differs from KSPACE by the unreproduced float32 rounding of k_finite(kx): <= 2e-7 max |acc| on an fp64 mesh; acc_y,
+        * acc_z and delta_k are KSPACE's bits. */
+       FPMHIP_GRADIENT_XSTENCIL = 2 };
 
 /* What pm_init takes (libfastpm/pmpfft.h:29-35 PMInit) + where this rank sits. */
 typedef struct {
@@ -227,6 +237,12 @@ int fpmhip_total_mass(fpmhip_plan *plan, const fpmhip_particles *p_dev, double *
 double *fpmhip_plan_scalars(fpmhip_plan *plan);
 int fpmhip_total_mass_dev(fpmhip_plan *plan, const fpmhip_particles *sets_dev, int nsets, double *out_dev);
 int fpmhip_plan_scale_from_device(fpmhip_plan *plan, const double *total_dev);
+/* FPMHIP_GRADIENT_XSTENCIL: fx_rows[p] = (8 (phi[p+1] - phi[p-1]) - (phi[p+2] - phi[p-2])) / (12 h) for the planes p of a
+ * mesh of half-spectrum rows (what fpmhip_fft_y_backward_grad2 leaves as out_pot), every plane [0, xl] of a slab -- its halo
+ * plane included -- or [0, N) on one rank (periodic).  halo4_dev (slabs; NULL on one rank): the potential's planes -2, -1
+ * (rank - 1's last two) and xl+1, xl+2 (rank + 1's planes 1, 2) as [4][plane]; plane xl of phi_rows must hold rank + 1's
+ * plane 0.  Out of place. */
+int fpmhip_xstencil_rows(fpmhip_plan *plan, const void *phi_rows_dev, const void *halo4_dev, void *fx_rows_dev);
 /* The pieces of an exchange ([first + k * stride, + piece), k < npieces, of each of nchunks chunks `chunk_elems` apart;
  * all in mesh ELEMENTS) converted between double and float at the same element positions, on the plan's stream: the
  * float32 wire format of fastpm_amd/host/fastpm_wire_hip.c (to_f32 != 0: dst float <- src double; 0: dst double <- src float) */

@@ -7,9 +7,9 @@ import numpy as np
 
 
 class GpuOps:
-    def __init__(self, N, L, precision=64, gradient_mode=0):
+    def __init__(self, N, L, precision=64, gradient_mode=0, paint_mode=0):
         from fastpm_amd import PM
-        self.pm = PM(N, L, precision, gradient_mode=gradient_mode)
+        self.pm = PM(N, L, precision, gradient_mode=gradient_mode, paint_mode=paint_mode)
         self.N, self.L = N, L
 
     def lpt(self, dk_xyk, q):

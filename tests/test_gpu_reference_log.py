@@ -31,9 +31,10 @@ def _check(log):
         assert abs(got / ref - 1) < 3e-4, (got, ref)
 
 
-@pytest.mark.parametrize("precision,gradient_mode", [(64, 0), (64, 1), (32, 0)])
+@pytest.mark.parametrize("precision,gradient_mode", [(64, 0), (64, 1), (32, 0), (64, 2)])
 def test_gpu_reproduces_the_reference_check_file(precision, gradient_mode):
-    ops = GpuOps(64, 512.0, precision, gradient_mode)
+    # (gradient_mode 2, FPMHIP_GRADIENT_XSTENCIL, lives on the strip tiles: asked for on this small mesh)
+    ops = GpuOps(64, 512.0, precision, gradient_mode, paint_mode=3 if gradient_mode == 2 else 0)
     log = R.run_lightcone_test(ops, F=np.float64 if precision == 64 else np.float32)
     _check(log)
     ops.pm.destroy()
@@ -64,7 +65,7 @@ def _check_restart(log):
             assert R.matches(got[atext][d], stext[d]), (atext, got[atext], stext)
 
 
-@pytest.mark.parametrize("precision,gradient_mode", [(64, 0), (32, 0), (64, 1)])
+@pytest.mark.parametrize("precision,gradient_mode", [(64, 0), (32, 0), (64, 1), (64, 2)])
 def test_gpu_reproduces_the_restart_check_lines_at_b2(precision, gradient_mode):
     """tests/run-test-restart.sh:12-13 (restart.lua: 128^3 particles, pm_nc_factor = 2 -> 256^3 force mesh, seed 100):
     the velocity dispersions after the kicks that applied the B = 2 accelerations, from the seed, every operator on
