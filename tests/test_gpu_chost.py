@@ -798,7 +798,10 @@ MPI_ROOT = os.environ.get("FPM_MPI_ROOT", "/opt/conda")
     # decomposition's rows GPU to GPU (fastpm_hip_resident_decompose = store_hip.c's fastpm_store_decompose), the force on
     # the twins; slabs and 2 x 2 / 4 x 2 pencils, a 1-byte mask column among the columns
     (2, 24, 2, 64, 0, 2, 1, 1, 0), (4, 32, 2, 64, 0, 2, 1, 1, 32), (4, 32, 2, 32, 0, 2, 1, 2, 0), (8, 32, 2, 64, 0, 2, 1, 2, 32),
-    (3, 24, 2, 64, 0, 2, 0, 1, 0)])
+    (3, 24, 2, 64, 0, 2, 0, 1, 0),
+    # round 6, FPMHIP_GRADIENT_XSTENCIL (gradient_mode 2: two transposes per force on the strip tiles, the potential's halo
+    # planes in the grouped exchange): 4 and 2 slabs as real processes, plane ranges / blocking, device and resident columns
+    (4, 32, 2, 64, 2, 0, 0, 1, 34), (2, 32, 2, 64, 2, 2, 1, 1, 29), (4, 32, 2, 32, 2, 0, 1, 1, 32)])
 def test_mpi_ranks_run_the_slab_force(oracle, P, nc, B, precision, gradient_mode, host_columns, decompose, nprocy, chunks):
     paint_mode = 0
     if chunks >= 20:                 # 30 + c: strip tiles forced on the small mesh, c plane ranges (29: the blocking sequence)
