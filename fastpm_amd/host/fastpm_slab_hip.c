@@ -365,6 +365,7 @@ static int slab_force_species(seq *q, const fpmhip_particles *sets, int nsets, i
     }
 
     void *f[4] = {canvas, fpmhip_plan_buffer(plan, B_F1), fpmhip_plan_buffer(plan, B_F2), NULL};
+    int halo_begun = 0;
     void *work2 = fpmhip_plan_buffer(plan, B_F0);
     if (!f[1] || !f[2] || !work2) return -2;
     if (go == 1 && fpmhip_plan_column_fft(plan)) {
@@ -387,11 +388,27 @@ static int slab_force_species(seq *q, const fpmhip_particles *sets, int nsets, i
                 TRY(wait_tag(q, TAG_POT + i));
                 if (strips) RUN(fpmhip_fft_y_backward_grad2_range(plan, work2, f[2], extra, potmesh, kernel, i * rx, rx));
                 else RUN(fpmhip_fft_yz_backward_grad2_range(plan, work2, f[2], extra, potmesh, kernel, i * rx, rx));
+                if (i == 0 && q->nb) {
+                    /* plane 0 of the y and z components [and the potential] is final with range 0: their halo messages go
+                     * behind the transposes already queued on the wire and travel under the passes still to come, instead
+                     * of after the last of them (the halo slot, plane xl, is written by no pass) */
+                    fastpm_hip_msg m[3];
+                    void *hm[3] = {f[2], extra, potmesh};
+                    int nm = 0;
+                    for (int d = 0; d < 3; d++)
+                        if (hm[d]) m[nm++] = plane_msg(q, hm[d], 0, 1, fpmhip_plane_ptr(plan, hm[d], xl), -1, plane_bytes);
+                    XCH(t->msgs_begin(t->ctx, m, nm, TAG_HALO));
+                    halo_begun = 1;
+                }
             }
             for (int i = 0; i < nr; i++) {
                 TRY(wait_tag(q, TAG_X + i));
                 if (strips) RUN(fpmhip_fft_y_backward_range(plan, work, f[1], i * rx, rx));
                 else RUN(fpmhip_fft_yz_backward_range(plan, work, f[1], i * rx, rx));
+                if (i == 0 && halo_begun) {                       /* ... and the x component's with ITS range 0 */
+                    const fastpm_hip_msg m = plane_msg(q, f[1], 0, 1, fpmhip_plane_ptr(plan, f[1], xl), -1, plane_bytes);
+                    XCH(t->msgs_begin(t->ctx, &m, 1, TAG_HALO2));
+                }
             }
             f[0] = f[1]; f[1] = f[2]; f[2] = extra;               /* (x, y, z); the canvas is free (scratch below) */
         } else {
@@ -416,7 +433,10 @@ static int slab_force_species(seq *q, const fpmhip_particles *sets, int nsets, i
             int nm = 0;
             for (int d = 0; d < 4; d++)
                 if (f[d]) m[nm++] = plane_msg(q, f[d], 0, 1, fpmhip_plane_ptr(plan, f[d], xl), -1, plane_bytes);
-            TRY(neighbours(q, m, nm, TAG_HALO));
+            if (halo_begun) {                                     /* begun under the ranged passes above */
+                TRY(wait_tag(q, TAG_HALO));
+                TRY(wait_tag(q, TAG_HALO2));
+            } else TRY(neighbours(q, m, nm, TAG_HALO));
             TRY(check_force_meshes(q, delta_k, f));
             TRY(readout_species_z(q, sets, nsets, f[0], f[1], f[2], strips));
             for (int si = 0; si < nsets && potmesh; si++)
@@ -471,7 +491,10 @@ static int slab_force_species(seq *q, const fpmhip_particles *sets, int nsets, i
             else RUN(fpmhip_fft_yz_backward(plan, land[2], f[2]));
         }
     }
-    {
+    if (halo_begun) {                                           /* box tiles, no potential column: begun under the ranged passes */
+        TRY(wait_tag(q, TAG_HALO));
+        TRY(wait_tag(q, TAG_HALO2));
+    } else {
         fastpm_hip_msg m[3];
         for (int d = 0; d < 3; d++) m[d] = plane_msg(q, f[d], 0, 1, fpmhip_plane_ptr(plan, f[d], xl), -1, plane_bytes);
         TRY(neighbours(q, m, 3, TAG_HALO));
