@@ -38,9 +38,12 @@ class ReplicatedSlabForce:
     """fastpm_solver_compute_force (gravity.c:458-529) for rank `rank` of P slabs of an N^3 mesh in the replicated
     universe, every stage call at full per-rank size through the C ABI; kernel 1_4, no softening (the default)."""
 
-    def __init__(self, N, L, P, rank, precision, paint_mode=0):
+    def __init__(self, N, L, P, rank, precision, paint_mode=0, gradient_mode=0):
         from fastpm_amd import PM
-        self.pm = PM(N, L, precision, nranks=P, rank=rank, paint_mode=paint_mode)
+        # gradient_mode 2 = FPMHIP_GRADIENT_XSTENCIL (round 6): ONE mesh back through the transpose, the x component from
+        # the potential's rows by the plane stencil (the sequence of fastpm_slab_hip.c's XSTENCIL branch, stage call by stage call)
+        self.pm = PM(N, L, precision, nranks=P, rank=rank, paint_mode=paint_mode, gradient_mode=gradient_mode)
+        self.xs = gradient_mode == 2
         self.N, self.L, self.P, self.rank = N, L, P, rank
         pm = self.pm
         # the k-space block of rank s carries rank s's ky range: its x passes run on a plan of rank s (tables only)
@@ -73,12 +76,30 @@ class ReplicatedSlabForce:
             chunk = self.send[s * ce:(s + 1) * ce]
             for j in range(P):                                  # the block of rank s: P copies of chunk s along x
                 self.block[j * ce:(j + 1) * ce].copy_(chunk)
-            self.kpm[s].fft_x_forward_transfer_backward(kernel, self.block, 2, [self.fx, self.pot])
+            if self.xs:
+                self.kpm[s].fft_x_forward_transfer_backward(kernel, self.block, 1, [self.pot])
+            else:
+                self.kpm[s].fft_x_forward_transfer_backward(kernel, self.block, 2, [self.fx, self.pot])
             if pk:      # solver.c:471 + the FORCE/AFTER handler (src/fastpm.c:1734): de-CIC and bin rank s's delta_k
                 sums = self.kpm[s].decic_powerspectrum_sums(self.block)
                 self.pk_sums = sums if self.pk_sums is None else tuple(a + b for a, b in zip(self.pk_sums, sums))
-            self.w1[s * ce:(s + 1) * ce].copy_(self.fx[r * ce:(r + 1) * ce])      # what rank s sends back to r
+            if not self.xs:
+                self.w1[s * ce:(s + 1) * ce].copy_(self.fx[r * ce:(r + 1) * ce])      # what rank s sends back to r
             self.w2[s * ce:(s + 1) * ce].copy_(self.pot[r * ce:(r + 1) * ce])
+        if self.xs:
+            import ctypes
+            phi, halo = self.w1, self.block                      # both free here
+            pm.fft_y_backward_grad2(kernel, self.w2, fy, fz, phi)
+            pe = int(pm.layout.plane_elems)
+            pm.plane(phi, xl).copy_(pm.plane(phi, 0))            # the neighbours are copies of this rank
+            halo[0:2 * pe].copy_(pm.plane(phi, xl - 2, 2))       # planes -2, -1
+            halo[2 * pe:4 * pe].copy_(pm.plane(phi, 1, 2))       # planes xl + 1, xl + 2
+            from fastpm_amd.pm import check, _ptr
+            check(pm._L.fpmhip_xstencil_rows(pm._plan, _ptr(phi), _ptr(halo), _ptr(self.fx)))
+            for f in (fy, fz):
+                pm.plane(f, xl).copy_(pm.plane(f, 0))
+            pm.readout3_zc2r([self.fx, fy, fz], store)
+            return store.acc
         (pm.fft_y_backward_grad2 if strips else pm.fft_yz_backward_grad2)(kernel, self.w2, fy, fz)
         (pm.fft_y_backward if strips else pm.fft_yz_backward)(self.w1, self.fx)
         for f in (self.fx, fy, fz):                              # the next slab's plane 0 = our own
@@ -87,7 +108,7 @@ class ReplicatedSlabForce:
         return store.acc
 
 
-def run_rank_share(N, P, precision, rank=3, ncube=None, timing=False, paint_mode=0):
+def run_rank_share(N, P, precision, rank=3, ncube=None, timing=False, paint_mode=0, gradient_mode=0):
     """Returns (acc of the slab's particles [P*P*n][3], acc of the small cubic problem [n][3], pm timings)."""
     from fastpm_amd import PM, Store
     Ncube = N // P
@@ -102,7 +123,7 @@ def run_rank_share(N, P, precision, rank=3, ncube=None, timing=False, paint_mode
     ref = st.acc.clone()
     small.destroy()
     x = replicate_into_slab(xc, Lcube, P, rank)
-    run = ReplicatedSlabForce(N, L, P, rank, precision, paint_mode)
+    run = ReplicatedSlabForce(N, L, P, rank, precision, paint_mode, gradient_mode)
     store = Store(x)
     if timing:
         run(store)                                               # warm-up: allocations, LDS grants

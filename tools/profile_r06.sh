@@ -19,6 +19,8 @@ for cfg in "1024 64" "2048 64" "2048 32" "3072 32 128" "3072 64 128"; do
   T=$(find /tmp/prof_rs -name '*.db' | head -1)
   python $REPO/tools/rocprof_summary.py $T $OUT/r06_rankshare_${tag}_rocprof_stats.md
 done
+# 3a'. the same slab rank at 1024^3 with FPMHIP_GRADIENT_XSTENCIL (one mesh back through the transpose; the stencil pass timed)
+python $REPO/tools/rank_share_bench.py 1024 64 0 0 xstencil > $OUT/r06_rankshare_1024_64_xstencil.json 2>/dev/null
 # 3b. ONE rank of the reference's 4 x 2 PENCIL mesh (tests/rank_share.py: ReplicatedPencilForce): strip tiles at 1024^3
 #     (the marching kernels on the exchange chunks), strip tiles at 2048^3 fp64 too (M = 1024: one workgroup per CU), and the
 #     1024^3 share on box tiles for the A/B

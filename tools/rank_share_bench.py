@@ -18,11 +18,13 @@ precision = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 ncube = int(sys.argv[3]) if len(sys.argv) > 3 and int(sys.argv[3]) > 0 else None
 paint_mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0        # 0: strips where they exist; 2: box tiles (A/B)
 pencil = len(sys.argv) > 5 and sys.argv[5] == "pencil"           # rank (1, 1) of the reference's 4 x 2 process mesh
+xstencil = len(sys.argv) > 5 and sys.argv[5] == "xstencil"       # FPMHIP_GRADIENT_XSTENCIL on the slab (round 6)
 P = 8
 if pencil:
     acc, ref, t, copies, strips = rank_share.run_pencil_share(N, 4, 2, precision, ncube=ncube, timing=True, paint_mode=paint_mode)
 else:
-    acc, ref, t = rank_share.run_rank_share(N, P, precision, ncube=ncube, timing=True, paint_mode=paint_mode)
+    acc, ref, t = rank_share.run_rank_share(N, P, precision, ncube=ncube, timing=True, paint_mode=paint_mode,
+                                            gradient_mode=2 if xstencil else 0)
     copies = P * P
 n = ref.shape[0]
 rms = float(ref.double().pow(2).mean().sqrt())
@@ -35,7 +37,7 @@ alg = {"sort": 52 * np_local, "paint": 24 * np_local + s * nr, "readout": 3 * s 
        "k_colfft": 2 * s * nr, "k_rowfft": 2 * s * nr, "k_zc2r": 2 * s * nr, "k_yback2": 3 * s * nr}
 out = {"workload": ("one rank of %d: %d^3 mesh fp%d, " % (P, N, precision)) +
                    (("pencil 4 x 2 (brick %d x %d x %d, %s tiles), " % (N // 4, N // 2, N, "strip" if strips else "box")) if pencil
-                    else "slab of %d planes, " % (N // P)) + "%d particles" % np_local,
+                    else "slab of %d planes, " % (N // P)) + "%d particles" % np_local + (", FPMHIP_GRADIENT_XSTENCIL" if xstencil else ""),
        "parity_vs_small_cube": err, "kernels": {}}
 for name, (ms, cnt) in sorted(t.items()):
     if cnt == 0:
@@ -52,6 +54,13 @@ for name, (ms, cnt) in sorted(t.items()):
 real_launches = {"xback3": 1, "k_colfft": 2, "k_yback2": 1} if pencil else {"xback3": 1}
 once = sum(v["ms_per_launch"] * real_launches.get(k, v["launches"]) for k, v in out["kernels"].items()
            if k in ("sort", "paint", "readout", "xback3", "k_colfft", "k_rowfft", "k_zc2r", "k_yback2", "halo"))
+if xstencil and "c2r" in out["kernels"] and "k_yback2" in out["kernels"]:
+    # the stencil pass has no timer of its own: it is what the c2r stage holds beside the y pass (no z passes on strips)
+    xs_ms = (out["kernels"]["c2r"]["ms_per_launch"] * out["kernels"]["c2r"]["launches"]
+             - out["kernels"]["k_yback2"]["ms_per_launch"] * out["kernels"]["k_yback2"]["launches"])
+    out["kernels"]["xstencil_rows"] = {"ms_per_launch": xs_ms, "launches": 1, "alg_GB": 2 * s * nr / 1e9,
+                                       "TBps": 2 * s * nr / xs_ms / 1e9, "frac_of_8TBps": 2 * s * nr / xs_ms / 1e9 / 8.0}
+    once += xs_ms
 out["per_rank_compute_ms_per_step"] = once
 out["particle_updates_per_s_per_gpu_compute_only"] = np_local / (once * 1e-3)
 print(json.dumps(out))
