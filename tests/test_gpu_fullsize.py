@@ -174,13 +174,16 @@ def test_hand_written_fft_passes_agree_with_rocfft_at_the_multi_gpu_mesh_sizes()
 
 
 # ---- configs[2], [3], [4]: ONE rank's share of the 8-GPU job at full per-rank size (tests/rank_share.py) ----
-@pytest.mark.parametrize("N,precision,ncube,tol", [
-    (1024, 64, None, 1e-6),      # configs[2]: 512^3 particles, 1024^3 mesh: slab of 128 planes, 16.8 M particles
-    (2048, 64, None, 1e-6),      # configs[3]: 1024^3 particles, 2048^3 mesh: slab of 256 planes, 134 M particles
-    (2048, 32, None, 3e-5),      #   ... on the reference's default mesh precision
-    (3072, 32, 128, 3e-5),       # configs[4] at B = 3: 1024^3 particles, 3072^3 mesh: slab of 384 planes
+@pytest.mark.parametrize("N,precision,ncube,tol,gradient_mode", [
+    (1024, 64, None, 1e-6, 0),   # configs[2]: 512^3 particles, 1024^3 mesh: slab of 128 planes, 16.8 M particles
+    (2048, 64, None, 1e-6, 0),   # configs[3]: 1024^3 particles, 2048^3 mesh: slab of 256 planes, 134 M particles
+    (2048, 32, None, 3e-5, 0),   #   ... on the reference's default mesh precision
+    (3072, 32, 128, 3e-5, 0),    # configs[4] at B = 3: 1024^3 particles, 3072^3 mesh: slab of 384 planes
+    # round 6, FPMHIP_GRADIENT_XSTENCIL at the slab's true geometry (the small cube runs the k-space mode: the bound is the
+    # float32 rounding of k_finite(kx) that the stencil does not reproduce -- measured 5.4e-7 of rms)
+    (1024, 64, None, 2e-6, 2),
 ])
-def test_one_rank_of_the_8_gpu_configs_at_full_per_rank_size(N, precision, ncube, tol):
+def test_one_rank_of_the_8_gpu_configs_at_full_per_rank_size(N, precision, ncube, tol, gradient_mode):
     """Every stage kernel of the slab force at the geometry and particle count ONE of the 8 GPUs sees, in a universe
     that is periodic with period L/8 (tests/rank_share.py): the accelerations must equal those of the small cubic
     problem (mesh N/8, one cube's particles) for every one of the 64 copies of the cube in the slab."""
@@ -190,7 +193,7 @@ def test_one_rank_of_the_8_gpu_configs_at_full_per_rank_size(N, precision, ncube
     need = 7.5 * (N // 8) * N * (N + 2) * (precision // 8) + 100.0 * (N // 16) ** 3 * 64
     if free < need:
         pytest.skip("needs %.0f GB of device memory" % (need / 1e9))
-    acc, ref, _ = rank_share.run_rank_share(N, 8, precision, ncube=ncube)
+    acc, ref, _ = rank_share.run_rank_share(N, 8, precision, ncube=ncube, gradient_mode=gradient_mode)
     n = ref.shape[0]
     assert acc.shape[0] == 64 * n and bool(torch.isfinite(acc).all())
     rms = float(ref.double().pow(2).mean().sqrt())
