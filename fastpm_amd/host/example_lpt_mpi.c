@@ -7,13 +7,17 @@
  * the MPI or RCCL transport.  With the reference's tests/powerspec.txt, nc = 64, boxsize = 512, seed = 100 the two lines
  * must read exactly as tests/run-test-lightcone.check has them, whatever P (tests/test_gpu_chost.py).
  *
- *   mpiexec -n P ./example_lpt_mpi powerspec.txt [nc] [boxsize] [seed] [precision] [gpu_aware] [nprocy] [chunks]
+ *   mpiexec -n P ./example_lpt_mpi powerspec.txt [nc] [boxsize] [seed] [precision] [gpu_aware] [nprocy] [chunks] [resident]
+ *
+ * resident = 1: x, dx1, dx2 and delta_k in HOST memory with device twins behind them, as pm2lpt_hip.c holds them
+ * (fastpm_hip_resident_2lpt_ranks: delta_k crosses in the reference's ORegion layout of this rank, dx1 / dx2 come home on a sync).
  */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 
 #include "fastpm_2lpt_hip.h"
+#include "fastpm_mirror_hip.h"
 #include "fastpm_slab_mpi.h"
 
 #define CHECK(expr) do { if ((expr) != 0) { fprintf(stderr, "rank %d: %s failed: %s\n", rank, #expr, fpmhip_last_error()); \
@@ -47,6 +51,7 @@ int main(int argc, char **argv)
     const int gpu_aware = argc > 6 ? atoi(argv[6]) : 0;
     const int nprocy = argc > 7 && atoi(argv[7]) > 1 ? atoi(argv[7]) : 1;
     const int chunks = argc > 8 ? atoi(argv[8]) : 0;
+    const int resident = argc > 9 ? atoi(argv[9]) : 0;
     const int nprocx = P / nprocy;
     if (P % nprocy || nc % nprocx || nc % nprocy) {
         if (rank == 0) fprintf(stderr, "PM mesh is not divided by the process mesh.\n");      /* vpm.c:45-53 */
@@ -99,9 +104,32 @@ int main(int argc, char **argv)
     CHECK(fpmhip_malloc(&d1, (np ? np : 1) * 3 * sizeof(float)));
     CHECK(fpmhip_malloc(&d2, (np ? np : 1) * 3 * sizeof(float)));
     CHECK(fpmhip_memcpy_h2d(plan, dx, q, np * 3 * sizeof(double)));
-    const long long syncs0 = fpmhip_plan_sync_count(plan);
-    CHECK(fastpm_hip_mesh_2lpt_solve(plan, t, delta_k, dx, d1, d2, (int64_t) np, FASTPM_KERNEL_1_4));    /* solver.c:141 */
-    const long long syncs = fpmhip_plan_sync_count(plan) - syncs0;
+    long long syncs0 = fpmhip_plan_sync_count(plan), syncs;
+    float (*h1)[3] = NULL, (*h2)[3] = NULL;
+    void *dk_host = NULL;
+    if (resident) {
+        /* as pm2lpt_hip.c: host buffers in, twins do the work; delta_k in the reference's ORegion layout of this rank */
+        h1 = calloc(np ? np : 1, sizeof(*h1));
+        h2 = calloc(np ? np : 1, sizeof(*h2));
+        dk_host = malloc(bytes);
+        CHECK(fpmhip_export_delta_k(plan, delta_k, dk_host));
+        syncs0 = fpmhip_plan_sync_count(plan);
+        if (fastpm_hip_resident_2lpt_ranks(plan, t, dk_host, np ? &q[0][0] : NULL, np ? &h1[0][0] : NULL, np ? &h2[0][0] : NULL,
+                                           (int64_t) np, FASTPM_KERNEL_1_4)) {
+            fprintf(stderr, "rank %d: %s | %s\n", rank, fastpm_hip_mirror_error(), fpmhip_last_error());
+            MPI_Abort(MPI_COMM_WORLD, 1);
+        }
+        syncs = fpmhip_plan_sync_count(plan) - syncs0;
+        if (np) {
+            CHECK(fastpm_hip_host_sync(h1));
+            CHECK(fastpm_hip_host_sync(h2));
+            CHECK(fpmhip_memcpy_h2d(plan, d1, h1, np * 3 * sizeof(float)));       /* for the summary below */
+            CHECK(fpmhip_memcpy_h2d(plan, d2, h2, np * 3 * sizeof(float)));
+        }
+    } else {
+        CHECK(fastpm_hip_mesh_2lpt_solve(plan, t, delta_k, dx, d1, d2, (int64_t) np, FASTPM_KERNEL_1_4));    /* solver.c:141 */
+        syncs = fpmhip_plan_sync_count(plan) - syncs0;
+    }
 
     /* fastpm_store_summary(p, COLUMN_DX1 / DX2, comm, "s", ...): store.c:807-908 */
     double s[13] = {0};
@@ -123,7 +151,8 @@ int main(int argc, char **argv)
         printf("dx2  : %g %g %g %g\n", b[0], b[1], b[2], (b[0] + b[1] + b[2]) / 3.0);
         printf("ranks %d process mesh %d x %d particles %.0f host waits in the call %lld\n", P, nprocx, nprocy, n, syncs);
     }
-    free(q);
+    fastpm_hip_mirror_release_all();
+    free(q); free(h1); free(h2); free(dk_host);
     fpmhip_free(dx); fpmhip_free(d1); fpmhip_free(d2); fpmhip_free(delta_k);
     fastpm_powerspectrum_destroy_hip(&linear);
     if (gpu_aware == 2) fastpm_hip_rccl_transport_destroy(t);

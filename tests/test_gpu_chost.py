@@ -1008,8 +1008,9 @@ def test_plain_c_program_prints_the_reference_lpt_lines(tmp_path, precision):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("P,nprocy,precision,chunks", [(2, 1, 64, 0), (4, 1, 64, 1), (4, 2, 64, 0), (8, 2, 64, 0), (4, 2, 32, -1)])
-def test_mpi_ranks_print_the_reference_lpt_lines(P, nprocy, precision, chunks):
+@pytest.mark.parametrize("P,nprocy,precision,chunks,resident", [(2, 1, 64, 0, 0), (4, 1, 64, 1, 0), (4, 2, 64, 0, 0), (8, 2, 64, 0, 0),
+                                                               (4, 2, 32, -1, 0), (4, 1, 64, 0, 1), (4, 2, 64, 0, 1)])
+def test_mpi_ranks_print_the_reference_lpt_lines(P, nprocy, precision, chunks, resident):
     """`mpiexec -n P example_lpt_mpi` (round 6): pm_2lpt_solve for NTask > 1 in C99 -- fastpm_hip_mesh_2lpt_solve, the
     reference's call order (pm2lpt.c:14-164) with its 12 c2r + 1 r2c split around the transposes and the mesh halo in front
     of each of the six readouts -- on x slabs and 2 x 2 / 4 x 2 pencils, from seed 100 on every rank's own block of the field:
@@ -1025,10 +1026,12 @@ def test_mpi_ranks_print_the_reference_lpt_lines(P, nprocy, precision, chunks):
     table = os.path.join(ROOT, "tests", "golden", "reference_tests_powerspec.txt")
     nc = 64
     r = subprocess.run([mpiexec, "-n", str(P), os.path.join(ROOT, "fastpm_amd", "example_lpt_mpi"), table, str(nc), "512",
-                        "100", str(precision), "0", str(nprocy), str(chunks)], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, FASTPM_HIP_MPI_STAGED_RANGES="1" if chunks > 0 else "0"))
+                        "100", str(precision), "0", str(nprocy), str(chunks), str(resident)], capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, FASTPM_HIP_MPI_STAGED_RANGES="1" if chunks > 0 else "0"))
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     out = r.stdout.splitlines()
+    # (resident = 1: host buffers with device twins behind them, delta_k through the reference's ORegion layout of each rank
+    # -- fastpm_hip_resident_2lpt_ranks, what pm2lpt_hip.c calls for NTask > 1)
     assert out[:2] == ["dx1  : " + " ".join(R.CHECK["dx1"]), "dx2  : " + " ".join(R.CHECK["dx2"])], out
     assert out[2].startswith("ranks %d process mesh %d x %d particles %d" % (P, P // nprocy, nprocy, nc ** 3))
 
