@@ -894,6 +894,9 @@ def main():
                                          + ("" if world == 1 else ": the C leg; the Python mirror ran the k-space mode")}[args.gradient],
                 "paint_mode": ("strip tiles: paint + z r2c pass and z c2r pass + readout in one kernel each" if strips
                                else {0: "box tiles", 1: "atomic", 2: "box tiles"}.get(args.paint_mode, str(args.paint_mode))),
+                "binning_walk": (lambda st: {0: "probing", 1: "natural (rows as they lie: no tile order read or written)",
+                                             2: "ordered (the previous call's tile order)"}.get(st[0], str(st[0]))
+                                 + ", %.2f tiles per wave" % st[1])(pm.walk_state()) if strips else "box tiles: ordered",
                 "fft": "hand-written row + column passes" if pm.column_fft() else "rocFFT",
                 "wire": ("float32 on the wire for the fp64 mesh's transposes (--wire f32)" if args.wire == "f32" and world > 1 and args.precision == 64
                          else "the mesh dtype")},

@@ -216,6 +216,20 @@ struct fpmhip_plan {
     int *d_flags = nullptr, *h_flags = nullptr;   // device flags of the binning and their pinned host copy
     hipEvent_t flags_event = nullptr;
     bool flags_pending = false;
+    // How the steady-state binning walks the store's rows (round 6; strip plans, bin_scatter_wave_kernel):
+    //   WALK_PROBE   : rows as they lie, once, right after a set's first (exact) binning -- the kernel counts the distinct tiles
+    //                  per wave; the tile order is still written, so that the next call can go either way;
+    //   WALK_NATURAL : rows as they lie (the positions stream, no order[] read, NO tile_order pass): a store whose rows are
+    //                  in lattice order with displacements of a cell or so (initial conditions, the early steps: load A);
+    //   WALK_ORDERED : the previous call's tile order (whatever the order of the rows: rounds 2-5's walk).
+    // The counts come back with the binning's flags, one call late; a natural walk whose waves touch more than six tiles on
+    // average (particles that have moved: load B; rows in random order: load C) hands over to the ordered walk.
+    enum { WALK_PROBE = 0, WALK_NATURAL = 1, WALK_ORDERED = 2 };
+    int walk_state = WALK_PROBE;
+    int flags_walk = -1;                    // the walk of the binning whose flags are pending (-1: the exact path)
+    bool order_valid = false;               // order[0] was written by the latest binning
+    bool want_order = false;                // fpmhip_tile_order: this binning must write order[0] whatever the walk
+    double walk_ratio = 0;                  // distinct tiles per wave and particle slot of the latest counted binning
     bool prebinned = false;                 // the leapfrog binned the moved particles on the way (bin_particles_leap)
     bool bin_trusted = false;               // inside fpmhip_force: the paint of this very call made the binning
     void *scan_tmp = nullptr;

@@ -106,7 +106,9 @@ __device__ __forceinline__ AggSlot2 block_agg_issue(BlockAgg &t, int *counters, 
 // exact two-pass path -- count, layout, scatter in natural order -- that is enqueued behind it, predicated on that
 // flag, redoes the binning in the same stream.  The first call on a plan runs the two-pass path unconditionally.
 // ------------------------------------------------------------------------------------------
-enum { FLAG_NEED_FULL = 0, FLAG_UNOWNED_FAST, FLAG_UNOWNED_FULL, FLAG_HARD_OVF, FLAG_TOTAL, FLAG_STALE, FLAG_COUNT };
+enum { FLAG_NEED_FULL = 0, FLAG_UNOWNED_FAST, FLAG_UNOWNED_FULL, FLAG_HARD_OVF, FLAG_TOTAL, FLAG_STALE,
+       FLAG_GROUPS, FLAG_SLOTS,      // sampled: distinct own tiles per wave and particle slot, summed | the slots counted
+       FLAG_COUNT };
 
 // A thread takes PPT particles (block-strided, so a wave still reads 64 consecutive rows): all
 // position loads first, then all atomics, then all stores -- the kernel is a chain of dependent
@@ -436,6 +438,18 @@ __global__ __launch_bounds__(256) void bin_scatter_wave_kernel(MeshGeo g, int nt
         kb[q] = kc[q] = 0;
         if (need[q]) { kb[q] = beg[key[q]]; kc[q] = cap[key[q]]; }
         if (need[q] && leader[q] == lane) base[q] = atomicAdd(&cnt[key[q]], count);      // every group's leader at once
+    }
+    // how coherent is this walk?  One wave in 16 reports the distinct OWN tiles of its particle slots (fpm_internal.h:
+    // walk_state); two fire-and-forget atomics per reporting wave
+    if ((blockIdx.x & 15) == 0) {
+        int groups = 0, slots = 0;
+#pragma unroll
+        for (int u = 0; u < BIN_PPT; u++) {
+            const unsigned long long lead = __ballot(need[2 * u] && leader[2 * u] == lane);
+            groups += __popcll(lead);
+            slots += lead != 0;
+        }
+        if (lane == 0 && slots) { atomicAdd(&flags[FLAG_GROUPS], groups); atomicAdd(&flags[FLAG_SLOTS], slots); }
     }
 #pragma unroll
     for (int q = 0; q < 2 * BIN_PPT; q++) {
@@ -1242,12 +1256,15 @@ static int bin_full(fpmhip_plan *p, const fpmhip_particles *pt, const int *pred)
 // (round 4, also not kept: the order written lazily by the three-component readout, which visits every own entry once -- a
 // 4-byte store per particle at the tile's exact offset: binning stage 0.39 -> 0.33 ms, readout 1.065 -> 1.093, 4.43 -> 4.40 ms
 // per force at 512^3; at 1024^3 2.73 -> 2.41 and 9.69 -> 9.94 ms, 38.3 -> 38.4: what the pass of its own costs, the readout pays)
-static int bin_finish(fpmhip_plan *p, const int *pred)
+static int bin_finish(fpmhip_plan *p, const int *pred, bool with_order = true)
 {
     const int nt = p->ntiles;
     FPM_TRY(make_layout(p, p->bin_beg[1], p->bin_cap[1], pred, false));       // leaves the exact offsets in bin_off
-    tile_order_kernel<<<blocks_for(nt, 4), 256, 0, p->stream>>>(nt, p->bin_beg[0], p->bin_cnt, p->bin_off, p->sidx,
-                                                                 p->mg.strips ? p->scell : nullptr, p->order[0], pred);
+    // (a confirmed natural walk -- walk_state, fpm_internal.h -- reads no tile order: the pass is skipped, 0.054 ms at 512^3)
+    if (with_order)
+        tile_order_kernel<<<blocks_for(nt, 4), 256, 0, p->stream>>>(nt, p->bin_beg[0], p->bin_cnt, p->bin_off, p->sidx,
+                                                                     p->mg.strips ? p->scell : nullptr, p->order[0], pred);
+    p->order_valid = with_order;
     FPM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1260,6 +1277,18 @@ int check_deferred(fpmhip_plan *p, bool wait)
     else if (hipEventQuery(p->flags_event) != hipSuccess) return 0;
     p->flags_pending = false;
     const int *f = p->h_flags;
+    // the walk of the binning these flags belong to: distinct own tiles per wave and slot (a sample of one wave in 16)
+    if (p->flags_walk >= 0 && f[FLAG_SLOTS] > 0) {
+        p->walk_ratio = (double) f[FLAG_GROUPS] / f[FLAG_SLOTS];
+        // natural while a wave's 64 rows stay within 6 tiles on average: measured on 256^3 lattice-ordered particles displaced
+        // by a Gaussian of sigma cells on the 512^3 mesh (tools/walk_sweep.py, profiles/r06_walk_sweep.jsonl; binning stage,
+        // ms, natural WITHOUT its tile-order pass | ordered): sigma 0.3: 0.28 | 0.39 (2.1 tiles per wave), 0.6: 0.35 | 0.41
+        // (5.7), 1.0: 0.44 | 0.43 (10.4), 1.5: 0.67 | 0.44 (23), 4.0: 1.03 | 0.49 (55)
+        static const double natural_max = getenv("FPMHIP_WALK_MAX") ? atof(getenv("FPMHIP_WALK_MAX")) : 6.0;
+        if (p->flags_walk != fpmhip_plan::WALK_ORDERED && p->walk_state != fpmhip_plan::WALK_ORDERED)
+            p->walk_state = p->walk_ratio <= natural_max ? fpmhip_plan::WALK_NATURAL : fpmhip_plan::WALK_ORDERED;
+    }
+    p->flags_walk = -1;
     const int unowned = f[FLAG_NEED_FULL] ? f[FLAG_UNOWNED_FULL] : f[FLAG_UNOWNED_FAST];
     // after any of these the tile order of that binning is incomplete (rows were dropped): the next call must not walk it
     if (unowned != 0 || f[FLAG_STALE] != 0 || f[FLAG_HARD_OVF] != 0) p->layout_np = -1;
@@ -1356,6 +1385,7 @@ int bin_particles_leap(fpmhip_plan *p, const fpmhip_particles *pt, const LeapArg
     FPM_CHECK_HIP(hipGetLastError());
     // a slab that overflowed: the exact path, predicated on the device flag, bins the (already updated) positions again
     FPM_TRY(bin_full(p, pt, p->d_flags + FLAG_NEED_FULL));
+    p->flags_walk = -1;                         // (the fused walk has its own order; its counts decide nothing)
     FPM_TRY(bin_finish(p, nullptr));
     p->binned_x = pt->x;
     p->binned_mass = pt->mass;
@@ -1373,9 +1403,20 @@ static int bin_particles_once(fpmhip_plan *p, const fpmhip_particles *pt, bool *
     // own + dup entries (up to 8 per particle, ~1.3 on average) are indexed with int32
     if (np >= 1000000000ll) FPM_FAIL(-1, "np %lld exceeds the int32 index range of one rank's binned entries", np);
     FPM_TRY(ensure_bins(p, np, 0, pt->mass != nullptr));
-    const bool have_layout = p->layout_np == np && np > 0;
+    bool have_layout = p->layout_np == np && np > 0;
+    // FPMHIP_BIN_ORDER = 1 | 0 forces the ordered / the natural walk (A/B); unset: adaptive (walk_state, fpm_internal.h)
+    static const int order_env = getenv("FPMHIP_BIN_ORDER") ? atoi(getenv("FPMHIP_BIN_ORDER")) : -1;
+    static const int wave_env = getenv("FPMHIP_BIN_WAVE") ? atoi(getenv("FPMHIP_BIN_WAVE")) : 1;      // A/B
+    const bool adaptive = order_env < 0 && p->mg.strips && wave_env;
+    if (!have_layout) p->walk_state = fpmhip_plan::WALK_PROBE;        // a new particle set: its first steady-state call probes
+    const bool ordered = adaptive ? p->walk_state == fpmhip_plan::WALK_ORDERED : order_env != 0;
+    // the ordered walk needs the tile order of the previous binning: a natural walk that has just been refused left none
+    // (exact path, once)
+    if (have_layout && ordered && !p->order_valid) have_layout = false;
+    const bool with_order = !adaptive || p->want_order || !have_layout || p->walk_state != fpmhip_plan::WALK_NATURAL;
     FPM_CHECK_HIP(hipMemsetAsync(p->d_flags, 0, FLAG_COUNT * sizeof(int), p->stream));
     const int *pred = nullptr;
+    p->flags_walk = !have_layout ? -1 : (ordered ? fpmhip_plan::WALK_ORDERED : p->walk_state);
     if (have_layout) {
         // ONE pass in the previous call's tile order into the slabs laid out from the previous call's counts
         std::swap(p->bin_beg[0], p->bin_beg[1]);
@@ -1385,8 +1426,6 @@ static int bin_particles_once(fpmhip_plan *p, const fpmhip_particles *pt, bool *
         // Walked in the previous call's tile order, a wave's particles fall into one or two tiles whatever the order of
         // the store's rows is: 0.62 / 0.67 / 0.9 ms on loads A / B / C (16.8 M particles), against 0.56 / 0.75 / 2.6 ms
         // walking the rows as they lie.  FPMHIP_BIN_ORDER=0 selects the latter (A/B).
-        static const bool ordered = !(getenv("FPMHIP_BIN_ORDER") && atoi(getenv("FPMHIP_BIN_ORDER")) == 0);
-        static const int wave_env = getenv("FPMHIP_BIN_WAVE") ? atoi(getenv("FPMHIP_BIN_WAVE")) : 1;      // A/B
         if (p->mg.strips && wave_env && ordered)
             bin_scatter_wave_kernel<true><<<blocks_for(np, 256 * BIN_PPT), 256, 0, p->stream>>>(
                 p->mg, nt, pt->x, pt->mass, np, p->order[1], p->bin_beg[0], p->bin_cap[0], p->bin_cnt, p->sx, p->sy, p->sz,
@@ -1408,7 +1447,7 @@ static int bin_particles_once(fpmhip_plan *p, const fpmhip_particles *pt, bool *
         FPM_CHECK_HIP(hipMemsetAsync(p->d_flags + FLAG_NEED_FULL, 1, 1, p->stream));    // = 1: the exact path is the one that ran
     }
     FPM_TRY(bin_full(p, pt, pred));
-    FPM_TRY(bin_finish(p, nullptr));
+    FPM_TRY(bin_finish(p, nullptr, with_order));
     p->binned_x = pt->x;
     p->binned_mass = pt->mass;
     p->binned_np = np;
@@ -1603,9 +1642,21 @@ int fpmhip_tile_order(fpmhip_plan *p, const fpmhip_particles *pt, int *order)
     if (pt->np == 0) return 0;
     if (!order) FPM_FAIL(-1, "null output");
     if (p->geom.paint_mode == FPMHIP_PAINT_ATOMIC) FPM_FAIL(-1, "tile_order needs the tiled painter");
-    FPM_TRY(bin_particles(p, pt));
+    p->want_order = true;                       // (a confirmed natural walk writes no tile order of its own accord)
+    const int rc_bin = bin_particles(p, pt);
+    p->want_order = false;
+    FPM_TRY(rc_bin);
     FPM_CHECK_HIP(hipMemcpyAsync(order, p->order[0], (size_t) pt->np * sizeof(int), hipMemcpyDeviceToDevice, p->stream));
     return fpmhip_invalidate_binning(p);          // the caller is about to permute the rows behind pt->x
+}
+
+// which walk the steady-state binning of the plan is in (0 probe, 1 natural, 2 ordered: fpm_internal.h walk_state) and
+// the distinct tiles per wave and particle slot its latest counted binning saw
+int fpmhip_plan_walk_state(const fpmhip_plan *p, double *ratio)
+{
+    if (!p) return -1;
+    if (ratio) *ratio = p->walk_ratio;
+    return p->walk_state;
 }
 
 int fpmhip_invalidate_binning(fpmhip_plan *p)

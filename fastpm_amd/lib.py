@@ -77,6 +77,7 @@ SYMBOLS = {
     "fpmhip_convert_pieces": (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _I, _I, _I]),
     "fpmhip_plan_buffers_ready": (_I, [_P, _I]),
     "fpmhip_tile_order": (_I, [_P, ctypes.POINTER(Particles), _P]),
+    "fpmhip_plan_walk_state": (_I, [_P, ctypes.POINTER(_D)]),
     "fpmhip_invalidate_binning": (_I, [_P]),
     "fpmhip_invalidate_binning_of": (_I, [_P, _P]),
     "fpmhip_plane_ptr": (_P, [_P, _P, _I64]),

@@ -715,6 +715,12 @@ class PM:
     def column_fft(self):
         return bool(self._L.fpmhip_plan_column_fft(self._plan))
 
+    def walk_state(self):
+        """(state, ratio): how the steady-state binning walks the rows -- 0 probing, 1 natural, 2 ordered -- and the distinct
+        tiles per wave and slot of its latest counted binning (include/fastpm_hip.h: fpmhip_plan_walk_state)"""
+        r = ctypes.c_double(0.0)
+        return int(self._L.fpmhip_plan_walk_state(self._plan, ctypes.byref(r))), float(r.value)
+
     def strips(self):
         """True if the plan bins into strip tiles (one rank or x slabs, Nmesh >= 192 by default): compute_force then paints into
         half-spectrum rows and reads the force meshes out before their z pass (csrc/fpm_strips.hip)."""

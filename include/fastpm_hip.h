@@ -258,6 +258,12 @@ int fpmhip_sum_rows_on(void *stream, double *out_dev, const double *rows_dev, in
  * small, -5) are reported by the call itself the first time a particle set of that size is binned and, from then on,
  * when the flags have arrived: by the next binning on the plan or by fpmhip_sync -- no host round trip sits between the
  * paint and the readout of a force call. */
+/* The steady-state binning adapts how it walks the store's rows (round 6, strip plans): 0 = probing (the first steady-state
+ * call of a particle set: rows as they lie, the distinct tiles per wave counted), 1 = NATURAL (rows as they lie: positions
+ * stream, no tile order read or written -- a store in lattice order whose particles have moved a cell or so), 2 = ORDERED (the
+ * previous call's tile order: any row order, any displacement).  *ratio: distinct own tiles per wave and particle slot of the
+ * latest counted binning (natural is kept while it stays <= 6; FPMHIP_WALK_MAX overrides, FPMHIP_BIN_ORDER = 0 | 1 forces). */
+int fpmhip_plan_walk_state(const fpmhip_plan *plan, double *ratio);
 int fpmhip_invalidate_binning(fpmhip_plan *plan);
 /* ... only when the binning the plan holds was made from the positions at x_dev (a device buffer that was rewritten) */
 int fpmhip_invalidate_binning_of(fpmhip_plan *plan, const void *x_dev);
