@@ -1,7 +1,10 @@
 #!/bin/bash
 # Round-6 A/B of the strip-entry layout, run ON THE GPU BOX: gpurun -- 'bash tools/entry_layout_ab.sh'.
 #   variant 0 = fastpm_amd/libfastpm_hip.so       : four arrays of 8-byte values (sx, sy, sz, scell)
-#   variant 1 = build/libfastpm_hip_aos.so        : one 32-byte record per entry (-DFPM_ENTRY_AOS=1, fpm_internal.h)
+#   variant 1 = build/libfastpm_hip_aos.so        : one 32-byte record per entry (-DFPM_ENTRY_AOS=1, fpm_internal.h); build it
+#               first (no GPU needed): compile fpm_plan / fpm_particles / fpm_strips / fpm_step / fpm_force.hip with the
+#               Makefile's flags + -DFPM_ENTRY_AOS=1 into a scratch directory and link them with the other objects of
+#               fastpm_amd/csrc into build/libfastpm_hip_aos.so (build/ is git-ignored and travels with gpurun)
 # (1) the record build must pass the strip / force parity tests, bit for bit; (2) timing side by side on configs[1] and the
 # 1024^3 mesh; (3) kernel trace + PMC traffic of both.  Output: gpurun_out/r06_entry_layout_*.
 set -u
