@@ -747,6 +747,7 @@ def main():
                     "value": nc2 ** 3 / t2, "unit": "particle-updates/s", "step_frac": round(b2 / t2 / 1e9 / HBM_PEAK_GBS, 4),
                     "kernel_fracs": {n: round(ab2[n] / (tm2b[n][0] / tm2b[n][1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                      for n in ab2 if n in tm2b and tm2b[n][1] > 0 and (n in KERNELS or n == "sort")},
+                    "binning_walk": list(pm2.walk_state()),
                     "finite": bool(torch.isfinite(st2.acc).all().item())}
                 # its dominant kernel against the roofline: this is the mesh north_star's >= 40 % is quoted on
                 try:
