@@ -37,6 +37,12 @@ def main():
         paint_mode = int(rng.choice([0, 0, 1, 2, 3, 3])) if P == 1 else 0
         if paint_mode == 3 and (grad or fft_mode or N not in (32, 64, 96, 128, 160)):      # strip tiles: where they exist
             paint_mode = 0
+        # round 6: FPMHIP_GRADIENT_XSTENCIL (strip plans, one rank here) against the k-space oracle, and SEVERAL calls on
+        # particles that move a little in between -- the steady-state binning with its adaptive walk (exact path, probe,
+        # natural or ordered) -- with the LAST call compared
+        if paint_mode == 3 and rng.random() < 0.4:
+            grad = 2
+        ncalls = int(rng.choice([1, 1, 3, 4])) if P == 1 else 1
         nc = max(2, int(N * rng.choice([0.25, 0.5, 0.5, 1.0])))
         L = float(rng.uniform(0.5, 4.0) * N)
         load = str(rng.choice(["a", "b", "c", "few"]))
@@ -51,15 +57,18 @@ def main():
         mass = rng.uniform(0, 2, len(x)).astype(np.float32) if rng.random() < 0.3 else None
         potential = bool(rng.random() < 0.5)
         chunks = int(rng.choice([1, 2, 4]))
-        desc = "N=%d P=%d fp%d grad=%d %s/%s fft=%d paint=%d np=%d load=%s mass=%s pot=%s chunks=%d" % (
-            N, P, prec, grad, kernel, soft, fft_mode, paint_mode, len(x), load, mass is not None, potential, chunks)
+        desc = "N=%d P=%d fp%d grad=%d %s/%s fft=%d paint=%d np=%d load=%s mass=%s pot=%s chunks=%d calls=%d" % (
+            N, P, prec, grad, kernel, soft, fft_mode, paint_mode, len(x), load, mass is not None, potential, chunks, ncalls)
         pmo = O.PMOracle(N, L, prec, threads=8)
+        xs = [x] + [np.remainder(x + rng.normal(0.0, 0.03 * L / N, x.shape), L) for _ in range(ncalls - 1)]
+        x = xs[-1]
         ref = O.compute_force(pmo, x, mass=mass, kernel=O.KERNELS[kernel], softening=O.SOFTENINGS[soft],
-                              potential=potential, gradient="real" if grad else "kspace")
+                              potential=potential, gradient="real" if grad == 1 else "kspace")
         if P == 1:
             pm = PM(N, L, prec, gradient_mode=grad, fft_mode=fft_mode, paint_mode=paint_mode)
-            st = Store(x, mass=mass, potential=potential)
-            pm.compute_force(st, kernel=kernel, softening=soft)
+            for xc in xs:
+                st = Store(xc, mass=mass, potential=potential)
+                pm.compute_force(st, kernel=kernel, softening=soft)
             torch.cuda.synchronize()
             acc = st.acc.cpu().numpy()
             pot = st.potential.cpu().numpy() if potential else None
