@@ -355,11 +355,13 @@ int fpmhip_plan_create(const fpmhip_geom *geom, void *stream, fpmhip_plan **out)
             FPM_FAIL(-1, "FPMHIP_PAINT_STRIPS: the k-space gradient, a mesh whose z rows fit the strip kernels and (pencils) local rows in whole strips");
         // (from Nmesh = 192: 0.51 -> 0.44 ms per force there, 0.89 -> 0.70 at 256^3 -- configs[0]'s mesh --; at 160 the two tie, at
         // 96 the box tiles win, 0.255 vs 0.272)
-        // Chosen BY MEASUREMENT per (N, process mesh): pencils at N = 3072 keep the box tiles by default (round 6, one rank of the
-        // reference's 4 x 2 at configs[4]'s load -- 134 M particles per rank, fp32, profiles/r06_rankshare_pencil_3072_32_256*:
-        // strips 132.6 ms, boxes 124.9 ms per step; the PEN readout at M = 1536 runs 52 ms = 0.12 of the peak where the box
-        // path's 3 x z c2r + readout take 39.8).  FPMHIP_PAINT_STRIPS still selects the strip kernels there.
-        const bool measured_slower = Ny > 1 && N == 3072;
+        // Chosen BY MEASUREMENT per (N, precision, process mesh), one rank of the reference's 4 x 2 at configs[4]'s load (134 M
+        // particles per rank, N = 3072): in fp32 the strips WIN since the three-waves-per-row readout (readout_split3_kernel, round
+        // 6: profiles/r06_split_readout_ab.md) -- strips 109.0 ms per step, boxes 124.5 (with the one-wave-per-row PEN readout the
+        // strips took 131.6: 52 ms of readout against the box path's 39.8 of 3 x z c2r + readout); fp64 has no such kernel (its
+        // window fills the LDS) and that rank does not fit one GPU for a measurement: it keeps the box tiles by default.
+        // FPMHIP_PAINT_STRIPS / FPMHIP_PAINT_TILES select either.
+        const bool measured_slower = Ny > 1 && N == 3072 && geom->precision == 64;
         if (can && (geom->paint_mode == FPMHIP_PAINT_STRIPS ||
                     (geom->paint_mode == FPMHIP_PAINT_TILED && N >= 192 && !env_off && !measured_slower))) {
             g.strips = STRIP_Y;

@@ -729,6 +729,469 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (PL::E == 4 ? FPM_RO
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// the long rows, M = 1024: TWO WAVES per row, joined once (round 6; the 2048^3 mesh of configs[3])
+// ------------------------------------------------------------------------------------------------------------------
+// What the long rows lack is waves in flight (profiles/r05_rows2_ab.md): one wave per row with E = 16 values per thread is
+// 236 - 252 VGPRs, five waves per workgroup, one (fp64) or two (fp32) workgroups per CU.  Two waves per row with E = 8 met at
+// every stage of the transform -- six workgroup barriers per plane -- and lost (10.4 -> 11.6 ms).  Here the two waves of a row
+// do not meet inside the transform: the M-point inverse transform is split by decimation in time,
+//     Z[n] = F0[n] + W_M^-n F1[n],   Z[n + M/2] = F0[n] - W_M^-n F1[n],   Fr = the M/2-point transform of Z'[2 m + r],
+// wave r of a row loads the half-spectrum values of parity r, untangles them (the partner M - k of k has k's parity: wave-local
+// but for X[M], which wave 0 loads), runs the E = 8, T = 64 wave-local transform of 512 points in its own region of the row's
+// LDS slot, and the two meet ONCE: each hands the other half of its results, one workgroup barrier, each forms the two sums of
+// half of the n.  Three workgroup barriers per plane instead of two, ten waves per workgroup at the M = 512 kernel's register
+// budget instead of five at twice that.
+// The hand-over is laid out so that no wave writes what the other still reads (A = [0, SUB), B = [SUB, 2 SUB) are the waves'
+// own regions of the row, SUB = 576): wave 0 leaves F0[n], n in [256, 512), at n (inside A); wave 1 leaves G[n] = W^-n F1[n],
+// n < 192, at SUB + n and n in [192, 256) at 1024 + (n - 192) (inside B, beyond the row's last value); after the barrier wave 0
+// writes [0, 256) and [512, 768), wave 1 [256, 512) and [768, 1024).
+template <typename F> struct SplitCfg {
+    static constexpr int M = 1024, MS = M / 2;
+    using PS = typename Fac<MS, 0>::type;                            // 512 = 8.8.8: E = 8, T = 64
+    static constexpr bool xs = strip_xs(MS, (int) sizeof(C2<F>), false, 8);
+    static constexpr int SUB = strip_xspan(MS, (int) sizeof(C2<F>), false, 8);
+    static constexpr int pitch = strip_pitch(2 * SUB, 13);
+    static constexpr int threads = 2 * 64 * STRIP_RW;
+    static constexpr size_t lds = (size_t) (MS + M + pitch * STRIP_RW) * sizeof(C2<F>);
+    static_assert(PS::T == 64 && PS::E == 8, "one wave per half row");
+    static_assert(SUB > MS && SUB + 192 <= 768 && 1024 + 64 <= 2 * SUB && 2 * SUB <= pitch, "the hand-over layout");
+};
+#ifndef FPM_RO_SPLIT_PF
+#define FPM_RO_SPLIT_PF 2
+#endif
+#ifndef FPM_RO_SPLIT_MINW32
+#define FPM_RO_SPLIT_MINW32 2
+#endif
+// VAR: 0 -- the LATE order of the long rows (a plane's rows requested right before their transform); 1 -- the rows a step
+// ahead (requested after the previous transform: they land during the gathers; E = 8 leaves the registers for it that the
+// E = 16 shape did not have); 2 -- rows and entries a step ahead
+template <typename F, bool PEN, int VAR = 0>
+__global__ __launch_bounds__((SplitCfg<F>::threads), (sizeof(F) == 8 ? 1 : FPM_RO_SPLIT_MINW32)) void readout_split_kernel(
+    MeshGeo g, int ncomp, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
+    const double *__restrict__ sy, const double *__restrict__ sz, const C2<F> *__restrict__ m0,
+    const C2<F> *__restrict__ m1, const C2<F> *__restrict__ m2, float *__restrict__ out, int nmemb, int memb0,
+    const double *__restrict__ tw_global, double *__restrict__ part_all, long long part_stride, const int2 *__restrict__ scell,
+    PenIO pen)
+{
+    using CF = SplitCfg<F>;
+    using PS = typename CF::PS;
+    constexpr int M = CF::M, MS = CF::MS, E = 8, NT = CF::threads, RP = CF::pitch, WP = 2 * RP, SUB = CF::SUB;
+    extern __shared__ __align__(16) unsigned char smem_st[];
+    C2<F> *tw = (C2<F> *) smem_st;                 // W_MS^j, j < MS
+    C2<F> *twn = tw + MS;                          // W_N^k, k < M (N = 2 M); W_M^n = twn[2 n]
+    C2<F> *S = twn + M;                            // RW rows of RP values: the waves' regions, then the real rows of the plane
+    const int tid = threadIdx.x, wv = tid >> 6, tau = tid & 63;
+    const int c = __builtin_amdgcn_readfirstlane(wv >> 1), r = __builtin_amdgcn_readfirstlane(wv & 1);
+    const int nseg = (g.xl + g.xseg - 1) / g.xseg;
+    const int t = xcd_remap(blockIdx.x, ncomp * g.ntyo * nseg);
+    const int comp = t % ncomp, strip = (t / ncomp) % g.ntyo, seg = nseg - 1 - t / (ncomp * g.ntyo);      // last segment first
+    const C2<F> *mesh = comp == 0 ? m0 : (comp == 1 ? m1 : m2);
+    double *part = part_all + comp * part_stride;
+    const int xa = seg * g.xseg, xb = min(xa + g.xseg, g.xl);
+    const int y0 = strip * STRIP_Y;
+    int gy = y0 + c;
+    gy -= gy >= g.N ? g.N : 0;
+    const C2<F> *rowbase = mesh + (long long) gy * g.rp;
+    const long long pstride = (long long) g.yplanes * g.rp;
+    C2<F> *row = S + c * RP, *sub = row + r * SUB;
+
+    C2<F> x[E], xm;
+    const int yrow = y0 + c;
+    const C2<F> *phx = PEN ? (const C2<F> *) pen.hx[comp] : nullptr, *phy = PEN ? (const C2<F> *) pen.hy[comp] : nullptr;
+    auto load_plane = [&](int xp) {                // the values of parity r of the row: k = 2 (tau + 64 j) + r
+        if (g.periodic_x) xp -= xp >= g.N ? g.N : 0;
+        if constexpr (PEN) {
+            const C2<F> *src;
+            bool chunked = false;
+            if (!g.periodic_x && xp == g.xl) src = phx + (long long) yrow * g.rp;
+            else if (yrow == g.ylr) src = phy + (long long) xp * g.rp;
+            else { src = mesh + ((long long) xp * g.ylr + yrow) * g.nzl; chunked = true; }
+            src = uniform_ptr(src);
+            const unsigned pjump = (unsigned) (pen.chunk - g.zblk);
+            // (a thread's 128 j .. 128 j + 127 cross at most one kz block boundary: zblk >= 128, host-checked)
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                const unsigned k = (unsigned) (128 * j + r + 2 * tau);
+                unsigned off = k;
+                if (chunked) {
+                    const unsigned B = ((unsigned) (128 * j) * pen.inv24) >> 24;
+                    off = k + (B + (k >= (B + 1) * (unsigned) g.zblk ? 1u : 0u)) * pjump;
+                }
+                x[j] = ld_stream(src + off);
+            }
+            xm = C2<F>{0, 0};
+            if (r == 0 && tau == 0) {
+                unsigned off = M;
+                if (chunked) off = M + (((unsigned) M * pen.inv24) >> 24) * pjump;
+                xm = src[off];
+            }
+            return;
+        }
+        const C2<F> *src = rowbase + (long long) xp * pstride + r;
+#pragma unroll
+        for (int j = 0; j < E; j++) x[j] = ld_stream(&src[2 * (tau + 64 * j)]);
+        xm = (r == 0 && tau == 0) ? src[M] : C2<F>{0, 0};
+    };
+    auto c2r_plane = [&]() {                       // x[] -> the RW real rows of the plane in S; one workgroup barrier inside
+        C2<F> v[vmax(E)];
+        // c2r_prepare on the values of one parity: element m = tau + 64 j of the wave is k = 2 m + r, its partner M - k is
+        // element MS - r - m (r = 0: m = 0 pairs with X[M], kept at MS)
+        if (r == 0 && tau == 0) { x[0].y = 0; xm.y = 0; }
+#pragma unroll
+        for (int j = 0; j < E; j++) sub[tau + 64 * j] = x[j];
+        if (r == 0 && tau == 0) sub[MS] = xm;
+        fft_sync<true>();
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const int m = tau + 64 * j;
+            const C2<F> a = x[j];
+            C2<F> bq = sub[MS - r - m];
+            bq.y = -bq.y;
+            const C2<F> s = cadd(a, bq), d = csub(a, bq);
+            const C2<F> wq = twn[2 * m + r];
+            const C2<F> o = cmul(C2<F>{wq.x, -wq.y}, d);               // conj W_N^k
+            v[in_slot<PS>(j)] = C2<F>{s.x - o.y, s.y + o.x};
+        }
+        fft_sync<true>();
+        fft_core<PS, +1, -RP, false, F, 0, true, CF::xs>(v, sub, tw, tau, 0);
+        // v[j] = Fr[n], n = tau + 64 j.  Wave 1: G = conj(W_M^n) F1
+        if (r) {
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                const C2<F> wq = twn[2 * (tau + 64 * j)];
+                v[j] = cmul(C2<F>{wq.x, -wq.y}, v[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++) row[SUB + tau + 64 * j] = v[j];
+            row[1024 + tau] = v[3];
+        } else {
+#pragma unroll
+            for (int j = 4; j < E; j++) row[tau + 64 * j] = v[j];
+        }
+        __syncthreads();
+        if (r) {
+            C2<F> f[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) f[j] = row[tau + 64 * (j + 4)];
+            fft_sync<true>();
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                row[tau + 64 * (j + 4)] = cadd(f[j], v[j + 4]);
+                row[MS + tau + 64 * (j + 4)] = csub(f[j], v[j + 4]);
+            }
+        } else {
+            C2<F> gq[4];
+#pragma unroll
+            for (int j = 0; j < 3; j++) gq[j] = row[SUB + tau + 64 * j];
+            gq[3] = row[1024 + tau];
+            fft_sync<true>();
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                row[tau + 64 * j] = cadd(v[j], gq[j]);
+                row[MS + tau + 64 * j] = csub(v[j], gq[j]);
+            }
+            if (tau == 0) row[M].x = v[0].x + gq[0].x;                 // value N of a row = value 0
+        }
+    };
+    // acc + the four corners of the window's plane (x bit `bx`), in the reference's order
+    const F *rs = (const F *) S;
+    auto half = [&](double qx, double qy, double qz, int qc, int bx, double acc) -> double {      // D and base cell of the entry
+        const StripEntry cc = strip_entry(g, qx, qy, qz, qc);
+        const int ly = cc.iy0 - y0, lz = cc.iz0;
+        const double wxb = bx ? cc.d[0] : cc.t[0];
+        const double wy[2] = {cc.t[1], cc.d[1]}, wz[2] = {cc.t[2], cc.d[2]};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int by = (k >> 1) & 1, bz = k & 1;
+            acc += (double) rs[(ly + by) * WP + lz + bz] * (wz[bz] * wxb * wy[by]);
+        }
+        return acc;
+    };
+    constexpr int PF = sizeof(F) == 8 && VAR ? 1 : FPM_RO_SPLIT_PF;       // (fp64 with the rows ahead: 59 spilled with two)
+    double px[PF + 1], py[PF + 1], pz[PF + 1], pv[PF + 1], qx[PF + 1], qy[PF + 1], qz[PF + 1];
+    int prow[PF + 1], qrow[PF + 1], pc[PF + 1], qc[PF + 1];
+    int pb = 0, pn = 0, qb = 0, qn = 0;            // p: the particles that finish this step; q: those that start
+    int kb_next = 0, kn_next = 0;
+    auto fetch_key = [&](int xi) {
+        const int key = xi * g.nty + strip;
+        kb_next = tbeg[key];
+        kn_next = tcnt[key];
+    };
+    auto fetch_q = [&](int xi) {
+        qb = kb_next;
+        qn = kn_next;
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int e = tid + u * NT;
+            qx[u] = qy[u] = qz[u] = 0;
+            qrow[u] = qc[u] = 0;
+            if (e < qn) {
+                qx[u] = ENT_X(qb + e); qy[u] = ENT_Y(qb + e); qz[u] = ENT_Z(qb + e);
+                const int2 rc = ENT_RC(qb + e);                     // (row, base cell)
+                qrow[u] = rc.x; qc[u] = rc.y;
+            }
+        }
+        if (xi + 1 < xb) fetch_key(xi + 1);
+    };
+    auto start_q = [&]() {                         // q -> p with the first four terms
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            px[u] = qx[u]; py[u] = qy[u]; pz[u] = qz[u]; prow[u] = qrow[u]; pc[u] = qc[u];
+            pv[u] = tid + u * NT < qn ? half(qx[u], qy[u], qz[u], qc[u], 0, 0.0) : 0.0;
+        }
+        for (int e = tid + PF * NT; e < qn; e += NT) part[qb + e] = half(ENT_X(qb + e), ENT_Y(qb + e), ENT_Z(qb + e), ENT_RC(qb + e).y, 0, 0.0);
+        pb = qb;
+        pn = qn;
+    };
+    auto finish_p = [&]() {
+#pragma unroll
+        for (int u = 0; u < PF; u++)
+            if (tid + u * NT < pn) out[(long long) prow[u] * nmemb + memb0 + comp] = (float) half(px[u], py[u], pz[u], pc[u], 1, pv[u]);
+        for (int e = tid + PF * NT; e < pn; e += NT) {
+            const int2 rc = ENT_RC(pb + e);
+            out[(long long) rc.x * nmemb + memb0 + comp] = (float) half(ENT_X(pb + e), ENT_Y(pb + e), ENT_Z(pb + e), rc.y, 1, part[pb + e]);
+        }
+    };
+
+    load_plane(xa);
+    fetch_key(xa);
+    fetch_q(xa);
+    stage_twiddles(tw, tw_global, MS, 4);
+    stage_twiddles(twn, tw_global, M, 1);
+    __syncthreads();
+    c2r_plane();
+    __syncthreads();
+    if (VAR) load_plane(xa + 1);
+    start_q();
+    for (int i = xa; i < xb; i++) {                // the window goes from plane i to plane i + 1
+        if (VAR == 2 && i + 1 < xb) fetch_q(i + 1);
+        if (!VAR) load_plane(i + 1);
+        __syncthreads();                           // every gather from plane i is done
+        c2r_plane();
+        __syncthreads();
+        if (VAR != 2 && i + 1 < xb) fetch_q(i + 1);
+        if (VAR && i + 1 < xb) load_plane(i + 2);  // lands during the gathers
+        finish_p();
+        if (i + 1 < xb) start_q();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// M = 1536 in fp32 (the 3072^3 mesh of configs[4] at B = 3): THREE WAVES per row, joined once (round 6)
+// ------------------------------------------------------------------------------------------------------------------
+// The same split by three: Z[n + 512 q] = F0[n] + w^q W_M^-n F1[n] + w^2q W_M^-2n F2[n], w = e^(2 pi i / 3), Fr the 512-point
+// transform of Z'[3 m + r].  The partner M - k of k = 3 m + r has residue 3 - r: waves 1 and 2 of a row need each other's
+// values, so the rows pass through LDS once more -- and fp32 has the room for a second area (148 KB in all): the WINDOW area
+// takes the half-spectrum rows as they are loaded (contiguous, coalesced), after a barrier every wave picks its residue class
+// and its partners out of it, the transforms and the hand-over live in the WORK area (a region of SUB values per wave), and
+// after the join barrier wave q writes block q of the real row into the window area -- nothing is ever written where another
+// wave may still read.  Four workgroup barriers per plane, fifteen waves per workgroup at <= 128 VGPRs instead of five at 252.
+struct Split3Cfg {
+    static constexpr int M = 1536, MS = 512;
+    using PS = typename Fac<MS, 0>::type;
+    static constexpr bool xs = strip_xs(MS, 8, false, 8);
+    static constexpr int SUB = strip_xspan(MS, 8, false, 8);
+    static constexpr int wpitch = 3 * SUB;                            // work area: a row's three regions
+    static constexpr int pitch = strip_pitch(M + 1, 13);             // window area: the rows the gathers read
+    static constexpr int threads = 3 * 64 * STRIP_RW;
+    static constexpr size_t lds = (size_t) (MS + M + (wpitch + pitch) * STRIP_RW) * sizeof(C2<float>);
+    static_assert(PS::T == 64 && PS::E == 8 && lds <= 160 * 1024, "one wave per third of a row; both areas in LDS");
+};
+template <bool PEN, int VAR>
+__global__ __launch_bounds__((Split3Cfg::threads), 4) void readout_split3_kernel(
+    MeshGeo g, int ncomp, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
+    const double *__restrict__ sy, const double *__restrict__ sz, const C2<float> *__restrict__ m0,
+    const C2<float> *__restrict__ m1, const C2<float> *__restrict__ m2, float *__restrict__ out, int nmemb, int memb0,
+    const double *__restrict__ tw_global, double *__restrict__ part_all, long long part_stride, const int2 *__restrict__ scell,
+    PenIO pen)
+{
+    using F = float;
+    using CF = Split3Cfg;
+    using PS = typename CF::PS;
+    constexpr int M = CF::M, MS = CF::MS, E = 8, NT = CF::threads, RP = CF::pitch, WP = 2 * RP, SUB = CF::SUB;
+    extern __shared__ __align__(16) unsigned char smem_st[];
+    C2<F> *tw = (C2<F> *) smem_st;                 // W_MS^j, j < MS
+    C2<F> *twn = tw + MS;                          // W_N^k, k < M (N = 2 M); W_N^(k + M) = -W_N^k
+    C2<F> *WIN = twn + M;                          // RW rows of RP values: the rows as loaded, then the real rows of the plane
+    C2<F> *WORK = WIN + RP * STRIP_RW;             // RW rows of three regions
+    const int tid = threadIdx.x, wv = tid >> 6, tau = tid & 63;
+    const int c = __builtin_amdgcn_readfirstlane(wv / 3), r = __builtin_amdgcn_readfirstlane(wv % 3);
+    const int nseg = (g.xl + g.xseg - 1) / g.xseg;
+    const int t = xcd_remap(blockIdx.x, ncomp * g.ntyo * nseg);
+    const int comp = t % ncomp, strip = (t / ncomp) % g.ntyo, seg = nseg - 1 - t / (ncomp * g.ntyo);      // last segment first
+    const C2<F> *mesh = comp == 0 ? m0 : (comp == 1 ? m1 : m2);
+    double *part = part_all + comp * part_stride;
+    const int xa = seg * g.xseg, xb = min(xa + g.xseg, g.xl);
+    const int y0 = strip * STRIP_Y;
+    int gy = y0 + c;
+    gy -= gy >= g.N ? g.N : 0;
+    const C2<F> *rowbase = mesh + (long long) gy * g.rp;
+    const long long pstride = (long long) g.yplanes * g.rp;
+    C2<F> *win = WIN + c * RP, *wrow = WORK + c * CF::wpitch, *sub = wrow + r * SUB;
+
+    C2<F> x[E], xm;
+    const int yrow = y0 + c;
+    const C2<F> *phx = PEN ? (const C2<F> *) pen.hx[comp] : nullptr, *phy = PEN ? (const C2<F> *) pen.hy[comp] : nullptr;
+    auto load_plane = [&](int xp) {                // the r-th third of the row, as it lies: k = 512 r + tau + 64 j
+        if (g.periodic_x) xp -= xp >= g.N ? g.N : 0;
+        if constexpr (PEN) {
+            const C2<F> *src;
+            bool chunked = false;
+            if (!g.periodic_x && xp == g.xl) src = phx + (long long) yrow * g.rp;
+            else if (yrow == g.ylr) src = phy + (long long) xp * g.rp;
+            else { src = mesh + ((long long) xp * g.ylr + yrow) * g.nzl; chunked = true; }
+            src = uniform_ptr(src);
+            const unsigned pjump = (unsigned) (pen.chunk - g.zblk);
+#pragma unroll
+            for (int j = 0; j < E; j++)
+                x[j] = ld_stream(pen_elem<64, F, true>(const_cast<C2<F> *>(src), chunked, MS * r + 64 * j, tau, g.zblk, pen.inv24, pjump));
+            xm = (r == 0 && tau == 0) ? *pen_elem<64, F, true>(const_cast<C2<F> *>(src), chunked, M, 0, g.zblk, pen.inv24, pjump) : C2<F>{0, 0};
+            return;
+        }
+        const C2<F> *src = rowbase + (long long) xp * pstride + MS * r;
+#pragma unroll
+        for (int j = 0; j < E; j++) x[j] = ld_stream(&src[tau + 64 * j]);
+        xm = (r == 0 && tau == 0) ? src[M] : C2<F>{0, 0};
+    };
+    auto c2r_plane = [&]() {                       // x[] -> the RW real rows of the plane in WIN; two workgroup barriers inside
+        C2<F> v[vmax(E)];
+        if (r == 0 && tau == 0) { x[0].y = 0; xm.y = 0; }
+#pragma unroll
+        for (int j = 0; j < E; j++) win[MS * r + tau + 64 * j] = x[j];
+        if (r == 0 && tau == 0) win[M] = xm;
+        __syncthreads();
+        // c2r_prepare on the residue class r: element m = tau + 64 j is k = 3 m + r, its partner M - k (k = 0: X[M])
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const int k = 3 * (tau + 64 * j) + r;
+            const C2<F> a = win[k];
+            C2<F> bq = win[M - k];
+            bq.y = -bq.y;
+            const C2<F> s = cadd(a, bq), d = csub(a, bq);
+            const C2<F> wq = twn[k];
+            const C2<F> o = cmul(C2<F>{wq.x, -wq.y}, d);               // conj W_N^k
+            v[in_slot<PS>(j)] = C2<F>{s.x - o.y, s.y + o.x};
+        }
+        fft_core<PS, +1, -RP, false, F, 0, true, CF::xs>(v, sub, tw, tau, 0);
+        // v[j] = Fr[n], n = tau + 64 j; waves 1, 2: times conj(W_M^(r n)) = conj(W_N^(2 r n))
+        if (r) {
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                const int idx = 2 * r * (tau + 64 * j);                // < 2048: beyond M the table repeats with the sign changed
+                const bool hi = idx >= M;
+                C2<F> wq = twn[hi ? idx - M : idx];
+                if (hi) { wq.x = -wq.x; wq.y = -wq.y; }
+                v[j] = cmul(C2<F>{wq.x, -wq.y}, v[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < E; j++) sub[tau + 64 * j] = v[j];
+        __syncthreads();                           // (every wave has also read what it needed from the window area)
+        // wave q writes block q of the real row: F0 + w^q G1 + w^2q G2
+        {
+            const F h3 = (F) 0.86602540378443864676;
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                const int n = tau + 64 * j;
+                const C2<F> f0 = r == 0 ? v[j] : wrow[n];
+                const C2<F> g1 = r == 1 ? v[j] : wrow[SUB + n];
+                const C2<F> g2 = r == 2 ? v[j] : wrow[2 * SUB + n];
+                const C2<F> sm = cadd(g1, g2), df = csub(g1, g2);
+                C2<F> o;
+                if (r == 0) o = cadd(f0, sm);
+                else {
+                    const F sg = r == 1 ? h3 : -h3;                     // +- i (sqrt 3 / 2) (g1 - g2)
+                    o = C2<F>{f0.x - (F) 0.5 * sm.x - sg * df.y, f0.y - (F) 0.5 * sm.y + sg * df.x};
+                }
+                win[MS * r + n] = o;
+                if (r == 0 && j == 0 && tau == 0) win[M].x = o.x;      // value N of a row = value 0
+            }
+        }
+    };
+    // acc + the four corners of the window's plane (x bit `bx`), in the reference's order
+    const F *rs = (const F *) WIN;
+    auto half = [&](double qx, double qy, double qz, int qc, int bx, double acc) -> double {      // D and base cell of the entry
+        const StripEntry cc = strip_entry(g, qx, qy, qz, qc);
+        const int ly = cc.iy0 - y0, lz = cc.iz0;
+        const double wxb = bx ? cc.d[0] : cc.t[0];
+        const double wy[2] = {cc.t[1], cc.d[1]}, wz[2] = {cc.t[2], cc.d[2]};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int by = (k >> 1) & 1, bz = k & 1;
+            acc += (double) rs[(ly + by) * WP + lz + bz] * (wz[bz] * wxb * wy[by]);
+        }
+        return acc;
+    };
+    constexpr int PF = 1;                          // (960 threads: configs[4]'s 569 entries per plane and strip)
+    double px[PF + 1], py[PF + 1], pz[PF + 1], pv[PF + 1], qx[PF + 1], qy[PF + 1], qz[PF + 1];
+    int prow[PF + 1], qrow[PF + 1], pc[PF + 1], qc[PF + 1];
+    int pb = 0, pn = 0, qb = 0, qn = 0;            // p: the particles that finish this step; q: those that start
+    int kb_next = 0, kn_next = 0;
+    auto fetch_key = [&](int xi) {
+        const int key = xi * g.nty + strip;
+        kb_next = tbeg[key];
+        kn_next = tcnt[key];
+    };
+    auto fetch_q = [&](int xi) {
+        qb = kb_next;
+        qn = kn_next;
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int e = tid + u * NT;
+            qx[u] = qy[u] = qz[u] = 0;
+            qrow[u] = qc[u] = 0;
+            if (e < qn) {
+                qx[u] = ENT_X(qb + e); qy[u] = ENT_Y(qb + e); qz[u] = ENT_Z(qb + e);
+                const int2 rc = ENT_RC(qb + e);                     // (row, base cell)
+                qrow[u] = rc.x; qc[u] = rc.y;
+            }
+        }
+        if (xi + 1 < xb) fetch_key(xi + 1);
+    };
+    auto start_q = [&]() {                         // q -> p with the first four terms
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            px[u] = qx[u]; py[u] = qy[u]; pz[u] = qz[u]; prow[u] = qrow[u]; pc[u] = qc[u];
+            pv[u] = tid + u * NT < qn ? half(qx[u], qy[u], qz[u], qc[u], 0, 0.0) : 0.0;
+        }
+        for (int e = tid + PF * NT; e < qn; e += NT) part[qb + e] = half(ENT_X(qb + e), ENT_Y(qb + e), ENT_Z(qb + e), ENT_RC(qb + e).y, 0, 0.0);
+        pb = qb;
+        pn = qn;
+    };
+    auto finish_p = [&]() {
+#pragma unroll
+        for (int u = 0; u < PF; u++)
+            if (tid + u * NT < pn) out[(long long) prow[u] * nmemb + memb0 + comp] = (float) half(px[u], py[u], pz[u], pc[u], 1, pv[u]);
+        for (int e = tid + PF * NT; e < pn; e += NT) {
+            const int2 rc = ENT_RC(pb + e);
+            out[(long long) rc.x * nmemb + memb0 + comp] = (float) half(ENT_X(pb + e), ENT_Y(pb + e), ENT_Z(pb + e), rc.y, 1, part[pb + e]);
+        }
+    };
+
+    load_plane(xa);
+    fetch_key(xa);
+    fetch_q(xa);
+    stage_twiddles(tw, tw_global, MS, 6);
+    stage_twiddles(twn, tw_global, M, 1);
+    __syncthreads();
+    c2r_plane();
+    __syncthreads();
+    if (VAR) load_plane(xa + 1);
+    start_q();
+    for (int i = xa; i < xb; i++) {                // the window goes from plane i to plane i + 1
+        if (VAR == 2 && i + 1 < xb) fetch_q(i + 1);
+        if (!VAR) load_plane(i + 1);
+        __syncthreads();                           // every gather from plane i is done
+        c2r_plane();
+        __syncthreads();
+        if (VAR != 2 && i + 1 < xb) fetch_q(i + 1);
+        if (VAR && i + 1 < xb) load_plane(i + 2);  // lands during the gathers
+        finish_p();
+        if (i + 1 < xb) start_q();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // fp32 on the long rows: TWO ROWS per wave (round 5; M = 1024 and 1536, the 2048^3 / 3072^3 meshes of configs[3] / [4])
 // ------------------------------------------------------------------------------------------------------------------
 // At M >= 1024 a row is one wave with E = 16 / 24 values per thread, and the fp32 kernel issued as many instructions per
@@ -1548,6 +2011,28 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
             (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride,          \
             p->scell, pen);                                                                                            \
     }
+#define CALL_RO_SPLIT3(PEN_, VAR_)                                                                                     \
+    {                                                                                                                  \
+        using CS = Split3Cfg;                                                                                          \
+        static int occs3 = 0;                                                                                          \
+        FPM_TRY(grant_lds(readout_split3_kernel<PEN_, VAR_>, CS::lds, p->device));                                     \
+        g.xseg = choose_xseg(g, readout_split3_kernel<PEN_, VAR_>, CS::threads, CS::lds, ncomp * g.ntyo, 16, 128, &occs3); \
+        const int nseg = (g.xl + g.xseg - 1) / g.xseg;                                                                 \
+        readout_split3_kernel<PEN_, VAR_><<<ncomp * g.ntyo * nseg, CS::threads, CS::lds, p->stream>>>(                 \
+            g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, (const C2<float> *) k0, (const C2<float> *) k1,  \
+            (const C2<float> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride, p->scell, pen);          \
+    }
+#define CALL_RO_SPLIT(PEN_, VAR_)                                                                                      \
+    {                                                                                                                  \
+        using CS = SplitCfg<F>;                                                                                        \
+        static int occs = 0;                                                                                           \
+        FPM_TRY(grant_lds(readout_split_kernel<F, PEN_, VAR_>, CS::lds, p->device));                                   \
+        g.xseg = choose_xseg(g, readout_split_kernel<F, PEN_, VAR_>, CS::threads, CS::lds, ncomp * g.ntyo, 16, 128, &occs); \
+        const int nseg = (g.xl + g.xseg - 1) / g.xseg;                                                                 \
+        readout_split_kernel<F, PEN_, VAR_><<<ncomp * g.ntyo * nseg, CS::threads, CS::lds, p->stream>>>(               \
+            g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, (const C2<F> *) k0, (const C2<F> *) k1,          \
+            (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride, p->scell, pen);              \
+    }
 /* fp32, M = 1024 / 1536: two rows per wave (readout_march_rows2_kernel): FPMHIP_RO_ROWS2 = 1 (A/B; measured slower) */ \
 #define CALL_RO_ROWS2(PX)                                                                                              \
     {                                                                                                                  \
@@ -1577,6 +2062,17 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
             break;                                                                                                     \
         }                                                                                                              \
     }                                                                                                                  \
+    if constexpr (PL::N == 1536 && sizeof(F) == 4) {                                                                   \
+        /* three waves per row, joined once (readout_split3_kernel): FPMHIP_RO_SPLIT = 0 | 1 | 2 | 3, default 3 */     \
+        static const int split3_env = getenv("FPMHIP_RO_SPLIT") ? atoi(getenv("FPMHIP_RO_SPLIT")) : 3;                 \
+        if (split3_env && !two_planes && ws_env != 0) {                                                                \
+            if (pen.on) CALL_RO_SPLIT3(true, 0) /* (rows ahead on pencils: 9 - 15 VGPRs spilled) */                    \
+            else if (split3_env == 2) CALL_RO_SPLIT3(false, 1)                                                         \
+            else if (split3_env == 3) CALL_RO_SPLIT3(false, 2)                                                         \
+            else CALL_RO_SPLIT3(false, 0)                                                                              \
+            break;                                                                                                     \
+        }                                                                                                              \
+    }                                                                                                                  \
     if constexpr (PL::N == 1536) {                                                                                     \
         static const int e24_env = getenv("FPMHIP_RO_E24") ? atoi(getenv("FPMHIP_RO_E24")) : 1;                        \
         if (e24_env && !two_planes && ws_env != 0) {                                                                   \
@@ -1587,6 +2083,16 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
         }                                                                                                              \
     }                                                                                                                  \
     if constexpr (PL::N == 1024) {                                                                                     \
+        /* two waves per row, joined once (readout_split_kernel): FPMHIP_RO_SPLIT = 0 (one wave per row) | 1 | 2 | 3 (the  */ \
+        /* kernel's VAR + 1); default: fp32 3, fp64 0 (measured: profiles/r06_split_readout_ab.md)                          */ \
+        static const int split_env = getenv("FPMHIP_RO_SPLIT") ? atoi(getenv("FPMHIP_RO_SPLIT")) : (sizeof(F) == 4 ? 3 : 0); \
+        if (split_env && !two_planes && ws_env != 0 && (!pen.on || g.zblk >= 128)) {                                   \
+            if (pen.on) { if (split_env == 1) CALL_RO_SPLIT(true, 0) else CALL_RO_SPLIT(true, (sizeof(F) == 4 ? 2 : 0)) } \
+            else if (split_env == 2) CALL_RO_SPLIT(false, 1)                                                           \
+            else if (split_env == 3) CALL_RO_SPLIT(false, 2)                                                           \
+            else CALL_RO_SPLIT(false, 0)                                                                               \
+            break;                                                                                                     \
+        }                                                                                                              \
         static const int e16_env = getenv("FPMHIP_RO_E16") ? atoi(getenv("FPMHIP_RO_E16")) : 1;                        \
         if (e16_env && !two_planes && ws_env != 0) {                                                                   \
             using PX = FFTPlan<1024, 16, 16, 8, 8, 1>;                                                                 \
@@ -1600,6 +2106,8 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
 #undef CALL_RO
 #undef CALL_RO_E16
 #undef CALL_RO_ROWS2
+#undef CALL_RO_SPLIT
+#undef CALL_RO_SPLIT3
 #undef CALL_RO_W
 #undef CALL_RO_P
     FPM_CHECK_HIP(hipGetLastError());

@@ -9,11 +9,14 @@ oracle is too slow to be a unit test at that size:
   * decomposition invariance: 2 virtual slab ranks reproduce the one-rank accelerations,
   * the fp32-mesh build agrees with the fp64-mesh build: acc to 1e-4 of rms, P(k) to < 1 % up to
     k_Nyquist / 2 (the metric's accuracy half, BASELINE.json north_star)."""
+import os
+
 import numpy as np
 import pytest
 
 import util
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
@@ -201,6 +204,35 @@ def test_one_rank_of_the_8_gpu_configs_at_full_per_rank_size(N, precision, ncube
     assert err <= tol, err
 
 
+@pytest.mark.parametrize("N,precision,ncube,split,tol", [
+    (2048, 32, 0, 0, 3e-5),      # the one-wave-per-row shape (E = 16), the default until round 6
+    (2048, 32, 0, 1, 3e-5),      # two waves per row, the LATE order
+    (2048, 32, 0, 2, 3e-5),      #   ... rows a step ahead (3, rows and entries ahead, is the default: the test above)
+    (2048, 64, 0, 1, 1e-6),      # fp64: two waves per row is an A/B (12.9 against 12.8 ms), the default stays one wave per row
+    (3072, 32, 128, 0, 3e-5),    # M = 1536: one wave per row, E = 24
+    (3072, 32, 128, 1, 3e-5),    #   three waves per row, LATE
+    (3072, 32, 128, 2, 3e-5),
+])
+def test_the_readout_shapes_of_the_long_rows_at_per_rank_size(N, precision, ncube, split, tol):
+    """FPMHIP_RO_SPLIT (read once per process: a child running tools/rank_share_bench.py): every shape of the marching readout
+    at M = 1024 / 1536 -- one wave per row, and the several-waves-per-row kernels of round 6 in their three orders -- against
+    the small cube at the slab's true geometry and load."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    need = 7.5 * (N // 8) * N * (N + 2) * (precision // 8) + 100.0 * (N // 16) ** 3 * 64
+    if free < need:
+        pytest.skip("needs %.0f GB of device memory" % (need / 1e9))
+    torch.cuda.empty_cache()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rank_share_bench.py"), str(N), str(precision), str(ncube)],
+                       env=dict(os.environ, FPMHIP_RO_SPLIT=str(split)), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["parity_vs_small_cube"] <= tol, d["parity_vs_small_cube"]
+
+
 # ---- configs[3] / configs[4] as SEQUENCES at per-rank size (tests/rank_share.py::run_rank_share_sequence) ----
 def _need_bytes(N, precision, np_slab):
     return 7.6 * (N // 8) * N * (N + 2) * (precision // 8) + 120.0 * np_slab
@@ -256,13 +288,15 @@ def test_config4_variable_mesh_steps_with_pk_at_per_rank_size(tmp_path):
 
 
 @pytest.mark.parametrize("N,precision,paint_mode", [(256, 64, 3), (256, 64, 2), (256, 32, 3), (1024, 64, 0), (2048, 64, 0),
-                                                     (3072, 32, 3)])
+                                                     (2048, 32, 0), (3072, 32, 0)])
 def test_one_pencil_rank_of_the_4x2_mesh_at_per_rank_size(N, precision, paint_mode):
     """Rank (1, 1) of the reference's 4 x 2 process mesh (pmpfft.c:117-136) in a universe periodic with period L/4
     (tests/rank_share.py: ReplicatedPencilForce): every stage kernel at the brick's true geometry -- at N = 1024 that of
     configs[2] on pencils, 16.8 M particles, strip tiles (the marching kernels on the exchange chunks), at N = 2048 that of
-    configs[3], 134 M particles, 4.3 GB per kz block (element offsets in the kernels, one wave per row of 1024 values) -- and the
-    accelerations of all 8 copies of the cube equal to the small cubic problem's."""
+    configs[3], 134 M particles, 4.3 GB per kz block (element offsets in the kernels, one wave per row of 1024 values in fp64, two
+    waves per row in fp32: readout_split_kernel on the exchange chunks), at N = 3072 in fp32 three waves per row
+    (readout_split3_kernel), strip tiles by default there since round 6 -- and the accelerations of all 8 copies of the cube equal
+    to the small cubic problem's."""
     import torch
     import rank_share
     import gc
@@ -278,7 +312,7 @@ def test_one_pencil_rank_of_the_4x2_mesh_at_per_rank_size(N, precision, paint_mo
         pytest.skip("needs %.0f GB of free device memory" % (need / 1e9))
     acc, ref, _, copies, strips = rank_share.run_pencil_share(N, 4, 2, precision, paint_mode=paint_mode,
                                                               ncube=128 if N == 3072 else None)
-    assert strips == (paint_mode != 2)             # (3072 on pencils: box tiles by default since round 6 -- asked for here)
+    assert strips == (paint_mode != 2)
     n = ref.shape[0]
     rms = float(ref.double().pow(2).mean().sqrt())
     err = float((acc.view(copies, n, 3).double() - ref.double()[None]).abs().max()) / rms

@@ -347,12 +347,13 @@ def test_strip_tiles_on_the_reference_4x2_mesh_at_128(oracle):
 
 
 def test_the_default_tiles_of_a_pencil_rank_follow_the_measurement():
-    """Round 6 (profiles/r06_rankshare_pencil_3072_32_256*.json: one rank of the 4 x 2 mesh at configs[4]'s load, strips 132.6 ms,
-    boxes 124.9 ms): at N = 3072 a pencil plan takes box tiles unless strip tiles are asked for; at 1024 / 2048 it takes
-    strips.  Plans only (mesh buffers are made on first use)."""
+    """Round 6 (profiles/r06_split_readout_ab.md: one rank of the 4 x 2 mesh at configs[4]'s load): at N = 3072 a pencil plan in
+    fp32 takes strip tiles (109.0 ms per step against 124.5 with box tiles, since the three-waves-per-row readout; 131.6 before it),
+    in fp64 -- no such kernel, no measurement that fits one GPU -- box tiles unless strip tiles are asked for; at 1024 / 2048 it
+    takes strips.  Plans only (mesh buffers are made on first use)."""
     from fastpm_amd import PM
-    for N, precision, mode, want in ((3072, 32, 0, False), (3072, 32, 3, True), (2048, 64, 0, True), (1024, 64, 0, True),
-                                     (3072, 32, 2, False)):
+    for N, precision, mode, want in ((3072, 32, 0, True), (3072, 32, 3, True), (3072, 64, 0, False), (3072, 64, 3, True),
+                                     (2048, 64, 0, True), (1024, 64, 0, True), (3072, 32, 2, False)):
         pm = PM(N, 3.0 * N / 2, precision, nranks=8, rank=3, nranks_y=2, paint_mode=mode)
         assert pm.strips() == want, (N, precision, mode)
         pm.destroy()
