@@ -2085,7 +2085,9 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
     if constexpr (PL::N == 1024) {                                                                                     \
         /* two waves per row, joined once (readout_split_kernel): FPMHIP_RO_SPLIT = 0 (one wave per row) | 1 | 2 | 3 (the  */ \
         /* kernel's VAR + 1); default: fp32 3, fp64 0 (measured: profiles/r06_split_readout_ab.md)                          */ \
-        static const int split_env = getenv("FPMHIP_RO_SPLIT") ? atoi(getenv("FPMHIP_RO_SPLIT")) : (sizeof(F) == 4 ? 3 : 0); \
+        /* (FPMHIP_RO_E16 = 0 alone still selects the round-4 shape, E = 8 through workgroup barriers)                      */ \
+        static const int split_env = getenv("FPMHIP_RO_SPLIT") ? atoi(getenv("FPMHIP_RO_SPLIT"))                       \
+                                     : (getenv("FPMHIP_RO_E16") && atoi(getenv("FPMHIP_RO_E16")) == 0) ? 0 : (sizeof(F) == 4 ? 3 : 0); \
         if (split_env && !two_planes && ws_env != 0 && (!pen.on || g.zblk >= 128)) {                                   \
             if (pen.on) { if (split_env == 1) CALL_RO_SPLIT(true, 0) else CALL_RO_SPLIT(true, (sizeof(F) == 4 ? 2 : 0)) } \
             else if (split_env == 2) CALL_RO_SPLIT(false, 1)                                                           \
