@@ -352,6 +352,218 @@ __global__ __launch_bounds__((StripCfg<PL, F>::pt_threads), (sizeof(F) == 4 && P
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// the paint of the long rows, M = 1024 / 1536: several waves per row, split once (round 6)
+// ------------------------------------------------------------------------------------------------------------------
+// The forward twin of readout_split_kernel.  A row of M = 512 P complex values took T = 64 P threads through workgroup barriers
+// at every stage of its r2c transform; here the M-point forward transform is split by decimation in FREQUENCY: wave q of a row
+// forms  y_q[n] = W_M^(n q) sum_s w_P^(s q) z[n + 512 s]  straight from the finished accumulators (every wave reads the whole
+// row), and after ONE barrier -- the accumulators have been read, their memory is the transforms' now -- runs the wave-local
+// 512-point transform in its own part of the row: Z[P m + q].  The r2c untangle pairs k with M - k: for P = 2 inside the wave,
+// for P = 3 between waves 1 and 2 (one more barrier pair).  Every wave then clears its own part of the row.  Workgroup barriers
+// per plane: 3 (P = 2) / 5 (P = 3) instead of 11 - 13; the stores are strided by P values (the waves of a row complete each
+// other's lines in L2).
+template <typename F, int P> struct PaintSplitCfg {
+    static constexpr int M = 512 * P, MS = 512;
+    using PS = typename Fac<MS, 0>::type;
+    using PR = typename Fac<M, 0>::type;
+    static constexpr int WP = StripCfg<PR, F>::pt_pitch;                       // doubles per window row
+    static constexpr int part = (WP / P) & ~1;                                  // a wave's part of a row, in doubles (16-byte aligned)
+    // the wave's transform region inside its part: skewed (SUB = 576 values) where that fits
+    static constexpr bool xs = strip_xs(MS, (int) sizeof(C2<F>), true, 8) && (size_t) strip_xspan(MS, (int) sizeof(C2<F>), true, 8) * sizeof(C2<F>) <= (size_t) part * 8;
+    static constexpr int threads = 64 * P * STRIP_Y;
+    static constexpr size_t twb = (size_t) (MS + M) * sizeof(C2<F>);
+    static constexpr size_t lds = twb + (size_t) STRIP_Y * WP * sizeof(double);
+    static_assert(PS::T == 64 && PS::E == 8 && (size_t) MS * sizeof(C2<F>) <= (size_t) part * 8 && 2 * M <= WP, "a wave's region inside its part of the row");
+};
+template <typename F, int P, bool PEN>
+__global__ __launch_bounds__((PaintSplitCfg<F, P>::threads), (sizeof(F) == 4 && P == 2 ? 4 : sizeof(F) == 4 ? 3 : 2)) void paint_split_kernel(
+    MeshGeo g, int ntiles, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
+    const double *__restrict__ sy, const double *__restrict__ sz, const float *__restrict__ smass, double M0, double scale_arg,
+    void *__restrict__ out_, const double *__restrict__ tw_global, const int2 *__restrict__ scell, PenIO pen)
+{
+    using CF = PaintSplitCfg<F, P>;
+    using PS = typename CF::PS;
+    const double scale = paint_scale(g, scale_arg);
+    constexpr int M = CF::M, MS = CF::MS, E = 8, NT = CF::threads, WP = CF::WP, SLOT = STRIP_Y * WP;
+    extern __shared__ __align__(16) unsigned char smem_st[];
+    C2<F> *tw = (C2<F> *) smem_st;                 // W_MS^j, j < MS
+    C2<F> *twn = tw + MS;                          // W_N^k, k < M (N = 2 M); W_N^(k + M) = -W_N^k
+    C2<F> *out = (C2<F> *) out_;
+    double *A = (double *) (smem_st + CF::twb);    // [STRIP_Y][WP]
+    const int tid = threadIdx.x, wv = tid >> 6, tau = tid & 63;
+    const int c = __builtin_amdgcn_readfirstlane(wv / P), q = __builtin_amdgcn_readfirstlane(wv % P);
+    const int nseg = (g.xl + g.xseg - 1) / g.xseg;
+    const int t = xcd_remap(blockIdx.x, g.nty * nseg);
+    const int strip = t % g.nty, seg = t / g.nty;
+    const int xa = seg * g.xseg, xb = min(xa + g.xseg, g.xl);
+    const int y0 = strip * STRIP_Y;
+    double *Arow = A + c * WP;
+    C2<F> *region = (C2<F> *) (Arow + q * CF::part);                 // this wave's transform region
+    auto region_of = [&](int qq) -> C2<F> * { return (C2<F> *) (Arow + qq * CF::part); };
+
+    for (int i = tid; i < SLOT; i += NT) A[i] = 0;
+    stage_twiddles(tw, tw_global, MS, 2 * P);
+    stage_twiddles(twn, tw_global, M, 1);
+
+    // the four corners with x bit `bx` of one entry (its D in q*, base cell in qc) into the window
+    auto add_half = [&](double qx, double qy, double qz, float qm, int qc, int bx) {
+        StripEntry e = strip_entry(g, qx, qy, qz, qc);
+        const double w = smass ? (M0 + qm) : M0;            // store.c:119-128
+        e.d[1] *= w;                                         // painter-cic.c:78-79
+        e.t[1] *= w;
+        const int ly[2] = {e.iy0 - y0, e.iy1 - y0};
+        const int lz[2] = {e.iz0, e.iz1};
+        const double wxb = bx ? e.d[0] : e.t[0], wy[2] = {e.t[1], e.d[1]}, wz[2] = {e.t[2], e.d[2]};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int by = (k >> 1) & 1, bz = k & 1;
+            if ((unsigned) ly[by] < (unsigned) STRIP_Y)
+                atomicAdd(&A[ly[by] * WP + lz[bz]], wz[bz] * wxb * wy[by]);        // painter-cic.c:84-107: Wz*Wx*Wy
+        }
+    };
+    constexpr int PF_OWN = 2, PF_DUP = 1, PF = PF_OWN + PF_DUP;
+    struct Ent {
+        double x[PF], y[PF], z[PF];
+        float m[PF];
+        int cell[PF];
+        int beg[2], cnt[2];
+    };
+    Ent cur, prev;
+    auto fetch = [&](Ent &e, int xi) {
+#pragma unroll
+        for (int part = 0; part < 2; part++) {
+            const int key = part * ntiles + xi * g.nty + strip;
+            e.beg[part] = tbeg[key];
+            e.cnt[part] = tcnt[key];
+        }
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int part = u < PF_OWN ? 0 : 1, r = u < PF_OWN ? u : u - PF_OWN;
+            const int k = tid + r * NT;
+            e.x[u] = e.y[u] = e.z[u] = 0;
+            e.m[u] = 0;
+            e.cell[u] = 0;
+            if (k < e.cnt[part]) {
+                const int s_ = e.beg[part] + k;
+                e.x[u] = ENT_X(s_); e.y[u] = ENT_Y(s_); e.z[u] = ENT_Z(s_);
+                e.cell[u] = ENT_RC(s_).y;
+                if (smass) e.m[u] = smass[s_];
+            }
+        }
+    };
+    auto none = [&](Ent &e) { e.cnt[0] = e.cnt[1] = 0; e.beg[0] = e.beg[1] = 0; };
+    auto add_ent = [&](const Ent &e, int bx) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int part = u < PF_OWN ? 0 : 1, r = u < PF_OWN ? u : u - PF_OWN;
+            if (tid + r * NT < e.cnt[part]) add_half(e.x[u], e.y[u], e.z[u], e.m[u], e.cell[u], bx);
+        }
+#pragma unroll
+        for (int part = 0; part < 2; part++)
+            for (int k = tid + (part == 0 ? PF_OWN : PF_DUP) * NT; k < e.cnt[part]; k += NT) {
+                const int s_ = e.beg[part] + k;
+                add_half(ENT_X(s_), ENT_Y(s_), ENT_Z(s_), smass ? smass[s_] : 0.f, ENT_RC(s_).y, bx);
+            }
+    };
+
+    if (g.periodic_x || xa > 0) fetch(prev, xa > 0 ? xa - 1 : g.N - 1);
+    else none(prev);
+    fetch(cur, xa);
+    __syncthreads();                                          // the window is clear, the twiddles are staged
+    const int xend = xb + ((!g.periodic_x && xb == g.xl) ? 1 : 0);
+    for (int i = xa; i < xend; i++) {
+        add_ent(prev, 1);
+        if (i < xb) add_ent(cur, 0);
+        __syncthreads();
+        prev = cur;
+        if (i + 1 < xb) fetch(cur, i + 1);                    // lands while plane i is transformed and stored
+        else none(cur);
+        // the first, radix-P stage of the row's forward transform, from the accumulators: y_q[n], n = tau + 64 j
+        C2<F> v[vmax(E)];
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const int n = tau + 64 * j;
+            C2<F> z[P];
+#pragma unroll
+            for (int s_ = 0; s_ < P; s_++) {
+                const fpm_v2d a = *(const fpm_v2d *) &Arow[2 * (n + MS * s_)];
+                z[s_] = C2<F>{(F) (a.x * scale), (F) (a.y * scale)};
+            }
+            C2<F> y;
+            if (P == 2) y = q == 0 ? cadd(z[0], z[1]) : csub(z[0], z[1]);
+            else {
+                // w = e^(-2 pi i / 3): z0 + w^q z1 + w^(2q) z2;  w z1 + w^2 z2 = -(z1 + z2) / 2 - i (sqrt 3 / 2) (z1 - z2)
+                const C2<F> sm = cadd(z[1], z[P - 1]), df = csub(z[1], z[P - 1]);
+                const F h3 = (F) 0.86602540378443864676;
+                if (q == 0) y = cadd(z[0], sm);
+                else {
+                    const F sg = q == 1 ? h3 : -h3;
+                    y = C2<F>{z[0].x - (F) 0.5 * sm.x + sg * df.y, z[0].y - (F) 0.5 * sm.y - sg * df.x};
+                }
+            }
+            if (q) {
+                const int idx = 2 * q * n;                               // W_M^(n q) = W_N^(2 n q); beyond M the table repeats, sign changed
+                const bool hi = idx >= M;
+                C2<F> wq = twn[hi ? idx - M : idx];
+                if (hi) { wq.x = -wq.x; wq.y = -wq.y; }
+                y = cmul(wq, y);
+            }
+            v[in_slot<PS>(j)] = y;
+        }
+        __syncthreads();                                      // every wave has read the rows: their memory is the transforms' now
+        fft_core<PS, -1, -1, false, F, 0, true, CF::xs>(v, region, tw, tau, 0);
+        // v[j] = Z[P m + q], m = tau + 64 j.  The untangle pairs it with Z[M - k]: residue (P - q) % P, element MS - m (q = 0:
+        // modulo MS) or MS - 1 - m
+#pragma unroll
+        for (int j = 0; j < E; j++) region[tau + 64 * j] = v[j];
+        if (P == 2) fft_sync<true>(); else __syncthreads();
+        const C2<F> *pr = region_of((P - q) % P);
+        const int yrow = y0 + c;
+        C2<F> *dst = out + ((long long) i * g.yplanes + yrow) * g.rp;
+        bool chunked = false, live = true;
+        if constexpr (PEN) {
+            live = yrow <= g.ylr;                                      // the y halo row's strip has one row
+            if (!g.periodic_x && i == g.xl) dst = (C2<F> *) pen.hx[0] + (long long) min(yrow, g.ylr) * g.rp;
+            else if (yrow >= g.ylr) dst = (C2<F> *) pen.hy[0] + (long long) i * g.rp;
+            else { dst = out + ((long long) i * g.ylr + yrow) * g.nzl; chunked = true; }
+        }
+        dst = uniform_ptr(dst);
+        const unsigned pjump = PEN ? (unsigned) (pen.chunk - g.zblk) : 0u;
+        auto at = [&](int kbase, int t_) -> C2<F> * {                  // element kbase + t_, kbase uniform, t_ < 64 P <= zblk
+            if constexpr (PEN) {
+                const unsigned k = (unsigned) (kbase + t_);
+                unsigned off = k;
+                if (chunked) {
+                    const unsigned B = ((unsigned) kbase * pen.inv24) >> 24;
+                    off = k + (B + (k >= (B + 1) * (unsigned) g.zblk ? 1u : 0u)) * pjump;
+                }
+                return dst + off;
+            }
+            return dst + kbase + t_;
+        };
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const int m = tau + 64 * j, k = P * m + q;
+            const C2<F> a = v[j];
+            const C2<F> b = pr[q == 0 ? ((MS - m) & (MS - 1)) : MS - 1 - m];
+            const C2<F> val = r2c_untangle(a, b, twn[k]);
+            if (!PEN || live) {
+                st_stream(at(64 * P * j, P * tau + q), val);
+                if (k == 0) *at(M, 0) = C2<F>{a.x - a.y, 0};           // X[N/2] = Re Z0 - Im Z0
+            }
+        }
+        if (q == 0 && (!PEN || (live && !chunked)))
+            for (int k = M + 1 + tau; k < g.rp; k += 64) dst[k] = C2<F>{0, 0};      // the padding of an aligned row
+        if (P == 2) fft_sync<true>(); else __syncthreads();   // the partners have been read
+        {
+            const int lo = q * CF::part, hi = q == P - 1 ? WP : (q + 1) * CF::part;      // a wave clears its own part of the row
+            for (int idx = lo + tau; idx < hi; idx += 64) Arow[idx] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // readout
 // ------------------------------------------------------------------------------------------------------------------
 // WS: every row's threads in one wave, the FFT exchanges wave-local (fft_sync in fpm_fftcore.h) in a region per row
@@ -1828,6 +2040,35 @@ static int paint_strips_launch(fpmhip_plan *p, const fpmhip_particles *pt, doubl
             g, p->ntiles, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, pt->mass ? p->smass : nullptr, pt->M0, scale, out, \
             accumulate, p->d_twiddle, p->scell, pen);                                                                  \
     }
+    // the long rows: several waves per row, split once (paint_split_kernel): FPMHIP_PT_SPLIT = 0 | 1; default: on at M = 1536
+    // (fp32: 9.10 -> 8.58 ms, one rank of eight), off at M = 1024 (fp32 2.77 -> 3.45 ms: 16 VGPRs spilled at the 128 that two
+    // workgroups per CU allow; fp64 4.72 -> 4.71) -- profiles/r06_split_readout_ab.md
+    static const int split_env = getenv("FPMHIP_PT_SPLIT") ? atoi(getenv("FPMHIP_PT_SPLIT")) : -1;
+    const bool split2 = split_env > 0, split3 = split_env != 0;
+#define CALL_PT_SPLIT(P_, PEN_)                                                                                        \
+    {                                                                                                                  \
+        using CS = PaintSplitCfg<F, P_>;                                                                               \
+        FPM_TRY(grant_lds(paint_split_kernel<F, P_, PEN_>, CS::lds, p->device));                                       \
+        static int occ = 0;                                                                                            \
+        g.xseg = choose_xseg(g, paint_split_kernel<F, P_, PEN_>, CS::threads, CS::lds, g.nty, 8, 64, &occ);            \
+        const int nseg = (g.xl + g.xseg - 1) / g.xseg;                                                                 \
+        paint_split_kernel<F, P_, PEN_><<<g.nty * nseg, CS::threads, CS::lds, p->stream>>>(                            \
+            g, p->ntiles, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, pt->mass ? p->smass : nullptr, pt->M0, scale, out, \
+            p->d_twiddle, p->scell, pen);                                                                              \
+        FPM_CHECK_HIP(hipGetLastError());                                                                              \
+        return 0;                                                                                                      \
+    }
+    if constexpr (R2C) {
+        if (split2 && g.N == 2048 && (g.periodic_y || g.zblk >= 128)) {
+            if (g.periodic_y) CALL_PT_SPLIT(2, false) else CALL_PT_SPLIT(2, true)
+        }
+        if constexpr (sizeof(F) == 4) {
+            if (split3 && g.N == 3072 && (g.periodic_y || g.zblk >= 192)) {
+                if (g.periodic_y) CALL_PT_SPLIT(3, false) else CALL_PT_SPLIT(3, true)
+            }
+        }
+    }
+#undef CALL_PT_SPLIT
 #define CALL_PM(PL)                                                                                                    \
     if (R2C && 64 % PL::T == 0 && ws_env) CALL_PM_W(PL, (R2C && 64 % PL::T == 0)) else CALL_PM_W(PL, false)
     STRIP_DISPATCH(g.N / 2, CALL_PM)

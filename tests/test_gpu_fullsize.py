@@ -204,30 +204,39 @@ def test_one_rank_of_the_8_gpu_configs_at_full_per_rank_size(N, precision, ncube
     assert err <= tol, err
 
 
-@pytest.mark.parametrize("N,precision,ncube,split,tol", [
-    (2048, 32, 0, 0, 3e-5),      # the one-wave-per-row shape (E = 16), the default until round 6
-    (2048, 32, 0, 1, 3e-5),      # two waves per row, the LATE order
-    (2048, 32, 0, 2, 3e-5),      #   ... rows a step ahead (3, rows and entries ahead, is the default: the test above)
-    (2048, 64, 0, 1, 1e-6),      # fp64: two waves per row is an A/B (12.9 against 12.8 ms), the default stays one wave per row
-    (3072, 32, 128, 0, 3e-5),    # M = 1536: one wave per row, E = 24
-    (3072, 32, 128, 1, 3e-5),    #   three waves per row, LATE
-    (3072, 32, 128, 2, 3e-5),
+@pytest.mark.parametrize("N,precision,ncube,env,tol", [
+    (2048, 32, 0, "FPMHIP_RO_SPLIT=0", 3e-5),      # the one-wave-per-row readout (E = 16), the default until round 6
+    (2048, 32, 0, "FPMHIP_RO_SPLIT=1", 3e-5),      # two waves per row, the LATE order
+    (2048, 32, 0, "FPMHIP_RO_SPLIT=2", 3e-5),      #   ... rows a step ahead (3, rows and entries ahead, is the default: the test above)
+    (2048, 64, 0, "FPMHIP_RO_SPLIT=1", 1e-6),      # fp64: two waves per row is an A/B (12.9 against 12.8 ms), the default stays one wave per row
+    (3072, 32, 128, "FPMHIP_RO_SPLIT=0", 3e-5),    # M = 1536: one wave per row, E = 24
+    (3072, 32, 128, "FPMHIP_RO_SPLIT=1", 3e-5),    #   three waves per row, LATE
+    (3072, 32, 128, "FPMHIP_RO_SPLIT=2", 3e-5),
+    (2048, 32, 0, "FPMHIP_PT_SPLIT=1", 3e-5),      # the paint with two waves per row (an A/B at M = 1024: slower in fp32, equal in fp64)
+    (2048, 64, 0, "FPMHIP_PT_SPLIT=1", 1e-6),
+    (3072, 32, 128, "FPMHIP_PT_SPLIT=0", 3e-5),    # M = 1536: the paint through workgroup barriers (three waves per row split once is the default)
+    (2048, 32, -1, "FPMHIP_PT_SPLIT=1", 1e-5),     # ncube < 0: the pencil rank (1, 1) of 4 x 2 -- the PEN forms of both kernels
+    (2048, 32, -1, "FPMHIP_RO_SPLIT=1", 1e-5),
 ])
-def test_the_readout_shapes_of_the_long_rows_at_per_rank_size(N, precision, ncube, split, tol):
-    """FPMHIP_RO_SPLIT (read once per process: a child running tools/rank_share_bench.py): every shape of the marching readout
-    at M = 1024 / 1536 -- one wave per row, and the several-waves-per-row kernels of round 6 in their three orders -- against
-    the small cube at the slab's true geometry and load."""
+def test_the_kernel_shapes_of_the_long_rows_at_per_rank_size(N, precision, ncube, env, tol):
+    """FPMHIP_RO_SPLIT / FPMHIP_PT_SPLIT (read once per process: a child running tools/rank_share_bench.py): every shape of the
+    marching kernels at M = 1024 / 1536 -- one wave per row, and the several-waves-per-row kernels of round 6 in their orders --
+    against the small cube at the slab's (or the pencil brick's) true geometry and load."""
     import json
     import subprocess
     import sys
     import torch
     free, _ = torch.cuda.mem_get_info()
     need = 7.5 * (N // 8) * N * (N + 2) * (precision // 8) + 100.0 * (N // 16) ** 3 * 64
+    if ncube < 0:
+        need = 16 * (N ** 3 // 8) * (precision // 8) * 1.2
     if free < need:
         pytest.skip("needs %.0f GB of device memory" % (need / 1e9))
     torch.cuda.empty_cache()
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rank_share_bench.py"), str(N), str(precision), str(ncube)],
-                       env=dict(os.environ, FPMHIP_RO_SPLIT=str(split)), capture_output=True, text=True, timeout=1200)
+    args = [str(N), str(precision), str(max(ncube, 0))] + (["0", "pencil"] if ncube < 0 else [])
+    key, val = env.split("=")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rank_share_bench.py")] + args,
+                       env=dict(os.environ, **{key: val}), capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["parity_vs_small_cube"] <= tol, d["parity_vs_small_cube"]
