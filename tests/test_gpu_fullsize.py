@@ -215,6 +215,10 @@ def test_one_rank_of_the_8_gpu_configs_at_full_per_rank_size(N, precision, ncube
     (2048, 32, 0, "FPMHIP_PT_SPLIT=1", 3e-5),      # the paint with two waves per row (an A/B at M = 1024: slower in fp32, equal in fp64)
     (2048, 64, 0, "FPMHIP_PT_SPLIT=1", 1e-6),
     (3072, 32, 128, "FPMHIP_PT_SPLIT=0", 3e-5),    # M = 1536: the paint through workgroup barriers (three waves per row split once is the default)
+    # denser cubes than the configurations': 2500 / 1920 entries per strip tile where the several-waves-per-row readouts keep
+    # 1280 / 960 in registers -- the rest of a tile goes through the global half-sum rows
+    (2048, 32, 160, "FPMHIP_RO_SPLIT=3", 3e-5),
+    (3072, 32, 192, "FPMHIP_RO_SPLIT=3", 3e-5),
     (2048, 32, -1, "FPMHIP_PT_SPLIT=1", 1e-5),     # ncube < 0: the pencil rank (1, 1) of 4 x 2 -- the PEN forms of both kernels
     (2048, 32, -1, "FPMHIP_RO_SPLIT=1", 1e-5),
 ])
@@ -227,7 +231,7 @@ def test_the_kernel_shapes_of_the_long_rows_at_per_rank_size(N, precision, ncube
     import sys
     import torch
     free, _ = torch.cuda.mem_get_info()
-    need = 7.5 * (N // 8) * N * (N + 2) * (precision // 8) + 100.0 * (N // 16) ** 3 * 64
+    need = 7.5 * (N // 8) * N * (N + 2) * (precision // 8) + 200.0 * (ncube if ncube > 0 else N // 16) ** 3 * 64
     if ncube < 0:
         need = 16 * (N ** 3 // 8) * (precision // 8) * 1.2
     if free < need:
