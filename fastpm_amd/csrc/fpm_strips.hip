@@ -1189,6 +1189,243 @@ __global__ __launch_bounds__((SplitCfg<F>::threads), (sizeof(F) == 8 ? 1 : FPM_R
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// M = 1024 in fp32: the transform and the gather on DIFFERENT WAVES of one workgroup, two window planes in LDS (round 6)
+// ------------------------------------------------------------------------------------------------------------------
+// readout_split_kernel runs one workgroup of ten waves per CU (two would need 96 VGPRs: 14 - 33 spilled), so its phases -- a
+// plane's transform, then the gathers from it -- follow each other and each waits for its own loads and LDS round trips alone.
+// fp32 leaves the LDS for a second window plane (105 KB in all), and a wave that only transforms or only gathers needs fewer
+// registers than one that does both: sixteen waves at <= 128 VGPRs -- ten TRANSFORM waves (two per row, the split transform of
+// readout_split_kernel: plane t + 1 into window (t + 1) & 1, its rows requested a plane ahead) and six GATHER waves (the entries
+// of plane t against window t & 1: the finishing set's x + 1 corners, the starting set's x + 0 corners, the next set requested)
+// work at the same time and meet at two workgroup barriers per plane (the transform's join, and the end of the plane).
+// The arithmetic is readout_split_kernel's, value for value.
+struct SplitWsCfg {
+    using CS = SplitCfg<float>;
+    static constexpr int NTF = CS::threads, NTG = 6 * 64, threads = NTF + NTG, PF = 4;      // 640 + 384 = 1024; 1536 entries in registers
+    static constexpr size_t lds = (size_t) (CS::MS + CS::M + 2 * CS::pitch * STRIP_RW) * sizeof(C2<float>);
+    static_assert(threads <= 1024 && lds <= 160 * 1024, "one workgroup of sixteen waves, two window planes");
+};
+template <bool PEN>
+__global__ __launch_bounds__((SplitWsCfg::threads), 4) void readout_split_ws_kernel(
+    MeshGeo g, int ncomp, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
+    const double *__restrict__ sy, const double *__restrict__ sz, const C2<float> *__restrict__ m0,
+    const C2<float> *__restrict__ m1, const C2<float> *__restrict__ m2, float *__restrict__ out, int nmemb, int memb0,
+    const double *__restrict__ tw_global, double *__restrict__ part_all, long long part_stride, const int2 *__restrict__ scell,
+    PenIO pen)
+{
+    using F = float;
+    using CF = SplitCfg<F>;
+    using PS = typename CF::PS;
+    constexpr int M = CF::M, MS = CF::MS, E = 8, RP = CF::pitch, WP = 2 * RP, SUB = CF::SUB, NTF = SplitWsCfg::NTF, NT = SplitWsCfg::NTG,
+                  PF = SplitWsCfg::PF, SLOT = RP * STRIP_RW;
+    extern __shared__ __align__(16) unsigned char smem_st[];
+    C2<F> *tw = (C2<F> *) smem_st;                 // W_MS^j, j < MS
+    C2<F> *twn = tw + MS;                          // W_N^k, k < M
+    C2<F> *S0 = twn + M;                           // two windows of RW rows of RP values
+    const int wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), tau = threadIdx.x & 63;
+    const int nseg = (g.xl + g.xseg - 1) / g.xseg;
+    const int t = xcd_remap(blockIdx.x, ncomp * g.ntyo * nseg);
+    const int comp = t % ncomp, strip = (t / ncomp) % g.ntyo, seg = nseg - 1 - t / (ncomp * g.ntyo);      // last segment first
+    const C2<F> *mesh = comp == 0 ? m0 : (comp == 1 ? m1 : m2);
+    const int xa = seg * g.xseg, xb = min(xa + g.xseg, g.xl);
+    const int y0 = strip * STRIP_Y;
+    const int nplanes = xb - xa + 1;               // the planes xa .. xb pass through the windows, one per tick
+
+    stage_twiddles(tw, tw_global, MS, 4);
+    stage_twiddles(twn, tw_global, M, 1);
+
+    if (wv < NTF / 64) {
+        // ---------------- the transform waves ----------------
+        const int c = wv >> 1, r = wv & 1;
+        int gy = y0 + c;
+        gy -= gy >= g.N ? g.N : 0;
+        const C2<F> *rowbase = mesh + (long long) gy * g.rp;
+        const long long pstride = (long long) g.yplanes * g.rp;
+        C2<F> xA[E], xmA, xB[E], xmB;
+        const int yrow = y0 + c;
+        const C2<F> *phx = PEN ? (const C2<F> *) pen.hx[comp] : nullptr, *phy = PEN ? (const C2<F> *) pen.hy[comp] : nullptr;
+        auto load_plane = [&](int xp, C2<F> (&x)[E], C2<F> &xm) {      // the values of parity r of the row: k = 2 (tau + 64 j) + r
+            if (g.periodic_x) xp -= xp >= g.N ? g.N : 0;
+            if constexpr (PEN) {
+                const C2<F> *src;
+                bool chunked = false;
+                if (!g.periodic_x && xp == g.xl) src = phx + (long long) yrow * g.rp;
+                else if (yrow == g.ylr) src = phy + (long long) xp * g.rp;
+                else { src = mesh + ((long long) xp * g.ylr + yrow) * g.nzl; chunked = true; }
+                src = uniform_ptr(src);
+                const unsigned pjump = (unsigned) (pen.chunk - g.zblk);
+#pragma unroll
+                for (int j = 0; j < E; j++) {
+                    const unsigned k = (unsigned) (128 * j + r + 2 * tau);
+                    unsigned off = k;
+                    if (chunked) {
+                        const unsigned B = ((unsigned) (128 * j) * pen.inv24) >> 24;
+                        off = k + (B + (k >= (B + 1) * (unsigned) g.zblk ? 1u : 0u)) * pjump;
+                    }
+                    x[j] = ld_stream(src + off);
+                }
+                xm = C2<F>{0, 0};
+                if (r == 0 && tau == 0) {
+                    unsigned off = M;
+                    if (chunked) off = M + (((unsigned) M * pen.inv24) >> 24) * pjump;
+                    xm = src[off];
+                }
+                return;
+            }
+            const C2<F> *src = rowbase + (long long) xp * pstride + r;
+#pragma unroll
+            for (int j = 0; j < E; j++) x[j] = ld_stream(&src[2 * (tau + 64 * j)]);
+            xm = (r == 0 && tau == 0) ? src[M] : C2<F>{0, 0};
+        };
+        load_plane(xa, xA, xmA);
+        __syncthreads();                           // the tables are staged
+        // one tick: plane xa + k (in x) into window k & 1; the next plane's rows are requested FIRST, into the other register set --
+        // a whole tick ahead of their use
+        auto tick = [&](int k, C2<F> (&x)[E], C2<F> &xm, C2<F> (&xn)[E], C2<F> &xmn) {
+            if (k + 1 < nplanes) load_plane(xa + k + 1, xn, xmn);
+            if (k < nplanes) {
+                C2<F> *row = S0 + (k & 1) * SLOT + c * RP, *sub = row + r * SUB;
+                C2<F> v[vmax(E)];
+                if (r == 0 && tau == 0) { x[0].y = 0; xm.y = 0; }
+#pragma unroll
+                for (int j = 0; j < E; j++) sub[tau + 64 * j] = x[j];
+                if (r == 0 && tau == 0) sub[MS] = xm;
+                fft_sync<true>();
+#pragma unroll
+                for (int j = 0; j < E; j++) {
+                    const int m = tau + 64 * j;
+                    const C2<F> a = x[j];
+                    C2<F> bq = sub[MS - r - m];
+                    bq.y = -bq.y;
+                    const C2<F> s_ = cadd(a, bq), d = csub(a, bq);
+                    const C2<F> wq = twn[2 * m + r];
+                    const C2<F> o = cmul(C2<F>{wq.x, -wq.y}, d);           // conj W_N^k
+                    v[in_slot<PS>(j)] = C2<F>{s_.x - o.y, s_.y + o.x};
+                }
+                fft_sync<true>();
+                fft_core<PS, +1, -RP, false, F, 0, true, CF::xs>(v, sub, tw, tau, 0);
+                if (r) {
+#pragma unroll
+                    for (int j = 0; j < E; j++) {
+                        const C2<F> wq = twn[2 * (tau + 64 * j)];
+                        v[j] = cmul(C2<F>{wq.x, -wq.y}, v[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; j++) row[SUB + tau + 64 * j] = v[j];
+                    row[1024 + tau] = v[3];
+                } else {
+#pragma unroll
+                    for (int j = 4; j < E; j++) row[tau + 64 * j] = v[j];
+                }
+                __syncthreads();                   // the join (the gather waves pass it too)
+                if (r) {
+                    C2<F> f[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) f[j] = row[tau + 64 * (j + 4)];
+                    fft_sync<true>();
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        row[tau + 64 * (j + 4)] = cadd(f[j], v[j + 4]);
+                        row[MS + tau + 64 * (j + 4)] = csub(f[j], v[j + 4]);
+                    }
+                } else {
+                    C2<F> gq[4];
+#pragma unroll
+                    for (int j = 0; j < 3; j++) gq[j] = row[SUB + tau + 64 * j];
+                    gq[3] = row[1024 + tau];
+                    fft_sync<true>();
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        row[tau + 64 * j] = cadd(v[j], gq[j]);
+                        row[MS + tau + 64 * j] = csub(v[j], gq[j]);
+                    }
+                    if (tau == 0) row[M].x = v[0].x + gq[0].x;             // value N of a row = value 0
+                }
+            } else {
+                __syncthreads();
+            }
+            __syncthreads();                       // the end of the tick: plane xa + k is in window k & 1
+        };
+        for (int k = 0; k <= nplanes; k += 2) {
+            tick(k, xA, xmA, xB, xmB);
+            if (k + 1 <= nplanes) tick(k + 1, xB, xmB, xA, xmA);
+        }
+        return;
+    }
+
+    // ---------------- the gather waves ----------------
+    const int tid = (int) threadIdx.x - NTF;
+    double *part = part_all + comp * part_stride;
+    const F *rs = (const F *) S0;
+    int wofs = 0;                                  // the window the tick gathers from, in floats
+    auto half = [&](double qx, double qy, double qz, int qc, int bx, double acc) -> double {      // D and base cell of the entry
+        const StripEntry cc = strip_entry(g, qx, qy, qz, qc);
+        const int ly = cc.iy0 - y0, lz = cc.iz0;
+        const double wxb = bx ? cc.d[0] : cc.t[0];
+        const double wy[2] = {cc.t[1], cc.d[1]}, wz[2] = {cc.t[2], cc.d[2]};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int by = (k >> 1) & 1, bz = k & 1;
+            acc += (double) rs[wofs + (ly + by) * WP + lz + bz] * (wz[bz] * wxb * wy[by]);
+        }
+        return acc;
+    };
+    double px[PF], py[PF], pz[PF], pv[PF], qx[PF], qy[PF], qz[PF];
+    int prow[PF], qrow[PF], pc[PF], qc[PF];
+    int pb = 0, pn = 0, qb = 0, qn = 0;            // p: the particles that finish this tick; q: those that start
+    auto fetch_q = [&](int xi) {
+        const int key = xi * g.nty + strip;
+        qb = tbeg[key];
+        qn = tcnt[key];
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int e = tid + u * NT;
+            qx[u] = qy[u] = qz[u] = 0;
+            qrow[u] = qc[u] = 0;
+            if (e < qn) {
+                qx[u] = ENT_X(qb + e); qy[u] = ENT_Y(qb + e); qz[u] = ENT_Z(qb + e);
+                const int2 rc = ENT_RC(qb + e);                     // (row, base cell)
+                qrow[u] = rc.x; qc[u] = rc.y;
+            }
+        }
+    };
+    auto start_q = [&]() {                         // q -> p with the first four terms
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            px[u] = qx[u]; py[u] = qy[u]; pz[u] = qz[u]; prow[u] = qrow[u]; pc[u] = qc[u];
+            pv[u] = tid + u * NT < qn ? half(qx[u], qy[u], qz[u], qc[u], 0, 0.0) : 0.0;
+        }
+        for (int e = tid + PF * NT; e < qn; e += NT) part[qb + e] = half(ENT_X(qb + e), ENT_Y(qb + e), ENT_Z(qb + e), ENT_RC(qb + e).y, 0, 0.0);
+        pb = qb;
+        pn = qn;
+    };
+    auto finish_p = [&]() {
+#pragma unroll
+        for (int u = 0; u < PF; u++)
+            if (tid + u * NT < pn) out[(long long) prow[u] * nmemb + memb0 + comp] = (float) half(px[u], py[u], pz[u], pc[u], 1, pv[u]);
+        for (int e = tid + PF * NT; e < pn; e += NT) {
+            const int2 rc = ENT_RC(pb + e);
+            out[(long long) rc.x * nmemb + memb0 + comp] = (float) half(ENT_X(pb + e), ENT_Y(pb + e), ENT_Z(pb + e), rc.y, 1, part[pb + e]);
+        }
+    };
+    fetch_q(xa);
+    __syncthreads();                               // the tables are staged
+    // tick k: the transform waves fill window k & 1 with plane xa + k; these waves gather from plane xa + k - 1 in the other window
+    for (int k = 0; k <= nplanes; k++) {
+        if (k >= 1) {
+            wofs = ((k - 1) & 1) * 2 * SLOT;
+            if (k >= 2) finish_p();                                        // the particles of plane xa + k - 2: their x + 1 corners
+            if (k < nplanes) {
+                start_q();                                                 // the particles of plane xa + k - 1: their x + 0 corners
+                if (k + 1 < nplanes) fetch_q(xa + k);                      // lands under the barriers
+            }
+        }
+        __syncthreads();
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // M = 1536 in fp32 (the 3072^3 mesh of configs[4] at B = 3): THREE WAVES per row, joined once (round 6)
 // ------------------------------------------------------------------------------------------------------------------
 // The same split by three: Z[n + 512 q] = F0[n] + w^q W_M^-n F1[n] + w^2q W_M^-2n F2[n], w = e^(2 pi i / 3), Fr the 512-point
@@ -2252,6 +2489,17 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
             (const C2<F> *) k1, (const C2<F> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride,          \
             p->scell, pen);                                                                                            \
     }
+#define CALL_RO_SPLIT_WS(PEN_)                                                                                            \
+    {                                                                                                                  \
+        using CS = SplitWsCfg;                                                                                         \
+        static int occw = 0;                                                                                           \
+        FPM_TRY(grant_lds(readout_split_ws_kernel<PEN_>, CS::lds, p->device));                                         \
+        g.xseg = choose_xseg(g, readout_split_ws_kernel<PEN_>, CS::threads, CS::lds, ncomp * g.ntyo, 16, 128, &occw);  \
+        const int nseg = (g.xl + g.xseg - 1) / g.xseg;                                                                 \
+        readout_split_ws_kernel<PEN_><<<ncomp * g.ntyo * nseg, CS::threads, CS::lds, p->stream>>>(                     \
+            g, ncomp, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, (const C2<float> *) k0, (const C2<float> *) k1,  \
+            (const C2<float> *) k2, out, nmemb, memb0, p->d_twiddle, p->ro_part, part_stride, p->scell, pen);          \
+    }
 #define CALL_RO_SPLIT3(PEN_, VAR_)                                                                                     \
     {                                                                                                                  \
         using CS = Split3Cfg;                                                                                          \
@@ -2325,10 +2573,18 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
     }                                                                                                                  \
     if constexpr (PL::N == 1024) {                                                                                     \
         /* two waves per row, joined once (readout_split_kernel): FPMHIP_RO_SPLIT = 0 (one wave per row) | 1 | 2 | 3 (the  */ \
-        /* kernel's VAR + 1); default: fp32 3, fp64 0 (measured: profiles/r06_split_readout_ab.md)                          */ \
+        /* kernel's VAR + 1) | 5 (fp32: transform and gather on different waves, readout_split_ws_kernel); default: fp32 5, */ \
+        /* fp64 0 (measured: profiles/r06_split_readout_ab.md)                                                              */ \
         /* (FPMHIP_RO_E16 = 0 alone still selects the round-4 shape, E = 8 through workgroup barriers)                      */ \
         static const int split_env = getenv("FPMHIP_RO_SPLIT") ? atoi(getenv("FPMHIP_RO_SPLIT"))                       \
-                                     : (getenv("FPMHIP_RO_E16") && atoi(getenv("FPMHIP_RO_E16")) == 0) ? 0 : (sizeof(F) == 4 ? 3 : 0); \
+                                     : (getenv("FPMHIP_RO_E16") && atoi(getenv("FPMHIP_RO_E16")) == 0) ? 0 : (sizeof(F) == 4 ? 5 : 0); \
+        if constexpr (sizeof(F) == 4) {                                                                                \
+            /* 5: transform and gather on different waves, two window planes (readout_split_ws_kernel) */              \
+            if (split_env >= 5 && !two_planes && ws_env != 0 && (!pen.on || g.zblk >= 128)) {                          \
+                if (pen.on) CALL_RO_SPLIT_WS(true) else CALL_RO_SPLIT_WS(false)                                        \
+                break;                                                                                                 \
+            }                                                                                                          \
+        }                                                                                                              \
         if (split_env && !two_planes && ws_env != 0 && (!pen.on || g.zblk >= 128)) {                                   \
             if (pen.on) { if (split_env == 1) CALL_RO_SPLIT(true, 0) else CALL_RO_SPLIT(true, (sizeof(F) == 4 ? 2 : 0)) } \
             else if (split_env == 2) CALL_RO_SPLIT(false, 1)                                                           \
@@ -2351,6 +2607,7 @@ static int readout_strips_launch(fpmhip_plan *p, const void *k0, const void *k1,
 #undef CALL_RO_ROWS2
 #undef CALL_RO_SPLIT
 #undef CALL_RO_SPLIT3
+#undef CALL_RO_SPLIT_WS
 #undef CALL_RO_W
 #undef CALL_RO_P
     FPM_CHECK_HIP(hipGetLastError());

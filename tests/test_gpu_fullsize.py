@@ -207,7 +207,9 @@ def test_one_rank_of_the_8_gpu_configs_at_full_per_rank_size(N, precision, ncube
 @pytest.mark.parametrize("N,precision,ncube,env,tol", [
     (2048, 32, 0, "FPMHIP_RO_SPLIT=0", 3e-5),      # the one-wave-per-row readout (E = 16), the default until round 6
     (2048, 32, 0, "FPMHIP_RO_SPLIT=1", 3e-5),      # two waves per row, the LATE order
-    (2048, 32, 0, "FPMHIP_RO_SPLIT=2", 3e-5),      #   ... rows a step ahead (3, rows and entries ahead, is the default: the test above)
+    (2048, 32, 0, "FPMHIP_RO_SPLIT=2", 3e-5),      #   ... rows a step ahead
+    (2048, 32, 0, "FPMHIP_RO_SPLIT=3", 3e-5),      #   ... rows and entries a step ahead (5, transform and gather on different waves,
+                                                   #   is the default: the test above)
     (2048, 64, 0, "FPMHIP_RO_SPLIT=1", 1e-6),      # fp64: two waves per row is an A/B (12.9 against 12.8 ms), the default stays one wave per row
     (3072, 32, 128, "FPMHIP_RO_SPLIT=0", 3e-5),    # M = 1536: one wave per row, E = 24
     (3072, 32, 128, "FPMHIP_RO_SPLIT=1", 3e-5),    #   three waves per row, LATE
@@ -218,9 +220,11 @@ def test_one_rank_of_the_8_gpu_configs_at_full_per_rank_size(N, precision, ncube
     # denser cubes than the configurations': 2500 / 1920 entries per strip tile where the several-waves-per-row readouts keep
     # 1280 / 960 in registers -- the rest of a tile goes through the global half-sum rows
     (2048, 32, 160, "FPMHIP_RO_SPLIT=3", 3e-5),
+    (2048, 32, 160, "FPMHIP_RO_SPLIT=5", 3e-5),    # (the gather waves keep 1536)
     (3072, 32, 192, "FPMHIP_RO_SPLIT=3", 3e-5),
     (2048, 32, -1, "FPMHIP_PT_SPLIT=1", 1e-5),     # ncube < 0: the pencil rank (1, 1) of 4 x 2 -- the PEN forms of both kernels
     (2048, 32, -1, "FPMHIP_RO_SPLIT=1", 1e-5),
+    (2048, 32, -1, "FPMHIP_RO_SPLIT=3", 1e-5),
 ])
 def test_the_kernel_shapes_of_the_long_rows_at_per_rank_size(N, precision, ncube, env, tol):
     """FPMHIP_RO_SPLIT / FPMHIP_PT_SPLIT (read once per process: a child running tools/rank_share_bench.py): every shape of the
