@@ -1999,6 +1999,205 @@ __global__ __launch_bounds__((3 * StripCfg<PL, F>::ro_threads), 4) void readout_
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// the three-component readout with the transform and the gather on DIFFERENT waves (round 6; M = 256: the 512^3 mesh)
+// ------------------------------------------------------------------------------------------------------------------
+// readout_march3_kernel runs two workgroups of 480 threads per CU, each alternating between a plane's three transforms and the
+// gathers from them; whether one workgroup's transform falls under the other's gathers is left to chance.  Here ONE workgroup
+// of 1024 threads owns the CU with TWO window planes in LDS (153 KB in fp64): 480 transform threads (row cg's T threads, as
+// before) fill window (t + 1) & 1 -- the rows requested a whole plane ahead into a second register set, which a wave that
+// does not carry particle state has the registers for -- while 512 gather threads take the entries of plane t through window
+// t & 1; ONE workgroup barrier per plane (the transforms are wave-local, nothing joins).  The arithmetic is
+// readout_march3_kernel's, value for value.
+template <typename PL, typename F> struct March3WsCfg {
+    using CF = StripCfg<PL, F>;
+    static constexpr int NTF = 3 * CF::ro_threads, NTFW = (NTF + 63) / 64 * 64, NTG = 1024 - NTFW, threads = NTFW + NTG;
+    static constexpr int slot = 3 * STRIP_RW * CF::ro_pitch;
+    static constexpr size_t lds = CF::twb + (size_t) 2 * slot * sizeof(C2<F>);
+    static constexpr bool ok = NTG >= 256 && lds <= 160 * 1024;
+};
+template <typename PL, typename F, bool PEN>
+__global__ __launch_bounds__(1024, 4) void readout_march3_ws_kernel(
+    MeshGeo g, const int *__restrict__ tbeg, const int *__restrict__ tcnt, const double *__restrict__ sx,
+    const double *__restrict__ sy, const double *__restrict__ sz, const C2<F> *__restrict__ m0, const C2<F> *__restrict__ m1,
+    const C2<F> *__restrict__ m2, float *__restrict__ out, int nmemb, int memb0, const double *__restrict__ tw_global,
+    double *__restrict__ part_all, long long part_stride, const int2 *__restrict__ scell, PenIO pen)
+{
+    using CF = StripCfg<PL, F>;
+    using CW = March3WsCfg<PL, F>;
+    constexpr int M = PL::N, RW = STRIP_RW, T = PL::T, E = PL::E, RP = CF::ro_pitch, WP = 2 * RP, SLOT = CW::slot;
+    static_assert(64 % T == 0 && CW::ok, "a row's threads sit in one wave; both windows in LDS");
+    extern __shared__ __align__(16) unsigned char smem_st[];
+    C2<F> *tw = (C2<F> *) smem_st;
+    C2<F> *twn = tw + PL::TWN;
+    C2<F> *S0 = twn + M;                           // two windows of [3 RW][RP]
+    constexpr int CWX = -RP, SKX = CF::ws_sk;
+    const int nseg = (g.xl + g.xseg - 1) / g.xseg;
+    const int t = xcd_remap(blockIdx.x, g.ntyo * nseg);
+    const int strip = t % g.ntyo, seg = nseg - 1 - t / g.ntyo;                    // last segment first
+    const int xa = seg * g.xseg, xb = min(xa + g.xseg, g.xl);
+    const int y0 = strip * STRIP_Y;
+    const int nplanes = xb - xa + 1;               // the planes xa .. xb pass through the windows, one per tick
+
+    stage_twiddles(tw, tw_global, PL::TWN, 2);
+    stage_twiddles(twn, tw_global, M, 1);
+
+    if ((int) threadIdx.x < CW::NTFW) {
+        // ---------------- the transform threads (the last wave of them may be partly idle) ----------------
+        const int tid = threadIdx.x;
+        const bool live = tid < CW::NTF;
+        const int cg = live ? tid / T : 0, tau = tid % T, comp = cg / RW, c = cg % RW;
+        const C2<F> *mesh = comp == 0 ? m0 : (comp == 1 ? m1 : m2);
+        int gy = y0 + c;
+        gy -= gy >= g.N ? g.N : 0;
+        const C2<F> *rowbase = mesh + (long long) gy * g.rp;
+        const long long pstride = (long long) g.yplanes * g.rp;
+        C2<F> xA[E], xmA, xB[E], xmB;
+        const int yrow = y0 + c;
+        const C2<F> *phx = PEN ? (const C2<F> *) pen.hx[comp] : nullptr, *phy = PEN ? (const C2<F> *) pen.hy[comp] : nullptr;
+        auto load_plane = [&](int xp, C2<F> (&x)[E], C2<F> &xm) {
+            if (g.periodic_x) xp -= xp >= g.N ? g.N : 0;
+            if constexpr (PEN) {
+                const C2<F> *src;
+                bool chunked = false;
+                if (!g.periodic_x && xp == g.xl) src = phx + (long long) yrow * g.rp;
+                else if (yrow == g.ylr) src = phy + (long long) xp * g.rp;
+                else { src = mesh + ((long long) xp * g.ylr + yrow) * g.nzl; chunked = true; }
+                const unsigned pjump = (unsigned) (pen.chunk - g.zblk);
+#pragma unroll
+                for (int j = 0; j < E; j++)
+                    x[j] = ld_stream(pen_elem<T, F>(const_cast<C2<F> *>(src), chunked, T * j, tau, g.zblk, pen.inv24, pjump));
+                xm = tau == 0 ? *pen_elem<T, F>(const_cast<C2<F> *>(src), chunked, M, 0, g.zblk, pen.inv24, pjump) : C2<F>{0, 0};
+                return;
+            }
+            const C2<F> *src = rowbase + (long long) xp * pstride;
+#pragma unroll
+            for (int j = 0; j < E; j++) x[j] = ld_stream(&src[tau + T * j]);
+            xm = tau == 0 ? src[M] : C2<F>{0, 0};
+        };
+        if (live) load_plane(xa, xA, xmA);
+        __syncthreads();                           // the tables are staged
+        // fp32: the next plane's rows are requested FIRST, into the other register set -- a whole tick ahead of their use; fp64
+        // (a row set is 36 VGPRs: two of them, or one across the transform, spill 62 - 77) requests them into the same set after
+        // the transform -- the barrier and the wait for the gather threads ahead of their use
+        constexpr bool TWO = sizeof(F) == 4;
+        auto tick = [&](int k, C2<F> (&x)[E], C2<F> &xm, C2<F> (&xn)[E], C2<F> &xmn) {
+            if (TWO && live && k + 1 < nplanes) load_plane(xa + k + 1, xn, xmn);
+            if (live && k < nplanes) {
+                C2<F> *S = S0 + (k & 1) * SLOT;
+                C2<F> v[vmax(E)];
+                c2r_prepare<PL, CWX, SKX, F, true>(v, x, xm, S, twn, tau, cg);
+                fft_core<PL, +1, CWX, false, F, SKX, true, CF::ro_xs>(v, S, tw, tau, cg);
+#pragma unroll
+                for (int j = 0; j < E; j++) S[cg * RP + tau + T * j] = v[j];
+                if (tau == 0) S[cg * RP + M].x = v[0].x;
+                if (!TWO && k + 1 < nplanes) load_plane(xa + k + 1, x, xm);
+            }
+            __syncthreads();                       // the end of the tick: plane xa + k is in window k & 1
+        };
+        if constexpr (TWO) {
+            for (int k = 0; k <= nplanes; k += 2) {
+                tick(k, xA, xmA, xB, xmB);
+                if (k + 1 <= nplanes) tick(k + 1, xB, xmB, xA, xmA);
+            }
+        } else {
+            for (int k = 0; k <= nplanes; k++) tick(k, xA, xmA, xA, xmA);
+        }
+        return;
+    }
+
+    // ---------------- the gather threads ----------------
+    constexpr int NT = CW::NTG;
+    const int tid = (int) threadIdx.x - CW::NTFW;
+    const F *rs = (const F *) S0;
+    int wofs = 0;                                  // the window the tick gathers from, in values of F
+    auto half3 = [&](double qx, double qy, double qz, int qc, int bx, double *a) {
+        const StripEntry cc = strip_entry(g, qx, qy, qz, qc);
+        const int ly = cc.iy0 - y0, lz = cc.iz0;
+        const double wxb = bx ? cc.d[0] : cc.t[0];
+        const double wy[2] = {cc.t[1], cc.d[1]}, wz[2] = {cc.t[2], cc.d[2]};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int by = (k >> 1) & 1, bz = k & 1;
+            const double w = wz[bz] * wxb * wy[by];
+#pragma unroll
+            for (int m = 0; m < 3; m++) a[m] += (double) rs[wofs + (m * RW + ly + by) * WP + lz + bz] * w;
+        }
+    };
+    struct F3 { float a, b, c; };
+    auto store3 = [&](int row, const double *a) {
+        float *o = out + (long long) row * nmemb + memb0;
+        if (nmemb == 3) *(F3 *) o = F3{(float) a[0], (float) a[1], (float) a[2]};
+        else { o[0] = (float) a[0]; o[1] = (float) a[1]; o[2] = (float) a[2]; }
+    };
+    constexpr int PF = 1;
+    double px[PF], py[PF], pz[PF], pv[PF][3], qx[PF], qy[PF], qz[PF];
+    int prow[PF], qrow[PF], pc[PF], qc[PF];
+    int pb = 0, pn = 0, qb = 0, qn = 0;
+    auto fetch_q = [&](int xi) {
+        const int key = xi * g.nty + strip;
+        qb = tbeg[key];
+        qn = tcnt[key];
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int e = tid + u * NT;
+            qx[u] = qy[u] = qz[u] = 0;
+            qrow[u] = qc[u] = 0;
+            if (e < qn) {
+                qx[u] = ENT_X(qb + e); qy[u] = ENT_Y(qb + e); qz[u] = ENT_Z(qb + e);
+                const int2 rc = ENT_RC(qb + e);
+                qrow[u] = rc.x; qc[u] = rc.y;
+            }
+        }
+    };
+    auto start_q = [&]() {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            px[u] = qx[u]; py[u] = qy[u]; pz[u] = qz[u]; prow[u] = qrow[u]; pc[u] = qc[u];
+            pv[u][0] = pv[u][1] = pv[u][2] = 0.0;
+            if (tid + u * NT < qn) half3(qx[u], qy[u], qz[u], qc[u], 0, pv[u]);
+        }
+        for (int e = tid + PF * NT; e < qn; e += NT) {
+            double a[3] = {0.0, 0.0, 0.0};
+            half3(ENT_X(qb + e), ENT_Y(qb + e), ENT_Z(qb + e), ENT_RC(qb + e).y, 0, a);
+#pragma unroll
+            for (int m = 0; m < 3; m++) part_all[m * part_stride + qb + e] = a[m];
+        }
+        pb = qb;
+        pn = qn;
+    };
+    auto finish_p = [&]() {
+#pragma unroll
+        for (int u = 0; u < PF; u++)
+            if (tid + u * NT < pn) {
+                half3(px[u], py[u], pz[u], pc[u], 1, pv[u]);
+                store3(prow[u], pv[u]);
+            }
+        for (int e = tid + PF * NT; e < pn; e += NT) {
+            const int2 rc = ENT_RC(pb + e);
+            double a[3];
+#pragma unroll
+            for (int m = 0; m < 3; m++) a[m] = part_all[m * part_stride + pb + e];
+            half3(ENT_X(pb + e), ENT_Y(pb + e), ENT_Z(pb + e), rc.y, 1, a);
+            store3(rc.x, a);
+        }
+    };
+    fetch_q(xa);
+    __syncthreads();                               // the tables are staged
+    // tick k: the transform threads fill window k & 1 with plane xa + k; these gather from plane xa + k - 1 in the other window
+    for (int k = 0; k <= nplanes; k++) {
+        if (k >= 1) {
+            wofs = ((k - 1) & 1) * 2 * SLOT;
+            if (k >= 2) finish_p();                                        // the particles of plane xa + k - 2: their x + 1 corners
+            if (k < nplanes) {
+                start_q();                                                 // the particles of plane xa + k - 1: their x + 0 corners
+                if (k + 1 < nplanes) fetch_q(xa + k);                      // lands under the barrier
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // readout with ONE plane in LDS and TWO ROWS PER TRANSFORM (round 4; the power-of-two meshes up to N = 512)
 // ------------------------------------------------------------------------------------------------------------------
 // The one-plane kernel above is bound by LDS traffic (profiles/r03_sq_counters.md: bank-conflict cycles alone are a quarter
@@ -2368,9 +2567,36 @@ template <int M, typename F> struct Ro3Launch<M, F, true> {
             nmemb, memb0, p->d_twiddle, p->ro_part, p->ro_part_elems, p->scell, pen);
         return 0;
     }
+    // transform and gather on different waves, two window planes (readout_march3_ws_kernel): FPMHIP_RO3_WS = 0 | 1
+    template <bool PEN>
+    static int run_ws(fpmhip_plan *p, MeshGeo &g, const void *k0, const void *k1, const void *k2, float *out, int nmemb, int memb0,
+                      const PenIO &pen)
+    {
+        using PL = typename Fac<M, 0>::type;
+        using CW = March3WsCfg<PL, F>;
+        if constexpr (CW::ok) {
+            static int occ = 0;
+            FPM_TRY(grant_lds(readout_march3_ws_kernel<PL, F, PEN>, CW::lds, p->device));
+            g.xseg = choose_xseg(g, readout_march3_ws_kernel<PL, F, PEN>, CW::threads, CW::lds, g.ntyo, 16, 128, &occ);
+            const int nseg = (g.xl + g.xseg - 1) / g.xseg;
+            readout_march3_ws_kernel<PL, F, PEN><<<g.ntyo * nseg, CW::threads, CW::lds, p->stream>>>(
+                g, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, (const C2<F> *) k0, (const C2<F> *) k1, (const C2<F> *) k2, out,
+                nmemb, memb0, p->d_twiddle, p->ro_part, p->ro_part_elems, p->scell, pen);
+            return 0;
+        }
+        return -1;
+    }
     static int go(fpmhip_plan *p, MeshGeo &g, const void *k0, const void *k1, const void *k2, float *out, int nmemb, int memb0,
                   bool late, const PenIO &pen)
     {
+        // default: fp64 on one rank and slabs (configs[1]: 1.056 -> 1.012 - 1.021 ms); fp32 loses (0.695 -> 0.867: its transform
+        // threads are done long before the gather threads), the pencil form is unmeasured -- both only when asked for (1)
+        static const int ws3_env = getenv("FPMHIP_RO3_WS") ? atoi(getenv("FPMHIP_RO3_WS")) : -1;
+        if constexpr (M == 256) {
+            if (ws3_env > 0 || (ws3_env < 0 && sizeof(F) == 8 && !pen.on))
+                return pen.on ? run_ws<true>(p, g, k0, k1, k2, out, nmemb, memb0, pen)
+                              : run_ws<false>(p, g, k0, k1, k2, out, nmemb, memb0, pen);
+        }
         if (pen.on) return run<true, true>(p, g, k0, k1, k2, out, nmemb, memb0, pen);      // (rows a step ahead: 52 VGPRs spilled)
         return late ? run<true, false>(p, g, k0, k1, k2, out, nmemb, memb0, pen)
                     : run<false, false>(p, g, k0, k1, k2, out, nmemb, memb0, pen);

@@ -232,6 +232,33 @@ def test_largest_strip_meshes_agree_with_box_tiles(N, precision):
     assert np.abs(acc[STRIPS][2] - acc[BOXES][2]).max() <= (1e-14 if precision == 64 else 5e-7) * np.abs(acc[BOXES][2]).max()
 
 
+@pytest.mark.parametrize("ws,precision", [(0, 64), (1, 64), (1, 32)])
+def test_the_three_component_readout_on_separate_waves_at_512(tmp_path, ws, precision):
+    """FPMHIP_RO3_WS (read once per process: a child): the marching readout of the 512^3 mesh with the transform and the gather
+    on different waves of one workgroup over two window planes (readout_march3_ws_kernel; the fp64 default since round 6), and
+    the two-workgroups-per-CU kernel it replaced (0), against the box path -- load B, 64^3 particles and a potential column."""
+    import subprocess
+    import sys
+    N, nc = 512, 64
+    L = 1.5 * N
+    np.save(tmp_path / "x.npy", util.load_b(nc, L, N, rms_cells=3.0))
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); from fastpm_amd import PM, Store\n"
+            "x = np.load(%r); out = {}\n"
+            "for mode in (2, 3):\n"
+            "    pm = PM(%d, %r, %d, paint_mode=mode); st = Store(x, potential=True)\n"
+            "    for i in range(2): pm.compute_force(st, kernel='1_4')\n"
+            "    torch.cuda.synchronize()\n"
+            "    out['a%%d' %% mode] = st.acc.cpu().numpy(); out['p%%d' %% mode] = st.potential.cpu().numpy()\n"
+            "    pm.destroy(); del st; torch.cuda.empty_cache()\n"
+            "np.savez(%r, **out)\n" % (ROOT, str(tmp_path / "x.npy"), N, L, precision, str(tmp_path / "out.npz")))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FPMHIP_RO3_WS=str(ws)), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = np.load(tmp_path / "out.npz")
+    tol = 1e-6 if precision == 64 else 2e-5
+    assert util.rel_err(d["a3"], d["a2"]) <= tol and util.rel_err(d["p3"], d["p2"]) <= tol
+
+
 def test_the_e8_readout_shape_at_2048_fp32_keeps_the_box_paths_bits(tmp_path):
     """FPMHIP_RO_E16=0 (read once per process: a child): the fp32 readout at M = 1024 in its round-4 shape, E = 8 values per
     thread, which repeats the box path's z transform -- held to the bound the default shape had before round 5 (2e-5 of rms)
