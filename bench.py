@@ -812,6 +812,10 @@ def main():
             # (one plane in LDS + wave-local z transforms on the power-of-two meshes; two planes elsewhere: fpm_strips.hip)
             # (round 4: the three components in one workgroup at N = 256 / 512 / 1024 -- readout_march3_kernel)
             march = "fpm::readout_march3_kernel" if Nmesh in (256, 512, 1024) and os.environ.get("FPMHIP_RO3") != "0" else "fpm::readout_march_kernel"
+            # (round 6: at N = 512 in fp64 the transform and the gather on different waves -- readout_march3_ws_kernel)
+            ws3 = os.environ.get("FPMHIP_RO3_WS")
+            if march.endswith("march3_kernel") and Nmesh == 512 and (ws3 == "1" or (ws3 is None and args.precision == 64 and world == 1)):
+                march = "fpm::readout_march3_ws_kernel"
             KERNELS["readout"] = march if 64 % max(Nmesh // 16, 1) == 0 else "fpm::readout_strips_kernel"
         elif args.precision == 64:
             KERNELS["readout"] = "fpm::readout1of3_tiles_kernel"
