@@ -2008,6 +2008,9 @@ __global__ __launch_bounds__((3 * StripCfg<PL, F>::ro_threads), 4) void readout_
 // does not carry particle state has the registers for -- while 512 gather threads take the entries of plane t through window
 // t & 1; ONE workgroup barrier per plane (the transforms are wave-local, nothing joins).  The arithmetic is
 // readout_march3_kernel's, value for value.
+#ifndef FPM_WS3_PROBE
+#define FPM_WS3_PROBE 0        // 1: the gathers compiled out, 2: the transforms (measurements of where each half stands alone)
+#endif
 template <typename PL, typename F> struct March3WsCfg {
     using CF = StripCfg<PL, F>;
     static constexpr int NTF = 3 * CF::ro_threads, NTFW = (NTF + 63) / 64 * 64, NTG = 1024 - NTFW, threads = NTFW + NTG;
@@ -2085,8 +2088,13 @@ __global__ __launch_bounds__(1024, 4) void readout_march3_ws_kernel(
             if (live && k < nplanes) {
                 C2<F> *S = S0 + (k & 1) * SLOT;
                 C2<F> v[vmax(E)];
+#if FPM_WS3_PROBE == 2
+#pragma unroll
+                for (int j = 0; j < E; j++) v[j] = x[j];
+#else
                 c2r_prepare<PL, CWX, SKX, F, true>(v, x, xm, S, twn, tau, cg);
                 fft_core<PL, +1, CWX, false, F, SKX, true, CF::ro_xs>(v, S, tw, tau, cg);
+#endif
 #pragma unroll
                 for (int j = 0; j < E; j++) S[cg * RP + tau + T * j] = v[j];
                 if (tau == 0) S[cg * RP + M].x = v[0].x;
@@ -2187,9 +2195,14 @@ __global__ __launch_bounds__(1024, 4) void readout_march3_ws_kernel(
     for (int k = 0; k <= nplanes; k++) {
         if (k >= 1) {
             wofs = ((k - 1) & 1) * 2 * SLOT;
+#if FPM_WS3_PROBE != 1
             if (k >= 2) finish_p();                                        // the particles of plane xa + k - 2: their x + 1 corners
+#endif
             if (k < nplanes) {
-                start_q();                                                 // the particles of plane xa + k - 1: their x + 0 corners
+#if FPM_WS3_PROBE != 1
+                start_q();
+#endif
+                //                                               // the particles of plane xa + k - 1: their x + 0 corners
                 if (k + 1 < nplanes) fetch_q(xa + k);                      // lands under the barrier
             }
         }
