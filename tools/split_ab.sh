@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/split_ab.sh [N precision ncube]: the several-waves-per-row readout of the long rows (readout_split_kernel /
-# readout_split3_kernel, FPMHIP_RO_SPLIT = 1 | 2 | 3) against the one-wave-per-row shapes (= 0), one rank of eight
+# readout_split3_kernel, FPMHIP_RO_SPLIT = 1 | 2 | 3; readout_split_ws_kernel, = 5) against the one-wave-per-row shapes (= 0), one rank of eight
 # (tools/rank_share_bench.py), same box.
 N=${1:-2048}; PREC=${2:-32}; NCUBE=${3:-0}
 mkdir -p gpurun_out/split
