@@ -204,6 +204,24 @@ def test_one_rank_of_the_8_gpu_configs_at_full_per_rank_size(N, precision, ncube
     assert err <= tol, err
 
 
+@pytest.mark.parametrize("N,P,precision,tol", [(2048, 16, 32, 3e-5), (2048, 32, 32, 3e-5), (3072, 16, 32, 3e-5), (3072, 24, 32, 3e-5)])
+def test_other_slab_widths_through_the_long_row_kernels(N, P, precision, tol):
+    """The marching kernels of the 2048^3 / 3072^3 fp32 meshes (round 6: several waves per row; transform and gather waves) on
+    slabs of 128, 64, 192 and 128 planes -- one rank of 16, 32, 16 and 24 -- against the small cube of that rank count."""
+    import torch
+    import rank_share
+    free, _ = torch.cuda.mem_get_info()
+    need = 7.5 * (N // P) * N * (N + 2) * (precision // 8) + 100.0 * (N // (2 * P)) ** 3 * P * P
+    if free < need:
+        pytest.skip("needs %.0f GB of device memory" % (need / 1e9))
+    acc, ref, _ = rank_share.run_rank_share(N, P, precision)
+    n = ref.shape[0]
+    assert acc.shape[0] == P * P * n and bool(torch.isfinite(acc).all())
+    rms = float(ref.double().pow(2).mean().sqrt())
+    err = float((acc.view(P * P, n, 3).double() - ref.double()[None]).abs().max()) / rms
+    assert err <= tol, err
+
+
 @pytest.mark.parametrize("N,precision,ncube,env,tol", [
     (2048, 32, 0, "FPMHIP_RO_SPLIT=0", 3e-5),      # the one-wave-per-row readout (E = 16), the default until round 6
     (2048, 32, 0, "FPMHIP_RO_SPLIT=1", 3e-5),      # two waves per row, the LATE order
