@@ -2602,8 +2602,9 @@ template <int M, typename F> struct Ro3Launch<M, F, true> {
     static int go(fpmhip_plan *p, MeshGeo &g, const void *k0, const void *k1, const void *k2, float *out, int nmemb, int memb0,
                   bool late, const PenIO &pen)
     {
-        // default: fp64 on one rank and slabs (configs[1]: 1.056 -> 1.012 - 1.021 ms); fp32 loses (0.695 -> 0.867: its transform
-        // threads are done long before the gather threads), the pencil form is unmeasured -- both only when asked for (1)
+        // default: fp64 on one rank and slabs (configs[1]: 1.056 -> 1.012 - 1.021 ms; one rank of eight: 0.174 -> 0.147); fp32 loses
+        // (0.695 -> 0.867: its transform threads are done long before the gather threads) and so does the pencil form (one rank of
+        // 4 x 2: 0.161 - 0.173 -> 0.179 - 0.182) -- both only when asked for (1)
         static const int ws3_env = getenv("FPMHIP_RO3_WS") ? atoi(getenv("FPMHIP_RO3_WS")) : -1;
         if constexpr (M == 256) {
             if (ws3_env > 0 || (ws3_env < 0 && sizeof(F) == 8 && !pen.on))
