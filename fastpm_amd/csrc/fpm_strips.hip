@@ -1830,6 +1830,9 @@ __global__ __launch_bounds__((Rows2Cfg<PL>::threads), (PL::E == 16 ? FPM_RO2_MIN
 // 9.60, 512^3 fp32 0.767 -> 0.669 (rows a step ahead; LATE 0.707), 1024^3 fp32 8.10 -> 6.40; clustered load C at 512^3 fp64
 // 2.16 -> 1.76.  FPM_RO3_PF = 2 (two entries per thread in registers) spills: 1.34 / 10.9 ms.  With the rows a step ahead
 // the fp64 kernels spill 23 VGPRs at the 128 budget (1.39 ms).
+#ifndef FPM_RO3_MID
+#define FPM_RO3_MID -1       // -1: the measured default per row length (see the kernel); 0 .. E - 1: forced (A/B builds)
+#endif
 #ifndef FPM_RO3_PF
 #define FPM_RO3_PF 1
 #endif
@@ -1846,6 +1849,13 @@ __global__ __launch_bounds__((3 * StripCfg<PL, F>::ro_threads), 4) void readout_
     using CF = StripCfg<PL, F>;
     constexpr int M = PL::N, RW = STRIP_RW, T = PL::T, E = PL::E, NT = 3 * CF::ro_threads, RP = CF::ro_pitch, WP = 2 * RP;
     static_assert(64 % T == 0, "a row's threads sit in one wave");
+    // MID (round 6): in the LATE order, the first MID of a row's E values are requested a plane ahead BETWEEN the two gathers (the
+    // rest right before the transform, as before).  One workgroup owns the CU at M = 512 and its load, transform and gather phases
+    // follow each other; the memory system idles while it computes and is saturated while it loads.  Two values per thread are
+    // what the 128-VGPR budget holds across the second gather without spilling (three: none either, four: 6 - 8 spilled):
+    // readout of the 1024^3 mesh, ms, MID = 0 | 2 | 3 | 4: fp64 9.53 | 8.99 | 9.26 | 10.24; fp32 6.16 | 5.79; one rank of eight (fp64)
+    // 1.255 | 1.181.  M = 128 (0.168 | 0.173) keeps 0; M = 256 in this order is a fall-back only (unmeasured: 0).
+    constexpr int MID = FPM_RO3_MID >= 0 ? (LATE && !PEN ? FPM_RO3_MID : 0) : (LATE && !PEN && M == 512 ? 2 : 0);
     extern __shared__ __align__(16) unsigned char smem_st[];
     C2<F> *tw = (C2<F> *) smem_st;
     C2<F> *twn = tw + PL::TWN;
@@ -1866,7 +1876,7 @@ __global__ __launch_bounds__((3 * StripCfg<PL, F>::ro_threads), 4) void readout_
     C2<F> x[E], xm;
     const int yrow = y0 + c;                       // pencils (PenIO): as in readout_march_kernel
     const C2<F> *phx = PEN ? (const C2<F> *) pen.hx[comp] : nullptr, *phy = PEN ? (const C2<F> *) pen.hy[comp] : nullptr;
-    auto load_plane = [&](int xp) {
+    auto load_plane = [&](int xp, int j0 = 0, int j1 = PL::E) {   // (j0, j1: compile-time after inlining -- FPM_RO3_MID loads a row in two parts)
         if (g.periodic_x) xp -= xp >= g.N ? g.N : 0;
         if constexpr (PEN) {
             const C2<F> *src;
@@ -1884,8 +1894,9 @@ __global__ __launch_bounds__((3 * StripCfg<PL, F>::ro_threads), 4) void readout_
         }
         const C2<F> *src = rowbase + (long long) xp * pstride;
 #pragma unroll
-        for (int j = 0; j < E; j++) x[j] = ld_stream(&src[tau + T * j]);
-        xm = tau == 0 ? src[M] : C2<F>{0, 0};
+        for (int j = 0; j < E; j++)
+            if (j >= j0 && j < j1) x[j] = ld_stream(&src[tau + T * j]);
+        if (j1 == E) xm = tau == 0 ? src[M] : C2<F>{0, 0};
     };
     auto c2r_plane = [&]() {
         C2<F> v[vmax(E)];
@@ -1984,16 +1995,19 @@ __global__ __launch_bounds__((3 * StripCfg<PL, F>::ro_threads), 4) void readout_
     c2r_plane();
     __syncthreads();
     if (!LATE) load_plane(xa + 1);
+    if (MID) load_plane(xa + 1, 0, MID);
     start_q();
     for (int i = xa; i < xb; i++) {
         if ((!LATE || FPM_RO3_EARLYQ) && i + 1 < xb) fetch_q(i + 1);
-        if (LATE) load_plane(i + 1);
+        if (LATE && !MID) load_plane(i + 1);
+        if (MID) load_plane(i + 1, MID, E);                              // the rest of the row
         __syncthreads();
         c2r_plane();
         __syncthreads();
         if (LATE && !FPM_RO3_EARLYQ && i + 1 < xb) fetch_q(i + 1);
         if (!LATE && i + 1 < xb) load_plane(i + 2);
         finish_p();
+        if (MID && i + 1 < xb) load_plane(i + 2, 0, MID);                // the first values of the next row, between the two gathers
         if (i + 1 < xb) start_q();
     }
 }
