@@ -718,6 +718,9 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads)) void readout_strips_
 // z c2r x 3 + readout: fp64 64.2 (box tiles) -> 47.0 ms, fp32 36.7 -> 35.2; the three-waves-per-row shape (E = 8, 960 threads, a
 // 128-VGPR budget: 91 spilled in fp64) takes 77.8 / 36.1 ms and stays as the A/B (FPMHIP_RO_E24=0).  8-row strips
 // (-DFPM_STRIP_Y=8) at M = 512 again, on this round's kernels: readout 11.3 -> 11.4 ms at 1024^3, paint 2.9 -> 3.5.
+#ifndef FPM_RO_MID
+#define FPM_RO_MID -1        // -1: the measured default (see readout_march_kernel); >= 0: forced (A/B builds)
+#endif
 #ifndef FPM_RO_E4_MINW
 #define FPM_RO_E4_MINW 4
 #endif
@@ -786,7 +789,12 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (PL::E == 4 ? FPM_RO
     // the neighbours' rows, in their own small buffers
     const int yrow = y0 + c;
     const C2<F> *phx = PEN ? (const C2<F> *) pen.hx[comp] : nullptr, *phy = PEN ? (const C2<F> *) pen.hy[comp] : nullptr;
-    auto load_plane = [&](int xp) {                // plane xl of a slab is the halo plane the next rank sent
+    // MID (round 6, as in readout_march3_kernel): in the LATE order of the one-wave-per-row shapes (E >= 16), the first MID values
+    // of the next plane's rows are requested BETWEEN the two gathers, the rest right before the transform.  M = 1024 in fp64 holds
+    // three of its sixteen without spilling (254 VGPRs; four: 2 spilled): one rank of eight of the 2048^3 mesh 12.74 - 12.81 ->
+    // 12.45 - 12.56 ms; M = 1536 (252 VGPRs as it is) spills with any: 0.
+    constexpr int MID = FPM_RO_MID >= 0 ? (LATE && !PEN && E >= 16 ? FPM_RO_MID : 0) : (LATE && !PEN && E == 16 && sizeof(F) == 8 ? 3 : 0);
+    auto load_plane = [&](int xp, int j0 = 0, int j1 = PL::E) {   // plane xl of a slab is the halo plane the next rank sent
         if (g.periodic_x) xp -= xp >= g.N ? g.N : 0;
         if constexpr (PEN) {
             const C2<F> *src;
@@ -810,8 +818,9 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (PL::E == 4 ? FPM_RO
         xm = C2<F>{0, 0};
 #else
 #pragma unroll
-        for (int j = 0; j < E; j++) x[j] = ld_stream(&src[tau + T * j]);
-        xm = tau == 0 ? src[M] : C2<F>{0, 0};
+        for (int j = 0; j < E; j++)
+            if (j >= j0 && j < j1) x[j] = ld_stream(&src[tau + T * j]);
+        if (j1 == E) xm = tau == 0 ? src[M] : C2<F>{0, 0};
 #endif
     };
 #if FPM_RO_EARLY
@@ -923,10 +932,12 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (PL::E == 4 ? FPM_RO
     c2r_plane();
     __syncthreads();
     if (!LATE && !FPM_RO_EARLY) load_plane(xa + 1);
+    if (MID) load_plane(xa + 1, 0, MID);
     start_q();
     for (int i = xa; i < xb; i++) {                // the window goes from plane i to plane i + 1
         if (!LATE && i + 1 < xb) fetch_q(i + 1);   // needed after the transform
-        if (LATE) load_plane(i + 1);
+        if (LATE && !MID) load_plane(i + 1);
+        if (MID) load_plane(i + 1, MID, E);        // the rest of the row
         __syncthreads();                           // every gather from plane i is done
 #if FPM_RO_EARLY
         early_xp = (!LATE && i + 1 < xb) ? i + 2 : -1;
@@ -936,6 +947,7 @@ __global__ __launch_bounds__((StripCfg<PL, F>::ro_threads), (PL::E == 4 ? FPM_RO
         if (LATE && i + 1 < xb) fetch_q(i + 1);
         if (!LATE && !FPM_RO_EARLY && i + 1 < xb) load_plane(i + 2);         // lands during the gathers
         finish_p();
+        if (MID && i + 1 < xb) load_plane(i + 2, 0, MID);
         if (i + 1 < xb) start_q();
     }
 }
