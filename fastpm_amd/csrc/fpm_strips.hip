@@ -2471,7 +2471,8 @@ template <typename K> static int grant_lds(K kernel, size_t bytes, int device)
 // readout of 1024^3 is 48 rounds at 32 planes (14.6 ms; 128 planes: 14.3).  Picks the length with the best modelled
 // efficiency  rounds / ceil(rounds) x xs / (xs + 1).  FPMHIP_XSEG forces a length (A/B).
 template <typename K>
-static int choose_xseg(const MeshGeo &g, K kernel, int threads, size_t lds, int wgs_per_plane_column, int lo, int hi, int *occ_cache)
+static int choose_xseg(const MeshGeo &g, K kernel, int threads, size_t lds, int wgs_per_plane_column, int lo, int hi, int *occ_cache,
+                       double min_rounds = 8)
 {
     if (g.xseg > 0) return g.xseg;
     if (*occ_cache == 0) {
@@ -2484,8 +2485,8 @@ static int choose_xseg(const MeshGeo &g, K kernel, int threads, size_t lds, int 
     double best_eff = -1;
     for (int xs = hi; xs >= lo; xs /= 2) {
         const double rounds = (double) wgs_per_plane_column * ((g.xl + xs - 1) / xs) / resident;
-        if (xs > 32 && rounds < 8) continue;         // (few long rounds end in a long tail: the readout of 512^3 at 64 planes,
-                                                     // 3 rounds instead of 6, runs 1.19 -> 1.22 ms)
+        if (xs > 32 && rounds < min_rounds) continue;      // (few long rounds end in a long tail: the readout of 512^3 at 64 planes,
+                                                     // 3 rounds instead of 6, runs 1.19 -> 1.22 ms; min_rounds: see readout_march3_ws_kernel)
         const double eff = rounds / std::ceil(rounds) * xs / (xs + 1.0);
         if (eff > best_eff + 1e-9) { best_eff = eff; best = xs; }
     }
@@ -2616,7 +2617,9 @@ template <int M, typename F> struct Ro3Launch<M, F, true> {
         if constexpr (CW::ok) {
             static int occ = 0;
             FPM_TRY(grant_lds(readout_march3_ws_kernel<PL, F, PEN>, CW::lds, p->device));
-            g.xseg = choose_xseg(g, readout_march3_ws_kernel<PL, F, PEN>, CW::threads, CW::lds, g.ntyo, 16, 128, &occ);
+            // (one workgroup per CU whose two halves overlap: long segments pay here -- configs[1], planes per workgroup 32 | 64 | 128:
+            // 1.019 | 1.001 | 0.985 ms -- so two rounds of workgroups are enough)
+            g.xseg = choose_xseg(g, readout_march3_ws_kernel<PL, F, PEN>, CW::threads, CW::lds, g.ntyo, 16, 128, &occ, 2.0);
             const int nseg = (g.xl + g.xseg - 1) / g.xseg;
             readout_march3_ws_kernel<PL, F, PEN><<<g.ntyo * nseg, CW::threads, CW::lds, p->stream>>>(
                 g, p->bin_beg[0], p->bin_cnt, p->sx, p->sy, p->sz, (const C2<F> *) k0, (const C2<F> *) k1, (const C2<F> *) k2, out,
