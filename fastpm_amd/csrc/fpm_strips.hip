@@ -2500,6 +2500,8 @@ static int paint_strips_launch(fpmhip_plan *p, const fpmhip_particles *pt, doubl
     MeshGeo g = p->mg;
     // the z pass wave-local where a row's threads fit one wave (the power-of-two meshes); FPMHIP_PT_WS = 0: A/B
     static const int ws_env = getenv("FPMHIP_PT_WS") ? atoi(getenv("FPMHIP_PT_WS")) : 1;
+    static const int pt_xseg_env = getenv("FPMHIP_PT_XSEG") ? atoi(getenv("FPMHIP_PT_XSEG")) : 0;      // planes per paint workgroup (A/B)
+    if (pt_xseg_env > 0) g.xseg = pt_xseg_env;
 // (pencil instantiations: the power-of-two meshes only -- fpm_plan.hip offers strip tiles on pencils there)
 #define CALL_PM_W(PL, WS_)                                                                                             \
     if (g.periodic_y) CALL_PM_P(PL, WS_, false)                                                                        \
